@@ -1,0 +1,217 @@
+"""Parameter/buffer inventory of KPFusion, by state-dict key.
+
+This is the *state-dict contract* of the drop-in boundary: a checkpoint written by the
+reference's train.py (`{"model": sd}` with `module.`-prefixed keys, train.py:269-293) must load into the
+MI355X model by key intersection exactly as train.py:100-107 does.  The names below therefore follow the
+reference's module tree (model/model.py:354-381 KPFusion, :207-273 Block_KPFusion, :129-164 DESA,
+:30-43/:106-114 TR_Encoder/KP_Interaction_TR, model/transfusion_head.py:94-110,635-665 decoder,
+convNeXT/resnetUnet.py:61-111, convNeXT/convnext.py:16-38,68-103, model/resnetUnet.py:248-289,
+model/resnet.py:30-60,137-170, model/hourglass.py:64-104) including every parameter the forward never
+touches.  tests/test_host.py checks the result against key/shape lists dumped from the imported reference.
+
+Each entry is (name, shape, dtype, init) where `init` tells keypointfusion_amd.weights how to draw a
+synthetic value of sensible scale (there is no checkpoint in this environment).
+"""
+
+CONVNEXT = {
+    "tiny": ([3, 3, 9, 3], [96, 192, 384, 768]),
+    "small": ([3, 3, 27, 3], [96, 192, 384, 768]),
+    "base": ([3, 3, 27, 3], [128, 256, 512, 1024]),
+    "large": ([3, 3, 27, 3], [192, 384, 768, 1536]),
+}
+RESNET = {18: ("basic", [2, 2, 2, 2])}
+
+
+def parse_net(net):
+    """'KPFusion-convnext-tiny' -> ('convnext','tiny'); 'KPFusion-resnet-18' -> ('resnet', 18)."""
+    tail = net.split("-")[-1]
+    if "convnext" in net:
+        if tail not in CONVNEXT:
+            raise KeyError(tail)  # the reference raises KeyError for e.g. 'T' (convNeXT/resnetUnet.py:65-66)
+        return "convnext", tail
+    depth = int(tail)
+    if depth not in RESNET:
+        raise NotImplementedError("resnet-%d (Bottleneck) backbones are not built yet" % depth)
+    return "resnet", depth
+
+
+class _Spec(list):
+    def add(self, name, shape, init, dtype="float32"):
+        self.append((name, tuple(shape), dtype, init))
+
+    def conv(self, p, cout, cin, kh, kw, bias=True, init="conv"):
+        self.add(p + ".weight", (cout, cin, kh, kw), init)
+        if bias:
+            self.add(p + ".bias", (cout,), "bias")
+
+    def conv1d(self, p, cout, cin, init="conv"):
+        self.add(p + ".weight", (cout, cin, 1), init)
+        self.add(p + ".bias", (cout,), "bias")
+
+    def linear(self, p, cout, cin, init="linear"):
+        self.add(p + ".weight", (cout, cin), init)
+        self.add(p + ".bias", (cout,), "bias")
+
+    def norm(self, p, c):  # LayerNorm
+        self.add(p + ".weight", (c,), "norm_w")
+        self.add(p + ".bias", (c,), "norm_b")
+
+    def bn(self, p, c):
+        self.add(p + ".weight", (c,), "norm_w")
+        self.add(p + ".bias", (c,), "norm_b")
+        self.add(p + ".running_mean", (c,), "bn_mean")
+        self.add(p + ".running_var", (c,), "bn_var")
+        self.add(p + ".num_batches_tracked", (), "zero_i64", "int64")
+
+    def residual(self, p, cin, cout):
+        h = cout // 2
+        self.bn(p + ".bn1", cin)
+        self.conv(p + ".conv1.conv", h, cin, 1, 1)
+        self.bn(p + ".bn2", h)
+        self.conv(p + ".conv2.conv", h, h, 3, 3)
+        self.bn(p + ".bn3", h)
+        self.conv(p + ".conv3.conv", cout, h, 1, 1)
+        self.conv(p + ".skip_layer.conv", cout, cin, 1, 1)  # constructed even when unused
+
+
+def _unet_decoder(s, p, d, deconv_dim, convnext):
+    """d = encoder widths at strides 4,8,16,32."""
+    s.residual(p + ".skip_layer4", d[2], d[2])
+    s.residual(p + ".up4.0", d[3], d[3])
+    s.residual(p + ".fusion_layer4", d[2] + d[3], d[2])
+    s.residual(p + ".skip_layer3", d[1], d[1])
+    s.residual(p + ".up3.0", d[2], d[2])
+    s.residual(p + ".fusion_layer3", d[2] + d[1], d[1])
+    s.residual(p + ".skip_layer2", d[0], d[0])
+    s.residual(p + ".up2.0", d[1], d[1])
+    s.residual(p + ".fusion_layer2", d[1] + d[0], deconv_dim)
+    if convnext:
+        s.residual(p + ".feat_emb", deconv_dim, deconv_dim)
+        s.residual(p + ".result_emb", deconv_dim, deconv_dim)
+    for i, od in enumerate((63, 21, 21)):
+        s.conv(p + ".finals.%d" % i, od, deconv_dim, 1, 1, init="final")
+
+
+def _convnext_unet(s, p, size, in_ch):
+    depths, dims = CONVNEXT[size]
+    b = p + ".backbone"
+    s.conv(b + ".downsample_layers.0.0", dims[0], in_ch, 4, 4)
+    s.norm(b + ".downsample_layers.0.1", dims[0])
+    for i in range(1, 4):
+        s.norm(b + ".downsample_layers.%d.0" % i, dims[i - 1])
+        s.conv(b + ".downsample_layers.%d.1" % i, dims[i], dims[i - 1], 2, 2)
+    for i in range(4):
+        for j in range(depths[i]):
+            q = b + ".stages.%d.%d" % (i, j)
+            c = dims[i]
+            s.add(q + ".gamma", (c,), "gamma")
+            s.conv(q + ".dwconv", c, 1, 7, 7, init="dwconv")
+            s.norm(q + ".norm", c)
+            s.linear(q + ".pwconv1", 4 * c, c, init="pw")
+            s.linear(q + ".pwconv2", c, 4 * c, init="pw")
+    s.norm(b + ".norm", dims[3])  # unused by forward_features
+    s.linear(b + ".head", 1000, dims[3], init="dead")  # unused
+    _unet_decoder(s, p, dims, 128, True)
+
+
+def _resnet_unet(s, p, depth, in_ch):
+    kind, layers = RESNET[depth]
+    b = p + ".backbone"
+    s.conv(b + ".conv1", 64, in_ch, 7, 7, bias=False)
+    s.bn(b + ".bn1", 64)
+    inpl = 64
+    for li, (planes, n) in enumerate(zip((64, 128, 256, 512), layers)):
+        for j in range(n):
+            q = b + ".layer%d.%d" % (li + 1, j)
+            stride = 2 if (li > 0 and j == 0) else 1
+            s.conv(q + ".conv1", planes, inpl, 3, 3, bias=False)
+            s.bn(q + ".bn1", planes)
+            s.conv(q + ".conv2", planes, planes, 3, 3, bias=False)
+            s.bn(q + ".bn2", planes)
+            if stride != 1 or inpl != planes:
+                s.conv(q + ".downsample.0", planes, inpl, 1, 1, bias=False)
+                s.bn(q + ".downsample.1", planes)
+            inpl = planes
+    _unet_decoder(s, p, (64, 128, 256, 512), 128, False)
+
+
+def _tr(s, p, din):
+    """KP_Interaction_TR (model/model.py:106-114) wrapping TR_Encoder (:30-43)."""
+    b = p + ".bert"
+    s.add(b + ".embeddings.word_embeddings.weight", (30522, 128), "dead")
+    s.add(b + ".embeddings.position_embeddings.weight", (512, 128), "dead")
+    s.add(b + ".embeddings.token_type_embeddings.weight", (2, 128), "dead")
+    s.norm(b + ".embeddings.LayerNorm", 128)
+    for l in range(4):
+        q = b + ".encoder.layer.%d" % l
+        for n in ("query", "key", "value"):
+            s.linear(q + ".attention.self." + n, 128, 128, init="tr")
+        s.linear(q + ".attention.output.dense", 128, 128, init="tr")
+        s.norm(q + ".attention.output.LayerNorm", 128)
+        s.linear(q + ".intermediate.dense", 16, 128, init="tr")
+        s.linear(q + ".output.dense", 128, 16, init="tr")
+        s.norm(q + ".output.LayerNorm", 128)
+    s.linear(b + ".pooler.dense", 128, 128, init="dead")
+    s.add(b + ".position_embeddings.weight", (512, 128), "emb")
+    s.linear(b + ".img_embedding", 128, din, init="tr")
+    s.linear(p + ".cls_head", 3, 128, init="head3")
+    s.linear(p + ".residual", 3, din, init="head3")
+
+
+def _block(s, p):
+    s.add(p + ".weight_dis", (1,), "weight_dis")
+    s.linear(p + ".sampling_offsets", 8, 128, init="dead")
+    s.linear(p + ".attention_weights", 4, 128, init="dead")
+    s.linear(p + ".sampling_feature_embding", 128, 128, init="dead")
+    fa = p + ".FA"
+    for i in range(3):
+        s.conv(fa + ".conv_blocks.%d.0" % i, 128, 128, 1, 1)
+    for i in range(3):
+        s.bn(fa + ".bn_blocks.%d.0" % i, 128)
+    for i in range(3):
+        s.conv(fa + ".conv_l0_blocks.%d" % i, 128, 3, 1, 1)
+    for i in range(3):
+        s.conv(fa + ".conv_f0_blocks.%d" % i, 128, 128, 1, 1)
+    for i in range(3):
+        s.bn(fa + ".bn_l0_blocks.%d" % i, 128)
+    for i in range(3):
+        s.bn(fa + ".bn_f0_blocks.%d" % i, 128)
+    s.conv1d(fa + ".fusion.0", 128, 512)
+    s.bn(fa + ".fusion.1", 128)
+    _tr(s, p + ".init_TR", 128)
+    _tr(s, p + ".final_TR", 131)
+    for l in range(4):
+        q = p + ".crossTR.decoder.%d" % l
+        s.add(q + ".multihead_attn.in_proj_weight", (384, 128), "tr")
+        s.add(q + ".multihead_attn.in_proj_bias", (384,), "bias")
+        s.linear(q + ".multihead_attn.out_proj", 128, 128, init="tr")
+        s.linear(q + ".linear1", 128, 128, init="tr")
+        s.linear(q + ".linear2", 128, 128, init="tr")
+        for n in ("norm1", "norm2", "norm3"):
+            s.norm(q + "." + n, 128)
+        s.add(q + ".self_posembed.weight", (21, 128), "emb")
+        s.add(q + ".cross_posembed.weight", (21, 128), "emb")
+    for n, cin in (("pcl_feat_emb", 128), ("pcl_xyz_emb", 3), ("pcl_pose_emb", 105),
+                   ("joint_feat_emb", 128), ("joint_xyz_emb", 3), ("pcl_feat_emb_RGB", 128)):
+        s.conv1d(p + "." + n + ".0", 128, cin)
+        s.bn(p + "." + n + ".1", 128)
+    s.conv(p + ".atten_spatial", 21, 149, 1, 1)
+    s.linear(p + ".fc_spatial2joint_feature", 1, 1024, init="fc_spatial")
+    s.linear(p + ".reduction_joint_feature", 128, 256, init="dead")
+    s.conv1d(p + ".reduction_joint_feature_update", 21, 63, init="dead")
+    s.linear(p + ".cls_head", 3, 128, init="dead")
+
+
+def kpfusion_spec(net):
+    """Ordered list of (key, shape, dtype, init) for KPFusion(net, ...)."""
+    fam, size = parse_net(net)
+    s = _Spec()
+    if fam == "convnext":
+        _convnext_unet(s, "backbone_rgb", size, 3)
+        _convnext_unet(s, "backbone_d", size, 1)
+    else:
+        _resnet_unet(s, "backbone_rgb", size, 3)
+        _resnet_unet(s, "backbone_d", size, 1)
+    _block(s, "block1")
+    _block(s, "block2")
+    return list(s)
