@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Benchmark of the KPFusion forward hot path on MI355X (driver contract: see the task statement).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N>1: launched once per rank by torch.distributed.run)
+
+Workload = BASELINE.json configs[1]: B=64 synthetic 256x256 RGB-D crops per GPU, KPFusion-convnext-tiny, both UNet
+backbones (depth + RGB) forward-only, fp32, eval.  (The fusion head only exists at 128x128 in the reference — SURVEY D1
+— so configs[1] is "backbones only"; `--workload full128` times the whole model at B=64, 128x128 instead.)
+A "step" is one forward over one batch already resident in HBM.  N GPUs = N independent shards of the batch
+dimension (weak scaling, no data-path collective: every sample is independent in eval).
+
+One JSON line is printed by rank 0 with, besides the contract fields:
+  roofline     : the implicit-GEMM MFMA kernel family (igemm_f32_kernel) — achieved = algorithmic conv/GEMM FLOPs of all its
+                 launches in one step / summed device time of those launches (HIP events on the launch stream, measured
+                 in an instrumented pass after the timed region), peak = 157.3 TFLOP/s dense fp32 MFMA.
+  cpu_baseline : the CPU oracle (oracle/kpf_oracle.py, torch-CPU fp32 = the reference's own arithmetic) on the host
+                 cores of this box, on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
+NET = "KPFusion-convnext-tiny"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--workload", default="backbones256", choices=["backbones256", "full128"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=8, help="images in the CPU-baseline sample")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from keypointfusion_amd import engine as E, lib as L
+    from keypointfusion_amd.model.model import KPFusion
+    from keypointfusion_amd.weights import synthetic_batch, synthetic_state_dict
+    L.load()
+
+    if args.workload == "full128":
+        args.size = 128
+    B, S = args.batch, args.size
+    model = KPFusion(NET, "", 21, "dexycb", "")
+    sd = {k: torch.from_numpy(v) for k, v in synthetic_state_dict(NET, 0).items()}
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    hb = synthetic_batch(B, S, seed=1 + rank)
+    batch = {k: torch.from_numpy(v).to(dev) for k, v in hb.items()}
+
+    class _Loader:
+        img_size, flip = 128, 1
+
+    def step():
+        with torch.no_grad():
+            if args.workload == "backbones256":
+                plan = model._plan(dev)
+                plan.backbone_d(batch["img"])
+                plan.backbone_rgb(batch["img_rgb"])
+            else:
+                model(batch["img_rgb"], batch["img"], batch["pcl"], _Loader(), batch["center"], batch["M"], batch["cube"],
+                      batch["cam_para"], 0.8)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+
+    # ---- instrumented pass: per-launch HIP events around every implicit-GEMM launch (same stream) ----
+    roofline = None
+    if rank == 0:
+        recs = []
+        orig_conv = E.conv
+
+        def timed_conv(pc, x, *a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig_conv(pc, x, *a, **k)
+            e1.record()
+            if pc.merge > 1:
+                M = x.B * (x.H // pc.sh) * (x.W // pc.merge)
+            else:
+                M = x.B * ((x.H + 2 * pc.ph - pc.KH) // pc.sh + 1) * ((x.W + 2 * pc.pw - pc.KW) // pc.sw + 1)
+            recs.append((e0, e1, pc.flops(M)))
+            return out
+
+        E.conv = timed_conv
+        try:
+            step()
+            torch.cuda.synchronize()
+            recs.clear()
+            step()
+            torch.cuda.synchronize()
+        finally:
+            E.conv = orig_conv
+        t_ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+        fl = sum(f for _, _, f in recs)
+        ach = fl / (t_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "igemm_f32_kernel", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": len(recs), "avg_launch_ms": round(t_ms / max(len(recs), 1), 4),
+                    "gflop_per_step": round(fl / 1e9, 1), "kernel_ms_per_step": round(t_ms, 3),
+                    "whole_step_tflops": round(fl / (ms_per_step * 1e-3) / 1e12, 2)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import kpf_oracle as O
+        n = min(args.cpu_sample, B)
+        cb = {k: torch.from_numpy(v[:n]) for k, v in hb.items()}
+        threads = torch.get_num_threads()
+
+        def cpu_step():
+            if args.workload == "backbones256":
+                O.backbones_forward(sd, cb["img_rgb"], cb["img"])
+            else:
+                O.kpfusion_forward(sd, cb["img_rgb"], cb["img"], cb["pcl"], cb["center"], cb["M"], cb["cube"], cb["cam_para"], 0.8)
+
+        cpu_step()  # warm-up (oneDNN primitive caches)
+        reps, t1 = 0, time.perf_counter()
+        while True:
+            cpu_step()
+            reps += 1
+            if time.perf_counter() - t1 > 10.0 or reps >= 5:
+                break
+        ct = time.perf_counter() - t1
+        cpu = {"value": round(n * reps / ct, 2), "unit": "img/s", "cores": threads, "kind": "port",
+               "sample": "%d x %d images of the same synthetic batch, oracle/kpf_oracle.py (torch-CPU fp32), %d threads" % (reps, n, threads)}
+
+    if rank == 0:
+        line = {
+            "metric": "RGB-D img/sec fwd (B=64, 256x256)" if args.workload == "backbones256" else "RGB-D img/sec fwd full model (B=%d, 128x128)" % B,
+            "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "KPFusion-convnext-tiny, depth+RGB UNet backbones forward, B=%d/GPU %dx%d fp32 (BASELINE configs[1])" % (B, S, S)
+                       if args.workload == "backbones256" else "KPFusion-convnext-tiny full forward, B=%d/GPU 128x128 fp32" % B,
+                       "batch_per_gpu": B, "global_batch": B * world, "input": "%dx%d" % (S, S), "parallelism": "dp%d (batch shards, no collective)" % world},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

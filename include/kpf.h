@@ -1,0 +1,98 @@
+/*
+ * kpf.h — C ABI of libkpf_hip.so, the MI355X (gfx950) compute library behind keypointfusion_amd.
+ *
+ * The reference (ru1ven/KeypointFusion) is pure Python on PyTorch: it has no FFI of its own, its "operators" are
+ * the nn.Module forwards listed below, and the native code it reaches is cuDNN/cuBLAS/ATen/pointnet2_ops
+ * (SURVEY.md §2.1).  Each entry point here replaces the native work behind one such forward, on raw device
+ * pointers (fp32, 16-byte aligned) and a hipStream_t passed as void*.  No torch type crosses this boundary; the
+ * Python host (keypointfusion_amd/model/model.py) owns memory through torch's caching allocator and passes
+ * data_ptr()s.  All activations are NHWC ("pixel-major, channels contiguous"), optionally a channel slice
+ * [coff, coff+C) of a wider buffer with pixel stride ld (this is how torch.cat along channels is made free).
+ *
+ * Every function returns 0 on success or a negative KPF_E* code; kpf_last_error() gives the thread-local message
+ * (the Python side raises RuntimeError with it, mirroring the reference's Python-exception error convention).
+ * Nothing here allocates, synchronises or touches the default stream: launches are graph-capturable.
+ */
+#ifndef KPF_H
+#define KPF_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KPF_OK 0
+#define KPF_EINVAL (-1)  /* bad shape / alignment / flag combination */
+#define KPF_ELAUNCH (-2) /* HIP launch error */
+
+/* kpf_conv_desc.flags */
+#define KPF_ACT_RELU 1u        /* y = relu(acc + bias)                                    */
+#define KPF_ACT_GELU 2u        /* y = gelu_erf(acc + bias)        (convNeXT/convnext.py:33) */
+#define KPF_RES_ADD 4u         /* y = res + y                                              */
+#define KPF_RES_GAMMA 8u       /* y = res + gamma[n] * y          (convNeXT/convnext.py:48-51) */
+#define KPF_RELU_AFTER_RES 16u /* y = relu(res + y)               (model/resnet.py:72-73)  */
+#define KPF_OUT_NCHW 32u       /* store out[b][n][oy][ox] (dense), ignoring out_ld/out_coff */
+
+typedef struct kpf_conv_desc {
+  int B, IH, IW, Cin;      /* input: B x IH x IW pixels, Cin channels consumed per pixel            */
+  int in_ld, in_coff;      /* floats between consecutive input pixels; first consumed channel       */
+  int OH, OW, N;           /* output: B x OH x OW pixels, N channels                                */
+  int KH, KW, sh, sw, ph, pw; /* filter taps, strides, zero padding                                 */
+  int Kp;                  /* packed weight row length: >= KH*KW*Cin, multiple of 32, zero padded   */
+  int out_ld, out_coff;    /* NHWC destination pixel stride / first channel                         */
+  int res_ld, res_coff;    /* residual source (NHWC) pixel stride / first channel                   */
+  unsigned flags;
+} kpf_conv_desc;
+
+/*
+ * Implicit-GEMM convolution / linear layer on fp32 MFMA (v_mfma_f32_16x16x4_f32):
+ *     out[m][n] = epilogue( sum_k A[m][k] * W[n][k] + bias[n] ),  m = (b,oy,ox),  k = (ky,kx,c) with c fastest,
+ *     A[m][k]  = prologue( in[b][oy*sh+ky-ph][ox*sw+kx-pw][c] ), zero outside the image,
+ *     prologue(x) = relu(x * pro_scale[c] + pro_shift[c]) when pro_scale != NULL (eval BatchNorm + ReLU on the operand).
+ * Replaces: nn.Conv2d / nn.Linear / nn.Conv1d(k=1) forwards reached from model/hourglass.py:64-119 (Conv, Residual),
+ * convNeXT/convnext.py:31-34,77,84 (pwconv1/2, stem, downsample), model/resnet.py:52-55,166 (BasicBlock, stem),
+ * convNeXT/resnetUnet.py:95-97 (finals) — i.e. cuDNN implicit GEMM + cuBLAS sgemm in the reference.
+ * w is [N][Kp] (PyTorch [out][in] order, taps reordered to (ky,kx,c)); bias may be NULL.
+ * Requirements: Cin, in_ld, in_coff, out_ld, out_coff, res_ld, res_coff multiples of 4 (float4 path) unless OUT_NCHW.
+ */
+int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const float* w, const float* bias,
+                   const float* pro_scale, const float* pro_shift, const float* gamma, const float* res,
+                   float* out, void* stream);
+
+/*
+ * ConvNeXt block front half: depthwise 7x7 (pad 3) + bias, then LayerNorm over channels (eps), fused.
+ * x, y: dense NHWC [B][H][W][C]; w_dw: [49][C] (tap-major); replaces convNeXT/convnext.py:41-43
+ * (cuDNN depthwise conv + permute + ATen layer_norm).  C % 4 == 0, C <= 2048.
+ */
+int kpf_dwconv7_ln_f32(const float* x, const float* w_dw, const float* b_dw, const float* ln_w, const float* ln_b,
+                       float* y, int B, int H, int W, int C, float eps, void* stream);
+
+/*
+ * LayerNorm over the channel dimension of `rows` pixels (biased variance, (x-u)/sqrt(var+eps)*w+b).
+ * Replaces convNeXT/convnext.py:205-214 in both data formats (stem/downsample norms).  In-place allowed.
+ */
+int kpf_layernorm_f32(const float* x, const float* w, const float* b, float* y, long rows, int C, float eps, void* stream);
+
+/*
+ * Bilinear x2 upsampling, align_corners=False (nn.Upsample(scale_factor=2, mode='bilinear'),
+ * convNeXT/resnetUnet.py:76-77): src dense NHWC [B][H][W][C] -> dst channel slice (ld, coff) of [B][2H][2W][*].
+ */
+int kpf_upsample2x_f32(const float* src, float* dst, int B, int H, int W, int C, int dst_ld, int dst_coff, void* stream);
+
+/* NCHW [B][C][H][W] -> NHWC [B][H][W][Cpad] (channels >= C zero-filled).  Boundary repack of the inputs of
+ * KPFusion.forward (model/model.py:395). */
+int kpf_nchw_to_nhwc_f32(const float* src, float* dst, int B, int C, int H, int W, int Cpad, void* stream);
+
+/* NHWC channel slice -> dense NCHW (boundary repack of returned tensors). */
+int kpf_nhwc_to_nchw_f32(const float* src, float* dst, int B, int C, int H, int W, int src_ld, int src_coff, void* stream);
+
+/* 3x3 stride-2 pad-1 max pooling on dense NHWC (model/resnet.py:169,236). */
+int kpf_maxpool3x3s2_f32(const float* src, float* dst, int B, int H, int W, int C, void* stream);
+
+const char* kpf_last_error(void);
+/* Library/ABI version, bumped when a signature changes. */
+int kpf_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,314 @@
+// HBM-bound kernels of the backbone path: depthwise 7x7 + LayerNorm (fused), LayerNorm, bilinear x2 upsample,
+// layout repacks, max-pool.  All fp32, NHWC, 16-byte vector accesses (float4 over channels), wave64 reductions.
+#include "kpf_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// depthwise 7x7 + bias + LayerNorm(C)
+//   grid.x = B*H*ceil(W/(8*S)) ; block = S * (C/4) threads ; thread (strip s, channel quad q) produces 8 consecutive
+//   output pixels of one image row for 4 channels with a register sliding window (7 rows x 14 input float4), parks the
+//   un-normalised result in an LDS tile [8*S pixels][C], then each wave normalises whole pixels from LDS (shuffle
+//   reductions) and writes them out fully coalesced.  Algorithmic traffic: read x once, write y once.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int DW_T = 8;
+
+__global__ __launch_bounds__(512) void dwconv7_ln_kernel(const float* __restrict__ x, const float* __restrict__ wdw,
+                                                         const float* __restrict__ bdw, const float* __restrict__ lw,
+                                                         const float* __restrict__ lb, float* __restrict__ y, int H, int W,
+                                                         int C, int S, int xblocks, float eps) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [8*S][C]
+  const int C4 = C >> 2;
+  const int tid = threadIdx.x;
+  const int s = tid / C4;
+  const int q = tid - s * C4;
+  int bid = blockIdx.x;
+  const int xb = bid % xblocks;
+  bid /= xblocks;
+  const int oy = bid % H;
+  const int b = bid / H;
+  const int x0 = (xb * S + s) * DW_T;
+
+  if (s < S && x0 < W) {
+    f32x4 acc[DW_T];
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(bdw + 4 * q);
+#pragma unroll
+    for (int t = 0; t < DW_T; ++t) acc[t] = bias;
+    const float* xb_ptr = x + (long)b * H * W * C + 4 * q;
+#pragma unroll 1
+    for (int ky = 0; ky < 7; ++ky) {
+      const int iy = oy + ky - 3;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      f32x4 in[DW_T + 6];
+      const float* row = xb_ptr + (long)iy * W * C;
+#pragma unroll
+      for (int i = 0; i < DW_T + 6; ++i) {
+        const int ix = x0 + i - 3;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)ix < (unsigned)W) v = *reinterpret_cast<const f32x4*>(row + (long)ix * C);
+        in[i] = v;
+      }
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wdw + (ky * 7 + kx) * C + 4 * q);
+#pragma unroll
+        for (int t = 0; t < DW_T; ++t) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[t][e] = fmaf(in[t + kx][e], wv[e], acc[t][e]);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < DW_T; ++t) *reinterpret_cast<f32x4*>(tile + (s * DW_T + t) * C + 4 * q) = acc[t];
+  }
+  __syncthreads();
+
+  // LayerNorm: one wave per pixel, round robin
+  const int lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int npix = S * DW_T;
+  const float invC = 1.0f / (float)C;
+  for (int p = wave; p < npix; p += nwaves) {
+    const int px = xb * S * DW_T + p;
+    if (px >= W) break;
+    const float* src = tile + p * C;
+    float sum = 0.f;
+    for (int i = lane; i < C4; i += 64) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * i);
+      sum += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    const float mean = wave_sum(sum) * invC;
+    float sq = 0.f;
+    for (int i = lane; i < C4; i += 64) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[e] - mean;
+        sq = fmaf(d, d, sq);
+      }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) * invC + eps);
+    float* dst = y + (((long)b * H + oy) * W + px) * C;
+    for (int i = lane; i < C4; i += 64) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * i);
+      const f32x4 g = *reinterpret_cast<const f32x4*>(lw + 4 * i);
+      const f32x4 be = *reinterpret_cast<const f32x4*>(lb + 4 * i);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * rstd * g[e] + be[e];
+      *reinterpret_cast<f32x4*>(dst + 4 * i) = o;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm over C for `rows` pixels: one wave per row, rows kept in registers (C <= 64*4*LN_MAXV)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int LN_MAXV = 8;  // float4 per lane -> C <= 2048
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float* __restrict__ y, long rows, int C,
+                                                        float eps) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int C4 = C >> 2;
+  const float* src = x + row * C;
+  f32x4 v[LN_MAXV];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c < C4) {
+      v[i] = *reinterpret_cast<const f32x4*>(src + 4 * c);
+      sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+  }
+  const float invC = 1.0f / (float)C;
+  const float mean = wave_sum(sum) * invC;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    if (lane + 64 * i < C4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[i][e] - mean;
+        sq = fmaf(d, d, sq);
+      }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(sq) * invC + eps);
+  float* dst = y + row * C;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < C4) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(w + 4 * c);
+      const f32x4 be = *reinterpret_cast<const f32x4*>(b + 4 * c);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + be[e];
+      *reinterpret_cast<f32x4*>(dst + 4 * c) = o;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// bilinear x2, align_corners = False:  src = (dst + 0.5) / 2 - 0.5 clamped at 0 ; i1 = min(i0 + 1, n - 1)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int H,
+                                                         int W, int C4, int dst_ld, int dst_coff) {
+  const long total = (long)B * 2 * H * 2 * W * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % C4);
+    long p = i / C4;
+    const int ox = (int)(p % (2 * W));
+    p /= (2 * W);
+    const int oy = (int)(p % (2 * H));
+    const int b = (int)(p / (2 * H));
+    float fy = (oy + 0.5f) * 0.5f - 0.5f;
+    float fx = (ox + 0.5f) * 0.5f - 0.5f;
+    fy = fy < 0.f ? 0.f : fy;
+    fx = fx < 0.f ? 0.f : fx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* sb = src + (long)b * H * W * C4 * 4 + 4 * q;
+    const f32x4 v00 = *reinterpret_cast<const f32x4*>(sb + ((long)y0 * W + x0) * C4 * 4);
+    const f32x4 v01 = *reinterpret_cast<const f32x4*>(sb + ((long)y0 * W + x1) * C4 * 4);
+    const f32x4 v10 = *reinterpret_cast<const f32x4*>(sb + ((long)y1 * W + x0) * C4 * 4);
+    const f32x4 v11 = *reinterpret_cast<const f32x4*>(sb + ((long)y1 * W + x1) * C4 * 4);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e]);
+    *reinterpret_cast<f32x4*>(dst + (((long)b * 2 * H + oy) * 2 * W + ox) * dst_ld + dst_coff + 4 * q) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int C,
+                                                           int HW, int Cpad) {
+  const long total = (long)B * HW * Cpad;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cpad);
+    const long p = i / Cpad;
+    const int pix = (int)(p % HW);
+    const int b = (int)(p / HW);
+    dst[i] = c < C ? src[((long)b * C + c) * HW + pix] : 0.f;
+  }
+}
+
+// tile transpose through LDS: NHWC slice -> NCHW
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int HW,
+                                                           int src_ld, int src_coff) {
+  __shared__ float t[32][33];
+  const int b = blockIdx.z;
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int p = p0 + r, c = c0 + tx;
+    t[r][tx] = (p < HW && c < C) ? src[((long)b * HW + p) * src_ld + src_coff + c] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, p = p0 + tx;
+    if (c < C && p < HW) dst[((long)b * C + c) * HW + p] = t[tx][r];
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int H,
+                                                           int W, int OH, int OW, int C4) {
+  const long total = (long)B * OH * OW * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % C4);
+    long p = i / C4;
+    const int ox = (int)(p % OW);
+    p /= OW;
+    const int oy = (int)(p % OH);
+    const int b = (int)(p / OH);
+    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * 2 + ky - 1;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * 2 + kx - 1;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (((long)b * H + iy) * W + ix) * C4 * 4 + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+      }
+    }
+    *reinterpret_cast<f32x4*>(dst + i * 4) = m;
+  }
+}
+
+inline int grid_for(long total, int block = 256, int cap = 256 * 16) {
+  long g = (total + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" int kpf_dwconv7_ln_f32(const float* x, const float* w_dw, const float* b_dw, const float* ln_w, const float* ln_b,
+                                  float* y, int B, int H, int W, int C, float eps, void* stream) {
+  KPF_REQUIRE(x && w_dw && b_dw && ln_w && ln_b && y, "kpf_dwconv7_ln_f32: null pointer");
+  KPF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && C <= 2048, "kpf_dwconv7_ln_f32: bad shape B=%d H=%d W=%d C=%d", B, H, W, C);
+  KPF_REQUIRE(kpf_aligned16(x) && kpf_aligned16(y) && kpf_aligned16(w_dw), "kpf_dwconv7_ln_f32: unaligned pointer");
+  const int C4 = C / 4;
+  int S = 1;
+  while (S * 2 * C4 <= 256 && S * DW_T < W) S *= 2;  // strips per block: <= 256 threads, no wider than the row
+  const int threads = ((S * C4 + 63) / 64) * 64;
+  KPF_REQUIRE(threads <= 512, "kpf_dwconv7_ln_f32: C too large");
+  const int xblocks = (W + S * DW_T - 1) / (S * DW_T);
+  const size_t lds = (size_t)S * DW_T * C * sizeof(float);
+  hipLaunchKernelGGL(dwconv7_ln_kernel, dim3((unsigned)((long)B * H * xblocks)), dim3(threads), lds,
+                     reinterpret_cast<hipStream_t>(stream), x, w_dw, b_dw, ln_w, ln_b, y, H, W, C, S, xblocks, eps);
+  return kpf_check_launch("kpf_dwconv7_ln_f32");
+}
+
+extern "C" int kpf_layernorm_f32(const float* x, const float* w, const float* b, float* y, long rows, int C, float eps,
+                                 void* stream) {
+  KPF_REQUIRE(x && w && b && y && rows > 0, "kpf_layernorm_f32: null pointer / empty");
+  KPF_REQUIRE(C % 4 == 0 && C > 0 && C <= 64 * 4 * LN_MAXV, "kpf_layernorm_f32: C=%d unsupported", C);
+  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, w,
+                     b, y, rows, C, eps);
+  return kpf_check_launch("kpf_layernorm_f32");
+}
+
+extern "C" int kpf_upsample2x_f32(const float* src, float* dst, int B, int H, int W, int C, int dst_ld, int dst_coff,
+                                  void* stream) {
+  KPF_REQUIRE(src && dst && B > 0 && H > 0 && W > 0, "kpf_upsample2x_f32: null pointer / empty");
+  KPF_REQUIRE(C % 4 == 0 && dst_ld % 4 == 0 && dst_coff % 4 == 0 && dst_coff + C <= dst_ld, "kpf_upsample2x_f32: bad channel slice");
+  const long total = (long)B * 4 * H * W * (C / 4);
+  hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst, B, H,
+                     W, C / 4, dst_ld, dst_coff);
+  return kpf_check_launch("kpf_upsample2x_f32");
+}
+
+extern "C" int kpf_nchw_to_nhwc_f32(const float* src, float* dst, int B, int C, int H, int W, int Cpad, void* stream) {
+  KPF_REQUIRE(src && dst && B > 0 && C > 0 && Cpad >= C, "kpf_nchw_to_nhwc_f32: bad arguments");
+  const long total = (long)B * H * W * Cpad;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst, B, C,
+                     H * W, Cpad);
+  return kpf_check_launch("kpf_nchw_to_nhwc_f32");
+}
+
+extern "C" int kpf_nhwc_to_nchw_f32(const float* src, float* dst, int B, int C, int H, int W, int src_ld, int src_coff,
+                                    void* stream) {
+  KPF_REQUIRE(src && dst && B > 0 && C > 0 && src_coff + C <= src_ld, "kpf_nhwc_to_nchw_f32: bad arguments");
+  const int HW = H * W;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), src, dst, C, HW, src_ld, src_coff);
+  return kpf_check_launch("kpf_nhwc_to_nchw_f32");
+}
+
+extern "C" int kpf_maxpool3x3s2_f32(const float* src, float* dst, int B, int H, int W, int C, void* stream) {
+  KPF_REQUIRE(src && dst && B > 0 && C % 4 == 0, "kpf_maxpool3x3s2_f32: bad arguments");
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  const long total = (long)B * OH * OW * (C / 4);
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst, B, H,
+                     W, OH, OW, C / 4);
+  return kpf_check_launch("kpf_maxpool3x3s2_f32");
+}

@@ -1,0 +1,369 @@
+"""Host-side execution plans for the KPFusion hot path on MI355X.
+
+Python here is plumbing: it repacks the reference-layout state dict (NCHW/OIHW, BatchNorm as separate tensors) into
+the kernel layouts once (OHWI rows padded to 32, eval-BatchNorm folded into the producing convolution or turned into
+an operand prologue), owns activation buffers through torch's caching allocator, and issues the C-ABI calls of
+include/kpf.h on torch's current HIP stream.  All arithmetic happens in libkpf_hip.so.
+
+Activation layout: NHWC everywhere ("pixel rows, channels contiguous"), so 1x1 convolutions / Linear layers are plain
+row-major GEMMs, channel concatenation is a slice of a wider pixel row (ld, coff) and patchify convolutions
+(4x4/s4 stem, 2x2/s2 downsample) are KHx1 convolutions over a [H, W/KW, KW*C] view of the same memory.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import lib as L
+from .spec import CONVNEXT, parse_net
+
+BN_EPS = 1e-5
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Act:
+    """A channel slice [coff, coff+C) of an NHWC buffer with pixel stride ld."""
+    __slots__ = ("buf", "B", "H", "W", "C", "ld", "coff")
+
+    def __init__(self, buf, B, H, W, C, ld=None, coff=0):
+        self.buf, self.B, self.H, self.W, self.C = buf, B, H, W, C
+        self.ld = C if ld is None else ld
+        self.coff = coff
+
+    @staticmethod
+    def empty(B, H, W, C, device):
+        return Act(torch.empty(B * H * W * C, device=device, dtype=torch.float32), B, H, W, C)
+
+    def slice(self, coff, C_):
+        return Act(self.buf, self.B, self.H, self.W, C_, self.ld, self.coff + coff)
+
+    def dense(self):
+        assert self.ld == self.C and self.coff == 0
+        return self.buf.view(self.B, self.H, self.W, self.C)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# weight packing
+# ----------------------------------------------------------------------------------------------------------------
+def bn_scale_shift(sd, p):
+    """eval BatchNorm as y = x*s + t (float64 fold, stored fp32)."""
+    w, b = sd[p + ".weight"].double(), sd[p + ".bias"].double()
+    m, v = sd[p + ".running_mean"].double(), sd[p + ".running_var"].double()
+    s = w / torch.sqrt(v + BN_EPS)
+    return s, b - m * s
+
+
+class PackedConv:
+    """Weights of one convolution/linear in kernel layout: w [N][Kp] with k = (ky,kx,c), bias [N], optional input
+    prologue (scale, shift) [Cin].  `view_kw` > 1 marks a patchify convolution executed as KHx1 over a merged view."""
+
+    def __init__(self, weight, bias, device, stride=1, pad=0, fold_bn=None, prologue=None, cin_pad=None, patchify=False):
+        w = weight.detach().double().cpu()
+        if w.dim() == 2:
+            w = w[:, :, None, None]
+        elif w.dim() == 3:
+            w = w[:, :, :, None]
+        N, Cin, KH, KW = w.shape
+        b = bias.detach().double().cpu() if bias is not None else torch.zeros(N, dtype=torch.float64)
+        if fold_bn is not None:  # conv -> BN : W' = W*s, b' = b*s + t
+            s, t = fold_bn
+            w = w * s.cpu()[:, None, None, None]
+            b = b * s.cpu() + t.cpu()
+        if cin_pad is not None and cin_pad > Cin:
+            w = torch.cat([w, torch.zeros(N, cin_pad - Cin, KH, KW, dtype=w.dtype)], 1)
+            Cin = cin_pad
+        w = w.permute(0, 2, 3, 1).contiguous()  # N KH KW Cin
+        if patchify:  # kernel == stride, pad 0: merge (kx, c) into the channel axis of a [H, W/KW, KW*C] view
+            assert stride == KH == KW and pad == 0
+            self.KH, self.KW, self.Cin = KH, 1, KW * Cin
+            self.sh, self.sw, self.ph, self.pw = KH, 1, 0, 0
+            self.merge = KW
+        else:
+            self.KH, self.KW, self.Cin = KH, KW, Cin
+            self.sh = self.sw = stride
+            self.ph = self.pw = pad
+            self.merge = 1
+        assert self.Cin % 4 == 0, "input channels (after view) must be a multiple of 4"
+        K = KH * KW * Cin
+        self.N, self.K = N, K
+        self.Kp = (K + 31) // 32 * 32
+        wp = torch.zeros(N, self.Kp, dtype=torch.float64)
+        wp[:, :K] = w.reshape(N, K)
+        self.w = wp.float().to(device)
+        self.b = b.float().to(device)
+        self.ps = self.pt = None
+        if prologue is not None:
+            s, t = prologue
+            assert s.numel() == Cin
+            self.ps, self.pt = s.float().to(device).contiguous(), t.float().to(device).contiguous()
+
+    def flops(self, M):
+        return 2.0 * M * self.N * self.K
+
+
+def conv(pc, x, out=None, flags=0, gamma=None, res=None, out_nchw=None):
+    """Launch kpf_conv2d_f32.  x: Act; out: Act (or None to allocate dense); res: Act."""
+    lib = L.load()
+    B = x.B
+    if pc.merge > 1:
+        assert x.ld == x.C and x.coff == 0 and x.W % pc.merge == 0
+        IH, IW, in_ld, in_coff = x.H, x.W // pc.merge, x.C * pc.merge, 0
+        assert in_ld == pc.Cin, (in_ld, pc.Cin)
+    else:
+        IH, IW, in_ld, in_coff = x.H, x.W, x.ld, x.coff
+        assert x.C == pc.Cin, (x.C, pc.Cin)
+    OH = (IH + 2 * pc.ph - pc.KH) // pc.sh + 1
+    OW = (IW + 2 * pc.pw - pc.KW) // pc.sw + 1
+    d = L.ConvDesc()
+    d.B, d.IH, d.IW, d.Cin, d.in_ld, d.in_coff = B, IH, IW, pc.Cin, in_ld, in_coff
+    d.OH, d.OW, d.N = OH, OW, pc.N
+    d.KH, d.KW, d.sh, d.sw, d.ph, d.pw, d.Kp = pc.KH, pc.KW, pc.sh, pc.sw, pc.ph, pc.pw, pc.Kp
+    if out_nchw is not None:
+        flags |= L.KPF_OUT_NCHW
+        optr = out_nchw
+        d.out_ld, d.out_coff = pc.N, 0
+    else:
+        if out is None:
+            out = Act.empty(B, OH, OW, pc.N, x.buf.device)
+        assert (out.B, out.H, out.W, out.C) == (B, OH, OW, pc.N), ((out.B, out.H, out.W, out.C), (B, OH, OW, pc.N))
+        optr = out.buf
+        d.out_ld, d.out_coff = out.ld, out.coff
+    if res is not None:
+        flags |= L.KPF_RES_ADD
+        d.res_ld, d.res_coff = res.ld, res.coff
+    if gamma is not None:
+        flags |= L.KPF_RES_GAMMA
+    d.flags = flags
+    L.check(lib.kpf_conv2d_f32(C.byref(d), _ptr(x.buf), _ptr(pc.w), _ptr(pc.b), _ptr(pc.ps), _ptr(pc.pt), _ptr(gamma),
+                               _ptr(res.buf if res is not None else None), _ptr(optr), _stream()), "kpf_conv2d_f32")
+    return out
+
+
+def layernorm(x, w, b, eps, out=None):
+    lib = L.load()
+    assert x.ld == x.C and x.coff == 0
+    out = x if out is None else out
+    L.check(lib.kpf_layernorm_f32(_ptr(x.buf), _ptr(w), _ptr(b), _ptr(out.buf), x.B * x.H * x.W, x.C, eps, _stream()),
+            "kpf_layernorm_f32")
+    return out
+
+
+def upsample2x(x, out):
+    lib = L.load()
+    assert x.ld == x.C and x.coff == 0 and out.C == x.C
+    L.check(lib.kpf_upsample2x_f32(_ptr(x.buf), _ptr(out.buf), x.B, x.H, x.W, x.C, out.ld, out.coff, _stream()),
+            "kpf_upsample2x_f32")
+    return out
+
+
+def nchw_to_nhwc(t, cpad=None):
+    lib = L.load()
+    B, Cc, H, W = t.shape
+    cpad = Cc if cpad is None else cpad
+    t = t.contiguous().float()
+    out = Act.empty(B, H, W, cpad, t.device)
+    L.check(lib.kpf_nchw_to_nhwc_f32(_ptr(t), _ptr(out.buf), B, Cc, H, W, cpad, _stream()), "kpf_nchw_to_nhwc_f32")
+    return out
+
+
+def nhwc_to_nchw(x):
+    lib = L.load()
+    out = torch.empty(x.B, x.C, x.H, x.W, device=x.buf.device, dtype=torch.float32)
+    L.check(lib.kpf_nhwc_to_nchw_f32(_ptr(x.buf), _ptr(out), x.B, x.C, x.H, x.W, x.ld, x.coff, _stream()),
+            "kpf_nhwc_to_nchw_f32")
+    return out
+
+
+def maxpool3x3s2(x):
+    lib = L.load()
+    assert x.ld == x.C and x.coff == 0
+    OH, OW = (x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1
+    out = Act.empty(x.B, OH, OW, x.C, x.buf.device)
+    L.check(lib.kpf_maxpool3x3s2_f32(_ptr(x.buf), _ptr(out.buf), x.B, x.H, x.W, x.C, _stream()), "kpf_maxpool3x3s2_f32")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# blocks
+# ----------------------------------------------------------------------------------------------------------------
+class ResidualPlan:
+    """Pre-activation bottleneck of model/hourglass.py:87-119 as 3 (4 with a skip conv) MFMA launches:
+    conv1 = [bn1+relu prologue] 1x1 [bn2 folded, relu] ; conv2 = 3x3 [bn3 folded, relu] ; conv3 = 1x1 + residual."""
+
+    def __init__(self, sd, p, device):
+        cin = sd[p + ".conv1.conv.weight"].shape[1]
+        cout = sd[p + ".conv3.conv.weight"].shape[0]
+        self.cin, self.cout = cin, cout
+        self.c1 = PackedConv(sd[p + ".conv1.conv.weight"], sd[p + ".conv1.conv.bias"], device,
+                             fold_bn=bn_scale_shift(sd, p + ".bn2"), prologue=bn_scale_shift(sd, p + ".bn1"))
+        self.c2 = PackedConv(sd[p + ".conv2.conv.weight"], sd[p + ".conv2.conv.bias"], device, pad=1,
+                             fold_bn=bn_scale_shift(sd, p + ".bn3"))
+        self.c3 = PackedConv(sd[p + ".conv3.conv.weight"], sd[p + ".conv3.conv.bias"], device)
+        self.skip = None
+        if cin != cout:
+            self.skip = PackedConv(sd[p + ".skip_layer.conv.weight"], sd[p + ".skip_layer.conv.bias"], device)
+
+    def __call__(self, x, out=None):
+        h = conv(self.c1, x, flags=L.KPF_ACT_RELU)
+        h = conv(self.c2, h, flags=L.KPF_ACT_RELU)
+        if out is None:
+            out = Act.empty(x.B, x.H, x.W, self.cout, x.buf.device)
+        if self.skip is not None:
+            conv(self.skip, x, out=out)
+            return conv(self.c3, h, out=out, res=out)
+        return conv(self.c3, h, out=out, res=x)
+
+    def flops(self, M):
+        f = self.c1.flops(M) + self.c2.flops(M) + self.c3.flops(M)
+        return f + (self.skip.flops(M) if self.skip else 0)
+
+
+class ConvNeXtBlockPlan:
+    """convNeXT/convnext.py:39-52 as: fused dw7x7+LN kernel, pw1 GEMM (+GELU), pw2 GEMM (+gamma*y + x, in place)."""
+
+    def __init__(self, sd, p, device):
+        c = sd[p + ".gamma"].numel()
+        self.C = c
+        self.wdw = sd[p + ".dwconv.weight"].detach().float().reshape(c, 49).t().contiguous().to(device)  # [49][C]
+        self.bdw = sd[p + ".dwconv.bias"].detach().float().to(device)
+        self.lnw = sd[p + ".norm.weight"].detach().float().to(device)
+        self.lnb = sd[p + ".norm.bias"].detach().float().to(device)
+        self.pw1 = PackedConv(sd[p + ".pwconv1.weight"], sd[p + ".pwconv1.bias"], device)
+        self.pw2 = PackedConv(sd[p + ".pwconv2.weight"], sd[p + ".pwconv2.bias"], device)
+        self.gamma = sd[p + ".gamma"].detach().float().to(device)
+
+    def __call__(self, x, y, h):
+        lib = L.load()
+        L.check(lib.kpf_dwconv7_ln_f32(_ptr(x.buf), _ptr(self.wdw), _ptr(self.bdw), _ptr(self.lnw), _ptr(self.lnb),
+                                       _ptr(y.buf), x.B, x.H, x.W, x.C, 1e-6, _stream()), "kpf_dwconv7_ln_f32")
+        conv(self.pw1, y, out=h, flags=L.KPF_ACT_GELU)
+        conv(self.pw2, h, out=x, gamma=self.gamma, res=x)
+        return x
+
+
+class UNetPlan:
+    """One backbone stream (encoder + 3-level Residual UNet decoder + heads): convNeXT/resnetUnet.py:129-152 /
+    model/resnetUnet.py:309-330.  __call__(img NCHW) -> (img_result NCHW B x 105 x F x F, img_feature Act NHWC 128)."""
+
+    def __init__(self, sd, p, net, device):
+        self.fam, size = parse_net(net)
+        self.device = device
+        sdp = {k[len(p) + 1:]: v for k, v in sd.items() if k.startswith(p + ".")}
+        self.in_ch = (sdp["backbone.downsample_layers.0.0.weight"] if self.fam == "convnext" else sdp["backbone.conv1.weight"]).shape[1]
+        if self.fam == "convnext":
+            depths, dims = CONVNEXT[size]
+            self.dims = dims
+            b = "backbone"
+            self.stem = PackedConv(sdp[b + ".downsample_layers.0.0.weight"], sdp[b + ".downsample_layers.0.0.bias"], device,
+                                   stride=4, patchify=True)
+            self.stem_ln = (sdp[b + ".downsample_layers.0.1.weight"].float().to(device), sdp[b + ".downsample_layers.0.1.bias"].float().to(device))
+            self.down, self.down_ln = [None], [None]
+            for i in range(1, 4):
+                self.down_ln.append((sdp[b + ".downsample_layers.%d.0.weight" % i].float().to(device),
+                                     sdp[b + ".downsample_layers.%d.0.bias" % i].float().to(device)))
+                self.down.append(PackedConv(sdp[b + ".downsample_layers.%d.1.weight" % i], sdp[b + ".downsample_layers.%d.1.bias" % i],
+                                            device, stride=2, patchify=True))
+            self.stages = [[ConvNeXtBlockPlan(sdp, b + ".stages.%d.%d" % (i, j), device) for j in range(depths[i])] for i in range(4)]
+        else:
+            self.dims = dims = (64, 128, 256, 512)
+            b = "backbone"
+            self.stem = PackedConv(sdp[b + ".conv1.weight"], None, device, stride=2, pad=3, fold_bn=bn_scale_shift(sdp, b + ".bn1"), cin_pad=4)
+            self.layers = []
+            for li in range(1, 5):
+                blocks = []
+                j = 0
+                while (b + ".layer%d.%d.conv1.weight" % (li, j)) in sdp:
+                    q = b + ".layer%d.%d" % (li, j)
+                    stride = 2 if (li > 1 and j == 0) else 1
+                    c1 = PackedConv(sdp[q + ".conv1.weight"], None, device, stride=stride, pad=1, fold_bn=bn_scale_shift(sdp, q + ".bn1"))
+                    c2 = PackedConv(sdp[q + ".conv2.weight"], None, device, pad=1, fold_bn=bn_scale_shift(sdp, q + ".bn2"))
+                    ds = None
+                    if (q + ".downsample.0.weight") in sdp:
+                        ds = PackedConv(sdp[q + ".downsample.0.weight"], None, device, stride=stride, fold_bn=bn_scale_shift(sdp, q + ".downsample.1"))
+                    blocks.append((c1, c2, ds))
+                    j += 1
+                self.layers.append(blocks)
+        d = dims
+        R = lambda name: ResidualPlan(sdp, name, device)
+        self.up4, self.skip4, self.fus4 = R("up4.0"), R("skip_layer4"), R("fusion_layer4")
+        self.up3, self.skip3, self.fus3 = R("up3.0"), R("skip_layer3"), R("fusion_layer3")
+        self.up2, self.skip2, self.fus2 = R("up2.0"), R("skip_layer2"), R("fusion_layer2")
+        self.result_emb = R("result_emb") if self.fam == "convnext" else None
+        wf = torch.cat([sdp["finals.%d.weight" % i] for i in range(3)], 0)
+        bf = torch.cat([sdp["finals.%d.bias" % i] for i in range(3)], 0)
+        self.finals = PackedConv(wf, bf, device)
+
+    # -- encoders -------------------------------------------------------------------------------------------
+    def _convnext(self, img):
+        B, Cc, S, _ = img.shape
+        x = Act(img.contiguous().float().view(-1), B, S, S, 1) if Cc == 1 else nchw_to_nhwc(img)
+        feats = []
+        cur = None
+        for i in range(4):
+            if i == 0:
+                cur = conv(self.stem, x)
+                layernorm(cur, self.stem_ln[0], self.stem_ln[1], 1e-6)
+            else:
+                t = Act.empty(cur.B, cur.H, cur.W, cur.C, self.device)
+                layernorm(cur, self.down_ln[i][0], self.down_ln[i][1], 1e-6, out=t)
+                cur = conv(self.down[i], t)
+            y = Act.empty(cur.B, cur.H, cur.W, cur.C, self.device)
+            h = Act.empty(cur.B, cur.H, cur.W, 4 * cur.C, self.device)
+            for blk in self.stages[i]:
+                blk(cur, y, h)
+            feats.append(cur)
+        return feats
+
+    def _resnet(self, img):
+        x = nchw_to_nhwc(img, cpad=4)
+        x = conv(self.stem, x, flags=L.KPF_ACT_RELU)
+        x = maxpool3x3s2(x)
+        feats = []
+        for blocks in self.layers:
+            for c1, c2, ds in blocks:
+                h = conv(c1, x, flags=L.KPF_ACT_RELU)
+                idt = conv(ds, x) if ds is not None else x
+                x = conv(c2, h, res=idt, flags=L.KPF_RELU_AFTER_RES)
+            feats.append(x)
+        return feats
+
+    def __call__(self, img):
+        c1, c2, c3, c4 = self._convnext(img) if self.fam == "convnext" else self._resnet(img)
+        d = self.dims
+        dev = self.device
+        B = c1.B
+
+        def level(up, skip, fus, lo, hi, fus_out_c):
+            cat = Act.empty(B, hi.H, hi.W, lo.C + hi.C, dev)
+            upsample2x(up(lo), cat.slice(0, lo.C))
+            skip(hi, out=cat.slice(lo.C, hi.C))
+            return fus(cat)
+
+        c3f = level(self.up4, self.skip4, self.fus4, c4, c3, d[2])
+        c2f = level(self.up3, self.skip3, self.fus3, c3f, c2, d[1])
+        feat = level(self.up2, self.skip2, self.fus2, c2f, c1, 128)
+        if self.result_emb is not None:
+            feat = self.result_emb(feat)
+        res = torch.empty(B, 105, feat.H, feat.W, device=dev, dtype=torch.float32)
+        conv(self.finals, feat, out_nchw=res)
+        return res, feat
+
+
+class ModelPlan:
+    """All kernel-layout weights of one KPFusion instance on one device."""
+
+    def __init__(self, sd, net, device):
+        self.net, self.device = net, device
+        self.backbone_d = UNetPlan(sd, "backbone_d", net, device)
+        self.backbone_rgb = UNetPlan(sd, "backbone_rgb", net, device)
+        self.sd = sd
+
+    def forward(self, img_rgb, img, pcl, center, M, cube, cam, kernel, img_size, flip):
+        raise NotImplementedError("fusion head kernels not built yet")

@@ -1,0 +1,66 @@
+"""ctypes binding of libkpf_hip.so (C ABI declared in include/kpf.h).
+
+The library is built in-tree by `make -C keypointfusion_amd/csrc` (or __graft_entry__.build()).  There is no CPU or
+PyTorch fallback: if the shared object is missing or a symbol is absent, import of the compute path fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkpf_hip.so")
+
+KPF_ACT_RELU = 1
+KPF_ACT_GELU = 2
+KPF_RES_ADD = 4
+KPF_RES_GAMMA = 8
+KPF_RELU_AFTER_RES = 16
+KPF_OUT_NCHW = 32
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "B", "IH", "IW", "Cin", "in_ld", "in_coff", "OH", "OW", "N", "KH", "KW", "sh", "sw", "ph", "pw", "Kp",
+        "out_ld", "out_coff", "res_ld", "res_coff")] + [("flags", C.c_uint)]
+
+
+_P = C.c_void_p
+_SIGS = {
+    "kpf_conv2d_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "kpf_dwconv7_ln_f32": [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P],
+    "kpf_layernorm_f32": [_P, _P, _P, _P, C.c_long, C.c_int, C.c_float, _P],
+    "kpf_upsample2x_f32": [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_nchw_to_nhwc_f32": [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_nhwc_to_nchw_f32": [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_maxpool3x3s2_f32": [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
+}
+EXPORTS = sorted(list(_SIGS) + ["kpf_last_error", "kpf_abi_version"])
+
+_lib = None
+
+
+class KpfError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library once; raise if it is not built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KpfError("libkpf_hip.so is not built: run `make -C keypointfusion_amd/csrc` "
+                       "(or __graft_entry__.build()); there is no fallback compute path")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = args
+        fn.restype = C.c_int
+    lib.kpf_last_error.restype = C.c_char_p
+    lib.kpf_abi_version.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise KpfError("%s failed (%d): %s" % (what, rc, load().kpf_last_error().decode()))

@@ -1,0 +1,110 @@
+"""Drop-in counterpart of the reference's `model.model.KPFusion` (model/model.py:354-426) for MI355X.
+
+Same constructor, same forward signature and return structure, same state-dict keys (keypointfusion_amd/spec.py),
+so `train.py` / `demo_RGBD.py`-style callers can switch `from model.model import KPFusion` to
+`from keypointfusion_amd.model.model import KPFusion`.  The module owns its parameters as ordinary
+torch Parameters/buffers in the reference (NCHW/OIHW) layout; at the first forward after construction or after a
+load_state_dict they are repacked into kernel layouts (keypointfusion_amd.engine) and all compute runs in
+libkpf_hip.so on the calling thread's current device/stream.  There is no CPU or PyTorch-op fallback.
+
+Differences that are deliberate: nothing is downloaded (`pretrain` is accepted and ignored — the
+reference pulls torchvision / fbaipublicfiles weights), no hard-coded `.cuda()`, no host synchronisation inside
+forward, dead sub-modules (decoder layers 0-2, BERT embeddings/poolers, ConvNeXt head) own their keys but cost nothing.
+"""
+import threading
+
+import torch
+import torch.nn as nn
+
+from ..spec import kpfusion_spec, parse_net
+from ..weights import _draw  # noqa: F401  (init scales shared with the synthetic generator)
+
+
+class _Node(nn.Module):
+    """Anonymous container used to reproduce the reference's dotted state-dict names."""
+
+
+def _attach(root, dotted, value, is_buffer):
+    parts = dotted.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, _Node())
+        mod = mod._modules[p]
+    if is_buffer:
+        mod.register_buffer(parts[-1], value)
+    else:
+        mod.register_parameter(parts[-1], nn.Parameter(value))
+
+
+class KPFusion(nn.Module):
+    def __init__(self, net, pretrain, joint_num, dataset, mano_dir, kernel_size=1, seed=0):
+        super().__init__()
+        if joint_num != 21:
+            raise ValueError("KPFusion is wired for 21 joints (Block_KPFusion, model/model.py:209)")
+        self.net = net
+        self.joint_num = joint_num
+        self.kernel_size = kernel_size
+        self.dim = 128
+        self.num_stages = 2
+        self.family, self.size = parse_net(net)
+        import numpy as np
+        import zlib
+        for name, shape, dtype, init in kpfusion_spec(net):
+            rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
+            val = torch.from_numpy(np.ascontiguousarray(_draw(rng, shape, init)))
+            is_buffer = name.endswith(("running_mean", "running_var", "num_batches_tracked"))
+            _attach(self, name, val, is_buffer)
+        self._plans = {}
+        self._plan_lock = threading.Lock()
+
+    # -- weight repacking ------------------------------------------------------------------------------------
+    def _state_version(self):
+        return sum(t._version for t in list(self.parameters()) + list(self.buffers()))
+
+    def _plan(self, device):
+        """Kernel-layout weights for `device`, rebuilt when any parameter changed (load_state_dict, optimiser step)."""
+        key = (device.type, device.index)
+        ver = self._state_version()
+        with self._plan_lock:
+            ent = self._plans.get(key)
+            if ent is None or ent[0] != ver:
+                from ..engine import ModelPlan
+                sd = {k: v.detach() for k, v in self.state_dict().items()}
+                ent = (ver, ModelPlan(sd, self.net, device))
+                self._plans[key] = ent
+            return ent[1]
+
+    def _load_from_state_dict(self, *a, **k):
+        self._plans.clear()
+        return super()._load_from_state_dict(*a, **k)
+
+    # -- forward ---------------------------------------------------------------------------------------------
+    @staticmethod
+    def _require_gpu(t):
+        if not t.is_cuda:
+            raise RuntimeError("keypointfusion_amd.KPFusion runs on MI355X only: inputs must be on a HIP device "
+                               "(there is no CPU fallback; the CPU oracle lives under oracle/ for tests)")
+
+    def forward_backbones(self, img_rgb, img):
+        """The two UNet streams only (BASELINE.json configs[1]): returns (img_offset, img_feat, img_offset_rgb,
+        img_feat_rgb) as NCHW tensors like the reference's backbone_d / backbone_rgb calls (model/model.py:397-398)."""
+        self._require_gpu(img)
+        from ..engine import nhwc_to_nchw
+        plan = self._plan(img.device)
+        with torch.cuda.device(img.device):
+            od, fd = plan.backbone_d(img)
+            orgb, frgb = plan.backbone_rgb(img_rgb)
+            return od, nhwc_to_nchw(fd), orgb, nhwc_to_nchw(frgb)
+
+    def forward(self, img_rgb, img, pcl, loader, center, M, cube, cam_para, kernel=0.8, writer=None, ii=0):
+        self._require_gpu(img)
+        if img.shape[-1] != 128:
+            # the reference hard-codes nn.Linear(32*32, 1) (model/model.py:264): the full model exists at S=128 only
+            raise RuntimeError("mat1 and mat2 shapes cannot be multiplied: the fusion block needs 128x128 crops "
+                               "(got %d); use forward_backbones() for other sizes" % img.shape[-1])
+        img_size = int(getattr(loader, "img_size", 128))
+        flip = int(getattr(loader, "flip", 1))
+        plan = self._plan(img.device)
+        with torch.cuda.device(img.device):
+            return plan.forward(img_rgb, img, pcl, center, M, cube, cam_para, float(kernel), img_size, flip)
