@@ -52,7 +52,8 @@ typedef struct kpf_conv_desc {
  * convNeXT/convnext.py:31-34,77,84 (pwconv1/2, stem, downsample), model/resnet.py:52-55,166 (BasicBlock, stem),
  * convNeXT/resnetUnet.py:95-97 (finals) — i.e. cuDNN implicit GEMM + cuBLAS sgemm in the reference.
  * w is [N][Kp] (PyTorch [out][in] order, taps reordered to (ky,kx,c)); bias may be NULL.
- * Requirements: Cin, in_ld, in_coff, out_ld, out_coff, res_ld, res_coff multiples of 4 (float4 path) unless OUT_NCHW.
+ * Requirements: Cin, in_ld, in_coff multiples of 4.  out/res ld and coff multiples of 4 select the float4 epilogue
+ * (scalar stores otherwise).
  */
 int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const float* w, const float* bias,
                    const float* pro_scale, const float* pro_shift, const float* gamma, const float* res,

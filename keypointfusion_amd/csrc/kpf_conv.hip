@@ -40,6 +40,7 @@ struct ConvArgs {
   int out_ld, out_coff, res_ld, res_coff;
   unsigned flags;
   int tilesN, nblk;
+  int vec;  // 1: output/residual rows are 16-byte aligned -> float4 epilogue
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const ConvArgs a) {
       const int n = n0 + (wn * TN + i) * 16 + fg * 4;
       if (n >= a.N) continue;
       f32x4 v = acc[i][j];
-      const bool full = (n + 3 < a.N);
+      const bool full = (n + 3 < a.N) && a.vec;
       f32x4 bv = zero4, gv = {1.f, 1.f, 1.f, 1.f}, rv = zero4;
       if (full) {
         if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
@@ -296,10 +297,10 @@ extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const flo
   KPF_REQUIRE(kpf_aligned16(in) && kpf_aligned16(w) && kpf_aligned16(out), "kpf_conv2d_f32: pointers must be 16-byte aligned");
   const unsigned fl = d->flags;
   if (!(fl & KPF_OUT_NCHW))
-    KPF_REQUIRE(d->out_ld % 4 == 0 && d->out_coff % 4 == 0 && d->out_coff + d->N <= d->out_ld,
-                "kpf_conv2d_f32: bad output slice ld=%d coff=%d N=%d", d->out_ld, d->out_coff, d->N);
+    KPF_REQUIRE(d->out_coff >= 0 && d->out_coff + d->N <= d->out_ld, "kpf_conv2d_f32: bad output slice ld=%d coff=%d N=%d",
+                d->out_ld, d->out_coff, d->N);
   if (fl & KPF_RES_ADD)
-    KPF_REQUIRE(res && kpf_aligned16(res) && d->res_ld % 4 == 0 && d->res_coff % 4 == 0, "kpf_conv2d_f32: bad residual");
+    KPF_REQUIRE(res && kpf_aligned16(res) && d->res_coff >= 0 && d->res_coff + d->N <= d->res_ld, "kpf_conv2d_f32: bad residual");
   if (fl & KPF_RES_GAMMA) KPF_REQUIRE(gamma && (fl & KPF_RES_ADD), "kpf_conv2d_f32: RES_GAMMA needs gamma and RES_ADD");
   KPF_REQUIRE((pro_scale == nullptr) == (pro_shift == nullptr), "kpf_conv2d_f32: prologue needs both scale and shift");
   KPF_REQUIRE(!((fl & KPF_ACT_RELU) && (fl & KPF_ACT_GELU)), "kpf_conv2d_f32: one activation only");
@@ -313,6 +314,7 @@ extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const flo
   a.sh = d->sh; a.sw = d->sw; a.ph = d->ph; a.pw = d->pw;
   a.out_ld = d->out_ld; a.out_coff = d->out_coff; a.res_ld = d->res_ld; a.res_coff = d->res_coff;
   a.flags = fl; a.tilesN = 0; a.nblk = 0;
+  a.vec = (d->out_ld % 4 == 0 && d->out_coff % 4 == 0 && (!(fl & KPF_RES_ADD) || (d->res_ld % 4 == 0 && d->res_coff % 4 == 0))) ? 1 : 0;
   const bool is1x1 = d->KH == 1 && d->KW == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0 &&
                      d->IH == d->OH && d->IW == d->OW;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -52,7 +52,7 @@ class KPFusion(nn.Module):
         import zlib
         for name, shape, dtype, init in kpfusion_spec(net):
             rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
-            val = torch.from_numpy(np.ascontiguousarray(_draw(rng, shape, init)))
+            val = torch.from_numpy(np.asarray(_draw(rng, shape, init)).copy()).reshape(shape)
             is_buffer = name.endswith(("running_mean", "running_var", "num_batches_tracked"))
             _attach(self, name, val, is_buffer)
         self._plans = {}

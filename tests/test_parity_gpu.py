@@ -101,7 +101,8 @@ def test_conv2d_prologue_epilogues_and_slices():
     ref2 = xr + gam[None, :, None, None] * F.conv2d(hmid, w2[:, :, None, None], b2)
     pc2 = E.PackedConv(w2, b2, dev)
     xa = nhwc(xr)
-    E.conv(pc2, nhwc(hmid), out=xa, gamma=gam.to(dev), res=xa)
+    gamd = gam.to(dev)
+    E.conv(pc2, nhwc(hmid), out=xa, gamma=gamd, res=xa)
     assert rel_err(to_nchw(xa), ref2) < 1e-5
     w1 = torch.randn(384, 96, generator=g) / 96 ** 0.5
     b1 = torch.randn(384, generator=g)
@@ -147,8 +148,11 @@ def test_dwconv7_ln(C, H, W):
     ref = F.layer_norm(F.conv2d(x, wd, bd, padding=3, groups=C).permute(0, 2, 3, 1), (C,), lw, lb, 1e-6).permute(0, 3, 1, 2)
     xa = nhwc(x)
     ya = E.Act.empty(2, H, W, C, dev)
-    L.check(L.load().kpf_dwconv7_ln_f32(E._ptr(xa.buf), E._ptr(wd.reshape(C, 49).t().contiguous().to(dev)), E._ptr(bd.to(dev)),
-                                        E._ptr(lw.to(dev)), E._ptr(lb.to(dev)), E._ptr(ya.buf), 2, H, W, C, 1e-6, E._stream()))
+    # keep the device tensors alive across the launch (raw pointers cross the C ABI)
+    wdd, bdd, lwd, lbd = wd.reshape(C, 49).t().contiguous().to(dev), bd.to(dev), lw.to(dev), lb.to(dev)
+    L.check(L.load().kpf_dwconv7_ln_f32(E._ptr(xa.buf), E._ptr(wdd), E._ptr(bdd), E._ptr(lwd), E._ptr(lbd), E._ptr(ya.buf),
+                                        2, H, W, C, 1e-6, E._stream()))
+    torch.cuda.synchronize()
     assert rel_err(to_nchw(ya), ref) < 2e-5
 
 
@@ -160,7 +164,8 @@ def test_layernorm_upsample_maxpool_repack():
     lw, lb = torch.rand(192, generator=g) + 0.5, torch.randn(192, generator=g)
     ref = F.layer_norm(x.permute(0, 2, 3, 1), (192,), lw, lb, 1e-6).permute(0, 3, 1, 2)
     xa = nhwc(x)
-    out = E.layernorm(xa, lw.to(dev), lb.to(dev), 1e-6, out=E.Act.empty(2, 9, 5, 192, dev))
+    lwd, lbd = lw.to(dev), lb.to(dev)
+    out = E.layernorm(xa, lwd, lbd, 1e-6, out=E.Act.empty(2, 9, 5, 192, dev))
     assert rel_err(to_nchw(out), ref) < 1e-5
     up_ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
     cat = E.Act.empty(2, 18, 10, 192 + 64, dev)
