@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--workload", default="backbones256", choices=["backbones256", "full128"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-launch", default="", help="write a per-launch table of the implicit-GEMM kernel to this file")
     ap.add_argument("--cpu-sample", type=int, default=8, help="images in the CPU-baseline sample")
     args = ap.parse_args()
 
@@ -120,7 +121,7 @@ def main():
                 M = x.B * (x.H // pc.sh) * (x.W // pc.merge)
             else:
                 M = x.B * ((x.H + 2 * pc.ph - pc.KH) // pc.sh + 1) * ((x.W + 2 * pc.pw - pc.KW) // pc.sw + 1)
-            recs.append((e0, e1, pc.flops(M)))
+            recs.append((e0, e1, pc.flops(M), (M, pc.N, pc.K, pc.KH, pc.KW)))
             return out
 
         E.conv = timed_conv
@@ -132,8 +133,14 @@ def main():
             torch.cuda.synchronize()
         finally:
             E.conv = orig_conv
-        t_ms = sum(a.elapsed_time(b) for a, b, _ in recs)
-        fl = sum(f for _, _, f in recs)
+        t_ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+        fl = sum(r[2] for r in recs)
+        if args.per_launch:
+            with open(args.per_launch, "w") as f:
+                f.write("M,N,K,KH,KW,ms,TFLOPs\n")
+                for e0, e1, fl_i, shp in recs:
+                    ms = e0.elapsed_time(e1)
+                    f.write("%d,%d,%d,%d,%d,%.4f,%.1f\n" % (shp + (ms, fl_i / ms / 1e9)))
         ach = fl / (t_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": "igemm_f32_kernel", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,

@@ -45,7 +45,7 @@ struct ConvArgs {
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-template <int TM, int TN, int WM, int WN, bool IS1X1>
+template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO>
 __global__ __launch_bounds__(256) void igemm_f32_kernel(const ConvArgs a) {
   constexpr int BM = 16 * TM * WM;
   constexpr int BN = 16 * TN * WN;
@@ -103,7 +103,12 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const ConvArgs a) {
     }
   }
 
+  // Staging registers.  Loads are issued unconditionally (from a safe address when the element is padding / out of range) and
+  // nothing touches their results until store_tile(), so the whole next K-tile stays in flight under the current tile's MFMAs;
+  // validity travels in a bit mask and the operand prologue is applied at store time.
   f32x4 ra[AP], rb[BP];
+  f32x4 ps4 = {0.f, 0.f, 0.f, 0.f}, pt4 = {0.f, 0.f, 0.f, 0.f};
+  unsigned amask = 0, bmask = 0;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
   auto load_tile = [&](int kt) {
@@ -116,12 +121,12 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const ConvArgs a) {
       ky = tap / a.KW;
       kx = tap - ky * a.KW;
     }
-    f32x4 s4 = zero4, t4 = zero4;
-    const bool pro = (a.ps != nullptr);
-    if (pro && kvalid) {
-      s4 = *reinterpret_cast<const f32x4*>(a.ps + c);
-      t4 = *reinterpret_cast<const f32x4*>(a.pt + c);
+    if (HAS_PRO) {
+      const int cs = kvalid ? c : 0;
+      ps4 = *reinterpret_cast<const f32x4*>(a.ps + cs);
+      pt4 = *reinterpret_cast<const f32x4*>(a.pt + cs);
     }
+    amask = 0;
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
       bool v = kvalid && rbase[p] >= 0;
@@ -133,33 +138,37 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const ConvArgs a) {
         v = v && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
         off = ((long)rbase[p] + (long)iy * a.IW + ix) * a.in_ld + a.in_coff + c;
       }
-      f32x4 x = zero4;
-      if (v) {
-        x = *reinterpret_cast<const f32x4*>(a.in + off);
-        if (pro) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) x[e] = fmaxf(fmaf(x[e], s4[e], t4[e]), 0.f);
-        }
-      }
-      ra[p] = x;
+      ra[p] = *reinterpret_cast<const f32x4*>(a.in + (v ? off : 0l));
+      amask |= (v ? 1u : 0u) << p;
     }
+    bmask = 0;
 #pragma unroll
     for (int p = 0; p < BP; ++p) {
       const int rl = lr + 32 * p;
       const int n = n0 + rl;
-      f32x4 x = zero4;
-      if (rl < BN && n < a.N) x = *reinterpret_cast<const f32x4*>(a.w + (long)n * a.Kp + kt * BK + kc);
-      rb[p] = x;
+      const bool v = rl < BN && n < a.N;
+      rb[p] = *reinterpret_cast<const f32x4*>(a.w + (v ? ((long)n * a.Kp + kt * BK + kc) : 0l));
+      bmask |= (v ? 1u : 0u) << p;
     }
   };
 
   auto store_tile = [&]() {
 #pragma unroll
-    for (int p = 0; p < AP; ++p) *reinterpret_cast<f32x4*>(As + (lr + 32 * p) * BK + wcol) = ra[p];
+    for (int p = 0; p < AP; ++p) {
+      f32x4 x = ra[p];
+      if (HAS_PRO) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = fmaxf(fmaf(x[e], ps4[e], pt4[e]), 0.f);
+      }
+      if (!((amask >> p) & 1u)) x = zero4;
+      *reinterpret_cast<f32x4*>(As + (lr + 32 * p) * BK + wcol) = x;
+    }
 #pragma unroll
     for (int p = 0; p < BP; ++p) {
       const int rl = lr + 32 * p;
-      if (rl < BN) *reinterpret_cast<f32x4*>(Bs + rl * BK + wcol) = rb[p];
+      f32x4 x = rb[p];
+      if (!((bmask >> p) & 1u)) x = zero4;
+      if (rl < BN) *reinterpret_cast<f32x4*>(Bs + rl * BK + wcol) = x;
     }
   };
 
@@ -260,10 +269,15 @@ int launch_cfg(ConvArgs& a, bool is1x1, hipStream_t st) {
   const int tilesM = (a.M + BM - 1) / BM;
   a.tilesN = (a.N + BN - 1) / BN;
   a.nblk = tilesM * a.tilesN;
-  if (is1x1)
-    hipLaunchKernelGGL((igemm_f32_kernel<TM, TN, WM, WN, true>), dim3(a.nblk), dim3(256), 0, st, a);
+  // the operand prologue only occurs on 1x1 convolutions (pre-activation Residual.conv1), so 3 instantiations suffice
+  if (is1x1 && a.ps)
+    hipLaunchKernelGGL((igemm_f32_kernel<TM, TN, WM, WN, true, true>), dim3(a.nblk), dim3(256), 0, st, a);
+  else if (is1x1)
+    hipLaunchKernelGGL((igemm_f32_kernel<TM, TN, WM, WN, true, false>), dim3(a.nblk), dim3(256), 0, st, a);
+  else if (!a.ps)
+    hipLaunchKernelGGL((igemm_f32_kernel<TM, TN, WM, WN, false, false>), dim3(a.nblk), dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL((igemm_f32_kernel<TM, TN, WM, WN, false>), dim3(a.nblk), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((igemm_f32_kernel<TM, TN, WM, WN, false, true>), dim3(a.nblk), dim3(256), 0, st, a);
   return kpf_check_launch("kpf_conv2d_f32");
 }
 

@@ -247,12 +247,13 @@ def pcl_joint2offset(joint, pcl, kernel):
 # --------------------------------------------------------------------------------------------------------------
 def ball_query(radius, nsample, xyz, new_xyz):
     """pointnet2_ops.ball_query (third party, unpinned): for each query, the first `nsample` point indices in index
-    order with d^2 < r^2 (d^2 = dx*dx+dy*dy+dz*dz in fp32); remaining slots repeat the first hit; zeros if none."""
+    order with d^2 < r^2 (d^2 = dx*dx+dy*dy+dz*dz and r^2 = r*r, all in fp32, products rounded individually); remaining slots repeat the first hit; zeros if none."""
     B, N, _ = xyz.shape
     S = new_xyz.shape[1]
     d = new_xyz.unsqueeze(2) - xyz.unsqueeze(1)
     d2 = d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1] + d[..., 2] * d[..., 2]
-    within = d2 < (radius * radius)
+    r32 = torch.tensor(radius, dtype=torch.float32)
+    within = d2 < (r32 * r32)  # radius2 = radius * radius in fp32, as the extension's kernel computes it
     # rank of each hit among the hits of its query
     rank = torch.cumsum(within.long(), -1) - 1
     idx = torch.zeros(B, S, nsample, dtype=torch.long)

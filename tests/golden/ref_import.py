@@ -45,7 +45,8 @@ class _QueryAndGroup(nn.Module):
         # d2 accumulated in the CUDA kernel's order: dx*dx + dy*dy + dz*dz
         d = new_xyz.unsqueeze(2) - xyz.unsqueeze(1)
         d2 = d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1] + d[..., 2] * d[..., 2]
-        within = d2 < (radius * radius)
+        r32 = torch.tensor(radius, dtype=torch.float32)
+        within = d2 < (r32 * r32)  # fp32 radius2, as in the CUDA kernel
         idx = torch.zeros(B, S, nsample, dtype=torch.long)
         ar = torch.arange(N)
         for b in range(B):
