@@ -89,6 +89,70 @@ int kpf_nhwc_to_nchw_f32(const float* src, float* dst, int B, int C, int H, int 
 /* 3x3 stride-2 pad-1 max pooling on dense NHWC (model/resnet.py:169,236). */
 int kpf_maxpool3x3s2_f32(const float* src, float* dst, int B, int H, int W, int C, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Keypoint-fusion head (Block_KPFusion, model/model.py:287-351) — geometry, point-cloud and 21-token kernels.
+ * J = 21 joints, feature maps F x F (P = F*F pixels), N points, C = 128 channels; all buffers dense fp32.
+ * ------------------------------------------------------------------------------------------------------------ */
+
+/* Masked soft-argmax decode of the depth stream's offset maps + uvd->xyz (model/model.py:466-500 offset2joint_weight,
+ * dataloader/loader.py:775-789 uvd_nl2xyznl_tensor).  offset NCHW [B][105][P]; depth [B][S][S] (nearest-downsampled to
+ * F on the fly, model/model.py:471); center [B][3], M [B][3][3], cube [B][3], cam [B][4].  -> joint_uvd, joint_xyz [B][21][3]. */
+int kpf_offset2joint_f32(const float* offset, const float* depth, const float* center, const float* M, const float* cube,
+                         const float* cam, float* joint_uvd, float* joint_xyz, int B, int S, int F, float kernel,
+                         int img_size, int flip, void* stream);
+
+/* Per point the 4 nearest feature pixels, ascending squared distance, and inverse-distance weights
+ * (dataloader/loader.py:936-967 img2pcl_index; replaces the B x N x P x 3 broadcast + ATen topk).
+ * -> closeness [B][N][4] fp32, index [B][N][4] int32 (values in [0,P)), img_xyz [B][P][3] (pixel positions, may be NULL). */
+int kpf_img2pcl_top4_f32(const float* pcl, const float* depth, const float* center, const float* M, const float* cube,
+                         const float* cam, float* closeness, int* index, float* img_xyz, int B, int N, int S, int F,
+                         int img_size, int flip, void* stream);
+
+/* Point feature gather + pcl_joint2offset (model/model.py:295-309, 503-525): builds the operand rows of the point
+ * embedding GEMMs: A1 [B*N][240] = [pf 128 | xyz 3 | pw 21 | unit offsets 63 | closeness 21 | 0 x4], A2 [B*N][128] = pf_rgb.
+ * feat_* NHWC [B][P][128]; offset NCHW [B][105][P]. */
+int kpf_point_assemble_f32(const float* feat_d, const float* feat_rgb, const float* offset, const float* pcl,
+                           const float* joint_xyz, const float* closeness, const int* index, float* A1, float* A2, int B,
+                           int N, int P, float kernel, void* stream);
+
+/* attention = softmax_N(pw), joint_feat = attention @ X (model/model.py:319-320).  X [B*N][128];
+ * -> JA [B*21][132] = [joint_feat 128 | joint xyz 3 | 0]. */
+int kpf_softmax_pool_f32(const float* A1, const float* X, const float* joint_xyz, float* JA, int B, int N, void* stream);
+
+/* pointnet2_ops ball_query + group_points for the 3 DESA radii (model/model.py:158,171-178): points = cat(pcl, joints),
+ * features = cat(X [B*N][128], JF [B*21][jf_ld]).  -> G [3][B*21*64][132] = [feat[idx]-feat_j | (xyz[idx]-xyz_j)/r | 0],
+ * idx_out [3][B*21][64] int32 (may be NULL). */
+int kpf_ball_group_f32(const float* pcl, const float* joint_xyz, const float* X, const float* JF, int jf_ld, float* G,
+                       int* idx_out, int B, int N, float r0, float r1, float r2, void* stream);
+
+/* max over groups of `group` consecutive rows (torch.max(dim=-1), model/model.py:198). */
+int kpf_group_max_f32(const float* in, float* out, long rows, int group, int C, int out_ld, int out_coff, void* stream);
+
+/* Heat-map, geometry adjacency map, spatial attention, gate (model/model.py:334-338; util/generateFeature.py:584-600;
+ * dataloader/loader.py:791-819).  SF [B*P][sf_ld] = feature part of atten_spatial (a GEMM), Wh [21][21] its heat-map part.
+ * -> sw_out NCHW [B][21][P] (returned spatial weight), Gw [B][21][P] = gate * fc_spatial2joint_feature.weight. */
+int kpf_heat_gam_gate_f32(const float* r3d, const float* img_xyz, const float* SF, int sf_ld, const float* Wh,
+                          const float* bias, const float* weight_dis, const float* wfc, const float* center,
+                          const float* M, const float* cube, const float* cam, float* sw_out, float* Gw, int B, int F,
+                          int img_size, int flip, void* stream);
+
+/* img_feat_j = Gw @ relu(feat) + b (model/model.py:340-344), optional relu((. + prev)/2).  -> out [B][21][128]. */
+int kpf_gate_reduce_f32(const float* Gw, const float* feat, const float* bfc, const float* prev, float* out, int B, int P,
+                        void* stream);
+
+/* KP_Interaction_TR (model/model.py:106-126): embed + 4 BERT layers + 3-vector heads on 21 tokens, one workgroup per
+ * sample.  x [B*21][ldx] (Din used), W = packed weights (keypointfusion_amd/engine.py:pack_tr), -> h [B][21][128],
+ * score [B][21][3]; score2 (may be NULL) receives a second copy with row stride score2_ld. */
+int kpf_tr_encoder_f32(const float* x, int ldx, int Din, const float* W, float* h, float* score, float* score2,
+                       int score2_ld, int B, void* stream);
+int kpf_tr_encoder_weight_floats(int Din);
+
+/* The observable layer of updatedDecoder (model/transfusion_head.py:137-173 with cross_only): query/key [B][21][128]
+ * -> out rows [B*21] with stride out_ld at column out_coff. */
+int kpf_xattn_layer_f32(const float* query, const float* key, const float* W, float* out, int out_ld, int out_coff, int B,
+                        void* stream);
+int kpf_xattn_weight_floats(void);
+
 const char* kpf_last_error(void);
 /* Library/ABI version, bumped when a signature changes. */
 int kpf_abi_version(void);

@@ -1,0 +1,553 @@
+// Geometry / point-cloud kernels of the keypoint-fusion head.  All are HBM- or latency-bound
+// gathers, reductions and small searches: one wave (or one workgroup) per joint / point / pixel tile, wave64 shuffles
+// for reductions, no materialised B x N x F^2 intermediates.
+//
+// Floating-point contraction is OFF in this file: the index-producing comparisons (top-4 nearest pixels, ball-query
+// membership) must see squared distances rounded like the oracle's (products rounded individually, left-to-right adds).
+#include "kpf_common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int J = 21;
+
+struct Cam {  // per-sample crop/camera constants
+  float mi00, mi01, mi02, mi10, mi11, mi12;  // first two rows of M^-1
+  float cx, cy, cz, hx, hy, hz;              // centre (mm), half cube (mm)
+  float fx, fy, u0, v0;
+};
+
+__device__ __forceinline__ Cam load_cam(const float* center, const float* M, const float* cube, const float* cam, int b) {
+  Cam c;
+  const float* m = M + 9 * b;
+  const float a = m[0], bb = m[1], cc = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+  const float A = e * i - f * h, Bc = -(d * i - f * g), Cc = d * h - e * g;
+  const float det = a * A + bb * Bc + cc * Cc;
+  const float id = 1.0f / det;
+  c.mi00 = A * id;
+  c.mi01 = -(bb * i - cc * h) * id;
+  c.mi02 = (bb * f - cc * e) * id;
+  c.mi10 = Bc * id;
+  c.mi11 = (a * i - cc * g) * id;
+  c.mi12 = -(a * f - cc * d) * id;
+  c.cx = center[3 * b];
+  c.cy = center[3 * b + 1];
+  c.cz = center[3 * b + 2];
+  c.hx = cube[3 * b] / 2.0f;
+  c.hy = cube[3 * b + 1] / 2.0f;
+  c.hz = cube[3 * b + 2] / 2.0f;
+  c.fx = cam[4 * b];
+  c.fy = cam[4 * b + 1];
+  c.u0 = cam[4 * b + 2];
+  c.v0 = cam[4 * b + 3];
+  return c;
+}
+
+// dataloader/loader.py:775-789: normalised uvd -> normalised xyz (un-crop through M^-1, pinhole back-projection)
+__device__ __forceinline__ void uvd2xyz(const Cam& c, float u, float v, float d, float half_img, float flip, float& x, float& y,
+                                        float& z) {
+  const float up = (u + 1.0f) * half_img, vp = (v + 1.0f) * half_img;
+  const float dm = d * c.hz + c.cz;
+  const float tu = (c.mi00 * up + c.mi01 * vp) + c.mi02;
+  const float tv = (c.mi10 * up + c.mi11 * vp) + c.mi12;
+  const float X = (tu - c.u0) * dm / c.fx;
+  const float Y = flip * (tv - c.v0) * dm / c.fy;
+  x = (X - c.cx) / c.hx;
+  y = (Y - c.cy) / c.hy;
+  z = (dm - c.cz) / c.hz;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {  // 256 threads
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// a7 + a8: masked soft-argmax decode (model/model.py:466-500) and uvd -> xyz.  grid (J, B), 256 threads.
+// offset: NCHW [B][105][F*F]; depth: [B][S][S] (nearest-downsampled on the fly).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void offset2joint_kernel(const float* __restrict__ offset, const float* __restrict__ depth,
+                                                           const float* __restrict__ center, const float* __restrict__ M,
+                                                           const float* __restrict__ cube, const float* __restrict__ cam,
+                                                           float* __restrict__ joint_uvd, float* __restrict__ joint_xyz, int S, int F,
+                                                           float kernel, float half_img, float flip) {
+  __shared__ float red[4];
+  const int j = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int P = F * F;
+  const float* ob = offset + (long)b * 5 * J * P;
+  const float* wp = ob + (4 * J + j) * P;
+  const float* hp = ob + (3 * J + j) * P;
+  const float* up = ob + (3 * j) * P;
+  float lmax = -INFINITY;
+  for (int p = tid; p < P; p += 256) {
+    const int py = p / F, px = p - py * F;
+    const float d = depth[(long)b * S * S + (long)((py * S) / F) * S + (px * S) / F];
+    const float w = d > 0.99f ? -1e8f : wp[p];
+    lmax = fmaxf(lmax, w);
+  }
+  const float mx = block_max(lmax, red);
+  float se = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int p = tid; p < P; p += 256) {
+    const int py = p / F, px = p - py * F;
+    const float d = depth[(long)b * S * S + (long)((py * S) / F) * S + (px * S) / F];
+    const float w = d > 0.99f ? -1e8f : wp[p];
+    const float e = expf(w - mx);
+    const float mask = d < 0.99f ? 1.f : 0.f;
+    const float dist = kernel - (hp[p] * mask) * kernel;
+    const float cu = 2.0f * ((float)px + 0.5f) / (float)F - 1.0f;
+    const float cv = 2.0f * ((float)py + 0.5f) / (float)F - 1.0f;
+    se += e;
+    s0 += ((up[p] * mask) * dist + cu) * e;
+    s1 += ((up[P + p] * mask) * dist + cv) * e;
+    s2 += ((up[2 * P + p] * mask) * dist + d) * e;
+  }
+  se = block_sum(se, red);
+  s0 = block_sum(s0, red);
+  s1 = block_sum(s1, red);
+  s2 = block_sum(s2, red);
+  if (tid == 0) {
+    const float u = s0 / se, v = s1 / se, d = s2 / se;
+    float* o = joint_uvd + ((long)b * J + j) * 3;
+    o[0] = u;
+    o[1] = v;
+    o[2] = d;
+    const Cam c = load_cam(center, M, cube, cam, b);
+    float x, y, z;
+    uvd2xyz(c, u, v, d, half_img, flip, x, y, z);
+    float* q = joint_xyz + ((long)b * J + j) * 3;
+    q[0] = x;
+    q[1] = y;
+    q[2] = z;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// a9: per point the 4 nearest feature pixels (dataloader/loader.py:936-967) without materialising B x N x F^2.
+// grid (ceil(N/256), B); the F*F pixel positions are rebuilt in LDS per workgroup (12 KB at F=32).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void img2pcl_top4_kernel(const float* __restrict__ pcl, const float* __restrict__ depth,
+                                                           const float* __restrict__ center, const float* __restrict__ M,
+                                                           const float* __restrict__ cube, const float* __restrict__ cam,
+                                                           float* __restrict__ closeness, int* __restrict__ index,
+                                                           float* __restrict__ img_xyz_out, int N, int S, int F, float half_img,
+                                                           float flip) {
+  extern __shared__ __attribute__((aligned(16))) float pix[];  // [P][3]
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int P = F * F;
+  const Cam c = load_cam(center, M, cube, cam, b);
+  for (int p = tid; p < P; p += 256) {
+    const int py = p / F, px = p - py * F;
+    const float d = depth[(long)b * S * S + (long)((py * S) / F) * S + (px * S) / F];
+    const float cu = 2.0f * ((float)px + 0.5f) / (float)F - 1.0f;
+    const float cv = 2.0f * ((float)py + 0.5f) / (float)F - 1.0f;
+    float x, y, z;
+    uvd2xyz(c, cu, cv, d, half_img, flip, x, y, z);
+    pix[3 * p] = x;
+    pix[3 * p + 1] = y;
+    pix[3 * p + 2] = z;
+    if (img_xyz_out && blockIdx.x == 0) {
+      float* o = img_xyz_out + ((long)b * P + p) * 3;
+      o[0] = x;
+      o[1] = y;
+      o[2] = z;
+    }
+  }
+  __syncthreads();
+  const int n = blockIdx.x * 256 + tid;
+  if (n >= N) return;
+  const float* q = pcl + ((long)b * N + n) * 3;
+  const float qx = q[0], qy = q[1], qz = q[2];
+  float d0 = INFINITY, d1 = INFINITY, d2 = INFINITY, d3 = INFINITY;
+  int i0 = 0, i1 = 0, i2 = 0, i3 = 0;
+  for (int p = 0; p < P; ++p) {
+    const float dx = qx - pix[3 * p], dy = qy - pix[3 * p + 1], dz = qz - pix[3 * p + 2];
+    const float dd = (dx * dx + dy * dy) + dz * dz;
+    if (dd < d3) {
+      if (dd < d2) {
+        d3 = d2; i3 = i2;
+        if (dd < d1) {
+          d2 = d1; i2 = i1;
+          if (dd < d0) { d1 = d0; i1 = i0; d0 = dd; i0 = p; } else { d1 = dd; i1 = p; }
+        } else { d2 = dd; i2 = p; }
+      } else { d3 = dd; i3 = p; }
+    }
+  }
+  const float c0 = 1.0f / (d0 + 1e-8f), c1 = 1.0f / (d1 + 1e-8f), c2 = 1.0f / (d2 + 1e-8f), c3 = 1.0f / (d3 + 1e-8f);
+  const float cs = (((c0 + c1) + c2) + c3) + 1e-8f;
+  float* co = closeness + ((long)b * N + n) * 4;
+  int* io = index + ((long)b * N + n) * 4;
+  co[0] = c0 / cs; co[1] = c1 / cs; co[2] = c2 / cs; co[3] = c3 / cs;
+  io[0] = i0; io[1] = i1; io[2] = i2; io[3] = i3;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// a10 + a11 (gather half): one wave per point builds the two operand rows of the point-embedding GEMMs:
+//   A1[b,n] = [ pf(128) | pcl xyz(3) | pw(21) | unit offsets (63) | closeness (21) | 0 0 0 0 ]   (240 floats)
+//   A2[b,n] = pf_rgb(128)
+// pf = sum_k clos_k * feat[b, idx_k, :] (model/model.py:297-301), pw from the weight-logit planes (:304-306),
+// offsets/closeness = pcl_joint2offset (:503-525).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int A1_LD = 240;
+
+__global__ __launch_bounds__(256) void point_assemble_kernel(const float* __restrict__ feat_d, const float* __restrict__ feat_rgb,
+                                                             const float* __restrict__ offset, const float* __restrict__ pcl,
+                                                             const float* __restrict__ joint_xyz, const float* __restrict__ closeness,
+                                                             const int* __restrict__ index, float* __restrict__ A1,
+                                                             float* __restrict__ A2, int N, int P, float kernel) {
+  const int lane = threadIdx.x & 63;
+  const long pt = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // global point id b*N+n
+  const int b = (int)(pt / N);
+  const float* cl = closeness + pt * 4;
+  const int* ix = index + pt * 4;
+  const float c0 = cl[0], c1 = cl[1], c2 = cl[2], c3 = cl[3];
+  const int i0 = ix[0], i1 = ix[1], i2 = ix[2], i3 = ix[3];
+  float* r1 = A1 + pt * A1_LD;
+  float* r2 = A2 + pt * 128;
+  {
+    const float* f = feat_d + (long)b * P * 128 + 2 * lane;
+    const float2 v0 = *reinterpret_cast<const float2*>(f + (long)i0 * 128), v1 = *reinterpret_cast<const float2*>(f + (long)i1 * 128);
+    const float2 v2 = *reinterpret_cast<const float2*>(f + (long)i2 * 128), v3 = *reinterpret_cast<const float2*>(f + (long)i3 * 128);
+    float2 o;
+    o.x = ((v0.x * c0 + v1.x * c1) + v2.x * c2) + v3.x * c3;
+    o.y = ((v0.y * c0 + v1.y * c1) + v2.y * c2) + v3.y * c3;
+    *reinterpret_cast<float2*>(r1 + 2 * lane) = o;
+  }
+  {
+    const float* f = feat_rgb + (long)b * P * 128 + 2 * lane;
+    const float2 v0 = *reinterpret_cast<const float2*>(f + (long)i0 * 128), v1 = *reinterpret_cast<const float2*>(f + (long)i1 * 128);
+    const float2 v2 = *reinterpret_cast<const float2*>(f + (long)i2 * 128), v3 = *reinterpret_cast<const float2*>(f + (long)i3 * 128);
+    float2 o;
+    o.x = ((v0.x * c0 + v1.x * c1) + v2.x * c2) + v3.x * c3;
+    o.y = ((v0.y * c0 + v1.y * c1) + v2.y * c2) + v3.y * c3;
+    *reinterpret_cast<float2*>(r2 + 2 * lane) = o;
+  }
+  const float* q = pcl + pt * 3;
+  const float qx = q[0], qy = q[1], qz = q[2];
+  if (lane < 3) r1[128 + lane] = q[lane];
+  if (lane < J) {
+    const float* w = offset + ((long)b * 5 * J + 4 * J + lane) * P;
+    r1[131 + lane] = ((w[i0] * c0 + w[i1] * c1) + w[i2] * c2) + w[i3] * c3;
+    const float* jp = joint_xyz + ((long)b * J + lane) * 3;
+    const float ox = jp[0] - qx, oy = jp[1] - qy, oz = jp[2] - qz;
+    const float dis = sqrtf((ox * ox + oy * oy) + oz * oz);
+    const float inv = dis + 1e-8f;
+    const float cls = (kernel - dis) / kernel;
+    const float mask = (cls >= 0.f ? 1.f : 0.f) * (qz < 0.99f ? 1.f : 0.f);
+    r1[152 + 3 * lane] = (ox / inv) * mask;
+    r1[152 + 3 * lane + 1] = (oy / inv) * mask;
+    r1[152 + 3 * lane + 2] = (oz / inv) * mask;
+    r1[152 + 3 * J + lane] = cls * mask;
+  }
+  if (lane < 4) r1[236 + lane] = 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// a11 (pool half): attention = softmax over the N points of the per-joint weight, joint_feat = attention @ pcl_feat
+// (model/model.py:319-320).  grid (J, B), 256 threads.  Output row of JA[b*J+j] = [joint_feat(128) | joint xyz(3) | 0].
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int JA_LD = 132;
+
+__global__ __launch_bounds__(256) void softmax_pool_kernel(const float* __restrict__ A1, const float* __restrict__ X,
+                                                           const float* __restrict__ joint_xyz, float* __restrict__ JA, int N) {
+  extern __shared__ __attribute__((aligned(16))) float att[];  // [N] + 4 + 128
+  float* red = att + N;
+  float* half = red + 4;
+  const int j = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const float* wcol = A1 + (long)b * N * A1_LD + 131 + j;
+  float lmax = -INFINITY;
+  for (int n = tid; n < N; n += 256) {
+    const float w = wcol[(long)n * A1_LD];
+    att[n] = w;
+    lmax = fmaxf(lmax, w);
+  }
+  const float mx = block_max(lmax, red);
+  float se = 0.f;
+  for (int n = tid; n < N; n += 256) {
+    const float e = expf(att[n] - mx);
+    att[n] = e;
+    se += e;
+  }
+  se = block_sum(se, red);
+  const float inv = 1.0f / se;
+  const int c = tid & 127, h = tid >> 7;
+  const float* xb = X + (long)b * N * 128 + c;
+  float acc = 0.f;
+  const int n0 = h * (N / 2), n1 = h ? N : N / 2;
+  for (int n = n0; n < n1; ++n) acc += (att[n] * inv) * xb[(long)n * 128];
+  if (h) half[c] = acc;
+  __syncthreads();
+  float* o = JA + ((long)b * J + j) * JA_LD;
+  if (!h) o[c] = acc + half[c];
+  if (tid < 3) o[128 + tid] = joint_xyz[((long)b * J + j) * 3 + tid];
+  if (tid == 3) o[131] = 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// a12 (search + gather half): pointnet2 ball query + grouping, one wave per (radius, joint).
+// Points = cat(pcl [N], joints [J]); features = cat(X [N][128], JF [J][128]).  For each query joint: first 64 point
+// indices in index order with d^2 < r^2 (wave ballot + prefix popcount keeps index order), unfilled slots repeat the first
+// hit.  Writes the GEMM operand rows  G[r][(b*J+j)*64 + s] = [ feat[idx]-feat_j (128) | (xyz[idx]-xyz_j)/r (3) | 0 ].
+// grid (B*J, 3).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int G_LD = 132;
+
+__global__ __launch_bounds__(64) void ball_group_kernel(const float* __restrict__ pcl, const float* __restrict__ joint_xyz,
+                                                        const float* __restrict__ X, const float* __restrict__ JF,
+                                                        float* __restrict__ G, int* __restrict__ idx_out, int N, int jf_ld, long g_stride,
+                                                        float r0, float r1, float r2) {
+  __shared__ int sidx[64];
+  const int lane = threadIdx.x;
+  const int bj = blockIdx.x, ri = blockIdx.y;
+  const int b = bj / J;
+  const float radius = ri == 0 ? r0 : (ri == 1 ? r1 : r2);
+  const float rad2 = radius * radius;
+  const float* qp = joint_xyz + (long)bj * 3;
+  const float qx = qp[0], qy = qp[1], qz = qp[2];
+  const int NT = N + J;
+  int cnt = 0;
+  sidx[lane] = 0;
+  __syncthreads();
+  for (int base = 0; base < NT && cnt < 64; base += 64) {
+    const int i = base + lane;
+    bool hit = false;
+    if (i < NT) {
+      const float* p = i < N ? pcl + ((long)b * N + i) * 3 : joint_xyz + ((long)b * J + (i - N)) * 3;
+      const float dx = qx - p[0], dy = qy - p[1], dz = qz - p[2];
+      const float d2 = (dx * dx + dy * dy) + dz * dz;
+      hit = d2 < rad2;
+    }
+    const unsigned long long m = __ballot(hit);
+    const int slot = cnt + __popcll(m & ((1ull << lane) - 1ull));
+    if (hit && slot < 64) sidx[slot] = i;
+    cnt += __popcll(m);
+  }
+  __syncthreads();
+  if (cnt > 64) cnt = 64;
+  const int first = sidx[0];
+  const int mine = lane < cnt ? sidx[lane] : first;
+  __syncthreads();
+  sidx[lane] = mine;
+  if (idx_out) idx_out[((long)ri * gridDim.x + bj) * 64 + lane] = mine;
+  __syncthreads();
+  const float2 fj = *reinterpret_cast<const float2*>(JF + (long)bj * jf_ld + 2 * lane);
+  float* gb = G + (long)ri * g_stride + (long)bj * 64 * G_LD;
+  for (int s = 0; s < 64; ++s) {
+    const int i = sidx[s];
+    const float* fp = i < N ? X + ((long)b * N + i) * 128 : JF + ((long)b * J + (i - N)) * jf_ld;
+    const float2 f = *reinterpret_cast<const float2*>(fp + 2 * lane);
+    float2 o;
+    o.x = f.x - fj.x;
+    o.y = f.y - fj.y;
+    *reinterpret_cast<float2*>(gb + (long)s * G_LD + 2 * lane) = o;
+    if (lane < 4) {
+      float v = 0.f;
+      if (lane < 3) {
+        const float* p = i < N ? pcl + ((long)b * N + i) * 3 : joint_xyz + ((long)b * J + (i - N)) * 3;
+        v = (p[lane] - qp[lane]) / radius;
+      }
+      gb[(long)s * G_LD + 128 + lane] = v;
+    }
+  }
+}
+
+// max over groups of `group` consecutive rows: in [rows*group][C] -> out slice (ld, coff) of [rows]
+__global__ __launch_bounds__(128) void group_max_kernel(const float* __restrict__ in, float* __restrict__ out, int group, int C,
+                                                        int out_ld, int out_coff) {
+  const long r = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float* p = in + r * group * C + c;
+    float m = -INFINITY;
+    for (int s = 0; s < group; ++s) m = fmaxf(m, p[(long)s * C]);
+    out[r * out_ld + out_coff + c] = m;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// a14 part 1: heat-map, geometry adjacency map, spatial attention and the gate (model/model.py:334-338).
+//   hm_j(p)  = exp(-(((x+.5-jx)/std)^2 + ((y+.5-jy)/std)^2) / (2 sigma^2))          util/generateFeature.py:584-600
+//   GAM_j(p) = 1 / (gamma * |img_xyz(p) - uvd2xyz(joint_j)|^2 + 1)                    dataloader/loader.py:791-819
+//   sw_j(p)  = sigmoid( SF[p][j] + sum_j' Wh[j][j'] hm_j'(p) + bias_j )               (SF = feature part of the 1x1 conv, a GEMM)
+//   g        = wd * GAM + (1 - wd) * sw ;  Gw[b][j][p] = g * w_fc[p]
+// grid (ceil(P/256), B).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void heat_gam_gate_kernel(const float* __restrict__ r3d, const float* __restrict__ img_xyz,
+                                                            const float* __restrict__ SF, int sf_ld, const float* __restrict__ Wh,
+                                                            const float* __restrict__ bias, const float* __restrict__ weight_dis,
+                                                            const float* __restrict__ wfc, const float* __restrict__ center,
+                                                            const float* __restrict__ M, const float* __restrict__ cube,
+                                                            const float* __restrict__ cam, float* __restrict__ sw_out,
+                                                            float* __restrict__ Gw, int F, float std_, float sigma, float gamma,
+                                                            float half_img, float flip) {
+  __shared__ float jht[J][2];
+  __shared__ float jxyz[J][3];
+  __shared__ float wh[J * J];
+  __shared__ float bs[J];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int P = F * F;
+  if (tid < J) {
+    const float* jp = r3d + ((long)b * J + tid) * 3;
+    jht[tid][0] = (jp[0] + 1.0f) / 2.0f * (float)F;
+    jht[tid][1] = (jp[1] + 1.0f) / 2.0f * (float)F;
+    const Cam c = load_cam(center, M, cube, cam, b);
+    float x, y, z;
+    uvd2xyz(c, jp[0], jp[1], jp[2], half_img, flip, x, y, z);
+    jxyz[tid][0] = x;
+    jxyz[tid][1] = y;
+    jxyz[tid][2] = z;
+    bs[tid] = bias[tid];
+  }
+  for (int i = tid; i < J * J; i += 256) wh[i] = Wh[i];
+  __syncthreads();
+  const int p = blockIdx.x * 256 + tid;
+  if (p >= P) return;
+  const int py = p / F, px = p - py * F;
+  const float mx = (float)px + 0.5f, my = (float)py + 0.5f;
+  const float* ip = img_xyz + ((long)b * P + p) * 3;
+  const float ix = ip[0], iy = ip[1], iz = ip[2];
+  float hm[J];
+  const float den = 2.0f * sigma * sigma;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const float ax = (mx - jht[j][0]) / std_, ay = (my - jht[j][1]) / std_;
+    hm[j] = expf(-(ax * ax + ay * ay) / den);
+  }
+  const float wd = 1.0f / (1.0f + expf(-weight_dis[0]));
+  const float fc = wfc[p];
+  const float* sf = SF + ((long)b * P + p) * sf_ld;
+#pragma unroll 1
+  for (int j = 0; j < J; ++j) {
+    float s = sf[j] + bs[j];
+#pragma unroll
+    for (int k = 0; k < J; ++k) s += wh[j * J + k] * hm[k];
+    const float sw = 1.0f / (1.0f + expf(-s));
+    const float dx = ix - jxyz[j][0], dy = iy - jxyz[j][1], dz = iz - jxyz[j][2];
+    const float dist = (dx * dx + dy * dy) + dz * dz;
+    const float gam = 1.0f / (gamma * dist + 1.0f);
+    const float g = wd * gam + (1.0f - wd) * sw;
+    sw_out[((long)b * J + j) * P + p] = sw;
+    Gw[((long)b * J + j) * P + p] = g * fc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// a14 part 2: img_feat_j[b][j][c] = sum_p Gw[b][j][p] * relu(feat[b][p][c]) + b_fc   (since the gate is >= 0,
+// relu(g*f) = g*relu(f): SURVEY a14), optionally relu((. + prev)/2) for block 2 (model/model.py:343-344).
+// grid (3, B): 7 joints per workgroup, 128 channels x 2 pixel halves.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gate_reduce_kernel(const float* __restrict__ Gw, const float* __restrict__ feat,
+                                                          const float* __restrict__ bfc, const float* __restrict__ prev,
+                                                          float* __restrict__ out, int P) {
+  __shared__ float part[7][128];
+  const int jc = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int c = tid & 127, h = tid >> 7;
+  const float* g = Gw + ((long)b * J + jc * 7) * P;
+  const float* f = feat + (long)b * P * 128 + c;
+  float acc[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) acc[j] = 0.f;
+  const int p0 = h * (P / 2), p1 = h ? P : P / 2;
+  for (int p = p0; p < p1; ++p) {
+    const float v = fmaxf(f[(long)p * 128], 0.f);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) acc[j] += g[(long)j * P + p] * v;
+  }
+  if (h) {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) part[j][c] = acc[j];
+  }
+  __syncthreads();
+  if (!h) {
+    const float bb = bfc[0];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      float v = (acc[j] + part[j][c]) + bb;
+      const long o = ((long)b * J + jc * 7 + j) * 128 + c;
+      if (prev) v = fmaxf((v + prev[o]) / 2.0f, 0.f);
+      out[o] = v;
+    }
+  }
+}
+
+}  // namespace
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int kpf_offset2joint_f32(const float* offset, const float* depth, const float* center, const float* M, const float* cube,
+                                    const float* cam, float* joint_uvd, float* joint_xyz, int B, int S, int F, float kernel,
+                                    int img_size, int flip, void* stream) {
+  KPF_REQUIRE(offset && depth && center && M && cube && cam && joint_uvd && joint_xyz && B > 0 && F > 0 && S >= F,
+              "kpf_offset2joint_f32: bad arguments");
+  hipLaunchKernelGGL(offset2joint_kernel, dim3(J, B), dim3(256), 0, ST(stream), offset, depth, center, M, cube, cam, joint_uvd,
+                     joint_xyz, S, F, kernel, (float)img_size / 2.0f, (float)flip);
+  return kpf_check_launch("kpf_offset2joint_f32");
+}
+
+extern "C" int kpf_img2pcl_top4_f32(const float* pcl, const float* depth, const float* center, const float* M, const float* cube,
+                                    const float* cam, float* closeness, int* index, float* img_xyz, int B, int N, int S, int F,
+                                    int img_size, int flip, void* stream) {
+  KPF_REQUIRE(pcl && depth && closeness && index && B > 0 && N > 0 && F * F >= 4 && F * F * 12 <= 64 * 1024,
+              "kpf_img2pcl_top4_f32: bad arguments");
+  hipLaunchKernelGGL(img2pcl_top4_kernel, dim3((N + 255) / 256, B), dim3(256), (size_t)F * F * 3 * sizeof(float), ST(stream), pcl,
+                     depth, center, M, cube, cam, closeness, index, img_xyz, N, S, F, (float)img_size / 2.0f, (float)flip);
+  return kpf_check_launch("kpf_img2pcl_top4_f32");
+}
+
+extern "C" int kpf_point_assemble_f32(const float* feat_d, const float* feat_rgb, const float* offset, const float* pcl,
+                                      const float* joint_xyz, const float* closeness, const int* index, float* A1, float* A2, int B,
+                                      int N, int P, float kernel, void* stream) {
+  KPF_REQUIRE(feat_d && feat_rgb && offset && pcl && joint_xyz && closeness && index && A1 && A2, "kpf_point_assemble_f32: null pointer");
+  KPF_REQUIRE(((long)B * N) % 4 == 0, "kpf_point_assemble_f32: B*N must be a multiple of 4");
+  hipLaunchKernelGGL(point_assemble_kernel, dim3((unsigned)((long)B * N / 4)), dim3(256), 0, ST(stream), feat_d, feat_rgb, offset, pcl,
+                     joint_xyz, closeness, index, A1, A2, N, P, kernel);
+  return kpf_check_launch("kpf_point_assemble_f32");
+}
+
+extern "C" int kpf_softmax_pool_f32(const float* A1, const float* X, const float* joint_xyz, float* JA, int B, int N, void* stream) {
+  KPF_REQUIRE(A1 && X && joint_xyz && JA && B > 0 && N > 1 && N % 2 == 0, "kpf_softmax_pool_f32: bad arguments");
+  hipLaunchKernelGGL(softmax_pool_kernel, dim3(J, B), dim3(256), (size_t)(N + 4 + 128) * sizeof(float), ST(stream), A1, X, joint_xyz,
+                     JA, N);
+  return kpf_check_launch("kpf_softmax_pool_f32");
+}
+
+extern "C" int kpf_ball_group_f32(const float* pcl, const float* joint_xyz, const float* X, const float* JF, int jf_ld, float* G,
+                                  int* idx_out, int B, int N, float r0, float r1, float r2, void* stream) {
+  KPF_REQUIRE(pcl && joint_xyz && X && JF && G && B > 0 && N > 0 && jf_ld >= 128 && jf_ld % 2 == 0, "kpf_ball_group_f32: bad arguments");
+  const long g_stride = (long)B * J * 64 * G_LD;
+  hipLaunchKernelGGL(ball_group_kernel, dim3(B * J, 3), dim3(64), 0, ST(stream), pcl, joint_xyz, X, JF, G, idx_out, N, jf_ld, g_stride,
+                     r0, r1, r2);
+  return kpf_check_launch("kpf_ball_group_f32");
+}
+
+extern "C" int kpf_group_max_f32(const float* in, float* out, long rows, int group, int C, int out_ld, int out_coff, void* stream) {
+  KPF_REQUIRE(in && out && rows > 0 && group > 0 && C > 0 && out_coff + C <= out_ld, "kpf_group_max_f32: bad arguments");
+  hipLaunchKernelGGL(group_max_kernel, dim3((unsigned)rows), dim3(128), 0, ST(stream), in, out, group, C, out_ld, out_coff);
+  return kpf_check_launch("kpf_group_max_f32");
+}
+
+extern "C" int kpf_heat_gam_gate_f32(const float* r3d, const float* img_xyz, const float* SF, int sf_ld, const float* Wh,
+                                     const float* bias, const float* weight_dis, const float* wfc, const float* center,
+                                     const float* M, const float* cube, const float* cam, float* sw_out, float* Gw, int B, int F,
+                                     int img_size, int flip, void* stream) {
+  KPF_REQUIRE(r3d && img_xyz && SF && Wh && bias && weight_dis && wfc && sw_out && Gw && B > 0, "kpf_heat_gam_gate_f32: null pointer");
+  hipLaunchKernelGGL(heat_gam_gate_kernel, dim3((F * F + 255) / 256, B), dim3(256), 0, ST(stream), r3d, img_xyz, SF, sf_ld, Wh, bias,
+                     weight_dis, wfc, center, M, cube, cam, sw_out, Gw, F, 0.8f, 1.0f, 10.0f, (float)img_size / 2.0f, (float)flip);
+  return kpf_check_launch("kpf_heat_gam_gate_f32");
+}
+
+extern "C" int kpf_gate_reduce_f32(const float* Gw, const float* feat, const float* bfc, const float* prev, float* out, int B, int P,
+                                   void* stream) {
+  KPF_REQUIRE(Gw && feat && bfc && out && B > 0 && P % 2 == 0, "kpf_gate_reduce_f32: bad arguments");
+  hipLaunchKernelGGL(gate_reduce_kernel, dim3(3, B), dim3(256), 0, ST(stream), Gw, feat, bfc, prev, out, P);
+  return kpf_check_launch("kpf_gate_reduce_f32");
+}

@@ -356,14 +356,182 @@ class UNetPlan:
         return res, feat
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# keypoint-fusion head
+# ----------------------------------------------------------------------------------------------------------------
+J = 21
+
+
+def _fold_emb(sd, p):
+    """Conv1d(k=1)+BatchNorm1d (model/model.py:254-259) as (W*s [128][Cin], b*s+t) in float64."""
+    s, t = bn_scale_shift(sd, p + ".1")
+    w = sd[p + ".0.weight"].double()[:, :, 0] * s[:, None]
+    return w, sd[p + ".0.bias"].double() * s + t
+
+
+def pack_tr(sd, p, din, device):
+    """Flat fp32 weight image of one KP_Interaction_TR for kpf_tr_encoder_f32 (layout: csrc/kpf_tr.hip)."""
+    g = lambda k: sd[p + "." + k].detach().float().cpu()
+    parts = [g("bert.img_embedding.weight").t().contiguous(), g("bert.img_embedding.bias"), g("bert.position_embeddings.weight")[:J]]
+    for l in range(4):
+        q = "bert.encoder.layer.%d." % l
+        wqkv = torch.cat([g(q + "attention.self.%s.weight" % n) for n in ("query", "key", "value")], 0)  # 384 x 128
+        bqkv = torch.cat([g(q + "attention.self.%s.bias" % n) for n in ("query", "key", "value")], 0)
+        parts += [wqkv.t().contiguous(), bqkv, g(q + "attention.output.dense.weight").t().contiguous(), g(q + "attention.output.dense.bias"),
+                  g(q + "attention.output.LayerNorm.weight"), g(q + "attention.output.LayerNorm.bias"),
+                  g(q + "intermediate.dense.weight").t().contiguous(), g(q + "intermediate.dense.bias"),
+                  g(q + "output.dense.weight").t().contiguous(), g(q + "output.dense.bias"),
+                  g(q + "output.LayerNorm.weight"), g(q + "output.LayerNorm.bias")]
+    parts += [g("cls_head.weight").t().contiguous(), g("cls_head.bias"), g("residual.weight").t().contiguous(), g("residual.bias")]
+    flat = torch.cat([x.reshape(-1) for x in parts])
+    assert flat.numel() == L.load().kpf_tr_encoder_weight_floats(din), (flat.numel(), din)
+    return flat.to(device)
+
+
+def pack_xattn(sd, p, device):
+    """Flat weight image of decoder layer `p` for kpf_xattn_layer_f32."""
+    g = lambda k: sd[p + "." + k].detach().float().cpu()
+    w, b = g("multihead_attn.in_proj_weight"), g("multihead_attn.in_proj_bias")
+    parts = [g("self_posembed.weight")[:J], g("cross_posembed.weight")[:J], w[:128].t().contiguous(), b[:128], w[128:].t().contiguous(), b[128:],
+             g("multihead_attn.out_proj.weight").t().contiguous(), g("multihead_attn.out_proj.bias"), g("norm2.weight"), g("norm2.bias"),
+             g("linear1.weight").t().contiguous(), g("linear1.bias"), g("linear2.weight").t().contiguous(), g("linear2.bias"),
+             g("norm3.weight"), g("norm3.bias")]
+    flat = torch.cat([x.reshape(-1) for x in parts])
+    assert flat.numel() == L.load().kpf_xattn_weight_floats()
+    return flat.to(device)
+
+
+class FusionBlockPlan:
+    """Block_KPFusion (model/model.py:207-351) in kernel layouts."""
+
+    def __init__(self, sd, p, device):
+        f64 = lambda k: sd[p + "." + k].double()
+        wf, bf = _fold_emb(sd, p + ".pcl_feat_emb")
+        wx, bx = _fold_emb(sd, p + ".pcl_xyz_emb")
+        wp, bp = _fold_emb(sd, p + ".pcl_pose_emb")
+        z4 = torch.zeros(128, 4, dtype=torch.float64, device=wf.device)
+        self.e_point = PackedConv(torch.cat([wf, wx, wp, z4], 1), bf + bx + bp, device)  # K = 128+3+105+4 = 240
+        wr, br = _fold_emb(sd, p + ".pcl_feat_emb_RGB")
+        self.e_rgb = PackedConv(wr, br, device)
+        wj, bj = _fold_emb(sd, p + ".joint_feat_emb")
+        wjx, bjx = _fold_emb(sd, p + ".joint_xyz_emb")
+        z1 = torch.zeros(128, 1, dtype=torch.float64, device=wf.device)
+        self.e_joint = PackedConv(torch.cat([wj, wjx, z1], 1), bj + bjx, device)  # K = 132
+        self.desa1, self.desa2 = [], []
+        fa = p + ".FA"
+        for i in range(3):
+            sl, tl = bn_scale_shift(sd, fa + ".bn_l0_blocks.%d" % i)
+            sf, tf = bn_scale_shift(sd, fa + ".bn_f0_blocks.%d" % i)
+            wl = sd[fa + ".conv_l0_blocks.%d.weight" % i].double()[:, :, 0, 0] * sl[:, None]
+            wfe = sd[fa + ".conv_f0_blocks.%d.weight" % i].double()[:, :, 0, 0] * sf[:, None]
+            b1 = sd[fa + ".conv_l0_blocks.%d.bias" % i].double() * sl + tl + sd[fa + ".conv_f0_blocks.%d.bias" % i].double() * sf + tf
+            self.desa1.append(PackedConv(torch.cat([wfe, wl, z1], 1), b1, device))  # rows of G: [feat 128 | xyz 3 | 0]
+            self.desa2.append(PackedConv(sd[fa + ".conv_blocks.%d.0.weight" % i], sd[fa + ".conv_blocks.%d.0.bias" % i], device,
+                                         fold_bn=bn_scale_shift(sd, fa + ".bn_blocks.%d.0" % i)))
+        self.desa_fusion = PackedConv(sd[fa + ".fusion.0.weight"], sd[fa + ".fusion.0.bias"], device, fold_bn=bn_scale_shift(sd, fa + ".fusion.1"))
+        self.init_tr = pack_tr(sd, p + ".init_TR", 128, device)
+        self.final_tr = pack_tr(sd, p + ".final_TR", 131, device)
+        self.xattn = pack_xattn(sd, p + ".crossTR.decoder.3", device)  # layers 0-2 never reach the output
+        wa = sd[p + ".atten_spatial.weight"].detach().float()[:, :, 0, 0]
+        self.att_feat = PackedConv(wa[:, :128].contiguous(), None, device)
+        self.att_wh = wa[:, 128:].contiguous().to(device)
+        self.att_b = sd[p + ".atten_spatial.bias"].detach().float().to(device)
+        self.wfc = sd[p + ".fc_spatial2joint_feature.weight"].detach().float().reshape(-1).contiguous().to(device)
+        self.bfc = sd[p + ".fc_spatial2joint_feature.bias"].detach().float().to(device)
+        self.weight_dis = sd[p + ".weight_dis"].detach().float().to(device)
+
+    def __call__(self, ctx, joint_xyz, prev):
+        """ctx: per-forward shared tensors (see ModelPlan.forward).  Returns (r3d, r2d, img_feat_j, spatial_weight)."""
+        lib = L.load()
+        dev, B, N, P, F = ctx["dev"], ctx["B"], ctx["N"], ctx["P"], ctx["F"]
+        st = _stream()
+        f32 = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        A1, A2 = f32(B * N, 240), f32(B * N, 128)
+        L.check(lib.kpf_point_assemble_f32(_ptr(ctx["feat_d"].buf), _ptr(ctx["feat_rgb"].buf), _ptr(ctx["img_offset"]), _ptr(ctx["pcl"]),
+                                           _ptr(joint_xyz), _ptr(ctx["closeness"]), _ptr(ctx["index"]), _ptr(A1), _ptr(A2), B, N, P,
+                                           ctx["kernel"], st), "kpf_point_assemble_f32")
+        rows = lambda t, c, ld=None: Act(t.view(-1), 1, 1, t.numel() // (ld or c), c, ld or c)
+        X = conv(self.e_point, rows(A1, 240), flags=L.KPF_ACT_RELU)
+        conv(self.e_rgb, rows(A2, 128), out=X, res=X, flags=L.KPF_RELU_AFTER_RES)
+        JA = f32(B * J, 132)
+        L.check(lib.kpf_softmax_pool_f32(_ptr(A1), _ptr(X.buf), _ptr(joint_xyz), _ptr(JA), B, N, st), "kpf_softmax_pool_f32")
+        DC = f32(B * J, 512)  # [r=0.1 | r=0.2 | r=0.4 | node_feat]
+        dc = rows(DC, 512)
+        JF = conv(self.e_joint, rows(JA, 132), out=dc.slice(384, 128), flags=L.KPF_ACT_RELU)
+        G = f32(3, B * J * 64, 132)
+        idx = torch.empty(3, B * J, 64, device=dev, dtype=torch.int32) if ctx.get("want_aux") else None
+        L.check(lib.kpf_ball_group_f32(_ptr(ctx["pcl"]), _ptr(joint_xyz), _ptr(X.buf), C.c_void_p(DC.data_ptr() + 384 * 4), 512, _ptr(G),
+                                       _ptr(idx), B, N, 0.1, 0.2, 0.4, st), "kpf_ball_group_f32")
+        for r in range(3):
+            y = conv(self.desa1[r], rows(G[r], 132), flags=L.KPF_ACT_RELU)
+            y = conv(self.desa2[r], y, flags=L.KPF_ACT_RELU)
+            L.check(lib.kpf_group_max_f32(_ptr(y.buf), _ptr(DC), B * J, 64, 128, 512, r * 128, st), "kpf_group_max_f32")
+        D = conv(self.desa_fusion, dc, flags=L.KPF_ACT_RELU)  # B*J x 128
+        h_init, r3d = f32(B, J, 128), f32(B, J, 3)
+        FA = f32(B * J, 132)  # final_TR input rows: [r3d 3 | decoder out 128 | pad]
+        L.check(lib.kpf_tr_encoder_f32(_ptr(D.buf), 128, 128, _ptr(self.init_tr), _ptr(h_init), _ptr(r3d), _ptr(FA), 132, B, st),
+                "kpf_tr_encoder_f32")
+        SF = Act(f32(B * P * 24), 1, 1, B * P, J, 24)
+        conv(self.att_feat, ctx["feat_rgb_rows"], out=SF)
+        sw, Gw = f32(B, J, F, F), f32(B, J, P)
+        L.check(lib.kpf_heat_gam_gate_f32(_ptr(r3d), _ptr(ctx["img_xyz"]), _ptr(SF.buf), 24, _ptr(self.att_wh), _ptr(self.att_b),
+                                          _ptr(self.weight_dis), _ptr(self.wfc), _ptr(ctx["center"]), _ptr(ctx["M"]), _ptr(ctx["cube"]),
+                                          _ptr(ctx["cam"]), _ptr(sw), _ptr(Gw), B, F, ctx["img_size"], ctx["flip"], st), "kpf_heat_gam_gate_f32")
+        fj = f32(B, J, 128)
+        L.check(lib.kpf_gate_reduce_f32(_ptr(Gw), _ptr(ctx["feat_rgb"].buf), _ptr(self.bfc), _ptr(prev), _ptr(fj), B, P, st),
+                "kpf_gate_reduce_f32")
+        L.check(lib.kpf_xattn_layer_f32(_ptr(fj), _ptr(h_init), _ptr(self.xattn), _ptr(FA), 132, 3, B, st), "kpf_xattn_layer_f32")
+        h_fin, r2d = f32(B, J, 128), f32(B, J, 3)
+        L.check(lib.kpf_tr_encoder_f32(_ptr(FA), 132, 131, _ptr(self.final_tr), _ptr(h_fin), _ptr(r2d), None, 0, B, st), "kpf_tr_encoder_f32")
+        if ctx.get("want_aux"):
+            ctx.setdefault("aux", []).append(dict(X=X.buf.view(B, N, 128), A1=A1.view(B, N, 240), JA=JA.view(B, J, 132), D=D.buf.view(B, J, 128),
+                                                  ball_idx=idx, h_init=h_init, fj=fj, dec=FA.view(B, J, 132)[:, :, 3:131], Gw=Gw))
+        return r3d, r2d, fj, sw
+
+
 class ModelPlan:
-    """All kernel-layout weights of one KPFusion instance on one device."""
+    """All kernel-layout weights of one KPFusion instance on one device, and the forward schedule
+    (model/model.py:395-426)."""
 
     def __init__(self, sd, net, device):
         self.net, self.device = net, device
         self.backbone_d = UNetPlan(sd, "backbone_d", net, device)
         self.backbone_rgb = UNetPlan(sd, "backbone_rgb", net, device)
-        self.sd = sd
+        self.blocks = [FusionBlockPlan(sd, "block%d" % i, device) for i in (1, 2)]
 
-    def forward(self, img_rgb, img, pcl, center, M, cube, cam, kernel, img_size, flip):
-        raise NotImplementedError("fusion head kernels not built yet")
+    def forward(self, img_rgb, img, pcl, center, M, cube, cam, kernel, img_size, flip, want_aux=False):
+        lib = L.load()
+        dev = self.device
+        B, _, S, _ = img.shape
+        N = pcl.shape[1]
+        prep = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        img, img_rgb, pcl, center, M, cube, cam = map(prep, (img, img_rgb, pcl, center, M, cube, cam))
+        img_offset, feat_d = self.backbone_d(img)
+        img_offset_rgb, feat_rgb = self.backbone_rgb(img_rgb)
+        F = feat_d.H
+        P = F * F
+        st = _stream()
+        f32 = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        joint_uvd, joint_xyz = f32(B, J, 3), f32(B, J, 3)
+        L.check(lib.kpf_offset2joint_f32(_ptr(img_offset), _ptr(img), _ptr(center), _ptr(M), _ptr(cube), _ptr(cam), _ptr(joint_uvd),
+                                         _ptr(joint_xyz), B, S, F, kernel, img_size, flip, st), "kpf_offset2joint_f32")
+        closeness, img_xyz = f32(B, N, 4), f32(B, P, 3)
+        index = torch.empty(B, N, 4, device=dev, dtype=torch.int32)
+        L.check(lib.kpf_img2pcl_top4_f32(_ptr(pcl), _ptr(img), _ptr(center), _ptr(M), _ptr(cube), _ptr(cam), _ptr(closeness), _ptr(index),
+                                         _ptr(img_xyz), B, N, S, F, img_size, flip, st), "kpf_img2pcl_top4_f32")
+        ctx = dict(dev=dev, B=B, N=N, P=P, F=F, kernel=kernel, img_size=img_size, flip=flip, feat_d=feat_d, feat_rgb=feat_rgb,
+                   feat_rgb_rows=Act(feat_rgb.buf, 1, 1, B * P, 128), img_offset=img_offset, pcl=pcl, closeness=closeness, index=index,
+                   img_xyz=img_xyz, center=center, M=M, cube=cube, cam=cam, want_aux=want_aux)
+        result = [img_offset, img_offset_rgb]
+        sws = []
+        prev = None
+        jx = joint_xyz
+        for blk in self.blocks:
+            r3d, r2d, prev, sw = blk(ctx, jx, prev)
+            result += [r3d, r2d]
+            sws.append(sw)
+            jx = r2d
+        if want_aux:
+            ctx.update(joint_uvd=joint_uvd, joint_xyz0=joint_xyz)
+            return result, sws, ctx
+        return result, sws, None

@@ -32,6 +32,18 @@ _SIGS = {
     "kpf_nchw_to_nhwc_f32": [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P],
     "kpf_nhwc_to_nchw_f32": [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P],
     "kpf_maxpool3x3s2_f32": [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_offset2joint_f32": [_P] * 8 + [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, _P],
+    "kpf_img2pcl_top4_f32": [_P] * 9 + [C.c_int] * 6 + [_P],
+    "kpf_point_assemble_f32": [_P] * 9 + [C.c_int, C.c_int, C.c_int, C.c_float, _P],
+    "kpf_softmax_pool_f32": [_P, _P, _P, _P, C.c_int, C.c_int, _P],
+    "kpf_ball_group_f32": [_P, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _P],
+    "kpf_group_max_f32": [_P, _P, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_heat_gam_gate_f32": [_P, _P, _P, C.c_int] + [_P] * 10 + [C.c_int] * 4 + [_P],
+    "kpf_gate_reduce_f32": [_P, _P, _P, _P, _P, C.c_int, C.c_int, _P],
+    "kpf_tr_encoder_f32": [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, _P],
+    "kpf_xattn_layer_f32": [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_tr_encoder_weight_floats": [C.c_int],
+    "kpf_xattn_weight_floats": [],
 }
 EXPORTS = sorted(list(_SIGS) + ["kpf_last_error", "kpf_abi_version"])
 

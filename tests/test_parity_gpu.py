@@ -205,3 +205,177 @@ def test_backbones_match_oracle(net, B, S):
         z = np.load(os.path.join(GOLDEN, "backbone_%s_B1_S64.npz" % net))
         assert rel_err(out[0], torch.from_numpy(z["img_offset"])) < 1e-3
         assert rel_err(out[2], torch.from_numpy(z["img_offset_rgb"])) < 1e-3
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# fusion head
+# ----------------------------------------------------------------------------------------------------------------
+def _run_full(net, B):
+    from oracle import kpf_oracle as O
+    sd = synthetic_sd("KPFusion-" + net)
+    b = {k: torch.from_numpy(v) for k, v in synthetic_batch(B, 128, seed=1).items()}
+    aux = {}
+    ref, rsw = O.kpfusion_forward(sd, b["img_rgb"], b["img"], b["pcl"], b["center"], b["M"], b["cube"], b["cam_para"], 0.8, aux=aux)
+    m = _model(net)
+    dev = _dev()
+    plan = m._plan(dev)
+    with torch.no_grad():
+        out, sws, ctx = plan.forward(b["img_rgb"].to(dev), b["img"].to(dev), b["pcl"].to(dev), b["center"].to(dev), b["M"].to(dev),
+                                     b["cube"].to(dev), b["cam_para"].to(dev), 0.8, 128, 1, want_aux=True)
+    torch.cuda.synchronize()
+    return b, ref, rsw, aux, out, sws, ctx
+
+
+@pytest.mark.parametrize("net", ["convnext-tiny", "resnet-18"])
+def test_full_forward_matches_oracle(net):
+    B = 2
+    b, ref, rsw, aux, out, sws, ctx = _run_full(net, B)
+    # geometry front end
+    assert rel_err(ctx["joint_uvd"], aux["joint_uvd"]) < 1e-4
+    assert rel_err(ctx["joint_xyz0"], aux["joint_xyz0"]) < 1e-4
+    # top-4 pixel indices: bit-exact, except where the oracle itself has a near-tie between consecutive ranks
+    img_xyz = O_img_xyz(aux, b)
+    dist = torch.sum(torch.pow(b["pcl"].unsqueeze(2) - img_xyz.unsqueeze(1), 2), dim=-1)
+    top5 = torch.topk(dist, 5, largest=False)[0]
+    gap = ((top5[..., 1:] - top5[..., :-1]) / (top5[..., 1:] + 1e-12)).min(-1)[0]  # smallest relative gap among ranks 1..5
+    idx_gpu = ctx["index"].cpu().long()
+    mism = (idx_gpu != aux["pcl_index"]).any(-1)
+    assert not bool((mism & (gap > 1e-4)).any()), "top-4 indices differ away from ties: %d points" % int((mism & (gap > 1e-4)).sum())
+    assert float(mism.float().mean()) < 0.01
+    ok = ~mism
+    assert rel_err(ctx["closeness"].cpu()[ok], aux["pcl_closeness"][ok]) < 1e-3
+    # per-block intermediates and outputs
+    for i in (0, 1):
+        a, g = aux["block%d" % (i + 1)], ctx["aux"][i]
+        assert rel_err(g["X"], a["pcl_feat"]) < 1e-3, "point features block %d" % (i + 1)
+        assert rel_err(g["D"], a["joint_feat_desa"]) < 2e-3, "DESA block %d" % (i + 1)
+        assert rel_err(g["h_init"], a["h_init"]) < 2e-3
+        assert rel_err(g["dec"], a["dec"]) < 2e-3
+    names = ["img_offset", "img_offset_rgb", "r3d1", "r2d1", "r3d2", "r2d2"]
+    for o, r, n in zip(out, ref, names):
+        e = rel_err(o, r)
+        assert e < 1e-3, "%s rel err %.2e" % (n, e)
+    for o, r in zip(sws, rsw):
+        assert rel_err(o, r) < 1e-3
+    # north_star accuracy bound: joints within 0.05 mm of the reference path (cube 250 mm => x * 125 mm)
+    for k in range(2, 6):
+        mm = float((out[k].cpu() - ref[k]).abs().max()) * 125.0
+        assert mm < 0.05, "%s deviates %.4f mm" % (names[k], mm)
+    # "argmax indices" (SURVEY D7): bit-exact argmax of masked weight logits and of the spatial weights
+    d = F.interpolate(b["img"], [32, 32])
+    for o, r in ((out[0], ref[0]), (out[1], ref[1])):
+        wg = o.cpu()[:, 84:].masked_fill(d > 0.99, -1e8).reshape(B, 21, -1)
+        wr = r[:, 84:].masked_fill(d > 0.99, -1e8).reshape(B, 21, -1)
+        top2 = torch.topk(wr, 2, -1)[0]
+        decided = (top2[..., 0] - top2[..., 1]) > 1e-3
+        assert bool((wg.argmax(-1) == wr.argmax(-1))[decided].all())
+    for o, r in zip(sws, rsw):
+        og, rr = o.cpu().reshape(B, 21, -1), r.reshape(B, 21, -1)
+        top2 = torch.topk(rr, 2, -1)[0]
+        decided = (top2[..., 0] - top2[..., 1]) > 1e-4
+        assert bool((og.argmax(-1) == rr.argmax(-1))[decided].all())
+
+
+def O_img_xyz(aux, b):
+    from oracle import kpf_oracle as O
+    return O.img_xyz_grid(aux["img_down"], b["center"], b["M"], b["cube"], b["cam_para"])
+
+
+def test_ball_group_bit_exact_on_identical_inputs():
+    """Ball query indices are integer work: with identical fp32 inputs the HIP kernel must reproduce the oracle exactly
+    (empty, partially filled and saturated neighbourhoods all occur at these radii), and the grouped operand rows too."""
+    import ctypes as C
+    from keypointfusion_amd import engine as E, lib as L
+    from oracle import kpf_oracle as O
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    B, N = 3, 1024
+    pcl = (torch.rand(B, N, 3, generator=g) * 1.6 - 0.8)
+    joints = (torch.rand(B, 21, 3, generator=g) * 1.6 - 0.8)
+    joints[0, 0] = 5.0  # isolated query: finds only itself
+    X = torch.randn(B, N, 128, generator=g)
+    JF = torch.randn(B, 21, 128, generator=g)
+    xyz = torch.cat((pcl, joints), 1)
+    feat = torch.cat((X, JF), 1)
+    G = torch.empty(3, B * 21 * 64, 132, device=dev)
+    idx = torch.empty(3, B * 21, 64, device=dev, dtype=torch.int32)
+    d = [t.to(dev) for t in (pcl, joints, X, JF)]
+    L.check(L.load().kpf_ball_group_f32(E._ptr(d[0]), E._ptr(d[1]), E._ptr(d[2]), E._ptr(d[3]), 128, E._ptr(G), E._ptr(idx), B, N,
+                                        0.1, 0.2, 0.4, E._stream()))
+    torch.cuda.synchronize()
+    fills = []
+    for ri, r in enumerate((0.1, 0.2, 0.4)):
+        ref = O.ball_query(r, 64, xyz, joints)
+        got = idx[ri].cpu().long().view(B, 21, 64)
+        assert torch.equal(got, ref), "radius %g: %d index mismatches" % (r, int((got != ref).sum()))
+        fills.append(int((ref != ref[..., :1]).any(-1).sum()))
+        flat = ref.reshape(B, -1)
+        gx = (torch.gather(xyz, 1, flat.unsqueeze(-1).expand(-1, -1, 3)).view(B, 21, 64, 3) - joints.unsqueeze(2)) / r
+        gf = torch.gather(feat, 1, flat.unsqueeze(-1).expand(-1, -1, 128)).view(B, 21, 64, 128) - JF.unsqueeze(2)
+        rows = G[ri].cpu().view(B, 21, 64, 132)
+        assert torch.equal(rows[..., :128], gf)
+        assert rel_err(rows[..., 128:131], gx) < 1e-6
+        assert float(rows[..., 131].abs().max()) == 0.0
+    assert int(idx[0].cpu().view(B, 21, 64)[0, 0].unique().numel()) == 1  # the isolated query holds its own index 64 times
+
+
+def test_top4_bit_exact_on_identical_inputs():
+    """img2pcl_index: same pixel positions in, same integer indices out (ties aside) — checked with the positions the kernel
+    itself produced, so only the search is under test."""
+    from keypointfusion_amd import engine as E, lib as L
+    dev = _dev()
+    b = {k: torch.from_numpy(v) for k, v in synthetic_batch(2, 128, seed=5).items()}
+    B, N = 2, 1024
+    d = {k: v.to(dev) for k, v in b.items()}
+    clos = torch.empty(B, N, 4, device=dev)
+    idx = torch.empty(B, N, 4, device=dev, dtype=torch.int32)
+    ixyz = torch.empty(B, 1024, 3, device=dev)
+    L.check(L.load().kpf_img2pcl_top4_f32(E._ptr(d["pcl"]), E._ptr(d["img"]), E._ptr(d["center"]), E._ptr(d["M"]), E._ptr(d["cube"]),
+                                          E._ptr(d["cam_para"]), E._ptr(clos), E._ptr(idx), E._ptr(ixyz), B, N, 128, 32, 128, 1, E._stream()))
+    torch.cuda.synchronize()
+    px = ixyz.cpu()
+    dist = torch.sum(torch.pow(b["pcl"].unsqueeze(2) - px.unsqueeze(1), 2), dim=-1)
+    val, ref = torch.topk(dist, 4, largest=False)
+    got = idx.cpu().long()
+    # distances of the chosen pixels must be exactly the 4 smallest, in ascending order (robust to exact ties in index)
+    assert torch.equal(torch.gather(dist, 2, got), val)
+    c = 1 / (val + 1e-8)
+    assert rel_err(clos, c / (c.sum(-1, keepdim=True) + 1e-8)) < 1e-6
+
+
+def test_module_boundary_forward_signature_and_errors():
+    """The nn.Module boundary: reference call signature (with a `loader` object), return structure, state-dict reload,
+    the reference's own failure at S != 128, and a loud error instead of a CPU fallback."""
+    from oracle import kpf_oracle as O
+    net = "convnext-tiny"
+    m = _model(net)
+    dev = _dev()
+    b = {k: torch.from_numpy(v) for k, v in synthetic_batch(1, 128, seed=2).items()}
+
+    class Loader:
+        img_size, flip = 128, 1
+
+    args = [b[k].to(dev) for k in ("img_rgb", "img", "pcl")] + [Loader()] + [b[k].to(dev) for k in ("center", "M", "cube", "cam_para")]
+    with torch.no_grad():
+        res, sws, none = m(*args, 0.8)
+    assert none is None and len(res) == 6 and len(sws) == 2
+    assert [tuple(t.shape) for t in res] == [(1, 105, 32, 32)] * 2 + [(1, 21, 3)] * 4
+    assert [tuple(t.shape) for t in sws] == [(1, 21, 32, 32)] * 2
+    assert all(t.is_cuda and t.dtype == torch.float32 for t in res + sws)
+    sd = synthetic_sd("KPFusion-" + net)
+    ref, _ = O.kpfusion_forward(sd, b["img_rgb"], b["img"], b["pcl"], b["center"], b["M"], b["cube"], b["cam_para"], 0.8)
+    assert rel_err(res[5], ref[5]) < 1e-3
+    # a checkpoint in the reference's format ({"model": sd} with "module." keys, loaded by intersection: train.py:100-107)
+    ck = {"module." + k: v * 0.5 if k.endswith("finals.0.weight") else v for k, v in sd.items()}
+    own = m.state_dict()
+    inter = {k[len("module."):]: v for k, v in ck.items() if k[len("module."):] in own}
+    own.update(inter)
+    m.load_state_dict(own)
+    with torch.no_grad():
+        res2, _, _ = m(*args, 0.8)
+    assert rel_err(res2[0][:, :63], ref[0][:, :63] * 0.5) < 2e-3  # repacked after load_state_dict (halved head weights+bias term)
+    with pytest.raises(RuntimeError):
+        m(b["img_rgb"], b["img"], b["pcl"], Loader(), b["center"], b["M"], b["cube"], b["cam_para"], 0.8)  # CPU tensors
+    big = {k: torch.from_numpy(v).to(dev) for k, v in synthetic_batch(1, 256, seed=2).items()}
+    with pytest.raises(RuntimeError):
+        m(big["img_rgb"], big["img"], big["pcl"], Loader(), big["center"], big["M"], big["cube"], big["cam_para"], 0.8)
