@@ -210,12 +210,10 @@ def test_backbones_match_oracle(net, B, S):
 # ----------------------------------------------------------------------------------------------------------------
 # fusion head
 # ----------------------------------------------------------------------------------------------------------------
-def _run_full(net, B):
-    from oracle import kpf_oracle as O
+def _run_full(net, B, seed=1):
+    from oracle.compare import oracle_with_device_decisions
     sd = synthetic_sd("KPFusion-" + net)
-    b = {k: torch.from_numpy(v) for k, v in synthetic_batch(B, 128, seed=1).items()}
-    aux = {}
-    ref, rsw = O.kpfusion_forward(sd, b["img_rgb"], b["img"], b["pcl"], b["center"], b["M"], b["cube"], b["cam_para"], 0.8, aux=aux)
+    b = {k: torch.from_numpy(v) for k, v in synthetic_batch(B, 128, seed=seed).items()}
     m = _model(net)
     dev = _dev()
     plan = m._plan(dev)
@@ -223,28 +221,20 @@ def _run_full(net, B):
         out, sws, ctx = plan.forward(b["img_rgb"].to(dev), b["img"].to(dev), b["pcl"].to(dev), b["center"].to(dev), b["M"].to(dev),
                                      b["cube"].to(dev), b["cam_para"].to(dev), 0.8, 128, 1, want_aux=True)
     torch.cuda.synchronize()
-    return b, ref, rsw, aux, out, sws, ctx
+    ref, rsw, aux, report = oracle_with_device_decisions(sd, b, ctx)
+    return b, ref, rsw, aux, out, sws, ctx, report
 
 
-@pytest.mark.parametrize("net", ["convnext-tiny", "resnet-18"])
-def test_full_forward_matches_oracle(net):
-    B = 2
-    b, ref, rsw, aux, out, sws, ctx = _run_full(net, B)
-    # geometry front end
+@pytest.mark.parametrize("net,B,seed", [("convnext-tiny", 2, 1), ("resnet-18", 2, 1), ("convnext-tiny", 1, 1), ("convnext-tiny", 3, 7)])
+def test_full_forward_matches_oracle(net, B, seed):
+    """End-to-end: all 6 results and both spatial weights within 1e-3 relative of the oracle, joints within 0.05 mm.
+    Integer decisions (top-4 pixels, ball-query sets) must equal the oracle's except at fp32 near-ties of the oracle's own
+    distances (checked inside oracle_with_device_decisions, which then compares the rest of the pipeline on equal decisions)."""
+    b, ref, rsw, aux, out, sws, ctx, report = _run_full(net, B, seed)
+    assert report["top4_flips"] <= 0.005 * B * 1024 and report["ball_flips"] <= 2 * B, report
     assert rel_err(ctx["joint_uvd"], aux["joint_uvd"]) < 1e-4
     assert rel_err(ctx["joint_xyz0"], aux["joint_xyz0"]) < 1e-4
-    # top-4 pixel indices: bit-exact, except where the oracle itself has a near-tie between consecutive ranks
-    img_xyz = O_img_xyz(aux, b)
-    dist = torch.sum(torch.pow(b["pcl"].unsqueeze(2) - img_xyz.unsqueeze(1), 2), dim=-1)
-    top5 = torch.topk(dist, 5, largest=False)[0]
-    gap = ((top5[..., 1:] - top5[..., :-1]) / (top5[..., 1:] + 1e-12)).min(-1)[0]  # smallest relative gap among ranks 1..5
-    idx_gpu = ctx["index"].cpu().long()
-    mism = (idx_gpu != aux["pcl_index"]).any(-1)
-    assert not bool((mism & (gap > 1e-4)).any()), "top-4 indices differ away from ties: %d points" % int((mism & (gap > 1e-4)).sum())
-    assert float(mism.float().mean()) < 0.01
-    ok = ~mism
-    assert rel_err(ctx["closeness"].cpu()[ok], aux["pcl_closeness"][ok]) < 1e-3
-    # per-block intermediates and outputs
+    assert rel_err(ctx["closeness"], aux["pcl_closeness"]) < 1e-3
     for i in (0, 1):
         a, g = aux["block%d" % (i + 1)], ctx["aux"][i]
         assert rel_err(g["X"], a["pcl_feat"]) < 1e-3, "point features block %d" % (i + 1)
@@ -366,14 +356,17 @@ def test_module_boundary_forward_signature_and_errors():
     ref, _ = O.kpfusion_forward(sd, b["img_rgb"], b["img"], b["pcl"], b["center"], b["M"], b["cube"], b["cam_para"], 0.8)
     assert rel_err(res[5], ref[5]) < 1e-3
     # a checkpoint in the reference's format ({"model": sd} with "module." keys, loaded by intersection: train.py:100-107)
-    ck = {"module." + k: v * 0.5 if k.endswith("finals.0.weight") else v for k, v in sd.items()}
+    sd2 = {k: (v * 0.5 if k == "backbone_d.finals.0.weight" else v) for k, v in sd.items()}
+    ck = {"module." + k: v for k, v in sd2.items()}
     own = m.state_dict()
     inter = {k[len("module."):]: v for k, v in ck.items() if k[len("module."):] in own}
     own.update(inter)
     m.load_state_dict(own)
     with torch.no_grad():
         res2, _, _ = m(*args, 0.8)
-    assert rel_err(res2[0][:, :63], ref[0][:, :63] * 0.5) < 2e-3  # repacked after load_state_dict (halved head weights+bias term)
+    with torch.no_grad():
+        ref2 = O.unet(sd2, "backbone_d", b["img"])[0]
+    assert rel_err(res2[0], ref2) < 1e-3 and rel_err(res2[0], ref[0]) > 1e-2  # weights were repacked after load_state_dict
     with pytest.raises(RuntimeError):
         m(b["img_rgb"], b["img"], b["pcl"], Loader(), b["center"], b["M"], b["cube"], b["cam_para"], 0.8)  # CPU tensors
     big = {k: torch.from_numpy(v).to(dev) for k, v in synthetic_batch(1, 256, seed=2).items()}
