@@ -1,0 +1,110 @@
+"""CPU tests of the host side: C-ABI library exports, data-parallel sharding over gloo (world_size 2), synthetic data."""
+import ctypes
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, synthetic_sd
+from keypointfusion_amd import lib as L
+from keypointfusion_amd.parallel import shard_bounds, shard_batch, gather_outputs, max_over_ranks
+from keypointfusion_amd.weights import synthetic_batch
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    """include/kpf.h is the contract: every function it declares must be exported by libkpf_hip.so (no compute calls)."""
+    hdr = open(os.path.join(ROOT, "include", "kpf.h")).read()
+    declared = set(re.findall(r"\b(kpf_[a-z0-9_]+)\s*\(", hdr)) - {"kpf_conv_desc"}
+    assert len(declared) >= 19
+    lib = ctypes.CDLL(L.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libkpf_hip.so does not export %s" % name
+    assert set(L.EXPORTS) == declared, (sorted(declared - set(L.EXPORTS)), sorted(set(L.EXPORTS) - declared))
+    l = L.load()
+    assert l.kpf_abi_version() >= 1
+    assert l.kpf_tr_encoder_weight_floats(128) == 128 * 128 + 128 + 21 * 128 + 4 * (128 * 384 + 384 + 128 * 128 + 128 * 6 + 128 * 16 + 16 + 16 * 128) + 128 * 3 + 3 + 128 * 3 + 3
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(L.KpfError):
+        L.load()
+
+
+def test_model_refuses_cpu_tensors():
+    from keypointfusion_amd.model.model import KPFusion
+    m = KPFusion("KPFusion-resnet-18", "", 21, "dexycb", "")
+    b = {k: torch.from_numpy(v) for k, v in synthetic_batch(1, 128).items()}
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(b["img_rgb"], b["img"], b["pcl"], None, b["center"], b["M"], b["cube"], b["cam_para"])
+    with pytest.raises(KeyError):
+        KPFusion("KPFusion-convnext-T", "", 21, "dexycb", "")  # the reference's own failure for this spelling
+
+
+def test_shard_bounds_partition():
+    for n in (1, 2, 7, 64, 65):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        from oracle import kpf_oracle as O
+        sd = synthetic_sd("KPFusion-resnet-18")
+        full = {k: torch.from_numpy(v) for k, v in synthetic_batch(n, 64, seed=3).items()}
+        mine = shard_batch(full, rank, world)
+        # the per-rank "model" here is the CPU oracle's backbone: the sharding/gather logic is what is under test
+        od, fd, orgb, frgb = O.backbones_forward(sd, mine["img_rgb"], mine["img"])
+        g = gather_outputs([od, orgb], n, dist)
+        t = max_over_ranks(1.0 + rank, torch.device("cpu"), dist)
+        if rank == 0:
+            ref = O.backbones_forward(sd, full["img_rgb"], full["img"])
+            q.put((float((g[0] - ref[0]).abs().max()), float((g[1] - ref[2]).abs().max()), tuple(g[0].shape), t))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_shards_and_gather_gloo_world2():
+    """N>1 path on CPU: 2 ranks, ragged split of 3 samples, gathered outputs equal the unsharded forward."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, 3, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    e0, e1, shape, t = q.get(timeout=10)
+    assert shape == (3, 105, 16, 16)
+    assert e0 < 1e-5 and e1 < 1e-5  # batch-size dependent conv algorithms may differ in the last bits
+    assert t == 2.0
+
+
+def test_synthetic_batch_is_geometrically_consistent():
+    b = synthetic_batch(2, 128, seed=1)
+    assert b["img"].shape == (2, 1, 128, 128) and b["pcl"].shape == (2, 1024, 3)
+    assert float(np.abs(b["pcl"]).max()) < 1.0  # back-projected foreground pixels fall inside the cube
+    fg = b["img"] < 0.99
+    assert 0.35 < fg.mean() < 0.55 and float(b["img"][~fg].min()) == 1.0
