@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkpf_hip.so")
+LIB_PATH = os.environ.get("KPF_LIB_PATH") or os.path.join(_HERE, "libkpf_hip.so")  # override: A/B builds while tuning
 
 KPF_ACT_RELU = 1
 KPF_ACT_GELU = 2

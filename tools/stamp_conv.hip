@@ -4,29 +4,28 @@
 //             k = (ky,kx,c) with the input channel c fastest (activations are NHWC, so k-runs are contiguous).
 //
 // MI355X mapping
-//  * One workgroup = 4 (or 8) waves computes a BM x BN tile, BM = 16*TM*WM pixels, BN = 16*TN*WN channels; each wave owns
-//    TM x TN accumulator tiles of 16x16 (TM*TN*4 registers).  f32-input MFMA runs at the f32 vector rate (157 TF peak, 1/16
-//    of bf16), so the kernel is MFMA-issue bound by construction; everything else is arranged to stay out of its way.
-//  * Staging is LDS-DMA (global_load_lds_dwordx4): every wave moves 8 rows x 128 B per instruction straight into LDS, no VGPR
-//    round trip and no ds_write.  Two LDS buffers: the DMA of K-tile k+1 is issued before the MFMAs of tile k and lands
-//    under them; one barrier per K tile.  A 128x128 tile takes 64 KB, so two workgroups share a CU: one's DMA issue (the
-//    CU's address unit moves 64 B/clk, ~500 cycles per 32 KB tile), pipeline fill and epilogue run under the other's MFMAs.
-//    Measured alternatives (round 1): register staging + 2 barriers 84 TF on the model's shapes; a dedicated loader wave
-//    with a 3-deep ring was latency-bound on its single instruction stream (MFMA waves waited ~1000 of 5400 cycles/tile).
+//  * One workgroup = 4 waves (256 threads) computes a BM x BN tile, BM = 16*TM*WM pixels, BN = 16*TN*WN channels;
+//    each wave owns TM x TN accumulator tiles of 16x16 (TM*TN*4 VGPRs).  f32 MFMA runs at the f32 vector rate
+//    (157 TF peak), i.e. 16x slower than bf16 MFMA, so the kernel is MFMA-issue bound by construction and the design
+//    goal is simply to never starve the matrix pipe: operands are staged global -> registers -> LDS one K-tile
+//    ahead (the loads fly under the current tile's MFMAs), and 2-3 workgroups per CU cover barrier bubbles and the
+//    epilogue VALU work (GELU) of their neighbours.
 //  * The MFMA is issued "transposed": A-operand = weight fragment W[n][k], B-operand = activation fragment X[m][k], so
 //    a lane's 4 accumulator registers are 4 *consecutive output channels* of one pixel -> the epilogue reads bias /
 //    gamma / residual and writes the result as float4 (16 B per lane, 64 B contiguous per pixel per instruction).
-//  * LDS images are [row][32 k] fp32 with the 16-byte chunk index XOR-swizzled by (row & 7) (applied on the DMA's source
-//    address): ds_read_b128 fragment reads are bank-conflict free and one ds_read_b128 feeds 4 MFMAs (the K order inside
-//    a 16-deep step is permuted identically for both operands, which a dot product allows).
+//  * LDS images are [row][32 k] fp32 with the 16-byte chunk index XOR-swizzled by (row & 7): ds_write_b128 when
+//    staging and ds_read_b128 when building fragments are both bank-conflict free; one ds_read_b128 feeds 4 MFMAs
+//    (the K order inside a 16-deep step is permuted identically for both operands, which a dot product allows).
 //  * Workgroup ids are remapped so that the 8 XCDs (private L2s) each get a contiguous range of tiles, channel tiles
 //    fastest: the tiles that re-read one activation panel run on one XCD back to back.
-//  * Prologue: eval-BatchNorm + ReLU of the *input* (pre-activation Residual, model/hourglass.py:106-108) is applied to
-//    the activation fragments after the LDS read (scale/shift table in LDS).  Epilogues are compiled per kind (linear/ReLU,
-//    GELU, residual) with an unguarded float4 fast path for interior tiles.
-#include "kpf_common.h"
+//  * Prologue: eval-BatchNorm + ReLU of the *input* (pre-activation Residual, model/hourglass.py:106-108) is applied
+//    in registers between the global load and the LDS store; zero padding stays zero.
+//    Epilogue: bias, ReLU / GELU(erf), layer-scale * y + residual, ReLU-after-add, NHWC slice or NCHW store.
+#include "../keypointfusion_amd/csrc/kpf_common.h"
 #include <stdlib.h>
 
+__device__ unsigned long long kpf_stamps[8];
+#define STAMP(t) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory")
 namespace {
 
 struct ConvArgs {
@@ -48,23 +47,7 @@ struct ConvArgs {
   int vec;  // 1: output/residual rows are 16-byte aligned -> float4 epilogue
 };
 
-// GELU(x) = x/2 * (1 + erf(x/sqrt2)) with erfc(z) = t*(a1 + t*(a2 + ...)) * exp(-z^2), t = 1/(1 + p z)  (Abramowitz-Stegun 7.1.26,
-// |error| <= 1.5e-7 absolute on erf, i.e. fp32 rounding level) written on the erfc side so the negative tail does not
-// cancel: gelu = max(x,0) - |x/2 * erfc(|x|/sqrt2)|.  12 VALU ops (2 transcendental) instead of libm erff's ~50 with branches:
-// the GELU epilogue of a K=96 GEMM would otherwise cost as much as its MFMAs.
-__device__ __forceinline__ float gelu_erf(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
-  const float q = 0.5f * x * (p * t) * e;  // x/2 * erfc(|x|/sqrt2), carries the sign of x
-  return fmaxf(x, 0.f) - fabsf(q);
-}
-
-enum { EPI_LIN = 0, EPI_GELU = 1, EPI_RES = 2 };
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) void gbl_void_t;
@@ -72,27 +55,25 @@ typedef __attribute__((address_space(1))) void gbl_void_t;
 __device__ __attribute__((aligned(16))) float kpf_zero16[4] = {0.f, 0.f, 0.f, 0.f};  // source of every padding / out-of-range chunk
 
 constexpr int BK = 32;  // K-tile depth: 8 chunks of 16 B per staged row
-// Two LDS buffers per workgroup (64 KB at 128x128): two workgroups share a CU, so one's DMA issue, pipeline fill and epilogue run
-// under the other's MFMAs.
+constexpr int NB = 3;   // LDS ring depth (loader runs 2 tiles ahead)
 
-template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO, int EPI>
-__global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const ConvArgs a) {
+template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO>
+__global__ __launch_bounds__(64 * (WM * WN + 1)) void igemm_f32_kernel(const ConvArgs a) {
   constexpr int BM = 16 * TM * WM;
   constexpr int BN = 16 * TN * WN;
-  constexpr int NW = WM * WN;               // waves per workgroup (4 or 8)
-  constexpr int RPP = 8 * NW;               // rows staged per pass: every wave moves 8 rows x 128 B = one 1-KiB DMA
-  constexpr int AP = (BM + RPP - 1) / RPP;  // A staging passes
-  constexpr int BP = (BN + RPP - 1) / RPP;  // B staging passes
+  constexpr int AQ = BM / 8;  // DMA instructions per A tile: each moves 8 rows x 128 B = 1 KiB
+  constexpr int BQ = BN / 8;
   constexpr int TILE = (BM + BN) * BK;
-  static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
-  static_assert(BM % 8 == 0 && BN % 8 == 0, "tile granularity");
+  constexpr int NW = WM * WN;   // MFMA waves (4 or 8); wave NW is the loader
+  constexpr int ND = AQ + BQ;   // DMA instructions per K tile
+  static_assert(NW == 4 || NW == 8, "4 or 8 MFMA waves per workgroup");
+  static_assert(BM % 8 == 0 && BN % 8 == 0 && ND <= 63, "tile granularity / vmcnt range");
 
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][TILE] (+ [2][Kp] operand prologue scale/shift)
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [NB][TILE] ring (+ [2][Kp] operand prologue scale/shift)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave % WM, wn = wave / WM;
+  const int wave = tid >> 6;  // 0..NW-1: MFMA waves, NW: loader wave
 
   // XCD-aware bijective remap: blocks b, b+8, b+16.. share an XCD -> give each XCD a contiguous range of logical tiles.
   int bid = blockIdx.x;
@@ -102,77 +83,113 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const ConvArgs 
   }
   const int nt = bid % a.tilesN, mt = bid / a.tilesN;
   const int m0 = mt * BM, n0 = nt * BN;
+  const int nk = a.Kp / BK;
+  float* pro_s = lds + NB * TILE;  // [Kp] scale, then [Kp] shift (zero beyond Cin: padded k contributes relu(0*x+0) = 0)
+  float* pro_t = pro_s + a.Kp;
 
-  // Staging: global -> LDS by DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write).  LDS rows are [32 k] fp32 = 8
-  // chunks of 16 B, chunk c of row r stored at position c ^ (r & 7) (bank-conflict-free ds_read_b128 fragments).  The DMA writes
-  // lane l of a wave at base + 16*l, so LDS stays linear and the swizzle is applied to the SOURCE: the lane at position (r, c')
-  // fetches logical chunk c' ^ (r & 7).  Out-of-range rows / K padding / conv halo read a 16-byte zero page instead.
-  const int lr = tid >> 3;                          // row within a staging pass; a wave owns rows 8*wave .. 8*wave+7
-  const int kc = (((tid & 7) ^ (lr & 7)) << 2);     // logical k offset (floats) this lane fetches within the K tile
-
-  int rbase[AP], riy[AP], rix[AP];
-#pragma unroll
-  for (int p = 0; p < AP; ++p) {
-    const int m = m0 + lr + RPP * p;
-    if (m < a.M && lr + RPP * p < BM) {
-      if (IS1X1) {
-        rbase[p] = m;
-        riy[p] = 0;
-        rix[p] = 0;
-      } else {
-        const int b = m / a.ohow;
-        const int r = m - b * a.ohow;
-        const int oy = r / a.OW;
-        const int ox = r - oy * a.OW;
-        rbase[p] = b * a.IH * a.IW;
-        riy[p] = oy * a.sh - a.ph;
-        rix[p] = ox * a.sw - a.pw;
-      }
-    } else {
-      rbase[p] = -1;
-      riy[p] = 0;
-      rix[p] = 0;
+  if (HAS_PRO) {
+    for (int i = tid; i < a.Kp; i += 64 * (NW + 1)) {
+      pro_s[i] = i < a.Cin ? a.ps[i] : 0.f;
+      pro_t[i] = i < a.Cin ? a.pt[i] : 0.f;
     }
   }
 
-  auto stage = [&](int kt, int buf) {
-    float* As = lds + buf * TILE;
-    float* Bs = As + BM * BK;
-    const int k = kt * BK + kc;
-    const bool kvalid = k < a.K;
-    int c = k, ky = 0, kx = 0;
-    if (!IS1X1) {
-      const int tap = k / a.Cin;
-      c = k - tap * a.Cin;
-      ky = tap / a.KW;
-      kx = tap - ky * a.KW;
-    }
+  if (wave == NW) {
+    // ---------------------------------------------------------------------------------------------------------------
+    // Loader wave: streams K tiles global -> LDS with global_load_lds_dwordx4 (no VGPR round trip), one tile ahead of the
+    // MFMA waves, into the buffer they are not reading.  A wave's VMEM issue is paced by the CU's address unit (64 B/clk,
+    // ~500 cycles per 32 KB tile); giving that job to its own wave keeps those stalls out of the MFMA waves' instruction
+    // streams (measured: 811 of 5368 cycles per K tile when each MFMA wave issued its own share).
+    // LDS rows are [32 k] fp32 = 8 chunks of 16 B, chunk c of row r stored at position c ^ (r & 7) (conflict-free
+    // ds_read_b128 fragments).  The DMA writes lane l at base + 16*l, so LDS stays linear and the swizzle is applied to the
+    // SOURCE: the lane at position (r, c') fetches logical chunk c' ^ (r & 7).
+    // ---------------------------------------------------------------------------------------------------------------
+    const int rr = lane >> 3;                           // row within the 8-row group of one DMA
+    const int kc = (((lane & 7) ^ (rr & 7)) << 2);      // logical k offset (floats) this lane fetches within the K tile
+    int rbase[AQ], riy[AQ], rix[AQ];
 #pragma unroll
-    for (int p = 0; p < AP; ++p) {
-      if (RPP * p + 8 * wave < BM) {  // wave-uniform
-        bool v = kvalid && rbase[p] >= 0;
+    for (int q = 0; q < AQ; ++q) {
+      const int m = m0 + 8 * q + rr;
+      if (m < a.M) {
+        if (IS1X1) {
+          rbase[q] = m;
+          riy[q] = 0;
+          rix[q] = 0;
+        } else {
+          const int b = m / a.ohow;
+          const int r = m - b * a.ohow;
+          const int oy = r / a.OW;
+          const int ox = r - oy * a.OW;
+          rbase[q] = b * a.IH * a.IW;
+          riy[q] = oy * a.sh - a.ph;
+          rix[q] = ox * a.sw - a.pw;
+        }
+      } else {
+        rbase[q] = -1;
+        riy[q] = 0;
+        rix[q] = 0;
+      }
+    }
+    auto stage = [&](int kt, int buf) {
+      float* As = lds + buf * TILE;
+      float* Bs = As + BM * BK;
+      const int k = kt * BK + kc;
+      const bool kvalid = k < a.K;
+      int c = k, ky = 0, kx = 0;
+      if (!IS1X1) {
+        const int tap = k / a.Cin;
+        c = k - tap * a.Cin;
+        ky = tap / a.KW;
+        kx = tap - ky * a.KW;
+      }
+#pragma unroll
+      for (int q = 0; q < AQ; ++q) {
+        bool v = kvalid && rbase[q] >= 0;
         long off;
         if (IS1X1) {
-          off = (long)rbase[p] * a.in_ld + a.in_coff + c;
+          off = (long)rbase[q] * a.in_ld + a.in_coff + c;
         } else {
-          const int iy = riy[p] + ky, ix = rix[p] + kx;
+          const int iy = riy[q] + ky, ix = rix[q] + kx;
           v = v && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
-          off = ((long)rbase[p] + (long)iy * a.IW + ix) * a.in_ld + a.in_coff + c;
+          off = ((long)rbase[q] + (long)iy * a.IW + ix) * a.in_ld + a.in_coff + c;
         }
         const float* src = v ? a.in + off : a.zero;
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(As + (RPP * p + 8 * wave) * BK), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(As + 8 * q * BK), 16, 0, 0);
       }
-    }
 #pragma unroll
-    for (int p = 0; p < BP; ++p) {
-      if (RPP * p + 8 * wave < BN) {  // wave-uniform: BN is a multiple of 8
-        const int n = n0 + lr + RPP * p;
+      for (int q = 0; q < BQ; ++q) {
+        const int n = n0 + 8 * q + rr;
         const float* src = (n < a.N) ? a.w + ((long)n * a.Kp + k) : a.zero;
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(Bs + (RPP * p + 8 * wave) * BK), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(Bs + 8 * q * BK), 16, 0, 0);
       }
+    };
+    // Ring of NB = 3 buffers, the loader runs two tiles ahead.  Only counted waits: `s_waitcnt vmcnt(ND)` = "all but the
+    // youngest tile's DMAs have landed"; raw s_barrier (a __syncthreads() would drain vmcnt to 0 and serialise the ring).
+    stage(0, 0);
+    if (nk > 1) {
+      stage(1, 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ND) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-  };
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // B0: tile 0 (and the prologue table) visible to the MFMA waves
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 2 < nk) {
+        stage(kt + 2, (kt + 2) % NB);  // that buffer held tile kt-1: released by the barrier that ended iteration kt-1
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ND) : "memory");  // tile kt+1 landed, tile kt+2 in flight
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+    return;
+  }
 
+  // -----------------------------------------------------------------------------------------------------------------
+  // MFMA waves: pure ds_read_b128 + v_mfma loop, one barrier per K tile.
+  // -----------------------------------------------------------------------------------------------------------------
+  const int wm = wave % WM, wn = wave / WM;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 acc[TN][TM];
 #pragma unroll
@@ -180,25 +197,19 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const ConvArgs 
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = zero4;
 
-  const int nk = a.Kp / BK;
   const int fr = lane & 15;  // fragment row (pixel for X, channel for W)
   const int fg = lane >> 4;  // k group 0..3
   const int rsw = fr & 7;    // this lane's row swizzle
-  float* pro_s = lds + 2 * TILE;  // [Kp] scale, then [Kp] shift (zero beyond Cin: padded k contributes relu(0*x+0) = 0)
-  float* pro_t = pro_s + a.Kp;
 
-  stage(0, 0);
-  if (HAS_PRO) {
-    for (int i = tid; i < a.Kp; i += 64 * NW) {
-      pro_s[i] = i < a.Cin ? a.ps[i] : 0.f;
-      pro_t[i] = i < a.Cin ? a.pt[i] : 0.f;
-    }
-  }
-  __syncthreads();  // (a pending global_load_lds is an outstanding vmcnt: the barrier's fence drains it)
-
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // B0: tile 0 (and the prologue table) in LDS
+  unsigned long long t0, t1, t2, acc_mm = 0, acc_bar = 0, tbeg, tend;
+  STAMP(tbeg);
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(kt + 1, cur ^ 1);  // next tile flies into the other buffer under this tile's MFMAs
+    const int cur = kt % NB;
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(t0);
+    __builtin_amdgcn_sched_barrier(0);
     const float* xrow = lds + cur * TILE + (wm * TM * 16 + fr) * BK;
     const float* wrow = lds + cur * TILE + BM * BK + (wn * TN * 16 + fr) * BK;
 #pragma unroll
@@ -226,84 +237,77 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const ConvArgs 
           for (int j = 0; j < TM; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][e], xf[j][e], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();  // next tile landed (vmcnt drained by the barrier's fence); every wave is done reading `cur`
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(t1);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();                        // ... and the loader's tile kt+1 has landed
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(t2);
+    acc_mm += t1 - t0; acc_bar += t2 - t1;
+  }
+  STAMP(tend);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    kpf_stamps[0] = 0; kpf_stamps[1] = acc_mm; kpf_stamps[2] = acc_bar; kpf_stamps[4] = tend - tbeg; kpf_stamps[5] = nk;
   }
 
   // ---- epilogue: lane holds channels n..n+3 (n = tile + 4*fg) of pixel m (= tile + fr) ----
   const unsigned fl = a.flags;
-  const bool interior = (m0 + BM <= a.M) && (n0 + BN <= a.N) && a.vec && !(fl & KPF_OUT_NCHW);  // workgroup-uniform
-  if (interior) {
-    // fast path: whole tile in range and 16-byte aligned -> no per-element guards, float4 bias / gamma / residual / store
-#pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      const int n = n0 + (wn * TN + i) * 16 + fg * 4;
-      f32x4 bv = zero4, gv = zero4;
-      if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
-      if (EPI == EPI_RES && (fl & KPF_RES_GAMMA)) gv = *reinterpret_cast<const f32x4*>(a.gamma + n);
-#pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        const long m = m0 + (wm * TM + j) * 16 + fr;
-        f32x4 v = acc[i][j];
-        if (EPI == EPI_RES) {
-          const f32x4 rv = *reinterpret_cast<const f32x4*>(a.res + m * a.res_ld + a.res_coff + n);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float y = v[e] + bv[e];
-            if (fl & KPF_RES_GAMMA) y *= gv[e];
-            y += rv[e];
-            if (fl & KPF_RELU_AFTER_RES) y = fmaxf(y, 0.f);
-            v[e] = y;
-          }
-        } else if (EPI == EPI_GELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e] + bv[e]);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float y = v[e] + bv[e];
-            v[e] = (fl & KPF_ACT_RELU) ? fmaxf(y, 0.f) : y;
-          }
-        }
-        *reinterpret_cast<f32x4*>(a.out + m * a.out_ld + a.out_coff + n) = v;
-      }
-    }
-    return;
-  }
-  // edge / NCHW / unaligned path: per-element guards
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     const int m = m0 + (wm * TM + j) * 16 + fr;
     if (m >= a.M) continue;
-    const int b = m / a.ohow;
-    const int pix = m - b * a.ohow;
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
       const int n = n0 + (wn * TN + i) * 16 + fg * 4;
+      if (n >= a.N) continue;
+      f32x4 v = acc[i][j];
+      const bool full = (n + 3 < a.N) && a.vec;
+      f32x4 bv = zero4, gv = {1.f, 1.f, 1.f, 1.f}, rv = zero4;
+      if (full) {
+        if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+        if (fl & KPF_RES_GAMMA) gv = *reinterpret_cast<const f32x4*>(a.gamma + n);
+        if (fl & KPF_RES_ADD) rv = *reinterpret_cast<const f32x4*>(a.res + (long)m * a.res_ld + a.res_coff + n);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < a.N) {
+            if (a.bias) bv[e] = a.bias[n + e];
+            if (fl & KPF_RES_GAMMA) gv[e] = a.gamma[n + e];
+            if (fl & KPF_RES_ADD) rv[e] = a.res[(long)m * a.res_ld + a.res_coff + n + e];
+          }
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        if (n + e >= a.N) continue;
-        float y = acc[i][j][e] + (a.bias ? a.bias[n + e] : 0.f);
-        if (EPI == EPI_GELU) y = gelu_erf(y);
-        if (EPI == EPI_LIN && (fl & KPF_ACT_RELU)) y = fmaxf(y, 0.f);
-        if (EPI == EPI_RES) {
-          if (fl & KPF_RES_GAMMA) y *= a.gamma[n + e];
-          y += a.res[(long)m * a.res_ld + a.res_coff + n + e];
-          if (fl & KPF_RELU_AFTER_RES) y = fmaxf(y, 0.f);
-        }
-        if (fl & KPF_OUT_NCHW)
-          a.out[((long)b * a.N + n + e) * a.ohow + pix] = y;
-        else
-          a.out[(long)m * a.out_ld + a.out_coff + n + e] = y;
+        float y = v[e] + bv[e];
+        if (fl & KPF_ACT_RELU) y = fmaxf(y, 0.f);
+        if (fl & KPF_ACT_GELU) y = gelu_erf(y);
+        if (fl & KPF_RES_GAMMA) y = y * gv[e];
+        if (fl & KPF_RES_ADD) y = rv[e] + y;
+        if (fl & KPF_RELU_AFTER_RES) y = fmaxf(y, 0.f);
+        v[e] = y;
+      }
+      if (fl & KPF_OUT_NCHW) {
+        const int b = m / a.ohow;
+        const int pix = m - b * a.ohow;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < a.N) a.out[((long)b * a.N + n + e) * a.ohow + pix] = v[e];
+      } else if (full) {
+        *reinterpret_cast<f32x4*>(a.out + (long)m * a.out_ld + a.out_coff + n) = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < a.N) a.out[(long)m * a.out_ld + a.out_coff + n + e] = v[e];
       }
     }
   }
 }
 
-template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO, int EPI>
+template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO>
 int launch_one(const ConvArgs& a, hipStream_t st) {
   constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
-  const size_t lds = (size_t)(2 * (BM + BN) * BK + (HAS_PRO ? 2 * a.Kp : 0)) * sizeof(float);
-  auto kern = igemm_f32_kernel<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI>;
+  const size_t lds = (size_t)(NB * (BM + BN) * BK + (HAS_PRO ? 2 * a.Kp : 0)) * sizeof(float);
+  auto kern = igemm_f32_kernel<TM, TN, WM, WN, IS1X1, HAS_PRO>;
   static bool attr_set = false;  // > 64 KiB of dynamic LDS needs an opt-in; benign if two threads race to set it
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
@@ -316,37 +320,24 @@ int launch_one(const ConvArgs& a, hipStream_t st) {
     kpf_set_error("kpf_conv2d_f32: operand prologue too long for LDS (Kp=%d)", a.Kp);
     return KPF_EINVAL;
   }
-  hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(64 * WM * WN), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(64 * (WM * WN + 1)), lds, st, a);
   return kpf_check_launch("kpf_conv2d_f32");
 }
 
-// Instantiated variants per tile shape (the combinations the model produces):
-//   1x1 + operand prologue + linear/ReLU   (Residual.conv1)            1x1 + linear/ReLU        (heads, embeddings, skip convs)
-//   1x1 + GELU                             (ConvNeXt pwconv1)          1x1 + residual           (pwconv2, Residual.conv3)
-//   conv + linear/ReLU                     (3x3, stems, downsamples)   conv + residual          (BasicBlock.conv2)
 template <int TM, int TN, int WM, int WN>
 int launch_cfg(ConvArgs& a, bool is1x1, hipStream_t st) {
   constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
   const int tilesM = (a.M + BM - 1) / BM;
   a.tilesN = (a.N + BN - 1) / BN;
   a.nblk = tilesM * a.tilesN;
-  const bool res = a.flags & KPF_RES_ADD, gelu = a.flags & KPF_ACT_GELU;
-  if (a.ps) {
-    if (!is1x1 || res || gelu) {
-      kpf_set_error("kpf_conv2d_f32: the operand prologue is only supported for 1x1 stride-1 convolutions with a linear/ReLU epilogue");
-      return KPF_EINVAL;
-    }
-    return launch_one<TM, TN, WM, WN, true, true, EPI_LIN>(a, st);
+  // the operand prologue only occurs on 1x1 convolutions (pre-activation Residual.conv1): 3 instantiations per tile shape
+  if (a.ps && !is1x1) {
+    kpf_set_error("kpf_conv2d_f32: the operand prologue is only supported for 1x1 stride-1 convolutions");
+    return KPF_EINVAL;
   }
-  if (gelu) {
-    if (!is1x1 || res) {
-      kpf_set_error("kpf_conv2d_f32: GELU is only supported on 1x1 convolutions without residual");
-      return KPF_EINVAL;
-    }
-    return launch_one<TM, TN, WM, WN, true, false, EPI_GELU>(a, st);
-  }
-  if (is1x1) return res ? launch_one<TM, TN, WM, WN, true, false, EPI_RES>(a, st) : launch_one<TM, TN, WM, WN, true, false, EPI_LIN>(a, st);
-  return res ? launch_one<TM, TN, WM, WN, false, false, EPI_RES>(a, st) : launch_one<TM, TN, WM, WN, false, false, EPI_LIN>(a, st);
+  if (a.ps) return launch_one<TM, TN, WM, WN, true, true>(a, st);
+  if (is1x1) return launch_one<TM, TN, WM, WN, true, false>(a, st);
+  return launch_one<TM, TN, WM, WN, false, false>(a, st);
 }
 
 // Tile choice.  The kernel is MFMA-bound, so a launch takes about ceil(blocks / 256 CUs) rounds of one tile's work
@@ -367,6 +358,8 @@ double cfg_cost(const Cfg& c, long M, long N) {
 
 }  // namespace
 
+extern "C" int kpf_debug_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(kpf_stamps), 64); }
+
 extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const float* w, const float* bias,
                               const float* pro_scale, const float* pro_shift, const float* gamma, const float* res,
                               float* out, void* stream) {
@@ -386,8 +379,6 @@ extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const flo
   if (fl & KPF_RES_GAMMA) KPF_REQUIRE(gamma && (fl & KPF_RES_ADD), "kpf_conv2d_f32: RES_GAMMA needs gamma and RES_ADD");
   KPF_REQUIRE((pro_scale == nullptr) == (pro_shift == nullptr), "kpf_conv2d_f32: prologue needs both scale and shift");
   KPF_REQUIRE(!((fl & KPF_ACT_RELU) && (fl & KPF_ACT_GELU)), "kpf_conv2d_f32: one activation only");
-  KPF_REQUIRE(!((fl & KPF_RES_ADD) && (fl & (KPF_ACT_RELU | KPF_ACT_GELU))), "kpf_conv2d_f32: activation before a residual add is not supported");
-  KPF_REQUIRE(!(fl & KPF_RELU_AFTER_RES) || (fl & KPF_RES_ADD), "kpf_conv2d_f32: RELU_AFTER_RES needs RES_ADD");
   KPF_REQUIRE((long)d->B * d->OH * d->OW < (1l << 31) && (long)d->B * d->IH * d->IW < (1l << 31), "kpf_conv2d_f32: too many pixels");
 
   ConvArgs a;
