@@ -349,20 +349,22 @@ int launch_cfg(ConvArgs& a, bool is1x1, hipStream_t st) {
   return res ? launch_one<TM, TN, WM, WN, false, false, EPI_RES>(a, st) : launch_one<TM, TN, WM, WN, false, false, EPI_LIN>(a, st);
 }
 
-// Tile choice.  The kernel is MFMA-bound, so a launch takes about ceil(blocks / 256 CUs) rounds of one tile's work
-// (co-resident workgroups share a CU's matrix pipe: they hide bubbles, they do not add throughput).  Padding waste is
-// inside blocks*bm*bn; small tiles amortise staging/epilogue worse, hence the mild penalty.
+// Tile choice.  The kernel is MFMA-bound and co-resident workgroups share a CU's matrix pipe (they hide each other's bubbles, they
+// do not add throughput), so a launch lasts about ceil(blocks / 256 CUs) rounds of one tile's work: 384 blocks cost as much as
+// 512.  `pen` is the measured relative cost per FLOP of each tile shape (smaller tiles amortise staging and epilogue worse).
+// (A persistent-workgroup variant with cross-tile prefetch was measured 5-14 % slower than letting the dispatcher balance.)
 struct Cfg {
   int bm, bn;
+  double pen;
 };
-static const Cfg kCfgs[] = {{128, 128}, {128, 96}, {128, 64}, {256, 48}, {128, 112}, {64, 128}, {64, 64}, {32, 64}, {256, 128}};
+static const Cfg kCfgs[] = {{128, 128, 1.00}, {128, 96, 1.03}, {128, 64, 1.10}, {256, 48, 1.10}, {128, 112, 1.03},
+                            {64, 128, 1.10},  {64, 64, 1.25},  {32, 64, 1.60},  {256, 128, 0.97}};
 
 double cfg_cost(const Cfg& c, long M, long N) {
   const long tm = (M + c.bm - 1) / c.bm, tn = (N + c.bn - 1) / c.bn;
   const long blocks = tm * tn;
-  const double rounds = blocks <= 256 ? 1.0 : (double)blocks / 256.0;  // beyond one round the tail overlaps
-  const double small_pen = 1.0 + 0.05 * (128.0 * 128.0 / (c.bm * c.bn) - 1.0);
-  return rounds * c.bm * c.bn * small_pen;
+  const long rounds = (blocks + 255) / 256;
+  return (double)rounds * c.bm * c.bn * c.pen;
 }
 
 }  // namespace

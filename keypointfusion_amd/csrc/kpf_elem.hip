@@ -101,35 +101,121 @@ __global__ __launch_bounds__(512) void dwconv7_ln_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// LayerNorm over C for `rows` pixels: one wave per row, rows kept in registers (C <= 64*4*LN_MAXV)
+// depthwise 7x7 + bias (no norm): thread = 4 channels x (2 output rows x 8 px).  Each of the 8 input rows it touches is loaded
+// once (14 float4) and feeds both output rows, the 49-tap weights of its channel quad come from LDS (when 49*C*4 B fits) so
+// the CU's address unit only carries activations: 7 activation loads per output float4 instead of 12.25 + 6.1 weight loads.
+// No LDS output tile -> occupancy is set by registers only.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int LN_MAXV = 8;  // float4 per lane -> C <= 2048
+template <bool WLDS>
+__global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ x, const float* __restrict__ wdw,
+                                                      const float* __restrict__ bdw, float* __restrict__ y, int B, int H, int W, int C,
+                                                      int xstrips, int ypairs) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [49][C] when WLDS
+  const int C4 = C >> 2;
+  if (WLDS) {
+    for (int i = threadIdx.x; i < 49 * C4; i += 256)
+      *reinterpret_cast<f32x4*>(wl + 4 * i) = *reinterpret_cast<const f32x4*>(wdw + 4 * i);
+    __syncthreads();
+  }
+  const long total = (long)B * ypairs * xstrips * C4;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int q = (int)(gid % C4);
+  long r = gid / C4;
+  const int xs = (int)(r % xstrips);
+  r /= xstrips;
+  const int yp = (int)(r % ypairs);
+  const int b = (int)(r / ypairs);
+  const int x0 = xs * 8, y0 = yp * 2;
+  const float* wsrc = WLDS ? wl : wdw;
+  f32x4 acc0[8], acc1[8];
+  const f32x4 bias = *reinterpret_cast<const f32x4*>(bdw + 4 * q);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    acc0[t] = bias;
+    acc1[t] = bias;
+  }
+  const float* xb = x + (long)b * H * W * C + 4 * q;
+#pragma unroll 1
+  for (int ir = 0; ir < 8; ++ir) {  // input rows y0-3 .. y0+4
+    const int iy = y0 + ir - 3;
+    if ((unsigned)iy >= (unsigned)H) continue;
+    f32x4 in[14];
+    const float* row = xb + (long)iy * W * C;
+#pragma unroll
+    for (int i = 0; i < 14; ++i) {
+      const int ix = x0 + i - 3;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)ix < (unsigned)W) v = *reinterpret_cast<const f32x4*>(row + (long)ix * C);
+      in[i] = v;
+    }
+    if (ir < 7) {  // output row y0: tap row ky = ir
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wsrc + (ir * 7 + kx) * C + 4 * q);
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc0[t][e] = fmaf(in[t + kx][e], wv[e], acc0[t][e]);
+      }
+    }
+    if (ir >= 1) {  // output row y0+1: tap row ky = ir-1
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wsrc + ((ir - 1) * 7 + kx) * C + 4 * q);
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc1[t][e] = fmaf(in[t + kx][e], wv[e], acc1[t][e]);
+      }
+    }
+  }
+  float* yb = y + (long)b * H * W * C + 4 * q;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    if (x0 + t < W) {
+      *reinterpret_cast<f32x4*>(yb + ((long)y0 * W + x0 + t) * C) = acc0[t];
+      if (y0 + 1 < H) *reinterpret_cast<f32x4*>(yb + ((long)(y0 + 1) * W + x0 + t) * C) = acc1[t];
+    }
+  }
+}
 
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm over C for `rows` pixels.  A row is handled by LPR = 16/32/64 lanes (the power of two covering C/4 float4s, so a
+// 96-channel row uses a 32-lane half wave instead of idling 40 of 64 lanes), rows stay in registers (two-pass variance),
+// reductions are xor-shuffles inside the LPR-lane group.  C <= 64*4*LN_MAXV.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int LN_MAXV = 8;  // float4 per lane at LPR = 64 -> C <= 2048
+
+template <int LPR, int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, float* __restrict__ y, long rows, int C,
                                                         float eps) {
-  const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  constexpr int RPB = 256 / LPR;  // rows per block
+  const int sub = threadIdx.x % LPR;
+  const long row = (long)blockIdx.x * RPB + threadIdx.x / LPR;
+  const bool live = row < rows;
   const int C4 = C >> 2;
-  const float* src = x + row * C;
-  f32x4 v[LN_MAXV];
+  const float* src = x + (live ? row : 0) * C;
+  f32x4 v[NV];
   float sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    const int c = lane + 64 * i;
+  for (int i = 0; i < NV; ++i) {
+    const int c = sub + LPR * i;
     v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (c < C4) {
       v[i] = *reinterpret_cast<const f32x4*>(src + 4 * c);
       sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
   }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
   const float invC = 1.0f / (float)C;
-  const float mean = wave_sum(sum) * invC;
+  const float mean = sum * invC;
   float sq = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    if (lane + 64 * i < C4) {
+  for (int i = 0; i < NV; ++i) {
+    if (sub + LPR * i < C4) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float d = v[i][e] - mean;
@@ -137,11 +223,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       }
     }
   }
-  const float rstd = 1.0f / sqrtf(wave_sum(sq) * invC + eps);
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  const float rstd = 1.0f / sqrtf(sq * invC + eps);
+  if (!live) return;
   float* dst = y + row * C;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    const int c = lane + 64 * i;
+  for (int i = 0; i < NV; ++i) {
+    const int c = sub + LPR * i;
     if (c < C4) {
       const f32x4 g = *reinterpret_cast<const f32x4*>(w + 4 * c);
       const f32x4 be = *reinterpret_cast<const f32x4*>(b + 4 * c);
@@ -257,6 +346,21 @@ extern "C" int kpf_dwconv7_ln_f32(const float* x, const float* w_dw, const float
   KPF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && C <= 2048, "kpf_dwconv7_ln_f32: bad shape B=%d H=%d W=%d C=%d", B, H, W, C);
   KPF_REQUIRE(kpf_aligned16(x) && kpf_aligned16(y) && kpf_aligned16(w_dw), "kpf_dwconv7_ln_f32: unaligned pointer");
   const int C4 = C / 4;
+  if (H * W >= 64) {
+    // two launches: register-tiled depthwise conv, then the row LayerNorm in place (each streams the tensor once; measured faster
+    // than the single fused kernel, whose LDS output tile caps occupancy).  Tiny maps keep the fused kernel (one launch).
+    const int xstrips = (W + 7) / 8, ypairs = (H + 1) / 2;
+    const long total = (long)B * ypairs * xstrips * C4;
+    const size_t wbytes = (size_t)49 * C * sizeof(float);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (wbytes <= 48 * 1024)
+      hipLaunchKernelGGL((dwconv7_kernel<true>), dim3((unsigned)((total + 255) / 256)), dim3(256), wbytes, st, x, w_dw, b_dw, y, B, H, W, C, xstrips, ypairs);
+    else
+      hipLaunchKernelGGL((dwconv7_kernel<false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, w_dw, b_dw, y, B, H, W, C, xstrips, ypairs);
+    int rc = kpf_check_launch("kpf_dwconv7_ln_f32");
+    if (rc) return rc;
+    return kpf_layernorm_f32(y, ln_w, ln_b, y, (long)B * H * W, C, eps, stream);
+  }
   int S = 1;
   while (S * 2 * C4 <= 256 && S * DW_T < W) S *= 2;  // strips per block: <= 256 threads, no wider than the row
   const int threads = ((S * C4 + 63) / 64) * 64;
@@ -272,8 +376,17 @@ extern "C" int kpf_layernorm_f32(const float* x, const float* w, const float* b,
                                  void* stream) {
   KPF_REQUIRE(x && w && b && y && rows > 0, "kpf_layernorm_f32: null pointer / empty");
   KPF_REQUIRE(C % 4 == 0 && C > 0 && C <= 64 * 4 * LN_MAXV, "kpf_layernorm_f32: C=%d unsupported", C);
-  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, w,
-                     b, y, rows, C, eps);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int C4 = C / 4;
+#define KPF_LN(LPR, NV) \
+  hipLaunchKernelGGL((layernorm_kernel<LPR, NV>), dim3((unsigned)((rows + 256 / LPR - 1) / (256 / LPR))), dim3(256), 0, st, x, w, b, y, rows, C, eps)
+  if (C4 <= 16) KPF_LN(16, 1);
+  else if (C4 <= 32) KPF_LN(32, 1);
+  else if (C4 <= 64) KPF_LN(64, 1);
+  else if (C4 <= 128) KPF_LN(64, 2);
+  else if (C4 <= 256) KPF_LN(64, 4);
+  else KPF_LN(64, LN_MAXV);
+#undef KPF_LN
   return kpf_check_launch("kpf_layernorm_f32");
 }
 
