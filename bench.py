@@ -79,9 +79,7 @@ def main():
     def step():
         with torch.no_grad():
             if args.workload == "backbones256":
-                plan = model._plan(dev)
-                plan.backbone_d(batch["img"])
-                plan.backbone_rgb(batch["img_rgb"])
+                model._plan(dev).backbones(batch["img"], batch["img_rgb"])
             else:
                 model(batch["img_rgb"], batch["img"], batch["pcl"], _Loader(), batch["center"], batch["M"], batch["cube"],
                       batch["cam_para"], 0.8)
@@ -125,6 +123,7 @@ def main():
             return out
 
         E.conv = timed_conv
+        model._plan(dev).serial_streams = True  # one stream: per-launch durations are each kernel's own, not a shared GPU's
         try:
             step()
             torch.cuda.synchronize()
@@ -133,6 +132,7 @@ def main():
             torch.cuda.synchronize()
         finally:
             E.conv = orig_conv
+            model._plan(dev).serial_streams = False
         t_ms = sum(r[0].elapsed_time(r[1]) for r in recs)
         fl = sum(r[2] for r in recs)
         if args.per_launch:

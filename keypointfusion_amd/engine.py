@@ -500,6 +500,26 @@ class ModelPlan:
         self.backbone_d = UNetPlan(sd, "backbone_d", net, device)
         self.backbone_rgb = UNetPlan(sd, "backbone_rgb", net, device)
         self.blocks = [FusionBlockPlan(sd, "block%d" % i, device) for i in (1, 2)]
+        self._side = None  # second HIP stream: the RGB backbone runs beside the depth backbone
+        self.serial_streams = False  # profiling aid: issue both backbones on one stream so per-kernel timings are not shared
+
+    def backbones(self, img, img_rgb):
+        """Both UNet streams (model/model.py:397-398).  They are independent, so the RGB stream is issued on a second HIP
+        stream: its small low-resolution layers (fewer tiles than CUs) fill the CUs the depth stream leaves idle."""
+        cur = torch.cuda.current_stream(self.device)
+        if self.serial_streams or torch.cuda.is_current_stream_capturing():
+            return self.backbone_d(img), self.backbone_rgb(img_rgb)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        side = self._side
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            out_rgb = self.backbone_rgb(img_rgb)
+        out_d = self.backbone_d(img)
+        cur.wait_stream(side)
+        for t in (out_rgb[0], out_rgb[1].buf):  # allocated on the side stream, consumed on the caller's stream
+            t.record_stream(cur)
+        return out_d, out_rgb
 
     def forward(self, img_rgb, img, pcl, center, M, cube, cam, kernel, img_size, flip, want_aux=False):
         lib = L.load()
@@ -508,8 +528,7 @@ class ModelPlan:
         N = pcl.shape[1]
         prep = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
         img, img_rgb, pcl, center, M, cube, cam = map(prep, (img, img_rgb, pcl, center, M, cube, cam))
-        img_offset, feat_d = self.backbone_d(img)
-        img_offset_rgb, feat_rgb = self.backbone_rgb(img_rgb)
+        (img_offset, feat_d), (img_offset_rgb, feat_rgb) = self.backbones(img, img_rgb)
         F = feat_d.H
         P = F * F
         st = _stream()

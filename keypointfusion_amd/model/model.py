@@ -93,8 +93,7 @@ class KPFusion(nn.Module):
         from ..engine import nhwc_to_nchw
         plan = self._plan(img.device)
         with torch.cuda.device(img.device):
-            od, fd = plan.backbone_d(img)
-            orgb, frgb = plan.backbone_rgb(img_rgb)
+            (od, fd), (orgb, frgb) = plan.backbones(img.detach().float().contiguous(), img_rgb.detach().float().contiguous())
             return od, nhwc_to_nchw(fd), orgb, nhwc_to_nchw(frgb)
 
     def forward(self, img_rgb, img, pcl, loader, center, M, cube, cam_para, kernel=0.8, writer=None, ii=0):
