@@ -119,7 +119,9 @@ def main():
                 M = x.B * (x.H // pc.sh) * (x.W // pc.merge)
             else:
                 M = x.B * ((x.H + 2 * pc.ph - pc.KH) // pc.sh + 1) * ((x.W + 2 * pc.pw - pc.KW) // pc.sw + 1)
-            recs.append((e0, e1, pc.flops(M), (M, pc.N, pc.K, pc.KH, pc.KW)))
+            # algorithmic bytes: input pixels once, weights once, output once (+ residual once)
+            ab = 4.0 * (x.B * x.H * x.W * x.C + pc.N * pc.K + M * pc.N * (2 if k.get("res") is not None else 1))
+            recs.append((e0, e1, pc.flops(M), (M, pc.N, pc.K, pc.KH, pc.KW), ab))
             return out
 
         E.conv = timed_conv
@@ -138,12 +140,17 @@ def main():
         if args.per_launch:
             with open(args.per_launch, "w") as f:
                 f.write("M,N,K,KH,KW,ms,TFLOPs\n")
-                for e0, e1, fl_i, shp in recs:
+                for e0, e1, fl_i, shp, _ in recs:
                     ms = e0.elapsed_time(e1)
                     f.write("%d,%d,%d,%d,%d,%.4f,%.1f\n" % (shp + (ms, fl_i / ms / 1e9)))
         ach = fl / (t_ms * 1e-3) / 1e12
+        traffic = None  # HBM bytes per launch from the rocprofv3 PMC passes of this command (tools/collect_traffic.py), when committed
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if args.workload == "backbones256" and B == 64 and os.path.exists(tpath):
+            traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
         roofline = {"bound": "mfma", "kernel": "igemm_f32_kernel", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "algo_bytes_per_launch": round(sum(r[4] for r in recs) / max(len(recs), 1)),
                     "launches_per_step": len(recs), "avg_launch_ms": round(t_ms / max(len(recs), 1), 4),
                     "gflop_per_step": round(fl / 1e9, 1), "kernel_ms_per_step": round(t_ms, 3),
                     "whole_step_tflops": round(fl / (ms_per_step * 1e-3) / 1e12, 2)}

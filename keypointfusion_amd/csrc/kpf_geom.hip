@@ -260,37 +260,56 @@ constexpr int JA_LD = 132;
 
 __global__ __launch_bounds__(256) void softmax_pool_kernel(const float* __restrict__ A1, const float* __restrict__ X,
                                                            const float* __restrict__ joint_xyz, float* __restrict__ JA, int N) {
-  extern __shared__ __attribute__((aligned(16))) float att[];  // [N] + 4 + 128
-  float* red = att + N;
-  float* half = red + 4;
-  const int j = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  const float* wcol = A1 + (long)b * N * A1_LD + 131 + j;
-  float lmax = -INFINITY;
-  for (int n = tid; n < N; n += 256) {
-    const float w = wcol[(long)n * A1_LD];
-    att[n] = w;
-    lmax = fmaxf(lmax, w);
+  // grid (3, B): 7 joints per workgroup, so the point features X[b] are streamed 3 times instead of 21
+  extern __shared__ __attribute__((aligned(16))) float att[];  // [7][N] + red[4] + part[7][128]
+  float* red = att + 7 * N;
+  float* part = red + 4;
+  const int jc = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const float* wbase = A1 + (long)b * N * A1_LD + 131 + jc * 7;
+  for (int j = 0; j < 7; ++j) {
+    float lmax = -INFINITY;
+    for (int n = tid; n < N; n += 256) {
+      const float w = wbase[(long)n * A1_LD + j];
+      att[j * N + n] = w;
+      lmax = fmaxf(lmax, w);
+    }
+    const float mx = block_max(lmax, red);
+    float se = 0.f;
+    for (int n = tid; n < N; n += 256) {
+      const float e = expf(att[j * N + n] - mx);
+      att[j * N + n] = e;
+      se += e;
+    }
+    se = block_sum(se, red);
+    const float inv = 1.0f / se;
+    for (int n = tid; n < N; n += 256) att[j * N + n] *= inv;
   }
-  const float mx = block_max(lmax, red);
-  float se = 0.f;
-  for (int n = tid; n < N; n += 256) {
-    const float e = expf(att[n] - mx);
-    att[n] = e;
-    se += e;
-  }
-  se = block_sum(se, red);
-  const float inv = 1.0f / se;
+  __syncthreads();
   const int c = tid & 127, h = tid >> 7;
   const float* xb = X + (long)b * N * 128 + c;
-  float acc = 0.f;
+  float acc[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) acc[j] = 0.f;
   const int n0 = h * (N / 2), n1 = h ? N : N / 2;
-  for (int n = n0; n < n1; ++n) acc += (att[n] * inv) * xb[(long)n * 128];
-  if (h) half[c] = acc;
+#pragma unroll 4
+  for (int n = n0; n < n1; ++n) {
+    const float xv = xb[(long)n * 128];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) acc[j] += att[j * N + n] * xv;
+  }
+  if (h) {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) part[j * 128 + c] = acc[j];
+  }
   __syncthreads();
-  float* o = JA + ((long)b * J + j) * JA_LD;
-  if (!h) o[c] = acc + half[c];
-  if (tid < 3) o[128 + tid] = joint_xyz[((long)b * J + j) * 3 + tid];
-  if (tid == 3) o[131] = 0.f;
+  if (!h) {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) JA[((long)b * J + jc * 7 + j) * JA_LD + c] = acc[j] + part[j * 128 + c];
+  }
+  if (tid < 28) {
+    const int j = tid >> 2, e = tid & 3;
+    JA[((long)b * J + jc * 7 + j) * JA_LD + 128 + e] = e < 3 ? joint_xyz[((long)b * J + jc * 7 + j) * 3 + e] : 0.f;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -448,30 +467,34 @@ __global__ __launch_bounds__(256) void heat_gam_gate_kernel(const float* __restr
 __global__ __launch_bounds__(256) void gate_reduce_kernel(const float* __restrict__ Gw, const float* __restrict__ feat,
                                                           const float* __restrict__ bfc, const float* __restrict__ prev,
                                                           float* __restrict__ out, int P) {
-  __shared__ float part[7][128];
+  extern __shared__ __attribute__((aligned(16))) float gl[];  // [7][P] gate rows of this workgroup's joints, then part[7][128]
+  float* part = gl + 7 * P;
   const int jc = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int c = tid & 127, h = tid >> 7;
   const float* g = Gw + ((long)b * J + jc * 7) * P;
+  for (int i = tid; i < 7 * P / 4; i += 256) *reinterpret_cast<f32x4*>(gl + 4 * i) = *reinterpret_cast<const f32x4*>(g + 4 * i);
+  __syncthreads();
   const float* f = feat + (long)b * P * 128 + c;
   float acc[7];
 #pragma unroll
   for (int j = 0; j < 7; ++j) acc[j] = 0.f;
   const int p0 = h * (P / 2), p1 = h ? P : P / 2;
+#pragma unroll 4
   for (int p = p0; p < p1; ++p) {
     const float v = fmaxf(f[(long)p * 128], 0.f);
 #pragma unroll
-    for (int j = 0; j < 7; ++j) acc[j] += g[(long)j * P + p] * v;
+    for (int j = 0; j < 7; ++j) acc[j] += gl[j * P + p] * v;
   }
   if (h) {
 #pragma unroll
-    for (int j = 0; j < 7; ++j) part[j][c] = acc[j];
+    for (int j = 0; j < 7; ++j) part[j * 128 + c] = acc[j];
   }
   __syncthreads();
   if (!h) {
     const float bb = bfc[0];
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
-      float v = (acc[j] + part[j][c]) + bb;
+      float v = (acc[j] + part[j * 128 + c]) + bb;
       const long o = ((long)b * J + jc * 7 + j) * 128 + c;
       if (prev) v = fmaxf((v + prev[o]) / 2.0f, 0.f);
       out[o] = v;
@@ -514,9 +537,9 @@ extern "C" int kpf_point_assemble_f32(const float* feat_d, const float* feat_rgb
 }
 
 extern "C" int kpf_softmax_pool_f32(const float* A1, const float* X, const float* joint_xyz, float* JA, int B, int N, void* stream) {
-  KPF_REQUIRE(A1 && X && joint_xyz && JA && B > 0 && N > 1 && N % 2 == 0, "kpf_softmax_pool_f32: bad arguments");
-  hipLaunchKernelGGL(softmax_pool_kernel, dim3(J, B), dim3(256), (size_t)(N + 4 + 128) * sizeof(float), ST(stream), A1, X, joint_xyz,
-                     JA, N);
+  KPF_REQUIRE(A1 && X && joint_xyz && JA && B > 0 && N > 1 && N % 2 == 0 && N <= 2048, "kpf_softmax_pool_f32: bad arguments");
+  hipLaunchKernelGGL(softmax_pool_kernel, dim3(3, B), dim3(256), (size_t)(7 * N + 4 + 7 * 128) * sizeof(float), ST(stream), A1, X,
+                     joint_xyz, JA, N);
   return kpf_check_launch("kpf_softmax_pool_f32");
 }
 
@@ -547,7 +570,8 @@ extern "C" int kpf_heat_gam_gate_f32(const float* r3d, const float* img_xyz, con
 
 extern "C" int kpf_gate_reduce_f32(const float* Gw, const float* feat, const float* bfc, const float* prev, float* out, int B, int P,
                                    void* stream) {
-  KPF_REQUIRE(Gw && feat && bfc && out && B > 0 && P % 2 == 0, "kpf_gate_reduce_f32: bad arguments");
-  hipLaunchKernelGGL(gate_reduce_kernel, dim3(3, B), dim3(256), 0, ST(stream), Gw, feat, bfc, prev, out, P);
+  KPF_REQUIRE(Gw && feat && bfc && out && B > 0 && P % 4 == 0 && P <= 4096, "kpf_gate_reduce_f32: bad arguments");
+  hipLaunchKernelGGL(gate_reduce_kernel, dim3(3, B), dim3(256), (size_t)(7 * P + 7 * 128) * sizeof(float), ST(stream), Gw, feat, bfc, prev,
+                     out, P);
   return kpf_check_launch("kpf_gate_reduce_f32");
 }

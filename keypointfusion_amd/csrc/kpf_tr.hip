@@ -3,10 +3,10 @@
 //                         intermediate 16, GELU-erf, LN eps 1e-12) + cls_head/residual 3-vector heads  (model/model.py:30-126)
 //   kpf_xattn_layer_f32 : the one observable decoder layer of updatedDecoder (cross attention 21x21, post-LN, ReLU FFN)
 //                         (model/transfusion_head.py:137-173, 635-708)
-// One workgroup (256 threads) owns one sample: all activations (21 x 128 tokens, Q/K/V, scores) live in LDS for the
+// One workgroup (512 threads) owns one sample: all activations (21 x 128 tokens, Q/K/V, scores) live in LDS for the
 // whole stack, weights stream from L2 (they are shared by every workgroup), nothing round-trips through HBM between
 // layers and the whole stack is ONE launch instead of ~30.  The work is tiny (12 MFLOP per sample) and latency-bound, so
-// it runs on the vector ALUs: each thread owns one output channel for half of the tokens, weights are stored transposed
+// it runs on the vector ALUs: each thread owns one output channel for a quarter of the tokens, weights are stored transposed
 // [K][N] so a wave reads 256 contiguous bytes per k and the token values are LDS broadcasts.
 #include "kpf_common.h"
 
@@ -16,25 +16,61 @@ constexpr int T = 21;    // tokens
 constexpr int H = 128;   // hidden
 constexpr int NH = 4;    // heads
 constexpr int HD = 32;   // head dim
-constexpr int TG = 11;   // tokens per thread group (2 groups: 11 + 10)
+constexpr int TG = 6;    // tokens per work item (4 token groups: 6 + 6 + 6 + 3)
+constexpr int NG = 4;    // token groups
+constexpr int NTHR = 512;  // threads per workgroup: 8 waves = 2 per SIMD, so LDS / L2 latency of one wave hides under the other
 
-// out[t][o] = act( sum_k in[t][k] * Wt[k][o] + bias[o] (+ add[t][o]) ), in/out/add in LDS, Wt/bias global
+// out[t][o] = act( (sum_k in[t][k] * Wt[k][o] + bias[o]) * scale (+ add[t][o]) ), in/out/add in LDS (row strides multiples of 4
+// floats), Wt/bias global.  Work item = (output channel o, token half); 8 weight loads are issued together (the k loop would
+// otherwise be one dependent L2 round trip per k: ~40 us per 128x128 layer) and the token values come as float4 LDS broadcasts.
 template <int ACT>  // 0 none, 1 relu, 2 gelu(erf)
 __device__ __forceinline__ void linear(const float* in, int ldin, const float* __restrict__ Wt, const float* __restrict__ bias, int K,
                                        int N, float* out, int ldo, const float* add, int ldadd, float scale) {
-  for (int item = threadIdx.x; item < 2 * N; item += 256) {
+  for (int item = threadIdx.x; item < NG * N; item += NTHR) {
     const int o = item % N, g = item / N;
     const int t0 = g * TG;
-    const int nt = g == 0 ? TG : T - TG;
+    const int nt = (T - t0) < TG ? (T - t0) : TG;
     float acc[TG];
 #pragma unroll
     for (int t = 0; t < TG; ++t) acc[t] = 0.f;
     const float* ip = in + t0 * ldin;
-    for (int k = 0; k < K; ++k) {
-      const float w = Wt[(long)k * N + o];
+    const float* wp = Wt + o;
+    constexpr int U = 16;  // weights fetched per batch; the next batch is in flight while this one is consumed
+    const int KU = K - K % U;
+    float w[U], wn[U];
+    if (KU > 0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) w[u] = wp[(long)u * N];
+    }
+    int k = 0;
+    for (; k < KU; k += U) {
+      if (k + U < KU) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) wn[u] = wp[(long)(k + U + u) * N];
+      }
+#pragma unroll
+      for (int t = 0; t < TG; ++t) {
+        if (t < nt) {
+          float s = acc[t];
+#pragma unroll
+          for (int v = 0; v < U / 4; ++v) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(ip + t * ldin + k + 4 * v);
+            s = fmaf(a[0], w[4 * v], s);
+            s = fmaf(a[1], w[4 * v + 1], s);
+            s = fmaf(a[2], w[4 * v + 2], s);
+            s = fmaf(a[3], w[4 * v + 3], s);
+          }
+          acc[t] = s;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) w[u] = wn[u];
+    }
+    for (; k < K; ++k) {
+      const float wv = wp[(long)k * N];
 #pragma unroll
       for (int t = 0; t < TG; ++t)
-        if (t < nt) acc[t] = fmaf(ip[t * ldin + k], w, acc[t]);
+        if (t < nt) acc[t] = fmaf(ip[t * ldin + k], wv, acc[t]);
     }
     const float bv = bias ? bias[o] : 0.f;
 #pragma unroll
@@ -53,7 +89,7 @@ __device__ __forceinline__ void linear(const float* in, int ldin, const float* _
 __device__ __forceinline__ void layernorm_tokens(const float* in, int ldin, const float* __restrict__ w, const float* __restrict__ b,
                                                  float eps, float* out, int ldo) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int t = wave; t < T; t += 4) {
+  for (int t = wave; t < T; t += NTHR / 64) {
     const float a0 = in[t * ldin + lane], a1 = in[t * ldin + 64 + lane];
     const float mean = wave_sum(a0 + a1) * (1.0f / H);
     const float d0 = a0 - mean, d1 = a1 - mean;
@@ -67,7 +103,7 @@ __device__ __forceinline__ void layernorm_tokens(const float* in, int ldin, cons
 // ctx[i][h*32+d] = sum_j softmax_j( q[i][h,:].k[j][h,:] * qscale ) v[j][h*32+d];  S is scratch [NH][T][T]
 __device__ __forceinline__ void attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float qscale,
                                           float* S, float* ctx, int ldc) {
-  for (int item = threadIdx.x; item < NH * T * T; item += 256) {
+  for (int item = threadIdx.x; item < NH * T * T; item += NTHR) {
     const int h = item / (T * T), r = item - h * T * T, i = r / T, j = r - i * T;
     const float* qp = q + i * ldq + h * HD;
     const float* kp = k + j * ldk + h * HD;
@@ -77,7 +113,7 @@ __device__ __forceinline__ void attention(const float* q, int ldq, const float* 
     S[item] = s * qscale;
   }
   __syncthreads();
-  for (int row = threadIdx.x; row < NH * T; row += 256) {
+  for (int row = threadIdx.x; row < NH * T; row += NTHR) {
     float* sp = S + row * T;
     float m = -INFINITY;
     for (int j = 0; j < T; ++j) m = fmaxf(m, sp[j]);
@@ -91,7 +127,7 @@ __device__ __forceinline__ void attention(const float* q, int ldq, const float* 
     for (int j = 0; j < T; ++j) sp[j] *= inv;
   }
   __syncthreads();
-  for (int item = threadIdx.x; item < T * H; item += 256) {
+  for (int item = threadIdx.x; item < T * H; item += NTHR) {
     const int i = item / H, c = item - i * H, h = c / HD;
     const float* sp = S + (h * T + i) * T;
     float a = 0.f;
@@ -108,19 +144,19 @@ __device__ __forceinline__ void attention(const float* q, int ldq, const float* 
 // then [Wcls_t 128 x 3][bcls 3][Wres_t Din x 3][bres 3]
 constexpr int ENC_LAYER = 128 * 384 + 384 + 128 * 128 + 128 + 128 + 128 + 128 * 16 + 16 + 16 * 128 + 128 + 128 + 128;
 
-__global__ __launch_bounds__(256) void tr_encoder_kernel(const float* __restrict__ x, int ldx, int Din, const float* __restrict__ W,
+__global__ __launch_bounds__(NTHR) void tr_encoder_kernel(const float* __restrict__ x, int ldx, int Din, const float* __restrict__ W,
                                                          float* __restrict__ hout, float* __restrict__ score, float* __restrict__ score2, int s2_ld) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int ldi = Din + 1;       // odd strides: conflict-free column walks
+  const int ldi = (Din + 3) & ~3;  // row strides are multiples of 4 floats: float4 LDS reads in linear()
   float* X0 = sm;                // [T][ldi]   input tokens (kept for the residual head)
-  float* Hb = X0 + T * ldi;      // [T][129]   hidden state
-  float* QKV = Hb + T * 129;     // [T][385]
-  float* CTX = QKV + T * 385;    // [T][129]
-  float* T1 = CTX + T * 129;     // [T][129]
-  float* S = T1 + T * 129;       // [NH*T*T]
-  float* IM = S + NH * T * T;    // [T][17]
+  float* Hb = X0 + T * ldi;      // [T][132]   hidden state
+  float* QKV = Hb + T * 132;     // [T][388]
+  float* CTX = QKV + T * 388;    // [T][132]
+  float* T1 = CTX + T * 132;     // [T][132]
+  float* S = T1 + T * 132;       // [NH*T*T]
+  float* IM = S + NH * T * T;    // [T][20]
   const int b = blockIdx.x;
-  for (int i = threadIdx.x; i < T * Din; i += 256) {
+  for (int i = threadIdx.x; i < T * Din; i += NTHR) {
     const int t = i / Din, k = i - t * Din;
     X0[t * ldi + k] = x[((long)b * T + t) * ldx + k];
   }
@@ -129,9 +165,9 @@ __global__ __launch_bounds__(256) void tr_encoder_kernel(const float* __restrict
   const float* bemb = Wemb + Din * H;
   const float* pos = bemb + H;
   // h = Linear(x) + pos : feed pos through the "add" operand (T1 <- pos)
-  for (int i = threadIdx.x; i < T * H; i += 256) T1[(i / H) * 129 + (i % H)] = pos[i];
+  for (int i = threadIdx.x; i < T * H; i += NTHR) T1[(i / H) * 132 + (i % H)] = pos[i];
   __syncthreads();
-  linear<0>(X0, ldi, Wemb, bemb, Din, H, Hb, 129, T1, 129, 1.0f);
+  linear<0>(X0, ldi, Wemb, bemb, Din, H, Hb, 132, T1, 132, 1.0f);
   __syncthreads();
   const float* L = pos + T * H;
   for (int l = 0; l < 4; ++l, L += ENC_LAYER) {
@@ -147,29 +183,29 @@ __global__ __launch_bounds__(256) void tr_encoder_kernel(const float* __restrict
     const float* bo2 = Wo2 + 16 * 128;
     const float* ln2w = bo2 + 128;
     const float* ln2b = ln2w + 128;
-    linear<0>(Hb, 129, Wqkv, bqkv, H, 384, QKV, 385, nullptr, 0, 1.0f);
+    linear<0>(Hb, 132, Wqkv, bqkv, H, 384, QKV, 388, nullptr, 0, 1.0f);
     __syncthreads();
-    attention(QKV, 385, QKV + 128, 385, QKV + 256, 385, 0.17677669529663687f /* 1/sqrt(32) */, S, CTX, 129);
-    linear<0>(CTX, 129, Wo, bo, H, H, T1, 129, Hb, 129, 1.0f);  // dense(ctx) + h
+    attention(QKV, 388, QKV + 128, 388, QKV + 256, 388, 0.17677669529663687f /* 1/sqrt(32) */, S, CTX, 132);
+    linear<0>(CTX, 132, Wo, bo, H, H, T1, 132, Hb, 132, 1.0f);  // dense(ctx) + h
     __syncthreads();
-    layernorm_tokens(T1, 129, ln1w, ln1b, 1e-12f, Hb, 129);     // h1
+    layernorm_tokens(T1, 132, ln1w, ln1b, 1e-12f, Hb, 132);     // h1
     __syncthreads();
-    linear<2>(Hb, 129, Wi, bi, H, 16, IM, 17, nullptr, 0, 1.0f);
+    linear<2>(Hb, 132, Wi, bi, H, 16, IM, 20, nullptr, 0, 1.0f);
     __syncthreads();
-    linear<0>(IM, 17, Wo2, bo2, 16, H, T1, 129, Hb, 129, 1.0f);  // dense(inter) + h1
+    linear<0>(IM, 20, Wo2, bo2, 16, H, T1, 132, Hb, 132, 1.0f);  // dense(inter) + h1
     __syncthreads();
-    layernorm_tokens(T1, 129, ln2w, ln2b, 1e-12f, Hb, 129);
+    layernorm_tokens(T1, 132, ln2w, ln2b, 1e-12f, Hb, 132);
     __syncthreads();
   }
   const float* Wcls = L;
   const float* bcls = Wcls + H * 3;
   const float* Wres = bcls + 3;
   const float* bres = Wres + Din * 3;
-  for (int i = threadIdx.x; i < T * H; i += 256) hout[(long)b * T * H + i] = Hb[(i / H) * 129 + (i % H)];
+  for (int i = threadIdx.x; i < T * H; i += NTHR) hout[(long)b * T * H + i] = Hb[(i / H) * 132 + (i % H)];
   if (threadIdx.x < T * 3) {
     const int t = threadIdx.x / 3, o = threadIdx.x - t * 3;
     float a = bcls[o];
-    for (int k = 0; k < H; ++k) a = fmaf(Hb[t * 129 + k], Wcls[k * 3 + o], a);
+    for (int k = 0; k < H; ++k) a = fmaf(Hb[t * 132 + k], Wcls[k * 3 + o], a);
     float r = bres[o];
     for (int k = 0; k < Din; ++k) r = fmaf(X0[t * ldi + k], Wres[k * 3 + o], r);
     score[((long)b * T + t) * 3 + o] = a + r;
@@ -179,16 +215,16 @@ __global__ __launch_bounds__(256) void tr_encoder_kernel(const float* __restrict
 
 // ---- packed decoder-layer weights --------------------------------------------------------------------------------
 // [qpos 21x128][kpos 21x128][Wq_t 128x128][bq 128][Wkv_t 128x256][bkv 256][Wo_t 128x128][bo 128][n2w][n2b][W1_t 128x128][b1][W2_t 128x128][b2][n3w][n3b]
-__global__ __launch_bounds__(256) void xattn_layer_kernel(const float* __restrict__ query, const float* __restrict__ key,
+__global__ __launch_bounds__(NTHR) void xattn_layer_kernel(const float* __restrict__ query, const float* __restrict__ key,
                                                           const float* __restrict__ W, float* __restrict__ out, int ldo, int ocoff) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* Q0 = sm;               // [T][129] un-embedded query (residual)
-  float* QE = Q0 + T * 129;     // [T][129] query + pos, later scratch
-  float* KE = QE + T * 129;     // [T][129] key + pos
-  float* Qp = KE + T * 129;     // [T][129] projected q
-  float* KV = Qp + T * 129;     // [T][257]
-  float* CTX = KV + T * 257;    // [T][129]
-  float* S = CTX + T * 129;     // [NH*T*T]
+  float* Q0 = sm;               // [T][132] un-embedded query (residual)
+  float* QE = Q0 + T * 132;     // [T][132] query + pos, later scratch
+  float* KE = QE + T * 132;     // [T][132] key + pos
+  float* Qp = KE + T * 132;     // [T][132] projected q
+  float* KV = Qp + T * 132;     // [T][260]
+  float* CTX = KV + T * 260;    // [T][132]
+  float* S = CTX + T * 132;     // [NH*T*T]
   const int b = blockIdx.x;
   const float* qpos = W;
   const float* kpos = qpos + T * H;
@@ -206,29 +242,29 @@ __global__ __launch_bounds__(256) void xattn_layer_kernel(const float* __restric
   const float* b2 = W2 + H * H;
   const float* n3w = b2 + H;
   const float* n3b = n3w + H;
-  for (int i = threadIdx.x; i < T * H; i += 256) {
+  for (int i = threadIdx.x; i < T * H; i += NTHR) {
     const int t = i / H, c = i - t * H;
     const float qv = query[(long)b * T * H + i], kv = key[(long)b * T * H + i];
-    Q0[t * 129 + c] = qv;
-    QE[t * 129 + c] = qv + qpos[i];
-    KE[t * 129 + c] = kv + kpos[i];
+    Q0[t * 132 + c] = qv;
+    QE[t * 132 + c] = qv + qpos[i];
+    KE[t * 132 + c] = kv + kpos[i];
   }
   __syncthreads();
-  linear<0>(QE, 129, Wq, bq, H, H, Qp, 129, nullptr, 0, 0.17677669529663687f);  // (Wq x + b) * head_dim^-1/2
-  linear<0>(KE, 129, Wkv, bkv, H, 256, KV, 257, nullptr, 0, 1.0f);
+  linear<0>(QE, 132, Wq, bq, H, H, Qp, 132, nullptr, 0, 0.17677669529663687f);  // (Wq x + b) * head_dim^-1/2
+  linear<0>(KE, 132, Wkv, bkv, H, 256, KV, 260, nullptr, 0, 1.0f);
   __syncthreads();
-  attention(Qp, 129, KV, 257, KV + 128, 257, 1.0f, S, CTX, 129);
-  linear<0>(CTX, 129, Wo, bo, H, H, QE, 129, Q0, 129, 1.0f);  // query + attn
+  attention(Qp, 132, KV, 260, KV + 128, 260, 1.0f, S, CTX, 132);
+  linear<0>(CTX, 132, Wo, bo, H, H, QE, 132, Q0, 132, 1.0f);  // query + attn
   __syncthreads();
-  layernorm_tokens(QE, 129, n2w, n2b, 1e-5f, Q0, 129);        // x = norm2(.)
+  layernorm_tokens(QE, 132, n2w, n2b, 1e-5f, Q0, 132);        // x = norm2(.)
   __syncthreads();
-  linear<1>(Q0, 129, W1, b1, H, H, CTX, 129, nullptr, 0, 1.0f);
+  linear<1>(Q0, 132, W1, b1, H, H, CTX, 132, nullptr, 0, 1.0f);
   __syncthreads();
-  linear<0>(CTX, 129, W2, b2, H, H, QE, 129, Q0, 129, 1.0f);
+  linear<0>(CTX, 132, W2, b2, H, H, QE, 132, Q0, 132, 1.0f);
   __syncthreads();
-  layernorm_tokens(QE, 129, n3w, n3b, 1e-5f, CTX, 129);
+  layernorm_tokens(QE, 132, n3w, n3b, 1e-5f, CTX, 132);
   __syncthreads();
-  for (int i = threadIdx.x; i < T * H; i += 256) out[((long)b * T + i / H) * ldo + ocoff + (i % H)] = CTX[(i / H) * 129 + (i % H)];
+  for (int i = threadIdx.x; i < T * H; i += NTHR) out[((long)b * T + i / H) * ldo + ocoff + (i % H)] = CTX[(i / H) * 132 + (i % H)];
 }
 
 }  // namespace
@@ -236,8 +272,8 @@ __global__ __launch_bounds__(256) void xattn_layer_kernel(const float* __restric
 extern "C" int kpf_tr_encoder_f32(const float* x, int ldx, int Din, const float* W, float* h, float* score, float* score2,
                                   int score2_ld, int B, void* stream) {
   KPF_REQUIRE(x && W && h && score && B > 0 && Din > 0 && Din <= 256 && ldx >= Din, "kpf_tr_encoder_f32: bad arguments");
-  const size_t lds = (size_t)(21 * (Din + 1) + 21 * 129 * 3 + 21 * 385 + 4 * 21 * 21 + 21 * 17) * sizeof(float);
-  hipLaunchKernelGGL(tr_encoder_kernel, dim3(B), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), x, ldx, Din, W, h, score,
+  const size_t lds = (size_t)(21 * ((Din + 3) & ~3) + 21 * 132 * 3 + 21 * 388 + 4 * 21 * 21 + 21 * 20) * sizeof(float);
+  hipLaunchKernelGGL(tr_encoder_kernel, dim3(B), dim3(NTHR), lds, reinterpret_cast<hipStream_t>(stream), x, ldx, Din, W, h, score,
                      score2, score2_ld);
   return kpf_check_launch("kpf_tr_encoder_f32");
 }
@@ -245,8 +281,8 @@ extern "C" int kpf_tr_encoder_f32(const float* x, int ldx, int Din, const float*
 extern "C" int kpf_xattn_layer_f32(const float* query, const float* key, const float* W, float* out, int out_ld, int out_coff, int B,
                                    void* stream) {
   KPF_REQUIRE(query && key && W && out && B > 0 && out_coff + 128 <= out_ld, "kpf_xattn_layer_f32: bad arguments");
-  const size_t lds = (size_t)(21 * 129 * 5 + 21 * 257 + 4 * 21 * 21) * sizeof(float);
-  hipLaunchKernelGGL(xattn_layer_kernel, dim3(B), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), query, key, W, out, out_ld,
+  const size_t lds = (size_t)(21 * 132 * 5 + 21 * 260 + 4 * 21 * 21) * sizeof(float);
+  hipLaunchKernelGGL(xattn_layer_kernel, dim3(B), dim3(NTHR), lds, reinterpret_cast<hipStream_t>(stream), query, key, W, out, out_ld,
                      out_coff);
   return kpf_check_launch("kpf_xattn_layer_f32");
 }
