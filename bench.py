@@ -40,6 +40,9 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--workload", default="backbones256", choices=["backbones256", "full128"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial-streams", action="store_true", help="issue both backbones on one stream (per-kernel profiling: rocprofv3 "
+                    "durations of overlapped kernels are otherwise shared-GPU durations)")
+    ap.add_argument("--graph", action="store_true", help="full128 only: replay the forward from a captured hipGraph")
     ap.add_argument("--per-launch", default="", help="write a per-launch table of the implicit-GEMM kernel to this file")
     ap.add_argument("--cpu-sample", type=int, default=8, help="images in the CPU-baseline sample")
     args = ap.parse_args()
@@ -70,6 +73,8 @@ def main():
     sd = {k: torch.from_numpy(v) for k, v in synthetic_state_dict(NET, 0).items()}
     model.load_state_dict(sd, strict=True)
     model = model.to(dev).eval()
+    model.use_graphs = bool(args.graph)
+    model._plan(dev).serial_streams = bool(args.serial_streams)
     hb = synthetic_batch(B, S, seed=1 + rank)
     batch = {k: torch.from_numpy(v).to(dev) for k, v in hb.items()}
 
@@ -104,56 +109,54 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt
 
-    # ---- instrumented pass: per-launch HIP events around every implicit-GEMM launch (same stream) ----
+    # ---- instrumented pass: per-launch HIP events around every MFMA-kernel launch (same stream, streams serialised) ----
     roofline = None
     if rank == 0:
-        recs = []
-        orig_conv = E.conv
-
-        def timed_conv(pc, x, *a, **k):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = orig_conv(pc, x, *a, **k)
-            e1.record()
-            if pc.merge > 1:
-                M = x.B * (x.H // pc.sh) * (x.W // pc.merge)
-            else:
-                M = x.B * ((x.H + 2 * pc.ph - pc.KH) // pc.sh + 1) * ((x.W + 2 * pc.pw - pc.KW) // pc.sw + 1)
-            # algorithmic bytes: input pixels once, weights once, output once (+ residual once)
-            ab = 4.0 * (x.B * x.H * x.W * x.C + pc.N * pc.K + M * pc.N * (2 if k.get("res") is not None else 1))
-            recs.append((e0, e1, pc.flops(M), (M, pc.N, pc.K, pc.KH, pc.KW), ab))
-            return out
-
-        E.conv = timed_conv
-        model._plan(dev).serial_streams = True  # one stream: per-launch durations are each kernel's own, not a shared GPU's
+        plan = model._plan(dev)
+        model.use_graphs = False  # the instrumented pass needs the individual launches
+        plan.serial_streams = True  # one stream: per-launch durations are each kernel's own, not a shared GPU's
         try:
+            E.PROFILE = []
             step()
             torch.cuda.synchronize()
-            recs.clear()
+            E.PROFILE = []
             step()
             torch.cuda.synchronize()
+            recs = E.PROFILE
         finally:
-            E.conv = orig_conv
-            model._plan(dev).serial_streams = False
-        t_ms = sum(r[0].elapsed_time(r[1]) for r in recs)
-        fl = sum(r[2] for r in recs)
+            E.PROFILE = None
+            plan.serial_streams = bool(args.serial_streams)
+        per = {}
+        for name, e0, e1, fl_i, nb, shp in recs:
+            d = per.setdefault(name, [0, 0.0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += e0.elapsed_time(e1)
+            d[2] += fl_i
+            d[3] += nb
         if args.per_launch:
             with open(args.per_launch, "w") as f:
-                f.write("M,N,K,KH,KW,ms,TFLOPs\n")
-                for e0, e1, fl_i, shp, _ in recs:
+                f.write("kernel,M,N,K,KH,KW,ms,TFLOPs\n")
+                for name, e0, e1, fl_i, nb, shp in recs:
                     ms = e0.elapsed_time(e1)
-                    f.write("%d,%d,%d,%d,%d,%.4f,%.1f\n" % (shp + (ms, fl_i / ms / 1e9)))
+                    f.write("%s,%d,%d,%d,%d,%d,%.4f,%.1f\n" % ((name,) + tuple(shp) + (ms, fl_i / ms / 1e9)))
+        dom = max(per, key=lambda k: per[k][1])  # dominant kernel by device time
+        n, t_ms, fl, nb = per[dom]
+        all_fl = sum(v[2] for v in per.values())
+        all_ms = sum(v[1] for v in per.values())
         ach = fl / (t_ms * 1e-3) / 1e12
         traffic = None  # HBM bytes per launch from the rocprofv3 PMC passes of this command (tools/collect_traffic.py), when committed
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if args.workload == "backbones256" and B == 64 and os.path.exists(tpath):
-            traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
-        roofline = {"bound": "mfma", "kernel": "igemm_f32_kernel", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+            tj = json.load(open(tpath))
+            if tj.get("kernel") == dom:
+                traffic = round(tj["hbm_bytes_per_launch"])
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                    "algo_bytes_per_launch": round(sum(r[4] for r in recs) / max(len(recs), 1)),
-                    "launches_per_step": len(recs), "avg_launch_ms": round(t_ms / max(len(recs), 1), 4),
+                    "algo_bytes_per_launch": round(nb / n), "launches_per_step": n, "avg_launch_ms": round(t_ms / n, 4),
                     "gflop_per_step": round(fl / 1e9, 1), "kernel_ms_per_step": round(t_ms, 3),
-                    "whole_step_tflops": round(fl / (ms_per_step * 1e-3) / 1e12, 2)}
+                    "all_mfma_kernels": {k: {"launches": v[0], "ms": round(v[1], 3), "tflops": round(v[2] / v[1] / 1e9, 2)} for k, v in per.items()},
+                    "all_mfma_tflops": round(all_fl / all_ms / 1e9, 2),
+                    "whole_step_tflops": round(all_fl / (ms_per_step * 1e-3) / 1e12, 2)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -68,6 +68,16 @@ int kpf_dwconv7_ln_f32(const float* x, const float* w_dw, const float* b_dw, con
                        float* y, int B, int H, int W, int C, float eps, void* stream);
 
 /*
+ * ConvNeXt block back half, fused: out = x + gamma * (W2 . GELU(W1 . y + b1) + b2)  (convNeXT/convnext.py:44-51: pwconv1, GELU,
+ * pwconv2, layer scale, residual).  y, x, out dense [M][C]; w1 [4C][C], w2 [C][4C] in PyTorch layout.  The 4C-wide hidden
+ * tensor never leaves registers.  Supported C: see kpf_convnext_mlp_supported(); other widths use two kpf_conv2d_f32 launches.
+ * out may alias x.
+ */
+int kpf_convnext_mlp_f32(const float* y, const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                         const float* gamma, float* out, long M, int C, void* stream);
+int kpf_convnext_mlp_supported(int C);
+
+/*
  * LayerNorm over the channel dimension of `rows` pixels (biased variance, (x-u)/sqrt(var+eps)*w+b).
  * Replaces convNeXT/convnext.py:205-214 in both data formats (stem/downsample norms).  In-place allowed.
  */

@@ -1,0 +1,247 @@
+// Fused ConvNeXt MLP (convNeXT/convnext.py:44-51):   out = x + gamma * ( W2 · GELU(W1 · y + b1) + b2 )
+// y = LayerNorm output [M][C], x = block input [M][C] (residual), W1 [4C][C], W2 [C][4C] in PyTorch layout, fp32.
+//
+// Why fuse: at C = 96/192 (the 64x64 and 32x32 stages of a 256x256 crop) the two GEMMs have K = C resp. N = C, only 3-6 K tiles
+// per output tile, so tile fill, epilogue and the 4C-wide hidden tensor's HBM round trip (402 MB written + 402 MB read per
+// block at B=64) cost as much as the MFMAs (measured 69-88 TF for the separate launches vs 100-119 TF for the large-K stages).
+// Fused, the hidden activations never leave registers:
+//   * a workgroup (4 waves) owns BM = 64*TM pixel rows; each WAVE owns 16*TM rows for ALL hidden and output channels, so no
+//     cross-wave exchange is needed.
+//   * the hidden dimension is processed in chunks of HC = 16*HT units.  GEMM1 (transposed issue: A operand = W1 fragment,
+//     B operand = y fragment) leaves acc1[ht][tm] with lane (pixel = lane&15, hidden = 16*ht + 4*(lane>>4) + r): exactly the
+//     activation-operand layout of a 16-deep k-step of GEMM2, so after bias+GELU the accumulator registers ARE the B operand
+//     of GEMM2 (acc2[n][tm] += W2frag[n] x h) — no LDS, no shuffle.
+//   * y tile stays in LDS for the whole tile; the W1 / W2 chunk pair is double-buffered and streamed by LDS-DMA
+//     (global_load_lds_dwordx4) one chunk ahead; weights are L2-resident (295 KB at C=96).
+//   * LDS images are row-major with the 16-byte chunk index XOR-swizzled per row (on the DMA source address) so that the
+//     ds_read_b128 fragment reads of 16 consecutive rows hit 16 different bank groups.
+#include "kpf_common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) void gbl_void_t;
+
+__device__ __attribute__((aligned(16))) float kpf_mlp_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+struct MlpArgs {
+  const float* y;
+  const float* x;
+  const float* w1;
+  const float* b1;
+  const float* w2;
+  const float* b2;
+  const float* gamma;
+  float* out;
+  const float* zero;
+  int M;
+};
+
+__device__ __forceinline__ float gelu_f(float x) {  // same evaluation as kpf_conv.hip (A&S 7.1.26 erfc form, |err| <= 1.5e-7)
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+  const float q = 0.5f * x * (p * t) * e;
+  return fmaxf(x, 0.f) - fabsf(q);
+}
+
+// row swizzle for rows of RC 16-byte chunks: makes 16 consecutive rows at one logical chunk land in 16 distinct 16-byte slots
+// of the 256-byte bank row
+template <int RC>
+__device__ __forceinline__ int row_sw(int r) {
+  static_assert(RC % 8 == 0, "row length must be a multiple of 32 floats");
+  return (RC % 16 == 0) ? (r & 15) : ((r >> 1) & 7);
+}
+
+// DMA a [ROWS][RC chunks] image: LDS linear (row-major, swizzled chunk positions), source rows at src + row*src_ld (floats);
+// rows >= valid_rows read the zero page.  All NT threads take part; ROWS*RC must be a multiple of NT.
+template <int ROWS, int RC, int NT>
+__device__ __forceinline__ void dma_image(float* lds_dst, const float* src, long src_ld, int valid_rows, const float* zero, int tid) {
+  static_assert((ROWS * RC) % NT == 0, "image must be a whole number of workgroup-wide passes");
+  constexpr int PASSES = ROWS * RC / NT;
+  const int wave = tid >> 6;
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    const int pos = p * NT + tid;  // 16-byte slot index in the LDS image
+    const int r = pos / RC, cp = pos - r * RC;
+    const int c = cp ^ row_sw<RC>(r);
+    const float* s = r < valid_rows ? src + (long)r * src_ld + 4 * c : zero;
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)s, (lds_void_t*)(lds_dst + (p * NT + wave * 64) * 4), 16, 0, 0);
+  }
+}
+
+template <int NC, int TM, int HT, int NW>
+__global__ __launch_bounds__(64 * NW) void convnext_mlp_kernel(const MlpArgs a) {
+  constexpr int NT = 64 * NW;    // NW = 8: two waves per SIMD, so one wave's GELU (VALU) and LDS waits run under its partner's MFMAs
+  constexpr int C = 16 * NC;     // channels
+  constexpr int H4 = 4 * C;      // hidden width
+  constexpr int HC = 16 * HT;    // hidden units per chunk
+  constexpr int BM = 16 * TM * NW;  // pixel rows per workgroup
+  constexpr int RCY = C / 4;     // 16-byte chunks per y / W1 row
+  constexpr int RCW = HC / 4;    // 16-byte chunks per W2-chunk row
+  constexpr int NCH = H4 / HC;   // chunks
+  constexpr int YF = BM * C, W1F = HC * C, W2F = C * HC;  // floats per image
+  static_assert(H4 % HC == 0, "chunking");
+
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Ys = lds;                   // [BM][C]
+  float* W1s = Ys + YF;              // [2][HC][C]
+  float* W2s = W1s + 2 * W1F;        // [2][C][HC]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const long m0 = (long)blockIdx.x * BM;
+  const int valid = (int)((a.M - m0) < BM ? (a.M - m0) : BM);
+
+  dma_image<BM, RCY, NT>(Ys, a.y + m0 * C, C, valid, a.zero, tid);
+  dma_image<HC, RCY, NT>(W1s, a.w1, C, HC, a.zero, tid);
+  dma_image<C, RCW, NT>(W2s, a.w2, H4, C, a.zero, tid);
+
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc2[NC][TM];
+#pragma unroll
+  for (int n = 0; n < NC; ++n)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc2[n][j] = zero4;
+
+  __syncthreads();
+
+  const int yrow0 = wave * TM * 16 + fr;  // this lane's first y row
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int cur = ch & 1;
+    if (ch + 1 < NCH) {  // next chunk's weights fly into the other buffers under this chunk's MFMAs
+      dma_image<HC, RCY, NT>(W1s + (cur ^ 1) * W1F, a.w1 + (long)(ch + 1) * HC * C, C, HC, a.zero, tid);
+      dma_image<C, RCW, NT>(W2s + (cur ^ 1) * W2F, a.w2 + (long)(ch + 1) * HC, H4, C, a.zero, tid);
+    }
+    const float* w1b = W1s + cur * W1F;
+    const float* w2b = W2s + cur * W2F;
+
+    // ---- GEMM1: acc1[ht][tm] = W1chunk (HC x C) . y^T ----
+    f32x4 acc1[HT][TM];
+#pragma unroll
+    for (int h = 0; h < HT; ++h)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc1[h][j] = zero4;
+#pragma unroll
+    for (int s = 0; s < NC; ++s) {  // 16-deep k-steps over the C input channels
+      f32x4 yf[TM], wf[HT];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int r = yrow0 + j * 16;
+        yf[j] = *reinterpret_cast<const f32x4*>(Ys + r * C + (((4 * s + fg) ^ row_sw<RCY>(r)) << 2));
+      }
+#pragma unroll
+      for (int h = 0; h < HT; ++h) {
+        const int r = h * 16 + fr;
+        wf[h] = *reinterpret_cast<const f32x4*>(w1b + r * C + (((4 * s + fg) ^ row_sw<RCY>(r)) << 2));
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int h = 0; h < HT; ++h)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) acc1[h][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[h][e], yf[j][e], acc1[h][j], 0, 0, 0);
+    }
+
+    // ---- bias + GELU in registers; GEMM2: acc2[n][tm] += W2chunk (C x HC) . h ----
+#pragma unroll
+    for (int h = 0; h < HT; ++h) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(a.b1 + ch * HC + h * 16 + 4 * fg);
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc1[h][j][e] = gelu_f(acc1[h][j][e] + bv[e]);
+      f32x4 wf[NC];
+#pragma unroll
+      for (int n = 0; n < NC; ++n) {
+        const int r = n * 16 + fr;
+        wf[n] = *reinterpret_cast<const f32x4*>(w2b + r * HC + (((4 * h + fg) ^ row_sw<RCW>(r)) << 2));
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int n = 0; n < NC; ++n)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) acc2[n][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n][e], acc1[h][j][e], acc2[n][j], 0, 0, 0);
+    }
+    __syncthreads();  // next chunk's weights landed; everyone is done with the current buffers
+  }
+
+  // ---- epilogue: out = x + gamma * (acc2 + b2); lane owns channels n*16 + 4*fg .. +3 of pixel row ----
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const long m = m0 + wave * TM * 16 + j * 16 + fr;
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int n = 0; n < NC; ++n) {
+      const int c = n * 16 + 4 * fg;
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(a.b2 + c);
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(a.gamma + c);
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + m * C + c);
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = xv[e] + gv[e] * (acc2[n][j][e] + bv[e]);
+      *reinterpret_cast<f32x4*>(a.out + m * C + c) = v;
+    }
+  }
+}
+
+template <int NC, int TM, int HT, int NW>
+int launch_mlp(MlpArgs& a, hipStream_t st) {
+  constexpr int C = 16 * NC, HC = 16 * HT, BM = 16 * TM * NW;
+  const size_t lds = (size_t)(BM * C + 2 * HC * C + 2 * C * HC) * sizeof(float);
+  auto kern = convnext_mlp_kernel<NC, TM, HT, NW>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      kpf_set_error("kpf_convnext_mlp_f32: cannot raise the dynamic LDS limit");
+      return KPF_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  const long tiles = (a.M + BM - 1) / BM;
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64 * NW), lds, st, a);
+  return kpf_check_launch("kpf_convnext_mlp_f32");
+}
+
+}  // namespace
+
+// 192 is implemented (4-wave variant: a 128-row y tile does not fit beside the weight ring) but measured slower than the two plain
+// GEMM launches at that width (93 vs 102 TF), so it is not advertised; kpf_convnext_mlp_f32 still accepts it.
+extern "C" int kpf_convnext_mlp_supported(int C) { return C == 96 || C == 128; }
+
+extern "C" int kpf_convnext_mlp_f32(const float* y, const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                                    const float* gamma, float* out, long M, int C, void* stream) {
+  KPF_REQUIRE(y && x && w1 && b1 && w2 && b2 && gamma && out && M > 0, "kpf_convnext_mlp_f32: null pointer / empty");
+  KPF_REQUIRE(C == 96 || C == 128 || C == 192, "kpf_convnext_mlp_f32: C=%d not supported (96, 128, 192)", C);
+  KPF_REQUIRE(M < (1l << 31), "kpf_convnext_mlp_f32: too many rows");
+  KPF_REQUIRE(kpf_aligned16(y) && kpf_aligned16(x) && kpf_aligned16(w1) && kpf_aligned16(w2) && kpf_aligned16(out) && kpf_aligned16(b1) &&
+                  kpf_aligned16(b2) && kpf_aligned16(gamma),
+              "kpf_convnext_mlp_f32: pointers must be 16-byte aligned");
+  MlpArgs a;
+  a.y = y; a.x = x; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.gamma = gamma; a.out = out; a.M = (int)M;
+  {
+    static const float* zero_of_dev[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!zero_of_dev[dev]) {
+      void* p = nullptr;
+      if (hipGetSymbolAddress(&p, HIP_SYMBOL(kpf_mlp_zero16)) != hipSuccess || !p) {
+        kpf_set_error("kpf_convnext_mlp_f32: cannot resolve the zero page");
+        return KPF_ELAUNCH;
+      }
+      zero_of_dev[dev] = static_cast<const float*>(p);
+    }
+    a.zero = zero_of_dev[dev];
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  switch (C) {
+    case 96: return launch_mlp<6, 1, 4, 8>(a, st);    // 8 waves, BM 128, HC 64: 48 + 96 KB LDS
+    case 128: return launch_mlp<8, 1, 2, 8>(a, st);   // 8 waves, BM 128, HC 32: 64 + 64 KB
+    default: return launch_mlp<12, 1, 2, 4>(a, st);   // C = 192: 4 waves, BM 64, HC 32: 48 + 96 KB (a 128-row y tile would not fit)
+  }
+}

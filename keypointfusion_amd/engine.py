@@ -18,6 +18,23 @@ from . import lib as L
 from .spec import CONVNEXT, parse_net
 
 BN_EPS = 1e-5
+FORCE_UNFUSED_MLP = bool(int(__import__("os").environ.get("KPF_UNFUSED_MLP", "0")))  # A/B switch for tuning
+
+
+# Per-launch profiling hook (bench.py): when PROFILE is a list, every MFMA-kernel launch is bracketed by HIP events recorded on
+# the launch stream and appended as (kernel, start_event, end_event, algorithmic_flops, algorithmic_bytes, shape).
+PROFILE = None
+
+
+def _launch(kernel, flops, nbytes, shape, fn):
+    if PROFILE is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    PROFILE.append((kernel, e0, e1, flops, nbytes, shape))
+    return r
 
 
 def _ptr(t):
@@ -143,8 +160,12 @@ def conv(pc, x, out=None, flags=0, gamma=None, res=None, out_nchw=None):
     if gamma is not None:
         flags |= L.KPF_RES_GAMMA
     d.flags = flags
-    L.check(lib.kpf_conv2d_f32(C.byref(d), _ptr(x.buf), _ptr(pc.w), _ptr(pc.b), _ptr(pc.ps), _ptr(pc.pt), _ptr(gamma),
-                               _ptr(res.buf if res is not None else None), _ptr(optr), _stream()), "kpf_conv2d_f32")
+    M = B * OH * OW
+    # algorithmic bytes: input pixels once, weights once, output once (+ residual once)
+    nbytes = 4.0 * (B * IH * IW * pc.Cin + pc.N * pc.K + M * pc.N * (2 if res is not None else 1))
+    _launch("igemm_f32_kernel", pc.flops(M), nbytes, (M, pc.N, pc.K, pc.KH, pc.KW),
+            lambda: L.check(lib.kpf_conv2d_f32(C.byref(d), _ptr(x.buf), _ptr(pc.w), _ptr(pc.b), _ptr(pc.ps), _ptr(pc.pt), _ptr(gamma),
+                                               _ptr(res.buf if res is not None else None), _ptr(optr), _stream()), "kpf_conv2d_f32"))
     return out
 
 
@@ -240,11 +261,24 @@ class ConvNeXtBlockPlan:
         self.pw1 = PackedConv(sd[p + ".pwconv1.weight"], sd[p + ".pwconv1.bias"], device)
         self.pw2 = PackedConv(sd[p + ".pwconv2.weight"], sd[p + ".pwconv2.bias"], device)
         self.gamma = sd[p + ".gamma"].detach().float().to(device)
+        self.fused = bool(L.load().kpf_convnext_mlp_supported(c))
+        if self.fused:  # fused MLP kernel takes the PyTorch layouts as they are
+            self.w1 = sd[p + ".pwconv1.weight"].detach().float().contiguous().to(device)
+            self.b1 = sd[p + ".pwconv1.bias"].detach().float().contiguous().to(device)
+            self.w2 = sd[p + ".pwconv2.weight"].detach().float().contiguous().to(device)
+            self.b2 = sd[p + ".pwconv2.bias"].detach().float().contiguous().to(device)
 
     def __call__(self, x, y, h):
         lib = L.load()
         L.check(lib.kpf_dwconv7_ln_f32(_ptr(x.buf), _ptr(self.wdw), _ptr(self.bdw), _ptr(self.lnw), _ptr(self.lnb),
                                        _ptr(y.buf), x.B, x.H, x.W, x.C, 1e-6, _stream()), "kpf_dwconv7_ln_f32")
+        if self.fused and not FORCE_UNFUSED_MLP:
+            M, Cc = x.B * x.H * x.W, x.C
+            _launch("convnext_mlp_kernel", 16.0 * M * Cc * Cc, 4.0 * (3 * M * Cc + 8 * Cc * Cc), (M, Cc, 4 * Cc, 1, 1),
+                    lambda: L.check(lib.kpf_convnext_mlp_f32(_ptr(y.buf), _ptr(x.buf), _ptr(self.w1), _ptr(self.b1), _ptr(self.w2),
+                                                             _ptr(self.b2), _ptr(self.gamma), _ptr(x.buf), M, Cc, _stream()),
+                                    "kpf_convnext_mlp_f32"))
+            return x
         conv(self.pw1, y, out=h, flags=L.KPF_ACT_GELU)
         conv(self.pw2, h, out=x, gamma=self.gamma, res=x)
         return x
@@ -500,6 +534,7 @@ class ModelPlan:
         self.backbone_d = UNetPlan(sd, "backbone_d", net, device)
         self.backbone_rgb = UNetPlan(sd, "backbone_rgb", net, device)
         self.blocks = [FusionBlockPlan(sd, "block%d" % i, device) for i in (1, 2)]
+        self._graphs = {}  # (B, S, N, img_size, flip, kernel) -> (hipGraph, static inputs, static outputs)
         self._side = None  # second HIP stream: the RGB backbone runs beside the depth backbone
         self.serial_streams = False  # profiling aid: issue both backbones on one stream so per-kernel timings are not shared
 
@@ -520,6 +555,34 @@ class ModelPlan:
         for t in (out_rgb[0], out_rgb[1].buf):  # allocated on the side stream, consumed on the caller's stream
             t.record_stream(cur)
         return out_d, out_rgb
+
+    def forward_graphed(self, img_rgb, img, pcl, center, M, cube, cam, kernel, img_size, flip):
+        """Same as forward(), replayed from a captured hipGraph: at small batch the ~300 launches of one forward are host-bound
+        (3.9 ms at B=1 vs ~1 ms of device time), a graph replay costs one submission.  One graph per input shape; inputs are
+        copied into the graph's static buffers, outputs are returned as copies."""
+        ins = [t.detach().to(device=self.device, dtype=torch.float32).contiguous() for t in (img_rgb, img, pcl, center, M, cube, cam)]
+        key = tuple(tuple(t.shape) for t in ins) + (kernel, img_size, flip)
+        ent = self._graphs.get(key)
+        if ent is None:
+            static = [t.clone() for t in ins]
+            cur = torch.cuda.current_stream(self.device)
+            warm = torch.cuda.Stream(device=self.device)
+            warm.wait_stream(cur)
+            with torch.cuda.stream(warm):  # eager warm-up: one-time attribute / symbol lookups must not happen under capture
+                self.forward(*static, kernel, img_size, flip)
+                self.forward(*static, kernel, img_size, flip)
+            cur.wait_stream(warm)
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                res, sws, _ = self.forward(*static, kernel, img_size, flip)
+            ent = (graph, static, res, sws)
+            self._graphs[key] = ent
+        graph, static, res, sws = ent
+        for d, t in zip(static, ins):
+            d.copy_(t)
+        graph.replay()
+        return [t.clone() for t in res], [t.clone() for t in sws], None
 
     def forward(self, img_rgb, img, pcl, center, M, cube, cam, kernel, img_size, flip, want_aux=False):
         lib = L.load()

@@ -42,6 +42,8 @@ _SIGS = {
     "kpf_gate_reduce_f32": [_P, _P, _P, _P, _P, C.c_int, C.c_int, _P],
     "kpf_tr_encoder_f32": [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, _P],
     "kpf_xattn_layer_f32": [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_convnext_mlp_f32": [_P] * 8 + [C.c_long, C.c_int, _P],
+    "kpf_convnext_mlp_supported": [C.c_int],
     "kpf_tr_encoder_weight_floats": [C.c_int],
     "kpf_xattn_weight_floats": [],
 }

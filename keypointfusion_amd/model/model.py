@@ -57,6 +57,7 @@ class KPFusion(nn.Module):
             _attach(self, name, val, is_buffer)
         self._plans = {}
         self._plan_lock = threading.Lock()
+        self.use_graphs = False  # opt-in: replay each forward from a captured hipGraph (eval / no_grad, fixed shapes)
 
     # -- weight repacking ------------------------------------------------------------------------------------
     def _state_version(self):
@@ -106,4 +107,6 @@ class KPFusion(nn.Module):
         flip = int(getattr(loader, "flip", 1))
         plan = self._plan(img.device)
         with torch.cuda.device(img.device):
+            if self.use_graphs and not torch.is_grad_enabled():
+                return plan.forward_graphed(img_rgb, img, pcl, center, M, cube, cam_para, float(kernel), img_size, flip)
             return plan.forward(img_rgb, img, pcl, center, M, cube, cam_para, float(kernel), img_size, flip)

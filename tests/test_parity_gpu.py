@@ -372,3 +372,48 @@ def test_module_boundary_forward_signature_and_errors():
     big = {k: torch.from_numpy(v).to(dev) for k, v in synthetic_batch(1, 256, seed=2).items()}
     with pytest.raises(RuntimeError):
         m(big["img_rgb"], big["img"], big["pcl"], Loader(), big["center"], big["M"], big["cube"], big["cam_para"], 0.8)
+
+
+def test_graph_replay_equals_eager():
+    """hipGraph replay of the whole forward (opt-in, small-batch latency path) returns exactly what the eager launches return,
+    also after the inputs change (static-buffer copy) — the graph holds no stale pointers."""
+    m = _model("convnext-tiny")
+    dev = _dev()
+
+    class Loader:
+        img_size, flip = 128, 1
+
+    outs = []
+    for seed in (3, 4):
+        b = {k: torch.from_numpy(v).to(dev) for k, v in synthetic_batch(2, 128, seed=seed).items()}
+        args = [b["img_rgb"], b["img"], b["pcl"], Loader(), b["center"], b["M"], b["cube"], b["cam_para"], 0.8]
+        with torch.no_grad():
+            m.use_graphs = False
+            eager = m(*args)
+            m.use_graphs = True
+            graphed = m(*args)
+        m.use_graphs = False
+        for a, g in zip(eager[0] + eager[1], graphed[0] + graphed[1]):
+            assert torch.equal(a, g)
+        outs.append(graphed[0][5].clone())
+    assert not torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("C,M", [(96, 128 * 3 + 37), (128, 64 * 5), (192, 64 * 2 + 5)])
+def test_fused_convnext_mlp(C, M):
+    """kpf_convnext_mlp_f32 == x + gamma * pwconv2(gelu(pwconv1(y))) (convNeXT/convnext.py:44-51), ragged row count, in place."""
+    from keypointfusion_amd import engine as E, lib as L
+    dev = _dev()
+    g = torch.Generator().manual_seed(C + M)
+    y = torch.randn(M, C, generator=g)
+    x = torch.randn(M, C, generator=g)
+    w1 = torch.randn(4 * C, C, generator=g) / C ** 0.5
+    b1 = torch.randn(4 * C, generator=g) * 0.5
+    w2 = torch.randn(C, 4 * C, generator=g) / (4 * C) ** 0.5
+    b2 = torch.randn(C, generator=g)
+    gam = torch.rand(C, generator=g)
+    ref = x + gam * F.linear(F.gelu(F.linear(y, w1, b1)), w2, b2)
+    d = [t.to(dev) for t in (y, x, w1, b1, w2, b2, gam)]
+    L.check(L.load().kpf_convnext_mlp_f32(*[E._ptr(t) for t in d], E._ptr(d[1]), M, C, E._stream()))
+    torch.cuda.synchronize()
+    assert rel_err(d[1], ref) < 1e-5

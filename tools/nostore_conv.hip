@@ -24,7 +24,7 @@
 //  * Prologue: eval-BatchNorm + ReLU of the *input* (pre-activation Residual, model/hourglass.py:106-108) is applied to
 //    the activation fragments after the LDS read (scale/shift table in LDS).  Epilogues are compiled per kind (linear/ReLU,
 //    GELU, residual) with an unguarded float4 fast path for interior tiles.
-#include "kpf_common.h"
+#include "../keypointfusion_amd/csrc/kpf_common.h"
 #include <stdlib.h>
 
 namespace {
@@ -65,9 +65,6 @@ __device__ __forceinline__ float gelu_erf(float x) {
 }
 
 enum { EPI_LIN = 0, EPI_GELU = 1, EPI_RES = 2 };
-#ifndef STORE4
-#define STORE4(p, v) *reinterpret_cast<f32x4*>(p) = (v)
-#endif
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) void gbl_void_t;
@@ -236,18 +233,16 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const ConvArgs 
   const unsigned fl = a.flags;
   const bool interior = (m0 + BM <= a.M) && (n0 + BN <= a.N) && a.vec && !(fl & KPF_OUT_NCHW);  // workgroup-uniform
   if (interior) {
-    // fast path: whole tile in range and 16-byte aligned -> no per-element guards, float4 bias / gamma / residual / store.
-    // Pixel tiles outermost: a wave's consecutive store instructions then cover the same 16 rows' adjacent 64-byte segments,
-    // so L2 merges them into whole 128-byte lines before write-back.
+    // fast path: whole tile in range and 16-byte aligned -> no per-element guards, float4 bias / gamma / residual / store
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      const long m = m0 + (wm * TM + j) * 16 + fr;
+    for (int i = 0; i < TN; ++i) {
+      const int n = n0 + (wn * TN + i) * 16 + fg * 4;
+      f32x4 bv = zero4, gv = zero4;
+      if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+      if (EPI == EPI_RES && (fl & KPF_RES_GAMMA)) gv = *reinterpret_cast<const f32x4*>(a.gamma + n);
 #pragma unroll
-      for (int i = 0; i < TN; ++i) {
-        const int n = n0 + (wn * TN + i) * 16 + fg * 4;
-        f32x4 bv = zero4, gv = zero4;
-        if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
-        if (EPI == EPI_RES && (fl & KPF_RES_GAMMA)) gv = *reinterpret_cast<const f32x4*>(a.gamma + n);
+      for (int j = 0; j < TM; ++j) {
+        const long m = m0 + (wm * TM + j) * 16 + fr;
         f32x4 v = acc[i][j];
         if (EPI == EPI_RES) {
           const f32x4 rv = *reinterpret_cast<const f32x4*>(a.res + m * a.res_ld + a.res_coff + n);
@@ -269,7 +264,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const ConvArgs 
             v[e] = (fl & KPF_ACT_RELU) ? fmaxf(y, 0.f) : y;
           }
         }
-        STORE4(a.out + m * a.out_ld + a.out_coff + n, v);
+        asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
       }
     }
     return;

@@ -24,7 +24,7 @@
 //  * Prologue: eval-BatchNorm + ReLU of the *input* (pre-activation Residual, model/hourglass.py:106-108) is applied to
 //    the activation fragments after the LDS read (scale/shift table in LDS).  Epilogues are compiled per kind (linear/ReLU,
 //    GELU, residual) with an unguarded float4 fast path for interior tiles.
-#include "kpf_common.h"
+#include "../keypointfusion_amd/csrc/kpf_common.h"
 #include <stdlib.h>
 
 namespace {
@@ -65,6 +65,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
 }
 
 enum { EPI_LIN = 0, EPI_GELU = 1, EPI_RES = 2 };
+#define STORE4(p, v) __builtin_nontemporal_store((v), reinterpret_cast<f32x4*>(p))
 #ifndef STORE4
 #define STORE4(p, v) *reinterpret_cast<f32x4*>(p) = (v)
 #endif
