@@ -99,6 +99,11 @@ class KPFusion(nn.Module):
 
     def forward(self, img_rgb, img, pcl, loader, center, M, cube, cam_para, kernel=0.8, writer=None, ii=0):
         self._require_gpu(img)
+        if self.training:
+            # train-mode semantics (batch-statistics BatchNorm, dropout, autograd through every kernel) are SURVEY §8 row f1 and
+            # are not built; silently running eval arithmetic under model.train() would be a wrong answer, so refuse.
+            raise NotImplementedError("keypointfusion_amd.KPFusion implements the inference forward: call .eval() "
+                                      "(the training step is not built yet)")
         if img.shape[-1] != 128:
             # the reference hard-codes nn.Linear(32*32, 1) (model/model.py:264): the full model exists at S=128 only
             raise RuntimeError("mat1 and mat2 shapes cannot be multiplied: the fusion block needs 128x128 crops "

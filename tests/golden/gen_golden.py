@@ -174,9 +174,31 @@ def run_backbone(net, B=1, S=64):
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
 
 
+def run_metrics():
+    """Metric known-answers from the reference's own numpy code (util/generateFeature.GFM.rigid_align, util/eval_utils)."""
+    ref_import.install_shims()
+    if ref_import.REF_ROOT not in sys.path:
+        sys.path.insert(0, ref_import.REF_ROOT)
+    from util.generateFeature import GFM
+    from util import eval_utils
+    rng = np.random.default_rng(5)
+    A = rng.normal(size=(4, 21, 3))
+    Bm = A * 1.3 + rng.normal(size=(4, 21, 3)) * 0.05 + np.array([0.2, -0.1, 0.4])
+    Bm[1] = Bm[1] * np.array([1, 1, -1])  # forces the reflection branch (det < 0)
+    g = GFM()
+    aligned = np.stack([g.rigid_align(A[i], Bm[i]) for i in range(4)])
+    errs = [list(rng.gamma(2.0, 6.0, size=200)) for _ in range(21)]
+    auc, curve, th = eval_utils.get_measures(errs, 0, 50, 20)
+    sub = eval_utils.calc_auc(th[8:] * 1000.0, curve[8:])
+    path = os.path.join(HERE, "metrics.npz")
+    np.savez_compressed(path, A=A, B=Bm, aligned=aligned, errs=np.array(errs), auc=auc, curve=curve, th=th, sub=sub)
+    print("wrote", path)
+
+
 if __name__ == "__main__":
     if not ref_import.reference_available():
         sys.exit("reference tree not found; golden vectors can only be generated in the build container")
     for net in ("KPFusion-convnext-tiny", "KPFusion-resnet-18"):
         run(net)
         run_backbone(net)
+    run_metrics()
