@@ -53,7 +53,7 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         sys.exit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("KPF_BENCH_FORCE_DIST"):  # (the env switch exercises the RCCL path on a 1-GPU box)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)

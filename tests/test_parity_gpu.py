@@ -187,7 +187,8 @@ def _model(net):
     return m.to(_dev()).eval()
 
 
-@pytest.mark.parametrize("net,B,S", [("convnext-tiny", 2, 128), ("convnext-tiny", 1, 64), ("resnet-18", 2, 128), ("resnet-18", 1, 64)])
+@pytest.mark.parametrize("net,B,S", [("convnext-tiny", 2, 128), ("convnext-tiny", 1, 64), ("resnet-18", 2, 128), ("resnet-18", 1, 64),
+                                     ("convnext-base", 1, 64), ("convnext-small", 1, 64), ("convnext-tiny", 3, 96)])
 def test_backbones_match_oracle(net, B, S):
     from oracle import kpf_oracle as O
     sd = synthetic_sd("KPFusion-" + net)
@@ -201,7 +202,7 @@ def test_backbones_match_oracle(net, B, S):
         assert e < 1e-3, "%s: rel err %.2e" % (name, e)  # north_star tolerance
         assert e < 2e-4, "%s: rel err %.2e (regression guard)" % (name, e)
     # against the committed reference-generated fixture as well (S=64 fixture holds full img_offset tensors)
-    if S == 64:
+    if S == 64 and net in ("convnext-tiny", "resnet-18"):
         z = np.load(os.path.join(GOLDEN, "backbone_%s_B1_S64.npz" % net))
         assert rel_err(out[0], torch.from_numpy(z["img_offset"])) < 1e-3
         assert rel_err(out[2], torch.from_numpy(z["img_offset_rgb"])) < 1e-3
