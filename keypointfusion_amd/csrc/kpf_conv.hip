@@ -113,67 +113,71 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const ConvArgs 
   const int lr = tid >> 3;                          // row within a staging pass; a wave owns rows 8*wave .. 8*wave+7
   const int kc = (((tid & 7) ^ (lr & 7)) << 2);     // logical k offset (floats) this lane fetches within the K tile
 
+  // IS1X1 (dense 1x1, stride 1, K % 32 == 0): one source pointer per staging pass, fixed for the whole K loop and advanced by the
+  // K-tile offset — the per-tile address arithmetic is two VALU ops per DMA.  Rows beyond M / channels beyond N are clamped to
+  // the last valid row (their products land in accumulator rows/columns the epilogue never stores), so no zero page is needed.
+  // General convolution: receptive-field origin per staged row, tap decoded per K tile, zero page outside the image / K range.
+  const float* pa[AP];
+  const float* pb[BP];
   int rbase[AP], riy[AP], rix[AP];
 #pragma unroll
   for (int p = 0; p < AP; ++p) {
     const int m = m0 + lr + RPP * p;
-    if (m < a.M && lr + RPP * p < BM) {
-      if (IS1X1) {
-        rbase[p] = m;
-        riy[p] = 0;
-        rix[p] = 0;
-      } else {
-        const int b = m / a.ohow;
-        const int r = m - b * a.ohow;
-        const int oy = r / a.OW;
-        const int ox = r - oy * a.OW;
-        rbase[p] = b * a.IH * a.IW;
-        riy[p] = oy * a.sh - a.ph;
-        rix[p] = ox * a.sw - a.pw;
-      }
+    if (IS1X1) {
+      const int mc = m < a.M ? m : a.M - 1;
+      pa[p] = a.in + (long)mc * a.in_ld + a.in_coff + kc;
+      rbase[p] = riy[p] = rix[p] = 0;
+    } else if (m < a.M && lr + RPP * p < BM) {
+      const int b = m / a.ohow;
+      const int r = m - b * a.ohow;
+      const int oy = r / a.OW;
+      const int ox = r - oy * a.OW;
+      rbase[p] = b * a.IH * a.IW;
+      riy[p] = oy * a.sh - a.ph;
+      rix[p] = ox * a.sw - a.pw;
     } else {
       rbase[p] = -1;
       riy[p] = 0;
       rix[p] = 0;
     }
   }
+#pragma unroll
+  for (int p = 0; p < BP; ++p) {
+    const int n = n0 + lr + RPP * p;
+    const int nc = n < a.N ? n : a.N - 1;
+    pb[p] = a.w + (long)nc * a.Kp + kc;
+  }
 
   auto stage = [&](int kt, int buf) {
     float* As = lds + buf * TILE;
     float* Bs = As + BM * BK;
-    const int k = kt * BK + kc;
-    const bool kvalid = k < a.K;
-    int c = k, ky = 0, kx = 0;
-    if (!IS1X1) {
+    if (IS1X1) {
+#pragma unroll
+      for (int p = 0; p < AP; ++p)
+        if (RPP * p + 8 * wave < BM)  // wave-uniform
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)(pa[p] + kt * BK), (lds_void_t*)(As + (RPP * p + 8 * wave) * BK), 16, 0, 0);
+    } else {
+      const int k = kt * BK + kc;
+      const bool kvalid = k < a.K;
       const int tap = k / a.Cin;
-      c = k - tap * a.Cin;
-      ky = tap / a.KW;
-      kx = tap - ky * a.KW;
-    }
+      const int c = k - tap * a.Cin;
+      const int ky = tap / a.KW;
+      const int kx = tap - ky * a.KW;
 #pragma unroll
-    for (int p = 0; p < AP; ++p) {
-      if (RPP * p + 8 * wave < BM) {  // wave-uniform
-        bool v = kvalid && rbase[p] >= 0;
-        long off;
-        if (IS1X1) {
-          off = (long)rbase[p] * a.in_ld + a.in_coff + c;
-        } else {
+      for (int p = 0; p < AP; ++p) {
+        if (RPP * p + 8 * wave < BM) {  // wave-uniform
           const int iy = riy[p] + ky, ix = rix[p] + kx;
-          v = v && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
-          off = ((long)rbase[p] + (long)iy * a.IW + ix) * a.in_ld + a.in_coff + c;
+          const bool v = kvalid && rbase[p] >= 0 && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+          const long off = ((long)rbase[p] + (long)iy * a.IW + ix) * a.in_ld + a.in_coff + c;
+          const float* src = v ? a.in + off : a.zero;
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(As + (RPP * p + 8 * wave) * BK), 16, 0, 0);
         }
-        const float* src = v ? a.in + off : a.zero;
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(As + (RPP * p + 8 * wave) * BK), 16, 0, 0);
       }
     }
 #pragma unroll
-    for (int p = 0; p < BP; ++p) {
-      if (RPP * p + 8 * wave < BN) {  // wave-uniform: BN is a multiple of 8
-        const int n = n0 + lr + RPP * p;
-        const float* src = (n < a.N) ? a.w + ((long)n * a.Kp + k) : a.zero;
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(Bs + (RPP * p + 8 * wave) * BK), 16, 0, 0);
-      }
-    }
+    for (int p = 0; p < BP; ++p)
+      if (RPP * p + 8 * wave < BN)  // wave-uniform: BN is a multiple of 8
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(pb[p] + kt * BK), (lds_void_t*)(Bs + (RPP * p + 8 * wave) * BK), 16, 0, 0);
   };
 
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -242,6 +246,11 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const ConvArgs 
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
       const long m = m0 + (wm * TM + j) * 16 + fr;
+      f32x4 rv[TN];
+      if (EPI == EPI_RES) {  // `out` may alias `res` (in-place residual): loads cannot be scheduled above earlier stores by the
+#pragma unroll               // compiler, so a row's residual loads are all issued before its first store
+        for (int i = 0; i < TN; ++i) rv[i] = *reinterpret_cast<const f32x4*>(a.res + m * a.res_ld + a.res_coff + n0 + (wn * TN + i) * 16 + fg * 4);
+      }
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
         const int n = n0 + (wn * TN + i) * 16 + fg * 4;
@@ -250,12 +259,11 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const ConvArgs 
         if (EPI == EPI_RES && (fl & KPF_RES_GAMMA)) gv = *reinterpret_cast<const f32x4*>(a.gamma + n);
         f32x4 v = acc[i][j];
         if (EPI == EPI_RES) {
-          const f32x4 rv = *reinterpret_cast<const f32x4*>(a.res + m * a.res_ld + a.res_coff + n);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float y = v[e] + bv[e];
             if (fl & KPF_RES_GAMMA) y *= gv[e];
-            y += rv[e];
+            y += rv[i][e];
             if (fl & KPF_RELU_AFTER_RES) y = fmaxf(y, 0.f);
             v[e] = y;
           }
@@ -338,14 +346,14 @@ int launch_cfg(ConvArgs& a, bool is1x1, hipStream_t st) {
   const bool res = a.flags & KPF_RES_ADD, gelu = a.flags & KPF_ACT_GELU;
   if (a.ps) {
     if (!is1x1 || res || gelu) {
-      kpf_set_error("kpf_conv2d_f32: the operand prologue is only supported for 1x1 stride-1 convolutions with a linear/ReLU epilogue");
+      kpf_set_error("kpf_conv2d_f32: the operand prologue is only supported for 1x1 stride-1 convolutions with Cin %% 32 == 0 and a linear/ReLU epilogue");
       return KPF_EINVAL;
     }
     return launch_one<TM, TN, WM, WN, true, true, EPI_LIN>(a, st);
   }
   if (gelu) {
     if (!is1x1 || res) {
-      kpf_set_error("kpf_conv2d_f32: GELU is only supported on 1x1 convolutions without residual");
+      kpf_set_error("kpf_conv2d_f32: GELU is only supported on 1x1 convolutions (Cin %% 32 == 0) without residual");
       return KPF_EINVAL;
     }
     return launch_one<TM, TN, WM, WN, true, false, EPI_GELU>(a, st);
@@ -420,8 +428,9 @@ extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const flo
   }
   a.flags = fl; a.tilesN = 0; a.nblk = 0;
   a.vec = (d->out_ld % 4 == 0 && d->out_coff % 4 == 0 && (!(fl & KPF_RES_ADD) || (d->res_ld % 4 == 0 && d->res_coff % 4 == 0))) ? 1 : 0;
+  // the dense-1x1 fast path also needs whole K tiles (its staging reads 32 channels at a time without a K mask)
   const bool is1x1 = d->KH == 1 && d->KW == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0 &&
-                     d->IH == d->OH && d->IW == d->OW;
+                     d->IH == d->OH && d->IW == d->OW && d->Cin % 32 == 0 && d->Kp == d->Cin;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
   int best = 0;

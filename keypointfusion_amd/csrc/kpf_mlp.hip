@@ -91,6 +91,8 @@ __global__ __launch_bounds__(64 * NW) void convnext_mlp_kernel(const MlpArgs a) 
   float* Ys = lds;                   // [BM][C]
   float* W1s = Ys + YF;              // [2][HC][C]
   float* W2s = W1s + 2 * W1F;        // [2][C][HC]
+  float* B1s = W2s + 2 * W2F;        // [4C] pwconv1 bias: read from LDS inside the chunk loop — an ordinary global load there would
+                                     // make hipcc wait vmcnt(0), i.e. drain the in-flight weight DMA of the next chunk every chunk
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
@@ -108,6 +110,13 @@ __global__ __launch_bounds__(64 * NW) void convnext_mlp_kernel(const MlpArgs a) 
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc2[n][j] = zero4;
 
+  float* B2s = B1s + H4;             // [C] pwconv2 bias, [C] layer scale
+  float* Gs = B2s + C;
+  for (int i = tid; i < H4; i += NT) B1s[i] = a.b1[i];
+  for (int i = tid; i < C; i += NT) {
+    B2s[i] = a.b2[i];
+    Gs[i] = a.gamma[i];
+  }
   __syncthreads();
 
   const int yrow0 = wave * TM * 16 + fr;  // this lane's first y row
@@ -150,7 +159,7 @@ __global__ __launch_bounds__(64 * NW) void convnext_mlp_kernel(const MlpArgs a) 
     // ---- bias + GELU in registers; GEMM2: acc2[n][tm] += W2chunk (C x HC) . h ----
 #pragma unroll
     for (int h = 0; h < HT; ++h) {
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(a.b1 + ch * HC + h * 16 + 4 * fg);
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(B1s + ch * HC + h * 16 + 4 * fg);
 #pragma unroll
       for (int j = 0; j < TM; ++j)
 #pragma unroll
@@ -171,20 +180,23 @@ __global__ __launch_bounds__(64 * NW) void convnext_mlp_kernel(const MlpArgs a) 
     __syncthreads();  // next chunk's weights landed; everyone is done with the current buffers
   }
 
-  // ---- epilogue: out = x + gamma * (acc2 + b2); lane owns channels n*16 + 4*fg .. +3 of pixel row ----
+  // ---- epilogue: out = x + gamma * (acc2 + b2); lane owns channels n*16 + 4*fg .. +3 of pixel row.  `out` may alias `x`, so
+  // the compiler will not move a residual load above an earlier store: issue all of a row's residual loads first, then store.
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     const long m = m0 + wave * TM * 16 + j * 16 + fr;
     if (m >= a.M) continue;
+    f32x4 xv[NC];
+#pragma unroll
+    for (int n = 0; n < NC; ++n) xv[n] = *reinterpret_cast<const f32x4*>(a.x + m * C + n * 16 + 4 * fg);
 #pragma unroll
     for (int n = 0; n < NC; ++n) {
       const int c = n * 16 + 4 * fg;
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(a.b2 + c);
-      const f32x4 gv = *reinterpret_cast<const f32x4*>(a.gamma + c);
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + m * C + c);
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(B2s + c);
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(Gs + c);
       f32x4 v;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = xv[e] + gv[e] * (acc2[n][j][e] + bv[e]);
+      for (int e = 0; e < 4; ++e) v[e] = xv[n][e] + gv[e] * (acc2[n][j][e] + bv[e]);
       *reinterpret_cast<f32x4*>(a.out + m * C + c) = v;
     }
   }
@@ -193,7 +205,7 @@ __global__ __launch_bounds__(64 * NW) void convnext_mlp_kernel(const MlpArgs a) 
 template <int NC, int TM, int HT, int NW>
 int launch_mlp(MlpArgs& a, hipStream_t st) {
   constexpr int C = 16 * NC, HC = 16 * HT, BM = 16 * TM * NW;
-  const size_t lds = (size_t)(BM * C + 2 * HC * C + 2 * C * HC) * sizeof(float);
+  const size_t lds = (size_t)(BM * C + 2 * HC * C + 2 * C * HC + 6 * C) * sizeof(float);
   auto kern = convnext_mlp_kernel<NC, TM, HT, NW>;
   static bool attr_set = false;
   if (!attr_set) {

@@ -111,8 +111,6 @@ class PackedConv:
         K = KH * KW * Cin
         self.N, self.K = N, K
         self.Kp = (K + 31) // 32 * 32
-        if (K + 63) // 64 * 64 <= 1.05 * K:  # 64-deep K tiles (one barrier pair per 64) when the padding is cheap
-            self.Kp = (K + 63) // 64 * 64
         wp = torch.zeros(N, self.Kp, dtype=torch.float64)
         wp[:, :K] = w.reshape(N, K)
         self.w = wp.float().to(device)
