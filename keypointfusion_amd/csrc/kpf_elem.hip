@@ -1,6 +1,7 @@
 // HBM-bound kernels of the backbone path: depthwise 7x7 + LayerNorm (fused), LayerNorm, bilinear x2 upsample,
 // layout repacks, max-pool.  All fp32, NHWC, 16-byte vector accesses (float4 over channels), wave64 reductions.
 #include "kpf_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(512) void dwconv7_ln_kernel(const float* __restrict
 // the CU's address unit only carries activations: 7 activation loads per output float4 instead of 12.25 + 6.1 weight loads.
 // No LDS output tile -> occupancy is set by registers only.
 // ---------------------------------------------------------------------------------------------------------------
-template <bool WLDS>
+template <bool WLDS, int PX>
 __global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ x, const float* __restrict__ wdw,
                                                       const float* __restrict__ bdw, float* __restrict__ y, int B, int H, int W, int C,
                                                       int xstrips, int ypairs) {
@@ -126,12 +127,12 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ 
   r /= xstrips;
   const int yp = (int)(r % ypairs);
   const int b = (int)(r / ypairs);
-  const int x0 = xs * 8, y0 = yp * 2;
+  const int x0 = xs * PX, y0 = yp * 2;
   const float* wsrc = WLDS ? wl : wdw;
-  f32x4 acc0[8], acc1[8];
+  f32x4 acc0[PX], acc1[PX];
   const f32x4 bias = *reinterpret_cast<const f32x4*>(bdw + 4 * q);
 #pragma unroll
-  for (int t = 0; t < 8; ++t) {
+  for (int t = 0; t < PX; ++t) {
     acc0[t] = bias;
     acc1[t] = bias;
   }
@@ -140,10 +141,10 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ 
   for (int ir = 0; ir < 8; ++ir) {  // input rows y0-3 .. y0+4
     const int iy = y0 + ir - 3;
     if ((unsigned)iy >= (unsigned)H) continue;
-    f32x4 in[14];
+    f32x4 in[PX + 6];
     const float* row = xb + (long)iy * W * C;
 #pragma unroll
-    for (int i = 0; i < 14; ++i) {
+    for (int i = 0; i < PX + 6; ++i) {
       const int ix = x0 + i - 3;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if ((unsigned)ix < (unsigned)W) v = *reinterpret_cast<const f32x4*>(row + (long)ix * C);
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ 
       for (int kx = 0; kx < 7; ++kx) {
         const f32x4 wv = *reinterpret_cast<const f32x4*>(wsrc + (ir * 7 + kx) * C + 4 * q);
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
+        for (int t = 0; t < PX; ++t)
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc0[t][e] = fmaf(in[t + kx][e], wv[e], acc0[t][e]);
       }
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ 
       for (int kx = 0; kx < 7; ++kx) {
         const f32x4 wv = *reinterpret_cast<const f32x4*>(wsrc + ((ir - 1) * 7 + kx) * C + 4 * q);
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
+        for (int t = 0; t < PX; ++t)
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc1[t][e] = fmaf(in[t + kx][e], wv[e], acc1[t][e]);
       }
@@ -172,10 +173,116 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ 
   }
   float* yb = y + (long)b * H * W * C + 4 * q;
 #pragma unroll
-  for (int t = 0; t < 8; ++t) {
+  for (int t = 0; t < PX; ++t) {
     if (x0 + t < W) {
       *reinterpret_cast<f32x4*>(yb + ((long)y0 * W + x0 + t) * C) = acc0[t];
       if (y0 + 1 < H) *reinterpret_cast<f32x4*>(yb + ((long)(y0 + 1) * W + x0 + t) * C) = acc1[t];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// depthwise 7x7 + bias + LayerNorm fused, for C <= 256: a pixel's C/4 channel quads sit on the lanes of one LG-lane group
+// (LG = 32 or 64), every lane computes 4 channels x (2 rows x 8 px) exactly like dwconv7_kernel, and the per-pixel mean /
+// variance are xor-shuffle reductions inside the group — no LDS tile (which capped the occupancy of the first fused kernel),
+// and the activation is read once and written once (the unfused pair reads and writes it twice).
+// ---------------------------------------------------------------------------------------------------------------
+template <int LG>
+__global__ __launch_bounds__(256) void dwconv7_ln_wave_kernel(const float* __restrict__ x, const float* __restrict__ wdw,
+                                                              const float* __restrict__ bdw, const float* __restrict__ lw,
+                                                              const float* __restrict__ lb, float* __restrict__ y, int B, int H, int W,
+                                                              int C, int xstrips, int ypairs, float eps) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [49][C]
+  const int C4 = C >> 2;
+  for (int i = threadIdx.x; i < 49 * C4; i += 256)
+    *reinterpret_cast<f32x4*>(wl + 4 * i) = *reinterpret_cast<const f32x4*>(wdw + 4 * i);
+  __syncthreads();
+  const long groups = (long)B * ypairs * xstrips;
+  const long gid = ((long)blockIdx.x * 256 + threadIdx.x) / LG;
+  const int q = threadIdx.x % LG;
+  const bool live = q < C4 && gid < groups;  // idle lanes still take part in the shuffles (with zeros)
+  const long gc = gid < groups ? gid : groups - 1;
+  const int xs = (int)(gc % xstrips);
+  long r = gc / xstrips;
+  const int yp = (int)(r % ypairs);
+  const int b = (int)(r / ypairs);
+  const int x0 = xs * 8, y0 = yp * 2;
+  const int qc = q < C4 ? q : 0;
+  f32x4 acc0[8], acc1[8];
+  const f32x4 bias = *reinterpret_cast<const f32x4*>(bdw + 4 * qc);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    acc0[t] = bias;
+    acc1[t] = bias;
+  }
+  const float* xb = x + (long)b * H * W * C + 4 * qc;
+  if (live) {
+#pragma unroll 1
+    for (int ir = 0; ir < 8; ++ir) {  // input rows y0-3 .. y0+4
+      const int iy = y0 + ir - 3;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      f32x4 in[14];
+      const float* row = xb + (long)iy * W * C;
+#pragma unroll
+      for (int i = 0; i < 14; ++i) {
+        const int ix = x0 + i - 3;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)ix < (unsigned)W) v = *reinterpret_cast<const f32x4*>(row + (long)ix * C);
+        in[i] = v;
+      }
+      if (ir < 7) {
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + (ir * 7 + kx) * C + 4 * qc);
+#pragma unroll
+          for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc0[t][e] = fmaf(in[t + kx][e], wv[e], acc0[t][e]);
+        }
+      }
+      if (ir >= 1) {
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + ((ir - 1) * 7 + kx) * C + 4 * qc);
+#pragma unroll
+          for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc1[t][e] = fmaf(in[t + kx][e], wv[e], acc1[t][e]);
+        }
+      }
+    }
+  }
+  // LayerNorm of the 16 pixels this lane group holds (two-pass variance like ATen's)
+  const float invC = 1.0f / (float)C;
+  const f32x4 g = *reinterpret_cast<const f32x4*>(lw + 4 * qc);
+  const f32x4 be = *reinterpret_cast<const f32x4*>(lb + 4 * qc);
+  float* yb = y + (long)b * H * W * C + 4 * qc;
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      f32x4 v = rr ? acc1[t] : acc0[t];
+      float s = live ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f;
+#pragma unroll
+      for (int o = LG / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      const float mean = s * invC;
+      float sq = 0.f;
+      if (live) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = v[e] - mean;
+          sq = fmaf(d, d, sq);
+        }
+      }
+#pragma unroll
+      for (int o = LG / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+      const float rstd = 1.0f / sqrtf(sq * invC + eps);
+      if (live && x0 + t < W && y0 + rr < H) {
+        f32x4 o4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o4[e] = (v[e] - mean) * rstd * g[e] + be[e];
+        *reinterpret_cast<f32x4*>(yb + ((long)(y0 + rr) * W + x0 + t) * C) = o4;
+      }
     }
   }
 }
@@ -346,17 +453,40 @@ extern "C" int kpf_dwconv7_ln_f32(const float* x, const float* w_dw, const float
   KPF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && C <= 2048, "kpf_dwconv7_ln_f32: bad shape B=%d H=%d W=%d C=%d", B, H, W, C);
   KPF_REQUIRE(kpf_aligned16(x) && kpf_aligned16(y) && kpf_aligned16(w_dw), "kpf_dwconv7_ln_f32: unaligned pointer");
   const int C4 = C / 4;
+  if (H * W >= 64 && C4 <= 64 && (size_t)49 * C * sizeof(float) <= 64 * 1024 && !getenv("KPF_DW_UNFUSED")) {
+    // fused, one pass over the activation: channel quads of a pixel on one 32- or 64-lane group, LayerNorm by shuffles
+    const int xstrips = (W + 7) / 8, ypairs = (H + 1) / 2;
+    const long groups = (long)B * ypairs * xstrips;
+    const size_t wbytes = (size_t)49 * C * sizeof(float);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (C4 <= 32) {
+      const long threads = groups * 32;
+      hipLaunchKernelGGL((dwconv7_ln_wave_kernel<32>), dim3((unsigned)((threads + 255) / 256)), dim3(256), wbytes, st, x, w_dw, b_dw, ln_w, ln_b,
+                         y, B, H, W, C, xstrips, ypairs, eps);
+    } else {
+      const long threads = groups * 64;
+      hipLaunchKernelGGL((dwconv7_ln_wave_kernel<64>), dim3((unsigned)((threads + 255) / 256)), dim3(256), wbytes, st, x, w_dw, b_dw, ln_w, ln_b,
+                         y, B, H, W, C, xstrips, ypairs, eps);
+    }
+    return kpf_check_launch("kpf_dwconv7_ln_f32");
+  }
   if (H * W >= 64) {
     // two launches: register-tiled depthwise conv, then the row LayerNorm in place (each streams the tensor once; measured faster
     // than the single fused kernel, whose LDS output tile caps occupancy).  Tiny maps keep the fused kernel (one launch).
-    const int xstrips = (W + 7) / 8, ypairs = (H + 1) / 2;
+    static const int px_env = []() { const char* e = getenv("KPF_DW_PX"); return e ? atoi(e) : 8; }();  // tuning aid
+    const int PXr = px_env == 4 ? 4 : 8;
+    const int xstrips = (W + PXr - 1) / PXr, ypairs = (H + 1) / 2;
     const long total = (long)B * ypairs * xstrips * C4;
     const size_t wbytes = (size_t)49 * C * sizeof(float);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (wbytes <= 48 * 1024)
-      hipLaunchKernelGGL((dwconv7_kernel<true>), dim3((unsigned)((total + 255) / 256)), dim3(256), wbytes, st, x, w_dw, b_dw, y, B, H, W, C, xstrips, ypairs);
-    else
-      hipLaunchKernelGGL((dwconv7_kernel<false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, w_dw, b_dw, y, B, H, W, C, xstrips, ypairs);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (wbytes <= 48 * 1024) {
+      if (PXr == 4) hipLaunchKernelGGL((dwconv7_kernel<true, 4>), grid, dim3(256), wbytes, st, x, w_dw, b_dw, y, B, H, W, C, xstrips, ypairs);
+      else hipLaunchKernelGGL((dwconv7_kernel<true, 8>), grid, dim3(256), wbytes, st, x, w_dw, b_dw, y, B, H, W, C, xstrips, ypairs);
+    } else {
+      if (PXr == 4) hipLaunchKernelGGL((dwconv7_kernel<false, 4>), grid, dim3(256), 0, st, x, w_dw, b_dw, y, B, H, W, C, xstrips, ypairs);
+      else hipLaunchKernelGGL((dwconv7_kernel<false, 8>), grid, dim3(256), 0, st, x, w_dw, b_dw, y, B, H, W, C, xstrips, ypairs);
+    }
     int rc = kpf_check_launch("kpf_dwconv7_ln_f32");
     if (rc) return rc;
     return kpf_layernorm_f32(y, ln_w, ln_b, y, (long)B * H * W, C, eps, stream);
