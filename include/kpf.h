@@ -30,6 +30,7 @@ extern "C" {
 #define KPF_RES_ADD 4u         /* y = res + y                                              */
 #define KPF_RES_GAMMA 8u       /* y = res + gamma[n] * y          (convNeXT/convnext.py:48-51) */
 #define KPF_RELU_AFTER_RES 16u /* y = relu(res + y)               (model/resnet.py:72-73)  */
+#define KPF_ACT_LEAKY 64u      /* y = leaky_relu(acc + bias, 0.01) (model/mano_head.py:199) */
 #define KPF_OUT_NCHW 32u       /* store out[b][n][oy][ox] (dense), ignoring out_ld/out_coff */
 
 typedef struct kpf_conv_desc {
@@ -162,6 +163,36 @@ int kpf_tr_encoder_weight_floats(int Din);
 int kpf_xattn_layer_f32(const float* query, const float* key, const float* W, float* out, int out_ld, int out_coff, int B,
                         void* stream);
 int kpf_xattn_weight_floats(void);
+
+/* ---- stand-alone heads: named by the north star, not called by KPFusion.forward ---------------------- */
+
+/* CBAM ChannelGate (model/cbam.py:26-57): scale[b][c] = sigmoid(mlp(avgpool(x)) + mlp(maxpool(x))), mlp = Linear(C,Cr) ReLU
+ * Linear(Cr,C) with w1 [Cr][C], w2 [C][Cr] (nn.Linear layout).  x NHWC [B][HW][C]; workspace >= kpf_cbam_workspace_floats(). */
+long kpf_cbam_workspace_floats(int B, int HW, int C);
+int kpf_cbam_channel_gate_f32(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                              float* workspace, float* scale, int B, int HW, int C, int Cr, void* stream);
+/* CBAM SpatialGate value (model/cbam.py:65-81): comp [B][H][W][2] = (max_c, mean_c) of x*scale, then
+ * sgate[b][y][x] = sigmoid(bn_scale * conv7x7_pad3(comp; w7 [2][7][7]) + bn_shift) (eval BatchNorm folded by the caller). */
+int kpf_cbam_spatial_gate_f32(const float* x, const float* scale, const float* w7, float bn_scale, float bn_shift, float* comp,
+                              float* sgate, int B, int H, int W, int C, void* stream);
+/* out0 = (x*scale)*sgate, out1 = (x*scale)*(1-sgate) — the tuple SpatialGate.forward returns (model/cbam.py:82);
+ * sgate == out1 == NULL: out0 = x*scale (CBAM(no_spatial=True), model/cbam.py:90-94). */
+int kpf_cbam_apply_f32(const float* x, const float* scale, const float* sgate, float* out0, float* out1, int B, int HW, int C,
+                       void* stream);
+
+/* nn.MaxPool2d(2,2) on NHWC (model/hourglass.py:8,128) and nn.Upsample(scale_factor=2, nearest) fused with the hourglass
+ * skip add `up1 + up2` (model/hourglass.py:138-149): out [B][2h][2w][C] = up1 + low[y/2][x/2]. */
+int kpf_maxpool2x2_f32(const float* src, float* dst, int B, int H, int W, int C, void* stream);
+int kpf_upnearest2x_add_f32(const float* low, const float* up1, float* out, int B, int h, int w, int C, void* stream);
+
+/* mano_regHead tail (model/mano_head.py:212-225) + ManoLayer.forward (util/manopth/manopth/manolayer.py:106-273; use_pca=False,
+ * axis-angle joints, right hand, no centring / translation): pose6d rows [B][ld6] (16 x 6D rotations), betas rows [B][ldb] (10)
+ * -> verts [B][778][3] mm, joints [B][21][3] mm in OBMAN2MANO order, rotmat [B][16][3][3], pose_aa [B][48].
+ * Model arrays: shapedirs_t [10][778*3], posedirs_t [135][778*3] (transposed blend-shape bases), v_template [778*3],
+ * j_regressor [16][778], skin_weights [778][16], hands_mean [45]. */
+int kpf_mano_forward_f32(const float* pose6d, int ld6, const float* betas, int ldb, const float* shapedirs_t,
+                         const float* posedirs_t, const float* v_template, const float* j_regressor, const float* skin_weights,
+                         const float* hands_mean, float* verts, float* joints, float* rotmat, float* pose_aa, int B, void* stream);
 
 const char* kpf_last_error(void);
 /* Library/ABI version, bumped when a signature changes. */

@@ -276,6 +276,10 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const ConvArgs 
             const float y = v[e] + bv[e];
             v[e] = (fl & KPF_ACT_RELU) ? fmaxf(y, 0.f) : y;
           }
+          if (fl & KPF_ACT_LEAKY) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.01f * v[e]);
+          }
         }
         STORE4(a.out + m * a.out_ld + a.out_coff + n, v);
       }
@@ -298,6 +302,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const ConvArgs 
         float y = acc[i][j][e] + (a.bias ? a.bias[n + e] : 0.f);
         if (EPI == EPI_GELU) y = gelu_erf(y);
         if (EPI == EPI_LIN && (fl & KPF_ACT_RELU)) y = fmaxf(y, 0.f);
+        if (EPI == EPI_LIN && (fl & KPF_ACT_LEAKY)) y = fmaxf(y, 0.01f * y);
         if (EPI == EPI_RES) {
           if (fl & KPF_RES_GAMMA) y *= a.gamma[n + e];
           y += a.res[(long)m * a.res_ld + a.res_coff + n + e];
@@ -400,8 +405,9 @@ extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const flo
     KPF_REQUIRE(res && kpf_aligned16(res) && d->res_coff >= 0 && d->res_coff + d->N <= d->res_ld, "kpf_conv2d_f32: bad residual");
   if (fl & KPF_RES_GAMMA) KPF_REQUIRE(gamma && (fl & KPF_RES_ADD), "kpf_conv2d_f32: RES_GAMMA needs gamma and RES_ADD");
   KPF_REQUIRE((pro_scale == nullptr) == (pro_shift == nullptr), "kpf_conv2d_f32: prologue needs both scale and shift");
-  KPF_REQUIRE(!((fl & KPF_ACT_RELU) && (fl & KPF_ACT_GELU)), "kpf_conv2d_f32: one activation only");
-  KPF_REQUIRE(!((fl & KPF_RES_ADD) && (fl & (KPF_ACT_RELU | KPF_ACT_GELU))), "kpf_conv2d_f32: activation before a residual add is not supported");
+  KPF_REQUIRE(((fl & KPF_ACT_RELU) != 0) + ((fl & KPF_ACT_GELU) != 0) + ((fl & KPF_ACT_LEAKY) != 0) <= 1, "kpf_conv2d_f32: one activation only");
+  KPF_REQUIRE(!((fl & KPF_RES_ADD) && (fl & (KPF_ACT_RELU | KPF_ACT_GELU | KPF_ACT_LEAKY))), "kpf_conv2d_f32: activation before a residual add is not supported");
+  KPF_REQUIRE(!((fl & KPF_ACT_LEAKY) && pro_scale), "kpf_conv2d_f32: LeakyReLU is not combined with an operand prologue");
   KPF_REQUIRE(!(fl & KPF_RELU_AFTER_RES) || (fl & KPF_RES_ADD), "kpf_conv2d_f32: RELU_AFTER_RES needs RES_ADD");
   KPF_REQUIRE((long)d->B * d->OH * d->OW < (1l << 31) && (long)d->B * d->IH * d->IW < (1l << 31), "kpf_conv2d_f32: too many pixels");
 

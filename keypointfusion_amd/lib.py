@@ -15,6 +15,7 @@ KPF_RES_ADD = 4
 KPF_RES_GAMMA = 8
 KPF_RELU_AFTER_RES = 16
 KPF_OUT_NCHW = 32
+KPF_ACT_LEAKY = 64
 
 
 class ConvDesc(C.Structure):
@@ -44,10 +45,16 @@ _SIGS = {
     "kpf_xattn_layer_f32": [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P],
     "kpf_convnext_mlp_f32": [_P] * 8 + [C.c_long, C.c_int, _P],
     "kpf_convnext_mlp_supported": [C.c_int],
+    "kpf_cbam_channel_gate_f32": [_P] * 7 + [C.c_int] * 4 + [_P],
+    "kpf_cbam_spatial_gate_f32": [_P, _P, _P, C.c_float, C.c_float, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_cbam_apply_f32": [_P] * 5 + [C.c_int] * 3 + [_P],
+    "kpf_maxpool2x2_f32": [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_upnearest2x_add_f32": [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_mano_forward_f32": [_P, C.c_int, _P, C.c_int] + [_P] * 10 + [C.c_int, _P],
     "kpf_tr_encoder_weight_floats": [C.c_int],
     "kpf_xattn_weight_floats": [],
 }
-EXPORTS = sorted(list(_SIGS) + ["kpf_last_error", "kpf_abi_version"])
+EXPORTS = sorted(list(_SIGS) + ["kpf_last_error", "kpf_abi_version", "kpf_cbam_workspace_floats"])
 
 _lib = None
 
@@ -71,6 +78,8 @@ def load():
         fn.restype = C.c_int
     lib.kpf_last_error.restype = C.c_char_p
     lib.kpf_abi_version.restype = C.c_int
+    lib.kpf_cbam_workspace_floats.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.kpf_cbam_workspace_floats.restype = C.c_long
     _lib = lib
     return lib
 

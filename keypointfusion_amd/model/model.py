@@ -18,23 +18,7 @@ import torch.nn as nn
 
 from ..spec import kpfusion_spec, parse_net
 from ..weights import _draw  # noqa: F401  (init scales shared with the synthetic generator)
-
-
-class _Node(nn.Module):
-    """Anonymous container used to reproduce the reference's dotted state-dict names."""
-
-
-def _attach(root, dotted, value, is_buffer):
-    parts = dotted.split(".")
-    mod = root
-    for p in parts[:-1]:
-        if p not in mod._modules:
-            mod.add_module(p, _Node())
-        mod = mod._modules[p]
-    if is_buffer:
-        mod.register_buffer(parts[-1], value)
-    else:
-        mod.register_parameter(parts[-1], nn.Parameter(value))
+from ._base import _Node, _attach  # noqa: F401  (shared with the stand-alone heads)
 
 
 class KPFusion(nn.Module):

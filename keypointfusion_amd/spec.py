@@ -215,3 +215,80 @@ def kpfusion_spec(net):
     _block(s, "block1")
     _block(s, "block2")
     return list(s)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Stand-alone heads named by the north star but not wired into KPFusion.forward
+# ----------------------------------------------------------------------------------------------------------------
+def cbam_spec(gate_channels, reduction_ratio=16, no_spatial=False):
+    """model/cbam.py:84-94 CBAM(gate_channels, reduction_ratio, pool_types=['avg','max'], no_spatial)."""
+    s = _Spec()
+    hid = gate_channels // reduction_ratio
+    s.linear("ChannelGate.mlp.1", hid, gate_channels)
+    s.linear("ChannelGate.mlp.3", gate_channels, hid)
+    if not no_spatial:
+        s.conv("SpatialGate.spatial.conv", 1, 2, 7, 7, bias=False)
+        s.bn("SpatialGate.spatial.bn", 1)
+    return list(s)
+
+
+def _hourglass(s, p, n, f, increase=0):
+    """model/hourglass.py:122-149 (recursive)."""
+    nf = f + increase
+    s.residual(p + ".up1", f, f)
+    s.residual(p + ".low1", f, nf)
+    if n > 1:
+        _hourglass(s, p + ".low2", n - 1, nf)
+    else:
+        s.residual(p + ".low2", nf, nf)
+    s.residual(p + ".low3", nf, f)
+
+
+def posenet_spec(nstack, joint_num, inp_dim=256, increase=0):
+    """model/hourglass.py:166-209 PoseNet(nstack, joint_num, inp_dim, increase=0) — registration order of __init__."""
+    s = _Spec()
+    s.conv("pre.0.conv", 64, 1, 7, 7)
+    s.bn("pre.0.bn", 64)
+    s.residual("pre.1", 64, 128)
+    s.residual("pre.3", 128, inp_dim)
+    s.residual("pre.4", inp_dim, inp_dim)
+    for i in range(nstack):
+        _hourglass(s, "hgs.%d" % i, 4, inp_dim, increase)
+    for i in range(nstack):
+        s.residual("features.%d.0" % i, inp_dim, inp_dim)
+        s.conv("features.%d.1.conv" % i, inp_dim, inp_dim, 1, 1)
+        s.bn("features.%d.1.bn" % i, inp_dim)
+    for name, od in (("outs_1", joint_num * 3), ("outs_2", joint_num), ("outs_3", joint_num)):
+        for i in range(nstack):
+            s.conv("%s.%d" % (name, i), od, inp_dim, 1, 1, init="final")
+    for i in range(nstack):
+        s.conv("merge_features.%d.conv.conv" % i, inp_dim, inp_dim, 1, 1)
+    for i in range(nstack):
+        s.conv("merge_preds.%d.conv.conv" % i, inp_dim, joint_num * 5, 1, 1)
+    for i in range(nstack):
+        s.conv("merge_all.%d.conv.conv" % i, inp_dim, inp_dim * 2, 1, 1)  # constructed, never called
+    return list(s)
+
+
+MANO_V, MANO_J, MANO_F = 778, 16, 1538
+
+
+def mano_head_spec(feature_size=1024, mano_neurons=(1024, 512)):
+    """model/mano_head.py:177-206 mano_regHead: ManoLayer buffers (util/manopth/manopth/manolayer.py:69-104, use_pca=False,
+    flat_hand_mean=True, joint_rot_mode='axisang') followed by the regression MLP."""
+    s = _Spec()
+    s.add("mano_layer.th_betas", (1, 10), "mano")
+    s.add("mano_layer.th_shapedirs", (MANO_V, 3, 10), "mano")
+    s.add("mano_layer.th_posedirs", (MANO_V, 3, 135), "mano")
+    s.add("mano_layer.th_v_template", (1, MANO_V, 3), "mano")
+    s.add("mano_layer.th_J_regressor", (MANO_J, MANO_V), "mano")
+    s.add("mano_layer.th_weights", (MANO_V, MANO_J), "mano")
+    s.add("mano_layer.th_faces", (MANO_F, 3), "mano", "int64")
+    s.add("mano_layer.th_hands_mean", (1, 45), "mano")
+    s.add("mano_layer.th_selected_comps", (6, 45), "mano")  # hands_components[:ncomps] with the ctor default ncomps=6
+    dims = [feature_size] + list(mano_neurons)
+    for i, (a, b) in enumerate(zip(dims[:-1], dims[1:])):
+        s.linear("mano_base_layer.%d" % (2 * i), b, a)
+    s.linear("pose_reg", 96, dims[-1])
+    s.linear("shape_reg", 10, dims[-1], init="shape_reg")
+    return list(s)

@@ -61,6 +61,8 @@ def _draw(rng, shape, init):
         return np.full(shape, 0.3, np.float32)
     if init == "dead":
         return normal(0.02)
+    if init == "shape_reg":
+        return normal(1.0 / math.sqrt(fan_in))
     if init == "zero_i64":
         return np.zeros(shape, np.int64)
     raise ValueError(init)
@@ -73,6 +75,73 @@ def synthetic_state_dict(net, seed=0):
         rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
         out[name] = _draw(rng, shape, init)
     return out
+
+
+def synthetic_from_spec(spec, seed=0, prefix=""):
+    """Same per-key generator for any (name, shape, dtype, init) list (CBAM / PoseNet / MANO-head specs of spec.py);
+    `prefix` namespaces the crc32 seed so equal key names of different modules draw different values."""
+    out = {}
+    for name, shape, dtype, init in spec:
+        if init == "mano":
+            continue
+        rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32((prefix + name).encode())]))
+        out[name] = _draw(rng, shape, init)
+    return out
+
+
+MANO_PARENTS = (-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 0, 10, 11, 0, 13, 14)  # kintree_table[0] of MANO_{LEFT,RIGHT}.pkl
+
+
+def synthetic_mano_model(seed=0):
+    """A random hand model with the *shapes and structure* of MANO_RIGHT.pkl (778 vertices, 16 joints, 10 shape and 135 pose
+    blend shapes, row-stochastic joint regressor and skinning weights, the MANO kinematic tree).  The MANO data itself is
+    licence-restricted and is neither shipped nor needed for parity: the MANO layer is linear-blend skinning over whatever
+    arrays it is given (util/manopth/manopth/manolayer.py:69-104)."""
+    rng = np.random.Generator(np.random.PCG64([seed, 778]))
+    V, Jn = 778, 16
+    v = (rng.random((V, 3)) - 0.5) * np.array([0.10, 0.18, 0.03])  # metres, hand-sized slab
+    shapedirs = rng.standard_normal((V, 3, 10)) * 0.004
+    posedirs = rng.standard_normal((V, 3, 135)) * 0.0015
+    jreg = np.zeros((Jn, V))
+    for j in range(Jn):
+        idx = rng.choice(V, 96, replace=False)
+        w = rng.random(96)
+        jreg[j, idx] = w / w.sum()
+    weights = np.zeros((V, Jn))
+    for i in range(V):
+        idx = rng.choice(Jn, 4, replace=False)
+        w = rng.random(4) ** 2
+        weights[i, idx] = w / w.sum()
+    faces = rng.integers(0, V, (1538, 3))
+    comps = rng.standard_normal((45, 45)) * 0.3
+    mean = rng.standard_normal(45) * 0.2
+    kin = np.stack([np.array([4294967295 if p < 0 else p for p in MANO_PARENTS], np.int64), np.arange(16, dtype=np.int64)])
+    return dict(v_template=v, shapedirs=shapedirs, posedirs=posedirs, J_regressor=jreg, weights=weights, f=faces.astype(np.uint32),
+                hands_components=comps, hands_mean=mean, kintree_table=kin)
+
+
+def mano_layer_buffers(model):
+    """MANO arrays -> the ManoLayer buffers of the reference (manolayer.py:69-104; use_pca=False, flat_hand_mean=True), fp32."""
+    f32 = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64).astype(np.float32))  # noqa: E731
+    return {
+        "mano_layer.th_betas": np.zeros((1, 10), np.float32),
+        "mano_layer.th_shapedirs": f32(model["shapedirs"]),
+        "mano_layer.th_posedirs": f32(model["posedirs"]),
+        "mano_layer.th_v_template": f32(model["v_template"])[None],
+        "mano_layer.th_J_regressor": f32(model["J_regressor"]),
+        "mano_layer.th_weights": f32(model["weights"]),
+        "mano_layer.th_faces": np.asarray(model["f"]).astype(np.int32).astype(np.int64),
+        "mano_layer.th_hands_mean": np.zeros((1, 45), np.float32),
+        "mano_layer.th_selected_comps": f32(np.asarray(model["hands_components"])[:6]),
+    }
+
+
+def synthetic_mano_head_state(seed=0, feature_size=1024, mano_neurons=(1024, 512)):
+    from .spec import mano_head_spec
+    spec = mano_head_spec(feature_size, mano_neurons)
+    sd = mano_layer_buffers(synthetic_mano_model(seed))
+    sd.update(synthetic_from_spec(spec, seed, prefix="mano_head."))
+    return {name: sd[name] for name, _, _, _ in spec}
 
 
 def state_dict_digest(sd, keys=None):
@@ -135,3 +204,11 @@ def synthetic_batch(B, S=128, seed=1, n_points=1024, img_size=None):
         xyz = np.stack([x, y, dmm], 1)
         pcl[b] = np.clip((xyz - center[b]) / (cube[b] / 2), -1, 1)
     return dict(img_rgb=rgb, img=depth, pcl=pcl, center=center, M=M, cube=cube, cam_para=cam)
+
+
+def synthetic_tensor(shape, seed, tag, lo=None, hi=None):
+    """Seeded fp32 test tensor (standard normal, or uniform [lo, hi)) — inputs of the stand-alone head fixtures."""
+    rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(tag.encode())]))
+    n = int(np.prod(shape))
+    a = rng.standard_normal(n) if lo is None else rng.random(n) * (hi - lo) + lo
+    return a.astype(np.float32).reshape(shape)

@@ -148,3 +148,58 @@ def build_reference_model(net):
         os.chdir(cwd)
     m.eval()
     return m, ld
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Stand-alone heads
+# ----------------------------------------------------------------------------------------------------------------
+def load_reference_aux():
+    """Returns the reference modules model.cbam and model.hourglass (torch-only, import as they are)."""
+    install_shims()
+    if REF_ROOT not in sys.path:
+        sys.path.insert(0, REF_ROOT)
+    from model import cbam, hourglass
+    return cbam, hourglass
+
+
+class _R:
+    """Stand-in for a chumpy array: the reference only reads `.r` (manolayer.py:69-88)."""
+
+    def __init__(self, a):
+        self.r = a
+
+
+def load_reference_mano_head(mano_model):
+    """The reference's mano_regHead (model/mano_head.py:177-231) built over `mano_model` (dict of arrays with MANO_RIGHT.pkl's
+    field names).  chumpy — needed only to unpickle the licence-restricted MANO file — is absent from this image, so the one
+    function that touches it, `ready_arguments` (util/manopth/mano/webuser/smpl_handpca_wrapper_HAND_only.py:22-68, a file
+    loader, no arithmetic on the path), is replaced by a stub handing the arrays over; ManoLayer.forward and mano_head's
+    rotation conversions are the reference's own code."""
+    import numpy as np
+    import scipy.sparse as sp
+    install_shims()
+    if REF_ROOT not in sys.path:
+        sys.path.insert(0, REF_ROOT)
+
+    def ready_arguments(fname_or_dict, posekey4vposed="pose"):
+        m = mano_model
+        return {"hands_components": np.asarray(m["hands_components"]), "hands_mean": np.asarray(m["hands_mean"]),
+                "betas": _R(np.zeros(10)), "shapedirs": _R(np.asarray(m["shapedirs"])), "posedirs": _R(np.asarray(m["posedirs"])),
+                "v_template": _R(np.asarray(m["v_template"])), "J_regressor": sp.csc_matrix(np.asarray(m["J_regressor"])),
+                "weights": _R(np.asarray(m["weights"])), "f": np.asarray(m["f"]), "kintree_table": np.asarray(m["kintree_table"])}
+
+    for name in ("util.manopth.mano", "util.manopth.mano.webuser"):
+        if name not in sys.modules:
+            mod = types.ModuleType(name)
+            mod.__path__ = []
+            sys.modules[name] = mod
+    w = types.ModuleType("util.manopth.mano.webuser.smpl_handpca_wrapper_HAND_only")
+    w.ready_arguments = ready_arguments
+    sys.modules[w.__name__] = w
+    import util.manopth.manopth as real_pkg
+    import util.manopth.manopth.manolayer as real_layer
+    real_layer.ready_arguments = ready_arguments
+    sys.modules["manopth"] = real_pkg  # model/mano_head.py:5 imports the top-level name
+    sys.modules["manopth.manolayer"] = real_layer
+    from model import mano_head
+    return mano_head

@@ -1,0 +1,160 @@
+"""GPU parity of the stand-alone heads (SURVEY.md §8 a17 CBAM, a18 PoseNet, a19 MANO head): the HIP path, driven through the drop-in
+modules and the C ABI, against oracle/aux_oracle.py on the same seeded inputs and against the golden vectors generated from the
+imported reference.  Nothing here reads /root/reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN
+from test_heads_oracle import CBAM_CASES, POSENET_CASES, cbam_case, mano_case, posenet_case
+from oracle import aux_oracle as A
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from keypointfusion_amd import lib
+    lib.load()
+    return torch.device("cuda:0")
+
+
+def rel_err(a, b):
+    a, b = a.detach().float().cpu(), torch.as_tensor(b).float()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+@pytest.mark.parametrize("case", CBAM_CASES)
+def test_cbam_module_matches_oracle_and_reference_vectors(case):
+    from keypointfusion_amd.model.cbam import CBAM
+    dev = _dev()
+    C, nosp = case[0], case[1]
+    tag, sd, x = cbam_case(*case)
+    m = CBAM(C, no_spatial=nosp)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).eval()
+    out = m(x.to(dev))
+    ref = A.cbam_forward(sd, x, nosp)
+    g = np.load(os.path.join(GOLDEN, "aux_cbam.npz"))
+    if nosp:
+        assert rel_err(out, ref) < 1e-5
+        assert rel_err(out[:, ::4], g[tag + "_out"]) < 1e-5
+    else:
+        assert isinstance(out, tuple) and len(out) == 2  # SpatialGate returns a tuple (model/cbam.py:82)
+        assert rel_err(out[0], ref[0]) < 1e-5 and rel_err(out[1], ref[1]) < 1e-5
+        assert rel_err(out[0][:, ::4], g[tag + "_out0"]) < 1e-5 and rel_err(out[1][:, ::4], g[tag + "_out1"]) < 1e-5
+
+
+def test_cbam_channel_gate_large_map_and_wide_channels():
+    """Pool splits (HW >= 1024 -> 64 partials), C4 > 64 lanes per pixel, non-power-of-two channel count."""
+    from keypointfusion_amd.engine import Act
+    from keypointfusion_amd.heads import CbamPlan
+    from keypointfusion_amd import spec as S
+    from keypointfusion_amd.weights import synthetic_from_spec, synthetic_tensor
+    from oracle.kpf_oracle import to_torch_sd
+    dev = _dev()
+    for C, B, H, W in ((96, 3, 40, 36), (528, 2, 9, 5), (1024, 1, 4, 4)):
+        sd = to_torch_sd(synthetic_from_spec(S.cbam_spec(C), 2, prefix="t%d." % C))
+        x = torch.from_numpy(synthetic_tensor((B, C, H, W), 9, "x%d" % C))
+        plan = CbamPlan(sd, dev)
+        act = Act(x.permute(0, 2, 3, 1).contiguous().view(-1).to(dev), B, H, W, C)
+        assert rel_err(plan.channel_scale(act), A.cbam_channel_scale(sd, x)) < 1e-5
+        o0, o1 = plan(act)
+        r0, r1 = A.cbam_forward(sd, x)
+        assert rel_err(o0.dense().permute(0, 3, 1, 2), r0) < 1e-5
+        assert rel_err(o1.dense().permute(0, 3, 1, 2), r1) < 1e-5
+
+
+def test_hourglass_glue_kernels():
+    from keypointfusion_amd.engine import Act
+    from keypointfusion_amd.heads import maxpool2x2, upnearest2x_add
+    dev = _dev()
+    torch.manual_seed(0)
+    x = torch.randn(2, 24, 12, 20)
+    act = Act(x.permute(0, 2, 3, 1).contiguous().view(-1).to(dev), 2, 12, 20, 24)
+    p = maxpool2x2(act)
+    assert torch.equal(p.dense().permute(0, 3, 1, 2).cpu(), F.max_pool2d(x, 2, 2))
+    up1 = torch.randn(2, 24, 12, 20)
+    a_up = Act(up1.permute(0, 2, 3, 1).contiguous().view(-1).to(dev), 2, 12, 20, 24)
+    o = upnearest2x_add(p, a_up)
+    assert torch.equal(o.dense().permute(0, 3, 1, 2).cpu(), up1 + F.interpolate(F.max_pool2d(x, 2, 2), scale_factor=2, mode="nearest"))
+
+
+@pytest.mark.parametrize("case", POSENET_CASES)
+def test_posenet_module_matches_oracle_and_reference_vectors(case):
+    from keypointfusion_amd.model.hourglass import PoseNet
+    dev = _dev()
+    nstack, dim = case[0], case[1]
+    tag, sd, x = posenet_case(*case)
+    m = PoseNet(nstack, 21, dim)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).eval()
+    preds, feat = m(x.to(dev))
+    rp, rf = A.posenet_forward(sd, x, nstack)
+    assert preds.shape == rp.shape and feat.shape == rf.shape
+    assert rel_err(preds, rp) < 1e-3 and rel_err(feat, rf) < 1e-3  # north_star tolerance; ~60 fp32 GEMMs deep
+    g = np.load(os.path.join(GOLDEN, "aux_posenet.npz"))
+    assert rel_err(preds[:, :, ::2, ::2], g[tag + "_preds_sub"]) < 1e-3
+    assert rel_err(feat[:, ::4], g[tag + "_feat_sub"]) < 1e-3
+
+
+def test_mano_head_matches_oracle_and_reference_vectors():
+    from keypointfusion_amd.model.mano_head import mano_regHead
+    dev = _dev()
+    sd, feats = mano_case()
+    m = mano_regHead()
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).eval()
+    out = m(feats.to(dev))
+    ref = A.mano_head_forward(sd, feats)
+    g = np.load(os.path.join(GOLDEN, "aux_mano.npz"))
+    for k in ("mano_shape", "mano_pose", "mano_pose_aa", "verts3d", "joints3d"):
+        assert out[k].shape == ref[k].shape, k
+        assert rel_err(out[k], ref[k]) < 1e-4, (k, rel_err(out[k], ref[k]))
+        assert rel_err(out[k], g[k]) < 1e-4, k
+    # millimetre bound on the mesh, as for the joints of the main path
+    assert float((out["verts3d"].cpu() - ref["verts3d"]).abs().max()) < 0.05
+
+
+def test_mano_kernel_edge_rotations():
+    """Identity, 180-degree and near-degenerate 6D inputs through the kernel's rotation algebra (all four quaternion branches)."""
+    import ctypes as C
+    from keypointfusion_amd import lib as L
+    from keypointfusion_amd.heads import ManoHeadPlan
+    from keypointfusion_amd.engine import _ptr, _stream
+    dev = _dev()
+    sd, _ = mano_case()
+    plan = ManoHeadPlan(sd, dev)
+    six = torch.tensor([[1, 0, 0, 0, 1, 0],        # identity
+                        [-1, 0, 0, 0, -1, 0],      # 180 deg about z   (m22 > 0, m00 < -m11)
+                        [1, 0, 0, 0, -1, 0],       # 180 deg about x   (m22 < 0, m00 > m11)
+                        [-1, 0, 0, 0, 1, 0],       # 180 deg about y   (m22 < 0, m00 <= m11)
+                        [0.3, -2.0, 0.5, 1.0, 0.2, -0.7],
+                        [1e-3, 0, 0, 0, 1e-3, 0]], dtype=torch.float32)
+    B = 3
+    gen = torch.Generator().manual_seed(3)
+    pose6d = six[torch.randint(0, six.shape[0], (B, 16), generator=gen)].reshape(B, 96)
+    pose6d[0] = six[0].repeat(16)
+    betas = torch.randn(B, 10, generator=gen) * 0.5
+    betas[0] = 0
+    lib = L.load()
+    p6, bt = pose6d.to(dev), betas.to(dev)
+    verts = torch.empty(B, 778, 3, device=dev)
+    joints = torch.empty(B, 21, 3, device=dev)
+    rot = torch.empty(B, 16, 3, 3, device=dev)
+    aa = torch.empty(B, 48, device=dev)
+    L.check(lib.kpf_mano_forward_f32(_ptr(p6), 96, _ptr(bt), 10, _ptr(plan.shape_t), _ptr(plan.pose_t), _ptr(plan.vtmpl), _ptr(plan.jreg),
+                                     _ptr(plan.skin), _ptr(plan.hands_mean), _ptr(verts), _ptr(joints), _ptr(rot), _ptr(aa), B, _stream()), "mano")
+    R = A.rot6d_to_mat(pose6d.reshape(-1, 6))
+    raa = A.quat_to_aa(A.mat_to_quat(R)).reshape(B, 48)
+    rv, rj = A.mano_layer(sd, raa, betas)
+    assert rel_err(rot.reshape(-1, 3, 3), R) < 1e-6
+    # at exactly 180 degrees the axis sign is arbitrary (atan2 of +-0): compare the rotations the axis-angles encode, then the mesh
+    assert rel_err(A.rodrigues(aa.cpu().reshape(-1, 3)), A.rodrigues(raa.reshape(-1, 3))) < 1e-5
+    assert float((verts.cpu() - rv).abs().max()) < 0.05 and float((joints.cpu() - rj[:, list(A.OBMAN2MANO)]).abs().max()) < 0.05
+    # identity pose, zero shape: the template comes back
+    assert float((verts[0].cpu() - sd["mano_layer.th_v_template"][0] * 1000).abs().max()) < 1e-3
