@@ -316,12 +316,19 @@ class UNetPlan:
                 while (b + ".layer%d.%d.conv1.weight" % (li, j)) in sdp:
                     q = b + ".layer%d.%d" % (li, j)
                     stride = 2 if (li > 1 and j == 0) else 1
-                    c1 = PackedConv(sdp[q + ".conv1.weight"], None, device, stride=stride, pad=1, fold_bn=bn_scale_shift(sdp, q + ".bn1"))
-                    c2 = PackedConv(sdp[q + ".conv2.weight"], None, device, pad=1, fold_bn=bn_scale_shift(sdp, q + ".bn2"))
                     ds = None
                     if (q + ".downsample.0.weight") in sdp:
                         ds = PackedConv(sdp[q + ".downsample.0.weight"], None, device, stride=stride, fold_bn=bn_scale_shift(sdp, q + ".downsample.1"))
-                    blocks.append((c1, c2, ds))
+                    if (q + ".conv3.weight") in sdp:  # Bottleneck (v1.5: the stride sits on the 3x3), model/resnet.py:78-135
+                        c1 = PackedConv(sdp[q + ".conv1.weight"], None, device, fold_bn=bn_scale_shift(sdp, q + ".bn1"))
+                        c2 = PackedConv(sdp[q + ".conv2.weight"], None, device, stride=stride, pad=1, fold_bn=bn_scale_shift(sdp, q + ".bn2"))
+                        c3 = PackedConv(sdp[q + ".conv3.weight"], None, device, fold_bn=bn_scale_shift(sdp, q + ".bn3"))
+                        blocks.append((c1, c2, c3, ds))
+                        j += 1
+                        continue
+                    c1 = PackedConv(sdp[q + ".conv1.weight"], None, device, stride=stride, pad=1, fold_bn=bn_scale_shift(sdp, q + ".bn1"))
+                    c2 = PackedConv(sdp[q + ".conv2.weight"], None, device, pad=1, fold_bn=bn_scale_shift(sdp, q + ".bn2"))
+                    blocks.append((c1, c2, None, ds))
                     j += 1
                 self.layers.append(blocks)
         d = dims
@@ -361,10 +368,13 @@ class UNetPlan:
         x = maxpool3x3s2(x)
         feats = []
         for blocks in self.layers:
-            for c1, c2, ds in blocks:
+            for c1, c2, c3, ds in blocks:
                 h = conv(c1, x, flags=L.KPF_ACT_RELU)
                 idt = conv(ds, x) if ds is not None else x
-                x = conv(c2, h, res=idt, flags=L.KPF_RELU_AFTER_RES)
+                if c3 is None:
+                    x = conv(c2, h, res=idt, flags=L.KPF_RELU_AFTER_RES)
+                else:
+                    x = conv(c3, conv(c2, h, flags=L.KPF_ACT_RELU), res=idt, flags=L.KPF_RELU_AFTER_RES)
             feats.append(x)
         return feats
 
@@ -375,9 +385,9 @@ class UNetPlan:
         B = c1.B
 
         def level(up, skip, fus, lo, hi, fus_out_c):
-            cat = Act.empty(B, hi.H, hi.W, lo.C + hi.C, dev)
-            upsample2x(up(lo), cat.slice(0, lo.C))
-            skip(hi, out=cat.slice(lo.C, hi.C))
+            cat = Act.empty(B, hi.H, hi.W, up.cout + skip.cout, dev)
+            upsample2x(up(lo), cat.slice(0, up.cout))
+            skip(hi, out=cat.slice(up.cout, skip.cout))
             return fus(cat)
 
         c3f = level(self.up4, self.skip4, self.fus4, c4, c3, d[2])

@@ -19,7 +19,7 @@ CONVNEXT = {
     "base": ([3, 3, 27, 3], [128, 256, 512, 1024]),
     "large": ([3, 3, 27, 3], [192, 384, 768, 1536]),
 }
-RESNET = {18: ("basic", [2, 2, 2, 2])}
+RESNET = {18: ("basic", [2, 2, 2, 2]), 50: ("bottleneck", [3, 4, 6, 3]), 101: ("bottleneck", [3, 4, 23, 3])}  # model/resnetUnet.py:12-16
 
 
 def parse_net(net):
@@ -31,7 +31,7 @@ def parse_net(net):
         return "convnext", tail
     depth = int(tail)
     if depth not in RESNET:
-        raise NotImplementedError("resnet-%d (Bottleneck) backbones are not built yet" % depth)
+        raise KeyError(depth)  # the reference indexes its `resnet` dict (model/resnetUnet.py:255); 152 is listed there but never offered
     return "resnet", depth
 
 
@@ -115,7 +115,9 @@ def _convnext_unet(s, p, size, in_ch):
 
 
 def _resnet_unet(s, p, depth, in_ch):
+    """model/resnetUnet.py:248-289 (OfficialResNetUnet) over model/resnet.py:137-230 (BasicBlock :30-76 / Bottleneck :78-135)."""
     kind, layers = RESNET[depth]
+    e = 4 if kind == "bottleneck" else 1
     b = p + ".backbone"
     s.conv(b + ".conv1", 64, in_ch, 7, 7, bias=False)
     s.bn(b + ".bn1", 64)
@@ -124,15 +126,34 @@ def _resnet_unet(s, p, depth, in_ch):
         for j in range(n):
             q = b + ".layer%d.%d" % (li + 1, j)
             stride = 2 if (li > 0 and j == 0) else 1
-            s.conv(q + ".conv1", planes, inpl, 3, 3, bias=False)
-            s.bn(q + ".bn1", planes)
-            s.conv(q + ".conv2", planes, planes, 3, 3, bias=False)
-            s.bn(q + ".bn2", planes)
-            if stride != 1 or inpl != planes:
-                s.conv(q + ".downsample.0", planes, inpl, 1, 1, bias=False)
-                s.bn(q + ".downsample.1", planes)
-            inpl = planes
-    _unet_decoder(s, p, (64, 128, 256, 512), 128, False)
+            if kind == "basic":
+                s.conv(q + ".conv1", planes, inpl, 3, 3, bias=False)
+                s.bn(q + ".bn1", planes)
+                s.conv(q + ".conv2", planes, planes, 3, 3, bias=False)
+                s.bn(q + ".bn2", planes)
+            else:
+                s.conv(q + ".conv1", planes, inpl, 1, 1, bias=False)
+                s.bn(q + ".bn1", planes)
+                s.conv(q + ".conv2", planes, planes, 3, 3, bias=False)
+                s.bn(q + ".bn2", planes)
+                s.conv(q + ".conv3", planes * 4, planes, 1, 1, bias=False)
+                s.bn(q + ".bn3", planes * 4)
+            if stride != 1 or inpl != planes * e:
+                s.conv(q + ".downsample.0", planes * e, inpl, 1, 1, bias=False)
+                s.bn(q + ".downsample.1", planes * e)
+            inpl = planes * e
+    # decoder widths are fixed; only the encoder-facing inputs grow with the block expansion (model/resnetUnet.py:256-271)
+    s.residual(p + ".skip_layer4", 256 * e, 256)
+    s.residual(p + ".up4.0", 512 * e, 512)
+    s.residual(p + ".fusion_layer4", 512 + 256, 256)
+    s.residual(p + ".skip_layer3", 128 * e, 128)
+    s.residual(p + ".up3.0", 256, 256)
+    s.residual(p + ".fusion_layer3", 256 + 128, 128)
+    s.residual(p + ".skip_layer2", 64 * e, 64)
+    s.residual(p + ".up2.0", 128, 128)
+    s.residual(p + ".fusion_layer2", 128 + 64, 128)
+    for i, od in enumerate((63, 21, 21)):
+        s.conv(p + ".finals.%d" % i, od, 128, 1, 1, init="final")
 
 
 def _tr(s, p, din):

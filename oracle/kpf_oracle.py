@@ -102,7 +102,7 @@ def convnext_features(sd, p, x):
 
 
 def resnet_features(sd, p, x):
-    """model/resnet.py:232-244 (stem + maxpool + 4 stages of BasicBlock model/resnet.py:59-76)."""
+    """model/resnet.py:232-244 (stem + maxpool + 4 stages of BasicBlock model/resnet.py:59-76 or Bottleneck :113-135)."""
     x = F.conv2d(x, sd[p + ".conv1.weight"], None, stride=2, padding=3)
     x = F.relu(_bn(sd, p + ".bn1", x))
     x = F.max_pool2d(x, 3, 2, 1)
@@ -113,10 +113,15 @@ def resnet_features(sd, p, x):
             q = p + ".layer%d.%d" % (li, j)
             stride = 2 if (li > 1 and j == 0) else 1
             idt = x
-            out = F.conv2d(x, sd[q + ".conv1.weight"], None, stride=stride, padding=1)
-            out = F.relu(_bn(sd, q + ".bn1", out))
-            out = F.conv2d(out, sd[q + ".conv2.weight"], None, padding=1)
-            out = _bn(sd, q + ".bn2", out)
+            if (q + ".conv3.weight") in sd:  # Bottleneck: 1x1 -> 3x3 (carries the stride) -> 1x1 (x4)
+                out = F.relu(_bn(sd, q + ".bn1", F.conv2d(x, sd[q + ".conv1.weight"], None)))
+                out = F.relu(_bn(sd, q + ".bn2", F.conv2d(out, sd[q + ".conv2.weight"], None, stride=stride, padding=1)))
+                out = _bn(sd, q + ".bn3", F.conv2d(out, sd[q + ".conv3.weight"], None))
+            else:
+                out = F.conv2d(x, sd[q + ".conv1.weight"], None, stride=stride, padding=1)
+                out = F.relu(_bn(sd, q + ".bn1", out))
+                out = F.conv2d(out, sd[q + ".conv2.weight"], None, padding=1)
+                out = _bn(sd, q + ".bn2", out)
             if (q + ".downsample.0.weight") in sd:
                 idt = _bn(sd, q + ".downsample.1", F.conv2d(x, sd[q + ".downsample.0.weight"], None, stride=stride))
             x = F.relu(out + idt)

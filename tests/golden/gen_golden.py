@@ -195,10 +195,26 @@ def run_metrics():
     print("wrote", path)
 
 
+def dump_keys(net):
+    """state_keys_<net>.json: [key, shape, dtype] of the reference module's state_dict, in order (the state-dict contract)."""
+    model, _ = ref_import.build_reference_model(net)
+    rows = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in model.state_dict().items()]
+    with open(os.path.join(HERE, "state_keys_%s.json" % net.split("KPFusion-")[1]), "w") as f:
+        json.dump(rows, f)
+
+
 if __name__ == "__main__":
     if not ref_import.reference_available():
         sys.exit("reference tree not found; golden vectors can only be generated in the build container")
-    for net in ("KPFusion-convnext-tiny", "KPFusion-resnet-18"):
+    only = sys.argv[1:]
+    for net in ("KPFusion-convnext-tiny", "KPFusion-resnet-18", "KPFusion-resnet-50"):
+        if only and net not in only:
+            continue
         run(net)
         run_backbone(net)
-    run_metrics()
+    for net in ("KPFusion-convnext-tiny", "KPFusion-convnext-base", "KPFusion-resnet-18", "KPFusion-resnet-50", "KPFusion-resnet-101"):
+        if only and net not in only:
+            continue
+        dump_keys(net)
+    if not only:
+        run_metrics()

@@ -13,7 +13,7 @@ from keypointfusion_amd.spec import kpfusion_spec
 from oracle import kpf_oracle as O
 
 ATOL, RTOL = 2e-5, 1e-4  # fp32 CPU restatement vs reference; integer tensors exact
-NETS = ["convnext-tiny", "resnet-18"]
+NETS = ["convnext-tiny", "resnet-18", "resnet-50"]
 
 
 def close(a, b, atol=ATOL, rtol=RTOL):
@@ -23,7 +23,7 @@ def close(a, b, atol=ATOL, rtol=RTOL):
     assert (err <= atol + rtol * np.abs(b)).all(), "max abs err %.3e" % err.max()
 
 
-@pytest.mark.parametrize("net", ["convnext-tiny", "convnext-base", "resnet-18"])
+@pytest.mark.parametrize("net", ["convnext-tiny", "convnext-base", "resnet-18", "resnet-50", "resnet-101"])
 def test_state_dict_contract(net):
     """Key names, shapes, dtypes and order equal the reference module tree's state_dict."""
     ref = json.load(open(os.path.join(GOLDEN, "state_keys_%s.json" % net)))

@@ -188,7 +188,8 @@ def _model(net):
 
 
 @pytest.mark.parametrize("net,B,S", [("convnext-tiny", 2, 128), ("convnext-tiny", 1, 64), ("resnet-18", 2, 128), ("resnet-18", 1, 64),
-                                     ("convnext-base", 1, 64), ("convnext-small", 1, 64), ("convnext-tiny", 3, 96)])
+                                     ("convnext-base", 1, 64), ("convnext-small", 1, 64), ("convnext-tiny", 3, 96), ("resnet-50", 2, 128),
+                                     ("resnet-50", 1, 64), ("resnet-101", 1, 64), ("convnext-large", 1, 64)])
 def test_backbones_match_oracle(net, B, S):
     from oracle import kpf_oracle as O
     sd = synthetic_sd("KPFusion-" + net)
@@ -202,7 +203,7 @@ def test_backbones_match_oracle(net, B, S):
         assert e < 1e-3, "%s: rel err %.2e" % (name, e)  # north_star tolerance
         assert e < 2e-4, "%s: rel err %.2e (regression guard)" % (name, e)
     # against the committed reference-generated fixture as well (S=64 fixture holds full img_offset tensors)
-    if S == 64 and net in ("convnext-tiny", "resnet-18"):
+    if S == 64 and net in ("convnext-tiny", "resnet-18", "resnet-50"):
         z = np.load(os.path.join(GOLDEN, "backbone_%s_B1_S64.npz" % net))
         assert rel_err(out[0], torch.from_numpy(z["img_offset"])) < 1e-3
         assert rel_err(out[2], torch.from_numpy(z["img_offset_rgb"])) < 1e-3
@@ -226,7 +227,8 @@ def _run_full(net, B, seed=1):
     return b, ref, rsw, aux, out, sws, ctx, report
 
 
-@pytest.mark.parametrize("net,B,seed", [("convnext-tiny", 2, 1), ("resnet-18", 2, 1), ("convnext-tiny", 1, 1), ("convnext-tiny", 3, 7)])
+@pytest.mark.parametrize("net,B,seed", [("convnext-tiny", 2, 1), ("resnet-18", 2, 1), ("convnext-tiny", 1, 1), ("convnext-tiny", 3, 7),
+                                        ("resnet-50", 2, 1)])
 def test_full_forward_matches_oracle(net, B, seed):
     """End-to-end: all 6 results and both spatial weights within 1e-3 relative of the oracle, joints within 0.05 mm.
     Integer decisions (top-4 pixels, ball-query sets) must equal the oracle's except at fp32 near-ties of the oracle's own
