@@ -8,7 +8,7 @@ bench.py's cpu_baseline leg may import this module; keypointfusion_amd/ never do
 Why torch-CPU and not C/numpy: the path is floating-point convolution/GEMM work and the thing being restated *is*
 the reference's PyTorch-CPU forward (BASELINE.json north_star: "match the reference PyTorch-CPU forward"), so ATen's
 fp32 CPU kernels are the reference arithmetic itself; the integer/index sub-ops (ball query, top-4) are additionally
-restated in plain C in oracle/kpf_index_oracle.c.
+restated in plain C in oracle/kpf_index_oracle.c (built by `make -C oracle`, checked in tests/test_index_oracle.py).
 
 Pinning: the reference has no tests or golden vectors for this path, so the oracle is pinned against
 *outputs of the reference itself run in the build container*: tests/golden/gen_golden.py imports the reference
