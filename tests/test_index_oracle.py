@@ -88,7 +88,7 @@ def test_c_index_ops_equal_reference_fixture(net):
     sd = synthetic_sd("KPFusion-" + net)
     aux = {}
     res, _ = O.kpfusion_forward(sd, b["img_rgb"], b["img"], b["pcl"], b["center"], b["M"], b["cube"], b["cam_para"], 0.8, aux=aux)
-    for blk, joints in ((1, aux["joint_xyz0"]), (2, res[2])):  # block 2 groups around block 1's refined 3D joints (model/model.py:413)
+    for blk, joints in ((1, aux["joint_xyz0"]), (2, res[3])):  # block 2 starts from block 1's final_TR joints (model/model.py:413-418)
         xyz = torch.cat([b["pcl"], joints], 1).numpy()
         for gi, r in enumerate((0.1, 0.2, 0.4)):
             np.testing.assert_array_equal(c_ball_query(r, 64, xyz, joints.numpy()), z["b%d_ball%d" % (blk, gi)].astype(np.int32))
