@@ -31,6 +31,9 @@ extern "C" {
 #define KPF_RES_GAMMA 8u       /* y = res + gamma[n] * y          (convNeXT/convnext.py:48-51) */
 #define KPF_RELU_AFTER_RES 16u /* y = relu(res + y)               (model/resnet.py:72-73)  */
 #define KPF_ACT_LEAKY 64u      /* y = leaky_relu(acc + bias, 0.01) (model/mano_head.py:199) */
+#define KPF_IN_SPLIT 128u      /* `in` and `w` are in the split format below; needs a dense 1x1, Cin % 32 == 0, desc.w_unscale   */
+#define KPF_W_SPLIT 512u       /* only `w` is split: fp32 activations are split in registers (any conv shape with Cin % 32 == 0)  */
+#define KPF_OUT_SPLIT 256u     /* `out` is written in the split format (N, out_ld, out_coff multiples of 32)                     */
 #define KPF_OUT_NCHW 32u       /* store out[b][n][oy][ox] (dense), ignoring out_ld/out_coff */
 
 typedef struct kpf_conv_desc {
@@ -42,6 +45,7 @@ typedef struct kpf_conv_desc {
   int out_ld, out_coff;    /* NHWC destination pixel stride / first channel                         */
   int res_ld, res_coff;    /* residual source (NHWC) pixel stride / first channel                   */
   unsigned flags;
+  float w_unscale;         /* KPF_IN_SPLIT only: weights were packed as w * 2^s, the accumulator is scaled by 2^-s */
 } kpf_conv_desc;
 
 /*
@@ -55,6 +59,15 @@ typedef struct kpf_conv_desc {
  * w is [N][Kp] (PyTorch [out][in] order, taps reordered to (ky,kx,c)); bias may be NULL.
  * Requirements: Cin, in_ld, in_coff multiples of 4.  out/res ld and coff multiples of 4 select the float4 epilogue
  * (scalar stores otherwise).
+ *
+ * Split operands (KPF_IN_SPLIT / KPF_OUT_SPLIT): fp32-accurate GEMM on the f16 matrix cores.  A row of C values (C % 32 == 0)
+ * keeps its C*4 bytes but holds, per 32-channel block, [32 x f16 hi | 32 x f16 lo] with x ~= hi + lo (22 significant bits).
+ * With KPF_IN_SPLIT both `in` and `w` (rows of Kp) are in that format and each 32-deep K tile is 3 v_mfma_f32_16x16x32_f16
+ * (hi*hi + hi*lo + lo*hi) accumulated in fp32: per-product error ~2^-21, below the rounding noise of an fp32 accumulation chain,
+ * at 3/16 of the f32-input MFMA's cycles.  Weights are packed as w * 2^s (keeps the lo halves out of the f16 subnormals) and
+ * desc.w_unscale = 2^-s.  With KPF_W_SPLIT only the weights are pre-split: activations stay fp32 in memory and are split in registers
+ * after the LDS read (and after the operand prologue), at some VALU cost per fragment.  Producers of split activations: this function with KPF_OUT_SPLIT, kpf_layernorm_split_f32,
+ * kpf_dwconv7_ln_split_f32.  Values are clamped to +-65504 when split; callers bound their activations (LayerNorm / GELU outputs).
  */
 int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const float* w, const float* bias,
                    const float* pro_scale, const float* pro_shift, const float* gamma, const float* res,
@@ -83,6 +96,12 @@ int kpf_convnext_mlp_supported(int C);
  * Replaces convNeXT/convnext.py:205-214 in both data formats (stem/downsample norms).  In-place allowed.
  */
 int kpf_layernorm_f32(const float* x, const float* w, const float* b, float* y, long rows, int C, float eps, void* stream);
+
+/* Same two ops writing their output in the split operand format of kpf_conv2d_f32 (C % 32 == 0): the LayerNorm output feeds only
+ * pwconv1 / a downsample convolution, so it is split where it is produced. */
+int kpf_dwconv7_ln_split_f32(const float* x, const float* w_dw, const float* b_dw, const float* ln_w, const float* ln_b, float* y,
+                             int B, int H, int W, int C, float eps, void* stream);
+int kpf_layernorm_split_f32(const float* x, const float* w, const float* b, float* y, long rows, int C, float eps, void* stream);
 
 /*
  * Bilinear x2 upsampling, align_corners=False (nn.Upsample(scale_factor=2, mode='bilinear'),

@@ -40,3 +40,24 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// "Split" operand format for the 3 x f16 MFMA path (kpf_conv.hip): a row of C fp32 values (C % 32 == 0) occupies the same
+// C*4 bytes as C/32 blocks of [32 x f16 hi | 32 x f16 lo] with x ~= hi + lo (22 significant bits; |x| is clamped to the
+// f16 range).  Producers (GEMM / LayerNorm epilogues) write it, the GEMM's LDS-DMA staging reads it byte-for-byte like fp32.
+// ---------------------------------------------------------------------------------------------------------------
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void kpf_store_split4(float* row, int c, const f32x4 v) {  // c % 4 == 0
+  f16x4 h, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float x = __builtin_amdgcn_fmed3f(v[e], -65504.0f, 65504.0f);
+    h[e] = (_Float16)x;
+    l[e] = (_Float16)(x - (float)h[e]);
+  }
+  _Float16* blk = reinterpret_cast<_Float16*>(row + (c & ~31)) + (c & 31);
+  *reinterpret_cast<f16x4*>(blk) = h;
+  *reinterpret_cast<f16x4*>(blk + 32) = l;
+}

@@ -43,6 +43,7 @@ struct ConvArgs {
   int OH, OW, ohow, KH, KW, sh, sw, ph, pw;
   int out_ld, out_coff, res_ld, res_coff;
   const float* zero;  // 16 zero bytes in device memory: DMA source of padding / out-of-range chunks
+  float w_unscale;    // split path: weights were packed as w * 2^s, the accumulator is multiplied by 2^-s
   unsigned flags;
   int tilesN, nblk;
   int vec;  // 1: output/residual rows are 16-byte aligned -> float4 epilogue
@@ -78,8 +79,17 @@ constexpr int BK = 32;  // K-tile depth: 8 chunks of 16 B per staged row
 // Two LDS buffers per workgroup (64 KB at 128x128): two workgroups share a CU, so one's DMA issue, pipeline fill and epilogue run
 // under the other's MFMAs.
 
-template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO, int EPI>
+// SPLIT = true: both operands are in the split format of kpf_common.h ([32 x f16 hi | 32 x f16 lo] per 32-k block, byte-identical
+// staging) and a 32-deep K tile is three v_mfma_f32_16x16x32_f16 per fragment pair (hi*hi + hi*lo + lo*hi, fp32 accumulate): the
+// dropped lo*lo term and the 22-bit operands leave a per-product error of ~2^-21, below the rounding noise of an fp32 accumulation
+// chain, at 3/16 of the f32-input MFMA's cycles.
+// ARITH = 2: weights split as above, activations staged as fp32 and split in registers after the LDS read (after the BatchNorm+ReLU
+// operand prologue when there is one): any fp32 tensor can feed the f16 matrix cores without a format pass over HBM.
+enum { ARITH_F32 = 0, ARITH_SPLIT = 1, ARITH_SPLIT_W = 2 };
+
+template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO, int EPI, int ARITH>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const ConvArgs a) {
+  constexpr bool SPLIT = ARITH != ARITH_F32;
   constexpr int BM = 16 * TM * WM;
   constexpr int BN = 16 * TN * WN;
   constexpr int NW = WM * WN;               // waves per workgroup (4 or 8)
@@ -208,30 +218,87 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const ConvArgs 
     if (kt + 1 < nk) stage(kt + 1, cur ^ 1);  // next tile flies into the other buffer under this tile's MFMAs
     const float* xrow = lds + cur * TILE + (wm * TM * 16 + fr) * BK;
     const float* wrow = lds + cur * TILE + BM * BK + (wn * TN * 16 + fr) * BK;
+    if (SPLIT) {
+      // lane group fg multiplies k = 8fg .. 8fg+7 of the tile: hi halves are logical chunk fg, lo halves chunk 4 + fg of the row
+      const int ch = ((fg ^ rsw) << 2), cl = (((4 + fg) ^ rsw) << 2);
+      f16x8 xh[TM], xl[TM], wh[TN], wl[TN];
+      if (ARITH == ARITH_SPLIT) {
 #pragma unroll
-    for (int s = 0; s < BK / 16; ++s) {
-      const int sc = (((4 * s + fg) ^ rsw) << 2);  // 16-deep k-step s: this lane's k group is logical chunk 4s+fg
-      f32x4 xf[TM], wf[TN];
+        for (int j = 0; j < TM; ++j) {
+          xh[j] = *reinterpret_cast<const f16x8*>(xrow + j * 16 * BK + ch);
+          xl[j] = *reinterpret_cast<const f16x8*>(xrow + j * 16 * BK + cl);
+        }
+      } else {  // fp32 rows: k = 8fg .. 8fg+7 are logical chunks 2fg and 2fg+1
+        const int c0 = (((2 * fg) ^ rsw) << 2), c1 = (((2 * fg + 1) ^ rsw) << 2);
+        f32x4 sp0, sp1, tp0, tp1;
+        if (HAS_PRO) {
+          const int kk = kt * BK + 8 * fg;
+          sp0 = *reinterpret_cast<const f32x4*>(pro_s + kk);
+          sp1 = *reinterpret_cast<const f32x4*>(pro_s + kk + 4);
+          tp0 = *reinterpret_cast<const f32x4*>(pro_t + kk);
+          tp1 = *reinterpret_cast<const f32x4*>(pro_t + kk + 4);
+        }
 #pragma unroll
-      for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const f32x4*>(xrow + j * 16 * BK + sc);
+        for (int j = 0; j < TM; ++j) {
+          f32x4 u0 = *reinterpret_cast<const f32x4*>(xrow + j * 16 * BK + c0);
+          f32x4 u1 = *reinterpret_cast<const f32x4*>(xrow + j * 16 * BK + c1);
+          if (HAS_PRO) {
 #pragma unroll
-      for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const f32x4*>(wrow + i * 16 * BK + sc);
-      if (HAS_PRO) {  // eval-BatchNorm + ReLU on the activation operand (pre-activation Residual.conv1), k = channel for 1x1
-        const int kk = kt * BK + 16 * s + 4 * fg;
-        const f32x4 sp = *reinterpret_cast<const f32x4*>(pro_s + kk);
-        const f32x4 tp = *reinterpret_cast<const f32x4*>(pro_t + kk);
+            for (int e = 0; e < 4; ++e) {
+              u0[e] = fmaxf(fmaf(u0[e], sp0[e], tp0[e]), 0.f);
+              u1[e] = fmaxf(fmaf(u1[e], sp1[e], tp1[e]), 0.f);
+            }
+          }
 #pragma unroll
-        for (int j = 0; j < TM; ++j)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) xf[j][e] = fmaxf(fmaf(xf[j][e], sp[e], tp[e]), 0.f);
+          for (int e = 0; e < 4; ++e) {
+            const float v0 = __builtin_amdgcn_fmed3f(u0[e], -65504.0f, 65504.0f), v1 = __builtin_amdgcn_fmed3f(u1[e], -65504.0f, 65504.0f);
+            const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+            xh[j][e] = h0;
+            xh[j][4 + e] = h1;
+            xl[j][e] = (_Float16)(v0 - (float)h0);
+            xl[j][4 + e] = (_Float16)(v1 - (float)h1);
+          }
+        }
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int i = 0; i < TN; ++i) {
+        wh[i] = *reinterpret_cast<const f16x8*>(wrow + i * 16 * BK + ch);
+        wl[i] = *reinterpret_cast<const f16x8*>(wrow + i * 16 * BK + cl);
+      }
 #pragma unroll
-        for (int i = 0; i < TN; ++i)
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xh[j], acc[i][j], 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+      for (int s = 0; s < BK / 16; ++s) {
+        const int sc = (((4 * s + fg) ^ rsw) << 2);  // 16-deep k-step s: this lane's k group is logical chunk 4s+fg
+        f32x4 xf[TM], wf[TN];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const f32x4*>(xrow + j * 16 * BK + sc);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const f32x4*>(wrow + i * 16 * BK + sc);
+        if (HAS_PRO) {  // eval-BatchNorm + ReLU on the activation operand (pre-activation Residual.conv1), k = channel for 1x1
+          const int kk = kt * BK + 16 * s + 4 * fg;
+          const f32x4 sp = *reinterpret_cast<const f32x4*>(pro_s + kk);
+          const f32x4 tp = *reinterpret_cast<const f32x4*>(pro_t + kk);
 #pragma unroll
           for (int j = 0; j < TM; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][e], xf[j][e], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xf[j][e] = fmaxf(fmaf(xf[j][e], sp[e], tp[e]), 0.f);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][e], xf[j][e], acc[i][j], 0, 0, 0);
+      }
     }
     __syncthreads();  // next tile landed (vmcnt drained by the barrier's fence); every wave is done reading `cur`
   }
@@ -258,6 +325,10 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const ConvArgs 
         if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
         if (EPI == EPI_RES && (fl & KPF_RES_GAMMA)) gv = *reinterpret_cast<const f32x4*>(a.gamma + n);
         f32x4 v = acc[i][j];
+        if (SPLIT) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= a.w_unscale;
+        }
         if (EPI == EPI_RES) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -281,7 +352,10 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const ConvArgs 
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.01f * v[e]);
           }
         }
-        STORE4(a.out + m * a.out_ld + a.out_coff + n, v);
+        if (fl & KPF_OUT_SPLIT)
+          kpf_store_split4(a.out + m * a.out_ld + a.out_coff, n, v);
+        else
+          STORE4(a.out + m * a.out_ld + a.out_coff + n, v);
       }
     }
     return;
@@ -299,7 +373,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const ConvArgs 
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         if (n + e >= a.N) continue;
-        float y = acc[i][j][e] + (a.bias ? a.bias[n + e] : 0.f);
+        float y = (SPLIT ? acc[i][j][e] * a.w_unscale : acc[i][j][e]) + (a.bias ? a.bias[n + e] : 0.f);
         if (EPI == EPI_GELU) y = gelu_erf(y);
         if (EPI == EPI_LIN && (fl & KPF_ACT_RELU)) y = fmaxf(y, 0.f);
         if (EPI == EPI_LIN && (fl & KPF_ACT_LEAKY)) y = fmaxf(y, 0.01f * y);
@@ -308,20 +382,26 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const ConvArgs 
           y += a.res[(long)m * a.res_ld + a.res_coff + n + e];
           if (fl & KPF_RELU_AFTER_RES) y = fmaxf(y, 0.f);
         }
-        if (fl & KPF_OUT_NCHW)
+        if (fl & KPF_OUT_NCHW) {
           a.out[((long)b * a.N + n + e) * a.ohow + pix] = y;
-        else
+        } else if (fl & KPF_OUT_SPLIT) {
+          const float yc = __builtin_amdgcn_fmed3f(y, -65504.0f, 65504.0f);
+          const _Float16 h = (_Float16)yc;
+          _Float16* blk = reinterpret_cast<_Float16*>(a.out + (long)m * a.out_ld + a.out_coff + ((n + e) & ~31)) + ((n + e) & 31);
+          blk[0] = h;
+          blk[32] = (_Float16)(yc - (float)h);
+        } else
           a.out[(long)m * a.out_ld + a.out_coff + n + e] = y;
       }
     }
   }
 }
 
-template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO, int EPI>
+template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO, int EPI, int ARITH>
 int launch_one(const ConvArgs& a, hipStream_t st) {
   constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
   const size_t lds = (size_t)(2 * (BM + BN) * BK + (HAS_PRO ? 2 * a.Kp : 0)) * sizeof(float);
-  auto kern = igemm_f32_kernel<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI>;
+  auto kern = igemm_f32_kernel<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH>;
   static bool attr_set = false;  // > 64 KiB of dynamic LDS needs an opt-in; benign if two threads race to set it
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
@@ -342,29 +422,37 @@ int launch_one(const ConvArgs& a, hipStream_t st) {
 //   1x1 + operand prologue + linear/ReLU   (Residual.conv1)            1x1 + linear/ReLU        (heads, embeddings, skip convs)
 //   1x1 + GELU                             (ConvNeXt pwconv1)          1x1 + residual           (pwconv2, Residual.conv3)
 //   conv + linear/ReLU                     (3x3, stems, downsamples)   conv + residual          (BasicBlock.conv2)
-template <int TM, int TN, int WM, int WN>
-int launch_cfg(ConvArgs& a, bool is1x1, hipStream_t st) {
-  constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
-  const int tilesM = (a.M + BM - 1) / BM;
-  a.tilesN = (a.N + BN - 1) / BN;
-  a.nblk = tilesM * a.tilesN;
+// Instantiated per tile shape: {1x1 (+prologue | GELU | residual | linear), general conv (linear | residual)} x {f32 MFMA, split, split weights}.
+template <int TM, int TN, int WM, int WN, int ARITH>
+int launch_arith(ConvArgs& a, bool is1x1, hipStream_t st) {
   const bool res = a.flags & KPF_RES_ADD, gelu = a.flags & KPF_ACT_GELU;
   if (a.ps) {
-    if (!is1x1 || res || gelu) {
-      kpf_set_error("kpf_conv2d_f32: the operand prologue is only supported for 1x1 stride-1 convolutions with Cin %% 32 == 0 and a linear/ReLU epilogue");
+    if (!is1x1 || res || gelu || ARITH == ARITH_SPLIT) {
+      kpf_set_error("kpf_conv2d_f32: the operand prologue is only supported for 1x1 stride-1 convolutions with Cin %% 32 == 0, fp32 activations and a linear/ReLU epilogue");
       return KPF_EINVAL;
     }
-    return launch_one<TM, TN, WM, WN, true, true, EPI_LIN>(a, st);
+    return launch_one<TM, TN, WM, WN, true, true, EPI_LIN, ARITH == ARITH_SPLIT ? ARITH_F32 : ARITH>(a, st);
   }
   if (gelu) {
     if (!is1x1 || res) {
       kpf_set_error("kpf_conv2d_f32: GELU is only supported on 1x1 convolutions (Cin %% 32 == 0) without residual");
       return KPF_EINVAL;
     }
-    return launch_one<TM, TN, WM, WN, true, false, EPI_GELU>(a, st);
+    return launch_one<TM, TN, WM, WN, true, false, EPI_GELU, ARITH>(a, st);
   }
-  if (is1x1) return res ? launch_one<TM, TN, WM, WN, true, false, EPI_RES>(a, st) : launch_one<TM, TN, WM, WN, true, false, EPI_LIN>(a, st);
-  return res ? launch_one<TM, TN, WM, WN, false, false, EPI_RES>(a, st) : launch_one<TM, TN, WM, WN, false, false, EPI_LIN>(a, st);
+  if (is1x1) return res ? launch_one<TM, TN, WM, WN, true, false, EPI_RES, ARITH>(a, st) : launch_one<TM, TN, WM, WN, true, false, EPI_LIN, ARITH>(a, st);
+  return res ? launch_one<TM, TN, WM, WN, false, false, EPI_RES, ARITH>(a, st) : launch_one<TM, TN, WM, WN, false, false, EPI_LIN, ARITH>(a, st);
+}
+
+template <int TM, int TN, int WM, int WN>
+int launch_cfg(ConvArgs& a, bool is1x1, hipStream_t st) {
+  constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
+  const int tilesM = (a.M + BM - 1) / BM;
+  a.tilesN = (a.N + BN - 1) / BN;
+  a.nblk = tilesM * a.tilesN;
+  if (a.flags & KPF_IN_SPLIT) return launch_arith<TM, TN, WM, WN, ARITH_SPLIT>(a, is1x1, st);
+  if (a.flags & KPF_W_SPLIT) return launch_arith<TM, TN, WM, WN, ARITH_SPLIT_W>(a, is1x1, st);
+  return launch_arith<TM, TN, WM, WN, ARITH_F32>(a, is1x1, st);
 }
 
 // Tile choice.  The kernel is MFMA-bound and co-resident workgroups share a CU's matrix pipe (they hide each other's bubbles, they
@@ -433,6 +521,13 @@ extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const flo
     a.zero = zero_of_dev[dev];
   }
   a.flags = fl; a.tilesN = 0; a.nblk = 0;
+  a.w_unscale = (fl & (KPF_IN_SPLIT | KPF_W_SPLIT)) ? d->w_unscale : 1.0f;
+  if (fl & (KPF_IN_SPLIT | KPF_W_SPLIT))
+    KPF_REQUIRE(d->w_unscale > 0.f && d->Cin % 32 == 0 && d->in_coff % 4 == 0, "kpf_conv2d_f32: split operands need w_unscale > 0 and Cin %% 32 == 0 (Cin=%d)", d->Cin);
+  if (fl & KPF_IN_SPLIT) KPF_REQUIRE(d->in_coff % 32 == 0 && d->in_ld % 32 == 0 && !pro_scale, "kpf_conv2d_f32: split activations need in_ld, in_coff multiples of 32 and no operand prologue");
+  if (fl & KPF_OUT_SPLIT)
+    KPF_REQUIRE(d->N % 32 == 0 && d->out_coff % 32 == 0 && d->out_ld % 32 == 0 && !(fl & KPF_OUT_NCHW),
+                "kpf_conv2d_f32: split output needs N, out_ld, out_coff multiples of 32 (N=%d ld=%d coff=%d)", d->N, d->out_ld, d->out_coff);
   a.vec = (d->out_ld % 4 == 0 && d->out_coff % 4 == 0 && (!(fl & KPF_RES_ADD) || (d->res_ld % 4 == 0 && d->res_coff % 4 == 0))) ? 1 : 0;
   // the dense-1x1 fast path also needs whole K tiles (its staging reads 32 channels at a time without a K mask)
   const bool is1x1 = d->KH == 1 && d->KW == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0 &&

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ 
 // variance are xor-shuffle reductions inside the group — no LDS tile (which capped the occupancy of the first fused kernel),
 // and the activation is read once and written once (the unfused pair reads and writes it twice).
 // ---------------------------------------------------------------------------------------------------------------
-template <int LG>
+template <int LG, bool SPLIT>
 __global__ __launch_bounds__(256) void dwconv7_ln_wave_kernel(const float* __restrict__ x, const float* __restrict__ wdw,
                                                               const float* __restrict__ bdw, const float* __restrict__ lw,
                                                               const float* __restrict__ lb, float* __restrict__ y, int B, int H, int W,
@@ -281,7 +281,10 @@ __global__ __launch_bounds__(256) void dwconv7_ln_wave_kernel(const float* __res
         f32x4 o4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o4[e] = (v[e] - mean) * rstd * g[e] + be[e];
-        *reinterpret_cast<f32x4*>(yb + ((long)(y0 + rr) * W + x0 + t) * C) = o4;
+        if (SPLIT)
+          kpf_store_split4(yb - 4 * qc + ((long)(y0 + rr) * W + x0 + t) * C, 4 * qc, o4);
+        else
+          *reinterpret_cast<f32x4*>(yb + ((long)(y0 + rr) * W + x0 + t) * C) = o4;
       }
     }
   }
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(256) void dwconv7_ln_wave_kernel(const float* __res
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int LN_MAXV = 8;  // float4 per lane at LPR = 64 -> C <= 2048
 
-template <int LPR, int NV>
+template <int LPR, int NV, bool SPLIT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, float* __restrict__ y, long rows, int C,
                                                         float eps) {
@@ -344,7 +347,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + be[e];
-      *reinterpret_cast<f32x4*>(dst + 4 * c) = o;
+      if (SPLIT)  // in place is safe: a row's lanes share a wave and every load precedes the reduction shuffles
+        kpf_store_split4(dst, 4 * c, o);
+      else
+        *reinterpret_cast<f32x4*>(dst + 4 * c) = o;
     }
   }
 }
@@ -447,11 +453,14 @@ inline int grid_for(long total, int block = 256, int cap = 256 * 16) {
 
 }  // namespace
 
-extern "C" int kpf_dwconv7_ln_f32(const float* x, const float* w_dw, const float* b_dw, const float* ln_w, const float* ln_b,
-                                  float* y, int B, int H, int W, int C, float eps, void* stream) {
+static int layernorm_impl(const float* x, const float* w, const float* b, float* y, long rows, int C, float eps, void* stream, bool split);
+
+static int dwconv7_ln_impl(const float* x, const float* w_dw, const float* b_dw, const float* ln_w, const float* ln_b, float* y, int B, int H,
+                           int W, int C, float eps, void* stream, bool split) {
   KPF_REQUIRE(x && w_dw && b_dw && ln_w && ln_b && y, "kpf_dwconv7_ln_f32: null pointer");
   KPF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && C <= 2048, "kpf_dwconv7_ln_f32: bad shape B=%d H=%d W=%d C=%d", B, H, W, C);
   KPF_REQUIRE(kpf_aligned16(x) && kpf_aligned16(y) && kpf_aligned16(w_dw), "kpf_dwconv7_ln_f32: unaligned pointer");
+  KPF_REQUIRE(!split || C % 32 == 0, "kpf_dwconv7_ln_split_f32: C=%d must be a multiple of 32", C);
   const int C4 = C / 4;
   if (H * W >= 64 && C4 <= 64 && (size_t)49 * C * sizeof(float) <= 64 * 1024 && !getenv("KPF_DW_UNFUSED")) {
     // fused, one pass over the activation: channel quads of a pixel on one 32- or 64-lane group, LayerNorm by shuffles
@@ -461,16 +470,24 @@ extern "C" int kpf_dwconv7_ln_f32(const float* x, const float* w_dw, const float
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (C4 <= 32) {
       const long threads = groups * 32;
-      hipLaunchKernelGGL((dwconv7_ln_wave_kernel<32>), dim3((unsigned)((threads + 255) / 256)), dim3(256), wbytes, st, x, w_dw, b_dw, ln_w, ln_b,
-                         y, B, H, W, C, xstrips, ypairs, eps);
+      if (split)
+        hipLaunchKernelGGL((dwconv7_ln_wave_kernel<32, true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), wbytes, st, x, w_dw, b_dw, ln_w,
+                           ln_b, y, B, H, W, C, xstrips, ypairs, eps);
+      else
+        hipLaunchKernelGGL((dwconv7_ln_wave_kernel<32, false>), dim3((unsigned)((threads + 255) / 256)), dim3(256), wbytes, st, x, w_dw, b_dw, ln_w,
+                           ln_b, y, B, H, W, C, xstrips, ypairs, eps);
     } else {
       const long threads = groups * 64;
-      hipLaunchKernelGGL((dwconv7_ln_wave_kernel<64>), dim3((unsigned)((threads + 255) / 256)), dim3(256), wbytes, st, x, w_dw, b_dw, ln_w, ln_b,
-                         y, B, H, W, C, xstrips, ypairs, eps);
+      if (split)
+        hipLaunchKernelGGL((dwconv7_ln_wave_kernel<64, true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), wbytes, st, x, w_dw, b_dw, ln_w,
+                           ln_b, y, B, H, W, C, xstrips, ypairs, eps);
+      else
+        hipLaunchKernelGGL((dwconv7_ln_wave_kernel<64, false>), dim3((unsigned)((threads + 255) / 256)), dim3(256), wbytes, st, x, w_dw, b_dw, ln_w,
+                           ln_b, y, B, H, W, C, xstrips, ypairs, eps);
     }
     return kpf_check_launch("kpf_dwconv7_ln_f32");
   }
-  if (H * W >= 64) {
+  if (H * W >= 64 || split) {
     // two launches: register-tiled depthwise conv, then the row LayerNorm in place (each streams the tensor once; measured faster
     // than the single fused kernel, whose LDS output tile caps occupancy).  Tiny maps keep the fused kernel (one launch).
     static const int px_env = []() { const char* e = getenv("KPF_DW_PX"); return e ? atoi(e) : 8; }();  // tuning aid
@@ -489,7 +506,7 @@ extern "C" int kpf_dwconv7_ln_f32(const float* x, const float* w_dw, const float
     }
     int rc = kpf_check_launch("kpf_dwconv7_ln_f32");
     if (rc) return rc;
-    return kpf_layernorm_f32(y, ln_w, ln_b, y, (long)B * H * W, C, eps, stream);
+    return layernorm_impl(y, ln_w, ln_b, y, (long)B * H * W, C, eps, stream, split);
   }
   int S = 1;
   while (S * 2 * C4 <= 256 && S * DW_T < W) S *= 2;  // strips per block: <= 256 threads, no wider than the row
@@ -502,14 +519,27 @@ extern "C" int kpf_dwconv7_ln_f32(const float* x, const float* w_dw, const float
   return kpf_check_launch("kpf_dwconv7_ln_f32");
 }
 
-extern "C" int kpf_layernorm_f32(const float* x, const float* w, const float* b, float* y, long rows, int C, float eps,
-                                 void* stream) {
+extern "C" int kpf_dwconv7_ln_f32(const float* x, const float* w_dw, const float* b_dw, const float* ln_w, const float* ln_b,
+                                  float* y, int B, int H, int W, int C, float eps, void* stream) {
+  return dwconv7_ln_impl(x, w_dw, b_dw, ln_w, ln_b, y, B, H, W, C, eps, stream, false);
+}
+extern "C" int kpf_dwconv7_ln_split_f32(const float* x, const float* w_dw, const float* b_dw, const float* ln_w, const float* ln_b,
+                                        float* y, int B, int H, int W, int C, float eps, void* stream) {
+  return dwconv7_ln_impl(x, w_dw, b_dw, ln_w, ln_b, y, B, H, W, C, eps, stream, true);
+}
+
+static int layernorm_impl(const float* x, const float* w, const float* b, float* y, long rows, int C, float eps, void* stream, bool split) {
   KPF_REQUIRE(x && w && b && y && rows > 0, "kpf_layernorm_f32: null pointer / empty");
   KPF_REQUIRE(C % 4 == 0 && C > 0 && C <= 64 * 4 * LN_MAXV, "kpf_layernorm_f32: C=%d unsupported", C);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int C4 = C / 4;
-#define KPF_LN(LPR, NV) \
-  hipLaunchKernelGGL((layernorm_kernel<LPR, NV>), dim3((unsigned)((rows + 256 / LPR - 1) / (256 / LPR))), dim3(256), 0, st, x, w, b, y, rows, C, eps)
+  KPF_REQUIRE(!split || C % 32 == 0, "kpf_layernorm_split_f32: C=%d must be a multiple of 32", C);
+#define KPF_LN(LPR, NV)                                                                                                                          \
+  do {                                                                                                                                           \
+    const dim3 g((unsigned)((rows + 256 / LPR - 1) / (256 / LPR)));                                                                              \
+    if (split) hipLaunchKernelGGL((layernorm_kernel<LPR, NV, true>), g, dim3(256), 0, st, x, w, b, y, rows, C, eps);                             \
+    else hipLaunchKernelGGL((layernorm_kernel<LPR, NV, false>), g, dim3(256), 0, st, x, w, b, y, rows, C, eps);                                  \
+  } while (0)
   if (C4 <= 16) KPF_LN(16, 1);
   else if (C4 <= 32) KPF_LN(32, 1);
   else if (C4 <= 64) KPF_LN(64, 1);
@@ -518,6 +548,13 @@ extern "C" int kpf_layernorm_f32(const float* x, const float* w, const float* b,
   else KPF_LN(64, LN_MAXV);
 #undef KPF_LN
   return kpf_check_launch("kpf_layernorm_f32");
+}
+
+extern "C" int kpf_layernorm_f32(const float* x, const float* w, const float* b, float* y, long rows, int C, float eps, void* stream) {
+  return layernorm_impl(x, w, b, y, rows, C, eps, stream, false);
+}
+extern "C" int kpf_layernorm_split_f32(const float* x, const float* w, const float* b, float* y, long rows, int C, float eps, void* stream) {
+  return layernorm_impl(x, w, b, y, rows, C, eps, stream, true);
 }
 
 extern "C" int kpf_upsample2x_f32(const float* src, float* dst, int B, int H, int W, int C, int dst_ld, int dst_coff,

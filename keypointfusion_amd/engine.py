@@ -19,6 +19,9 @@ from .spec import CONVNEXT, parse_net
 
 BN_EPS = 1e-5
 FORCE_UNFUSED_MLP = bool(int(__import__("os").environ.get("KPF_UNFUSED_MLP", "0")))  # A/B switch for tuning
+# GEMM arithmetic of the ConvNeXt pointwise MLPs: "f32" = f32-input MFMA; "split" = 3 x f16 MFMA on split operands (include/kpf.h)
+GEMM_MODE = __import__("os").environ.get("KPF_GEMM", "f32")
+F16_MAX = 65504.0
 
 
 # Per-launch profiling hook (bench.py): when PROFILE is a list, every MFMA-kernel launch is bracketed by HIP events recorded on
@@ -47,12 +50,13 @@ def _stream():
 
 class Act:
     """A channel slice [coff, coff+C) of an NHWC buffer with pixel stride ld."""
-    __slots__ = ("buf", "B", "H", "W", "C", "ld", "coff")
+    __slots__ = ("buf", "B", "H", "W", "C", "ld", "coff", "split")
 
-    def __init__(self, buf, B, H, W, C, ld=None, coff=0):
+    def __init__(self, buf, B, H, W, C, ld=None, coff=0, split=False):
         self.buf, self.B, self.H, self.W, self.C = buf, B, H, W, C
         self.ld = C if ld is None else ld
         self.coff = coff
+        self.split = split  # rows hold [32 x f16 hi | 32 x f16 lo] blocks instead of fp32 (same bytes; include/kpf.h)
 
     @staticmethod
     def empty(B, H, W, C, device):
@@ -81,7 +85,7 @@ class PackedConv:
     """Weights of one convolution/linear in kernel layout: w [N][Kp] with k = (ky,kx,c), bias [N], optional input
     prologue (scale, shift) [Cin].  `view_kw` > 1 marks a patchify convolution executed as KHx1 over a merged view."""
 
-    def __init__(self, weight, bias, device, stride=1, pad=0, fold_bn=None, prologue=None, cin_pad=None, patchify=False):
+    def __init__(self, weight, bias, device, stride=1, pad=0, fold_bn=None, prologue=None, cin_pad=None, patchify=False, n_pad=None):
         w = weight.detach().double().cpu()
         if w.dim() == 2:
             w = w[:, :, None, None]
@@ -93,6 +97,10 @@ class PackedConv:
             s, t = fold_bn
             w = w * s.cpu()[:, None, None, None]
             b = b * s.cpu() + t.cpu()
+        if n_pad is not None and n_pad > N:  # extra output channels that are identically zero (zero rows, zero bias)
+            w = torch.cat([w, torch.zeros(n_pad - N, Cin, KH, KW, dtype=w.dtype)], 0)
+            b = torch.cat([b, torch.zeros(n_pad - N, dtype=b.dtype)])
+            N = n_pad
         if cin_pad is not None and cin_pad > Cin:
             w = torch.cat([w, torch.zeros(N, cin_pad - Cin, KH, KW, dtype=w.dtype)], 1)
             Cin = cin_pad
@@ -115,6 +123,7 @@ class PackedConv:
         wp[:, :K] = w.reshape(N, K)
         self.w = wp.float().to(device)
         self.b = b.float().to(device)
+        self.split_allowed = True
         self.ps = self.pt = None
         if prologue is not None:
             s, t = prologue
@@ -124,8 +133,27 @@ class PackedConv:
     def flops(self, M):
         return 2.0 * M * self.N * self.K
 
+    def split_weights(self):
+        """(w_split, w_unscale): rows of [Kp/32][hi 32 | lo 32] f16 of w * 2^s (s keeps the lo halves out of the f16 subnormals),
+        viewed as fp32 [N][Kp]; built once from the fp32 pack (exactly representable inputs: the split is of the fp32 weights)."""
+        if getattr(self, "_ws", None) is None:
+            assert self.Kp % 32 == 0
+            w = self.w.double().cpu()
+            amax = float(w.abs().max())
+            s = 7 - math.floor(math.log2(amax)) if amax > 0 else 0
+            ws = w * (2.0 ** s)
+            hi = ws.half()
+            lo = (ws - hi.double()).half()
+            blk = torch.stack([hi.view(self.N, self.Kp // 32, 32), lo.view(self.N, self.Kp // 32, 32)], 2).contiguous()  # N, K/32, 2, 32
+            self._ws = blk.view(torch.float32).reshape(self.N, self.Kp).contiguous().to(self.w.device)
+            self._wus = 2.0 ** (-s)
+        return self._ws, self._wus
 
-def conv(pc, x, out=None, flags=0, gamma=None, res=None, out_nchw=None):
+    def row_l1(self):
+        return float(self.w.abs().sum(1).max())
+
+
+def conv(pc, x, out=None, flags=0, gamma=None, res=None, out_nchw=None, out_split=False):
     """Launch kpf_conv2d_f32.  x: Act; out: Act (or None to allocate dense); res: Act."""
     lib = L.load()
     B = x.B
@@ -157,22 +185,35 @@ def conv(pc, x, out=None, flags=0, gamma=None, res=None, out_nchw=None):
         d.res_ld, d.res_coff = res.ld, res.coff
     if gamma is not None:
         flags |= L.KPF_RES_GAMMA
+    w = pc.w
+    if x.split:
+        flags |= L.KPF_IN_SPLIT
+        w, d.w_unscale = pc.split_weights()
+    elif GEMM_MODE == "split" and pc.Cin % 32 == 0 and pc.split_allowed:
+        flags |= L.KPF_W_SPLIT  # fp32 activations, split in registers
+        w, d.w_unscale = pc.split_weights()
+    if out_split:
+        flags |= L.KPF_OUT_SPLIT
+        out.split = True
+    elif out is not None and out_nchw is None:
+        out.split = False
     d.flags = flags
     M = B * OH * OW
     # algorithmic bytes: input pixels once, weights once, output once (+ residual once)
     nbytes = 4.0 * (B * IH * IW * pc.Cin + pc.N * pc.K + M * pc.N * (2 if res is not None else 1))
-    _launch("igemm_f32_kernel", pc.flops(M), nbytes, (M, pc.N, pc.K, pc.KH, pc.KW),
-            lambda: L.check(lib.kpf_conv2d_f32(C.byref(d), _ptr(x.buf), _ptr(pc.w), _ptr(pc.b), _ptr(pc.ps), _ptr(pc.pt), _ptr(gamma),
+    _launch("igemm_split_kernel" if flags & (L.KPF_IN_SPLIT | L.KPF_W_SPLIT) else "igemm_f32_kernel", pc.flops(M), nbytes, (M, pc.N, pc.K, pc.KH, pc.KW),
+            lambda: L.check(lib.kpf_conv2d_f32(C.byref(d), _ptr(x.buf), _ptr(w), _ptr(pc.b), _ptr(pc.ps), _ptr(pc.pt), _ptr(gamma),
                                                _ptr(res.buf if res is not None else None), _ptr(optr), _stream()), "kpf_conv2d_f32"))
     return out
 
 
-def layernorm(x, w, b, eps, out=None):
+def layernorm(x, w, b, eps, out=None, out_split=False):
     lib = L.load()
     assert x.ld == x.C and x.coff == 0
     out = x if out is None else out
-    L.check(lib.kpf_layernorm_f32(_ptr(x.buf), _ptr(w), _ptr(b), _ptr(out.buf), x.B * x.H * x.W, x.C, eps, _stream()),
-            "kpf_layernorm_f32")
+    fn = lib.kpf_layernorm_split_f32 if out_split else lib.kpf_layernorm_f32
+    L.check(fn(_ptr(x.buf), _ptr(w), _ptr(b), _ptr(out.buf), x.B * x.H * x.W, x.C, eps, _stream()), "kpf_layernorm_f32")
+    out.split = out_split
     return out
 
 
@@ -216,24 +257,29 @@ def maxpool3x3s2(x):
 # ----------------------------------------------------------------------------------------------------------------
 class ResidualPlan:
     """Pre-activation bottleneck of model/hourglass.py:87-119 as 3 (4 with a skip conv) MFMA launches:
-    conv1 = [bn1+relu prologue] 1x1 [bn2 folded, relu] ; conv2 = 3x3 [bn3 folded, relu] ; conv3 = 1x1 + residual."""
+    conv1 = [bn1+relu prologue] 1x1 [bn2 folded, relu] ; conv2 = 3x3 [bn3 folded, relu] ; conv3 = 1x1 + residual.
+    In split mode the two hidden tensors (consumed only by the next convolution) are written in the split operand format, their
+    width padded to a multiple of 32 with identically-zero channels; the block input stays fp32 (it is also the residual)."""
 
     def __init__(self, sd, p, device):
         cin = sd[p + ".conv1.conv.weight"].shape[1]
         cout = sd[p + ".conv3.conv.weight"].shape[0]
+        h = cout // 2
         self.cin, self.cout = cin, cout
+        self.split = GEMM_MODE == "split"
+        hp = (h + 31) // 32 * 32 if self.split else h
         self.c1 = PackedConv(sd[p + ".conv1.conv.weight"], sd[p + ".conv1.conv.bias"], device,
-                             fold_bn=bn_scale_shift(sd, p + ".bn2"), prologue=bn_scale_shift(sd, p + ".bn1"))
+                             fold_bn=bn_scale_shift(sd, p + ".bn2"), prologue=bn_scale_shift(sd, p + ".bn1"), n_pad=hp)
         self.c2 = PackedConv(sd[p + ".conv2.conv.weight"], sd[p + ".conv2.conv.bias"], device, pad=1,
-                             fold_bn=bn_scale_shift(sd, p + ".bn3"))
-        self.c3 = PackedConv(sd[p + ".conv3.conv.weight"], sd[p + ".conv3.conv.bias"], device)
+                             fold_bn=bn_scale_shift(sd, p + ".bn3"), cin_pad=hp, n_pad=hp)
+        self.c3 = PackedConv(sd[p + ".conv3.conv.weight"], sd[p + ".conv3.conv.bias"], device, cin_pad=hp)
         self.skip = None
         if cin != cout:
             self.skip = PackedConv(sd[p + ".skip_layer.conv.weight"], sd[p + ".skip_layer.conv.bias"], device)
 
     def __call__(self, x, out=None):
-        h = conv(self.c1, x, flags=L.KPF_ACT_RELU)
-        h = conv(self.c2, h, flags=L.KPF_ACT_RELU)
+        h = conv(self.c1, x, flags=L.KPF_ACT_RELU, out_split=self.split)
+        h = conv(self.c2, h, flags=L.KPF_ACT_RELU, out_split=self.split)
         if out is None:
             out = Act.empty(x.B, x.H, x.W, self.cout, x.buf.device)
         if self.skip is not None:
@@ -259,6 +305,11 @@ class ConvNeXtBlockPlan:
         self.pw1 = PackedConv(sd[p + ".pwconv1.weight"], sd[p + ".pwconv1.bias"], device)
         self.pw2 = PackedConv(sd[p + ".pwconv2.weight"], sd[p + ".pwconv2.bias"], device)
         self.gamma = sd[p + ".gamma"].detach().float().to(device)
+        # split (3 x f16) arithmetic needs activations inside the f16 range: |LN out| <= sqrt(C) max|w| + max|b| (a normalised row has
+        # L2 norm sqrt(C)), |pw1 out| <= max row L1 norm of W1 times that, plus the bias; GELU does not grow magnitudes
+        ln_bound = math.sqrt(c) * float(self.lnw.abs().max()) + float(self.lnb.abs().max())
+        h_bound = self.pw1.row_l1() * ln_bound + float(self.pw1.b.abs().max())
+        self.split_ok = c % 32 == 0 and ln_bound < F16_MAX and h_bound < F16_MAX
         self.fused = bool(L.load().kpf_convnext_mlp_supported(c))
         if self.fused:  # fused MLP kernel takes the PyTorch layouts as they are
             self.w1 = sd[p + ".pwconv1.weight"].detach().float().contiguous().to(device)
@@ -268,6 +319,14 @@ class ConvNeXtBlockPlan:
 
     def __call__(self, x, y, h):
         lib = L.load()
+        if GEMM_MODE == "split" and self.split_ok and not (self.fused and not FORCE_UNFUSED_MLP):
+            L.check(lib.kpf_dwconv7_ln_split_f32(_ptr(x.buf), _ptr(self.wdw), _ptr(self.bdw), _ptr(self.lnw), _ptr(self.lnb),
+                                                 _ptr(y.buf), x.B, x.H, x.W, x.C, 1e-6, _stream()), "kpf_dwconv7_ln_split_f32")
+            y.split = True
+            conv(self.pw1, y, out=h, flags=L.KPF_ACT_GELU, out_split=True)
+            conv(self.pw2, h, out=x, gamma=self.gamma, res=x)
+            y.split = h.split = False
+            return x
         L.check(lib.kpf_dwconv7_ln_f32(_ptr(x.buf), _ptr(self.wdw), _ptr(self.bdw), _ptr(self.lnw), _ptr(self.lnb),
                                        _ptr(y.buf), x.B, x.H, x.W, x.C, 1e-6, _stream()), "kpf_dwconv7_ln_f32")
         if self.fused and not FORCE_UNFUSED_MLP:
@@ -298,8 +357,10 @@ class UNetPlan:
             self.stem = PackedConv(sdp[b + ".downsample_layers.0.0.weight"], sdp[b + ".downsample_layers.0.0.bias"], device,
                                    stride=4, patchify=True)
             self.stem_ln = (sdp[b + ".downsample_layers.0.1.weight"].float().to(device), sdp[b + ".downsample_layers.0.1.bias"].float().to(device))
-            self.down, self.down_ln = [None], [None]
+            self.down, self.down_ln, self.down_ln_bound = [None], [None], [None]
             for i in range(1, 4):
+                lw_, lb_ = sdp[b + ".downsample_layers.%d.0.weight" % i], sdp[b + ".downsample_layers.%d.0.bias" % i]
+                self.down_ln_bound.append(math.sqrt(lw_.numel()) * float(lw_.abs().max()) + float(lb_.abs().max()))
                 self.down_ln.append((sdp[b + ".downsample_layers.%d.0.weight" % i].float().to(device),
                                      sdp[b + ".downsample_layers.%d.0.bias" % i].float().to(device)))
                 self.down.append(PackedConv(sdp[b + ".downsample_layers.%d.1.weight" % i], sdp[b + ".downsample_layers.%d.1.bias" % i],
@@ -353,7 +414,9 @@ class UNetPlan:
                 layernorm(cur, self.stem_ln[0], self.stem_ln[1], 1e-6)
             else:
                 t = Act.empty(cur.B, cur.H, cur.W, cur.C, self.device)
-                layernorm(cur, self.down_ln[i][0], self.down_ln[i][1], 1e-6, out=t)
+                # the normalised map feeds only the 2x2/s2 convolution: split it where it is produced (|LN out| is bounded)
+                sp = GEMM_MODE == "split" and cur.C % 32 == 0 and self.down_ln_bound[i] < F16_MAX
+                layernorm(cur, self.down_ln[i][0], self.down_ln[i][1], 1e-6, out=t, out_split=sp)
                 cur = conv(self.down[i], t)
             y = Act.empty(cur.B, cur.H, cur.W, cur.C, self.device)
             h = Act.empty(cur.B, cur.H, cur.W, 4 * cur.C, self.device)

@@ -16,12 +16,15 @@ KPF_RES_GAMMA = 8
 KPF_RELU_AFTER_RES = 16
 KPF_OUT_NCHW = 32
 KPF_ACT_LEAKY = 64
+KPF_IN_SPLIT = 128
+KPF_OUT_SPLIT = 256
+KPF_W_SPLIT = 512
 
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "B", "IH", "IW", "Cin", "in_ld", "in_coff", "OH", "OW", "N", "KH", "KW", "sh", "sw", "ph", "pw", "Kp",
-        "out_ld", "out_coff", "res_ld", "res_coff")] + [("flags", C.c_uint)]
+        "out_ld", "out_coff", "res_ld", "res_coff")] + [("flags", C.c_uint), ("w_unscale", C.c_float)]
 
 
 _P = C.c_void_p
@@ -29,6 +32,8 @@ _SIGS = {
     "kpf_conv2d_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "kpf_dwconv7_ln_f32": [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P],
     "kpf_layernorm_f32": [_P, _P, _P, _P, C.c_long, C.c_int, C.c_float, _P],
+    "kpf_layernorm_split_f32": [_P, _P, _P, _P, C.c_long, C.c_int, C.c_float, _P],
+    "kpf_dwconv7_ln_split_f32": [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P],
     "kpf_upsample2x_f32": [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P],
     "kpf_nchw_to_nhwc_f32": [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P],
     "kpf_nhwc_to_nchw_f32": [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P],

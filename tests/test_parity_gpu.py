@@ -420,3 +420,114 @@ def test_fused_convnext_mlp(C, M):
     L.check(L.load().kpf_convnext_mlp_f32(*[E._ptr(t) for t in d], E._ptr(d[1]), M, C, E._stream()))
     torch.cuda.synchronize()
     assert rel_err(d[1], ref) < 1e-5
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# split (3 x f16 MFMA) GEMM arithmetic
+# ----------------------------------------------------------------------------------------------------------------
+def to_split(t):
+    """fp32 [..., C] -> same-shape fp32 tensor whose bytes are [32 x f16 hi | 32 x f16 lo] per 32-channel block (include/kpf.h)."""
+    C = t.shape[-1]
+    hi = t.half()
+    lo = (t - hi.float()).half()
+    blk = torch.stack([hi.reshape(-1, C // 32, 32), lo.reshape(-1, C // 32, 32)], 2).contiguous()
+    return blk.view(torch.float32).reshape(t.shape)
+
+
+def from_split(t):
+    C = t.shape[-1]
+    blk = t.contiguous().view(torch.float16).reshape(-1, C // 32, 2, 32).float()
+    return (blk[:, :, 0] + blk[:, :, 1]).reshape(t.shape)
+
+
+@pytest.mark.parametrize("M,N,K,wscale", [(1024, 384, 96, 0.1), (16384, 1536, 384, 0.05), (4096, 768, 3072, 0.02), (300, 96, 384, 1e-3),
+                                          (777, 160, 64, 0.3)])
+def test_split_gemm_is_as_accurate_as_fp32(M, N, K, wscale):
+    """kpf_conv2d_f32 with KPF_IN_SPLIT against an fp64 product: the 3 x f16 split must be at least as close to the exact result as
+    the f32-input MFMA path and the CPU's fp32 GEMM (per-product error ~2^-21, fp32 accumulation in all three)."""
+    from keypointfusion_amd.engine import Act, PackedConv, conv
+    from keypointfusion_amd import lib as L
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * wscale
+    bias = torch.randn(N, generator=g) * 0.1
+    ref = a.double() @ w.double().t() + bias.double()
+    pc = PackedConv(w, bias, dev)
+    xa = Act(a.to(dev).view(-1), M, 1, 1, K)
+    o32 = conv(pc, xa).buf.view(M, N).cpu().double()
+    xs = Act(to_split(a).to(dev).view(-1), M, 1, 1, K, split=True)
+    osp = conv(pc, xs).buf.view(M, N).cpu().double()
+    cpu32 = (a @ w.t() + bias).double()
+    den = ref.abs().max()
+    e_split, e_mfma, e_cpu = [float((o - ref).abs().max() / den) for o in (osp, o32, cpu32)]
+    assert e_split < 2e-6, (e_split, e_mfma, e_cpu)
+    assert e_split < 2.0 * max(e_mfma, e_cpu) + 1e-7, (e_split, e_mfma, e_cpu)
+    # split output of the same product (GELU epilogue): decode and compare
+    if N % 32 == 0:
+        out = Act(torch.empty(M * N, device=dev), M, 1, 1, N)
+        conv(pc, xs, out=out, flags=L.KPF_ACT_GELU, out_split=True)
+        got = from_split(out.buf.view(M, N).cpu()).double()
+        want = F.gelu(ref)
+        assert float((got - want).abs().max() / want.abs().max()) < 2e-6
+
+
+def test_split_layernorm_producers():
+    from keypointfusion_amd import lib as L
+    from keypointfusion_amd.engine import _ptr, _stream
+    dev = _dev()
+    lib = L.load()
+    torch.manual_seed(3)
+    for B, H, W, C in ((2, 16, 16, 192), (1, 8, 8, 384), (2, 12, 20, 96), (1, 4, 4, 768)):
+        x = torch.randn(B, H, W, C) * 3 + 0.5
+        wdw, bdw = torch.randn(49, C) / 7, torch.randn(C) * 0.1
+        lw, lb = torch.rand(C) + 0.5, torch.randn(C) * 0.1
+        dx, dw, db, dlw, dlb = (t.to(dev).contiguous() for t in (x, wdw, bdw, lw, lb))
+        y32 = torch.empty_like(dx)
+        ysp = torch.empty_like(dx)
+        L.check(lib.kpf_dwconv7_ln_f32(_ptr(dx), _ptr(dw), _ptr(db), _ptr(dlw), _ptr(dlb), _ptr(y32), B, H, W, C, 1e-6, _stream()), "dw")
+        L.check(lib.kpf_dwconv7_ln_split_f32(_ptr(dx), _ptr(dw), _ptr(db), _ptr(dlw), _ptr(dlb), _ptr(ysp), B, H, W, C, 1e-6, _stream()), "dws")
+        assert rel_err(from_split(ysp.cpu()), y32.cpu()) < 1e-6
+        z32 = torch.empty_like(dx)
+        zsp = torch.empty_like(dx)
+        L.check(lib.kpf_layernorm_f32(_ptr(dx), _ptr(dlw), _ptr(dlb), _ptr(z32), B * H * W, C, 1e-6, _stream()), "ln")
+        L.check(lib.kpf_layernorm_split_f32(_ptr(dx), _ptr(dlw), _ptr(dlb), _ptr(zsp), B * H * W, C, 1e-6, _stream()), "lns")
+        assert rel_err(from_split(zsp.cpu()), z32.cpu()) < 1e-6
+        inpl = dx.clone()  # in place, as the two-kernel depthwise path uses it
+        L.check(lib.kpf_layernorm_split_f32(_ptr(inpl), _ptr(dlw), _ptr(dlb), _ptr(inpl), B * H * W, C, 1e-6, _stream()), "lns")
+        assert torch.equal(inpl.cpu().view(torch.int32), zsp.cpu().view(torch.int32))
+
+
+@pytest.mark.parametrize("net,B,S", [("convnext-tiny", 2, 128), ("convnext-base", 1, 64), ("convnext-tiny", 3, 96), ("resnet-18", 2, 128),
+                                     ("resnet-50", 1, 64)])
+def test_backbones_match_oracle_in_split_mode(net, B, S, monkeypatch):
+    """The ConvNeXt pointwise MLPs on split arithmetic: same parity bars as the f32-MFMA path."""
+    from keypointfusion_amd import engine as E
+    from oracle import kpf_oracle as O
+    monkeypatch.setattr(E, "GEMM_MODE", "split")
+    monkeypatch.setattr(E, "FORCE_UNFUSED_MLP", True)  # route every block (also C = 96 / 128) through the split GEMMs
+    sd = synthetic_sd("KPFusion-" + net)
+    b = {k: torch.from_numpy(v) for k, v in synthetic_batch(B, S, seed=1).items()}
+    ref = O.backbones_forward(sd, b["img_rgb"], b["img"])
+    m = _model(net)
+    launched = []
+    monkeypatch.setattr(E, "PROFILE", launched)
+    with torch.no_grad():
+        out = m.forward_backbones(b["img_rgb"].to(_dev()), b["img"].to(_dev()))
+    n_split = sum(1 for r in launched if r[0] == "igemm_split_kernel")
+    n_f32 = sum(1 for r in launched if r[0] == "igemm_f32_kernel")
+    assert n_split >= 2 * 30 and n_f32 <= 2 * 8, "split GEMMs did not run (%d split, %d f32)" % (n_split, n_f32)
+    for o, r, name in zip(out, ref, ("img_offset", "img_feat", "img_offset_rgb", "img_feat_rgb")):
+        e = rel_err(o, r)
+        assert e < 2e-4, "%s: rel err %.2e" % (name, e)
+
+
+def test_full_forward_matches_oracle_in_split_mode(monkeypatch):
+    from keypointfusion_amd import engine as E
+    monkeypatch.setattr(E, "GEMM_MODE", "split")
+    b, ref, rsw, aux, out, sws, ctx, report = _run_full("convnext-tiny", 2, 1)
+    names = ["img_offset", "img_offset_rgb", "r3d1", "r2d1", "r3d2", "r2d2"]
+    for o, r, n in zip(out, ref, names):
+        assert rel_err(o, r) < 1e-3, "%s rel err %.2e" % (n, rel_err(o, r))
+    for k in range(2, 6):
+        assert float((out[k].cpu() - ref[k]).abs().max()) * 125.0 < 0.05
