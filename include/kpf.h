@@ -90,6 +90,14 @@ int kpf_dwconv7_ln_f32(const float* x, const float* w_dw, const float* b_dw, con
 int kpf_convnext_mlp_f32(const float* y, const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
                          const float* gamma, float* out, long M, int C, void* stream);
 int kpf_convnext_mlp_supported(int C);
+/* The same block on the f16 matrix cores with split operands (see kpf_conv2d_f32): y is the split LayerNorm output
+ * (kpf_dwconv7_ln_split_f32), w1 [4C][C] and w2 [C][4C] are split-packed and scaled by 1/w*_unscale (powers of two); inside each
+ * 32-wide hidden block w2's columns are ordered k = 8g+j -> hidden 16*(j>>2) + 4g + (j&3), the order in which GEMM1's accumulator
+ * registers become GEMM2's operand.  x and out are fp32. */
+int kpf_convnext_mlp_split_f32(const float* y_split, const float* x, const float* w1_split, const float* b1, float w1_unscale,
+                               const float* w2_split_perm, const float* b2, float w2_unscale, const float* gamma, float* out, long M,
+                               int C, void* stream);
+int kpf_convnext_mlp_split_supported(int C);
 
 /*
  * LayerNorm over the channel dimension of `rows` pixels (biased variance, (x-u)/sqrt(var+eps)*w+b).

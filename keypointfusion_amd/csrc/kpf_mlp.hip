@@ -202,6 +202,171 @@ __global__ __launch_bounds__(64 * NW) void convnext_mlp_kernel(const MlpArgs a) 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same fusion on the f16 matrix cores with split operands (include/kpf.h): y arrives split from the depthwise+LayerNorm kernel,
+// W1 / W2 are packed split, every 32-deep K step is 3 v_mfma_f32_16x16x32_f16 (hi*hi + hi*lo + lo*hi, fp32 accumulate).
+// GEMM1 leaves the lane with hidden units 16*ht + 4*fg + e of pixel fr; after bias + GELU those registers are split into f16 hi/lo
+// and two neighbouring hidden tiles form the B operand of one 32-deep K step of GEMM2: k-slot (fg, j) is hidden
+// 32q + 16*(j>>2) + 4*fg + (j&3).  W2 is packed with that order inside each 32-block (keypointfusion_amd/engine.py), so the hidden
+// tensor still never leaves registers and no lane movement is needed.
+// ---------------------------------------------------------------------------------------------------------------
+struct MlpSplitArgs {
+  const float* y;    // [M][C] split
+  const float* x;    // [M][C] fp32 residual
+  const float* w1;   // [4C][C] split, scaled by 1/us1
+  const float* b1;
+  const float* w2;   // [C][4C] split, hidden order permuted per 32-block, scaled by 1/us2
+  const float* b2;
+  const float* gamma;
+  float* out;
+  const float* zero;
+  float us1, us2;
+  int M;
+};
+
+template <int NC, int HT, int NW>
+__global__ __launch_bounds__(64 * NW) void convnext_mlp_split_kernel(const MlpSplitArgs a) {
+  constexpr int NT = 64 * NW;
+  constexpr int C = 16 * NC;      // channels (multiple of 32)
+  constexpr int KC = C / 32;      // K steps of GEMM1
+  constexpr int H4 = 4 * C;
+  constexpr int HC = 16 * HT;     // hidden units per chunk (multiple of 32)
+  constexpr int HK = HC / 32;     // K steps of GEMM2 per chunk
+  constexpr int BM = 16 * NW;     // one 16-pixel tile per wave
+  constexpr int RCY = C / 4, RCW = HC / 4;
+  constexpr int NCH = H4 / HC;
+  constexpr int YF = BM * C, W1F = HC * C, W2F = C * HC;
+  static_assert(C % 32 == 0 && HC % 32 == 0 && H4 % HC == 0, "split blocks are 32 wide");
+
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Ys = lds;
+  float* W1s = Ys + YF;
+  float* W2s = W1s + 2 * W1F;
+  float* B1s = W2s + 2 * W2F;
+  float* B2s = B1s + H4;
+  float* Gs = B2s + C;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const long m0 = (long)blockIdx.x * BM;
+  const int valid = (int)((a.M - m0) < BM ? (a.M - m0) : BM);
+
+  dma_image<BM, RCY, NT>(Ys, a.y + m0 * C, C, valid, a.zero, tid);
+  dma_image<HC, RCY, NT>(W1s, a.w1, C, HC, a.zero, tid);
+  dma_image<C, RCW, NT>(W2s, a.w2, H4, C, a.zero, tid);
+
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc2[NC];
+#pragma unroll
+  for (int n = 0; n < NC; ++n) acc2[n] = zero4;
+  for (int i = tid; i < H4; i += NT) B1s[i] = a.b1[i];
+  for (int i = tid; i < C; i += NT) {
+    B2s[i] = a.b2[i];
+    Gs[i] = a.gamma[i];
+  }
+  __syncthreads();
+
+  // this lane's y fragments (hi, lo per K step) are the same for every chunk: read them once
+  const int yr = wave * 16 + fr;
+  f16x8 yh[KC], yl[KC];
+#pragma unroll
+  for (int k = 0; k < KC; ++k) {
+    yh[k] = *reinterpret_cast<const f16x8*>(Ys + yr * C + (((8 * k + fg) ^ row_sw<RCY>(yr)) << 2));
+    yl[k] = *reinterpret_cast<const f16x8*>(Ys + yr * C + (((8 * k + 4 + fg) ^ row_sw<RCY>(yr)) << 2));
+  }
+  const float us1 = a.us1;
+
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int cur = ch & 1;
+    if (ch + 1 < NCH) {
+      dma_image<HC, RCY, NT>(W1s + (cur ^ 1) * W1F, a.w1 + (long)(ch + 1) * HC * C, C, HC, a.zero, tid);
+      dma_image<C, RCW, NT>(W2s + (cur ^ 1) * W2F, a.w2 + (long)(ch + 1) * HC, H4, C, a.zero, tid);
+    }
+    const float* w1b = W1s + cur * W1F;
+    const float* w2b = W2s + cur * W2F;
+
+    // ---- GEMM1: acc1[ht] = W1chunk (HC x C) . y^T, 3 MFMAs per (hidden tile, K step) ----
+    f32x4 acc1[HT];
+#pragma unroll
+    for (int h = 0; h < HT; ++h) acc1[h] = zero4;
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+#pragma unroll
+      for (int h = 0; h < HT; ++h) {
+        const int r = h * 16 + fr;
+        const f16x8 wh = *reinterpret_cast<const f16x8*>(w1b + r * C + (((8 * k + fg) ^ row_sw<RCY>(r)) << 2));
+        const f16x8 wl = *reinterpret_cast<const f16x8*>(w1b + r * C + (((8 * k + 4 + fg) ^ row_sw<RCY>(r)) << 2));
+        acc1[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, yh[k], acc1[h], 0, 0, 0);
+        acc1[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, yl[k], acc1[h], 0, 0, 0);
+        acc1[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, yh[k], acc1[h], 0, 0, 0);
+      }
+    }
+
+    // ---- bias + GELU, split in registers; GEMM2: acc2[n] += W2chunk (C x HC) . h ----
+#pragma unroll
+    for (int q = 0; q < HK; ++q) {
+      f16x8 hh, hl;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int h = 2 * q + t;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(B1s + ch * HC + h * 16 + 4 * fg);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float g = gelu_f(fmaf(acc1[h][e], us1, bv[e]));
+          const _Float16 hi = (_Float16)g;
+          hh[4 * t + e] = hi;
+          hl[4 * t + e] = (_Float16)(g - (float)hi);
+        }
+      }
+#pragma unroll
+      for (int n = 0; n < NC; ++n) {
+        const int r = n * 16 + fr;
+        const f16x8 wh = *reinterpret_cast<const f16x8*>(w2b + r * HC + (((8 * q + fg) ^ row_sw<RCW>(r)) << 2));
+        const f16x8 wl = *reinterpret_cast<const f16x8*>(w2b + r * HC + (((8 * q + 4 + fg) ^ row_sw<RCW>(r)) << 2));
+        acc2[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, hh, acc2[n], 0, 0, 0);
+        acc2[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, hl, acc2[n], 0, 0, 0);
+        acc2[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, hh, acc2[n], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  const long m = m0 + wave * 16 + fr;
+  if (m >= a.M) return;
+  const float us2 = a.us2;
+  f32x4 xv[NC];
+#pragma unroll
+  for (int n = 0; n < NC; ++n) xv[n] = *reinterpret_cast<const f32x4*>(a.x + m * C + n * 16 + 4 * fg);
+#pragma unroll
+  for (int n = 0; n < NC; ++n) {
+    const int c = n * 16 + 4 * fg;
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(B2s + c);
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(Gs + c);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = xv[n][e] + gv[e] * fmaf(acc2[n][e], us2, bv[e]);
+    *reinterpret_cast<f32x4*>(a.out + m * C + c) = v;
+  }
+}
+
+template <int NC, int HT, int NW>
+int launch_mlp_split(MlpSplitArgs& a, hipStream_t st) {
+  constexpr int C = 16 * NC, HC = 16 * HT, BM = 16 * NW;
+  const size_t lds = (size_t)(BM * C + 2 * HC * C + 2 * C * HC + 6 * C) * sizeof(float);
+  auto kern = convnext_mlp_split_kernel<NC, HT, NW>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      kpf_set_error("kpf_convnext_mlp_split_f32: cannot raise the dynamic LDS limit");
+      return KPF_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  const long tiles = (a.M + BM - 1) / BM;
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64 * NW), lds, st, a);
+  return kpf_check_launch("kpf_convnext_mlp_split_f32");
+}
+
 template <int NC, int TM, int HT, int NW>
 int launch_mlp(MlpArgs& a, hipStream_t st) {
   constexpr int C = 16 * NC, HC = 16 * HT, BM = 16 * TM * NW;
@@ -256,4 +421,37 @@ extern "C" int kpf_convnext_mlp_f32(const float* y, const float* x, const float*
     case 128: return launch_mlp<8, 1, 2, 8>(a, st);   // 8 waves, BM 128, HC 32: 64 + 64 KB
     default: return launch_mlp<12, 1, 2, 4>(a, st);   // C = 192: 4 waves, BM 64, HC 32: 48 + 96 KB (a 128-row y tile would not fit)
   }
+}
+
+static const float* mlp_zero_page() {
+  static const float* zero_of_dev[64] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!zero_of_dev[dev]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(kpf_mlp_zero16)) != hipSuccess || !p) return nullptr;
+    zero_of_dev[dev] = static_cast<const float*>(p);
+  }
+  return zero_of_dev[dev];
+}
+
+extern "C" int kpf_convnext_mlp_split_supported(int C) { return C == 96 || C == 128; }
+
+extern "C" int kpf_convnext_mlp_split_f32(const float* y_split, const float* x, const float* w1_split, const float* b1, float w1_unscale,
+                                          const float* w2_split_perm, const float* b2, float w2_unscale, const float* gamma, float* out, long M,
+                                          int C, void* stream) {
+  KPF_REQUIRE(y_split && x && w1_split && b1 && w2_split_perm && b2 && gamma && out && M > 0, "kpf_convnext_mlp_split_f32: null pointer / empty");
+  KPF_REQUIRE(C == 96 || C == 128, "kpf_convnext_mlp_split_f32: C=%d not supported (96, 128)", C);
+  KPF_REQUIRE(M < (1l << 31) && w1_unscale > 0.f && w2_unscale > 0.f, "kpf_convnext_mlp_split_f32: bad M / scales");
+  KPF_REQUIRE(kpf_aligned16(y_split) && kpf_aligned16(x) && kpf_aligned16(w1_split) && kpf_aligned16(w2_split_perm) && kpf_aligned16(out) &&
+                  kpf_aligned16(b1) && kpf_aligned16(b2) && kpf_aligned16(gamma),
+              "kpf_convnext_mlp_split_f32: pointers must be 16-byte aligned");
+  MlpSplitArgs a;
+  a.y = y_split; a.x = x; a.w1 = w1_split; a.b1 = b1; a.w2 = w2_split_perm; a.b2 = b2; a.gamma = gamma; a.out = out; a.M = (int)M;
+  a.us1 = w1_unscale; a.us2 = w2_unscale;
+  a.zero = mlp_zero_page();
+  KPF_REQUIRE(a.zero, "kpf_convnext_mlp_split_f32: cannot resolve the zero page");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (C == 96) return launch_mlp_split<6, 4, 8>(a, st);  // BM 128, HC 64: 48 + 96 KB LDS
+  return launch_mlp_split<8, 2, 8>(a, st);               // C = 128: BM 128, HC 32: 64 + 64 KB
 }

@@ -81,6 +81,26 @@ def bn_scale_shift(sd, p):
     return s, b - m * s
 
 
+def split_pack(w):
+    """fp32/fp64 [N][K] (K % 32 == 0) -> (fp32-viewed [N][K] tensor holding [K/32][hi 32 | lo 32] f16 of w * 2^s, 2^-s): the split
+    operand format of include/kpf.h; s keeps the lo halves out of the f16 subnormals."""
+    w = w.double().cpu()
+    N, K = w.shape
+    assert K % 32 == 0
+    amax = float(w.abs().max())
+    s = 7 - math.floor(math.log2(amax)) if amax > 0 else 0
+    ws = w * (2.0 ** s)
+    hi = ws.half()
+    lo = (ws - hi.double()).half()
+    blk = torch.stack([hi.view(N, K // 32, 32), lo.view(N, K // 32, 32)], 2).contiguous()  # N, K/32, 2, 32
+    return blk.view(torch.float32).reshape(N, K).contiguous(), 2.0 ** (-s)
+
+
+# order in which GEMM1's accumulator registers of two neighbouring 16-wide hidden tiles form a 32-deep f16 MFMA operand
+# (csrc/kpf_mlp.hip, convnext_mlp_split_kernel): k-slot 8g+j holds hidden 16*(j>>2) + 4g + (j&3)
+MLP_HIDDEN_PERM = [16 * ((k & 7) >> 2) + 4 * (k >> 3) + (k & 3) for k in range(32)]
+
+
 class PackedConv:
     """Weights of one convolution/linear in kernel layout: w [N][Kp] with k = (ky,kx,c), bias [N], optional input
     prologue (scale, shift) [Cin].  `view_kw` > 1 marks a patchify convolution executed as KHx1 over a merged view."""
@@ -137,16 +157,8 @@ class PackedConv:
         """(w_split, w_unscale): rows of [Kp/32][hi 32 | lo 32] f16 of w * 2^s (s keeps the lo halves out of the f16 subnormals),
         viewed as fp32 [N][Kp]; built once from the fp32 pack (exactly representable inputs: the split is of the fp32 weights)."""
         if getattr(self, "_ws", None) is None:
-            assert self.Kp % 32 == 0
-            w = self.w.double().cpu()
-            amax = float(w.abs().max())
-            s = 7 - math.floor(math.log2(amax)) if amax > 0 else 0
-            ws = w * (2.0 ** s)
-            hi = ws.half()
-            lo = (ws - hi.double()).half()
-            blk = torch.stack([hi.view(self.N, self.Kp // 32, 32), lo.view(self.N, self.Kp // 32, 32)], 2).contiguous()  # N, K/32, 2, 32
-            self._ws = blk.view(torch.float32).reshape(self.N, self.Kp).contiguous().to(self.w.device)
-            self._wus = 2.0 ** (-s)
+            ws, self._wus = split_pack(self.w)
+            self._ws = ws.to(self.w.device)
         return self._ws, self._wus
 
     def row_l1(self):
@@ -310,6 +322,13 @@ class ConvNeXtBlockPlan:
         ln_bound = math.sqrt(c) * float(self.lnw.abs().max()) + float(self.lnb.abs().max())
         h_bound = self.pw1.row_l1() * ln_bound + float(self.pw1.b.abs().max())
         self.split_ok = c % 32 == 0 and ln_bound < F16_MAX and h_bound < F16_MAX
+        self.fused_split = GEMM_MODE == "split" and self.split_ok and bool(L.load().kpf_convnext_mlp_split_supported(c))
+        if self.fused_split:
+            self.w1s, self.us1 = self.pw1.split_weights()
+            w2 = self.pw2.w.double().cpu()  # [C][4C]
+            perm = torch.tensor([32 * q + k for q in range(4 * c // 32) for k in MLP_HIDDEN_PERM])
+            w2s, self.us2 = split_pack(w2[:, perm])
+            self.w2s = w2s.to(device)
         self.fused = bool(L.load().kpf_convnext_mlp_supported(c))
         if self.fused:  # fused MLP kernel takes the PyTorch layouts as they are
             self.w1 = sd[p + ".pwconv1.weight"].detach().float().contiguous().to(device)
@@ -319,7 +338,16 @@ class ConvNeXtBlockPlan:
 
     def __call__(self, x, y, h):
         lib = L.load()
-        if GEMM_MODE == "split" and self.split_ok and not (self.fused and not FORCE_UNFUSED_MLP):
+        if GEMM_MODE == "split" and self.fused_split and not FORCE_UNFUSED_MLP:
+            L.check(lib.kpf_dwconv7_ln_split_f32(_ptr(x.buf), _ptr(self.wdw), _ptr(self.bdw), _ptr(self.lnw), _ptr(self.lnb),
+                                                 _ptr(y.buf), x.B, x.H, x.W, x.C, 1e-6, _stream()), "kpf_dwconv7_ln_split_f32")
+            M, Cc = x.B * x.H * x.W, x.C
+            _launch("convnext_mlp_split_kernel", 16.0 * M * Cc * Cc, 4.0 * (3 * M * Cc + 8 * Cc * Cc), (M, Cc, 4 * Cc, 1, 1),
+                    lambda: L.check(lib.kpf_convnext_mlp_split_f32(_ptr(y.buf), _ptr(x.buf), _ptr(self.w1s), _ptr(self.pw1.b), self.us1,
+                                                                   _ptr(self.w2s), _ptr(self.pw2.b), self.us2, _ptr(self.gamma), _ptr(x.buf), M, Cc,
+                                                                   _stream()), "kpf_convnext_mlp_split_f32"))
+            return x
+        if GEMM_MODE == "split" and self.split_ok:
             L.check(lib.kpf_dwconv7_ln_split_f32(_ptr(x.buf), _ptr(self.wdw), _ptr(self.bdw), _ptr(self.lnw), _ptr(self.lnb),
                                                  _ptr(y.buf), x.B, x.H, x.W, x.C, 1e-6, _stream()), "kpf_dwconv7_ln_split_f32")
             y.split = True

@@ -50,6 +50,8 @@ _SIGS = {
     "kpf_xattn_layer_f32": [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P],
     "kpf_convnext_mlp_f32": [_P] * 8 + [C.c_long, C.c_int, _P],
     "kpf_convnext_mlp_supported": [C.c_int],
+    "kpf_convnext_mlp_split_f32": [_P, _P, _P, _P, C.c_float, _P, _P, C.c_float, _P, _P, C.c_long, C.c_int, _P],
+    "kpf_convnext_mlp_split_supported": [C.c_int],
     "kpf_cbam_channel_gate_f32": [_P] * 7 + [C.c_int] * 4 + [_P],
     "kpf_cbam_spatial_gate_f32": [_P, _P, _P, C.c_float, C.c_float, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
     "kpf_cbam_apply_f32": [_P] * 5 + [C.c_int] * 3 + [_P],

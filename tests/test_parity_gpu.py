@@ -500,12 +500,13 @@ def test_split_layernorm_producers():
 
 @pytest.mark.parametrize("net,B,S", [("convnext-tiny", 2, 128), ("convnext-base", 1, 64), ("convnext-tiny", 3, 96), ("resnet-18", 2, 128),
                                      ("resnet-50", 1, 64)])
-def test_backbones_match_oracle_in_split_mode(net, B, S, monkeypatch):
-    """The ConvNeXt pointwise MLPs on split arithmetic: same parity bars as the f32-MFMA path."""
+@pytest.mark.parametrize("unfused", [False, True])
+def test_backbones_match_oracle_in_split_mode(net, B, S, unfused, monkeypatch):
+    """Every GEMM on split arithmetic (with and without the fused ConvNeXt MLP at C = 96 / 128): same parity bars as the f32-MFMA path."""
     from keypointfusion_amd import engine as E
     from oracle import kpf_oracle as O
     monkeypatch.setattr(E, "GEMM_MODE", "split")
-    monkeypatch.setattr(E, "FORCE_UNFUSED_MLP", True)  # route every block (also C = 96 / 128) through the split GEMMs
+    monkeypatch.setattr(E, "FORCE_UNFUSED_MLP", unfused)
     sd = synthetic_sd("KPFusion-" + net)
     b = {k: torch.from_numpy(v) for k, v in synthetic_batch(B, S, seed=1).items()}
     ref = O.backbones_forward(sd, b["img_rgb"], b["img"])
@@ -517,6 +518,8 @@ def test_backbones_match_oracle_in_split_mode(net, B, S, monkeypatch):
     n_split = sum(1 for r in launched if r[0] == "igemm_split_kernel")
     n_f32 = sum(1 for r in launched if r[0] == "igemm_f32_kernel")
     assert n_split >= 2 * 30 and n_f32 <= 2 * 8, "split GEMMs did not run (%d split, %d f32)" % (n_split, n_f32)
+    if "convnext" in net and not unfused:
+        assert sum(1 for r in launched if r[0] == "convnext_mlp_split_kernel") >= 2 * 3, "fused split MLP did not run"
     for o, r, name in zip(out, ref, ("img_offset", "img_feat", "img_offset_rgb", "img_feat_rgb")):
         e = rel_err(o, r)
         assert e < 2e-4, "%s: rel err %.2e" % (name, e)
@@ -531,3 +534,31 @@ def test_full_forward_matches_oracle_in_split_mode(monkeypatch):
         assert rel_err(o, r) < 1e-3, "%s rel err %.2e" % (n, rel_err(o, r))
     for k in range(2, 6):
         assert float((out[k].cpu() - ref[k]).abs().max()) * 125.0 < 0.05
+
+
+@pytest.mark.parametrize("C,M", [(96, 4096 + 37), (128, 1000)])
+def test_fused_split_mlp_matches_fp64(C, M):
+    """kpf_convnext_mlp_split_f32 (hidden tensor in registers, f16 matrix cores) against an fp64 evaluation of the block's MLP."""
+    from keypointfusion_amd import lib as L
+    from keypointfusion_amd.engine import MLP_HIDDEN_PERM, _ptr, _stream, split_pack
+    dev = _dev()
+    lib = L.load()
+    g = torch.Generator().manual_seed(C)
+    y = torch.randn(M, C, generator=g)
+    x = torch.randn(M, C, generator=g)
+    w1 = torch.randn(4 * C, C, generator=g) / C ** 0.5
+    b1 = torch.randn(4 * C, generator=g) * 0.1
+    w2 = torch.randn(C, 4 * C, generator=g) / (4 * C) ** 0.5
+    b2 = torch.randn(C, generator=g) * 0.1
+    gamma = torch.rand(C, generator=g) * 0.2 + 0.05
+    ref = x.double() + gamma.double() * (F.gelu(y.double() @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double())
+    w1s, us1 = split_pack(w1)
+    perm = torch.tensor([32 * q + k for q in range(4 * C // 32) for k in MLP_HIDDEN_PERM])
+    w2s, us2 = split_pack(w2[:, perm])
+    d = lambda t: t.to(dev).contiguous()  # noqa: E731
+    out = torch.empty(M, C, device=dev)
+    ys, xd, w1d, w2d, b1d, b2d, gd = d(to_split(y)), d(x), d(w1s), d(w2s), d(b1), d(b2), d(gamma)
+    L.check(lib.kpf_convnext_mlp_split_f32(_ptr(ys), _ptr(xd), _ptr(w1d), _ptr(b1d), us1, _ptr(w2d), _ptr(b2d), us2, _ptr(gd), _ptr(out), M, C,
+                                           _stream()), "mlp_split")
+    e = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
+    assert e < 2e-6, e
