@@ -10,9 +10,11 @@ A "step" is one forward over one batch already resident in HBM.  N GPUs = N inde
 dimension (weak scaling, no data-path collective: every sample is independent in eval).
 
 One JSON line is printed by rank 0 with, besides the contract fields:
-  roofline     : the implicit-GEMM MFMA kernel family (igemm_f32_kernel) — achieved = algorithmic conv/GEMM FLOPs of all its
-                 launches in one step / summed device time of those launches (HIP events on the launch stream, measured
-                 in an instrumented pass after the timed region), peak = 157.3 TFLOP/s dense fp32 MFMA.
+  roofline     : the dominant MFMA kernel family — achieved = algorithmic conv/GEMM FLOPs (2*M*N*K) of all its launches in one step /
+                 summed device time of those launches (HIP events on the launch stream, measured in an instrumented pass after
+                 the timed region).  peak: split-arithmetic kernels execute 3 f16 MFMAs per algorithmic product, so their roof is
+                 2500/3 = 833.3 algorithmic TFLOP/s (dense f16 MFMA peak / 3); f32-input MFMA kernels: 157.3 TFLOP/s.
+  f32_mfma     : the same workload timed with KPF_GEMM=f32 (every GEMM on v_mfma_f32_16x16x4_f32), rank 0 at N=1, for reference.
   cpu_baseline : the CPU oracle (oracle/kpf_oracle.py, torch-CPU fp32 = the reference's own arithmetic) on the host
                  cores of this box, on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -28,6 +30,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_F16_MFMA_TFLOPS = 2500.0  # dense f16/bf16 matrix peak
+PEAK_SPLIT_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3  # 3 f16 MFMAs per algorithmic fp32 product (hi*hi + hi*lo + lo*hi)
+
+
+def kernel_peak(name):
+    return PEAK_SPLIT_TFLOPS if "split" in name else PEAK_F32_MFMA_TFLOPS
 NET = "KPFusion-convnext-tiny"
 
 
@@ -45,6 +53,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="full128 only: replay the forward from a captured hipGraph")
     ap.add_argument("--per-launch", default="", help="write a per-launch table of the implicit-GEMM kernel to this file")
     ap.add_argument("--cpu-sample", type=int, default=8, help="images in the CPU-baseline sample")
+    ap.add_argument("--gemm", default=None, choices=["split", "f32"], help="GEMM arithmetic (default: the engine's, KPF_GEMM or 'split')")
+    ap.add_argument("--no-f32-reference", action="store_true", help="skip the extra KPF_GEMM=f32 timing")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -65,6 +75,8 @@ def main():
     from keypointfusion_amd.model.model import KPFusion
     from keypointfusion_amd.weights import synthetic_batch, synthetic_state_dict
     L.load()
+    if args.gemm:
+        E.GEMM_MODE = args.gemm
 
     if args.workload == "full128":
         args.size = 128
@@ -100,6 +112,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_issue = time.perf_counter() - t0  # host time to enqueue the K steps (close to dt => the step is launch-bound)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -150,13 +163,39 @@ def main():
             tj = json.load(open(tpath))
             if tj.get("kernel") == dom:
                 traffic = round(tj["hbm_bytes_per_launch"])
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+        peak = kernel_peak(dom)
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": round(peak, 1),
+                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                    "peak_note": ("algorithmic-FLOP roof of the 3 x f16 split scheme = dense f16 MFMA peak 2500 / 3; executed MFMA rate = %.0f TFLOP/s"
+                                  % (3 * ach)) if "split" in dom else "dense f32-input MFMA peak",
                     "algo_bytes_per_launch": round(nb / n), "launches_per_step": n, "avg_launch_ms": round(t_ms / n, 4),
                     "gflop_per_step": round(fl / 1e9, 1), "kernel_ms_per_step": round(t_ms, 3),
-                    "all_mfma_kernels": {k: {"launches": v[0], "ms": round(v[1], 3), "tflops": round(v[2] / v[1] / 1e9, 2)} for k, v in per.items()},
+                    "all_mfma_kernels": {k: {"launches": v[0], "ms": round(v[1], 3), "tflops": round(v[2] / v[1] / 1e9, 2),
+                                             "frac": round(v[2] / v[1] / 1e9 / kernel_peak(k), 4)} for k, v in per.items()},
                     "all_mfma_tflops": round(all_fl / all_ms / 1e9, 2),
                     "whole_step_tflops": round(all_fl / (ms_per_step * 1e-3) / 1e12, 2)}
+
+    # ---- reference timing of the strict f32-input MFMA arithmetic (outside the timed region; rank 0, N=1) ----
+    f32_ref = None
+    if rank == 0 and world == 1 and E.GEMM_MODE != "f32" and not args.no_f32_reference:
+        mode = E.GEMM_MODE
+        try:
+            E.GEMM_MODE = "f32"
+            model._plans.clear()
+            model._plan(dev).serial_streams = bool(args.serial_streams)
+            for _ in range(max(2, args.warmup)):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            dt32 = time.perf_counter() - t1
+            f32_ref = {"value": round(B * args.steps / dt32, 2), "unit": "img/s", "ms_per_step": round(dt32 / args.steps * 1e3, 3),
+                       "gemm_arithmetic": "v_mfma_f32_16x16x4_f32 (KPF_GEMM=f32)", "peak_tflops": PEAK_F32_MFMA_TFLOPS}
+        finally:
+            E.GEMM_MODE = mode
+            model._plans.clear()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -187,12 +226,15 @@ def main():
             "metric": "RGB-D img/sec fwd (B=64, 256x256)" if args.workload == "backbones256" else "RGB-D img/sec fwd full model (B=%d, 128x128)" % B,
             "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if E.GEMM_MODE == "f32" else "f32 (GEMM products as 3 x f16 split MFMA, f32 accumulate)", "data": "synthetic",
             "config": {"workload": "KPFusion-convnext-tiny, depth+RGB UNet backbones forward, B=%d/GPU %dx%d fp32 (BASELINE configs[1])" % (B, S, S)
                        if args.workload == "backbones256" else "KPFusion-convnext-tiny full forward, B=%d/GPU 128x128 fp32" % B,
                        "batch_per_gpu": B, "global_batch": B * world, "input": "%dx%d" % (S, S), "parallelism": "dp%d (batch shards, no collective)" % world},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "f32_mfma": f32_ref, "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 3),
         }
+        line["config"]["gemm_arithmetic"] = ("fp32 emulation on the f16 matrix cores: operands split into f16 hi+lo (22 bits), 3 MFMAs per product, "
+                                             "fp32 accumulate; error vs fp64 <= the f32-input MFMA path's (tests/test_parity_gpu.py)"
+                                             if E.GEMM_MODE == "split" else "f32-input MFMA")
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

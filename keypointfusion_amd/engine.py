@@ -19,8 +19,11 @@ from .spec import CONVNEXT, parse_net
 
 BN_EPS = 1e-5
 FORCE_UNFUSED_MLP = bool(int(__import__("os").environ.get("KPF_UNFUSED_MLP", "0")))  # A/B switch for tuning
-# GEMM arithmetic of the ConvNeXt pointwise MLPs: "f32" = f32-input MFMA; "split" = 3 x f16 MFMA on split operands (include/kpf.h)
-GEMM_MODE = __import__("os").environ.get("KPF_GEMM", "f32")
+# GEMM arithmetic.  "split" (default): fp32 emulation on the f16 matrix cores — operands as f16 hi + lo (22 bits), 3 MFMAs per product
+# (hi*hi + hi*lo + lo*hi), fp32 accumulate; measured at least as close to an fp64 product as the f32-input MFMA (tests/test_parity_gpu.py::
+# test_split_gemm_is_as_accurate_as_fp32) at 3/16 of its matrix-pipe cycles.  "f32": v_mfma_f32_16x16x4_f32 everywhere (KPF_GEMM=f32).
+GEMM_MODE = __import__("os").environ.get("KPF_GEMM", "split")
+assert GEMM_MODE in ("split", "f32"), "KPF_GEMM must be 'split' or 'f32'"
 F16_MAX = 65504.0
 
 

@@ -525,9 +525,29 @@ def test_backbones_match_oracle_in_split_mode(net, B, S, unfused, monkeypatch):
         assert e < 2e-4, "%s: rel err %.2e" % (name, e)
 
 
-def test_full_forward_matches_oracle_in_split_mode(monkeypatch):
+@pytest.mark.parametrize("net,B,S", [("convnext-tiny", 2, 128), ("resnet-18", 1, 64), ("convnext-base", 1, 64)])
+def test_backbones_match_oracle_in_f32_mfma_mode(net, B, S, monkeypatch):
+    """KPF_GEMM=f32: every GEMM on the f32-input MFMA (the strict-fp32 arithmetic path)."""
     from keypointfusion_amd import engine as E
-    monkeypatch.setattr(E, "GEMM_MODE", "split")
+    from oracle import kpf_oracle as O
+    monkeypatch.setattr(E, "GEMM_MODE", "f32")
+    sd = synthetic_sd("KPFusion-" + net)
+    b = {k: torch.from_numpy(v) for k, v in synthetic_batch(B, S, seed=1).items()}
+    ref = O.backbones_forward(sd, b["img_rgb"], b["img"])
+    m = _model(net)
+    launched = []
+    monkeypatch.setattr(E, "PROFILE", launched)
+    with torch.no_grad():
+        out = m.forward_backbones(b["img_rgb"].to(_dev()), b["img"].to(_dev()))
+    assert not any(r[0].endswith("split_kernel") for r in launched)
+    for o, r in zip(out, ref):
+        assert rel_err(o, r) < 2e-4
+
+
+@pytest.mark.parametrize("mode", ["split", "f32"])
+def test_full_forward_matches_oracle_in_both_gemm_modes(mode, monkeypatch):
+    from keypointfusion_amd import engine as E
+    monkeypatch.setattr(E, "GEMM_MODE", mode)
     b, ref, rsw, aux, out, sws, ctx, report = _run_full("convnext-tiny", 2, 1)
     names = ["img_offset", "img_offset_rgb", "r3d1", "r2d1", "r3d2", "r2d2"]
     for o, r, n in zip(out, ref, names):
