@@ -87,7 +87,11 @@ constexpr int BK = 32;  // K-tile depth: 8 chunks of 16 B per staged row
 // operand prologue when there is one): any fp32 tensor can feed the f16 matrix cores without a format pass over HBM.
 enum { ARITH_F32 = 0, ARITH_SPLIT = 1, ARITH_SPLIT_W = 2 };
 
-template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO, int EPI, int ARITH>
+// NS = LDS stages.  NS = 2: the DMA of tile k+1 flies under the MFMAs of tile k, one __syncthreads per K tile (its fence drains the
+// DMA).  NS > 2 (split arithmetic, where a K tile's MFMAs are shorter than the DMA latency): a ring with NS-1 tiles in flight — a
+// counted s_waitcnt vmcnt leaves the younger tiles' DMAs outstanding across a raw s_barrier; every wave issues the same number of DMA
+// instructions per tile (the staged row count is rounded up to whole passes) so that one immediate count fits all waves.
+template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO, int EPI, int ARITH, int NS>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const ConvArgs a) {
   constexpr bool SPLIT = ARITH != ARITH_F32;
   constexpr int BM = 16 * TM * WM;
@@ -96,8 +100,12 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const ConvArgs 
   constexpr int RPP = 8 * NW;               // rows staged per pass: every wave moves 8 rows x 128 B = one 1-KiB DMA
   constexpr int AP = (BM + RPP - 1) / RPP;  // A staging passes
   constexpr int BP = (BN + RPP - 1) / RPP;  // B staging passes
-  constexpr int TILE = (BM + BN) * BK;
+  constexpr int BMR = NS > 2 ? AP * RPP : BM;  // staged rows (whole passes in ring mode; the extra rows are never read)
+  constexpr int BNR = NS > 2 ? BP * RPP : BN;
+  constexpr int TILE = (BMR + BNR) * BK;
+  constexpr int CNT = AP + BP;  // DMA instructions per wave per K tile in ring mode
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+  static_assert(NS >= 2 && (NS - 2) * CNT < 64, "vmcnt is a 6-bit counter");
   static_assert(BM % 8 == 0 && BN % 8 == 0, "tile granularity");
 
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][TILE] (+ [2][Kp] operand prologue scale/shift)
@@ -137,7 +145,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const ConvArgs 
       const int mc = m < a.M ? m : a.M - 1;
       pa[p] = a.in + (long)mc * a.in_ld + a.in_coff + kc;
       rbase[p] = riy[p] = rix[p] = 0;
-    } else if (m < a.M && lr + RPP * p < BM) {
+    } else if (m < a.M && lr + RPP * p < BM) {  // (ring mode stages whole passes: rows beyond BM read the zero page)
       const int b = m / a.ohow;
       const int r = m - b * a.ohow;
       const int oy = r / a.OW;
@@ -160,11 +168,11 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const ConvArgs 
 
   auto stage = [&](int kt, int buf) {
     float* As = lds + buf * TILE;
-    float* Bs = As + BM * BK;
+    float* Bs = As + BMR * BK;
     if (IS1X1) {
 #pragma unroll
       for (int p = 0; p < AP; ++p)
-        if (RPP * p + 8 * wave < BM)  // wave-uniform
+        if (NS > 2 || RPP * p + 8 * wave < BM)  // wave-uniform
           __builtin_amdgcn_global_load_lds((gbl_void_t*)(pa[p] + kt * BK), (lds_void_t*)(As + (RPP * p + 8 * wave) * BK), 16, 0, 0);
     } else {
       const int k = kt * BK + kc;
@@ -175,7 +183,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const ConvArgs 
       const int kx = tap - ky * a.KW;
 #pragma unroll
       for (int p = 0; p < AP; ++p) {
-        if (RPP * p + 8 * wave < BM) {  // wave-uniform
+        if (NS > 2 || RPP * p + 8 * wave < BM) {  // wave-uniform
           const int iy = riy[p] + ky, ix = rix[p] + kx;
           const bool v = kvalid && rbase[p] >= 0 && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
           const long off = ((long)rbase[p] + (long)iy * a.IW + ix) * a.in_ld + a.in_coff + c;
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const ConvArgs 
     }
 #pragma unroll
     for (int p = 0; p < BP; ++p)
-      if (RPP * p + 8 * wave < BN)  // wave-uniform: BN is a multiple of 8
+      if (NS > 2 || RPP * p + 8 * wave < BN)  // wave-uniform: BN is a multiple of 8
         __builtin_amdgcn_global_load_lds((gbl_void_t*)(pb[p] + kt * BK), (lds_void_t*)(Bs + (RPP * p + 8 * wave) * BK), 16, 0, 0);
   };
 
@@ -201,23 +209,46 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const ConvArgs 
   const int fr = lane & 15;  // fragment row (pixel for X, channel for W)
   const int fg = lane >> 4;  // k group 0..3
   const int rsw = fr & 7;    // this lane's row swizzle
-  float* pro_s = lds + 2 * TILE;  // [Kp] scale, then [Kp] shift (zero beyond Cin: padded k contributes relu(0*x+0) = 0)
-  float* pro_t = pro_s + a.Kp;
 
-  stage(0, 0);
+  float* pro_s = lds + NS * TILE;  // [Kp] scale, then [Kp] shift (zero beyond Cin: padded k contributes relu(0*x+0) = 0)
+  float* pro_t = pro_s + a.Kp;
+  if (NS == 2) {
+    stage(0, 0);
+  } else {
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+      if (t < nk) stage(t, t);
+  }
   if (HAS_PRO) {
     for (int i = tid; i < a.Kp; i += 64 * NW) {
       pro_s[i] = i < a.Cin ? a.ps[i] : 0.f;
       pro_t[i] = i < a.Cin ? a.pt[i] : 0.f;
     }
   }
-  __syncthreads();  // (a pending global_load_lds is an outstanding vmcnt: the barrier's fence drains it)
+  if (NS == 2) __syncthreads();  // (a pending global_load_lds is an outstanding vmcnt: the barrier's fence drains it)
 
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(kt + 1, cur ^ 1);  // next tile flies into the other buffer under this tile's MFMAs
+    int cur;
+    if (NS == 2) {
+      cur = kt & 1;
+      if (kt + 1 < nk) stage(kt + 1, cur ^ 1);  // next tile flies into the other buffer under this tile's MFMAs
+    } else {
+      cur = kt % NS;
+      // tile kt has landed once at most the younger tiles' DMAs are outstanding: NS-2 tiles in steady state, fewer at the tail
+      const int younger = nk - 1 - kt;
+      if (younger >= NS - 2) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * CNT) : "memory");
+      } else if (NS > 3 && younger == 1) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if (HAS_PRO && kt == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the prologue table's ds_writes
+      __builtin_amdgcn_s_barrier();  // everyone's part of tile kt is in LDS; everyone has finished reading tile kt-1's stage
+      if (kt + NS - 1 < nk) stage(kt + NS - 1, (kt + NS - 1) % NS);
+    }
     const float* xrow = lds + cur * TILE + (wm * TM * 16 + fr) * BK;
-    const float* wrow = lds + cur * TILE + BM * BK + (wn * TN * 16 + fr) * BK;
+    const float* wrow = lds + cur * TILE + BMR * BK + (wn * TN * 16 + fr) * BK;
     if (SPLIT) {
       // lane group fg multiplies k = 8fg .. 8fg+7 of the tile: hi halves are logical chunk fg, lo halves chunk 4 + fg of the row
       const int ch = ((fg ^ rsw) << 2), cl = (((4 + fg) ^ rsw) << 2);
@@ -300,7 +331,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const ConvArgs 
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][e], xf[j][e], acc[i][j], 0, 0, 0);
       }
     }
-    __syncthreads();  // next tile landed (vmcnt drained by the barrier's fence); every wave is done reading `cur`
+    if (NS == 2) __syncthreads();  // next tile landed (vmcnt drained by the barrier's fence); every wave is done reading `cur`
   }
 
   // ---- epilogue: lane holds channels n..n+3 (n = tile + 4*fg) of pixel m (= tile + fr) ----
@@ -397,11 +428,12 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const ConvArgs 
   }
 }
 
-template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO, int EPI, int ARITH>
+template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO, int EPI, int ARITH, int NS>
 int launch_one(const ConvArgs& a, hipStream_t st) {
-  constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
-  const size_t lds = (size_t)(2 * (BM + BN) * BK + (HAS_PRO ? 2 * a.Kp : 0)) * sizeof(float);
-  auto kern = igemm_f32_kernel<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH>;
+  constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN, RPP = 8 * WM * WN;
+  constexpr int BMR = NS > 2 ? (BM + RPP - 1) / RPP * RPP : BM, BNR = NS > 2 ? (BN + RPP - 1) / RPP * RPP : BN;
+  const size_t lds = (size_t)(NS * (BMR + BNR) * BK + (HAS_PRO ? 2 * a.Kp : 0)) * sizeof(float);
+  auto kern = igemm_f32_kernel<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH, NS>;
   static bool attr_set = false;  // > 64 KiB of dynamic LDS needs an opt-in; benign if two threads race to set it
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
@@ -423,7 +455,7 @@ int launch_one(const ConvArgs& a, hipStream_t st) {
 //   1x1 + GELU                             (ConvNeXt pwconv1)          1x1 + residual           (pwconv2, Residual.conv3)
 //   conv + linear/ReLU                     (3x3, stems, downsamples)   conv + residual          (BasicBlock.conv2)
 // Instantiated per tile shape: {1x1 (+prologue | GELU | residual | linear), general conv (linear | residual)} x {f32 MFMA, split, split weights}.
-template <int TM, int TN, int WM, int WN, int ARITH>
+template <int TM, int TN, int WM, int WN, int ARITH, int NS>
 int launch_arith(ConvArgs& a, bool is1x1, hipStream_t st) {
   const bool res = a.flags & KPF_RES_ADD, gelu = a.flags & KPF_ACT_GELU;
   if (a.ps) {
@@ -431,28 +463,28 @@ int launch_arith(ConvArgs& a, bool is1x1, hipStream_t st) {
       kpf_set_error("kpf_conv2d_f32: the operand prologue is only supported for 1x1 stride-1 convolutions with Cin %% 32 == 0, fp32 activations and a linear/ReLU epilogue");
       return KPF_EINVAL;
     }
-    return launch_one<TM, TN, WM, WN, true, true, EPI_LIN, ARITH == ARITH_SPLIT ? ARITH_F32 : ARITH>(a, st);
+    return launch_one<TM, TN, WM, WN, true, true, EPI_LIN, ARITH == ARITH_SPLIT ? ARITH_F32 : ARITH, NS>(a, st);
   }
   if (gelu) {
     if (!is1x1 || res) {
       kpf_set_error("kpf_conv2d_f32: GELU is only supported on 1x1 convolutions (Cin %% 32 == 0) without residual");
       return KPF_EINVAL;
     }
-    return launch_one<TM, TN, WM, WN, true, false, EPI_GELU, ARITH>(a, st);
+    return launch_one<TM, TN, WM, WN, true, false, EPI_GELU, ARITH, NS>(a, st);
   }
-  if (is1x1) return res ? launch_one<TM, TN, WM, WN, true, false, EPI_RES, ARITH>(a, st) : launch_one<TM, TN, WM, WN, true, false, EPI_LIN, ARITH>(a, st);
-  return res ? launch_one<TM, TN, WM, WN, false, false, EPI_RES, ARITH>(a, st) : launch_one<TM, TN, WM, WN, false, false, EPI_LIN, ARITH>(a, st);
+  if (is1x1) return res ? launch_one<TM, TN, WM, WN, true, false, EPI_RES, ARITH, NS>(a, st) : launch_one<TM, TN, WM, WN, true, false, EPI_LIN, ARITH, NS>(a, st);
+  return res ? launch_one<TM, TN, WM, WN, false, false, EPI_RES, ARITH, NS>(a, st) : launch_one<TM, TN, WM, WN, false, false, EPI_LIN, ARITH, NS>(a, st);
 }
 
-template <int TM, int TN, int WM, int WN>
+template <int TM, int TN, int WM, int WN, int NS_SPLIT = 2>
 int launch_cfg(ConvArgs& a, bool is1x1, hipStream_t st) {
   constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
   const int tilesM = (a.M + BM - 1) / BM;
   a.tilesN = (a.N + BN - 1) / BN;
   a.nblk = tilesM * a.tilesN;
-  if (a.flags & KPF_IN_SPLIT) return launch_arith<TM, TN, WM, WN, ARITH_SPLIT>(a, is1x1, st);
-  if (a.flags & KPF_W_SPLIT) return launch_arith<TM, TN, WM, WN, ARITH_SPLIT_W>(a, is1x1, st);
-  return launch_arith<TM, TN, WM, WN, ARITH_F32>(a, is1x1, st);
+  if (a.flags & KPF_IN_SPLIT) return launch_arith<TM, TN, WM, WN, ARITH_SPLIT, NS_SPLIT>(a, is1x1, st);
+  if (a.flags & KPF_W_SPLIT) return launch_arith<TM, TN, WM, WN, ARITH_SPLIT_W, NS_SPLIT>(a, is1x1, st);
+  return launch_arith<TM, TN, WM, WN, ARITH_F32, 2>(a, is1x1, st);
 }
 
 // Tile choice.  The kernel is MFMA-bound and co-resident workgroups share a CU's matrix pipe (they hide each other's bubbles, they
@@ -551,6 +583,10 @@ extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const flo
     case 5: return launch_cfg<2, 4, 2, 2>(a, is1x1, st);   // 64 x 128
     case 6: return launch_cfg<2, 2, 2, 2>(a, is1x1, st);   // 64 x 64
     case 8: return launch_cfg<4, 4, 4, 2>(a, is1x1, st);   // 256 x 128, 8 MFMA waves
+    case 9: return launch_cfg<4, 4, 4, 2, 3>(a, is1x1, st);   // split: 256 x 128, 3-stage ring (144 KB, 2 tiles in flight)
+    case 10: return launch_cfg<4, 4, 2, 2, 4>(a, is1x1, st);  // split: 128 x 128, 4-stage ring (128 KB, 3 tiles in flight)
+    case 11: return launch_cfg<4, 3, 2, 2, 4>(a, is1x1, st);  // split: 128 x 96, 4-stage ring (112 KB)
+    case 12: return launch_cfg<2, 4, 4, 1, 3>(a, is1x1, st);  // split: 128 x 64, 3-stage ring (72 KB, two workgroups per CU)
     default: return launch_cfg<2, 1, 1, 4>(a, is1x1, st);  // 32 x 64
   }
 }

@@ -8,7 +8,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SHAPES = [(16384, 1536, 384, "gelu"), (16384, 384, 1536, "res"), (65536, 768, 192, "gelu"), (65536, 192, 768, "res"), (4096, 3072, 768, "gelu"),
           (4096, 768, 3072, "res"), (262144, 128, 288, "lin"), (262144, 64, 288, "lin"), (65536, 192, 576, "lin"), (16384, 384, 1152, "lin"),
           (262144, 128, 64, "res"), (65536, 192, 96, "res"), (16384, 384, 192, "res")]
-CFGS = ["128x128", "128x96", "128x64", "256x48", "128x112", "64x128", "64x64", "32x64", "256x128"]
+CFGS = ["128x128", "128x96", "128x64", "256x48", "128x112", "64x128", "64x64", "32x64", "256x128", "r256x128", "r128x128", "r128x96", "r128x64"]
+ONLY = [int(c) for c in os.environ.get("SCAN_CFGS", "").split(",") if c]
 
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     import torch
@@ -42,6 +43,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
 
 res = {}
 for ci, name in enumerate(CFGS):
+    if ONLY and ci not in ONLY:
+        continue
     env = dict(os.environ, KPF_FORCE_CFG=str(ci), KPF_GEMM="split")
     r = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, capture_output=True, text=True)
     out = r.stdout
@@ -50,6 +53,7 @@ for ci, name in enumerate(CFGS):
     for line in out.strip().splitlines():
         M, N, K, kind, ms, tf = line.split()
         res.setdefault((int(M), int(N), int(K), kind), {})[name] = float(ms)
+CFGS = [c for i, c in enumerate(CFGS) if not ONLY or i in ONLY]
 print("%-28s" % "shape" + "".join("%9s" % c for c in CFGS))
 for k, v in res.items():
     best = min(v.values())
