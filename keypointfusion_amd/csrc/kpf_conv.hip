@@ -92,7 +92,7 @@ enum { ARITH_F32 = 0, ARITH_SPLIT = 1, ARITH_SPLIT_W = 2 };
 // counted s_waitcnt vmcnt leaves the younger tiles' DMAs outstanding across a raw s_barrier; every wave issues the same number of DMA
 // instructions per tile (the staged row count is rounded up to whole passes) so that one immediate count fits all waves.
 template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO, int EPI, int ARITH, int NS>
-__global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const ConvArgs a) {
+__device__ __forceinline__ void igemm_body(const ConvArgs& a) {
   constexpr bool SPLIT = ARITH != ARITH_F32;
   constexpr int BM = 16 * TM * WM;
   constexpr int BN = 16 * TN * WN;
@@ -428,12 +428,27 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const ConvArgs 
   }
 }
 
+// Two kernel names so that profiles tell the arithmetic apart: igemm_f32_kernel = f32-input MFMA, igemm_split_kernel = 3 x f16 MFMA
+// on split operands (ARITH 1: activations pre-split in memory, 2: split in registers).
+template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO, int EPI, int NS>
+__global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const ConvArgs a) {
+  igemm_body<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH_F32, NS>(a);
+}
+template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO, int EPI, int ARITH, int NS>
+__global__ __launch_bounds__(64 * WM * WN) void igemm_split_kernel(const ConvArgs a) {
+  igemm_body<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH, NS>(a);
+}
+
 template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO, int EPI, int ARITH, int NS>
 int launch_one(const ConvArgs& a, hipStream_t st) {
   constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN, RPP = 8 * WM * WN;
   constexpr int BMR = NS > 2 ? (BM + RPP - 1) / RPP * RPP : BM, BNR = NS > 2 ? (BN + RPP - 1) / RPP * RPP : BN;
   const size_t lds = (size_t)(NS * (BMR + BNR) * BK + (HAS_PRO ? 2 * a.Kp : 0)) * sizeof(float);
-  auto kern = igemm_f32_kernel<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH, NS>;
+  void (*kern)(const ConvArgs);
+  if constexpr (ARITH == ARITH_F32)
+    kern = igemm_f32_kernel<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, NS>;
+  else
+    kern = igemm_split_kernel<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH, NS>;
   static bool attr_set = false;  // > 64 KiB of dynamic LDS needs an opt-in; benign if two threads race to set it
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {

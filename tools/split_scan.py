@@ -5,7 +5,7 @@ import subprocess
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-SHAPES = [(16384, 1536, 384, "gelu"), (16384, 384, 1536, "res"), (65536, 768, 192, "gelu"), (65536, 192, 768, "res"), (4096, 3072, 768, "gelu"),
+SHAPES = [(16384, 1536, 384, "gelu32"), (65536, 768, 192, "gelu32"), (16384, 1536, 384, "gelu"), (16384, 384, 1536, "res"), (65536, 768, 192, "gelu"), (65536, 192, 768, "res"), (4096, 3072, 768, "gelu"),
           (4096, 768, 3072, "res"), (262144, 128, 288, "lin"), (262144, 64, 288, "lin"), (65536, 192, 576, "lin"), (16384, 384, 1152, "lin"),
           (262144, 128, 64, "res"), (65536, 192, 96, "res"), (16384, 384, 192, "res")]
 CFGS = ["128x128", "128x96", "128x64", "256x48", "128x112", "64x128", "64x64", "32x64", "256x128", "r256x128", "r128x128", "r128x96", "r128x64"]
@@ -28,7 +28,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         pc = E.PackedConv(torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g), dev)
         out = E.Act.empty(M, 1, 1, N, dev)
         res = E.Act(torch.randn(M * N, generator=g).to(dev), M, 1, 1, N)
-        kw = dict(flags=L.KPF_ACT_GELU, out_split=True) if kind == "gelu" else (dict(res=res) if kind == "res" else dict(flags=L.KPF_ACT_RELU, out_split=True))
+        kw = dict(flags=L.KPF_ACT_GELU) if kind == "gelu32" else dict(flags=L.KPF_ACT_GELU, out_split=True) if kind == "gelu" else (dict(res=res) if kind == "res" else dict(flags=L.KPF_ACT_RELU, out_split=True))
         E.conv(pc, xs, out=out, **kw)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
