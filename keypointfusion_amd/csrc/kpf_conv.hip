@@ -16,8 +16,10 @@
 //  * The MFMA is issued "transposed": A-operand = weight fragment W[n][k], B-operand = activation fragment X[m][k], so
 //    a lane's 4 accumulator registers are 4 *consecutive output channels* of one pixel -> the epilogue reads bias /
 //    gamma / residual and writes the result as float4 (16 B per lane, 64 B contiguous per pixel per instruction).
-//  * LDS images are [row][32 k] fp32 with the 16-byte chunk index XOR-swizzled by (row & 7) (applied on the DMA's source
-//    address): ds_read_b128 fragment reads are bank-conflict free and one ds_read_b128 feeds 4 MFMAs (the K order inside
+//  * LDS images are [row][32 k] fp32 with the 16-byte chunk index XOR-swizzled by ((row >> 1) & 7) (applied on the DMA's source
+//    address): rows are 128 B, so even / odd rows start in different halves of the 256-byte bank row and the 16 rows of a fragment
+//    read land in 16 distinct 16-byte slots (a swizzle by row & 7 repeats every 8 rows: 2-way conflicts); ds_read_b128 fragment
+//    reads are bank-conflict free and one ds_read_b128 feeds 4 MFMAs (the K order inside
 //    a 16-deep step is permuted identically for both operands, which a dot product allows).
 //  * Workgroup ids are remapped so that the 8 XCDs (private L2s) each get a contiguous range of tiles, channel tiles
 //    fastest: the tiles that re-read one activation panel run on one XCD back to back.
@@ -75,6 +77,12 @@ typedef __attribute__((address_space(1))) void gbl_void_t;
 
 __device__ __attribute__((aligned(16))) float kpf_zero16[4] = {0.f, 0.f, 0.f, 0.f};  // source of every padding / out-of-range chunk
 
+#ifdef KPF_DBG_TIME
+__device__ unsigned long long kpf_dbg_t[4 * 8192];
+#define KPF_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) kpf_dbg_t[4 * blockIdx.x + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define KPF_STAMP(i)
+#endif
 constexpr int BK = 32;  // K-tile depth: 8 chunks of 16 B per staged row
 // Two LDS buffers per workgroup (64 KB at 128x128): two workgroups share a CU, so one's DMA issue, pipeline fill and epilogue run
 // under the other's MFMAs.
@@ -114,6 +122,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave % WM, wn = wave / WM;
+  KPF_STAMP(0);
 
   // XCD-aware bijective remap: blocks b, b+8, b+16.. share an XCD -> give each XCD a contiguous range of logical tiles.
   int bid = blockIdx.x;
@@ -125,11 +134,11 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
   const int m0 = mt * BM, n0 = nt * BN;
 
   // Staging: global -> LDS by DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write).  LDS rows are [32 k] fp32 = 8
-  // chunks of 16 B, chunk c of row r stored at position c ^ (r & 7) (bank-conflict-free ds_read_b128 fragments).  The DMA writes
-  // lane l of a wave at base + 16*l, so LDS stays linear and the swizzle is applied to the SOURCE: the lane at position (r, c')
-  // fetches logical chunk c' ^ (r & 7).  Out-of-range rows / K padding / conv halo read a 16-byte zero page instead.
+  // chunks of 16 B, chunk c of row r stored at position c ^ ((r >> 1) & 7) (bank-conflict-free ds_read_b128 fragments).  The DMA
+  // writes lane l of a wave at base + 16*l, so LDS stays linear and the swizzle is applied to the SOURCE: the lane at position
+  // (r, c') fetches logical chunk c' ^ ((r >> 1) & 7).  Out-of-range rows / K padding / conv halo read a 16-byte zero page instead.
   const int lr = tid >> 3;                          // row within a staging pass; a wave owns rows 8*wave .. 8*wave+7
-  const int kc = (((tid & 7) ^ (lr & 7)) << 2);     // logical k offset (floats) this lane fetches within the K tile
+  const int kc = (((tid & 7) ^ ((lr >> 1) & 7)) << 2);  // logical k offset (floats) this lane fetches within the K tile
 
   // IS1X1 (dense 1x1, stride 1, K % 32 == 0): one source pointer per staging pass, fixed for the whole K loop and advanced by the
   // K-tile offset — the per-tile address arithmetic is two VALU ops per DMA.  Rows beyond M / channels beyond N are clamped to
@@ -208,7 +217,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
   const int nk = a.Kp / BK;
   const int fr = lane & 15;  // fragment row (pixel for X, channel for W)
   const int fg = lane >> 4;  // k group 0..3
-  const int rsw = fr & 7;    // this lane's row swizzle
+  const int rsw = (fr >> 1) & 7;  // this lane's row swizzle
 
   float* pro_s = lds + NS * TILE;  // [Kp] scale, then [Kp] shift (zero beyond Cin: padded k contributes relu(0*x+0) = 0)
   float* pro_t = pro_s + a.Kp;
@@ -227,6 +236,73 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
   }
   if (NS == 2) __syncthreads();  // (a pending global_load_lds is an outstanding vmcnt: the barrier's fence drains it)
 
+  // Ring mode with pre-split operands: software-pipelined main loop.  The fragments of tile t+1 are read from LDS into a second
+  // register set while the MFMAs of tile t run from the first, so a wave's LDS latency sits under its own MFMAs (the plain loop
+  // relies on the SIMD's other wave for that); DMA runs NS-1 tiles ahead.
+  KPF_STAMP(1);
+  if constexpr (NS > 2 && ARITH == ARITH_SPLIT && !HAS_PRO) {
+    const int ch = ((fg ^ rsw) << 2), cl = (((4 + fg) ^ rsw) << 2);
+    auto read_frags = [&](int buf, f16x8(&xh)[TM], f16x8(&xl)[TM], f16x8(&wh)[TN], f16x8(&wl)[TN]) {
+      const float* xrow = lds + buf * TILE + (wm * TM * 16 + fr) * BK;
+      const float* wrow = lds + buf * TILE + BMR * BK + (wn * TN * 16 + fr) * BK;
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        xh[j] = *reinterpret_cast<const f16x8*>(xrow + j * 16 * BK + ch);
+        xl[j] = *reinterpret_cast<const f16x8*>(xrow + j * 16 * BK + cl);
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        wh[i] = *reinterpret_cast<const f16x8*>(wrow + i * 16 * BK + ch);
+        wl[i] = *reinterpret_cast<const f16x8*>(wrow + i * 16 * BK + cl);
+      }
+    };
+    auto mma = [&](const f16x8(&xh)[TM], const f16x8(&xl)[TM], const f16x8(&wh)[TN], const f16x8(&wl)[TN]) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xh[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    // wait until tile t has landed: the DMAs of tiles t+1 .. min(nk-1, issued) may stay outstanding
+    auto wait_tile = [&](int t, int issued) {
+      const int younger = (issued < nk - 1 ? issued : nk - 1) - t;
+      if (younger >= NS - 2) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * CNT) : "memory");
+      } else if (NS > 3 && younger == NS - 3 && NS - 3 > 0) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * CNT) : "memory");
+      } else if (NS > 4 && younger == 1) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    };
+    f16x8 xhA[TM], xlA[TM], whA[TN], wlA[TN], xhB[TM], xlB[TM], whB[TN], wlB[TN];
+    wait_tile(0, NS - 2);
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, xhA, xlA, whA, wlA);
+    for (int kt = 0; kt < nk; kt += 2) {
+      // even half: MFMAs of tile kt (set A) over the LDS reads of tile kt+1 (set B)
+      if (kt + 1 < nk) {
+        wait_tile(kt + 1, kt + NS - 2);
+        __builtin_amdgcn_s_barrier();  // tile kt+1 is complete in LDS; every wave's reads of tile kt-1 retired long ago
+      }
+      if (kt + NS - 1 < nk) stage(kt + NS - 1, (kt + NS - 1) % NS);
+      if (kt + 1 < nk) read_frags((kt + 1) % NS, xhB, xlB, whB, wlB);
+      mma(xhA, xlA, whA, wlA);
+      if (kt + 1 < nk) {  // odd half: tile kt+1 (set B) over the reads of tile kt+2 (set A)
+        if (kt + 2 < nk) {
+          wait_tile(kt + 2, kt + NS - 1);
+          __builtin_amdgcn_s_barrier();
+        }
+        if (kt + NS < nk) stage(kt + NS, (kt + NS) % NS);
+        if (kt + 2 < nk) read_frags((kt + 2) % NS, xhA, xlA, whA, wlA);
+        mma(xhB, xlB, whB, wlB);
+      }
+    }
+  } else
   for (int kt = 0; kt < nk; ++kt) {
     int cur;
     if (NS == 2) {
@@ -334,6 +410,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
     if (NS == 2) __syncthreads();  // next tile landed (vmcnt drained by the barrier's fence); every wave is done reading `cur`
   }
 
+  KPF_STAMP(2);
   // ---- epilogue: lane holds channels n..n+3 (n = tile + 4*fg) of pixel m (= tile + fr) ----
   const unsigned fl = a.flags;
   const bool interior = (m0 + BM <= a.M) && (n0 + BN <= a.N) && a.vec && !(fl & KPF_OUT_NCHW);  // workgroup-uniform
@@ -389,6 +466,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
           STORE4(a.out + m * a.out_ld + a.out_coff + n, v);
       }
     }
+    KPF_STAMP(3);
     return;
   }
   // edge / NCHW / unaligned path: per-element guards
@@ -605,3 +683,9 @@ extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const flo
     default: return launch_cfg<2, 1, 1, 4>(a, is1x1, st);  // 32 x 64
   }
 }
+
+#ifdef KPF_DBG_TIME
+extern "C" int kpf_dbg_read(unsigned long long* host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(kpf_dbg_t), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#endif
