@@ -224,7 +224,9 @@ struct MlpSplitArgs {
   int M;
 };
 
-template <int NC, int HT, int NW>
+// YLDS = false (C >= 192): the y tile is not staged in LDS — every lane reads its y fragments straight from global memory once
+// (they live in registers for the whole tile anyway), which leaves the LDS to the W1 / W2 chunk ring.
+template <int NC, int HT, int NW, bool YLDS>
 __global__ __launch_bounds__(64 * NW) void convnext_mlp_split_kernel(const MlpSplitArgs a) {
   constexpr int NT = 64 * NW;
   constexpr int C = 16 * NC;      // channels (multiple of 32)
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(64 * NW) void convnext_mlp_split_kernel(const MlpSp
   constexpr int BM = 16 * NW;     // one 16-pixel tile per wave
   constexpr int RCY = C / 4, RCW = HC / 4;
   constexpr int NCH = H4 / HC;
-  constexpr int YF = BM * C, W1F = HC * C, W2F = C * HC;
+  constexpr int YF = YLDS ? BM * C : 0, W1F = HC * C, W2F = C * HC;
   static_assert(C % 32 == 0 && HC % 32 == 0 && H4 % HC == 0, "split blocks are 32 wide");
 
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(64 * NW) void convnext_mlp_split_kernel(const MlpSp
   const long m0 = (long)blockIdx.x * BM;
   const int valid = (int)((a.M - m0) < BM ? (a.M - m0) : BM);
 
-  dma_image<BM, RCY, NT>(Ys, a.y + m0 * C, C, valid, a.zero, tid);
+  if (YLDS) dma_image<BM, RCY, NT>(Ys, a.y + m0 * C, C, valid, a.zero, tid);
   dma_image<HC, RCY, NT>(W1s, a.w1, C, HC, a.zero, tid);
   dma_image<C, RCW, NT>(W2s, a.w2, H4, C, a.zero, tid);
 
@@ -269,10 +271,20 @@ __global__ __launch_bounds__(64 * NW) void convnext_mlp_split_kernel(const MlpSp
   // this lane's y fragments (hi, lo per K step) are the same for every chunk: read them once
   const int yr = wave * 16 + fr;
   f16x8 yh[KC], yl[KC];
+  if (YLDS) {
 #pragma unroll
-  for (int k = 0; k < KC; ++k) {
-    yh[k] = *reinterpret_cast<const f16x8*>(Ys + yr * C + (((8 * k + fg) ^ row_sw<RCY>(yr)) << 2));
-    yl[k] = *reinterpret_cast<const f16x8*>(Ys + yr * C + (((8 * k + 4 + fg) ^ row_sw<RCY>(yr)) << 2));
+    for (int k = 0; k < KC; ++k) {
+      yh[k] = *reinterpret_cast<const f16x8*>(Ys + yr * C + (((8 * k + fg) ^ row_sw<RCY>(yr)) << 2));
+      yl[k] = *reinterpret_cast<const f16x8*>(Ys + yr * C + (((8 * k + 4 + fg) ^ row_sw<RCY>(yr)) << 2));
+    }
+  } else {
+    const long mr = (m0 + yr < a.M) ? m0 + yr : a.M - 1;  // rows beyond M repeat the last row; their results are never stored
+    const float* yrow = a.y + mr * C;
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+      yh[k] = *reinterpret_cast<const f16x8*>(yrow + ((8 * k + fg) << 2));
+      yl[k] = *reinterpret_cast<const f16x8*>(yrow + ((8 * k + 4 + fg) << 2));
+    }
   }
   const float us1 = a.us1;
 
@@ -349,11 +361,11 @@ __global__ __launch_bounds__(64 * NW) void convnext_mlp_split_kernel(const MlpSp
   }
 }
 
-template <int NC, int HT, int NW>
+template <int NC, int HT, int NW, bool YLDS>
 int launch_mlp_split(MlpSplitArgs& a, hipStream_t st) {
   constexpr int C = 16 * NC, HC = 16 * HT, BM = 16 * NW;
-  const size_t lds = (size_t)(BM * C + 2 * HC * C + 2 * C * HC + 6 * C) * sizeof(float);
-  auto kern = convnext_mlp_split_kernel<NC, HT, NW>;
+  const size_t lds = (size_t)((YLDS ? BM * C : 0) + 2 * HC * C + 2 * C * HC + 6 * C) * sizeof(float);
+  auto kern = convnext_mlp_split_kernel<NC, HT, NW, YLDS>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
@@ -435,13 +447,13 @@ static const float* mlp_zero_page() {
   return zero_of_dev[dev];
 }
 
-extern "C" int kpf_convnext_mlp_split_supported(int C) { return C == 96 || C == 128; }
+extern "C" int kpf_convnext_mlp_split_supported(int C) { return C == 96 || C == 128 || C == 192 || C == 256; }
 
 extern "C" int kpf_convnext_mlp_split_f32(const float* y_split, const float* x, const float* w1_split, const float* b1, float w1_unscale,
                                           const float* w2_split_perm, const float* b2, float w2_unscale, const float* gamma, float* out, long M,
                                           int C, void* stream) {
   KPF_REQUIRE(y_split && x && w1_split && b1 && w2_split_perm && b2 && gamma && out && M > 0, "kpf_convnext_mlp_split_f32: null pointer / empty");
-  KPF_REQUIRE(C == 96 || C == 128, "kpf_convnext_mlp_split_f32: C=%d not supported (96, 128)", C);
+  KPF_REQUIRE(kpf_convnext_mlp_split_supported(C), "kpf_convnext_mlp_split_f32: C=%d not supported (96, 128, 192, 256)", C);
   KPF_REQUIRE(M < (1l << 31) && w1_unscale > 0.f && w2_unscale > 0.f, "kpf_convnext_mlp_split_f32: bad M / scales");
   KPF_REQUIRE(kpf_aligned16(y_split) && kpf_aligned16(x) && kpf_aligned16(w1_split) && kpf_aligned16(w2_split_perm) && kpf_aligned16(out) &&
                   kpf_aligned16(b1) && kpf_aligned16(b2) && kpf_aligned16(gamma),
@@ -452,6 +464,8 @@ extern "C" int kpf_convnext_mlp_split_f32(const float* y_split, const float* x, 
   a.zero = mlp_zero_page();
   KPF_REQUIRE(a.zero, "kpf_convnext_mlp_split_f32: cannot resolve the zero page");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (C == 96) return launch_mlp_split<6, 4, 8>(a, st);  // BM 128, HC 64: 48 + 96 KB LDS
-  return launch_mlp_split<8, 2, 8>(a, st);               // C = 128: BM 128, HC 32: 64 + 64 KB
+  if (C == 96) return launch_mlp_split<6, 4, 8, true>(a, st);    // BM 128, HC 64: 48 + 96 KB LDS
+  if (C == 128) return launch_mlp_split<8, 2, 8, true>(a, st);   // BM 128, HC 32: 64 + 64 KB
+  if (C == 192) return launch_mlp_split<12, 2, 8, false>(a, st);  // y fragments from global; HC 32: 96 KB of weight chunks
+  return launch_mlp_split<16, 2, 8, false>(a, st);                // C = 256: 128 KB of weight chunks
 }

@@ -556,7 +556,7 @@ def test_full_forward_matches_oracle_in_both_gemm_modes(mode, monkeypatch):
         assert float((out[k].cpu() - ref[k]).abs().max()) * 125.0 < 0.05
 
 
-@pytest.mark.parametrize("C,M", [(96, 4096 + 37), (128, 1000)])
+@pytest.mark.parametrize("C,M", [(96, 4096 + 37), (128, 1000), (192, 2048 + 5), (256, 777)])
 def test_fused_split_mlp_matches_fp64(C, M):
     """kpf_convnext_mlp_split_f32 (hidden tensor in registers, f16 matrix cores) against an fp64 evaluation of the block's MLP."""
     from keypointfusion_amd import lib as L
