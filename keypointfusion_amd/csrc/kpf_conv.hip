@@ -418,20 +418,32 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
     // fast path: whole tile in range and 16-byte aligned -> no per-element guards, float4 bias / gamma / residual / store.
     // Pixel tiles outermost: a wave's consecutive store instructions then cover the same 16 rows' adjacent 64-byte segments,
     // so L2 merges them into whole 128-byte lines before write-back.
+    // Bias / layer scale once per channel quad; ALL residual rows of the tile are requested before the first store (`out` may alias
+    // `res`, so the compiler keeps loads behind earlier stores: row by row, each row would expose a full memory round trip).
+    f32x4 bvv[TN], gvv[TN];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int n = n0 + (wn * TN + i) * 16 + fg * 4;
+      bvv[i] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n) : zero4;
+      gvv[i] = (EPI == EPI_RES && (fl & KPF_RES_GAMMA)) ? *reinterpret_cast<const f32x4*>(a.gamma + n) : zero4;
+    }
+    f32x4 rvv[EPI == EPI_RES ? TM : 1][TN];
+    if (EPI == EPI_RES) {
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const long m = m0 + (wm * TM + j) * 16 + fr;
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+          rvv[j][i] = *reinterpret_cast<const f32x4*>(a.res + m * a.res_ld + a.res_coff + n0 + (wn * TN + i) * 16 + fg * 4);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
       const long m = m0 + (wm * TM + j) * 16 + fr;
-      f32x4 rv[TN];
-      if (EPI == EPI_RES) {  // `out` may alias `res` (in-place residual): loads cannot be scheduled above earlier stores by the
-#pragma unroll               // compiler, so a row's residual loads are all issued before its first store
-        for (int i = 0; i < TN; ++i) rv[i] = *reinterpret_cast<const f32x4*>(a.res + m * a.res_ld + a.res_coff + n0 + (wn * TN + i) * 16 + fg * 4);
-      }
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
         const int n = n0 + (wn * TN + i) * 16 + fg * 4;
-        f32x4 bv = zero4, gv = zero4;
-        if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
-        if (EPI == EPI_RES && (fl & KPF_RES_GAMMA)) gv = *reinterpret_cast<const f32x4*>(a.gamma + n);
+        const f32x4 bv = bvv[i], gv = gvv[i];
         f32x4 v = acc[i][j];
         if (SPLIT) {
 #pragma unroll
@@ -442,7 +454,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
           for (int e = 0; e < 4; ++e) {
             float y = v[e] + bv[e];
             if (fl & KPF_RES_GAMMA) y *= gv[e];
-            y += rv[i][e];
+            y += rvv[EPI == EPI_RES ? j : 0][i][e];
             if (fl & KPF_RELU_AFTER_RES) y = fmaxf(y, 0.f);
             v[e] = y;
           }
