@@ -45,7 +45,9 @@ typedef struct kpf_conv_desc {
   int out_ld, out_coff;    /* NHWC destination pixel stride / first channel                         */
   int res_ld, res_coff;    /* residual source (NHWC) pixel stride / first channel                   */
   unsigned flags;
-  float w_unscale;         /* KPF_IN_SPLIT only: weights were packed as w * 2^s, the accumulator is scaled by 2^-s */
+  float w_unscale;         /* split operands only: weights were packed as w * 2^s, the accumulator is scaled by 2^-s */
+  int tile_cfg;            /* 0: tile shape chosen by the built-in cost model; i+1: use configuration i < kpf_conv_num_tile_cfgs()
+                              (the host side times the candidates once per shape and passes the fastest) */
 } kpf_conv_desc;
 
 /*
@@ -220,6 +222,8 @@ int kpf_upnearest2x_add_f32(const float* low, const float* up1, float* out, int 
 int kpf_mano_forward_f32(const float* pose6d, int ld6, const float* betas, int ldb, const float* shapedirs_t,
                          const float* posedirs_t, const float* v_template, const float* j_regressor, const float* skin_weights,
                          const float* hands_mean, float* verts, float* joints, float* rotmat, float* pose_aa, int B, void* stream);
+
+int kpf_conv_num_tile_cfgs(void);
 
 const char* kpf_last_error(void);
 /* Library/ABI version, bumped when a signature changes. */

@@ -596,6 +596,7 @@ int launch_cfg(ConvArgs& a, bool is1x1, hipStream_t st) {
 // do not add throughput), so a launch lasts about ceil(blocks / 256 CUs) rounds of one tile's work: 384 blocks cost as much as
 // 512.  `pen` is the measured relative cost per FLOP of each tile shape (smaller tiles amortise staging and epilogue worse).
 // (A persistent-workgroup variant with cross-tile prefetch was measured 5-14 % slower than letting the dispatcher balance.)
+constexpr int KPF_NUM_TILE_CFGS = 13;  // cases of the switch in kpf_conv2d_f32 (9-12: LDS-ring variants of 8, 0, 1, 2 for split operands)
 struct Cfg {
   int bm, bn;
   double pen;
@@ -679,6 +680,10 @@ extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const flo
     if (c < bc) { bc = c; best = i; }
   }
   if (forced >= 0) best = forced;
+  if (d->tile_cfg > 0) {  // the caller's choice (engine autotuning): tile_cfg = configuration index + 1
+    KPF_REQUIRE(d->tile_cfg <= KPF_NUM_TILE_CFGS, "kpf_conv2d_f32: tile_cfg %d out of range", d->tile_cfg);
+    best = d->tile_cfg - 1;
+  }
   switch (best) {
     case 0: return launch_cfg<4, 4, 2, 2>(a, is1x1, st);   // 128 x 128
     case 1: return launch_cfg<4, 3, 2, 2>(a, is1x1, st);   // 128 x 96
@@ -701,3 +706,5 @@ extern "C" int kpf_dbg_read(unsigned long long* host, int n) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(kpf_dbg_t), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
 }
 #endif
+
+extern "C" int kpf_conv_num_tile_cfgs(void) { return KPF_NUM_TILE_CFGS; }

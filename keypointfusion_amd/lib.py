@@ -24,7 +24,7 @@ KPF_W_SPLIT = 512
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "B", "IH", "IW", "Cin", "in_ld", "in_coff", "OH", "OW", "N", "KH", "KW", "sh", "sw", "ph", "pw", "Kp",
-        "out_ld", "out_coff", "res_ld", "res_coff")] + [("flags", C.c_uint), ("w_unscale", C.c_float)]
+        "out_ld", "out_coff", "res_ld", "res_coff")] + [("flags", C.c_uint), ("w_unscale", C.c_float), ("tile_cfg", C.c_int)]
 
 
 _P = C.c_void_p
@@ -59,6 +59,7 @@ _SIGS = {
     "kpf_upnearest2x_add_f32": [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
     "kpf_mano_forward_f32": [_P, C.c_int, _P, C.c_int] + [_P] * 10 + [C.c_int, _P],
     "kpf_tr_encoder_weight_floats": [C.c_int],
+    "kpf_conv_num_tile_cfgs": [],
     "kpf_xattn_weight_floats": [],
 }
 EXPORTS = sorted(list(_SIGS) + ["kpf_last_error", "kpf_abi_version", "kpf_cbam_workspace_floats"])
