@@ -50,7 +50,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial-streams", action="store_true", help="issue both backbones on one stream (per-kernel profiling: rocprofv3 "
                     "durations of overlapped kernels are otherwise shared-GPU durations)")
-    ap.add_argument("--graph", action="store_true", help="full128 only: replay the forward from a captured hipGraph")
+    ap.add_argument("--graph", action="store_true", help="full128: replay the forward from a captured hipGraph")
+    ap.add_argument("--no-graph", action="store_true", help="backbones256: issue the ~250 launches of a step from Python instead of replaying the "
+                    "captured hipGraph (the default; same device time, but the step then depends on the host keeping up)")
     ap.add_argument("--per-launch", default="", help="write a per-launch table of the implicit-GEMM kernel to this file")
     ap.add_argument("--cpu-sample", type=int, default=8, help="images in the CPU-baseline sample")
     ap.add_argument("--gemm", default=None, choices=["split", "f32"], help="GEMM arithmetic (default: the engine's, KPF_GEMM or 'split')")
@@ -93,10 +95,17 @@ def main():
     class _Loader:
         img_size, flip = 128, 1
 
+    # backbones256 replays a captured hipGraph by default (both streams as parallel branches, inputs copied into its static buffers
+    # inside the timed step): ~1.7 ms of host work per step instead of ~3.3 ms, so host jitter on a shared box cannot stall the GPU
+    graph_on = [args.workload == "backbones256" and not args.no_graph and not args.serial_streams]
+
     def step():
         with torch.no_grad():
             if args.workload == "backbones256":
-                model._plan(dev).backbones(batch["img"], batch["img_rgb"])
+                if graph_on[0]:
+                    model._plan(dev).backbones_graphed(batch["img"], batch["img_rgb"])
+                else:
+                    model._plan(dev).backbones(batch["img"], batch["img_rgb"])
             else:
                 model(batch["img_rgb"], batch["img"], batch["pcl"], _Loader(), batch["center"], batch["M"], batch["cube"],
                       batch["cam_para"], 0.8)
@@ -127,6 +136,7 @@ def main():
     if rank == 0:
         plan = model._plan(dev)
         model.use_graphs = False  # the instrumented pass needs the individual launches
+        graph_on[0] = False
         plan.serial_streams = True  # one stream: per-launch durations are each kernel's own, not a shared GPU's
         try:
             E.PROFILE = []
@@ -231,6 +241,7 @@ def main():
                        if args.workload == "backbones256" else "KPFusion-convnext-tiny full forward, B=%d/GPU 128x128 fp32" % B,
                        "batch_per_gpu": B, "global_batch": B * world, "input": "%dx%d" % (S, S), "parallelism": "dp%d (batch shards, no collective)" % world},
             "roofline": roofline, "cpu_baseline": cpu, "f32_mfma": f32_ref, "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 3),
+            "launch": "hipGraph replay" if (args.workload == "backbones256" and not args.no_graph and not args.serial_streams) or args.graph else "eager",
         }
         line["config"]["gemm_arithmetic"] = ("fp32 emulation on the f16 matrix cores: operands split into f16 hi+lo (22 bits), 3 MFMAs per product, "
                                              "fp32 accumulate; error vs fp64 <= the f32-input MFMA path's (tests/test_parity_gpu.py)"

@@ -684,7 +684,8 @@ class ModelPlan:
         """Both UNet streams (model/model.py:397-398).  They are independent, so the RGB stream is issued on a second HIP
         stream: its small low-resolution layers (fewer tiles than CUs) fill the CUs the depth stream leaves idle."""
         cur = torch.cuda.current_stream(self.device)
-        if self.serial_streams or torch.cuda.is_current_stream_capturing():
+        capturing = torch.cuda.is_current_stream_capturing()
+        if self.serial_streams:
             return self.backbone_d(img), self.backbone_rgb(img_rgb)
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
@@ -693,10 +694,39 @@ class ModelPlan:
         with torch.cuda.stream(side):
             out_rgb = self.backbone_rgb(img_rgb)
         out_d = self.backbone_d(img)
-        cur.wait_stream(side)
-        for t in (out_rgb[0], out_rgb[1].buf):  # allocated on the side stream, consumed on the caller's stream
-            t.record_stream(cur)
+        cur.wait_stream(side)  # (under graph capture the fork / join become graph dependencies: two parallel branches)
+        if not capturing:
+            for t in (out_rgb[0], out_rgb[1].buf):  # allocated on the side stream, consumed on the caller's stream
+                t.record_stream(cur)
         return out_d, out_rgb
+
+    def backbones_graphed(self, img, img_rgb):
+        """backbones() replayed from a captured hipGraph (one graph per input shape; both streams are captured as parallel
+        branches).  One submission per step instead of ~250 launches: the step no longer depends on the host keeping up.
+        Inputs are copied into the graph's static buffers; the returned tensors are the graph's own and are overwritten by the
+        next replay (the caller copies what it keeps)."""
+        key = ("bb", tuple(img.shape), tuple(img_rgb.shape))
+        ent = self._graphs.get(key)
+        if ent is None:
+            static = [img.detach().float().contiguous().clone(), img_rgb.detach().float().contiguous().clone()]
+            cur = torch.cuda.current_stream(self.device)
+            warm = torch.cuda.Stream(device=self.device)
+            warm.wait_stream(cur)
+            with torch.cuda.stream(warm):  # eager warm-up: one-time weight packing / attribute lookups must not happen under capture
+                self.backbones(*static)
+                self.backbones(*static)
+            cur.wait_stream(warm)
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self.backbones(*static)
+            ent = (graph, static, out)
+            self._graphs[key] = ent
+        graph, static, out = ent
+        static[0].copy_(img)
+        static[1].copy_(img_rgb)
+        graph.replay()
+        return out
 
     def forward_graphed(self, img_rgb, img, pcl, center, M, cube, cam, kernel, img_size, flip):
         """Same as forward(), replayed from a captured hipGraph: at small batch the ~300 launches of one forward are host-bound
