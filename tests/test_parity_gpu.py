@@ -582,3 +582,30 @@ def test_fused_split_mlp_matches_fp64(C, M):
                                            _stream()), "mlp_split")
     e = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
     assert e < 2e-6, e
+
+
+def test_split_arithmetic_is_no_less_accurate_than_fp32_end_to_end(monkeypatch):
+    """Both ConvNeXt-T backbones at 64x64 against an fp64 evaluation of the oracle: the default split arithmetic (3 x f16 MFMA per
+    product) must be as close to the exact forward as fp32 implementations are — the f32-input MFMA path and the CPU fp32 oracle."""
+    from keypointfusion_amd import engine as E
+    from oracle import kpf_oracle as O
+    net = "convnext-tiny"
+    sd = synthetic_sd("KPFusion-" + net)
+    b = {k: torch.from_numpy(v) for k, v in synthetic_batch(1, 64, seed=1).items()}
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    exact = O.backbones_forward(sd64, b["img_rgb"].double(), b["img"].double())
+    cpu32 = O.backbones_forward(sd, b["img_rgb"], b["img"])
+    outs = {}
+    for mode in ("split", "f32"):
+        monkeypatch.setattr(E, "GEMM_MODE", mode)
+        m = _model(net)
+        with torch.no_grad():
+            outs[mode] = [t.cpu().double() for t in m.forward_backbones(b["img_rgb"].to(_dev()), b["img"].to(_dev()))]
+    for i, name in enumerate(("img_offset", "img_feat", "img_offset_rgb", "img_feat_rgb")):
+        den = float(exact[i].abs().max())
+        e_split = float((outs["split"][i] - exact[i]).abs().max()) / den
+        e_mfma = float((outs["f32"][i] - exact[i]).abs().max()) / den
+        e_cpu = float((cpu32[i].double() - exact[i]).abs().max()) / den
+        print("%s: |err| / max|exact|  split %.2e  f32-MFMA %.2e  CPU fp32 %.2e" % (name, e_split, e_mfma, e_cpu))
+        assert e_split < 1e-4, (name, e_split)
+        assert e_split <= 2.0 * max(e_mfma, e_cpu), "%s: split %.2e vs f32-MFMA %.2e, CPU fp32 %.2e" % (name, e_split, e_mfma, e_cpu)
