@@ -16,6 +16,7 @@
 //   * LDS images are row-major with the 16-byte chunk index XOR-swizzled per row (on the DMA source address) so that the
 //     ds_read_b128 fragment reads of 16 consecutive rows hit 16 different bank groups.
 #include "kpf_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -226,7 +227,7 @@ struct MlpSplitArgs {
 
 // YLDS = false (C >= 192): the y tile is not staged in LDS — every lane reads its y fragments straight from global memory once
 // (they live in registers for the whole tile anyway), which leaves the LDS to the W1 / W2 chunk ring.
-template <int NC, int HT, int NW, bool YLDS>
+template <int NC, int HT, int NW, bool YLDS, int TM>
 __global__ __launch_bounds__(64 * NW) void convnext_mlp_split_kernel(const MlpSplitArgs a) {
   constexpr int NT = 64 * NW;
   constexpr int C = 16 * NC;      // channels (multiple of 32)
@@ -234,7 +235,8 @@ __global__ __launch_bounds__(64 * NW) void convnext_mlp_split_kernel(const MlpSp
   constexpr int H4 = 4 * C;
   constexpr int HC = 16 * HT;     // hidden units per chunk (multiple of 32)
   constexpr int HK = HC / 32;     // K steps of GEMM2 per chunk
-  constexpr int BM = 16 * NW;     // one 16-pixel tile per wave
+  constexpr int BM = 16 * TM * NW;  // TM 16-pixel tiles per wave: every weight fragment read from LDS feeds TM x 3 MFMAs (at TM = 1 the
+                                    // kernel needs ~340 B/clk of LDS reads per CU and is LDS-bound)
   constexpr int RCY = C / 4, RCW = HC / 4;
   constexpr int NCH = H4 / HC;
   constexpr int YF = YLDS ? BM * C : 0, W1F = HC * C, W2F = C * HC;
@@ -258,9 +260,11 @@ __global__ __launch_bounds__(64 * NW) void convnext_mlp_split_kernel(const MlpSp
   dma_image<C, RCW, NT>(W2s, a.w2, H4, C, a.zero, tid);
 
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  f32x4 acc2[NC];
+  f32x4 acc2[NC][TM];
 #pragma unroll
-  for (int n = 0; n < NC; ++n) acc2[n] = zero4;
+  for (int n = 0; n < NC; ++n)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc2[n][j] = zero4;
   for (int i = tid; i < H4; i += NT) B1s[i] = a.b1[i];
   for (int i = tid; i < C; i += NT) {
     B2s[i] = a.b2[i];
@@ -268,22 +272,25 @@ __global__ __launch_bounds__(64 * NW) void convnext_mlp_split_kernel(const MlpSp
   }
   __syncthreads();
 
-  // this lane's y fragments (hi, lo per K step) are the same for every chunk: read them once
-  const int yr = wave * 16 + fr;
-  f16x8 yh[KC], yl[KC];
-  if (YLDS) {
+  // this lane's y fragments (hi, lo per K step and pixel tile) are the same for every chunk: read them once
+  f16x8 yh[KC][TM], yl[KC][TM];
 #pragma unroll
-    for (int k = 0; k < KC; ++k) {
-      yh[k] = *reinterpret_cast<const f16x8*>(Ys + yr * C + (((8 * k + fg) ^ row_sw<RCY>(yr)) << 2));
-      yl[k] = *reinterpret_cast<const f16x8*>(Ys + yr * C + (((8 * k + 4 + fg) ^ row_sw<RCY>(yr)) << 2));
-    }
-  } else {
-    const long mr = (m0 + yr < a.M) ? m0 + yr : a.M - 1;  // rows beyond M repeat the last row; their results are never stored
-    const float* yrow = a.y + mr * C;
+  for (int j = 0; j < TM; ++j) {
+    const int yr = (wave * TM + j) * 16 + fr;
+    if (YLDS) {
 #pragma unroll
-    for (int k = 0; k < KC; ++k) {
-      yh[k] = *reinterpret_cast<const f16x8*>(yrow + ((8 * k + fg) << 2));
-      yl[k] = *reinterpret_cast<const f16x8*>(yrow + ((8 * k + 4 + fg) << 2));
+      for (int k = 0; k < KC; ++k) {
+        yh[k][j] = *reinterpret_cast<const f16x8*>(Ys + yr * C + (((8 * k + fg) ^ row_sw<RCY>(yr)) << 2));
+        yl[k][j] = *reinterpret_cast<const f16x8*>(Ys + yr * C + (((8 * k + 4 + fg) ^ row_sw<RCY>(yr)) << 2));
+      }
+    } else {
+      const long mr = (m0 + yr < a.M) ? m0 + yr : a.M - 1;  // rows beyond M repeat the last row; their results are never stored
+      const float* yrow = a.y + mr * C;
+#pragma unroll
+      for (int k = 0; k < KC; ++k) {
+        yh[k][j] = *reinterpret_cast<const f16x8*>(yrow + ((8 * k + fg) << 2));
+        yl[k][j] = *reinterpret_cast<const f16x8*>(yrow + ((8 * k + 4 + fg) << 2));
+      }
     }
   }
   const float us1 = a.us1;
@@ -297,10 +304,12 @@ __global__ __launch_bounds__(64 * NW) void convnext_mlp_split_kernel(const MlpSp
     const float* w1b = W1s + cur * W1F;
     const float* w2b = W2s + cur * W2F;
 
-    // ---- GEMM1: acc1[ht] = W1chunk (HC x C) . y^T, 3 MFMAs per (hidden tile, K step) ----
-    f32x4 acc1[HT];
+    // ---- GEMM1: acc1[ht][tm] = W1chunk (HC x C) . y^T, 3 MFMAs per (hidden tile, pixel tile, K step) ----
+    f32x4 acc1[HT][TM];
 #pragma unroll
-    for (int h = 0; h < HT; ++h) acc1[h] = zero4;
+    for (int h = 0; h < HT; ++h)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc1[h][j] = zero4;
 #pragma unroll
     for (int k = 0; k < KC; ++k) {
 #pragma unroll
@@ -308,64 +317,75 @@ __global__ __launch_bounds__(64 * NW) void convnext_mlp_split_kernel(const MlpSp
         const int r = h * 16 + fr;
         const f16x8 wh = *reinterpret_cast<const f16x8*>(w1b + r * C + (((8 * k + fg) ^ row_sw<RCY>(r)) << 2));
         const f16x8 wl = *reinterpret_cast<const f16x8*>(w1b + r * C + (((8 * k + 4 + fg) ^ row_sw<RCY>(r)) << 2));
-        acc1[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, yh[k], acc1[h], 0, 0, 0);
-        acc1[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, yl[k], acc1[h], 0, 0, 0);
-        acc1[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, yh[k], acc1[h], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          acc1[h][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, yh[k][j], acc1[h][j], 0, 0, 0);
+          acc1[h][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, yl[k][j], acc1[h][j], 0, 0, 0);
+          acc1[h][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, yh[k][j], acc1[h][j], 0, 0, 0);
+        }
       }
     }
 
-    // ---- bias + GELU, split in registers; GEMM2: acc2[n] += W2chunk (C x HC) . h ----
+    // ---- bias + GELU, split in registers; GEMM2: acc2[n][tm] += W2chunk (C x HC) . h ----
 #pragma unroll
     for (int q = 0; q < HK; ++q) {
-      f16x8 hh, hl;
+      f16x8 hh[TM], hl[TM];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int h = 2 * q + t;
         const f32x4 bv = *reinterpret_cast<const f32x4*>(B1s + ch * HC + h * 16 + 4 * fg);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float g = gelu_f(fmaf(acc1[h][e], us1, bv[e]));
-          const _Float16 hi = (_Float16)g;
-          hh[4 * t + e] = hi;
-          hl[4 * t + e] = (_Float16)(g - (float)hi);
-        }
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float g = gelu_f(fmaf(acc1[h][j][e], us1, bv[e]));
+            const _Float16 hi = (_Float16)g;
+            hh[j][4 * t + e] = hi;
+            hl[j][4 * t + e] = (_Float16)(g - (float)hi);
+          }
       }
 #pragma unroll
       for (int n = 0; n < NC; ++n) {
         const int r = n * 16 + fr;
         const f16x8 wh = *reinterpret_cast<const f16x8*>(w2b + r * HC + (((8 * q + fg) ^ row_sw<RCW>(r)) << 2));
         const f16x8 wl = *reinterpret_cast<const f16x8*>(w2b + r * HC + (((8 * q + 4 + fg) ^ row_sw<RCW>(r)) << 2));
-        acc2[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, hh, acc2[n], 0, 0, 0);
-        acc2[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, hl, acc2[n], 0, 0, 0);
-        acc2[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, hh, acc2[n], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          acc2[n][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, hh[j], acc2[n][j], 0, 0, 0);
+          acc2[n][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, hl[j], acc2[n][j], 0, 0, 0);
+          acc2[n][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, hh[j], acc2[n][j], 0, 0, 0);
+        }
       }
     }
     __syncthreads();
   }
 
-  const long m = m0 + wave * 16 + fr;
-  if (m >= a.M) return;
   const float us2 = a.us2;
-  f32x4 xv[NC];
 #pragma unroll
-  for (int n = 0; n < NC; ++n) xv[n] = *reinterpret_cast<const f32x4*>(a.x + m * C + n * 16 + 4 * fg);
+  for (int j = 0; j < TM; ++j) {
+    const long m = m0 + (wave * TM + j) * 16 + fr;
+    if (m >= a.M) continue;
+    f32x4 xv[NC];
 #pragma unroll
-  for (int n = 0; n < NC; ++n) {
-    const int c = n * 16 + 4 * fg;
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(B2s + c);
-    const f32x4 gv = *reinterpret_cast<const f32x4*>(Gs + c);
-    f32x4 v;
+    for (int n = 0; n < NC; ++n) xv[n] = *reinterpret_cast<const f32x4*>(a.x + m * C + n * 16 + 4 * fg);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = xv[n][e] + gv[e] * fmaf(acc2[n][e], us2, bv[e]);
-    *reinterpret_cast<f32x4*>(a.out + m * C + c) = v;
+    for (int n = 0; n < NC; ++n) {
+      const int c = n * 16 + 4 * fg;
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(B2s + c);
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(Gs + c);
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = xv[n][e] + gv[e] * fmaf(acc2[n][j][e], us2, bv[e]);
+      *reinterpret_cast<f32x4*>(a.out + m * C + c) = v;
+    }
   }
 }
 
-template <int NC, int HT, int NW, bool YLDS>
+template <int NC, int HT, int NW, bool YLDS, int TM>
 int launch_mlp_split(MlpSplitArgs& a, hipStream_t st) {
-  constexpr int C = 16 * NC, HC = 16 * HT, BM = 16 * NW;
+  constexpr int C = 16 * NC, HC = 16 * HT, BM = 16 * TM * NW;
   const size_t lds = (size_t)((YLDS ? BM * C : 0) + 2 * HC * C + 2 * C * HC + 6 * C) * sizeof(float);
-  auto kern = convnext_mlp_split_kernel<NC, HT, NW, YLDS>;
+  auto kern = convnext_mlp_split_kernel<NC, HT, NW, YLDS, TM>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
@@ -464,8 +484,16 @@ extern "C" int kpf_convnext_mlp_split_f32(const float* y_split, const float* x, 
   a.zero = mlp_zero_page();
   KPF_REQUIRE(a.zero, "kpf_convnext_mlp_split_f32: cannot resolve the zero page");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (C == 96) return launch_mlp_split<6, 4, 8, true>(a, st);    // BM 128, HC 64: 48 + 96 KB LDS
-  if (C == 128) return launch_mlp_split<8, 2, 8, true>(a, st);   // BM 128, HC 32: 64 + 64 KB
-  if (C == 192) return launch_mlp_split<12, 2, 8, false>(a, st);  // y fragments from global; HC 32: 96 KB of weight chunks
-  return launch_mlp_split<16, 2, 8, false>(a, st);                // C = 256: 128 KB of weight chunks
+  static const int tm_env = []() { const char* e = getenv("KPF_MLP_TM"); return e ? atoi(e) : 2; }();  // tuning aid
+  if (tm_env == 1) {
+    if (C == 96) return launch_mlp_split<6, 4, 8, true, 1>(a, st);    // BM 128, HC 64: 48 + 96 KB LDS
+    if (C == 128) return launch_mlp_split<8, 2, 8, true, 1>(a, st);   // BM 128, HC 32: 64 + 64 KB
+    if (C == 192) return launch_mlp_split<12, 2, 8, false, 1>(a, st);  // y fragments from global; HC 32: 96 KB of weight chunks
+    return launch_mlp_split<16, 2, 8, false, 1>(a, st);                // C = 256: 128 KB of weight chunks
+  }
+  // two pixel tiles per wave (BM 256): y fragments from global memory, the LDS holds only the weight ring
+  if (C == 96) return launch_mlp_split<6, 4, 8, false, 2>(a, st);
+  if (C == 128) return launch_mlp_split<8, 2, 8, false, 2>(a, st);
+  if (C == 192) return launch_mlp_split<12, 2, 8, false, 2>(a, st);
+  return launch_mlp_split<16, 2, 8, false, 1>(a, st);  // C = 256: registers only allow one tile per wave
 }
