@@ -609,3 +609,38 @@ def test_split_arithmetic_is_no_less_accurate_than_fp32_end_to_end(monkeypatch):
         print("%s: |err| / max|exact|  split %.2e  f32-MFMA %.2e  CPU fp32 %.2e" % (name, e_split, e_mfma, e_cpu))
         assert e_split < 1e-4, (name, e_split)
         assert e_split <= 2.0 * max(e_mfma, e_cpu), "%s: split %.2e vs f32-MFMA %.2e, CPU fp32 %.2e" % (name, e_split, e_mfma, e_cpu)
+
+
+def test_full_size_bench_config_properties():
+    """BASELINE.json configs[1] at its full size (B=64, 256x256, ConvNeXt-T, both backbones): size-independent properties of the
+    forward — every sample is independent of its batch mates and of its position in the batch, the graph replay the benchmark
+    times equals the eager launches — plus the CPU oracle on two of the 64 samples."""
+    from oracle import kpf_oracle as O
+    net, B, S = "convnext-tiny", 64, 256
+    sd = synthetic_sd("KPFusion-" + net)
+    hb = synthetic_batch(B, S, seed=1)
+    img, rgb = torch.from_numpy(hb["img"]).to(_dev()), torch.from_numpy(hb["img_rgb"]).to(_dev())
+    m = _model(net)
+    plan = m._plan(_dev())
+    with torch.no_grad():
+        full = [t.clone() for t in m.forward_backbones(rgb, img)]
+        # graph replay (what bench.py times) == eager
+        (od, fd), (orgb, frgb) = plan.backbones_graphed(img, rgb)
+        from keypointfusion_amd.engine import nhwc_to_nchw
+        for a, b in zip(full, (od, nhwc_to_nchw(fd), orgb, nhwc_to_nchw(frgb))):
+            assert torch.equal(a, b)
+        # sample independence: a sample run alone gives the same result as inside the batch
+        for s in (0, 31, 63):
+            one = m.forward_backbones(rgb[s:s + 1], img[s:s + 1])
+            for a, b in zip(full, one):
+                assert rel_err(b, a[s:s + 1].cpu()) < 1e-5
+        # position independence: a permuted batch gives the permuted outputs
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(0)).to(_dev())
+        pout = m.forward_backbones(rgb[perm], img[perm])
+        for a, b in zip(full, pout):
+            assert rel_err(b, a[perm].cpu()) < 1e-6
+    # the CPU oracle on two samples of the batch
+    for s in (5, 40):
+        ref = O.backbones_forward(sd, torch.from_numpy(hb["img_rgb"][s:s + 1]), torch.from_numpy(hb["img"][s:s + 1]))
+        for a, r in zip(full, ref):
+            assert rel_err(a[s:s + 1], r) < 2e-4
