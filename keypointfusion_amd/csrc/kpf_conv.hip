@@ -113,7 +113,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
   constexpr int TILE = (BMR + BNR) * BK;
   constexpr int CNT = AP + BP;  // DMA instructions per wave per K tile in ring mode
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
-  static_assert(NS >= 2 && (NS - 2) * CNT < 64, "vmcnt is a 6-bit counter");
+  static_assert(NS >= 1 && (NS < 2 || (NS - 2) * CNT < 64), "vmcnt is a 6-bit counter");
   static_assert(BM % 8 == 0 && BN % 8 == 0, "tile granularity");
 
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][TILE] (+ [2][Kp] operand prologue scale/shift)
@@ -221,7 +221,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
 
   float* pro_s = lds + NS * TILE;  // [Kp] scale, then [Kp] shift (zero beyond Cin: padded k contributes relu(0*x+0) = 0)
   float* pro_t = pro_s + a.Kp;
-  if (NS == 2) {
+  if (NS <= 2) {
     stage(0, 0);
   } else {
 #pragma unroll
@@ -234,7 +234,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
       pro_t[i] = i < a.Cin ? a.pt[i] : 0.f;
     }
   }
-  if (NS == 2) __syncthreads();  // (a pending global_load_lds is an outstanding vmcnt: the barrier's fence drains it)
+  if (NS <= 2) __syncthreads();  // (a pending global_load_lds is an outstanding vmcnt: the barrier's fence drains it)
 
   // Ring mode with pre-split operands: software-pipelined main loop.  The fragments of tile t+1 are read from LDS into a second
   // register set while the MFMAs of tile t run from the first, so a wave's LDS latency sits under its own MFMAs (the plain loop
@@ -305,7 +305,10 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
   } else
   for (int kt = 0; kt < nk; ++kt) {
     int cur;
-    if (NS == 2) {
+    if (NS == 1) {
+      cur = 0;  // one LDS stage: the DMA of the next tile is issued after this tile's reads (second barrier below); overlap comes
+                // from the 4-5 workgroups that fit a CU at 32 KB of LDS and <= 128 VGPRs, not from double buffering
+    } else if (NS == 2) {
       cur = kt & 1;
       if (kt + 1 < nk) stage(kt + 1, cur ^ 1);  // next tile flies into the other buffer under this tile's MFMAs
     } else {
@@ -408,6 +411,11 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
       }
     }
     if (NS == 2) __syncthreads();  // next tile landed (vmcnt drained by the barrier's fence); every wave is done reading `cur`
+    if (NS == 1 && kt + 1 < nk) {
+      __syncthreads();  // every wave has read tile kt out of the stage
+      stage(kt + 1, 0);
+      __syncthreads();  // tile kt+1 landed
+    }
   }
 
   KPF_STAMP(2);
@@ -528,6 +536,13 @@ template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO, int EPI, int
 __global__ __launch_bounds__(64 * WM * WN) void igemm_split_kernel(const ConvArgs a) {
   igemm_body<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH, NS>(a);
 }
+// Single LDS stage, registers capped for 4 waves per SIMD: with the MFMA phase of a K tile this short, four or five co-resident
+// workgroups hide each other's DMA / LDS / barrier latencies better than double buffering inside two (tools/split_probe.hip: 600 vs
+// 430-490 TFLOP/s for the bare loop).
+template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO, int EPI, int ARITH>
+__global__ __launch_bounds__(64 * WM * WN, 4) void igemm_split_occ_kernel(const ConvArgs a) {
+  igemm_body<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH, 1>(a);
+}
 
 template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO, int EPI, int ARITH, int NS>
 int launch_one(const ConvArgs& a, hipStream_t st) {
@@ -537,6 +552,8 @@ int launch_one(const ConvArgs& a, hipStream_t st) {
   void (*kern)(const ConvArgs);
   if constexpr (ARITH == ARITH_F32)
     kern = igemm_f32_kernel<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, NS>;
+  else if constexpr (NS == 1)
+    kern = igemm_split_occ_kernel<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH>;
   else
     kern = igemm_split_kernel<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH, NS>;
   static bool attr_set = false;  // > 64 KiB of dynamic LDS needs an opt-in; benign if two threads race to set it
@@ -589,14 +606,14 @@ int launch_cfg(ConvArgs& a, bool is1x1, hipStream_t st) {
   a.nblk = tilesM * a.tilesN;
   if (a.flags & KPF_IN_SPLIT) return launch_arith<TM, TN, WM, WN, ARITH_SPLIT, NS_SPLIT>(a, is1x1, st);
   if (a.flags & KPF_W_SPLIT) return launch_arith<TM, TN, WM, WN, ARITH_SPLIT_W, NS_SPLIT>(a, is1x1, st);
-  return launch_arith<TM, TN, WM, WN, ARITH_F32, 2>(a, is1x1, st);
+  return launch_arith<TM, TN, WM, WN, ARITH_F32, NS_SPLIT == 1 ? 2 : 2>(a, is1x1, st);
 }
 
 // Tile choice.  The kernel is MFMA-bound and co-resident workgroups share a CU's matrix pipe (they hide each other's bubbles, they
 // do not add throughput), so a launch lasts about ceil(blocks / 256 CUs) rounds of one tile's work: 384 blocks cost as much as
 // 512.  `pen` is the measured relative cost per FLOP of each tile shape (smaller tiles amortise staging and epilogue worse).
 // (A persistent-workgroup variant with cross-tile prefetch was measured 5-14 % slower than letting the dispatcher balance.)
-constexpr int KPF_NUM_TILE_CFGS = 13;  // cases of the switch in kpf_conv2d_f32 (9-12: LDS-ring variants of 8, 0, 1, 2 for split operands)
+constexpr int KPF_NUM_TILE_CFGS = 17;  // cases of the switch in kpf_conv2d_f32 (9-12: LDS-ring variants of 8, 0, 1, 2 for split operands)
 struct Cfg {
   int bm, bn;
   double pen;
@@ -679,6 +696,9 @@ extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const flo
     const double c = cfg_cost(kCfgs[i], a.M, a.N);
     if (c < bc) { bc = c; best = i; }
   }
+  // split arithmetic without a residual epilogue: the single-stage, 4-waves-per-SIMD variant of the 128 x 128 tile is 4-10 % faster
+  // than the double-buffered 128 x 128 / 256 x 128 ones (its residual epilogue would spill at 128 registers, so those keep two stages)
+  if ((fl & (KPF_IN_SPLIT | KPF_W_SPLIT)) && !(fl & KPF_RES_ADD) && !pro_scale && (best == 0 || best == 8)) best = 13;
   if (forced >= 0) best = forced;
   if (d->tile_cfg > 0) {  // the caller's choice (engine autotuning): tile_cfg = configuration index + 1
     KPF_REQUIRE(d->tile_cfg <= KPF_NUM_TILE_CFGS, "kpf_conv2d_f32: tile_cfg %d out of range", d->tile_cfg);
@@ -697,6 +717,10 @@ extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const flo
     case 10: return launch_cfg<4, 4, 2, 2, 4>(a, is1x1, st);  // split: 128 x 128, 4-stage ring (128 KB, 3 tiles in flight)
     case 11: return launch_cfg<4, 3, 2, 2, 4>(a, is1x1, st);  // split: 128 x 96, 4-stage ring (112 KB)
     case 12: return launch_cfg<2, 4, 4, 1, 3>(a, is1x1, st);  // split: 128 x 64, 3-stage ring (72 KB, two workgroups per CU)
+    case 13: return launch_cfg<4, 4, 2, 2, 1>(a, is1x1, st);  // split: 128 x 128, one LDS stage (32 KB), 4 waves per SIMD
+    case 14: return launch_cfg<4, 3, 2, 2, 1>(a, is1x1, st);  // split: 128 x 96, one LDS stage (28 KB)
+    case 15: return launch_cfg<2, 4, 4, 1, 1>(a, is1x1, st);  // split: 128 x 64, one LDS stage (24 KB)
+    case 16: return launch_cfg<2, 2, 2, 2, 1>(a, is1x1, st);  // split: 64 x 64, one LDS stage (16 KB)
     default: return launch_cfg<2, 1, 1, 4>(a, is1x1, st);  // 32 x 64
   }
 }

@@ -13,7 +13,7 @@ typedef __attribute__((address_space(1))) void gbl_void_t;
 constexpr int TILE = 8192;  // floats per stage: (128 + 128) rows x 32
 
 template <int MODE, int NS>
-__global__ __launch_bounds__(256) void probe(float* out, unsigned long long* cyc, int iters, float seed, const float* src) {
+__global__ __launch_bounds__(256, 4) void probe(float* out, unsigned long long* cyc, int iters, float seed, const float* src) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < NS * TILE; i += 256) lds[i] = seed + i;
@@ -122,6 +122,14 @@ __global__ __launch_bounds__(256) void probe(float* out, unsigned long long* cyc
         }
       }
     }
+  } else if (MODE == 8) {  // single LDS stage, two barriers per K tile: relies on 3-4 co-resident workgroups for overlap
+    for (int it = 0; it < iters; ++it) {
+      dma(it, 0);
+      __syncthreads();  // tile landed
+      reads(0);
+      mma();
+      __syncthreads();  // everyone done reading before the next DMA overwrites the stage
+    }
   } else if (MODE == 5) {
     dma(0, 0);
     dma(1, 1);
@@ -164,7 +172,7 @@ int run(const char* name, int blocks, float* out, unsigned long long* cyc, const
   CK(hipEventSynchronize(e1));
   float ms;
   CK(hipEventElapsedTime(&ms, e0, e1));
-  static unsigned long long h[4096];
+  static unsigned long long h[8192];
   CK(hipMemcpy(h, cyc, blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   double c = 0;
   for (int i = 0; i < blocks; ++i) c += (double)h[i];
@@ -180,6 +188,10 @@ int main() {
   CK(hipMalloc(&cyc, 4096 * 8));
   CK(hipMalloc(&src, 80 * TILE * 4));
   CK(hipMemset(src, 0, 80 * TILE * 4));
+  for (int blocks : {768, 1024, 1280}) {
+    run<8, 1>("8 single LDS stage, 2 barriers", blocks, out, cyc, src);
+    run<3, 2>("3 double-buffered (64 KB)", blocks, out, cyc, src);
+  }
   for (int blocks : {256, 512}) {
     run<0, 2>("0 mfma only (register operands)", blocks, out, cyc, src);
     run<1, 2>("1 + ds_read_b128 fragments", blocks, out, cyc, src);
