@@ -714,8 +714,8 @@ extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const flo
     case 6: return launch_cfg<2, 2, 2, 2>(a, is1x1, st);   // 64 x 64
     case 8: return launch_cfg<4, 4, 4, 2>(a, is1x1, st);   // 256 x 128, 8 MFMA waves
     case 9: return launch_cfg<4, 4, 4, 2, 3>(a, is1x1, st);   // split: 256 x 128, 3-stage ring (144 KB, 2 tiles in flight)
-    case 10: return launch_cfg<4, 4, 2, 2, 4>(a, is1x1, st);  // split: 128 x 128, 4-stage ring (128 KB, 3 tiles in flight)
-    case 11: return launch_cfg<4, 3, 2, 2, 4>(a, is1x1, st);  // split: 128 x 96, 4-stage ring (112 KB)
+    case 10: return launch_cfg<4, 4, 2, 2>(a, is1x1, st);     // (was: 128 x 128 4-stage ring — one workgroup per CU, 1.5x slower; retired)
+    case 11: return launch_cfg<4, 3, 2, 2>(a, is1x1, st);     // (was: 128 x 96 4-stage ring; retired)
     case 12: return launch_cfg<2, 4, 4, 1, 3>(a, is1x1, st);  // split: 128 x 64, 3-stage ring (72 KB, two workgroups per CU)
     case 13: return launch_cfg<4, 4, 2, 2, 1>(a, is1x1, st);  // split: 128 x 128, one LDS stage (32 KB), 4 waves per SIMD
     case 14: return launch_cfg<4, 3, 2, 2, 1>(a, is1x1, st);  // split: 128 x 96, one LDS stage (28 KB)
