@@ -644,3 +644,44 @@ def test_full_size_bench_config_properties():
         ref = O.backbones_forward(sd, torch.from_numpy(hb["img_rgb"][s:s + 1]), torch.from_numpy(hb["img"][s:s + 1]))
         for a, r in zip(full, ref):
             assert rel_err(a[s:s + 1], r) < 2e-4
+
+
+def test_module_under_dataparallel_and_threads():
+    """The reference wraps the model in torch.nn.DataParallel (train.py:81, demo_RGBD.py:49) and calls it from worker threads: the
+    drop-in must survive replicate() and concurrent forwards from several Python threads on their own streams."""
+    import threading
+    net = "resnet-18"
+    m = _model(net)
+    dev = _dev()
+    b = {k: torch.from_numpy(v).to(dev) for k, v in synthetic_batch(2, 128, seed=3).items()}
+
+    class Loader:
+        img_size, flip = 128, 1
+
+    args = [b[k] for k in ("img_rgb", "img", "pcl")] + [Loader()] + [b[k] for k in ("center", "M", "cube", "cam_para")]
+    with torch.no_grad():
+        want, want_sw, _ = m(*args, 0.8)
+        dp = torch.nn.DataParallel(m, device_ids=[0])
+        got, got_sw, _ = dp(*args, 0.8)
+    for a, c in zip(want + want_sw, got + got_sw):
+        assert torch.equal(a, c)
+    outs, errs = {}, []
+
+    def worker(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(device=dev)), torch.no_grad():
+                outs[i] = m(*args, 0.8)[0]
+                torch.cuda.current_stream().synchronize()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    torch.cuda.synchronize()
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for i in range(3):
+        for a, c in zip(want, outs[i]):
+            assert torch.equal(a, c)
