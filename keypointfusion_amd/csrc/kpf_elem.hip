@@ -298,6 +298,138 @@ __global__ __launch_bounds__(256) void dwconv7_ln_wave_kernel(const float* __res
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// depthwise 7x7 + bias + LayerNorm, LDS-tiled (C = 96 / 128, large maps).  The register-tiled kernels above fetch every input pixel
+// ~7 times through L2 -> L1; here a workgroup stages the (8+6) x (32+6) pixel halo of its 8 x 32 output tile once per 32-channel
+// chunk in LDS and all 49 taps read LDS.  Thread = (channel quad of the chunk, 1 x 8 pixel strip); the outputs of all NCHK chunks
+// stay in registers, so the LayerNorm over the pixel's C channels is 8-lane shuffles at the end: one pass over the activation.
+// LDS rows are padded by one pixel (39 x 128 B): the two strips of a 16-lane group are vertical neighbours, a row apart = 128 B
+// apart modulo the 256-byte bank row, so the ds_read_b128 of 8 quads x 2 strips is conflict-free.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int DT_TY = 8, DT_HR = DT_TY + 6;  // tile rows, halo rows
+
+// PXS = strip width (8: C <= 128, 4: C = 192 so that NCHK x PXS accumulators fit); the tile is 8 rows x 4 strips.
+template <int NCHK, int PXS, bool SPLIT>
+__global__ __launch_bounds__(256) void dwconv7_ln_tile_kernel(const float* __restrict__ x, const float* __restrict__ wdw,
+                                                              const float* __restrict__ bdw, const float* __restrict__ lw,
+                                                              const float* __restrict__ lb, float* __restrict__ y, int B, int H, int W,
+                                                              int tiles_x, int tiles_y, float eps) {
+  constexpr int C = 32 * NCHK;
+  constexpr int DT_TX = 4 * PXS, DT_HP = DT_TX + 6, DT_RS = (DT_HP + 1) * 32;  // halo pixels per row; row stride in floats (1 pad pixel)
+  static_assert(DT_HP % 2 == 0, "the padded row must be an odd number of 128-byte pixels");
+  __shared__ __attribute__((aligned(16))) float tile[DT_HR * DT_RS];  // [14][39][32]
+  __shared__ __attribute__((aligned(16))) float wl[49 * 32];          // this chunk's taps [49][32]
+  const int tid = threadIdx.x;
+  const int q8 = tid & 7, strip = tid >> 3;
+  const int srow = strip & 7, sx = (strip >> 3) * PXS;  // consecutive strips are vertical neighbours (bank layout, see above)
+  unsigned bid = xcd_contiguous_block_id();
+  const int tx = (int)(bid % tiles_x);
+  bid /= tiles_x;
+  const int ty = (int)(bid % tiles_y);
+  const int b = (int)(bid / tiles_y);
+  const int y0 = ty * DT_TY, x0 = tx * DT_TX;
+  const float* xb = x + (long)b * H * W * C;
+
+  f32x4 acc[NCHK][PXS];
+#pragma unroll  // (acc is indexed by ch: it must be a compile-time index to stay in registers)
+  for (int ch = 0; ch < NCHK; ++ch) {
+    // stage the halo tile of this chunk: 14 x 38 pixels x 8 quads, zero outside the image.  All of a thread's loads are issued
+    // before the first LDS write (unconditional loads from a clamped address, zeroed by a select: a branch around a load would
+    // make the compiler wait for each one), so a chunk exposes one memory round trip, not seventeen.
+    constexpr int NIT = (DT_HR * DT_HP * 8 + 255) / 256;
+    f32x4 sv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + it * 256;
+      const int q = i & 7, p = i >> 3;
+      const int pr = p / DT_HP, pc = p - pr * DT_HP;
+      const int iy = y0 + pr - 3, ix = x0 + pc - 3;
+      const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && i < DT_HR * DT_HP * 8;
+      const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(xb + ((long)cy * W + cx) * C + ch * 32 + q * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sv[it][e] = ok ? v[e] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + it * 256;
+      const int q = i & 7, p = i >> 3;
+      const int pr = p / DT_HP, pc = p - pr * DT_HP;
+      if (i < DT_HR * DT_HP * 8) *reinterpret_cast<f32x4*>(tile + pr * DT_RS + pc * 32 + q * 4) = sv[it];
+    }
+    for (int i = tid; i < 49 * 8; i += 256) {
+      const int q = i & 7, t = i >> 3;
+      *reinterpret_cast<f32x4*>(wl + t * 32 + q * 4) = *reinterpret_cast<const f32x4*>(wdw + (long)t * C + ch * 32 + q * 4);
+    }
+    __syncthreads();
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(bdw + ch * 32 + q8 * 4);
+    f32x4 a8[PXS];
+#pragma unroll
+    for (int t = 0; t < PXS; ++t) a8[t] = bias;
+#pragma unroll 1
+    for (int ky = 0; ky < 7; ++ky) {
+      const float* row = tile + (srow + ky) * DT_RS + sx * 32 + q8 * 4;
+      f32x4 in[PXS + 6];
+#pragma unroll
+      for (int i = 0; i < PXS + 6; ++i) in[i] = *reinterpret_cast<const f32x4*>(row + i * 32);
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + (ky * 7 + kx) * 32 + q8 * 4);
+#pragma unroll
+        for (int t = 0; t < PXS; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a8[t][e] = fmaf(in[t + kx][e], wv[e], a8[t][e]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < PXS; ++t) acc[ch][t] = a8[t];
+    __syncthreads();  // everyone is done with the tile before the next chunk overwrites it
+  }
+
+  // LayerNorm of this strip's pixels: the pixel's C channels are the NCHK x 4 values of 8 neighbouring lanes
+  const float invC = 1.0f / (float)C;
+  const int oy = y0 + srow;
+#pragma unroll
+  for (int t = 0; t < PXS; ++t) {
+    float s = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < NCHK; ++ch) s += (acc[ch][t][0] + acc[ch][t][1]) + (acc[ch][t][2] + acc[ch][t][3]);
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    const float mean = s * invC;
+    float sq = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < NCHK; ++ch)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = acc[ch][t][e] - mean;
+        sq = fmaf(d, d, sq);
+      }
+    sq += __shfl_xor(sq, 1, 64);
+    sq += __shfl_xor(sq, 2, 64);
+    sq += __shfl_xor(sq, 4, 64);
+    const float rstd = 1.0f / sqrtf(sq * invC + eps);
+    const int ox = x0 + sx + t;
+    if (oy < H && ox < W) {
+      float* dst = y + (((long)b * H + oy) * W + ox) * C;
+#pragma unroll
+      for (int ch = 0; ch < NCHK; ++ch) {
+        const int c = ch * 32 + q8 * 4;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(lw + c);
+        const f32x4 be = *reinterpret_cast<const f32x4*>(lb + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (acc[ch][t][e] - mean) * rstd * g[e] + be[e];
+        if (SPLIT)
+          kpf_store_split4(dst, c, o);
+        else
+          *reinterpret_cast<f32x4*>(dst + c) = o;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // LayerNorm over C for `rows` pixels.  A row is handled by LPR = 16/32/64 lanes (the power of two covering C/4 float4s, so a
 // 96-channel row uses a 32-lane half wave instead of idling 40 of 64 lanes), rows stay in registers (two-pass variance),
 // reductions are xor-shuffles inside the LPR-lane group.  C <= 64*4*LN_MAXV.
@@ -469,6 +601,28 @@ static int dwconv7_ln_impl(const float* x, const float* w_dw, const float* b_dw,
   KPF_REQUIRE(kpf_aligned16(x) && kpf_aligned16(y) && kpf_aligned16(w_dw), "kpf_dwconv7_ln_f32: unaligned pointer");
   KPF_REQUIRE(!split || C % 32 == 0, "kpf_dwconv7_ln_split_f32: C=%d must be a multiple of 32", C);
   const int C4 = C / 4;
+  static const int tile_env = []() { const char* e = getenv("KPF_DW_TILE"); return e ? atoi(e) : 1; }();  // tuning aid
+  if (tile_env && (C == 96 || C == 128 || C == 192) && H >= 16 && W >= 16) {
+    // LDS-tiled, fused: every input pixel crosses L2 -> L1 about twice instead of seven times
+    const int TX = C == 192 ? 16 : 32;
+    const int tiles_x = (W + TX - 1) / TX, tiles_y = (H + DT_TY - 1) / DT_TY;
+    const dim3 grid((unsigned)((long)B * tiles_y * tiles_x));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define KPF_DWT(NCHK, PXS)                                                                                                                  \
+  do {                                                                                                                                      \
+    if (split)                                                                                                                              \
+      hipLaunchKernelGGL((dwconv7_ln_tile_kernel<NCHK, PXS, true>), grid, dim3(256), 0, st, x, w_dw, b_dw, ln_w, ln_b, y, B, H, W, tiles_x, \
+                         tiles_y, eps);                                                                                                     \
+    else                                                                                                                                    \
+      hipLaunchKernelGGL((dwconv7_ln_tile_kernel<NCHK, PXS, false>), grid, dim3(256), 0, st, x, w_dw, b_dw, ln_w, ln_b, y, B, H, W, tiles_x, \
+                         tiles_y, eps);                                                                                                     \
+  } while (0)
+    if (C == 96) KPF_DWT(3, 8);
+    else if (C == 128) KPF_DWT(4, 8);
+    else KPF_DWT(6, 4);
+#undef KPF_DWT
+    return kpf_check_launch("kpf_dwconv7_ln_f32");
+  }
   if (H * W >= 64 && C4 <= 64 && (size_t)49 * C * sizeof(float) <= 64 * 1024 && !getenv("KPF_DW_UNFUSED")) {
     // fused, one pass over the activation: channel quads of a pixel on one 32- or 64-lane group, LayerNorm by shuffles
     const int xstrips = (W + 7) / 8, ypairs = (H + 1) / 2;
