@@ -699,6 +699,14 @@ extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const flo
   // split arithmetic without a residual epilogue: the single-stage, 4-waves-per-SIMD variant of the 128 x 128 tile is 4-10 % faster
   // than the double-buffered 128 x 128 / 256 x 128 ones (its residual epilogue would spill at 128 registers, so those keep two stages)
   if ((fl & (KPF_IN_SPLIT | KPF_W_SPLIT)) && !(fl & KPF_RES_ADD) && !pro_scale && (best == 0 || best == 8)) best = 13;
+  // split arithmetic, few tiles and a long K (stage-4 layers, 3x3 convolutions on small maps): the cost model's large tile leaves
+  // at most two workgroups per CU running ~50-100 K tiles each; 64 x 64 single-stage tiles (4-5 per CU) are 10-25 % faster there
+  if ((fl & (KPF_IN_SPLIT | KPF_W_SPLIT)) && !pro_scale && a.Kp >= 1024) {
+    const long blocks = ((a.M + kCfgs[best < 9 ? best : 0].bm - 1) / kCfgs[best < 9 ? best : 0].bm) *
+                        ((a.N + kCfgs[best < 9 ? best : 0].bn - 1) / kCfgs[best < 9 ? best : 0].bn);
+    const long blocks64 = ((a.M + 63) / 64) * ((a.N + 63) / 64);
+    if (best < 9 && blocks <= 512 && blocks64 >= 512) best = 16;
+  }
   if (forced >= 0) best = forced;
   if (d->tile_cfg > 0) {  // the caller's choice (engine autotuning): tile_cfg = configuration index + 1
     KPF_REQUIRE(d->tile_cfg <= KPF_NUM_TILE_CFGS, "kpf_conv2d_f32: tile_cfg %d out of range", d->tile_cfg);

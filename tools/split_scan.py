@@ -5,7 +5,7 @@ import subprocess
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-SHAPES = [(16384, 1536, 384, "gelu32"), (65536, 768, 192, "gelu32"), (16384, 1536, 384, "gelu"), (16384, 384, 1536, "res"), (65536, 768, 192, "gelu"), (65536, 192, 768, "res"), (4096, 3072, 768, "gelu"),
+SHAPES = [(4096, 768, 3072, "res"), (4096, 384, 3456, "lin"), (4096, 768, 1536, "lin"), (4096, 3072, 768, "gelu"), (16384, 192, 1728, "lin"), (16384, 1536, 384, "gelu"), (16384, 384, 1536, "res"), (65536, 768, 192, "gelu"), (65536, 192, 768, "res"), (4096, 3072, 768, "gelu"),
           (4096, 768, 3072, "res"), (262144, 128, 288, "lin"), (262144, 64, 288, "lin"), (65536, 192, 576, "lin"), (16384, 384, 1152, "lin"),
           (262144, 128, 64, "res"), (65536, 192, 96, "res"), (16384, 384, 192, "res")]
 CFGS = ["128x128", "128x96", "128x64", "256x48", "128x112", "64x128", "64x64", "32x64", "256x128", "r256x128", "(retired)", "(retired)", "r128x64", "o128x128", "o128x96", "o128x64", "o64x64"]
