@@ -685,3 +685,39 @@ def test_module_under_dataparallel_and_threads():
     for i in range(3):
         for a, c in zip(want, outs[i]):
             assert torch.equal(a, c)
+
+
+def test_offset2joint_edge_cases():
+    """Masked soft-argmax decode (model/model.py:466-500) on the inputs where the reference's masks are delicate: an all-background
+    crop (every logit masked: softmax over a constant), pixels at exactly 0.99 (`< 0.99` and `> 0.99` are not complements there:
+    unmasked logit, zero offset term), a single foreground pixel, and a large-logit crop (softmax overflow guard)."""
+    from keypointfusion_amd import lib as L
+    from keypointfusion_amd.engine import _ptr, _stream
+    from oracle import kpf_oracle as O
+    dev = _dev()
+    lib = L.load()
+    g = torch.Generator().manual_seed(11)
+    B, S, Fs = 5, 128, 32
+    off = torch.randn(B, 105, Fs, Fs, generator=g)
+    off[4, 84:] *= 60.0  # large logits
+    depth = torch.ones(B, 1, S, S)
+    depth[1] = torch.rand(1, S, S, generator=g) * 1.2 - 0.6
+    depth[1, 0][torch.rand(S, S, generator=g) < 0.3] = 0.99      # exactly on the threshold
+    depth[1, 0][torch.rand(S, S, generator=g) < 0.3] = 1.0
+    depth[2, 0, 66, 70] = 0.25                                     # one foreground pixel (it is sampled by the nearest downsample)
+    depth[2, 0, 64, 68] = 0.25
+    depth[3] = torch.rand(1, S, S, generator=g) * 1.2 - 0.6
+    depth[4] = torch.rand(1, S, S, generator=g) * 1.2 - 0.6
+    sb = synthetic_batch(B, S, seed=3)
+    center, M, cube, cam = (torch.from_numpy(sb[k]) for k in ("center", "M", "cube", "cam_para"))
+    uvd_ref = O.offset2joint_weight(off, depth, 0.8)
+    xyz_ref = O.uvd2xyz(uvd_ref, center, M, cube, cam, 128, 1)
+    d = [t.to(dev).contiguous() for t in (off, depth, center, M, cube, cam)]
+    uvd = torch.empty(B, 21, 3, device=dev)
+    xyz = torch.empty(B, 21, 3, device=dev)
+    L.check(lib.kpf_offset2joint_f32(_ptr(d[0]), _ptr(d[1]), _ptr(d[2]), _ptr(d[3]), _ptr(d[4]), _ptr(d[5]), _ptr(uvd), _ptr(xyz), B, S, Fs, 0.8,
+                                     128, 1, _stream()), "offset2joint")
+    assert torch.isfinite(uvd).all() and torch.isfinite(xyz).all()
+    for b in range(B):
+        assert float((uvd[b].cpu() - uvd_ref[b]).abs().max()) < 2e-5, (b, float((uvd[b].cpu() - uvd_ref[b]).abs().max()))
+    assert rel_err(xyz, xyz_ref) < 1e-4
