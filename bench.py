@@ -212,7 +212,31 @@ def main():
             torch.cuda.synchronize()
             dt32 = time.perf_counter() - t1
             f32_ref = {"value": round(B * args.steps / dt32, 2), "unit": "img/s", "ms_per_step": round(dt32 / args.steps * 1e3, 3),
-                       "gemm_arithmetic": "v_mfma_f32_16x16x4_f32 (KPF_GEMM=f32)", "peak_tflops": PEAK_F32_MFMA_TFLOPS}
+                       "gemm_arithmetic": "v_mfma_f32_16x16x4_f32 (KPF_GEMM=f32)", "launch": "eager"}
+            # the same instrumented pass for this arithmetic: dominant kernel against the dense f32-input MFMA peak
+            plan32 = model._plan(dev)
+            plan32.serial_streams = True
+            try:
+                E.PROFILE = []
+                step()
+                torch.cuda.synchronize()
+                E.PROFILE = []
+                step()
+                torch.cuda.synchronize()
+                recs32 = E.PROFILE
+            finally:
+                E.PROFILE = None
+            per32 = {}
+            for name, e0, e1, fl_i, nb, shp in recs32:
+                d = per32.setdefault(name, [0, 0.0, 0.0])
+                d[0] += 1
+                d[1] += e0.elapsed_time(e1)
+                d[2] += fl_i
+            dom32 = max(per32, key=lambda k: per32[k][1])
+            a32 = per32[dom32][2] / (per32[dom32][1] * 1e-3) / 1e12
+            f32_ref["roofline"] = {"bound": "mfma", "kernel": dom32, "achieved": round(a32, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": round(a32 / PEAK_F32_MFMA_TFLOPS, 4), "launches_per_step": per32[dom32][0],
+                                   "kernel_ms_per_step": round(per32[dom32][1], 3)}
         finally:
             E.GEMM_MODE = mode
             model._plans.clear()
