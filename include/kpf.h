@@ -134,17 +134,25 @@ int kpf_maxpool3x3s2_f32(const float* src, float* dst, int B, int H, int W, int 
  * J = 21 joints, feature maps F x F (P = F*F pixels), N points, C = 128 channels; all buffers dense fp32.
  * ------------------------------------------------------------------------------------------------------------ */
 
+/* Inverse of B 3x3 crop matrices [B][3][3] -> Minv [B][3][3] in the operation order of the reference's torch.linalg.inv on the CPU
+ * (dataloader/loader.py:781 -> ATen linalg_solve_ex on A^T -> LAPACK getrf/getrs), bit-identical to it, so that pixel positions and
+ * the integer top-4 / ball-query decisions derived from them match the reference bit for bit.  fused = 1: the library's FMA code
+ * path (Intel hosts), 0: its separately-rounded path (AMD hosts) — keypointfusion_amd/inv3x3.py::host_mode() tells which one the
+ * host's torch.linalg.inv takes.  The geometry entry points below take this Minv (or one computed by torch.linalg.inv itself). */
+int kpf_inv3x3_f32(const float* M, float* Minv, int B, int fused, void* stream);
+
 /* Masked soft-argmax decode of the depth stream's offset maps + uvd->xyz (model/model.py:466-500 offset2joint_weight,
  * dataloader/loader.py:775-789 uvd_nl2xyznl_tensor).  offset NCHW [B][105][P]; depth [B][S][S] (nearest-downsampled to
- * F on the fly, model/model.py:471); center [B][3], M [B][3][3], cube [B][3], cam [B][4].  -> joint_uvd, joint_xyz [B][21][3]. */
-int kpf_offset2joint_f32(const float* offset, const float* depth, const float* center, const float* M, const float* cube,
+ * F on the fly, model/model.py:471); center [B][3], Minv [B][3][3] (kpf_inv3x3_f32), cube [B][3], cam [B][4].
+ * -> joint_uvd, joint_xyz [B][21][3]. */
+int kpf_offset2joint_f32(const float* offset, const float* depth, const float* center, const float* Minv, const float* cube,
                          const float* cam, float* joint_uvd, float* joint_xyz, int B, int S, int F, float kernel,
                          int img_size, int flip, void* stream);
 
 /* Per point the 4 nearest feature pixels, ascending squared distance, and inverse-distance weights
  * (dataloader/loader.py:936-967 img2pcl_index; replaces the B x N x P x 3 broadcast + ATen topk).
  * -> closeness [B][N][4] fp32, index [B][N][4] int32 (values in [0,P)), img_xyz [B][P][3] (pixel positions, may be NULL). */
-int kpf_img2pcl_top4_f32(const float* pcl, const float* depth, const float* center, const float* M, const float* cube,
+int kpf_img2pcl_top4_f32(const float* pcl, const float* depth, const float* center, const float* Minv, const float* cube,
                          const float* cam, float* closeness, int* index, float* img_xyz, int B, int N, int S, int F,
                          int img_size, int flip, void* stream);
 
@@ -173,7 +181,7 @@ int kpf_group_max_f32(const float* in, float* out, long rows, int group, int C, 
  * -> sw_out NCHW [B][21][P] (returned spatial weight), Gw [B][21][P] = gate * fc_spatial2joint_feature.weight. */
 int kpf_heat_gam_gate_f32(const float* r3d, const float* img_xyz, const float* SF, int sf_ld, const float* Wh,
                           const float* bias, const float* weight_dis, const float* wfc, const float* center,
-                          const float* M, const float* cube, const float* cam, float* sw_out, float* Gw, int B, int F,
+                          const float* Minv, const float* cube, const float* cam, float* sw_out, float* Gw, int B, int F,
                           int img_size, int flip, void* stream);
 
 /* img_feat_j = Gw @ relu(feat) + b (model/model.py:340-344), optional relu((. + prev)/2).  -> out [B][21][128]. */

@@ -27,6 +27,20 @@ static inline int kpf_check_launch(const char* what) {
   return KPF_OK;
 }
 
+// Opt a kernel into > 64 KiB of dynamic LDS on the CURRENT device, once per (kernel instantiation, device): the attribute is per
+// device, and one process may drive several GPUs (torch.nn.DataParallel, the reference's own wrapper).  `done` is the caller's
+// function-local static array, one flag per device ordinal.
+#include <atomic>
+constexpr int KPF_MAX_DEVICES = 64;
+static inline bool kpf_raise_lds_limit(const void* kern, std::atomic<bool>* done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= KPF_MAX_DEVICES) return false;
+  if (done[dev].load(std::memory_order_acquire)) return true;
+  if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+  done[dev].store(true, std::memory_order_release);
+  return true;
+}
+
 static inline bool kpf_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // wave64 butterfly sum

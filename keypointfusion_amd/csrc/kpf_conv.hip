@@ -556,13 +556,10 @@ int launch_one(const ConvArgs& a, hipStream_t st) {
     kern = igemm_split_occ_kernel<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH>;
   else
     kern = igemm_split_kernel<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH, NS>;
-  static bool attr_set = false;  // > 64 KiB of dynamic LDS needs an opt-in; benign if two threads race to set it
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-      kpf_set_error("kpf_conv2d_f32: cannot raise the dynamic LDS limit");
-      return KPF_ELAUNCH;
-    }
-    attr_set = true;
+  static std::atomic<bool> lds_opt_in[KPF_MAX_DEVICES];  // per device: the attribute does not carry over to other GPUs of the process
+  if (!kpf_raise_lds_limit(reinterpret_cast<const void*>(kern), lds_opt_in)) {
+    kpf_set_error("kpf_conv2d_f32: cannot raise the dynamic LDS limit");
+    return KPF_ELAUNCH;
   }
   if (lds > 160 * 1024) {
     kpf_set_error("kpf_conv2d_f32: operand prologue too long for LDS (Kp=%d)", a.Kp);

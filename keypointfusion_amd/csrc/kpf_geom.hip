@@ -18,19 +18,84 @@ struct Cam {  // per-sample crop/camera constants
   float fx, fy, u0, v0;
 };
 
-__device__ __forceinline__ Cam load_cam(const float* center, const float* M, const float* cube, const float* cam, int b) {
+// M^-1 with the operation order of the reference's torch.linalg.inv on the CPU (dataloader/loader.py:781), so that the pixel positions
+// -- and with them the integer top-4 / ball-query decisions -- come out bit for bit like the reference's.  ATen solves A X = I by
+// factoring the row-major matrix as its transpose (no copy) and calling getrs with trans = 'T' (linalg_solve_ex: use_A_T); MKL's
+// 3x3 path was pinned empirically (tools/mkl_inv_probe.py, tests/test_inv3x3.py: 10^4 crop matrices, bitwise): partial-pivot LU of
+// A^T with column 0 scaled by the reciprocal of the pivot, column 1 by a true division; U^T y = e with reciprocal diagonals;
+// x1 = y1 - l21 x2; x0 = y0 - (l10 x1 + l20 x2); row interchanges undone.  FUSED = MKL's FMA code path (Intel hosts): every c - a*b
+// is one fused operation and x0 = y0 - fma(l10, x1, l20*x2); otherwise (its generic path, AMD hosts) every product and sum is
+// rounded separately.  keypointfusion_amd/inv3x3.py finds out which one the host's library takes.
+template <bool FUSED>
+__device__ __forceinline__ float msub(float c, float a, float b) {  // c - a*b
+  return FUSED ? __builtin_fmaf(-a, b, c) : c - a * b;  // (contraction is off in this file: the second form rounds twice)
+}
+template <bool FUSED>
+__device__ __forceinline__ void inv3x3_lapack_order(const float* __restrict__ m, float (&inv)[3][3]) {
+  // rows of A^T = columns of A
+  float r0x = m[0], r0y = m[3], r0z = m[6];
+  float r1x = m[1], r1y = m[4], r1z = m[7];
+  float r2x = m[2], r2y = m[5], r2z = m[8];
+  int p0 = 0;
+  float best = fabsf(r0x);
+  if (fabsf(r1x) > best) { best = fabsf(r1x); p0 = 1; }
+  if (fabsf(r2x) > best) p0 = 2;
+#define KPF_SWAP3(a, b) do { float t_; t_ = a##x; a##x = b##x; b##x = t_; t_ = a##y; a##y = b##y; b##y = t_; t_ = a##z; a##z = b##z; b##z = t_; } while (0)
+  if (p0 == 1) KPF_SWAP3(r0, r1);
+  if (p0 == 2) KPF_SWAP3(r0, r2);
+  const float rc = 1.0f / r0x;
+  r1x = r1x * rc;  // l10
+  r2x = r2x * rc;  // l20
+  r1y = msub<FUSED>(r1y, r1x, r0y);
+  r1z = msub<FUSED>(r1z, r1x, r0z);
+  r2y = msub<FUSED>(r2y, r2x, r0y);
+  r2z = msub<FUSED>(r2z, r2x, r0z);
+  const int p1 = fabsf(r2y) > fabsf(r1y) ? 2 : 1;
+  if (p1 == 2) KPF_SWAP3(r1, r2);
+#undef KPF_SWAP3
+  const float l10 = r1x, l20 = r2x;
+  const float l21 = r2y / r1y;
+  r2z = msub<FUSED>(r2z, l21, r1z);
+  const float rd0 = 1.0f / r0x, rd1 = 1.0f / r1y, rd2 = 1.0f / r2z;
+  float x[3][3];  // x[row][rhs column]
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float b0 = c == 0 ? 1.f : 0.f, b1 = c == 1 ? 1.f : 0.f, b2 = c == 2 ? 1.f : 0.f;
+    const float y0 = b0 * rd0;
+    b1 = b1 - y0 * r0y;
+    b2 = b2 - y0 * r0z;
+    const float y1 = b1 * rd1;
+    b2 = b2 - y1 * r1z;
+    const float y2 = b2 * rd2;
+    const float x2 = y2;
+    const float x1 = msub<FUSED>(y1, x2, l21);
+    const float p2 = l20 * x2;
+    const float x0 = y0 - (FUSED ? __builtin_fmaf(l10, x1, p2) : l10 * x1 + p2);
+    x[0][c] = x0;
+    x[1][c] = x1;
+    x[2][c] = x2;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {  // undo the row interchanges, last first
+    float a0 = x[0][c], a1 = x[1][c], a2 = x[2][c], t;
+    if (p1 == 2) { t = a1; a1 = a2; a2 = t; }
+    if (p0 == 1) { t = a0; a0 = a1; a1 = t; }
+    if (p0 == 2) { t = a0; a0 = a2; a2 = t; }
+    inv[0][c] = a0;
+    inv[1][c] = a1;
+    inv[2][c] = a2;
+  }
+}
+
+__device__ __forceinline__ Cam load_cam(const float* center, const float* Minv, const float* cube, const float* cam, int b) {
   Cam c;
-  const float* m = M + 9 * b;
-  const float a = m[0], bb = m[1], cc = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
-  const float A = e * i - f * h, Bc = -(d * i - f * g), Cc = d * h - e * g;
-  const float det = a * A + bb * Bc + cc * Cc;
-  const float id = 1.0f / det;
-  c.mi00 = A * id;
-  c.mi01 = -(bb * i - cc * h) * id;
-  c.mi02 = (bb * f - cc * e) * id;
-  c.mi10 = Bc * id;
-  c.mi11 = (a * i - cc * g) * id;
-  c.mi12 = -(a * f - cc * d) * id;
+  const float* mi = Minv + 9 * b;  // M^-1 from kpf_inv3x3_f32 (or the host's torch.linalg.inv): only its first two rows are used
+  c.mi00 = mi[0];
+  c.mi01 = mi[1];
+  c.mi02 = mi[2];
+  c.mi10 = mi[3];
+  c.mi11 = mi[4];
+  c.mi12 = mi[5];
   c.cx = center[3 * b];
   c.cy = center[3 * b + 1];
   c.cz = center[3 * b + 2];
@@ -73,12 +138,25 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
+// M^-1 for a batch of crop matrices: computed once per forward, read by every geometry kernel below.
+template <bool FUSED>
+__global__ __launch_bounds__(64) void inv3x3_kernel(const float* __restrict__ M, float* __restrict__ Minv, int B) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  float inv[3][3];
+  inv3x3_lapack_order<FUSED>(M + 9 * b, inv);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) Minv[9 * b + 3 * i + k] = inv[i][k];
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // a7 + a8: masked soft-argmax decode (model/model.py:466-500) and uvd -> xyz.  grid (J, B), 256 threads.
 // offset: NCHW [B][105][F*F]; depth: [B][S][S] (nearest-downsampled on the fly).
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void offset2joint_kernel(const float* __restrict__ offset, const float* __restrict__ depth,
-                                                           const float* __restrict__ center, const float* __restrict__ M,
+                                                           const float* __restrict__ center, const float* __restrict__ Minv,
                                                            const float* __restrict__ cube, const float* __restrict__ cam,
                                                            float* __restrict__ joint_uvd, float* __restrict__ joint_xyz, int S, int F,
                                                            float kernel, float half_img, float flip) {
@@ -122,7 +200,7 @@ __global__ __launch_bounds__(256) void offset2joint_kernel(const float* __restri
     o[0] = u;
     o[1] = v;
     o[2] = d;
-    const Cam c = load_cam(center, M, cube, cam, b);
+    const Cam c = load_cam(center, Minv, cube, cam, b);
     float x, y, z;
     uvd2xyz(c, u, v, d, half_img, flip, x, y, z);
     float* q = joint_xyz + ((long)b * J + j) * 3;
@@ -137,7 +215,7 @@ __global__ __launch_bounds__(256) void offset2joint_kernel(const float* __restri
 // grid (ceil(N/256), B); the F*F pixel positions are rebuilt in LDS per workgroup (12 KB at F=32).
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void img2pcl_top4_kernel(const float* __restrict__ pcl, const float* __restrict__ depth,
-                                                           const float* __restrict__ center, const float* __restrict__ M,
+                                                           const float* __restrict__ center, const float* __restrict__ Minv,
                                                            const float* __restrict__ cube, const float* __restrict__ cam,
                                                            float* __restrict__ closeness, int* __restrict__ index,
                                                            float* __restrict__ img_xyz_out, int N, int S, int F, float half_img,
@@ -145,7 +223,7 @@ __global__ __launch_bounds__(256) void img2pcl_top4_kernel(const float* __restri
   extern __shared__ __attribute__((aligned(16))) float pix[];  // [P][3]
   const int b = blockIdx.y, tid = threadIdx.x;
   const int P = F * F;
-  const Cam c = load_cam(center, M, cube, cam, b);
+  const Cam c = load_cam(center, Minv, cube, cam, b);
   for (int p = tid; p < P; p += 256) {
     const int py = p / F, px = p - py * F;
     const float d = depth[(long)b * S * S + (long)((py * S) / F) * S + (px * S) / F];
@@ -404,7 +482,7 @@ __global__ __launch_bounds__(256) void heat_gam_gate_kernel(const float* __restr
                                                             const float* __restrict__ SF, int sf_ld, const float* __restrict__ Wh,
                                                             const float* __restrict__ bias, const float* __restrict__ weight_dis,
                                                             const float* __restrict__ wfc, const float* __restrict__ center,
-                                                            const float* __restrict__ M, const float* __restrict__ cube,
+                                                            const float* __restrict__ Minv, const float* __restrict__ cube,
                                                             const float* __restrict__ cam, float* __restrict__ sw_out,
                                                             float* __restrict__ Gw, int F, float std_, float sigma, float gamma,
                                                             float half_img, float flip) {
@@ -418,7 +496,7 @@ __global__ __launch_bounds__(256) void heat_gam_gate_kernel(const float* __restr
     const float* jp = r3d + ((long)b * J + tid) * 3;
     jht[tid][0] = (jp[0] + 1.0f) / 2.0f * (float)F;
     jht[tid][1] = (jp[1] + 1.0f) / 2.0f * (float)F;
-    const Cam c = load_cam(center, M, cube, cam, b);
+    const Cam c = load_cam(center, Minv, cube, cam, b);
     float x, y, z;
     uvd2xyz(c, jp[0], jp[1], jp[2], half_img, flip, x, y, z);
     jxyz[tid][0] = x;
@@ -506,23 +584,32 @@ __global__ __launch_bounds__(256) void gate_reduce_kernel(const float* __restric
 
 #define ST(s) reinterpret_cast<hipStream_t>(s)
 
-extern "C" int kpf_offset2joint_f32(const float* offset, const float* depth, const float* center, const float* M, const float* cube,
+extern "C" int kpf_inv3x3_f32(const float* M, float* Minv, int B, int fused, void* stream) {
+  KPF_REQUIRE(M && Minv && B > 0 && (fused == 0 || fused == 1), "kpf_inv3x3_f32: bad arguments");
+  if (fused)
+    hipLaunchKernelGGL(inv3x3_kernel<true>, dim3((B + 63) / 64), dim3(64), 0, ST(stream), M, Minv, B);
+  else
+    hipLaunchKernelGGL(inv3x3_kernel<false>, dim3((B + 63) / 64), dim3(64), 0, ST(stream), M, Minv, B);
+  return kpf_check_launch("kpf_inv3x3_f32");
+}
+
+extern "C" int kpf_offset2joint_f32(const float* offset, const float* depth, const float* center, const float* Minv, const float* cube,
                                     const float* cam, float* joint_uvd, float* joint_xyz, int B, int S, int F, float kernel,
                                     int img_size, int flip, void* stream) {
-  KPF_REQUIRE(offset && depth && center && M && cube && cam && joint_uvd && joint_xyz && B > 0 && F > 0 && S >= F,
+  KPF_REQUIRE(offset && depth && center && Minv && cube && cam && joint_uvd && joint_xyz && B > 0 && F > 0 && S >= F,
               "kpf_offset2joint_f32: bad arguments");
-  hipLaunchKernelGGL(offset2joint_kernel, dim3(J, B), dim3(256), 0, ST(stream), offset, depth, center, M, cube, cam, joint_uvd,
+  hipLaunchKernelGGL(offset2joint_kernel, dim3(J, B), dim3(256), 0, ST(stream), offset, depth, center, Minv, cube, cam, joint_uvd,
                      joint_xyz, S, F, kernel, (float)img_size / 2.0f, (float)flip);
   return kpf_check_launch("kpf_offset2joint_f32");
 }
 
-extern "C" int kpf_img2pcl_top4_f32(const float* pcl, const float* depth, const float* center, const float* M, const float* cube,
+extern "C" int kpf_img2pcl_top4_f32(const float* pcl, const float* depth, const float* center, const float* Minv, const float* cube,
                                     const float* cam, float* closeness, int* index, float* img_xyz, int B, int N, int S, int F,
                                     int img_size, int flip, void* stream) {
-  KPF_REQUIRE(pcl && depth && closeness && index && B > 0 && N > 0 && F * F >= 4 && F * F * 12 <= 64 * 1024,
+  KPF_REQUIRE(pcl && depth && center && Minv && cube && cam && closeness && index && B > 0 && N > 0 && F * F >= 4 && F * F * 12 <= 64 * 1024,
               "kpf_img2pcl_top4_f32: bad arguments");
   hipLaunchKernelGGL(img2pcl_top4_kernel, dim3((N + 255) / 256, B), dim3(256), (size_t)F * F * 3 * sizeof(float), ST(stream), pcl,
-                     depth, center, M, cube, cam, closeness, index, img_xyz, N, S, F, (float)img_size / 2.0f, (float)flip);
+                     depth, center, Minv, cube, cam, closeness, index, img_xyz, N, S, F, (float)img_size / 2.0f, (float)flip);
   return kpf_check_launch("kpf_img2pcl_top4_f32");
 }
 
@@ -560,11 +647,11 @@ extern "C" int kpf_group_max_f32(const float* in, float* out, long rows, int gro
 
 extern "C" int kpf_heat_gam_gate_f32(const float* r3d, const float* img_xyz, const float* SF, int sf_ld, const float* Wh,
                                      const float* bias, const float* weight_dis, const float* wfc, const float* center,
-                                     const float* M, const float* cube, const float* cam, float* sw_out, float* Gw, int B, int F,
+                                     const float* Minv, const float* cube, const float* cam, float* sw_out, float* Gw, int B, int F,
                                      int img_size, int flip, void* stream) {
-  KPF_REQUIRE(r3d && img_xyz && SF && Wh && bias && weight_dis && wfc && sw_out && Gw && B > 0, "kpf_heat_gam_gate_f32: null pointer");
+  KPF_REQUIRE(r3d && img_xyz && SF && Wh && bias && weight_dis && wfc && center && Minv && cube && cam && sw_out && Gw && B > 0, "kpf_heat_gam_gate_f32: null pointer");
   hipLaunchKernelGGL(heat_gam_gate_kernel, dim3((F * F + 255) / 256, B), dim3(256), 0, ST(stream), r3d, img_xyz, SF, sf_ld, Wh, bias,
-                     weight_dis, wfc, center, M, cube, cam, sw_out, Gw, F, 0.8f, 1.0f, 10.0f, (float)img_size / 2.0f, (float)flip);
+                     weight_dis, wfc, center, Minv, cube, cam, sw_out, Gw, F, 0.8f, 1.0f, 10.0f, (float)img_size / 2.0f, (float)flip);
   return kpf_check_launch("kpf_heat_gam_gate_f32");
 }
 

@@ -386,13 +386,10 @@ int launch_mlp_split(MlpSplitArgs& a, hipStream_t st) {
   constexpr int C = 16 * NC, HC = 16 * HT, BM = 16 * TM * NW;
   const size_t lds = (size_t)((YLDS ? BM * C : 0) + 2 * HC * C + 2 * C * HC + 6 * C) * sizeof(float);
   auto kern = convnext_mlp_split_kernel<NC, HT, NW, YLDS, TM>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-      kpf_set_error("kpf_convnext_mlp_split_f32: cannot raise the dynamic LDS limit");
-      return KPF_ELAUNCH;
-    }
-    attr_set = true;
+  static std::atomic<bool> lds_opt_in[KPF_MAX_DEVICES];  // per device: the attribute does not carry over to other GPUs of the process
+  if (!kpf_raise_lds_limit(reinterpret_cast<const void*>(kern), lds_opt_in)) {
+    kpf_set_error("kpf_convnext_mlp_split_f32: cannot raise the dynamic LDS limit");
+    return KPF_ELAUNCH;
   }
   const long tiles = (a.M + BM - 1) / BM;
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64 * NW), lds, st, a);
@@ -404,13 +401,10 @@ int launch_mlp(MlpArgs& a, hipStream_t st) {
   constexpr int C = 16 * NC, HC = 16 * HT, BM = 16 * TM * NW;
   const size_t lds = (size_t)(BM * C + 2 * HC * C + 2 * C * HC + 6 * C) * sizeof(float);
   auto kern = convnext_mlp_kernel<NC, TM, HT, NW>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-      kpf_set_error("kpf_convnext_mlp_f32: cannot raise the dynamic LDS limit");
-      return KPF_ELAUNCH;
-    }
-    attr_set = true;
+  static std::atomic<bool> lds_opt_in[KPF_MAX_DEVICES];  // per device: the attribute does not carry over to other GPUs of the process
+  if (!kpf_raise_lds_limit(reinterpret_cast<const void*>(kern), lds_opt_in)) {
+    kpf_set_error("kpf_convnext_mlp_f32: cannot raise the dynamic LDS limit");
+    return KPF_ELAUNCH;
   }
   const long tiles = (a.M + BM - 1) / BM;
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64 * NW), lds, st, a);

@@ -19,10 +19,12 @@ from .spec import CONVNEXT, parse_net
 
 BN_EPS = 1e-5
 FORCE_UNFUSED_MLP = bool(int(__import__("os").environ.get("KPF_UNFUSED_MLP", "0")))  # A/B switch for tuning
-# GEMM arithmetic.  "split" (default): fp32 emulation on the f16 matrix cores — operands as f16 hi + lo (22 bits), 3 MFMAs per product
-# (hi*hi + hi*lo + lo*hi), fp32 accumulate; measured at least as close to an fp64 product as the f32-input MFMA (tests/test_parity_gpu.py::
-# test_split_gemm_is_as_accurate_as_fp32) at 3/16 of its matrix-pipe cycles.  "f32": v_mfma_f32_16x16x4_f32 everywhere (KPF_GEMM=f32).
-GEMM_MODE = __import__("os").environ.get("KPF_GEMM", "split")
+# GEMM arithmetic.  "f32" (default): every GEMM on v_mfma_f32_16x16x4_f32 — IEEE fp32 products and accumulation, bit for bit an
+# fmaf chain, the reference's arithmetic.  "split" (KPF_GEMM=split, opt-in): fp32 emulation on the f16 matrix cores — operands as
+# f16 hi + lo (22 bits), 3 MFMAs per product (hi*hi + hi*lo + lo*hi), fp32 accumulate — used ONLY for layers whose operands have a
+# bound proven at pack time (PackedConv.split_allowed; LayerNorm / GELU outputs of the ConvNeXt blocks): operands outside the f16
+# range would saturate, so every other layer (pre-activation Residuals, ResNet stages, the fusion head) stays on the f32 MFMA.
+GEMM_MODE = __import__("os").environ.get("KPF_GEMM", "f32")
 assert GEMM_MODE in ("split", "f32"), "KPF_GEMM must be 'split' or 'f32'"
 F16_MAX = 65504.0
 # Optional tile-shape autotuning of the implicit GEMM (KPF_AUTOTUNE=1): the first time a (layer, shape, epilogue) combination runs,
@@ -151,7 +153,9 @@ class PackedConv:
         wp[:, :K] = w.reshape(N, K)
         self.w = wp.float().to(device)
         self.b = b.float().to(device)
-        self.split_allowed = True
+        # split (3 x f16) arithmetic only where the caller has proven |activation| < 65504 at pack time (ConvNeXtBlockPlan, the
+        # downsample LayerNorms): everywhere else a large activation would saturate silently, so the default is the f32 MFMA
+        self.split_allowed = False
         self.tuned = {}  # (shape, epilogue) -> tile configuration index + 1 (autotuning cache)
         self.ps = self.pt = None
         if prologue is not None:
@@ -280,6 +284,20 @@ def upsample2x(x, out):
     return out
 
 
+def crop_inverse(M):
+    """M^-1 [B][3][3] bit-identical to the reference's torch.linalg.inv on this host's CPU (dataloader/loader.py:781): on the device in
+    the host library's rounding order (inv3x3.host_mode), or — if the host's order is not one of the two known — by torch.linalg.inv
+    itself on a host copy of M (one device->host round trip per forward)."""
+    from .inv3x3 import host_mode
+    mode = host_mode()
+    B = M.shape[0]
+    if mode < 0:
+        return torch.linalg.inv(M.detach().float().cpu().view(B, 1, 3, 3)).view(B, 3, 3).to(M.device)
+    out = torch.empty(B, 3, 3, device=M.device, dtype=torch.float32)
+    L.check(L.load().kpf_inv3x3_f32(_ptr(M), _ptr(out), B, mode, _stream()), "kpf_inv3x3_f32")
+    return out
+
+
 def nchw_to_nhwc(t, cpad=None):
     lib = L.load()
     B, Cc, H, W = t.shape
@@ -313,28 +331,25 @@ def maxpool3x3s2(x):
 class ResidualPlan:
     """Pre-activation bottleneck of model/hourglass.py:87-119 as 3 (4 with a skip conv) MFMA launches:
     conv1 = [bn1+relu prologue] 1x1 [bn2 folded, relu] ; conv2 = 3x3 [bn3 folded, relu] ; conv3 = 1x1 + residual.
-    In split mode the two hidden tensors (consumed only by the next convolution) are written in the split operand format, their
-    width padded to a multiple of 32 with identically-zero channels; the block input stays fp32 (it is also the residual)."""
+    Always on the f32-input MFMA, also under KPF_GEMM=split: its operands are unbounded ReLU outputs and residual sums (no pack-time
+    bound on |activation| exists), which the f16 split format would saturate at 65504."""
 
     def __init__(self, sd, p, device):
         cin = sd[p + ".conv1.conv.weight"].shape[1]
         cout = sd[p + ".conv3.conv.weight"].shape[0]
-        h = cout // 2
         self.cin, self.cout = cin, cout
-        self.split = GEMM_MODE == "split"
-        hp = (h + 31) // 32 * 32 if self.split else h
         self.c1 = PackedConv(sd[p + ".conv1.conv.weight"], sd[p + ".conv1.conv.bias"], device,
-                             fold_bn=bn_scale_shift(sd, p + ".bn2"), prologue=bn_scale_shift(sd, p + ".bn1"), n_pad=hp)
+                             fold_bn=bn_scale_shift(sd, p + ".bn2"), prologue=bn_scale_shift(sd, p + ".bn1"))
         self.c2 = PackedConv(sd[p + ".conv2.conv.weight"], sd[p + ".conv2.conv.bias"], device, pad=1,
-                             fold_bn=bn_scale_shift(sd, p + ".bn3"), cin_pad=hp, n_pad=hp)
-        self.c3 = PackedConv(sd[p + ".conv3.conv.weight"], sd[p + ".conv3.conv.bias"], device, cin_pad=hp)
+                             fold_bn=bn_scale_shift(sd, p + ".bn3"))
+        self.c3 = PackedConv(sd[p + ".conv3.conv.weight"], sd[p + ".conv3.conv.bias"], device)
         self.skip = None
         if cin != cout:
             self.skip = PackedConv(sd[p + ".skip_layer.conv.weight"], sd[p + ".skip_layer.conv.bias"], device)
 
     def __call__(self, x, out=None):
-        h = conv(self.c1, x, flags=L.KPF_ACT_RELU, out_split=self.split)
-        h = conv(self.c2, h, flags=L.KPF_ACT_RELU, out_split=self.split)
+        h = conv(self.c1, x, flags=L.KPF_ACT_RELU)
+        h = conv(self.c2, h, flags=L.KPF_ACT_RELU)
         if out is None:
             out = Act.empty(x.B, x.H, x.W, self.cout, x.buf.device)
         if self.skip is not None:
@@ -365,6 +380,7 @@ class ConvNeXtBlockPlan:
         ln_bound = math.sqrt(c) * float(self.lnw.abs().max()) + float(self.lnb.abs().max())
         h_bound = self.pw1.row_l1() * ln_bound + float(self.pw1.b.abs().max())
         self.split_ok = c % 32 == 0 and ln_bound < F16_MAX and h_bound < F16_MAX
+        self.pw1.split_allowed = self.pw2.split_allowed = self.split_ok  # operands proven inside the f16 range
         self.fused_split = GEMM_MODE == "split" and self.split_ok and bool(L.load().kpf_convnext_mlp_split_supported(c))
         if self.fused_split:
             self.w1s, self.us1 = self.pw1.split_weights()
@@ -627,7 +643,7 @@ class FusionBlockPlan:
         A1, A2 = f32(B * N, 240), f32(B * N, 128)
         L.check(lib.kpf_point_assemble_f32(_ptr(ctx["feat_d"].buf), _ptr(ctx["feat_rgb"].buf), _ptr(ctx["img_offset"]), _ptr(ctx["pcl"]),
                                            _ptr(joint_xyz), _ptr(ctx["closeness"]), _ptr(ctx["index"]), _ptr(A1), _ptr(A2), B, N, P,
-                                           ctx["kernel"], st), "kpf_point_assemble_f32")
+                                           0.8, st), "kpf_point_assemble_f32")  # pcl_joint2offset(joint_xyz, pcl, 0.8): model/model.py:294 hard-codes the radius
         rows = lambda t, c, ld=None: Act(t.view(-1), 1, 1, t.numel() // (ld or c), c, ld or c)
         X = conv(self.e_point, rows(A1, 240), flags=L.KPF_ACT_RELU)
         conv(self.e_rgb, rows(A2, 128), out=X, res=X, flags=L.KPF_RELU_AFTER_RES)
@@ -677,6 +693,7 @@ class ModelPlan:
         self.backbone_rgb = UNetPlan(sd, "backbone_rgb", net, device)
         self.blocks = [FusionBlockPlan(sd, "block%d" % i, device) for i in (1, 2)]
         self._graphs = {}  # (B, S, N, img_size, flip, kernel) -> (hipGraph, static inputs, static outputs)
+        self._graph_lock = __import__("threading").Lock()  # a graph's static buffers are shared by every caller of this plan
         self._side = None  # second HIP stream: the RGB backbone runs beside the depth backbone
         self.serial_streams = False  # profiling aid: issue both backbones on one stream so per-kernel timings are not shared
 
@@ -706,27 +723,29 @@ class ModelPlan:
         Inputs are copied into the graph's static buffers; the returned tensors are the graph's own and are overwritten by the
         next replay (the caller copies what it keeps)."""
         key = ("bb", tuple(img.shape), tuple(img_rgb.shape))
-        ent = self._graphs.get(key)
-        if ent is None:
-            static = [img.detach().float().contiguous().clone(), img_rgb.detach().float().contiguous().clone()]
-            cur = torch.cuda.current_stream(self.device)
-            warm = torch.cuda.Stream(device=self.device)
-            warm.wait_stream(cur)
-            with torch.cuda.stream(warm):  # eager warm-up: one-time weight packing / attribute lookups must not happen under capture
-                self.backbones(*static)
-                self.backbones(*static)
-            cur.wait_stream(warm)
-            torch.cuda.synchronize(self.device)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = self.backbones(*static)
-            ent = (graph, static, out)
-            self._graphs[key] = ent
-        graph, static, out = ent
-        static[0].copy_(img)
-        static[1].copy_(img_rgb)
-        graph.replay()
-        return out
+        with self._graph_lock:  # capture, copy-in and replay are one critical section per plan (static buffers are shared; the returned
+                                # tensors stay the graph's own: one consumer at a time, see the docstring)
+            ent = self._graphs.get(key)
+            if ent is None:
+                static = [img.detach().float().contiguous().clone(), img_rgb.detach().float().contiguous().clone()]
+                cur = torch.cuda.current_stream(self.device)
+                warm = torch.cuda.Stream(device=self.device)
+                warm.wait_stream(cur)
+                with torch.cuda.stream(warm):  # eager warm-up: one-time weight packing / attribute lookups must not happen under capture
+                    self.backbones(*static)
+                    self.backbones(*static)
+                cur.wait_stream(warm)
+                torch.cuda.synchronize(self.device)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    out = self.backbones(*static)
+                ent = (graph, static, out)
+                self._graphs[key] = ent
+            graph, static, out = ent
+            static[0].copy_(img)
+            static[1].copy_(img_rgb)
+            graph.replay()
+            return out
 
     def forward_graphed(self, img_rgb, img, pcl, center, M, cube, cam, kernel, img_size, flip):
         """Same as forward(), replayed from a captured hipGraph: at small batch the ~300 launches of one forward are host-bound
@@ -734,27 +753,28 @@ class ModelPlan:
         copied into the graph's static buffers, outputs are returned as copies."""
         ins = [t.detach().to(device=self.device, dtype=torch.float32).contiguous() for t in (img_rgb, img, pcl, center, M, cube, cam)]
         key = tuple(tuple(t.shape) for t in ins) + (kernel, img_size, flip)
-        ent = self._graphs.get(key)
-        if ent is None:
-            static = [t.clone() for t in ins]
-            cur = torch.cuda.current_stream(self.device)
-            warm = torch.cuda.Stream(device=self.device)
-            warm.wait_stream(cur)
-            with torch.cuda.stream(warm):  # eager warm-up: one-time attribute / symbol lookups must not happen under capture
-                self.forward(*static, kernel, img_size, flip)
-                self.forward(*static, kernel, img_size, flip)
-            cur.wait_stream(warm)
-            torch.cuda.synchronize(self.device)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                res, sws, _ = self.forward(*static, kernel, img_size, flip)
-            ent = (graph, static, res, sws)
-            self._graphs[key] = ent
-        graph, static, res, sws = ent
-        for d, t in zip(static, ins):
-            d.copy_(t)
-        graph.replay()
-        return [t.clone() for t in res], [t.clone() for t in sws], None
+        with self._graph_lock:  # capture, copy-in, replay and copy-out are one critical section per plan (static buffers are shared)
+            ent = self._graphs.get(key)
+            if ent is None:
+                static = [t.clone() for t in ins]
+                cur = torch.cuda.current_stream(self.device)
+                warm = torch.cuda.Stream(device=self.device)
+                warm.wait_stream(cur)
+                with torch.cuda.stream(warm):  # eager warm-up: one-time attribute / symbol lookups must not happen under capture
+                    self.forward(*static, kernel, img_size, flip)
+                    self.forward(*static, kernel, img_size, flip)
+                cur.wait_stream(warm)
+                torch.cuda.synchronize(self.device)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    res, sws, _ = self.forward(*static, kernel, img_size, flip)
+                ent = (graph, static, res, sws)
+                self._graphs[key] = ent
+            graph, static, res, sws = ent
+            for d, t in zip(static, ins):
+                d.copy_(t)
+            graph.replay()
+            return [t.clone() for t in res], [t.clone() for t in sws], None
 
     def forward(self, img_rgb, img, pcl, center, M, cube, cam, kernel, img_size, flip, want_aux=False):
         lib = L.load()
@@ -769,6 +789,7 @@ class ModelPlan:
         st = _stream()
         f32 = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
         joint_uvd, joint_xyz = f32(B, J, 3), f32(B, J, 3)
+        M = crop_inverse(M)  # from here on M holds M^-1 (the only form the geometry kernels use)
         L.check(lib.kpf_offset2joint_f32(_ptr(img_offset), _ptr(img), _ptr(center), _ptr(M), _ptr(cube), _ptr(cam), _ptr(joint_uvd),
                                          _ptr(joint_xyz), B, S, F, kernel, img_size, flip, st), "kpf_offset2joint_f32")
         closeness, img_xyz = f32(B, N, 4), f32(B, P, 3)

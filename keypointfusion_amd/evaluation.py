@@ -30,6 +30,8 @@ def decode_stage(result, stage_type, img, center, M, cube, cam_para, kernel=0.8,
     uvd = torch.empty(B, 21, 3, device=result.device, dtype=torch.float32)
     xyz = torch.empty_like(uvd)
     p = lambda t: C.c_void_p(t.data_ptr())
+    from .engine import crop_inverse
+    M = crop_inverse(M)  # kpf_offset2joint_f32 takes M^-1 in the reference's torch.linalg.inv rounding order
     L.check(lib.kpf_offset2joint_f32(p(result), p(img), p(center), p(M), p(cube), p(cam_para), p(uvd), p(xyz), B, img.shape[-1], F,
                                      float(kernel), int(img_size), int(flip), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
             "kpf_offset2joint_f32")

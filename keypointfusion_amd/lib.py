@@ -38,6 +38,7 @@ _SIGS = {
     "kpf_nchw_to_nhwc_f32": [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P],
     "kpf_nhwc_to_nchw_f32": [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P],
     "kpf_maxpool3x3s2_f32": [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_inv3x3_f32": [_P, _P, C.c_int, C.c_int, _P],
     "kpf_offset2joint_f32": [_P] * 8 + [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, _P],
     "kpf_img2pcl_top4_f32": [_P] * 9 + [C.c_int] * 6 + [_P],
     "kpf_point_assemble_f32": [_P] * 9 + [C.c_int, C.c_int, C.c_int, C.c_float, _P],

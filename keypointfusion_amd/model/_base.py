@@ -50,7 +50,15 @@ class SpecModule(nn.Module):
             _attach(self, name, val, is_buffer)
 
     def _state_version(self):
-        return sum(t._version for t in list(self.parameters()) + list(self.buffers()))
+        ts = self.__dict__.get("_tensor_list")  # the module tree is walked once; later calls only read the version counters
+        if ts is None:
+            ts = self.__dict__["_tensor_list"] = list(self.parameters()) + list(self.buffers())
+        return sum(t._version for t in ts)
+
+    def _apply(self, fn, *a, **k):
+        self.__dict__["_tensor_list"] = None
+        self._plans.clear()
+        return super()._apply(fn, *a, **k)
 
     def _plan(self, device, build):
         """Kernel-layout weights for `device` (build(sd, device)), rebuilt when any parameter changed."""
@@ -66,6 +74,7 @@ class SpecModule(nn.Module):
 
     def _load_from_state_dict(self, *a, **k):
         self._plans.clear()
+        self.__dict__["_tensor_list"] = None
         return super()._load_from_state_dict(*a, **k)
 
     @staticmethod

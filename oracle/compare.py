@@ -1,29 +1,33 @@
-"""TEST INFRASTRUCTURE: tolerant comparison of a device forward with the oracle across fp32 near-tie index flips."""
+"""TEST INFRASTRUCTURE: comparison of a device forward with the oracle.  Top-4 pixel indices must be exact; ball-query sets are computed
+around network outputs (joints that differ from the oracle's in the last bits), so a point sitting on a radius may flip."""
 import torch
 
 from . import kpf_oracle as O
 
 
 def oracle_with_device_decisions(sd, b, ctx, kernel=0.8):
-    """Runs the oracle; where the device's integer decisions (top-4 pixel indices, ball-query indices) differ from the
-    oracle's own, checks that every difference sits at an fp32 near-tie of the oracle's distances and re-runs the oracle
-    with the device's decisions injected.  Returns (ref_results, ref_spatial, aux, report)."""
+    """Runs the oracle.  Asserts that the device's top-4 pixel indices equal the oracle's.  Where the device's ball-query sets differ
+    from the oracle's own, checks that every difference sits on the radius boundary and re-runs the oracle with the device's
+    decisions injected.  Returns (ref_results, ref_spatial, aux, report)."""
     aux = {}
     args = (sd, b["img_rgb"], b["img"], b["pcl"], b["center"], b["M"], b["cube"], b["cam_para"], kernel)
     ref, rsw = O.kpfusion_forward(*args, aux=aux)
     B = b["img"].shape[0]
     report = {"top4_flips": 0, "ball_flips": 0}
     overrides = {}
+    # top-4 pixel indices depend on raw inputs only (points, depth image, crop matrix): they must EQUAL the oracle's — the device
+    # computes M^-1 and the pixel positions in the reference's rounding order (keypointfusion_amd/inv3x3.py).  The only admissible
+    # difference is the order of two pixels at exactly the same fp32 distance.
     idx_dev = ctx["index"].cpu().long()
     mism = (idx_dev != aux["pcl_index"]).any(-1)
     if bool(mism.any()):
         img_xyz = O.img_xyz_grid(aux["img_down"], b["center"], b["M"], b["cube"], b["cam_para"])
         dist = torch.sum(torch.pow(b["pcl"].unsqueeze(2) - img_xyz.unsqueeze(1), 2), dim=-1)
-        top5 = torch.topk(dist, 5, largest=False)[0]
-        gap = ((top5[..., 1:] - top5[..., :-1]) / (top5[..., 1:] + 1e-12)).min(-1)[0]
-        assert not bool((mism & (gap > 1e-4)).any()), "top-4 indices differ away from fp32 near-ties"
-        report["top4_flips"] = int(mism.sum())
-        overrides["top4"] = (ctx["closeness"].cpu(), idx_dev)
+        same_dist = torch.equal(torch.gather(dist, 2, idx_dev), torch.gather(dist, 2, aux["pcl_index"]))
+        assert same_dist, "top-4 indices differ from the oracle's on %d points (identical raw inputs: must be bit-exact)" % int(mism.sum())
+        report["top4_flips"] = 0
+        report["top4_exact_tie_reorders"] = int(mism.sum())
+        overrides["top4"] = (ctx["closeness"].cpu(), idx_dev)  # same distances, so only the gather order of equal-weight pixels changes
     ball = {}
     for bi in (1, 2):
         dev_idx = [ctx["aux"][bi - 1]["ball_idx"][r].cpu().long().view(B, 21, 64) for r in range(3)]

@@ -98,7 +98,7 @@ def test_c_index_ops_equal_reference_fixture(net):
 def test_hip_index_kernels_equal_c_oracle():
     """kpf_img2pcl_top4_f32 and kpf_ball_group_f32 against the C checker on identical inputs (bit-exact index tensors)."""
     from keypointfusion_amd import lib as L
-    from keypointfusion_amd.engine import _ptr, _stream
+    from keypointfusion_amd.engine import _ptr, _stream, crop_inverse
     assert torch.cuda.is_available()
     lib = L.load()
     dev = torch.device("cuda:0")
@@ -108,7 +108,7 @@ def test_hip_index_kernels_equal_c_oracle():
     clo = torch.empty(B, N, 4, device=dev)
     idx = torch.empty(B, N, 4, device=dev, dtype=torch.int32)
     ixyz = torch.empty(B, 1024, 3, device=dev)
-    L.check(lib.kpf_img2pcl_top4_f32(_ptr(g["pcl"]), _ptr(g["img"]), _ptr(g["center"]), _ptr(g["M"]), _ptr(g["cube"]), _ptr(g["cam_para"]), _ptr(clo),
+    L.check(lib.kpf_img2pcl_top4_f32(_ptr(g["pcl"]), _ptr(g["img"]), _ptr(g["center"]), _ptr(crop_inverse(g["M"])), _ptr(g["cube"]), _ptr(g["cam_para"]), _ptr(clo),
                                      _ptr(idx), _ptr(ixyz), B, N, 128, 32, 128, 1, _stream()), "top4")
     torch.cuda.synchronize()
     cidx, _ = c_top4(b["pcl"].numpy(), ixyz.cpu().numpy())  # same pixel positions -> the search itself must agree exactly
