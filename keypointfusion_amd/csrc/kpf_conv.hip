@@ -77,9 +77,12 @@ typedef __attribute__((address_space(1))) void gbl_void_t;
 
 __device__ __attribute__((aligned(16))) float kpf_zero16[4] = {0.f, 0.f, 0.f, 0.f};  // source of every padding / out-of-range chunk
 
-#ifdef KPF_DBG_TIME
-__device__ unsigned long long kpf_dbg_t[4 * 8192];
-#define KPF_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) kpf_dbg_t[4 * blockIdx.x + (i)] = __builtin_readcyclecounter(); } while (0)
+#ifdef KPF_DBG_TIME  // tuning build (make dbg): per-workgroup stamps read back by tools/f32_tile_time.py
+// [0..3] shader-clock stamps (start, main loop start, main loop end, end), [4],[5] 100-MHz real-time stamps at start / end, [6] HW_ID
+__device__ unsigned long long kpf_dbg_t[8 * 8192];
+#define KPF_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) { kpf_dbg_t[8 * blockIdx.x + (i)] = __builtin_readcyclecounter(); \
+    if ((i) == 0) { kpf_dbg_t[8 * blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime(); kpf_dbg_t[8 * blockIdx.x + 6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32); } \
+    if ((i) == 3) kpf_dbg_t[8 * blockIdx.x + 5] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define KPF_STAMP(i)
 #endif
@@ -108,8 +111,9 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
   constexpr int RPP = 8 * NW;               // rows staged per pass: every wave moves 8 rows x 128 B = one 1-KiB DMA
   constexpr int AP = (BM + RPP - 1) / RPP;  // A staging passes
   constexpr int BP = (BN + RPP - 1) / RPP;  // B staging passes
-  constexpr int BMR = NS > 2 ? AP * RPP : BM;  // staged rows (whole passes in ring mode; the extra rows are never read)
-  constexpr int BNR = NS > 2 ? BP * RPP : BN;
+  constexpr bool WHOLE = NS > 2 || ARITH == ARITH_F32;  // every wave issues every staging pass (no exec-masked DMA branches)
+  constexpr int BMR = WHOLE ? AP * RPP : BM;  // staged rows (whole passes; the extra rows are never read)
+  constexpr int BNR = WHOLE ? BP * RPP : BN;
   constexpr int TILE = (BMR + BNR) * BK;
   constexpr int CNT = AP + BP;  // DMA instructions per wave per K tile in ring mode
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
@@ -120,7 +124,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: LDS-DMA destinations (M0) become scalar arithmetic
   const int wm = wave % WM, wn = wave / WM;
   KPF_STAMP(0);
 
@@ -181,7 +185,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
     if (IS1X1) {
 #pragma unroll
       for (int p = 0; p < AP; ++p)
-        if (NS > 2 || RPP * p + 8 * wave < BM)  // wave-uniform
+        if (WHOLE || RPP * p + 8 * wave < BM)  // wave-uniform
           __builtin_amdgcn_global_load_lds((gbl_void_t*)(pa[p] + kt * BK), (lds_void_t*)(As + (RPP * p + 8 * wave) * BK), 16, 0, 0);
     } else {
       const int k = kt * BK + kc;
@@ -192,7 +196,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
       const int kx = tap - ky * a.KW;
 #pragma unroll
       for (int p = 0; p < AP; ++p) {
-        if (NS > 2 || RPP * p + 8 * wave < BM) {  // wave-uniform
+        if (WHOLE || RPP * p + 8 * wave < BM) {  // wave-uniform
           const int iy = riy[p] + ky, ix = rix[p] + kx;
           const bool v = kvalid && rbase[p] >= 0 && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
           const long off = ((long)rbase[p] + (long)iy * a.IW + ix) * a.in_ld + a.in_coff + c;
@@ -203,7 +207,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
     }
 #pragma unroll
     for (int p = 0; p < BP; ++p)
-      if (NS > 2 || RPP * p + 8 * wave < BN)  // wave-uniform: BN is a multiple of 8
+      if (WHOLE || RPP * p + 8 * wave < BN)  // wave-uniform: BN is a multiple of 8
         __builtin_amdgcn_global_load_lds((gbl_void_t*)(pb[p] + kt * BK), (lds_void_t*)(Bs + (RPP * p + 8 * wave) * BK), 16, 0, 0);
   };
 
@@ -240,6 +244,81 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
   // register set while the MFMAs of tile t run from the first, so a wave's LDS latency sits under its own MFMAs (the plain loop
   // relies on the SIMD's other wave for that); DMA runs NS-1 tiles ahead.
   KPF_STAMP(1);
+  if constexpr (ARITH == ARITH_F32 && NS == 2) {
+    // f32-input MFMA main loop, software-pipelined so that the matrix pipe never waits for anything but the barrier's skew.  An
+    // f32 MFMA occupies the pipe for 32 cycles and the wave's issue port for a few, so everything else a K tile needs — 16 fragment
+    // reads, the next tile's DMA issue (8-16 instructions with their address arithmetic), the barrier — is placed BETWEEN MFMAs of the
+    // same wave instead of in front of them (the plain loop exposed ~500 cycles of DMA issue + ~150 of LDS latency per 4096-cycle K
+    // tile whenever the CU's two workgroups ran in lockstep).  Per K tile kt (two 16-deep steps s = 0, 1 of four k4 sub-steps e):
+    //     read frags(kt, s=1) | 64 MFMAs (kt, s=0) | 48 MFMAs (kt, s=1, e=0..2) | vmcnt(0), barrier: tile kt+1 has landed and every wave
+    //     has read tile kt | read frags(kt+1, s=0) | issue the DMA of tile kt+2 into tile kt's buffer, interleaved with the last 16
+    //     MFMAs (kt, s=1, e=3), which also cover the LDS latency of the reads just issued.
+    auto read_frags = [&](int buf, int s16, f32x4(&xf)[TM], f32x4(&wf)[TN]) {
+      const float* xrow = lds + buf * TILE + (wm * TM * 16 + fr) * BK;
+      const float* wrow = lds + buf * TILE + BMR * BK + (wn * TN * 16 + fr) * BK;
+      const int sc = (((4 * s16 + fg) ^ rsw) << 2);  // 16-deep k-step s16: this lane's k group is logical chunk 4*s16 + fg
+#pragma unroll
+      for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const f32x4*>(xrow + j * 16 * BK + sc);
+#pragma unroll
+      for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const f32x4*>(wrow + i * 16 * BK + sc);
+    };
+    auto prologue = [&](int kt, int s16, f32x4(&xf)[TM]) {  // eval-BatchNorm + ReLU on the activation operand (k = channel for 1x1)
+      if constexpr (HAS_PRO) {
+        const int kk = kt * BK + 16 * s16 + 4 * fg;
+        const f32x4 sp = *reinterpret_cast<const f32x4*>(pro_s + kk);
+        const f32x4 tp = *reinterpret_cast<const f32x4*>(pro_t + kk);
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xf[j][e] = fmaxf(fmaf(xf[j][e], sp[e], tp[e]), 0.f);
+      }
+    };
+    auto mma = [&](int e, const f32x4(&xf)[TM], const f32x4(&wf)[TN]) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][e], xf[j][e], acc[i][j], 0, 0, 0);
+    };
+    f32x4 xa[TM], wa[TN], xb[TM], wb[TN];
+    read_frags(0, 0, xa, wa);
+    if (nk > 1) stage(1, 1);
+    for (int kt = 0; kt + 1 < nk; ++kt) {  // (branch-free body: the last tile is peeled, so fragment registers carry over the back edge as they are)
+      const int cur = kt & 1;
+      read_frags(cur, 1, xb, wb);
+      prologue(kt, 0, xa);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mma(e, xa, wa);
+      prologue(kt, 1, xb);
+#pragma unroll
+      for (int e = 0; e < 3; ++e) mma(e, xb, wb);
+      __builtin_amdgcn_sched_barrier(0);  // (MFMAs are register-only: without this the scheduler sinks them below the barrier)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wave's part of tile kt+1 (issued a whole K tile ago) has landed
+      __builtin_amdgcn_s_barrier();                     // ... and everyone's; every wave's reads of tile kt retired with its MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(cur ^ 1, 0, xa, wa);
+      stage(kt + 2 < nk ? kt + 2 : nk - 1, cur);  // (clamped: the last tiles re-stage a tile nobody reads rather than branch)
+      mma(3, xb, wb);
+      // issue order of this tail: the fragment reads first, then the DMAs spread evenly between the 16 MFMAs (the CU's address unit takes
+      // ~16 cycles per 1-KiB DMA and is shared by the workgroup's waves: bunched up they would stall the wave's issue port)
+      __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+      for (int q = 0; q < AP + BP; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, (TM * TN) / (AP + BP) > 0 ? (TM * TN) / (AP + BP) : 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+    }
+    {
+      const int kt = nk - 1, cur = kt & 1;
+      read_frags(cur, 1, xb, wb);
+      prologue(kt, 0, xa);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mma(e, xa, wa);
+      prologue(kt, 1, xb);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mma(e, xb, wb);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may be in flight into this workgroup's LDS when it ends
+  } else
   if constexpr (NS > 2 && ARITH == ARITH_SPLIT && !HAS_PRO) {
     const int ch = ((fg ^ rsw) << 2), cl = (((4 + fg) ^ rsw) << 2);
     auto read_frags = [&](int buf, f16x8(&xh)[TM], f16x8(&xl)[TM], f16x8(&wh)[TN], f16x8(&wl)[TN]) {
@@ -547,7 +626,8 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void igemm_split_occ_kernel(const 
 template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO, int EPI, int ARITH, int NS>
 int launch_one(const ConvArgs& a, hipStream_t st) {
   constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN, RPP = 8 * WM * WN;
-  constexpr int BMR = NS > 2 ? (BM + RPP - 1) / RPP * RPP : BM, BNR = NS > 2 ? (BN + RPP - 1) / RPP * RPP : BN;
+  constexpr bool WHOLE = NS > 2 || ARITH == ARITH_F32;
+  constexpr int BMR = WHOLE ? (BM + RPP - 1) / RPP * RPP : BM, BNR = WHOLE ? (BN + RPP - 1) / RPP * RPP : BN;
   const size_t lds = (size_t)(NS * (BMR + BNR) * BK + (HAS_PRO ? 2 * a.Kp : 0)) * sizeof(float);
   void (*kern)(const ConvArgs);
   if constexpr (ARITH == ARITH_F32)
@@ -610,7 +690,7 @@ int launch_cfg(ConvArgs& a, bool is1x1, hipStream_t st) {
 // do not add throughput), so a launch lasts about ceil(blocks / 256 CUs) rounds of one tile's work: 384 blocks cost as much as
 // 512.  `pen` is the measured relative cost per FLOP of each tile shape (smaller tiles amortise staging and epilogue worse).
 // (A persistent-workgroup variant with cross-tile prefetch was measured 5-14 % slower than letting the dispatcher balance.)
-constexpr int KPF_NUM_TILE_CFGS = 17;  // cases of the switch in kpf_conv2d_f32 (9-12: LDS-ring variants of 8, 0, 1, 2 for split operands)
+constexpr int KPF_NUM_TILE_CFGS = 18;  // cases of the switch in kpf_conv2d_f32 (9-12: LDS-ring variants of 8, 0, 1, 2 for split operands)
 struct Cfg {
   int bm, bn;
   double pen;
@@ -693,6 +773,14 @@ extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const flo
     const double c = cfg_cost(kCfgs[i], a.M, a.N);
     if (c < bc) { bc = c; best = i; }
   }
+  // f32 arithmetic, 128 x 192 tiles (80 KB of LDS: exactly two workgroups per CU): taken when they make the tile count a whole number of
+  // 512-workgroup rounds and the cost model's choice does not (stage-4 pwconv1: 4096 x 3072 -> 512 tiles instead of 768 of 128 x 128,
+  // which the dispatcher spreads 2..4 per CU)
+  if (!(fl & (KPF_IN_SPLIT | KPF_W_SPLIT)) && !pro_scale && a.M % 128 == 0 && a.N % 192 == 0) {
+    const long b192 = (long)(a.M / 128) * (a.N / 192);
+    const long bb = ((a.M + kCfgs[best].bm - 1) / kCfgs[best].bm) * ((a.N + kCfgs[best].bn - 1) / kCfgs[best].bn);
+    if (b192 % 512 == 0 && bb % 512 != 0 && bb > 256) best = 17;
+  }
   // split arithmetic without a residual epilogue: the single-stage, 4-waves-per-SIMD variant of the 128 x 128 tile is 4-10 % faster
   // than the double-buffered 128 x 128 / 256 x 128 ones (its residual epilogue would spill at 128 registers, so those keep two stages)
   if ((fl & (KPF_IN_SPLIT | KPF_W_SPLIT)) && !(fl & KPF_RES_ADD) && !pro_scale && (best == 0 || best == 8)) best = 13;
@@ -709,6 +797,9 @@ extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const flo
     KPF_REQUIRE(d->tile_cfg <= KPF_NUM_TILE_CFGS, "kpf_conv2d_f32: tile_cfg %d out of range", d->tile_cfg);
     best = d->tile_cfg - 1;
   }
+#ifdef KPF_FAST_BUILD  // tuning aid: one tile shape only (asm inspection / quick A-B builds), never shipped
+  return launch_cfg<4, 4, 2, 2>(a, is1x1, st);
+#else
   switch (best) {
     case 0: return launch_cfg<4, 4, 2, 2>(a, is1x1, st);   // 128 x 128
     case 1: return launch_cfg<4, 3, 2, 2>(a, is1x1, st);   // 128 x 96
@@ -726,13 +817,19 @@ extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const flo
     case 14: return launch_cfg<4, 3, 2, 2, 1>(a, is1x1, st);  // split: 128 x 96, one LDS stage (28 KB)
     case 15: return launch_cfg<2, 4, 4, 1, 1>(a, is1x1, st);  // split: 128 x 64, one LDS stage (24 KB)
     case 16: return launch_cfg<2, 2, 2, 2, 1>(a, is1x1, st);  // split: 64 x 64, one LDS stage (16 KB)
+    case 17: return launch_cfg<4, 6, 2, 2>(a, is1x1, st);     // 128 x 192 (f32: 80 KB of LDS, two workgroups fill a CU's 160 KB)
     default: return launch_cfg<2, 1, 1, 4>(a, is1x1, st);  // 32 x 64
   }
+#endif
 }
 
 #ifdef KPF_DBG_TIME
 extern "C" int kpf_dbg_read(unsigned long long* host, int n) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(kpf_dbg_t), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+extern "C" int kpf_dbg_clear(void) {
+  static unsigned long long z[8 * 8192];
+  return hipMemcpyToSymbol(HIP_SYMBOL(kpf_dbg_t), z, sizeof(z)) == hipSuccess ? 0 : -1;
 }
 #endif
 

@@ -243,7 +243,7 @@ def _autotune(lib, d, x, w, pc, gamma, res, optr, flags):
     update, so repeated runs do not accumulate) and return the fastest as index + 1."""
     ncfg = int(lib.kpf_conv_num_tile_cfgs())
     split = bool(flags & (L.KPF_IN_SPLIT | L.KPF_W_SPLIT))
-    cands = [i for i in range(ncfg) if split or i < 9]  # 9-12 are LDS-ring variants for split operands
+    cands = [i for i in range(ncfg) if split or i < 9 or i == 17]  # 9-16 are LDS-ring / single-stage variants for split operands
     out_t = optr
     if res is not None and res.buf.data_ptr() == optr.data_ptr():
         out_t = torch.empty_like(optr)
