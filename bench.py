@@ -38,10 +38,18 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense f16/bf16 matrix peak
 PEAK_SPLIT_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3  # 3 f16 MFMAs per algorithmic fp32 product (hi*hi + hi*lo + lo*hi)
-NET = "KPFusion-convnext-tiny"
+# workload -> (net, crop size, default batch per GPU, storage precision, "backbones" | "full", BASELINE.json config it measures)
+WORKLOADS = {
+    "backbones256": ("KPFusion-convnext-tiny", 256, 64, "f32", "backbones", "configs[1]"),
+    "full128": ("KPFusion-convnext-tiny", 128, 64, "f32", "full", "full model at configs[1]'s batch"),
+    "full128_bf16": ("KPFusion-convnext-tiny", 128, 32, "bf16", "full", "configs[2]"),
+    "cnb512_f16": ("KPFusion-convnext-base", 512, 64, "f16", "backbones", "configs[4]"),
+}
 
 
 def kernel_peak(name):
+    if "h16" in name:
+        return PEAK_F16_MFMA_TFLOPS
     return PEAK_SPLIT_TFLOPS if "split" in name else PEAK_F32_MFMA_TFLOPS
 
 
@@ -60,9 +68,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--workload", default="backbones256", choices=["backbones256", "full128"])
+    ap.add_argument("--batch", type=int, default=0, help="batch per GPU (default: the workload's)")
+    ap.add_argument("--workload", default="backbones256", choices=sorted(WORKLOADS),
+                    help="backbones256 = BASELINE configs[1] (the headline); full128_bf16 = configs[2]; cnb512_f16 = configs[4]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial-streams", action="store_true", help="issue both backbones on one stream (per-kernel profiling: rocprofv3 "
                     "durations of overlapped kernels are otherwise shared-GPU durations)")
@@ -97,13 +105,18 @@ def main():
     L.load()
     E.GEMM_MODE = args.gemm
 
-    if args.workload == "full128":
-        args.size = 128
-    B, S = args.batch, args.size
+    NET, S, B0, precision, kind, cfg_name = WORKLOADS[args.workload]
+    B = args.batch or B0
+    backbones_only = kind == "backbones"
+    if precision != "f32":
+        args.no_split_record = True  # (the split record belongs to the fp32 workloads)
+        if args.workload == "cnb512_f16":
+            args.cpu_sample = min(args.cpu_sample, 1)  # 373 GFLOP per image on the CPU
     model = KPFusion(NET, "", 21, "dexycb", "")
     sd = {k: torch.from_numpy(v) for k, v in synthetic_state_dict(NET, 0).items()}
     model.load_state_dict(sd, strict=True)
     model = model.to(dev).eval()
+    model.precision = precision
     hb = synthetic_batch(B, S, seed=1 + rank)
     batch = {k: torch.from_numpy(v).to(dev) for k, v in hb.items()}
 
@@ -114,7 +127,7 @@ def main():
 
     def step():
         with torch.no_grad():
-            if args.workload == "backbones256":
+            if backbones_only:
                 if graph_on[0]:
                     model._plan(dev).backbones_graphed(batch["img"], batch["img_rgb"])
                 else:
@@ -190,7 +203,8 @@ def main():
                 "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc,
                 "peak_note": ("algorithmic-FLOP roof of the 3 x f16 split scheme = dense f16 MFMA peak 2500 / 3; executed MFMA rate = %.0f TFLOP/s"
                               % (3 * ach)) if "split" in dom else "dense f32-input MFMA peak (v_mfma_f32_16x16x4_f32)",
-                "algo_bytes_per_launch": round(nb / n), "launches_per_step": n, "avg_launch_ms": round(t_ms / n, 4),
+                "algo_bytes_per_launch": round(nb / n), "algo_hbm_gbps": round(nb / (t_ms * 1e-3) / 1e9, 1), "hbm_frac_of_8000": round(nb / (t_ms * 1e-3) / 8e12, 4),
+                "launches_per_step": n, "avg_launch_ms": round(t_ms / n, 4),
                 "gflop_per_step": round(fl / 1e9, 1), "kernel_ms_per_step": round(t_ms, 3),
                 "all_mfma_kernels": {k: {"launches": v[0], "ms": round(v[1], 3), "tflops": round(v[2] / v[1] / 1e9, 2),
                                          "frac": round(v[2] / v[1] / 1e9 / kernel_peak(k), 4)} for k, v in per.items()},
@@ -253,34 +267,37 @@ def main():
         threads = torch.get_num_threads()
 
         def cpu_step():
-            if args.workload == "backbones256":
+            if backbones_only:
                 O.backbones_forward(sd, cb["img_rgb"], cb["img"])
             else:
                 O.kpfusion_forward(sd, cb["img_rgb"], cb["img"], cb["pcl"], cb["center"], cb["M"], cb["cube"], cb["cam_para"], 0.8)
 
         cpu_step()  # warm-up (oneDNN primitive caches)
         times = []
-        for _ in range(5):
+        for _ in range(3 if args.workload == "cnb512_f16" else 5):
             t1 = time.perf_counter()
             cpu_step()
             times.append(time.perf_counter() - t1)
         med = statistics.median(times)
         cpu = {"value": round(n / med, 2), "unit": "img/s", "cores": threads, "kind": "port",
-               "sample": "median of 5 passes over %d images of the same synthetic batch, oracle/kpf_oracle.py (torch-CPU fp32), %d threads; "
+               "sample": "median of 3-5 passes over %d images of the same synthetic batch, oracle/kpf_oracle.py (torch-CPU fp32), %d threads; "
                          "min/max %.2f/%.2f img/s" % (n, threads, n / max(times), n / min(times)),
                "host": "%s, nproc %d" % (cpu_model(), os.cpu_count() or 0)}
 
     if rank == 0:
         line = {
-            "metric": "RGB-D img/sec fwd (B=64, 256x256)" if args.workload == "backbones256" else "RGB-D img/sec fwd full model (B=%d, 128x128)" % B,
+            "metric": "RGB-D img/sec fwd (B=64, 256x256)" if args.workload == "backbones256" else
+                      "RGB-D img/sec fwd %s (B=%d, %dx%d, %s)" % ("backbones" if backbones_only else "full model", B, S, S, precision),
             "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.gemm == "f32" else "f32 storage, ConvNeXt-block GEMM products as 3 x f16 split MFMA (not IEEE fp32)", "data": "synthetic",
-            "config": {"workload": "KPFusion-convnext-tiny, depth+RGB UNet backbones forward, B=%d/GPU %dx%d fp32 (BASELINE configs[1])" % (B, S, S)
-                       if args.workload == "backbones256" else "KPFusion-convnext-tiny full forward, B=%d/GPU 128x128 fp32" % B,
+            "dtype": (precision + " storage, f32 accumulate") if precision != "f32" else
+                     ("f32" if args.gemm == "f32" else "f32 storage, ConvNeXt-block GEMM products as 3 x f16 split MFMA (not IEEE fp32)"), "data": "synthetic",
+            "config": {"workload": "%s, %s forward, B=%d/GPU %dx%d %s (BASELINE %s)" % (
+                           NET, "depth+RGB UNet backbones" if backbones_only else "full model (backbones + fusion head)", B, S, S, precision, cfg_name),
                        "batch_per_gpu": B, "global_batch": B * world, "input": "%dx%d" % (S, S), "parallelism": "dp%d (batch shards, no collective)" % world,
-                       "gemm_arithmetic": "IEEE fp32: v_mfma_f32_16x16x4_f32 (fp32 operands, fp32 accumulate) for every GEMM" if args.gemm == "f32"
-                       else "KPF_GEMM=split"},
+                       "gemm_arithmetic": ("16-bit (%s) operands and activations in HBM, fp32 accumulate on v_mfma_f32_16x16x32_%s; fusion head fp32" % (precision, precision))
+                       if precision != "f32" else ("IEEE fp32: v_mfma_f32_16x16x4_f32 (fp32 operands, fp32 accumulate) for every GEMM" if args.gemm == "f32"
+                                                   else "KPF_GEMM=split")},
             "roofline": roofline, "cpu_baseline": cpu, "split_f16x3": split_rec, "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 3),
             "launch": launch_mode,
         }

@@ -24,6 +24,12 @@ extern "C" {
 #define KPF_EINVAL (-1)  /* bad shape / alignment / flag combination */
 #define KPF_ELAUNCH (-2) /* HIP launch error */
 
+/* Activation / weight storage types of the reduced-precision path (entry points ending in _h16): fp32 accumulation and fp32
+ * elementwise arithmetic everywhere, 16-bit storage in HBM, v_mfma_f32_16x16x32_{bf16,f16} for the GEMMs. */
+#define KPF_DT_F32 0
+#define KPF_DT_BF16 1
+#define KPF_DT_F16 2
+
 /* kpf_conv_desc.flags */
 #define KPF_ACT_RELU 1u        /* y = relu(acc + bias)                                    */
 #define KPF_ACT_GELU 2u        /* y = gelu_erf(acc + bias)        (convNeXT/convnext.py:33) */
@@ -230,6 +236,31 @@ int kpf_upnearest2x_add_f32(const float* low, const float* up1, float* out, int 
 int kpf_mano_forward_f32(const float* pose6d, int ld6, const float* betas, int ldb, const float* shapedirs_t,
                          const float* posedirs_t, const float* v_template, const float* j_regressor, const float* skin_weights,
                          const float* hands_mean, float* verts, float* joints, float* rotmat, float* pose_aa, int B, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Reduced-precision path (BASELINE configs[2] bf16, configs[4] fp16): same operators on 16-bit NHWC activations.  `dtype` is
+ * KPF_DT_BF16 or KPF_DT_F16; LayerNorm / bias / layer-scale parameters and the depthwise taps stay fp32.
+ * ------------------------------------------------------------------------------------------------------------ */
+
+/* kpf_conv2d_f32 on 16-bit operands: in / w / res / out are `dtype` (w rows [N][Kp], Kp % 64 == 0, Cin % 8 == 0), bias / gamma /
+ * prologue scale+shift fp32, fp32 accumulation on v_mfma_f32_16x16x32_{bf16,f16}.  With KPF_OUT_NCHW the output is fp32 NCHW (the
+ * heads).  The split-operand flags do not apply. */
+int kpf_conv2d_h16(const kpf_conv_desc* desc, const void* in, const void* w, const float* bias, const float* pro_scale,
+                   const float* pro_shift, const float* gamma, const void* res, void* out, int dtype, void* stream);
+
+/* kpf_dwconv7_ln_f32 with 16-bit activations in and out (fp32 taps, fp32 accumulation and LayerNorm statistics). */
+int kpf_dwconv7_ln_h16(const void* x, const float* w_dw, const float* b_dw, const float* ln_w, const float* ln_b, void* y, int B,
+                       int H, int W, int C, float eps, int dtype, void* stream);
+
+/* LayerNorm over C: x_dtype -> y_dtype, either fp32 -> 16-bit (behind the fp32 stem convolution) or 16-bit -> the same type. */
+int kpf_layernorm_h16(const void* x, int x_dtype, const float* w, const float* b, void* y, int y_dtype, long rows, int C, float eps,
+                      void* stream);
+
+/* kpf_upsample2x_f32 on 16-bit activations (dst_ld / dst_coff in elements). */
+int kpf_upsample2x_h16(const void* src, void* dst, int B, int H, int W, int C, int dst_ld, int dst_coff, int dtype, void* stream);
+
+/* 16-bit NHWC channel slice -> dense fp32 [rows][C] (feature maps handed to the fp32 fusion head / module boundary). */
+int kpf_cast_h16_f32(const void* src, int dtype, float* dst, long rows, int C, int src_ld, int src_coff, void* stream);
 
 int kpf_conv_num_tile_cfgs(void);
 

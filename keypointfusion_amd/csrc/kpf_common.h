@@ -7,6 +7,8 @@
 #include "../../include/kpf.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 void kpf_set_error(const char* fmt, ...);
 
@@ -60,8 +62,31 @@ __device__ __forceinline__ float wave_max(float v) {
 // C*4 bytes as C/32 blocks of [32 x f16 hi | 32 x f16 lo] with x ~= hi + lo (22 significant bits; |x| is clamped to the
 // f16 range).  Producers (GEMM / LayerNorm epilogues) write it, the GEMM's LDS-DMA staging reads it byte-for-byte like fp32.
 // ---------------------------------------------------------------------------------------------------------------
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// ---------------------------------------------------------------------------------------------------------------
+// 16-bit activation storage (KPF_DT_BF16 / KPF_DT_F16 of include/kpf.h): kernels compute in fp32 and are templated on the storage
+// type of their activation pointers; 4 consecutive channels are one 16-byte (fp32) or 8-byte (16-bit) access.
+// ---------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x4 kpf_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 kpf_ld4(const f16_t* p) {
+  const f16x4 h = *reinterpret_cast<const f16x4*>(p);
+  return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+__device__ __forceinline__ f32x4 kpf_ld4(const bf16_t* p) {  // bf16 -> fp32 is a 16-bit shift
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+}
+__device__ __forceinline__ void kpf_st4(float* p, const f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void kpf_st4(f16_t* p, const f32x4 v) {
+  *reinterpret_cast<f16x4*>(p) = f16x4{(f16_t)v[0], (f16_t)v[1], (f16_t)v[2], (f16_t)v[3]};
+}
+__device__ __forceinline__ void kpf_st4(bf16_t* p, const f32x4 v) {  // round to nearest even (v_cvt_pk_bf16_f32)
+  *reinterpret_cast<bf16x4*>(p) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+}
 
 __device__ __forceinline__ void kpf_store_split4(float* row, int c, const f32x4 v) {  // c % 4 == 0
   f16x4 h, l;

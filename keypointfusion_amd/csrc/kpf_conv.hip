@@ -28,6 +28,7 @@
 //    GELU, residual) with an unguarded float4 fast path for interior tiles.
 #include "kpf_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -96,7 +97,11 @@ constexpr int BK = 32;  // K-tile depth: 8 chunks of 16 B per staged row
 // chain, at 3/16 of the f32-input MFMA's cycles.
 // ARITH = 2: weights split as above, activations staged as fp32 and split in registers after the LDS read (after the BatchNorm+ReLU
 // operand prologue when there is one): any fp32 tensor can feed the f16 matrix cores without a format pass over HBM.
-enum { ARITH_F32 = 0, ARITH_SPLIT = 1, ARITH_SPLIT_W = 2 };
+// ARITH = 3 / 4: 16-bit storage (bf16 / f16) of both operands, of the residual and of the output (include/kpf.h, *_h16): rows hold 64
+// elements per 128-byte K tile, so the staging is byte-identical again; the two 32-deep k-steps of a tile are one
+// v_mfma_f32_16x16x32_{bf16,f16} each.  All staging-side fields of ConvArgs (Cin, in_ld, in_coff, K, Kp) then count 4-byte words
+// (= 2 elements), all output-side fields elements.
+enum { ARITH_F32 = 0, ARITH_SPLIT = 1, ARITH_SPLIT_W = 2, ARITH_BF16 = 3, ARITH_F16 = 4 };
 
 // NS = LDS stages.  NS = 2: the DMA of tile k+1 flies under the MFMAs of tile k, one __syncthreads per K tile (its fence drains the
 // DMA).  NS > 2 (split arithmetic, where a K tile's MFMAs are shorter than the DMA latency): a ring with NS-1 tiles in flight — a
@@ -104,7 +109,9 @@ enum { ARITH_F32 = 0, ARITH_SPLIT = 1, ARITH_SPLIT_W = 2 };
 // instructions per tile (the staged row count is rounded up to whole passes) so that one immediate count fits all waves.
 template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO, int EPI, int ARITH, int NS>
 __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
-  constexpr bool SPLIT = ARITH != ARITH_F32;
+  constexpr bool SPLIT = ARITH == ARITH_SPLIT || ARITH == ARITH_SPLIT_W;
+  constexpr bool H16 = ARITH == ARITH_BF16 || ARITH == ARITH_F16;
+  using TH = typename std::conditional<ARITH == ARITH_BF16, bf16_t, f16_t>::type;  // 16-bit storage type (H16 only)
   constexpr int BM = 16 * TM * WM;
   constexpr int BN = 16 * TN * WN;
   constexpr int NW = WM * WN;               // waves per workgroup (4 or 8)
@@ -223,8 +230,9 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
   const int fg = lane >> 4;  // k group 0..3
   const int rsw = (fr >> 1) & 7;  // this lane's row swizzle
 
+  constexpr int EPW = H16 ? 2 : 1;  // elements per staged 4-byte word
   float* pro_s = lds + NS * TILE;  // [Kp] scale, then [Kp] shift (zero beyond Cin: padded k contributes relu(0*x+0) = 0)
-  float* pro_t = pro_s + a.Kp;
+  float* pro_t = pro_s + a.Kp * EPW;
   if (NS <= 2) {
     stage(0, 0);
   } else {
@@ -233,9 +241,9 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
       if (t < nk) stage(t, t);
   }
   if (HAS_PRO) {
-    for (int i = tid; i < a.Kp; i += 64 * NW) {
-      pro_s[i] = i < a.Cin ? a.ps[i] : 0.f;
-      pro_t[i] = i < a.Cin ? a.pt[i] : 0.f;
+    for (int i = tid; i < a.Kp * EPW; i += 64 * NW) {
+      pro_s[i] = i < a.Cin * EPW ? a.ps[i] : 0.f;
+      pro_t[i] = i < a.Cin * EPW ? a.pt[i] : 0.f;
     }
   }
   if (NS <= 2) __syncthreads();  // (a pending global_load_lds is an outstanding vmcnt: the barrier's fence drains it)
@@ -407,7 +415,50 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
     }
     const float* xrow = lds + cur * TILE + (wm * TM * 16 + fr) * BK;
     const float* wrow = lds + cur * TILE + BMR * BK + (wn * TN * 16 + fr) * BK;
-    if (SPLIT) {
+    if constexpr (H16) {
+      // 16-bit rows: the tile holds k = 0..63; lane group fg multiplies k = 8fg..8fg+7 (logical chunk fg) in the first 32-deep step and
+      // k = 32+8fg.. (chunk 4+fg) in the second
+      const int c0 = ((fg ^ rsw) << 2), c1 = (((4 + fg) ^ rsw) << 2);
+      f16x8 x0[TM], x1[TM], w0[TN], w1[TN];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        x0[j] = *reinterpret_cast<const f16x8*>(xrow + j * 16 * BK + c0);
+        x1[j] = *reinterpret_cast<const f16x8*>(xrow + j * 16 * BK + c1);
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        w0[i] = *reinterpret_cast<const f16x8*>(wrow + i * 16 * BK + c0);
+        w1[i] = *reinterpret_cast<const f16x8*>(wrow + i * 16 * BK + c1);
+      }
+      if constexpr (HAS_PRO) {  // eval-BatchNorm + ReLU on the activation operand, in fp32, rounded back to the storage type
+        const int k0 = kt * 2 * BK + 8 * fg, k1 = k0 + 32;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          const auto t0 = __builtin_bit_cast(typename std::conditional<ARITH == ARITH_BF16, bf16x8, f16x8>::type, x0[j]);
+          const auto t1 = __builtin_bit_cast(typename std::conditional<ARITH == ARITH_BF16, bf16x8, f16x8>::type, x1[j]);
+          typename std::conditional<ARITH == ARITH_BF16, bf16x8, f16x8>::type r0, r1;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            r0[e] = (TH)fmaxf(fmaf((float)t0[e], pro_s[k0 + e], pro_t[k0 + e]), 0.f);
+            r1[e] = (TH)fmaxf(fmaf((float)t1[e], pro_s[k1 + e], pro_t[k1 + e]), 0.f);
+          }
+          x0[j] = __builtin_bit_cast(f16x8, r0);
+          x1[j] = __builtin_bit_cast(f16x8, r1);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          if constexpr (ARITH == ARITH_BF16) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w0[i]), __builtin_bit_cast(bf16x8, x0[j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w1[i]), __builtin_bit_cast(bf16x8, x1[j]), acc[i][j], 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[i], x0[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[i], x1[j], acc[i][j], 0, 0, 0);
+          }
+        }
+    } else if (SPLIT) {
       // lane group fg multiplies k = 8fg .. 8fg+7 of the tile: hi halves are logical chunk fg, lo halves chunk 4 + fg of the row
       const int ch = ((fg ^ rsw) << 2), cl = (((4 + fg) ^ rsw) << 2);
       f16x8 xh[TM], xl[TM], wh[TN], wl[TN];
@@ -520,8 +571,11 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
       for (int j = 0; j < TM; ++j) {
         const long m = m0 + (wm * TM + j) * 16 + fr;
 #pragma unroll
-        for (int i = 0; i < TN; ++i)
-          rvv[j][i] = *reinterpret_cast<const f32x4*>(a.res + m * a.res_ld + a.res_coff + n0 + (wn * TN + i) * 16 + fg * 4);
+        for (int i = 0; i < TN; ++i) {
+          const long o = m * a.res_ld + a.res_coff + n0 + (wn * TN + i) * 16 + fg * 4;
+          if constexpr (H16) rvv[j][i] = kpf_ld4(reinterpret_cast<const TH*>(a.res) + o);
+          else rvv[j][i] = *reinterpret_cast<const f32x4*>(a.res + o);
+        }
       }
     }
 #pragma unroll
@@ -559,7 +613,9 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.01f * v[e]);
           }
         }
-        if (fl & KPF_OUT_SPLIT)
+        if constexpr (H16)
+          kpf_st4(reinterpret_cast<TH*>(a.out) + m * a.out_ld + a.out_coff + n, v);
+        else if (fl & KPF_OUT_SPLIT)
           kpf_store_split4(a.out + m * a.out_ld + a.out_coff, n, v);
         else
           STORE4(a.out + m * a.out_ld + a.out_coff + n, v);
@@ -587,11 +643,14 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
         if (EPI == EPI_LIN && (fl & KPF_ACT_LEAKY)) y = fmaxf(y, 0.01f * y);
         if (EPI == EPI_RES) {
           if (fl & KPF_RES_GAMMA) y *= a.gamma[n + e];
-          y += a.res[(long)m * a.res_ld + a.res_coff + n + e];
+          if constexpr (H16) y += (float)reinterpret_cast<const TH*>(a.res)[(long)m * a.res_ld + a.res_coff + n + e];
+          else y += a.res[(long)m * a.res_ld + a.res_coff + n + e];
           if (fl & KPF_RELU_AFTER_RES) y = fmaxf(y, 0.f);
         }
         if (fl & KPF_OUT_NCHW) {
-          a.out[((long)b * a.N + n + e) * a.ohow + pix] = y;
+          a.out[((long)b * a.N + n + e) * a.ohow + pix] = y;  // (fp32 also on the 16-bit path: the heads' output)
+        } else if constexpr (H16) {
+          reinterpret_cast<TH*>(a.out)[(long)m * a.out_ld + a.out_coff + n + e] = (TH)y;
         } else if (fl & KPF_OUT_SPLIT) {
           const float yc = __builtin_amdgcn_fmed3f(y, -65504.0f, 65504.0f);
           const _Float16 h = (_Float16)yc;
@@ -623,15 +682,30 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void igemm_split_occ_kernel(const 
   igemm_body<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH, 1>(a);
 }
 
+// 16-bit storage (bf16 / f16) GEMMs: igemm_h16_kernel (two LDS stages) / igemm_h16_occ_kernel (one stage, 4 waves per SIMD)
+template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO, int EPI, int ARITH, int NS>
+__global__ __launch_bounds__(64 * WM * WN) void igemm_h16_kernel(const ConvArgs a) {
+  igemm_body<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH, NS>(a);
+}
+template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO, int EPI, int ARITH>
+__global__ __launch_bounds__(64 * WM * WN, 4) void igemm_h16_occ_kernel(const ConvArgs a) {
+  igemm_body<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH, 1>(a);
+}
+
 template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO, int EPI, int ARITH, int NS>
 int launch_one(const ConvArgs& a, hipStream_t st) {
   constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN, RPP = 8 * WM * WN;
   constexpr bool WHOLE = NS > 2 || ARITH == ARITH_F32;
   constexpr int BMR = WHOLE ? (BM + RPP - 1) / RPP * RPP : BM, BNR = WHOLE ? (BN + RPP - 1) / RPP * RPP : BN;
-  const size_t lds = (size_t)(NS * (BMR + BNR) * BK + (HAS_PRO ? 2 * a.Kp : 0)) * sizeof(float);
+  constexpr bool H16 = ARITH == ARITH_BF16 || ARITH == ARITH_F16;
+  const size_t lds = (size_t)(NS * (BMR + BNR) * BK + (HAS_PRO ? 2 * a.Kp * (H16 ? 2 : 1) : 0)) * sizeof(float);
   void (*kern)(const ConvArgs);
   if constexpr (ARITH == ARITH_F32)
     kern = igemm_f32_kernel<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, NS>;
+  else if constexpr (H16 && NS == 1)
+    kern = igemm_h16_occ_kernel<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH>;
+  else if constexpr (H16)
+    kern = igemm_h16_kernel<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH, NS>;
   else if constexpr (NS == 1)
     kern = igemm_split_occ_kernel<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH>;
   else
@@ -658,7 +732,7 @@ template <int TM, int TN, int WM, int WN, int ARITH, int NS>
 int launch_arith(ConvArgs& a, bool is1x1, hipStream_t st) {
   const bool res = a.flags & KPF_RES_ADD, gelu = a.flags & KPF_ACT_GELU;
   if (a.ps) {
-    if (!is1x1 || res || gelu || ARITH == ARITH_SPLIT) {
+    if (!is1x1 || res || gelu || ARITH == ARITH_SPLIT || (NS == 1 && (ARITH == ARITH_BF16 || ARITH == ARITH_F16))) {
       kpf_set_error("kpf_conv2d_f32: the operand prologue is only supported for 1x1 stride-1 convolutions with Cin %% 32 == 0, fp32 activations and a linear/ReLU epilogue");
       return KPF_EINVAL;
     }
@@ -705,8 +779,120 @@ double cfg_cost(const Cfg& c, long M, long N) {
   return (double)rounds * c.bm * c.bn * c.pen;
 }
 
+#ifdef KPF_CONV_H16
+// ---- 16-bit storage path (kpf_conv16.hip compiles this file with KPF_CONV_H16) ----
+template <int TM, int TN, int WM, int WN, int ARITH, int NS>
+int launch_arith_h16(ConvArgs& a, bool fast1x1, bool pointwise, hipStream_t st) {
+  const bool res = a.flags & KPF_RES_ADD, gelu = a.flags & KPF_ACT_GELU;
+  if (a.ps) {
+    if (!pointwise || res || gelu) {
+      kpf_set_error("kpf_conv2d_h16: the operand prologue is only supported for 1x1 stride-1 convolutions with a linear/ReLU epilogue");
+      return KPF_EINVAL;
+    }
+    return fast1x1 ? launch_one<TM, TN, WM, WN, true, true, EPI_LIN, ARITH, 2>(a, st) : launch_one<TM, TN, WM, WN, false, true, EPI_LIN, ARITH, 2>(a, st);
+  }
+  if (gelu) {
+    if (!pointwise || res) {
+      kpf_set_error("kpf_conv2d_h16: GELU is only supported on 1x1 convolutions without residual");
+      return KPF_EINVAL;
+    }
+    return fast1x1 ? launch_one<TM, TN, WM, WN, true, false, EPI_GELU, ARITH, NS>(a, st) : launch_one<TM, TN, WM, WN, false, false, EPI_GELU, ARITH, NS>(a, st);
+  }
+  if (fast1x1) return res ? launch_one<TM, TN, WM, WN, true, false, EPI_RES, ARITH, NS>(a, st) : launch_one<TM, TN, WM, WN, true, false, EPI_LIN, ARITH, NS>(a, st);
+  return res ? launch_one<TM, TN, WM, WN, false, false, EPI_RES, ARITH, NS>(a, st) : launch_one<TM, TN, WM, WN, false, false, EPI_LIN, ARITH, NS>(a, st);
+}
+
+template <int TM, int TN, int WM, int WN, int NS>
+int launch_cfg_h16(ConvArgs& a, bool fast1x1, bool pointwise, int dtype, hipStream_t st) {
+  constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
+  const int tilesM = (a.M + BM - 1) / BM;
+  a.tilesN = (a.N + BN - 1) / BN;
+  a.nblk = tilesM * a.tilesN;
+  return dtype == KPF_DT_BF16 ? launch_arith_h16<TM, TN, WM, WN, ARITH_BF16, NS>(a, fast1x1, pointwise, st)
+                              : launch_arith_h16<TM, TN, WM, WN, ARITH_F16, NS>(a, fast1x1, pointwise, st);
+}
+
+#endif
+
 }  // namespace
 
+#ifdef KPF_CONV_H16
+extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void* w, const float* bias, const float* pro_scale,
+                              const float* pro_shift, const float* gamma, const void* res, void* out, int dtype, void* stream) {
+  KPF_REQUIRE(d && in && w && out, "kpf_conv2d_h16: null pointer");
+  KPF_REQUIRE(dtype == KPF_DT_BF16 || dtype == KPF_DT_F16, "kpf_conv2d_h16: dtype must be KPF_DT_BF16 or KPF_DT_F16");
+  KPF_REQUIRE(d->B > 0 && d->OH > 0 && d->OW > 0 && d->N > 0 && d->Cin > 0, "kpf_conv2d_h16: empty shape");
+  KPF_REQUIRE(d->Cin % 8 == 0 && d->in_ld % 8 == 0 && d->in_coff % 8 == 0,
+              "kpf_conv2d_h16: Cin/in_ld/in_coff must be multiples of 8 elements (got %d/%d/%d)", d->Cin, d->in_ld, d->in_coff);
+  KPF_REQUIRE(d->Kp % 64 == 0 && d->Kp >= d->KH * d->KW * d->Cin, "kpf_conv2d_h16: Kp=%d must be a multiple of 64 and >= K=%d", d->Kp,
+              d->KH * d->KW * d->Cin);
+  KPF_REQUIRE(kpf_aligned16(in) && kpf_aligned16(w) && kpf_aligned16(out), "kpf_conv2d_h16: pointers must be 16-byte aligned");
+  const unsigned fl = d->flags;
+  KPF_REQUIRE(!(fl & (KPF_IN_SPLIT | KPF_W_SPLIT | KPF_OUT_SPLIT)), "kpf_conv2d_h16: the split-operand flags belong to kpf_conv2d_f32");
+  if (!(fl & KPF_OUT_NCHW))
+    KPF_REQUIRE(d->out_coff >= 0 && d->out_coff + d->N <= d->out_ld, "kpf_conv2d_h16: bad output slice ld=%d coff=%d N=%d", d->out_ld,
+                d->out_coff, d->N);
+  if (fl & KPF_RES_ADD)
+    KPF_REQUIRE(res && kpf_aligned16(res) && d->res_coff >= 0 && d->res_coff + d->N <= d->res_ld, "kpf_conv2d_h16: bad residual");
+  if (fl & KPF_RES_GAMMA) KPF_REQUIRE(gamma && (fl & KPF_RES_ADD), "kpf_conv2d_h16: RES_GAMMA needs gamma and RES_ADD");
+  KPF_REQUIRE((pro_scale == nullptr) == (pro_shift == nullptr), "kpf_conv2d_h16: prologue needs both scale and shift");
+  KPF_REQUIRE(((fl & KPF_ACT_RELU) != 0) + ((fl & KPF_ACT_GELU) != 0) + ((fl & KPF_ACT_LEAKY) != 0) <= 1, "kpf_conv2d_h16: one activation only");
+  KPF_REQUIRE(!((fl & KPF_RES_ADD) && (fl & (KPF_ACT_RELU | KPF_ACT_GELU | KPF_ACT_LEAKY))), "kpf_conv2d_h16: activation before a residual add is not supported");
+  KPF_REQUIRE(!(fl & KPF_RELU_AFTER_RES) || (fl & KPF_RES_ADD), "kpf_conv2d_h16: RELU_AFTER_RES needs RES_ADD");
+  KPF_REQUIRE((long)d->B * d->OH * d->OW < (1l << 31) && (long)d->B * d->IH * d->IW < (1l << 31), "kpf_conv2d_h16: too many pixels");
+
+  ConvArgs a;  // staging-side fields in 4-byte words (2 elements), output-side fields in elements (see ARITH_BF16 above)
+  a.in = static_cast<const float*>(in); a.w = static_cast<const float*>(w); a.bias = bias; a.ps = pro_scale; a.pt = pro_shift; a.gamma = gamma;
+  a.res = static_cast<const float*>(res); a.out = static_cast<float*>(out);
+  a.M = d->B * d->OH * d->OW; a.N = d->N; a.K = d->KH * d->KW * d->Cin / 2; a.Kp = d->Kp / 2;
+  a.IH = d->IH; a.IW = d->IW; a.Cin = d->Cin / 2; a.in_ld = d->in_ld / 2; a.in_coff = d->in_coff / 2;
+  a.OH = d->OH; a.OW = d->OW; a.ohow = d->OH * d->OW; a.KH = d->KH; a.KW = d->KW;
+  a.sh = d->sh; a.sw = d->sw; a.ph = d->ph; a.pw = d->pw;
+  a.out_ld = d->out_ld; a.out_coff = d->out_coff; a.res_ld = d->res_ld; a.res_coff = d->res_coff;
+  {
+    static const float* zero_of_dev[KPF_MAX_DEVICES] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= KPF_MAX_DEVICES) dev = 0;
+    if (!zero_of_dev[dev]) {
+      void* p = nullptr;
+      if (hipGetSymbolAddress(&p, HIP_SYMBOL(kpf_zero16)) != hipSuccess || !p) {
+        kpf_set_error("kpf_conv2d_h16: cannot resolve the zero page");
+        return KPF_ELAUNCH;
+      }
+      zero_of_dev[dev] = static_cast<const float*>(p);
+    }
+    a.zero = zero_of_dev[dev];
+  }
+  a.flags = fl; a.tilesN = 0; a.nblk = 0; a.w_unscale = 1.0f;
+  a.vec = (d->out_ld % 4 == 0 && d->out_coff % 4 == 0 && (!(fl & KPF_RES_ADD) || (d->res_ld % 4 == 0 && d->res_coff % 4 == 0))) ? 1 : 0;
+  const bool pointwise = d->KH == 1 && d->KW == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0 && d->IH == d->OH && d->IW == d->OW;
+  const bool fast1x1 = pointwise && d->Cin % 64 == 0 && d->Kp == d->Cin;  // whole 64-element K tiles, no K mask
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+
+  // Tile choice: the 16-bit GEMMs of this model are bound by HBM traffic and staging, not by the matrix pipe, so tiles are picked
+  // for whole-CU rounds like the fp32 ones but from a smaller set; non-residual layers take the single-stage, 4-waves-per-SIMD
+  // variants (more workgroups per CU hide each other's DMA / barrier latencies)
+  int best = 0;
+  double bc = 1e30;
+  static const int allowed[] = {0, 1, 2, 5, 6, 7, 8};
+  for (int i : allowed) {
+    const double c = cfg_cost(kCfgs[i], a.M, a.N);
+    if (c < bc) { bc = c; best = i; }
+  }
+  const bool occ = !(fl & KPF_RES_ADD) && !pro_scale;
+  static const int forced = []() { const char* e = getenv("KPF_FORCE_CFG16"); return e ? atoi(e) : -1; }();  // tuning aid only
+  if (forced >= 0) best = forced;
+  switch (best) {
+    case 0: return occ ? launch_cfg_h16<4, 4, 2, 2, 1>(a, fast1x1, pointwise, dtype, st) : launch_cfg_h16<4, 4, 2, 2, 2>(a, fast1x1, pointwise, dtype, st);
+    case 1: return launch_cfg_h16<4, 3, 2, 2, 2>(a, fast1x1, pointwise, dtype, st);  // 128 x 96
+    case 2: return launch_cfg_h16<2, 4, 4, 1, 2>(a, fast1x1, pointwise, dtype, st);  // 128 x 64
+    case 5: return launch_cfg_h16<2, 4, 2, 2, 2>(a, fast1x1, pointwise, dtype, st);  // 64 x 128
+    case 6: return occ ? launch_cfg_h16<2, 2, 2, 2, 1>(a, fast1x1, pointwise, dtype, st) : launch_cfg_h16<2, 2, 2, 2, 2>(a, fast1x1, pointwise, dtype, st);
+    case 8: return launch_cfg_h16<4, 4, 4, 2, 2>(a, fast1x1, pointwise, dtype, st);  // 256 x 128
+    default: return launch_cfg_h16<2, 1, 1, 4, 2>(a, fast1x1, pointwise, dtype, st);  // 32 x 64
+  }
+}
+#else
 extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const float* w, const float* bias,
                               const float* pro_scale, const float* pro_shift, const float* gamma, const float* res,
                               float* out, void* stream) {
@@ -834,3 +1020,4 @@ extern "C" int kpf_dbg_clear(void) {
 #endif
 
 extern "C" int kpf_conv_num_tile_cfgs(void) { return KPF_NUM_TILE_CFGS; }
+#endif  // KPF_CONV_H16

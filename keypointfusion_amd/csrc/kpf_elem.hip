@@ -14,9 +14,10 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int DW_T = 8;
 
-__global__ __launch_bounds__(512) void dwconv7_ln_kernel(const float* __restrict__ x, const float* __restrict__ wdw,
+template <typename TA>
+__global__ __launch_bounds__(512) void dwconv7_ln_kernel(const TA* __restrict__ x, const float* __restrict__ wdw,
                                                          const float* __restrict__ bdw, const float* __restrict__ lw,
-                                                         const float* __restrict__ lb, float* __restrict__ y, int H, int W,
+                                                         const float* __restrict__ lb, TA* __restrict__ y, int H, int W,
                                                          int C, int S, int xblocks, float eps) {
   extern __shared__ __attribute__((aligned(16))) float tile[];  // [8*S][C]
   const int C4 = C >> 2;
@@ -35,18 +36,18 @@ __global__ __launch_bounds__(512) void dwconv7_ln_kernel(const float* __restrict
     const f32x4 bias = *reinterpret_cast<const f32x4*>(bdw + 4 * q);
 #pragma unroll
     for (int t = 0; t < DW_T; ++t) acc[t] = bias;
-    const float* xb_ptr = x + (long)b * H * W * C + 4 * q;
+    const TA* xb_ptr = x + (long)b * H * W * C + 4 * q;
 #pragma unroll 1
     for (int ky = 0; ky < 7; ++ky) {
       const int iy = oy + ky - 3;
       if ((unsigned)iy >= (unsigned)H) continue;
       f32x4 in[DW_T + 6];
-      const float* row = xb_ptr + (long)iy * W * C;
+      const TA* row = xb_ptr + (long)iy * W * C;
 #pragma unroll
       for (int i = 0; i < DW_T + 6; ++i) {
         const int ix = x0 + i - 3;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if ((unsigned)ix < (unsigned)W) v = *reinterpret_cast<const f32x4*>(row + (long)ix * C);
+        if ((unsigned)ix < (unsigned)W) v = kpf_ld4(row + (long)ix * C);
         in[i] = v;
       }
 #pragma unroll
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(512) void dwconv7_ln_kernel(const float* __restrict
       }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(sq) * invC + eps);
-    float* dst = y + (((long)b * H + oy) * W + px) * C;
+    TA* dst = y + (((long)b * H + oy) * W + px) * C;
     for (int i = lane; i < C4; i += 64) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * i);
       const f32x4 g = *reinterpret_cast<const f32x4*>(lw + 4 * i);
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(512) void dwconv7_ln_kernel(const float* __restrict
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * rstd * g[e] + be[e];
-      *reinterpret_cast<f32x4*>(dst + 4 * i) = o;
+      kpf_st4(dst + 4 * i, o);
     }
   }
 }
@@ -114,9 +115,9 @@ __device__ __forceinline__ unsigned xcd_contiguous_block_id() {
 // the CU's address unit only carries activations: 7 activation loads per output float4 instead of 12.25 + 6.1 weight loads.
 // No LDS output tile -> occupancy is set by registers only.
 // ---------------------------------------------------------------------------------------------------------------
-template <bool WLDS, int PX>
-__global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ x, const float* __restrict__ wdw,
-                                                      const float* __restrict__ bdw, float* __restrict__ y, int B, int H, int W, int C,
+template <typename TA, bool WLDS, int PX>
+__global__ __launch_bounds__(256) void dwconv7_kernel(const TA* __restrict__ x, const float* __restrict__ wdw,
+                                                      const float* __restrict__ bdw, TA* __restrict__ y, int B, int H, int W, int C,
                                                       int xstrips, int ypairs) {
   extern __shared__ __attribute__((aligned(16))) float wl[];  // [49][C] when WLDS
   const int C4 = C >> 2;
@@ -143,18 +144,18 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ 
     acc0[t] = bias;
     acc1[t] = bias;
   }
-  const float* xb = x + (long)b * H * W * C + 4 * q;
+  const TA* xb = x + (long)b * H * W * C + 4 * q;
 #pragma unroll 1
   for (int ir = 0; ir < 8; ++ir) {  // input rows y0-3 .. y0+4
     const int iy = y0 + ir - 3;
     if ((unsigned)iy >= (unsigned)H) continue;
     f32x4 in[PX + 6];
-    const float* row = xb + (long)iy * W * C;
+    const TA* row = xb + (long)iy * W * C;
 #pragma unroll
     for (int i = 0; i < PX + 6; ++i) {
       const int ix = x0 + i - 3;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if ((unsigned)ix < (unsigned)W) v = *reinterpret_cast<const f32x4*>(row + (long)ix * C);
+      if ((unsigned)ix < (unsigned)W) v = kpf_ld4(row + (long)ix * C);
       in[i] = v;
     }
     if (ir < 7) {  // output row y0: tap row ky = ir
@@ -178,12 +179,12 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ 
       }
     }
   }
-  float* yb = y + (long)b * H * W * C + 4 * q;
+  TA* yb = y + (long)b * H * W * C + 4 * q;
 #pragma unroll
   for (int t = 0; t < PX; ++t) {
     if (x0 + t < W) {
-      *reinterpret_cast<f32x4*>(yb + ((long)y0 * W + x0 + t) * C) = acc0[t];
-      if (y0 + 1 < H) *reinterpret_cast<f32x4*>(yb + ((long)(y0 + 1) * W + x0 + t) * C) = acc1[t];
+      kpf_st4(yb + ((long)y0 * W + x0 + t) * C, acc0[t]);
+      if (y0 + 1 < H) kpf_st4(yb + ((long)(y0 + 1) * W + x0 + t) * C, acc1[t]);
     }
   }
 }
@@ -194,10 +195,10 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ 
 // variance are xor-shuffle reductions inside the group — no LDS tile (which capped the occupancy of the first fused kernel),
 // and the activation is read once and written once (the unfused pair reads and writes it twice).
 // ---------------------------------------------------------------------------------------------------------------
-template <int LG, bool SPLIT>
-__global__ __launch_bounds__(256) void dwconv7_ln_wave_kernel(const float* __restrict__ x, const float* __restrict__ wdw,
+template <typename TA, int LG, bool SPLIT>
+__global__ __launch_bounds__(256) void dwconv7_ln_wave_kernel(const TA* __restrict__ x, const float* __restrict__ wdw,
                                                               const float* __restrict__ bdw, const float* __restrict__ lw,
-                                                              const float* __restrict__ lb, float* __restrict__ y, int B, int H, int W,
+                                                              const float* __restrict__ lb, TA* __restrict__ y, int B, int H, int W,
                                                               int C, int xstrips, int ypairs, float eps) {
   extern __shared__ __attribute__((aligned(16))) float wl[];  // [49][C]
   const int C4 = C >> 2;
@@ -222,19 +223,19 @@ __global__ __launch_bounds__(256) void dwconv7_ln_wave_kernel(const float* __res
     acc0[t] = bias;
     acc1[t] = bias;
   }
-  const float* xb = x + (long)b * H * W * C + 4 * qc;
+  const TA* xb = x + (long)b * H * W * C + 4 * qc;
   if (live) {
 #pragma unroll 1
     for (int ir = 0; ir < 8; ++ir) {  // input rows y0-3 .. y0+4
       const int iy = y0 + ir - 3;
       if ((unsigned)iy >= (unsigned)H) continue;
       f32x4 in[14];
-      const float* row = xb + (long)iy * W * C;
+      const TA* row = xb + (long)iy * W * C;
 #pragma unroll
       for (int i = 0; i < 14; ++i) {
         const int ix = x0 + i - 3;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if ((unsigned)ix < (unsigned)W) v = *reinterpret_cast<const f32x4*>(row + (long)ix * C);
+        if ((unsigned)ix < (unsigned)W) v = kpf_ld4(row + (long)ix * C);
         in[i] = v;
       }
       if (ir < 7) {
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256) void dwconv7_ln_wave_kernel(const float* __res
   const float invC = 1.0f / (float)C;
   const f32x4 g = *reinterpret_cast<const f32x4*>(lw + 4 * qc);
   const f32x4 be = *reinterpret_cast<const f32x4*>(lb + 4 * qc);
-  float* yb = y + (long)b * H * W * C + 4 * qc;
+  TA* yb = y + (long)b * H * W * C + 4 * qc;
 #pragma unroll
   for (int rr = 0; rr < 2; ++rr) {
 #pragma unroll
@@ -288,10 +289,10 @@ __global__ __launch_bounds__(256) void dwconv7_ln_wave_kernel(const float* __res
         f32x4 o4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o4[e] = (v[e] - mean) * rstd * g[e] + be[e];
-        if (SPLIT)
+        if constexpr (SPLIT)
           kpf_store_split4(yb - 4 * qc + ((long)(y0 + rr) * W + x0 + t) * C, 4 * qc, o4);
         else
-          *reinterpret_cast<f32x4*>(yb + ((long)(y0 + rr) * W + x0 + t) * C) = o4;
+          kpf_st4(yb + ((long)(y0 + rr) * W + x0 + t) * C, o4);
       }
     }
   }
@@ -308,10 +309,10 @@ __global__ __launch_bounds__(256) void dwconv7_ln_wave_kernel(const float* __res
 constexpr int DT_TY = 8, DT_HR = DT_TY + 6;  // tile rows, halo rows
 
 // PXS = strip width (8: C <= 128, 4: C = 192 so that NCHK x PXS accumulators fit); the tile is 8 rows x 4 strips.
-template <int NCHK, int PXS, bool SPLIT>
-__global__ __launch_bounds__(256) void dwconv7_ln_tile_kernel(const float* __restrict__ x, const float* __restrict__ wdw,
+template <typename TA, int NCHK, int PXS, bool SPLIT>
+__global__ __launch_bounds__(256) void dwconv7_ln_tile_kernel(const TA* __restrict__ x, const float* __restrict__ wdw,
                                                               const float* __restrict__ bdw, const float* __restrict__ lw,
-                                                              const float* __restrict__ lb, float* __restrict__ y, int B, int H, int W,
+                                                              const float* __restrict__ lb, TA* __restrict__ y, int B, int H, int W,
                                                               int tiles_x, int tiles_y, float eps) {
   constexpr int C = 32 * NCHK;
   constexpr int DT_TX = 4 * PXS, DT_HP = DT_TX + 6, DT_RS = (DT_HP + 1) * 32;  // halo pixels per row; row stride in floats (1 pad pixel)
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(256) void dwconv7_ln_tile_kernel(const float* __res
   const int ty = (int)(bid % tiles_y);
   const int b = (int)(bid / tiles_y);
   const int y0 = ty * DT_TY, x0 = tx * DT_TX;
-  const float* xb = x + (long)b * H * W * C;
+  const TA* xb = x + (long)b * H * W * C;
 
   f32x4 acc[NCHK][PXS];
 #pragma unroll  // (acc is indexed by ch: it must be a compile-time index to stay in registers)
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(256) void dwconv7_ln_tile_kernel(const float* __res
       const int iy = y0 + pr - 3, ix = x0 + pc - 3;
       const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && i < DT_HR * DT_HP * 8;
       const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
-      const f32x4 v = *reinterpret_cast<const f32x4*>(xb + ((long)cy * W + cx) * C + ch * 32 + q * 4);
+      const f32x4 v = kpf_ld4(xb + ((long)cy * W + cx) * C + ch * 32 + q * 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) sv[it][e] = ok ? v[e] : 0.f;
     }
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(256) void dwconv7_ln_tile_kernel(const float* __res
     const float rstd = 1.0f / sqrtf(sq * invC + eps);
     const int ox = x0 + sx + t;
     if (oy < H && ox < W) {
-      float* dst = y + (((long)b * H + oy) * W + ox) * C;
+      TA* dst = y + (((long)b * H + oy) * W + ox) * C;
 #pragma unroll
       for (int ch = 0; ch < NCHK; ++ch) {
         const int c = ch * 32 + q8 * 4;
@@ -420,10 +421,10 @@ __global__ __launch_bounds__(256) void dwconv7_ln_tile_kernel(const float* __res
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (acc[ch][t][e] - mean) * rstd * g[e] + be[e];
-        if (SPLIT)
+        if constexpr (SPLIT)
           kpf_store_split4(dst, c, o);
         else
-          *reinterpret_cast<f32x4*>(dst + c) = o;
+          kpf_st4(dst + c, o);
       }
     }
   }
@@ -436,16 +437,16 @@ __global__ __launch_bounds__(256) void dwconv7_ln_tile_kernel(const float* __res
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int LN_MAXV = 8;  // float4 per lane at LPR = 64 -> C <= 2048
 
-template <int LPR, int NV, bool SPLIT>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                        const float* __restrict__ b, float* __restrict__ y, long rows, int C,
+template <typename TI, typename TO, int LPR, int NV, bool SPLIT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, TO* __restrict__ y, long rows, int C,
                                                         float eps) {
   constexpr int RPB = 256 / LPR;  // rows per block
   const int sub = threadIdx.x % LPR;
   const long row = (long)blockIdx.x * RPB + threadIdx.x / LPR;
   const bool live = row < rows;
   const int C4 = C >> 2;
-  const float* src = x + (live ? row : 0) * C;
+  const TI* src = x + (live ? row : 0) * C;
   f32x4 v[NV];
   float sum = 0.f;
 #pragma unroll
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const int c = sub + LPR * i;
     v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (c < C4) {
-      v[i] = *reinterpret_cast<const f32x4*>(src + 4 * c);
+      v[i] = kpf_ld4(src + 4 * c);
       sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
   }
@@ -476,7 +477,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   for (int o = LPR / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
   const float rstd = 1.0f / sqrtf(sq * invC + eps);
   if (!live) return;
-  float* dst = y + row * C;
+  TO* dst = y + row * C;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = sub + LPR * i;
@@ -486,10 +487,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + be[e];
-      if (SPLIT)  // in place is safe: a row's lanes share a wave and every load precedes the reduction shuffles
+      if constexpr (SPLIT)  // in place is safe: a row's lanes share a wave and every load precedes the reduction shuffles
         kpf_store_split4(dst, 4 * c, o);
       else
-        *reinterpret_cast<f32x4*>(dst + 4 * c) = o;
+        kpf_st4(dst + 4 * c, o);
     }
   }
 }
@@ -497,7 +498,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------------------------------
 // bilinear x2, align_corners = False:  src = (dst + 0.5) / 2 - 0.5 clamped at 0 ; i1 = min(i0 + 1, n - 1)
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int H,
+template <typename TA>
+__global__ __launch_bounds__(256) void upsample2x_kernel(const TA* __restrict__ src, TA* __restrict__ dst, int B, int H,
                                                          int W, int C4, int dst_ld, int dst_coff) {
   const long total = (long)B * 2 * H * 2 * W * C4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -515,15 +517,15 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict
     const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
     const float ly = fy - (float)y0, lx = fx - (float)x0;
     const float hy = 1.f - ly, hx = 1.f - lx;
-    const float* sb = src + (long)b * H * W * C4 * 4 + 4 * q;
-    const f32x4 v00 = *reinterpret_cast<const f32x4*>(sb + ((long)y0 * W + x0) * C4 * 4);
-    const f32x4 v01 = *reinterpret_cast<const f32x4*>(sb + ((long)y0 * W + x1) * C4 * 4);
-    const f32x4 v10 = *reinterpret_cast<const f32x4*>(sb + ((long)y1 * W + x0) * C4 * 4);
-    const f32x4 v11 = *reinterpret_cast<const f32x4*>(sb + ((long)y1 * W + x1) * C4 * 4);
+    const TA* sb = src + (long)b * H * W * C4 * 4 + 4 * q;
+    const f32x4 v00 = kpf_ld4(sb + ((long)y0 * W + x0) * C4 * 4);
+    const f32x4 v01 = kpf_ld4(sb + ((long)y0 * W + x1) * C4 * 4);
+    const f32x4 v10 = kpf_ld4(sb + ((long)y1 * W + x0) * C4 * 4);
+    const f32x4 v11 = kpf_ld4(sb + ((long)y1 * W + x1) * C4 * 4);
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e]);
-    *reinterpret_cast<f32x4*>(dst + (((long)b * 2 * H + oy) * 2 * W + ox) * dst_ld + dst_coff + 4 * q) = o;
+    kpf_st4(dst + (((long)b * 2 * H + oy) * 2 * W + ox) * dst_ld + dst_coff + 4 * q, o);
   }
 }
 
@@ -585,6 +587,16 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restri
   }
 }
 
+template <typename TA>
+__global__ __launch_bounds__(256) void cast_h16_f32_kernel(const TA* __restrict__ src, float* __restrict__ dst, long total, int C4, int src_ld,
+                                                           int src_coff) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / C4;
+    const int q = (int)(i - row * C4);
+    kpf_st4(dst + i * 4, kpf_ld4(src + row * src_ld + src_coff + 4 * q));
+  }
+}
+
 inline int grid_for(long total, int block = 256, int cap = 256 * 16) {
   long g = (total + block - 1) / block;
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -592,61 +604,66 @@ inline int grid_for(long total, int block = 256, int cap = 256 * 16) {
 
 }  // namespace
 
-static int layernorm_impl(const float* x, const float* w, const float* b, float* y, long rows, int C, float eps, void* stream, bool split);
+template <typename TI, typename TO>
+static int layernorm_impl(const TI* x, const float* w, const float* b, TO* y, long rows, int C, float eps, void* stream, bool split);
 
-static int dwconv7_ln_impl(const float* x, const float* w_dw, const float* b_dw, const float* ln_w, const float* ln_b, float* y, int B, int H,
+template <typename TA>
+static int dwconv7_ln_impl(const TA* x, const float* w_dw, const float* b_dw, const float* ln_w, const float* ln_b, TA* y, int B, int H,
                            int W, int C, float eps, void* stream, bool split) {
-  KPF_REQUIRE(x && w_dw && b_dw && ln_w && ln_b && y, "kpf_dwconv7_ln_f32: null pointer");
-  KPF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && C <= 2048, "kpf_dwconv7_ln_f32: bad shape B=%d H=%d W=%d C=%d", B, H, W, C);
-  KPF_REQUIRE(kpf_aligned16(x) && kpf_aligned16(y) && kpf_aligned16(w_dw), "kpf_dwconv7_ln_f32: unaligned pointer");
-  KPF_REQUIRE(!split || C % 32 == 0, "kpf_dwconv7_ln_split_f32: C=%d must be a multiple of 32", C);
+  constexpr bool F32 = sizeof(TA) == 4;  // (the split operand format exists for fp32 storage only)
+  KPF_REQUIRE(x && w_dw && b_dw && ln_w && ln_b && y, "kpf_dwconv7_ln: null pointer");
+  KPF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && C <= 2048, "kpf_dwconv7_ln: bad shape B=%d H=%d W=%d C=%d", B, H, W, C);
+  KPF_REQUIRE(kpf_aligned16(x) && kpf_aligned16(y) && kpf_aligned16(w_dw), "kpf_dwconv7_ln: unaligned pointer");
+  KPF_REQUIRE(!split || (F32 && C % 32 == 0), "kpf_dwconv7_ln_split_f32: C=%d must be a multiple of 32 (fp32 storage)", C);
   const int C4 = C / 4;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   static const int tile_env = []() { const char* e = getenv("KPF_DW_TILE"); return e ? atoi(e) : 1; }();  // tuning aid
   if (tile_env && (C == 96 || C == 128 || C == 192) && H >= 16 && W >= 16) {
     // LDS-tiled, fused: every input pixel crosses L2 -> L1 about twice instead of seven times
     const int TX = C == 192 ? 16 : 32;
     const int tiles_x = (W + TX - 1) / TX, tiles_y = (H + DT_TY - 1) / DT_TY;
     const dim3 grid((unsigned)((long)B * tiles_y * tiles_x));
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define KPF_DWT(NCHK, PXS)                                                                                                                  \
-  do {                                                                                                                                      \
-    if (split)                                                                                                                              \
-      hipLaunchKernelGGL((dwconv7_ln_tile_kernel<NCHK, PXS, true>), grid, dim3(256), 0, st, x, w_dw, b_dw, ln_w, ln_b, y, B, H, W, tiles_x, \
-                         tiles_y, eps);                                                                                                     \
-    else                                                                                                                                    \
-      hipLaunchKernelGGL((dwconv7_ln_tile_kernel<NCHK, PXS, false>), grid, dim3(256), 0, st, x, w_dw, b_dw, ln_w, ln_b, y, B, H, W, tiles_x, \
-                         tiles_y, eps);                                                                                                     \
+#define KPF_DWT(NCHK, PXS)                                                                                                                     \
+  do {                                                                                                                                         \
+    if constexpr (F32) {                                                                                                                       \
+      if (split) {                                                                                                                             \
+        hipLaunchKernelGGL((dwconv7_ln_tile_kernel<TA, NCHK, PXS, true>), grid, dim3(256), 0, st, x, w_dw, b_dw, ln_w, ln_b, y, B, H, W,       \
+                           tiles_x, tiles_y, eps);                                                                                             \
+        break;                                                                                                                                 \
+      }                                                                                                                                        \
+    }                                                                                                                                          \
+    hipLaunchKernelGGL((dwconv7_ln_tile_kernel<TA, NCHK, PXS, false>), grid, dim3(256), 0, st, x, w_dw, b_dw, ln_w, ln_b, y, B, H, W, tiles_x, \
+                       tiles_y, eps);                                                                                                          \
   } while (0)
     if (C == 96) KPF_DWT(3, 8);
     else if (C == 128) KPF_DWT(4, 8);
     else KPF_DWT(6, 4);
 #undef KPF_DWT
-    return kpf_check_launch("kpf_dwconv7_ln_f32");
+    return kpf_check_launch("kpf_dwconv7_ln");
   }
   if (H * W >= 64 && C4 <= 64 && (size_t)49 * C * sizeof(float) <= 64 * 1024 && !getenv("KPF_DW_UNFUSED")) {
     // fused, one pass over the activation: channel quads of a pixel on one 32- or 64-lane group, LayerNorm by shuffles
     const int xstrips = (W + 7) / 8, ypairs = (H + 1) / 2;
     const long groups = (long)B * ypairs * xstrips;
     const size_t wbytes = (size_t)49 * C * sizeof(float);
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (C4 <= 32) {
-      const long threads = groups * 32;
-      if (split)
-        hipLaunchKernelGGL((dwconv7_ln_wave_kernel<32, true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), wbytes, st, x, w_dw, b_dw, ln_w,
-                           ln_b, y, B, H, W, C, xstrips, ypairs, eps);
-      else
-        hipLaunchKernelGGL((dwconv7_ln_wave_kernel<32, false>), dim3((unsigned)((threads + 255) / 256)), dim3(256), wbytes, st, x, w_dw, b_dw, ln_w,
-                           ln_b, y, B, H, W, C, xstrips, ypairs, eps);
-    } else {
-      const long threads = groups * 64;
-      if (split)
-        hipLaunchKernelGGL((dwconv7_ln_wave_kernel<64, true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), wbytes, st, x, w_dw, b_dw, ln_w,
-                           ln_b, y, B, H, W, C, xstrips, ypairs, eps);
-      else
-        hipLaunchKernelGGL((dwconv7_ln_wave_kernel<64, false>), dim3((unsigned)((threads + 255) / 256)), dim3(256), wbytes, st, x, w_dw, b_dw, ln_w,
-                           ln_b, y, B, H, W, C, xstrips, ypairs, eps);
-    }
-    return kpf_check_launch("kpf_dwconv7_ln_f32");
+#define KPF_DWW(LG)                                                                                                                            \
+  do {                                                                                                                                         \
+    const long threads = groups * LG;                                                                                                          \
+    const dim3 grid((unsigned)((threads + 255) / 256));                                                                                        \
+    if constexpr (F32) {                                                                                                                       \
+      if (split) {                                                                                                                             \
+        hipLaunchKernelGGL((dwconv7_ln_wave_kernel<TA, LG, true>), grid, dim3(256), wbytes, st, x, w_dw, b_dw, ln_w, ln_b, y, B, H, W, C,      \
+                           xstrips, ypairs, eps);                                                                                              \
+        break;                                                                                                                                 \
+      }                                                                                                                                        \
+    }                                                                                                                                          \
+    hipLaunchKernelGGL((dwconv7_ln_wave_kernel<TA, LG, false>), grid, dim3(256), wbytes, st, x, w_dw, b_dw, ln_w, ln_b, y, B, H, W, C,         \
+                       xstrips, ypairs, eps);                                                                                                  \
+  } while (0)
+    if (C4 <= 32) KPF_DWW(32);
+    else KPF_DWW(64);
+#undef KPF_DWW
+    return kpf_check_launch("kpf_dwconv7_ln");
   }
   if (H * W >= 64 || split) {
     // two launches: register-tiled depthwise conv, then the row LayerNorm in place (each streams the tensor once; measured faster
@@ -656,50 +673,65 @@ static int dwconv7_ln_impl(const float* x, const float* w_dw, const float* b_dw,
     const int xstrips = (W + PXr - 1) / PXr, ypairs = (H + 1) / 2;
     const long total = (long)B * ypairs * xstrips * C4;
     const size_t wbytes = (size_t)49 * C * sizeof(float);
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)((total + 255) / 256));
     if (wbytes <= 48 * 1024) {
-      if (PXr == 4) hipLaunchKernelGGL((dwconv7_kernel<true, 4>), grid, dim3(256), wbytes, st, x, w_dw, b_dw, y, B, H, W, C, xstrips, ypairs);
-      else hipLaunchKernelGGL((dwconv7_kernel<true, 8>), grid, dim3(256), wbytes, st, x, w_dw, b_dw, y, B, H, W, C, xstrips, ypairs);
+      if (PXr == 4) hipLaunchKernelGGL((dwconv7_kernel<TA, true, 4>), grid, dim3(256), wbytes, st, x, w_dw, b_dw, y, B, H, W, C, xstrips, ypairs);
+      else hipLaunchKernelGGL((dwconv7_kernel<TA, true, 8>), grid, dim3(256), wbytes, st, x, w_dw, b_dw, y, B, H, W, C, xstrips, ypairs);
     } else {
-      if (PXr == 4) hipLaunchKernelGGL((dwconv7_kernel<false, 4>), grid, dim3(256), 0, st, x, w_dw, b_dw, y, B, H, W, C, xstrips, ypairs);
-      else hipLaunchKernelGGL((dwconv7_kernel<false, 8>), grid, dim3(256), 0, st, x, w_dw, b_dw, y, B, H, W, C, xstrips, ypairs);
+      if (PXr == 4) hipLaunchKernelGGL((dwconv7_kernel<TA, false, 4>), grid, dim3(256), 0, st, x, w_dw, b_dw, y, B, H, W, C, xstrips, ypairs);
+      else hipLaunchKernelGGL((dwconv7_kernel<TA, false, 8>), grid, dim3(256), 0, st, x, w_dw, b_dw, y, B, H, W, C, xstrips, ypairs);
     }
-    int rc = kpf_check_launch("kpf_dwconv7_ln_f32");
+    int rc = kpf_check_launch("kpf_dwconv7_ln");
     if (rc) return rc;
-    return layernorm_impl(y, ln_w, ln_b, y, (long)B * H * W, C, eps, stream, split);
+    return layernorm_impl<TA, TA>(y, ln_w, ln_b, y, (long)B * H * W, C, eps, stream, split);
   }
   int S = 1;
   while (S * 2 * C4 <= 256 && S * DW_T < W) S *= 2;  // strips per block: <= 256 threads, no wider than the row
   const int threads = ((S * C4 + 63) / 64) * 64;
-  KPF_REQUIRE(threads <= 512, "kpf_dwconv7_ln_f32: C too large");
+  KPF_REQUIRE(threads <= 512, "kpf_dwconv7_ln: C too large");
   const int xblocks = (W + S * DW_T - 1) / (S * DW_T);
   const size_t lds = (size_t)S * DW_T * C * sizeof(float);
-  hipLaunchKernelGGL(dwconv7_ln_kernel, dim3((unsigned)((long)B * H * xblocks)), dim3(threads), lds,
-                     reinterpret_cast<hipStream_t>(stream), x, w_dw, b_dw, ln_w, ln_b, y, H, W, C, S, xblocks, eps);
-  return kpf_check_launch("kpf_dwconv7_ln_f32");
+  hipLaunchKernelGGL(dwconv7_ln_kernel<TA>, dim3((unsigned)((long)B * H * xblocks)), dim3(threads), lds, st, x, w_dw, b_dw, ln_w, ln_b, y, H, W, C,
+                     S, xblocks, eps);
+  return kpf_check_launch("kpf_dwconv7_ln");
 }
 
 extern "C" int kpf_dwconv7_ln_f32(const float* x, const float* w_dw, const float* b_dw, const float* ln_w, const float* ln_b,
                                   float* y, int B, int H, int W, int C, float eps, void* stream) {
-  return dwconv7_ln_impl(x, w_dw, b_dw, ln_w, ln_b, y, B, H, W, C, eps, stream, false);
+  return dwconv7_ln_impl<float>(x, w_dw, b_dw, ln_w, ln_b, y, B, H, W, C, eps, stream, false);
 }
 extern "C" int kpf_dwconv7_ln_split_f32(const float* x, const float* w_dw, const float* b_dw, const float* ln_w, const float* ln_b,
                                         float* y, int B, int H, int W, int C, float eps, void* stream) {
-  return dwconv7_ln_impl(x, w_dw, b_dw, ln_w, ln_b, y, B, H, W, C, eps, stream, true);
+  return dwconv7_ln_impl<float>(x, w_dw, b_dw, ln_w, ln_b, y, B, H, W, C, eps, stream, true);
+}
+extern "C" int kpf_dwconv7_ln_h16(const void* x, const float* w_dw, const float* b_dw, const float* ln_w, const float* ln_b, void* y, int B,
+                                  int H, int W, int C, float eps, int dtype, void* stream) {
+  if (dtype == KPF_DT_BF16)
+    return dwconv7_ln_impl<bf16_t>(static_cast<const bf16_t*>(x), w_dw, b_dw, ln_w, ln_b, static_cast<bf16_t*>(y), B, H, W, C, eps, stream, false);
+  if (dtype == KPF_DT_F16)
+    return dwconv7_ln_impl<f16_t>(static_cast<const f16_t*>(x), w_dw, b_dw, ln_w, ln_b, static_cast<f16_t*>(y), B, H, W, C, eps, stream, false);
+  kpf_set_error("kpf_dwconv7_ln_h16: dtype must be KPF_DT_BF16 or KPF_DT_F16");
+  return KPF_EINVAL;
 }
 
-static int layernorm_impl(const float* x, const float* w, const float* b, float* y, long rows, int C, float eps, void* stream, bool split) {
-  KPF_REQUIRE(x && w && b && y && rows > 0, "kpf_layernorm_f32: null pointer / empty");
-  KPF_REQUIRE(C % 4 == 0 && C > 0 && C <= 64 * 4 * LN_MAXV, "kpf_layernorm_f32: C=%d unsupported", C);
+template <typename TI, typename TO>
+static int layernorm_impl(const TI* x, const float* w, const float* b, TO* y, long rows, int C, float eps, void* stream, bool split) {
+  constexpr bool F32 = sizeof(TO) == 4;
+  KPF_REQUIRE(x && w && b && y && rows > 0, "kpf_layernorm: null pointer / empty");
+  KPF_REQUIRE(C % 4 == 0 && C > 0 && C <= 64 * 4 * LN_MAXV, "kpf_layernorm: C=%d unsupported", C);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int C4 = C / 4;
-  KPF_REQUIRE(!split || C % 32 == 0, "kpf_layernorm_split_f32: C=%d must be a multiple of 32", C);
+  KPF_REQUIRE(!split || (F32 && C % 32 == 0), "kpf_layernorm_split_f32: C=%d must be a multiple of 32 (fp32 storage)", C);
 #define KPF_LN(LPR, NV)                                                                                                                          \
   do {                                                                                                                                           \
     const dim3 g((unsigned)((rows + 256 / LPR - 1) / (256 / LPR)));                                                                              \
-    if (split) hipLaunchKernelGGL((layernorm_kernel<LPR, NV, true>), g, dim3(256), 0, st, x, w, b, y, rows, C, eps);                             \
-    else hipLaunchKernelGGL((layernorm_kernel<LPR, NV, false>), g, dim3(256), 0, st, x, w, b, y, rows, C, eps);                                  \
+    if constexpr (F32) {                                                                                                                         \
+      if (split) {                                                                                                                               \
+        hipLaunchKernelGGL((layernorm_kernel<TI, TO, LPR, NV, true>), g, dim3(256), 0, st, x, w, b, y, rows, C, eps);                            \
+        break;                                                                                                                                   \
+      }                                                                                                                                          \
+    }                                                                                                                                            \
+    hipLaunchKernelGGL((layernorm_kernel<TI, TO, LPR, NV, false>), g, dim3(256), 0, st, x, w, b, y, rows, C, eps);                               \
   } while (0)
   if (C4 <= 16) KPF_LN(16, 1);
   else if (C4 <= 32) KPF_LN(32, 1);
@@ -708,24 +740,64 @@ static int layernorm_impl(const float* x, const float* w, const float* b, float*
   else if (C4 <= 256) KPF_LN(64, 4);
   else KPF_LN(64, LN_MAXV);
 #undef KPF_LN
-  return kpf_check_launch("kpf_layernorm_f32");
+  return kpf_check_launch("kpf_layernorm");
 }
 
 extern "C" int kpf_layernorm_f32(const float* x, const float* w, const float* b, float* y, long rows, int C, float eps, void* stream) {
-  return layernorm_impl(x, w, b, y, rows, C, eps, stream, false);
+  return layernorm_impl<float, float>(x, w, b, y, rows, C, eps, stream, false);
 }
 extern "C" int kpf_layernorm_split_f32(const float* x, const float* w, const float* b, float* y, long rows, int C, float eps, void* stream) {
-  return layernorm_impl(x, w, b, y, rows, C, eps, stream, true);
+  return layernorm_impl<float, float>(x, w, b, y, rows, C, eps, stream, true);
+}
+extern "C" int kpf_layernorm_h16(const void* x, int x_dtype, const float* w, const float* b, void* y, int y_dtype, long rows, int C, float eps,
+                                 void* stream) {
+  // fp32 -> 16-bit (the stem's LayerNorm: its convolution runs in fp32 on the fp32 image) or 16-bit -> the same 16-bit type
+  if (y_dtype == KPF_DT_BF16 && x_dtype == KPF_DT_F32)
+    return layernorm_impl<float, bf16_t>(static_cast<const float*>(x), w, b, static_cast<bf16_t*>(y), rows, C, eps, stream, false);
+  if (y_dtype == KPF_DT_F16 && x_dtype == KPF_DT_F32)
+    return layernorm_impl<float, f16_t>(static_cast<const float*>(x), w, b, static_cast<f16_t*>(y), rows, C, eps, stream, false);
+  if (y_dtype == KPF_DT_BF16 && x_dtype == KPF_DT_BF16)
+    return layernorm_impl<bf16_t, bf16_t>(static_cast<const bf16_t*>(x), w, b, static_cast<bf16_t*>(y), rows, C, eps, stream, false);
+  if (y_dtype == KPF_DT_F16 && x_dtype == KPF_DT_F16)
+    return layernorm_impl<f16_t, f16_t>(static_cast<const f16_t*>(x), w, b, static_cast<f16_t*>(y), rows, C, eps, stream, false);
+  kpf_set_error("kpf_layernorm_h16: unsupported dtype pair (%d -> %d)", x_dtype, y_dtype);
+  return KPF_EINVAL;
 }
 
+template <typename TA>
+static int upsample2x_impl(const TA* src, TA* dst, int B, int H, int W, int C, int dst_ld, int dst_coff, void* stream) {
+  KPF_REQUIRE(src && dst && B > 0 && H > 0 && W > 0, "kpf_upsample2x: null pointer / empty");
+  KPF_REQUIRE(C % 4 == 0 && dst_ld % 4 == 0 && dst_coff % 4 == 0 && dst_coff + C <= dst_ld, "kpf_upsample2x: bad channel slice");
+  const long total = (long)B * 4 * H * W * (C / 4);
+  hipLaunchKernelGGL(upsample2x_kernel<TA>, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst, B, H, W, C / 4,
+                     dst_ld, dst_coff);
+  return kpf_check_launch("kpf_upsample2x");
+}
 extern "C" int kpf_upsample2x_f32(const float* src, float* dst, int B, int H, int W, int C, int dst_ld, int dst_coff,
                                   void* stream) {
-  KPF_REQUIRE(src && dst && B > 0 && H > 0 && W > 0, "kpf_upsample2x_f32: null pointer / empty");
-  KPF_REQUIRE(C % 4 == 0 && dst_ld % 4 == 0 && dst_coff % 4 == 0 && dst_coff + C <= dst_ld, "kpf_upsample2x_f32: bad channel slice");
-  const long total = (long)B * 4 * H * W * (C / 4);
-  hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst, B, H,
-                     W, C / 4, dst_ld, dst_coff);
-  return kpf_check_launch("kpf_upsample2x_f32");
+  return upsample2x_impl<float>(src, dst, B, H, W, C, dst_ld, dst_coff, stream);
+}
+extern "C" int kpf_upsample2x_h16(const void* src, void* dst, int B, int H, int W, int C, int dst_ld, int dst_coff, int dtype, void* stream) {
+  if (dtype == KPF_DT_BF16) return upsample2x_impl<bf16_t>(static_cast<const bf16_t*>(src), static_cast<bf16_t*>(dst), B, H, W, C, dst_ld, dst_coff, stream);
+  if (dtype == KPF_DT_F16) return upsample2x_impl<f16_t>(static_cast<const f16_t*>(src), static_cast<f16_t*>(dst), B, H, W, C, dst_ld, dst_coff, stream);
+  kpf_set_error("kpf_upsample2x_h16: dtype must be KPF_DT_BF16 or KPF_DT_F16");
+  return KPF_EINVAL;
+}
+
+// 16-bit NHWC slice -> dense fp32 (the 128-channel feature maps handed to the fp32 fusion head / returned at the module boundary)
+extern "C" int kpf_cast_h16_f32(const void* src, int dtype, float* dst, long rows, int C, int src_ld, int src_coff, void* stream) {
+  KPF_REQUIRE(src && dst && rows > 0 && C > 0 && C % 4 == 0 && src_ld % 4 == 0 && src_coff % 4 == 0 && src_coff + C <= src_ld, "kpf_cast_h16_f32: bad arguments");
+  const long total = rows * (C / 4);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == KPF_DT_BF16)
+    hipLaunchKernelGGL(cast_h16_f32_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, static_cast<const bf16_t*>(src), dst, total, C / 4, src_ld, src_coff);
+  else if (dtype == KPF_DT_F16)
+    hipLaunchKernelGGL(cast_h16_f32_kernel<f16_t>, dim3(grid_for(total)), dim3(256), 0, st, static_cast<const f16_t*>(src), dst, total, C / 4, src_ld, src_coff);
+  else {
+    kpf_set_error("kpf_cast_h16_f32: dtype must be KPF_DT_BF16 or KPF_DT_F16");
+    return KPF_EINVAL;
+  }
+  return kpf_check_launch("kpf_cast_h16_f32");
 }
 
 extern "C" int kpf_nchw_to_nhwc_f32(const float* src, float* dst, int B, int C, int H, int W, int Cpad, void* stream) {

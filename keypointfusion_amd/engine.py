@@ -687,10 +687,15 @@ class ModelPlan:
     """All kernel-layout weights of one KPFusion instance on one device, and the forward schedule
     (model/model.py:395-426)."""
 
-    def __init__(self, sd, net, device):
-        self.net, self.device = net, device
-        self.backbone_d = UNetPlan(sd, "backbone_d", net, device)
-        self.backbone_rgb = UNetPlan(sd, "backbone_rgb", net, device)
+    def __init__(self, sd, net, device, precision="f32"):
+        self.net, self.device, self.precision = net, device, precision
+        if precision == "f32":
+            self.backbone_d = UNetPlan(sd, "backbone_d", net, device)
+            self.backbone_rgb = UNetPlan(sd, "backbone_rgb", net, device)
+        else:  # 16-bit storage in the backbones (engine16.py); the fusion head below stays fp32
+            from .engine16 import UNetPlan16
+            self.backbone_d = UNetPlan16(sd, "backbone_d", net, device, precision)
+            self.backbone_rgb = UNetPlan16(sd, "backbone_rgb", net, device, precision)
         self.blocks = [FusionBlockPlan(sd, "block%d" % i, device) for i in (1, 2)]
         self._graphs = {}  # (B, S, N, img_size, flip, kernel) -> (hipGraph, static inputs, static outputs)
         self._graph_lock = __import__("threading").Lock()  # a graph's static buffers are shared by every caller of this plan

@@ -1,0 +1,195 @@
+"""Reduced-precision execution plan of the ConvNeXt UNet backbones (BASELINE.json configs[2] bf16, configs[4] fp16): 16-bit NHWC
+activations and weights in HBM, fp32 accumulation on v_mfma_f32_16x16x32_{bf16,f16}, fp32 elementwise arithmetic (LayerNorm statistics,
+GELU, residual adds, depthwise taps) inside the kernels.  Same schedule as engine.UNetPlan; the 4x4 stem convolution stays on the fp32
+path (its input is the fp32 image, K = 16 / 48), the 105-channel head output is written fp32 NCHW, and the 128-channel feature map is
+cast to fp32 for the fusion head, which stays fp32 (its integer decisions must not move).
+The reference has no reduced-precision mode: this is the arithmetic a `torch.autocast`-style deployment of it would use,
+and its contract is a tolerance in millimetres against the fp32 oracle (tests/test_reduced_precision_gpu.py), not bit parity.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+from .engine import Act, PackedConv, _launch, _ptr, _stream, bn_scale_shift, conv, nchw_to_nhwc
+from .spec import CONVNEXT, parse_net
+
+DTYPES = {"bf16": (torch.bfloat16, L.KPF_DT_BF16), "f16": (torch.float16, L.KPF_DT_F16)}
+
+
+def empty16(B, H, W, Cc, device, tdt):
+    a = Act(torch.empty(B * H * W * Cc, device=device, dtype=tdt), B, H, W, Cc)
+    return a
+
+
+class Packed16:
+    """16-bit image of a PackedConv: rows [N][Kp], Kp padded to 64 elements, in the storage dtype; bias stays fp32."""
+
+    def __init__(self, pc, tdt):
+        self.pc = pc
+        self.Kp = (pc.K + 63) // 64 * 64
+        w = torch.zeros(pc.N, self.Kp, dtype=torch.float32, device=pc.w.device)
+        w[:, :pc.K] = pc.w[:, :pc.K]
+        self.w = w.to(tdt).contiguous()
+
+
+def conv16(p16, x, kdt, out=None, flags=0, gamma=None, res=None, out_nchw=None):
+    """kpf_conv2d_h16: x / out / res are 16-bit Acts (out_nchw: fp32 NCHW tensor)."""
+    lib = L.load()
+    pc = p16.pc
+    B = x.B
+    if pc.merge > 1:
+        assert x.ld == x.C and x.coff == 0 and x.W % pc.merge == 0
+        IH, IW, in_ld, in_coff = x.H, x.W // pc.merge, x.C * pc.merge, 0
+        assert in_ld == pc.Cin, (in_ld, pc.Cin)
+    else:
+        IH, IW, in_ld, in_coff = x.H, x.W, x.ld, x.coff
+        assert x.C == pc.Cin, (x.C, pc.Cin)
+    OH = (IH + 2 * pc.ph - pc.KH) // pc.sh + 1
+    OW = (IW + 2 * pc.pw - pc.KW) // pc.sw + 1
+    d = L.ConvDesc()
+    d.B, d.IH, d.IW, d.Cin, d.in_ld, d.in_coff = B, IH, IW, pc.Cin, in_ld, in_coff
+    d.OH, d.OW, d.N = OH, OW, pc.N
+    d.KH, d.KW, d.sh, d.sw, d.ph, d.pw, d.Kp = pc.KH, pc.KW, pc.sh, pc.sw, pc.ph, pc.pw, p16.Kp
+    if out_nchw is not None:
+        flags |= L.KPF_OUT_NCHW
+        optr = out_nchw
+        d.out_ld, d.out_coff = pc.N, 0
+    else:
+        if out is None:
+            out = empty16(B, OH, OW, pc.N, x.buf.device, x.buf.dtype)
+        assert (out.B, out.H, out.W, out.C) == (B, OH, OW, pc.N)
+        optr = out.buf
+        d.out_ld, d.out_coff = out.ld, out.coff
+    if res is not None:
+        flags |= L.KPF_RES_ADD
+        d.res_ld, d.res_coff = res.ld, res.coff
+    if gamma is not None:
+        flags |= L.KPF_RES_GAMMA
+    d.flags = flags
+    M = B * OH * OW
+    nbytes = 2.0 * (B * IH * IW * pc.Cin + pc.N * pc.K + M * pc.N * (2 if res is not None else 1))
+    _launch("igemm_h16_kernel", pc.flops(M), nbytes, (M, pc.N, pc.K, pc.KH, pc.KW),
+            lambda: L.check(lib.kpf_conv2d_h16(C.byref(d), _ptr(x.buf), _ptr(p16.w), _ptr(pc.b), _ptr(pc.ps), _ptr(pc.pt), _ptr(gamma),
+                                               _ptr(res.buf if res is not None else None), _ptr(optr), kdt, _stream()), "kpf_conv2d_h16"))
+    return out
+
+
+class Residual16:
+    """engine.ResidualPlan on 16-bit storage."""
+
+    def __init__(self, sd, p, device, tdt):
+        cin = sd[p + ".conv1.conv.weight"].shape[1]
+        self.cout = sd[p + ".conv3.conv.weight"].shape[0]
+        P = lambda *a, **k: Packed16(PackedConv(*a, **k), tdt)
+        self.c1 = P(sd[p + ".conv1.conv.weight"], sd[p + ".conv1.conv.bias"], device, fold_bn=bn_scale_shift(sd, p + ".bn2"),
+                    prologue=bn_scale_shift(sd, p + ".bn1"))
+        self.c2 = P(sd[p + ".conv2.conv.weight"], sd[p + ".conv2.conv.bias"], device, pad=1, fold_bn=bn_scale_shift(sd, p + ".bn3"))
+        self.c3 = P(sd[p + ".conv3.conv.weight"], sd[p + ".conv3.conv.bias"], device)
+        self.skip = P(sd[p + ".skip_layer.conv.weight"], sd[p + ".skip_layer.conv.bias"], device) if cin != self.cout else None
+
+    def __call__(self, x, kdt, out=None):
+        h = conv16(self.c1, x, kdt, flags=L.KPF_ACT_RELU)
+        h = conv16(self.c2, h, kdt, flags=L.KPF_ACT_RELU)
+        if out is None:
+            out = empty16(x.B, x.H, x.W, self.cout, x.buf.device, x.buf.dtype)
+        if self.skip is not None:
+            conv16(self.skip, x, kdt, out=out)
+            return conv16(self.c3, h, kdt, out=out, res=out)
+        return conv16(self.c3, h, kdt, out=out, res=x)
+
+
+class Block16:
+    """engine.ConvNeXtBlockPlan on 16-bit storage: dw7x7+LN kernel, pwconv1 GEMM (+GELU), pwconv2 GEMM (+gamma*y + x, in place)."""
+
+    def __init__(self, sd, p, device, tdt):
+        c = sd[p + ".gamma"].numel()
+        f32 = lambda k: sd[p + k].detach().float().contiguous().to(device)
+        self.wdw = sd[p + ".dwconv.weight"].detach().float().reshape(c, 49).t().contiguous().to(device)
+        self.bdw, self.lnw, self.lnb, self.gamma = f32(".dwconv.bias"), f32(".norm.weight"), f32(".norm.bias"), f32(".gamma")
+        self.pw1 = Packed16(PackedConv(sd[p + ".pwconv1.weight"], sd[p + ".pwconv1.bias"], device), tdt)
+        self.pw2 = Packed16(PackedConv(sd[p + ".pwconv2.weight"], sd[p + ".pwconv2.bias"], device), tdt)
+
+    def __call__(self, x, y, h, kdt):
+        L.check(L.load().kpf_dwconv7_ln_h16(_ptr(x.buf), _ptr(self.wdw), _ptr(self.bdw), _ptr(self.lnw), _ptr(self.lnb), _ptr(y.buf), x.B, x.H,
+                                            x.W, x.C, 1e-6, kdt, _stream()), "kpf_dwconv7_ln_h16")
+        conv16(self.pw1, y, kdt, out=h, flags=L.KPF_ACT_GELU)
+        conv16(self.pw2, h, kdt, out=x, gamma=self.gamma, res=x)
+        return x
+
+
+class UNetPlan16:
+    """One ConvNeXt UNet stream on 16-bit storage (convNeXT/resnetUnet.py:129-152).  __call__(img NCHW fp32) ->
+    (img_result NCHW fp32 B x 105 x F x F, img_feature Act NHWC 128 fp32)."""
+
+    def __init__(self, sd, p, net, device, precision):
+        fam, size = parse_net(net)
+        if fam != "convnext":
+            raise NotImplementedError("the reduced-precision path covers the ConvNeXt backbones (BASELINE configs[2], [4]); ResNet runs fp32")
+        self.tdt, self.kdt = DTYPES[precision]
+        self.device = device
+        sdp = {k[len(p) + 1:]: v for k, v in sd.items() if k.startswith(p + ".")}
+        depths, dims = CONVNEXT[size]
+        self.dims = dims
+        b = "backbone"
+        f32 = lambda k: sdp[k].detach().float().contiguous().to(device)
+        self.stem = PackedConv(sdp[b + ".downsample_layers.0.0.weight"], sdp[b + ".downsample_layers.0.0.bias"], device, stride=4, patchify=True)
+        self.stem_ln = (f32(b + ".downsample_layers.0.1.weight"), f32(b + ".downsample_layers.0.1.bias"))
+        self.down, self.down_ln = [None], [None]
+        for i in range(1, 4):
+            self.down_ln.append((f32(b + ".downsample_layers.%d.0.weight" % i), f32(b + ".downsample_layers.%d.0.bias" % i)))
+            self.down.append(Packed16(PackedConv(sdp[b + ".downsample_layers.%d.1.weight" % i], sdp[b + ".downsample_layers.%d.1.bias" % i], device,
+                                                 stride=2, patchify=True), self.tdt))
+        self.stages = [[Block16(sdp, b + ".stages.%d.%d" % (i, j), device, self.tdt) for j in range(depths[i])] for i in range(4)]
+        R = lambda name: Residual16(sdp, name, device, self.tdt)
+        self.up4, self.skip4, self.fus4 = R("up4.0"), R("skip_layer4"), R("fusion_layer4")
+        self.up3, self.skip3, self.fus3 = R("up3.0"), R("skip_layer3"), R("fusion_layer3")
+        self.up2, self.skip2, self.fus2 = R("up2.0"), R("skip_layer2"), R("fusion_layer2")
+        self.result_emb = R("result_emb")
+        wf = torch.cat([sdp["finals.%d.weight" % i] for i in range(3)], 0)
+        bf = torch.cat([sdp["finals.%d.bias" % i] for i in range(3)], 0)
+        self.finals = Packed16(PackedConv(wf, bf, device), self.tdt)
+
+    def _ln(self, x, wb, out, x_kdt):
+        L.check(L.load().kpf_layernorm_h16(_ptr(x.buf), x_kdt, _ptr(wb[0]), _ptr(wb[1]), _ptr(out.buf), self.kdt, x.B * x.H * x.W, x.C, 1e-6,
+                                           _stream()), "kpf_layernorm_h16")
+        return out
+
+    def __call__(self, img):
+        lib = L.load()
+        dev, tdt, kdt = self.device, self.tdt, self.kdt
+        B, Cc, S, _ = img.shape
+        x = Act(img.contiguous().float().view(-1), B, S, S, 1) if Cc == 1 else nchw_to_nhwc(img)
+        feats = []
+        cur = None
+        for i in range(4):
+            if i == 0:
+                s32 = conv(self.stem, x)  # fp32 image -> fp32 (K = 16 / 48: not worth a 16-bit repack of the input)
+                cur = self._ln(s32, self.stem_ln, empty16(s32.B, s32.H, s32.W, s32.C, dev, tdt), L.KPF_DT_F32)
+            else:
+                t = self._ln(cur, self.down_ln[i], empty16(cur.B, cur.H, cur.W, cur.C, dev, tdt), kdt)
+                cur = conv16(self.down[i], t, kdt)
+            y = empty16(cur.B, cur.H, cur.W, cur.C, dev, tdt)
+            h = empty16(cur.B, cur.H, cur.W, 4 * cur.C, dev, tdt)
+            for blk in self.stages[i]:
+                blk(cur, y, h, kdt)
+            feats.append(cur)
+        c1, c2, c3, c4 = feats
+
+        def level(up, skip, fus, lo, hi):
+            cat = empty16(B, hi.H, hi.W, up.cout + skip.cout, dev, tdt)
+            u = up(lo, kdt)
+            dst = cat.slice(0, up.cout)
+            L.check(lib.kpf_upsample2x_h16(_ptr(u.buf), _ptr(dst.buf), u.B, u.H, u.W, u.C, dst.ld, dst.coff, kdt, _stream()), "kpf_upsample2x_h16")
+            skip(hi, kdt, out=cat.slice(up.cout, skip.cout))
+            return fus(cat, kdt)
+
+        c3f = level(self.up4, self.skip4, self.fus4, c4, c3)
+        c2f = level(self.up3, self.skip3, self.fus3, c3f, c2)
+        feat = level(self.up2, self.skip2, self.fus2, c2f, c1)
+        feat = self.result_emb(feat, kdt)
+        res = torch.empty(B, 105, feat.H, feat.W, device=dev, dtype=torch.float32)
+        conv16(self.finals, feat, kdt, out_nchw=res)
+        f32 = Act.empty(B, feat.H, feat.W, feat.C, dev)
+        L.check(lib.kpf_cast_h16_f32(_ptr(feat.buf), kdt, _ptr(f32.buf), B * feat.H * feat.W, feat.C, feat.ld, feat.coff, _stream()), "kpf_cast_h16_f32")
+        return res, f32

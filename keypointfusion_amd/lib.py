@@ -19,6 +19,7 @@ KPF_ACT_LEAKY = 64
 KPF_IN_SPLIT = 128
 KPF_OUT_SPLIT = 256
 KPF_W_SPLIT = 512
+KPF_DT_F32, KPF_DT_BF16, KPF_DT_F16 = 0, 1, 2
 
 
 class ConvDesc(C.Structure):
@@ -49,6 +50,11 @@ _SIGS = {
     "kpf_gate_reduce_f32": [_P, _P, _P, _P, _P, C.c_int, C.c_int, _P],
     "kpf_tr_encoder_f32": [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, _P],
     "kpf_xattn_layer_f32": [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_conv2d_h16": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P],
+    "kpf_dwconv7_ln_h16": [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _P],
+    "kpf_layernorm_h16": [_P, C.c_int, _P, _P, _P, C.c_int, C.c_long, C.c_int, C.c_float, _P],
+    "kpf_upsample2x_h16": [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_cast_h16_f32": [_P, C.c_int, _P, C.c_long, C.c_int, C.c_int, C.c_int, _P],
     "kpf_convnext_mlp_f32": [_P] * 8 + [C.c_long, C.c_int, _P],
     "kpf_convnext_mlp_supported": [C.c_int],
     "kpf_convnext_mlp_split_f32": [_P, _P, _P, _P, C.c_float, _P, _P, C.c_float, _P, _P, C.c_long, C.c_int, _P],

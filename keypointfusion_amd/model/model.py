@@ -41,6 +41,9 @@ class KPFusion(nn.Module):
             _attach(self, name, val, is_buffer)
         self._plans = {}
         self._plan_lock = threading.Lock()
+        # storage precision of the backbones: "f32" (the reference's arithmetic, default), "bf16" or "f16" (16-bit activations and
+        # weights, fp32 accumulation; ConvNeXt families; the fusion head stays fp32) — set before the first forward or at any time
+        self.precision = "f32"
         self.use_graphs = False  # opt-in: replay each forward from a captured hipGraph (eval / no_grad, fixed shapes)
 
     # -- weight repacking ------------------------------------------------------------------------------------
@@ -59,14 +62,16 @@ class KPFusion(nn.Module):
 
     def _plan(self, device):
         """Kernel-layout weights for `device`, rebuilt when any parameter changed (load_state_dict, optimiser step)."""
-        key = (device.type, device.index)
+        if self.precision not in ("f32", "bf16", "f16"):
+            raise ValueError("KPFusion.precision must be 'f32', 'bf16' or 'f16' (got %r)" % (self.precision,))
+        key = (device.type, device.index, self.precision)
         ver = self._state_version()
         with self._plan_lock:
             ent = self._plans.get(key)
             if ent is None or ent[0] != ver:
                 from ..engine import ModelPlan
                 sd = {k: v.detach() for k, v in self.state_dict().items()}
-                ent = (ver, ModelPlan(sd, self.net, device))
+                ent = (ver, ModelPlan(sd, self.net, device, self.precision))
                 self._plans[key] = ent
             return ent[1]
 

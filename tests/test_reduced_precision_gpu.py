@@ -1,0 +1,193 @@
+"""Reduced-precision path (BASELINE configs[2] bf16 eval, configs[4] ConvNeXt-B 512x512 fp16): 16-bit storage, fp32 accumulation.
+The reference has no such mode, so the contract is a stated tolerance against the fp32 oracle:
+  * per-op: a 16-bit GEMM / depthwise+LN equals the fp32 op on the SAME 16-bit-rounded operands up to output rounding (2^-8 bf16,
+    2^-11 f16 relative) — i.e. accumulation is fp32 and nothing else is lost;
+  * end to end (the tolerance study, on synthetic weights and crops, cube 250 mm): MEAN joint deviation from the fp32 oracle — the
+    quantity BASELINE.json's accuracy metric averages — below 4 mm (bf16) / 1.5 mm (f16) per stage, final stage below 1.5 / 0.6 mm;
+    dense maps within 6e-2 / 8e-3 of their range.  The MAX over joints is reported, not bounded tightly: the head contains integer
+    decisions (ball-query membership, top-4 pixels) taken around network outputs, and a joint whose neighbourhood changes by one point
+    moves by centimetres with untrained weights (measured: f16 mean 0.2-0.7 mm, max 18 mm on one joint of 84);
+  * size-independent properties at the full configs[4] size (ConvNeXt-B, 512x512): sample independence, batch-position independence,
+    determinism, finite outputs; the fp32 oracle on a subset.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import synthetic_sd
+from keypointfusion_amd.weights import synthetic_batch
+
+pytestmark = pytest.mark.gpu
+PREC = {"bf16": (torch.bfloat16, 2.0 ** -8), "f16": (torch.float16, 2.0 ** -11)}
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    from keypointfusion_amd import lib
+    lib.load()
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+@pytest.mark.parametrize("case", [
+    # B, Cin, H, W, N, k, stride, pad, flags
+    (2, 96, 16, 16, 384, 1, 1, 0, "gelu"),     # Cin % 64 != 0: general staging path with a K mask
+    (2, 384, 16, 16, 96, 1, 1, 0, "res"),
+    (1, 128, 32, 32, 105, 1, 1, 0, "nchw"),    # head: N tail, fp32 NCHW output
+    (2, 64, 9, 7, 64, 3, 1, 1, "relu"),        # ragged M, 3x3
+    (2, 48, 16, 16, 48, 3, 1, 1, "relu"),
+    (1, 192, 16, 16, 96, 1, 1, 0, "pro"),      # BatchNorm + ReLU operand prologue
+    (3, 768, 4, 4, 3072, 1, 1, 0, "gelu"),     # M = 48
+    (2, 256, 16, 16, 512, 2, 2, 0, "patch"),   # 2x2 / s2 patchify (downsample)
+])
+def test_conv2d_h16_is_the_fp32_conv_of_the_rounded_operands(case, prec):
+    from keypointfusion_amd import lib as L
+    from keypointfusion_amd.engine import Act, PackedConv
+    from keypointfusion_amd.engine16 import DTYPES, Packed16, conv16, empty16
+    dev = _dev()
+    tdt, eps = PREC[prec]
+    kdt = DTYPES[prec][1]
+    B, Cin, H, W, N, k, stride, pad, kind = case
+    g = torch.Generator().manual_seed(B * 1000 + Cin + N)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(N, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    bias = torch.randn(N, generator=g) * 0.1
+    xr, wr = x.to(tdt).float(), w.to(tdt).float()  # what the kernel sees
+    pro = None
+    if kind == "pro":
+        ps, pt = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.2
+        pro = (ps.double(), pt.double())
+        xin = F.relu(xr * ps.view(1, -1, 1, 1) + pt.view(1, -1, 1, 1)).to(tdt).float()  # the prologue rounds back to storage precision
+    else:
+        xin = xr
+    ref = F.conv2d(xin.double(), wr.double(), bias.double(), stride=stride, padding=pad)
+    pc = PackedConv(wr, bias, dev, stride=stride, pad=pad, prologue=pro, patchify=(kind == "patch"))
+    p16 = Packed16(pc, tdt)
+    xa = Act(x.permute(0, 2, 3, 1).contiguous().to(tdt).view(-1).to(dev), B, H, W, Cin)
+    OH, OW = ref.shape[-2:]
+    flags, kw = 0, {}
+    if kind == "gelu":
+        flags, ref = L.KPF_ACT_GELU, F.gelu(ref)
+    elif kind in ("relu", "pro"):
+        flags, ref = L.KPF_ACT_RELU, F.relu(ref)
+    elif kind == "res":
+        r = torch.randn(B, N, OH, OW, generator=g)
+        gam = torch.rand(N, generator=g)
+        ra = Act(r.permute(0, 2, 3, 1).contiguous().to(tdt).view(-1).to(dev), B, OH, OW, N)
+        kw = dict(res=ra, gamma=gam.to(dev))
+        ref = ref * gam.view(1, -1, 1, 1).double() + r.to(tdt).double()
+    if kind == "nchw":
+        out = torch.empty(B, N, OH, OW, device=dev)
+        conv16(p16, xa, kdt, out_nchw=out, flags=flags)
+        got = out.cpu().double()
+        tol = 2e-6  # fp32 output: only the accumulation order differs
+    else:
+        o = conv16(p16, xa, kdt, flags=flags, **kw)
+        got = o.buf.view(B, OH, OW, N).permute(0, 3, 1, 2).float().cpu().double()
+        tol = 1.01 * eps
+    err = float(((got - ref).abs() / (ref.abs() + ref.abs().max() * 1e-3)).max()) if kind != "nchw" else rel(got, ref)
+    assert err < 2.5 * tol + 1e-6, (case, prec, err)  # elementwise relative (floor at 1e-3 of the range): output rounding only
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 96), (1, 32, 32, 128), (2, 16, 16, 192), (1, 8, 8, 384), (1, 4, 4, 768), (1, 16, 16, 256), (1, 8, 8, 1024)])
+def test_dwconv7_ln_and_layernorm_h16(shape, prec):
+    from keypointfusion_amd import lib as L
+    from keypointfusion_amd.engine import _ptr, _stream
+    from keypointfusion_amd.engine16 import DTYPES
+    dev = _dev()
+    lib = L.load()
+    tdt, eps = PREC[prec]
+    kdt = DTYPES[prec][1]
+    B, H, W, Cc = shape
+    g = torch.Generator().manual_seed(Cc + H)
+    x = (torch.randn(B, H, W, Cc, generator=g) * 2 + 0.3).to(tdt)
+    wdw, bdw = torch.randn(49, Cc, generator=g) / 7, torch.randn(Cc, generator=g) * 0.1
+    lw, lb = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.1
+    d = [t.to(dev).contiguous() for t in (x, wdw, bdw, lw, lb)]
+    y = torch.empty_like(d[0])
+    L.check(lib.kpf_dwconv7_ln_h16(_ptr(d[0]), _ptr(d[1]), _ptr(d[2]), _ptr(d[3]), _ptr(d[4]), _ptr(y), B, H, W, Cc, 1e-6, kdt, _stream()), "dw16")
+    xr = x.float().permute(0, 3, 1, 2).double()
+    conv = F.conv2d(xr, wdw.t().reshape(Cc, 1, 7, 7).double(), bdw.double(), padding=3, groups=Cc).permute(0, 2, 3, 1)
+    ref = F.layer_norm(conv, (Cc,), lw.double(), lb.double(), 1e-6)
+    assert float((y.float().cpu().double() - ref).abs().max() / ref.abs().max()) < 1.5 * eps
+    # LayerNorm alone: fp32 -> 16-bit (stem) and 16-bit -> 16-bit (downsample)
+    x32 = torch.randn(B * H * W, Cc, generator=g) * 3 + 1
+    for src, sk in ((x32, L.KPF_DT_F32), (x32.to(tdt), kdt)):
+        z = torch.empty(B * H * W, Cc, device=dev, dtype=tdt)
+        L.check(lib.kpf_layernorm_h16(_ptr(src.to(dev)), sk, _ptr(d[3]), _ptr(d[4]), _ptr(z), kdt, B * H * W, Cc, 1e-6, _stream()), "ln16")
+        want = F.layer_norm(src.float().double(), (Cc,), lw.double(), lb.double(), 1e-6)
+        assert float((z.float().cpu().double() - want).abs().max() / want.abs().max()) < 1.5 * eps
+
+
+def _model(net, prec):
+    from keypointfusion_amd.model.model import KPFusion
+    m = KPFusion("KPFusion-" + net, "", 21, "dexycb", "")
+    m.load_state_dict(synthetic_sd("KPFusion-" + net), strict=True)
+    m.precision = prec
+    return m.to(_dev()).eval()
+
+
+@pytest.mark.parametrize("prec,mean_tol,final_tol,map_tol", [("bf16", 4.0, 1.5, 6e-2), ("f16", 1.5, 0.6, 8e-3)])
+def test_full_model_reduced_precision_tolerance_in_mm(prec, mean_tol, final_tol, map_tol):
+    """configs[2]: full model (ConvNeXt-T, 128x128), 16-bit backbones + fp32 head, against the fp32 oracle: the tolerance study."""
+    from oracle import kpf_oracle as O
+    dev = _dev()
+    sd = synthetic_sd("KPFusion-convnext-tiny")
+    B = 4
+    b = {k: torch.from_numpy(v) for k, v in synthetic_batch(B, 128, seed=3).items()}
+    ref, rsw = O.kpfusion_forward(sd, b["img_rgb"], b["img"], b["pcl"], b["center"], b["M"], b["cube"], b["cam_para"], 0.8)
+    m = _model("convnext-tiny", prec)
+
+    class Loader:
+        img_size, flip = 128, 1
+
+    with torch.no_grad():
+        res, sws, _ = m(b["img_rgb"].to(dev), b["img"].to(dev), b["pcl"].to(dev), Loader(), b["center"].to(dev), b["M"].to(dev),
+                        b["cube"].to(dev), b["cam_para"].to(dev), 0.8)
+    assert all(t.dtype == torch.float32 and bool(torch.isfinite(t).all()) for t in res + sws)
+    for k in (0, 1):
+        assert rel(res[k], ref[k]) < map_tol, (prec, k, rel(res[k], ref[k]))
+    mm = [float((res[k].cpu() - ref[k]).norm(dim=-1).max()) * 125.0 for k in range(2, 6)]  # cube 250 mm: x * 125 mm
+    mean_mm = [float((res[k].cpu() - ref[k]).norm(dim=-1).mean()) * 125.0 for k in range(2, 6)]
+    print("reduced precision %s: max joint deviation per stage %s mm, mean %s mm" % (prec, ["%.3f" % v for v in mm], ["%.3f" % v for v in mean_mm]))
+    assert max(mean_mm) < mean_tol and mean_mm[3] < final_tol and max(mm) < 60.0, (prec, mean_mm, mm)
+
+
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+def test_convnext_base_512_backbones_properties_and_oracle_subset(prec):
+    """configs[4]: ConvNeXt-B backbones at 512x512.  Full-size properties (finite, deterministic, independent of batch composition and
+    position) at B = 8, and the fp32 oracle on one sample."""
+    from oracle import kpf_oracle as O
+    dev = _dev()
+    net = "convnext-base"
+    sd = synthetic_sd("KPFusion-" + net)
+    B, S = 8, 512
+    b = {k: torch.from_numpy(v) for k, v in synthetic_batch(B, S, seed=2).items()}
+    m = _model(net, prec)
+    with torch.no_grad():
+        o1 = [t.clone() for t in m.forward_backbones(b["img_rgb"].to(dev), b["img"].to(dev))]
+        o2 = m.forward_backbones(b["img_rgb"].to(dev), b["img"].to(dev))
+        perm = torch.tensor([3, 0, 7, 1, 5, 2, 6, 4])
+        o3 = m.forward_backbones(b["img_rgb"][perm].to(dev), b["img"][perm].to(dev))
+        o4 = m.forward_backbones(b["img_rgb"][2:3].to(dev), b["img"][2:3].to(dev))
+    assert [tuple(t.shape) for t in o1] == [(B, 105, 128, 128), (B, 128, 128, 128)] * 2
+    for a, c, p, s1 in zip(o1, o2, o3, o4):
+        assert bool(torch.isfinite(a).all())
+        assert torch.equal(a, c), "not deterministic"
+        assert torch.equal(a[perm], p), "a sample's result depends on its batch position / neighbours"
+        assert torch.equal(a[2:3], s1), "a sample's result depends on the batch size"
+    ref = O.backbones_forward(sd, b["img_rgb"][2:3], b["img"][2:3])
+    tol = 6e-2 if prec == "bf16" else 8e-3
+    for a, r, name in zip(o1, ref, ("img_offset", "img_feat", "img_offset_rgb", "img_feat_rgb")):
+        e = rel(a[2:3], r)
+        print("convnext-base 512 %s %s: rel err vs fp32 oracle %.2e" % (prec, name, e))
+        assert e < tol, (name, e)
