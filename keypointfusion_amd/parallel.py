@@ -52,3 +52,109 @@ def max_over_ranks(value, device, dist_mod=None):
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
     return float(t.item())
+
+
+class GradBucketReducer:
+    """Data-parallel gradient averaging for the training step: the replacement of the reference's single-process
+    DataParallel reduce (train.py:81).  One process per GPU; after `loss.backward()` every rank holds the mean gradient.
+
+    Parameters are packed, in REVERSE registration order (the order backward produces gradients), into flat buckets of about
+    `bucket_mb` megabytes; a bucket is all-reduced (sum, asynchronously — RCCL over xGMI for "nccl", tests use "gloo") the moment its
+    last gradient has been accumulated (post-accumulate-grad hooks), so communication overlaps the rest of backward; `finish()` waits
+    for the outstanding reductions, divides by the world size and scatters the averaged values back into `.grad`.  Parameters that
+    received no gradient in a step (the dead modules of the reference: decoder layers 0-2, BERT embeddings / poolers, ConvNeXt heads —
+    20-23 % of the parameters) travel as zeros in their bucket slot; to keep them out of the payload altogether pass
+    `params` = the live ones only (`live_parameters`).  BatchNorm statistics stay per replica, like DataParallel's (no SyncBN)."""
+
+    def __init__(self, params, dist_mod, bucket_mb=64.0, group=None):
+        self.dist, self.group = dist_mod, group
+        self.world = dist_mod.get_world_size(group) if dist_mod is not None and dist_mod.is_initialized() else 1
+        self.params = [p for p in params if p.requires_grad]
+        cap = int(bucket_mb * 1024 * 1024)
+        self.buckets = []  # (flat buffer, [(param, offset, numel)])
+        cur, cur_bytes = [], 0
+        for p in reversed(self.params):
+            nb = p.numel() * p.element_size()
+            if cur and (cur_bytes + nb > cap or cur[0].dtype != p.dtype or cur[0].device != p.device):
+                self._close(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nb
+        if cur:
+            self._close(cur)
+        self._slot = {}
+        for bi, (_, slots) in enumerate(self.buckets):
+            for p, off, n in slots:
+                self._slot[id(p)] = (bi, off, n)
+        self._pending = [0] * len(self.buckets)
+        self._work = [None] * len(self.buckets)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self.reset()
+
+    def _close(self, plist):
+        total = sum(p.numel() for p in plist)
+        flat = torch.zeros(total, dtype=plist[0].dtype, device=plist[0].device)
+        slots, off = [], 0
+        for p in plist:
+            slots.append((p, off, p.numel()))
+            off += p.numel()
+        self.buckets.append((flat, slots))
+
+    def reset(self):
+        """Call before each backward (after optimizer.zero_grad())."""
+        for bi, (flat, slots) in enumerate(self.buckets):
+            self._pending[bi] = len(slots)
+            self._work[bi] = None
+            flat.zero_()
+        self._seen = set()
+
+    def _on_grad(self, p):
+        if id(p) in self._seen:  # a parameter used twice accumulates twice: the slot is refreshed at finish()
+            return
+        self._seen.add(id(p))
+        bi, off, n = self._slot[id(p)]
+        flat = self.buckets[bi][0]
+        flat[off:off + n].copy_(p.grad.reshape(-1))
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0:
+            self._launch(bi)
+
+    def _launch(self, bi):
+        if self.world > 1:
+            self._work[bi] = self.dist.all_reduce(self.buckets[bi][0], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self):
+        """Wait for every bucket, average, and write the result back into the parameters' .grad."""
+        for bi, (flat, slots) in enumerate(self.buckets):
+            if self._pending[bi] > 0:  # some parameters of this bucket got no gradient this step: reduce what is there (zeros for them)
+                self._pending[bi] = 0
+                self._launch(bi)
+        for bi, (flat, slots) in enumerate(self.buckets):
+            if self._work[bi] is not None:
+                self._work[bi].wait()
+            if self.world > 1:
+                flat.div_(self.world)
+            for p, off, n in slots:
+                if p.grad is not None or self.world > 1:
+                    g = flat[off:off + n].view_as(p)
+                    if p.grad is None:
+                        p.grad = g.clone()
+                    else:
+                        p.grad.copy_(g)
+
+    def payload_bytes(self):
+        return sum(f.numel() * f.element_size() for f, _ in self.buckets)
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+
+
+DEAD_PREFIXES = ("crossTR.decoder.0.", "crossTR.decoder.1.", "crossTR.decoder.2.", ".bert.embeddings.", ".bert.pooler.", "backbone.head.",
+                 "backbone.norm.", "feat_emb")
+
+
+def live_parameters(module):
+    """Parameters that can receive a gradient in the reference's forward (decoder layers 0-2, the BERT embedding and
+    pooler tables, the ConvNeXt classifier head and `feat_emb` are dead code whose parameters never reach the outputs)."""
+    return [p for n, p in module.named_parameters() if not any(d in n for d in DEAD_PREFIXES)]

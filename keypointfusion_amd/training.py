@@ -1,0 +1,219 @@
+"""Training-step pieces of the KPFusion path, first slice: the loss codec, the loss schedule of `train.py`, the
+optimiser set-up, and autograd Functions that put convolution / Linear forward and data-gradient on the HIP implicit GEMM.
+
+What exists here
+  * `joint2offset`      GFM.joint2offset (util/generateFeature.py:59-84): ground-truth offset / heat maps B x 4J x F x F.
+  * `offset2joint_weight`  the differentiable decode of GFM.offset2joint_weight (util/generateFeature.py:166-195) used INSIDE the loss
+                        (train.py:222-223: the coordinate loss back-propagates through the soft-argmax into the dense maps).
+  * `joint2heatmap`     GFM.joint2heatmap (util/generateFeature.py:584-600).
+  * `SmoothL1Loss`      model/loss.py:3-26 (quadratic below 0.01, linear above; mean over the last dim, then over the rest).
+  * `kpfusion_loss`     the stage-typed schedule of train.py:211-261 (stage_type [1,1,2,3,2,3], coord 100, deconv 1, spatial 10, sigma 3/2).
+  * `make_optimizer`    AdamW(lr 8e-4, wd 0.01) + StepLR(10, 0.1) (train.py:84-91,120; config.py).
+  * `Conv2dNHWC`        torch.autograd.Function: forward and data-gradient on kpf_conv2d_f32 (dgrad = the forward kernel on flipped /
+                        transposed weights; patchify convolutions: a GEMM + pixel un-shuffle), weight-gradient as a plain
+                        library GEMM (1x1) or torch.nn.grad.conv2d_weight (k > 1), bias-gradient a pixel reduction.
+These are torch tensors in, torch tensors out (autograd and the optimiser are PyTorch-ROCm's: host-side plumbing, as BASELINE.json's
+north_star puts it); the loss arithmetic itself is a handful of elementwise ops and reductions over B x 105 x 32 x 32 maps.
+What does NOT exist yet: a train-mode forward of the whole model (batch-statistics BatchNorm, dropout, backward through the fusion
+head) — `KPFusion.forward` still refuses `.train()`; see DESIGN.md §8.
+"""
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+STAGE_TYPE = (1, 1, 2, 3, 2, 3)  # config.py: depth backbone, RGB backbone, (RGB KFAM, depth KFAM) x 2
+COORD_WEIGHT, DECONV_WEIGHT = 100.0, 1.0
+SPATIAL_WEIGHT, SPATIAL_EPOCH = (10.0, 10.0, 10.0), (24, 24, 24)
+FEATURE_PARA = 0.8  # kernel size of the 'weight_offset' feature
+
+
+def _pixel_grid(Fs, device):
+    c = 2.0 * (torch.arange(Fs, device=device).float() + 0.5) / Fs - 1.0
+    return c.view(1, Fs).expand(Fs, Fs), c.view(Fs, 1).expand(Fs, Fs)  # u (column), v (row)
+
+
+def joint2offset(joint, img, kernel_size, feature_size):
+    """util/generateFeature.py:59-84.  joint B x J x 3 (normalised uvd), img B x 1 x S x S -> B x 4J x F x F: per joint the unit
+    offset (3 maps) from every pixel's (u, v, depth) to the joint and the closeness heat map, both masked to pixels within
+    `kernel_size` of the joint on the hand (depth < 0.99)."""
+    B = joint.shape[0]
+    Fs = feature_size
+    img = F.interpolate(img, size=[Fs, Fs])
+    J = joint.reshape(B, -1, 3).shape[1]
+    jf = joint.reshape(B, -1, 1, 1).repeat(1, 1, Fs, Fs)
+    u, v = _pixel_grid(Fs, joint.device)
+    coords = torch.stack((u, v), 0).unsqueeze(0).repeat(B, 1, 1, 1)
+    coords = torch.cat((coords, img), 1).repeat(1, J, 1, 1)
+    offset = (jf - coords).view(B, J, 3, Fs, Fs)
+    dist = torch.sqrt(torch.sum(torch.pow(offset, 2), dim=2) + 1e-8)
+    offset_norm = offset / dist.unsqueeze(2)
+    heatmap = (kernel_size - dist) / kernel_size
+    mask = heatmap.ge(0).float() * img.lt(0.99).float().view(B, 1, Fs, Fs)
+    offset_norm_mask = (offset_norm * mask.unsqueeze(2)).view(B, -1, Fs, Fs).float()
+    return torch.cat((offset_norm_mask, heatmap * mask), 1)
+
+
+def offset2joint_weight(offset, depth, kernel_size):
+    """util/generateFeature.py:166-195 with autograd intact (the inference path decodes with kpf_offset2joint_f32; the loss needs the
+    gradient of the soft-argmax).  offset B x 5J x F x F, depth B x 1 x S x S -> B x J x 3."""
+    B, ch, Fs, _ = offset.shape
+    J = ch // 5
+    if depth.shape[-1] != Fs:
+        depth = F.interpolate(depth, size=[Fs, Fs])
+    unit = offset[:, :J * 3].contiguous()
+    heat = offset[:, J * 3:J * 4].contiguous()
+    weight = offset[:, J * 4:].contiguous()
+    u, v = _pixel_grid(Fs, offset.device)
+    coords = torch.stack((u, v), 0).unsqueeze(0).repeat(B, 1, 1, 1)
+    coords = torch.cat((coords, depth), 1).repeat(1, J, 1, 1).view(B, J, 3, -1)
+    mask = depth.lt(0.99).float()
+    offset_mask = (unit * mask).view(B, J, 3, -1)
+    heat_mask = (heat * mask).view(B, J, -1)
+    w = F.softmax(weight.masked_fill(depth.gt(0.99), -1e8).view(B, J, -1), dim=-1)
+    dist = kernel_size - heat_mask * kernel_size
+    return torch.sum((offset_mask * dist.unsqueeze(2).repeat(1, 1, 3, 1) + coords) * w.unsqueeze(2).repeat(1, 1, 3, 1), dim=-1)
+
+
+def joint2heatmap(joint_uv, std, heatmap_size, sigma=1.5):
+    """util/generateFeature.py:584-600: Gaussian of the joint's (u, v) on the pixel-centre grid."""
+    B, J, _ = joint_uv.shape
+    dev = joint_uv.device
+    xs = (torch.arange(heatmap_size, device=dev).float() + 0.5).view(1, 1, 1, heatmap_size).repeat(B, J, heatmap_size, 1)
+    ys = (torch.arange(heatmap_size, device=dev).float() + 0.5).view(1, 1, heatmap_size, 1).repeat(B, J, 1, heatmap_size)
+    jx = ((joint_uv[:, :, 0] + 1) / 2 * heatmap_size).view(B, J, 1, 1).float()
+    jy = ((joint_uv[:, :, 1] + 1) / 2 * heatmap_size).view(B, J, 1, 1).float()
+    return torch.exp(-(torch.pow((xs - jx) / std, 2) + torch.pow((ys - jy) / std, 2)) / (2 * pow(sigma, 2)))
+
+
+class SmoothL1Loss(torch.nn.Module):
+    """model/loss.py:3-26 (not torch's SmoothL1Loss: the quadratic zone ends at 0.01 and the linear branch is 0.01 (|z| - 0.005))."""
+
+    def __init__(self, size_average=True):
+        super().__init__()
+        self.size_average = size_average
+
+    def forward(self, x, y):
+        assert x.shape == y.shape
+        z = (x - y).float()
+        mse_mask = (torch.abs(z) < 0.01).float()
+        l1_mask = (torch.abs(z) >= 0.01).float()
+        total = torch.mean(0.5 * torch.pow(mse_mask * z, 2) * mse_mask, dim=-1)
+        total = total + torch.mean(0.01 * (torch.abs(l1_mask * z) - 0.005) * l1_mask, dim=-1)
+        return total.mean() if self.size_average else total.sum()
+
+
+def kpfusion_loss(results, spatial_weight, img, uvd_gt, xyz_gt, epoch=0, stage_type=STAGE_TYPE, l1=None):
+    """The loss of one training iteration, train.py:211-261.  results: the 6 forward outputs, spatial_weight: the 2 spatial weights.
+    Returns (loss, parts) with parts a dict of the named scalar terms the reference logs."""
+    l1 = l1 or SmoothL1Loss()
+    loss = 0
+    parts = {}
+    feature_size = None
+    for index, st in enumerate(stage_type):
+        if st == 1:  # dense stage: pixel-wise maps + decoded joints (both streams decode with the DEPTH image, train.py:221)
+            pixel_pd = results[index]
+            feature_size = pixel_pd.size(-1)
+            pixel_gt = joint2offset(uvd_gt, img, FEATURE_PARA, feature_size)
+            joint_uvd = offset2joint_weight(pixel_pd, img, FEATURE_PARA)
+            loss_pixel = l1(pixel_pd[:, :pixel_gt.size(1)], pixel_gt) * DECONV_WEIGHT
+            loss_coord = l1(joint_uvd, uvd_gt) * COORD_WEIGHT
+            loss = loss + (loss_pixel + loss_coord)
+            parts["loss_pixel_%d" % index], parts["loss_coord_%d" % index] = loss_pixel, loss_coord
+        elif st in (2, 3):
+            loss_coord = l1(results[index], xyz_gt) * COORD_WEIGHT
+            loss = loss + loss_coord
+            parts["loss_coord_%d" % index] = loss_coord
+    for index, sw in enumerate(spatial_weight):
+        if epoch <= SPATIAL_EPOCH[index] and sw is not None:
+            hm_gt = joint2heatmap(uvd_gt[:, :, :2], FEATURE_PARA, feature_size, sigma=3 if index == 0 else 2)
+            gt = hm_gt / hm_gt.max()
+            ls = l1(sw, gt) * SPATIAL_WEIGHT[index]
+            loss = loss + ls
+            parts["loss_spatial_%d" % index] = ls
+    return loss, parts
+
+
+def make_optimizer(params, lr=8e-4, step_size=10, start_epoch=0):
+    """train.py:84-91,120 with config.py's defaults: AdamW(weight_decay 0.01) over all parameters + StepLR(step_size, 0.1)."""
+    opt = torch.optim.AdamW([{"params": list(params), "initial_lr": lr}], lr=lr, weight_decay=0.01)
+    return opt, torch.optim.lr_scheduler.StepLR(opt, step_size=step_size, gamma=0.1, last_epoch=start_epoch)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# convolution / Linear with forward and data-gradient on the HIP implicit GEMM
+# ----------------------------------------------------------------------------------------------------------------
+class Conv2dNHWC(torch.autograd.Function):
+    """y = conv2d(x, w) + b on NHWC activations [B, H, W, Cin] (fp32, HIP device), weight in the reference's OIHW layout.
+    forward : kpf_conv2d_f32 (f32-input MFMA implicit GEMM).
+    backward: dX  = kpf_conv2d_f32 of dY with the spatially flipped, channel-transposed weight (stride 1, any padding); for patchify
+                    convolutions (kernel == stride, pad 0) a 1x1 GEMM dY @ W[N][(ky,kx,c)] followed by the pixel un-shuffle;
+              dW  = dY^T X as a library GEMM for 1x1, torch.nn.grad.conv2d_weight otherwise (weight gradients are plain reductions
+                    over pixels: not on the hand-written path yet);
+              db  = sum of dY over pixels.
+    Linear layers are the 1x1 case on a [rows, 1, 1, K] view."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad):
+        from .engine import Act, PackedConv, conv
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+        B, H, W, Cin = x.shape
+        N, Cw, KH, KW = weight.shape
+        assert Cw == Cin and Cin % 4 == 0, "Conv2dNHWC: input channels must match and be a multiple of 4"
+        patch = stride == KH == KW and pad == 0 and stride > 1
+        pc = PackedConv(weight, bias, x.device, stride=stride, pad=pad, patchify=patch)
+        xa = Act(x.contiguous().view(-1), B, H, W, Cin)
+        out = conv(pc, xa)
+        ctx.save_for_backward(x, weight)
+        ctx.conf = (stride, pad, patch, bias is not None)
+        return out.buf.view(out.B, out.H, out.W, out.C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .engine import Act, PackedConv, conv
+        x, weight = ctx.saved_tensors
+        stride, pad, patch, has_bias = ctx.conf
+        B, H, W, Cin = x.shape
+        N, _, KH, KW = weight.shape
+        dy = dy.contiguous()
+        OH, OW = dy.shape[1], dy.shape[2]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if patch:  # dX[b, oy*s+ky, ox*s+kx, c] = sum_n dY[b,oy,ox,n] W[n,c,ky,kx]: rows of a GEMM, then un-shuffle
+                wt = weight.permute(2, 3, 1, 0).reshape(KH * KW * Cin, N)  # [(ky,kx,c)][n]
+                pc = PackedConv(wt, None, x.device)
+                g = conv(pc, Act(dy.view(-1), B, OH, OW, N)).buf.view(B, OH, OW, KH, KW, Cin)
+                dx = g.permute(0, 1, 3, 2, 4, 5).reshape(B, OH * KH, OW * KW, Cin)
+                if dx.shape[1] != H or dx.shape[2] != W:  # rows / columns the strided convolution never read
+                    dx = F.pad(dx, (0, 0, 0, W - dx.shape[2], 0, H - dx.shape[1]))
+            else:
+                if stride != 1:
+                    raise NotImplementedError("Conv2dNHWC.backward: data gradient of strided non-patchify convolutions is not built yet")
+                wt = weight.flip(2, 3).permute(1, 0, 2, 3).contiguous()  # [Cin][N][KH][KW], taps mirrored
+                npad = (N + 3) // 4 * 4
+                if npad != N:  # the kernel needs a multiple of 4 input channels: zero-pad dY's channel axis
+                    dy_in = F.pad(dy, (0, npad - N))
+                    wt = F.pad(wt, (0, 0, 0, 0, 0, npad - N))
+                else:
+                    dy_in = dy
+                pc = PackedConv(wt, None, x.device, stride=1, pad=KH - 1 - pad)
+                dx = conv(pc, Act(dy_in.contiguous().view(-1), B, OH, OW, npad)).buf.view(B, H, W, Cin)
+        if ctx.needs_input_grad[1]:
+            if KH == 1 and KW == 1 and stride == 1:
+                dw = (dy.view(-1, N).t() @ x.reshape(-1, Cin)).view(N, Cin, 1, 1)
+            else:
+                dw = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2), weight.shape, dy.permute(0, 3, 1, 2), stride=stride, padding=pad)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dy.view(-1, N).sum(0)
+        return dx, dw, db, None, None
+
+
+def conv2d_nhwc(x, weight, bias=None, stride=1, pad=0):
+    return Conv2dNHWC.apply(x, weight, bias, stride, pad)
+
+
+def linear_hip(x, weight, bias=None):
+    """nn.Linear on rows [..., K] through the same Function (a 1x1 convolution over a [rows, 1, 1, K] view)."""
+    K = x.shape[-1]
+    y = Conv2dNHWC.apply(x.reshape(-1, 1, 1, K), weight.view(weight.shape[0], K, 1, 1), bias, 1, 0)
+    return y.view(*x.shape[:-1], weight.shape[0])
