@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void offset2joint_kernel(const float* __restri
 
 // ---------------------------------------------------------------------------------------------------------------
 // a9: per point the 4 nearest feature pixels (dataloader/loader.py:936-967) without materialising B x N x F^2.
-// grid (ceil(N/256), B); the F*F pixel positions are rebuilt in LDS per workgroup (12 KB at F=32).
+// grid (ceil(N/32), B): 32 points per workgroup, 8 lanes per point; the F*F pixel positions are rebuilt in LDS per workgroup (12 KB at F=32).
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void img2pcl_top4_kernel(const float* __restrict__ pcl, const float* __restrict__ depth,
                                                            const float* __restrict__ center, const float* __restrict__ Minv,
@@ -242,25 +242,59 @@ __global__ __launch_bounds__(256) void img2pcl_top4_kernel(const float* __restri
     }
   }
   __syncthreads();
-  const int n = blockIdx.x * 256 + tid;
-  if (n >= N) return;
-  const float* q = pcl + ((long)b * N + n) * 3;
+  // 8 lanes per point: lane s scans the pixels p = s, s+8, s+16, .. (neighbouring lanes read neighbouring LDS words) with a branch-free
+  // sorted insert, skipped for the whole wave while no lane has a candidate below its 4th best; the 8 sorted lists are then merged by
+  // lane 0 of the group with the comparison (distance, pixel index) — so the result is the list sorted by distance with the lower
+  // index first among equal distances, exactly what a sequential scan with a strict < produces.
+  const int sub = tid & 7;
+  const int n = blockIdx.x * 32 + (tid >> 3);
+  const int nc = n < N ? n : N - 1;  // (idle groups still take part in the shuffles)
+  const float* q = pcl + ((long)b * N + nc) * 3;
   const float qx = q[0], qy = q[1], qz = q[2];
   float d0 = INFINITY, d1 = INFINITY, d2 = INFINITY, d3 = INFINITY;
-  int i0 = 0, i1 = 0, i2 = 0, i3 = 0;
-  for (int p = 0; p < P; ++p) {
+  int i0 = 0x7fffffff, i1 = 0x7fffffff, i2 = 0x7fffffff, i3 = 0x7fffffff;
+  auto insert = [&](float dd, int p) {  // (dd, p) < (d_k, i_k) lexicographically
+    const bool c0 = dd < d0 || (dd == d0 && p < i0), c1 = dd < d1 || (dd == d1 && p < i1);
+    const bool c2 = dd < d2 || (dd == d2 && p < i2), c3 = dd < d3 || (dd == d3 && p < i3);
+    d3 = c2 ? d2 : (c3 ? dd : d3);
+    i3 = c2 ? i2 : (c3 ? p : i3);
+    d2 = c1 ? d1 : (c2 ? dd : d2);
+    i2 = c1 ? i1 : (c2 ? p : i2);
+    d1 = c0 ? d0 : (c1 ? dd : d1);
+    i1 = c0 ? i0 : (c1 ? p : i1);
+    d0 = c0 ? dd : d0;
+    i0 = c0 ? p : i0;
+  };
+  for (int p = sub; p < P; p += 8) {
     const float dx = qx - pix[3 * p], dy = qy - pix[3 * p + 1], dz = qz - pix[3 * p + 2];
     const float dd = (dx * dx + dy * dy) + dz * dz;
-    if (dd < d3) {
-      if (dd < d2) {
-        d3 = d2; i3 = i2;
-        if (dd < d1) {
-          d2 = d1; i2 = i1;
-          if (dd < d0) { d1 = d0; i1 = i0; d0 = dd; i0 = p; } else { d1 = dd; i1 = p; }
-        } else { d2 = dd; i2 = p; }
-      } else { d3 = dd; i3 = p; }
+    if (__builtin_amdgcn_ballot_w64(dd < d3) != 0) {  // wave-uniform: within a lane p only grows, so an equal distance never enters
+      const bool c0 = dd < d0, c1 = dd < d1, c2 = dd < d2, c3 = dd < d3;
+      d3 = c2 ? d2 : (c3 ? dd : d3);
+      i3 = c2 ? i2 : (c3 ? p : i3);
+      d2 = c1 ? d1 : (c2 ? dd : d2);
+      i2 = c1 ? i1 : (c2 ? p : i2);
+      d1 = c0 ? d0 : (c1 ? dd : d1);
+      i1 = c0 ? i0 : (c1 ? p : i1);
+      d0 = c0 ? dd : d0;
+      i0 = c0 ? p : i0;
     }
   }
+  const float m0 = d0, m1 = d1, m2 = d2, m3 = d3;
+  const int j0 = i0, j1 = i1, j2 = i2, j3 = i3;
+  const int base = (tid & 63) & ~7;
+#pragma unroll
+  for (int s2 = 1; s2 < 8; ++s2) {
+    const float e0 = __shfl(m0, base + s2, 64), e1 = __shfl(m1, base + s2, 64), e2 = __shfl(m2, base + s2, 64), e3 = __shfl(m3, base + s2, 64);
+    const int k0 = __shfl(j0, base + s2, 64), k1 = __shfl(j1, base + s2, 64), k2 = __shfl(j2, base + s2, 64), k3 = __shfl(j3, base + s2, 64);
+    if (sub == 0) {
+      insert(e0, k0);
+      insert(e1, k1);
+      insert(e2, k2);
+      insert(e3, k3);
+    }
+  }
+  if (sub != 0 || n >= N) return;
   const float c0 = 1.0f / (d0 + 1e-8f), c1 = 1.0f / (d1 + 1e-8f), c2 = 1.0f / (d2 + 1e-8f), c3 = 1.0f / (d3 + 1e-8f);
   const float cs = (((c0 + c1) + c2) + c3) + 1e-8f;
   float* co = closeness + ((long)b * N + n) * 4;
@@ -540,42 +574,77 @@ __global__ __launch_bounds__(256) void heat_gam_gate_kernel(const float* __restr
 // ---------------------------------------------------------------------------------------------------------------
 // a14 part 2: img_feat_j[b][j][c] = sum_p Gw[b][j][p] * relu(feat[b][p][c]) + b_fc   (since the gate is >= 0,
 // relu(g*f) = g*relu(f): SURVEY a14), optionally relu((. + prev)/2) for block 2 (model/model.py:343-344).
-// grid (3, B): 7 joints per workgroup, 128 channels x 2 pixel halves.
+// Per sample this is the GEMM (21 x P) @ (P x 128) of model/model.py:336-341 on the f32 matrix cores (v_mfma_f32_16x16x4_f32):
+// grid (4, B): a workgroup owns 32 channels of one sample, its 4 waves = 2 channel tiles x 2 pixel halves; a wave multiplies both
+// joint tiles (21 joints padded to 32) against its 16 channels over P/2 pixels, fragments straight from global memory (the gate
+// rows as one 16-byte load per 16 pixels, the features as four 64-byte row segments per load: each 128-byte line is used by the
+// workgroup's two channel tiles), the two pixel halves are added through LDS in a fixed order (deterministic).
+// Within a 16-pixel block, k-step e of lane group g multiplies pixel 4g+e — the same permutation on both operands.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gate_reduce_kernel(const float* __restrict__ Gw, const float* __restrict__ feat,
                                                           const float* __restrict__ bfc, const float* __restrict__ prev,
                                                           float* __restrict__ out, int P) {
-  extern __shared__ __attribute__((aligned(16))) float gl[];  // [7][P] gate rows of this workgroup's joints, then part[7][128]
-  float* part = gl + 7 * P;
-  const int jc = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  const int c = tid & 127, h = tid >> 7;
-  const float* g = Gw + ((long)b * J + jc * 7) * P;
-  for (int i = tid; i < 7 * P / 4; i += 256) *reinterpret_cast<f32x4*>(gl + 4 * i) = *reinterpret_cast<const f32x4*>(g + 4 * i);
-  __syncthreads();
-  const float* f = feat + (long)b * P * 128 + c;
-  float acc[7];
+  __shared__ float part[2][32][17];  // [channel tile][joint][channel] partial sums of the second pixel half
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ct = wave & 1, ph = wave >> 1;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int c0 = blockIdx.x * 32 + ct * 16;
+  const int j0 = fr, j1 = (16 + fr) < J ? (16 + fr) : J - 1;  // rows of the second joint tile beyond 20 are never stored
+  const float* g0 = Gw + ((long)b * J + j0) * P;
+  const float* g1 = Gw + ((long)b * J + j1) * P;
+  const float* f = feat + (long)b * P * 128 + c0 + fr;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const int pbeg = ph * (P / 2), pend = pbeg + P / 2;
+  // the loads of block p+16 are in flight while block p is multiplied (explicit register double buffer: one memory round trip per
+  // block would otherwise be exposed 32 times)
+  f32x4 a0, a1, na0, na1;
+  float v[4], nv[4];
+  {
+    const int pk = pbeg + 4 * fg;
+    a0 = *reinterpret_cast<const f32x4*>(g0 + pk);
+    a1 = *reinterpret_cast<const f32x4*>(g1 + pk);
 #pragma unroll
-  for (int j = 0; j < 7; ++j) acc[j] = 0.f;
-  const int p0 = h * (P / 2), p1 = h ? P : P / 2;
-#pragma unroll 4
-  for (int p = p0; p < p1; ++p) {
-    const float v = fmaxf(f[(long)p * 128], 0.f);
-#pragma unroll
-    for (int j = 0; j < 7; ++j) acc[j] += gl[j * P + p] * v;
+    for (int e = 0; e < 4; ++e) v[e] = f[(long)(pk + e) * 128];
   }
-  if (h) {
+  for (int p = pbeg; p < pend; p += 16) {
+    const int pn = (p + 16 < pend ? p + 16 : p) + 4 * fg;  // (the last block re-loads itself: no branch around the loads)
+    na0 = *reinterpret_cast<const f32x4*>(g0 + pn);
+    na1 = *reinterpret_cast<const f32x4*>(g1 + pn);
 #pragma unroll
-    for (int j = 0; j < 7; ++j) part[j * 128 + c] = acc[j];
+    for (int e = 0; e < 4; ++e) nv[e] = f[(long)(pn + e) * 128];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float r = fmaxf(v[e], 0.f);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(r, a0[e], acc0, 0, 0, 0);  // A = features (row = channel), B = gate (col = joint)
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(r, a1[e], acc1, 0, 0, 0);
+    }
+    a0 = na0;
+    a1 = na1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = nv[e];
+  }
+  // accumulator: column = lane & 15 = joint within the tile, rows 4*fg + r = channel within the tile
+  if (ph == 1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      part[ct][fr][4 * fg + r] = acc0[r];
+      part[ct][16 + fr][4 * fg + r] = acc1[r];
+    }
   }
   __syncthreads();
-  if (!h) {
+  if (ph == 0) {
     const float bb = bfc[0];
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
-      float v = (acc[j] + part[j * 128 + c]) + bb;
-      const long o = ((long)b * J + jc * 7 + j) * 128 + c;
-      if (prev) v = fmaxf((v + prev[o]) / 2.0f, 0.f);
-      out[o] = v;
+    for (int t = 0; t < 2; ++t) {
+      const int j = 16 * t + fr;
+      if (j >= J) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = ((t ? acc1[r] : acc0[r]) + part[ct][j][4 * fg + r]) + bb;
+        const long o = ((long)b * J + j) * 128 + c0 + 4 * fg + r;
+        if (prev) v = fmaxf((v + prev[o]) / 2.0f, 0.f);
+        out[o] = v;
+      }
     }
   }
 }
@@ -608,7 +677,7 @@ extern "C" int kpf_img2pcl_top4_f32(const float* pcl, const float* depth, const 
                                     int img_size, int flip, void* stream) {
   KPF_REQUIRE(pcl && depth && center && Minv && cube && cam && closeness && index && B > 0 && N > 0 && F * F >= 4 && F * F * 12 <= 64 * 1024,
               "kpf_img2pcl_top4_f32: bad arguments");
-  hipLaunchKernelGGL(img2pcl_top4_kernel, dim3((N + 255) / 256, B), dim3(256), (size_t)F * F * 3 * sizeof(float), ST(stream), pcl,
+  hipLaunchKernelGGL(img2pcl_top4_kernel, dim3((N + 31) / 32, B), dim3(256), (size_t)F * F * 3 * sizeof(float), ST(stream), pcl,
                      depth, center, Minv, cube, cam, closeness, index, img_xyz, N, S, F, (float)img_size / 2.0f, (float)flip);
   return kpf_check_launch("kpf_img2pcl_top4_f32");
 }
@@ -657,8 +726,7 @@ extern "C" int kpf_heat_gam_gate_f32(const float* r3d, const float* img_xyz, con
 
 extern "C" int kpf_gate_reduce_f32(const float* Gw, const float* feat, const float* bfc, const float* prev, float* out, int B, int P,
                                    void* stream) {
-  KPF_REQUIRE(Gw && feat && bfc && out && B > 0 && P % 4 == 0 && P <= 4096, "kpf_gate_reduce_f32: bad arguments");
-  hipLaunchKernelGGL(gate_reduce_kernel, dim3(3, B), dim3(256), (size_t)(7 * P + 7 * 128) * sizeof(float), ST(stream), Gw, feat, bfc, prev,
-                     out, P);
+  KPF_REQUIRE(Gw && feat && bfc && out && B > 0 && P % 32 == 0 && kpf_aligned16(Gw), "kpf_gate_reduce_f32: bad arguments (P %% 32 == 0)");
+  hipLaunchKernelGGL(gate_reduce_kernel, dim3(4, B), dim3(256), 0, ST(stream), Gw, feat, bfc, prev, out, P);
   return kpf_check_launch("kpf_gate_reduce_f32");
 }

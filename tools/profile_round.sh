@@ -1,0 +1,22 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence of a round on the GPU box (run through gpurun from the repo root):  bash tools/profile_round.sh r02
+# kernel-trace statistics of the headline command (both backbones on one stream, so per-kernel durations are each kernel's own) and the
+# two PMC passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass) of the same command; summaries land in gpurun_out/<tag>_*.
+TAG=${1:-r02}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+CMD="$ROOT/bench.py --serial-streams --no-cpu-baseline --no-split-record"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_f32 -- python3 $CMD --steps 15 > $OUT/prof_${TAG}_f32.log 2>&1
+cp $(find $OUT/prof_${TAG}_f32 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats.csv
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_${TAG}_fetch -- python3 $CMD --steps 3 --warmup 1 > $OUT/pmc_${TAG}_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_${TAG}_write -- python3 $CMD --steps 3 --warmup 1 > $OUT/pmc_${TAG}_write.log 2>&1
+python3 $ROOT/tools/collect_traffic.py $OUT/pmc_${TAG}_fetch $OUT/pmc_${TAG}_write $OUT/${TAG}_traffic.json igemm_f32_kernel
+for W in full128 full128_bf16 cnb512_f16; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_$W -- python3 $ROOT/bench.py --workload $W --serial-streams --no-cpu-baseline --no-split-record --steps 10 > $OUT/prof_${TAG}_$W.log 2>&1
+  cp $(find $OUT/prof_${TAG}_$W -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_${W}_kernel_stats.csv
+done
+# keep the merge small: the raw traces stay on the box
+for d in $OUT/prof_${TAG}_* $OUT/pmc_${TAG}_fetch $OUT/pmc_${TAG}_write; do [ -d "$d" ] && rm -rf "$d"; done
+ls -la $OUT | grep ${TAG}_
