@@ -488,6 +488,30 @@ def test_split_gemm_is_as_accurate_as_fp32(M, N, K, wscale):
         assert float((got - want).abs().max() / want.abs().max()) < 2e-6
 
 
+def test_split_operand_precision_floor_is_what_the_docs_say():
+    """split operands are stored unscaled, so an element of magnitude |x| keeps about 25 + log2|x| bits (22 from |x| = 1/8
+    up).  With every activation ~1e-4 the split GEMM is therefore only ~12-bit accurate ELEMENTWISE — which is why the engine uses it
+    solely behind LayerNorm / GELU outputs with a pack-time bound — while the f32-input MFMA (the default) stays at fp32 accuracy."""
+    from keypointfusion_amd.engine import Act, PackedConv, conv
+    dev = _dev()
+    g = torch.Generator().manual_seed(4)
+    M, N, K = 512, 128, 256
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    pc = PackedConv(w, None, dev)
+    for scale, lo_bits, hi_bits in ((1.0, 19, 30), (1e-4, 9, 15)):
+        a = torch.randn(M, K, generator=g).abs() * scale + scale  # one sign: no cancellation, so the elementwise relative error is meaningful
+        wp = w.abs()
+        pcp = PackedConv(wp, None, dev)
+        ref = a.double() @ wp.double().t()
+        o32 = conv(pcp, Act(a.to(dev).view(-1), M, 1, 1, K)).buf.view(M, N).cpu().double()
+        osp = conv(pcp, Act(to_split(a).to(dev).view(-1), M, 1, 1, K, split=True)).buf.view(M, N).cpu().double()
+        e32 = float(((o32 - ref).abs() / ref).max())
+        esp = float(((osp - ref).abs() / ref).max())
+        assert e32 < 2e-6, (scale, e32)                                  # IEEE fp32 at any magnitude
+        assert 2.0 ** -hi_bits < esp < 2.0 ** -lo_bits, (scale, esp)     # the documented floor, neither better nor worse
+    del pc
+
+
 def test_split_layernorm_producers():
     from keypointfusion_amd import lib as L
     from keypointfusion_amd.engine import _ptr, _stream
