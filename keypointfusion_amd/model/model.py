@@ -44,6 +44,7 @@ class KPFusion(nn.Module):
         # storage precision of the backbones: "f32" (the reference's arithmetic, default), "bf16" or "f16" (16-bit activations and
         # weights, fp32 accumulation; ConvNeXt families; the fusion head stays fp32) — set before the first forward or at any time
         self.precision = "f32"
+        self.train_dropout = 0.1  # dropout probability of the transformer layers in train mode (config/config.json; transfusion_head.py:95)
         self.use_graphs = False  # opt-in: replay each forward from a captured hipGraph (eval / no_grad, fixed shapes)
 
     # -- weight repacking ------------------------------------------------------------------------------------
@@ -99,17 +100,20 @@ class KPFusion(nn.Module):
 
     def forward(self, img_rgb, img, pcl, loader, center, M, cube, cam_para, kernel=0.8, writer=None, ii=0):
         self._require_gpu(img)
-        if self.training:
-            # train-mode semantics (batch-statistics BatchNorm, dropout, autograd through every kernel) are SURVEY §8 row f1 and
-            # are not built; silently running eval arithmetic under model.train() would be a wrong answer, so refuse.
-            raise NotImplementedError("keypointfusion_amd.KPFusion implements the inference forward: call .eval() "
-                                      "(the training step is not built yet)")
         if img.shape[-1] != 128:
             # the reference hard-codes nn.Linear(32*32, 1) (model/model.py:264): the full model exists at S=128 only
             raise RuntimeError("mat1 and mat2 shapes cannot be multiplied: the fusion block needs 128x128 crops "
                                "(got %d); use forward_backbones() for other sizes" % img.shape[-1])
         img_size = int(getattr(loader, "img_size", 128))
         flip = int(getattr(loader, "flip", 1))
+        if self.training:
+            # train mode: batch-statistics BatchNorm, dropout, autograd-connected outputs on the module's own
+            # Parameters — keypointfusion_amd/train_graph.py (convolutions / Linears forward + data-gradient on the HIP GEMM)
+            if self.precision != "f32":
+                raise NotImplementedError("train mode runs fp32 (KPFusion.precision = 'f32'); reduced-precision training is not built")
+            from ..train_graph import TrainGraph
+            with torch.cuda.device(img.device):
+                return TrainGraph(self).forward(img_rgb, img, pcl, center, M, cube, cam_para, float(kernel), img_size, flip)
         plan = self._plan(img.device)
         with torch.cuda.device(img.device):
             if self.use_graphs and not torch.is_grad_enabled():

@@ -1,0 +1,380 @@
+"""Train-mode forward of KPFusion: the same graph as the inference engine, differentiable.
+
+`KPFusion.forward` under `.train()` comes here.  The reference trains with batch-statistics BatchNorm, dropout in the transformer
+layers and autograd through everything (`train.py:209-265`, `model/model.py:287-426`); this module builds that graph on the module's
+own Parameters so that `loss.backward()` fills their `.grad`:
+
+  * every convolution / Linear whose shape the HIP implicit GEMM takes (input channels a multiple of 4; stride 1 or a patchify
+    kernel == stride) runs forward AND data-gradient on `kpf_conv2d_f32` through `training.Conv2dNHWC` (weight gradients: library GEMM /
+    torch.nn.grad); the few that do not (the 1- and 3-channel stems, ResNet's strided 3x3 / 7x7) go through torch's convolution;
+  * normalisations, activations, the depthwise 7x7, gathers, softmaxes and the 21-token attention use PyTorch-ROCm ops with torch
+    autograd ("host code stays Python on PyTorch-ROCm for autograd", BASELINE.json north_star) — they are elementwise / reduction work
+    whose backward is generated, not hand-written, in this round;
+  * the integer decisions (top-4 pixels, ball-query sets) and the detached soft-argmax decode come from the HIP kernels of the
+    inference path (`kpf_img2pcl_top4_f32`, `kpf_offset2joint_f32`) or a no-grad torch restatement (ball query): no gradient flows
+    through them in the reference either (`model/model.py:308-309,324,327,404-405`).
+
+BatchNorm: per-replica batch statistics, running statistics updated in place with momentum 0.1 (PyTorch semantics, like the
+reference under DataParallel).  Dropout: `module.train_dropout` (default 0.1 = config/config.json hidden_dropout_prob /
+attention_probs_dropout_prob and the decoder layer's default, model/transfusion_head.py:95); the parity tests run with 0 because the
+reference's random stream cannot be reproduced.  Everything is fp32.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import lib as L
+from .engine import _ptr, _stream, crop_inverse
+from .training import conv2d_nhwc, linear_hip
+
+J = 21
+
+
+class TrainGraph:
+    def __init__(self, module):
+        self.m = module
+        self.t = dict(module.named_parameters())
+        self.t.update(dict(module.named_buffers()))
+        self.pd = float(getattr(module, "train_dropout", 0.1))
+        self.momentum = 0.1
+        # parity-test hook: ball-query index tensors to use instead of the computed ones (the sets are integer decisions taken around
+        # network outputs; a test that compares gradients with the reference's must compare on equal decisions) + a flip counter
+        self.ball_override = list(getattr(module, "_ball_override", None) or [])
+        self.ball_flips = 0
+
+    # ---- primitives ---------------------------------------------------------------------------------------------------------------
+    def has(self, name):
+        return name in self.t
+
+    def conv(self, x, p_w, p_b=None, stride=1, pad=0):
+        """NCHW in / out.  HIP forward + data-gradient where the implicit GEMM takes the shape, torch otherwise."""
+        w = self.t[p_w]
+        b = self.t[p_b] if p_b is not None else None
+        cin, k = w.shape[1], w.shape[2]
+        patch = stride == k and pad == 0 and stride > 1
+        if cin % 4 == 0 and (stride == 1 or patch) and w.shape[2] == w.shape[3]:
+            y = conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous(), w, b, stride, pad)
+            return y.permute(0, 3, 1, 2)
+        return F.conv2d(x, w, b, stride=stride, padding=pad)
+
+    def linear(self, x, p_w, p_b=None):
+        w = self.t[p_w]
+        b = self.t[p_b] if p_b is not None else None
+        if w.shape[1] % 4 == 0:
+            return linear_hip(x.contiguous(), w, b)
+        return F.linear(x, w, b)
+
+    def bn(self, x, p, eps=1e-5):
+        rm, rv = self.t[p + ".running_mean"], self.t[p + ".running_var"]
+        y = F.batch_norm(x, rm, rv, self.t[p + ".weight"], self.t[p + ".bias"], True, self.momentum, eps)
+        self.t[p + ".num_batches_tracked"].add_(1)
+        return y
+
+    def drop(self, x):
+        return F.dropout(x, self.pd, True) if self.pd > 0 else x
+
+    # ---- backbones (convNeXT/convnext.py, convNeXT/resnetUnet.py, model/resnet.py, model/resnetUnet.py, model/hourglass.py) -----------
+    def residual(self, p, x):
+        cin = x.shape[1]
+        out = F.relu(self.bn(x, p + ".bn1"))
+        out = self.conv(out, p + ".conv1.conv.weight", p + ".conv1.conv.bias")
+        out = F.relu(self.bn(out, p + ".bn2"))
+        out = self.conv(out, p + ".conv2.conv.weight", p + ".conv2.conv.bias", pad=1)
+        out = F.relu(self.bn(out, p + ".bn3"))
+        out = self.conv(out, p + ".conv3.conv.weight", p + ".conv3.conv.bias")
+        if cin != out.shape[1]:
+            x = self.conv(x, p + ".skip_layer.conv.weight", p + ".skip_layer.conv.bias")
+        return out + x
+
+    @staticmethod
+    def layernorm_cf(x, w, b, eps=1e-6):
+        u = x.mean(1, keepdim=True)
+        s = (x - u).pow(2).mean(1, keepdim=True)
+        x = (x - u) / torch.sqrt(s + eps)
+        return w[:, None, None] * x + b[:, None, None]
+
+    def convnext_block(self, p, x):
+        c = x.shape[1]
+        y = F.conv2d(x, self.t[p + ".dwconv.weight"], self.t[p + ".dwconv.bias"], padding=3, groups=c)
+        y = y.permute(0, 2, 3, 1)
+        y = F.layer_norm(y, (c,), self.t[p + ".norm.weight"], self.t[p + ".norm.bias"], 1e-6)
+        y = F.gelu(self.linear(y, p + ".pwconv1.weight", p + ".pwconv1.bias"))
+        y = self.linear(y, p + ".pwconv2.weight", p + ".pwconv2.bias")
+        y = self.t[p + ".gamma"] * y
+        return x + y.permute(0, 3, 1, 2)  # (drop_path_rate is 0 in the reference's constructor call: identity)
+
+    def convnext_features(self, p, x):
+        feats = []
+        i = 0
+        while self.has(p + ".downsample_layers.%d.0.weight" % i):
+            q = p + ".downsample_layers.%d" % i
+            if i == 0:
+                x = self.conv(x, q + ".0.weight", q + ".0.bias", stride=4)
+                x = self.layernorm_cf(x, self.t[q + ".1.weight"], self.t[q + ".1.bias"])
+            else:
+                x = self.layernorm_cf(x, self.t[q + ".0.weight"], self.t[q + ".0.bias"])
+                x = self.conv(x, q + ".1.weight", q + ".1.bias", stride=2)
+            j = 0
+            while self.has(p + ".stages.%d.%d.gamma" % (i, j)):
+                x = self.convnext_block(p + ".stages.%d.%d" % (i, j), x)
+                j += 1
+            feats.append(x)
+            i += 1
+        return feats
+
+    def resnet_features(self, p, x):
+        x = self.conv(x, p + ".conv1.weight", None, stride=2, pad=3)
+        x = F.relu(self.bn(x, p + ".bn1"))
+        x = F.max_pool2d(x, 3, 2, 1)
+        feats = []
+        for li in range(1, 5):
+            j = 0
+            while self.has(p + ".layer%d.%d.conv1.weight" % (li, j)):
+                q = p + ".layer%d.%d" % (li, j)
+                stride = 2 if (li > 1 and j == 0) else 1
+                idt = x
+                if self.has(q + ".conv3.weight"):
+                    out = F.relu(self.bn(self.conv(x, q + ".conv1.weight"), q + ".bn1"))
+                    out = F.relu(self.bn(self.conv(out, q + ".conv2.weight", None, stride, 1), q + ".bn2"))
+                    out = self.bn(self.conv(out, q + ".conv3.weight"), q + ".bn3")
+                else:
+                    out = F.relu(self.bn(self.conv(x, q + ".conv1.weight", None, stride, 1), q + ".bn1"))
+                    out = self.bn(self.conv(out, q + ".conv2.weight", None, 1, 1), q + ".bn2")
+                if self.has(q + ".downsample.0.weight"):
+                    idt = self.bn(self.conv(x, q + ".downsample.0.weight", None, stride, 0), q + ".downsample.1")
+                x = F.relu(out + idt)
+                j += 1
+            feats.append(x)
+        return feats
+
+    def unet(self, p, img):
+        convnext = self.has(p + ".backbone.downsample_layers.0.0.weight")
+        c1, c2, c3, c4 = self.convnext_features(p + ".backbone", img) if convnext else self.resnet_features(p + ".backbone", img)
+        up = lambda t: F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=False)
+        c4_up = up(self.residual(p + ".up4.0", c4))
+        c3_f = self.residual(p + ".fusion_layer4", torch.cat((c4_up, self.residual(p + ".skip_layer4", c3)), 1))
+        c3_up = up(self.residual(p + ".up3.0", c3_f))
+        c2_f = self.residual(p + ".fusion_layer3", torch.cat((c3_up, self.residual(p + ".skip_layer3", c2)), 1))
+        c2_up = up(self.residual(p + ".up2.0", c2_f))
+        feat = self.residual(p + ".fusion_layer2", torch.cat((c2_up, self.residual(p + ".skip_layer2", c1)), 1))
+        if convnext:
+            feat = self.residual(p + ".result_emb", feat)
+        res = torch.cat([self.conv(feat, p + ".finals.%d.weight" % i, p + ".finals.%d.bias" % i) for i in range(3)], 1)
+        return res, feat
+
+    # ---- geometry -------------------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def uvd2xyz(uvd, center, Minv, cube, cam, img_size, flip):
+        """dataloader/loader.py:775-789 with M^-1 given (differentiable in uvd)."""
+        B = uvd.shape[0]
+        uv = (uvd[:, :, 0:2] + 1) * (img_size / 2)
+        d = uvd[:, :, 2:] * (cube.view(B, 1, 3)[:, :, 2:] / 2.0) + center.view(B, 1, 3)[:, :, 2:]
+        hom = torch.cat((uv, torch.ones_like(d)), -1)
+        tr = torch.matmul(Minv.view(B, 1, 3, 3), hom.unsqueeze(-1)).squeeze(-1)[:, :, 0:2]
+        x = (tr[:, :, 0] - cam[:, 2:3]) * d[:, :, 0] / cam[:, 0:1]
+        y = flip * (tr[:, :, 1] - cam[:, 3:4]) * d[:, :, 0] / cam[:, 1:2]
+        xyz = torch.stack((x, y, d[:, :, 0]), -1)
+        return (xyz - center.view(B, 1, 3)) / (cube.view(B, 1, 3) / 2.0)
+
+    @staticmethod
+    def pixel_grid(Fs, dev):
+        c = 2.0 * (torch.arange(Fs, device=dev).float() + 0.5) / Fs - 1.0
+        return c.view(1, Fs).expand(Fs, Fs).reshape(-1), c.view(Fs, 1).expand(Fs, Fs).reshape(-1)
+
+    @staticmethod
+    def ball_query(radius, nsample, xyz, new_xyz):
+        """pointnet2_ops.ball_query semantics (first `nsample` indices in index order with d^2 < r^2, unfilled slots repeat the first
+        hit) — indices only, no gradient."""
+        with torch.no_grad():
+            B, N, _ = xyz.shape
+            S = new_xyz.shape[1]
+            d = new_xyz.unsqueeze(2) - xyz.unsqueeze(1)
+            d2 = d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1] + d[..., 2] * d[..., 2]
+            r32 = torch.tensor(radius, dtype=torch.float32, device=xyz.device)
+            within = d2 < (r32 * r32)
+            rank = torch.cumsum(within.long(), -1) - 1
+            first = torch.argmax(within.long(), -1)
+            idx = (first * within.any(-1).long()).unsqueeze(-1).repeat(1, 1, nsample)
+            sel = within & (rank < nsample)
+            b, s, n = torch.nonzero(sel, as_tuple=True)
+            idx[b, s, rank[b, s, n]] = n
+            return idx
+
+    # ---- fusion head (model/model.py:129-351, model/transfusion_head.py:137-173) -----------------------------------------------------------
+    def emb1d(self, p, x):
+        B, N, Cin = x.shape
+        w = self.t[p + ".0.weight"]  # [128, Cin, 1]
+        if Cin % 4 == 0:
+            y = linear_hip(x.reshape(B * N, Cin).contiguous(), w[:, :, 0], self.t[p + ".0.bias"])
+        else:
+            y = F.linear(x.reshape(B * N, Cin), w[:, :, 0], self.t[p + ".0.bias"])
+        return self.bn(y.view(B, N, -1).permute(0, 2, 1), p + ".1").permute(0, 2, 1)
+
+    @staticmethod
+    def gather_interp(feat, idx, clos):
+        B, C, _ = feat.shape
+        N, K = idx.shape[1:]
+        g = torch.gather(feat, -1, idx.view(B, 1, -1).expand(-1, C, -1)).view(B, C, N, K)
+        return torch.sum(g * clos.unsqueeze(1), -1).permute(0, 2, 1)
+
+    @staticmethod
+    def pcl_joint2offset(joint, pcl, kernel):
+        B, Jn, _ = joint.shape
+        N = pcl.shape[1]
+        off = joint.unsqueeze(2) - pcl.unsqueeze(1)
+        dis = torch.sqrt(torch.sum(torch.pow(off, 2), dim=-1))
+        unit = (off / (dis.unsqueeze(-1) + 1e-8)).permute(0, 1, 3, 2).reshape(B, Jn * 3, N)
+        clos = (kernel - dis) / kernel
+        mask = (clos >= 0).float() * (pcl[:, :, 2] < 0.99).float().unsqueeze(1)
+        clos = clos * mask
+        unit = unit * mask.view(B, Jn, 1, N).expand(B, Jn, 3, N).reshape(B, -1, N)
+        return torch.cat((unit, clos), 1).permute(0, 2, 1)
+
+    def conv1x1_rows(self, x_bchw, p_w, p_b):
+        """nn.Conv2d(k=1) of DESA on a B x C x J x S tensor as a Linear over rows."""
+        B, Cc, A, S = x_bchw.shape
+        w = self.t[p_w][:, :, 0, 0]
+        rows = x_bchw.permute(0, 2, 3, 1).reshape(-1, Cc)
+        y = linear_hip(rows.contiguous(), w, self.t[p_b]) if Cc % 4 == 0 else F.linear(rows, w, self.t[p_b])
+        return y.view(B, A, S, -1).permute(0, 3, 1, 2)
+
+    def desa(self, p, pcl_feat, node_feat, pcl_xyz, node_xyz):
+        B, Jn, C = node_feat.shape
+        xyz = torch.cat((pcl_xyz, node_xyz), 1)
+        feat = torch.cat((pcl_feat, node_feat), 1)
+        outs = []
+        for i, r in enumerate((0.1, 0.2, 0.4)):
+            idx = self.ball_query(r, 64, xyz, node_xyz)
+            if self.ball_override:
+                given = self.ball_override.pop(0).to(idx.device).long()
+                self.ball_flips += int((given != idx).any(-1).sum())
+                idx = given
+            flat = idx.reshape(B, Jn * 64)
+            gx = torch.gather(xyz, 1, flat.unsqueeze(-1).expand(-1, -1, 3)).view(B, Jn, 64, 3) - node_xyz.unsqueeze(2)
+            gf = torch.gather(feat, 1, flat.unsqueeze(-1).expand(-1, -1, C)).view(B, Jn, 64, C) - node_feat.unsqueeze(2)
+            gx = (gx / r).permute(0, 3, 1, 2)
+            gf = gf.permute(0, 3, 1, 2)
+            loc = self.bn(self.conv1x1_rows(gx, p + ".conv_l0_blocks.%d.weight" % i, p + ".conv_l0_blocks.%d.bias" % i), p + ".bn_l0_blocks.%d" % i)
+            ft = self.bn(self.conv1x1_rows(gf, p + ".conv_f0_blocks.%d.weight" % i, p + ".conv_f0_blocks.%d.bias" % i), p + ".bn_f0_blocks.%d" % i)
+            g = F.relu(loc + ft)
+            g = F.relu(self.bn(self.conv1x1_rows(g, p + ".conv_blocks.%d.0.weight" % i, p + ".conv_blocks.%d.0.bias" % i), p + ".bn_blocks.%d.0" % i))
+            outs.append(g.max(-1)[0])
+        outs.append(node_feat.permute(0, 2, 1))
+        cat = torch.cat(outs, 1)  # B x 512 x J
+        w = self.t[p + ".fusion.0.weight"][:, :, 0]
+        y = linear_hip(cat.permute(0, 2, 1).reshape(B * Jn, -1).contiguous(), w, self.t[p + ".fusion.0.bias"]).view(B, Jn, -1).permute(0, 2, 1)
+        return F.relu(self.bn(y, p + ".fusion.1")).permute(0, 2, 1)
+
+    def bert_layer(self, p, h, heads=4):
+        B, T, C = h.shape
+        hd = C // heads
+
+        def proj(n):
+            return self.linear(h, p + ".attention.self.%s.weight" % n, p + ".attention.self.%s.bias" % n).view(B, T, heads, hd).transpose(1, 2)
+
+        q, k, v = proj("query"), proj("key"), proj("value")
+        a = self.drop(torch.softmax(torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(hd), -1))
+        ctx = torch.matmul(a, v).transpose(1, 2).reshape(B, T, C)
+        o = self.drop(self.linear(ctx, p + ".attention.output.dense.weight", p + ".attention.output.dense.bias"))
+        h1 = F.layer_norm(o + h, (C,), self.t[p + ".attention.output.LayerNorm.weight"], self.t[p + ".attention.output.LayerNorm.bias"], 1e-12)
+        it = F.gelu(self.linear(h1, p + ".intermediate.dense.weight", p + ".intermediate.dense.bias"))
+        o2 = self.drop(self.linear(it, p + ".output.dense.weight", p + ".output.dense.bias"))
+        return F.layer_norm(o2 + h1, (C,), self.t[p + ".output.LayerNorm.weight"], self.t[p + ".output.LayerNorm.bias"], 1e-12)
+
+    def kp_interaction_tr(self, p, x):
+        T = x.shape[1]
+        h = self.linear(x, p + ".bert.img_embedding.weight", p + ".bert.img_embedding.bias") + self.t[p + ".bert.position_embeddings.weight"][:T]
+        h = self.drop(h)  # TR_Encoder applies the embedding dropout (model/model.py:84)
+        for l in range(4):
+            h = self.bert_layer(p + ".bert.encoder.layer.%d" % l, h)
+        score = self.linear(h, p + ".cls_head.weight", p + ".cls_head.bias") + self.linear(x, p + ".residual.weight", p + ".residual.bias")
+        return h, score
+
+    def decoder_layer(self, p, query, key, heads=4):
+        B, T, C = query.shape
+        hd = C // heads
+        qe = query + self.t[p + ".self_posembed.weight"][:T]
+        ke = key + self.t[p + ".cross_posembed.weight"][:T]
+        W, bqkv = self.t[p + ".multihead_attn.in_proj_weight"], self.t[p + ".multihead_attn.in_proj_bias"]
+        q = linear_hip(qe.contiguous(), W[:C], bqkv[:C]) * (float(hd) ** -0.5)
+        k = linear_hip(ke.contiguous(), W[C:2 * C], bqkv[C:2 * C])
+        v = linear_hip(ke.contiguous(), W[2 * C:], bqkv[2 * C:])
+        q = q.view(B, T, heads, hd).transpose(1, 2)
+        k = k.view(B, T, heads, hd).transpose(1, 2)
+        v = v.view(B, T, heads, hd).transpose(1, 2)
+        a = self.drop(torch.softmax(torch.matmul(q, k.transpose(-1, -2)), -1))
+        ctx = torch.matmul(a, v).transpose(1, 2).reshape(B, T, C)
+        o = self.linear(ctx, p + ".multihead_attn.out_proj.weight", p + ".multihead_attn.out_proj.bias")
+        x = F.layer_norm(query + self.drop(o), (C,), self.t[p + ".norm2.weight"], self.t[p + ".norm2.bias"], 1e-5)
+        f = self.linear(self.drop(F.relu(self.linear(x, p + ".linear1.weight", p + ".linear1.bias"))), p + ".linear2.weight", p + ".linear2.bias")
+        return F.layer_norm(x + self.drop(f), (C,), self.t[p + ".norm3.weight"], self.t[p + ".norm3.bias"], 1e-5)
+
+    def block(self, p, img_feat, img_feat_rgb, pcl, joint_xyz, clos, idx, img_offset, prev_feat, img_down, center, Minv, cube, cam,
+              img_size, flip):
+        from .training import joint2heatmap
+        B, C, H, W = img_feat.shape
+        pcl_off = self.pcl_joint2offset(joint_xyz, pcl, 0.8).detach()
+        pf = self.gather_interp(img_feat.reshape(B, C, -1), idx, clos)
+        pf_rgb = self.gather_interp(img_feat_rgb.reshape(B, C, -1), idx, clos)
+        pw = self.gather_interp(img_offset[:, J * 4:].reshape(B, J, -1), idx, clos).detach()
+        x = self.emb1d(p + ".pcl_feat_emb", pf) + self.emb1d(p + ".pcl_xyz_emb", pcl) + self.emb1d(p + ".pcl_pose_emb", torch.cat((pw, pcl_off), -1))
+        x = F.relu(x)
+        x = F.relu(x + self.emb1d(p + ".pcl_feat_emb_RGB", pf_rgb))
+        att = F.softmax(pw.permute(0, 2, 1), -1)
+        jf = torch.matmul(att, x)
+        jf = F.relu(self.emb1d(p + ".joint_feat_emb", jf) + self.emb1d(p + ".joint_xyz_emb", joint_xyz.detach()))
+        jf = self.desa(p + ".FA", x, jf, pcl, joint_xyz.detach())
+        h_init, r3d = self.kp_interaction_tr(p + ".init_TR", jf)
+        hm = joint2heatmap(r3d[:, :, :2], 0.8, H, sigma=1)
+        # geometry adjacency map (dataloader/loader.py:791-819): the joints go through the uvd -> xyz map again, like the pixels
+        u, v = self.pixel_grid(H, img_feat.device)
+        uvd_pix = torch.stack((u.expand(B, -1), v.expand(B, -1), img_down.reshape(B, -1)), -1)
+        ix = self.uvd2xyz(uvd_pix, center, Minv, cube, cam, img_size, flip)
+        jx = self.uvd2xyz(r3d, center, Minv, cube, cam, img_size, flip)
+        gam = (1 / (10 * torch.sum(torch.pow(ix.unsqueeze(1) - jx.unsqueeze(2), 2), dim=-1) + 1)).view(B, J, H, W)
+        sw = torch.sigmoid(self.conv(torch.cat([img_feat_rgb, hm], 1), p + ".atten_spatial.weight", p + ".atten_spatial.bias"))
+        wd = torch.sigmoid(self.t[p + ".weight_dis"])
+        g = wd * gam + (1 - wd) * sw
+        t = F.relu(g.unsqueeze(2) * img_feat_rgb.unsqueeze(1)).view(B, J, C, -1)
+        fj = F.linear(t, self.t[p + ".fc_spatial2joint_feature.weight"], self.t[p + ".fc_spatial2joint_feature.bias"]).view(B, J, C)
+        if prev_feat is not None:
+            fj = F.relu((fj + prev_feat) / 2)
+        dec = self.decoder_layer(p + ".crossTR.decoder.3", fj, h_init)
+        _, r2d = self.kp_interaction_tr(p + ".final_TR", torch.cat([r3d, dec], 2))
+        return r3d, r2d, fj, sw
+
+    def forward(self, img_rgb, img, pcl, center, M, cube, cam, kernel, img_size, flip):
+        """model/model.py:395-426 in train mode.  Returns ([6 results], [2 spatial weights], None), autograd-connected."""
+        lib = L.load()
+        dev = img.device
+        f = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        img_rgb, img, pcl, center, M, cube, cam = map(f, (img_rgb, img, pcl, center, M, cube, cam))
+        img_offset, img_feat = self.unet("backbone_d", img)
+        img_offset_rgb, img_feat_rgb = self.unet("backbone_rgb", img_rgb)
+        result = [img_offset, img_offset_rgb]
+        B, _, S, _ = img.shape
+        Fs = img_feat.shape[-1]
+        N = pcl.shape[1]
+        Minv = crop_inverse(M)
+        off_d = img_offset.detach().contiguous()  # model/model.py:404-405: the decode and the pose tokens see detached maps
+        joint_uvd = torch.empty(B, J, 3, device=dev)
+        joint_xyz = torch.empty(B, J, 3, device=dev)
+        L.check(lib.kpf_offset2joint_f32(_ptr(off_d), _ptr(img), _ptr(center), _ptr(Minv), _ptr(cube), _ptr(cam), _ptr(joint_uvd), _ptr(joint_xyz),
+                                         B, S, Fs, float(kernel), int(img_size), int(flip), _stream()), "kpf_offset2joint_f32")
+        clos = torch.empty(B, N, 4, device=dev)
+        index = torch.empty(B, N, 4, device=dev, dtype=torch.int32)
+        L.check(lib.kpf_img2pcl_top4_f32(_ptr(pcl), _ptr(img), _ptr(center), _ptr(Minv), _ptr(cube), _ptr(cam), _ptr(clos), _ptr(index), None,
+                                         B, N, S, Fs, int(img_size), int(flip), _stream()), "kpf_img2pcl_top4_f32")
+        idx = index.long()
+        img_down = F.interpolate(img, [Fs, Fs])
+        sws = []
+        prev = None
+        for i in (1, 2):
+            r3d, r2d, prev, sw = self.block("block%d" % i, img_feat, img_feat_rgb, pcl, joint_xyz, clos, idx, off_d, prev, img_down, center,
+                                            Minv, cube, cam, img_size, flip)
+            result += [r3d, r2d]
+            sws.append(sw)
+            joint_xyz = r2d
+        self.m.__dict__["_last_ball_flips"] = self.ball_flips
+        return result, sws, None

@@ -170,3 +170,71 @@ def test_linear_hip_autograd_and_sgd_step_reduce_the_loss():
         opt.step()
         losses.append(float(loss.detach()))
     assert losses[-1] < losses[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("net", ["convnext-tiny", "resnet-18"])
+def test_train_step_matches_the_reference_loss_and_gradients(net):
+    """One iteration of train.py:209-265 through the product: KPFusion in .train() mode (batch-statistics BatchNorm; dropout 0 like the
+    fixture), the loss schedule, loss.backward() — against what the imported reference produced on the same seeded weights and batch
+    (tests/golden/gen_golden_trainstep.py): the loss and its parts, which parameters receive a gradient, every per-parameter
+    gradient norm, updated BatchNorm running statistics; then an AdamW step must lower the loss."""
+    from conftest import synthetic_sd
+    from keypointfusion_amd.model.model import KPFusion
+    Zs = np.load(os.path.join(GOLDEN, "train_step_%s.npz" % net))
+    dev = torch.device("cuda:0")
+    m = KPFusion("KPFusion-" + net, "", 21, "dexycb", "")
+    m.load_state_dict(synthetic_sd("KPFusion-" + net), strict=True)
+    m = m.to(dev).train()
+    m.train_dropout = 0.0
+    B = 3
+    b = {k: torch.from_numpy(v).to(dev) for k, v in synthetic_batch(B, 128, seed=11).items()}
+    uvd_gt, xyz_gt = torch.from_numpy(Zs["uvd_gt"]).to(dev), torch.from_numpy(Zs["xyz_gt"]).to(dev)
+
+    class Loader:
+        img_size, flip = 128, 1
+
+    def step_loss(ball=None):
+        m._ball_override = ball
+        results, sws, _ = m(b["img_rgb"], b["img"], b["pcl"], Loader(), b["center"], b["M"], b["cube"], b["cam_para"], 0.8)
+        m._ball_override = None
+        return results, T.kpfusion_loss(results, sws, b["img"], uvd_gt, xyz_gt, epoch=0)
+
+    # ball-query sets are integer decisions taken around network outputs (joints equal to the reference's only to ~1e-6): the comparison
+    # runs on the reference's sets, and the product's own sets may differ from them only by a few boundary points
+    ball = [torch.from_numpy(Zs["ball_idx"][i].astype(np.int64)) for i in range(6)]
+    results, (loss, parts) = step_loss(ball)
+    assert m._last_ball_flips <= 4, m._last_ball_flips
+    assert all(r.requires_grad for r in results)
+    assert float((results[2].detach().cpu() - torch.from_numpy(Zs["r3d1"])).abs().max()) < 5e-4
+    assert float((results[5].detach().cpu() - torch.from_numpy(Zs["r2d2"])).abs().max()) < 5e-4
+    assert abs(float(loss.detach()) - float(Zs["loss"])) < 1e-5 * float(Zs["loss"]), (float(loss.detach()), float(Zs["loss"]))
+    for k, v in parts.items():
+        assert abs(float(v) - float(Zs[k])) < 1e-4 * max(float(Zs[k]), 1e-3), (k, float(v), float(Zs[k]))
+    loss.backward()
+    ref_norm = dict(zip([str(n) for n in Zs["grad_names"]], Zs["grad_norms"]))
+    got = {n: float(p.grad.double().norm()) for n, p in m.named_parameters() if p.grad is not None}
+    assert set(got) == set(ref_norm), (sorted(set(got) ^ set(ref_norm))[:10])  # exactly the reference's live parameters receive gradients
+    scale = max(ref_norm.values())
+    # (biases in front of a BatchNorm have a mathematically zero gradient: both sides hold rounding noise there, hence the floor)
+    bad = [(n, got[n], ref_norm[n]) for n in ref_norm if abs(got[n] - ref_norm[n]) > 5e-3 * ref_norm[n] + 2e-6 * scale]
+    assert not bad, "%d of %d gradient norms off: %s" % (len(bad), len(ref_norm), bad[:5])
+    # per top-level module, tighter
+    for top in ("backbone_d", "backbone_rgb", "block1", "block2"):
+        a = sum(v * v for n, v in got.items() if n.startswith(top)) ** 0.5
+        r = sum(v * v for n, v in ref_norm.items() if n.startswith(top)) ** 0.5
+        assert abs(a - r) < 5e-4 * r, (top, a, r)
+    sd = m.state_dict()
+    for k in [k for k in Zs.files if k.startswith("bn::")]:
+        assert float((sd[k[4:]].cpu() - torch.from_numpy(Zs[k])).abs().max()) < 1e-4 * (float(np.abs(Zs[k]).max()) + 1e-3), k
+    # an optimiser step on these gradients lowers the loss (same batch)
+    from keypointfusion_amd.parallel import live_parameters
+    opt, _ = T.make_optimizer(live_parameters(m), lr=2e-4)
+    opt.step()
+    with torch.no_grad():
+        _, (loss2, _) = step_loss()
+    assert float(loss2) < float(loss)
+    m.eval()  # and the module still serves inference afterwards (weights repacked from the updated parameters)
+    with torch.no_grad():
+        res_eval, _, _ = m(b["img_rgb"], b["img"], b["pcl"], Loader(), b["center"], b["M"], b["cube"], b["cam_para"], 0.8)
+    assert all(bool(torch.isfinite(t).all()) and not t.requires_grad for t in res_eval)
