@@ -44,6 +44,9 @@ WORKLOADS = {
     "full128": ("KPFusion-convnext-tiny", 128, 64, "f32", "full", "full model at configs[1]'s batch"),
     "full128_bf16": ("KPFusion-convnext-tiny", 128, 32, "bf16", "full", "configs[2]"),
     "cnb512_f16": ("KPFusion-convnext-base", 512, 64, "f16", "backbones", "configs[4]"),
+    # one training iteration of train.py:209-265 (forward in train mode, loss, backward, gradient all-reduce over RCCL when N > 1, AdamW
+    # step); fp32 — bf16 training is not built, so this is configs[3]'s schedule, not its precision
+    "train128": ("KPFusion-convnext-tiny", 128, 32, "f32", "train", "configs[3] (fp32)"),
 }
 
 
@@ -108,6 +111,10 @@ def main():
     NET, S, B0, precision, kind, cfg_name = WORKLOADS[args.workload]
     B = args.batch or B0
     backbones_only = kind == "backbones"
+    train = kind == "train"
+    if train:
+        args.no_graph = True
+        args.no_split_record = True
     if precision != "f32":
         args.no_split_record = True  # (the split record belongs to the fp32 workloads)
         if args.workload == "cnb512_f16":
@@ -119,6 +126,17 @@ def main():
     model.precision = precision
     hb = synthetic_batch(B, S, seed=1 + rank)
     batch = {k: torch.from_numpy(v).to(dev) for k, v in hb.items()}
+    reducer = opt = None
+    if train:
+        from keypointfusion_amd import training as T
+        from keypointfusion_amd.parallel import GradBucketReducer, live_parameters
+        model.train()
+        gg = torch.Generator().manual_seed(100 + rank)
+        uvd_gt = (torch.rand(B, 21, 3, generator=gg) * 1.2 - 0.6).to(dev)
+        xyz_gt = (torch.rand(B, 21, 3, generator=gg) * 1.2 - 0.6).to(dev)
+        live = live_parameters(model)
+        opt, _ = T.make_optimizer(live)
+        reducer = GradBucketReducer(live, dist if dist is not None else None)
 
     class _Loader:
         img_size, flip = 128, 1
@@ -126,6 +144,16 @@ def main():
     graph_on = [not args.no_graph and not args.serial_streams]
 
     def step():
+        if train:
+            opt.zero_grad(set_to_none=False)
+            reducer.reset()
+            results, sws, _ = model(batch["img_rgb"], batch["img"], batch["pcl"], _Loader(), batch["center"], batch["M"], batch["cube"],
+                                    batch["cam_para"], 0.8)
+            loss, _ = T.kpfusion_loss(results, sws, batch["img"], uvd_gt, xyz_gt, epoch=0)
+            loss.backward()
+            reducer.finish()
+            opt.step()
+            return
         with torch.no_grad():
             if backbones_only:
                 if graph_on[0]:
@@ -144,7 +172,8 @@ def main():
 
     def fresh_plan():
         model._plans.clear()
-        model._plan(dev).serial_streams = bool(args.serial_streams)
+        if not train:
+            model._plan(dev).serial_streams = bool(args.serial_streams)
 
     def timed(K, W):
         """W untimed steps, then exactly K steps between barrier + synchronize pairs; returns (seconds, host issue seconds)."""
@@ -160,7 +189,7 @@ def main():
 
     def instrumented():
         """Per-launch HIP events around every MFMA-kernel launch, both backbones on one stream (each duration is the kernel's own)."""
-        plan = model._plan(dev)
+        plan = model._plan(dev) if not train else type("P", (), {"serial_streams": False})()
         g = graph_on[0]
         graph_on[0] = False
         plan.serial_streams = True
@@ -267,7 +296,10 @@ def main():
         threads = torch.get_num_threads()
 
         def cpu_step():
-            if backbones_only:
+            if train:  # the reference's arithmetic for a training iteration is not restated on the CPU side: forward only, said in `sample`
+                with torch.no_grad():
+                    O.kpfusion_forward(sd, cb["img_rgb"], cb["img"], cb["pcl"], cb["center"], cb["M"], cb["cube"], cb["cam_para"], 0.8)
+            elif backbones_only:
                 O.backbones_forward(sd, cb["img_rgb"], cb["img"])
             else:
                 O.kpfusion_forward(sd, cb["img_rgb"], cb["img"], cb["pcl"], cb["center"], cb["M"], cb["cube"], cb["cam_para"], 0.8)
@@ -287,6 +319,7 @@ def main():
     if rank == 0:
         line = {
             "metric": "RGB-D img/sec fwd (B=64, 256x256)" if args.workload == "backbones256" else
+                      "RGB-D img/sec trained (fwd + loss + bwd + AdamW, B=%d, %dx%d, %s)" % (B, S, S, precision) if train else
                       "RGB-D img/sec fwd %s (B=%d, %dx%d, %s)" % ("backbones" if backbones_only else "full model", B, S, S, precision),
             "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -1,5 +1,6 @@
-"""Training-step pieces of the KPFusion path, first slice: the loss codec, the loss schedule of `train.py`, the
-optimiser set-up, and autograd Functions that put convolution / Linear forward and data-gradient on the HIP implicit GEMM.
+"""Training-step pieces of the KPFusion path: the loss codec, the loss schedule of `train.py`, the optimiser
+set-up, and autograd Functions that put convolution / Linear forward and data-gradient on the HIP implicit GEMM.  The train-mode
+forward that uses them is keypointfusion_amd/train_graph.py (reached through `KPFusion.forward` under `.train()`).
 
 What exists here
   * `joint2offset`      GFM.joint2offset (util/generateFeature.py:59-84): ground-truth offset / heat maps B x 4J x F x F.
@@ -14,8 +15,8 @@ What exists here
                         library GEMM (1x1) or torch.nn.grad.conv2d_weight (k > 1), bias-gradient a pixel reduction.
 These are torch tensors in, torch tensors out (autograd and the optimiser are PyTorch-ROCm's: host-side plumbing, as BASELINE.json's
 north_star puts it); the loss arithmetic itself is a handful of elementwise ops and reductions over B x 105 x 32 x 32 maps.
-What does NOT exist yet: a train-mode forward of the whole model (batch-statistics BatchNorm, dropout, backward through the fusion
-head) — `KPFusion.forward` still refuses `.train()`; see DESIGN.md §8.
+Not hand-written yet: weight-gradient GEMMs and the backward of the elementwise / normalisation / attention ops (torch autograd);
+reduced-precision training.  See DESIGN.md §8.
 """
 import ctypes as C
 
@@ -143,6 +144,33 @@ def make_optimizer(params, lr=8e-4, step_size=10, start_epoch=0):
 # ----------------------------------------------------------------------------------------------------------------
 # convolution / Linear with forward and data-gradient on the HIP implicit GEMM
 # ----------------------------------------------------------------------------------------------------------------
+class DevPack:
+    """Kernel-layout view of a convolution weight built ON THE DEVICE (training repacks every step: no host round trip, no BatchNorm
+    folding): the attributes engine.conv() reads from a PackedConv.  weight OIHW (or [N][K] for Linear) -> rows [N][Kp], k = (ky,kx,c)."""
+    split_allowed = False
+    ps = pt = None
+
+    def __init__(self, weight, bias, stride=1, pad=0, patchify=False):
+        w = weight.detach()
+        if w.dim() == 2:
+            w = w[:, :, None, None]
+        N, Cin, KH, KW = w.shape
+        if patchify:
+            assert stride == KH == KW and pad == 0
+            self.KH, self.KW, self.Cin, self.sh, self.sw, self.ph, self.pw, self.merge = KH, 1, KW * Cin, KH, 1, 0, 0, KW
+        else:
+            self.KH, self.KW, self.Cin, self.sh, self.sw, self.ph, self.pw, self.merge = KH, KW, Cin, stride, stride, pad, pad, 1
+        K = KH * KW * Cin
+        self.N, self.K, self.Kp = N, K, (K + 31) // 32 * 32
+        wk = w.permute(0, 2, 3, 1).reshape(N, K).float()
+        self.w = wk.contiguous() if self.Kp == K else F.pad(wk, (0, self.Kp - K)).contiguous()
+        self.b = bias.detach().float().contiguous() if bias is not None else torch.zeros(N, device=w.device)
+        self.tuned = {}
+
+    def flops(self, M):
+        return 2.0 * M * self.N * self.K
+
+
 class Conv2dNHWC(torch.autograd.Function):
     """y = conv2d(x, w) + b on NHWC activations [B, H, W, Cin] (fp32, HIP device), weight in the reference's OIHW layout.
     forward : kpf_conv2d_f32 (f32-input MFMA implicit GEMM).
@@ -155,13 +183,13 @@ class Conv2dNHWC(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad):
-        from .engine import Act, PackedConv, conv
+        from .engine import Act, conv
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
         B, H, W, Cin = x.shape
         N, Cw, KH, KW = weight.shape
         assert Cw == Cin and Cin % 4 == 0, "Conv2dNHWC: input channels must match and be a multiple of 4"
         patch = stride == KH == KW and pad == 0 and stride > 1
-        pc = PackedConv(weight, bias, x.device, stride=stride, pad=pad, patchify=patch)
+        pc = DevPack(weight, bias, stride=stride, pad=pad, patchify=patch)
         xa = Act(x.contiguous().view(-1), B, H, W, Cin)
         out = conv(pc, xa)
         ctx.save_for_backward(x, weight)
@@ -170,7 +198,7 @@ class Conv2dNHWC(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        from .engine import Act, PackedConv, conv
+        from .engine import Act, conv
         x, weight = ctx.saved_tensors
         stride, pad, patch, has_bias = ctx.conf
         B, H, W, Cin = x.shape
@@ -181,7 +209,7 @@ class Conv2dNHWC(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if patch:  # dX[b, oy*s+ky, ox*s+kx, c] = sum_n dY[b,oy,ox,n] W[n,c,ky,kx]: rows of a GEMM, then un-shuffle
                 wt = weight.permute(2, 3, 1, 0).reshape(KH * KW * Cin, N)  # [(ky,kx,c)][n]
-                pc = PackedConv(wt, None, x.device)
+                pc = DevPack(wt, None)
                 g = conv(pc, Act(dy.view(-1), B, OH, OW, N)).buf.view(B, OH, OW, KH, KW, Cin)
                 dx = g.permute(0, 1, 3, 2, 4, 5).reshape(B, OH * KH, OW * KW, Cin)
                 if dx.shape[1] != H or dx.shape[2] != W:  # rows / columns the strided convolution never read
@@ -196,7 +224,7 @@ class Conv2dNHWC(torch.autograd.Function):
                     wt = F.pad(wt, (0, 0, 0, 0, 0, npad - N))
                 else:
                     dy_in = dy
-                pc = PackedConv(wt, None, x.device, stride=1, pad=KH - 1 - pad)
+                pc = DevPack(wt, None, stride=1, pad=KH - 1 - pad)
                 dx = conv(pc, Act(dy_in.contiguous().view(-1), B, OH, OW, npad)).buf.view(B, H, W, Cin)
         if ctx.needs_input_grad[1]:
             if KH == 1 and KW == 1 and stride == 1:
