@@ -165,6 +165,17 @@ def prepare_rgbd(rgb, depth, bbox, cam, cube=(250.0, 250.0, 250.0), img_size=128
                 cam_para=np.asarray(cam, np.float32), crop_rgb=crop_rgb, com=com)
 
 
+def project_to_crop(xyz_nl, center, M, cube, cam, img_size=128, flip=1):
+    """loader.xyz_nl2uvdnl_tensor (dataloader/loader.py:821-834; demo_RGBD.py:121-123): normalised xyz joints -> pixel coordinates in
+    the crop (u, v in [0, img_size), d in mm): de-normalise, pinhole-project (points3DToImg), apply the crop matrix M."""
+    xyz = np.asarray(xyz_nl, np.float64) * (np.asarray(cube, np.float64) / 2.0) + np.asarray(center, np.float64)
+    fx, fy, u0, v0 = [float(c) for c in cam]
+    u = xyz[:, 0] * fx / xyz[:, 2] + u0
+    v = flip * xyz[:, 1] * fy / xyz[:, 2] + v0
+    h = np.stack([u, v, np.ones_like(u)], 1) @ np.asarray(M, np.float64).T
+    return np.stack([h[:, 0], h[:, 1], xyz[:, 2]], 1)
+
+
 def uncrop_points(uv, M):
     """demo_RGBD.py:192-212 — crop pixel coordinates back to the original image (projective divide included)."""
     Mi = np.linalg.inv(np.asarray(M, np.float64))

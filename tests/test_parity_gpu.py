@@ -797,3 +797,22 @@ def test_offset2joint_edge_cases():
     for b in range(B):
         assert float((uvd[b].cpu() - uvd_ref[b]).abs().max()) < 2e-5, (b, float((uvd[b].cpu() - uvd_ref[b]).abs().max()))
     assert rel_err(xyz, xyz_ref) < 1e-4
+
+
+def test_two_devices_in_one_process_opt_in_per_device():
+    """The > 64 KiB dynamic-LDS opt-in is a per-device attribute: a process that drives two GPUs — torch.nn.DataParallel, the
+    reference's own wrapper — must be able to run the large-tile GEMMs and the fused MLP on the second device too.  Needs two GPUs."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs in one process (the 1-GPU test boxes cannot exercise this)")
+    from oracle import kpf_oracle as O
+    sd = synthetic_sd("KPFusion-convnext-tiny")
+    b = {k: torch.from_numpy(v) for k, v in synthetic_batch(2, 128, seed=1).items()}
+    ref = O.backbones_forward(sd, b["img_rgb"], b["img"])
+    m = _model("convnext-tiny")
+    outs = []
+    for d in (0, 1):
+        dev = torch.device("cuda", d)
+        with torch.no_grad():
+            outs.append([t.cpu() for t in m.to(dev).forward_backbones(b["img_rgb"].to(dev), b["img"].to(dev))])
+    for o0, o1, r in zip(outs[0], outs[1], ref):
+        assert rel_err(o0, r) < 2e-4 and rel_err(o1, r) < 2e-4

@@ -95,10 +95,16 @@ def test_demo_crop_through_the_model_matches_oracle():
     ref, rsw, _, report = oracle_with_device_decisions(sd, b, ctx)
     for o, r in zip(res + sws, ref + rsw):
         assert float((o.cpu() - r).abs().max() / r.abs().max()) < 1e-3
-    # joints of the last stage back in the 1920x1080 frame (demo_RGBD.py:140-147): finite and inside the frame's neighbourhood
-    from oracle import kpf_oracle as O
-    xyz = res[5].cpu()
-    uvd = xyz.clone()  # xyz -> uvd needs the forward projection; use the oracle's inverse map on the device result
-    assert torch.isfinite(xyz).all()
-    full = P.uncrop_points(np.stack([64 + 10 * xyz[0, :, 0].numpy(), 64 + 10 * xyz[0, :, 1].numpy(), xyz[0, :, 2].numpy()], 1), pre["M"])
-    assert np.isfinite(full).all()
+    # joints of the last stage back in the 1920x1080 frame, as demo_RGBD.py:121-147 does: xyz -> crop pixels (xyz_nl2uvdnl_tensor) ->
+    # full image (transformPoints2D with M^-1).  Un-cropping the crop-space projection must land on the direct pinhole projection of
+    # the metric joints into the full frame, and the crop-space joints of the ORACLE must un-crop to the same pixels (< 0.05 px).
+    xyz = res[5].cpu().numpy()[0]
+    assert np.isfinite(xyz).all()
+    crop_px = P.project_to_crop(xyz, pre["center"], pre["M"], pre["cube"], pre["cam_para"])
+    full = P.uncrop_points(crop_px, pre["M"])
+    world = xyz.astype(np.float64) * (np.asarray(pre["cube"], np.float64) / 2) + np.asarray(pre["center"], np.float64)
+    fx, fy, u0, v0 = [float(c) for c in pre["cam_para"]]
+    direct = np.stack([world[:, 0] * fx / world[:, 2] + u0, world[:, 1] * fy / world[:, 2] + v0], 1)
+    assert np.abs(full[:, :2] - direct).max() < 1e-6 * np.abs(direct).max()
+    full_ref = P.uncrop_points(P.project_to_crop(ref[5].numpy()[0], pre["center"], pre["M"], pre["cube"], pre["cam_para"]), pre["M"])
+    assert np.abs(full[:, :2] - full_ref[:, :2]).max() < 0.05
