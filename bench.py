@@ -113,7 +113,6 @@ def main():
     backbones_only = kind == "backbones"
     train = kind == "train"
     if train:
-        args.no_graph = True
         args.no_split_record = True
     if precision != "f32":
         args.no_split_record = True  # (the split record belongs to the fp32 workloads)
@@ -135,8 +134,16 @@ def main():
         uvd_gt = (torch.rand(B, 21, 3, generator=gg) * 1.2 - 0.6).to(dev)
         xyz_gt = (torch.rand(B, 21, 3, generator=gg) * 1.2 - 0.6).to(dev)
         live = live_parameters(model)
-        opt, _ = T.make_optimizer(live)
-        reducer = GradBucketReducer(live, dist if dist is not None else None)
+        graphed_train = world == 1 and not args.no_graph  # one process: the whole iteration replays from a hipGraph
+        opt, _ = T.make_optimizer(live, capturable=graphed_train)
+        reducer = GradBucketReducer(live, dist if dist is not None else None) if not graphed_train else None
+        tbatch = dict(batch, uvd_gt=uvd_gt, xyz_gt=xyz_gt)
+
+        def train_loss(mdl, bt):
+            results, sws, _ = mdl(bt["img_rgb"], bt["img"], bt["pcl"], _Loader(), bt["center"], bt["M"], bt["cube"], bt["cam_para"], 0.8)
+            return T.kpfusion_loss(results, sws, bt["img"], bt["uvd_gt"], bt["xyz_gt"], epoch=0)[0]
+
+        gstep = [None]
 
     class _Loader:
         img_size, flip = 128, 1
@@ -145,13 +152,18 @@ def main():
 
     def step():
         if train:
+            if graphed_train and graph_on[0]:
+                if gstep[0] is None:
+                    gstep[0] = T.GraphedTrainStep(model, opt, train_loss, tbatch)
+                gstep[0](tbatch)
+                return
             opt.zero_grad(set_to_none=False)
-            reducer.reset()
-            results, sws, _ = model(batch["img_rgb"], batch["img"], batch["pcl"], _Loader(), batch["center"], batch["M"], batch["cube"],
-                                    batch["cam_para"], 0.8)
-            loss, _ = T.kpfusion_loss(results, sws, batch["img"], uvd_gt, xyz_gt, epoch=0)
+            if reducer is not None:
+                reducer.reset()
+            loss = train_loss(model, tbatch)
             loss.backward()
-            reducer.finish()
+            if reducer is not None:
+                reducer.finish()
             opt.step()
             return
         with torch.no_grad():

@@ -191,8 +191,8 @@ class TrainGraph:
             S = new_xyz.shape[1]
             d = new_xyz.unsqueeze(2) - xyz.unsqueeze(1)
             d2 = d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1] + d[..., 2] * d[..., 2]
-            r32 = torch.tensor(radius, dtype=torch.float32, device=xyz.device)
-            within = d2 < (r32 * r32)
+            import numpy as np
+            within = d2 < float(np.float32(radius) * np.float32(radius))  # r^2 rounded in fp32 like the extension's kernel
             rank = torch.cumsum(within.long(), -1) - 1
             first = torch.argmax(within.long(), -1)
             idx = (first * within.any(-1).long()).unsqueeze(-1).repeat(1, 1, nsample)
@@ -239,13 +239,28 @@ class TrainGraph:
         y = linear_hip(rows.contiguous(), w, self.t[p_b]) if Cc % 4 == 0 else F.linear(rows, w, self.t[p_b])
         return y.view(B, A, S, -1).permute(0, 3, 1, 2)
 
+    def ball_query_hip(self, pcl_xyz, node_xyz, pcl_feat, node_feat):
+        """The three ball-query index tensors of DESA from the inference path's kernel (kpf_ball_group_f32: same semantics as
+        ball_query above, no host synchronisation, so a training iteration can be captured in a hipGraph).  Indices only."""
+        with torch.no_grad():
+            B, N, _ = pcl_xyz.shape
+            dev = pcl_xyz.device
+            X = pcl_feat.detach().contiguous()
+            JF = node_feat.detach().contiguous()
+            G = torch.empty(3, B * J * 64, 132, device=dev)
+            idx = torch.empty(3, B * J, 64, device=dev, dtype=torch.int32)
+            L.check(L.load().kpf_ball_group_f32(_ptr(pcl_xyz.contiguous()), _ptr(node_xyz.detach().contiguous()), _ptr(X), _ptr(JF), 128, _ptr(G),
+                                                _ptr(idx), B, N, 0.1, 0.2, 0.4, _stream()), "kpf_ball_group_f32")
+            return [idx[i].view(B, J, 64).long() for i in range(3)]
+
     def desa(self, p, pcl_feat, node_feat, pcl_xyz, node_xyz):
         B, Jn, C = node_feat.shape
         xyz = torch.cat((pcl_xyz, node_xyz), 1)
         feat = torch.cat((pcl_feat, node_feat), 1)
         outs = []
+        hip_idx = self.ball_query_hip(pcl_xyz, node_xyz, pcl_feat, node_feat) if (C == 128 and not self.ball_override) else None
         for i, r in enumerate((0.1, 0.2, 0.4)):
-            idx = self.ball_query(r, 64, xyz, node_xyz)
+            idx = hip_idx[i] if hip_idx is not None else self.ball_query(r, 64, xyz, node_xyz)
             if self.ball_override:
                 given = self.ball_override.pop(0).to(idx.device).long()
                 self.ball_flips += int((given != idx).any(-1).sum())
