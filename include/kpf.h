@@ -262,6 +262,9 @@ int kpf_upsample2x_h16(const void* src, void* dst, int B, int H, int W, int C, i
 /* 16-bit NHWC channel slice -> dense fp32 [rows][C] (feature maps handed to the fp32 fusion head / module boundary). */
 int kpf_cast_h16_f32(const void* src, int dtype, float* dst, long rows, int C, int src_ld, int src_coff, void* stream);
 
+/* dense fp32 [n] -> 16-bit (behind the fp32 stem + max-pool of the ResNet backbones); n % 4 == 0. */
+int kpf_cast_f32_h16(const float* src, void* dst, int dtype, long n, void* stream);
+
 int kpf_conv_num_tile_cfgs(void);
 
 const char* kpf_last_error(void);

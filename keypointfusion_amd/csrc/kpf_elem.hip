@@ -597,6 +597,11 @@ __global__ __launch_bounds__(256) void cast_h16_f32_kernel(const TA* __restrict_
   }
 }
 
+template <typename TA>
+__global__ __launch_bounds__(256) void cast_f32_h16_kernel(const float* __restrict__ src, TA* __restrict__ dst, long total4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) kpf_st4(dst + i * 4, kpf_ld4(src + i * 4));
+}
+
 inline int grid_for(long total, int block = 256, int cap = 256 * 16) {
   long g = (total + block - 1) / block;
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -798,6 +803,21 @@ extern "C" int kpf_cast_h16_f32(const void* src, int dtype, float* dst, long row
     return KPF_EINVAL;
   }
   return kpf_check_launch("kpf_cast_h16_f32");
+}
+
+// dense fp32 -> 16-bit (behind the fp32 stem + max-pool of the ResNet backbones)
+extern "C" int kpf_cast_f32_h16(const float* src, void* dst, int dtype, long n, void* stream) {
+  KPF_REQUIRE(src && dst && n > 0 && n % 4 == 0, "kpf_cast_f32_h16: bad arguments (n %% 4 == 0)");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == KPF_DT_BF16)
+    hipLaunchKernelGGL(cast_f32_h16_kernel<bf16_t>, dim3(grid_for(n / 4)), dim3(256), 0, st, src, static_cast<bf16_t*>(dst), n / 4);
+  else if (dtype == KPF_DT_F16)
+    hipLaunchKernelGGL(cast_f32_h16_kernel<f16_t>, dim3(grid_for(n / 4)), dim3(256), 0, st, src, static_cast<f16_t*>(dst), n / 4);
+  else {
+    kpf_set_error("kpf_cast_f32_h16: dtype must be KPF_DT_BF16 or KPF_DT_F16");
+    return KPF_EINVAL;
+  }
+  return kpf_check_launch("kpf_cast_f32_h16");
 }
 
 extern "C" int kpf_nchw_to_nhwc_f32(const float* src, float* dst, int B, int C, int H, int W, int Cpad, void* stream) {

@@ -1,4 +1,4 @@
-"""Reduced-precision execution plan of the ConvNeXt UNet backbones (BASELINE.json configs[2] bf16, configs[4] fp16): 16-bit NHWC
+"""Reduced-precision execution plan of the UNet backbones (BASELINE.json configs[2] bf16 — ConvNeXt and ResNet —, configs[4] fp16): 16-bit NHWC
 activations and weights in HBM, fp32 accumulation on v_mfma_f32_16x16x32_{bf16,f16}, fp32 elementwise arithmetic (LayerNorm statistics,
 GELU, residual adds, depthwise taps) inside the kernels.  Same schedule as engine.UNetPlan; the 4x4 stem convolution stays on the fp32
 path (its input is the fp32 image, K = 16 / 48), the 105-channel head output is written fp32 NCHW, and the 128-channel feature map is
@@ -11,7 +11,7 @@ import ctypes as C
 import torch
 
 from . import lib as L
-from .engine import Act, PackedConv, _launch, _ptr, _stream, bn_scale_shift, conv, nchw_to_nhwc
+from .engine import Act, PackedConv, _launch, _ptr, _stream, bn_scale_shift, conv, maxpool3x3s2, nchw_to_nhwc
 from .spec import CONVNEXT, parse_net
 
 DTYPES = {"bf16": (torch.bfloat16, L.KPF_DT_BF16), "f16": (torch.float16, L.KPF_DT_F16)}
@@ -119,33 +119,53 @@ class Block16:
 
 
 class UNetPlan16:
-    """One ConvNeXt UNet stream on 16-bit storage (convNeXT/resnetUnet.py:129-152).  __call__(img NCHW fp32) ->
+    """One UNet stream (ConvNeXt or ResNet encoder) on 16-bit storage (convNeXT/resnetUnet.py:129-152, model/resnetUnet.py:309-330).  __call__(img NCHW fp32) ->
     (img_result NCHW fp32 B x 105 x F x F, img_feature Act NHWC 128 fp32)."""
 
     def __init__(self, sd, p, net, device, precision):
-        fam, size = parse_net(net)
-        if fam != "convnext":
-            raise NotImplementedError("the reduced-precision path covers the ConvNeXt backbones (BASELINE configs[2], [4]); ResNet runs fp32")
+        self.fam, size = parse_net(net)
         self.tdt, self.kdt = DTYPES[precision]
         self.device = device
         sdp = {k[len(p) + 1:]: v for k, v in sd.items() if k.startswith(p + ".")}
-        depths, dims = CONVNEXT[size]
-        self.dims = dims
         b = "backbone"
         f32 = lambda k: sdp[k].detach().float().contiguous().to(device)
-        self.stem = PackedConv(sdp[b + ".downsample_layers.0.0.weight"], sdp[b + ".downsample_layers.0.0.bias"], device, stride=4, patchify=True)
-        self.stem_ln = (f32(b + ".downsample_layers.0.1.weight"), f32(b + ".downsample_layers.0.1.bias"))
-        self.down, self.down_ln = [None], [None]
-        for i in range(1, 4):
-            self.down_ln.append((f32(b + ".downsample_layers.%d.0.weight" % i), f32(b + ".downsample_layers.%d.0.bias" % i)))
-            self.down.append(Packed16(PackedConv(sdp[b + ".downsample_layers.%d.1.weight" % i], sdp[b + ".downsample_layers.%d.1.bias" % i], device,
-                                                 stride=2, patchify=True), self.tdt))
-        self.stages = [[Block16(sdp, b + ".stages.%d.%d" % (i, j), device, self.tdt) for j in range(depths[i])] for i in range(4)]
+        P16 = lambda *a, **k: Packed16(PackedConv(*a, **k), self.tdt)
+        if self.fam == "convnext":
+            depths, dims = CONVNEXT[size]
+            self.dims = dims
+            self.stem = PackedConv(sdp[b + ".downsample_layers.0.0.weight"], sdp[b + ".downsample_layers.0.0.bias"], device, stride=4, patchify=True)
+            self.stem_ln = (f32(b + ".downsample_layers.0.1.weight"), f32(b + ".downsample_layers.0.1.bias"))
+            self.down, self.down_ln = [None], [None]
+            for i in range(1, 4):
+                self.down_ln.append((f32(b + ".downsample_layers.%d.0.weight" % i), f32(b + ".downsample_layers.%d.0.bias" % i)))
+                self.down.append(P16(sdp[b + ".downsample_layers.%d.1.weight" % i], sdp[b + ".downsample_layers.%d.1.bias" % i], device, stride=2, patchify=True))
+            self.stages = [[Block16(sdp, b + ".stages.%d.%d" % (i, j), device, self.tdt) for j in range(depths[i])] for i in range(4)]
+        else:  # ResNet (model/resnet.py:232-244): fp32 7x7/s2 stem (BatchNorm folded) + max-pool, then 16-bit stages with folded BatchNorms
+            self.stem = PackedConv(sdp[b + ".conv1.weight"], None, device, stride=2, pad=3, fold_bn=bn_scale_shift(sdp, b + ".bn1"), cin_pad=4)
+            self.layers = []
+            for li in range(1, 5):
+                blocks = []
+                j = 0
+                while (b + ".layer%d.%d.conv1.weight" % (li, j)) in sdp:
+                    q = b + ".layer%d.%d" % (li, j)
+                    stride = 2 if (li > 1 and j == 0) else 1
+                    ds = None
+                    if (q + ".downsample.0.weight") in sdp:
+                        ds = P16(sdp[q + ".downsample.0.weight"], None, device, stride=stride, fold_bn=bn_scale_shift(sdp, q + ".downsample.1"))
+                    if (q + ".conv3.weight") in sdp:
+                        blocks.append((P16(sdp[q + ".conv1.weight"], None, device, fold_bn=bn_scale_shift(sdp, q + ".bn1")),
+                                       P16(sdp[q + ".conv2.weight"], None, device, stride=stride, pad=1, fold_bn=bn_scale_shift(sdp, q + ".bn2")),
+                                       P16(sdp[q + ".conv3.weight"], None, device, fold_bn=bn_scale_shift(sdp, q + ".bn3")), ds))
+                    else:
+                        blocks.append((P16(sdp[q + ".conv1.weight"], None, device, stride=stride, pad=1, fold_bn=bn_scale_shift(sdp, q + ".bn1")),
+                                       P16(sdp[q + ".conv2.weight"], None, device, pad=1, fold_bn=bn_scale_shift(sdp, q + ".bn2")), None, ds))
+                    j += 1
+                self.layers.append(blocks)
         R = lambda name: Residual16(sdp, name, device, self.tdt)
         self.up4, self.skip4, self.fus4 = R("up4.0"), R("skip_layer4"), R("fusion_layer4")
         self.up3, self.skip3, self.fus3 = R("up3.0"), R("skip_layer3"), R("fusion_layer3")
         self.up2, self.skip2, self.fus2 = R("up2.0"), R("skip_layer2"), R("fusion_layer2")
-        self.result_emb = R("result_emb")
+        self.result_emb = R("result_emb") if self.fam == "convnext" else None
         wf = torch.cat([sdp["finals.%d.weight" % i] for i in range(3)], 0)
         bf = torch.cat([sdp["finals.%d.bias" % i] for i in range(3)], 0)
         self.finals = Packed16(PackedConv(wf, bf, device), self.tdt)
@@ -155,8 +175,26 @@ class UNetPlan16:
                                            _stream()), "kpf_layernorm_h16")
         return out
 
-    def __call__(self, img):
+    def _resnet(self, img):
         lib = L.load()
+        kdt = self.kdt
+        x = maxpool3x3s2(conv(self.stem, nchw_to_nhwc(img, cpad=4), flags=L.KPF_ACT_RELU))  # fp32 stem + pool
+        x16 = empty16(x.B, x.H, x.W, x.C, self.device, self.tdt)
+        L.check(lib.kpf_cast_f32_h16(_ptr(x.buf), _ptr(x16.buf), kdt, x.buf.numel(), _stream()), "kpf_cast_f32_h16")
+        x = x16
+        feats = []
+        for blocks in self.layers:
+            for c1, c2, c3, ds in blocks:
+                h = conv16(c1, x, kdt, flags=L.KPF_ACT_RELU)
+                idt = conv16(ds, x, kdt) if ds is not None else x
+                if c3 is None:
+                    x = conv16(c2, h, kdt, res=idt, flags=L.KPF_RELU_AFTER_RES)
+                else:
+                    x = conv16(c3, conv16(c2, h, kdt, flags=L.KPF_ACT_RELU), kdt, res=idt, flags=L.KPF_RELU_AFTER_RES)
+            feats.append(x)
+        return feats
+
+    def _convnext(self, img):
         dev, tdt, kdt = self.device, self.tdt, self.kdt
         B, Cc, S, _ = img.shape
         x = Act(img.contiguous().float().view(-1), B, S, S, 1) if Cc == 1 else nchw_to_nhwc(img)
@@ -174,7 +212,13 @@ class UNetPlan16:
             for blk in self.stages[i]:
                 blk(cur, y, h, kdt)
             feats.append(cur)
-        c1, c2, c3, c4 = feats
+        return feats
+
+    def __call__(self, img):
+        lib = L.load()
+        dev, tdt, kdt = self.device, self.tdt, self.kdt
+        B = img.shape[0]
+        c1, c2, c3, c4 = self._convnext(img) if self.fam == "convnext" else self._resnet(img)
 
         def level(up, skip, fus, lo, hi):
             cat = empty16(B, hi.H, hi.W, up.cout + skip.cout, dev, tdt)
@@ -187,7 +231,8 @@ class UNetPlan16:
         c3f = level(self.up4, self.skip4, self.fus4, c4, c3)
         c2f = level(self.up3, self.skip3, self.fus3, c3f, c2)
         feat = level(self.up2, self.skip2, self.fus2, c2f, c1)
-        feat = self.result_emb(feat, kdt)
+        if self.result_emb is not None:
+            feat = self.result_emb(feat, kdt)
         res = torch.empty(B, 105, feat.H, feat.W, device=dev, dtype=torch.float32)
         conv16(self.finals, feat, kdt, out_nchw=res)
         f32 = Act.empty(B, feat.H, feat.W, feat.C, dev)

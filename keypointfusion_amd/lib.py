@@ -55,6 +55,7 @@ _SIGS = {
     "kpf_layernorm_h16": [_P, C.c_int, _P, _P, _P, C.c_int, C.c_long, C.c_int, C.c_float, _P],
     "kpf_upsample2x_h16": [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P],
     "kpf_cast_h16_f32": [_P, C.c_int, _P, C.c_long, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_cast_f32_h16": [_P, _P, C.c_int, C.c_long, _P],
     "kpf_convnext_mlp_f32": [_P] * 8 + [C.c_long, C.c_int, _P],
     "kpf_convnext_mlp_supported": [C.c_int],
     "kpf_convnext_mlp_split_f32": [_P, _P, _P, _P, C.c_float, _P, _P, C.c_float, _P, _P, C.c_long, C.c_int, _P],

@@ -136,16 +136,17 @@ def _model(net, prec):
     return m.to(_dev()).eval()
 
 
-@pytest.mark.parametrize("prec,mean_tol,final_tol,map_tol", [("bf16", 4.0, 1.5, 6e-2), ("f16", 1.5, 0.6, 8e-3)])
-def test_full_model_reduced_precision_tolerance_in_mm(prec, mean_tol, final_tol, map_tol):
-    """configs[2]: full model (ConvNeXt-T, 128x128), 16-bit backbones + fp32 head, against the fp32 oracle: the tolerance study."""
+@pytest.mark.parametrize("net,prec,mean_tol,final_tol,map_tol", [("convnext-tiny", "bf16", 4.0, 1.5, 6e-2), ("convnext-tiny", "f16", 1.5, 0.6, 8e-3),
+                                                                  ("resnet-18", "bf16", 6.0, 3.0, 6e-2), ("resnet-18", "f16", 1.5, 0.8, 8e-3)])
+def test_full_model_reduced_precision_tolerance_in_mm(net, prec, mean_tol, final_tol, map_tol):
+    """configs[2]: full model (ConvNeXt-T and ResNet-18, 128x128), 16-bit backbones + fp32 head, against the fp32 oracle: the tolerance study."""
     from oracle import kpf_oracle as O
     dev = _dev()
-    sd = synthetic_sd("KPFusion-convnext-tiny")
+    sd = synthetic_sd("KPFusion-" + net)
     B = 4
     b = {k: torch.from_numpy(v) for k, v in synthetic_batch(B, 128, seed=3).items()}
     ref, rsw = O.kpfusion_forward(sd, b["img_rgb"], b["img"], b["pcl"], b["center"], b["M"], b["cube"], b["cam_para"], 0.8)
-    m = _model("convnext-tiny", prec)
+    m = _model(net, prec)
 
     class Loader:
         img_size, flip = 128, 1
@@ -158,7 +159,7 @@ def test_full_model_reduced_precision_tolerance_in_mm(prec, mean_tol, final_tol,
         assert rel(res[k], ref[k]) < map_tol, (prec, k, rel(res[k], ref[k]))
     mm = [float((res[k].cpu() - ref[k]).norm(dim=-1).max()) * 125.0 for k in range(2, 6)]  # cube 250 mm: x * 125 mm
     mean_mm = [float((res[k].cpu() - ref[k]).norm(dim=-1).mean()) * 125.0 for k in range(2, 6)]
-    print("reduced precision %s: max joint deviation per stage %s mm, mean %s mm" % (prec, ["%.3f" % v for v in mm], ["%.3f" % v for v in mean_mm]))
+    print("reduced precision %s %s: max joint deviation per stage %s mm, mean %s mm" % (net, prec, ["%.3f" % v for v in mm], ["%.3f" % v for v in mean_mm]))
     assert max(mean_mm) < mean_tol and mean_mm[3] < final_tol and max(mm) < 60.0, (prec, mean_mm, mm)
 
 
