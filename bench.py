@@ -47,6 +47,7 @@ WORKLOADS = {
     # one training iteration of train.py:209-265 (forward in train mode, loss, backward, gradient all-reduce over RCCL when N > 1, AdamW
     # step); fp32 — bf16 training is not built, so this is configs[3]'s schedule, not its precision
     "train128": ("KPFusion-convnext-tiny", 128, 32, "f32", "train", "configs[3] (fp32)"),
+    "train128_bf16": ("KPFusion-convnext-tiny", 128, 32, "bf16", "train", "configs[3]"),
 }
 
 

@@ -37,6 +37,7 @@ AUTOTUNE = bool(int(__import__("os").environ.get("KPF_AUTOTUNE", "0")))
 # Per-launch profiling hook (bench.py): when PROFILE is a list, every MFMA-kernel launch is bracketed by HIP events recorded on
 # the launch stream and appended as (kernel, start_event, end_event, algorithmic_flops, algorithmic_bytes, shape).
 PROFILE = None
+FORCE_TILE = 0  # tuning aid (tools/smallk_scan.py): tile configuration index + 1 for every kpf_conv2d_f32 launch, 0 = the library's choice
 
 
 def _launch(kernel, flops, nbytes, shape, fn):
@@ -230,6 +231,8 @@ def conv(pc, x, out=None, flags=0, gamma=None, res=None, out_nchw=None, out_spli
         if cfg is None and PROFILE is None and not torch.cuda.is_current_stream_capturing():
             cfg = pc.tuned[key] = _autotune(lib, d, x, w, pc, gamma, res, optr, flags)
         d.tile_cfg = cfg or 0
+    if FORCE_TILE:
+        d.tile_cfg = FORCE_TILE
     # algorithmic bytes: input pixels once, weights once, output once (+ residual once)
     nbytes = 4.0 * (B * IH * IW * pc.Cin + pc.N * pc.K + M * pc.N * (2 if res is not None else 1))
     _launch("igemm_split_kernel" if flags & (L.KPF_IN_SPLIT | L.KPF_W_SPLIT) else "igemm_f32_kernel", pc.flops(M), nbytes, (M, pc.N, pc.K, pc.KH, pc.KW),

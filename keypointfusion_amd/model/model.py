@@ -42,7 +42,7 @@ class KPFusion(nn.Module):
         self._plans = {}
         self._plan_lock = threading.Lock()
         # storage precision of the backbones: "f32" (the reference's arithmetic, default), "bf16" or "f16" (16-bit activations and
-        # weights, fp32 accumulation; ConvNeXt families; the fusion head stays fp32) — set before the first forward or at any time
+        # weights, fp32 accumulation; the fusion head stays fp32) — set before the first forward or at any time
         self.precision = "f32"
         self.train_dropout = 0.1  # dropout probability of the transformer layers in train mode (config/config.json; transfusion_head.py:95)
         self.use_graphs = False  # opt-in: replay each forward from a captured hipGraph (eval / no_grad, fixed shapes)
@@ -109,8 +109,8 @@ class KPFusion(nn.Module):
         if self.training:
             # train mode: batch-statistics BatchNorm, dropout, autograd-connected outputs on the module's own
             # Parameters — keypointfusion_amd/train_graph.py (convolutions / Linears forward + data-gradient on the HIP GEMM)
-            if self.precision != "f32":
-                raise NotImplementedError("train mode runs fp32 (KPFusion.precision = 'f32'); reduced-precision training is not built")
+            if self.precision == "f16":
+                raise NotImplementedError("train mode supports precision 'f32' and 'bf16' (fp16 training needs loss scaling, which is not built)")
             from ..train_graph import TrainGraph
             with torch.cuda.device(img.device):
                 return TrainGraph(self).forward(img_rgb, img, pcl, center, M, cube, cam_para, float(kernel), img_size, flip)

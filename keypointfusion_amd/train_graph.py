@@ -38,6 +38,11 @@ class TrainGraph:
         self.t.update(dict(module.named_buffers()))
         self.pd = float(getattr(module, "train_dropout", 0.1))
         self.momentum = 0.1
+        # "f32" | "bf16" | "f16": 16-bit = mixed precision as torch.autocast does it — fp32 master weights and optimiser state, GEMM
+        # operands rounded to 16 bits (HIP convolutions / Linears on the 16-bit MFMA, library ops under torch.autocast), fp32
+        # normalisation statistics, softmaxes, geometry and loss
+        self.prec = getattr(module, "precision", "f32")
+        self.cmul = 4 if self.prec == "f32" else 8
         # parity-test hook: ball-query index tensors to use instead of the computed ones (the sets are integer decisions taken around
         # network outputs; a test that compares gradients with the reference's must compare on equal decisions) + a flip counter
         self.ball_override = list(getattr(module, "_ball_override", None) or [])
@@ -53,16 +58,16 @@ class TrainGraph:
         b = self.t[p_b] if p_b is not None else None
         cin, k = w.shape[1], w.shape[2]
         patch = stride == k and pad == 0 and stride > 1
-        if cin % 4 == 0 and (stride == 1 or patch) and w.shape[2] == w.shape[3]:
-            y = conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous(), w, b, stride, pad)
+        if cin % self.cmul == 0 and (stride == 1 or patch) and w.shape[2] == w.shape[3]:
+            y = conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous(), w, b, stride, pad, self.prec)
             return y.permute(0, 3, 1, 2)
         return F.conv2d(x, w, b, stride=stride, padding=pad)
 
     def linear(self, x, p_w, p_b=None):
         w = self.t[p_w]
         b = self.t[p_b] if p_b is not None else None
-        if w.shape[1] % 4 == 0:
-            return linear_hip(x.contiguous(), w, b)
+        if w.shape[1] % self.cmul == 0:
+            return linear_hip(x.contiguous(), w, b, self.prec)
         return F.linear(x, w, b)
 
     def bn(self, x, p, eps=1e-5):
@@ -205,8 +210,8 @@ class TrainGraph:
     def emb1d(self, p, x):
         B, N, Cin = x.shape
         w = self.t[p + ".0.weight"]  # [128, Cin, 1]
-        if Cin % 4 == 0:
-            y = linear_hip(x.reshape(B * N, Cin).contiguous(), w[:, :, 0], self.t[p + ".0.bias"])
+        if Cin % self.cmul == 0:
+            y = linear_hip(x.reshape(B * N, Cin).contiguous(), w[:, :, 0], self.t[p + ".0.bias"], self.prec)
         else:
             y = F.linear(x.reshape(B * N, Cin), w[:, :, 0], self.t[p + ".0.bias"])
         return self.bn(y.view(B, N, -1).permute(0, 2, 1), p + ".1").permute(0, 2, 1)
@@ -236,7 +241,7 @@ class TrainGraph:
         B, Cc, A, S = x_bchw.shape
         w = self.t[p_w][:, :, 0, 0]
         rows = x_bchw.permute(0, 2, 3, 1).reshape(-1, Cc)
-        y = linear_hip(rows.contiguous(), w, self.t[p_b]) if Cc % 4 == 0 else F.linear(rows, w, self.t[p_b])
+        y = linear_hip(rows.contiguous(), w, self.t[p_b], self.prec) if Cc % self.cmul == 0 else F.linear(rows, w, self.t[p_b])
         return y.view(B, A, S, -1).permute(0, 3, 1, 2)
 
     def ball_query_hip(self, pcl_xyz, node_xyz, pcl_feat, node_feat):
@@ -245,11 +250,11 @@ class TrainGraph:
         with torch.no_grad():
             B, N, _ = pcl_xyz.shape
             dev = pcl_xyz.device
-            X = pcl_feat.detach().contiguous()
-            JF = node_feat.detach().contiguous()
+            X = pcl_feat.detach().float().contiguous()   # (the kernel takes fp32 rows; under mixed precision the features are 16-bit)
+            JF = node_feat.detach().float().contiguous()
             G = torch.empty(3, B * J * 64, 132, device=dev)
             idx = torch.empty(3, B * J, 64, device=dev, dtype=torch.int32)
-            L.check(L.load().kpf_ball_group_f32(_ptr(pcl_xyz.contiguous()), _ptr(node_xyz.detach().contiguous()), _ptr(X), _ptr(JF), 128, _ptr(G),
+            L.check(L.load().kpf_ball_group_f32(_ptr(pcl_xyz.float().contiguous()), _ptr(node_xyz.detach().float().contiguous()), _ptr(X), _ptr(JF), 128, _ptr(G),
                                                 _ptr(idx), B, N, 0.1, 0.2, 0.4, _stream()), "kpf_ball_group_f32")
             return [idx[i].view(B, J, 64).long() for i in range(3)]
 
@@ -278,7 +283,7 @@ class TrainGraph:
         outs.append(node_feat.permute(0, 2, 1))
         cat = torch.cat(outs, 1)  # B x 512 x J
         w = self.t[p + ".fusion.0.weight"][:, :, 0]
-        y = linear_hip(cat.permute(0, 2, 1).reshape(B * Jn, -1).contiguous(), w, self.t[p + ".fusion.0.bias"]).view(B, Jn, -1).permute(0, 2, 1)
+        y = linear_hip(cat.permute(0, 2, 1).reshape(B * Jn, -1).contiguous(), w, self.t[p + ".fusion.0.bias"], self.prec).view(B, Jn, -1).permute(0, 2, 1)
         return F.relu(self.bn(y, p + ".fusion.1")).permute(0, 2, 1)
 
     def bert_layer(self, p, h, heads=4):
@@ -312,9 +317,9 @@ class TrainGraph:
         qe = query + self.t[p + ".self_posembed.weight"][:T]
         ke = key + self.t[p + ".cross_posembed.weight"][:T]
         W, bqkv = self.t[p + ".multihead_attn.in_proj_weight"], self.t[p + ".multihead_attn.in_proj_bias"]
-        q = linear_hip(qe.contiguous(), W[:C], bqkv[:C]) * (float(hd) ** -0.5)
-        k = linear_hip(ke.contiguous(), W[C:2 * C], bqkv[C:2 * C])
-        v = linear_hip(ke.contiguous(), W[2 * C:], bqkv[2 * C:])
+        q = linear_hip(qe.contiguous(), W[:C], bqkv[:C], self.prec) * (float(hd) ** -0.5)
+        k = linear_hip(ke.contiguous(), W[C:2 * C], bqkv[C:2 * C], self.prec)
+        v = linear_hip(ke.contiguous(), W[2 * C:], bqkv[2 * C:], self.prec)
         q = q.view(B, T, heads, hd).transpose(1, 2)
         k = k.view(B, T, heads, hd).transpose(1, 2)
         v = v.view(B, T, heads, hd).transpose(1, 2)
@@ -341,6 +346,7 @@ class TrainGraph:
         jf = F.relu(self.emb1d(p + ".joint_feat_emb", jf) + self.emb1d(p + ".joint_xyz_emb", joint_xyz.detach()))
         jf = self.desa(p + ".FA", x, jf, pcl, joint_xyz.detach())
         h_init, r3d = self.kp_interaction_tr(p + ".init_TR", jf)
+        r3d = r3d.float()  # geometry, heat map and the returned joints are fp32 in every precision
         hm = joint2heatmap(r3d[:, :, :2], 0.8, H, sigma=1)
         # geometry adjacency map (dataloader/loader.py:791-819): the joints go through the uvd -> xyz map again, like the pixels
         u, v = self.pixel_grid(H, img_feat.device)
@@ -356,8 +362,8 @@ class TrainGraph:
         if prev_feat is not None:
             fj = F.relu((fj + prev_feat) / 2)
         dec = self.decoder_layer(p + ".crossTR.decoder.3", fj, h_init)
-        _, r2d = self.kp_interaction_tr(p + ".final_TR", torch.cat([r3d, dec], 2))
-        return r3d, r2d, fj, sw
+        _, r2d = self.kp_interaction_tr(p + ".final_TR", torch.cat([r3d, dec.float()], 2))
+        return r3d, r2d.float(), fj, sw.float()
 
     def forward(self, img_rgb, img, pcl, center, M, cube, cam, kernel, img_size, flip):
         """model/model.py:395-426 in train mode.  Returns ([6 results], [2 spatial weights], None), autograd-connected."""
@@ -365,8 +371,16 @@ class TrainGraph:
         dev = img.device
         f = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
         img_rgb, img, pcl, center, M, cube, cam = map(f, (img_rgb, img, pcl, center, M, cube, cam))
+        if self.prec != "f32":
+            from .training import _TDT
+            with torch.autocast("cuda", dtype=_TDT[self.prec]):
+                return self._forward(lib, dev, img_rgb, img, pcl, center, M, cube, cam, kernel, img_size, flip)
+        return self._forward(lib, dev, img_rgb, img, pcl, center, M, cube, cam, kernel, img_size, flip)
+
+    def _forward(self, lib, dev, img_rgb, img, pcl, center, M, cube, cam, kernel, img_size, flip):
         img_offset, img_feat = self.unet("backbone_d", img)
         img_offset_rgb, img_feat_rgb = self.unet("backbone_rgb", img_rgb)
+        img_offset, img_offset_rgb = img_offset.float(), img_offset_rgb.float()  # the dense maps are returned (and decoded) in fp32
         result = [img_offset, img_offset_rgb]
         B, _, S, _ = img.shape
         Fs = img_feat.shape[-1]

@@ -170,6 +170,29 @@ class DevPack:
     def flops(self, M):
         return 2.0 * M * self.N * self.K
 
+    def as16(self, tdt):
+        """The object engine16.conv16() takes: 16-bit rows [N][Kp64] of the same weights."""
+        kp = (self.K + 63) // 64 * 64
+        w = self.w[:, :self.K]
+        w16 = (w if kp == self.K else F.pad(w, (0, kp - self.K))).to(tdt).contiguous()
+        return type("P16", (), {"pc": self, "Kp": kp, "w": w16})()
+
+
+_TDT = {"bf16": torch.bfloat16, "f16": torch.float16}
+
+
+def _conv_any(pc, x4, prec):
+    """engine.conv (fp32) or engine16.conv16 (bf16 / f16) on an NHWC tensor [B, H, W, C]; returns the NHWC output tensor."""
+    from .engine import Act, conv
+    B, H, W, Cc = x4.shape
+    if prec == "f32":
+        out = conv(pc, Act(x4.contiguous().view(-1), B, H, W, Cc))
+    else:
+        from .engine16 import DTYPES, conv16
+        tdt, kdt = DTYPES[prec]
+        out = conv16(pc.as16(tdt), Act(x4.to(tdt).contiguous().view(-1), B, H, W, Cc), kdt)
+    return out.buf.view(out.B, out.H, out.W, out.C)
+
 
 class Conv2dNHWC(torch.autograd.Function):
     """y = conv2d(x, w) + b on NHWC activations [B, H, W, Cin] (fp32, HIP device), weight in the reference's OIHW layout.
@@ -182,35 +205,38 @@ class Conv2dNHWC(torch.autograd.Function):
     Linear layers are the 1x1 case on a [rows, 1, 1, K] view."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad):
-        from .engine import Act, conv
-        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+    def forward(ctx, x, weight, bias, stride, pad, prec="f32"):
+        """prec "bf16" / "f16": operands rounded to 16 bits, fp32 accumulation on the 16-bit MFMA (kpf_conv2d_h16), 16-bit output;
+        the weight stays the fp32 master copy and receives an fp32 gradient."""
+        assert x.is_cuda and x.dim() == 4
         B, H, W, Cin = x.shape
         N, Cw, KH, KW = weight.shape
-        assert Cw == Cin and Cin % 4 == 0, "Conv2dNHWC: input channels must match and be a multiple of 4"
+        assert Cw == Cin and Cin % (4 if prec == "f32" else 8) == 0, "Conv2dNHWC: input channels must match and be a multiple of 4 (8 for 16-bit)"
         patch = stride == KH == KW and pad == 0 and stride > 1
         pc = DevPack(weight, bias, stride=stride, pad=pad, patchify=patch)
-        xa = Act(x.contiguous().view(-1), B, H, W, Cin)
-        out = conv(pc, xa)
+        y = _conv_any(pc, x if prec != "f32" else x.float(), prec)
         ctx.save_for_backward(x, weight)
-        ctx.conf = (stride, pad, patch, bias is not None)
-        return out.buf.view(out.B, out.H, out.W, out.C)
+        ctx.conf = (stride, pad, patch, bias is not None, prec)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
-        from .engine import Act, conv
         x, weight = ctx.saved_tensors
-        stride, pad, patch, has_bias = ctx.conf
+        stride, pad, patch, has_bias, prec = ctx.conf
         B, H, W, Cin = x.shape
         N, _, KH, KW = weight.shape
         dy = dy.contiguous()
         OH, OW = dy.shape[1], dy.shape[2]
         dx = dw = db = None
+        cmul = 4 if prec == "f32" else 8  # channel granularity of the GEMM's activation operand
         if ctx.needs_input_grad[0]:
             if patch:  # dX[b, oy*s+ky, ox*s+kx, c] = sum_n dY[b,oy,ox,n] W[n,c,ky,kx]: rows of a GEMM, then un-shuffle
                 wt = weight.permute(2, 3, 1, 0).reshape(KH * KW * Cin, N)  # [(ky,kx,c)][n]
-                pc = DevPack(wt, None)
-                g = conv(pc, Act(dy.view(-1), B, OH, OW, N)).buf.view(B, OH, OW, KH, KW, Cin)
+                npad = (N + cmul - 1) // cmul * cmul
+                dy_in = dy if npad == N else F.pad(dy, (0, npad - N))
+                if npad != N:
+                    wt = F.pad(wt, (0, npad - N))
+                g = _conv_any(DevPack(wt, None), dy_in, prec).view(B, OH, OW, KH, KW, Cin)
                 dx = g.permute(0, 1, 3, 2, 4, 5).reshape(B, OH * KH, OW * KW, Cin)
                 if dx.shape[1] != H or dx.shape[2] != W:  # rows / columns the strided convolution never read
                     dx = F.pad(dx, (0, 0, 0, W - dx.shape[2], 0, H - dx.shape[1]))
@@ -218,32 +244,34 @@ class Conv2dNHWC(torch.autograd.Function):
                 if stride != 1:
                     raise NotImplementedError("Conv2dNHWC.backward: data gradient of strided non-patchify convolutions is not built yet")
                 wt = weight.flip(2, 3).permute(1, 0, 2, 3).contiguous()  # [Cin][N][KH][KW], taps mirrored
-                npad = (N + 3) // 4 * 4
-                if npad != N:  # the kernel needs a multiple of 4 input channels: zero-pad dY's channel axis
+                npad = (N + cmul - 1) // cmul * cmul
+                if npad != N:  # the kernel needs whole channel groups: zero-pad dY's channel axis
                     dy_in = F.pad(dy, (0, npad - N))
                     wt = F.pad(wt, (0, 0, 0, 0, 0, npad - N))
                 else:
                     dy_in = dy
-                pc = DevPack(wt, None, stride=1, pad=KH - 1 - pad)
-                dx = conv(pc, Act(dy_in.contiguous().view(-1), B, OH, OW, npad)).buf.view(B, H, W, Cin)
+                dx = _conv_any(DevPack(wt, None, stride=1, pad=KH - 1 - pad), dy_in, prec).view(B, H, W, Cin)
+            dx = dx.to(x.dtype)
         if ctx.needs_input_grad[1]:
+            xw = x if prec == "f32" else x.to(_TDT[prec])  # weight gradient in the compute precision, handed to the fp32 master weight
+            dyw = dy if prec == "f32" else dy.to(_TDT[prec])
             if KH == 1 and KW == 1 and stride == 1:
-                dw = (dy.view(-1, N).t() @ x.reshape(-1, Cin)).view(N, Cin, 1, 1)
+                dw = (dyw.view(-1, N).t() @ xw.reshape(-1, Cin)).view(N, Cin, 1, 1).float()
             else:
-                dw = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2), weight.shape, dy.permute(0, 3, 1, 2), stride=stride, padding=pad)
+                dw = torch.nn.grad.conv2d_weight(xw.permute(0, 3, 1, 2), weight.shape, dyw.permute(0, 3, 1, 2), stride=stride, padding=pad).float()
         if has_bias and ctx.needs_input_grad[2]:
-            db = dy.view(-1, N).sum(0)
-        return dx, dw, db, None, None
+            db = dy.float().view(-1, N).sum(0)
+        return dx, dw, db, None, None, None
 
 
-def conv2d_nhwc(x, weight, bias=None, stride=1, pad=0):
-    return Conv2dNHWC.apply(x, weight, bias, stride, pad)
+def conv2d_nhwc(x, weight, bias=None, stride=1, pad=0, prec="f32"):
+    return Conv2dNHWC.apply(x, weight, bias, stride, pad, prec)
 
 
-def linear_hip(x, weight, bias=None):
+def linear_hip(x, weight, bias=None, prec="f32"):
     """nn.Linear on rows [..., K] through the same Function (a 1x1 convolution over a [rows, 1, 1, K] view)."""
     K = x.shape[-1]
-    y = Conv2dNHWC.apply(x.reshape(-1, 1, 1, K), weight.view(weight.shape[0], K, 1, 1), bias, 1, 0)
+    y = Conv2dNHWC.apply(x.reshape(-1, 1, 1, K), weight.view(weight.shape[0], K, 1, 1), bias, 1, 0, prec)
     return y.view(*x.shape[:-1], weight.shape[0])
 
 
