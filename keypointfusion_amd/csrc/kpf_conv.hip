@@ -565,6 +565,13 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
       bvv[i] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n) : zero4;
       gvv[i] = (EPI == EPI_RES && (fl & KPF_RES_GAMMA)) ? *reinterpret_cast<const f32x4*>(a.gamma + n) : zero4;
     }
+    // 16-bit output without residual, 64-channel wave tiles: the results go through LDS so that the global stores are whole 128-byte
+    // rows (a lane's 4 channels are 8 bytes: stored directly, a pixel row would be written in 32-byte pieces by four different
+    // instructions — the GELU layers of the 16-bit path write 4C-wide tensors and were bound by exactly that)
+    constexpr bool STAGED = H16 && EPI != EPI_RES && TN == 4;
+    constexpr int RS = TN * 16 + 8;  // staging row stride in elements (144 B: the 8-byte writes of a fragment column spread over the banks)
+    TH* stg = reinterpret_cast<TH*>(lds) + wave * (TM * 16) * RS;
+    if constexpr (STAGED) __syncthreads();  // every wave is done reading the last K tile: LDS becomes the staging area
     f32x4 rvv[EPI == EPI_RES ? TM : 1][TN];
     if (EPI == EPI_RES) {
 #pragma unroll
@@ -613,12 +620,25 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.01f * v[e]);
           }
         }
-        if constexpr (H16)
+        if constexpr (STAGED)
+          kpf_st4(stg + (j * 16 + fr) * RS + i * 16 + fg * 4, v);
+        else if constexpr (H16)
           kpf_st4(reinterpret_cast<TH*>(a.out) + m * a.out_ld + a.out_coff + n, v);
         else if (fl & KPF_OUT_SPLIT)
           kpf_store_split4(a.out + m * a.out_ld + a.out_coff, n, v);
         else
           STORE4(a.out + m * a.out_ld + a.out_coff + n, v);
+      }
+    }
+    if constexpr (STAGED) {
+      __syncthreads();  // (only this wave's own region is read back; the barrier doubles as the LDS fence)
+      TH* ob = reinterpret_cast<TH*>(a.out) + (long)(m0 + wm * TM * 16) * a.out_ld + a.out_coff + n0 + wn * TN * 16;
+      const int prow = lane >> 3, pch = (lane & 7) * 8;  // 8 lanes x 16 bytes = one 128-byte pixel row of the wave tile, 8 rows per instruction
+#pragma unroll
+      for (int r = 0; r < TM * 2; ++r) {
+        const int px = r * 8 + prow;
+        const f32x4 q = *reinterpret_cast<const f32x4*>(stg + px * RS + pch);
+        *reinterpret_cast<f32x4*>(ob + (long)px * a.out_ld + pch) = q;
       }
     }
     KPF_STAMP(3);
@@ -698,7 +718,11 @@ int launch_one(const ConvArgs& a, hipStream_t st) {
   constexpr bool WHOLE = NS > 2 || ARITH == ARITH_F32;
   constexpr int BMR = WHOLE ? (BM + RPP - 1) / RPP * RPP : BM, BNR = WHOLE ? (BN + RPP - 1) / RPP * RPP : BN;
   constexpr bool H16 = ARITH == ARITH_BF16 || ARITH == ARITH_F16;
-  const size_t lds = (size_t)(NS * (BMR + BNR) * BK + (HAS_PRO ? 2 * a.Kp * (H16 ? 2 : 1) : 0)) * sizeof(float);
+  size_t lds = (size_t)(NS * (BMR + BNR) * BK + (HAS_PRO ? 2 * a.Kp * (H16 ? 2 : 1) : 0)) * sizeof(float);
+  if (H16 && EPI != EPI_RES && TN == 4) {  // LDS-staged epilogue of the 16-bit path (igemm_body: STAGED)
+    const size_t stg = (size_t)WM * WN * TM * 16 * (TN * 16 + 8) * 2;
+    if (stg > lds) lds = stg;
+  }
   void (*kern)(const ConvArgs);
   if constexpr (ARITH == ARITH_F32)
     kern = igemm_f32_kernel<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, NS>;
@@ -869,17 +893,20 @@ extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void
   const bool fast1x1 = pointwise && d->Cin % 64 == 0 && d->Kp == d->Cin;  // whole 64-element K tiles, no K mask
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
-  // Tile choice: the 16-bit GEMMs of this model are bound by HBM traffic and staging, not by the matrix pipe, so tiles are picked
-  // for whole-CU rounds like the fp32 ones but from a smaller set; non-residual layers take the single-stage, 4-waves-per-SIMD
-  // variants (more workgroups per CU hide each other's DMA / barrier latencies)
+  // Tile choice (tools/gemm16_bench.py on the ConvNeXt-B 512^2 shapes): the 16-bit GEMMs are bound by HBM traffic, staging and
+  // barriers, not by the matrix pipe, and 128 x 128 tiles with several workgroups per CU beat 256 x 128 (one workgroup per CU) on
+  // every heavy shape (65536 x 2048 x 512 + GELU: 585 vs 425 TFLOP/s); non-residual layers take the single-stage, 4-waves-per-SIMD
+  // variant; residual layers with a long K take 256 x 128 with a 3-stage LDS ring (two K tiles of DMA in flight: 705 vs 667 at K = 2048)
   int best = 0;
   double bc = 1e30;
-  static const int allowed[] = {0, 1, 2, 5, 6, 7, 8};
+  static const int allowed[] = {0, 1, 2, 5, 6, 7};
   for (int i : allowed) {
     const double c = cfg_cost(kCfgs[i], a.M, a.N);
     if (c < bc) { bc = c; best = i; }
   }
+  if (a.M >= 4096 && a.N >= 256 && a.N % 128 == 0) best = 0;  // (the round model over-rates the narrow tiles at these sizes)
   const bool occ = !(fl & KPF_RES_ADD) && !pro_scale;
+  if ((fl & KPF_RES_ADD) && fast1x1 && a.Kp * 2 >= 2048 && a.M >= 32768 && a.N >= 256 && a.N % 128 == 0) best = 20;
   static const int forced = []() { const char* e = getenv("KPF_FORCE_CFG16"); return e ? atoi(e) : -1; }();  // tuning aid only
   if (forced >= 0) best = forced;
   switch (best) {
@@ -889,6 +916,9 @@ extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void
     case 5: return launch_cfg_h16<2, 4, 2, 2, 2>(a, fast1x1, pointwise, dtype, st);  // 64 x 128
     case 6: return occ ? launch_cfg_h16<2, 2, 2, 2, 1>(a, fast1x1, pointwise, dtype, st) : launch_cfg_h16<2, 2, 2, 2, 2>(a, fast1x1, pointwise, dtype, st);
     case 8: return launch_cfg_h16<4, 4, 4, 2, 2>(a, fast1x1, pointwise, dtype, st);  // 256 x 128
+    case 20: return launch_cfg_h16<4, 4, 4, 2, 3>(a, fast1x1, pointwise, dtype, st);  // 256 x 128, 3-stage LDS ring (144 KB): two K tiles of DMA in flight
+    case 21: return launch_cfg_h16<4, 4, 2, 2, 3>(a, fast1x1, pointwise, dtype, st);  // 128 x 128, 3-stage ring (96 KB)
+    case 22: return launch_cfg_h16<4, 4, 2, 2, 4>(a, fast1x1, pointwise, dtype, st);  // 128 x 128, 4-stage ring (128 KB)
     default: return launch_cfg_h16<2, 1, 1, 4, 2>(a, fast1x1, pointwise, dtype, st);  // 32 x 64
   }
 }
