@@ -265,6 +265,27 @@ int kpf_cast_h16_f32(const void* src, int dtype, float* dst, long rows, int C, i
 /* dense fp32 [n] -> 16-bit (behind the fp32 stem + max-pool of the ResNet backbones); n % 4 == 0. */
 int kpf_cast_f32_h16(const float* src, void* dst, int dtype, long n, void* stream);
 
+/*
+ * Training: weight and bias gradients of nn.Conv2d / nn.Linear — what autograd's convolution_backward /
+ * addmm_backward compute for the layers of kpf_conv2d_f32 when the reference trains (train.py:198-232).
+ *     dw[n][c][ky][kx] = sum_{b,oy,ox} dy[b][oy][ox][n] * x[b][oy*sh+ky-ph][ox*sw+kx-pw][c]      (OIHW, PyTorch's layout)
+ *     db[n]            = sum_{b,oy,ox} dy[b][oy][ox][n]                                           (db may be NULL)
+ * dy: NHWC [B][OH][OW] with pixel stride ldy (N channels used), x: NHWC [B][H][W] with pixel stride ldx (Cin channels used);
+ * Cin, N, ldx, ldy multiples of 4, 16-byte aligned pointers.  fp32 on v_mfma_f32_16x16x4_f32, split over the pixel range with a
+ * fixed-order (run-to-run deterministic) reduction through `ws` (>= kpf_conv2d_wgrad_ws_floats(B*OH*OW, N, KH*KW*Cin) floats).
+ */
+long kpf_conv2d_wgrad_ws_floats(long M, int N, int K);
+int kpf_conv2d_wgrad_f32(const float* dy, const float* x, float* dw, float* db, float* ws, long ws_floats, int B, int H, int W, int Cin,
+                         int ldx, int OH, int OW, int N, int ldy, int KH, int KW, int sh, int sw, int ph, int pw, void* stream);
+/* Depthwise 7x7 (pad 3) + bias alone, y = dwconv(x): the ConvNeXt block's first op with its output kept for the LayerNorm backward,
+ * and its data gradient (dx = the same convolution of dy with w_dw's taps mirrored, zero bias).  w_dw [49][C], x != y. */
+int kpf_dwconv7_f32(const float* x, const float* w_dw, const float* b_dw, float* y, int B, int H, int W, int C, void* stream);
+/* The same for the ConvNeXt block's depthwise 7x7 (pad 3): dw [C][7][7] (= PyTorch's [C][1][7][7]), db [C] or NULL; dy, x dense NHWC
+ * [B][H][W][C], C % 4 == 0; ws >= kpf_dwconv7_wgrad_ws_floats(B, H, C) floats. */
+long kpf_dwconv7_wgrad_ws_floats(int B, int H, int C);
+int kpf_dwconv7_wgrad_f32(const float* dy, const float* x, float* dw, float* db, float* ws, long ws_floats, int B, int H, int W, int C,
+                          void* stream);
+
 int kpf_conv_num_tile_cfgs(void);
 
 const char* kpf_last_error(void);

@@ -701,6 +701,22 @@ static int dwconv7_ln_impl(const TA* x, const float* w_dw, const float* b_dw, co
   return kpf_check_launch("kpf_dwconv7_ln");
 }
 
+// depthwise 7x7 + bias alone (training: forward of the ConvNeXt block's dwconv with the pre-norm activation kept for backward, and
+// its data gradient = the same convolution of dY with the taps mirrored)
+extern "C" int kpf_dwconv7_f32(const float* x, const float* w_dw, const float* b_dw, float* y, int B, int H, int W, int C, void* stream) {
+  KPF_REQUIRE(x && w_dw && b_dw && y && x != y, "kpf_dwconv7_f32: null pointer or in-place call");
+  KPF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "kpf_dwconv7_f32: bad shape (C %% 4 == 0)");
+  KPF_REQUIRE(kpf_aligned16(x) && kpf_aligned16(y) && kpf_aligned16(w_dw) && kpf_aligned16(b_dw), "kpf_dwconv7_f32: pointers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int xstrips = (W + 7) / 8, ypairs = (H + 1) / 2;
+  const long total = (long)B * ypairs * xstrips * (C / 4);
+  const size_t wbytes = (size_t)49 * C * sizeof(float);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (wbytes <= 48 * 1024) hipLaunchKernelGGL((dwconv7_kernel<float, true, 8>), grid, dim3(256), wbytes, st, x, w_dw, b_dw, y, B, H, W, C, xstrips, ypairs);
+  else hipLaunchKernelGGL((dwconv7_kernel<float, false, 8>), grid, dim3(256), 0, st, x, w_dw, b_dw, y, B, H, W, C, xstrips, ypairs);
+  return kpf_check_launch("kpf_dwconv7_f32");
+}
+
 extern "C" int kpf_dwconv7_ln_f32(const float* x, const float* w_dw, const float* b_dw, const float* ln_w, const float* ln_b,
                                   float* y, int B, int H, int W, int C, float eps, void* stream) {
   return dwconv7_ln_impl<float>(x, w_dw, b_dw, ln_w, ln_b, y, B, H, W, C, eps, stream, false);

@@ -1,0 +1,396 @@
+// Weight gradients of the training step on gfx950.
+//
+// (1) wgrad_f32_kernel — dense convolution / Linear:
+//         dW[n][(ky,kx,c)] = sum over pixels m = (b,oy,ox) of dY[m][n] * X[b][oy*sh+ky-ph][ox*sw+kx-pw][c]
+//     = a GEMM whose REDUCTION dimension is the pixel index: both operands are stored with the reduction index as the slow (row)
+//     dimension (dY rows are n-contiguous, X pixels c-contiguous), which is exactly the fragment order of v_mfma_f32_16x16x4_f32
+//     when LDS holds the tiles as they are in memory: lane l reads 16 bytes at row (l/16 + 4*kstep), column 4*(l%16) and gets the
+//     operands of four MFMA tiles at once (MFMA row r of tile i <-> n = 4r+i: a permutation of the OUTPUT only).  No transposes
+//     anywhere; the tiles are staged by LDS-DMA (global_load_lds_dwordx4) straight from dY and from the im2col addresses of X
+//     (out-of-image / out-of-range chunks read a zero page).  The pixel range is split over gridDim.y workgroups per output tile
+//     (split-K); partial tiles go to a workspace and wgrad_reduce_kernel sums them in a fixed order (deterministic, no atomics)
+//     while permuting (ky,kx,c) -> the reference's OIHW weight layout.  db = sum_m dY[m][n] falls out of the dY fragments.
+// (2) dwconv7_wgrad_kernel — depthwise 7x7: 49 x C outputs, HBM/L2-bound; thread = (4 channels, tap row ky), sliding 14-pixel
+//     window in registers, partial sums per (image, row band) chunk, same fixed-order reduce.
+#include "kpf_common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) void gbl_void_t;
+
+__device__ __attribute__((aligned(16))) float wg_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+struct WgradArgs {
+  const float* dy;   // [M][ldy]
+  const float* x;    // NHWC [B][H][W][ldx]
+  float* part;       // [S][N][K]
+  float* dbpart;     // [S][N] or nullptr
+  const float* zero;
+  int H, W, Cin, ldx, OH, OW, N, ldy, KH, KW, sh, sw, ph, pw;
+  int M, K, tilesK, stages_per_split;
+  int is1x1;
+};
+
+constexpr int RB = 32;  // pixels (reduction rows) per LDS stage
+
+template <int VN, int VK>
+__global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradArgs a) {
+  constexpr int BN = 32 * VN, BK = 32 * VK;     // output tile; 2 x 2 waves, wave tile (16 VN) x (16 VK)
+  constexpr int GA = BN / 4, GB = BK / 4;       // 16-byte granules per staged row
+  constexpr int RA = 64 / GA, RBW = 64 / GB;    // rows one wave-DMA (64 lanes x 16 B) covers
+  constexpr int TILE = RB * (BN + BK);
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][TILE]: A = dY tile [RB][BN], B = X tile [RB][BK]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 1, wk = wave >> 1;
+  const int nt = blockIdx.x / a.tilesK, kt = blockIdx.x % a.tilesK;
+  const int n0 = nt * BN, k0 = kt * BK;
+  const int split = blockIdx.y;
+  const int total_stages = (a.M + RB - 1) / RB;
+  const int s_begin = split * a.stages_per_split;
+  const int ns = min(a.stages_per_split, total_stages - s_begin);
+  const int m_begin = s_begin * RB;
+
+  // --- per-thread staging constants ---------------------------------------------------------------------------------------
+  const int ga = lane % GA, ra = lane / GA;     // A: granule column / row inside one wave-DMA
+  const int gb = lane % GB, rb = lane / GB;
+  const bool a_ok = n0 + 4 * ga < a.N;
+  const float* a_src = a.dy + n0 + 4 * ga;
+  const int kcol = k0 + 4 * gb;
+  const bool b_ok = kcol < a.K;
+  const int tap = kcol / a.Cin, cch = kcol - tap * a.Cin;
+  const int ky = tap / a.KW, kx = tap - ky * a.KW;
+  const int ohw = a.OH * a.OW;
+
+  auto stage = [&](int s, float* buf) {
+    const int mb = m_begin + s * RB;
+#pragma unroll
+    for (int i = 0; i < VN; ++i) {  // A: VN wave-DMAs per wave
+      const int d = i * 4 + wave;
+      const int m = mb + d * RA + ra;
+      const float* src = (a_ok && m < a.M) ? a_src + (size_t)m * a.ldy : a.zero;
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(buf + d * 256), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < VK; ++i) {
+      const int d = i * 4 + wave;
+      const int m = mb + d * RBW + rb;
+      const float* src = a.zero;
+      if (b_ok && m < a.M) {
+        if (a.is1x1) {
+          src = a.x + (size_t)m * a.ldx + cch;
+        } else {
+          const int b = m / ohw, r = m - b * ohw;
+          const int oy = r / a.OW, ox = r - oy * a.OW;
+          const int iy = oy * a.sh + ky - a.ph, ix = ox * a.sw + kx - a.pw;
+          if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) src = a.x + ((size_t)(b * a.H + iy) * a.W + ix) * a.ldx + cch;
+        }
+      }
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(buf + RB * BN + d * 256), 16, 0, 0);
+    }
+  };
+
+  typedef float fvn __attribute__((ext_vector_type(VN)));
+  typedef float fvk __attribute__((ext_vector_type(VK)));
+  f32x4 acc[VN][VK];
+#pragma unroll
+  for (int i = 0; i < VN; ++i)
+#pragma unroll
+    for (int j = 0; j < VK; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  fvn dbs = 0.f;
+  const bool want_db = a.dbpart != nullptr && kt == 0 && wk == 0;
+
+  const int fr = lane >> 4, fc = lane & 15;  // fragment row inside a 4-pixel k-step / 16-lane column index
+  const int a_off = fr * BN + wn * (16 * VN) + VN * fc;
+  const int b_off = RB * BN + fr * BK + wk * (16 * VK) + VK * fc;
+
+  if (ns > 0) stage(0, lds);
+  for (int s = 0; s < ns; ++s) {
+    __syncthreads();  // the barrier's fence drains the DMA of tile s; every wave is done with tile s-1
+    float* cur = lds + (s & 1) * TILE;
+    if (s + 1 < ns) stage(s + 1, lds + ((s + 1) & 1) * TILE);
+#pragma unroll
+    for (int q = 0; q < RB / 4; ++q) {
+      const fvn af = *reinterpret_cast<const fvn*>(cur + a_off + 4 * q * BN);
+      const fvk bf = *reinterpret_cast<const fvk*>(cur + b_off + 4 * q * BK);
+      if (want_db) dbs += af;
+#pragma unroll
+      for (int i = 0; i < VN; ++i)
+#pragma unroll
+        for (int j = 0; j < VK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // --- partial tile -> workspace: lane holds, for tile (i, j) and r = 0..3: n = 4*(4*fr + r) + i (VN-interleaved), k = VK*fc + j ---
+  float* part = a.part + (size_t)split * a.N * a.K;
+  const int kk = k0 + wk * (16 * VK) + VK * fc;
+#pragma unroll
+  for (int i = 0; i < VN; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + wn * (16 * VN) + VN * (4 * fr + r) + i;
+      if (n < a.N && kk < a.K) {
+        fvk v;
+#pragma unroll
+        for (int j = 0; j < VK; ++j) v[j] = acc[i][j][r];
+        *reinterpret_cast<fvk*>(part + (size_t)n * a.K + kk) = v;
+      }
+    }
+  if (want_db) {
+#pragma unroll
+    for (int i = 0; i < VN; ++i) {
+      float v = dbs[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int n = n0 + wn * (16 * VN) + VN * fc + i;
+      if (fr == 0 && n < a.N) a.dbpart[(size_t)split * a.N + n] = v;
+    }
+  }
+}
+
+// Fixed-order sum of S partial arrays of n floats: a workgroup owns 64 consecutive outputs, its four waves sum the partials
+// p = w, w+4, w+8, ... (four independent chains each) and the four wave sums are combined through LDS — the same order every run.
+__device__ __forceinline__ float sum_partials(const float* __restrict__ part, long n, int S, long i, float (*red)[64]) {
+  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n) {
+    int p = g;
+    for (; p + 12 < S; p += 16) {
+      s0 += part[(size_t)p * n + i];
+      s1 += part[(size_t)(p + 4) * n + i];
+      s2 += part[(size_t)(p + 8) * n + i];
+      s3 += part[(size_t)(p + 12) * n + i];
+    }
+    for (; p < S; p += 4) s0 += part[(size_t)p * n + i];
+  }
+  red[g][o] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  return (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
+}
+
+// dw[n][c][ky][kx] = sum_s part[s][n][(ky,kx,c)];  db[n] = sum_s dbpart[s][n]   (blocks [0, nkb) reduce dw, the rest db)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbpart,
+                                                           float* __restrict__ dw, float* __restrict__ db, int S, int N, int K, int Cin,
+                                                           int KHW, int nkb) {
+  __shared__ float red[4][64];
+  const int o = threadIdx.x & 63;
+  if ((int)blockIdx.x < nkb) {
+    const long NK = (long)N * K;
+    const long i = (long)blockIdx.x * 64 + o;
+    const float v = sum_partials(part, NK, S, i, red);
+    if (threadIdx.x < 64 && i < NK) {
+      const int n = (int)(i / K), k = (int)(i - (long)n * K);
+      const int tap = k / Cin, c = k - tap * Cin;
+      dw[((size_t)n * Cin + c) * KHW + tap] = v;
+    }
+  } else {
+    const long i = (long)(blockIdx.x - nkb) * 64 + o;
+    const float v = sum_partials(dbpart, N, S, i, red);
+    if (threadIdx.x < 64 && i < N) db[i] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// depthwise 7x7 (pad 3, stride 1): dW[c][ky][kx] = sum_{b,y,x} dY[b][y][x][c] * X[b][y+ky-3][x+kx-3][c],  db[c] = sum dY
+// thread = (channel quad q, tap row ky); chunk (blockIdx.y) = a range of (b, y) output rows.
+// part: [S][7][7][C] (+ [S][C] for db, accumulated by the ky == 3 threads)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            float* __restrict__ part, float* __restrict__ dbpart, int B, int H, int W,
+                                                            int C, int rows_per_chunk) {
+  const int Q = C >> 2;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= 7 * Q) return;
+  const int ky = t / Q, q = t - ky * Q;
+  const int c = 4 * q;
+  const long rows = (long)B * H;
+  const long r0 = (long)blockIdx.y * rows_per_chunk;
+  const long r1 = min(rows, r0 + rows_per_chunk);
+  f32x4 acc[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 dbs = f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (long r = r0; r < r1; ++r) {
+    const int b = (int)(r / H), y = (int)(r - (long)b * H);
+    const int iy = y + ky - 3;
+    const float* dyr = dy + ((size_t)r * W) * C + c;
+    if (ky == 3) {
+      for (int xx = 0; xx < W; ++xx) dbs += kpf_ld4(dyr + (size_t)xx * C);
+    }
+    if ((unsigned)iy >= (unsigned)H) continue;
+    const float* xr = x + (((size_t)b * H + iy) * W) * C + c;
+    for (int x0 = 0; x0 < W; x0 += 8) {
+      f32x4 win[14], g[8];
+#pragma unroll
+      for (int j = 0; j < 14; ++j) {
+        const int ix = x0 + j - 3;
+        win[j] = (unsigned)ix < (unsigned)W ? kpf_ld4(xr + (size_t)ix * C) : z4;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] = x0 + j < W ? kpf_ld4(dyr + (size_t)(x0 + j) * C) : z4;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) acc[kx] += g[j] * win[j + kx];
+    }
+  }
+  float* p = part + ((size_t)blockIdx.y * 49 + ky * 7) * C + c;
+#pragma unroll
+  for (int kx = 0; kx < 7; ++kx) kpf_st4(p + (size_t)kx * C, acc[kx]);
+  if (ky == 3) kpf_st4(dbpart + (size_t)blockIdx.y * C + c, dbs);
+}
+
+// dw[c][tap] = sum_s part[s][tap][c];  db[c] = sum_s dbpart[s][c]
+__global__ __launch_bounds__(256) void dwconv7_wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbpart,
+                                                                   float* __restrict__ dw, float* __restrict__ db, int S, int C, int nkb) {
+  __shared__ float red[4][64];
+  const int o = threadIdx.x & 63;
+  if ((int)blockIdx.x < nkb) {
+    const long n = 49L * C;
+    const long i = (long)blockIdx.x * 64 + o;
+    const float v = sum_partials(part, n, S, i, red);
+    if (threadIdx.x < 64 && i < n) {
+      const int tap = (int)(i / C), c = (int)(i - (long)tap * C);
+      dw[c * 49 + tap] = v;
+    }
+  } else {
+    const long i = (long)(blockIdx.x - nkb) * 64 + o;
+    const float v = sum_partials(dbpart, C, S, i, red);
+    if (threadIdx.x < 64 && i < C) db[i] = v;
+  }
+}
+
+struct Plan { int vn, vk, tilesN, tilesK, S, sps; };
+
+// Tile shape and split count from a small cost model: MFMA time of the padded tiles, L2 -> LDS bytes (every dY row is staged once
+// per K tile column, every X row once per N tile row), and the workspace round trip of S partial outputs; S fills the chip
+// (~3 workgroups per CU) with at least four stages per workgroup.
+Plan plan_wgrad(long M, int N, int K) {
+  const int total = (int)((M + RB - 1) / RB);
+  Plan best{};
+  double best_t = 1e30;
+  for (int vn = 2; vn <= 4; vn += 2)
+    for (int vk = 2; vk <= 4; vk += 2) {
+      Plan p;
+      p.vn = vn, p.vk = vk;
+      p.tilesN = (N + 32 * vn - 1) / (32 * vn);
+      p.tilesK = (K + 32 * vk - 1) / (32 * vk);
+      const int tiles = p.tilesN * p.tilesK;
+      int S = (768 + tiles - 1) / tiles;
+      const int smax = (total + 3) / 4;
+      if (S > smax) S = smax < 1 ? 1 : smax;
+      p.sps = (total + S - 1) / S;
+      p.S = (total + p.sps - 1) / p.sps;
+      const double np = 32.0 * vn * p.tilesN, kp = 32.0 * vk * p.tilesK;
+      const double t_mfma = 2.0 * M * np * kp / 110e12;
+      const double t_l2 = 4.0 * M * (np * p.tilesK + kp * p.tilesN) / 5e12;
+      const double t_ws = 8.0 * p.S * (double)N * K / 3e12;
+      const double occ = (double)tiles * p.S / 512.0;  // fewer than two workgroups per CU: the chip is not full
+      const double t = (t_mfma > t_l2 ? t_mfma : t_l2) / (occ < 1.0 ? occ : 1.0) + t_ws;
+      if (t < best_t) best_t = t, best = p;
+    }
+  return best;
+}
+
+const float* zero_page() {
+  static std::atomic<const float*> cache[KPF_MAX_DEVICES];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= KPF_MAX_DEVICES) return nullptr;
+  const float* p = cache[dev].load(std::memory_order_acquire);
+  if (p) return p;
+  void* q = nullptr;
+  if (hipGetSymbolAddress(&q, HIP_SYMBOL(wg_zero16)) != hipSuccess || !q) return nullptr;
+  cache[dev].store((const float*)q, std::memory_order_release);
+  return (const float*)q;
+}
+
+template <int VN, int VK>
+int launch_wgrad(const WgradArgs& a, const Plan& p, hipStream_t st) {
+  constexpr int LDS = 2 * RB * 32 * (VN + VK) * 4;
+  hipLaunchKernelGGL((wgrad_f32_kernel<VN, VK>), dim3(p.tilesN * p.tilesK, p.S), dim3(256), LDS, st, a);
+  return kpf_check_launch("kpf_conv2d_wgrad_f32");
+}
+
+int dw_chunk_rows(int B, int H, int C) {
+  const long rows = (long)B * H;
+  const int bx = (7 * (C / 4) + 255) / 256;
+  long S = 768 / bx;  // ~3 workgroups per CU
+  if (S < 1) S = 1;
+  if (S > rows) S = rows;
+  return (int)((rows + S - 1) / S);
+}
+
+}  // namespace
+
+extern "C" {
+
+long kpf_conv2d_wgrad_ws_floats(long M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const Plan p = plan_wgrad(M, N, K);
+  return (long)p.S * N * K + (long)p.S * N;
+}
+
+int kpf_conv2d_wgrad_f32(const float* dy, const float* x, float* dw, float* db, float* ws, long ws_floats, int B, int H, int W, int Cin,
+                         int ldx, int OH, int OW, int N, int ldy, int KH, int KW, int sh, int sw, int ph, int pw, void* stream) {
+  KPF_REQUIRE(dy && x && dw && ws, "kpf_conv2d_wgrad_f32: null pointer");
+  KPF_REQUIRE(B > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && KH > 0 && KW > 0 && sh > 0 && sw > 0, "kpf_conv2d_wgrad_f32: bad shape");
+  KPF_REQUIRE(Cin > 0 && Cin % 4 == 0 && ldx % 4 == 0 && ldx >= Cin, "kpf_conv2d_wgrad_f32: Cin and ldx must be multiples of 4 (got %d, %d)", Cin, ldx);
+  KPF_REQUIRE(N > 0 && N % 4 == 0 && ldy % 4 == 0 && ldy >= N, "kpf_conv2d_wgrad_f32: N and ldy must be multiples of 4 (got %d, %d)", N, ldy);
+  KPF_REQUIRE(kpf_aligned16(dy) && kpf_aligned16(x) && kpf_aligned16(ws), "kpf_conv2d_wgrad_f32: dy, x, ws must be 16-byte aligned");
+  KPF_REQUIRE(OH == (H + 2 * ph - KH) / sh + 1 && OW == (W + 2 * pw - KW) / sw + 1, "kpf_conv2d_wgrad_f32: output size %dx%d does not match the convolution", OH, OW);
+  const long M = (long)B * OH * OW;
+  const long K = (long)KH * KW * Cin;
+  KPF_REQUIRE(M < (1L << 31) && K < (1L << 24) && (long)B * H * W < (1L << 31), "kpf_conv2d_wgrad_f32: problem too large");
+  const Plan p = plan_wgrad(M, N, (int)K);
+  KPF_REQUIRE(ws_floats >= (long)p.S * N * K + (long)p.S * N, "kpf_conv2d_wgrad_f32: workspace too small (%ld floats, need %ld)", ws_floats,
+              (long)p.S * N * K + (long)p.S * N);
+  WgradArgs a;
+  a.dy = dy, a.x = x, a.part = ws, a.dbpart = db ? ws + (size_t)p.S * N * K : nullptr;
+  a.zero = zero_page();
+  KPF_REQUIRE(a.zero, "kpf_conv2d_wgrad_f32: cannot resolve the zero page");
+  a.H = H, a.W = W, a.Cin = Cin, a.ldx = ldx, a.OH = OH, a.OW = OW, a.N = N, a.ldy = ldy, a.KH = KH, a.KW = KW;
+  a.sh = sh, a.sw = sw, a.ph = ph, a.pw = pw, a.M = (int)M, a.K = (int)K, a.tilesK = p.tilesK, a.stages_per_split = p.sps;
+  a.is1x1 = KH == 1 && KW == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0 && OH == H && OW == W;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (p.vn == 4 && p.vk == 4) rc = launch_wgrad<4, 4>(a, p, st);
+  else if (p.vn == 4) rc = launch_wgrad<4, 2>(a, p, st);
+  else if (p.vk == 4) rc = launch_wgrad<2, 4>(a, p, st);
+  else rc = launch_wgrad<2, 2>(a, p, st);
+  if (rc != KPF_OK) return rc;
+  const long NK = (long)N * K;
+  const int nkb = (int)((NK + 63) / 64);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nkb + (db ? (N + 63) / 64 : 0)), dim3(256), 0, st, ws, a.dbpart, dw, db, p.S, N, (int)K, Cin,
+                     KH * KW, nkb);
+  return kpf_check_launch("kpf_conv2d_wgrad_f32 (reduce)");
+}
+
+long kpf_dwconv7_wgrad_ws_floats(int B, int H, int C) {
+  if (B <= 0 || H <= 0 || C <= 0) return 0;
+  const int rpc = dw_chunk_rows(B, H, C);
+  const long S = ((long)B * H + rpc - 1) / rpc;
+  return S * 50 * C;
+}
+
+int kpf_dwconv7_wgrad_f32(const float* dy, const float* x, float* dw, float* db, float* ws, long ws_floats, int B, int H, int W, int C,
+                          void* stream) {
+  KPF_REQUIRE(dy && x && dw && ws, "kpf_dwconv7_wgrad_f32: null pointer");
+  KPF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "kpf_dwconv7_wgrad_f32: bad shape (C %% 4 == 0)");
+  KPF_REQUIRE(kpf_aligned16(dy) && kpf_aligned16(x) && kpf_aligned16(ws), "kpf_dwconv7_wgrad_f32: dy, x, ws must be 16-byte aligned");
+  const int rpc = dw_chunk_rows(B, H, C);
+  const int S = (int)(((long)B * H + rpc - 1) / rpc);
+  KPF_REQUIRE(ws_floats >= (long)S * 50 * C, "kpf_dwconv7_wgrad_f32: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* dbpart = ws + (size_t)S * 49 * C;
+  hipLaunchKernelGGL(dwconv7_wgrad_kernel, dim3((7 * (C / 4) + 255) / 256, S), dim3(256), 0, st, dy, x, ws, dbpart, B, H, W, C, rpc);
+  int rc = kpf_check_launch("kpf_dwconv7_wgrad_f32");
+  if (rc != KPF_OK) return rc;
+  const int nkb = (49 * C + 63) / 64;
+  hipLaunchKernelGGL(dwconv7_wgrad_reduce_kernel, dim3(nkb + (db ? (C + 63) / 64 : 0)), dim3(256), 0, st, ws, dbpart, dw, db, S, C, nkb);
+  return kpf_check_launch("kpf_dwconv7_wgrad_f32 (reduce)");
+}
+
+}  // extern "C"

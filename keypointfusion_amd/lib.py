@@ -69,8 +69,16 @@ _SIGS = {
     "kpf_tr_encoder_weight_floats": [C.c_int],
     "kpf_conv_num_tile_cfgs": [],
     "kpf_xattn_weight_floats": [],
+    "kpf_conv2d_wgrad_f32": [_P] * 5 + [C.c_long] + [C.c_int] * 15 + [_P],
+    "kpf_dwconv7_f32": [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_dwconv7_wgrad_f32": [_P] * 5 + [C.c_long] + [C.c_int] * 4 + [_P],
 }
-EXPORTS = sorted(list(_SIGS) + ["kpf_last_error", "kpf_abi_version", "kpf_cbam_workspace_floats"])
+_LONG_SIGS = {  # entries returning a long
+    "kpf_cbam_workspace_floats": [C.c_int, C.c_int, C.c_int],
+    "kpf_conv2d_wgrad_ws_floats": [C.c_long, C.c_int, C.c_int],
+    "kpf_dwconv7_wgrad_ws_floats": [C.c_int, C.c_int, C.c_int],
+}
+EXPORTS = sorted(list(_SIGS) + list(_LONG_SIGS) + ["kpf_last_error", "kpf_abi_version"])
 
 _lib = None
 
@@ -94,8 +102,10 @@ def load():
         fn.restype = C.c_int
     lib.kpf_last_error.restype = C.c_char_p
     lib.kpf_abi_version.restype = C.c_int
-    lib.kpf_cbam_workspace_floats.argtypes = [C.c_int, C.c_int, C.c_int]
-    lib.kpf_cbam_workspace_floats.restype = C.c_long
+    for name, args in _LONG_SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_long
     _lib = lib
     return lib
 

@@ -26,7 +26,7 @@ import torch.nn.functional as F
 
 from . import lib as L
 from .engine import _ptr, _stream, crop_inverse
-from .training import conv2d_nhwc, linear_hip
+from .training import conv2d_nhwc, dwconv7_nhwc, linear_hip
 
 J = 21
 
@@ -80,34 +80,43 @@ class TrainGraph:
         return F.dropout(x, self.pd, True) if self.pd > 0 else x
 
     # ---- backbones (convNeXT/convnext.py, convNeXT/resnetUnet.py, model/resnet.py, model/resnetUnet.py, model/hourglass.py) -----------
+    # Activations stay NHWC ([B, H, W, C] contiguous) from the stem to the heads: the HIP convolutions take and return that layout, a
+    # BatchNorm2d over (B, H, W) is F.batch_norm on the [pixels, C] view, the channels-first LayerNorms of the ConvNeXt stem /
+    # downsample layers are F.layer_norm over the last axis (same biased variance, eps inside the root), and the ops that want NCHW
+    # (bilinear upsample, max-pool, the few library convolutions) see the same memory as a channels_last view: no layout copies.
+    def conv_l(self, x, p_w, p_b=None, stride=1, pad=0):
+        """NHWC in / out."""
+        w = self.t[p_w]
+        b = self.t[p_b] if p_b is not None else None
+        cin, k = w.shape[1], w.shape[2]
+        patch = stride == k and pad == 0 and stride > 1
+        if cin % self.cmul == 0 and (stride == 1 or patch) and w.shape[2] == w.shape[3]:
+            return conv2d_nhwc(x.contiguous(), w, b, stride, pad, self.prec)
+        return F.conv2d(x.permute(0, 3, 1, 2), w, b, stride=stride, padding=pad).permute(0, 2, 3, 1).contiguous()
+
+    def bn_l(self, x, p, eps=1e-5):
+        shp = x.shape
+        return self.bn(x.reshape(-1, shp[-1]), p, eps).view(shp)
+
     def residual(self, p, x):
-        cin = x.shape[1]
-        out = F.relu(self.bn(x, p + ".bn1"))
-        out = self.conv(out, p + ".conv1.conv.weight", p + ".conv1.conv.bias")
-        out = F.relu(self.bn(out, p + ".bn2"))
-        out = self.conv(out, p + ".conv2.conv.weight", p + ".conv2.conv.bias", pad=1)
-        out = F.relu(self.bn(out, p + ".bn3"))
-        out = self.conv(out, p + ".conv3.conv.weight", p + ".conv3.conv.bias")
-        if cin != out.shape[1]:
-            x = self.conv(x, p + ".skip_layer.conv.weight", p + ".skip_layer.conv.bias")
+        cin = x.shape[-1]
+        out = F.relu(self.bn_l(x, p + ".bn1"))
+        out = self.conv_l(out, p + ".conv1.conv.weight", p + ".conv1.conv.bias")
+        out = F.relu(self.bn_l(out, p + ".bn2"))
+        out = self.conv_l(out, p + ".conv2.conv.weight", p + ".conv2.conv.bias", pad=1)
+        out = F.relu(self.bn_l(out, p + ".bn3"))
+        out = self.conv_l(out, p + ".conv3.conv.weight", p + ".conv3.conv.bias")
+        if cin != out.shape[-1]:
+            x = self.conv_l(x, p + ".skip_layer.conv.weight", p + ".skip_layer.conv.bias")
         return out + x
 
-    @staticmethod
-    def layernorm_cf(x, w, b, eps=1e-6):
-        u = x.mean(1, keepdim=True)
-        s = (x - u).pow(2).mean(1, keepdim=True)
-        x = (x - u) / torch.sqrt(s + eps)
-        return w[:, None, None] * x + b[:, None, None]
-
     def convnext_block(self, p, x):
-        c = x.shape[1]
-        y = F.conv2d(x, self.t[p + ".dwconv.weight"], self.t[p + ".dwconv.bias"], padding=3, groups=c)
-        y = y.permute(0, 2, 3, 1)
+        c = x.shape[-1]
+        y = dwconv7_nhwc(x.float(), self.t[p + ".dwconv.weight"], self.t[p + ".dwconv.bias"])
         y = F.layer_norm(y, (c,), self.t[p + ".norm.weight"], self.t[p + ".norm.bias"], 1e-6)
         y = F.gelu(self.linear(y, p + ".pwconv1.weight", p + ".pwconv1.bias"))
         y = self.linear(y, p + ".pwconv2.weight", p + ".pwconv2.bias")
-        y = self.t[p + ".gamma"] * y
-        return x + y.permute(0, 3, 1, 2)  # (drop_path_rate is 0 in the reference's constructor call: identity)
+        return x + self.t[p + ".gamma"] * y  # (drop_path_rate is 0 in the reference's constructor call: identity)
 
     def convnext_features(self, p, x):
         feats = []
@@ -115,11 +124,11 @@ class TrainGraph:
         while self.has(p + ".downsample_layers.%d.0.weight" % i):
             q = p + ".downsample_layers.%d" % i
             if i == 0:
-                x = self.conv(x, q + ".0.weight", q + ".0.bias", stride=4)
-                x = self.layernorm_cf(x, self.t[q + ".1.weight"], self.t[q + ".1.bias"])
+                x = self.conv_l(x, q + ".0.weight", q + ".0.bias", stride=4)
+                x = F.layer_norm(x, (x.shape[-1],), self.t[q + ".1.weight"], self.t[q + ".1.bias"], 1e-6)
             else:
-                x = self.layernorm_cf(x, self.t[q + ".0.weight"], self.t[q + ".0.bias"])
-                x = self.conv(x, q + ".1.weight", q + ".1.bias", stride=2)
+                x = F.layer_norm(x, (x.shape[-1],), self.t[q + ".0.weight"], self.t[q + ".0.bias"], 1e-6)
+                x = self.conv_l(x, q + ".1.weight", q + ".1.bias", stride=2)
             j = 0
             while self.has(p + ".stages.%d.%d.gamma" % (i, j)):
                 x = self.convnext_block(p + ".stages.%d.%d" % (i, j), x)
@@ -129,9 +138,9 @@ class TrainGraph:
         return feats
 
     def resnet_features(self, p, x):
-        x = self.conv(x, p + ".conv1.weight", None, stride=2, pad=3)
-        x = F.relu(self.bn(x, p + ".bn1"))
-        x = F.max_pool2d(x, 3, 2, 1)
+        x = self.conv_l(x, p + ".conv1.weight", None, stride=2, pad=3)
+        x = F.relu(self.bn_l(x, p + ".bn1"))
+        x = F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).contiguous()
         feats = []
         for li in range(1, 5):
             j = 0
@@ -140,33 +149,38 @@ class TrainGraph:
                 stride = 2 if (li > 1 and j == 0) else 1
                 idt = x
                 if self.has(q + ".conv3.weight"):
-                    out = F.relu(self.bn(self.conv(x, q + ".conv1.weight"), q + ".bn1"))
-                    out = F.relu(self.bn(self.conv(out, q + ".conv2.weight", None, stride, 1), q + ".bn2"))
-                    out = self.bn(self.conv(out, q + ".conv3.weight"), q + ".bn3")
+                    out = F.relu(self.bn_l(self.conv_l(x, q + ".conv1.weight"), q + ".bn1"))
+                    out = F.relu(self.bn_l(self.conv_l(out, q + ".conv2.weight", None, stride, 1), q + ".bn2"))
+                    out = self.bn_l(self.conv_l(out, q + ".conv3.weight"), q + ".bn3")
                 else:
-                    out = F.relu(self.bn(self.conv(x, q + ".conv1.weight", None, stride, 1), q + ".bn1"))
-                    out = self.bn(self.conv(out, q + ".conv2.weight", None, 1, 1), q + ".bn2")
+                    out = F.relu(self.bn_l(self.conv_l(x, q + ".conv1.weight", None, stride, 1), q + ".bn1"))
+                    out = self.bn_l(self.conv_l(out, q + ".conv2.weight", None, 1, 1), q + ".bn2")
                 if self.has(q + ".downsample.0.weight"):
-                    idt = self.bn(self.conv(x, q + ".downsample.0.weight", None, stride, 0), q + ".downsample.1")
+                    idt = self.bn_l(self.conv_l(x, q + ".downsample.0.weight", None, stride, 0), q + ".downsample.1")
                 x = F.relu(out + idt)
                 j += 1
             feats.append(x)
         return feats
 
     def unet(self, p, img):
+        """img NCHW (the module boundary); returns (res, feat) NCHW-shaped."""
         convnext = self.has(p + ".backbone.downsample_layers.0.0.weight")
-        c1, c2, c3, c4 = self.convnext_features(p + ".backbone", img) if convnext else self.resnet_features(p + ".backbone", img)
-        up = lambda t: F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=False)
+        x = img.permute(0, 2, 3, 1)
+        c1, c2, c3, c4 = self.convnext_features(p + ".backbone", x) if convnext else self.resnet_features(p + ".backbone", x)
+
+        def up(t):  # bilinear x2 on the channels_last view of the same memory
+            return F.interpolate(t.permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+
         c4_up = up(self.residual(p + ".up4.0", c4))
-        c3_f = self.residual(p + ".fusion_layer4", torch.cat((c4_up, self.residual(p + ".skip_layer4", c3)), 1))
+        c3_f = self.residual(p + ".fusion_layer4", torch.cat((c4_up, self.residual(p + ".skip_layer4", c3)), -1))
         c3_up = up(self.residual(p + ".up3.0", c3_f))
-        c2_f = self.residual(p + ".fusion_layer3", torch.cat((c3_up, self.residual(p + ".skip_layer3", c2)), 1))
+        c2_f = self.residual(p + ".fusion_layer3", torch.cat((c3_up, self.residual(p + ".skip_layer3", c2)), -1))
         c2_up = up(self.residual(p + ".up2.0", c2_f))
-        feat = self.residual(p + ".fusion_layer2", torch.cat((c2_up, self.residual(p + ".skip_layer2", c1)), 1))
+        feat = self.residual(p + ".fusion_layer2", torch.cat((c2_up, self.residual(p + ".skip_layer2", c1)), -1))
         if convnext:
             feat = self.residual(p + ".result_emb", feat)
-        res = torch.cat([self.conv(feat, p + ".finals.%d.weight" % i, p + ".finals.%d.bias" % i) for i in range(3)], 1)
-        return res, feat
+        res = torch.cat([self.conv_l(feat, p + ".finals.%d.weight" % i, p + ".finals.%d.bias" % i) for i in range(3)], -1)
+        return res.permute(0, 3, 1, 2).contiguous(), feat.permute(0, 3, 1, 2).contiguous()
 
     # ---- geometry -------------------------------------------------------------------------------------------------------------------
     @staticmethod

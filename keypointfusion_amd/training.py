@@ -194,6 +194,71 @@ def _conv_any(pc, x4, prec):
     return out.buf.view(out.B, out.H, out.W, out.C)
 
 
+def conv_wgrad_hip(dy, x, wshape, stride, pad, want_db=True):
+    """(dW in OIHW, db or None) of a convolution from NHWC fp32 dY [B,OH,OW,N] and X [B,H,W,Cin]: kpf_conv2d_wgrad_f32 (f32 MFMA GEMM
+    with the pixel index as the reduction dimension, split over workgroups, fixed-order reduce)."""
+    from . import lib as L
+    lib = L.load()
+    dy, x = dy.contiguous(), x.contiguous()
+    B, H, W, Cin = x.shape
+    _, OH, OW, N = dy.shape
+    KH, KW = int(wshape[2]), int(wshape[3])
+    nws = lib.kpf_conv2d_wgrad_ws_floats(B * OH * OW, N, KH * KW * Cin)
+    ws = torch.empty(nws, device=x.device, dtype=torch.float32)
+    dw = torch.empty(tuple(wshape), device=x.device, dtype=torch.float32)
+    db = torch.empty(N, device=x.device, dtype=torch.float32) if want_db else None
+    L.check(lib.kpf_conv2d_wgrad_f32(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr() if want_db else None, ws.data_ptr(), nws,
+                                     B, H, W, Cin, Cin, OH, OW, N, N, KH, KW, stride, stride, pad, pad,
+                                     torch.cuda.current_stream().cuda_stream), "kpf_conv2d_wgrad_f32")
+    return dw, db
+
+
+class DwConv7NHWC(torch.autograd.Function):
+    """Depthwise 7x7 (pad 3) + bias on NHWC fp32 [B,H,W,C] (convNeXT/convnext.py:41), weight in the reference's [C,1,7,7] layout.
+    forward kpf_dwconv7_f32; backward: dX = the same kernel on dY with mirrored taps, dW / db = kpf_dwconv7_wgrad_f32."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from . import lib as L
+        lib = L.load()
+        x = x.contiguous()
+        B, H, W, Cc = x.shape
+        assert x.dtype == torch.float32 and Cc % 4 == 0
+        wt = weight.detach().reshape(Cc, 49).t().contiguous()  # [49][C]
+        y = torch.empty_like(x)
+        L.check(lib.kpf_dwconv7_f32(x.data_ptr(), wt.data_ptr(), bias.detach().contiguous().data_ptr(), y.data_ptr(), B, H, W, Cc,
+                                    torch.cuda.current_stream().cuda_stream), "kpf_dwconv7_f32")
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import lib as L
+        lib = L.load()
+        x, weight = ctx.saved_tensors
+        B, H, W, Cc = x.shape
+        dy = dy.contiguous()
+        st = torch.cuda.current_stream().cuda_stream
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wf = weight.detach().reshape(Cc, 49).flip(1).t().contiguous()  # taps mirrored, [49][C]
+            dx = torch.empty_like(x)
+            zb = torch.zeros(Cc, device=x.device, dtype=torch.float32)
+            L.check(lib.kpf_dwconv7_f32(dy.data_ptr(), wf.data_ptr(), zb.data_ptr(), dx.data_ptr(), B, H, W, Cc, st), "kpf_dwconv7_f32")
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            nws = lib.kpf_dwconv7_wgrad_ws_floats(B, H, Cc)
+            ws = torch.empty(nws, device=x.device, dtype=torch.float32)
+            dw = torch.empty(Cc, 1, 7, 7, device=x.device, dtype=torch.float32)
+            db = torch.empty(Cc, device=x.device, dtype=torch.float32)
+            L.check(lib.kpf_dwconv7_wgrad_f32(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nws, B, H, W, Cc, st),
+                    "kpf_dwconv7_wgrad_f32")
+        return dx, dw, db
+
+
+def dwconv7_nhwc(x, weight, bias):
+    return DwConv7NHWC.apply(x, weight, bias)
+
+
 class Conv2dNHWC(torch.autograd.Function):
     """y = conv2d(x, w) + b on NHWC activations [B, H, W, Cin] (fp32, HIP device), weight in the reference's OIHW layout.
     forward : kpf_conv2d_f32 (f32-input MFMA implicit GEMM).
@@ -252,6 +317,11 @@ class Conv2dNHWC(torch.autograd.Function):
                     dy_in = dy
                 dx = _conv_any(DevPack(wt, None, stride=1, pad=KH - 1 - pad), dy_in, prec).view(B, H, W, Cin)
             dx = dx.to(x.dtype)
+        if ctx.needs_input_grad[1] and Cin % 4 == 0 and N % 4 == 0:
+            # hand-written split-K weight gradient (fp32 operands and accumulation in every precision mode: the master weight's
+            # gradient is not rounded to 16 bits), bias gradient from the same pass
+            dw, db = conv_wgrad_hip(dy.float(), x.float(), weight.shape, stride, pad, has_bias and ctx.needs_input_grad[2])
+            return dx, dw, db, None, None, None
         if ctx.needs_input_grad[1]:
             xw = x if prec == "f32" else x.to(_TDT[prec])  # weight gradient in the compute precision, handed to the fp32 master weight
             dyw = dy if prec == "f32" else dy.to(_TDT[prec])

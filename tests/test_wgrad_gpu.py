@@ -1,0 +1,85 @@
+"""Weight-gradient kernels of the training step (kpf_conv2d_wgrad_f32, kpf_dwconv7_wgrad_f32, kpf_dwconv7_f32) against
+torch's CPU float64 convolution_backward on the same seeded inputs.  fp32 tolerance: 2e-5 of the gradient's range
+(sums of up to 1.3e5 products, different summation order)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x_nhwc, dy_nhwc, wshape, stride, pad, groups=1):
+    x = x_nhwc.double().cpu().permute(0, 3, 1, 2).requires_grad_(False)
+    dy = dy_nhwc.double().cpu().permute(0, 3, 1, 2)
+    w = torch.zeros(wshape, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(wshape[0], dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x, w, b, stride=stride, padding=pad, groups=groups)
+    assert y.shape == dy.shape, (y.shape, dy.shape)
+    y.backward(dy)
+    return w.grad, b.grad
+
+
+CASES = [  # B, H, W, Cin, N, k, stride, pad
+    (2, 8, 8, 384, 1536, 1, 1, 0),     # pwconv1 at stage 3
+    (2, 8, 8, 1536, 384, 1, 1, 0),     # pwconv2
+    (4, 32, 32, 96, 384, 1, 1, 0),
+    (4, 16, 16, 64, 64, 3, 1, 1),      # Residual conv2
+    (3, 5, 7, 8, 12, 3, 1, 1),         # ragged everything
+    (2, 16, 16, 96, 192, 2, 2, 0),     # ConvNeXt downsample (patchify)
+    (2, 12, 12, 16, 48, 4, 4, 0),
+    (1, 1, 21, 128, 512, 1, 1, 0),     # a Linear over 21 tokens
+    (5, 9, 9, 4, 4, 1, 1, 0),
+    (2, 16, 16, 144, 72, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_wgrad_matches_torch(case):
+    from keypointfusion_amd.training import conv_wgrad_hip
+    B, H, W, Cin, N, k, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case))
+    OH = (H + 2 * pad - k) // stride + 1
+    OW = (W + 2 * pad - k) // stride + 1
+    x = torch.randn(B, H, W, Cin, generator=g)
+    dy = torch.randn(B, OH, OW, N, generator=g)
+    dw, db = conv_wgrad_hip(dy.cuda(), x.cuda(), (N, Cin, k, k), stride, pad, True)
+    rw, rb = _ref(x, dy, (N, Cin, k, k), stride, pad)
+    assert dw.shape == rw.shape
+    assert float((dw.cpu().double() - rw).abs().max()) <= 2e-5 * float(rw.abs().max())
+    assert float((db.cpu().double() - rb).abs().max()) <= 2e-5 * max(float(rb.abs().max()), 1.0)
+    dw2, _ = conv_wgrad_hip(dy.cuda(), x.cuda(), (N, Cin, k, k), stride, pad, False)
+    assert torch.equal(dw, dw2), "fixed-order reduction: run-to-run bit-identical"
+
+
+def test_conv_wgrad_large_pixel_count():
+    from keypointfusion_amd.training import conv_wgrad_hip
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(32, 64, 64, 48, generator=g)
+    dy = torch.randn(32, 64, 64, 128, generator=g)
+    dw, db = conv_wgrad_hip(dy.cuda(), x.cuda(), (128, 48, 1, 1), 1, 0, True)
+    rw = (dy.double().view(-1, 128).t() @ x.double().view(-1, 48)).view(128, 48, 1, 1)
+    assert float((dw.cpu().double() - rw).abs().max()) <= 2e-5 * float(rw.abs().max())
+    assert float((db.cpu().double() - dy.double().view(-1, 128).sum(0)).abs().max()) <= 2e-5 * 2000
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32, 96), (3, 16, 16, 192), (2, 8, 8, 384), (2, 4, 4, 768), (1, 5, 11, 8)])
+def test_dwconv7_forward_backward_match_torch(shape):
+    from keypointfusion_amd.training import dwconv7_nhwc
+    B, H, W, Cc = shape
+    g = torch.Generator().manual_seed(B * H + Cc)
+    x = torch.randn(B, H, W, Cc, generator=g)
+    w = torch.randn(Cc, 1, 7, 7, generator=g) * 0.2
+    b = torch.randn(Cc, generator=g)
+    dy = torch.randn(B, H, W, Cc, generator=g)
+    xd, wd, bd = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    y = dwconv7_nhwc(xd, wd, bd)
+    y.backward(dy.cuda())
+    xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, padding=3, groups=Cc)
+    yr.backward(dy.double().permute(0, 3, 1, 2))
+    tol = lambda r: 2e-5 * max(float(r.detach().abs().max()), 1e-3)
+    assert float((y.detach().cpu().double() - yr.detach().permute(0, 2, 3, 1)).abs().max()) <= tol(yr)
+    assert float((xd.grad.cpu().double() - xr.grad.permute(0, 2, 3, 1)).abs().max()) <= tol(xr.grad)
+    assert float((wd.grad.cpu().double() - wr.grad).abs().max()) <= tol(wr.grad)
+    assert float((bd.grad.cpu().double() - br.grad).abs().max()) <= tol(br.grad)
