@@ -162,6 +162,20 @@ class TrainGraph:
             feats.append(x)
         return feats
 
+    def heads(self, p, feat):
+        """The three 1x1 heads (convNeXT/resnetUnet.py:95-97) as ONE convolution over the concatenated weights, output channels
+        zero-padded to a multiple of 4 (the forward, data- and weight-gradient kernels take whole channel quads); autograd hands each
+        head's slice of the gradient back to its own parameter."""
+        ws = [self.t[p + ".finals.%d.weight" % i] for i in range(3)]
+        bs = [self.t[p + ".finals.%d.bias" % i] for i in range(3)]
+        n = sum(w.shape[0] for w in ws)
+        npad = (n + 3) // 4 * 4
+        if npad != n:
+            ws.append(ws[0].new_zeros((npad - n,) + tuple(ws[0].shape[1:])))
+            bs.append(bs[0].new_zeros(npad - n))
+        y = conv2d_nhwc(feat.contiguous(), torch.cat(ws, 0), torch.cat(bs, 0), 1, 0, self.prec)
+        return y[..., :n]
+
     def unet(self, p, img):
         """img NCHW (the module boundary); returns (res, feat) NCHW-shaped."""
         convnext = self.has(p + ".backbone.downsample_layers.0.0.weight")
@@ -179,7 +193,7 @@ class TrainGraph:
         feat = self.residual(p + ".fusion_layer2", torch.cat((c2_up, self.residual(p + ".skip_layer2", c1)), -1))
         if convnext:
             feat = self.residual(p + ".result_emb", feat)
-        res = torch.cat([self.conv_l(feat, p + ".finals.%d.weight" % i, p + ".finals.%d.bias" % i) for i in range(3)], -1)
+        res = self.heads(p, feat)
         return res.permute(0, 3, 1, 2).contiguous(), feat.permute(0, 3, 1, 2).contiguous()
 
     # ---- geometry -------------------------------------------------------------------------------------------------------------------

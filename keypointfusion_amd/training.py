@@ -137,7 +137,11 @@ def kpfusion_loss(results, spatial_weight, img, uvd_gt, xyz_gt, epoch=0, stage_t
 
 def make_optimizer(params, lr=8e-4, step_size=10, start_epoch=0, capturable=False):
     """train.py:84-91,120 with config.py's defaults: AdamW(weight_decay 0.01) over all parameters + StepLR(step_size, 0.1)."""
-    opt = torch.optim.AdamW([{"params": list(params), "initial_lr": lr}], lr=lr, weight_decay=0.01, capturable=capturable)
+    # capturable (hipGraph replay): the fused multi-tensor kernel — the per-tensor path issues ~3 scalar-tensor divisions per parameter
+    params = list(params)
+    fused = bool(capturable and params and params[0].is_cuda)
+    opt = torch.optim.AdamW([{"params": params, "initial_lr": lr}], lr=lr, weight_decay=0.01, capturable=capturable,
+                            **({"fused": True} if fused else {}))
     return opt, torch.optim.lr_scheduler.StepLR(opt, step_size=step_size, gamma=0.1, last_epoch=start_epoch)
 
 
@@ -164,8 +168,22 @@ class DevPack:
         self.N, self.K, self.Kp = N, K, (K + 31) // 32 * 32
         wk = w.permute(0, 2, 3, 1).reshape(N, K).float()
         self.w = wk.contiguous() if self.Kp == K else F.pad(wk, (0, self.Kp - K)).contiguous()
-        self.b = bias.detach().float().contiguous() if bias is not None else torch.zeros(N, device=w.device)
+        self.b = bias.detach().float().contiguous() if bias is not None else None  # NULL bias: the kernel adds nothing
         self.tuned = {}
+
+    @classmethod
+    def from_rows(cls, rows, KH, KW, Cin, pad):
+        """Stride-1 convolution whose weight is already in kernel order: rows [N][(ky,kx,c)] (no bias)."""
+        self = cls.__new__(cls)
+        N, K = rows.shape
+        assert K == KH * KW * Cin
+        self.KH, self.KW, self.Cin, self.sh, self.sw, self.ph, self.pw, self.merge = KH, KW, Cin, 1, 1, pad, pad, 1
+        self.N, self.K, self.Kp = N, K, (K + 31) // 32 * 32
+        rows = rows.float()
+        self.w = rows.contiguous() if self.Kp == K else F.pad(rows, (0, self.Kp - K)).contiguous()
+        self.b = None
+        self.tuned = {}
+        return self
 
     def flops(self, M):
         return 2.0 * M * self.N * self.K
@@ -308,14 +326,17 @@ class Conv2dNHWC(torch.autograd.Function):
             else:
                 if stride != 1:
                     raise NotImplementedError("Conv2dNHWC.backward: data gradient of strided non-patchify convolutions is not built yet")
-                wt = weight.flip(2, 3).permute(1, 0, 2, 3).contiguous()  # [Cin][N][KH][KW], taps mirrored
                 npad = (N + cmul - 1) // cmul * cmul
-                if npad != N:  # the kernel needs whole channel groups: zero-pad dY's channel axis
+                wd = weight.detach()
+                if npad != N:  # the kernel needs whole channel groups: zero-pad dY's channel axis (and the weight's output axis)
                     dy_in = F.pad(dy, (0, npad - N))
-                    wt = F.pad(wt, (0, 0, 0, 0, 0, npad - N))
+                    wd = F.pad(wd, (0, 0, 0, 0, 0, 0, 0, npad - N))
                 else:
                     dy_in = dy
-                dx = _conv_any(DevPack(wt, None, stride=1, pad=KH - 1 - pad), dy_in, prec).view(B, H, W, Cin)
+                if KH > 1 or KW > 1:
+                    wd = wd.flip(2, 3)  # taps mirrored
+                rows = wd.permute(1, 2, 3, 0).reshape(Cin, KH * KW * npad)  # [c][(ky,kx,n)]: one transposing copy
+                dx = _conv_any(DevPack.from_rows(rows, KH, KW, npad, KH - 1 - pad), dy_in, prec).view(B, H, W, Cin)
             dx = dx.to(x.dtype)
         if ctx.needs_input_grad[1] and Cin % 4 == 0 and N % 4 == 0:
             # hand-written split-K weight gradient (fp32 operands and accumulation in every precision mode: the master weight's
