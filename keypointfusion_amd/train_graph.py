@@ -177,7 +177,7 @@ class TrainGraph:
         return y[..., :n]
 
     def unet(self, p, img):
-        """img NCHW (the module boundary); returns (res, feat) NCHW-shaped."""
+        """img NCHW (the module boundary); returns (res, feat) NCHW-shaped views of NHWC memory."""
         convnext = self.has(p + ".backbone.downsample_layers.0.0.weight")
         x = img.permute(0, 2, 3, 1)
         c1, c2, c3, c4 = self.convnext_features(p + ".backbone", x) if convnext else self.resnet_features(p + ".backbone", x)
@@ -194,7 +194,7 @@ class TrainGraph:
         if convnext:
             feat = self.residual(p + ".result_emb", feat)
         res = self.heads(p, feat)
-        return res.permute(0, 3, 1, 2).contiguous(), feat.permute(0, 3, 1, 2).contiguous()
+        return res.permute(0, 3, 1, 2), feat.permute(0, 3, 1, 2)  # channels_last views: the consumers below gather pixel rows
 
     # ---- geometry -------------------------------------------------------------------------------------------------------------------
     @staticmethod
@@ -246,10 +246,13 @@ class TrainGraph:
 
     @staticmethod
     def gather_interp(feat, idx, clos):
-        B, C, _ = feat.shape
+        """feat [B, C, H, W] (channels_last memory: the row view below is free) -> [B, N, C]: the 4 nearest pixels' feature rows
+        weighted by clos (model/model.py:368-376).  Row gathers: the backward is an index_add of contiguous C-vectors."""
+        B, C = feat.shape[:2]
         N, K = idx.shape[1:]
-        g = torch.gather(feat, -1, idx.view(B, 1, -1).expand(-1, C, -1)).view(B, C, N, K)
-        return torch.sum(g * clos.unsqueeze(1), -1).permute(0, 2, 1)
+        rows = feat.permute(0, 2, 3, 1).reshape(B, -1, C)
+        g = torch.gather(rows, 1, idx.reshape(B, N * K, 1).expand(-1, -1, C)).view(B, N, K, C)
+        return torch.sum(g * clos.unsqueeze(-1), 2)
 
     @staticmethod
     def pcl_joint2offset(joint, pcl, kernel):
@@ -363,9 +366,9 @@ class TrainGraph:
         from .training import joint2heatmap
         B, C, H, W = img_feat.shape
         pcl_off = self.pcl_joint2offset(joint_xyz, pcl, 0.8).detach()
-        pf = self.gather_interp(img_feat.reshape(B, C, -1), idx, clos)
-        pf_rgb = self.gather_interp(img_feat_rgb.reshape(B, C, -1), idx, clos)
-        pw = self.gather_interp(img_offset[:, J * 4:].reshape(B, J, -1), idx, clos).detach()
+        pf = self.gather_interp(img_feat, idx, clos)
+        pf_rgb = self.gather_interp(img_feat_rgb, idx, clos)
+        pw = self.gather_interp(img_offset[:, J * 4:], idx, clos).detach()
         x = self.emb1d(p + ".pcl_feat_emb", pf) + self.emb1d(p + ".pcl_xyz_emb", pcl) + self.emb1d(p + ".pcl_pose_emb", torch.cat((pw, pcl_off), -1))
         x = F.relu(x)
         x = F.relu(x + self.emb1d(p + ".pcl_feat_emb_RGB", pf_rgb))
@@ -385,8 +388,12 @@ class TrainGraph:
         sw = torch.sigmoid(self.conv(torch.cat([img_feat_rgb, hm], 1), p + ".atten_spatial.weight", p + ".atten_spatial.bias"))
         wd = torch.sigmoid(self.t[p + ".weight_dis"])
         g = wd * gam + (1 - wd) * sw
-        t = F.relu(g.unsqueeze(2) * img_feat_rgb.unsqueeze(1)).view(B, J, C, -1)
-        fj = F.linear(t, self.t[p + ".fc_spatial2joint_feature.weight"], self.t[p + ".fc_spatial2joint_feature.bias"]).view(B, J, C)
+        # model/model.py:386-388: fj[b,j,c] = sum_hw relu(g[b,j,hw] * f[b,c,hw]) * w[hw] + bias.  g >= 0 (a convex mix of a positive
+        # kernel and a sigmoid), so relu(g*f) == g*relu(f) exactly and the B x J x C x HW intermediate (352 MB at B = 32) collapses
+        # into one batched GEMM [J x HW] @ [HW x C] — the same identity the inference kernel (kpf_gate_reduce_f32) uses
+        wsp = self.t[p + ".fc_spatial2joint_feature.weight"].view(1, 1, -1)
+        frows = F.relu(img_feat_rgb.float()).permute(0, 2, 3, 1).reshape(B, H * W, C)
+        fj = torch.bmm(g.reshape(B, J, H * W) * wsp, frows) + self.t[p + ".fc_spatial2joint_feature.bias"]
         if prev_feat is not None:
             fj = F.relu((fj + prev_feat) / 2)
         dec = self.decoder_layer(p + ".crossTR.decoder.3", fj, h_init)
