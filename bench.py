@@ -244,7 +244,8 @@ def main():
         return {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc,
                 "peak_note": ("algorithmic-FLOP roof of the 3 x f16 split scheme = dense f16 MFMA peak 2500 / 3; executed MFMA rate = %.0f TFLOP/s"
-                              % (3 * ach)) if "split" in dom else "dense f32-input MFMA peak (v_mfma_f32_16x16x4_f32)",
+                              % (3 * ach)) if "split" in dom else ("dense 16-bit MFMA peak (v_mfma_f32_16x16x32_bf16 / _f16)" if "h16" in dom
+                                                                    else "dense f32-input MFMA peak (v_mfma_f32_16x16x4_f32)"),
                 "algo_bytes_per_launch": round(nb / n), "algo_hbm_gbps": round(nb / (t_ms * 1e-3) / 1e9, 1), "hbm_frac_of_8000": round(nb / (t_ms * 1e-3) / 8e12, 4),
                 "launches_per_step": n, "avg_launch_ms": round(t_ms / n, 4),
                 "gflop_per_step": round(fl / 1e9, 1), "kernel_ms_per_step": round(t_ms, 3),

@@ -286,6 +286,22 @@ long kpf_dwconv7_wgrad_ws_floats(int B, int H, int C);
 int kpf_dwconv7_wgrad_f32(const float* dy, const float* x, float* dw, float* db, float* ws, long ws_floats, int B, int H, int W, int C,
                           void* stream);
 
+/*
+ * BatchNorm with batch statistics (+ optional ReLU) on NHWC rows x [M][C], forward and backward: nn.BatchNorm2d / BatchNorm1d in
+ * train mode as the reference's Residual blocks use them (model/hourglass.py:84-119, `BN -> ReLU -> conv`), C % 4 == 0.
+ * forward : mean[c], invstd[c] = 1/sqrt(biased var + eps) are written for the backward; running_mean / running_var (may be NULL)
+ *           are updated with `momentum` (unbiased variance), y = [relu]((x - mean) * invstd * w + b).
+ * backward: dz = dy (masked by y > 0 when relu; y = the forward output), dx = w*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)),
+ *           dw = sum dz*xhat, db = sum dz (dw, db may be NULL).
+ * ws >= kpf_bn_ws_floats(M, C) floats; sums are added in a fixed order (run-to-run deterministic).
+ */
+long kpf_bn_ws_floats(long M, int C);
+int kpf_bn_train_forward_f32(const float* x, const float* w, const float* b, float* y, float* mean, float* invstd, float* running_mean,
+                             float* running_var, float momentum, float eps, int relu, float* ws, long ws_floats, long M, int C,
+                             void* stream);
+int kpf_bn_train_backward_f32(const float* dy, const float* x, const float* y, const float* mean, const float* invstd, const float* w,
+                              float* dx, float* dw, float* db, int relu, float* ws, long ws_floats, long M, int C, void* stream);
+
 int kpf_conv_num_tile_cfgs(void);
 
 const char* kpf_last_error(void);

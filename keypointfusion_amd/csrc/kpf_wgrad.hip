@@ -394,3 +394,228 @@ int kpf_dwconv7_wgrad_f32(const float* dy, const float* x, float* dw, float* db,
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// BatchNorm (batch statistics) + optional ReLU on NHWC rows [M][C], forward and backward — the `BN -> ReLU` pairs of the
+// pre-activation Residual blocks (model/hourglass.py:84-119) when the reference trains.  Three launches each way: per-chunk partial
+// sums (thread = channel quad x row lane, coalesced float4 rows), a per-channel finalize that adds the partials in a fixed order,
+// and the elementwise pass.  Sums are taken about the first row's value (shifted data: no cancellation for |mean| >> std).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct BnGeom { int Q, QL, RL; };
+__host__ __device__ inline BnGeom bn_geom(int C) {
+  BnGeom g;
+  g.Q = C >> 2;
+  g.QL = g.Q < 64 ? g.Q : 64;
+  g.RL = 256 / g.QL;
+  return g;
+}
+
+// MODE 0: forward statistics  p0 = sum(x - K), p1 = sum((x - K)^2)          (K = x[0][c])
+// MODE 1: backward sums       p0 = sum(dz),    p1 = sum(dz * (x - mean))     (dz = dy masked by y > 0 when RELU)
+template <int MODE, bool RELU>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
+                                                         const float* __restrict__ mean, float* __restrict__ ws, long M, int C,
+                                                         int rows_per_chunk) {
+  __shared__ f32x4 red[2][256];
+  const BnGeom g = bn_geom(C);
+  const int ql = threadIdx.x % g.QL, rl = threadIdx.x / g.QL;
+  const int q = blockIdx.y * 64 + ql;
+  const bool active = rl < g.RL && q < g.Q;
+  f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = {0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    const long r0 = (long)blockIdx.x * rows_per_chunk;
+    const long r1 = min(M, r0 + rows_per_chunk);
+    const f32x4 k = MODE == 0 ? kpf_ld4(x + 4 * q) : kpf_ld4(mean + 4 * q);
+    for (long r = r0 + rl; r < r1; r += g.RL) {
+      const f32x4 xv = kpf_ld4(x + r * C + 4 * q) - k;
+      if (MODE == 0) {
+        p0 += xv;
+        p1 += xv * xv;
+      } else {
+        f32x4 d = kpf_ld4(dy + r * C + 4 * q);
+        if (RELU) {
+          const f32x4 yv = kpf_ld4(y + r * C + 4 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) d[e] = yv[e] > 0.f ? d[e] : 0.f;
+        }
+        p0 += d;
+        p1 += d * xv;
+      }
+    }
+  }
+  red[0][threadIdx.x] = p0;
+  red[1][threadIdx.x] = p1;
+  __syncthreads();
+  if (rl == 0 && q < g.Q) {
+    f32x4 s0 = red[0][ql], s1 = red[1][ql];
+    for (int i = 1; i < g.RL; ++i) {
+      s0 += red[0][i * g.QL + ql];
+      s1 += red[1][i * g.QL + ql];
+    }
+    float* o = ws + (size_t)blockIdx.x * 2 * C;
+    kpf_st4(o + 4 * q, s0);
+    kpf_st4(o + C + 4 * q, s1);
+  }
+}
+
+// sums of the S per-chunk partials ws[p][{0,1}][C] for channel c, in a fixed order: wave g adds p = g, g+4, ... in four chains
+__device__ __forceinline__ void bn_sum_partials(const float* __restrict__ ws, int S, int C, int c, float (*red)[2][64], float& r0, float& r1) {
+  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+  if (c < C) {
+    int p = g;
+    for (; p + 12 < S; p += 16) {
+      const float* w0 = ws + (size_t)p * 2 * C + c;
+      a0 += w0[0], b0 += w0[C];
+      a1 += w0[(size_t)8 * C], b1 += w0[(size_t)9 * C];
+      a2 += w0[(size_t)16 * C], b2 += w0[(size_t)17 * C];
+      a3 += w0[(size_t)24 * C], b3 += w0[(size_t)25 * C];
+    }
+    for (; p < S; p += 4) a0 += ws[(size_t)p * 2 * C + c], b0 += ws[(size_t)p * 2 * C + C + c];
+  }
+  red[g][0][o] = (a0 + a1) + (a2 + a3);
+  red[g][1][o] = (b0 + b1) + (b2 + b3);
+  __syncthreads();
+  r0 = (red[0][0][o] + red[1][0][o]) + (red[2][0][o] + red[3][0][o]);
+  r1 = (red[0][1][o] + red[1][1][o]) + (red[2][1][o] + red[3][1][o]);
+}
+
+// forward finalize: batch mean / 1/sqrt(biased var + eps), running statistics (unbiased variance); 64 channels per workgroup
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ x, const float* __restrict__ ws, int S, long M, int C,
+                                                                float* __restrict__ mean, float* __restrict__ invstd,
+                                                                float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps) {
+  __shared__ float red[4][2][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  float s, ss;
+  bn_sum_partials(ws, S, C, c, red, s, ss);
+  if (threadIdx.x >= 64 || c >= C) return;
+  const float n = (float)M;
+  const float ms = s / n;
+  const float var = fmaxf(ss / n - ms * ms, 0.f);
+  const float m = x[c] + ms;
+  mean[c] = m;
+  invstd[c] = 1.0f / sqrtf(var + eps);
+  if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * m;
+  if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (M > 1 ? var * n / (n - 1.f) : var);
+}
+
+// backward finalize: db = sum dz, dw = invstd * sum dz (x - mean); coef[c] = (sum dz / M, invstd^2 * sum dz (x-mean) / M)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ ws, int S, long M, int C, const float* __restrict__ invstd,
+                                                              float* __restrict__ dw, float* __restrict__ db, float* __restrict__ coef) {
+  __shared__ float red[4][2][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  float s1, s2;
+  bn_sum_partials(ws, S, C, c, red, s1, s2);
+  if (threadIdx.x >= 64 || c >= C) return;
+  const float is = invstd[c];
+  if (db) db[c] = s1;
+  if (dw) dw[c] = s2 * is;
+  coef[c] = s1 / (float)M;
+  coef[C + c] = s2 * is * is / (float)M;
+}
+
+// MODE 0: y = [relu]((x - mean) * invstd * w + b)
+// MODE 1: dx = w * invstd * (dz - coef0 - (x - mean) * coef1)
+template <int MODE, bool RELU>
+__global__ __launch_bounds__(256) void bn_elem_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
+                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                      const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ coef,
+                                                      float* __restrict__ out, long M, int C, int rows_per_block) {
+  const BnGeom g = bn_geom(C);
+  const int ql = threadIdx.x % g.QL, rl = threadIdx.x / g.QL;
+  const int q = blockIdx.y * 64 + ql;
+  if (rl >= g.RL || q >= g.Q) return;
+  const f32x4 mu = kpf_ld4(mean + 4 * q), is = kpf_ld4(invstd + 4 * q), wv = kpf_ld4(w + 4 * q);
+  const f32x4 a = is * wv;
+  f32x4 t0, t1;
+  if (MODE == 0) t0 = kpf_ld4(b + 4 * q);
+  else t0 = kpf_ld4(coef + 4 * q), t1 = kpf_ld4(coef + C + 4 * q);
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = min(M, r0 + rows_per_block);
+  for (long r = r0 + rl; r < r1; r += g.RL) {
+    const f32x4 xv = kpf_ld4(x + r * C + 4 * q) - mu;
+    f32x4 o;
+    if (MODE == 0) {
+      o = xv * a + t0;
+      if (RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+      }
+    } else {
+      f32x4 d = kpf_ld4(dy + r * C + 4 * q);
+      if (RELU) {
+        const f32x4 yv = kpf_ld4(y + r * C + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = yv[e] > 0.f ? d[e] : 0.f;
+      }
+      o = a * (d - t0 - xv * t1);
+    }
+    kpf_st4(out + r * C + 4 * q, o);
+  }
+}
+
+int bn_chunks(long M, int C, int* rows_per_chunk) {
+  const BnGeom g = bn_geom(C);
+  const int cg = (g.Q + 63) / 64;
+  long S = 512 / cg;  // ~2 workgroups per CU
+  const long smax = (M + 4L * g.RL - 1) / (4L * g.RL);  // at least four rows per thread
+  if (S > smax) S = smax;
+  if (S < 1) S = 1;
+  *rows_per_chunk = (int)((M + S - 1) / S);
+  return (int)((M + *rows_per_chunk - 1) / *rows_per_chunk);
+}
+
+}  // namespace
+
+extern "C" {
+
+long kpf_bn_ws_floats(long M, int C) {
+  if (M <= 0 || C <= 0) return 0;
+  int rpc;
+  const int S = bn_chunks(M, C, &rpc);
+  return (long)S * 2 * C + 2 * C;
+}
+
+int kpf_bn_train_forward_f32(const float* x, const float* w, const float* b, float* y, float* mean, float* invstd, float* running_mean,
+                             float* running_var, float momentum, float eps, int relu, float* ws, long ws_floats, long M, int C,
+                             void* stream) {
+  KPF_REQUIRE(x && w && b && y && mean && invstd && ws, "kpf_bn_train_forward_f32: null pointer");
+  KPF_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "kpf_bn_train_forward_f32: bad shape (C %% 4 == 0)");
+  KPF_REQUIRE(kpf_aligned16(x) && kpf_aligned16(y) && kpf_aligned16(w) && kpf_aligned16(b) && kpf_aligned16(mean) && kpf_aligned16(invstd) &&
+                  kpf_aligned16(ws), "kpf_bn_train_forward_f32: pointers must be 16-byte aligned");
+  int rpc;
+  const int S = bn_chunks(M, C, &rpc);
+  KPF_REQUIRE(ws_floats >= (long)S * 2 * C + 2 * C, "kpf_bn_train_forward_f32: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int cg = (C / 4 + 63) / 64;
+  hipLaunchKernelGGL((bn_partial_kernel<0, false>), dim3(S, cg), dim3(256), 0, st, x, nullptr, nullptr, nullptr, ws, M, C, rpc);
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, x, ws, S, M, C, mean, invstd, running_mean, running_var,
+                     momentum, eps);
+  if (relu) hipLaunchKernelGGL((bn_elem_kernel<0, true>), dim3(S, cg), dim3(256), 0, st, x, nullptr, nullptr, mean, invstd, w, b, nullptr, y, M, C, rpc);
+  else hipLaunchKernelGGL((bn_elem_kernel<0, false>), dim3(S, cg), dim3(256), 0, st, x, nullptr, nullptr, mean, invstd, w, b, nullptr, y, M, C, rpc);
+  return kpf_check_launch("kpf_bn_train_forward_f32");
+}
+
+int kpf_bn_train_backward_f32(const float* dy, const float* x, const float* y, const float* mean, const float* invstd, const float* w,
+                              float* dx, float* dw, float* db, int relu, float* ws, long ws_floats, long M, int C, void* stream) {
+  KPF_REQUIRE(dy && x && mean && invstd && w && dx && ws && (!relu || y), "kpf_bn_train_backward_f32: null pointer");
+  KPF_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "kpf_bn_train_backward_f32: bad shape (C %% 4 == 0)");
+  KPF_REQUIRE(kpf_aligned16(dy) && kpf_aligned16(x) && kpf_aligned16(dx) && kpf_aligned16(ws) && (!relu || kpf_aligned16(y)),
+              "kpf_bn_train_backward_f32: pointers must be 16-byte aligned");
+  int rpc;
+  const int S = bn_chunks(M, C, &rpc);
+  KPF_REQUIRE(ws_floats >= (long)S * 2 * C + 2 * C, "kpf_bn_train_backward_f32: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int cg = (C / 4 + 63) / 64;
+  float* coef = ws + (size_t)S * 2 * C;
+  if (relu) hipLaunchKernelGGL((bn_partial_kernel<1, true>), dim3(S, cg), dim3(256), 0, st, x, dy, y, mean, ws, M, C, rpc);
+  else hipLaunchKernelGGL((bn_partial_kernel<1, false>), dim3(S, cg), dim3(256), 0, st, x, dy, nullptr, mean, ws, M, C, rpc);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, ws, S, M, C, invstd, dw, db, coef);
+  if (relu) hipLaunchKernelGGL((bn_elem_kernel<1, true>), dim3(S, cg), dim3(256), 0, st, x, dy, y, mean, invstd, w, nullptr, coef, dx, M, C, rpc);
+  else hipLaunchKernelGGL((bn_elem_kernel<1, false>), dim3(S, cg), dim3(256), 0, st, x, dy, nullptr, mean, invstd, w, nullptr, coef, dx, M, C, rpc);
+  return kpf_check_launch("kpf_bn_train_backward_f32");
+}
+
+}  // extern "C"

@@ -26,7 +26,7 @@ import torch.nn.functional as F
 
 from . import lib as L
 from .engine import _ptr, _stream, crop_inverse
-from .training import conv2d_nhwc, dwconv7_nhwc, linear_hip
+from .training import batchnorm_relu_rows, conv2d_nhwc, dwconv7_nhwc, linear_hip
 
 J = 21
 
@@ -94,17 +94,25 @@ class TrainGraph:
             return conv2d_nhwc(x.contiguous(), w, b, stride, pad, self.prec)
         return F.conv2d(x.permute(0, 3, 1, 2), w, b, stride=stride, padding=pad).permute(0, 2, 3, 1).contiguous()
 
-    def bn_l(self, x, p, eps=1e-5):
+    def bn_l(self, x, p, eps=1e-5, relu=False):
+        """BatchNorm2d (batch statistics) [+ ReLU] on NHWC: the HIP kernels for fp32 rows, F.batch_norm otherwise."""
         shp = x.shape
-        return self.bn(x.reshape(-1, shp[-1]), p, eps).view(shp)
+        rows = x.reshape(-1, shp[-1])
+        if rows.dtype == torch.float32 and shp[-1] % 4 == 0 and rows.is_cuda:
+            y = batchnorm_relu_rows(rows, self.t[p + ".weight"], self.t[p + ".bias"], self.t[p + ".running_mean"], self.t[p + ".running_var"],
+                                    self.momentum, eps, relu)
+            self.t[p + ".num_batches_tracked"].add_(1)
+            return y.view(shp)
+        y = self.bn(rows, p, eps).view(shp)
+        return F.relu(y) if relu else y
 
     def residual(self, p, x):
         cin = x.shape[-1]
-        out = F.relu(self.bn_l(x, p + ".bn1"))
+        out = self.bn_l(x, p + ".bn1", relu=True)
         out = self.conv_l(out, p + ".conv1.conv.weight", p + ".conv1.conv.bias")
-        out = F.relu(self.bn_l(out, p + ".bn2"))
+        out = self.bn_l(out, p + ".bn2", relu=True)
         out = self.conv_l(out, p + ".conv2.conv.weight", p + ".conv2.conv.bias", pad=1)
-        out = F.relu(self.bn_l(out, p + ".bn3"))
+        out = self.bn_l(out, p + ".bn3", relu=True)
         out = self.conv_l(out, p + ".conv3.conv.weight", p + ".conv3.conv.bias")
         if cin != out.shape[-1]:
             x = self.conv_l(x, p + ".skip_layer.conv.weight", p + ".skip_layer.conv.bias")
@@ -139,7 +147,7 @@ class TrainGraph:
 
     def resnet_features(self, p, x):
         x = self.conv_l(x, p + ".conv1.weight", None, stride=2, pad=3)
-        x = F.relu(self.bn_l(x, p + ".bn1"))
+        x = self.bn_l(x, p + ".bn1", relu=True)
         x = F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).contiguous()
         feats = []
         for li in range(1, 5):
@@ -149,11 +157,11 @@ class TrainGraph:
                 stride = 2 if (li > 1 and j == 0) else 1
                 idt = x
                 if self.has(q + ".conv3.weight"):
-                    out = F.relu(self.bn_l(self.conv_l(x, q + ".conv1.weight"), q + ".bn1"))
-                    out = F.relu(self.bn_l(self.conv_l(out, q + ".conv2.weight", None, stride, 1), q + ".bn2"))
+                    out = self.bn_l(self.conv_l(x, q + ".conv1.weight"), q + ".bn1", relu=True)
+                    out = self.bn_l(self.conv_l(out, q + ".conv2.weight", None, stride, 1), q + ".bn2", relu=True)
                     out = self.bn_l(self.conv_l(out, q + ".conv3.weight"), q + ".bn3")
                 else:
-                    out = F.relu(self.bn_l(self.conv_l(x, q + ".conv1.weight", None, stride, 1), q + ".bn1"))
+                    out = self.bn_l(self.conv_l(x, q + ".conv1.weight", None, stride, 1), q + ".bn1", relu=True)
                     out = self.bn_l(self.conv_l(out, q + ".conv2.weight", None, 1, 1), q + ".bn2")
                 if self.has(q + ".downsample.0.weight"):
                     idt = self.bn_l(self.conv_l(x, q + ".downsample.0.weight", None, stride, 0), q + ".downsample.1")

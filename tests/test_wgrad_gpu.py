@@ -83,3 +83,32 @@ def test_dwconv7_forward_backward_match_torch(shape):
     assert float((xd.grad.cpu().double() - xr.grad.permute(0, 2, 3, 1)).abs().max()) <= tol(xr.grad)
     assert float((wd.grad.cpu().double() - wr.grad).abs().max()) <= tol(wr.grad)
     assert float((bd.grad.cpu().double() - br.grad).abs().max()) <= tol(br.grad)
+
+
+@pytest.mark.parametrize("M,Cc,relu", [(32 * 32 * 32, 128, True), (2048, 384, True), (4097, 48, True), (37, 8, False), (512, 576, False),
+                                        (32 * 16 * 16, 144, True)])
+def test_batchnorm_relu_rows_matches_torch(M, Cc, relu):
+    from keypointfusion_amd.training import batchnorm_relu_rows
+    g = torch.Generator().manual_seed(M + Cc)
+    x = torch.randn(M, Cc, generator=g) * 2.0 + 5.0 * torch.randn(Cc, generator=g)  # per-channel means well away from zero
+    w = torch.rand(Cc, generator=g) + 0.5
+    b = torch.randn(Cc, generator=g)
+    dy = torch.randn(M, Cc, generator=g)
+    rm, rv = torch.randn(Cc, generator=g), torch.rand(Cc, generator=g) + 0.5
+    xd, wd, bd = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    rmd, rvd = rm.cuda(), rv.cuda()
+    y = batchnorm_relu_rows(xd, wd, bd, rmd, rvd, 0.1, 1e-5, relu)
+    y.backward(dy.cuda())
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    rmr, rvr = rm.double(), rv.double()
+    yr = F.batch_norm(xr, rmr, rvr, wr, br, True, 0.1, 1e-5)
+    if relu:
+        yr = F.relu(yr)
+    yr.backward(dy.double())
+    tol = lambda r: 3e-5 * max(float(r.detach().abs().max()), 1e-3)
+    assert float((y.detach().cpu().double() - yr.detach()).abs().max()) <= tol(yr)
+    assert float((rmd.cpu().double() - rmr).abs().max()) <= tol(rmr)
+    assert float((rvd.cpu().double() - rvr).abs().max()) <= tol(rvr)
+    assert float((xd.grad.cpu().double() - xr.grad).abs().max()) <= tol(xr.grad)
+    assert float((wd.grad.cpu().double() - wr.grad).abs().max()) <= tol(wr.grad)
+    assert float((bd.grad.cpu().double() - br.grad).abs().max()) <= tol(br.grad)

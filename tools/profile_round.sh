@@ -17,6 +17,14 @@ for W in full128 full128_bf16 cnb512_f16; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_$W -- python3 $ROOT/bench.py --workload $W --serial-streams --no-cpu-baseline --no-split-record --steps 10 > $OUT/prof_${TAG}_$W.log 2>&1
   cp $(find $OUT/prof_${TAG}_$W -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_${W}_kernel_stats.csv
 done
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_train128 -- python3 $ROOT/bench.py --workload train128 --no-cpu-baseline --steps 10 --warmup 3 > $OUT/prof_${TAG}_train128.log 2>&1
+cp $(find $OUT/prof_${TAG}_train128 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_train128_kernel_stats.csv
+# the bench lines of the same build, without the profiler
+cd $ROOT
+python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+for W in full128 full128_bf16 cnb512_f16 train128 train128_bf16; do
+  python3 bench.py --workload $W --no-cpu-baseline > $OUT/${TAG}_bench_$W.json 2> $OUT/${TAG}_bench_$W.err
+done
 # keep the merge small: the raw traces stay on the box
 for d in $OUT/prof_${TAG}_* $OUT/pmc_${TAG}_fetch $OUT/pmc_${TAG}_write; do [ -d "$d" ] && rm -rf "$d"; done
 ls -la $OUT | grep ${TAG}_
