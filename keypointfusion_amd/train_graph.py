@@ -243,14 +243,20 @@ class TrainGraph:
             return idx
 
     # ---- fusion head (model/model.py:129-351, model/transfusion_head.py:137-173) -----------------------------------------------------------
+    def linear_rows(self, rows, w, b):
+        """nn.Linear / Conv1d(k=1) / Conv2d(k=1) over rows [M, Cin] on the HIP GEMM (forward, data- and weight-gradient); input widths
+        that are not whole channel groups (3-d coordinates, the 105 pose channels) are zero-padded together with the weight."""
+        cin = rows.shape[-1]
+        pad = (-cin) % self.cmul
+        if pad:
+            rows, w = F.pad(rows, (0, pad)), F.pad(w, (0, pad))
+        return linear_hip(rows.contiguous(), w, b, self.prec)
+
     def emb1d(self, p, x):
+        """Conv1d(k=1) + BatchNorm1d over (B, N) (model/model.py:254-259) on rows."""
         B, N, Cin = x.shape
-        w = self.t[p + ".0.weight"]  # [128, Cin, 1]
-        if Cin % self.cmul == 0:
-            y = linear_hip(x.reshape(B * N, Cin).contiguous(), w[:, :, 0], self.t[p + ".0.bias"], self.prec)
-        else:
-            y = F.linear(x.reshape(B * N, Cin), w[:, :, 0], self.t[p + ".0.bias"])
-        return self.bn(y.view(B, N, -1).permute(0, 2, 1), p + ".1").permute(0, 2, 1)
+        y = self.linear_rows(x.reshape(B * N, Cin), self.t[p + ".0.weight"][:, :, 0], self.t[p + ".0.bias"])
+        return self.bn_l(y.view(B, N, -1), p + ".1")
 
     @staticmethod
     def gather_interp(feat, idx, clos):
@@ -274,14 +280,6 @@ class TrainGraph:
         clos = clos * mask
         unit = unit * mask.view(B, Jn, 1, N).expand(B, Jn, 3, N).reshape(B, -1, N)
         return torch.cat((unit, clos), 1).permute(0, 2, 1)
-
-    def conv1x1_rows(self, x_bchw, p_w, p_b):
-        """nn.Conv2d(k=1) of DESA on a B x C x J x S tensor as a Linear over rows."""
-        B, Cc, A, S = x_bchw.shape
-        w = self.t[p_w][:, :, 0, 0]
-        rows = x_bchw.permute(0, 2, 3, 1).reshape(-1, Cc)
-        y = linear_hip(rows.contiguous(), w, self.t[p_b], self.prec) if Cc % self.cmul == 0 else F.linear(rows, w, self.t[p_b])
-        return y.view(B, A, S, -1).permute(0, 3, 1, 2)
 
     def ball_query_hip(self, pcl_xyz, node_xyz, pcl_feat, node_feat):
         """The three ball-query index tensors of DESA from the inference path's kernel (kpf_ball_group_f32: same semantics as
@@ -312,18 +310,20 @@ class TrainGraph:
             flat = idx.reshape(B, Jn * 64)
             gx = torch.gather(xyz, 1, flat.unsqueeze(-1).expand(-1, -1, 3)).view(B, Jn, 64, 3) - node_xyz.unsqueeze(2)
             gf = torch.gather(feat, 1, flat.unsqueeze(-1).expand(-1, -1, C)).view(B, Jn, 64, C) - node_feat.unsqueeze(2)
-            gx = (gx / r).permute(0, 3, 1, 2)
-            gf = gf.permute(0, 3, 1, 2)
-            loc = self.bn(self.conv1x1_rows(gx, p + ".conv_l0_blocks.%d.weight" % i, p + ".conv_l0_blocks.%d.bias" % i), p + ".bn_l0_blocks.%d" % i)
-            ft = self.bn(self.conv1x1_rows(gf, p + ".conv_f0_blocks.%d.weight" % i, p + ".conv_f0_blocks.%d.bias" % i), p + ".bn_f0_blocks.%d" % i)
+            # the three 1x1 Conv2d + BatchNorm2d of a scale (model/model.py:176-192) on rows [B*J*64, .]
+            q = lambda name, k: self.t[p + ".%s.%d%s" % (name, i, k)]
+            loc = self.bn_l(self.linear_rows((gx / r).reshape(-1, 3), q("conv_l0_blocks", ".weight")[:, :, 0, 0], q("conv_l0_blocks", ".bias")),
+                            p + ".bn_l0_blocks.%d" % i)
+            ft = self.bn_l(self.linear_rows(gf.reshape(-1, C), q("conv_f0_blocks", ".weight")[:, :, 0, 0], q("conv_f0_blocks", ".bias")),
+                           p + ".bn_f0_blocks.%d" % i)
             g = F.relu(loc + ft)
-            g = F.relu(self.bn(self.conv1x1_rows(g, p + ".conv_blocks.%d.0.weight" % i, p + ".conv_blocks.%d.0.bias" % i), p + ".bn_blocks.%d.0" % i))
-            outs.append(g.max(-1)[0])
-        outs.append(node_feat.permute(0, 2, 1))
-        cat = torch.cat(outs, 1)  # B x 512 x J
-        w = self.t[p + ".fusion.0.weight"][:, :, 0]
-        y = linear_hip(cat.permute(0, 2, 1).reshape(B * Jn, -1).contiguous(), w, self.t[p + ".fusion.0.bias"], self.prec).view(B, Jn, -1).permute(0, 2, 1)
-        return F.relu(self.bn(y, p + ".fusion.1")).permute(0, 2, 1)
+            g = self.bn_l(self.linear_rows(g, q("conv_blocks", ".0.weight")[:, :, 0, 0], q("conv_blocks", ".0.bias")), p + ".bn_blocks.%d.0" % i,
+                          relu=True)
+            outs.append(g.view(B, Jn, 64, -1).max(2)[0])  # B x J x 128
+        outs.append(node_feat)
+        cat = torch.cat(outs, -1).reshape(B * Jn, -1)  # rows of 512
+        y = self.linear_rows(cat, self.t[p + ".fusion.0.weight"][:, :, 0], self.t[p + ".fusion.0.bias"])
+        return self.bn_l(y, p + ".fusion.1", relu=True).view(B, Jn, -1)
 
     def bert_layer(self, p, h, heads=4):
         B, T, C = h.shape
