@@ -98,8 +98,8 @@ class TrainGraph:
         """BatchNorm2d (batch statistics) [+ ReLU] on NHWC: the HIP kernels for fp32 rows, F.batch_norm otherwise."""
         shp = x.shape
         rows = x.reshape(-1, shp[-1])
-        if rows.dtype == torch.float32 and shp[-1] % 4 == 0 and rows.is_cuda:
-            y = batchnorm_relu_rows(rows, self.t[p + ".weight"], self.t[p + ".bias"], self.t[p + ".running_mean"], self.t[p + ".running_var"],
+        if shp[-1] % 4 == 0 and rows.is_cuda:  # (16-bit rows of the mixed-precision mode are normalised in fp32)
+            y = batchnorm_relu_rows(rows.float(), self.t[p + ".weight"], self.t[p + ".bias"], self.t[p + ".running_mean"], self.t[p + ".running_var"],
                                     self.momentum, eps, relu)
             self.t[p + ".num_batches_tracked"].add_(1)
             return y.view(shp)
