@@ -90,7 +90,10 @@ class TrainGraph:
         b = self.t[p_b] if p_b is not None else None
         cin, k = w.shape[1], w.shape[2]
         patch = stride == k and pad == 0 and stride > 1
-        if cin % self.cmul == 0 and (stride == 1 or patch) and w.shape[2] == w.shape[3]:
+        if (stride == 1 or patch) and w.shape[2] == w.shape[3]:
+            cpad = (-cin) % self.cmul
+            if cpad:  # the 3- / 1-channel images of the stems: zero channels on both operands (the weight's gradient is sliced back)
+                x, w = F.pad(x, (0, cpad)), F.pad(w, (0, 0, 0, 0, 0, cpad))
             return conv2d_nhwc(x.contiguous(), w, b, stride, pad, self.prec)
         return F.conv2d(x.permute(0, 3, 1, 2), w, b, stride=stride, padding=pad).permute(0, 2, 3, 1).contiguous()
 
