@@ -190,6 +190,137 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const TA* __restrict__ x, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// depthwise 7x7 + bias + LayerNorm fused, for 256 < C <= 1024 (ConvNeXt stages 3-4): one workgroup of NT = C/4 rounded up to whole
+// waves owns a 2-row x 8-pixel strip, thread q computes channel quad q exactly like dwconv7_kernel (taps from global: 49*C*4 B does
+// not fit beside a useful occupancy; they stay L2 / L1 resident), and the per-pixel LayerNorm statistics cross the 2-4 waves
+// through LDS: every thread writes its 16 per-pixel partial sums, 8 threads per pixel add NT/8 of them each and finish with three
+// xor-shuffles (mean first, then the centred squares: two-pass variance like ATen's).  One pass over the activation instead of
+// the conv + LayerNorm pair's two.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename TA, int NT, bool SPLIT>
+__global__ __launch_bounds__(NT) void dwconv7_ln_wide_kernel(const TA* __restrict__ x, const float* __restrict__ wdw,
+                                                             const float* __restrict__ bdw, const float* __restrict__ lw,
+                                                             const float* __restrict__ lb, TA* __restrict__ y, int B, int H, int W,
+                                                             int C, int xstrips, int ypairs, float eps) {
+  __shared__ float red[16 * NT];
+  __shared__ float stat[16];
+  const int C4 = C >> 2;
+  const int q = threadIdx.x;
+  const bool live = q < C4;
+  const int qc = live ? q : 0;
+  long r = xcd_contiguous_block_id();
+  const int xs = (int)(r % xstrips);
+  r /= xstrips;
+  const int yp = (int)(r % ypairs);
+  const int b = (int)(r / ypairs);
+  const int x0 = xs * 8, y0 = yp * 2;
+  f32x4 acc0[8], acc1[8];
+  const f32x4 bias = *reinterpret_cast<const f32x4*>(bdw + 4 * qc);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    acc0[t] = bias;
+    acc1[t] = bias;
+  }
+  const TA* xb = x + (long)b * H * W * C + 4 * qc;
+  if (live) {
+#pragma unroll 1
+    for (int ir = 0; ir < 8; ++ir) {  // input rows y0-3 .. y0+4
+      const int iy = y0 + ir - 3;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      f32x4 in[14];
+      const TA* row = xb + (long)iy * W * C;
+#pragma unroll
+      for (int i = 0; i < 14; ++i) {
+        const int ix = x0 + i - 3;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)ix < (unsigned)W) v = kpf_ld4(row + (long)ix * C);
+        in[i] = v;
+      }
+      if (ir < 7) {
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(wdw + (ir * 7 + kx) * C + 4 * qc);
+#pragma unroll
+          for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc0[t][e] = fmaf(in[t + kx][e], wv[e], acc0[t][e]);
+        }
+      }
+      if (ir >= 1) {
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(wdw + ((ir - 1) * 7 + kx) * C + 4 * qc);
+#pragma unroll
+          for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc1[t][e] = fmaf(in[t + kx][e], wv[e], acc1[t][e]);
+        }
+      }
+    }
+  }
+  // ---- LayerNorm statistics of the strip's 16 pixels across the workgroup ----
+  const float invC = 1.0f / (float)C;
+  const int rp = threadIdx.x >> 3, rg = threadIdx.x & 7;  // reducer role (threads 0..127): pixel rp, one of its 8 adders
+  float mean[16];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      const f32x4 v = p < 8 ? acc0[p] : acc1[p - 8];
+      float s = 0.f;
+      if (live) {
+        if (pass == 0) {
+          s = (v[0] + v[1]) + (v[2] + v[3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float d = v[e] - mean[p];
+            s = fmaf(d, d, s);
+          }
+        }
+      }
+      red[p * NT + threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < NT / 8; ++j) s += red[rp * NT + rg + 8 * j];
+      s += __shfl_xor(s, 4, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 1, 64);
+      if (rg == 0) stat[rp] = pass == 0 ? s * invC : 1.0f / sqrtf(s * invC + eps);
+    }
+    __syncthreads();
+    if (pass == 0) {
+#pragma unroll
+      for (int p = 0; p < 16; ++p) mean[p] = stat[p];
+      __syncthreads();  // stat is rewritten by the second pass
+    }
+  }
+  if (!live) return;
+  const f32x4 g = *reinterpret_cast<const f32x4*>(lw + 4 * q);
+  const f32x4 be = *reinterpret_cast<const f32x4*>(lb + 4 * q);
+  TA* yb = y + (long)b * H * W * C;
+#pragma unroll
+  for (int p = 0; p < 16; ++p) {
+    const int t = p & 7, rr = p >> 3;
+    if (x0 + t < W && y0 + rr < H) {
+      const f32x4 v = rr ? acc1[t] : acc0[t];
+      const float rstd = stat[p];
+      f32x4 o4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o4[e] = (v[e] - mean[p]) * rstd * g[e] + be[e];
+      TA* dst = yb + ((long)(y0 + rr) * W + x0 + t) * C;
+      if constexpr (SPLIT)
+        kpf_store_split4(dst, 4 * q, o4);
+      else
+        kpf_st4(dst + 4 * q, o4);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // depthwise 7x7 + bias + LayerNorm fused, for C <= 256: a pixel's C/4 channel quads sit on the lanes of one LG-lane group
 // (LG = 32 or 64), every lane computes 4 channels x (2 rows x 8 px) exactly like dwconv7_kernel, and the per-pixel mean /
 // variance are xor-shuffle reductions inside the group — no LDS tile (which capped the occupancy of the first fused kernel),
@@ -668,6 +799,28 @@ static int dwconv7_ln_impl(const TA* x, const float* w_dw, const float* b_dw, co
     if (C4 <= 32) KPF_DWW(32);
     else KPF_DWW(64);
 #undef KPF_DWW
+    return kpf_check_launch("kpf_dwconv7_ln");
+  }
+  static const int wide_env = []() { const char* e = getenv("KPF_DW_WIDE"); return e ? atoi(e) : 1; }();  // tuning aid
+  if (wide_env && C4 > 64 && C4 <= 256 && H * W >= 16) {
+    const int xstrips = (W + 7) / 8, ypairs = (H + 1) / 2;
+    const dim3 grid((unsigned)((long)B * ypairs * xstrips));
+#define KPF_DWX(NT)                                                                                                                            \
+  do {                                                                                                                                         \
+    if constexpr (F32) {                                                                                                                       \
+      if (split) {                                                                                                                             \
+        hipLaunchKernelGGL((dwconv7_ln_wide_kernel<TA, NT, true>), grid, dim3(NT), 0, st, x, w_dw, b_dw, ln_w, ln_b, y, B, H, W, C, xstrips,   \
+                           ypairs, eps);                                                                                                       \
+        break;                                                                                                                                 \
+      }                                                                                                                                        \
+    }                                                                                                                                          \
+    hipLaunchKernelGGL((dwconv7_ln_wide_kernel<TA, NT, false>), grid, dim3(NT), 0, st, x, w_dw, b_dw, ln_w, ln_b, y, B, H, W, C, xstrips,      \
+                       ypairs, eps);                                                                                                           \
+  } while (0)
+    if (C4 <= 128) KPF_DWX(128);
+    else if (C4 <= 192) KPF_DWX(192);
+    else KPF_DWX(256);
+#undef KPF_DWX
     return kpf_check_launch("kpf_dwconv7_ln");
   }
   if (H * W >= 64 || split) {

@@ -135,7 +135,8 @@ def test_patchify_conv(cin, k):
     assert rel_err(to_nchw(out), ref) < 1e-5
 
 
-@pytest.mark.parametrize("C,H,W", [(96, 16, 16), (192, 8, 8), (384, 5, 7), (768, 4, 4), (128, 32, 32), (1024, 2, 2)])
+@pytest.mark.parametrize("C,H,W", [(96, 16, 16), (192, 8, 8), (384, 5, 7), (768, 4, 4), (128, 32, 32), (1024, 2, 2), (384, 16, 16), (768, 8, 8),
+                                   (512, 32, 32), (1024, 16, 16), (320, 9, 13), (1024, 3, 3)])
 def test_dwconv7_ln(C, H, W):
     import ctypes
     from keypointfusion_amd import engine as E, lib as L
