@@ -135,7 +135,7 @@ def main():
         uvd_gt = (torch.rand(B, 21, 3, generator=gg) * 1.2 - 0.6).to(dev)
         xyz_gt = (torch.rand(B, 21, 3, generator=gg) * 1.2 - 0.6).to(dev)
         live = live_parameters(model)
-        graphed_train = world == 1 and not args.no_graph  # one process: the whole iteration replays from a hipGraph
+        graphed_train = not args.no_graph and not args.serial_streams  # the iteration replays from hipGraphs (N > 1: bucketed all-reduce between two graphs)
         opt, _ = T.make_optimizer(live, capturable=graphed_train)
         reducer = GradBucketReducer(live, dist if dist is not None else None) if not graphed_train else None
         tbatch = dict(batch, uvd_gt=uvd_gt, xyz_gt=xyz_gt)
@@ -155,7 +155,7 @@ def main():
         if train:
             if graphed_train and graph_on[0]:
                 if gstep[0] is None:
-                    gstep[0] = T.GraphedTrainStep(model, opt, train_loss, tbatch)
+                    gstep[0] = T.GraphedTrainStep(model, opt, train_loss, tbatch, dist_mod=dist, params=live)
                 gstep[0](tbatch)
                 return
             opt.zero_grad(set_to_none=False)

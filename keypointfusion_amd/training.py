@@ -414,39 +414,107 @@ def linear_hip(x, weight, bias=None, prec="f32"):
 
 
 class GraphedTrainStep:
-    """One training iteration (train-mode forward, loss, backward, optimiser step) replayed from a captured hipGraph.
+    """One training iteration (train-mode forward, loss, backward, optimiser step) replayed from captured hipGraphs.
 
-    The eager iteration is host-bound (a few thousand small launches: ~127 ms at B = 32 for ~45 ms of device work); nothing in it
+    The eager iteration is host-bound (several thousand small launches: ~127 ms at B = 32 for ~40 ms of device work); nothing in it
     depends on the host — the integer decisions come from device kernels, BatchNorm statistics and AdamW state are device tensors
-    (`capturable=True`) — so after three eager warm-up iterations on a side stream the whole iteration is captured once and replayed
-    with the batch copied into static buffers.  Single-process only (the gradient all-reduce of N > 1 stays eager).
-    usage:  step = GraphedTrainStep(model, optimizer, loss_fn, example_batch);  loss = step(batch)"""
+    (`capturable=True`) — so after three eager warm-up iterations on a side stream the iteration is captured once and replayed with
+    the batch copied into static buffers.
 
-    def __init__(self, model, optimizer, loss_fn, batch, warmup=3):
+    One process (dist_mod None): a single graph [zero grads, forward, loss, backward, optimiser step].
+    Data parallel (dist_mod = torch.distributed, one process per GPU): graph A [zero grads, forward, loss, backward, pack the
+    gradients into flat buckets] -> eager all-reduce of the buckets over RCCL (SUM; a handful of large collectives, reverse
+    registration order like `parallel.GradBucketReducer`) -> graph B [average, unpack into .grad, optimiser step].  The reduction is
+    not overlapped with backward here (backward is inside a graph); it moves the payload once over xGMI (268 MB for ConvNeXt-T) where
+    the eager iteration would spend 3x the whole step on launch overhead.
+    usage:  step = GraphedTrainStep(model, optimizer, loss_fn, example_batch[, dist_mod=dist, params=live]);  loss = step(batch)"""
+
+    def __init__(self, model, optimizer, loss_fn, batch, warmup=3, dist_mod=None, params=None, bucket_mb=64.0, group=None):
         self.model, self.opt, self.loss_fn = model, optimizer, loss_fn
+        self.dist, self.group = dist_mod, group
         self.static = {k: v.detach().clone() for k, v in batch.items()}
+        self.params = [p for p in (params if params is not None else model.parameters()) if p.requires_grad]
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                self._iteration()
+                self._forward_backward()
+                self._reduce_eager()
+                self.opt.step()
         cur.wait_stream(side)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
         self.opt.zero_grad(set_to_none=True)
+        self.graph = torch.cuda.CUDAGraph()
+        self.graph_b = None
+        if self.dist is None:
+            with torch.cuda.graph(self.graph):
+                self.loss = self._forward_backward()
+                self.opt.step()
+            return
+        self.world = self.dist.get_world_size(group)
         with torch.cuda.graph(self.graph):
-            self.loss = self._iteration()
+            self.loss = self._forward_backward()
+            self._make_buckets(bucket_mb)  # (the gradients now exist: static tensors of the graph's pool)
+            for flat, views, grads in self.buckets:
+                torch._foreach_copy_(views, grads)
+        self.graph_b = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_b, pool=self.graph.pool()):
+            for flat, views, grads in self.buckets:
+                if self.world > 1:
+                    flat.div_(self.world)
+                torch._foreach_copy_(grads, views)
+            self.opt.step()
 
-    def _iteration(self):
+    def _forward_backward(self):
         self.opt.zero_grad(set_to_none=True)
         loss = self.loss_fn(self.model, self.static)
         loss.backward()
-        self.opt.step()
         return loss.detach()
+
+    def _reduce_eager(self):
+        """Warm-up iterations only: per-parameter all-reduce (keeps the replicas in step before the capture)."""
+        if self.dist is None or self.dist.get_world_size(self.group) == 1:
+            return
+        w = self.dist.get_world_size(self.group)
+        for p in self.params:
+            if p.grad is not None:
+                self.dist.all_reduce(p.grad, group=self.group)
+                p.grad.div_(w)
+
+    def _make_buckets(self, bucket_mb):
+        cap = int(bucket_mb * 1024 * 1024)
+        self.buckets, cur, cur_bytes = [], [], 0
+        live = [p for p in reversed(self.params) if p.grad is not None]
+
+        def close(plist):
+            flat = torch.zeros(sum(p.numel() for p in plist), dtype=plist[0].grad.dtype, device=plist[0].device)
+            views, off = [], 0
+            for q in plist:
+                views.append(flat[off:off + q.numel()].view_as(q.grad))
+                off += q.numel()
+            self.buckets.append((flat, views, [q.grad for q in plist]))
+
+        for p in live:
+            nb = p.numel() * p.grad.element_size()
+            if cur and (cur_bytes + nb > cap or cur[0].grad.dtype != p.grad.dtype):
+                close(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nb
+        if cur:
+            close(cur)
+
+    def payload_bytes(self):
+        return sum(f.numel() * f.element_size() for f, _, _ in self.buckets) if self.dist is not None else 0
 
     def __call__(self, batch):
         for k, v in batch.items():
             self.static[k].copy_(v)
         self.graph.replay()
+        if self.graph_b is not None:
+            works = [self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True) for flat, _, _ in self.buckets]
+            for w in works:
+                w.wait()
+            self.graph_b.replay()
         return self.loss
