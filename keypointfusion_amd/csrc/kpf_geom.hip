@@ -372,51 +372,85 @@ constexpr int JA_LD = 132;
 
 __global__ __launch_bounds__(256) void softmax_pool_kernel(const float* __restrict__ A1, const float* __restrict__ X,
                                                            const float* __restrict__ joint_xyz, float* __restrict__ JA, int N) {
-  // grid (3, B): 7 joints per workgroup, so the point features X[b] are streamed 3 times instead of 21
-  extern __shared__ __attribute__((aligned(16))) float att[];  // [7][N] + red[4] + part[7][128]
+  // grid (3, B): 7 joints per workgroup, so the point features X[b] are streamed 3 times instead of 21.  The seven softmaxes share
+  // their block reductions (two barriers for the maxima, two for the sums); the pooling loop is split over 8 point groups x 32
+  // channel quads (float4 rows, 128 dependent iterations instead of 512) and combined through LDS in a fixed order.
+  extern __shared__ __attribute__((aligned(16))) float att[];  // [7][N] | red[4][8] | part[8][7][128]
   float* red = att + 7 * N;
-  float* part = red + 4;
-  const int jc = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  float* part = red + 32;
+  const int jc = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* wbase = A1 + (long)b * N * A1_LD + 131 + jc * 7;
-  for (int j = 0; j < 7; ++j) {
-    float lmax = -INFINITY;
-    for (int n = tid; n < N; n += 256) {
+  float mx[7], inv[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) mx[j] = -INFINITY;
+  for (int n = tid; n < N; n += 256) {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
       const float w = wbase[(long)n * A1_LD + j];
       att[j * N + n] = w;
-      lmax = fmaxf(lmax, w);
+      mx[j] = fmaxf(mx[j], w);
     }
-    const float mx = block_max(lmax, red);
-    float se = 0.f;
-    for (int n = tid; n < N; n += 256) {
-      const float e = expf(att[j * N + n] - mx);
-      att[j * N + n] = e;
-      se += e;
-    }
-    se = block_sum(se, red);
-    const float inv = 1.0f / se;
-    for (int n = tid; n < N; n += 256) att[j * N + n] *= inv;
+  }
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const float m = wave_max(mx[j]);
+    if (lane == 0) red[wave * 8 + j] = m;
   }
   __syncthreads();
-  const int c = tid & 127, h = tid >> 7;
-  const float* xb = X + (long)b * N * 128 + c;
-  float acc[7];
 #pragma unroll
-  for (int j = 0; j < 7; ++j) acc[j] = 0.f;
-  const int n0 = h * (N / 2), n1 = h ? N : N / 2;
-#pragma unroll 4
-  for (int n = n0; n < n1; ++n) {
-    const float xv = xb[(long)n * 128];
+  for (int j = 0; j < 7; ++j) mx[j] = fmaxf(fmaxf(red[j], red[8 + j]), fmaxf(red[16 + j], red[24 + j]));
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 7; ++j) inv[j] = 0.f;
+  for (int n = tid; n < N; n += 256) {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const float e = expf(att[j * N + n] - mx[j]);
+      att[j * N + n] = e;
+      inv[j] += e;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const float sm = wave_sum(inv[j]);
+    if (lane == 0) red[wave * 8 + j] = sm;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 7; ++j) inv[j] = 1.0f / ((red[j] + red[8 + j]) + (red[16 + j] + red[24 + j]));
+  const int cq = tid & 31, ng = tid >> 5;
+  const float* xb = X + (long)b * N * 128 + 4 * cq;
+  f32x4 acc[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // 16 rows in flight per thread: the loop is latency-bound on the row loads (X[b] is read from L2 / HBM once per joint group)
+  int n = ng;
+  for (; n + 8 * 15 < N; n += 8 * 16) {
+    f32x4 xv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) xv[u] = *reinterpret_cast<const f32x4*>(xb + (long)(n + 8 * u) * 128);
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+#pragma unroll
+      for (int j = 0; j < 7; ++j) acc[j] += att[j * N + n + 8 * u] * xv[u];
+  }
+  for (; n < N; n += 8) {
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + (long)n * 128);
 #pragma unroll
     for (int j = 0; j < 7; ++j) acc[j] += att[j * N + n] * xv;
   }
-  if (h) {
 #pragma unroll
-    for (int j = 0; j < 7; ++j) part[j * 128 + c] = acc[j];
-  }
+  for (int j = 0; j < 7; ++j) *reinterpret_cast<f32x4*>(part + (ng * 7 + j) * 128 + 4 * cq) = acc[j];
   __syncthreads();
-  if (!h) {
+  for (int o = tid; o < 7 * 128; o += 256) {
+    const int j = o >> 7, c = o & 127;
+    float sacc = 0.f;
 #pragma unroll
-    for (int j = 0; j < 7; ++j) JA[((long)b * J + jc * 7 + j) * JA_LD + c] = acc[j] + part[j * 128 + c];
+    for (int g = 0; g < 8; ++g) sacc += part[(g * 7 + j) * 128 + c];
+    float scale = inv[0];
+#pragma unroll
+    for (int jj = 1; jj < 7; ++jj) scale = j == jj ? inv[jj] : scale;
+    JA[((long)b * J + jc * 7 + j) * JA_LD + c] = sacc * scale;
   }
   if (tid < 28) {
     const int j = tid >> 2, e = tid & 3;
@@ -694,7 +728,13 @@ extern "C" int kpf_point_assemble_f32(const float* feat_d, const float* feat_rgb
 
 extern "C" int kpf_softmax_pool_f32(const float* A1, const float* X, const float* joint_xyz, float* JA, int B, int N, void* stream) {
   KPF_REQUIRE(A1 && X && joint_xyz && JA && B > 0 && N > 1 && N % 2 == 0 && N <= 2048, "kpf_softmax_pool_f32: bad arguments");
-  hipLaunchKernelGGL(softmax_pool_kernel, dim3(3, B), dim3(256), (size_t)(7 * N + 4 + 7 * 128) * sizeof(float), ST(stream), A1, X,
+  const size_t lds = (size_t)(7 * N + 32 + 8 * 7 * 128) * sizeof(float);
+  static std::atomic<bool> lds_opt_in[KPF_MAX_DEVICES];
+  if (lds > 64 * 1024 && !kpf_raise_lds_limit(reinterpret_cast<const void*>(&softmax_pool_kernel), lds_opt_in)) {
+    kpf_set_error("kpf_softmax_pool_f32: cannot raise the dynamic LDS limit");
+    return KPF_ELAUNCH;
+  }
+  hipLaunchKernelGGL(softmax_pool_kernel, dim3(3, B), dim3(256), lds, ST(stream), A1, X,
                      joint_xyz, JA, N);
   return kpf_check_launch("kpf_softmax_pool_f32");
 }
