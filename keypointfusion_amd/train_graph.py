@@ -47,6 +47,20 @@ class TrainGraph:
         # network outputs; a test that compares gradients with the reference's must compare on equal decisions) + a flip counter
         self.ball_override = list(getattr(module, "_ball_override", None) or [])
         self.ball_flips = 0
+        # mixed precision: every GEMM weight rounded to the compute type ONCE per step by a fused multi-tensor copy into persistent
+        # shadow tensors (the per-layer casts were ~600 small kernels per iteration); the packs of forward and data gradient read them
+        self.w16 = {}
+        if self.prec != "f32":
+            from .training import _TDT
+            tdt = _TDT[self.prec]
+            names = [n for n, p in module.named_parameters() if p.dim() >= 2 and p.is_cuda and p.dtype == torch.float32 and n.endswith("weight")]
+            sh = module.__dict__.get("_w16_shadow")
+            if sh is None or sh[0] != (tdt, names) or any(a.device != self.t[n].device for a, n in zip(sh[1], names)):
+                sh = module.__dict__["_w16_shadow"] = ((tdt, names), [torch.empty_like(self.t[n], dtype=tdt) for n in names])
+            if names:
+                with torch.no_grad():
+                    torch._foreach_copy_(sh[1], [self.t[n].detach() for n in names])
+            self.w16 = dict(zip(names, sh[1]))
 
     # ---- primitives ---------------------------------------------------------------------------------------------------------------
     def has(self, name):
@@ -59,7 +73,7 @@ class TrainGraph:
         cin, k = w.shape[1], w.shape[2]
         patch = stride == k and pad == 0 and stride > 1
         if cin % self.cmul == 0 and (stride == 1 or patch) and w.shape[2] == w.shape[3]:
-            y = conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous(), w, b, stride, pad, self.prec)
+            y = conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous(), w, b, stride, pad, self.prec, self.w16.get(p_w))
             return y.permute(0, 3, 1, 2)
         return F.conv2d(x, w, b, stride=stride, padding=pad)
 
@@ -67,7 +81,7 @@ class TrainGraph:
         w = self.t[p_w]
         b = self.t[p_b] if p_b is not None else None
         if w.shape[1] % self.cmul == 0:
-            return linear_hip(x.contiguous(), w, b, self.prec)
+            return linear_hip(x.contiguous(), w, b, self.prec, self.w16.get(p_w))
         return F.linear(x, w, b)
 
     def bn(self, x, p, eps=1e-5):
@@ -92,9 +106,11 @@ class TrainGraph:
         patch = stride == k and pad == 0 and stride > 1
         if (stride == 1 or patch) and w.shape[2] == w.shape[3]:
             cpad = (-cin) % self.cmul
+            w16 = self.w16.get(p_w)
             if cpad:  # the 3- / 1-channel images of the stems: zero channels on both operands (the weight's gradient is sliced back)
                 x, w = F.pad(x, (0, cpad)), F.pad(w, (0, 0, 0, 0, 0, cpad))
-            return conv2d_nhwc(x.contiguous(), w, b, stride, pad, self.prec)
+                w16 = F.pad(w16, (0, 0, 0, 0, 0, cpad)) if w16 is not None else None
+            return conv2d_nhwc(x.contiguous(), w, b, stride, pad, self.prec, w16)
         return F.conv2d(x.permute(0, 3, 1, 2), w, b, stride=stride, padding=pad).permute(0, 2, 3, 1).contiguous()
 
     def bn_l(self, x, p, eps=1e-5, relu=False):
@@ -181,10 +197,14 @@ class TrainGraph:
         bs = [self.t[p + ".finals.%d.bias" % i] for i in range(3)]
         n = sum(w.shape[0] for w in ws)
         npad = (n + 3) // 4 * 4
+        w16s = [self.w16.get(p + ".finals.%d.weight" % i) for i in range(3)]
         if npad != n:
             ws.append(ws[0].new_zeros((npad - n,) + tuple(ws[0].shape[1:])))
             bs.append(bs[0].new_zeros(npad - n))
-        y = conv2d_nhwc(feat.contiguous(), torch.cat(ws, 0), torch.cat(bs, 0), 1, 0, self.prec)
+            if w16s[0] is not None:
+                w16s.append(w16s[0].new_zeros((npad - n,) + tuple(ws[0].shape[1:])))
+        w16 = torch.cat(w16s, 0) if all(w is not None for w in w16s) else None
+        y = conv2d_nhwc(feat.contiguous(), torch.cat(ws, 0), torch.cat(bs, 0), 1, 0, self.prec, w16)
         return y[..., :n]
 
     def unet(self, p, img):
@@ -246,19 +266,21 @@ class TrainGraph:
             return idx
 
     # ---- fusion head (model/model.py:129-351, model/transfusion_head.py:137-173) -----------------------------------------------------------
-    def linear_rows(self, rows, w, b):
+    def linear_rows(self, rows, w, b, w16=None):
         """nn.Linear / Conv1d(k=1) / Conv2d(k=1) over rows [M, Cin] on the HIP GEMM (forward, data- and weight-gradient); input widths
         that are not whole channel groups (3-d coordinates, the 105 pose channels) are zero-padded together with the weight."""
         cin = rows.shape[-1]
         pad = (-cin) % self.cmul
         if pad:
             rows, w = F.pad(rows, (0, pad)), F.pad(w, (0, pad))
-        return linear_hip(rows.contiguous(), w, b, self.prec)
+            w16 = F.pad(w16, (0, pad)) if w16 is not None else None
+        return linear_hip(rows.contiguous(), w, b, self.prec, w16)
 
     def emb1d(self, p, x):
         """Conv1d(k=1) + BatchNorm1d over (B, N) (model/model.py:254-259) on rows."""
         B, N, Cin = x.shape
-        y = self.linear_rows(x.reshape(B * N, Cin), self.t[p + ".0.weight"][:, :, 0], self.t[p + ".0.bias"])
+        w16 = self.w16.get(p + ".0.weight")
+        y = self.linear_rows(x.reshape(B * N, Cin), self.t[p + ".0.weight"][:, :, 0], self.t[p + ".0.bias"], w16[:, :, 0] if w16 is not None else None)
         return self.bn_l(y.view(B, N, -1), p + ".1")
 
     @staticmethod
@@ -315,17 +337,23 @@ class TrainGraph:
             gf = torch.gather(feat, 1, flat.unsqueeze(-1).expand(-1, -1, C)).view(B, Jn, 64, C) - node_feat.unsqueeze(2)
             # the three 1x1 Conv2d + BatchNorm2d of a scale (model/model.py:176-192) on rows [B*J*64, .]
             q = lambda name, k: self.t[p + ".%s.%d%s" % (name, i, k)]
-            loc = self.bn_l(self.linear_rows((gx / r).reshape(-1, 3), q("conv_l0_blocks", ".weight")[:, :, 0, 0], q("conv_l0_blocks", ".bias")),
-                            p + ".bn_l0_blocks.%d" % i)
-            ft = self.bn_l(self.linear_rows(gf.reshape(-1, C), q("conv_f0_blocks", ".weight")[:, :, 0, 0], q("conv_f0_blocks", ".bias")),
-                           p + ".bn_f0_blocks.%d" % i)
+
+            def q16(name, k):
+                w16 = self.w16.get(p + ".%s.%d%s" % (name, i, k))
+                return w16[:, :, 0, 0] if w16 is not None else None
+
+            loc = self.bn_l(self.linear_rows((gx / r).reshape(-1, 3), q("conv_l0_blocks", ".weight")[:, :, 0, 0], q("conv_l0_blocks", ".bias"),
+                                             q16("conv_l0_blocks", ".weight")), p + ".bn_l0_blocks.%d" % i)
+            ft = self.bn_l(self.linear_rows(gf.reshape(-1, C), q("conv_f0_blocks", ".weight")[:, :, 0, 0], q("conv_f0_blocks", ".bias"),
+                                            q16("conv_f0_blocks", ".weight")), p + ".bn_f0_blocks.%d" % i)
             g = F.relu(loc + ft)
-            g = self.bn_l(self.linear_rows(g, q("conv_blocks", ".0.weight")[:, :, 0, 0], q("conv_blocks", ".0.bias")), p + ".bn_blocks.%d.0" % i,
-                          relu=True)
+            g = self.bn_l(self.linear_rows(g, q("conv_blocks", ".0.weight")[:, :, 0, 0], q("conv_blocks", ".0.bias"), q16("conv_blocks", ".0.weight")),
+                          p + ".bn_blocks.%d.0" % i, relu=True)
             outs.append(g.view(B, Jn, 64, -1).max(2)[0])  # B x J x 128
         outs.append(node_feat)
         cat = torch.cat(outs, -1).reshape(B * Jn, -1)  # rows of 512
-        y = self.linear_rows(cat, self.t[p + ".fusion.0.weight"][:, :, 0], self.t[p + ".fusion.0.bias"])
+        wf16 = self.w16.get(p + ".fusion.0.weight")
+        y = self.linear_rows(cat, self.t[p + ".fusion.0.weight"][:, :, 0], self.t[p + ".fusion.0.bias"], wf16[:, :, 0] if wf16 is not None else None)
         return self.bn_l(y, p + ".fusion.1", relu=True).view(B, Jn, -1)
 
     def bert_layer(self, p, h, heads=4):

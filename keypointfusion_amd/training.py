@@ -166,10 +166,22 @@ class DevPack:
             self.KH, self.KW, self.Cin, self.sh, self.sw, self.ph, self.pw, self.merge = KH, KW, Cin, stride, stride, pad, pad, 1
         K = KH * KW * Cin
         self.N, self.K, self.Kp = N, K, (K + 31) // 32 * 32
-        wk = w.permute(0, 2, 3, 1).reshape(N, K).float()
-        self.w = wk.contiguous() if self.Kp == K else F.pad(wk, (0, self.Kp - K)).contiguous()
+        wk = w.permute(0, 2, 3, 1).reshape(N, K)
+        self._set_rows(wk)
         self.b = bias.detach().float().contiguous() if bias is not None else None  # NULL bias: the kernel adds nothing
         self.tuned = {}
+
+    def _set_rows(self, rows):
+        """rows [N][K]: fp32 -> the fp32 kernel operand (K padded to 32); 16-bit (a shadow copy of the master weight, cast once per
+        step for the whole model) -> the 16-bit operand (K padded to 64) with no per-layer cast."""
+        N, K = rows.shape
+        if rows.dtype == torch.float32:
+            self.w = rows.contiguous() if self.Kp == K else F.pad(rows, (0, self.Kp - K)).contiguous()
+            self.w16 = None
+        else:
+            kp = (K + 63) // 64 * 64
+            self.w = None
+            self.w16 = rows.contiguous() if kp == K else F.pad(rows, (0, kp - K)).contiguous()
 
     @classmethod
     def from_rows(cls, rows, KH, KW, Cin, pad):
@@ -179,8 +191,7 @@ class DevPack:
         assert K == KH * KW * Cin
         self.KH, self.KW, self.Cin, self.sh, self.sw, self.ph, self.pw, self.merge = KH, KW, Cin, 1, 1, pad, pad, 1
         self.N, self.K, self.Kp = N, K, (K + 31) // 32 * 32
-        rows = rows.float()
-        self.w = rows.contiguous() if self.Kp == K else F.pad(rows, (0, self.Kp - K)).contiguous()
+        self._set_rows(rows)
         self.b = None
         self.tuned = {}
         return self
@@ -191,6 +202,9 @@ class DevPack:
     def as16(self, tdt):
         """The object engine16.conv16() takes: 16-bit rows [N][Kp64] of the same weights."""
         kp = (self.K + 63) // 64 * 64
+        if self.w16 is not None:
+            assert self.w16.dtype == tdt
+            return type("P16", (), {"pc": self, "Kp": kp, "w": self.w16})()
         w = self.w[:, :self.K]
         w16 = (w if kp == self.K else F.pad(w, (0, kp - self.K))).to(tdt).contiguous()
         return type("P16", (), {"pc": self, "Kp": kp, "w": w16})()
@@ -335,17 +349,20 @@ class Conv2dNHWC(torch.autograd.Function):
     Linear layers are the 1x1 case on a [rows, 1, 1, K] view."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, prec="f32"):
+    def forward(ctx, x, weight, bias, stride, pad, prec="f32", w16=None):
         """prec "bf16" / "f16": operands rounded to 16 bits, fp32 accumulation on the 16-bit MFMA (kpf_conv2d_h16), 16-bit output;
-        the weight stays the fp32 master copy and receives an fp32 gradient."""
+        the weight stays the fp32 master copy and receives an fp32 gradient.  w16: the weight already rounded to the compute type
+        (same shape; TrainGraph casts all of them once per step) — the packs are then built from it without per-layer casts."""
         assert x.is_cuda and x.dim() == 4
         B, H, W, Cin = x.shape
         N, Cw, KH, KW = weight.shape
         assert Cw == Cin and Cin % (4 if prec == "f32" else 8) == 0, "Conv2dNHWC: input channels must match and be a multiple of 4 (8 for 16-bit)"
         patch = stride == KH == KW and pad == 0 and stride > 1
-        pc = DevPack(weight, bias, stride=stride, pad=pad, patchify=patch)
+        use16 = prec != "f32" and w16 is not None
+        pc = DevPack(w16 if use16 else weight, bias, stride=stride, pad=pad, patchify=patch)
         y = _conv_any(pc, x if prec != "f32" else x.float(), prec)
         ctx.save_for_backward(x, weight)
+        ctx.w16 = w16 if use16 else None
         ctx.conf = (stride, pad, patch, bias is not None, prec)
         return y
 
@@ -360,8 +377,9 @@ class Conv2dNHWC(torch.autograd.Function):
         dx = dw = db = None
         cmul = 4 if prec == "f32" else 8  # channel granularity of the GEMM's activation operand
         if ctx.needs_input_grad[0]:
+            wsrc = ctx.w16 if ctx.w16 is not None else weight.detach()
             if patch:  # dX[b, oy*s+ky, ox*s+kx, c] = sum_n dY[b,oy,ox,n] W[n,c,ky,kx]: rows of a GEMM, then un-shuffle
-                wt = weight.permute(2, 3, 1, 0).reshape(KH * KW * Cin, N)  # [(ky,kx,c)][n]
+                wt = wsrc.permute(2, 3, 1, 0).reshape(KH * KW * Cin, N)  # [(ky,kx,c)][n]
                 npad = (N + cmul - 1) // cmul * cmul
                 dy_in = dy if npad == N else F.pad(dy, (0, npad - N))
                 if npad != N:
@@ -374,7 +392,7 @@ class Conv2dNHWC(torch.autograd.Function):
                 if stride != 1:
                     raise NotImplementedError("Conv2dNHWC.backward: data gradient of strided non-patchify convolutions is not built yet")
                 npad = (N + cmul - 1) // cmul * cmul
-                wd = weight.detach()
+                wd = wsrc
                 if npad != N:  # the kernel needs whole channel groups: zero-pad dY's channel axis (and the weight's output axis)
                     dy_in = F.pad(dy, (0, npad - N))
                     wd = F.pad(wd, (0, 0, 0, 0, 0, 0, 0, npad - N))
@@ -389,7 +407,7 @@ class Conv2dNHWC(torch.autograd.Function):
             # hand-written split-K weight gradient (fp32 operands and accumulation in every precision mode: the master weight's
             # gradient is not rounded to 16 bits), bias gradient from the same pass
             dw, db = conv_wgrad_hip(dy.float(), x.float(), weight.shape, stride, pad, has_bias and ctx.needs_input_grad[2])
-            return dx, dw, db, None, None, None
+            return dx, dw, db, None, None, None, None
         if ctx.needs_input_grad[1]:
             xw = x if prec == "f32" else x.to(_TDT[prec])  # weight gradient in the compute precision, handed to the fp32 master weight
             dyw = dy if prec == "f32" else dy.to(_TDT[prec])
@@ -399,17 +417,18 @@ class Conv2dNHWC(torch.autograd.Function):
                 dw = torch.nn.grad.conv2d_weight(xw.permute(0, 3, 1, 2), weight.shape, dyw.permute(0, 3, 1, 2), stride=stride, padding=pad).float()
         if has_bias and ctx.needs_input_grad[2]:
             db = dy.float().view(-1, N).sum(0)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
-def conv2d_nhwc(x, weight, bias=None, stride=1, pad=0, prec="f32"):
-    return Conv2dNHWC.apply(x, weight, bias, stride, pad, prec)
+def conv2d_nhwc(x, weight, bias=None, stride=1, pad=0, prec="f32", w16=None):
+    return Conv2dNHWC.apply(x, weight, bias, stride, pad, prec, w16)
 
 
-def linear_hip(x, weight, bias=None, prec="f32"):
+def linear_hip(x, weight, bias=None, prec="f32", w16=None):
     """nn.Linear on rows [..., K] through the same Function (a 1x1 convolution over a [rows, 1, 1, K] view)."""
     K = x.shape[-1]
-    y = Conv2dNHWC.apply(x.reshape(-1, 1, 1, K), weight.view(weight.shape[0], K, 1, 1), bias, 1, 0, prec)
+    y = Conv2dNHWC.apply(x.reshape(-1, 1, 1, K), weight.reshape(weight.shape[0], K, 1, 1), bias, 1, 0, prec,
+                         w16.reshape(weight.shape[0], K, 1, 1) if w16 is not None else None)
     return y.view(*x.shape[:-1], weight.shape[0])
 
 
