@@ -277,6 +277,10 @@ int kpf_cast_f32_h16(const float* src, void* dst, int dtype, long n, void* strea
 long kpf_conv2d_wgrad_ws_floats(long M, int N, int K);
 int kpf_conv2d_wgrad_f32(const float* dy, const float* x, float* dw, float* db, float* ws, long ws_floats, int B, int H, int W, int Cin,
                          int ldx, int OH, int OW, int N, int ldy, int KH, int KW, int sh, int sw, int ph, int pw, void* stream);
+/* The same with dy and x in 16-bit storage (dtype = KPF_DT_BF16 / KPF_DT_F16; mixed-precision training): values are widened to fp32
+ * on the way into LDS, products and sums are the fp32 ones (the master weight's gradient is not rounded).  Cin, N, ldx, ldy % 8 == 0. */
+int kpf_conv2d_wgrad_h16(const void* dy, const void* x, int dtype, float* dw, float* db, float* ws, long ws_floats, int B, int H, int W, int Cin,
+                         int ldx, int OH, int OW, int N, int ldy, int KH, int KW, int sh, int sw, int ph, int pw, void* stream);
 /* Depthwise 7x7 (pad 3) + bias alone, y = dwconv(x): the ConvNeXt block's first op with its output kept for the LayerNorm backward,
  * and its data gradient (dx = the same convolution of dy with w_dw's taps mirrored, zero bias).  w_dw [49][C], x != y. */
 int kpf_dwconv7_f32(const float* x, const float* w_dw, const float* b_dw, float* y, int B, int H, int W, int C, void* stream);

@@ -14,6 +14,8 @@
 //     window in registers, partial sums per (image, row band) chunk, same fixed-order reduce.
 #include "kpf_common.h"
 
+#include <type_traits>
+
 namespace {
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -22,8 +24,8 @@ typedef __attribute__((address_space(1))) void gbl_void_t;
 __device__ __attribute__((aligned(16))) float wg_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
 struct WgradArgs {
-  const float* dy;   // [M][ldy]
-  const float* x;    // NHWC [B][H][W][ldx]
+  const void* dy;    // [M][ldy]                 fp32, or the 16-bit storage type of the mixed-precision step (TIN)
+  const void* x;     // NHWC [B][H][W][ldx]
   float* part;       // [S][N][K]
   float* dbpart;     // [S][N] or nullptr
   const float* zero;
@@ -34,8 +36,26 @@ struct WgradArgs {
 
 constexpr int RB = 32;  // pixels (reduction rows) per LDS stage
 
-template <int VN, int VK>
+// 8 consecutive 16-bit values (one 16-byte load) -> 8 floats
+__device__ __forceinline__ void unpack8(const uint4 u, bf16_t, f32x4& lo, f32x4& hi) {
+  lo = f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+  hi = f32x4{__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
+}
+__device__ __forceinline__ void unpack8(const uint4 u, f16_t, f32x4& lo, f32x4& hi) {
+  const f16x8 h = __builtin_bit_cast(f16x8, u);
+  lo = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+  hi = f32x4{(float)h[4], (float)h[5], (float)h[6], (float)h[7]};
+}
+
+__device__ __forceinline__ void unpack8(const uint4, float, f32x4&, f32x4&) {}  // (fp32 operands take the DMA path: never called)
+
+// TIN = float: operands staged by LDS-DMA.  TIN = bf16_t / f16_t (mixed-precision training: dY and the saved activations are 16-bit):
+// 16-byte global loads of 8 values into registers while the previous tile is multiplied, widened to fp32 on the way into LDS — the
+// MFMAs, accumulation and reduction are the fp32 ones (the master weight's gradient is not rounded), and the separate
+// 16-bit -> fp32 passes over dY and X disappear.
+template <int VN, int VK, typename TIN>
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradArgs a) {
+  constexpr bool DMA = std::is_same<TIN, float>::value;
   constexpr int BN = 32 * VN, BK = 32 * VK;     // output tile; 2 x 2 waves, wave tile (16 VN) x (16 VK)
   constexpr int GA = BN / 4, GB = BK / 4;       // 16-byte granules per staged row
   constexpr int RA = 64 / GA, RBW = 64 / GB;    // rows one wave-DMA (64 lanes x 16 B) covers
@@ -57,7 +77,8 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradArgs a) {
   const int ga = lane % GA, ra = lane / GA;     // A: granule column / row inside one wave-DMA
   const int gb = lane % GB, rb = lane / GB;
   const bool a_ok = n0 + 4 * ga < a.N;
-  const float* a_src = a.dy + n0 + 4 * ga;
+  const float* a_src = static_cast<const float*>(a.dy) + n0 + 4 * ga;
+  const float* xf = static_cast<const float*>(a.x);
   const int kcol = k0 + 4 * gb;
   const bool b_ok = kcol < a.K;
   const int tap = kcol / a.Cin, cch = kcol - tap * a.Cin;
@@ -80,12 +101,12 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradArgs a) {
       const float* src = a.zero;
       if (b_ok && m < a.M) {
         if (a.is1x1) {
-          src = a.x + (size_t)m * a.ldx + cch;
+          src = xf + (size_t)m * a.ldx + cch;
         } else {
           const int b = m / ohw, r = m - b * ohw;
           const int oy = r / a.OW, ox = r - oy * a.OW;
           const int iy = oy * a.sh + ky - a.ph, ix = ox * a.sw + kx - a.pw;
-          if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) src = a.x + ((size_t)(b * a.H + iy) * a.W + ix) * a.ldx + cch;
+          if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) src = xf + ((size_t)(b * a.H + iy) * a.W + ix) * a.ldx + cch;
         }
       }
       __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(buf + RB * BN + d * 256), 16, 0, 0);
@@ -106,11 +127,84 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradArgs a) {
   const int a_off = fr * BN + wn * (16 * VN) + VN * fc;
   const int b_off = RB * BN + fr * BK + wk * (16 * VK) + VK * fc;
 
-  if (ns > 0) stage(0, lds);
+  // ---- 16-bit operands: register staging (8-element granules) ----
+  constexpr int GA8 = BN / 8, GB8 = BK / 8;          // granules per staged row
+  constexpr int NA = RB * GA8 / 256 > 0 ? RB * GA8 / 256 : 1, NB = RB * GB8 / 256 > 0 ? RB * GB8 / 256 : 1;
+  const TIN* dyh = static_cast<const TIN*>(a.dy);
+  const TIN* xh = static_cast<const TIN*>(a.x);
+  const int gcolb = tid % GB8;                        // (256 % GB8 == 0: a thread's X granule column is the same for every pass)
+  const int kcol8 = k0 + 8 * gcolb;
+  const bool b8_ok = kcol8 < a.K;
+  const int tap8 = kcol8 / a.Cin, cch8 = kcol8 - tap8 * a.Cin;
+  const int ky8 = tap8 / a.KW, kx8 = tap8 - ky8 * a.KW;
+  uint4 rga[NA], rgb[NB];
+  auto load_regs = [&](int s) {
+    const int mb = m_begin + s * RB;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int g = i * 256 + tid, row = g / GA8, gc = g % GA8;
+      const int m = mb + row, n = n0 + 8 * gc;
+      uint4 v = {0u, 0u, 0u, 0u};
+      if (row < RB && m < a.M && n < a.N) v = *reinterpret_cast<const uint4*>(dyh + (size_t)m * a.ldy + n);
+      rga[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int g = i * 256 + tid, row = g / GB8;
+      const int m = mb + row;
+      uint4 v = {0u, 0u, 0u, 0u};
+      if (row < RB && b8_ok && m < a.M) {
+        if (a.is1x1) {
+          v = *reinterpret_cast<const uint4*>(xh + (size_t)m * a.ldx + cch8);
+        } else {
+          const int b = m / ohw, r = m - b * ohw;
+          const int oy = r / a.OW, ox = r - oy * a.OW;
+          const int iy = oy * a.sh + ky8 - a.ph, ix = ox * a.sw + kx8 - a.pw;
+          if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+            v = *reinterpret_cast<const uint4*>(xh + ((size_t)(b * a.H + iy) * a.W + ix) * a.ldx + cch8);
+        }
+      }
+      rgb[i] = v;
+    }
+  };
+  auto write_lds = [&](float* buf) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int g = i * 256 + tid, row = g / GA8, gc = g % GA8;
+      if (row < RB) {
+        f32x4 lo, hi;
+        unpack8(rga[i], TIN(), lo, hi);
+        *reinterpret_cast<f32x4*>(buf + row * BN + 8 * gc) = lo;
+        *reinterpret_cast<f32x4*>(buf + row * BN + 8 * gc + 4) = hi;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int g = i * 256 + tid, row = g / GB8;
+      if (row < RB) {
+        f32x4 lo, hi;
+        unpack8(rgb[i], TIN(), lo, hi);
+        *reinterpret_cast<f32x4*>(buf + RB * BN + row * BK + 8 * gcolb) = lo;
+        *reinterpret_cast<f32x4*>(buf + RB * BN + row * BK + 8 * gcolb + 4) = hi;
+      }
+    }
+  };
+
+  if (ns > 0) {
+    if constexpr (DMA) {
+      stage(0, lds);
+    } else {
+      load_regs(0);
+      write_lds(lds);
+    }
+  }
   for (int s = 0; s < ns; ++s) {
-    __syncthreads();  // the barrier's fence drains the DMA of tile s; every wave is done with tile s-1
+    __syncthreads();  // tile s is in LDS (DMA: the barrier's fence drains it); every wave is done with tile s-1
     float* cur = lds + (s & 1) * TILE;
-    if (s + 1 < ns) stage(s + 1, lds + ((s + 1) & 1) * TILE);
+    if (s + 1 < ns) {
+      if constexpr (DMA) stage(s + 1, lds + ((s + 1) & 1) * TILE);
+      else load_regs(s + 1);  // in flight under this tile's MFMAs, written to the other buffer below
+    }
 #pragma unroll
     for (int q = 0; q < RB / 4; ++q) {
       const fvn af = *reinterpret_cast<const fvn*>(cur + a_off + 4 * q * BN);
@@ -120,6 +214,9 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradArgs a) {
       for (int i = 0; i < VN; ++i)
 #pragma unroll
         for (int j = 0; j < VK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if constexpr (!DMA) {
+      if (s + 1 < ns) write_lds(lds + ((s + 1) & 1) * TILE);
     }
   }
 
@@ -307,11 +404,19 @@ const float* zero_page() {
   return (const float*)q;
 }
 
-template <int VN, int VK>
+template <int VN, int VK, typename TIN>
 int launch_wgrad(const WgradArgs& a, const Plan& p, hipStream_t st) {
   constexpr int LDS = 2 * RB * 32 * (VN + VK) * 4;
-  hipLaunchKernelGGL((wgrad_f32_kernel<VN, VK>), dim3(p.tilesN * p.tilesK, p.S), dim3(256), LDS, st, a);
-  return kpf_check_launch("kpf_conv2d_wgrad_f32");
+  hipLaunchKernelGGL((wgrad_f32_kernel<VN, VK, TIN>), dim3(p.tilesN * p.tilesK, p.S), dim3(256), LDS, st, a);
+  return kpf_check_launch("kpf_conv2d_wgrad");
+}
+
+template <typename TIN>
+int launch_wgrad_any(const WgradArgs& a, const Plan& p, hipStream_t st) {
+  if (p.vn == 4 && p.vk == 4) return launch_wgrad<4, 4, TIN>(a, p, st);
+  if (p.vn == 4) return launch_wgrad<4, 2, TIN>(a, p, st);
+  if (p.vk == 4) return launch_wgrad<2, 4, TIN>(a, p, st);
+  return launch_wgrad<2, 2, TIN>(a, p, st);
 }
 
 int dw_chunk_rows(int B, int H, int C) {
@@ -333,9 +438,13 @@ long kpf_conv2d_wgrad_ws_floats(long M, int N, int K) {
   return (long)p.S * N * K + (long)p.S * N;
 }
 
-int kpf_conv2d_wgrad_f32(const float* dy, const float* x, float* dw, float* db, float* ws, long ws_floats, int B, int H, int W, int Cin,
-                         int ldx, int OH, int OW, int N, int ldy, int KH, int KW, int sh, int sw, int ph, int pw, void* stream) {
+static int conv2d_wgrad_impl(const void* dy, const void* x, int dtype, float* dw, float* db, float* ws, long ws_floats, int B, int H, int W,
+                             int Cin, int ldx, int OH, int OW, int N, int ldy, int KH, int KW, int sh, int sw, int ph, int pw,
+                             void* stream) {
   KPF_REQUIRE(dy && x && dw && ws, "kpf_conv2d_wgrad_f32: null pointer");
+  KPF_REQUIRE(dtype == KPF_DT_F32 || dtype == KPF_DT_BF16 || dtype == KPF_DT_F16, "kpf_conv2d_wgrad: unknown dtype %d", dtype);
+  if (dtype != KPF_DT_F32)
+    KPF_REQUIRE(Cin % 8 == 0 && ldx % 8 == 0 && N % 8 == 0 && ldy % 8 == 0, "kpf_conv2d_wgrad_h16: Cin, N, ldx, ldy must be multiples of 8");
   KPF_REQUIRE(B > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && KH > 0 && KW > 0 && sh > 0 && sw > 0, "kpf_conv2d_wgrad_f32: bad shape");
   KPF_REQUIRE(Cin > 0 && Cin % 4 == 0 && ldx % 4 == 0 && ldx >= Cin, "kpf_conv2d_wgrad_f32: Cin and ldx must be multiples of 4 (got %d, %d)", Cin, ldx);
   KPF_REQUIRE(N > 0 && N % 4 == 0 && ldy % 4 == 0 && ldy >= N, "kpf_conv2d_wgrad_f32: N and ldy must be multiples of 4 (got %d, %d)", N, ldy);
@@ -355,17 +464,25 @@ int kpf_conv2d_wgrad_f32(const float* dy, const float* x, float* dw, float* db, 
   a.sh = sh, a.sw = sw, a.ph = ph, a.pw = pw, a.M = (int)M, a.K = (int)K, a.tilesK = p.tilesK, a.stages_per_split = p.sps;
   a.is1x1 = KH == 1 && KW == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0 && OH == H && OW == W;
   hipStream_t st = (hipStream_t)stream;
-  int rc;
-  if (p.vn == 4 && p.vk == 4) rc = launch_wgrad<4, 4>(a, p, st);
-  else if (p.vn == 4) rc = launch_wgrad<4, 2>(a, p, st);
-  else if (p.vk == 4) rc = launch_wgrad<2, 4>(a, p, st);
-  else rc = launch_wgrad<2, 2>(a, p, st);
+  const int rc = dtype == KPF_DT_F32 ? launch_wgrad_any<float>(a, p, st)
+                 : (dtype == KPF_DT_BF16 ? launch_wgrad_any<bf16_t>(a, p, st) : launch_wgrad_any<f16_t>(a, p, st));
   if (rc != KPF_OK) return rc;
   const long NK = (long)N * K;
   const int nkb = (int)((NK + 63) / 64);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nkb + (db ? (N + 63) / 64 : 0)), dim3(256), 0, st, ws, a.dbpart, dw, db, p.S, N, (int)K, Cin,
                      KH * KW, nkb);
   return kpf_check_launch("kpf_conv2d_wgrad_f32 (reduce)");
+}
+
+int kpf_conv2d_wgrad_f32(const float* dy, const float* x, float* dw, float* db, float* ws, long ws_floats, int B, int H, int W, int Cin,
+                         int ldx, int OH, int OW, int N, int ldy, int KH, int KW, int sh, int sw, int ph, int pw, void* stream) {
+  return conv2d_wgrad_impl(dy, x, KPF_DT_F32, dw, db, ws, ws_floats, B, H, W, Cin, ldx, OH, OW, N, ldy, KH, KW, sh, sw, ph, pw, stream);
+}
+
+int kpf_conv2d_wgrad_h16(const void* dy, const void* x, int dtype, float* dw, float* db, float* ws, long ws_floats, int B, int H, int W, int Cin,
+                         int ldx, int OH, int OW, int N, int ldy, int KH, int KW, int sh, int sw, int ph, int pw, void* stream) {
+  KPF_REQUIRE(dtype == KPF_DT_BF16 || dtype == KPF_DT_F16, "kpf_conv2d_wgrad_h16: dtype must be KPF_DT_BF16 or KPF_DT_F16");
+  return conv2d_wgrad_impl(dy, x, dtype, dw, db, ws, ws_floats, B, H, W, Cin, ldx, OH, OW, N, ldy, KH, KW, sh, sw, ph, pw, stream);
 }
 
 long kpf_dwconv7_wgrad_ws_floats(int B, int H, int C) {

@@ -73,6 +73,7 @@ _SIGS = {
     "kpf_bn_train_forward_f32": [_P] * 8 + [C.c_float, C.c_float, C.c_int, _P, C.c_long, C.c_long, C.c_int, _P],
     "kpf_bn_train_backward_f32": [_P] * 9 + [C.c_int, _P, C.c_long, C.c_long, C.c_int, _P],
     "kpf_dwconv7_f32": [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_conv2d_wgrad_h16": [_P, _P, C.c_int] + [_P] * 3 + [C.c_long] + [C.c_int] * 15 + [_P],
     "kpf_dwconv7_wgrad_f32": [_P] * 5 + [C.c_long] + [C.c_int] * 4 + [_P],
 }
 _LONG_SIGS = {  # entries returning a long

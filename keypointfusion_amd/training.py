@@ -227,21 +227,31 @@ def _conv_any(pc, x4, prec):
 
 
 def conv_wgrad_hip(dy, x, wshape, stride, pad, want_db=True):
-    """(dW in OIHW, db or None) of a convolution from NHWC fp32 dY [B,OH,OW,N] and X [B,H,W,Cin]: kpf_conv2d_wgrad_f32 (f32 MFMA GEMM
+    """(dW in OIHW, db or None) of a convolution from NHWC dY [B,OH,OW,N] and X [B,H,W,Cin]: kpf_conv2d_wgrad_f32 / _h16 (f32 MFMA GEMM
     with the pixel index as the reduction dimension, split over workgroups, fixed-order reduce)."""
     from . import lib as L
     lib = L.load()
-    dy, x = dy.contiguous(), x.contiguous()
     B, H, W, Cin = x.shape
     _, OH, OW, N = dy.shape
     KH, KW = int(wshape[2]), int(wshape[3])
+    # both operands in the same 16-bit storage type (mixed-precision step) and whole 8-element granules: kpf_conv2d_wgrad_h16 reads them
+    # as they are (fp32 products and sums); anything else is widened to fp32 first
+    h16 = dy.dtype == x.dtype and dy.dtype in (torch.bfloat16, torch.float16) and Cin % 8 == 0 and N % 8 == 0
+    if not h16:
+        dy, x = dy.float(), x.float()
+    dy, x = dy.contiguous(), x.contiguous()
     nws = lib.kpf_conv2d_wgrad_ws_floats(B * OH * OW, N, KH * KW * Cin)
     ws = torch.empty(nws, device=x.device, dtype=torch.float32)
     dw = torch.empty(tuple(wshape), device=x.device, dtype=torch.float32)
     db = torch.empty(N, device=x.device, dtype=torch.float32) if want_db else None
-    L.check(lib.kpf_conv2d_wgrad_f32(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr() if want_db else None, ws.data_ptr(), nws,
-                                     B, H, W, Cin, Cin, OH, OW, N, N, KH, KW, stride, stride, pad, pad,
-                                     torch.cuda.current_stream().cuda_stream), "kpf_conv2d_wgrad_f32")
+    st = torch.cuda.current_stream().cuda_stream
+    if h16:
+        L.check(lib.kpf_conv2d_wgrad_h16(dy.data_ptr(), x.data_ptr(), L.KPF_DT_BF16 if dy.dtype == torch.bfloat16 else L.KPF_DT_F16, dw.data_ptr(),
+                                         db.data_ptr() if want_db else None, ws.data_ptr(), nws, B, H, W, Cin, Cin, OH, OW, N, N, KH, KW,
+                                         stride, stride, pad, pad, st), "kpf_conv2d_wgrad_h16")
+    else:
+        L.check(lib.kpf_conv2d_wgrad_f32(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr() if want_db else None, ws.data_ptr(), nws,
+                                         B, H, W, Cin, Cin, OH, OW, N, N, KH, KW, stride, stride, pad, pad, st), "kpf_conv2d_wgrad_f32")
     return dw, db
 
 
@@ -360,9 +370,11 @@ class Conv2dNHWC(torch.autograd.Function):
         patch = stride == KH == KW and pad == 0 and stride > 1
         use16 = prec != "f32" and w16 is not None
         pc = DevPack(w16 if use16 else weight, bias, stride=stride, pad=pad, patchify=patch)
-        y = _conv_any(pc, x if prec != "f32" else x.float(), prec)
-        ctx.save_for_backward(x, weight)
+        xc = x.float() if prec == "f32" else x.to(_TDT[prec])  # the operand as the GEMM sees it — also what the weight gradient multiplies
+        y = _conv_any(pc, xc, prec)
+        ctx.save_for_backward(xc, weight)
         ctx.w16 = w16 if use16 else None
+        ctx.x_dtype = x.dtype
         ctx.conf = (stride, pad, patch, bias is not None, prec)
         return y
 
@@ -402,11 +414,11 @@ class Conv2dNHWC(torch.autograd.Function):
                     wd = wd.flip(2, 3)  # taps mirrored
                 rows = wd.permute(1, 2, 3, 0).reshape(Cin, KH * KW * npad)  # [c][(ky,kx,n)]: one transposing copy
                 dx = _conv_any(DevPack.from_rows(rows, KH, KW, npad, KH - 1 - pad), dy_in, prec).view(B, H, W, Cin)
-            dx = dx.to(x.dtype)
+            dx = dx.to(ctx.x_dtype)
         if ctx.needs_input_grad[1] and Cin % 4 == 0 and N % 4 == 0:
-            # hand-written split-K weight gradient (fp32 operands and accumulation in every precision mode: the master weight's
-            # gradient is not rounded to 16 bits), bias gradient from the same pass
-            dw, db = conv_wgrad_hip(dy.float(), x.float(), weight.shape, stride, pad, has_bias and ctx.needs_input_grad[2])
+            # hand-written split-K weight gradient (fp32 products and accumulation in every precision mode: the master weight's
+            # gradient is not rounded to 16 bits; 16-bit dY / X are read as stored), bias gradient from the same pass
+            dw, db = conv_wgrad_hip(dy, x, weight.shape, stride, pad, has_bias and ctx.needs_input_grad[2])
             return dx, dw, db, None, None, None, None
         if ctx.needs_input_grad[1]:
             xw = x if prec == "f32" else x.to(_TDT[prec])  # weight gradient in the compute precision, handed to the fp32 master weight

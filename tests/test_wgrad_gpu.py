@@ -112,3 +112,23 @@ def test_batchnorm_relu_rows_matches_torch(M, Cc, relu):
     assert float((xd.grad.cpu().double() - xr.grad).abs().max()) <= tol(xr.grad)
     assert float((wd.grad.cpu().double() - wr.grad).abs().max()) <= tol(wr.grad)
     assert float((bd.grad.cpu().double() - br.grad).abs().max()) <= tol(br.grad)
+
+
+@pytest.mark.parametrize("tdt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [(2, 8, 8, 384, 1536, 1, 1, 0), (4, 16, 16, 64, 64, 3, 1, 1), (3, 5, 7, 8, 16, 3, 1, 1), (2, 16, 16, 96, 192, 2, 2, 0),
+                                  (1, 1, 21, 128, 512, 1, 1, 0), (2, 16, 16, 144, 72, 1, 1, 0), (32, 32, 32, 48, 128, 1, 1, 0)])
+def test_conv_wgrad_16bit_operands_match_fp64_on_the_rounded_values(case, tdt):
+    """kpf_conv2d_wgrad_h16: dY and X in 16-bit storage, fp32 products and sums — equal to the fp64 gradient of the ROUNDED operands to
+    fp32 accumulation accuracy (nothing else is rounded)."""
+    from keypointfusion_amd.training import conv_wgrad_hip
+    B, H, W, Cin, N, k, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    OH = (H + 2 * pad - k) // stride + 1
+    OW = (W + 2 * pad - k) // stride + 1
+    x = torch.randn(B, H, W, Cin, generator=g).to(tdt)
+    dy = torch.randn(B, OH, OW, N, generator=g).to(tdt)
+    dw, db = conv_wgrad_hip(dy.cuda(), x.cuda(), (N, Cin, k, k), stride, pad, True)
+    assert dw.dtype == torch.float32
+    rw, rb = _ref(x.float(), dy.float(), (N, Cin, k, k), stride, pad)
+    assert float((dw.cpu().double() - rw).abs().max()) <= 2e-5 * float(rw.abs().max())
+    assert float((db.cpu().double() - rb).abs().max()) <= 2e-5 * max(float(rb.abs().max()), 1.0)
