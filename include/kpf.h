@@ -300,6 +300,13 @@ int kpf_dwconv7_wgrad_f32(const float* dy, const float* x, float* dw, float* db,
  * ws >= kpf_bn_ws_floats(M, C) floats; sums are added in a fixed order (run-to-run deterministic).
  */
 long kpf_bn_ws_floats(long M, int C);
+/* Storage-type generic forms (mixed-precision training): x / dx in x_dtype, y / dy in y_dtype, each KPF_DT_F32 or one 16-bit type
+ * (the same on both sides when both are 16-bit); statistics, parameters and all arithmetic stay fp32. */
+int kpf_bn_train_forward(const void* x, int x_dtype, const float* w, const float* b, void* y, int y_dtype, float* mean, float* invstd,
+                         float* running_mean, float* running_var, float momentum, float eps, int relu, float* ws, long ws_floats, long M, int C,
+                         void* stream);
+int kpf_bn_train_backward(const void* dy, const void* x, const void* y, int x_dtype, int y_dtype, const float* mean, const float* invstd,
+                          const float* w, void* dx, float* dw, float* db, int relu, float* ws, long ws_floats, long M, int C, void* stream);
 int kpf_bn_train_forward_f32(const float* x, const float* w, const float* b, float* y, float* mean, float* invstd, float* running_mean,
                              float* running_var, float momentum, float eps, int relu, float* ws, long ws_floats, long M, int C,
                              void* stream);

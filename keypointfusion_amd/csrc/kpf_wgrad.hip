@@ -531,8 +531,10 @@ __host__ __device__ inline BnGeom bn_geom(int C) {
 
 // MODE 0: forward statistics  p0 = sum(x - K), p1 = sum((x - K)^2)          (K = x[0][c])
 // MODE 1: backward sums       p0 = sum(dz),    p1 = sum(dz * (x - mean))     (dz = dy masked by y > 0 when RELU)
-template <int MODE, bool RELU>
-__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
+// TX: storage type of the layer's input side (x, dx); TY: of its output side (y, dy) — fp32 or the 16-bit type of the
+// mixed-precision step; the arithmetic is fp32 either way.
+template <int MODE, bool RELU, typename TX, typename TY>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const TX* __restrict__ x, const TY* __restrict__ dy, const TY* __restrict__ y,
                                                          const float* __restrict__ mean, float* __restrict__ ws, long M, int C,
                                                          int rows_per_chunk) {
   __shared__ f32x4 red[2][256];
@@ -600,7 +602,8 @@ __device__ __forceinline__ void bn_sum_partials(const float* __restrict__ ws, in
 }
 
 // forward finalize: batch mean / 1/sqrt(biased var + eps), running statistics (unbiased variance); 64 channels per workgroup
-__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ x, const float* __restrict__ ws, int S, long M, int C,
+template <typename TX>
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const TX* __restrict__ x, const float* __restrict__ ws, int S, long M, int C,
                                                                 float* __restrict__ mean, float* __restrict__ invstd,
                                                                 float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps) {
   __shared__ float red[4][2][64];
@@ -611,7 +614,7 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
   const float n = (float)M;
   const float ms = s / n;
   const float var = fmaxf(ss / n - ms * ms, 0.f);
-  const float m = x[c] + ms;
+  const float m = (float)x[c] + ms;
   mean[c] = m;
   invstd[c] = 1.0f / sqrtf(var + eps);
   if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * m;
@@ -635,11 +638,13 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 
 // MODE 0: y = [relu]((x - mean) * invstd * w + b)
 // MODE 1: dx = w * invstd * (dz - coef0 - (x - mean) * coef1)
-template <int MODE, bool RELU>
-__global__ __launch_bounds__(256) void bn_elem_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
+// (MODE 0 writes y: TY; MODE 1 writes dx: TX)
+template <int MODE, bool RELU, typename TX, typename TY>
+__global__ __launch_bounds__(256) void bn_elem_kernel(const TX* __restrict__ x, const TY* __restrict__ dy, const TY* __restrict__ y,
                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
                                                       const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ coef,
-                                                      float* __restrict__ out, long M, int C, int rows_per_block) {
+                                                      typename std::conditional<MODE == 0, TY, TX>::type* __restrict__ out, long M, int C,
+                                                      int rows_per_block) {
   const BnGeom g = bn_geom(C);
   const int ql = threadIdx.x % g.QL, rl = threadIdx.x / g.QL;
   const int q = blockIdx.y * 64 + ql;
@@ -695,44 +700,105 @@ long kpf_bn_ws_floats(long M, int C) {
   return (long)S * 2 * C + 2 * C;
 }
 
+}  // extern "C"
+
+template <typename TX, typename TY>
+static int bn_forward_impl(const void* xv, const float* w, const float* b, void* yv, float* mean, float* invstd, float* running_mean,
+                           float* running_var, float momentum, float eps, int relu, float* ws, long ws_floats, long M, int C, void* stream) {
+  const TX* x = static_cast<const TX*>(xv);
+  TY* y = static_cast<TY*>(yv);
+  int rpc;
+  const int S = bn_chunks(M, C, &rpc);
+  KPF_REQUIRE(ws_floats >= (long)S * 2 * C + 2 * C, "kpf_bn_train_forward: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int cg = (C / 4 + 63) / 64;
+  hipLaunchKernelGGL((bn_partial_kernel<0, false, TX, TY>), dim3(S, cg), dim3(256), 0, st, x, (const TY*)nullptr, (const TY*)nullptr,
+                     (const float*)nullptr, ws, M, C, rpc);
+  hipLaunchKernelGGL(bn_stats_finalize_kernel<TX>, dim3((C + 63) / 64), dim3(256), 0, st, x, ws, S, M, C, mean, invstd, running_mean, running_var,
+                     momentum, eps);
+  if (relu)
+    hipLaunchKernelGGL((bn_elem_kernel<0, true, TX, TY>), dim3(S, cg), dim3(256), 0, st, x, (const TY*)nullptr, (const TY*)nullptr, mean, invstd, w, b,
+                       (const float*)nullptr, y, M, C, rpc);
+  else
+    hipLaunchKernelGGL((bn_elem_kernel<0, false, TX, TY>), dim3(S, cg), dim3(256), 0, st, x, (const TY*)nullptr, (const TY*)nullptr, mean, invstd, w, b,
+                       (const float*)nullptr, y, M, C, rpc);
+  return kpf_check_launch("kpf_bn_train_forward");
+}
+
+template <typename TX, typename TY>
+static int bn_backward_impl(const void* dyv, const void* xv, const void* yv, const float* mean, const float* invstd, const float* w, void* dxv,
+                            float* dw, float* db, int relu, float* ws, long ws_floats, long M, int C, void* stream) {
+  const TY* dy = static_cast<const TY*>(dyv);
+  const TY* y = static_cast<const TY*>(yv);
+  const TX* x = static_cast<const TX*>(xv);
+  TX* dx = static_cast<TX*>(dxv);
+  int rpc;
+  const int S = bn_chunks(M, C, &rpc);
+  KPF_REQUIRE(ws_floats >= (long)S * 2 * C + 2 * C, "kpf_bn_train_backward: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int cg = (C / 4 + 63) / 64;
+  float* coef = ws + (size_t)S * 2 * C;
+  if (relu) hipLaunchKernelGGL((bn_partial_kernel<1, true, TX, TY>), dim3(S, cg), dim3(256), 0, st, x, dy, y, mean, ws, M, C, rpc);
+  else hipLaunchKernelGGL((bn_partial_kernel<1, false, TX, TY>), dim3(S, cg), dim3(256), 0, st, x, dy, (const TY*)nullptr, mean, ws, M, C, rpc);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, ws, S, M, C, invstd, dw, db, coef);
+  if (relu)
+    hipLaunchKernelGGL((bn_elem_kernel<1, true, TX, TY>), dim3(S, cg), dim3(256), 0, st, x, dy, y, mean, invstd, w, (const float*)nullptr, coef, dx, M,
+                       C, rpc);
+  else
+    hipLaunchKernelGGL((bn_elem_kernel<1, false, TX, TY>), dim3(S, cg), dim3(256), 0, st, x, dy, (const TY*)nullptr, mean, invstd, w,
+                       (const float*)nullptr, coef, dx, M, C, rpc);
+  return kpf_check_launch("kpf_bn_train_backward");
+}
+
+// dispatch on (input-side dtype, output-side dtype): fp32 or ONE 16-bit type on either side
+#define KPF_BN_DISPATCH(FN, xdt, ydt, ...)                                                                             \
+  do {                                                                                                                 \
+    const int h = (xdt) != KPF_DT_F32 ? (xdt) : (ydt);                                                                 \
+    KPF_REQUIRE(((xdt) == KPF_DT_F32 || (xdt) == h) && ((ydt) == KPF_DT_F32 || (ydt) == h) && h >= 0 && h <= KPF_DT_F16, \
+                "kpf_bn_train: unsupported dtype pair (%d, %d)", (int)(xdt), (int)(ydt));                               \
+    if ((xdt) == KPF_DT_F32 && (ydt) == KPF_DT_F32) return FN<float, float>(__VA_ARGS__);                             \
+    if (h == KPF_DT_BF16) {                                                                                            \
+      if ((xdt) == KPF_DT_F32) return FN<float, bf16_t>(__VA_ARGS__);                                                 \
+      if ((ydt) == KPF_DT_F32) return FN<bf16_t, float>(__VA_ARGS__);                                                 \
+      return FN<bf16_t, bf16_t>(__VA_ARGS__);                                                                         \
+    }                                                                                                                  \
+    if ((xdt) == KPF_DT_F32) return FN<float, f16_t>(__VA_ARGS__);                                                    \
+    if ((ydt) == KPF_DT_F32) return FN<f16_t, float>(__VA_ARGS__);                                                    \
+    return FN<f16_t, f16_t>(__VA_ARGS__);                                                                             \
+  } while (0)
+
+extern "C" {
+
+int kpf_bn_train_forward(const void* x, int x_dtype, const float* w, const float* b, void* y, int y_dtype, float* mean, float* invstd,
+                         float* running_mean, float* running_var, float momentum, float eps, int relu, float* ws, long ws_floats, long M, int C,
+                         void* stream) {
+  KPF_REQUIRE(x && w && b && y && mean && invstd && ws, "kpf_bn_train_forward: null pointer");
+  KPF_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "kpf_bn_train_forward: bad shape (C %% 4 == 0)");
+  KPF_REQUIRE(kpf_aligned16(x) && kpf_aligned16(y) && kpf_aligned16(w) && kpf_aligned16(b) && kpf_aligned16(mean) && kpf_aligned16(invstd) &&
+                  kpf_aligned16(ws), "kpf_bn_train_forward: pointers must be 16-byte aligned");
+  KPF_BN_DISPATCH(bn_forward_impl, x_dtype, y_dtype, x, w, b, y, mean, invstd, running_mean, running_var, momentum, eps, relu, ws, ws_floats, M, C,
+                  stream);
+}
+
+int kpf_bn_train_backward(const void* dy, const void* x, const void* y, int x_dtype, int y_dtype, const float* mean, const float* invstd,
+                          const float* w, void* dx, float* dw, float* db, int relu, float* ws, long ws_floats, long M, int C, void* stream) {
+  KPF_REQUIRE(dy && x && mean && invstd && w && dx && ws && (!relu || y), "kpf_bn_train_backward: null pointer");
+  KPF_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "kpf_bn_train_backward: bad shape (C %% 4 == 0)");
+  KPF_REQUIRE(kpf_aligned16(dy) && kpf_aligned16(x) && kpf_aligned16(dx) && kpf_aligned16(ws) && (!relu || kpf_aligned16(y)),
+              "kpf_bn_train_backward: pointers must be 16-byte aligned");
+  KPF_BN_DISPATCH(bn_backward_impl, x_dtype, y_dtype, dy, x, y, mean, invstd, w, dx, dw, db, relu, ws, ws_floats, M, C, stream);
+}
+
 int kpf_bn_train_forward_f32(const float* x, const float* w, const float* b, float* y, float* mean, float* invstd, float* running_mean,
                              float* running_var, float momentum, float eps, int relu, float* ws, long ws_floats, long M, int C,
                              void* stream) {
-  KPF_REQUIRE(x && w && b && y && mean && invstd && ws, "kpf_bn_train_forward_f32: null pointer");
-  KPF_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "kpf_bn_train_forward_f32: bad shape (C %% 4 == 0)");
-  KPF_REQUIRE(kpf_aligned16(x) && kpf_aligned16(y) && kpf_aligned16(w) && kpf_aligned16(b) && kpf_aligned16(mean) && kpf_aligned16(invstd) &&
-                  kpf_aligned16(ws), "kpf_bn_train_forward_f32: pointers must be 16-byte aligned");
-  int rpc;
-  const int S = bn_chunks(M, C, &rpc);
-  KPF_REQUIRE(ws_floats >= (long)S * 2 * C + 2 * C, "kpf_bn_train_forward_f32: workspace too small");
-  hipStream_t st = (hipStream_t)stream;
-  const int cg = (C / 4 + 63) / 64;
-  hipLaunchKernelGGL((bn_partial_kernel<0, false>), dim3(S, cg), dim3(256), 0, st, x, nullptr, nullptr, nullptr, ws, M, C, rpc);
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, x, ws, S, M, C, mean, invstd, running_mean, running_var,
-                     momentum, eps);
-  if (relu) hipLaunchKernelGGL((bn_elem_kernel<0, true>), dim3(S, cg), dim3(256), 0, st, x, nullptr, nullptr, mean, invstd, w, b, nullptr, y, M, C, rpc);
-  else hipLaunchKernelGGL((bn_elem_kernel<0, false>), dim3(S, cg), dim3(256), 0, st, x, nullptr, nullptr, mean, invstd, w, b, nullptr, y, M, C, rpc);
-  return kpf_check_launch("kpf_bn_train_forward_f32");
+  return kpf_bn_train_forward(x, KPF_DT_F32, w, b, y, KPF_DT_F32, mean, invstd, running_mean, running_var, momentum, eps, relu, ws, ws_floats, M, C,
+                              stream);
 }
 
 int kpf_bn_train_backward_f32(const float* dy, const float* x, const float* y, const float* mean, const float* invstd, const float* w,
                               float* dx, float* dw, float* db, int relu, float* ws, long ws_floats, long M, int C, void* stream) {
-  KPF_REQUIRE(dy && x && mean && invstd && w && dx && ws && (!relu || y), "kpf_bn_train_backward_f32: null pointer");
-  KPF_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "kpf_bn_train_backward_f32: bad shape (C %% 4 == 0)");
-  KPF_REQUIRE(kpf_aligned16(dy) && kpf_aligned16(x) && kpf_aligned16(dx) && kpf_aligned16(ws) && (!relu || kpf_aligned16(y)),
-              "kpf_bn_train_backward_f32: pointers must be 16-byte aligned");
-  int rpc;
-  const int S = bn_chunks(M, C, &rpc);
-  KPF_REQUIRE(ws_floats >= (long)S * 2 * C + 2 * C, "kpf_bn_train_backward_f32: workspace too small");
-  hipStream_t st = (hipStream_t)stream;
-  const int cg = (C / 4 + 63) / 64;
-  float* coef = ws + (size_t)S * 2 * C;
-  if (relu) hipLaunchKernelGGL((bn_partial_kernel<1, true>), dim3(S, cg), dim3(256), 0, st, x, dy, y, mean, ws, M, C, rpc);
-  else hipLaunchKernelGGL((bn_partial_kernel<1, false>), dim3(S, cg), dim3(256), 0, st, x, dy, nullptr, mean, ws, M, C, rpc);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, ws, S, M, C, invstd, dw, db, coef);
-  if (relu) hipLaunchKernelGGL((bn_elem_kernel<1, true>), dim3(S, cg), dim3(256), 0, st, x, dy, y, mean, invstd, w, nullptr, coef, dx, M, C, rpc);
-  else hipLaunchKernelGGL((bn_elem_kernel<1, false>), dim3(S, cg), dim3(256), 0, st, x, dy, nullptr, mean, invstd, w, nullptr, coef, dx, M, C, rpc);
-  return kpf_check_launch("kpf_bn_train_backward_f32");
+  return kpf_bn_train_backward(dy, x, y, KPF_DT_F32, KPF_DT_F32, mean, invstd, w, dx, dw, db, relu, ws, ws_floats, M, C, stream);
 }
 
 }  // extern "C"

@@ -70,6 +70,8 @@ _SIGS = {
     "kpf_conv_num_tile_cfgs": [],
     "kpf_xattn_weight_floats": [],
     "kpf_conv2d_wgrad_f32": [_P] * 5 + [C.c_long] + [C.c_int] * 15 + [_P],
+    "kpf_bn_train_forward": [_P, C.c_int, _P, _P, _P, C.c_int, _P, _P, _P, _P, C.c_float, C.c_float, C.c_int, _P, C.c_long, C.c_long, C.c_int, _P],
+    "kpf_bn_train_backward": [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P, C.c_long, C.c_long, C.c_int, _P],
     "kpf_bn_train_forward_f32": [_P] * 8 + [C.c_float, C.c_float, C.c_int, _P, C.c_long, C.c_long, C.c_int, _P],
     "kpf_bn_train_backward_f32": [_P] * 9 + [C.c_int, _P, C.c_long, C.c_long, C.c_int, _P],
     "kpf_dwconv7_f32": [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],

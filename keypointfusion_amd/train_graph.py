@@ -113,13 +113,16 @@ class TrainGraph:
             return conv2d_nhwc(x.contiguous(), w, b, stride, pad, self.prec, w16)
         return F.conv2d(x.permute(0, 3, 1, 2), w, b, stride=stride, padding=pad).permute(0, 2, 3, 1).contiguous()
 
-    def bn_l(self, x, p, eps=1e-5, relu=False):
+    def bn_l(self, x, p, eps=1e-5, relu=False, out16=True):
         """BatchNorm2d (batch statistics) [+ ReLU] on NHWC: the HIP kernels for fp32 rows, F.batch_norm otherwise."""
         shp = x.shape
         rows = x.reshape(-1, shp[-1])
-        if shp[-1] % 4 == 0 and rows.is_cuda:  # (16-bit rows of the mixed-precision mode are normalised in fp32)
-            y = batchnorm_relu_rows(rows.float(), self.t[p + ".weight"], self.t[p + ".bias"], self.t[p + ".running_mean"], self.t[p + ".running_var"],
-                                    self.momentum, eps, relu)
+        if shp[-1] % 4 == 0 and rows.is_cuda:
+            # mixed precision: 16-bit rows are read as stored (fp32 statistics and arithmetic) and the output is written in the compute
+            # type the following convolution reads — no cast passes on either side
+            from .training import _TDT
+            y = batchnorm_relu_rows(rows, self.t[p + ".weight"], self.t[p + ".bias"], self.t[p + ".running_mean"], self.t[p + ".running_var"],
+                                    self.momentum, eps, relu, _TDT[self.prec] if (self.prec != "f32" and out16) else None)
             self.t[p + ".num_batches_tracked"].add_(1)
             return y.view(shp)
         y = self.bn(rows, p, eps).view(shp)
@@ -281,7 +284,7 @@ class TrainGraph:
         B, N, Cin = x.shape
         w16 = self.w16.get(p + ".0.weight")
         y = self.linear_rows(x.reshape(B * N, Cin), self.t[p + ".0.weight"][:, :, 0], self.t[p + ".0.bias"], w16[:, :, 0] if w16 is not None else None)
-        return self.bn_l(y.view(B, N, -1), p + ".1")
+        return self.bn_l(y.view(B, N, -1), p + ".1", out16=False)  # (summed with the other embeddings: kept fp32)
 
     @staticmethod
     def gather_interp(feat, idx, clos):
@@ -343,9 +346,9 @@ class TrainGraph:
                 return w16[:, :, 0, 0] if w16 is not None else None
 
             loc = self.bn_l(self.linear_rows((gx / r).reshape(-1, 3), q("conv_l0_blocks", ".weight")[:, :, 0, 0], q("conv_l0_blocks", ".bias"),
-                                             q16("conv_l0_blocks", ".weight")), p + ".bn_l0_blocks.%d" % i)
+                                             q16("conv_l0_blocks", ".weight")), p + ".bn_l0_blocks.%d" % i, out16=False)
             ft = self.bn_l(self.linear_rows(gf.reshape(-1, C), q("conv_f0_blocks", ".weight")[:, :, 0, 0], q("conv_f0_blocks", ".bias"),
-                                            q16("conv_f0_blocks", ".weight")), p + ".bn_f0_blocks.%d" % i)
+                                            q16("conv_f0_blocks", ".weight")), p + ".bn_f0_blocks.%d" % i, out16=False)
             g = F.relu(loc + ft)
             g = self.bn_l(self.linear_rows(g, q("conv_blocks", ".0.weight")[:, :, 0, 0], q("conv_blocks", ".0.bias"), q16("conv_blocks", ".0.weight")),
                           p + ".bn_blocks.%d.0" % i, relu=True)
@@ -354,7 +357,7 @@ class TrainGraph:
         cat = torch.cat(outs, -1).reshape(B * Jn, -1)  # rows of 512
         wf16 = self.w16.get(p + ".fusion.0.weight")
         y = self.linear_rows(cat, self.t[p + ".fusion.0.weight"][:, :, 0], self.t[p + ".fusion.0.bias"], wf16[:, :, 0] if wf16 is not None else None)
-        return self.bn_l(y, p + ".fusion.1", relu=True).view(B, Jn, -1)
+        return self.bn_l(y, p + ".fusion.1", relu=True, out16=False).view(B, Jn, -1)
 
     def bert_layer(self, p, h, heads=4):
         B, T, C = h.shape

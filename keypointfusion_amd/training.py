@@ -301,29 +301,35 @@ def dwconv7_nhwc(x, weight, bias):
     return DwConv7NHWC.apply(x, weight, bias)
 
 
+_KDT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}  # KPF_DT_* of include/kpf.h
+
+
 class BatchNormReLU(torch.autograd.Function):
-    """Train-mode BatchNorm (+ ReLU) on fp32 rows [M, C] (NHWC pixels): kpf_bn_train_forward_f32 / kpf_bn_train_backward_f32.
+    """Train-mode BatchNorm (+ ReLU) on rows [M, C] (NHWC pixels): kpf_bn_train_forward / kpf_bn_train_backward.  x may be fp32 or the
+    16-bit storage type of the mixed-precision step, y is written in `out_dtype` (default: x's); statistics and arithmetic are fp32.
     Same arithmetic as F.batch_norm(training=True): biased variance for normalisation, unbiased for the running estimate."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, out_dtype=None):
         from . import lib as L
         lib = L.load()
         x = x.contiguous()
         M, Cc = x.shape
-        assert x.dtype == torch.float32 and Cc % 4 == 0
-        y = torch.empty_like(x)
+        out_dtype = out_dtype or x.dtype
+        assert x.dtype in _KDT and out_dtype in _KDT and Cc % 4 == 0
+        y = torch.empty(M, Cc, device=x.device, dtype=out_dtype)
         stats = torch.empty(2, Cc, device=x.device, dtype=torch.float32)
         nws = lib.kpf_bn_ws_floats(M, Cc)
         ws = torch.empty(nws, device=x.device, dtype=torch.float32)
-        L.check(lib.kpf_bn_train_forward_f32(x.data_ptr(), weight.detach().contiguous().data_ptr(), bias.detach().contiguous().data_ptr(),
-                                             y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
-                                             running_mean.data_ptr() if running_mean is not None else None,
-                                             running_var.data_ptr() if running_var is not None else None, float(momentum), float(eps),
-                                             int(relu), ws.data_ptr(), nws, M, Cc, torch.cuda.current_stream().cuda_stream),
-                "kpf_bn_train_forward_f32")
+        L.check(lib.kpf_bn_train_forward(x.data_ptr(), _KDT[x.dtype], weight.detach().contiguous().data_ptr(), bias.detach().contiguous().data_ptr(),
+                                         y.data_ptr(), _KDT[out_dtype], stats[0].data_ptr(), stats[1].data_ptr(),
+                                         running_mean.data_ptr() if running_mean is not None else None,
+                                         running_var.data_ptr() if running_var is not None else None, float(momentum), float(eps),
+                                         int(relu), ws.data_ptr(), nws, M, Cc, torch.cuda.current_stream().cuda_stream),
+                "kpf_bn_train_forward")
         ctx.save_for_backward(x, y if relu else None, stats, weight)
         ctx.relu = bool(relu)
+        ctx.out_dtype = out_dtype
         return y
 
     @staticmethod
@@ -332,20 +338,20 @@ class BatchNormReLU(torch.autograd.Function):
         lib = L.load()
         x, y, stats, weight = ctx.saved_tensors
         M, Cc = x.shape
-        dy = dy.contiguous()
+        dy = dy.to(ctx.out_dtype).contiguous()
         dx = torch.empty_like(x)
         dwb = torch.empty(2, Cc, device=x.device, dtype=torch.float32)
         nws = lib.kpf_bn_ws_floats(M, Cc)
         ws = torch.empty(nws, device=x.device, dtype=torch.float32)
-        L.check(lib.kpf_bn_train_backward_f32(dy.data_ptr(), x.data_ptr(), y.data_ptr() if ctx.relu else None, stats[0].data_ptr(),
-                                              stats[1].data_ptr(), weight.detach().contiguous().data_ptr(), dx.data_ptr(), dwb[0].data_ptr(),
-                                              dwb[1].data_ptr(), int(ctx.relu), ws.data_ptr(), nws, M, Cc,
-                                              torch.cuda.current_stream().cuda_stream), "kpf_bn_train_backward_f32")
-        return dx, dwb[0], dwb[1], None, None, None, None, None
+        L.check(lib.kpf_bn_train_backward(dy.data_ptr(), x.data_ptr(), y.data_ptr() if ctx.relu else None, _KDT[x.dtype], _KDT[ctx.out_dtype],
+                                          stats[0].data_ptr(), stats[1].data_ptr(), weight.detach().contiguous().data_ptr(), dx.data_ptr(),
+                                          dwb[0].data_ptr(), dwb[1].data_ptr(), int(ctx.relu), ws.data_ptr(), nws, M, Cc,
+                                          torch.cuda.current_stream().cuda_stream), "kpf_bn_train_backward")
+        return dx, dwb[0], dwb[1], None, None, None, None, None, None
 
 
-def batchnorm_relu_rows(x, weight, bias, running_mean, running_var, momentum=0.1, eps=1e-5, relu=True):
-    return BatchNormReLU.apply(x, weight, bias, running_mean, running_var, momentum, eps, relu)
+def batchnorm_relu_rows(x, weight, bias, running_mean, running_var, momentum=0.1, eps=1e-5, relu=True, out_dtype=None):
+    return BatchNormReLU.apply(x, weight, bias, running_mean, running_var, momentum, eps, relu, out_dtype)
 
 
 class Conv2dNHWC(torch.autograd.Function):

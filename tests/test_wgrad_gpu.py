@@ -132,3 +132,35 @@ def test_conv_wgrad_16bit_operands_match_fp64_on_the_rounded_values(case, tdt):
     rw, rb = _ref(x.float(), dy.float(), (N, Cin, k, k), stride, pad)
     assert float((dw.cpu().double() - rw).abs().max()) <= 2e-5 * float(rw.abs().max())
     assert float((db.cpu().double() - rb).abs().max()) <= 2e-5 * max(float(rb.abs().max()), 1.0)
+
+
+@pytest.mark.parametrize("xdt,ydt", [(torch.bfloat16, torch.bfloat16), (torch.float32, torch.bfloat16), (torch.bfloat16, torch.float32),
+                                     (torch.float16, torch.float16), (torch.float32, torch.float16)])
+@pytest.mark.parametrize("M,Cc,relu", [(4096, 128, True), (777, 48, False)])
+def test_batchnorm_rows_mixed_storage_types(M, Cc, relu, xdt, ydt):
+    """16-bit input and / or output rows: statistics and arithmetic are fp32 on the stored values; only the written y / dx are
+    rounded to their storage type (2^-8 bf16, 2^-11 f16)."""
+    from keypointfusion_amd.training import batchnorm_relu_rows
+    g = torch.Generator().manual_seed(M + Cc + 5)
+    x = (torch.randn(M, Cc, generator=g) * 2.0 + 3.0 * torch.randn(Cc, generator=g)).to(xdt)
+    w, b = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g)
+    dy = torch.randn(M, Cc, generator=g).to(ydt)
+    rm, rv = torch.zeros(Cc), torch.ones(Cc)
+    xd, wd, bd = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    rmd, rvd = rm.cuda(), rv.cuda()
+    y = batchnorm_relu_rows(xd, wd, bd, rmd, rvd, 0.1, 1e-5, relu, ydt)
+    assert y.dtype == ydt
+    y.backward(dy.cuda())
+    assert xd.grad.dtype == xdt
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = F.batch_norm(xr, rm.double(), rv.double(), wr, br, True, 0.1, 1e-5)
+    if relu:
+        # the mask the kernel uses is the stored (rounded) output's sign; identical except where |y| rounds to zero
+        yr = F.relu(yr)
+    yr.backward(dy.double())
+    eps = {torch.float32: 3e-5, torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}
+    rel = lambda a, r: float((a.detach().cpu().double() - r.detach()).abs().max()) / max(float(r.detach().abs().max()), 1e-3)
+    assert rel(y, yr) <= 1.01 * eps[ydt] + 3e-5
+    assert rel(xd.grad, xr.grad) <= 1.01 * eps[xdt] + 3e-5
+    assert rel(wd.grad, wr.grad) <= 1e-4 and rel(bd.grad, br.grad) <= 1e-4
+    assert rel(rmd, rm.double() * 0.9 + 0.1 * x.double().mean(0)) <= 1e-5
