@@ -10,8 +10,12 @@
 //     (out-of-image / out-of-range chunks read a zero page).  The pixel range is split over gridDim.y workgroups per output tile
 //     (split-K); partial tiles go to a workspace and wgrad_reduce_kernel sums them in a fixed order (deterministic, no atomics)
 //     while permuting (ky,kx,c) -> the reference's OIHW weight layout.  db = sum_m dY[m][n] falls out of the dY fragments.
+//     With 16-bit dY / X (mixed-precision step) the same kernel stages through registers instead (16-byte loads of 8 values in
+//     flight under the previous tile's MFMAs, widened to fp32 on the way into LDS): kpf_conv2d_wgrad_h16.
 // (2) dwconv7_wgrad_kernel — depthwise 7x7: 49 x C outputs, HBM/L2-bound; thread = (4 channels, tap row ky), sliding 14-pixel
 //     window in registers, partial sums per (image, row band) chunk, same fixed-order reduce.
+// (3) bn_*_kernel — train-mode BatchNorm (+ ReLU) forward / backward on NHWC rows, fp32 or 16-bit storage on either side
+//     (kpf_bn_train_forward / kpf_bn_train_backward), at the end of this file.
 #include "kpf_common.h"
 
 #include <type_traits>
