@@ -1,5 +1,5 @@
 // Register-only MFMA throughput under sustained load (no memory traffic): what the matrix pipe delivers at the clock the chip
-// actually holds.  usage: ./mfma_peak   (prints TFLOP/s and the implied clock for bf16 16x16x32, f16 16x16x32 and f32 16x16x4)
+// actually holds.  usage: hipcc -O3 --offload-arch=gfx950 tools/mfma_issue_rate.hip -o tools/bin/mfma_issue_rate && tools/bin/mfma_issue_rate   (prints TFLOP/s and the implied clock for bf16 16x16x32, f16 16x16x32 and f32 16x16x4)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #pragma clang diagnostic ignored "-Wunused-value"
