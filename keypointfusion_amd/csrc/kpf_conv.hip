@@ -1039,7 +1039,10 @@ extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const flo
 #endif
 }
 
-#ifdef KPF_DBG_TIME
+extern "C" int kpf_conv_num_tile_cfgs(void) { return KPF_NUM_TILE_CFGS; }
+#endif  // KPF_CONV_H16
+
+#ifdef KPF_DBG_TIME  // (build ONE of the two translation units with it: the stamp buffer is a plain global)
 extern "C" int kpf_dbg_read(unsigned long long* host, int n) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(kpf_dbg_t), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
 }
@@ -1048,6 +1051,3 @@ extern "C" int kpf_dbg_clear(void) {
   return hipMemcpyToSymbol(HIP_SYMBOL(kpf_dbg_t), z, sizeof(z)) == hipSuccess ? 0 : -1;
 }
 #endif
-
-extern "C" int kpf_conv_num_tile_cfgs(void) { return KPF_NUM_TILE_CFGS; }
-#endif  // KPF_CONV_H16
