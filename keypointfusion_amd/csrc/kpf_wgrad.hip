@@ -583,34 +583,42 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const TX* __restrict__ 
   }
 }
 
-// sums of the S per-chunk partials ws[p][{0,1}][C] for channel c, in a fixed order: wave g adds p = g, g+4, ... in four chains
+// sums of the S per-chunk partials ws[p][{0,1}][C] for channel c, in a fixed order: wave g of the 16 adds p = g, g+16, ... in four
+// chains (S/64 dependent loads per thread: the finalize kernels are pure latency), then the 16 wave sums are combined through LDS
+constexpr int BN_FW = 16;  // waves per finalize workgroup
 __device__ __forceinline__ void bn_sum_partials(const float* __restrict__ ws, int S, int C, int c, float (*red)[2][64], float& r0, float& r1) {
   const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
   if (c < C) {
     int p = g;
-    for (; p + 12 < S; p += 16) {
+    for (; p + 3 * BN_FW < S; p += 4 * BN_FW) {
       const float* w0 = ws + (size_t)p * 2 * C + c;
       a0 += w0[0], b0 += w0[C];
-      a1 += w0[(size_t)8 * C], b1 += w0[(size_t)9 * C];
-      a2 += w0[(size_t)16 * C], b2 += w0[(size_t)17 * C];
-      a3 += w0[(size_t)24 * C], b3 += w0[(size_t)25 * C];
+      a1 += w0[(size_t)2 * BN_FW * C], b1 += w0[(size_t)(2 * BN_FW + 1) * C];
+      a2 += w0[(size_t)4 * BN_FW * C], b2 += w0[(size_t)(4 * BN_FW + 1) * C];
+      a3 += w0[(size_t)6 * BN_FW * C], b3 += w0[(size_t)(6 * BN_FW + 1) * C];
     }
-    for (; p < S; p += 4) a0 += ws[(size_t)p * 2 * C + c], b0 += ws[(size_t)p * 2 * C + C + c];
+    for (; p < S; p += BN_FW) a0 += ws[(size_t)p * 2 * C + c], b0 += ws[(size_t)p * 2 * C + C + c];
   }
   red[g][0][o] = (a0 + a1) + (a2 + a3);
   red[g][1][o] = (b0 + b1) + (b2 + b3);
   __syncthreads();
-  r0 = (red[0][0][o] + red[1][0][o]) + (red[2][0][o] + red[3][0][o]);
-  r1 = (red[0][1][o] + red[1][1][o]) + (red[2][1][o] + red[3][1][o]);
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < BN_FW; ++i) {
+    s0 += red[i][0][o];
+    s1 += red[i][1][o];
+  }
+  r0 = s0;
+  r1 = s1;
 }
 
 // forward finalize: batch mean / 1/sqrt(biased var + eps), running statistics (unbiased variance); 64 channels per workgroup
 template <typename TX>
-__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const TX* __restrict__ x, const float* __restrict__ ws, int S, long M, int C,
+__global__ __launch_bounds__(64 * BN_FW) void bn_stats_finalize_kernel(const TX* __restrict__ x, const float* __restrict__ ws, int S, long M, int C,
                                                                 float* __restrict__ mean, float* __restrict__ invstd,
                                                                 float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps) {
-  __shared__ float red[4][2][64];
+  __shared__ float red[BN_FW][2][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   float s, ss;
   bn_sum_partials(ws, S, C, c, red, s, ss);
@@ -626,9 +634,9 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const TX* __rest
 }
 
 // backward finalize: db = sum dz, dw = invstd * sum dz (x - mean); coef[c] = (sum dz / M, invstd^2 * sum dz (x-mean) / M)
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ ws, int S, long M, int C, const float* __restrict__ invstd,
+__global__ __launch_bounds__(64 * BN_FW) void bn_bwd_finalize_kernel(const float* __restrict__ ws, int S, long M, int C, const float* __restrict__ invstd,
                                                               float* __restrict__ dw, float* __restrict__ db, float* __restrict__ coef) {
-  __shared__ float red[4][2][64];
+  __shared__ float red[BN_FW][2][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   float s1, s2;
   bn_sum_partials(ws, S, C, c, red, s1, s2);
@@ -718,7 +726,7 @@ static int bn_forward_impl(const void* xv, const float* w, const float* b, void*
   const int cg = (C / 4 + 63) / 64;
   hipLaunchKernelGGL((bn_partial_kernel<0, false, TX, TY>), dim3(S, cg), dim3(256), 0, st, x, (const TY*)nullptr, (const TY*)nullptr,
                      (const float*)nullptr, ws, M, C, rpc);
-  hipLaunchKernelGGL(bn_stats_finalize_kernel<TX>, dim3((C + 63) / 64), dim3(256), 0, st, x, ws, S, M, C, mean, invstd, running_mean, running_var,
+  hipLaunchKernelGGL(bn_stats_finalize_kernel<TX>, dim3((C + 63) / 64), dim3(64 * BN_FW), 0, st, x, ws, S, M, C, mean, invstd, running_mean, running_var,
                      momentum, eps);
   if (relu)
     hipLaunchKernelGGL((bn_elem_kernel<0, true, TX, TY>), dim3(S, cg), dim3(256), 0, st, x, (const TY*)nullptr, (const TY*)nullptr, mean, invstd, w, b,
@@ -744,7 +752,7 @@ static int bn_backward_impl(const void* dyv, const void* xv, const void* yv, con
   float* coef = ws + (size_t)S * 2 * C;
   if (relu) hipLaunchKernelGGL((bn_partial_kernel<1, true, TX, TY>), dim3(S, cg), dim3(256), 0, st, x, dy, y, mean, ws, M, C, rpc);
   else hipLaunchKernelGGL((bn_partial_kernel<1, false, TX, TY>), dim3(S, cg), dim3(256), 0, st, x, dy, (const TY*)nullptr, mean, ws, M, C, rpc);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, ws, S, M, C, invstd, dw, db, coef);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64 * BN_FW), 0, st, ws, S, M, C, invstd, dw, db, coef);
   if (relu)
     hipLaunchKernelGGL((bn_elem_kernel<1, true, TX, TY>), dim3(S, cg), dim3(256), 0, st, x, dy, y, mean, invstd, w, (const float*)nullptr, coef, dx, M,
                        C, rpc);
