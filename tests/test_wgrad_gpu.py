@@ -164,3 +164,26 @@ def test_batchnorm_rows_mixed_storage_types(M, Cc, relu, xdt, ydt):
     assert rel(xd.grad, xr.grad) <= 1.01 * eps[xdt] + 3e-5
     assert rel(wd.grad, wr.grad) <= 1e-4 and rel(bd.grad, br.grad) <= 1e-4
     assert rel(rmd, rm.double() * 0.9 + 0.1 * x.double().mean(0)) <= 1e-5
+
+
+def test_conv_wgrad_full_size_properties():
+    """At the training benchmark's own sizes (B = 32, stage-1 / stage-3 ConvNeXt-T shapes and a 3x3 decoder convolution), where a CPU
+    reference would take minutes: the gradient is additive over a split of the batch, linear in dY, run-to-run identical, and its
+    bias part equals the pixel sum of dY."""
+    from keypointfusion_amd.training import conv_wgrad_hip
+    g = torch.Generator(device="cuda").manual_seed(11)
+    for (B, H, Cin, N, k) in ((32, 32, 96, 384, 1), (32, 8, 1536, 384, 1), (32, 32, 64, 64, 3)):
+        x = torch.randn(B, H, H, Cin, device="cuda", generator=g)
+        dy = torch.randn(B, H, H, N, device="cuda", generator=g)
+        args = ((N, Cin, k, k), 1, k // 2, True)
+        dw, db = conv_wgrad_hip(dy, x, *args)
+        dw2, db2 = conv_wgrad_hip(dy, x, *args)
+        assert torch.equal(dw, dw2) and torch.equal(db, db2)
+        da, ba = conv_wgrad_hip(dy[:16].contiguous(), x[:16].contiguous(), *args)
+        dc, bc = conv_wgrad_hip(dy[16:].contiguous(), x[16:].contiguous(), *args)
+        scale = float(dw.abs().max())
+        assert float((dw - (da + dc)).abs().max()) <= 2e-5 * scale
+        assert float((db - (ba + bc)).abs().max()) <= 2e-5 * float(db.abs().max())
+        d3, _ = conv_wgrad_hip(dy * 0.5, x, *args)  # exact: a power-of-two scale commutes with every rounding
+        assert torch.equal(d3, dw * 0.5)
+        assert float((db - dy.double().sum((0, 1, 2)).float()).abs().max()) <= 2e-5 * float(db.abs().max())
