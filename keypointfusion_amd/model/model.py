@@ -56,6 +56,21 @@ class KPFusion(nn.Module):
             ts = self.__dict__["_tensor_list"] = list(self.parameters()) + list(self.buffers())
         return sum(t._version for t in ts)
 
+    # -- copy.deepcopy / pickle: the per-device caches (packed weights, captured graphs, streams, locks) are rebuilt on demand ----
+    _CACHE_ATTRS = ("_plans", "_plan_lock", "_tensor_list", "_train_side_stream", "_w16_shadow")
+
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        for k in self._CACHE_ATTRS:
+            st.pop(k, None)
+        return st
+
+    def __setstate__(self, st):
+        super().__setstate__(st)
+        self.__dict__["_plans"] = {}
+        self.__dict__["_plan_lock"] = threading.Lock()
+        self.__dict__["_tensor_list"] = None
+
     def _apply(self, fn, *a, **k):  # .to() / .cuda() / .float(): tensors may be replaced
         self.__dict__["_tensor_list"] = None
         self._plans.clear()

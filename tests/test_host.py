@@ -108,3 +108,18 @@ def test_synthetic_batch_is_geometrically_consistent():
     assert float(np.abs(b["pcl"]).max()) < 1.0  # back-projected foreground pixels fall inside the cube
     fg = b["img"] < 0.99
     assert 0.35 < fg.mean() < 0.55 and float(b["img"][~fg].min()) == 1.0
+
+
+def test_modules_survive_deepcopy_and_pickle():
+    """The modules hold per-device caches (locks, packed weights, captured graphs): copy.deepcopy / pickle (EMA copies, torch.save of
+    a whole module) must drop them and keep parameters, buffers and settings."""
+    import copy
+    import io
+    import torch
+    from keypointfusion_amd.model.model import KPFusion
+    m = KPFusion("KPFusion-resnet-18", "", 21, "dexycb", "")
+    m.precision = "bf16"
+    for clone in (copy.deepcopy(m), torch.load(io.BytesIO((lambda b: (torch.save(m, b), b.getvalue())[1])(io.BytesIO())), weights_only=False)):
+        assert clone.precision == "bf16" and clone._plans == {} and clone._plan_lock is not m._plan_lock
+        sd, sc = m.state_dict(), clone.state_dict()
+        assert list(sd) == list(sc) and all(torch.equal(sd[k], sc[k]) for k in sd)
