@@ -1,5 +1,6 @@
-"""Per-shape table of the headline step's MFMA launches (GPU box): both backbones on one stream, HIP events per launch, 5 passes
-averaged; sorted by total time.  Shows where igemm_f32_kernel's step time goes and which shapes sit furthest below the roof."""
+"""Per-shape table of the backbones' MFMA launches (GPU box): both backbones on one stream, HIP events per launch, 5 passes
+averaged; sorted by total time.  Shows where the GEMM kernel's step time goes and which shapes sit furthest below the roof.
+usage: python tools/shape_table.py [B=64] [S=256] [precision=f32]"""
 import collections
 import os
 import sys
@@ -17,7 +18,9 @@ net = "KPFusion-convnext-tiny"
 m = KPFusion(net, "", 21, "dexycb", "")
 m.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state_dict(net, 0).items()}, strict=True)
 m = m.to(dev).eval()
-b = {k: torch.from_numpy(v).to(dev) for k, v in synthetic_batch(64, 256, seed=1).items()}
+B_, S_ = int(sys.argv[1]) if len(sys.argv) > 1 else 64, int(sys.argv[2]) if len(sys.argv) > 2 else 256
+m.precision = sys.argv[3] if len(sys.argv) > 3 else "f32"
+b = {k: torch.from_numpy(v).to(dev) for k, v in synthetic_batch(B_, S_, seed=1).items()}
 plan = m._plan(dev)
 plan.serial_streams = True
 acc = collections.OrderedDict()
