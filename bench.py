@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=8, help="images in the CPU-baseline sample")
     ap.add_argument("--gemm", default="f32", choices=["f32", "split"], help="GEMM arithmetic of the headline run (default f32 = IEEE fp32)")
     ap.add_argument("--no-split-record", action="store_true", help="skip the secondary KPF_GEMM=split timing")
+    ap.add_argument("--in-flight", type=int, default=2, help="full-model eval workloads: batches in flight (serving.PipelinedEval: independent "
+                    "hipGraph slots on their own streams, the latency-bound fusion head of one batch beside the backbones of the next); "
+                    "1 = one synchronous forward per step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -150,6 +153,7 @@ def main():
         img_size, flip = 128, 1
 
     graph_on = [not args.no_graph and not args.serial_streams]
+    pipe, pending = [None], []
 
     def step():
         if train:
@@ -173,18 +177,30 @@ def main():
                     model._plan(dev).backbones_graphed(batch["img"], batch["img_rgb"])
                 else:
                     model._plan(dev).backbones(batch["img"], batch["img_rgb"])
+            elif graph_on[0] and args.in_flight > 1:
+                if pipe[0] is None:
+                    from keypointfusion_amd.serving import PipelinedEval
+                    pipe[0] = PipelinedEval(model, depth=args.in_flight)
+                pending.append(pipe[0].submit(batch["img_rgb"], batch["img"], batch["pcl"], _Loader(), batch["center"], batch["M"], batch["cube"],
+                                              batch["cam_para"], 0.8))
+                if len(pending) > args.in_flight:  # a real loop consumes the oldest batch's outputs here
+                    pipe[0].collect(pending.pop(0))
             else:
                 model.use_graphs = graph_on[0]
                 model(batch["img_rgb"], batch["img"], batch["pcl"], _Loader(), batch["center"], batch["M"], batch["cube"],
                       batch["cam_para"], 0.8)
 
     def barrier():
+        while pending:  # (pipelined eval: every submitted batch is collected inside the timed region)
+            pipe[0].collect(pending.pop(0))
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
     def fresh_plan():
         model._plans.clear()
+        pipe[0] = None
+        del pending[:]
         if not train:
             model._plan(dev).serial_streams = bool(args.serial_streams)
 
@@ -265,6 +281,8 @@ def main():
             graph_on[0] = False
             fresh_plan()
     launch_mode = "hipGraph replay" if graph_on[0] else "eager"
+    if graph_on[0] and not train and not backbones_only and args.in_flight > 1:
+        launch_mode += ", %d batches in flight (independent graph slots / streams)" % args.in_flight
     dt, t_issue = timed(args.steps, args.warmup)
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)

@@ -755,12 +755,13 @@ class ModelPlan:
             graph.replay()
             return out
 
-    def forward_graphed(self, img_rgb, img, pcl, center, M, cube, cam, kernel, img_size, flip):
+    def forward_graphed(self, img_rgb, img, pcl, center, M, cube, cam, kernel, img_size, flip, slot=0):
         """Same as forward(), replayed from a captured hipGraph: at small batch the ~300 launches of one forward are host-bound
-        (3.9 ms at B=1 vs ~1 ms of device time), a graph replay costs one submission.  One graph per input shape; inputs are
-        copied into the graph's static buffers, outputs are returned as copies."""
+        (3.9 ms at B=1 vs ~1 ms of device time), a graph replay costs one submission.  One graph per (input shape, slot); inputs are
+        copied into the graph's static buffers, outputs are returned as copies.  Slots are independent instances (own static buffers
+        and workspace pool) so that several batches can be in flight on different streams (serving.PipelinedEval)."""
         ins = [t.detach().to(device=self.device, dtype=torch.float32).contiguous() for t in (img_rgb, img, pcl, center, M, cube, cam)]
-        key = tuple(tuple(t.shape) for t in ins) + (kernel, img_size, flip)
+        key = tuple(tuple(t.shape) for t in ins) + (kernel, img_size, flip, slot)
         with self._graph_lock:  # capture, copy-in, replay and copy-out are one critical section per plan (static buffers are shared)
             ent = self._graphs.get(key)
             if ent is None:

@@ -817,3 +817,32 @@ def test_two_devices_in_one_process_opt_in_per_device():
             outs.append([t.cpu() for t in m.to(dev).forward_backbones(b["img_rgb"].to(dev), b["img"].to(dev))])
     for o0, o1, r in zip(outs[0], outs[1], ref):
         assert rel_err(o0, r) < 2e-4 and rel_err(o1, r) < 2e-4
+
+
+def test_pipelined_eval_returns_what_forward_returns():
+    """serving.PipelinedEval: several batches in flight on independent graph slots / streams must give, batch by batch, exactly the
+    tensors the module's own forward gives (same kernels, same order of arithmetic)."""
+    from keypointfusion_amd.model.model import KPFusion
+    from keypointfusion_amd.serving import PipelinedEval
+    from keypointfusion_amd.weights import synthetic_batch, synthetic_state_dict
+    dev = _dev()
+    net = "KPFusion-resnet-18"
+    m = KPFusion(net, "", 21, "dexycb", "")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state_dict(net, 0).items()}, strict=True)
+    m = m.to(dev).eval()
+
+    class Loader:
+        img_size, flip = 128, 1
+
+    batches = [{k: torch.from_numpy(v).to(dev) for k, v in synthetic_batch(3, 128, seed=20 + i).items()} for i in range(5)]
+    args = lambda b: (b["img_rgb"], b["img"], b["pcl"], Loader(), b["center"], b["M"], b["cube"], b["cam_para"], 0.8)
+    with torch.no_grad():
+        ref = [m(*args(b)) for b in batches]
+    pe = PipelinedEval(m, depth=2)
+    tickets = [pe.submit(*args(b)) for b in batches]
+    for t, (rres, rsw, _) in zip(tickets, ref):
+        res, sws, _ = pe.collect(t)
+        assert all(torch.equal(a, b) for a, b in zip(res + sws, rres + rsw))
+    with pytest.raises(RuntimeError):
+        m.train()
+        pe.submit(*args(batches[0]))
