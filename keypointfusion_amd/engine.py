@@ -725,12 +725,12 @@ class ModelPlan:
                 t.record_stream(cur)
         return out_d, out_rgb
 
-    def backbones_graphed(self, img, img_rgb):
+    def backbones_graphed(self, img, img_rgb, slot=0):
         """backbones() replayed from a captured hipGraph (one graph per input shape; both streams are captured as parallel
         branches).  One submission per step instead of ~250 launches: the step no longer depends on the host keeping up.
         Inputs are copied into the graph's static buffers; the returned tensors are the graph's own and are overwritten by the
         next replay (the caller copies what it keeps)."""
-        key = ("bb", tuple(img.shape), tuple(img_rgb.shape))
+        key = ("bb", tuple(img.shape), tuple(img_rgb.shape), slot)  # (slots: independent instances for several batches in flight)
         with self._graph_lock:  # capture, copy-in and replay are one critical section per plan (static buffers are shared; the returned
                                 # tensors stay the graph's own: one consumer at a time, see the docstring)
             ent = self._graphs.get(key)
