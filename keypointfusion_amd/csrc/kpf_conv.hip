@@ -446,6 +446,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
           x1[j] = __builtin_bit_cast(f16x8, r1);
         }
       }
+      if constexpr (TM == 8) __builtin_amdgcn_s_setprio(1);  // (keeps hipcc from moving the cluster across the barriers: cdna_hip_programming T5)
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -458,6 +459,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[i], x1[j], acc[i][j], 0, 0, 0);
           }
         }
+      if constexpr (TM == 8) __builtin_amdgcn_s_setprio(0);
     } else if (SPLIT) {
       // lane group fg multiplies k = 8fg .. 8fg+7 of the tile: hi halves are logical chunk fg, lo halves chunk 4 + fg of the row
       const int ch = ((fg ^ rsw) << 2), cl = (((4 + fg) ^ rsw) << 2);
@@ -907,6 +909,9 @@ extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void
   if (a.M >= 4096 && a.N >= 256 && a.N % 128 == 0) best = 0;  // (the round model over-rates the narrow tiles at these sizes)
   const bool occ = !(fl & KPF_RES_ADD) && !pro_scale;
   if ((fl & KPF_RES_ADD) && fast1x1 && a.Kp * 2 >= 2048 && a.M >= 32768 && a.N >= 256 && a.N % 128 == 0) best = 20;
+  // 256 x 256 tiles, 8 waves of 128 x 64 (the geometry of cdna_hip_programming's 256^2 template, two-phase loop, s_setprio around the
+  // MFMA cluster): +24 % over case 20 on 65536 x 512 x 2048 (841 vs 679 TFLOP/s), 1049 vs 935 on 16384 x 1024 x 4096
+  if ((fl & KPF_RES_ADD) && fast1x1 && a.Kp * 2 >= 2048 && a.M >= 16384 && a.N >= 256 && a.N % 256 == 0) best = 26;
   static const int forced = []() { const char* e = getenv("KPF_FORCE_CFG16"); return e ? atoi(e) : -1; }();  // tuning aid only
   if (forced >= 0) best = forced;
   switch (best) {
@@ -919,6 +924,7 @@ extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void
     case 20: return launch_cfg_h16<4, 4, 4, 2, 3>(a, fast1x1, pointwise, dtype, st);  // 256 x 128, 3-stage LDS ring (144 KB): two K tiles of DMA in flight
     case 21: return launch_cfg_h16<4, 4, 2, 2, 3>(a, fast1x1, pointwise, dtype, st);  // 128 x 128, 3-stage ring (96 KB)
     case 22: return launch_cfg_h16<4, 4, 2, 2, 4>(a, fast1x1, pointwise, dtype, st);  // 128 x 128, 4-stage ring (128 KB)
+    case 26: return launch_cfg_h16<8, 4, 2, 4, 2>(a, fast1x1, pointwise, dtype, st);  // 256 x 256, 8 waves of 128 x 64 (2 per SIMD), 128 KB of LDS
     default: return launch_cfg_h16<2, 1, 1, 4, 2>(a, fast1x1, pointwise, dtype, st);  // 32 x 64
   }
 }

@@ -47,6 +47,9 @@ def rel(a, b):
     (1, 192, 16, 16, 96, 1, 1, 0, "pro"),      # BatchNorm + ReLU operand prologue
     (3, 768, 4, 4, 3072, 1, 1, 0, "gelu"),     # M = 48
     (2, 256, 16, 16, 512, 2, 2, 0, "patch"),   # 2x2 / s2 patchify (downsample)
+    (4, 1024, 64, 64, 256, 1, 1, 0, "res"),    # M = 16384, long K, N % 256 == 0: the 256 x 256-tile configuration (ConvNeXt-B pwconv2)
+    (5, 2048, 60, 60, 512, 1, 1, 0, "res"),    # ... with a ragged last M tile (M = 18000)
+    (16, 512, 32, 32, 2048, 1, 1, 0, "gelu"),  # M = 16384, ConvNeXt-B pwconv1 at stage 3
 ])
 def test_conv2d_h16_is_the_fp32_conv_of_the_rounded_operands(case, prec):
     from keypointfusion_amd import lib as L
