@@ -313,10 +313,31 @@ int kpf_bn_train_forward_f32(const float* x, const float* w, const float* b, flo
 int kpf_bn_train_backward_f32(const float* dy, const float* x, const float* y, const float* mean, const float* invstd, const float* w,
                               float* dx, float* dw, float* db, int relu, float* ws, long ws_floats, long M, int C, void* stream);
 
+/*
+ * Training: data-movement ops of the train-mode forward with a run-to-run deterministic backward (gather form, fixed
+ * summation order, no floating-point atomics) — what torch autograd computes with atomics for F.interpolate(bilinear)
+ * (model/resnetUnet.py:259), nn.MaxPool2d(3, 2, 1) (model/resnet.py:168), torch.gather on feature rows (model/model.py:297-306) and
+ * pointnet2's group_points (model/model.py:174).  NHWC, C % 4 == 0; `dtype` = KPF_DT_F32 / _BF16 / _F16 storage of the activations.
+ *   kpf_upsample2x_bwd    dy [B][2H][2W][C] -> dx [B][H][W][C]: the exact transpose of kpf_upsample2x_f32 / _h16.
+ *   kpf_maxpool3x3s2_fwd  y [B][OH][OW][C] and tap [B][OH][OW][C] (uint8: winning tap ky*3+kx, first maximum in scan order).
+ *   kpf_maxpool3x3s2_bwd  dx[b][iy][ix][c] = sum of dy over the <= 4 windows whose winning tap is (iy, ix).
+ *   kpf_row_gather_fwd_f32  out[b][r][:] = sum_{g<G} w[b][r*G+g] * src[b][idx[b][r*G+g]][:]   (src [B][P][C], idx int32 [B][R*G],
+ *                           w [B][R*G] or NULL for unit weights, out [B][R][C]).
+ *   kpf_row_gather_bwd_f32  dsrc[b][p][:] = sum over entries e ascending with idx[b][e] == p of w[b][e] * dout[b][e/G][:];
+ *                           R*G <= 8192 entries and P <= 2048 source rows per image.
+ */
+int kpf_upsample2x_bwd(const void* dy, void* dx, int dtype, int B, int H, int W, int C, void* stream);
+int kpf_maxpool3x3s2_fwd(const void* x, void* y, unsigned char* tap, int dtype, int B, int H, int W, int C, void* stream);
+int kpf_maxpool3x3s2_bwd(const void* dy, const unsigned char* tap, void* dx, int dtype, int B, int H, int W, int C, void* stream);
+int kpf_row_gather_fwd_f32(const float* src, const int* idx, const float* w, float* out, int B, int P, int R, int G, int C, void* stream);
+int kpf_row_gather_bwd_f32(const float* dout, const int* idx, const float* w, float* dsrc, int B, int P, int R, int G, int C, void* stream);
+
 int kpf_conv_num_tile_cfgs(void);
 
 const char* kpf_last_error(void);
-/* Library/ABI version, bumped when a signature changes. */
+/* Library/ABI version, bumped when a signature or the meaning of an argument changes (KPF_ABI_VERSION is what this header
+ * describes; the Python binding refuses a library that reports another). */
+#define KPF_ABI_VERSION 6
 int kpf_abi_version(void);
 
 #ifdef __cplusplus

@@ -11,4 +11,4 @@ void kpf_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* kpf_last_error(void) { return g_err; }
-extern "C" int kpf_abi_version(void) { return 5; }
+extern "C" int kpf_abi_version(void) { return KPF_ABI_VERSION; }

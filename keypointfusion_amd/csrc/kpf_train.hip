@@ -1,0 +1,320 @@
+// Deterministic backward (and the matching forward) kernels of the training step's data-movement ops:
+//
+//   kpf_upsample2x_bwd      gradient of the bilinear x2 of the UNet decoder (model/resnetUnet.py:259, align_corners False)
+//   kpf_maxpool3x3s2_fwd/bwd ResNet's 3x3 / s2 / pad 1 max-pool (model/resnet.py:168) with the argmax tap kept for the backward
+//   kpf_row_gather_fwd/bwd  weighted row gathers: the 4-nearest-pixel feature sampling of the points (model/model.py:297-306) and the
+//                           ball-query grouping of DESA (model/model.py:174 -> pointnet2 group_points)
+//
+// The library kernels behind torch's autograd for these ops accumulate with float atomics, so two runs of the same iteration
+// differ in the last bits and, through the integer decisions of the fusion head, occasionally in whole joints.  Everything here is
+// written in GATHER form: one thread (or wave) owns an output element and adds its contributions in a fixed order — no atomics on
+// floating-point data, run-to-run bit-identical.  All of it is HBM-bound data movement (read the gradient once, write once).
+#include "kpf_common.h"
+
+namespace {
+
+inline int grid_for(long total, int block = 256, int cap = 256 * 16) {
+  long g = (total + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// bilinear x2 backward.  Forward (kpf_elem.hip, upsample2x_kernel): f = (o + 0.5) / 2 - 0.5 clamped at 0, i0 = floor(f),
+// i1 = min(i0 + 1, n - 1), weights (1 - l, l).  A source row y receives from destination rows 2y-1 .. 2y+2; the weight is recomputed
+// with the forward's own expressions so that forward and backward are exact transposes of each other.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float up2_weight(int o, int i, int n) {
+  float f = (o + 0.5f) * 0.5f - 0.5f;
+  f = f < 0.f ? 0.f : f;
+  const int i0 = (int)f;
+  const int i1 = i0 + (i0 < n - 1 ? 1 : 0);
+  const float l = f - (float)i0;
+  return (i0 == i ? 1.f - l : 0.f) + (i1 == i ? l : 0.f);
+}
+
+template <typename TA>
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const TA* __restrict__ dy, TA* __restrict__ dx, int B, int H, int W, int C4) {
+  const long total = (long)B * H * W * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % C4);
+    long p = i / C4;
+    const int x = (int)(p % W);
+    p /= W;
+    const int y = (int)(p % H);
+    const int b = (int)(p / H);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dyo = -1; dyo <= 2; ++dyo) {
+      const int oy = 2 * y + dyo;
+      if ((unsigned)oy >= (unsigned)(2 * H)) continue;
+      const float wy = up2_weight(oy, y, H);
+      if (wy == 0.f) continue;
+#pragma unroll
+      for (int dxo = -1; dxo <= 2; ++dxo) {
+        const int ox = 2 * x + dxo;
+        if ((unsigned)ox >= (unsigned)(2 * W)) continue;
+        const float wx = up2_weight(ox, x, W);
+        if (wx == 0.f) continue;
+        const f32x4 g = kpf_ld4(dy + ((((long)b * 2 * H + oy) * 2 * W + ox) * C4 + q) * 4);
+        const float w = wy * wx;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += w * g[e];
+      }
+    }
+    kpf_st4(dx + i * 4, acc);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// max-pool 3x3 / s2 / pad 1 with the winning tap (0..8, scan order ky, kx; the FIRST maximum wins, NaN propagates like ATen's
+// `val > max || isnan(val)`) stored per output element; the backward lets every input element look at the <= 4 windows that cover it.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename TA>
+__global__ __launch_bounds__(256) void maxpool3x3s2_fwd_kernel(const TA* __restrict__ src, TA* __restrict__ dst, unsigned char* __restrict__ tap,
+                                                               int B, int H, int W, int OH, int OW, int C4) {
+  const long total = (long)B * OH * OW * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % C4);
+    long p = i / C4;
+    const int ox = (int)(p % OW);
+    p /= OW;
+    const int oy = (int)(p % OH);
+    const int b = (int)(p / OH);
+    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int t[4] = {-1, -1, -1, -1};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * 2 + ky - 1;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * 2 + kx - 1;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        const f32x4 v = kpf_ld4(src + ((((long)b * H + iy) * W + ix) * C4 + q) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (t[e] < 0 || v[e] > m[e] || v[e] != v[e]) {
+            m[e] = v[e];
+            t[e] = ky * 3 + kx;
+          }
+      }
+    }
+    kpf_st4(dst + i * 4, m);
+    *reinterpret_cast<uchar4*>(tap + i * 4) = make_uchar4((unsigned char)t[0], (unsigned char)t[1], (unsigned char)t[2], (unsigned char)t[3]);
+  }
+}
+
+template <typename TA>
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const TA* __restrict__ dy, const unsigned char* __restrict__ tap, TA* __restrict__ dx,
+                                                               int B, int H, int W, int OH, int OW, int C4) {
+  const long total = (long)B * H * W * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % C4);
+    long p = i / C4;
+    const int ix = (int)(p % W);
+    p /= W;
+    const int iy = (int)(p % H);
+    const int b = (int)(p / H);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // windows oy with 2*oy - 1 <= iy <= 2*oy + 1
+    const int oy_lo = iy >> 1, oy_hi = (iy + 1) >> 1;
+    const int ox_lo = ix >> 1, ox_hi = (ix + 1) >> 1;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      if (oy >= OH) continue;
+      const int ky = iy - 2 * oy + 1;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        if (ox >= OW) continue;
+        const int kx = ix - 2 * ox + 1;
+        const long o = (((long)b * OH + oy) * OW + ox) * C4 + q;
+        const uchar4 t = *reinterpret_cast<const uchar4*>(tap + o * 4);
+        const f32x4 g = kpf_ld4(dy + o * 4);
+        const int want = ky * 3 + kx;
+        if (t.x == want) acc[0] += g[0];
+        if (t.y == want) acc[1] += g[1];
+        if (t.z == want) acc[2] += g[2];
+        if (t.w == want) acc[3] += g[3];
+      }
+    }
+    kpf_st4(dx + i * 4, acc);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weighted row gather:  out[b][r][:] = sum_{g < G} w[b][r*G + g] * src[b][idx[b][r*G + g]][:]      (w == nullptr: weights 1)
+// One wave per output row; lanes over channel quads (C % 4 == 0), rows of C fp32.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_gather_fwd_kernel(const float* __restrict__ src, const int* __restrict__ idx, const float* __restrict__ w,
+                                                             float* __restrict__ out, int B, int P, int R, int G, int C4) {
+  const int lane = threadIdx.x & 63;
+  const long rows = (long)B * R;
+  for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * 4) {
+    const int b = (int)(r / R);
+    const int* ip = idx + r * G;
+    const float* wp = w ? w + r * G : nullptr;
+    for (int q = lane; q < C4; q += 64) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < G; ++g) {
+        const f32x4 v = kpf_ld4(src + ((long)b * P + ip[g]) * C4 * 4 + 4 * q);
+        const float ww = wp ? wp[g] : 1.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += ww * v[e];
+      }
+      kpf_st4(out + r * C4 * 4 + 4 * q, acc);
+    }
+  }
+}
+
+// backward:  dsrc[b][p][:] = sum over entries e (ascending) with idx[b][e] == p of w[b][e] * dout[b][e / G][:]
+// grid (S, B): every workgroup inverts the whole index list of its image in LDS (counting sort by source row; the per-row lists are
+// then sorted by entry number, so the summation order is the entry order whatever order the LDS atomics filled them in) and
+// accumulates the source rows p = s, s + S, ...  E <= KPF_GATHER_MAX_E entries, P <= KPF_GATHER_MAX_P rows per image.
+constexpr int GATHER_MAX_E = 8192, GATHER_MAX_P = 2048;
+
+__global__ __launch_bounds__(256) void row_gather_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ idx, const float* __restrict__ w,
+                                                             float* __restrict__ dsrc, int P, int E, int G, int C4) {
+  __shared__ unsigned short list[GATHER_MAX_E];
+  __shared__ int start[GATHER_MAX_P + 1];
+  __shared__ int cursor[GATHER_MAX_P];
+  __shared__ int wsum[4];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int* ib = idx + (long)b * E;
+  for (int p = tid; p < P; p += 256) cursor[p] = 0;
+  __syncthreads();
+  for (int e = tid; e < E; e += 256) atomicAdd(&cursor[ib[e]], 1);  // integer counts: order-independent
+  __syncthreads();
+  // exclusive scan of the counts: thread t owns the contiguous range [t*per, (t+1)*per)
+  const int per = (P + 255) / 256;
+  int local = 0;
+  for (int j = 0; j < per; ++j) {
+    const int p = tid * per + j;
+    if (p < P) local += cursor[p];
+  }
+  int incl = local;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o, 64);
+    if ((tid & 63) >= o) incl += v;
+  }
+  if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+  __syncthreads();
+  int base = incl - local;
+  for (int wv = 0; wv < (tid >> 6); ++wv) base += wsum[wv];
+  for (int j = 0; j < per; ++j) {
+    const int p = tid * per + j;
+    if (p < P) {
+      start[p] = base;
+      base += cursor[p];
+    }
+  }
+  if (tid == 255) start[P] = E;
+  __syncthreads();
+  for (int p = tid; p < P; p += 256) cursor[p] = start[p];
+  __syncthreads();
+  for (int e = tid; e < E; e += 256) list[atomicAdd(&cursor[ib[e]], 1)] = (unsigned short)e;
+  __syncthreads();
+  for (int p = tid; p < P; p += 256) {  // insertion sort of each (short) list: fixed summation order
+    const int s0 = start[p], s1 = start[p + 1];
+    for (int a = s0 + 1; a < s1; ++a) {
+      const unsigned short v = list[a];
+      int c = a - 1;
+      while (c >= s0 && list[c] > v) {
+        list[c + 1] = list[c];
+        --c;
+      }
+      list[c + 1] = v;
+    }
+  }
+  __syncthreads();
+  const int lane = tid & 63;
+  const float* wb = w ? w + (long)b * E : nullptr;
+  for (int p = blockIdx.x * 4 + (tid >> 6); p < P; p += gridDim.x * 4) {
+    const int s0 = start[p], s1 = start[p + 1];
+    for (int q = lane; q < C4; q += 64) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int a = s0; a < s1; ++a) {
+        const int e = list[a];
+        const f32x4 g = kpf_ld4(dout + (((long)b * E + e) / G) * C4 * 4 + 4 * q);
+        const float ww = wb ? wb[e] : 1.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] += ww * g[k];
+      }
+      kpf_st4(dsrc + ((long)b * P + p) * C4 * 4 + 4 * q, acc);
+    }
+  }
+}
+
+template <typename TA>
+int up_bwd(const void* dy, void* dx, int B, int H, int W, int C, void* stream) {
+  const long total = (long)B * H * W * (C / 4);
+  hipLaunchKernelGGL(upsample2x_bwd_kernel<TA>, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), static_cast<const TA*>(dy),
+                     static_cast<TA*>(dx), B, H, W, C / 4);
+  return kpf_check_launch("kpf_upsample2x_bwd");
+}
+template <typename TA>
+int mp_fwd(const void* x, void* y, unsigned char* tap, int B, int H, int W, int C, void* stream) {
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const long total = (long)B * OH * OW * (C / 4);
+  hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel<TA>, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), static_cast<const TA*>(x),
+                     static_cast<TA*>(y), tap, B, H, W, OH, OW, C / 4);
+  return kpf_check_launch("kpf_maxpool3x3s2_fwd");
+}
+template <typename TA>
+int mp_bwd(const void* dy, const unsigned char* tap, void* dx, int B, int H, int W, int C, void* stream) {
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const long total = (long)B * H * W * (C / 4);
+  hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel<TA>, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), static_cast<const TA*>(dy), tap,
+                     static_cast<TA*>(dx), B, H, W, OH, OW, C / 4);
+  return kpf_check_launch("kpf_maxpool3x3s2_bwd");
+}
+
+}  // namespace
+
+#define KPF_DISPATCH_DT(dtype, what, CALL)                                 \
+  do {                                                                     \
+    if ((dtype) == KPF_DT_F32) return CALL(float);                         \
+    if ((dtype) == KPF_DT_BF16) return CALL(bf16_t);                       \
+    if ((dtype) == KPF_DT_F16) return CALL(f16_t);                         \
+    kpf_set_error(what ": dtype must be KPF_DT_F32 / _BF16 / _F16");        \
+    return KPF_EINVAL;                                                     \
+  } while (0)
+
+extern "C" int kpf_upsample2x_bwd(const void* dy, void* dx, int dtype, int B, int H, int W, int C, void* stream) {
+  KPF_REQUIRE(dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "kpf_upsample2x_bwd: bad arguments");
+#define CALL(T) up_bwd<T>(dy, dx, B, H, W, C, stream)
+  KPF_DISPATCH_DT(dtype, "kpf_upsample2x_bwd", CALL);
+#undef CALL
+}
+
+extern "C" int kpf_maxpool3x3s2_fwd(const void* x, void* y, unsigned char* tap, int dtype, int B, int H, int W, int C, void* stream) {
+  KPF_REQUIRE(x && y && tap && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "kpf_maxpool3x3s2_fwd: bad arguments");
+#define CALL(T) mp_fwd<T>(x, y, tap, B, H, W, C, stream)
+  KPF_DISPATCH_DT(dtype, "kpf_maxpool3x3s2_fwd", CALL);
+#undef CALL
+}
+
+extern "C" int kpf_maxpool3x3s2_bwd(const void* dy, const unsigned char* tap, void* dx, int dtype, int B, int H, int W, int C, void* stream) {
+  KPF_REQUIRE(dy && dx && tap && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "kpf_maxpool3x3s2_bwd: bad arguments");
+#define CALL(T) mp_bwd<T>(dy, tap, dx, B, H, W, C, stream)
+  KPF_DISPATCH_DT(dtype, "kpf_maxpool3x3s2_bwd", CALL);
+#undef CALL
+}
+
+extern "C" int kpf_row_gather_fwd_f32(const float* src, const int* idx, const float* w, float* out, int B, int P, int R, int G, int C, void* stream) {
+  KPF_REQUIRE(src && idx && out && B > 0 && P > 0 && R > 0 && G > 0 && C > 0 && C % 4 == 0, "kpf_row_gather_fwd_f32: bad arguments");
+  const long rows = (long)B * R;
+  hipLaunchKernelGGL(row_gather_fwd_kernel, dim3(grid_for(rows, 4, 256 * 32)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, idx, w, out, B, P, R,
+                     G, C / 4);
+  return kpf_check_launch("kpf_row_gather_fwd_f32");
+}
+
+extern "C" int kpf_row_gather_bwd_f32(const float* dout, const int* idx, const float* w, float* dsrc, int B, int P, int R, int G, int C, void* stream) {
+  KPF_REQUIRE(dout && idx && dsrc && B > 0 && P > 0 && R > 0 && G > 0 && C > 0 && C % 4 == 0, "kpf_row_gather_bwd_f32: bad arguments");
+  const long E = (long)R * G;
+  KPF_REQUIRE(E <= GATHER_MAX_E && P <= GATHER_MAX_P, "kpf_row_gather_bwd_f32: at most %d gathered entries and %d source rows per image", GATHER_MAX_E,
+              GATHER_MAX_P);
+  // enough workgroups per image to fill the chip, each re-inverting the index list (E <= 8192 integers: cheap next to the rows)
+  int S = (1024 + B - 1) / B;
+  S = S < 1 ? 1 : (S > (P + 3) / 4 ? (P + 3) / 4 : S);
+  hipLaunchKernelGGL(row_gather_bwd_kernel, dim3(S, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dout, idx, w, dsrc, P, (int)E, G, C / 4);
+  return kpf_check_launch("kpf_row_gather_bwd_f32");
+}

@@ -288,16 +288,13 @@ def upsample2x(x, out):
 
 
 def crop_inverse(M):
-    """M^-1 [B][3][3] bit-identical to the reference's torch.linalg.inv on this host's CPU (dataloader/loader.py:781): on the device in
-    the host library's rounding order (inv3x3.host_mode), or — if the host's order is not one of the two known — by torch.linalg.inv
-    itself on a host copy of M (one device->host round trip per forward)."""
+    """M^-1 [B][3][3] on the device, in the rounding order of the reference's PyTorch-CPU forward on this host (torch.linalg.inv ->
+    MKL getrf / getrs, dataloader/loader.py:781; inv3x3.host_mode picks the fused or the separately rounded variant, a fixed one if
+    the host's library is neither).  No host round trip: capturable in a hipGraph on every host."""
     from .inv3x3 import host_mode
-    mode = host_mode()
     B = M.shape[0]
-    if mode < 0:
-        return torch.linalg.inv(M.detach().float().cpu().view(B, 1, 3, 3)).view(B, 3, 3).to(M.device)
     out = torch.empty(B, 3, 3, device=M.device, dtype=torch.float32)
-    L.check(L.load().kpf_inv3x3_f32(_ptr(M), _ptr(out), B, mode, _stream()), "kpf_inv3x3_f32")
+    L.check(L.load().kpf_inv3x3_f32(_ptr(M.detach().float().contiguous()), _ptr(out), B, host_mode(), _stream()), "kpf_inv3x3_f32")
     return out
 
 

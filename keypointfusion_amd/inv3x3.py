@@ -1,10 +1,12 @@
-"""The rounding order of the reference's 3x3 inverse, and which of its two variants this host's CPU library takes.
+"""The rounding order of the reference's 3x3 inverse in its PyTorch-CPU forward, and which of its two variants this host's CPU library takes.
 
-The reference inverts the crop matrix with `torch.linalg.inv` on the CPU (dataloader/loader.py:781).  Pixel positions — and through
-them the integer top-4 pixel indices and ball-query sets — depend on the last bit of that inverse, so the device computes M^-1 in the
-same operation order (csrc/kpf_geom.hip, inv3x3_lapack_order).  ATen's linalg_inv_ex -> linalg_solve_ex factors a contiguous row-major
-A as its transpose (no copy) and solves with trans = 'T':  getrf(A^T) = P L U;  U^T y = e_c;  L^T x = y;  rows of X un-permuted.
-MKL's 3x3 path was pinned bit for bit with tools/mkl_inv_probe.py on both host types this project runs on:
+The reference inverts the crop matrix with `torch.linalg.inv` on whatever device `uvd` lives on (dataloader/loader.py:780-781).  The
+parity target of this project is the reference's PyTorch-CPU forward (BASELINE.json north_star), where that call lands in MKL's
+getrf / getrs; run on a GPU the reference inverts in the GPU solver library instead, and no bit contract exists against that.  Pixel
+positions — and through them the integer top-4 pixel indices and ball-query sets — depend on the last bit of that inverse, so the device
+computes M^-1 in the CPU library's operation order (csrc/kpf_geom.hip, inv3x3_lapack_order).  ATen's linalg_inv_ex -> linalg_solve_ex
+factors a contiguous row-major A as its transpose (no copy) and solves with trans = 'T':  getrf(A^T) = P L U;  U^T y = e_c;  L^T x = y;
+rows of X un-permuted.  MKL's 3x3 path was pinned bit for bit with tools/mkl_inv_probe.py on both host types this project runs on:
 
   * partial-pivot LU of A^T, column 0 scaled by the RECIPROCAL of the pivot, column 1 by a true DIVISION;
   * U^T y = e_c with reciprocal diagonals;  x1 = y1 - l21*x2;  x0 = y0 - (l10*x1 + l20*x2);
@@ -12,8 +14,10 @@ MKL's 3x3 path was pinned bit for bit with tools/mkl_inv_probe.py on both host t
     y0 - fma(l10, x1, l20*x2); on its generic path (AMD EPYC) every product and sum is rounded separately.
 
 `host_mode()` finds out which of the two this host runs by comparing both restatements with torch.linalg.inv on a set of crop matrices
-(milliseconds, once per process): 1 = fused, 0 = separately rounded, -1 = neither (then the engine inverts on the host with
-torch.linalg.inv itself, at the price of a device->host copy per forward).
+(milliseconds, once per process): 1 = fused, 0 = separately rounded.  If the host's library follows neither (a non-MKL torch build) the
+device uses the separately rounded order (0) and says so once: the inverse is then a correctly pivoted fp32 LU inverse that may differ
+from that host's torch.linalg.inv in the last bit, and nothing ever leaves the device (no host copy, hipGraph-capturable).
+`KPF_INV3X3_MODE=0|1` pins the order whatever the host (bit-reproducible results across machines).
 """
 import threading
 
@@ -84,19 +88,35 @@ _lock = threading.Lock()
 
 
 def host_mode():
-    """1 / 0: this host's torch.linalg.inv follows the fused / separately rounded order; -1: neither (see module docstring)."""
+    """The rounding order the device uses for M^-1: 1 / 0 = this host's torch.linalg.inv follows the fused / separately rounded order;
+    0 with a one-time warning if it follows neither; KPF_INV3X3_MODE overrides (see module docstring).  Never negative."""
     global _mode
     if _mode is None:
         with _lock:
             if _mode is None:
-                import torch
-                rng = np.random.default_rng(12345)
-                Ms = np.concatenate([crop_matrices(48, seed=777), rng.normal(size=(16, 3, 3)).astype(f)])
-                ref = torch.linalg.inv(torch.from_numpy(Ms).view(-1, 1, 3, 3)).view(-1, 3, 3).numpy()
-                mode = -1
-                for cand in (1, 0):
-                    if all(np.array_equal(inv3x3(m, cand), r) for m, r in zip(Ms, ref)):
-                        mode = cand
-                        break
+                import os
+                env = os.environ.get("KPF_INV3X3_MODE")
+                if env is not None:
+                    assert env in ("0", "1"), "KPF_INV3X3_MODE must be 0 or 1"
+                    _mode = int(env)
+                    return _mode
+                mode = probe_host()
+                if mode < 0:
+                    import warnings
+                    warnings.warn("keypointfusion_amd: this host's torch.linalg.inv follows neither known 3x3 rounding order; the device uses the "
+                                  "separately rounded LU order (last-bit differences from this host's CPU inverse are possible)")
+                    mode = 0
                 _mode = mode
     return _mode
+
+
+def probe_host():
+    """1 / 0 / -1: which restatement (fused / separately rounded / neither) equals this host's torch.linalg.inv bit for bit."""
+    import torch
+    rng = np.random.default_rng(12345)
+    Ms = np.concatenate([crop_matrices(48, seed=777), rng.normal(size=(16, 3, 3)).astype(f)])
+    ref = torch.linalg.inv(torch.from_numpy(Ms).view(-1, 1, 3, 3)).view(-1, 3, 3).numpy()
+    for cand in (1, 0):
+        if all(np.array_equal(inv3x3(m, cand), r) for m, r in zip(Ms, ref)):
+            return cand
+    return -1

@@ -20,6 +20,7 @@ KPF_IN_SPLIT = 128
 KPF_OUT_SPLIT = 256
 KPF_W_SPLIT = 512
 KPF_DT_F32, KPF_DT_BF16, KPF_DT_F16 = 0, 1, 2
+ABI_VERSION = 6  # KPF_ABI_VERSION of include/kpf.h: load() refuses a library built from another revision of the interface
 
 
 class ConvDesc(C.Structure):
@@ -77,6 +78,11 @@ _SIGS = {
     "kpf_dwconv7_f32": [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
     "kpf_conv2d_wgrad_h16": [_P, _P, C.c_int] + [_P] * 3 + [C.c_long] + [C.c_int] * 15 + [_P],
     "kpf_dwconv7_wgrad_f32": [_P] * 5 + [C.c_long] + [C.c_int] * 4 + [_P],
+    "kpf_upsample2x_bwd": [_P, _P] + [C.c_int] * 5 + [_P],
+    "kpf_maxpool3x3s2_fwd": [_P, _P, _P] + [C.c_int] * 5 + [_P],
+    "kpf_maxpool3x3s2_bwd": [_P, _P, _P] + [C.c_int] * 5 + [_P],
+    "kpf_row_gather_fwd_f32": [_P] * 4 + [C.c_int] * 5 + [_P],
+    "kpf_row_gather_bwd_f32": [_P] * 4 + [C.c_int] * 5 + [_P],
 }
 _LONG_SIGS = {  # entries returning a long
     "kpf_cbam_workspace_floats": [C.c_int, C.c_int, C.c_int],
@@ -108,6 +114,9 @@ def load():
         fn.restype = C.c_int
     lib.kpf_last_error.restype = C.c_char_p
     lib.kpf_abi_version.restype = C.c_int
+    if lib.kpf_abi_version() != ABI_VERSION:
+        raise KpfError("libkpf_hip.so reports ABI version %d, this binding was written for %d: rebuild it (`make -C keypointfusion_amd/csrc`)"
+                       % (lib.kpf_abi_version(), ABI_VERSION))
     for name, args in _LONG_SIGS.items():
         fn = getattr(lib, name)
         fn.argtypes = args

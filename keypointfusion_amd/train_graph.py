@@ -26,7 +26,7 @@ import torch.nn.functional as F
 
 from . import lib as L
 from .engine import _ptr, _stream, crop_inverse
-from .training import batchnorm_relu_rows, conv2d_nhwc, dwconv7_nhwc, linear_hip
+from .training import batchnorm_relu_rows, conv2d_nhwc, dwconv7_nhwc, linear_hip, maxpool3x3s2_nhwc, row_gather, upsample2x_nhwc
 
 J = 21
 
@@ -104,7 +104,7 @@ class TrainGraph:
         b = self.t[p_b] if p_b is not None else None
         cin, k = w.shape[1], w.shape[2]
         patch = stride == k and pad == 0 and stride > 1
-        if (stride == 1 or patch) and w.shape[2] == w.shape[3]:
+        if w.shape[2] == w.shape[3]:  # every square kernel, any stride / padding: forward, data- and weight-gradient on the HIP kernels
             cpad = (-cin) % self.cmul
             w16 = self.w16.get(p_w)
             if cpad:  # the 3- / 1-channel images of the stems: zero channels on both operands (the weight's gradient is sliced back)
@@ -170,7 +170,7 @@ class TrainGraph:
     def resnet_features(self, p, x):
         x = self.conv_l(x, p + ".conv1.weight", None, stride=2, pad=3)
         x = self.bn_l(x, p + ".bn1", relu=True)
-        x = F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).contiguous()
+        x = maxpool3x3s2_nhwc(x)
         feats = []
         for li in range(1, 5):
             j = 0
@@ -216,8 +216,7 @@ class TrainGraph:
         x = img.permute(0, 2, 3, 1)
         c1, c2, c3, c4 = self.convnext_features(p + ".backbone", x) if convnext else self.resnet_features(p + ".backbone", x)
 
-        def up(t):  # bilinear x2 on the channels_last view of the same memory
-            return F.interpolate(t.permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+        up = upsample2x_nhwc  # bilinear x2 on NHWC rows (HIP forward + deterministic gather-form backward)
 
         c4_up = up(self.residual(p + ".up4.0", c4))
         c3_f = self.residual(p + ".fusion_layer4", torch.cat((c4_up, self.residual(p + ".skip_layer4", c3)), -1))
@@ -289,10 +288,13 @@ class TrainGraph:
     @staticmethod
     def gather_interp(feat, idx, clos):
         """feat [B, C, H, W] (channels_last memory: the row view below is free) -> [B, N, C]: the 4 nearest pixels' feature rows
-        weighted by clos (model/model.py:368-376).  Row gathers: the backward is an index_add of contiguous C-vectors."""
+        weighted by clos (model/model.py:368-376).  Feature maps with whole channel quads go through kpf_row_gather_fwd/_bwd_f32 (the
+        backward adds in a fixed order); the 21 weight-logit channels (no gradient: detached by the caller) use torch.gather."""
         B, C = feat.shape[:2]
         N, K = idx.shape[1:]
         rows = feat.permute(0, 2, 3, 1).reshape(B, -1, C)
+        if C % 4 == 0 and rows.is_cuda:
+            return row_gather(rows.float(), idx.int(), clos)
         g = torch.gather(rows, 1, idx.reshape(B, N * K, 1).expand(-1, -1, C)).view(B, N, K, C)
         return torch.sum(g * clos.unsqueeze(-1), 2)
 
@@ -337,7 +339,10 @@ class TrainGraph:
                 idx = given
             flat = idx.reshape(B, Jn * 64)
             gx = torch.gather(xyz, 1, flat.unsqueeze(-1).expand(-1, -1, 3)).view(B, Jn, 64, 3) - node_xyz.unsqueeze(2)
-            gf = torch.gather(feat, 1, flat.unsqueeze(-1).expand(-1, -1, C)).view(B, Jn, 64, C) - node_feat.unsqueeze(2)
+            if C % 4 == 0 and feat.is_cuda:  # group_points with a deterministic (gather-form) backward
+                gf = row_gather(feat.float(), flat.int().unsqueeze(-1)).view(B, Jn, 64, C) - node_feat.unsqueeze(2)
+            else:
+                gf = torch.gather(feat, 1, flat.unsqueeze(-1).expand(-1, -1, C)).view(B, Jn, 64, C) - node_feat.unsqueeze(2)
             # the three 1x1 Conv2d + BatchNorm2d of a scale (model/model.py:176-192) on rows [B*J*64, .]
             q = lambda name, k: self.t[p + ".%s.%d%s" % (name, i, k)]
 
@@ -427,7 +432,13 @@ class TrainGraph:
         ix = self.uvd2xyz(uvd_pix, center, Minv, cube, cam, img_size, flip)
         jx = self.uvd2xyz(r3d, center, Minv, cube, cam, img_size, flip)
         gam = (1 / (10 * torch.sum(torch.pow(ix.unsqueeze(1) - jx.unsqueeze(2), 2), dim=-1) + 1)).view(B, J, H, W)
-        sw = torch.sigmoid(self.conv(torch.cat([img_feat_rgb, hm], 1), p + ".atten_spatial.weight", p + ".atten_spatial.bias"))
+        # Conv2d(128 + 21 -> 21, k = 1) (model/model.py:262,336): rows of 149 channels, input and output channel counts zero-padded to
+        # whole quads so that forward, data- and weight-gradient all run on the HIP kernels (fixed summation order)
+        sw_in = torch.cat([img_feat_rgb.permute(0, 2, 3, 1).float(), hm.permute(0, 2, 3, 1)], -1).reshape(B * H * W, C + J)
+        w_sp, b_sp = self.t[p + ".atten_spatial.weight"][:, :, 0, 0], self.t[p + ".atten_spatial.bias"]
+        npad = (-J) % 4
+        sw = self.linear_rows(sw_in, F.pad(w_sp, (0, 0, 0, npad)), F.pad(b_sp, (0, npad)))[:, :J].float()
+        sw = torch.sigmoid(sw.view(B, H, W, J).permute(0, 3, 1, 2))
         wd = torch.sigmoid(self.t[p + ".weight_dis"])
         g = wd * gam + (1 - wd) * sw
         # model/model.py:386-388: fj[b,j,c] = sum_hw relu(g[b,j,hw] * f[b,c,hw]) * w[hw] + bias.  g >= 0 (a convex mix of a positive

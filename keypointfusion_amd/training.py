@@ -10,13 +10,19 @@ What exists here
   * `SmoothL1Loss`      model/loss.py:3-26 (quadratic below 0.01, linear above; mean over the last dim, then over the rest).
   * `kpfusion_loss`     the stage-typed schedule of train.py:211-261 (stage_type [1,1,2,3,2,3], coord 100, deconv 1, spatial 10, sigma 3/2).
   * `make_optimizer`    AdamW(lr 8e-4, wd 0.01) + StepLR(10, 0.1) (train.py:84-91,120; config.py).
-  * `Conv2dNHWC`        torch.autograd.Function: forward and data-gradient on kpf_conv2d_f32 (dgrad = the forward kernel on flipped /
-                        transposed weights; patchify convolutions: a GEMM + pixel un-shuffle), weight-gradient as a plain
-                        library GEMM (1x1) or torch.nn.grad.conv2d_weight (k > 1), bias-gradient a pixel reduction.
+  * `Conv2dNHWC`        torch.autograd.Function: forward and data-gradient on kpf_conv2d_f32 / _h16 (dgrad = the forward kernel on
+                        flipped / transposed weights, of the stride-dilated dY for strided convolutions; patchify convolutions: a
+                        GEMM + pixel un-shuffle), weight and bias gradient on kpf_conv2d_wgrad_f32 / _h16 (f32 MFMA, pixel index
+                        as the reduction dimension, fixed-order split reduction).
+  * `DwConv7NHWC`, `BatchNormReLU`, `Upsample2xNHWC`, `MaxPool3x3s2NHWC`, `RowGather`: depthwise 7x7, train-mode BatchNorm(+ReLU),
+                        bilinear x2, max-pool and the weighted row gathers with hand-written, run-to-run deterministic backward
+                        kernels (csrc/kpf_wgrad.hip, csrc/kpf_train.hip).
+  * `GraphedTrainStep`  the whole iteration replayed from captured hipGraphs (single process, or graph A -> bucket all-reduce over
+                        RCCL -> graph B for data parallelism).
 These are torch tensors in, torch tensors out (autograd and the optimiser are PyTorch-ROCm's: host-side plumbing, as BASELINE.json's
-north_star puts it); the loss arithmetic itself is a handful of elementwise ops and reductions over B x 105 x 32 x 32 maps.
-Not hand-written yet: weight-gradient GEMMs and the backward of the elementwise / normalisation / attention ops (torch autograd);
-reduced-precision training.  See DESIGN.md §8.
+north_star puts it).  Mixed precision ("bf16"): 16-bit GEMM operands, fp32 master weights / statistics / loss / weight gradients.
+Still on torch autograd: LayerNorm / GELU / softmax / the 21-token attention and the loss codec (elementwise ops and reductions
+over B x 105 x 32 x 32 maps).  See DESIGN.md §8.
 """
 import ctypes as C
 
@@ -126,21 +132,29 @@ def kpfusion_loss(results, spatial_weight, img, uvd_gt, xyz_gt, epoch=0, stage_t
             loss = loss + loss_coord
             parts["loss_coord_%d" % index] = loss_coord
     for index, sw in enumerate(spatial_weight):
-        if epoch <= SPATIAL_EPOCH[index] and sw is not None:
+        # `epoch` may be a device scalar (hipGraph replay: the host-side `if` of train.py:251 would be frozen at capture time);
+        # the spatial term is then multiplied by the gate (epoch <= SPATIAL_EPOCH) on the device
+        on_dev = torch.is_tensor(epoch)
+        if sw is not None and (on_dev or epoch <= SPATIAL_EPOCH[index]):
             hm_gt = joint2heatmap(uvd_gt[:, :, :2], FEATURE_PARA, feature_size, sigma=3 if index == 0 else 2)
             gt = hm_gt / hm_gt.max()
             ls = l1(sw, gt) * SPATIAL_WEIGHT[index]
+            if on_dev:
+                ls = ls * (epoch <= SPATIAL_EPOCH[index]).to(ls.dtype)
             loss = loss + ls
             parts["loss_spatial_%d" % index] = ls
     return loss, parts
 
 
 def make_optimizer(params, lr=8e-4, step_size=10, start_epoch=0, capturable=False):
-    """train.py:84-91,120 with config.py's defaults: AdamW(weight_decay 0.01) over all parameters + StepLR(step_size, 0.1)."""
-    # capturable (hipGraph replay): the fused multi-tensor kernel — the per-tensor path issues ~3 scalar-tensor divisions per parameter
+    """train.py:84-91,120 with config.py's defaults: AdamW(weight_decay 0.01) over all parameters + StepLR(step_size, 0.1).
+    capturable (hipGraph replay, GraphedTrainStep): the fused multi-tensor kernel with the learning rate held in a DEVICE scalar —
+    a Python float would be baked into the captured kernel arguments and StepLR's decay would never reach the replays; the scheduler
+    updates the tensor in place, so the next replay steps with the new rate."""
     params = list(params)
     fused = bool(capturable and params and params[0].is_cuda)
-    opt = torch.optim.AdamW([{"params": params, "initial_lr": lr}], lr=lr, weight_decay=0.01, capturable=capturable,
+    lr0 = torch.tensor(float(lr), device=params[0].device, dtype=torch.float32) if fused else lr
+    opt = torch.optim.AdamW([{"params": params, "initial_lr": lr}], lr=lr0, weight_decay=0.01, capturable=capturable,
                             **({"fused": True} if fused else {}))
     return opt, torch.optim.lr_scheduler.StepLR(opt, step_size=step_size, gamma=0.1, last_epoch=start_epoch)
 
@@ -354,6 +368,115 @@ def batchnorm_relu_rows(x, weight, bias, running_mean, running_var, momentum=0.1
     return BatchNormReLU.apply(x, weight, bias, running_mean, running_var, momentum, eps, relu, out_dtype)
 
 
+class Upsample2xNHWC(torch.autograd.Function):
+    """Bilinear x2 (align_corners False: nn.Upsample of model/resnetUnet.py:259) on NHWC [B,H,W,C], fp32 or 16-bit storage.
+    forward kpf_upsample2x_f32 / _h16, backward kpf_upsample2x_bwd (gather form: run-to-run deterministic, unlike the library's
+    atomic scatter)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        from . import lib as L
+        lib = L.load()
+        x = x.contiguous()
+        B, H, W, Cc = x.shape
+        assert x.dtype in _KDT and Cc % 4 == 0
+        y = torch.empty(B, 2 * H, 2 * W, Cc, device=x.device, dtype=x.dtype)
+        st = torch.cuda.current_stream().cuda_stream
+        if x.dtype == torch.float32:
+            L.check(lib.kpf_upsample2x_f32(x.data_ptr(), y.data_ptr(), B, H, W, Cc, Cc, 0, st), "kpf_upsample2x_f32")
+        else:
+            L.check(lib.kpf_upsample2x_h16(x.data_ptr(), y.data_ptr(), B, H, W, Cc, Cc, 0, _KDT[x.dtype], st), "kpf_upsample2x_h16")
+        ctx.shape = (B, H, W, Cc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import lib as L
+        B, H, W, Cc = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty(B, H, W, Cc, device=dy.device, dtype=dy.dtype)
+        L.check(L.load().kpf_upsample2x_bwd(dy.data_ptr(), dx.data_ptr(), _KDT[dy.dtype], B, H, W, Cc, torch.cuda.current_stream().cuda_stream),
+                "kpf_upsample2x_bwd")
+        return dx
+
+
+class MaxPool3x3s2NHWC(torch.autograd.Function):
+    """nn.MaxPool2d(3, 2, 1) (model/resnet.py:168) on NHWC; the winning tap of every window is kept (one byte per element) and the
+    backward is a gather over the <= 4 windows covering an input element: deterministic, first maximum wins like ATen."""
+
+    @staticmethod
+    def forward(ctx, x):
+        from . import lib as L
+        x = x.contiguous()
+        B, H, W, Cc = x.shape
+        assert x.dtype in _KDT and Cc % 4 == 0
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty(B, OH, OW, Cc, device=x.device, dtype=x.dtype)
+        tap = torch.empty(B, OH, OW, Cc, device=x.device, dtype=torch.uint8)
+        L.check(L.load().kpf_maxpool3x3s2_fwd(x.data_ptr(), y.data_ptr(), tap.data_ptr(), _KDT[x.dtype], B, H, W, Cc,
+                                              torch.cuda.current_stream().cuda_stream), "kpf_maxpool3x3s2_fwd")
+        ctx.save_for_backward(tap)
+        ctx.shape = (B, H, W, Cc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import lib as L
+        (tap,) = ctx.saved_tensors
+        B, H, W, Cc = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty(B, H, W, Cc, device=dy.device, dtype=dy.dtype)
+        L.check(L.load().kpf_maxpool3x3s2_bwd(dy.data_ptr(), tap.data_ptr(), dx.data_ptr(), _KDT[dy.dtype], B, H, W, Cc,
+                                              torch.cuda.current_stream().cuda_stream), "kpf_maxpool3x3s2_bwd")
+        return dx
+
+
+class RowGather(torch.autograd.Function):
+    """out[b, r] = sum_{g < G} w[b, r, g] * src[b, idx[b, r, g]] over feature rows (fp32): the 4-nearest-pixel sampling of the point
+    features (model/model.py:297-306; w = closeness) and DESA's ball-query grouping (model/model.py:174; G = 1, no weights).
+    src [B, P, C], idx int32 [B, R, G], w [B, R, G] or None.  Gradient w.r.t. src only (indices / closeness carry none in the
+    reference either): kpf_row_gather_bwd_f32 inverts the index list per image and adds in entry order — no atomics."""
+
+    @staticmethod
+    def forward(ctx, src, idx, w):
+        from . import lib as L
+        src = src.contiguous()
+        idx = idx.contiguous()
+        B, P, Cc = src.shape
+        _, R, G = idx.shape
+        assert src.dtype == torch.float32 and idx.dtype == torch.int32 and Cc % 4 == 0
+        w = w.detach().float().contiguous() if w is not None else None
+        out = torch.empty(B, R, Cc, device=src.device, dtype=torch.float32)
+        L.check(L.load().kpf_row_gather_fwd_f32(src.data_ptr(), idx.data_ptr(), w.data_ptr() if w is not None else None, out.data_ptr(), B, P, R, G, Cc,
+                                                torch.cuda.current_stream().cuda_stream), "kpf_row_gather_fwd_f32")
+        ctx.save_for_backward(idx, w)
+        ctx.shape = (B, P, R, G, Cc)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import lib as L
+        idx, w = ctx.saved_tensors
+        B, P, R, G, Cc = ctx.shape
+        dout = dout.float().contiguous()
+        dsrc = torch.empty(B, P, Cc, device=dout.device, dtype=torch.float32)
+        L.check(L.load().kpf_row_gather_bwd_f32(dout.data_ptr(), idx.data_ptr(), w.data_ptr() if w is not None else None, dsrc.data_ptr(), B, P, R, G, Cc,
+                                                torch.cuda.current_stream().cuda_stream), "kpf_row_gather_bwd_f32")
+        return dsrc, None, None
+
+
+def upsample2x_nhwc(x):
+    return Upsample2xNHWC.apply(x)
+
+
+def maxpool3x3s2_nhwc(x):
+    return MaxPool3x3s2NHWC.apply(x)
+
+
+def row_gather(src, idx, w=None):
+    return RowGather.apply(src, idx, w)
+
+
 class Conv2dNHWC(torch.autograd.Function):
     """y = conv2d(x, w) + b on NHWC activations [B, H, W, Cin] (fp32, HIP device), weight in the reference's OIHW layout.
     forward : kpf_conv2d_f32 (f32-input MFMA implicit GEMM).
@@ -407,8 +530,6 @@ class Conv2dNHWC(torch.autograd.Function):
                 if dx.shape[1] != H or dx.shape[2] != W:  # rows / columns the strided convolution never read
                     dx = F.pad(dx, (0, 0, 0, W - dx.shape[2], 0, H - dx.shape[1]))
             else:
-                if stride != 1:
-                    raise NotImplementedError("Conv2dNHWC.backward: data gradient of strided non-patchify convolutions is not built yet")
                 npad = (N + cmul - 1) // cmul * cmul
                 wd = wsrc
                 if npad != N:  # the kernel needs whole channel groups: zero-pad dY's channel axis (and the weight's output axis)
@@ -416,6 +537,14 @@ class Conv2dNHWC(torch.autograd.Function):
                     wd = F.pad(wd, (0, 0, 0, 0, 0, 0, 0, npad - N))
                 else:
                     dy_in = dy
+                if stride != 1:
+                    # strided (non-patchify) convolution — ResNet's 3x3/s2 and 1x1/s2 (model/resnet.py:52-55,190-194): the data gradient
+                    # is the stride-1 transposed convolution of dY dilated by the stride (zeros between its pixels), laid out so that
+                    # the symmetric padding KH-1-pad yields exactly H x W rows (rows the strided convolution never read get zeros)
+                    hz, wz = H - KH + 1 + 2 * pad, W - KW + 1 + 2 * pad
+                    dil = dy_in.new_zeros(B, hz, wz, npad)
+                    dil[:, :(OH - 1) * stride + 1:stride, :(OW - 1) * stride + 1:stride] = dy_in
+                    dy_in = dil
                 if KH > 1 or KW > 1:
                     wd = wd.flip(2, 3)  # taps mirrored
                 rows = wd.permute(1, 2, 3, 0).reshape(Cin, KH * KW * npad)  # [c][(ky,kx,n)]: one transposing copy
@@ -453,10 +582,12 @@ def linear_hip(x, weight, bias=None, prec="f32", w16=None):
 class GraphedTrainStep:
     """One training iteration (train-mode forward, loss, backward, optimiser step) replayed from captured hipGraphs.
 
-    The eager iteration is host-bound (several thousand small launches: ~127 ms at B = 32 for ~40 ms of device work); nothing in it
-    depends on the host — the integer decisions come from device kernels, BatchNorm statistics and AdamW state are device tensors
-    (`capturable=True`) — so after three eager warm-up iterations on a side stream the iteration is captured once and replayed with
-    the batch copied into static buffers.
+    The eager iteration is host-bound (several thousand small launches: ~127 ms at B = 32 for ~40 ms of device work); the integer
+    decisions come from device kernels, BatchNorm statistics and AdamW state are device tensors (`capturable=True`), so after the
+    eager warm-up iterations on a side stream the iteration is captured once and replayed with the batch copied into static buffers.
+    What the host still decides is frozen at capture time unless it is handed over as device data: build the optimiser with
+    `make_optimizer(..., capturable=True)` (learning rate in a device scalar that StepLR updates in place) and pass the epoch of the
+    loss schedule as a 0-d device tensor inside the batch (`kpfusion_loss(epoch=batch["epoch"])` gates the spatial terms on the device).
 
     One process (dist_mod None): a single graph [zero grads, forward, loss, backward, optimiser step].
     Data parallel (dist_mod = torch.distributed, one process per GPU): graph A [zero grads, forward, loss, backward, pack the
@@ -469,6 +600,8 @@ class GraphedTrainStep:
     def __init__(self, model, optimizer, loss_fn, batch, warmup=3, dist_mod=None, params=None, bucket_mb=64.0, group=None):
         self.model, self.opt, self.loss_fn = model, optimizer, loss_fn
         self.dist, self.group = dist_mod, group
+        from .graphs import assert_replay_is_sound
+        assert_replay_is_sound(next(iter(batch.values())).device)  # (once per process: refuses a runtime that mis-replays reductions)
         self.static = {k: v.detach().clone() for k, v in batch.items()}
         self.params = [p for p in (params if params is not None else model.parameters()) if p.requires_grad]
         cur = torch.cuda.current_stream()
@@ -484,6 +617,15 @@ class GraphedTrainStep:
         self.opt.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
         self.graph_b = None
+        import gc
+        gc.collect()  # nothing may be finalised while the stream is capturing: an older CUDAGraph (or any tensor whose deleter touches
+        gc.disable()  # the device) collected in the middle of a capture aborts the process
+        try:
+            self._capture(bucket_mb, group)
+        finally:
+            gc.enable()
+
+    def _capture(self, bucket_mb, group):
         if self.dist is None:
             with torch.cuda.graph(self.graph):
                 self.loss = self._forward_backward()

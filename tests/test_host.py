@@ -26,8 +26,17 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, name), "libkpf_hip.so does not export %s" % name
     assert set(L.EXPORTS) == declared, (sorted(declared - set(L.EXPORTS)), sorted(set(L.EXPORTS) - declared))
     l = L.load()
-    assert l.kpf_abi_version() >= 1
+    m = re.search(r"#define KPF_ABI_VERSION (\d+)", hdr)
+    assert m and l.kpf_abi_version() == int(m.group(1)) == L.ABI_VERSION  # header, library and binding describe the same interface
     assert l.kpf_tr_encoder_weight_floats(128) == 128 * 128 + 128 + 21 * 128 + 4 * (128 * 384 + 384 + 128 * 128 + 128 * 6 + 128 * 16 + 16 + 16 * 128) + 128 * 3 + 3 + 128 * 3 + 3
+
+
+def test_library_of_another_abi_version_is_refused(monkeypatch):
+    """A stale libkpf_hip.so (entry points whose arguments changed meaning under the same names) must not load silently."""
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "ABI_VERSION", L.ABI_VERSION + 1)
+    with pytest.raises(L.KpfError, match="ABI version"):
+        L.load()
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -11,8 +11,9 @@ from keypointfusion_amd import inv3x3 as I
 def test_restated_order_equals_torch_linalg_inv_bitwise():
     """The host library takes one of the two pinned rounding orders (fused on Intel, separately rounded on AMD), and the restatement
     of that order reproduces torch.linalg.inv bit for bit — crop matrices, general matrices (every pivot pattern), synthetic crops."""
-    mode = I.host_mode()
-    assert mode in (0, 1), "this host's torch.linalg.inv follows neither pinned order (the engine then inverts on the host)"
+    mode = I.probe_host()
+    assert mode in (0, 1), "this host's torch.linalg.inv follows neither pinned order (the device then uses a fixed one: no bit parity here)"
+    assert I.host_mode() == mode
     Ms = I.crop_matrices(1500, seed=3)
     ref = torch.linalg.inv(torch.from_numpy(Ms).view(-1, 1, 3, 3)).view(-1, 3, 3).numpy()
     for m, r in zip(Ms, ref):
@@ -44,6 +45,40 @@ def test_hip_inverse_equals_torch_linalg_inv_bitwise():
         L.check(L.load().kpf_inv3x3_f32(E._ptr(M[:64].to(dev)), E._ptr(out), 64, fused, E._stream()), "kpf_inv3x3_f32")
         want = np.stack([I.inv3x3(m, fused) for m in Ms[:64]])
         assert np.array_equal(out.cpu().numpy(), want)
+
+
+def test_unknown_host_library_selects_a_fixed_device_order_and_warns(monkeypatch):
+    """Third branch: a host whose torch.linalg.inv follows neither pinned order.  The device must then use a fixed order
+    and say so — never a host copy of M per forward (that would abort a hipGraph capture)."""
+    monkeypatch.setattr(I, "_mode", None)
+    monkeypatch.setattr(I, "probe_host", lambda: -1)
+    monkeypatch.delenv("KPF_INV3X3_MODE", raising=False)
+    with pytest.warns(UserWarning, match="neither known 3x3 rounding order"):
+        assert I.host_mode() == 0
+    monkeypatch.setattr(I, "_mode", None)
+    monkeypatch.setenv("KPF_INV3X3_MODE", "1")
+    assert I.host_mode() == 1  # pinned by the environment whatever the host
+
+
+@pytest.mark.gpu
+def test_crop_inverse_is_capturable_on_an_unknown_host(monkeypatch):
+    """The fallback order runs on the device like the pinned ones: crop_inverse inside a hipGraph capture, results = the scalar
+    restatement of that order."""
+    from keypointfusion_amd import engine as E
+    monkeypatch.setattr(I, "_mode", None)
+    monkeypatch.setattr(I, "probe_host", lambda: -1)
+    monkeypatch.delenv("KPF_INV3X3_MODE", raising=False)
+    dev = torch.device("cuda:0")
+    Ms = I.crop_matrices(32, seed=8)
+    M = torch.from_numpy(Ms).to(dev)
+    with pytest.warns(UserWarning):
+        E.crop_inverse(M)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = E.crop_inverse(M)
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), np.stack([I.inv3x3(m, 0) for m in Ms]))
 
 
 @pytest.mark.gpu

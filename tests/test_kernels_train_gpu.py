@@ -30,6 +30,10 @@ CASES = [  # B, H, W, Cin, N, k, stride, pad
     (1, 1, 21, 128, 512, 1, 1, 0),     # a Linear over 21 tokens
     (5, 9, 9, 4, 4, 1, 1, 0),
     (2, 16, 16, 144, 72, 1, 1, 0),
+    (2, 16, 16, 64, 128, 3, 2, 1),     # ResNet 3x3 / s2
+    (2, 16, 16, 64, 128, 1, 2, 0),     # ResNet 1x1 / s2 downsample
+    (2, 32, 32, 4, 64, 7, 2, 3),       # ResNet stem
+    (2, 15, 17, 8, 16, 3, 2, 1),
 ]
 
 
@@ -187,3 +191,128 @@ def test_conv_wgrad_full_size_properties():
         d3, _ = conv_wgrad_hip(dy * 0.5, x, *args)  # exact: a power-of-two scale commutes with every rounding
         assert torch.equal(d3, dw * 0.5)
         assert float((db - dy.double().sum((0, 1, 2)).float()).abs().max()) <= 2e-5 * float(db.abs().max())
+
+
+@pytest.mark.parametrize("case", [
+    # B, H, W, Cin, N, k, stride, pad
+    (2, 16, 16, 96, 384, 1, 1, 0),
+    (2, 12, 10, 64, 48, 3, 1, 1),
+    (1, 16, 16, 48, 105, 1, 1, 0),    # N not a multiple of 4 (heads): the data gradient pads dY's channels
+    (2, 16, 16, 96, 192, 2, 2, 0),    # 2x2 / s2 patchify (ConvNeXt downsample)
+    (2, 32, 32, 4, 96, 4, 4, 0),      # 4x4 / s4 stem
+    (2, 16, 16, 64, 128, 3, 2, 1),    # ResNet stage entry: 3x3 / s2 (data gradient = transposed convolution of the dilated dY)
+    (2, 16, 16, 64, 128, 1, 2, 0),    # ResNet downsample: 1x1 / s2
+    (2, 32, 32, 4, 64, 7, 2, 3),      # ResNet stem 7x7 / s2 on the channel-padded image
+    (2, 15, 17, 8, 16, 3, 2, 1),      # odd sizes
+    (1, 10, 9, 8, 8, 3, 2, 0),        # rows / columns the strided window never reaches
+])
+def test_conv2d_nhwc_autograd_matches_torch(case):
+    from keypointfusion_amd.training import conv2d_nhwc
+    B, H, W, Cin, N, k, stride, pad = case
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(N, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(N, generator=g) * 0.1
+    xr, wr, br = (t.clone().double().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv2d(xr.permute(0, 3, 1, 2), wr, br, stride=stride, padding=pad).permute(0, 2, 3, 1)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy.double())
+    xd, wd, bd = (t.clone().to(dev).requires_grad_(True) for t in (x, w, b))
+    y = conv2d_nhwc(xd, wd, bd, stride, pad)
+    y.backward(gy.to(dev))
+    rel = lambda a, r: float((a.detach().cpu().double() - r).abs().max() / (r.abs().max() + 1e-12))
+    assert rel(y, yr.detach()) < 1e-5
+    assert rel(xd.grad, xr.grad) < 1e-5, "data gradient"
+    assert rel(wd.grad, wr.grad) < 1e-4, "weight gradient"
+    assert rel(bd.grad, br.grad) < 1e-5
+
+
+def test_linear_hip_autograd_and_sgd_step_reduce_the_loss():
+    from keypointfusion_amd.training import SmoothL1Loss, linear_hip, make_optimizer
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    w = torch.nn.Parameter((torch.randn(32, 64) / 8).to(dev))
+    b = torch.nn.Parameter(torch.zeros(32, device=dev))
+    x, y = torch.randn(40, 64, device=dev), torch.randn(40, 32, device=dev)
+    opt, _ = make_optimizer([w, b], lr=1e-2)
+    losses = []
+    for _ in range(5):
+        opt.zero_grad()
+        loss = SmoothL1Loss()(linear_hip(x, w, b), y)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 4, 4, 8), (3, 5, 7, 12), (2, 16, 16, 128), (1, 1, 1, 4), (2, 1, 6, 4)])
+def test_upsample2x_forward_backward_match_torch(shape, dt):
+    """kpf_upsample2x_* / kpf_upsample2x_bwd vs F.interpolate(scale_factor=2, bilinear, align_corners=False) in float64; the backward is a
+    gather (no atomics): two runs return the same bits."""
+    from keypointfusion_amd.training import upsample2x_nhwc
+    B, H, W, Cc = shape
+    g = torch.Generator().manual_seed(H * 31 + W)
+    x = torch.randn(B, H, W, Cc, generator=g).to(dt)
+    dy = torch.randn(B, 2 * H, 2 * W, Cc, generator=g).to(dt)
+    xd = x.cuda().requires_grad_(True)
+    y = upsample2x_nhwc(xd)
+    y.backward(dy.cuda())
+    xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = F.interpolate(xr, scale_factor=2, mode="bilinear", align_corners=False)
+    yr.backward(dy.double().permute(0, 3, 1, 2))
+    eps = 2e-6 if dt == torch.float32 else 2.0 ** -8
+    assert float((y.detach().cpu().double() - yr.detach().permute(0, 2, 3, 1)).abs().max()) <= eps * max(float(yr.abs().max()), 1.0)
+    assert float((xd.grad.cpu().double() - xr.grad.permute(0, 2, 3, 1)).abs().max()) <= eps * max(float(xr.grad.abs().max()), 1.0)
+    g1 = xd.grad.clone()
+    xd.grad = None
+    upsample2x_nhwc(xd).backward(dy.cuda())
+    assert torch.equal(g1, xd.grad)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 8, 8), (2, 7, 9, 12), (1, 64, 64, 64), (2, 1, 1, 4), (1, 2, 5, 4)])
+def test_maxpool3x3s2_forward_backward_match_torch_including_ties(shape):
+    """kpf_maxpool3x3s2_fwd/_bwd vs F.max_pool2d(3, 2, 1): values drawn from a small integer set so that most windows hold ties — the
+    gradient must go to the FIRST maximum in scan order, as ATen routes it."""
+    from keypointfusion_amd.training import maxpool3x3s2_nhwc
+    B, H, W, Cc = shape
+    g = torch.Generator().manual_seed(H + W * 7)
+    x = torch.randint(0, 3, (B, H, W, Cc), generator=g).float()
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    dy = torch.randn(B, OH, OW, Cc, generator=g)
+    xd = x.cuda().requires_grad_(True)
+    y = maxpool3x3s2_nhwc(xd)
+    y.backward(dy.cuda())
+    xr = x.clone().permute(0, 3, 1, 2).contiguous().requires_grad_(True)  # CPU fp32: ATen's reference tie-breaking
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    yr.backward(dy.permute(0, 3, 1, 2).contiguous())
+    assert torch.equal(y.detach().cpu(), yr.detach().permute(0, 2, 3, 1))
+    assert float((xd.grad.cpu() - xr.grad.permute(0, 2, 3, 1)).abs().max()) <= 1e-6 * float(xr.grad.abs().max())
+
+
+@pytest.mark.parametrize("case", [(3, 1024, 1024, 4, 128, True), (2, 1045, 21 * 64, 1, 128, False), (2, 37, 50, 3, 8, True), (1, 5, 4096, 2, 4, True)])
+def test_row_gather_forward_backward_match_torch(case):
+    """kpf_row_gather_fwd/_bwd_f32 vs torch.gather + weighted sum in float64 (heavily repeated indices included); the backward adds
+    in entry order without atomics: bit-identical across runs."""
+    from keypointfusion_amd.training import row_gather
+    B, P, R, G, Cc, weighted = case
+    g = torch.Generator().manual_seed(P + R)
+    src = torch.randn(B, P, Cc, generator=g)
+    idx = torch.randint(0, P, (B, R, G), generator=g)
+    idx[0, : R // 2] = idx[0, 0, 0]  # one source row gathered by many entries
+    w = torch.rand(B, R, G, generator=g) if weighted else None
+    dout = torch.randn(B, R, Cc, generator=g)
+    sd = src.cuda().requires_grad_(True)
+    out = row_gather(sd, idx.int().cuda(), w.cuda() if weighted else None)
+    out.backward(dout.cuda())
+    sr = src.double().requires_grad_(True)
+    gr = torch.gather(sr, 1, idx.reshape(B, R * G, 1).expand(-1, -1, Cc)).view(B, R, G, Cc)
+    outr = (gr * (w.double().unsqueeze(-1) if weighted else 1.0)).sum(2)
+    outr.backward(dout.double())
+    assert float((out.detach().cpu().double() - outr.detach()).abs().max()) <= 2e-6 * float(outr.abs().max())
+    assert float((sd.grad.cpu().double() - sr.grad).abs().max()) <= 2e-5 * float(sr.grad.abs().max())
+    g1 = sd.grad.clone()
+    sd.grad = None
+    row_gather(sd, idx.int().cuda(), w.cuda() if weighted else None).backward(dout.cuda())
+    assert torch.equal(g1, sd.grad)
