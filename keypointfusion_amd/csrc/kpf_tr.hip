@@ -5,9 +5,10 @@
 //                         (model/transfusion_head.py:137-173, 635-708)
 // One workgroup (512 threads) owns one sample: all activations (21 x 128 tokens, Q/K/V, scores) live in LDS for the
 // whole stack, weights stream from L2 (they are shared by every workgroup), nothing round-trips through HBM between
-// layers and the whole stack is ONE launch instead of ~30.  The work is tiny (12 MFLOP per sample) and latency-bound, so
-// it runs on the vector ALUs: each thread owns one output channel for a quarter of the tokens, weights are stored transposed
-// [K][N] so a wave reads 256 contiguous bytes per k and the token values are LDS broadcasts.
+// layers and the whole stack is ONE launch instead of ~30.  The work is tiny (12 MFLOP per sample) and latency-bound on the
+// weight stream: every Linear runs on the f32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 fmaf chains, tokens = rows padded to
+// two 16-row tiles) with its weights, stored transposed [K][N], streamed chunk by chunk through a two-slot LDS ring by LDS-DMA
+// (below); softmax / LayerNorm / GELU are wave-shuffle reductions on the vector ALUs.
 #include "kpf_common.h"
 
 namespace {

@@ -63,7 +63,9 @@ class GradBucketReducer:
     last gradient has been accumulated (post-accumulate-grad hooks), so communication overlaps the rest of backward; `finish()` waits
     for the outstanding reductions, divides by the world size and scatters the averaged values back into `.grad`.  Parameters that
     received no gradient in a step (the dead modules of the reference: decoder layers 0-2, BERT embeddings / poolers, ConvNeXt heads —
-    20-23 % of the parameters) travel as zeros in their bucket slot; to keep them out of the payload altogether pass
+    20-23 % of the parameters) travel as zeros in their bucket slot and KEEP `.grad = None` afterwards when no rank
+    produced a gradient for them (one flag per parameter rides at the end of the bucket), so the optimiser skips them exactly as it
+    does behind the reference's DataParallel (no weight decay on dead parameters); to keep them out of the payload altogether pass
     `params` = the live ones only (`live_parameters`).  BatchNorm statistics stay per replica, like DataParallel's (no SyncBN)."""
 
     def __init__(self, params, dist_mod, bucket_mb=64.0, group=None):
@@ -82,10 +84,11 @@ class GradBucketReducer:
             cur_bytes += nb
         if cur:
             self._close(cur)
-        self._slot = {}
+        self._slot, self._index = {}, {}
         for bi, (_, slots) in enumerate(self.buckets):
-            for p, off, n in slots:
+            for i, (p, off, n) in enumerate(slots):
                 self._slot[id(p)] = (bi, off, n)
+                self._index[id(p)] = i
         self._pending = [0] * len(self.buckets)
         self._work = [None] * len(self.buckets)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
@@ -93,7 +96,7 @@ class GradBucketReducer:
 
     def _close(self, plist):
         total = sum(p.numel() for p in plist)
-        flat = torch.zeros(total, dtype=plist[0].dtype, device=plist[0].device)
+        flat = torch.zeros(total + len(plist), dtype=plist[0].dtype, device=plist[0].device)  # values, then one "seen" flag per parameter
         slots, off = [], 0
         for p in plist:
             slots.append((p, off, p.numel()))
@@ -109,12 +112,13 @@ class GradBucketReducer:
         self._seen = set()
 
     def _on_grad(self, p):
-        if id(p) in self._seen:  # a parameter used twice accumulates twice: the slot is refreshed at finish()
+        if id(p) in self._seen:  # (the hook runs once per backward, after all uses of the parameter have been accumulated)
             return
         self._seen.add(id(p))
         bi, off, n = self._slot[id(p)]
-        flat = self.buckets[bi][0]
+        flat, slots = self.buckets[bi]
         flat[off:off + n].copy_(p.grad.reshape(-1))
+        flat[flat.numel() - len(slots) + self._index[id(p)]] = 1.0
         self._pending[bi] -= 1
         if self._pending[bi] == 0:
             self._launch(bi)
@@ -132,10 +136,11 @@ class GradBucketReducer:
         for bi, (flat, slots) in enumerate(self.buckets):
             if self._work[bi] is not None:
                 self._work[bi].wait()
+            seen = flat[flat.numel() - len(slots):].tolist() if self.world > 1 else None  # > 0: some rank produced a gradient
             if self.world > 1:
                 flat.div_(self.world)
-            for p, off, n in slots:
-                if p.grad is not None or self.world > 1:
+            for i, (p, off, n) in enumerate(slots):
+                if p.grad is not None or (self.world > 1 and seen[i] > 0):
                     g = flat[off:off + n].view_as(p)
                     if p.grad is None:
                         p.grad = g.clone()
@@ -143,7 +148,7 @@ class GradBucketReducer:
                         p.grad.copy_(g)
 
     def payload_bytes(self):
-        return sum(f.numel() * f.element_size() for f, _ in self.buckets)
+        return sum((f.numel() - len(sl)) * f.element_size() for f, sl in self.buckets)  # (gradient values; + 4 B of flag per parameter)
 
     def remove(self):
         for h in self._hooks:

@@ -132,3 +132,15 @@ def test_modules_survive_deepcopy_and_pickle():
         assert clone.precision == "bf16" and clone._plans == {} and clone._plan_lock is not m._plan_lock
         sd, sc = m.state_dict(), clone.state_dict()
         assert list(sd) == list(sc) and all(torch.equal(sd[k], sc[k]) for k in sd)
+
+
+def test_dropin_model_package_resolves_the_reference_import_lines(tmp_path):
+    """dropin/model replaces the reference's model/ directory: with it first on the path, the reference's own import statements
+    (train.py:5-6 `from model.model import KPFusion`; cbam / hourglass / mano_head likewise) give the HIP classes."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r);"
+            "from model.model import KPFusion; from model.cbam import CBAM; from model.hourglass import PoseNet; from model.mano_head import mano_regHead;"
+            "import keypointfusion_amd.model.model as M; assert KPFusion is M.KPFusion; print('ok')") % (ROOT, os.path.join(ROOT, "dropin"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path))
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr[-2000:]
