@@ -383,50 +383,45 @@ def test_graphed_train_step_with_bucketed_allreduce_equals_the_single_graph():
     assert not bad, "%d gradient tensors differ between the single-graph and the bucketed form" % len(bad)
 
 
-def _graphed_dp_worker(rank, world, port, q):
+def _graphed_dp_worker(rank, world, port, q, ref_path):
     """One of two processes sharing cuda:0: GraphedTrainStep in its data-parallel form over the gloo backend (RCCL cannot host two
     ranks on one device; gloo reduces CUDA tensors through host memory) on this rank's shard of the batch."""
-    import torch.distributed as dist
-    from keypointfusion_amd.parallel import live_parameters, shard_batch
-    dev = torch.device("cuda:0")
-    torch.cuda.set_device(dev)
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    net = "KPFusion-resnet-18"
-    sd, batch, loss_fn = _train_fixture(net, 4, dev)
-    shard = {k: v.contiguous() for k, v in shard_batch(batch, rank, world).items()}
-    torch.manual_seed(0)
-    m = _fresh(net, sd).to(dev).train()
-    m.train_dropout = 0.0
-    live = live_parameters(m)
-    names = [n for n, p in m.named_parameters() if any(p is x for x in live)]
-    opt = torch.optim.SGD(live, lr=0.0)
-    step = T.GraphedTrainStep(m, opt, loss_fn, shard, warmup=1, dist_mod=dist, params=live, bucket_mb=16.0)
-    losses = [float(step(shard)) for _ in range(2)]
-    torch.cuda.synchronize()
-    grads = {n: p.grad.detach().cpu() for n, p in zip(names, live) if p.grad is not None}
-    q.put((rank, losses, len(step.buckets), grads))
-    dist.barrier()
-    dist.destroy_process_group()
+    try:
+        import torch.distributed as dist
+        from keypointfusion_amd.parallel import live_parameters, shard_batch
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+        net = "KPFusion-resnet-18"
+        sd, batch, loss_fn = _train_fixture(net, 4, dev)
+        shard = {k: v.contiguous() for k, v in shard_batch(batch, rank, world).items()}
+        torch.manual_seed(0)
+        m = _fresh(net, sd).to(dev).train()
+        m.train_dropout = 0.0
+        live = live_parameters(m)
+        names = [n for n, p in m.named_parameters() if any(p is x for x in live)]
+        opt = torch.optim.SGD(live, lr=0.0)
+        step = T.GraphedTrainStep(m, opt, loss_fn, shard, warmup=1, dist_mod=dist, params=live, bucket_mb=16.0)
+        losses = [float(step(shard)) for _ in range(2)]
+        torch.cuda.synchronize()
+        ref = torch.load(ref_path)
+        got = {n: p.grad.detach().cpu() for n, p in zip(names, live) if p.grad is not None}
+        bad = [n for n in ref["mean"] if n not in got or not torch.equal(got[n], ref["mean"][n])]
+        q.put((rank, None, losses, len(step.buckets), len(got), len(bad), bad[:4]))
+        dist.destroy_process_group()
+    except Exception as e:  # report instead of dying silently: the parent would only see a queue time-out
+        import traceback
+        q.put((rank, traceback.format_exc()[-3000:], None, 0, 0, 0, []))
 
 
 @pytest.mark.gpu
-def test_graphed_train_step_data_parallel_two_ranks_on_one_gpu():
+def test_graphed_train_step_data_parallel_two_ranks_on_one_gpu(tmp_path):
     """VERDICT r02 missing #2: the product's graphed data-parallel step (graph A -> bucket all-reduce -> graph B) with world_size 2.
     Two processes share cuda:0 and reduce over gloo; each takes half of a 4-image batch.  Every rank must end with the MEAN of the two
     shards' gradients, where the per-shard gradients are what a single process computes eagerly on that shard (per-replica BatchNorm
     statistics, like the reference's DataParallel) — bit for bit, since every kernel of the iteration adds in a fixed order."""
     import torch.multiprocessing as mp
     from keypointfusion_amd.parallel import live_parameters, shard_batch
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 29800 + os.getpid() % 150
-    procs = [ctx.Process(target=_graphed_dp_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
     dev = torch.device("cuda:0")
     net = "KPFusion-resnet-18"
     sd, batch, loss_fn = _train_fixture(net, 4, dev)
@@ -441,10 +436,25 @@ def test_graphed_train_step_data_parallel_two_ranks_on_one_gpu():
         loss.backward()
         shard_loss.append(float(loss))
         per_shard.append({n: p.grad.detach().cpu() for n, p in zip(names, live) if p.grad is not None})
-    for rank, losses, nb, grads in res:
+        del m, live, loss
+    ref_path = str(tmp_path / "ref.pt")
+    torch.save({"mean": {n: (per_shard[0][n] + per_shard[1][n]) / 2 for n in per_shard[0]}}, ref_path)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29800 + os.getpid() % 150
+    procs = [ctx.Process(target=_graphed_dp_worker, args=(r, 2, port, q, ref_path)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    finally:
+        for p in procs:
+            p.join(30)
+            if p.is_alive():
+                p.kill()
+    for rank, err, losses, nb, ngot, nbad, bad in res:
+        assert err is None, "rank %d failed:\n%s" % (rank, err)
         assert nb >= 2, "several buckets expected at 16 MB"
         assert losses == [shard_loss[rank]] * 2, (rank, losses, shard_loss)
-        assert set(grads) == set(per_shard[0])
-        bad = [n for n in grads if not torch.equal(grads[n], (per_shard[0][n] + per_shard[1][n]) / 2)]
-        assert not bad, "rank %d: %d gradient tensors are not the mean of the two shards' gradients, e.g. %s" % (rank, len(bad), bad[:4])
-    assert all(torch.equal(res[0][3][n], res[1][3][n]) for n in res[0][3]), "the two replicas hold different gradients"
+        assert ngot == len(per_shard[0]) > 100
+        assert nbad == 0, "rank %d: %d gradient tensors are not the mean of the two shards' gradients, e.g. %s" % (rank, nbad, bad)
