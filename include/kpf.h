@@ -324,13 +324,16 @@ int kpf_bn_train_backward_f32(const float* dy, const float* x, const float* y, c
  *   kpf_row_gather_fwd_f32  out[b][r][:] = sum_{g<G} w[b][r*G+g] * src[b][idx[b][r*G+g]][:]   (src [B][P][C], idx int32 [B][R*G],
  *                           w [B][R*G] or NULL for unit weights, out [B][R][C]).
  *   kpf_row_gather_bwd_f32  dsrc[b][p][:] = sum over entries e ascending with idx[b][e] == p of w[b][e] * dout[b][e/G][:];
- *                           R*G <= 8192 entries and P <= 2048 source rows per image.
+ *                           R*G <= 8192 entries and P <= 2048 source rows per image; ws >= kpf_row_gather_ws_ints(B, P, R, G) ints
+ *                           (the per-image inverse lists: a stable counting sort of the entries by source row).
  */
 int kpf_upsample2x_bwd(const void* dy, void* dx, int dtype, int B, int H, int W, int C, void* stream);
 int kpf_maxpool3x3s2_fwd(const void* x, void* y, unsigned char* tap, int dtype, int B, int H, int W, int C, void* stream);
 int kpf_maxpool3x3s2_bwd(const void* dy, const unsigned char* tap, void* dx, int dtype, int B, int H, int W, int C, void* stream);
 int kpf_row_gather_fwd_f32(const float* src, const int* idx, const float* w, float* out, int B, int P, int R, int G, int C, void* stream);
-int kpf_row_gather_bwd_f32(const float* dout, const int* idx, const float* w, float* dsrc, int B, int P, int R, int G, int C, void* stream);
+long kpf_row_gather_ws_ints(int B, int P, int R, int G);
+int kpf_row_gather_bwd_f32(const float* dout, const int* idx, const float* w, float* dsrc, int* ws, long ws_ints, int B, int P, int R, int G, int C,
+                           void* stream);
 
 int kpf_conv_num_tile_cfgs(void);
 

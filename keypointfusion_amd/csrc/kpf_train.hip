@@ -165,80 +165,101 @@ __global__ __launch_bounds__(256) void row_gather_fwd_kernel(const float* __rest
 }
 
 // backward:  dsrc[b][p][:] = sum over entries e (ascending) with idx[b][e] == p of w[b][e] * dout[b][e / G][:]
-// grid (S, B): every workgroup inverts the whole index list of its image in LDS (counting sort by source row; the per-row lists are
-// then sorted by entry number, so the summation order is the entry order whatever order the LDS atomics filled them in) and
-// accumulates the source rows p = s, s + S, ...  E <= KPF_GATHER_MAX_E entries, P <= KPF_GATHER_MAX_P rows per image.
+// Two kernels.  (1) row_gather_invert_kernel, one wave per image: a STABLE counting sort of the entry numbers by source row — counts
+// by integer LDS atomics, an exclusive scan, then the entries are ranked 64 at a time in entry order: the wave loops over the distinct
+// rows present among its 64 lanes (readfirstlane + ballot), a lane's slot is its row's running base + the number of lower lanes with the
+// same row.  The lists therefore hold ascending entry numbers whatever the timing: the summation order below is fixed.
+// (2) row_gather_accum_kernel, one wave per source row: lanes over channel quads; with C <= 128 the two half-waves take alternate list
+// positions (two accumulators, added lower + upper at the end: still one fixed order).  E <= 8192 entries, P <= 2048 rows per image.
 constexpr int GATHER_MAX_E = 8192, GATHER_MAX_P = 2048;
 
-__global__ __launch_bounds__(256) void row_gather_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ idx, const float* __restrict__ w,
-                                                             float* __restrict__ dsrc, int P, int E, int G, int C4) {
-  __shared__ unsigned short list[GATHER_MAX_E];
-  __shared__ int start[GATHER_MAX_P + 1];
-  __shared__ int cursor[GATHER_MAX_P];
-  __shared__ int wsum[4];
-  const int b = blockIdx.y, tid = threadIdx.x;
+__global__ __launch_bounds__(64) void row_gather_invert_kernel(const int* __restrict__ idx, int* __restrict__ start, int* __restrict__ list, int P, int E) {
+  __shared__ int cnt[GATHER_MAX_P + 1];
+  const int b = blockIdx.x, lane = threadIdx.x;
   const int* ib = idx + (long)b * E;
-  for (int p = tid; p < P; p += 256) cursor[p] = 0;
+  int* sb = start + (long)b * (P + 1);
+  int* lb = list + (long)b * E;
+  for (int p = lane; p <= P; p += 64) cnt[p] = 0;
   __syncthreads();
-  for (int e = tid; e < E; e += 256) atomicAdd(&cursor[ib[e]], 1);  // integer counts: order-independent
+  for (int e = lane; e < E; e += 64) atomicAdd(&cnt[ib[e]], 1);  // integer counts: order-independent
   __syncthreads();
-  // exclusive scan of the counts: thread t owns the contiguous range [t*per, (t+1)*per)
-  const int per = (P + 255) / 256;
+  // exclusive scan over P counts by one wave: lane owns a contiguous range
+  const int per = (P + 63) / 64;
   int local = 0;
   for (int j = 0; j < per; ++j) {
-    const int p = tid * per + j;
-    if (p < P) local += cursor[p];
+    const int p = lane * per + j;
+    if (p < P) local += cnt[p];
   }
   int incl = local;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
     const int v = __shfl_up(incl, o, 64);
-    if ((tid & 63) >= o) incl += v;
+    if (lane >= o) incl += v;
   }
-  if ((tid & 63) == 63) wsum[tid >> 6] = incl;
-  __syncthreads();
   int base = incl - local;
-  for (int wv = 0; wv < (tid >> 6); ++wv) base += wsum[wv];
   for (int j = 0; j < per; ++j) {
-    const int p = tid * per + j;
+    const int p = lane * per + j;
     if (p < P) {
-      start[p] = base;
-      base += cursor[p];
+      const int c = cnt[p];
+      cnt[p] = base;  // from here on: the next free slot of row p
+      sb[p] = base;
+      base += c;
     }
   }
-  if (tid == 255) start[P] = E;
+  if (lane == 63) sb[P] = E;
   __syncthreads();
-  for (int p = tid; p < P; p += 256) cursor[p] = start[p];
-  __syncthreads();
-  for (int e = tid; e < E; e += 256) list[atomicAdd(&cursor[ib[e]], 1)] = (unsigned short)e;
-  __syncthreads();
-  for (int p = tid; p < P; p += 256) {  // insertion sort of each (short) list: fixed summation order
-    const int s0 = start[p], s1 = start[p + 1];
-    for (int a = s0 + 1; a < s1; ++a) {
-      const unsigned short v = list[a];
-      int c = a - 1;
-      while (c >= s0 && list[c] > v) {
-        list[c + 1] = list[c];
-        --c;
-      }
-      list[c + 1] = v;
+  for (int e0 = 0; e0 < E; e0 += 64) {  // 64 entries at a time, in entry order
+    const int e = e0 + lane;
+    const bool valid = e < E;
+    const int key = valid ? ib[e] : -1;
+    unsigned long long todo = __ballot(valid);
+    int slot = 0;
+    while (todo) {
+      const int lead = __ffsll((long long)todo) - 1;
+      const int k = __shfl(key, lead, 64);
+      const unsigned long long same = __ballot(valid && key == k);
+      const int first = cnt[k];  // (every lane reads the same word: broadcast)
+      if (key == k && valid) slot = first + __popcll(same & ((1ull << lane) - 1ull));
+      __syncthreads();  // all lanes have read cnt[k] before it moves
+      if (lane == lead) cnt[k] = first + __popcll(same);
+      __syncthreads();
+      todo &= ~same;
     }
+    if (valid) lb[slot] = e;
   }
-  __syncthreads();
-  const int lane = tid & 63;
-  const float* wb = w ? w + (long)b * E : nullptr;
-  for (int p = blockIdx.x * 4 + (tid >> 6); p < P; p += gridDim.x * 4) {
-    const int s0 = start[p], s1 = start[p + 1];
-    for (int q = lane; q < C4; q += 64) {
+}
+
+__global__ __launch_bounds__(256) void row_gather_accum_kernel(const float* __restrict__ dout, const int* __restrict__ start, const int* __restrict__ list,
+                                                               const float* __restrict__ w, float* __restrict__ dsrc, int B, int P, int E, int G, int C4) {
+  const int lane = threadIdx.x & 63;
+  const long rows = (long)B * P;
+  const bool halves = C4 <= 32;  // two half-waves on alternate list positions
+  const int q0 = halves ? (lane & 31) : lane;
+  const int phase = halves ? (lane >> 5) : 0, nph = halves ? 2 : 1;
+  for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * 4) {
+    const int b = (int)(r / P), p = (int)(r - (long)b * P);
+    const int s0 = start[(long)b * (P + 1) + p], s1 = start[(long)b * (P + 1) + p + 1];
+    const int* lb = list + (long)b * E;
+    const float* wb = w ? w + (long)b * E : nullptr;
+    for (int q = q0; q < (halves ? 32 : C4 + 63 - (C4 + 63) % 64); q += (halves ? 32 : 64)) {
+      const bool live = q < C4;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      for (int a = s0; a < s1; ++a) {
-        const int e = list[a];
-        const f32x4 g = kpf_ld4(dout + (((long)b * E + e) / G) * C4 * 4 + 4 * q);
+      for (int a = s0 + phase; a < s1; a += nph) {
+        const int e = lb[a];
         const float ww = wb ? wb[e] : 1.f;
+        if (live) {
+          const f32x4 g = kpf_ld4(dout + (((long)b * E + e) / G) * C4 * 4 + 4 * q);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc[k] += ww * g[k];
+          for (int k = 0; k < 4; ++k) acc[k] += ww * g[k];
+        }
       }
-      kpf_st4(dsrc + ((long)b * P + p) * C4 * 4 + 4 * q, acc);
+      if (halves) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] += __shfl_down(acc[k], 32, 64);  // even positions + odd positions, always in this order
+        if (phase == 0 && live) kpf_st4(dsrc + r * C4 * 4 + 4 * q, acc);
+      } else if (live) {
+        kpf_st4(dsrc + r * C4 * 4 + 4 * q, acc);
+      }
     }
   }
 }
@@ -307,14 +328,21 @@ extern "C" int kpf_row_gather_fwd_f32(const float* src, const int* idx, const fl
   return kpf_check_launch("kpf_row_gather_fwd_f32");
 }
 
-extern "C" int kpf_row_gather_bwd_f32(const float* dout, const int* idx, const float* w, float* dsrc, int B, int P, int R, int G, int C, void* stream) {
-  KPF_REQUIRE(dout && idx && dsrc && B > 0 && P > 0 && R > 0 && G > 0 && C > 0 && C % 4 == 0, "kpf_row_gather_bwd_f32: bad arguments");
+extern "C" long kpf_row_gather_ws_ints(int B, int P, int R, int G) { return (long)B * (P + 1) + (long)B * R * G; }
+
+extern "C" int kpf_row_gather_bwd_f32(const float* dout, const int* idx, const float* w, float* dsrc, int* ws, long ws_ints, int B, int P, int R, int G, int C,
+                                      void* stream) {
+  KPF_REQUIRE(dout && idx && dsrc && ws && B > 0 && P > 0 && R > 0 && G > 0 && C > 0 && C % 4 == 0, "kpf_row_gather_bwd_f32: bad arguments");
   const long E = (long)R * G;
   KPF_REQUIRE(E <= GATHER_MAX_E && P <= GATHER_MAX_P, "kpf_row_gather_bwd_f32: at most %d gathered entries and %d source rows per image", GATHER_MAX_E,
               GATHER_MAX_P);
-  // enough workgroups per image to fill the chip, each re-inverting the index list (E <= 8192 integers: cheap next to the rows)
-  int S = (1024 + B - 1) / B;
-  S = S < 1 ? 1 : (S > (P + 3) / 4 ? (P + 3) / 4 : S);
-  hipLaunchKernelGGL(row_gather_bwd_kernel, dim3(S, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dout, idx, w, dsrc, P, (int)E, G, C / 4);
+  KPF_REQUIRE(ws_ints >= kpf_row_gather_ws_ints(B, P, R, G), "kpf_row_gather_bwd_f32: workspace too small");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int* start = ws;
+  int* list = ws + (long)B * (P + 1);
+  hipLaunchKernelGGL(row_gather_invert_kernel, dim3(B), dim3(64), 0, st, idx, start, list, P, (int)E);
+  int rc = kpf_check_launch("kpf_row_gather_bwd_f32 (invert)");
+  if (rc != KPF_OK) return rc;
+  hipLaunchKernelGGL(row_gather_accum_kernel, dim3(grid_for((long)B * P, 4, 256 * 32)), dim3(256), 0, st, dout, start, list, w, dsrc, B, P, (int)E, G, C / 4);
   return kpf_check_launch("kpf_row_gather_bwd_f32");
 }

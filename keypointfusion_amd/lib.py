@@ -82,13 +82,14 @@ _SIGS = {
     "kpf_maxpool3x3s2_fwd": [_P, _P, _P] + [C.c_int] * 5 + [_P],
     "kpf_maxpool3x3s2_bwd": [_P, _P, _P] + [C.c_int] * 5 + [_P],
     "kpf_row_gather_fwd_f32": [_P] * 4 + [C.c_int] * 5 + [_P],
-    "kpf_row_gather_bwd_f32": [_P] * 4 + [C.c_int] * 5 + [_P],
+    "kpf_row_gather_bwd_f32": [_P] * 5 + [C.c_long] + [C.c_int] * 5 + [_P],
 }
 _LONG_SIGS = {  # entries returning a long
     "kpf_cbam_workspace_floats": [C.c_int, C.c_int, C.c_int],
     "kpf_conv2d_wgrad_ws_floats": [C.c_long, C.c_int, C.c_int],
     "kpf_dwconv7_wgrad_ws_floats": [C.c_int, C.c_int, C.c_int],
     "kpf_bn_ws_floats": [C.c_long, C.c_int],
+    "kpf_row_gather_ws_ints": [C.c_int] * 4,
 }
 EXPORTS = sorted(list(_SIGS) + list(_LONG_SIGS) + ["kpf_last_error", "kpf_abi_version"])
 

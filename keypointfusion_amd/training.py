@@ -460,8 +460,11 @@ class RowGather(torch.autograd.Function):
         B, P, R, G, Cc = ctx.shape
         dout = dout.float().contiguous()
         dsrc = torch.empty(B, P, Cc, device=dout.device, dtype=torch.float32)
-        L.check(L.load().kpf_row_gather_bwd_f32(dout.data_ptr(), idx.data_ptr(), w.data_ptr() if w is not None else None, dsrc.data_ptr(), B, P, R, G, Cc,
-                                                torch.cuda.current_stream().cuda_stream), "kpf_row_gather_bwd_f32")
+        lib = L.load()
+        nws = lib.kpf_row_gather_ws_ints(B, P, R, G)
+        ws = torch.empty(nws, device=dout.device, dtype=torch.int32)
+        L.check(lib.kpf_row_gather_bwd_f32(dout.data_ptr(), idx.data_ptr(), w.data_ptr() if w is not None else None, dsrc.data_ptr(), ws.data_ptr(), nws,
+                                           B, P, R, G, Cc, torch.cuda.current_stream().cuda_stream), "kpf_row_gather_bwd_f32")
         return dsrc, None, None
 
 
