@@ -157,7 +157,9 @@ def test_train_step_matches_the_reference_loss_and_gradients(net):
     # runs on the reference's sets, and the product's own sets may differ from them only by a few boundary points
     ball = [torch.from_numpy(Zs["ball_idx"][i].astype(np.int64)) for i in range(6)]
     results, (loss, parts) = step_loss(ball)
-    assert m._last_ball_flips <= 4, m._last_ball_flips
+    print("train-mode ball-query sets that differ from the reference's: %d" % m._last_ball_flips)
+    # frozen to the observed values on the committed fixtures: one boundary point in the ConvNeXt fixture, none in the ResNet one
+    assert m._last_ball_flips == {"convnext-tiny": 1, "resnet-18": 0}[net], m._last_ball_flips
     assert all(r.requires_grad for r in results)
     assert float((results[2].detach().cpu() - torch.from_numpy(Zs["r3d1"])).abs().max()) < 1e-3
     assert float((results[5].detach().cpu() - torch.from_numpy(Zs["r2d2"])).abs().max()) < 1e-3
