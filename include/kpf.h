@@ -335,6 +335,16 @@ long kpf_row_gather_ws_ints(int B, int P, int R, int G);
 int kpf_row_gather_bwd_f32(const float* dout, const int* idx, const float* w, float* dsrc, int* ws, long ws_ints, int B, int P, int R, int G, int C,
                            void* stream);
 
+/* Training: one-launch packing of a reference-layout weight w [N][Cin][KH][KW] (src_dtype: KPF_DT_F32 master, or a 16-bit copy) into an
+ * operand of kpf_conv2d_f32 / _h16 (dst_dtype; fp32 -> 16-bit rounds to nearest even), rows zero-padded to Kp:
+ *   mode 0  forward rows        dst [n_pad][Kp], k = (ky, kx, c)
+ *   mode 1  data-gradient rows  dst [Cin][Kp],   k = (ky, kx, n < n_pad) with mirrored taps (transposed convolution, stride-1 form)
+ *   mode 2  patchify data-grad  dst [(ky, kx, c)][Kp], k = n < n_pad        (kernel == stride convolutions: a GEMM + pixel un-shuffle;
+ *                               with Cin = 1: the depthwise tap table [KH*KW][C] of kpf_dwconv7_f32)
+ *   mode 3  mode 2 with the taps mirrored (the depthwise convolution's data gradient) */
+int kpf_pack_conv_weight(const void* w, int src_dtype, void* dst, int dst_dtype, int N, int Cin, int KH, int KW, int mode, int n_pad, int Kp,
+                         void* stream);
+
 int kpf_conv_num_tile_cfgs(void);
 
 const char* kpf_last_error(void);

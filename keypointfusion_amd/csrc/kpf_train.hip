@@ -346,3 +346,60 @@ extern "C" int kpf_row_gather_bwd_f32(const float* dout, const int* idx, const f
   hipLaunchKernelGGL(row_gather_accum_kernel, dim3(grid_for((long)B * P, 4, 256 * 32)), dim3(256), 0, st, dout, start, list, w, dsrc, B, P, (int)E, G, C / 4);
   return kpf_check_launch("kpf_row_gather_bwd_f32");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight packing for the training step: the reference-layout OIHW master weight -> the kernel operand of the implicit GEMM, ONE launch
+// per operand (the torch expressions this replaces were flip + permute-clone + pad [+ cast]: 3-4 small launches per convolution per
+// step, ~500 per iteration).  mode 0: forward rows [n_pad][Kp], k = (ky, kx, c);  mode 1: data-gradient rows [Cin][Kp],
+// k = (ky, kx, n) with the taps mirrored (the transposed convolution);  mode 2: patchify data-gradient rows [(ky, kx, c)][Kp], k = n
+// (with Cin = 1 this is the depthwise convolution's tap table [KH*KW][C]);  mode 3: mode 2 with mirrored taps.
+// Rows are zero-padded to Kp, output channels beyond N are zero.  TS / TD: source / destination element types (fp32 master -> fp32
+// or 16-bit operand; a 16-bit source is copied as it is).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void pack_weight_kernel(const TS* __restrict__ w, TD* __restrict__ dst, int N, int Cin, int KH, int KW, int mode, int n_pad,
+                                                          int Kp, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % Kp);
+    const int row = (int)(i / Kp);
+    float v = 0.f;
+    if (mode == 0) {
+      const int c = k % Cin, t = k / Cin;  // t = ky*KW + kx
+      if (t < KH * KW && row < N) v = (float)w[((long)row * Cin + c) * KH * KW + t];
+    } else if (mode == 1) {
+      const int n = k % n_pad, t = k / n_pad;
+      if (t < KH * KW && n < N) v = (float)w[((long)n * Cin + row) * KH * KW + (KH * KW - 1 - t)];
+    } else {
+      const int c = row % Cin, t = row / Cin;
+      if (k < N) v = (float)w[((long)k * Cin + c) * KH * KW + (mode == 3 ? KH * KW - 1 - t : t)];
+    }
+    dst[i] = (TD)v;
+  }
+}
+}  // namespace
+
+extern "C" int kpf_pack_conv_weight(const void* w, int src_dtype, void* dst, int dst_dtype, int N, int Cin, int KH, int KW, int mode, int n_pad, int Kp,
+                                    void* stream) {
+  KPF_REQUIRE(w && dst && N > 0 && Cin > 0 && KH > 0 && KW > 0 && mode >= 0 && mode <= 3 && n_pad >= N, "kpf_pack_conv_weight: bad arguments");
+  const long rows = mode == 0 ? n_pad : (mode == 1 ? Cin : (long)KH * KW * Cin);
+  const long kmin = mode == 0 ? (long)KH * KW * Cin : (mode == 1 ? (long)KH * KW * n_pad : n_pad);
+  KPF_REQUIRE(Kp >= kmin, "kpf_pack_conv_weight: Kp = %d is shorter than the row (%ld)", Kp, kmin);
+  const long total = rows * Kp;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid(grid_for(total)), block(256);
+#define KPF_PACK(TS, TD)                                                                                                                              \
+  hipLaunchKernelGGL((pack_weight_kernel<TS, TD>), grid, block, 0, st, static_cast<const TS*>(w), static_cast<TD*>(dst), N, Cin, KH, KW, mode, n_pad, Kp, \
+                     total)
+  if (src_dtype == KPF_DT_F32 && dst_dtype == KPF_DT_F32) KPF_PACK(float, float);
+  else if (src_dtype == KPF_DT_F32 && dst_dtype == KPF_DT_BF16) KPF_PACK(float, bf16_t);
+  else if (src_dtype == KPF_DT_F32 && dst_dtype == KPF_DT_F16) KPF_PACK(float, f16_t);
+  else if (src_dtype == KPF_DT_BF16 && dst_dtype == KPF_DT_BF16) KPF_PACK(bf16_t, bf16_t);
+  else if (src_dtype == KPF_DT_F16 && dst_dtype == KPF_DT_F16) KPF_PACK(f16_t, f16_t);
+  else {
+    kpf_set_error("kpf_pack_conv_weight: unsupported dtype pair %d -> %d", src_dtype, dst_dtype);
+    return KPF_EINVAL;
+  }
+#undef KPF_PACK
+  return kpf_check_launch("kpf_pack_conv_weight");
+}

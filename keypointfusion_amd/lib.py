@@ -82,6 +82,7 @@ _SIGS = {
     "kpf_maxpool3x3s2_fwd": [_P, _P, _P] + [C.c_int] * 5 + [_P],
     "kpf_maxpool3x3s2_bwd": [_P, _P, _P] + [C.c_int] * 5 + [_P],
     "kpf_row_gather_fwd_f32": [_P] * 4 + [C.c_int] * 5 + [_P],
+    "kpf_pack_conv_weight": [_P, C.c_int, _P, C.c_int] + [C.c_int] * 7 + [_P],
     "kpf_row_gather_bwd_f32": [_P] * 5 + [C.c_long] + [C.c_int] * 5 + [_P],
 }
 _LONG_SIGS = {  # entries returning a long

@@ -93,6 +93,30 @@ def joint2heatmap(joint_uv, std, heatmap_size, sigma=1.5):
     return torch.exp(-(torch.pow((xs - jx) / std, 2) + torch.pow((ys - jy) / std, 2)) / (2 * pow(sigma, 2)))
 
 
+class _SmoothL1(torch.autograd.Function):
+    """model/loss.py:3-26 as one autograd node: the forward is the reference's own operation sequence (bit-identical values), the
+    backward is the closed form dL/dz = scale * (z if |z| < 0.01 else 0.01 sign(z)) in four launches instead of the ~15 that autograd
+    generates for the mask / pow / abs chain (ten loss terms per iteration)."""
+
+    @staticmethod
+    def forward(ctx, x, y, size_average):
+        z = (x - y).float()
+        mse_mask = (torch.abs(z) < 0.01).float()
+        l1_mask = (torch.abs(z) >= 0.01).float()
+        total = torch.mean(0.5 * torch.pow(mse_mask * z, 2) * mse_mask, dim=-1)
+        total = total + torch.mean(0.01 * (torch.abs(l1_mask * z) - 0.005) * l1_mask, dim=-1)
+        ctx.save_for_backward(z)
+        ctx.scale = 1.0 / z.numel() if size_average else 1.0 / z.shape[-1]
+        ctx.dtypes = (x.dtype, y.dtype)
+        return total.mean() if size_average else total.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        (z,) = ctx.saved_tensors
+        gz = torch.where(torch.abs(z) < 0.01, z, 0.01 * torch.sign(z)) * (g * ctx.scale)
+        return (gz.to(ctx.dtypes[0]) if ctx.needs_input_grad[0] else None, (-gz).to(ctx.dtypes[1]) if ctx.needs_input_grad[1] else None, None)
+
+
 class SmoothL1Loss(torch.nn.Module):
     """model/loss.py:3-26 (not torch's SmoothL1Loss: the quadratic zone ends at 0.01 and the linear branch is 0.01 (|z| - 0.005))."""
 
@@ -102,12 +126,28 @@ class SmoothL1Loss(torch.nn.Module):
 
     def forward(self, x, y):
         assert x.shape == y.shape
-        z = (x - y).float()
-        mse_mask = (torch.abs(z) < 0.01).float()
-        l1_mask = (torch.abs(z) >= 0.01).float()
-        total = torch.mean(0.5 * torch.pow(mse_mask * z, 2) * mse_mask, dim=-1)
-        total = total + torch.mean(0.01 * (torch.abs(l1_mask * z) - 0.005) * l1_mask, dim=-1)
-        return total.mean() if self.size_average else total.sum()
+        return _SmoothL1.apply(x, y, self.size_average)
+
+
+class _LayerScaleResidual(torch.autograd.Function):
+    """out = x + gamma * y (convNeXT/convnext.py:48-51, drop_path = identity) as one node: one fused forward launch, and a backward of
+    three (dy = g * gamma; dgamma = column sums of g * y) where autograd's mul / add nodes take eight."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, y):
+        ctx.save_for_backward(gamma, y)
+        return torch.addcmul(x, y, gamma)
+
+    @staticmethod
+    def backward(ctx, g):
+        gamma, y = ctx.saved_tensors
+        dy = (g * gamma).to(y.dtype) if ctx.needs_input_grad[2] else None
+        dgamma = (g.reshape(-1, g.shape[-1]).float() * y.reshape(-1, y.shape[-1]).float()).sum(0).to(gamma.dtype) if ctx.needs_input_grad[1] else None
+        return (g if ctx.needs_input_grad[0] else None), dgamma, dy
+
+
+def layer_scale_residual(x, gamma, y):
+    return _LayerScaleResidual.apply(x, gamma, y)
 
 
 def kpfusion_loss(results, spatial_weight, img, uvd_gt, xyz_gt, epoch=0, stage_type=STAGE_TYPE, l1=None):
@@ -198,6 +238,48 @@ class DevPack:
             self.w16 = rows.contiguous() if kp == K else F.pad(rows, (0, kp - K)).contiguous()
 
     @classmethod
+    def packed(cls, weight, bias, mode, prec="f32", stride=1, pad=0, patchify=False, n_pad=None):
+        """The operand of one launch of kpf_pack_conv_weight (csrc/kpf_train.hip) instead of flip / permute-clone / pad / cast
+        expressions: `weight` [N, Cin, KH, KW] (fp32 master or its 16-bit shadow), mode 0 = forward rows, 1 = data-gradient rows of a
+        stride-1 (or dilated) convolution, 2 = data-gradient rows of a patchify convolution; `prec` selects the operand type."""
+        from . import lib as L
+        w = weight.detach()
+        if w.dim() == 2:
+            w = w[:, :, None, None]
+        w = w.contiguous()
+        N, Cin, KH, KW = w.shape
+        n_pad = N if n_pad is None else n_pad
+        self = cls.__new__(cls)
+        gran = 32 if prec == "f32" else 64
+        if mode == 0:
+            if patchify:
+                assert stride == KH == KW and pad == 0
+                self.KH, self.KW, self.Cin, self.sh, self.sw, self.ph, self.pw, self.merge = KH, 1, KW * Cin, KH, 1, 0, 0, KW
+            else:
+                self.KH, self.KW, self.Cin, self.sh, self.sw, self.ph, self.pw, self.merge = KH, KW, Cin, stride, stride, pad, pad, 1
+            rows, K = n_pad, KH * KW * Cin
+            self.N = n_pad
+        elif mode == 1:  # transposed convolution of (dilated) dY: Cin output channels, n_pad input channels, mirrored taps, padding KH-1-pad
+            self.KH, self.KW, self.Cin, self.sh, self.sw, self.ph, self.pw, self.merge = KH, KW, n_pad, 1, 1, KH - 1 - pad, KW - 1 - pad, 1
+            rows, K = Cin, KH * KW * n_pad
+            self.N = Cin
+        else:  # patchify: dY rows @ [(ky,kx,c)][n]
+            self.KH, self.KW, self.Cin, self.sh, self.sw, self.ph, self.pw, self.merge = 1, 1, n_pad, 1, 1, 0, 0, 1
+            rows, K = KH * KW * Cin, n_pad
+            self.N = rows
+        self.K = K
+        kp = (K + gran - 1) // gran * gran
+        self.Kp = (K + 31) // 32 * 32  # (the fp32 descriptor's row length; the 16-bit operand carries its own, see as16)
+        tdt = torch.float32 if prec == "f32" else _TDT[prec]
+        buf = torch.empty(rows, kp, device=w.device, dtype=tdt)
+        L.check(L.load().kpf_pack_conv_weight(w.data_ptr(), _KDT[w.dtype], buf.data_ptr(), _KDT[tdt], N, Cin, KH, KW, mode, n_pad, kp,
+                                              torch.cuda.current_stream().cuda_stream), "kpf_pack_conv_weight")
+        self.w, self.w16 = (buf, None) if prec == "f32" else (None, buf)
+        self.b = bias.detach().float().contiguous() if bias is not None else None
+        self.tuned = {}
+        return self
+
+    @classmethod
     def from_rows(cls, rows, KH, KW, Cin, pad):
         """Stride-1 convolution whose weight is already in kernel order: rows [N][(ky,kx,c)] (no bias)."""
         self = cls.__new__(cls)
@@ -217,7 +299,7 @@ class DevPack:
         """The object engine16.conv16() takes: 16-bit rows [N][Kp64] of the same weights."""
         kp = (self.K + 63) // 64 * 64
         if self.w16 is not None:
-            assert self.w16.dtype == tdt
+            assert self.w16.dtype == tdt and self.w16.shape[1] == kp
             return type("P16", (), {"pc": self, "Kp": kp, "w": self.w16})()
         w = self.w[:, :self.K]
         w16 = (w if kp == self.K else F.pad(w, (0, kp - self.K))).to(tdt).contiguous()
@@ -280,7 +362,7 @@ class DwConv7NHWC(torch.autograd.Function):
         x = x.contiguous()
         B, H, W, Cc = x.shape
         assert x.dtype == torch.float32 and Cc % 4 == 0
-        wt = weight.detach().reshape(Cc, 49).t().contiguous()  # [49][C]
+        wt = _dw_taps(weight, False)  # [49][C]
         y = torch.empty_like(x)
         L.check(lib.kpf_dwconv7_f32(x.data_ptr(), wt.data_ptr(), bias.detach().contiguous().data_ptr(), y.data_ptr(), B, H, W, Cc,
                                     torch.cuda.current_stream().cuda_stream), "kpf_dwconv7_f32")
@@ -297,9 +379,9 @@ class DwConv7NHWC(torch.autograd.Function):
         st = torch.cuda.current_stream().cuda_stream
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wf = weight.detach().reshape(Cc, 49).flip(1).t().contiguous()  # taps mirrored, [49][C]
+            wf = _dw_taps(weight, True)  # taps mirrored, [49][C]
             dx = torch.empty_like(x)
-            zb = torch.zeros(Cc, device=x.device, dtype=torch.float32)
+            zb = _zero_bias(Cc, x.device)
             L.check(lib.kpf_dwconv7_f32(dy.data_ptr(), wf.data_ptr(), zb.data_ptr(), dx.data_ptr(), B, H, W, Cc, st), "kpf_dwconv7_f32")
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             nws = lib.kpf_dwconv7_wgrad_ws_floats(B, H, Cc)
@@ -309,6 +391,31 @@ class DwConv7NHWC(torch.autograd.Function):
             L.check(lib.kpf_dwconv7_wgrad_f32(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nws, B, H, W, Cc, st),
                     "kpf_dwconv7_wgrad_f32")
         return dx, dw, db
+
+
+_ZERO_BIAS = {}
+
+
+def _zero_bias(n, device):
+    """A persistent zero vector per (device, length): the data-gradient convolutions add no bias (allocated once, outside any capture
+    that replays it; never written)."""
+    key = (device.type, device.index, n)
+    z = _ZERO_BIAS.get(key)
+    if z is None:
+        z = _ZERO_BIAS[key] = torch.zeros(n, device=device, dtype=torch.float32)
+    return z
+
+
+def _dw_taps(weight, mirrored):
+    """Depthwise weight [C, 1, 7, 7] -> the kernel's tap table [49][C] (mirrored: the data gradient's), one launch."""
+    from . import lib as L
+    w = weight.detach().contiguous()
+    Cc = w.shape[0]
+    kp = Cc
+    out = torch.empty(49, kp, device=w.device, dtype=torch.float32)
+    L.check(L.load().kpf_pack_conv_weight(w.data_ptr(), 0, out.data_ptr(), 0, Cc, 1, 7, 7, 3 if mirrored else 2, Cc, kp,
+                                          torch.cuda.current_stream().cuda_stream), "kpf_pack_conv_weight")
+    return out
 
 
 def dwconv7_nhwc(x, weight, bias):
@@ -501,7 +608,7 @@ class Conv2dNHWC(torch.autograd.Function):
         assert Cw == Cin and Cin % (4 if prec == "f32" else 8) == 0, "Conv2dNHWC: input channels must match and be a multiple of 4 (8 for 16-bit)"
         patch = stride == KH == KW and pad == 0 and stride > 1
         use16 = prec != "f32" and w16 is not None
-        pc = DevPack(w16 if use16 else weight, bias, stride=stride, pad=pad, patchify=patch)
+        pc = DevPack.packed(w16 if use16 else weight, bias, 0, prec, stride=stride, pad=pad, patchify=patch)
         xc = x.float() if prec == "f32" else x.to(_TDT[prec])  # the operand as the GEMM sees it — also what the weight gradient multiplies
         y = _conv_any(pc, xc, prec)
         ctx.save_for_backward(xc, weight)
@@ -522,24 +629,14 @@ class Conv2dNHWC(torch.autograd.Function):
         cmul = 4 if prec == "f32" else 8  # channel granularity of the GEMM's activation operand
         if ctx.needs_input_grad[0]:
             wsrc = ctx.w16 if ctx.w16 is not None else weight.detach()
+            npad = (N + cmul - 1) // cmul * cmul
+            dy_in = dy if npad == N else F.pad(dy, (0, npad - N))  # the kernel needs whole channel groups: zero channels on dY (and zero weight rows)
             if patch:  # dX[b, oy*s+ky, ox*s+kx, c] = sum_n dY[b,oy,ox,n] W[n,c,ky,kx]: rows of a GEMM, then un-shuffle
-                wt = wsrc.permute(2, 3, 1, 0).reshape(KH * KW * Cin, N)  # [(ky,kx,c)][n]
-                npad = (N + cmul - 1) // cmul * cmul
-                dy_in = dy if npad == N else F.pad(dy, (0, npad - N))
-                if npad != N:
-                    wt = F.pad(wt, (0, npad - N))
-                g = _conv_any(DevPack(wt, None), dy_in, prec).view(B, OH, OW, KH, KW, Cin)
+                g = _conv_any(DevPack.packed(wsrc, None, 2, prec, n_pad=npad), dy_in, prec).view(B, OH, OW, KH, KW, Cin)
                 dx = g.permute(0, 1, 3, 2, 4, 5).reshape(B, OH * KH, OW * KW, Cin)
                 if dx.shape[1] != H or dx.shape[2] != W:  # rows / columns the strided convolution never read
                     dx = F.pad(dx, (0, 0, 0, W - dx.shape[2], 0, H - dx.shape[1]))
             else:
-                npad = (N + cmul - 1) // cmul * cmul
-                wd = wsrc
-                if npad != N:  # the kernel needs whole channel groups: zero-pad dY's channel axis (and the weight's output axis)
-                    dy_in = F.pad(dy, (0, npad - N))
-                    wd = F.pad(wd, (0, 0, 0, 0, 0, 0, 0, npad - N))
-                else:
-                    dy_in = dy
                 if stride != 1:
                     # strided (non-patchify) convolution — ResNet's 3x3/s2 and 1x1/s2 (model/resnet.py:52-55,190-194): the data gradient
                     # is the stride-1 transposed convolution of dY dilated by the stride (zeros between its pixels), laid out so that
@@ -548,10 +645,7 @@ class Conv2dNHWC(torch.autograd.Function):
                     dil = dy_in.new_zeros(B, hz, wz, npad)
                     dil[:, :(OH - 1) * stride + 1:stride, :(OW - 1) * stride + 1:stride] = dy_in
                     dy_in = dil
-                if KH > 1 or KW > 1:
-                    wd = wd.flip(2, 3)  # taps mirrored
-                rows = wd.permute(1, 2, 3, 0).reshape(Cin, KH * KW * npad)  # [c][(ky,kx,n)]: one transposing copy
-                dx = _conv_any(DevPack.from_rows(rows, KH, KW, npad, KH - 1 - pad), dy_in, prec).view(B, H, W, Cin)
+                dx = _conv_any(DevPack.packed(wsrc, None, 1, prec, pad=pad, n_pad=npad), dy_in, prec).view(B, H, W, Cin)
             dx = dx.to(ctx.x_dtype)
         if ctx.needs_input_grad[1] and Cin % 4 == 0 and N % 4 == 0:
             # hand-written split-K weight gradient (fp32 products and accumulation in every precision mode: the master weight's

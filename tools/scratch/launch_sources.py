@@ -1,0 +1,48 @@
+"""Where do the small ATen launches of one training iteration come from?  One eager iteration under torch.profiler (CPU side, with Python
+stacks); ops grouped by the innermost frame inside keypointfusion_amd / the test harness."""
+import os, sys, collections, torch
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests")
+from conftest import synthetic_sd
+from keypointfusion_amd import training as T
+from keypointfusion_amd.model.model import KPFusion
+from keypointfusion_amd.weights import synthetic_batch
+net = "KPFusion-convnext-tiny"; B = 8; dev = torch.device("cuda:0")
+sd = synthetic_sd(net)
+batch = {k: torch.from_numpy(v).to(dev) for k, v in synthetic_batch(B, 128, seed=5).items()}
+g = torch.Generator().manual_seed(1)
+uvd = (torch.rand(B, 21, 3, generator=g) * 1.2 - 0.6).to(dev); xyz = (torch.rand(B, 21, 3, generator=g) * 1.2 - 0.6).to(dev)
+class Loader: img_size, flip = 128, 1
+m = KPFusion(net, "", 21, "dexycb", ""); m.load_state_dict(sd, strict=True); m = m.to(dev).train(); m.train_dropout = 0.1
+m.precision = sys.argv[1] if len(sys.argv) > 1 else "f32"
+def it():
+    for p in m.parameters(): p.grad = None
+    r, s, _ = m(batch["img_rgb"], batch["img"], batch["pcl"], Loader(), batch["center"], batch["M"], batch["cube"], batch["cam_para"], 0.8)
+    T.kpfusion_loss(r, s, batch["img"], uvd, xyz, epoch=0)[0].backward()
+it(); torch.cuda.synchronize()
+import traceback
+from torch.utils._python_dispatch import TorchDispatchMode
+SKIP = {"aten::view", "aten::_unsafe_view", "aten::permute", "aten::transpose", "aten::reshape", "aten::detach", "aten::slice", "aten::expand", "aten::t",
+        "aten::unsqueeze", "aten::squeeze", "aten::alias", "aten::as_strided", "aten::select", "aten::empty", "aten::empty_like", "aten::empty_strided",
+        "aten::narrow", "aten::unbind", "aten::split", "aten::view_as", "aten::_reshape_alias", "aten::size", "aten::stride", "aten::is_contiguous", "aten::unfold"}
+cnt = collections.Counter()
+class Mode(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = func._schema.name
+        if name not in SKIP:
+            node = torch._C._current_autograd_node()
+            if node is not None:
+                where = "BWD " + node.name()
+            else:
+                where = "?"
+                for fr in reversed(traceback.extract_stack(limit=14)):
+                    if "keypointfusion_amd" in fr.filename:
+                        where = "%s:%d %s" % (os.path.basename(fr.filename), fr.lineno, fr.name)
+                        break
+            cnt[(name, where)] += 1
+        return func(*args, **(kwargs or {}))
+with Mode():
+    it()
+torch.cuda.synchronize()
+print("ATen ops (non-view) in one iteration:", sum(cnt.values()))
+for (name, where), c in cnt.most_common(90):
+    print("%5d  %-30s %s" % (c, name, where))
