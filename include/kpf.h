@@ -345,6 +345,17 @@ int kpf_row_gather_bwd_f32(const float* dout, const int* idx, const float* w, fl
 int kpf_pack_conv_weight(const void* w, int src_dtype, void* dst, int dst_dtype, int N, int Cin, int KH, int KW, int mode, int n_pad, int Kp,
                          void* stream);
 
+/* All operands of an iteration in ONE launch: `descs_device` is an array of `ndesc` descriptors in DEVICE memory, sorted by
+ * first_block; descriptor i owns workgroups [first_block, first_block + ceil(rows * Kp / 1024)) of the `total_blocks` launched.
+ * Fields as the arguments of kpf_pack_conv_weight (rows = destination rows: n_pad / Cin / KH*KW*Cin for mode 0 / 1 / 2-3). */
+typedef struct kpf_pack_desc {
+  const void* src;
+  void* dst;
+  int N, Cin, KH, KW, mode, n_pad, Kp, rows;
+  int src_dtype, dst_dtype, first_block, reserved;
+} kpf_pack_desc;
+int kpf_pack_conv_weights_multi(const kpf_pack_desc* descs_device, int ndesc, int total_blocks, void* stream);
+
 int kpf_conv_num_tile_cfgs(void);
 
 const char* kpf_last_error(void);

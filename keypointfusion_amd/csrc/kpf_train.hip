@@ -403,3 +403,54 @@ extern "C" int kpf_pack_conv_weight(const void* w, int src_dtype, void* dst, int
 #undef KPF_PACK
   return kpf_check_launch("kpf_pack_conv_weight");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same packing for EVERY operand of the training step in one launch: a table of descriptors in device memory (built once by the
+// host when the set of layers is known; sources are the parameters' own storage, destinations persistent operand buffers), refreshed
+// at the start of each iteration — "weights kept in kernel layout across steps" without giving up the reference's state-dict layout.
+// Workgroup b serves the descriptor whose [first_block, first_block + nblocks) range holds b (binary search, uniform per workgroup).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+template <typename TS>
+__device__ __forceinline__ float pack_value(const TS* __restrict__ w, const kpf_pack_desc& d, int row, int k) {
+  const int T = d.KH * d.KW;
+  if (d.mode == 0) {
+    const int c = k % d.Cin, t = k / d.Cin;
+    return (t < T && row < d.N) ? (float)w[((long)row * d.Cin + c) * T + t] : 0.f;
+  }
+  if (d.mode == 1) {
+    const int n = k % d.n_pad, t = k / d.n_pad;
+    return (t < T && n < d.N) ? (float)w[((long)n * d.Cin + row) * T + (T - 1 - t)] : 0.f;
+  }
+  const int c = row % d.Cin, t = row / d.Cin;
+  return k < d.N ? (float)w[((long)k * d.Cin + c) * T + (d.mode == 3 ? T - 1 - t : t)] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const kpf_pack_desc* __restrict__ descs, int ndesc) {
+  int lo = 0, hi = ndesc - 1;
+  const int b = blockIdx.x;
+  while (lo < hi) {  // last descriptor with first_block <= b
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].first_block <= b) lo = mid;
+    else hi = mid - 1;
+  }
+  const kpf_pack_desc d = descs[lo];
+  const long total = (long)d.rows * d.Kp;
+  for (long i = (long)(b - d.first_block) * 1024 + threadIdx.x; i < total && i < (long)(b - d.first_block + 1) * 1024; i += 256) {
+    const int k = (int)(i % d.Kp), row = (int)(i / d.Kp);
+    float v;
+    if (d.src_dtype == KPF_DT_F32) v = pack_value(static_cast<const float*>(d.src), d, row, k);
+    else if (d.src_dtype == KPF_DT_BF16) v = pack_value(static_cast<const bf16_t*>(d.src), d, row, k);
+    else v = pack_value(static_cast<const f16_t*>(d.src), d, row, k);
+    if (d.dst_dtype == KPF_DT_F32) static_cast<float*>(d.dst)[i] = v;
+    else if (d.dst_dtype == KPF_DT_BF16) static_cast<bf16_t*>(d.dst)[i] = (bf16_t)v;
+    else static_cast<f16_t*>(d.dst)[i] = (f16_t)v;
+  }
+}
+}  // namespace
+
+extern "C" int kpf_pack_conv_weights_multi(const kpf_pack_desc* descs_device, int ndesc, int total_blocks, void* stream) {
+  KPF_REQUIRE(descs_device && ndesc > 0 && total_blocks > 0, "kpf_pack_conv_weights_multi: bad arguments");
+  hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(total_blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), descs_device, ndesc);
+  return kpf_check_launch("kpf_pack_conv_weights_multi");
+}

@@ -29,6 +29,11 @@ class ConvDesc(C.Structure):
         "out_ld", "out_coff", "res_ld", "res_coff")] + [("flags", C.c_uint), ("w_unscale", C.c_float), ("tile_cfg", C.c_int)]
 
 
+class PackDesc(C.Structure):  # kpf_pack_desc (include/kpf.h)
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p)] + [(n, C.c_int) for n in (
+        "N", "Cin", "KH", "KW", "mode", "n_pad", "Kp", "rows", "src_dtype", "dst_dtype", "first_block", "reserved")]
+
+
 _P = C.c_void_p
 _SIGS = {
     "kpf_conv2d_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P],
@@ -83,6 +88,7 @@ _SIGS = {
     "kpf_maxpool3x3s2_bwd": [_P, _P, _P] + [C.c_int] * 5 + [_P],
     "kpf_row_gather_fwd_f32": [_P] * 4 + [C.c_int] * 5 + [_P],
     "kpf_pack_conv_weight": [_P, C.c_int, _P, C.c_int] + [C.c_int] * 7 + [_P],
+    "kpf_pack_conv_weights_multi": [_P, C.c_int, C.c_int, _P],
     "kpf_row_gather_bwd_f32": [_P] * 5 + [C.c_long] + [C.c_int] * 5 + [_P],
 }
 _LONG_SIGS = {  # entries returning a long

@@ -57,7 +57,7 @@ class KPFusion(nn.Module):
         return sum(t._version for t in ts)
 
     # -- copy.deepcopy / pickle: the per-device caches (packed weights, captured graphs, streams, locks) are rebuilt on demand ----
-    _CACHE_ATTRS = ("_plans", "_plan_lock", "_tensor_list", "_train_side_stream", "_w16_shadow")
+    _CACHE_ATTRS = ("_plans", "_plan_lock", "_tensor_list", "_train_side_stream", "_w16_shadow", "_pack_cache")
 
     def __getstate__(self):
         st = self.__dict__.copy()
@@ -73,6 +73,7 @@ class KPFusion(nn.Module):
 
     def _apply(self, fn, *a, **k):  # .to() / .cuda() / .float(): tensors may be replaced
         self.__dict__["_tensor_list"] = None
+        self.__dict__.pop("_pack_cache", None)
         self._plans.clear()
         return super()._apply(fn, *a, **k)
 

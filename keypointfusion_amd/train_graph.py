@@ -48,20 +48,18 @@ class TrainGraph:
         self.nbt = []  # BatchNorm num_batches_tracked counters touched by this forward: incremented by ONE multi-tensor launch at its end
         self.ball_override = list(getattr(module, "_ball_override", None) or [])
         self.ball_flips = 0
-        # mixed precision: every GEMM weight rounded to the compute type ONCE per step by a fused multi-tensor copy into persistent
-        # shadow tensors (the per-layer casts were ~600 small kernels per iteration); the packs of forward and data gradient read them
+        # kernel-layout operands of every convolution / Linear whose source is parameter storage: persistent buffers, rewritten from the
+        # current parameter values by one multi-tensor launch here (training.PackCache); mixed precision rounds the fp32 master to the
+        # 16-bit operand in the same kernel (no shadow copies)
         self.w16 = {}
-        if self.prec != "f32":
-            from .training import _TDT
-            tdt = _TDT[self.prec]
-            names = [n for n, p in module.named_parameters() if p.dim() >= 2 and p.is_cuda and p.dtype == torch.float32 and n.endswith("weight")]
-            sh = module.__dict__.get("_w16_shadow")
-            if sh is None or sh[0] != (tdt, names) or any(a.device != self.t[n].device for a, n in zip(sh[1], names)):
-                sh = module.__dict__["_w16_shadow"] = ((tdt, names), [torch.empty_like(self.t[n], dtype=tdt) for n in names])
-            if names:
-                with torch.no_grad():
-                    torch._foreach_copy_(sh[1], [self.t[n].detach() for n in names])
-            self.w16 = dict(zip(names, sh[1]))
+        from .training import PackCache
+        caches = module.__dict__.setdefault("_pack_cache", {})
+        dev = next(module.parameters()).device
+        ck = (dev.type, dev.index, self.prec)
+        if ck not in caches:
+            caches[ck] = PackCache()
+        self.packs = caches[ck]
+        self.packs.refresh()
 
     # ---- primitives ---------------------------------------------------------------------------------------------------------------
     def has(self, name):
@@ -74,7 +72,7 @@ class TrainGraph:
         cin, k = w.shape[1], w.shape[2]
         patch = stride == k and pad == 0 and stride > 1
         if cin % self.cmul == 0 and (stride == 1 or patch) and w.shape[2] == w.shape[3]:
-            y = conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous(), w, b, stride, pad, self.prec, self.w16.get(p_w))
+            y = conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous(), w, b, stride, pad, self.prec, None, p_w, self.packs)
             return y.permute(0, 3, 1, 2)
         return F.conv2d(x, w, b, stride=stride, padding=pad)
 
@@ -82,7 +80,7 @@ class TrainGraph:
         w = self.t[p_w]
         b = self.t[p_b] if p_b is not None else None
         if w.shape[1] % self.cmul == 0:
-            return linear_hip(x.contiguous(), w, b, self.prec, self.w16.get(p_w))
+            return linear_hip(x.contiguous(), w, b, self.prec, None, p_w, self.packs)
         return F.linear(x, w, b)
 
     def bn(self, x, p, eps=1e-5):
@@ -111,7 +109,7 @@ class TrainGraph:
             if cpad:  # the 3- / 1-channel images of the stems: zero channels on both operands (the weight's gradient is sliced back)
                 x, w = F.pad(x, (0, cpad)), F.pad(w, (0, 0, 0, 0, 0, cpad))
                 w16 = F.pad(w16, (0, 0, 0, 0, 0, cpad)) if w16 is not None else None
-            return conv2d_nhwc(x.contiguous(), w, b, stride, pad, self.prec, w16)
+            return conv2d_nhwc(x.contiguous(), w, b, stride, pad, self.prec, w16, None if cpad else p_w, self.packs)
         return F.conv2d(x.permute(0, 3, 1, 2), w, b, stride=stride, padding=pad).permute(0, 2, 3, 1).contiguous()
 
     def bn_l(self, x, p, eps=1e-5, relu=False, out16=True):
@@ -269,7 +267,7 @@ class TrainGraph:
             return idx
 
     # ---- fusion head (model/model.py:129-351, model/transfusion_head.py:137-173) -----------------------------------------------------------
-    def linear_rows(self, rows, w, b, w16=None):
+    def linear_rows(self, rows, w, b, w16=None, key=None):
         """nn.Linear / Conv1d(k=1) / Conv2d(k=1) over rows [M, Cin] on the HIP GEMM (forward, data- and weight-gradient); input widths
         that are not whole channel groups (3-d coordinates, the 105 pose channels) are zero-padded together with the weight."""
         cin = rows.shape[-1]
@@ -277,13 +275,13 @@ class TrainGraph:
         if pad:
             rows, w = F.pad(rows, (0, pad)), F.pad(w, (0, pad))
             w16 = F.pad(w16, (0, pad)) if w16 is not None else None
-        return linear_hip(rows.contiguous(), w, b, self.prec, w16)
+        return linear_hip(rows.contiguous(), w, b, self.prec, w16, None if pad else key, self.packs)
 
     def emb1d(self, p, x):
         """Conv1d(k=1) + BatchNorm1d over (B, N) (model/model.py:254-259) on rows."""
         B, N, Cin = x.shape
         w16 = self.w16.get(p + ".0.weight")
-        y = self.linear_rows(x.reshape(B * N, Cin), self.t[p + ".0.weight"].flatten(1), self.t[p + ".0.bias"], w16.flatten(1) if w16 is not None else None)
+        y = self.linear_rows(x.reshape(B * N, Cin), self.t[p + ".0.weight"].flatten(1), self.t[p + ".0.bias"], w16.flatten(1) if w16 is not None else None, p + ".0.weight")
         return self.bn_l(y.view(B, N, -1), p + ".1", out16=False)  # (summed with the other embeddings: kept fp32)
 
     @staticmethod
@@ -352,17 +350,17 @@ class TrainGraph:
                 return w16.flatten(1) if w16 is not None else None
 
             loc = self.bn_l(self.linear_rows((gx / r).reshape(-1, 3), q("conv_l0_blocks", ".weight").flatten(1), q("conv_l0_blocks", ".bias"),
-                                             q16("conv_l0_blocks", ".weight")), p + ".bn_l0_blocks.%d" % i, out16=False)
+                                             q16("conv_l0_blocks", ".weight"), p + ".conv_l0_blocks.%d.weight" % i), p + ".bn_l0_blocks.%d" % i, out16=False)
             ft = self.bn_l(self.linear_rows(gf.reshape(-1, C), q("conv_f0_blocks", ".weight").flatten(1), q("conv_f0_blocks", ".bias"),
-                                            q16("conv_f0_blocks", ".weight")), p + ".bn_f0_blocks.%d" % i, out16=False)
+                                            q16("conv_f0_blocks", ".weight"), p + ".conv_f0_blocks.%d.weight" % i), p + ".bn_f0_blocks.%d" % i, out16=False)
             g = F.relu(loc + ft)
-            g = self.bn_l(self.linear_rows(g, q("conv_blocks", ".0.weight").flatten(1), q("conv_blocks", ".0.bias"), q16("conv_blocks", ".0.weight")),
+            g = self.bn_l(self.linear_rows(g, q("conv_blocks", ".0.weight").flatten(1), q("conv_blocks", ".0.bias"), q16("conv_blocks", ".0.weight"), p + ".conv_blocks.%d.0.weight" % i),
                           p + ".bn_blocks.%d.0" % i, relu=True)
             outs.append(g.view(B, Jn, 64, -1).max(2)[0])  # B x J x 128
         outs.append(node_feat)
         cat = torch.cat(outs, -1).reshape(B * Jn, -1)  # rows of 512
         wf16 = self.w16.get(p + ".fusion.0.weight")
-        y = self.linear_rows(cat, self.t[p + ".fusion.0.weight"].flatten(1), self.t[p + ".fusion.0.bias"], wf16.flatten(1) if wf16 is not None else None)
+        y = self.linear_rows(cat, self.t[p + ".fusion.0.weight"].flatten(1), self.t[p + ".fusion.0.bias"], wf16.flatten(1) if wf16 is not None else None, p + ".fusion.0.weight")
         return self.bn_l(y, p + ".fusion.1", relu=True, out16=False).view(B, Jn, -1)
 
     def bert_layer(self, p, h, heads=4):
@@ -396,9 +394,10 @@ class TrainGraph:
         qe = query + self.t[p + ".self_posembed.weight"][:T]
         ke = key + self.t[p + ".cross_posembed.weight"][:T]
         W, bqkv = self.t[p + ".multihead_attn.in_proj_weight"], self.t[p + ".multihead_attn.in_proj_bias"]
-        q = linear_hip(qe.contiguous(), W[:C], bqkv[:C], self.prec) * (float(hd) ** -0.5)
-        k = linear_hip(ke.contiguous(), W[C:2 * C], bqkv[C:2 * C], self.prec)
-        v = linear_hip(ke.contiguous(), W[2 * C:], bqkv[2 * C:], self.prec)
+        ipw = p + ".multihead_attn.in_proj_weight"
+        q = linear_hip(qe.contiguous(), W[:C], bqkv[:C], self.prec, None, ipw + ":q", self.packs) * (float(hd) ** -0.5)
+        k = linear_hip(ke.contiguous(), W[C:2 * C], bqkv[C:2 * C], self.prec, None, ipw + ":k", self.packs)
+        v = linear_hip(ke.contiguous(), W[2 * C:], bqkv[2 * C:], self.prec, None, ipw + ":v", self.packs)
         q = q.view(B, T, heads, hd).transpose(1, 2)
         k = k.view(B, T, heads, hd).transpose(1, 2)
         v = v.view(B, T, heads, hd).transpose(1, 2)

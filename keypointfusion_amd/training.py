@@ -309,6 +309,64 @@ class DevPack:
 _TDT = {"bf16": torch.bfloat16, "f16": torch.float16}
 
 
+class PackCache:
+    """Persistent kernel-layout operands of the training step's convolutions / Linears, refreshed from the parameters by ONE launch per
+    iteration (kpf_pack_conv_weights_multi): the state dict keeps the reference's OIHW layout and fp32 master values, the kernels read
+    buffers that live across steps.  An operand is registered under a key (parameter name + role) the first time it is needed — packed
+    on the spot by kpf_pack_conv_weight — and from the next `refresh()` on it is rewritten together with all the others at the start of
+    the forward.  Only operands whose source is parameter storage (stable address) are registered; derived weights (padded / concatenated
+    copies) are packed per use.  Mixed precision: the fp32 master is rounded to the 16-bit operand by the same kernel."""
+
+    def __init__(self):
+        self.entries = {}
+        self.table = None
+        self.total_blocks = 0
+        self.dirty = False
+
+    def get(self, key, weight, bias, mode, prec, **kw):
+        w = weight.detach()
+        ent = self.entries.get(key)
+        if ent is not None and ent["src"] == w.data_ptr() and ent["shape"] == tuple(w.shape) and ent["prec"] == prec:
+            pc = ent["pc"]
+        else:
+            assert w.is_contiguous(), "PackCache: a registered source must be a contiguous view of parameter storage"
+            pc = DevPack.packed(w, None, mode, prec, **kw)
+            w4 = w if w.dim() == 4 else w[:, :, None, None]
+            buf = pc.w if pc.w is not None else pc.w16
+            self.entries[key] = {"src": w.data_ptr(), "shape": tuple(w.shape), "prec": prec, "pc": pc, "keep": w,
+                                 "desc": (w.data_ptr(), buf.data_ptr(), w4.shape[0], w4.shape[1], w4.shape[2], w4.shape[3], mode,
+                                          kw.get("n_pad") or w4.shape[0], buf.shape[1], buf.shape[0], _KDT[w.dtype], _KDT[buf.dtype])}
+            self.dirty = True
+        pc.b = bias.detach().float().contiguous() if bias is not None else None
+        return pc
+
+    def refresh(self):
+        """Rewrite every registered operand from the current parameter values (call at the start of a forward)."""
+        if not self.entries:
+            return
+        from . import lib as L
+        lib = L.load()
+        st = torch.cuda.current_stream().cuda_stream
+        if self.dirty:
+            if torch.cuda.is_current_stream_capturing():  # no host -> device table upload inside a capture: one launch per operand
+                for ent in self.entries.values():
+                    d = ent["desc"]
+                    L.check(lib.kpf_pack_conv_weight(d[0], d[10], d[1], d[11], d[2], d[3], d[4], d[5], d[6], d[7], d[8], st), "kpf_pack_conv_weight")
+                return
+            arr = (L.PackDesc * len(self.entries))()
+            blk = 0
+            for i, ent in enumerate(self.entries.values()):
+                d = ent["desc"]
+                arr[i].src, arr[i].dst = d[0], d[1]
+                arr[i].N, arr[i].Cin, arr[i].KH, arr[i].KW, arr[i].mode, arr[i].n_pad, arr[i].Kp, arr[i].rows = d[2:10]
+                arr[i].src_dtype, arr[i].dst_dtype, arr[i].first_block = d[10], d[11], blk
+                blk += (d[8] * d[9] + 1023) // 1024
+            dev = next(iter(self.entries.values()))["keep"].device
+            self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+            self.total_blocks, self.dirty = blk, False
+        L.check(lib.kpf_pack_conv_weights_multi(self.table.data_ptr(), len(self.entries), self.total_blocks, st), "kpf_pack_conv_weights_multi")
+
+
 def _conv_any(pc, x4, prec):
     """engine.conv (fp32) or engine16.conv16 (bf16 / f16) on an NHWC tensor [B, H, W, C]; returns the NHWC output tensor."""
     from .engine import Act, conv
@@ -598,7 +656,7 @@ class Conv2dNHWC(torch.autograd.Function):
     Linear layers are the 1x1 case on a [rows, 1, 1, K] view."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, prec="f32", w16=None):
+    def forward(ctx, x, weight, bias, stride, pad, prec="f32", w16=None, key=None, cache=None):
         """prec "bf16" / "f16": operands rounded to 16 bits, fp32 accumulation on the 16-bit MFMA (kpf_conv2d_h16), 16-bit output;
         the weight stays the fp32 master copy and receives an fp32 gradient.  w16: the weight already rounded to the compute type
         (same shape; TrainGraph casts all of them once per step) — the packs are then built from it without per-layer casts."""
@@ -608,7 +666,11 @@ class Conv2dNHWC(torch.autograd.Function):
         assert Cw == Cin and Cin % (4 if prec == "f32" else 8) == 0, "Conv2dNHWC: input channels must match and be a multiple of 4 (8 for 16-bit)"
         patch = stride == KH == KW and pad == 0 and stride > 1
         use16 = prec != "f32" and w16 is not None
-        pc = DevPack.packed(w16 if use16 else weight, bias, 0, prec, stride=stride, pad=pad, patchify=patch)
+        if cache is not None and key is not None:  # persistent operand, refreshed once per iteration for all layers (PackCache)
+            pc = cache.get((key, 0), weight, bias, 0, prec, stride=stride, pad=pad, patchify=patch)
+        else:
+            pc = DevPack.packed(w16 if use16 else weight, bias, 0, prec, stride=stride, pad=pad, patchify=patch)
+        ctx.pack = (key, cache)
         xc = x.float() if prec == "f32" else x.to(_TDT[prec])  # the operand as the GEMM sees it — also what the weight gradient multiplies
         y = _conv_any(pc, xc, prec)
         ctx.save_for_backward(xc, weight)
@@ -632,7 +694,7 @@ class Conv2dNHWC(torch.autograd.Function):
             npad = (N + cmul - 1) // cmul * cmul
             dy_in = dy if npad == N else F.pad(dy, (0, npad - N))  # the kernel needs whole channel groups: zero channels on dY (and zero weight rows)
             if patch:  # dX[b, oy*s+ky, ox*s+kx, c] = sum_n dY[b,oy,ox,n] W[n,c,ky,kx]: rows of a GEMM, then un-shuffle
-                g = _conv_any(DevPack.packed(wsrc, None, 2, prec, n_pad=npad), dy_in, prec).view(B, OH, OW, KH, KW, Cin)
+                g = _conv_any(_dgrad_pack(ctx, wsrc, 2, prec, n_pad=npad), dy_in, prec).view(B, OH, OW, KH, KW, Cin)
                 dx = g.permute(0, 1, 3, 2, 4, 5).reshape(B, OH * KH, OW * KW, Cin)
                 if dx.shape[1] != H or dx.shape[2] != W:  # rows / columns the strided convolution never read
                     dx = F.pad(dx, (0, 0, 0, W - dx.shape[2], 0, H - dx.shape[1]))
@@ -645,13 +707,13 @@ class Conv2dNHWC(torch.autograd.Function):
                     dil = dy_in.new_zeros(B, hz, wz, npad)
                     dil[:, :(OH - 1) * stride + 1:stride, :(OW - 1) * stride + 1:stride] = dy_in
                     dy_in = dil
-                dx = _conv_any(DevPack.packed(wsrc, None, 1, prec, pad=pad, n_pad=npad), dy_in, prec).view(B, H, W, Cin)
+                dx = _conv_any(_dgrad_pack(ctx, wsrc, 1, prec, pad=pad, n_pad=npad), dy_in, prec).view(B, H, W, Cin)
             dx = dx.to(ctx.x_dtype)
         if ctx.needs_input_grad[1] and Cin % 4 == 0 and N % 4 == 0:
             # hand-written split-K weight gradient (fp32 products and accumulation in every precision mode: the master weight's
             # gradient is not rounded to 16 bits; 16-bit dY / X are read as stored), bias gradient from the same pass
             dw, db = conv_wgrad_hip(dy, x, weight.shape, stride, pad, has_bias and ctx.needs_input_grad[2])
-            return dx, dw, db, None, None, None, None
+            return dx, dw, db, None, None, None, None, None, None
         if ctx.needs_input_grad[1]:
             xw = x if prec == "f32" else x.to(_TDT[prec])  # weight gradient in the compute precision, handed to the fp32 master weight
             dyw = dy if prec == "f32" else dy.to(_TDT[prec])
@@ -661,18 +723,25 @@ class Conv2dNHWC(torch.autograd.Function):
                 dw = torch.nn.grad.conv2d_weight(xw.permute(0, 3, 1, 2), weight.shape, dyw.permute(0, 3, 1, 2), stride=stride, padding=pad).float()
         if has_bias and ctx.needs_input_grad[2]:
             db = dy.float().view(-1, N).sum(0)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
-def conv2d_nhwc(x, weight, bias=None, stride=1, pad=0, prec="f32", w16=None):
-    return Conv2dNHWC.apply(x, weight, bias, stride, pad, prec, w16)
+def _dgrad_pack(ctx, wsrc, mode, prec, **kw):
+    key, cache = ctx.pack
+    if cache is not None and key is not None:
+        return cache.get((key, mode), wsrc, None, mode, prec, **kw)
+    return DevPack.packed(wsrc, None, mode, prec, **kw)
 
 
-def linear_hip(x, weight, bias=None, prec="f32", w16=None):
+def conv2d_nhwc(x, weight, bias=None, stride=1, pad=0, prec="f32", w16=None, key=None, cache=None):
+    return Conv2dNHWC.apply(x, weight, bias, stride, pad, prec, w16, key, cache)
+
+
+def linear_hip(x, weight, bias=None, prec="f32", w16=None, key=None, cache=None):
     """nn.Linear on rows [..., K] through the same Function (a 1x1 convolution over a [rows, 1, 1, K] view)."""
     K = x.shape[-1]
     y = Conv2dNHWC.apply(x.reshape(-1, 1, 1, K), weight.reshape(weight.shape[0], K, 1, 1), bias, 1, 0, prec,
-                         w16.reshape(weight.shape[0], K, 1, 1) if w16 is not None else None)
+                         w16.reshape(weight.shape[0], K, 1, 1) if w16 is not None else None, key, cache)
     return y.view(*x.shape[:-1], weight.shape[0])
 
 
