@@ -165,30 +165,46 @@ __global__ __launch_bounds__(256) void row_gather_fwd_kernel(const float* __rest
 }
 
 // backward:  dsrc[b][p][:] = sum over entries e (ascending) with idx[b][e] == p of w[b][e] * dout[b][e / G][:]
-// Two kernels.  (1) row_gather_invert_kernel, one wave per image: a STABLE counting sort of the entry numbers by source row — counts
-// by integer LDS atomics, an exclusive scan, then the entries are ranked 64 at a time in entry order: the wave loops over the distinct
-// rows present among its 64 lanes (readfirstlane + ballot), a lane's slot is its row's running base + the number of lower lanes with the
-// same row.  The lists therefore hold ascending entry numbers whatever the timing: the summation order below is fixed.
+// Two kernels.  (1) row_gather_invert_kernel, one 16-wave workgroup per image: a STABLE counting sort of the entry numbers by source row.
+// Each wave owns a contiguous range of entries: per-wave counts by integer LDS atomics, a workgroup scan that gives every (wave, row) its
+// first slot (lower waves first), then each wave ranks its range 64 entries at a time in entry order — the loop visits the distinct rows
+// among its 64 lanes (shuffle + ballot), a lane's slot is its row's next free slot + the number of lower lanes with the same row.
+// The lists therefore hold ascending entry numbers whatever the timing: the summation order below is fixed.
 // (2) row_gather_accum_kernel, one wave per source row: lanes over channel quads; with C <= 128 the two half-waves take alternate list
 // positions (two accumulators, added lower + upper at the end: still one fixed order).  E <= 8192 entries, P <= 2048 rows per image.
 constexpr int GATHER_MAX_E = 8192, GATHER_MAX_P = 2048;
 
-__global__ __launch_bounds__(64) void row_gather_invert_kernel(const int* __restrict__ idx, int* __restrict__ start, int* __restrict__ list, int P, int E) {
-  __shared__ int cnt[GATHER_MAX_P + 1];
-  const int b = blockIdx.x, lane = threadIdx.x;
+constexpr int INV_W = 16;  // waves per image in the inversion
+__global__ __launch_bounds__(64 * INV_W) void row_gather_invert_kernel(const int* __restrict__ idx, int* __restrict__ start, int* __restrict__ list, int P,
+                                                                      int E) {
+  extern __shared__ int inv_lds[];  // cnt[INV_W][P] (per-wave counts, then per-wave next-free slots) | tot[P] | wsum[INV_W]
+  int* cnt = inv_lds;
+  int* tot = inv_lds + INV_W * P;
+  int* wsum = tot + P;  // (no static LDS next to the dynamic block: the opt-in above 64 KB covers the dynamic size only)
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int* ib = idx + (long)b * E;
   int* sb = start + (long)b * (P + 1);
   int* lb = list + (long)b * E;
-  for (int p = lane; p <= P; p += 64) cnt[p] = 0;
+  const int seg = ((E + INV_W - 1) / INV_W + 63) / 64 * 64;  // entries per wave: a contiguous range, whole 64-chunks
+  const int e_lo = wave * seg, e_hi = min(E, e_lo + seg);
+  for (int i = tid; i < INV_W * P; i += 64 * INV_W) cnt[i] = 0;
   __syncthreads();
-  for (int e = lane; e < E; e += 64) atomicAdd(&cnt[ib[e]], 1);  // integer counts: order-independent
+  int* mine = cnt + wave * P;
+  for (int e = e_lo + lane; e < e_hi; e += 64) atomicAdd(&mine[ib[e]], 1);  // integer counts: order-independent
   __syncthreads();
-  // exclusive scan over P counts by one wave: lane owns a contiguous range
-  const int per = (P + 63) / 64;
+  for (int p = tid; p < P; p += 64 * INV_W) {
+    int t = 0;
+#pragma unroll
+    for (int w = 0; w < INV_W; ++w) t += cnt[w * P + p];
+    tot[p] = t;
+  }
+  __syncthreads();
+  // exclusive scan of tot[0..P) by the whole workgroup: thread t owns the contiguous range [t*per, (t+1)*per)
+  const int per = (P + 64 * INV_W - 1) / (64 * INV_W);
   int local = 0;
   for (int j = 0; j < per; ++j) {
-    const int p = lane * per + j;
-    if (p < P) local += cnt[p];
+    const int p = tid * per + j;
+    if (p < P) local += tot[p];
   }
   int incl = local;
 #pragma unroll
@@ -196,21 +212,31 @@ __global__ __launch_bounds__(64) void row_gather_invert_kernel(const int* __rest
     const int v = __shfl_up(incl, o, 64);
     if (lane >= o) incl += v;
   }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
   int base = incl - local;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
   for (int j = 0; j < per; ++j) {
-    const int p = lane * per + j;
+    const int p = tid * per + j;
     if (p < P) {
-      const int c = cnt[p];
-      cnt[p] = base;  // from here on: the next free slot of row p
       sb[p] = base;
-      base += c;
+      int run = base;
+#pragma unroll
+      for (int w = 0; w < INV_W; ++w) {  // wave w's entries of row p go behind those of the waves before it (they hold lower entry numbers)
+        const int c = cnt[w * P + p];
+        cnt[w * P + p] = run;
+        run += c;
+      }
+      base = run;
     }
   }
-  if (lane == 63) sb[P] = E;
+  if (tid == 0) sb[P] = E;
   __syncthreads();
-  for (int e0 = 0; e0 < E; e0 += 64) {  // 64 entries at a time, in entry order
+  // every wave ranks its own range, 64 entries at a time in entry order: the loop visits the distinct rows among the 64 lanes; a lane's
+  // slot is its row's next free slot + the number of lower lanes with the same row (only this wave touches cnt[wave][*] from here on)
+  for (int e0 = e_lo; e0 < e_hi; e0 += 64) {
     const int e = e0 + lane;
-    const bool valid = e < E;
+    const bool valid = e < e_hi;
     const int key = valid ? ib[e] : -1;
     unsigned long long todo = __ballot(valid);
     int slot = 0;
@@ -218,11 +244,12 @@ __global__ __launch_bounds__(64) void row_gather_invert_kernel(const int* __rest
       const int lead = __ffsll((long long)todo) - 1;
       const int k = __shfl(key, lead, 64);
       const unsigned long long same = __ballot(valid && key == k);
-      const int first = cnt[k];  // (every lane reads the same word: broadcast)
-      if (key == k && valid) slot = first + __popcll(same & ((1ull << lane) - 1ull));
-      __syncthreads();  // all lanes have read cnt[k] before it moves
-      if (lane == lead) cnt[k] = first + __popcll(same);
-      __syncthreads();
+      const int first = mine[k];  // (every lane reads the same word: broadcast)
+      if (valid && key == k) slot = first + __popcll(same & ((1ull << lane) - 1ull));
+      __builtin_amdgcn_wave_barrier();
+      if (lane == lead) mine[k] = first + __popcll(same);
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the LDS write has landed before the next iteration's read
+      __builtin_amdgcn_wave_barrier();
       todo &= ~same;
     }
     if (valid) lb[slot] = e;
@@ -340,7 +367,11 @@ extern "C" int kpf_row_gather_bwd_f32(const float* dout, const int* idx, const f
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int* start = ws;
   int* list = ws + (long)B * (P + 1);
-  hipLaunchKernelGGL(row_gather_invert_kernel, dim3(B), dim3(64), 0, st, idx, start, list, P, (int)E);
+  const size_t inv_lds = (size_t)(INV_W * P + P + INV_W) * sizeof(int);
+  static std::atomic<bool> lds_opt_in[KPF_MAX_DEVICES];
+  KPF_REQUIRE(inv_lds <= 64 * 1024 || kpf_raise_lds_limit(reinterpret_cast<const void*>(&row_gather_invert_kernel), lds_opt_in),
+              "kpf_row_gather_bwd_f32: cannot raise the dynamic LDS limit");
+  hipLaunchKernelGGL(row_gather_invert_kernel, dim3(B), dim3(64 * INV_W), inv_lds, st, idx, start, list, P, (int)E);
   int rc = kpf_check_launch("kpf_row_gather_bwd_f32 (invert)");
   if (rc != KPF_OK) return rc;
   hipLaunchKernelGGL(row_gather_accum_kernel, dim3(grid_for((long)B * P, 4, 256 * 32)), dim3(256), 0, st, dout, start, list, w, dsrc, B, P, (int)E, G, C / 4);
