@@ -466,6 +466,33 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const kpf_pack_
     else hi = mid - 1;
   }
   const kpf_pack_desc d = descs[lo];
+  if (d.mode == 1 && d.KH * d.KW == 1 && d.src_dtype == KPF_DT_F32) {
+    // 1x1 data-gradient operand = the transpose of the weight: 32 x 32 tiles through LDS, both sides coalesced
+    // (blocks of such a descriptor: ceil(rows / 32) * ceil(Kp / 32), see training.PackCache)
+    __shared__ float tl[32][33];
+    const int tiles_k = (d.Kp + 31) / 32;
+    const int t = b - d.first_block, tr = t / tiles_k, tc = t - tr * tiles_k;
+    const int x = threadIdx.x & 31, y8 = threadIdx.x >> 5;
+    const float* w = static_cast<const float*>(d.src);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int n = tc * 32 + y8 + 8 * p, c = tr * 32 + x;  // read w[n][c]: c fastest
+      tl[y8 + 8 * p][x] = (n < d.N && c < d.Cin) ? w[(long)n * d.Cin + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int c = tr * 32 + y8 + 8 * p, k = tc * 32 + x;  // write dst[c][k = n]: k fastest
+      if (c < d.rows && k < d.Kp) {
+        const float v = tl[x][y8 + 8 * p];
+        const long i = (long)c * d.Kp + k;
+        if (d.dst_dtype == KPF_DT_F32) static_cast<float*>(d.dst)[i] = v;
+        else if (d.dst_dtype == KPF_DT_BF16) static_cast<bf16_t*>(d.dst)[i] = (bf16_t)v;
+        else static_cast<f16_t*>(d.dst)[i] = (f16_t)v;
+      }
+    }
+    return;
+  }
   const long total = (long)d.rows * d.Kp;
   for (long i = (long)(b - d.first_block) * 1024 + threadIdx.x; i < total && i < (long)(b - d.first_block + 1) * 1024; i += 256) {
     const int k = (int)(i % d.Kp), row = (int)(i / d.Kp);

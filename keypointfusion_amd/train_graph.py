@@ -141,7 +141,7 @@ class TrainGraph:
 
     def convnext_block(self, p, x):
         c = x.shape[-1]
-        y = dwconv7_nhwc(x.float(), self.t[p + ".dwconv.weight"], self.t[p + ".dwconv.bias"])
+        y = dwconv7_nhwc(x.float(), self.t[p + ".dwconv.weight"], self.t[p + ".dwconv.bias"], p + ".dwconv.weight", self.packs)
         y = F.layer_norm(y, (c,), self.t[p + ".norm.weight"], self.t[p + ".norm.bias"], 1e-6)
         y = F.gelu(self.linear(y, p + ".pwconv1.weight", p + ".pwconv1.bias"))
         y = self.linear(y, p + ".pwconv2.weight", p + ".pwconv2.bias")

@@ -263,7 +263,7 @@ class DevPack:
             self.KH, self.KW, self.Cin, self.sh, self.sw, self.ph, self.pw, self.merge = KH, KW, n_pad, 1, 1, KH - 1 - pad, KW - 1 - pad, 1
             rows, K = Cin, KH * KW * n_pad
             self.N = Cin
-        else:  # patchify: dY rows @ [(ky,kx,c)][n]
+        else:  # mode 2 / 3, patchify: dY rows @ [(ky,kx,c)][n] (Cin = 1: the depthwise tap table [KH*KW][C], mode 3 mirrored)
             self.KH, self.KW, self.Cin, self.sh, self.sw, self.ph, self.pw, self.merge = 1, 1, n_pad, 1, 1, 0, 0, 1
             rows, K = KH * KW * Cin, n_pad
             self.N = rows
@@ -360,7 +360,10 @@ class PackCache:
                 arr[i].src, arr[i].dst = d[0], d[1]
                 arr[i].N, arr[i].Cin, arr[i].KH, arr[i].KW, arr[i].mode, arr[i].n_pad, arr[i].Kp, arr[i].rows = d[2:10]
                 arr[i].src_dtype, arr[i].dst_dtype, arr[i].first_block = d[10], d[11], blk
-                blk += (d[8] * d[9] + 1023) // 1024
+                if d[6] == 1 and d[4] * d[5] == 1 and d[10] == 0:  # 1x1 data-gradient operand: 32 x 32 transpose tiles (csrc/kpf_train.hip)
+                    blk += ((d[9] + 31) // 32) * ((d[8] + 31) // 32)
+                else:
+                    blk += (d[8] * d[9] + 1023) // 1024
             dev = next(iter(self.entries.values()))["keep"].device
             self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
             self.total_blocks, self.dirty = blk, False
@@ -414,13 +417,14 @@ class DwConv7NHWC(torch.autograd.Function):
     forward kpf_dwconv7_f32; backward: dX = the same kernel on dY with mirrored taps, dW / db = kpf_dwconv7_wgrad_f32."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, key=None, cache=None):
         from . import lib as L
         lib = L.load()
         x = x.contiguous()
         B, H, W, Cc = x.shape
         assert x.dtype == torch.float32 and Cc % 4 == 0
-        wt = _dw_taps(weight, False)  # [49][C]
+        ctx.pack = (key, cache) if (cache is not None and key is not None and Cc % 32 == 0) else (None, None)
+        wt = _dw_taps(weight, False, ctx.pack)  # [49][C]
         y = torch.empty_like(x)
         L.check(lib.kpf_dwconv7_f32(x.data_ptr(), wt.data_ptr(), bias.detach().contiguous().data_ptr(), y.data_ptr(), B, H, W, Cc,
                                     torch.cuda.current_stream().cuda_stream), "kpf_dwconv7_f32")
@@ -437,7 +441,7 @@ class DwConv7NHWC(torch.autograd.Function):
         st = torch.cuda.current_stream().cuda_stream
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wf = _dw_taps(weight, True)  # taps mirrored, [49][C]
+            wf = _dw_taps(weight, True, ctx.pack)  # taps mirrored, [49][C]
             dx = torch.empty_like(x)
             zb = _zero_bias(Cc, x.device)
             L.check(lib.kpf_dwconv7_f32(dy.data_ptr(), wf.data_ptr(), zb.data_ptr(), dx.data_ptr(), B, H, W, Cc, st), "kpf_dwconv7_f32")
@@ -448,7 +452,7 @@ class DwConv7NHWC(torch.autograd.Function):
             db = torch.empty(Cc, device=x.device, dtype=torch.float32)
             L.check(lib.kpf_dwconv7_wgrad_f32(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nws, B, H, W, Cc, st),
                     "kpf_dwconv7_wgrad_f32")
-        return dx, dw, db
+        return dx, dw, db, None, None
 
 
 _ZERO_BIAS = {}
@@ -464,11 +468,16 @@ def _zero_bias(n, device):
     return z
 
 
-def _dw_taps(weight, mirrored):
-    """Depthwise weight [C, 1, 7, 7] -> the kernel's tap table [49][C] (mirrored: the data gradient's), one launch."""
+def _dw_taps(weight, mirrored, pack=(None, None)):
+    """Depthwise weight [C, 1, 7, 7] -> the kernel's tap table [49][C] (mirrored: the data gradient's): a persistent operand of the
+    PackCache when the layer is registered there, one launch otherwise."""
     from . import lib as L
     w = weight.detach().contiguous()
     Cc = w.shape[0]
+    key, cache = pack
+    if cache is not None:
+        mode = 3 if mirrored else 2
+        return cache.get((key, mode), w, None, mode, "f32", n_pad=Cc).w
     kp = Cc
     out = torch.empty(49, kp, device=w.device, dtype=torch.float32)
     L.check(L.load().kpf_pack_conv_weight(w.data_ptr(), 0, out.data_ptr(), 0, Cc, 1, 7, 7, 3 if mirrored else 2, Cc, kp,
@@ -476,8 +485,8 @@ def _dw_taps(weight, mirrored):
     return out
 
 
-def dwconv7_nhwc(x, weight, bias):
-    return DwConv7NHWC.apply(x, weight, bias)
+def dwconv7_nhwc(x, weight, bias, key=None, cache=None):
+    return DwConv7NHWC.apply(x, weight, bias, key, cache)
 
 
 _KDT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}  # KPF_DT_* of include/kpf.h
