@@ -17,7 +17,7 @@ One JSON line is printed by rank 0 with, besides the contract fields:
                  launches in one step / summed device time of those launches (HIP events recorded on the launch stream in an
                  instrumented pass after the timed region, both backbones on ONE stream), against the dense f32-input MFMA peak
                  157.3 TFLOP/s.  `traffic` = HBM bytes per launch from the rocprofv3 PMC passes of this same command, collected
-                 offline and committed (profiles/r02_traffic.json, tools/collect_traffic.py): `traffic_source` says so.
+                 offline and committed (profiles/r03_traffic.json, tools/collect_traffic.py): `traffic_source` says so.
   split_f16x3  : SECONDARY record, not the headline and not IEEE fp32: the same workload with KPF_GEMM=split (the ConvNeXt-block GEMMs
                  as 3 x f16 MFMA on hi/lo-split operands with a pack-time range proof; everything else stays on the f32 MFMA).
   cpu_baseline : the CPU oracle (oracle/kpf_oracle.py, torch-CPU fp32 = the reference's own arithmetic) on the host
@@ -300,7 +300,7 @@ def main():
                 for name, e0, e1, fl_i, nb, shp in recs:
                     ms = e0.elapsed_time(e1)
                     f.write("%s,%d,%d,%d,%d,%d,%.4f,%.1f\n" % ((name,) + tuple(shp) + (ms, fl_i / ms / 1e9)))
-        roofline = roofline_of(recs, ms_per_step, "r02_traffic.json" if args.gemm == "f32" else "r02_traffic_split.json")
+        roofline = roofline_of(recs, ms_per_step, "r03_traffic.json" if args.gemm == "f32" else "r03_traffic_split.json")
 
     # ---- secondary record: split (3 x f16) arithmetic where a range proof exists; NOT the headline, NOT IEEE fp32 ----
     split_rec = None
@@ -315,7 +315,7 @@ def main():
                          "note": "SECONDARY, not IEEE fp32: ConvNeXt-block GEMMs as 3 x v_mfma_f32_16x16x32_f16 on f16 hi+lo operands (22-bit "
                                  "significands, f16 range, operands proven in range at pack time and pre-scaled), fp32 accumulate; all "
                                  "other GEMMs on the f32-input MFMA"}
-            split_rec["roofline"] = roofline_of(instrumented(), dts / args.steps * 1e3, "r02_traffic_split.json")
+            split_rec["roofline"] = roofline_of(instrumented(), dts / args.steps * 1e3, "r03_traffic_split.json")
         finally:
             E.GEMM_MODE = args.gemm
             fresh_plan()

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Collects the rocprofv3 evidence of a round on the GPU box (run through gpurun from the repo root):  bash tools/profile_round.sh r02
+# Collects the rocprofv3 evidence of a round on the GPU box (run through gpurun from the repo root):  bash tools/profile_round.sh r03
 # kernel-trace statistics of the headline command (both backbones on one stream, so per-kernel durations are each kernel's own) and the
 # two PMC passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass) of the same command; summaries land in gpurun_out/<tag>_*.
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
@@ -19,6 +19,8 @@ for W in full128 full128_bf16 cnb512_f16; do
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_train128 -- python3 $ROOT/bench.py --workload train128 --no-cpu-baseline --steps 10 --warmup 3 > $OUT/prof_${TAG}_train128.log 2>&1
 cp $(find $OUT/prof_${TAG}_train128 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_train128_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_train128_bf16 -- python3 $ROOT/bench.py --workload train128_bf16 --no-cpu-baseline --steps 10 --warmup 3 > $OUT/prof_${TAG}_train128_bf16.log 2>&1
+cp $(find $OUT/prof_${TAG}_train128_bf16 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_train128_bf16_kernel_stats.csv
 # the bench lines of the same build, without the profiler
 cd $ROOT
 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
@@ -27,4 +29,6 @@ for W in full128 full128_bf16 cnb512_f16 train128 train128_bf16; do
 done
 # keep the merge small: the raw traces stay on the box
 for d in $OUT/prof_${TAG}_* $OUT/pmc_${TAG}_fetch $OUT/pmc_${TAG}_write; do [ -d "$d" ] && rm -rf "$d"; done
+python3 tools/shape_table.py > $OUT/${TAG}_shape_table.txt 2>/dev/null
+[ -x tools/bin/mfma_issue_rate2 ] && tools/bin/mfma_issue_rate2 > $OUT/${TAG}_mfma_issue_rate2.txt
 ls -la $OUT | grep ${TAG}_
