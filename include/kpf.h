@@ -335,6 +335,18 @@ long kpf_row_gather_ws_ints(int B, int P, int R, int G);
 int kpf_row_gather_bwd_f32(const float* dout, const int* idx, const float* w, float* dsrc, int* ws, long ws_ints, int B, int P, int R, int G, int C,
                            void* stream);
 
+/* Training: LayerNorm over the last axis (nn.LayerNorm / F.layer_norm of convNeXT/convnext.py:43,199-214 and the fusion head's post-LN
+ * layers) and GELU(erf) (convNeXT/convnext.py:33), forward and backward.  x [rows][C] fp32, C % 4 == 0, C <= 1024; y in y_dtype (fp32 or the
+ * 16-bit operand type of the following GEMM); mean / rstd [rows] are kept for the backward.  backward: dx fp32, dw / db [C] column sums over
+ * all rows added in a fixed order through ws (>= kpf_ln_ws_floats(rows, C) floats).  GELU: element-wise on n % 4 == 0 elements of `dtype`. */
+long kpf_ln_ws_floats(long rows, int C);
+int kpf_ln_train_forward(const float* x, const float* w, const float* b, void* y, int y_dtype, float* mean, float* rstd, long rows, int C, float eps,
+                         void* stream);
+int kpf_ln_train_backward(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd, const float* w, float* dx, float* dw,
+                          float* db, float* ws, long ws_floats, long rows, int C, void* stream);
+int kpf_gelu_forward(const void* x, void* y, int dtype, long n, void* stream);
+int kpf_gelu_backward(const void* dy, const void* x, void* dx, int dtype, long n, void* stream);
+
 /* Training: one-launch packing of a reference-layout weight w [N][Cin][KH][KW] (src_dtype: KPF_DT_F32 master, or a 16-bit copy) into an
  * operand of kpf_conv2d_f32 / _h16 (dst_dtype; fp32 -> 16-bit rounds to nearest even), rows zero-padded to Kp:
  *   mode 0  forward rows        dst [n_pad][Kp], k = (ky, kx, c)

@@ -512,3 +512,242 @@ extern "C" int kpf_pack_conv_weights_multi(const kpf_pack_desc* descs_device, in
   hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(total_blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), descs_device, ndesc);
   return kpf_check_launch("kpf_pack_conv_weights_multi");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm over the last axis and GELU(erf), forward and backward, for the training step (convNeXT/convnext.py:43-46, 199-214; the
+// post-LN BERT / decoder layers of the fusion head).  LayerNorm: one wave per row, a lane holds up to 4 channel quads (C <= 1024), two-pass
+// statistics in registers (mean, then centred squares) like ATen; the backward's input gradient needs two more wave reductions per row,
+// the parameter gradients are column sums over all rows: every workgroup adds its rows in registers (fixed row order), its four waves
+// combine through LDS in wave order, and a second kernel adds the per-workgroup partials in workgroup order — no atomics, two launches
+// (ATen: three).  x / dy / dx fp32; y in fp32 or the 16-bit storage type of the following GEMM (no separate cast pass).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int LN_MAXQ = 4;  // channel quads per lane: C <= 64 * 4 * LN_MAXQ = 1024
+
+template <typename TY>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, TY* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, long rows, int C4, float eps) {
+  const int lane = threadIdx.x & 63;
+  const float invC = 1.0f / (float)(4 * C4);
+  for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * 4) {
+    f32x4 v[LN_MAXQ];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXQ; ++i) {
+      const int q = lane + 64 * i;
+      v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (q < C4) v[i] = kpf_ld4(x + r * C4 * 4 + 4 * q);
+      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float m = wave_sum(s) * invC;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXQ; ++i)
+      if (lane + 64 * i < C4)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = v[i][e] - m;
+          sq = fmaf(d, d, sq);
+        }
+    const float rs = 1.0f / sqrtf(wave_sum(sq) * invC + eps);
+    if (lane == 0) {
+      mean[r] = m;
+      rstd[r] = rs;
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAXQ; ++i) {
+      const int q = lane + 64 * i;
+      if (q < C4) {
+        const f32x4 g = kpf_ld4(w + 4 * q), be = kpf_ld4(b + 4 * q);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - m) * rs * g[e] + be[e];
+        kpf_st4(y + r * C4 * 4 + 4 * q, o);
+      }
+    }
+  }
+}
+
+// grid.x workgroups, each owning the rows r = blockIdx.x*4 + wave, + gridDim.x*4, ...  part: [gridDim.x][2][C] (dw | db)
+template <typename TD>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ w, float* __restrict__ dx, float* __restrict__ part,
+                                                     long rows, int C4) {
+  extern __shared__ float ln_lds[];  // [4 waves][2][C]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C = 4 * C4;
+  const float invC = 1.0f / (float)C;
+  f32x4 aw[LN_MAXQ], ab[LN_MAXQ], g[LN_MAXQ];
+#pragma unroll
+  for (int i = 0; i < LN_MAXQ; ++i) {
+    aw[i] = ab[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    g[i] = lane + 64 * i < C4 ? kpf_ld4(w + 4 * (lane + 64 * i)) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+    const float m = mean[r], rs = rstd[r];
+    f32x4 xh[LN_MAXQ], d[LN_MAXQ];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXQ; ++i) {
+      const int q = lane + 64 * i;
+      xh[i] = d[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (q < C4) {
+        const f32x4 xv = kpf_ld4(x + r * C + 4 * q);
+        d[i] = kpf_ld4(dy + r * C + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[i][e] = (xv[e] - m) * rs;
+          const float gd = d[i][e] * g[i][e];
+          s1 += gd;
+          s2 = fmaf(gd, xh[i][e], s2);
+          aw[i][e] = fmaf(d[i][e], xh[i][e], aw[i][e]);
+          ab[i][e] += d[i][e];
+        }
+      }
+    }
+    const float m1 = wave_sum(s1) * invC, m2 = wave_sum(s2) * invC;
+#pragma unroll
+    for (int i = 0; i < LN_MAXQ; ++i) {
+      const int q = lane + 64 * i;
+      if (q < C4) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rs * (d[i][e] * g[i][e] - m1 - xh[i][e] * m2);
+        kpf_st4(dx + r * C + 4 * q, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < LN_MAXQ; ++i) {
+    const int q = lane + 64 * i;
+    if (q < C4) {
+      kpf_st4(ln_lds + (wave * 2 + 0) * C + 4 * q, aw[i]);
+      kpf_st4(ln_lds + (wave * 2 + 1) * C + 4 * q, ab[i]);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const int which = i / C, c = i - which * C;
+    float s = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) s += ln_lds[(wv * 2 + which) * C + c];
+    part[((long)blockIdx.x * 2 + which) * C + c] = s;
+  }
+}
+
+// 64 columns x 8 segments per workgroup: segment g adds the partials of workgroups g*per .. (g+1)*per - 1 in order, the eight segment
+// sums are added in segment order through LDS (fixed order, 8 x fewer dependent loads per thread than one thread per column)
+__global__ __launch_bounds__(512) void ln_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nblk, int C) {
+  __shared__ float seg[8][64];
+  const int col = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + col;
+  const int per = (nblk + 7) / 8;
+  float s = 0.f;
+  if (i < 2 * C) {
+    const int which = i / C, c = i - which * C;
+    const int b1 = min(nblk, (g + 1) * per);
+    for (int bk = g * per; bk < b1; ++bk) s += part[((long)bk * 2 + which) * C + c];
+  }
+  seg[g][col] = s;
+  __syncthreads();
+  if (g == 0 && i < 2 * C) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += seg[k][col];
+    const int which = i / C, c = i - which * C;
+    (which ? db : dw)[c] = t;
+  }
+}
+
+__device__ __forceinline__ float gelu_exact(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad(float v) {
+  const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+  return cdf + v * 0.3989422804014327f * __expf(-0.5f * v * v);
+}
+
+template <typename TA>
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const TA* __restrict__ x, TA* __restrict__ y, long n4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 v = kpf_ld4(x + 4 * i);
+    kpf_st4(y + 4 * i, f32x4{gelu_exact(v[0]), gelu_exact(v[1]), gelu_exact(v[2]), gelu_exact(v[3])});
+  }
+}
+template <typename TA>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const TA* __restrict__ dy, const TA* __restrict__ x, TA* __restrict__ dx, long n4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 v = kpf_ld4(x + 4 * i), g = kpf_ld4(dy + 4 * i);
+    kpf_st4(dx + 4 * i, f32x4{g[0] * gelu_grad(v[0]), g[1] * gelu_grad(v[1]), g[2] * gelu_grad(v[2]), g[3] * gelu_grad(v[3])});
+  }
+}
+
+inline int ln_blocks(long rows) {
+  long g = (rows + 3) / 4;
+  return (int)(g < 1 ? 1 : (g > 256 ? 256 : g));
+}
+}  // namespace
+
+extern "C" long kpf_ln_ws_floats(long rows, int C) { return (long)ln_blocks(rows) * 2 * C; }
+
+extern "C" int kpf_ln_train_forward(const float* x, const float* w, const float* b, void* y, int y_dtype, float* mean, float* rstd, long rows, int C, float eps,
+                                    void* stream) {
+  KPF_REQUIRE(x && w && b && y && mean && rstd && rows > 0 && C > 0 && C % 4 == 0 && C <= 256 * LN_MAXQ, "kpf_ln_train_forward: bad arguments (C %% 4 == 0, C <= 1024)");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid(grid_for(rows, 4, 256 * 16));
+  if (y_dtype == KPF_DT_F32) hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, dim3(256), 0, st, x, w, b, static_cast<float*>(y), mean, rstd, rows, C / 4, eps);
+  else if (y_dtype == KPF_DT_BF16) hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, x, w, b, static_cast<bf16_t*>(y), mean, rstd, rows, C / 4, eps);
+  else if (y_dtype == KPF_DT_F16) hipLaunchKernelGGL(ln_fwd_kernel<f16_t>, grid, dim3(256), 0, st, x, w, b, static_cast<f16_t*>(y), mean, rstd, rows, C / 4, eps);
+  else {
+    kpf_set_error("kpf_ln_train_forward: unknown y_dtype %d", y_dtype);
+    return KPF_EINVAL;
+  }
+  return kpf_check_launch("kpf_ln_train_forward");
+}
+
+extern "C" int kpf_ln_train_backward(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd, const float* w, float* dx, float* dw,
+                                     float* db, float* ws, long ws_floats, long rows, int C, void* stream) {
+  KPF_REQUIRE(dy && x && mean && rstd && w && dx && dw && db && ws && rows > 0 && C > 0 && C % 4 == 0 && C <= 256 * LN_MAXQ, "kpf_ln_train_backward: bad arguments");
+  const int nblk = ln_blocks(rows);
+  KPF_REQUIRE(ws_floats >= (long)nblk * 2 * C, "kpf_ln_train_backward: workspace too small");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const size_t lds = (size_t)8 * C * sizeof(float);
+  if (dy_dtype == KPF_DT_F32) hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nblk), dim3(256), lds, st, static_cast<const float*>(dy), x, mean, rstd, w, dx, ws, rows, C / 4);
+  else if (dy_dtype == KPF_DT_BF16) hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(nblk), dim3(256), lds, st, static_cast<const bf16_t*>(dy), x, mean, rstd, w, dx, ws, rows, C / 4);
+  else if (dy_dtype == KPF_DT_F16) hipLaunchKernelGGL(ln_bwd_kernel<f16_t>, dim3(nblk), dim3(256), lds, st, static_cast<const f16_t*>(dy), x, mean, rstd, w, dx, ws, rows, C / 4);
+  else {
+    kpf_set_error("kpf_ln_train_backward: unknown dy_dtype %d", dy_dtype);
+    return KPF_EINVAL;
+  }
+  int rc = kpf_check_launch("kpf_ln_train_backward");
+  if (rc != KPF_OK) return rc;
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * C + 63) / 64), dim3(512), 0, st, ws, dw, db, nblk, C);
+  return kpf_check_launch("kpf_ln_train_backward (reduce)");
+}
+
+namespace {
+template <typename T>
+int gelu_fwd_launch(const void* x, void* y, long n, void* stream) {
+  hipLaunchKernelGGL(gelu_fwd_kernel<T>, dim3(grid_for(n / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), static_cast<const T*>(x), static_cast<T*>(y),
+                     n / 4);
+  return kpf_check_launch("kpf_gelu_forward");
+}
+template <typename T>
+int gelu_bwd_launch(const void* dy, const void* x, void* dx, long n, void* stream) {
+  hipLaunchKernelGGL(gelu_bwd_kernel<T>, dim3(grid_for(n / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), static_cast<const T*>(dy),
+                     static_cast<const T*>(x), static_cast<T*>(dx), n / 4);
+  return kpf_check_launch("kpf_gelu_backward");
+}
+}  // namespace
+
+extern "C" int kpf_gelu_forward(const void* x, void* y, int dtype, long n, void* stream) {
+  KPF_REQUIRE(x && y && n > 0 && n % 4 == 0, "kpf_gelu_forward: bad arguments (n %% 4 == 0)");
+#define CALL(T) gelu_fwd_launch<T>(x, y, n, stream)
+  KPF_DISPATCH_DT(dtype, "kpf_gelu_forward", CALL);
+#undef CALL
+}
+
+extern "C" int kpf_gelu_backward(const void* dy, const void* x, void* dx, int dtype, long n, void* stream) {
+  KPF_REQUIRE(dy && x && dx && n > 0 && n % 4 == 0, "kpf_gelu_backward: bad arguments (n %% 4 == 0)");
+#define CALL(T) gelu_bwd_launch<T>(dy, x, dx, n, stream)
+  KPF_DISPATCH_DT(dtype, "kpf_gelu_backward", CALL);
+#undef CALL
+}

@@ -89,6 +89,10 @@ _SIGS = {
     "kpf_row_gather_fwd_f32": [_P] * 4 + [C.c_int] * 5 + [_P],
     "kpf_pack_conv_weight": [_P, C.c_int, _P, C.c_int] + [C.c_int] * 7 + [_P],
     "kpf_pack_conv_weights_multi": [_P, C.c_int, C.c_int, _P],
+    "kpf_ln_train_forward": [_P, _P, _P, _P, C.c_int, _P, _P, C.c_long, C.c_int, C.c_float, _P],
+    "kpf_ln_train_backward": [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, C.c_long, C.c_long, C.c_int, _P],
+    "kpf_gelu_forward": [_P, _P, C.c_int, C.c_long, _P],
+    "kpf_gelu_backward": [_P, _P, _P, C.c_int, C.c_long, _P],
     "kpf_row_gather_bwd_f32": [_P] * 5 + [C.c_long] + [C.c_int] * 5 + [_P],
 }
 _LONG_SIGS = {  # entries returning a long
@@ -97,6 +101,7 @@ _LONG_SIGS = {  # entries returning a long
     "kpf_dwconv7_wgrad_ws_floats": [C.c_int, C.c_int, C.c_int],
     "kpf_bn_ws_floats": [C.c_long, C.c_int],
     "kpf_row_gather_ws_ints": [C.c_int] * 4,
+    "kpf_ln_ws_floats": [C.c_long, C.c_int],
 }
 EXPORTS = sorted(list(_SIGS) + list(_LONG_SIGS) + ["kpf_last_error", "kpf_abi_version"])
 

@@ -26,7 +26,8 @@ import torch.nn.functional as F
 
 from . import lib as L
 from .engine import _ptr, _stream, crop_inverse
-from .training import batchnorm_relu_rows, conv2d_nhwc, dwconv7_nhwc, layer_scale_residual, linear_hip, maxpool3x3s2_nhwc, row_gather, upsample2x_nhwc
+from .training import (batchnorm_relu_rows, conv2d_nhwc, dwconv7_nhwc, gelu_rows, layer_norm_rows, layer_scale_residual, linear_hip, maxpool3x3s2_nhwc,
+                       row_gather, upsample2x_nhwc)
 
 J = 21
 
@@ -89,6 +90,19 @@ class TrainGraph:
         self.nbt.append(self.t[p + ".num_batches_tracked"])
         return y
 
+    def ln(self, x, p_w, p_b, eps, to_gemm=False):
+        """LayerNorm over the last axis on the HIP kernels (C % 4 == 0, C <= 1024), torch otherwise; to_gemm: the output feeds a GEMM, so under
+        mixed precision it is written in the 16-bit operand type directly."""
+        c = x.shape[-1]
+        if x.is_cuda and c % 4 == 0 and c <= 1024:
+            from .training import _TDT
+            return layer_norm_rows(x, self.t[p_w], self.t[p_b], eps, _TDT[self.prec] if (to_gemm and self.prec != "f32") else None)
+        return F.layer_norm(x, (c,), self.t[p_w], self.t[p_b], eps)
+
+    @staticmethod
+    def gelu(x):
+        return gelu_rows(x) if (x.is_cuda and x.numel() % 4 == 0 and x.dtype in (torch.float32, torch.bfloat16, torch.float16)) else F.gelu(x)
+
     def drop(self, x):
         return F.dropout(x, self.pd, True) if self.pd > 0 else x
 
@@ -142,8 +156,8 @@ class TrainGraph:
     def convnext_block(self, p, x):
         c = x.shape[-1]
         y = dwconv7_nhwc(x.float(), self.t[p + ".dwconv.weight"], self.t[p + ".dwconv.bias"], p + ".dwconv.weight", self.packs)
-        y = F.layer_norm(y, (c,), self.t[p + ".norm.weight"], self.t[p + ".norm.bias"], 1e-6)
-        y = F.gelu(self.linear(y, p + ".pwconv1.weight", p + ".pwconv1.bias"))
+        y = self.ln(y, p + ".norm.weight", p + ".norm.bias", 1e-6, to_gemm=True)
+        y = self.gelu(self.linear(y, p + ".pwconv1.weight", p + ".pwconv1.bias"))
         y = self.linear(y, p + ".pwconv2.weight", p + ".pwconv2.bias")
         return layer_scale_residual(x, self.t[p + ".gamma"], y)  # (drop_path_rate is 0 in the reference's constructor call: identity)
 
@@ -154,9 +168,9 @@ class TrainGraph:
             q = p + ".downsample_layers.%d" % i
             if i == 0:
                 x = self.conv_l(x, q + ".0.weight", q + ".0.bias", stride=4)
-                x = F.layer_norm(x, (x.shape[-1],), self.t[q + ".1.weight"], self.t[q + ".1.bias"], 1e-6)
+                x = self.ln(x, q + ".1.weight", q + ".1.bias", 1e-6)
             else:
-                x = F.layer_norm(x, (x.shape[-1],), self.t[q + ".0.weight"], self.t[q + ".0.bias"], 1e-6)
+                x = self.ln(x, q + ".0.weight", q + ".0.bias", 1e-6, to_gemm=True)
                 x = self.conv_l(x, q + ".1.weight", q + ".1.bias", stride=2)
             j = 0
             while self.has(p + ".stages.%d.%d.gamma" % (i, j)):
@@ -374,10 +388,10 @@ class TrainGraph:
         a = self.drop(torch.softmax(torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(hd), -1))
         ctx = torch.matmul(a, v).transpose(1, 2).reshape(B, T, C)
         o = self.drop(self.linear(ctx, p + ".attention.output.dense.weight", p + ".attention.output.dense.bias"))
-        h1 = F.layer_norm(o + h, (C,), self.t[p + ".attention.output.LayerNorm.weight"], self.t[p + ".attention.output.LayerNorm.bias"], 1e-12)
-        it = F.gelu(self.linear(h1, p + ".intermediate.dense.weight", p + ".intermediate.dense.bias"))
+        h1 = self.ln(o + h, p + ".attention.output.LayerNorm.weight", p + ".attention.output.LayerNorm.bias", 1e-12)
+        it = self.gelu(self.linear(h1, p + ".intermediate.dense.weight", p + ".intermediate.dense.bias"))
         o2 = self.drop(self.linear(it, p + ".output.dense.weight", p + ".output.dense.bias"))
-        return F.layer_norm(o2 + h1, (C,), self.t[p + ".output.LayerNorm.weight"], self.t[p + ".output.LayerNorm.bias"], 1e-12)
+        return self.ln(o2 + h1, p + ".output.LayerNorm.weight", p + ".output.LayerNorm.bias", 1e-12)
 
     def kp_interaction_tr(self, p, x):
         T = x.shape[1]
@@ -404,9 +418,9 @@ class TrainGraph:
         a = self.drop(torch.softmax(torch.matmul(q, k.transpose(-1, -2)), -1))
         ctx = torch.matmul(a, v).transpose(1, 2).reshape(B, T, C)
         o = self.linear(ctx, p + ".multihead_attn.out_proj.weight", p + ".multihead_attn.out_proj.bias")
-        x = F.layer_norm(query + self.drop(o), (C,), self.t[p + ".norm2.weight"], self.t[p + ".norm2.bias"], 1e-5)
+        x = self.ln(query + self.drop(o), p + ".norm2.weight", p + ".norm2.bias", 1e-5)
         f = self.linear(self.drop(F.relu(self.linear(x, p + ".linear1.weight", p + ".linear1.bias"))), p + ".linear2.weight", p + ".linear2.bias")
-        return F.layer_norm(x + self.drop(f), (C,), self.t[p + ".norm3.weight"], self.t[p + ".norm3.bias"], 1e-5)
+        return self.ln(x + self.drop(f), p + ".norm3.weight", p + ".norm3.bias", 1e-5)
 
     def block(self, p, img_feat, img_feat_rgb, pcl, joint_xyz, clos, idx, img_offset, prev_feat, img_down, center, Minv, cube, cam,
               img_size, flip):

@@ -542,6 +542,78 @@ def batchnorm_relu_rows(x, weight, bias, running_mean, running_var, momentum=0.1
     return BatchNormReLU.apply(x, weight, bias, running_mean, running_var, momentum, eps, relu, out_dtype)
 
 
+class LayerNormRows(torch.autograd.Function):
+    """F.layer_norm over the last axis (convNeXT/convnext.py:43, 199-214; the post-LN layers of the fusion head): kpf_ln_train_forward /
+    kpf_ln_train_backward.  x any shape [..., C] fp32; the output may be written directly in the 16-bit operand type of the GEMM that
+    follows (`out_dtype`); statistics and gradients are fp32, parameter gradients are added in a fixed order."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype=None):
+        from . import lib as L
+        x = x.float().contiguous()
+        Cc = x.shape[-1]
+        rows = x.numel() // Cc
+        out_dtype = out_dtype or torch.float32
+        y = torch.empty(x.shape, device=x.device, dtype=out_dtype)
+        stats = torch.empty(2, rows, device=x.device, dtype=torch.float32)
+        w, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        L.check(L.load().kpf_ln_train_forward(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), _KDT[out_dtype], stats[0].data_ptr(), stats[1].data_ptr(),
+                                              rows, Cc, float(eps), torch.cuda.current_stream().cuda_stream), "kpf_ln_train_forward")
+        ctx.save_for_backward(x, stats, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import lib as L
+        lib = L.load()
+        x, stats, w = ctx.saved_tensors
+        Cc = x.shape[-1]
+        rows = x.numel() // Cc
+        dy = dy.contiguous()
+        if dy.dtype not in _KDT:
+            dy = dy.float()
+        dx = torch.empty_like(x)
+        dwb = torch.empty(2, Cc, device=x.device, dtype=torch.float32)
+        nws = lib.kpf_ln_ws_floats(rows, Cc)
+        ws = torch.empty(nws, device=x.device, dtype=torch.float32)
+        L.check(lib.kpf_ln_train_backward(dy.data_ptr(), _KDT[dy.dtype], x.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), w.data_ptr(), dx.data_ptr(),
+                                          dwb[0].data_ptr(), dwb[1].data_ptr(), ws.data_ptr(), nws, rows, Cc, torch.cuda.current_stream().cuda_stream),
+                "kpf_ln_train_backward")
+        return dx, dwb[0], dwb[1], None, None
+
+
+class GeluRows(torch.autograd.Function):
+    """GELU(erf) (convNeXT/convnext.py:33; BERT's intermediate activation): kpf_gelu_forward / kpf_gelu_backward on fp32 or 16-bit tensors."""
+
+    @staticmethod
+    def forward(ctx, x):
+        from . import lib as L
+        x = x.contiguous()
+        assert x.dtype in _KDT and x.numel() % 4 == 0
+        y = torch.empty_like(x)
+        L.check(L.load().kpf_gelu_forward(x.data_ptr(), y.data_ptr(), _KDT[x.dtype], x.numel(), torch.cuda.current_stream().cuda_stream), "kpf_gelu_forward")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import lib as L
+        (x,) = ctx.saved_tensors
+        dy = dy.to(x.dtype).contiguous()
+        dx = torch.empty_like(x)
+        L.check(L.load().kpf_gelu_backward(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), _KDT[x.dtype], x.numel(), torch.cuda.current_stream().cuda_stream),
+                "kpf_gelu_backward")
+        return dx
+
+
+def layer_norm_rows(x, weight, bias, eps, out_dtype=None):
+    return LayerNormRows.apply(x, weight, bias, eps, out_dtype)
+
+
+def gelu_rows(x):
+    return GeluRows.apply(x)
+
+
 class Upsample2xNHWC(torch.autograd.Function):
     """Bilinear x2 (align_corners False: nn.Upsample of model/resnetUnet.py:259) on NHWC [B,H,W,C], fp32 or 16-bit storage.
     forward kpf_upsample2x_f32 / _h16, backward kpf_upsample2x_bwd (gather form: run-to-run deterministic, unlike the library's

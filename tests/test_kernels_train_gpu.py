@@ -316,3 +316,48 @@ def test_row_gather_forward_backward_match_torch(case):
     sd.grad = None
     row_gather(sd, idx.int().cuda(), w.cuda() if weighted else None).backward(dout.cuda())
     assert torch.equal(g1, sd.grad)
+
+
+@pytest.mark.parametrize("shape,ydt", [((4, 16, 16, 96), torch.float32), ((3, 21, 128), torch.float32), ((2, 4, 4, 768), torch.bfloat16),
+                                       ((777, 1024), torch.float32), ((5, 8), torch.float16), ((2, 9, 9, 384), torch.float32)])
+def test_layer_norm_rows_forward_backward_match_torch(shape, ydt):
+    """kpf_ln_train_forward / _backward vs F.layer_norm in float64 (per-channel means far from zero); the parameter gradients are column
+    sums added in a fixed order: two runs return the same bits."""
+    from keypointfusion_amd.training import layer_norm_rows
+    Cc = shape[-1]
+    g = torch.Generator().manual_seed(Cc + len(shape))
+    x = torch.randn(*shape, generator=g) * 2.0 + 4.0 * torch.randn(Cc, generator=g)
+    w, b = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g)
+    dy = torch.randn(*shape, generator=g)
+    xd, wd, bd = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    y = layer_norm_rows(xd, wd, bd, 1e-6, ydt)
+    assert y.dtype == ydt
+    y.backward(dy.cuda().to(ydt))
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = F.layer_norm(xr, (Cc,), wr, br, 1e-6)
+    yr.backward(dy.to(ydt).double())
+    eps = {torch.float32: 2e-5, torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}[ydt]
+    rel = lambda a, r: float((a.detach().cpu().double() - r.detach()).abs().max()) / max(float(r.detach().abs().max()), 1e-3)
+    assert rel(y, yr) <= 1.01 * eps
+    assert rel(xd.grad, xr.grad) <= 3e-5 and rel(wd.grad, wr.grad) <= 3e-5 and rel(bd.grad, br.grad) <= 3e-5
+    g1 = (xd.grad.clone(), wd.grad.clone(), bd.grad.clone())
+    xd.grad = wd.grad = bd.grad = None
+    layer_norm_rows(xd, wd, bd, 1e-6, ydt).backward(dy.cuda().to(ydt))
+    assert torch.equal(g1[0], xd.grad) and torch.equal(g1[1], wd.grad) and torch.equal(g1[2], bd.grad)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gelu_rows_forward_backward_match_torch(dt):
+    from keypointfusion_amd.training import gelu_rows
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(1024, 36, generator=g) * 3).to(dt)
+    dy = torch.randn(1024, 36, generator=g).to(dt)
+    xd = x.cuda().requires_grad_(True)
+    y = gelu_rows(xd)
+    y.backward(dy.cuda())
+    xr = x.double().requires_grad_(True)
+    yr = F.gelu(xr)
+    yr.backward(dy.double())
+    eps = 3e-6 if dt == torch.float32 else 2.0 ** -8
+    assert float((y.detach().cpu().double() - yr.detach()).abs().max()) <= eps * max(float(yr.abs().max()), 1.0)
+    assert float((xd.grad.cpu().double() - xr.grad).abs().max()) <= eps * max(float(xr.grad.abs().max()), 1.0)
