@@ -347,6 +347,16 @@ int kpf_ln_train_backward(const void* dy, int dy_dtype, const float* x, const fl
 int kpf_gelu_forward(const void* x, void* y, int dtype, long n, void* stream);
 int kpf_gelu_backward(const void* dy, const void* x, void* dx, int dtype, long n, void* stream);
 
+/* Training: the attention core of the 21-token stacks (BertSelfAttention of model/model.py:30-126; multi_head_attention_forward,
+ * model/transfusion_head.py:527-546): per (sample, head) P = softmax(scale * Q K^T), ctx = dropout(P) V.  q, k, v, ctx, dq, dk, dv are rows
+ * [B*T][ld] fp32 with head h in channels [h*hd, (h+1)*hd) (the projections' own layout: no head transposes); T = 21, hd = 32.  P
+ * [B][H][T][T] fp32 and the keep mask M (bytes) are kept for the backward.  p_drop > 0: masks from a hash of (rng[0] = seed, rng[1] =
+ * counter advanced by the host once per forward, call_id, element); rng is a device pointer to two int64. */
+int kpf_attn21_forward(const float* q, const float* k, const float* v, float* ctx, float* P, unsigned char* M, int B, int T, int H, int hd, int ld,
+                       float scale, float p_drop, const long* rng, int call_id, void* stream);
+int kpf_attn21_backward(const float* dctx, const float* q, const float* k, const float* v, const float* P, const unsigned char* M, float* dq, float* dk,
+                        float* dv, int B, int T, int H, int hd, int ld, float scale, float p_drop, void* stream);
+
 /* Training: one-launch packing of a reference-layout weight w [N][Cin][KH][KW] (src_dtype: KPF_DT_F32 master, or a 16-bit copy) into an
  * operand of kpf_conv2d_f32 / _h16 (dst_dtype; fp32 -> 16-bit rounds to nearest even), rows zero-padded to Kp:
  *   mode 0  forward rows        dst [n_pad][Kp], k = (ky, kx, c)

@@ -751,3 +751,155 @@ extern "C" int kpf_gelu_backward(const void* dy, const void* x, void* dx, int dt
   KPF_DISPATCH_DT(dtype, "kpf_gelu_backward", CALL);
 #undef CALL
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The attention core of the 21-token stacks in train mode (BertSelfAttention, model/model.py:30-126 via transformers; the decoder
+// layer's multi_head_attention_forward, model/transfusion_head.py:527-546): per (sample, head) S = scale * Q K^T, P = softmax(S),
+// P' = dropout(P), ctx = P' V, and its backward — one wave per (sample, head), everything in LDS / registers.  Q, K, V are read where
+// the projections left them ([B*T][C] rows, head h = channels h*hd .. h*hd+hd-1), ctx is written in the layout the output projection
+// reads: no head transposes, no batched-GEMM launches for 21 x 21 x 32 problems (library path: ~15 launches per layer).
+// Dropout: keep = hash(seed, counter, call, element) >= p * 2^32 with a counter the host advances once per forward (device-resident, so
+// a captured iteration draws new masks at every replay); the mask is kept for the backward (one byte per probability).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int AT_T = 21, AT_HD = 32;
+
+__device__ __forceinline__ unsigned hash32(unsigned x) {  // "lowbias32" integer hash: full avalanche in three multiplies
+  x ^= x >> 16;
+  x *= 0x7feb352dU;
+  x ^= x >> 15;
+  x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
+
+__global__ __launch_bounds__(64) void attn21_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, float* __restrict__ ctx,
+                                                        float* __restrict__ P, unsigned char* __restrict__ M, int H, int ld, float scale, float p_drop,
+                                                        const long* __restrict__ rng, int call_id) {
+  __shared__ float sq[AT_T][AT_HD + 1], sk[AT_T][AT_HD + 1], sv[AT_T][AT_HD + 1], sp[AT_T][AT_T + 1];
+  const int b = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
+  const long row0 = (long)b * AT_T;
+  for (int i = lane; i < AT_T * AT_HD; i += 64) {
+    const int t = i / AT_HD, d = i % AT_HD;
+    const long off = (row0 + t) * ld + h * AT_HD + d;
+    sq[t][d] = q[off];
+    sk[t][d] = k[off];
+    sv[t][d] = v[off];
+  }
+  __syncthreads();
+  for (int e = lane; e < AT_T * AT_T; e += 64) {
+    const int i = e / AT_T, j = e % AT_T;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < AT_HD; ++d) s = fmaf(sq[i][d], sk[j][d], s);
+    sp[i][j] = s * scale;
+  }
+  __syncthreads();
+  if (lane < AT_T) {  // row softmax
+    float mx = -INFINITY;
+    for (int j = 0; j < AT_T; ++j) mx = fmaxf(mx, sp[lane][j]);
+    float sum = 0.f;
+    for (int j = 0; j < AT_T; ++j) {
+      const float e = __expf(sp[lane][j] - mx);
+      sp[lane][j] = e;
+      sum += e;
+    }
+    const float inv = 1.0f / sum;
+    for (int j = 0; j < AT_T; ++j) sp[lane][j] *= inv;
+  }
+  __syncthreads();
+  const long pbase = (long)blockIdx.x * AT_T * AT_T;
+  const float keep_scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+  const unsigned thr = p_drop > 0.f ? (unsigned)fminf(p_drop * 4294967296.0f, 4294967295.0f) : 0u;
+  const unsigned seed = rng ? (unsigned)rng[0] : 0u, ctr = rng ? (unsigned)rng[1] : 0u;
+  for (int e = lane; e < AT_T * AT_T; e += 64) {
+    const int i = e / AT_T, j = e % AT_T;
+    const float pv = sp[i][j];
+    P[pbase + e] = pv;
+    unsigned char keep = 1;
+    if (p_drop > 0.f) keep = hash32(hash32(seed ^ (ctr * 0x9e3779b9U)) ^ hash32((unsigned)call_id * 0x85ebca6bU + (unsigned)(pbase + e))) >= thr;
+    M[pbase + e] = keep;
+    sp[i][j] = keep ? pv * keep_scale : 0.f;
+  }
+  __syncthreads();
+  for (int e = lane; e < AT_T * AT_HD; e += 64) {
+    const int i = e / AT_HD, d = e % AT_HD;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < AT_T; ++j) s = fmaf(sp[i][j], sv[j][d], s);
+    ctx[(row0 + i) * ld + h * AT_HD + d] = s;
+  }
+}
+
+__global__ __launch_bounds__(64) void attn21_bwd_kernel(const float* __restrict__ dctx, const float* __restrict__ q, const float* __restrict__ k,
+                                                        const float* __restrict__ v, const float* __restrict__ P, const unsigned char* __restrict__ M,
+                                                        float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv, int H, int ld, float scale,
+                                                        float p_drop) {
+  __shared__ float sq[AT_T][AT_HD + 1], sk[AT_T][AT_HD + 1], sv[AT_T][AT_HD + 1], sg[AT_T][AT_HD + 1], sp[AT_T][AT_T + 1], sd[AT_T][AT_T + 1];
+  const int b = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
+  const long row0 = (long)b * AT_T;
+  for (int i = lane; i < AT_T * AT_HD; i += 64) {
+    const int t = i / AT_HD, d = i % AT_HD;
+    const long off = (row0 + t) * ld + h * AT_HD + d;
+    sq[t][d] = q[off];
+    sk[t][d] = k[off];
+    sv[t][d] = v[off];
+    sg[t][d] = dctx[off];
+  }
+  const long pbase = (long)blockIdx.x * AT_T * AT_T;
+  const float keep_scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+  __syncthreads();
+  // dP' = dctx V^T ; dP = dP' * mask ; sd <- dP, sp <- P' (dropped probabilities, for dV)
+  for (int e = lane; e < AT_T * AT_T; e += 64) {
+    const int i = e / AT_T, j = e % AT_T;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < AT_HD; ++d) s = fmaf(sg[i][d], sv[j][d], s);
+    const float m = M[pbase + e] ? keep_scale : 0.f;
+    sd[i][j] = s * m;
+    sp[i][j] = P[pbase + e];
+  }
+  __syncthreads();
+  // dV[j][d] = sum_i P'[i][j] dctx[i][d]
+  for (int e = lane; e < AT_T * AT_HD; e += 64) {
+    const int j = e / AT_HD, d = e % AT_HD;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < AT_T; ++i) s = fmaf(sp[i][j] * (M[pbase + i * AT_T + j] ? keep_scale : 0.f), sg[i][d], s);
+    dv[(row0 + j) * ld + h * AT_HD + d] = s;
+  }
+  __syncthreads();
+  if (lane < AT_T) {  // dS = P * (dP - sum_j dP * P), scaled
+    float dot = 0.f;
+    for (int j = 0; j < AT_T; ++j) dot = fmaf(sd[lane][j], sp[lane][j], dot);
+    for (int j = 0; j < AT_T; ++j) sd[lane][j] = sp[lane][j] * (sd[lane][j] - dot) * scale;
+  }
+  __syncthreads();
+  for (int e = lane; e < AT_T * AT_HD; e += 64) {
+    const int i = e / AT_HD, d = e % AT_HD;
+    float a = 0.f, c = 0.f;
+#pragma unroll
+    for (int j = 0; j < AT_T; ++j) {
+      a = fmaf(sd[i][j], sk[j][d], a);  // dQ[i] = sum_j dS[i][j] K[j]
+      c = fmaf(sd[j][i], sq[j][d], c);  // dK[i] = sum_j dS[j][i] Q[j]
+    }
+    dq[(row0 + i) * ld + h * AT_HD + d] = a;
+    dk[(row0 + i) * ld + h * AT_HD + d] = c;
+  }
+}
+}  // namespace
+
+extern "C" int kpf_attn21_forward(const float* q, const float* k, const float* v, float* ctx, float* P, unsigned char* M, int B, int T, int H, int hd, int ld,
+                                  float scale, float p_drop, const long* rng, int call_id, void* stream) {
+  KPF_REQUIRE(q && k && v && ctx && P && M && B > 0 && T == AT_T && hd == AT_HD && H > 0 && ld >= H * hd, "kpf_attn21_forward: needs 21 tokens and 32-wide heads");
+  KPF_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || rng), "kpf_attn21_forward: dropout needs 0 <= p < 1 and the rng state");
+  hipLaunchKernelGGL(attn21_fwd_kernel, dim3(B * H), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), q, k, v, ctx, P, M, H, ld, scale, p_drop, rng, call_id);
+  return kpf_check_launch("kpf_attn21_forward");
+}
+
+extern "C" int kpf_attn21_backward(const float* dctx, const float* q, const float* k, const float* v, const float* P, const unsigned char* M, float* dq, float* dk,
+                                   float* dv, int B, int T, int H, int hd, int ld, float scale, float p_drop, void* stream) {
+  KPF_REQUIRE(dctx && q && k && v && P && M && dq && dk && dv && B > 0 && T == AT_T && hd == AT_HD && H > 0 && ld >= H * hd, "kpf_attn21_backward: bad arguments");
+  hipLaunchKernelGGL(attn21_bwd_kernel, dim3(B * H), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), dctx, q, k, v, P, M, dq, dk, dv, H, ld, scale, p_drop);
+  return kpf_check_launch("kpf_attn21_backward");
+}

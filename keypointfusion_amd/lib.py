@@ -92,6 +92,8 @@ _SIGS = {
     "kpf_ln_train_forward": [_P, _P, _P, _P, C.c_int, _P, _P, C.c_long, C.c_int, C.c_float, _P],
     "kpf_ln_train_backward": [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, C.c_long, C.c_long, C.c_int, _P],
     "kpf_gelu_forward": [_P, _P, C.c_int, C.c_long, _P],
+    "kpf_attn21_forward": [_P] * 6 + [C.c_int] * 5 + [C.c_float, C.c_float, _P, C.c_int, _P],
+    "kpf_attn21_backward": [_P] * 9 + [C.c_int] * 5 + [C.c_float, C.c_float, _P],
     "kpf_gelu_backward": [_P, _P, _P, C.c_int, C.c_long, _P],
     "kpf_row_gather_bwd_f32": [_P] * 5 + [C.c_long] + [C.c_int] * 5 + [_P],
 }

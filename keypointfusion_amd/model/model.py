@@ -57,7 +57,7 @@ class KPFusion(nn.Module):
         return sum(t._version for t in ts)
 
     # -- copy.deepcopy / pickle: the per-device caches (packed weights, captured graphs, streams, locks) are rebuilt on demand ----
-    _CACHE_ATTRS = ("_plans", "_plan_lock", "_tensor_list", "_train_side_stream", "_w16_shadow", "_pack_cache")
+    _CACHE_ATTRS = ("_plans", "_plan_lock", "_tensor_list", "_train_side_stream", "_w16_shadow", "_pack_cache", "_drop_rng")
 
     def __getstate__(self):
         st = self.__dict__.copy()

@@ -606,6 +606,44 @@ class GeluRows(torch.autograd.Function):
         return dx
 
 
+class Attn21(torch.autograd.Function):
+    """ctx = dropout(softmax(scale * Q K^T)) V per (sample, head) for the 21-token stacks: kpf_attn21_forward / _backward.  q, k, v
+    [B, 21, H*32] fp32 as the projections produced them; returns ctx in the same layout."""
+
+    @staticmethod
+    def forward(ctx_, q, k, v, heads, scale, p_drop, rng, call_id):
+        from . import lib as L
+        q, k, v = q.float().contiguous(), k.float().contiguous(), v.float().contiguous()
+        B, T, Cc = q.shape
+        hd = Cc // heads
+        out = torch.empty_like(q)
+        P = torch.empty(B, heads, T, T, device=q.device, dtype=torch.float32)
+        M = torch.empty(B, heads, T, T, device=q.device, dtype=torch.uint8)
+        L.check(L.load().kpf_attn21_forward(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), P.data_ptr(), M.data_ptr(), B, T, heads, hd, Cc,
+                                            float(scale), float(p_drop), rng.data_ptr() if rng is not None else None, int(call_id),
+                                            torch.cuda.current_stream().cuda_stream), "kpf_attn21_forward")
+        ctx_.save_for_backward(q, k, v, P, M)
+        ctx_.conf = (heads, float(scale), float(p_drop))
+        return out
+
+    @staticmethod
+    def backward(ctx_, dctx):
+        from . import lib as L
+        q, k, v, P, M = ctx_.saved_tensors
+        heads, scale, p_drop = ctx_.conf
+        B, T, Cc = q.shape
+        dctx = dctx.float().contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        L.check(L.load().kpf_attn21_backward(dctx.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), P.data_ptr(), M.data_ptr(), dq.data_ptr(), dk.data_ptr(),
+                                             dv.data_ptr(), B, T, heads, Cc // heads, Cc, scale, p_drop, torch.cuda.current_stream().cuda_stream),
+                "kpf_attn21_backward")
+        return dq, dk, dv, None, None, None, None, None
+
+
+def attn21(q, k, v, heads, scale, p_drop=0.0, rng=None, call_id=0):
+    return Attn21.apply(q, k, v, heads, scale, p_drop, rng, call_id)
+
+
 def layer_norm_rows(x, weight, bias, eps, out_dtype=None):
     return LayerNormRows.apply(x, weight, bias, eps, out_dtype)
 

@@ -361,3 +361,53 @@ def test_gelu_rows_forward_backward_match_torch(dt):
     eps = 3e-6 if dt == torch.float32 else 2.0 ** -8
     assert float((y.detach().cpu().double() - yr.detach()).abs().max()) <= eps * max(float(yr.abs().max()), 1.0)
     assert float((xd.grad.cpu().double() - xr.grad).abs().max()) <= eps * max(float(xr.grad.abs().max()), 1.0)
+
+
+@pytest.mark.parametrize("B,scale", [(3, 32 ** -0.5), (1, 1.0)])
+def test_attn21_forward_backward_match_torch(B, scale):
+    """kpf_attn21_forward / _backward (softmax(scale QK^T) V per head, heads read in place) vs the matmul / softmax chain in float64."""
+    from keypointfusion_amd.training import attn21
+    g = torch.Generator().manual_seed(B)
+    q, k, v, dctx = (torch.randn(B, 21, 128, generator=g) for _ in range(4))
+    qd, kd, vd = (t.cuda().requires_grad_(True) for t in (q, k, v))
+    out = attn21(qd, kd, vd, 4, scale)
+    out.backward(dctx.cuda())
+    qr, kr, vr = (t.double().requires_grad_(True) for t in (q, k, v))
+    sp = lambda t: t.view(B, 21, 4, 32).transpose(1, 2)
+    a = torch.softmax(torch.matmul(sp(qr), sp(kr).transpose(-1, -2)) * scale, -1)
+    ref = torch.matmul(a, sp(vr)).transpose(1, 2).reshape(B, 21, 128)
+    ref.backward(dctx.double())
+    rel = lambda x, r: float((x.detach().cpu().double() - r.detach()).abs().max()) / float(r.detach().abs().max())
+    assert rel(out, ref) < 1e-5
+    assert rel(qd.grad, qr.grad) < 1e-5 and rel(kd.grad, kr.grad) < 1e-5 and rel(vd.grad, vr.grad) < 1e-5
+
+
+def test_attn21_dropout_is_a_bernoulli_mask_consistent_between_forward_and_backward():
+    """Dropout inside the fused attention: the kept fraction is 1 - p, kept probabilities are scaled by 1/(1-p), the backward uses the same
+    mask (finite-difference-free check: with V = identity-like rows the output reveals the dropped probabilities), and the counter
+    changes the mask."""
+    from keypointfusion_amd.training import attn21
+    B, p = 64, 0.25
+    g = torch.Generator().manual_seed(0)
+    q, k = torch.randn(B, 21, 128, generator=g).cuda(), torch.randn(B, 21, 128, generator=g).cuda()
+    v = torch.zeros(B, 21, 128)
+    for h in range(4):
+        v[:, :, 32 * h:32 * h + 21] = torch.eye(21)  # ctx[b, i, 32h + j] = P'[b, h, i, j]
+    v = v.cuda().requires_grad_(True)
+    rng = torch.tensor([1234, 0], dtype=torch.int64, device="cuda")
+    out = attn21(q, k, v, 4, 32 ** -0.5, p, rng, 1)
+    ref = attn21(q, k, v, 4, 32 ** -0.5, 0.0, None, 1)
+    pd = torch.stack([out[:, :, 32 * h:32 * h + 21] for h in range(4)], 1)   # [B, 4, 21, 21] dropped probabilities
+    pr = torch.stack([ref[:, :, 32 * h:32 * h + 21] for h in range(4)], 1)
+    kept = pd != 0
+    frac = float(kept.float().mean())
+    assert abs(frac - (1 - p)) < 0.01, frac
+    assert float((pd[kept] - pr[kept] / (1 - p)).abs().max()) < 1e-6
+    out.sum().backward()  # d ctx = 1: dV[b, j, 32h + d] = sum_i P'[b,h,i,j] for every d
+    dv = v.grad
+    want = pd.sum(2)  # [B, 4, 21(j)]
+    for h in range(4):
+        assert float((dv[:, :, 32 * h] - want[:, h]).abs().max()) < 1e-5
+    rng2 = torch.tensor([1234, 1], dtype=torch.int64, device="cuda")
+    out2 = attn21(q, k, v, 4, 32 ** -0.5, p, rng2, 1)
+    assert not torch.equal(out2 != 0, out != 0)
