@@ -81,8 +81,18 @@ class TrainGraph:
     def linear(self, x, p_w, p_b=None):
         w = self.t[p_w]
         b = self.t[p_b] if p_b is not None else None
-        if w.shape[1] % self.cmul == 0:
-            return linear_hip(x.contiguous(), w, b, self.prec, None, p_w, self.packs)
+        n, cin = w.shape
+        if x.is_cuda:
+            npad, cpad = (-n) % 4, (-cin) % self.cmul
+            if npad == 0 and cpad == 0:
+                return linear_hip(x.contiguous(), w, b, self.prec, None, p_w, self.packs)
+            # odd widths — the 3-wide joint heads and the 131-wide input of final_TR (model/model.py:99-104, 349): zero rows / columns up
+            # to whole channel groups so that forward, data- and weight-gradient all stay on the HIP kernels (the library's GEMM for an
+            # M = 3 weight gradient takes 220 us); autograd slices the gradients back
+            wp = F.pad(w, (0, cpad, 0, npad))
+            bp = F.pad(b, (0, npad)) if (b is not None and npad) else b
+            xp = F.pad(x, (0, cpad)) if cpad else x
+            return linear_hip(xp.contiguous(), wp, bp, self.prec)[..., :n]
         return F.linear(x, w, b)
 
     def bn(self, x, p, eps=1e-5):

@@ -158,8 +158,9 @@ def test_train_step_matches_the_reference_loss_and_gradients(net):
     ball = [torch.from_numpy(Zs["ball_idx"][i].astype(np.int64)) for i in range(6)]
     results, (loss, parts) = step_loss(ball)
     print("train-mode ball-query sets that differ from the reference's: %d" % m._last_ball_flips)
-    # frozen to the observed values on the committed fixtures: one boundary point in the ConvNeXt fixture, none in the ResNet one
-    assert m._last_ball_flips == {"convnext-tiny": 1, "resnet-18": 0}[net], m._last_ball_flips
+    # observed on the committed fixtures: 0 (ResNet-18) and 0 or 1 (ConvNeXt-T: one point sits on a radius to within the last bits of the
+    # train-mode LayerNorm / GELU arithmetic — 1 with the library kernels, 0 with the HIP ones)
+    assert m._last_ball_flips <= {"convnext-tiny": 1, "resnet-18": 0}[net], m._last_ball_flips
     assert all(r.requires_grad for r in results)
     assert float((results[2].detach().cpu() - torch.from_numpy(Zs["r3d1"])).abs().max()) < 1e-3
     assert float((results[5].detach().cpu() - torch.from_numpy(Zs["r2d2"])).abs().max()) < 1e-3
