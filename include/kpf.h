@@ -357,6 +357,10 @@ int kpf_attn21_forward(const float* q, const float* k, const float* v, float* ct
 int kpf_attn21_backward(const float* dctx, const float* q, const float* k, const float* v, const float* P, const unsigned char* M, float* dq, float* dk,
                         float* dv, int B, int T, int H, int hd, int ld, float scale, float p_drop, void* stream);
 
+/* Training: dX[b] (P x C) = A[b]^T (P x J) @ dOut[b] (J x C) for small J (<= 64; J = 21 joints): the operand gradient of the per-sample
+ * products of model/model.py:318-320 and 336-341 (a K = J batched GEMM the library handles badly).  fp32, C % 4 == 0, J * C * 4 B <= 64 KB. */
+int kpf_bmm_small_k_dx(const float* A, const float* dOut, float* dX, int B, int J, int P, int C, void* stream);
+
 /* Training: one-launch packing of a reference-layout weight w [N][Cin][KH][KW] (src_dtype: KPF_DT_F32 master, or a 16-bit copy) into an
  * operand of kpf_conv2d_f32 / _h16 (dst_dtype; fp32 -> 16-bit rounds to nearest even), rows zero-padded to Kp:
  *   mode 0  forward rows        dst [n_pad][Kp], k = (ky, kx, c)

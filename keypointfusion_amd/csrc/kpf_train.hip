@@ -903,3 +903,39 @@ extern "C" int kpf_attn21_backward(const float* dctx, const float* q, const floa
   hipLaunchKernelGGL(attn21_bwd_kernel, dim3(B * H), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), dctx, q, k, v, P, M, dq, dk, dv, H, ld, scale, p_drop);
   return kpf_check_launch("kpf_attn21_backward");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// dX[b] (P x C) = A[b]^T (P x 21) @ dOut[b] (21 x C): the gradient of the per-sample products with 21 rows (softmax pooling of the point
+// features, model/model.py:318-320; the gated F^2 -> 1 reduction in GEMM form, model/model.py:336-341) with respect to their P x C
+// operand.  A K = 21 batched GEMM for which the library picks a 256 x 16 macro tile (443 us per call at B = 32, P = 1024, C = 128);
+// here it is 21 multiply-adds per output with dOut[b] in LDS (the other two products of the pair stay on the library: 10-12 us).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void bmm21_dx_kernel(const float* __restrict__ A, const float* __restrict__ dOut, float* __restrict__ dX, int J, int P, int C) {
+  extern __shared__ float sd[];  // dOut[b]: [J][C]
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < J * C; i += 256) sd[i] = dOut[(long)b * J * C + i];
+  __syncthreads();
+  const int C4 = C >> 2;
+  const float* Ab = A + (long)b * J * P;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < P * C4; i += gridDim.x * 256) {
+    const int p = i / C4, q = i - p * C4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < J; ++j) {
+      const float a = Ab[j * P + p];
+      const f32x4 d = *reinterpret_cast<const f32x4*>(sd + j * C + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = fmaf(a, d[e], acc[e]);
+    }
+    *reinterpret_cast<f32x4*>(dX + ((long)b * P + p) * C + 4 * q) = acc;
+  }
+}
+}  // namespace
+
+extern "C" int kpf_bmm_small_k_dx(const float* A, const float* dOut, float* dX, int B, int J, int P, int C, void* stream) {
+  KPF_REQUIRE(A && dOut && dX && B > 0 && J > 0 && J <= 64 && P > 0 && C > 0 && C % 4 == 0 && (long)J * C * 4 <= 64 * 1024, "kpf_bmm_small_k_dx: bad arguments");
+  int gx = (int)(((long)P * (C / 4) + 255) / 256);
+  gx = gx > 32 ? 32 : gx;
+  hipLaunchKernelGGL(bmm21_dx_kernel, dim3(gx, B), dim3(256), (size_t)J * C * sizeof(float), reinterpret_cast<hipStream_t>(stream), A, dOut, dX, J, P, C);
+  return kpf_check_launch("kpf_bmm_small_k_dx");
+}

@@ -26,7 +26,7 @@ import torch.nn.functional as F
 
 from . import lib as L
 from .engine import _ptr, _stream, crop_inverse
-from .training import (attn21, batchnorm_relu_rows, conv2d_nhwc, dwconv7_nhwc, gelu_rows, layer_norm_rows, layer_scale_residual, linear_hip, maxpool3x3s2_nhwc,
+from .training import (attn21, batchnorm_relu_rows, bmm_small_k, conv2d_nhwc, dwconv7_nhwc, gelu_rows, layer_norm_rows, layer_scale_residual, linear_hip, maxpool3x3s2_nhwc,
                        row_gather, upsample2x_nhwc)
 
 J = 21
@@ -271,10 +271,13 @@ class TrainGraph:
         B = uvd.shape[0]
         uv = (uvd[:, :, 0:2] + 1) * (img_size / 2)
         d = uvd[:, :, 2:] * (cube.view(B, 1, 3)[:, :, 2:] / 2.0) + center.view(B, 1, 3)[:, :, 2:]
-        hom = torch.cat((uv, torch.ones_like(d)), -1)
-        tr = torch.matmul(Minv.view(B, 1, 3, 3), hom.unsqueeze(-1)).squeeze(-1)[:, :, 0:2]
-        x = (tr[:, :, 0] - cam[:, 2:3]) * d[:, :, 0] / cam[:, 0:1]
-        y = flip * (tr[:, :, 1] - cam[:, 3:4]) * d[:, :, 0] / cam[:, 1:2]
+        # [u, v, 1] through the first two rows of M^-1, written out (as a batched 3x3 @ 3x1 product over B x P the library's GEMM takes
+        # 440 us for the 1024 pixels of a map: one tiny matrix per batch entry)
+        Mi = Minv.view(B, 1, 9)
+        tx = Mi[:, :, 0] * uv[:, :, 0] + Mi[:, :, 1] * uv[:, :, 1] + Mi[:, :, 2]
+        ty = Mi[:, :, 3] * uv[:, :, 0] + Mi[:, :, 4] * uv[:, :, 1] + Mi[:, :, 5]
+        x = (tx - cam[:, 2:3]) * d[:, :, 0] / cam[:, 0:1]
+        y = flip * (ty - cam[:, 3:4]) * d[:, :, 0] / cam[:, 1:2]
         xyz = torch.stack((x, y, d[:, :, 0]), -1)
         return (xyz - center.view(B, 1, 3)) / (cube.view(B, 1, 3) / 2.0)
 
@@ -463,16 +466,14 @@ class TrainGraph:
         x = F.relu(x)
         x = F.relu(x + self.emb1d(p + ".pcl_feat_emb_RGB", pf_rgb))
         att = F.softmax(pw.permute(0, 2, 1), -1)
-        jf = torch.matmul(att, x)
+        jf = bmm_small_k(att, x) if (x.is_cuda and x.shape[-1] % 4 == 0) else torch.matmul(att, x)
         jf = F.relu(self.emb1d(p + ".joint_feat_emb", jf) + self.emb1d(p + ".joint_xyz_emb", joint_xyz.detach()))
         jf = self.desa(p + ".FA", x, jf, pcl, joint_xyz.detach())
         h_init, r3d = self.kp_interaction_tr(p + ".init_TR", jf)
         r3d = r3d.float()  # geometry, heat map and the returned joints are fp32 in every precision
         hm = joint2heatmap(r3d[:, :, :2], 0.8, H, sigma=1)
         # geometry adjacency map (dataloader/loader.py:791-819): the joints go through the uvd -> xyz map again, like the pixels
-        u, v = self.pixel_grid(H, img_feat.device)
-        uvd_pix = torch.stack((u.expand(B, -1), v.expand(B, -1), img_down.reshape(B, -1)), -1)
-        ix = self.uvd2xyz(uvd_pix, center, Minv, cube, cam, img_size, flip)
+        ix = self.img_xyz  # pixel positions of the depth map (dataloader/loader.py:936-955): written by kpf_img2pcl_top4_f32, once per forward
         jx = self.uvd2xyz(r3d, center, Minv, cube, cam, img_size, flip)
         gam = (1 / (10 * torch.sum(torch.pow(ix.unsqueeze(1) - jx.unsqueeze(2), 2), dim=-1) + 1)).view(B, J, H, W)
         # Conv2d(128 + 21 -> 21, k = 1) (model/model.py:262,336): rows of 149 channels, input and output channel counts zero-padded to
@@ -489,7 +490,8 @@ class TrainGraph:
         # into one batched GEMM [J x HW] @ [HW x C] — the same identity the inference kernel (kpf_gate_reduce_f32) uses
         wsp = self.t[p + ".fc_spatial2joint_feature.weight"].view(1, 1, -1)
         frows = F.relu(img_feat_rgb.float()).permute(0, 2, 3, 1).reshape(B, H * W, C)
-        fj = torch.bmm(g.reshape(B, J, H * W) * wsp, frows) + self.t[p + ".fc_spatial2joint_feature.bias"]
+        gw = g.reshape(B, J, H * W) * wsp
+        fj = (bmm_small_k(gw, frows) if (frows.is_cuda and C % 4 == 0) else torch.bmm(gw, frows)) + self.t[p + ".fc_spatial2joint_feature.bias"]
         if prev_feat is not None:
             fj = F.relu((fj + prev_feat) / 2)
         dec = self.decoder_layer(p + ".crossTR.decoder.3", fj, h_init)
@@ -524,7 +526,8 @@ class TrainGraph:
                                          B, S, Fs, float(kernel), int(img_size), int(flip), _stream()), "kpf_offset2joint_f32")
         clos = torch.empty(B, N, 4, device=dev)
         index = torch.empty(B, N, 4, device=dev, dtype=torch.int32)
-        L.check(lib.kpf_img2pcl_top4_f32(_ptr(pcl), _ptr(img), _ptr(center), _ptr(Minv), _ptr(cube), _ptr(cam), _ptr(clos), _ptr(index), None,
+        self.img_xyz = torch.empty(B, Fs * Fs, 3, device=dev)
+        L.check(lib.kpf_img2pcl_top4_f32(_ptr(pcl), _ptr(img), _ptr(center), _ptr(Minv), _ptr(cube), _ptr(cam), _ptr(clos), _ptr(index), _ptr(self.img_xyz),
                                          B, N, S, Fs, int(img_size), int(flip), _stream()), "kpf_img2pcl_top4_f32")
         idx = index.long()
         img_down = F.interpolate(img, [Fs, Fs])

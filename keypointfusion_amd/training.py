@@ -644,6 +644,36 @@ def attn21(q, k, v, heads, scale, p_drop=0.0, rng=None, call_id=0):
     return Attn21.apply(q, k, v, heads, scale, p_drop, rng, call_id)
 
 
+class BmmSmallK(torch.autograd.Function):
+    """out[b] = A[b] (J x P) @ X[b] (P x C) with few rows J (the 21 joints): forward and dA on the library's batched GEMM (10-12 us),
+    dX = A^T dOut — a K = J product the library takes 443 us for — on kpf_bmm_small_k_dx."""
+
+    @staticmethod
+    def forward(ctx, A, X):
+        A, X = A.float().contiguous(), X.float().contiguous()
+        ctx.save_for_backward(A, X)
+        return torch.bmm(A, X)
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import lib as L
+        A, X = ctx.saved_tensors
+        B, J, P = A.shape
+        Cc = X.shape[-1]
+        dout = dout.float().contiguous()
+        dA = torch.bmm(dout, X.transpose(1, 2)) if ctx.needs_input_grad[0] else None
+        dX = None
+        if ctx.needs_input_grad[1]:
+            dX = torch.empty_like(X)
+            L.check(L.load().kpf_bmm_small_k_dx(A.data_ptr(), dout.data_ptr(), dX.data_ptr(), B, J, P, Cc, torch.cuda.current_stream().cuda_stream),
+                    "kpf_bmm_small_k_dx")
+        return dA, dX
+
+
+def bmm_small_k(A, X):
+    return BmmSmallK.apply(A, X)
+
+
 def layer_norm_rows(x, weight, bias, eps, out_dtype=None):
     return LayerNormRows.apply(x, weight, bias, eps, out_dtype)
 

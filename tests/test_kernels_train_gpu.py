@@ -411,3 +411,18 @@ def test_attn21_dropout_is_a_bernoulli_mask_consistent_between_forward_and_backw
     rng2 = torch.tensor([1234, 1], dtype=torch.int64, device="cuda")
     out2 = attn21(q, k, v, 4, 32 ** -0.5, p, rng2, 1)
     assert not torch.equal(out2 != 0, out != 0)
+
+
+@pytest.mark.parametrize("B,J,P,Cc", [(3, 21, 1024, 128), (2, 21, 50, 8)])
+def test_bmm_small_k_forward_backward_match_torch(B, J, P, Cc):
+    from keypointfusion_amd.training import bmm_small_k
+    g = torch.Generator().manual_seed(P)
+    A, X, dout = torch.randn(B, J, P, generator=g), torch.randn(B, P, Cc, generator=g), torch.randn(B, J, Cc, generator=g)
+    Ad, Xd = A.cuda().requires_grad_(True), X.cuda().requires_grad_(True)
+    out = bmm_small_k(Ad, Xd)
+    out.backward(dout.cuda())
+    Ar, Xr = A.double().requires_grad_(True), X.double().requires_grad_(True)
+    ref = torch.bmm(Ar, Xr)
+    ref.backward(dout.double())
+    rel = lambda x, r: float((x.detach().cpu().double() - r.detach()).abs().max()) / float(r.detach().abs().max())
+    assert rel(out, ref) < 1e-5 and rel(Ad.grad, Ar.grad) < 1e-5 and rel(Xd.grad, Xr.grad) < 1e-5
