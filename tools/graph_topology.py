@@ -1,3 +1,6 @@
+"""Capture one training iteration and dump the hipGraph's topology (hipGraphDebugDotPrint): node kinds, in / out degrees (a single
+chain?), and the memset / memcpy nodes with their neighbours -> gpurun_out/graph_nodes.txt.  Used to pin the replay defect of
+DESIGN.md §4.5 on the runtime (5244 nodes in one chain: 5120 kernels, 112 D2D copies, 12 eight-byte memsets)."""
 import os, sys, re, torch, collections
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests")
 from conftest import synthetic_sd

@@ -1,3 +1,5 @@
+"""Top rows of a rocprofv3 --stats kernel summary:  python3 tools/kstats.py <output dir> [rows]
+"""
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)[0]
 for r in list(csv.DictReader(open(f)))[:int(sys.argv[2]) if len(sys.argv) > 2 else 16]:

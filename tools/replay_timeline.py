@@ -1,3 +1,7 @@
+"""Per-replay timeline of a captured training iteration from a rocprofv3 kernel trace: kernels, span, busy time, gaps and the largest
+gaps of the last replays (iterations are delimited by pack_weights_multi_kernel, the first launch of every forward).
+  rocprofv3 --kernel-trace --output-format csv -d /tmp/p -- python3 bench.py --workload train128 --no-cpu-baseline; python3 tools/replay_timeline.py /tmp/p
+"""
 import csv, sys, glob
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))

@@ -1,3 +1,7 @@
+"""Wall-time decomposition of the two-stream backbone step from a rocprofv3 kernel trace: time with two GEMMs resident, one GEMM alone, GEMM +
+elementwise, elementwise only, idle (why a staggered schedule has nothing to gain).
+  rocprofv3 --kernel-trace --output-format csv -d /tmp/p -- python3 bench.py --no-cpu-baseline --no-split-record; python3 tools/two_stream_timeline.py /tmp/p
+"""
 import csv, sys, glob
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
