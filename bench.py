@@ -30,7 +30,8 @@ import statistics
 import sys
 import time
 
-import torch
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")  # HIP-runtime graph-replay workaround (keypointfusion_amd/__init__.py): before the first HIP call
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
