@@ -2,22 +2,26 @@
 
 `KPFusion.forward` under `.train()` comes here.  The reference trains with batch-statistics BatchNorm, dropout in the transformer
 layers and autograd through everything (`train.py:209-265`, `model/model.py:287-426`); this module builds that graph on the module's
-own Parameters so that `loss.backward()` fills their `.grad`:
+own Parameters so that `loss.backward()` fills their `.grad`, out of autograd Functions whose forward AND backward are HIP kernels
+(keypointfusion_amd/training.py):
 
-  * every convolution / Linear whose shape the HIP implicit GEMM takes (input channels a multiple of 4; stride 1 or a patchify
-    kernel == stride) runs forward AND data-gradient on `kpf_conv2d_f32` through `training.Conv2dNHWC` (weight gradients: library GEMM /
-    torch.nn.grad); the few that do not (the 1- and 3-channel stems, ResNet's strided 3x3 / 7x7) go through torch's convolution;
-  * normalisations, activations, the depthwise 7x7, gathers, softmaxes and the 21-token attention use PyTorch-ROCm ops with torch
-    autograd ("host code stays Python on PyTorch-ROCm for autograd", BASELINE.json north_star) — they are elementwise / reduction work
-    whose backward is generated, not hand-written, in this round;
-  * the integer decisions (top-4 pixels, ball-query sets) and the detached soft-argmax decode come from the HIP kernels of the
-    inference path (`kpf_img2pcl_top4_f32`, `kpf_offset2joint_f32`) or a no-grad torch restatement (ball query): no gradient flows
-    through them in the reference either (`model/model.py:308-309,324,327,404-405`).
+  * every convolution / Linear (any stride, padding, channel count: odd widths are zero-padded to whole channel groups) — implicit GEMM
+    forward and data gradient, split-K weight gradient; kernel-layout operands persistent across steps (`training.PackCache`);
+  * depthwise 7x7, BatchNorm(+ReLU) with batch statistics, LayerNorm, GELU, layer scale + residual, bilinear x2, max-pool, the
+    4-nearest-pixel sampling, DESA's grouping, the 21-token attention core (softmax(QK^T)V with dropout), the small-K batched products
+    of the joint pooling;
+  * the integer decisions (top-4 pixels, ball-query sets) and the detached soft-argmax decode come from the kernels of the inference path
+    (`kpf_img2pcl_top4_f32`, `kpf_ball_group_f32`, `kpf_offset2joint_f32`): no gradient flows through them in the reference either
+    (`model/model.py:308-309,324,327,404-405`).
+What stays on torch ops: residual / embedding adds, ReLU / sigmoid, concatenations, dropout outside the attention, the geometry of the
+gate (a few element-wise ops on B x 21 x 1024 maps) and the loss codec.  Every kernel adds in a fixed order: two iterations on the same
+batch and weights give the same bits (tests/test_training.py::test_graphed_train_step_replays_are_bit_identical).
 
 BatchNorm: per-replica batch statistics, running statistics updated in place with momentum 0.1 (PyTorch semantics, like the
 reference under DataParallel).  Dropout: `module.train_dropout` (default 0.1 = config/config.json hidden_dropout_prob /
 attention_probs_dropout_prob and the decoder layer's default, model/transfusion_head.py:95); the parity tests run with 0 because the
-reference's random stream cannot be reproduced.  Everything is fp32.
+reference's random stream cannot be reproduced.  `module.precision`: "f32", or "bf16" mixed precision (fp32 master weights, statistics,
+geometry and loss; GEMM operands rounded to bf16).
 """
 import math
 
@@ -53,7 +57,6 @@ class TrainGraph:
         # kernel-layout operands of every convolution / Linear whose source is parameter storage: persistent buffers, rewritten from the
         # current parameter values by one multi-tensor launch here (training.PackCache); mixed precision rounds the fp32 master to the
         # 16-bit operand in the same kernel (no shadow copies)
-        self.w16 = {}
         from .training import PackCache
         caches = module.__dict__.setdefault("_pack_cache", {})
         dev = next(module.parameters()).device
@@ -66,17 +69,6 @@ class TrainGraph:
     # ---- primitives ---------------------------------------------------------------------------------------------------------------
     def has(self, name):
         return name in self.t
-
-    def conv(self, x, p_w, p_b=None, stride=1, pad=0):
-        """NCHW in / out.  HIP forward + data-gradient where the implicit GEMM takes the shape, torch otherwise."""
-        w = self.t[p_w]
-        b = self.t[p_b] if p_b is not None else None
-        cin, k = w.shape[1], w.shape[2]
-        patch = stride == k and pad == 0 and stride > 1
-        if cin % self.cmul == 0 and (stride == 1 or patch) and w.shape[2] == w.shape[3]:
-            y = conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous(), w, b, stride, pad, self.prec, None, p_w, self.packs)
-            return y.permute(0, 3, 1, 2)
-        return F.conv2d(x, w, b, stride=stride, padding=pad)
 
     def linear(self, x, p_w, p_b=None):
         w = self.t[p_w]
@@ -141,11 +133,9 @@ class TrainGraph:
         patch = stride == k and pad == 0 and stride > 1
         if w.shape[2] == w.shape[3]:  # every square kernel, any stride / padding: forward, data- and weight-gradient on the HIP kernels
             cpad = (-cin) % self.cmul
-            w16 = self.w16.get(p_w)
             if cpad:  # the 3- / 1-channel images of the stems: zero channels on both operands (the weight's gradient is sliced back)
                 x, w = F.pad(x, (0, cpad)), F.pad(w, (0, 0, 0, 0, 0, cpad))
-                w16 = F.pad(w16, (0, 0, 0, 0, 0, cpad)) if w16 is not None else None
-            return conv2d_nhwc(x.contiguous(), w, b, stride, pad, self.prec, w16, None if cpad else p_w, self.packs)
+            return conv2d_nhwc(x.contiguous(), w, b, stride, pad, self.prec, None, None if cpad else p_w, self.packs)
         return F.conv2d(x.permute(0, 3, 1, 2), w, b, stride=stride, padding=pad).permute(0, 2, 3, 1).contiguous()
 
     def bn_l(self, x, p, eps=1e-5, relu=False, out16=True):
@@ -235,14 +225,10 @@ class TrainGraph:
         bs = [self.t[p + ".finals.%d.bias" % i] for i in range(3)]
         n = sum(w.shape[0] for w in ws)
         npad = (n + 3) // 4 * 4
-        w16s = [self.w16.get(p + ".finals.%d.weight" % i) for i in range(3)]
         if npad != n:
             ws.append(ws[0].new_zeros((npad - n,) + tuple(ws[0].shape[1:])))
             bs.append(bs[0].new_zeros(npad - n))
-            if w16s[0] is not None:
-                w16s.append(w16s[0].new_zeros((npad - n,) + tuple(ws[0].shape[1:])))
-        w16 = torch.cat(w16s, 0) if all(w is not None for w in w16s) else None
-        y = conv2d_nhwc(feat.contiguous(), torch.cat(ws, 0), torch.cat(bs, 0), 1, 0, self.prec, w16)
+        y = conv2d_nhwc(feat.contiguous(), torch.cat(ws, 0), torch.cat(bs, 0), 1, 0, self.prec)
         return y[..., :n]
 
     def unet(self, p, img):
@@ -306,21 +292,19 @@ class TrainGraph:
             return idx
 
     # ---- fusion head (model/model.py:129-351, model/transfusion_head.py:137-173) -----------------------------------------------------------
-    def linear_rows(self, rows, w, b, w16=None, key=None):
+    def linear_rows(self, rows, w, b, key=None):
         """nn.Linear / Conv1d(k=1) / Conv2d(k=1) over rows [M, Cin] on the HIP GEMM (forward, data- and weight-gradient); input widths
         that are not whole channel groups (3-d coordinates, the 105 pose channels) are zero-padded together with the weight."""
         cin = rows.shape[-1]
         pad = (-cin) % self.cmul
         if pad:
             rows, w = F.pad(rows, (0, pad)), F.pad(w, (0, pad))
-            w16 = F.pad(w16, (0, pad)) if w16 is not None else None
-        return linear_hip(rows.contiguous(), w, b, self.prec, w16, None if pad else key, self.packs)
+        return linear_hip(rows.contiguous(), w, b, self.prec, None, None if pad else key, self.packs)
 
     def emb1d(self, p, x):
         """Conv1d(k=1) + BatchNorm1d over (B, N) (model/model.py:254-259) on rows."""
         B, N, Cin = x.shape
-        w16 = self.w16.get(p + ".0.weight")
-        y = self.linear_rows(x.reshape(B * N, Cin), self.t[p + ".0.weight"].flatten(1), self.t[p + ".0.bias"], w16.flatten(1) if w16 is not None else None, p + ".0.weight")
+        y = self.linear_rows(x.reshape(B * N, Cin), self.t[p + ".0.weight"].flatten(1), self.t[p + ".0.bias"], p + ".0.weight")
         return self.bn_l(y.view(B, N, -1), p + ".1", out16=False)  # (summed with the other embeddings: kept fp32)
 
     @staticmethod
@@ -384,22 +368,17 @@ class TrainGraph:
             # the three 1x1 Conv2d + BatchNorm2d of a scale (model/model.py:176-192) on rows [B*J*64, .]
             q = lambda name, k: self.t[p + ".%s.%d%s" % (name, i, k)]
 
-            def q16(name, k):
-                w16 = self.w16.get(p + ".%s.%d%s" % (name, i, k))
-                return w16.flatten(1) if w16 is not None else None
-
             loc = self.bn_l(self.linear_rows((gx / r).reshape(-1, 3), q("conv_l0_blocks", ".weight").flatten(1), q("conv_l0_blocks", ".bias"),
-                                             q16("conv_l0_blocks", ".weight"), p + ".conv_l0_blocks.%d.weight" % i), p + ".bn_l0_blocks.%d" % i, out16=False)
+                                             p + ".conv_l0_blocks.%d.weight" % i), p + ".bn_l0_blocks.%d" % i, out16=False)
             ft = self.bn_l(self.linear_rows(gf.reshape(-1, C), q("conv_f0_blocks", ".weight").flatten(1), q("conv_f0_blocks", ".bias"),
-                                            q16("conv_f0_blocks", ".weight"), p + ".conv_f0_blocks.%d.weight" % i), p + ".bn_f0_blocks.%d" % i, out16=False)
+                                            p + ".conv_f0_blocks.%d.weight" % i), p + ".bn_f0_blocks.%d" % i, out16=False)
             g = F.relu(loc + ft)
-            g = self.bn_l(self.linear_rows(g, q("conv_blocks", ".0.weight").flatten(1), q("conv_blocks", ".0.bias"), q16("conv_blocks", ".0.weight"), p + ".conv_blocks.%d.0.weight" % i),
+            g = self.bn_l(self.linear_rows(g, q("conv_blocks", ".0.weight").flatten(1), q("conv_blocks", ".0.bias"), p + ".conv_blocks.%d.0.weight" % i),
                           p + ".bn_blocks.%d.0" % i, relu=True)
             outs.append(g.view(B, Jn, 64, -1).max(2)[0])  # B x J x 128
         outs.append(node_feat)
         cat = torch.cat(outs, -1).reshape(B * Jn, -1)  # rows of 512
-        wf16 = self.w16.get(p + ".fusion.0.weight")
-        y = self.linear_rows(cat, self.t[p + ".fusion.0.weight"].flatten(1), self.t[p + ".fusion.0.bias"], wf16.flatten(1) if wf16 is not None else None, p + ".fusion.0.weight")
+        y = self.linear_rows(cat, self.t[p + ".fusion.0.weight"].flatten(1), self.t[p + ".fusion.0.bias"], p + ".fusion.0.weight")
         return self.bn_l(y, p + ".fusion.1", relu=True, out16=False).view(B, Jn, -1)
 
     def bert_layer(self, p, h, heads=4):
