@@ -483,15 +483,21 @@ class TrainGraph:
         dev = img.device
         f = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
         img_rgb, img, pcl, center, M, cube, cam = map(f, (img_rgb, img, pcl, center, M, cube, cam))
-        if self.prec != "f32":
-            from .training import _TDT
-            with torch.autocast("cuda", dtype=_TDT[self.prec]):
-                return self._forward(lib, dev, img_rgb, img, pcl, center, M, cube, cam, kernel, img_size, flip)
         return self._forward(lib, dev, img_rgb, img, pcl, center, M, cube, cam, kernel, img_size, flip)
 
     def _forward(self, lib, dev, img_rgb, img, pcl, center, M, cube, cam, kernel, img_size, flip):
-        img_offset, img_feat = self.unet("backbone_d", img)
-        img_offset_rgb, img_feat_rgb = self.unet("backbone_rgb", img_rgb)
+        # mixed precision covers the two backbones (where the FLOPs are); the fusion head runs fp32 like the inference path's (its tensors
+        # are small and latency-bound, and a consistent type there removes several hundred cast launches per iteration)
+        if self.prec != "f32":
+            from .training import _TDT
+            with torch.autocast("cuda", dtype=_TDT[self.prec]):
+                img_offset, img_feat = self.unet("backbone_d", img)
+                img_offset_rgb, img_feat_rgb = self.unet("backbone_rgb", img_rgb)
+            img_feat, img_feat_rgb = img_feat.float(), img_feat_rgb.float()
+            self.prec, self.cmul = "f32", 4
+        else:
+            img_offset, img_feat = self.unet("backbone_d", img)
+            img_offset_rgb, img_feat_rgb = self.unet("backbone_rgb", img_rgb)
         img_offset, img_offset_rgb = img_offset.float(), img_offset_rgb.float()  # the dense maps are returned (and decoded) in fp32
         result = [img_offset, img_offset_rgb]
         B, _, S, _ = img.shape
