@@ -361,6 +361,14 @@ int kpf_attn21_backward(const float* dctx, const float* q, const float* k, const
  * products of model/model.py:318-320 and 336-341 (a K = J batched GEMM the library handles badly).  fp32, C % 4 == 0, J * C * 4 B <= 64 KB. */
 int kpf_bmm_small_k_dx(const float* A, const float* dOut, float* dX, int B, int J, int P, int C, void* stream);
 
+/* Training: layer scale + residual of the ConvNeXt block, out = x + gamma * y (convNeXT/convnext.py:48-51): x / out / g fp32 [rows][C], y / dy in
+ * y_dtype (fp32 or the 16-bit GEMM storage type), gamma / dgamma [C].  backward: dy = g * gamma, dgamma = column sums of g * y added in a
+ * fixed order through ws (>= kpf_layer_scale_ws_floats(rows, C) floats); C % 4 == 0, C <= 1024. */
+long kpf_layer_scale_ws_floats(long rows, int C);
+int kpf_layer_scale_forward(const float* x, const void* y, int y_dtype, const float* gamma, float* out, long rows, int C, void* stream);
+int kpf_layer_scale_backward(const float* g, const void* y, int y_dtype, const float* gamma, void* dy, float* dgamma, float* ws, long ws_floats,
+                             long rows, int C, void* stream);
+
 /* Training: one-launch packing of a reference-layout weight w [N][Cin][KH][KW] (src_dtype: KPF_DT_F32 master, or a 16-bit copy) into an
  * operand of kpf_conv2d_f32 / _h16 (dst_dtype; fp32 -> 16-bit rounds to nearest even), rows zero-padded to Kp:
  *   mode 0  forward rows        dst [n_pad][Kp], k = (ky, kx, c)

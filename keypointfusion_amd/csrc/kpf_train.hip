@@ -939,3 +939,99 @@ extern "C" int kpf_bmm_small_k_dx(const float* A, const float* dOut, float* dX, 
   hipLaunchKernelGGL(bmm21_dx_kernel, dim3(gx, B), dim3(256), (size_t)J * C * sizeof(float), reinterpret_cast<hipStream_t>(stream), A, dOut, dX, J, P, C);
   return kpf_check_launch("kpf_bmm_small_k_dx");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Layer scale + residual of the ConvNeXt block, out = x + gamma * y (convNeXT/convnext.py:48-51), forward and backward.  x, out and the
+// incoming gradient are fp32 (the residual stream), y / dy are in the GEMM's storage type (fp32, or 16-bit under mixed precision: the
+// torch expression needs a cast on either side).  dgamma = column sums of g * y: per-workgroup partial sums in registers (a lane owns up
+// to 4 channel quads, rows walked in a fixed order), four waves combined through LDS, then the LayerNorm backward's fixed-order reduce.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+template <typename TY>
+__global__ __launch_bounds__(256) void layer_scale_fwd_kernel(const float* __restrict__ x, const TY* __restrict__ y, const float* __restrict__ gamma,
+                                                              float* __restrict__ out, long rows, int C4) {
+  const long total = rows * C4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int q = (int)(i % C4);
+    const f32x4 xv = kpf_ld4(x + 4 * i), yv = kpf_ld4(y + 4 * i), g = kpf_ld4(gamma + 4 * q);
+    kpf_st4(out + 4 * i, f32x4{fmaf(g[0], yv[0], xv[0]), fmaf(g[1], yv[1], xv[1]), fmaf(g[2], yv[2], xv[2]), fmaf(g[3], yv[3], xv[3])});
+  }
+}
+
+template <typename TY>
+__global__ __launch_bounds__(256) void layer_scale_bwd_kernel(const float* __restrict__ g, const TY* __restrict__ y, const float* __restrict__ gamma,
+                                                              TY* __restrict__ dy, float* __restrict__ part, long rows, int C4) {
+  extern __shared__ float ls_lds[];  // [4 waves][C]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C = 4 * C4;
+  f32x4 acc[LN_MAXQ], gm[LN_MAXQ];
+#pragma unroll
+  for (int i = 0; i < LN_MAXQ; ++i) {
+    acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gm[i] = lane + 64 * i < C4 ? kpf_ld4(gamma + 4 * (lane + 64 * i)) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+#pragma unroll
+    for (int i = 0; i < LN_MAXQ; ++i) {
+      const int q = lane + 64 * i;
+      if (q < C4) {
+        const f32x4 gv = kpf_ld4(g + r * C + 4 * q), yv = kpf_ld4(y + r * C + 4 * q);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = gv[e] * gm[i][e];
+          acc[i][e] = fmaf(gv[e], yv[e], acc[i][e]);
+        }
+        kpf_st4(dy + r * C + 4 * q, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < LN_MAXQ; ++i)
+    if (lane + 64 * i < C4) kpf_st4(ls_lds + wave * C + 4 * (lane + 64 * i), acc[i]);
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) s += ls_lds[wv * C + c];
+    part[((long)blockIdx.x * 2) * C + c] = s;  // (slot layout of ln_bwd_reduce_kernel: [block][2][C]; the second plane is unused here)
+    part[((long)blockIdx.x * 2 + 1) * C + c] = 0.f;
+  }
+}
+
+template <typename T>
+int layer_scale_fwd_launch(const float* x, const void* y, const float* gamma, float* out, long rows, int C, void* stream) {
+  hipLaunchKernelGGL(layer_scale_fwd_kernel<T>, dim3(grid_for(rows * (C / 4))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, static_cast<const T*>(y),
+                     gamma, out, rows, C / 4);
+  return kpf_check_launch("kpf_layer_scale_forward");
+}
+template <typename T>
+int layer_scale_bwd_launch(const float* g, const void* y, const float* gamma, void* dy, float* dgamma, float* ws, long rows, int C, void* stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int nblk = ln_blocks(rows);
+  hipLaunchKernelGGL(layer_scale_bwd_kernel<T>, dim3(nblk), dim3(256), (size_t)4 * C * sizeof(float), st, g, static_cast<const T*>(y), gamma, static_cast<T*>(dy), ws,
+                     rows, C / 4);
+  int rc = kpf_check_launch("kpf_layer_scale_backward");
+  if (rc != KPF_OK) return rc;
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * C + 63) / 64), dim3(512), 0, st, ws, dgamma, ws + (long)nblk * 2 * C, nblk, C);
+  return kpf_check_launch("kpf_layer_scale_backward (reduce)");
+}
+}  // namespace
+
+extern "C" long kpf_layer_scale_ws_floats(long rows, int C) { return (long)ln_blocks(rows) * 2 * C + C; }
+
+extern "C" int kpf_layer_scale_forward(const float* x, const void* y, int y_dtype, const float* gamma, float* out, long rows, int C, void* stream) {
+  KPF_REQUIRE(x && y && gamma && out && rows > 0 && C > 0 && C % 4 == 0, "kpf_layer_scale_forward: bad arguments");
+#define CALL(T) layer_scale_fwd_launch<T>(x, y, gamma, out, rows, C, stream)
+  KPF_DISPATCH_DT(y_dtype, "kpf_layer_scale_forward", CALL);
+#undef CALL
+}
+
+extern "C" int kpf_layer_scale_backward(const float* g, const void* y, int y_dtype, const float* gamma, void* dy, float* dgamma, float* ws, long ws_floats,
+                                        long rows, int C, void* stream) {
+  KPF_REQUIRE(g && y && gamma && dy && dgamma && ws && rows > 0 && C > 0 && C % 4 == 0 && C <= 256 * LN_MAXQ, "kpf_layer_scale_backward: bad arguments (C <= 1024)");
+  KPF_REQUIRE(ws_floats >= kpf_layer_scale_ws_floats(rows, C), "kpf_layer_scale_backward: workspace too small");
+#define CALL(T) layer_scale_bwd_launch<T>(g, y, gamma, dy, dgamma, ws, rows, C, stream)
+  KPF_DISPATCH_DT(y_dtype, "kpf_layer_scale_backward", CALL);
+#undef CALL
+}

@@ -92,6 +92,8 @@ _SIGS = {
     "kpf_ln_train_forward": [_P, _P, _P, _P, C.c_int, _P, _P, C.c_long, C.c_int, C.c_float, _P],
     "kpf_ln_train_backward": [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, C.c_long, C.c_long, C.c_int, _P],
     "kpf_gelu_forward": [_P, _P, C.c_int, C.c_long, _P],
+    "kpf_layer_scale_forward": [_P, _P, C.c_int, _P, _P, C.c_long, C.c_int, _P],
+    "kpf_layer_scale_backward": [_P, _P, C.c_int, _P, _P, _P, _P, C.c_long, C.c_long, C.c_int, _P],
     "kpf_bmm_small_k_dx": [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
     "kpf_attn21_forward": [_P] * 6 + [C.c_int] * 5 + [C.c_float, C.c_float, _P, C.c_int, _P],
     "kpf_attn21_backward": [_P] * 9 + [C.c_int] * 5 + [C.c_float, C.c_float, _P],
@@ -105,6 +107,7 @@ _LONG_SIGS = {  # entries returning a long
     "kpf_bn_ws_floats": [C.c_long, C.c_int],
     "kpf_row_gather_ws_ints": [C.c_int] * 4,
     "kpf_ln_ws_floats": [C.c_long, C.c_int],
+    "kpf_layer_scale_ws_floats": [C.c_long, C.c_int],
 }
 EXPORTS = sorted(list(_SIGS) + list(_LONG_SIGS) + ["kpf_last_error", "kpf_abi_version"])
 

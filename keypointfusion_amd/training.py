@@ -130,20 +130,38 @@ class SmoothL1Loss(torch.nn.Module):
 
 
 class _LayerScaleResidual(torch.autograd.Function):
-    """out = x + gamma * y (convNeXT/convnext.py:48-51, drop_path = identity) as one node: one fused forward launch, and a backward of
-    three (dy = g * gamma; dgamma = column sums of g * y) where autograd's mul / add nodes take eight."""
+    """out = x + gamma * y (convNeXT/convnext.py:48-51, drop_path = identity) on kpf_layer_scale_forward / _backward: x / out fp32 (the
+    residual stream), y in the GEMM's storage type (no casts under mixed precision); dgamma added in a fixed order."""
 
     @staticmethod
     def forward(ctx, x, gamma, y):
-        ctx.save_for_backward(gamma, y)
-        return torch.addcmul(x, y, gamma)
+        from . import lib as L
+        x, y = x.float().contiguous(), y.contiguous()
+        Cc = x.shape[-1]
+        rows = x.numel() // Cc
+        gm = gamma.detach().float().contiguous()
+        assert y.dtype in _KDT and y.shape == x.shape and Cc % 4 == 0
+        out = torch.empty_like(x)
+        L.check(L.load().kpf_layer_scale_forward(x.data_ptr(), y.data_ptr(), _KDT[y.dtype], gm.data_ptr(), out.data_ptr(), rows, Cc,
+                                                 torch.cuda.current_stream().cuda_stream), "kpf_layer_scale_forward")
+        ctx.save_for_backward(gm, y)
+        return out
 
     @staticmethod
     def backward(ctx, g):
-        gamma, y = ctx.saved_tensors
-        dy = (g * gamma).to(y.dtype) if ctx.needs_input_grad[2] else None
-        dgamma = (g.reshape(-1, g.shape[-1]).float() * y.reshape(-1, y.shape[-1]).float()).sum(0).to(gamma.dtype) if ctx.needs_input_grad[1] else None
-        return (g if ctx.needs_input_grad[0] else None), dgamma, dy
+        from . import lib as L
+        lib = L.load()
+        gm, y = ctx.saved_tensors
+        Cc = y.shape[-1]
+        rows = y.numel() // Cc
+        g = g.float().contiguous()
+        dy = torch.empty_like(y)
+        dgamma = torch.empty(Cc, device=y.device, dtype=torch.float32)
+        nws = lib.kpf_layer_scale_ws_floats(rows, Cc)
+        ws = torch.empty(nws, device=y.device, dtype=torch.float32)
+        L.check(lib.kpf_layer_scale_backward(g.data_ptr(), y.data_ptr(), _KDT[y.dtype], gm.data_ptr(), dy.data_ptr(), dgamma.data_ptr(), ws.data_ptr(), nws, rows, Cc,
+                                             torch.cuda.current_stream().cuda_stream), "kpf_layer_scale_backward")
+        return g, dgamma, dy
 
 
 def layer_scale_residual(x, gamma, y):

@@ -426,3 +426,26 @@ def test_bmm_small_k_forward_backward_match_torch(B, J, P, Cc):
     ref.backward(dout.double())
     rel = lambda x, r: float((x.detach().cpu().double() - r.detach()).abs().max()) / float(r.detach().abs().max())
     assert rel(out, ref) < 1e-5 and rel(Ad.grad, Ar.grad) < 1e-5 and rel(Xd.grad, Xr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("ydt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(4, 16, 16, 96), (2, 4, 4, 768), (3, 5, 7, 192)])
+def test_layer_scale_residual_forward_backward_match_torch(shape, ydt):
+    from keypointfusion_amd.training import layer_scale_residual
+    Cc = shape[-1]
+    g = torch.Generator().manual_seed(Cc)
+    x, y, gm, dout = torch.randn(*shape, generator=g), torch.randn(*shape, generator=g).to(ydt), torch.randn(Cc, generator=g), torch.randn(*shape, generator=g)
+    xd, yd, gd = x.cuda().requires_grad_(True), y.cuda().requires_grad_(True), gm.cuda().requires_grad_(True)
+    out = layer_scale_residual(xd, gd, yd)
+    out.backward(dout.cuda())
+    xr, yr, gr = x.double().requires_grad_(True), y.double().requires_grad_(True), gm.double().requires_grad_(True)
+    ref = xr + gr * yr
+    ref.backward(dout.double())
+    rel = lambda a, r: float((a.detach().cpu().double() - r.detach()).abs().max()) / float(r.detach().abs().max())
+    eps = 2e-6 if ydt == torch.float32 else 2.0 ** -8
+    assert out.dtype == torch.float32 and rel(out, ref) < 2e-6
+    assert torch.equal(xd.grad.cpu(), dout) and yd.grad.dtype == ydt and rel(yd.grad, yr.grad) <= 1.01 * eps and rel(gd.grad, gr.grad) < 2e-5
+    g1 = gd.grad.clone()
+    gd.grad = None
+    layer_scale_residual(xd, gd, yd).backward(dout.cuda())
+    assert torch.equal(g1, gd.grad)
