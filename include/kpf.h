@@ -369,6 +369,15 @@ int kpf_layer_scale_forward(const float* x, const void* y, int y_dtype, const fl
 int kpf_layer_scale_backward(const float* g, const void* y, int y_dtype, const float* gamma, void* dy, float* dgamma, float* ws, long ws_floats,
                              long rows, int C, void* stream);
 
+/* Training: the dense-stage loss (train.py:211-224 with GFM.joint2offset / offset2joint_weight, util/generateFeature.py:59-84,166-195, and
+ * model/loss.py's SmoothL1): pd [B][5J][F][F] fp32 NCHW (3J unit offsets (j, xyz), J heat maps, J weight logits), img [B][1][S][S], uvd_gt
+ * [B][J][3].  forward writes part [B][J][2] = per-(sample, joint) sums of the element losses (pixel term over its 4 channels, coordinate
+ * term over its 3 coordinates): loss_pixel = sum(part[..., 0]) / (B*4J*F*F), loss_coord = sum(part[..., 1]) / (B*J*3).  backward: grad2 =
+ * device pointer to {dL/dloss_pixel, dL/dloss_coord}; every element of dpd [B][5J][F][F] is written.  F*F <= 1024, S % F == 0. */
+int kpf_dense_loss_forward(const float* pd, const float* img, const float* uvd_gt, float* part, int B, int J, int F, int S, float kernel_size, void* stream);
+int kpf_dense_loss_backward(const float* pd, const float* img, const float* uvd_gt, const float* grad2, float* dpd, int B, int J, int F, int S,
+                            float kernel_size, void* stream);
+
 /* Training: one-launch packing of a reference-layout weight w [N][Cin][KH][KW] (src_dtype: KPF_DT_F32 master, or a 16-bit copy) into an
  * operand of kpf_conv2d_f32 / _h16 (dst_dtype; fp32 -> 16-bit rounds to nearest even), rows zero-padded to Kp:
  *   mode 0  forward rows        dst [n_pad][Kp], k = (ky, kx, c)

@@ -1035,3 +1035,153 @@ extern "C" int kpf_layer_scale_backward(const float* g, const void* y, int y_dty
   KPF_DISPATCH_DT(y_dtype, "kpf_layer_scale_backward", CALL);
 #undef CALL
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The dense-stage loss of the training iteration in one kernel each way (train.py:211-224; util/generateFeature.py:59-84 joint2offset,
+// :166-195 offset2joint_weight; model/loss.py:3-26): for stage output pd [B][5J][F][F] (3J unit offsets (j, xyz), J heat maps, J weight
+// logits), the depth crop and the ground-truth joints uvd_gt [B][J][3]
+//     loss_pixel = mean SmoothL1(pd[:, :4J] - joint2offset(uvd_gt))          loss_coord = mean SmoothL1(decode(pd) - uvd_gt)
+// where decode is the masked soft-argmax.  One workgroup per (joint, sample): the F*F = 1024 pixels are 4 per thread, the softmax and the
+// three weighted sums are block reductions, the target maps are computed on the fly (never materialised); it writes the two partial
+// sums of its (sample, joint) and, backward, the gradient of its five channels — every element of d pd is written exactly once.
+// The library path was ~200 element-wise launches per iteration over B x 105 x 32 x 32 maps.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int LS_PX = 4;  // pixels per thread: F * F <= 1024
+
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ float block_max256(float v, float* red) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__device__ __forceinline__ float sl1(float z) {  // model/loss.py: quadratic below 0.01, 0.01 (|z| - 0.005) from there on
+  const float a = fabsf(z);
+  return a < 0.01f ? 0.5f * z * z : 0.01f * (a - 0.005f);
+}
+__device__ __forceinline__ float sl1_grad(float z) { return fabsf(z) < 0.01f ? z : (z > 0.f ? 0.01f : (z < 0.f ? -0.01f : 0.f)); }
+
+// MODE 0: forward (part[b][j] = {pixel sum, coord sum});  MODE 1: backward (dpd), scaled by gp = dL/dloss_pixel / n_pix, gc = dL/dloss_coord / n_coord
+template <int MODE>
+__global__ __launch_bounds__(256) void dense_loss_kernel(const float* __restrict__ pd, const float* __restrict__ img, const float* __restrict__ gt,
+                                                         float* __restrict__ part, float* __restrict__ dpd, const float* __restrict__ gscale, int J, int F, int S,
+                                                         float ks, float pix_w, float coord_w) {
+  __shared__ float red[4];
+  const int j = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int P = F * F, st = S / F;
+  const float* pdb = pd + (long)b * 5 * J * P;
+  const float* imb = img + (long)b * S * S;
+  const float gx = gt[((long)b * J + j) * 3 + 0], gy = gt[((long)b * J + j) * 3 + 1], gz = gt[((long)b * J + j) * 3 + 2];
+  float d[LS_PX], m[LS_PX], lg[LS_PX], u[LS_PX], v[LS_PX];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < LS_PX; ++k) {
+    const int p = tid + 256 * k;
+    const bool in = p < P;
+    const int py = in ? p / F : 0, px = in ? p - py * F : 0;
+    d[k] = in ? imb[(long)(py * st) * S + px * st] : 1.f;  // F.interpolate(nearest): source index = floor(dst * S / F)
+    m[k] = d[k] < 0.99f ? 1.f : 0.f;
+    u[k] = 2.f * ((float)px + 0.5f) / (float)F - 1.f;
+    v[k] = 2.f * ((float)py + 0.5f) / (float)F - 1.f;
+    lg[k] = in ? (d[k] > 0.99f ? -1e8f : pdb[(long)(4 * J + j) * P + p]) : -INFINITY;
+    mx = fmaxf(mx, lg[k]);
+  }
+  mx = block_max256(mx, red);
+  float w[LS_PX], se = 0.f;
+#pragma unroll
+  for (int k = 0; k < LS_PX; ++k) {
+    w[k] = tid + 256 * k < P ? __expf(lg[k] - mx) : 0.f;
+    se += w[k];
+  }
+  se = block_sum256(se, red);
+  const float inv = 1.0f / se;
+  float heat[LS_PX], dist[LS_PX], un[3][LS_PX], val[3][LS_PX], Jc[3];
+#pragma unroll
+  for (int k = 0; k < LS_PX; ++k) {
+    const int p = tid + 256 * k;
+    w[k] *= inv;
+    heat[k] = p < P ? pdb[(long)(3 * J + j) * P + p] : 0.f;
+    dist[k] = ks - heat[k] * m[k] * ks;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LS_PX; ++k) {
+      const int p = tid + 256 * k;
+      un[c][k] = p < P ? pdb[(long)(3 * j + c) * P + p] : 0.f;
+      const float coord = c == 0 ? u[k] : (c == 1 ? v[k] : d[k]);
+      val[c][k] = un[c][k] * m[k] * dist[k] + coord;
+      s = fmaf(val[c][k], w[k], s);
+    }
+    Jc[c] = block_sum256(s, red);
+  }
+  const float zc[3] = {Jc[0] - gx, Jc[1] - gy, Jc[2] - gz};
+  if (MODE == 0) {
+    // pixel term: the target maps of util/generateFeature.py:59-84 on the fly
+    float ps = 0.f;
+#pragma unroll
+    for (int k = 0; k < LS_PX; ++k) {
+      if (tid + 256 * k >= P) continue;
+      const float ox = gx - u[k], oy = gy - v[k], oz = gz - d[k];
+      const float dg = sqrtf(ox * ox + oy * oy + oz * oz + 1e-8f);
+      const float hm = (ks - dg) / ks;
+      const float mg = (hm >= 0.f ? 1.f : 0.f) * m[k];
+      ps += sl1(un[0][k] - ox / dg * mg) + sl1(un[1][k] - oy / dg * mg) + sl1(un[2][k] - oz / dg * mg) + sl1(heat[k] - hm * mg);
+    }
+    ps = block_sum256(ps, red);
+    if (tid == 0) {
+      part[((long)b * J + j) * 2 + 0] = ps;
+      part[((long)b * J + j) * 2 + 1] = sl1(zc[0]) + sl1(zc[1]) + sl1(zc[2]);
+    }
+  } else {
+    const float gp = gscale[0] * pix_w, gcs = gscale[1] * coord_w;
+    const float gJ[3] = {gcs * sl1_grad(zc[0]), gcs * sl1_grad(zc[1]), gcs * sl1_grad(zc[2])};
+    float* db = dpd + (long)b * 5 * J * P;
+#pragma unroll
+    for (int k = 0; k < LS_PX; ++k) {
+      const int p = tid + 256 * k;
+      if (p >= P) continue;
+      const float ox = gx - u[k], oy = gy - v[k], oz = gz - d[k];
+      const float dg = sqrtf(ox * ox + oy * oy + oz * oz + 1e-8f);
+      const float hm = (ks - dg) / ks;
+      const float mg = (hm >= 0.f ? 1.f : 0.f) * m[k];
+      const float tg[3] = {ox / dg * mg, oy / dg * mg, oz / dg * mg};
+      float dheat = gp * sl1_grad(heat[k] - hm * mg), dlog = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        db[(long)(3 * j + c) * P + p] = gp * sl1_grad(un[c][k] - tg[c]) + gJ[c] * w[k] * m[k] * dist[k];
+        dheat -= gJ[c] * w[k] * un[c][k] * m[k] * m[k] * ks;
+        dlog += gJ[c] * w[k] * (val[c][k] - Jc[c]);
+      }
+      db[(long)(3 * J + j) * P + p] = dheat;
+      db[(long)(4 * J + j) * P + p] = d[k] > 0.99f ? 0.f : dlog;  // masked_fill: no gradient into a replaced logit
+    }
+  }
+}
+}  // namespace
+
+extern "C" int kpf_dense_loss_forward(const float* pd, const float* img, const float* uvd_gt, float* part, int B, int J, int F, int S, float kernel_size,
+                                      void* stream) {
+  KPF_REQUIRE(pd && img && uvd_gt && part && B > 0 && J > 0 && F > 0 && F * F <= 256 * LS_PX && S % F == 0, "kpf_dense_loss_forward: bad arguments (F*F <= 1024)");
+  hipLaunchKernelGGL(dense_loss_kernel<0>, dim3(J, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pd, img, uvd_gt, part, (float*)nullptr,
+                     (const float*)nullptr, J, F, S, kernel_size, 0.f, 0.f);
+  return kpf_check_launch("kpf_dense_loss_forward");
+}
+
+extern "C" int kpf_dense_loss_backward(const float* pd, const float* img, const float* uvd_gt, const float* grad2, float* dpd, int B, int J, int F, int S,
+                                       float kernel_size, void* stream) {
+  KPF_REQUIRE(pd && img && uvd_gt && grad2 && dpd && B > 0 && J > 0 && F > 0 && F * F <= 256 * LS_PX && S % F == 0, "kpf_dense_loss_backward: bad arguments");
+  const float pix_w = 1.0f / ((float)B * 4 * J * F * F), coord_w = 1.0f / ((float)B * J * 3);
+  hipLaunchKernelGGL(dense_loss_kernel<1>, dim3(J, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pd, img, uvd_gt, (float*)nullptr, dpd, grad2, J, F, S,
+                     kernel_size, pix_w, coord_w);
+  return kpf_check_launch("kpf_dense_loss_backward");
+}

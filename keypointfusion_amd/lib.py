@@ -92,6 +92,8 @@ _SIGS = {
     "kpf_ln_train_forward": [_P, _P, _P, _P, C.c_int, _P, _P, C.c_long, C.c_int, C.c_float, _P],
     "kpf_ln_train_backward": [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, C.c_long, C.c_long, C.c_int, _P],
     "kpf_gelu_forward": [_P, _P, C.c_int, C.c_long, _P],
+    "kpf_dense_loss_forward": [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P],
+    "kpf_dense_loss_backward": [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P],
     "kpf_layer_scale_forward": [_P, _P, C.c_int, _P, _P, C.c_long, C.c_int, _P],
     "kpf_layer_scale_backward": [_P, _P, C.c_int, _P, _P, _P, _P, C.c_long, C.c_long, C.c_int, _P],
     "kpf_bmm_small_k_dx": [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],

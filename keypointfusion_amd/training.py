@@ -168,9 +168,43 @@ def layer_scale_residual(x, gamma, y):
     return _LayerScaleResidual.apply(x, gamma, y)
 
 
+class DenseStageLoss(torch.autograd.Function):
+    """(loss_pixel, loss_coord) of one dense stage (train.py:211-224) before their weights: SmoothL1 between the first 4J maps and
+    GFM.joint2offset(uvd_gt), and between the masked soft-argmax decode (GFM.offset2joint_weight) and uvd_gt — kpf_dense_loss_forward /
+    _backward: one workgroup per (joint, sample), target maps computed on the fly, one kernel each way instead of ~100 element-wise
+    launches per stage.  pixel_pd [B, 5J, F, F] (any strides), img [B, 1, S, S], uvd_gt [B, J, 3]."""
+
+    @staticmethod
+    def forward(ctx, pixel_pd, img, uvd_gt, kernel_size):
+        from . import lib as L
+        pd = pixel_pd.float().contiguous()
+        im, gt = img.detach().float().contiguous(), uvd_gt.detach().float().contiguous()
+        B, ch, Fs, _ = pd.shape
+        J = ch // 5
+        part = torch.empty(B, J, 2, device=pd.device, dtype=torch.float32)
+        L.check(L.load().kpf_dense_loss_forward(pd.data_ptr(), im.data_ptr(), gt.data_ptr(), part.data_ptr(), B, J, Fs, im.shape[-1], float(kernel_size),
+                                                torch.cuda.current_stream().cuda_stream), "kpf_dense_loss_forward")
+        sums = part.sum((0, 1))
+        ctx.save_for_backward(pd, im, gt)
+        ctx.ks = float(kernel_size)
+        return sums[0] / float(B * 4 * J * Fs * Fs), sums[1] / float(B * J * 3)
+
+    @staticmethod
+    def backward(ctx, g_pixel, g_coord):
+        from . import lib as L
+        pd, im, gt = ctx.saved_tensors
+        B, ch, Fs, _ = pd.shape
+        g2 = torch.stack((g_pixel, g_coord)).float().contiguous()
+        dpd = torch.empty_like(pd)
+        L.check(L.load().kpf_dense_loss_backward(pd.data_ptr(), im.data_ptr(), gt.data_ptr(), g2.data_ptr(), dpd.data_ptr(), B, ch // 5, Fs, im.shape[-1], ctx.ks,
+                                                 torch.cuda.current_stream().cuda_stream), "kpf_dense_loss_backward")
+        return dpd, None, None, None
+
+
 def kpfusion_loss(results, spatial_weight, img, uvd_gt, xyz_gt, epoch=0, stage_type=STAGE_TYPE, l1=None):
     """The loss of one training iteration, train.py:211-261.  results: the 6 forward outputs, spatial_weight: the 2 spatial weights.
     Returns (loss, parts) with parts a dict of the named scalar terms the reference logs."""
+    custom_l1 = l1
     l1 = l1 or SmoothL1Loss()
     loss = 0
     parts = {}
@@ -179,10 +213,14 @@ def kpfusion_loss(results, spatial_weight, img, uvd_gt, xyz_gt, epoch=0, stage_t
         if st == 1:  # dense stage: pixel-wise maps + decoded joints (both streams decode with the DEPTH image, train.py:221)
             pixel_pd = results[index]
             feature_size = pixel_pd.size(-1)
-            pixel_gt = joint2offset(uvd_gt, img, FEATURE_PARA, feature_size)
-            joint_uvd = offset2joint_weight(pixel_pd, img, FEATURE_PARA)
-            loss_pixel = l1(pixel_pd[:, :pixel_gt.size(1)], pixel_gt) * DECONV_WEIGHT
-            loss_coord = l1(joint_uvd, uvd_gt) * COORD_WEIGHT
+            if pixel_pd.is_cuda and custom_l1 is None and feature_size * feature_size <= 1024 and img.shape[-1] % feature_size == 0:
+                lp, lc = DenseStageLoss.apply(pixel_pd, img, uvd_gt, FEATURE_PARA)  # the same arithmetic in one HIP kernel each way
+                loss_pixel, loss_coord = lp * DECONV_WEIGHT, lc * COORD_WEIGHT
+            else:
+                pixel_gt = joint2offset(uvd_gt, img, FEATURE_PARA, feature_size)
+                joint_uvd = offset2joint_weight(pixel_pd, img, FEATURE_PARA)
+                loss_pixel = l1(pixel_pd[:, :pixel_gt.size(1)], pixel_gt) * DECONV_WEIGHT
+                loss_coord = l1(joint_uvd, uvd_gt) * COORD_WEIGHT
             loss = loss + (loss_pixel + loss_coord)
             parts["loss_pixel_%d" % index], parts["loss_coord_%d" % index] = loss_pixel, loss_coord
         elif st in (2, 3):

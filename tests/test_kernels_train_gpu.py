@@ -449,3 +449,31 @@ def test_layer_scale_residual_forward_backward_match_torch(shape, ydt):
     gd.grad = None
     layer_scale_residual(xd, gd, yd).backward(dout.cuda())
     assert torch.equal(g1, gd.grad)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_dense_stage_loss_kernel_matches_the_torch_codec(seed):
+    """kpf_dense_loss_forward / _backward against the torch restatement of GFM.joint2offset / offset2joint_weight + SmoothL1 (itself pinned to
+    the reference's fixtures on the CPU): both loss terms and the gradient of all 105 maps, on crops with background, a joint far from
+    the hand (empty target mask) and an all-background sample."""
+    from keypointfusion_amd import training as T
+    from keypointfusion_amd.weights import synthetic_batch
+    B = 3
+    g = torch.Generator().manual_seed(seed)
+    img = torch.from_numpy(synthetic_batch(B, 128, seed=seed + 2)["img"])
+    img[2] = 1.0  # all background: uniform soft-argmax weights, empty masks
+    pd = torch.randn(B, 105, 32, 32, generator=g) * 0.5
+    gt = torch.rand(B, 21, 3, generator=g) * 1.6 - 0.8
+    gt[0, 0] = torch.tensor([3.0, 3.0, 3.0])  # farther than the kernel size from every pixel
+    pr = pd.clone().double().requires_grad_(True)
+    l1 = T.SmoothL1Loss()
+    pg = T.joint2offset(gt.double(), img.double(), 0.8, 32)
+    lp_r = l1(pr[:, :84], pg)
+    lc_r = l1(T.offset2joint_weight(pr, img.double(), 0.8), gt.double())
+    (lp_r * 1.0 + lc_r * 100.0).backward()
+    pdd = pd.cuda().requires_grad_(True)
+    lp, lc = T.DenseStageLoss.apply(pdd, img.cuda(), gt.cuda(), 0.8)
+    (lp * 1.0 + lc * 100.0).backward()
+    assert abs(float(lp) - float(lp_r)) < 2e-6 * abs(float(lp_r)) and abs(float(lc) - float(lc_r)) < 2e-6 * abs(float(lc_r)), (float(lp), float(lp_r), float(lc), float(lc_r))
+    d = (pdd.grad.cpu().double() - pr.grad).abs().max()
+    assert float(d) < 2e-5 * float(pr.grad.abs().max()), float(d)
