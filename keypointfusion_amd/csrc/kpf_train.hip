@@ -646,7 +646,13 @@ __global__ __launch_bounds__(512) void ln_bwd_reduce_kernel(const float* __restr
   if (i < 2 * C) {
     const int which = i / C, c = i - which * C;
     const int b1 = min(nblk, (g + 1) * per);
-    for (int bk = g * per; bk < b1; ++bk) s += part[((long)bk * 2 + which) * C + c];
+    int bk = g * per;
+    for (; bk + 4 <= b1; bk += 4) {  // four loads in flight, added in index order
+      const float p0 = part[((long)bk * 2 + which) * C + c], p1 = part[((long)(bk + 1) * 2 + which) * C + c];
+      const float p2 = part[((long)(bk + 2) * 2 + which) * C + c], p3 = part[((long)(bk + 3) * 2 + which) * C + c];
+      s = (((s + p0) + p1) + p2) + p3;
+    }
+    for (; bk < b1; ++bk) s += part[((long)bk * 2 + which) * C + c];
   }
   seg[g][col] = s;
   __syncthreads();
@@ -680,8 +686,8 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const TA* __restrict__ dy
   }
 }
 
-inline int ln_blocks(long rows) {
-  long g = (rows + 3) / 4;
+inline int ln_blocks(long rows) {  // ~4 rows per wave at least: few partials to add for the small (B x 21)-row tensors of the fusion head
+  long g = (rows + 15) / 16;
   return (int)(g < 1 ? 1 : (g > 256 ? 256 : g));
 }
 }  // namespace
