@@ -285,6 +285,18 @@ def main():
     if graph_on[0] and not train and not backbones_only and args.in_flight > 1:
         launch_mode += ", %d batches in flight (independent graph slots / streams)" % args.in_flight
     dt, t_issue = timed(args.steps, args.warmup)
+    single = None
+    if train:  # one step issued into an idle GPU: host time of the enqueue vs the step's whole duration (which of the two bounds a replay)
+        iss, tot = [], []
+        for _ in range(3):
+            barrier()
+            t0 = time.perf_counter()
+            step()
+            t1 = time.perf_counter()
+            barrier()
+            iss.append(t1 - t0)
+            tot.append(time.perf_counter() - t0)
+        single = {"issue_ms": round(min(iss) * 1e3, 3), "total_ms": round(min(tot) * 1e3, 3)}
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -367,6 +379,8 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "split_f16x3": split_rec, "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 3),
             "launch": launch_mode,
         }
+        if single is not None:
+            line["single_step_into_idle_gpu"] = single
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -378,6 +378,24 @@ int kpf_dense_loss_forward(const float* pd, const float* img, const float* uvd_g
 int kpf_dense_loss_backward(const float* pd, const float* img, const float* uvd_gt, const float* grad2, float* dpd, int B, int J, int F, int S,
                             float kernel_size, void* stream);
 
+/* Training: the rest of the loss of train.py:225-261 (two launches forward, one backward): SmoothL1 (model/loss.py) between the four
+ * fusion-block joint sets joints4[i] [B][J][3] and xyz_gt, the two spatial-weight terms against GFM.joint2heatmap(uvd_gt[..., :2])
+ * (util/generateFeature.py:584-600) divided by its global maximum, the epoch gate of train.py:251 read from a device scalar, the weights and
+ * the total, together with the dense stages' partial sums dense0 / dense1 (kpf_dense_loss_forward's part; nullable).
+ * joints4 / sw2 / djoints4 / dsw2: HOST arrays of device pointers (entries nullable = term absent / gradient not wanted); sw2[t] element
+ * (b, j, p = y*F + x) at b*sw_strides6[3t] + j*sw_strides6[3t+1] + p*sw_strides6[3t+2]; epoch: device float (nullable: gates = 1);
+ * cfg9 (host) = {std, sigma0, sigma1, coord_weight, deconv_weight, spatial_weight0, spatial_weight1, spatial_epoch0, spatial_epoch1};
+ * sp_part: 2*B*J floats of workspace; out16: [0] loss, [1..4] pixel_0 coord_0 pixel_1 coord_1, [5..8] coord_2..5, [9..10] spatial_0..1
+ * (weighted, gated), [12..13] gates, [14..15] the heat maps' maxima (read again by the backward).
+ * backward: g = device pointer to dL/dloss; writes djoints4[i], dsw2[t] (same strides as sw2[t]) and gdense2 = {g*deconv_weight,
+ * g*coord_weight}, the grad2 of kpf_dense_loss_backward. */
+int kpf_loss_tail_forward(const float* dense0, const float* dense1, const float* const* joints4, const float* xyz_gt, const float* uvd_gt,
+                          const float* const* sw2, const long* sw_strides6, const float* epoch, const float* cfg9, float* sp_part, float* out16,
+                          int B, int J, int F, void* stream);
+int kpf_loss_tail_backward(const float* const* joints4, const float* xyz_gt, const float* uvd_gt, const float* const* sw2, const long* sw_strides6,
+                           const float* cfg9, const float* out16, const float* g, float* const* djoints4, float* const* dsw2, float* gdense2,
+                           int B, int J, int F, void* stream);
+
 /* Training: one-launch packing of a reference-layout weight w [N][Cin][KH][KW] (src_dtype: KPF_DT_F32 master, or a 16-bit copy) into an
  * operand of kpf_conv2d_f32 / _h16 (dst_dtype; fp32 -> 16-bit rounds to nearest even), rows zero-padded to Kp:
  *   mode 0  forward rows        dst [n_pad][Kp], k = (ky, kx, c)
@@ -404,7 +422,7 @@ int kpf_conv_num_tile_cfgs(void);
 const char* kpf_last_error(void);
 /* Library/ABI version, bumped when a signature or the meaning of an argument changes (KPF_ABI_VERSION is what this header
  * describes; the Python binding refuses a library that reports another). */
-#define KPF_ABI_VERSION 6
+#define KPF_ABI_VERSION 7
 int kpf_abi_version(void);
 
 #ifdef __cplusplus

@@ -1191,3 +1191,191 @@ extern "C" int kpf_dense_loss_backward(const float* pd, const float* img, const 
                      kernel_size, pix_w, coord_w);
   return kpf_check_launch("kpf_dense_loss_backward");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The rest of the loss (train.py:225-261) in two launches forward and one backward: the four SmoothL1 terms between the fusion blocks'
+// joints and xyz_gt, the two spatial-weight terms against the Gaussian heat maps of util/generateFeature.py:584-600 divided by their
+// global maximum, the epoch gate of train.py:251 read from the device, the weights, and the total — together with the partial sums the
+// two dense-stage kernels leave.  `out` (16 floats): [0] loss, [1..4] pixel_0 coord_0 pixel_1 coord_1, [5..8] coord_2..5, [9..10]
+// spatial_0..1 (weighted and gated, as the reference logs them), [12..13] the gates, [14..15] the heat maps' global maxima.
+// The library path was ~260 element-wise launches forward and as many backward for a few thousand numbers.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+struct LossTailArgs {
+  const float* dense[2];   // [B][J][2] partial sums of the dense stages (nullable)
+  const float* joints[4];  // [B][J][3] (nullable)
+  const float* xyz_gt;
+  const float* uvd_gt;
+  const float* sw[2];      // spatial weights (nullable): element (b, j, p) at b * sw_sb + j * sw_sj + p * sw_sp
+  long sw_sb[2], sw_sj[2], sw_sp[2];
+  const float* epoch;      // device scalar (nullable: gates = 1)
+  float epoch_max[2];
+  float sigma[2];
+  float std_, coord_w, deconv_w, sp_w[2];
+  int B, J, F;
+};
+
+// the heat map of joint (b, j) at pixel (x, y): util/generateFeature.py:584-600
+__device__ __forceinline__ float hm_sq(float c, float jc, float std_) {
+  const float t = (c + 0.5f - jc) / std_;
+  return t * t;
+}
+__device__ __forceinline__ float hm_center(float uv, int F) { return (uv + 1.f) / 2.f * (float)F; }
+
+// global maximum of the heat maps of every (sample, joint): exp is monotone and the exponent separable, so the maximum of a map is at
+// (argmin_x, argmin_y) — 2F evaluations per joint instead of F*F; every workgroup recomputes it (B*J*2F values) rather than wait for one
+__device__ float heatmap_global_max(const LossTailArgs& a, float sigma, float* red) {
+  float best = 0.f;
+  for (int q = threadIdx.x; q < a.B * a.J; q += 256) {
+    const float jx = hm_center(a.uvd_gt[(long)q * 3 + 0], a.F), jy = hm_center(a.uvd_gt[(long)q * 3 + 1], a.F);
+    float mx = INFINITY, my = INFINITY;
+    for (int c = 0; c < a.F; ++c) {
+      mx = fminf(mx, hm_sq((float)c, jx, a.std_));
+      my = fminf(my, hm_sq((float)c, jy, a.std_));
+    }
+    best = fmaxf(best, expf(-(mx + my) / (2.f * sigma * sigma)));
+  }
+  return block_max256(best, red);
+}
+
+__device__ __forceinline__ float epoch_gate(const LossTailArgs& a, int t) { return a.epoch == nullptr ? 1.f : (a.epoch[0] <= a.epoch_max[t] ? 1.f : 0.f); }
+
+// grid (J, B, 2): MODE 0 -> sp_part[t][b*J + j] = sum of SmoothL1(sw - hm / max);  MODE 1 -> d sw
+template <int MODE>
+__global__ __launch_bounds__(256) void spatial_loss_kernel(LossTailArgs a, float* __restrict__ sp_part, float* __restrict__ out, float* __restrict__ dsw0,
+                                                           float* __restrict__ dsw1, const float* __restrict__ g, float* __restrict__ dj0, float* __restrict__ dj1,
+                                                           float* __restrict__ dj2, float* __restrict__ dj3, float* __restrict__ gdense) {
+  __shared__ float red[4];
+  const int j = blockIdx.x, b = blockIdx.y, t = blockIdx.z, tid = threadIdx.x;
+  const int P = a.F * a.F;
+  if (MODE == 1 && t == 2) {  // the joints' gradients (and the two scalars the dense-stage backward kernels read), one (sample, joint) per workgroup
+    float* dj[4] = {dj0, dj1, dj2, dj3};
+    if (tid < 12) {
+      const int s = tid / 3, c = tid - 3 * s;
+      const long e = ((long)b * a.J + j) * 3 + c;
+      if (a.joints[s] != nullptr && dj[s] != nullptr) dj[s][e] = g[0] * a.coord_w / (float)(a.B * a.J * 3) * sl1_grad(a.joints[s][e] - a.xyz_gt[e]);
+    }
+    if (j == 0 && b == 0 && tid == 64 && gdense != nullptr) {
+      gdense[0] = g[0] * a.deconv_w;
+      gdense[1] = g[0] * a.coord_w;
+    }
+    return;
+  }
+  if (a.sw[t] == nullptr) return;
+  const float gmax = MODE == 0 ? heatmap_global_max(a, a.sigma[t], red) : out[14 + t];
+  const float jx = hm_center(a.uvd_gt[((long)b * a.J + j) * 3 + 0], a.F), jy = hm_center(a.uvd_gt[((long)b * a.J + j) * 3 + 1], a.F);
+  const float* sw = a.sw[t] + (long)b * a.sw_sb[t] + (long)j * a.sw_sj[t];
+  float* dsw = MODE == 1 ? (t == 0 ? dsw0 : dsw1) + (long)b * a.sw_sb[t] + (long)j * a.sw_sj[t] : nullptr;
+  const float gs = MODE == 1 ? g[0] * a.sp_w[t] * out[12 + t] / (float)((long)a.B * a.J * P) : 0.f;
+  float s = 0.f;
+  for (int p = tid; p < P; p += 256) {
+    const int py = p / a.F, px = p - py * a.F;
+    const float h = expf(-(hm_sq((float)px, jx, a.std_) + hm_sq((float)py, jy, a.std_)) / (2.f * a.sigma[t] * a.sigma[t]));
+    const float z = sw[(long)p * a.sw_sp[t]] - h / gmax;
+    if (MODE == 0) s += sl1(z);
+    else dsw[(long)p * a.sw_sp[t]] = gs * sl1_grad(z);
+  }
+  if (MODE == 0) {
+    s = block_sum256(s, red);
+    if (tid == 0) {
+      sp_part[(long)t * a.B * a.J + (long)b * a.J + j] = s;
+      if (j == 0 && b == 0) out[14 + t] = gmax;
+    }
+  }
+}
+
+// one workgroup: every partial sum in a fixed order, the weights, the gates, the total (train.py:224-261 in the reference's order of additions)
+__global__ __launch_bounds__(256) void loss_combine_kernel(LossTailArgs a, const float* __restrict__ sp_part, float* __restrict__ out) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x, BJ = a.B * a.J, P = a.F * a.F;
+  float term[10];
+  for (int i = 0; i < 2; ++i)
+    for (int k = 0; k < 2; ++k) {
+      float s = 0.f;
+      if (a.dense[i] != nullptr)
+        for (int q = tid; q < BJ; q += 256) s += a.dense[i][(long)q * 2 + k];
+      s = block_sum256(s, red);
+      term[2 * i + k] = k == 0 ? s / (float)((long)BJ * 4 * P) * a.deconv_w : s / (float)(BJ * 3) * a.coord_w;
+    }
+  for (int i = 0; i < 4; ++i) {
+    float s = 0.f;
+    if (a.joints[i] != nullptr)
+      for (int q = tid; q < BJ * 3; q += 256) s += sl1(a.joints[i][q] - a.xyz_gt[q]);
+    s = block_sum256(s, red);
+    term[4 + i] = s / (float)(BJ * 3) * a.coord_w;
+  }
+  float gate[2];
+  for (int t = 0; t < 2; ++t) {
+    float s = 0.f;
+    if (a.sw[t] != nullptr)
+      for (int q = tid; q < BJ; q += 256) s += sp_part[(long)t * BJ + q];
+    s = block_sum256(s, red);
+    gate[t] = epoch_gate(a, t);
+    term[8 + t] = s / (float)((long)BJ * P) * a.sp_w[t] * gate[t];
+  }
+  if (tid == 0) {
+    float loss = 0.f;
+    loss += term[0] + term[1];
+    loss += term[2] + term[3];
+    for (int i = 4; i < 10; ++i) loss += term[i];
+    out[0] = loss;
+    for (int i = 0; i < 10; ++i) out[1 + i] = term[i];
+    out[11] = 0.f;
+    out[12] = gate[0];
+    out[13] = gate[1];
+  }
+}
+
+int fill_loss_args(LossTailArgs& a, const float* dense0, const float* dense1, const float* const* joints4, const float* xyz_gt, const float* uvd_gt,
+                   const float* const* sw2, const long* sw_strides6, const float* epoch, const float* cfg9, int B, int J, int F) {
+  a.dense[0] = dense0;
+  a.dense[1] = dense1;
+  for (int i = 0; i < 4; ++i) a.joints[i] = joints4[i];
+  a.xyz_gt = xyz_gt;
+  a.uvd_gt = uvd_gt;
+  for (int t = 0; t < 2; ++t) {
+    a.sw[t] = sw2[t];
+    a.sw_sb[t] = sw_strides6[3 * t + 0];
+    a.sw_sj[t] = sw_strides6[3 * t + 1];
+    a.sw_sp[t] = sw_strides6[3 * t + 2];
+    a.epoch_max[t] = cfg9[7 + t];
+    a.sigma[t] = cfg9[1 + t];
+    a.sp_w[t] = cfg9[5 + t];
+  }
+  a.epoch = epoch;
+  a.std_ = cfg9[0];
+  a.coord_w = cfg9[3];
+  a.deconv_w = cfg9[4];
+  a.B = B;
+  a.J = J;
+  a.F = F;
+  return 0;
+}
+}  // namespace
+
+extern "C" int kpf_loss_tail_forward(const float* dense0, const float* dense1, const float* const* joints4, const float* xyz_gt, const float* uvd_gt,
+                                     const float* const* sw2, const long* sw_strides6, const float* epoch, const float* cfg9, float* sp_part, float* out16,
+                                     int B, int J, int F, void* stream) {
+  KPF_REQUIRE(joints4 && xyz_gt && uvd_gt && sw2 && sw_strides6 && cfg9 && sp_part && out16 && B > 0 && J > 0 && F > 0, "kpf_loss_tail_forward: bad arguments");
+  LossTailArgs a;
+  fill_loss_args(a, dense0, dense1, joints4, xyz_gt, uvd_gt, sw2, sw_strides6, epoch, cfg9, B, J, F);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (a.sw[0] != nullptr || a.sw[1] != nullptr)
+    hipLaunchKernelGGL(spatial_loss_kernel<0>, dim3(J, B, 2), dim3(256), 0, st, a, sp_part, out16, (float*)nullptr, (float*)nullptr, (const float*)nullptr,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+  hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(256), 0, st, a, sp_part, out16);
+  return kpf_check_launch("kpf_loss_tail_forward");
+}
+
+extern "C" int kpf_loss_tail_backward(const float* const* joints4, const float* xyz_gt, const float* uvd_gt, const float* const* sw2, const long* sw_strides6, const float* cfg9, const float* out16, const float* g,
+                                      float* const* djoints4, float* const* dsw2, float* gdense2, int B, int J, int F, void* stream) {
+  KPF_REQUIRE(joints4 && xyz_gt && uvd_gt && sw2 && sw_strides6 && cfg9 && out16 && g && djoints4 && dsw2 && B > 0 && J > 0 && F > 0,
+              "kpf_loss_tail_backward: bad arguments");
+  LossTailArgs a;
+  fill_loss_args(a, nullptr, nullptr, joints4, xyz_gt, uvd_gt, sw2, sw_strides6, nullptr, cfg9, B, J, F);
+  for (int t = 0; t < 2; ++t)
+    if (dsw2[t] == nullptr) a.sw[t] = nullptr;
+  hipLaunchKernelGGL(spatial_loss_kernel<1>, dim3(J, B, 3), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, (float*)nullptr, const_cast<float*>(out16),
+                     dsw2[0], dsw2[1], g, djoints4[0], djoints4[1], djoints4[2], djoints4[3], gdense2);
+  return kpf_check_launch("kpf_loss_tail_backward");
+}

@@ -23,7 +23,9 @@ attention_probs_dropout_prob and the decoder layer's default, model/transfusion_
 reference's random stream cannot be reproduced.  `module.precision`: "f32", or "bf16" mixed precision (fp32 master weights, statistics,
 geometry and loss; GEMM operands rounded to bf16).
 """
+import contextlib
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -32,6 +34,8 @@ from . import lib as L
 from .engine import _ptr, _stream, crop_inverse
 from .training import (attn21, batchnorm_relu_rows, bmm_small_k, conv2d_nhwc, dwconv7_nhwc, gelu_rows, layer_norm_rows, layer_scale_residual, linear_hip, maxpool3x3s2_nhwc,
                        row_gather, upsample2x_nhwc)
+
+_N_STREAMS = int(os.environ.get("KPF_TRAIN_STREAMS", "2"))  # 2: the RGB backbone (forward and backward) on a side stream
 
 J = 21
 
@@ -485,19 +489,36 @@ class TrainGraph:
         img_rgb, img, pcl, center, M, cube, cam = map(f, (img_rgb, img, pcl, center, M, cube, cam))
         return self._forward(lib, dev, img_rgb, img, pcl, center, M, cube, cam, kernel, img_size, flip)
 
+    def _side_stream(self, dev):
+        st = self.m.__dict__.get("_train_side_stream")
+        if st is None or st.device != dev:
+            st = self.m.__dict__["_train_side_stream"] = torch.cuda.Stream(dev)
+        return st
+
     def _forward(self, lib, dev, img_rgb, img, pcl, center, M, cube, cam, kernel, img_size, flip):
         # mixed precision covers the two backbones (where the FLOPs are); the fusion head runs fp32 like the inference path's (its tensors
         # are small and latency-bound, and a consistent type there removes several hundred cast launches per iteration)
-        if self.prec != "f32":
-            from .training import _TDT
-            with torch.autocast("cuda", dtype=_TDT[self.prec]):
-                img_offset, img_feat = self.unet("backbone_d", img)
-                img_offset_rgb, img_feat_rgb = self.unet("backbone_rgb", img_rgb)
-            img_feat, img_feat_rgb = img_feat.float(), img_feat_rgb.float()
-            self.prec, self.cmul = "f32", 4
-        else:
-            img_offset, img_feat = self.unet("backbone_d", img)
+        # The two backbones are independent until the fusion head: the RGB one is issued on a side stream (KPF_TRAIN_STREAMS=1: both on
+        # the caller's stream).  autograd runs every backward node on its forward's stream, so the two backward chains overlap the same
+        # way, inside a captured iteration too (fork / join are event nodes of the graph).  At 128^2 / B = 32 most launches are far
+        # too small to fill 256 CUs, which is what the overlap buys back.
+        main = torch.cuda.current_stream(dev)
+        side = self._side_stream(dev) if _N_STREAMS > 1 else main
+        from .training import _TDT
+        amp = (lambda: torch.autocast("cuda", dtype=_TDT[self.prec])) if self.prec != "f32" else contextlib.nullcontext
+        side.wait_stream(main) if side is not main else None
+        with torch.cuda.stream(side), amp():
             img_offset_rgb, img_feat_rgb = self.unet("backbone_rgb", img_rgb)
+            img_offset_rgb, img_feat_rgb = img_offset_rgb.float(), img_feat_rgb.float()
+        with amp():
+            img_offset, img_feat = self.unet("backbone_d", img)
+        img_feat = img_feat.float()
+        if side is not main:
+            main.wait_stream(side)
+            for t in (img_offset_rgb, img_feat_rgb):  # produced on the side stream, consumed by the head on the caller's
+                t.record_stream(main)
+        if self.prec != "f32":
+            self.prec, self.cmul = "f32", 4
         img_offset, img_offset_rgb = img_offset.float(), img_offset_rgb.float()  # the dense maps are returned (and decoded) in fp32
         result = [img_offset, img_offset_rgb]
         B, _, S, _ = img.shape

@@ -201,9 +201,120 @@ class DenseStageLoss(torch.autograd.Function):
         return dpd, None, None, None
 
 
+class FusedLoss(torch.autograd.Function):
+    """The whole loss of train.py:211-261 for the reference's stage schedule (STAGE_TYPE) as ONE autograd node: the two dense-stage kernels
+    (kpf_dense_loss_forward), the spatial-weight terms and the final combination (kpf_loss_tail_forward: two launches), and three launches
+    backward — the library path issued ~260 element-wise kernels each way for a few thousand numbers.  Returns (loss, out16) with out16 the
+    named terms the reference logs (layout: include/kpf.h).  epoch: python number (host gate, like the reference's `if`) or a device scalar
+    (hipGraph replay: gated on the device)."""
+
+    @staticmethod
+    def forward(ctx, img, uvd_gt, xyz_gt, epoch, r0, r1, r2, r3, r4, r5, sw0, sw1):
+        from . import lib as L
+        lib = L.load()
+        dev = r0.device
+        st = torch.cuda.current_stream().cuda_stream
+        im, ugt, xgt = img.detach().float().contiguous(), uvd_gt.detach().float().contiguous(), xyz_gt.detach().float().contiguous()
+        B, ch, Fs, _ = r0.shape
+        J = ch // 5
+        dense = [r.float().contiguous() for r in (r0, r1)]
+        parts = torch.empty(2, B, J, 2, device=dev, dtype=torch.float32)
+        for i, pd in enumerate(dense):
+            L.check(lib.kpf_dense_loss_forward(pd.data_ptr(), im.data_ptr(), ugt.data_ptr(), parts[i].data_ptr(), B, J, Fs, im.shape[-1], float(FEATURE_PARA), st),
+                    "kpf_dense_loss_forward")
+        joints = [r.float().contiguous() for r in (r2, r3, r4, r5)]
+        on_dev = torch.is_tensor(epoch)
+        sws, strides = [], []
+        for t, sw in enumerate((sw0, sw1)):
+            if sw is not None and not on_dev and epoch > SPATIAL_EPOCH[t]:
+                sw = None  # (host gate: the term is absent, train.py:251)
+            if sw is not None:
+                sw = sw.float()
+                sb, sj, sy, sx = sw.stride()
+                if sy != Fs * sx or sw.shape != (B, J, Fs, Fs):
+                    sw = sw.contiguous()
+                    sb, sj, sy, sx = sw.stride()
+                strides += [sb, sj, sx]
+            else:
+                strides += [0, 0, 0]
+            sws.append(sw)
+        ep = epoch.detach().to(device=dev, dtype=torch.float32).reshape(1) if on_dev else None
+        cfg = (C.c_float * 9)(FEATURE_PARA, 3.0, 2.0, COORD_WEIGHT, DECONV_WEIGHT, SPATIAL_WEIGHT[0], SPATIAL_WEIGHT[1], SPATIAL_EPOCH[0], SPATIAL_EPOCH[1])
+        j4 = (C.c_void_p * 4)(*[j.data_ptr() for j in joints])
+        s2 = (C.c_void_p * 2)(*[None if s is None else s.data_ptr() for s in sws])
+        st6 = (C.c_long * 6)(*strides)
+        sp_part = torch.empty(2 * B * J, device=dev, dtype=torch.float32)
+        out = torch.empty(16, device=dev, dtype=torch.float32)
+        L.check(lib.kpf_loss_tail_forward(parts[0].data_ptr(), parts[1].data_ptr(), j4, xgt.data_ptr(), ugt.data_ptr(), s2, st6, None if ep is None else ep.data_ptr(),
+                                          cfg, sp_part.data_ptr(), out.data_ptr(), B, J, Fs, st), "kpf_loss_tail_forward")
+        ctx.save_for_backward(im, ugt, xgt, out, *dense, *joints, *[s for s in sws if s is not None])
+        ctx.have_sw = [s is not None for s in sws]
+        ctx.strides = strides
+        ctx.dims = (B, J, Fs)
+        ctx.in_dtypes = [None if r is None else r.dtype for r in (r0, r1, r2, r3, r4, r5, sw0, sw1)]
+        ctx.mark_non_differentiable(out)
+        return out[0], out
+
+    @staticmethod
+    def backward(ctx, g, _g_out):
+        from . import lib as L
+        lib = L.load()
+        im, ugt, xgt, out, d0, d1, j0, j1, j2, j3, *rest = ctx.saved_tensors
+        B, J, Fs = ctx.dims
+        st = torch.cuda.current_stream().cuda_stream
+        sws = [rest.pop(0) if h else None for h in ctx.have_sw]
+        need = ctx.needs_input_grad[4:]
+        g = g.float().reshape(1).contiguous()
+        dj = [torch.empty_like(j) if need[2 + i] else None for i, j in enumerate((j0, j1, j2, j3))]
+        dsw = [torch.empty_like(s) if (s is not None and need[6 + t]) else None for t, s in enumerate(sws)]  # (preserve_format: the strides of sw)
+        gd = torch.empty(2, device=g.device, dtype=torch.float32)
+        cfg = (C.c_float * 9)(FEATURE_PARA, 3.0, 2.0, COORD_WEIGHT, DECONV_WEIGHT, SPATIAL_WEIGHT[0], SPATIAL_WEIGHT[1], SPATIAL_EPOCH[0], SPATIAL_EPOCH[1])
+        j4 = (C.c_void_p * 4)(*[j.data_ptr() for j in (j0, j1, j2, j3)])
+        s2 = (C.c_void_p * 2)(*[None if s is None else s.data_ptr() for s in sws])
+        dj4 = (C.c_void_p * 4)(*[None if d is None else d.data_ptr() for d in dj])
+        ds2 = (C.c_void_p * 2)(*[None if d is None else d.data_ptr() for d in dsw])
+        st6 = (C.c_long * 6)(*ctx.strides)
+        L.check(lib.kpf_loss_tail_backward(j4, xgt.data_ptr(), ugt.data_ptr(), s2, st6, cfg, out.data_ptr(), g.data_ptr(), dj4, ds2, gd.data_ptr(), B, J, Fs, st),
+                "kpf_loss_tail_backward")
+        dd = []
+        for i, pd in enumerate((d0, d1)):
+            if not need[i]:
+                dd.append(None)
+                continue
+            dpd = torch.empty_like(pd)
+            L.check(lib.kpf_dense_loss_backward(pd.data_ptr(), im.data_ptr(), ugt.data_ptr(), gd.data_ptr(), dpd.data_ptr(), B, J, Fs, im.shape[-1], float(FEATURE_PARA), st),
+                    "kpf_dense_loss_backward")
+            dd.append(dpd)
+        grads = dd + dj + dsw
+        grads = [None if x is None else (x if x.dtype == dt else x.to(dt)) for x, dt in zip(grads, ctx.in_dtypes)]
+        return (None, None, None, None, *grads)
+
+
+def _fused_loss_applies(results, spatial_weight, img, stage_type, l1):
+    if l1 is not None or tuple(stage_type) != STAGE_TYPE or len(results) != 6 or len(spatial_weight) != 2:
+        return False
+    r0 = results[0]
+    if not (r0.is_cuda and r0.dim() == 4 and results[1].shape == r0.shape and r0.shape[1] % 5 == 0):
+        return False
+    Fs, J = r0.shape[-1], r0.shape[1] // 5
+    if Fs * Fs > 1024 or img.shape[-1] % Fs or r0.shape[-2] != Fs:
+        return False
+    if any(tuple(r.shape) != (r0.shape[0], J, 3) for r in results[2:]):
+        return False
+    return all(s is None or tuple(s.shape) == (r0.shape[0], J, Fs, Fs) for s in spatial_weight)
+
+
 def kpfusion_loss(results, spatial_weight, img, uvd_gt, xyz_gt, epoch=0, stage_type=STAGE_TYPE, l1=None):
     """The loss of one training iteration, train.py:211-261.  results: the 6 forward outputs, spatial_weight: the 2 spatial weights.
     Returns (loss, parts) with parts a dict of the named scalar terms the reference logs."""
+    if _fused_loss_applies(results, spatial_weight, img, stage_type, l1):
+        loss, out = FusedLoss.apply(img, uvd_gt, xyz_gt, epoch, *results, *spatial_weight)
+        parts = {"loss_pixel_0": out[1], "loss_coord_0": out[2], "loss_pixel_1": out[3], "loss_coord_1": out[4]}
+        parts.update({"loss_coord_%d" % i: out[3 + i] for i in range(2, 6)})
+        for t, sw in enumerate(spatial_weight):
+            if sw is not None and (torch.is_tensor(epoch) or epoch <= SPATIAL_EPOCH[t]):
+                parts["loss_spatial_%d" % t] = out[9 + t]
+        return loss, parts
     custom_l1 = l1
     l1 = l1 or SmoothL1Loss()
     loss = 0

@@ -477,3 +477,47 @@ def test_dense_stage_loss_kernel_matches_the_torch_codec(seed):
     assert abs(float(lp) - float(lp_r)) < 2e-6 * abs(float(lp_r)) and abs(float(lc) - float(lc_r)) < 2e-6 * abs(float(lc_r)), (float(lp), float(lp_r), float(lc), float(lc_r))
     d = (pdd.grad.cpu().double() - pr.grad).abs().max()
     assert float(d) < 2e-5 * float(pr.grad.abs().max()), float(d)
+
+
+@pytest.mark.parametrize("epoch", [0, 25, "dev0", "dev25"])
+def test_fused_loss_matches_the_torch_schedule(epoch):
+    """training.FusedLoss (the whole loss of train.py:211-261 as one autograd node: kpf_dense_loss_* + kpf_loss_tail_*) against
+    kpfusion_loss's torch restatement in float64 on the CPU (itself pinned to the reference's train_loss.npz): the total, every named
+    term and the gradient of all six results and both spatial weights; host epoch gate (term present / absent) and device epoch gate;
+    spatial weights in the permuted [B, H, W, J] memory the model produces."""
+    from keypointfusion_amd import training as T
+    from keypointfusion_amd.weights import synthetic_batch
+    B, J, Fs = 3, 21, 32
+    g = torch.Generator().manual_seed(7)
+    img = torch.from_numpy(synthetic_batch(B, 128, seed=3)["img"])
+    uvd = torch.rand(B, J, 3, generator=g) * 1.6 - 0.8
+    xyz = torch.rand(B, J, 3, generator=g) * 1.6 - 0.8
+    res = [torch.randn(B, 5 * J, Fs, Fs, generator=g) * 0.5 for _ in range(2)] + [xyz + torch.randn(B, J, 3, generator=g) * s for s in (0.003, 0.02, 0.1, 0.008)]
+    sws = [torch.rand(B, Fs, Fs, J, generator=g).permute(0, 3, 1, 2) for _ in range(2)]
+    ep_host = int(epoch[3:]) if isinstance(epoch, str) else epoch
+
+    ref_in = [r.clone().double().requires_grad_(True) for r in res + sws]
+    lr, pr = T.kpfusion_loss(ref_in[:6], ref_in[6:], img.double(), uvd.double(), xyz.double(), epoch=ep_host, l1=T.SmoothL1Loss())
+    lr.backward()
+    dev_in = [r.cuda().requires_grad_(True) for r in res]
+    dev_sw = [torch.empty(B, Fs, Fs, J, device="cuda").copy_(s.permute(0, 2, 3, 1)).permute(0, 3, 1, 2).requires_grad_(True) for s in sws]
+    ep = torch.tensor(ep_host, device="cuda") if isinstance(epoch, str) else epoch
+    ld, pdv = T.kpfusion_loss(dev_in, dev_sw, img.cuda(), uvd.cuda(), xyz.cuda(), epoch=ep)
+    assert ld.grad_fn is not None and type(ld.grad_fn).__name__.startswith("FusedLoss"), ld.grad_fn
+    (ld * 1.5).backward()
+    assert abs(float(ld) - float(lr)) < 3e-6 * abs(float(lr)), (float(ld), float(lr))
+    if isinstance(epoch, str):  # device gate: the spatial entries exist and are 0 behind the gate
+        assert set(pdv) == set(pr) | {"loss_spatial_0", "loss_spatial_1"}
+        if ep_host > 24:
+            assert float(pdv["loss_spatial_0"]) == 0.0 and float(pdv["loss_spatial_1"]) == 0.0
+    else:
+        assert set(pdv) == set(pr)
+    for k in pr:
+        assert abs(float(pdv[k]) - float(pr[k])) < 5e-6 * max(abs(float(pr[k])), 1e-6), (k, float(pdv[k]), float(pr[k]))
+    for i, (a, b) in enumerate(zip(dev_in + dev_sw, ref_in)):
+        want = torch.zeros_like(b) if b.grad is None else b.grad * 1.5
+        if a.grad is None:
+            assert float(want.abs().max()) == 0.0, i
+            continue
+        d = float((a.grad.cpu().double() - want).abs().max())
+        assert d <= 3e-5 * float(want.abs().max()) + 1e-12, (i, d, float(want.abs().max()))

@@ -16,5 +16,18 @@ for a, b in list(zip(marks, marks[1:]))[-4:]:
     big = sorted(((g, it[i]["Kernel_Name"][:60], it[i + 1]["Kernel_Name"][:60]) for i, g in enumerate(gaps)), reverse=True)[:5]
     print("iteration: %d kernels, span %.2f ms, busy %.2f ms, gaps %.2f ms (mean %.2f us, median %.2f us)" % (
         len(it), span, busy, sum(gaps) / 1e6, sum(gaps) / len(gaps) / 1e3, sorted(gaps)[len(gaps) // 2] / 1e3))
+    iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in it)  # union of the busy intervals: what side streams overlap
+    union, cs, ce = 0, iv[0][0], iv[0][1]
+    for a_, b_ in iv[1:]:
+        if a_ > ce:
+            union += ce - cs
+            cs, ce = a_, b_
+        else:
+            ce = max(ce, b_)
+    union += ce - cs
+    queues = {}
+    for r in it:
+        queues[r.get("Queue_Id", "?")] = queues.get(r.get("Queue_Id", "?"), 0) + 1
+    print("    union of busy intervals %.2f ms (sum %.2f: %.2f ms overlapped); launches per queue %s" % (union / 1e6, busy, busy - union / 1e6, queues))
     for g, x, y in big:
         print("    gap %.1f us after %s before %s" % (g / 1e3, x, y))
