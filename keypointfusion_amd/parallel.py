@@ -6,6 +6,8 @@ uses running statistics), so the MI355X-native form is: weights 
 contiguous shard of the batch, and the only communication is an optional all_gather of the (small) outputs over
 RCCL/xGMI — B x 1.03 MB per image.  `torch.distributed` backend "nccl" is RCCL on ROCm; tests use "gloo" on CPU.
 """
+import re
+
 import torch
 
 
@@ -155,11 +157,14 @@ class GradBucketReducer:
             h.remove()
 
 
-DEAD_PREFIXES = ("crossTR.decoder.0.", "crossTR.decoder.1.", "crossTR.decoder.2.", ".bert.embeddings.", ".bert.pooler.", "backbone.head.",
-                 "backbone.norm.", "feat_emb")
+DEAD_PREFIXES = ("crossTR.decoder.0.", "crossTR.decoder.1.", "crossTR.decoder.2.", "crossTR.decoder.3.norm1.", ".bert.embeddings.", ".bert.pooler.",
+                 "backbone.head.", "backbone.norm.", ".attention_weights.", ".reduction_joint_feature.", ".reduction_joint_feature_update.",
+                 ".sampling_feature_embding.", ".sampling_offsets.",
+                 ".feat_emb.")  # (the backbones' unused Residual — NOT block*.joint_feat_emb / pcl_feat_emb*, which train)
+DEAD_PATTERNS = (re.compile(r"^block\d+\.cls_head\."),)  # (block*.init_TR.cls_head / final_TR.cls_head are live)
 
 
 def live_parameters(module):
     """Parameters that can receive a gradient in the reference's forward (decoder layers 0-2, the BERT embedding and
     pooler tables, the ConvNeXt classifier head and `feat_emb` are dead code whose parameters never reach the outputs)."""
-    return [p for n, p in module.named_parameters() if not any(d in n for d in DEAD_PREFIXES)]
+    return [p for n, p in module.named_parameters() if not (any(d in n for d in DEAD_PREFIXES) or any(r.search(n) for r in DEAD_PATTERNS))]

@@ -125,6 +125,26 @@ def test_live_parameters_excludes_the_dead_modules():
     assert 0.55 * total < live < 0.9 * total, (live, total)  # 28.7 M live of 46.3 M (R18)
 
 
+@pytest.mark.parametrize("net", ["convnext-tiny", "resnet-18"])
+def test_live_parameters_cover_every_parameter_the_reference_gives_a_gradient(net):
+    """live_parameters() (what bench.py / GraphedTrainStep hand to the optimiser and to the gradient all-reduce) against the set of
+    parameters that received a gradient in the imported reference's own iteration (train_step_*.npz `grad_names`): a parameter missing
+    here would silently never train (round 3 found block*.joint_feat_emb / pcl_feat_emb* excluded by a substring match on 'feat_emb')."""
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    from keypointfusion_amd.model.model import KPFusion
+    from keypointfusion_amd.parallel import live_parameters
+    m = KPFusion("KPFusion-" + net, "", 21, "dexycb", "")
+    live = {id(p) for p in live_parameters(m)}
+    names = {n for n, p in m.named_parameters() if id(p) in live}
+    ref = set(np.load(os.path.join(GOLDEN, "train_step_%s.npz" % net), allow_pickle=True)["grad_names"].tolist())
+    assert ref <= names, sorted(ref - names)[:10]
+    # (a superset is harmless — a parameter without a gradient keeps .grad = None and the optimiser / the buckets skip it: the identity
+    # skips of equal-width Residual blocks, whose 1x1 convolution exists in the state dict but is never called, model/hourglass.py:106-116)
+    assert all(".skip_layer.conv." in n for n in names - ref), sorted(names - ref)[:10]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("net", ["convnext-tiny", "resnet-18"])
 def test_train_step_matches_the_reference_loss_and_gradients(net):
