@@ -417,12 +417,29 @@ typedef struct kpf_pack_desc {
 } kpf_pack_desc;
 int kpf_pack_conv_weights_multi(const kpf_pack_desc* descs_device, int ndesc, int total_blocks, void* stream);
 
+/* Training: AdamW (train.py:84-91) over many tensors in ceil(n / KPF_ADAMW_BATCH) launches.  descs: HOST array (p, m, v updated in place;
+ * g read; all fp32, n elements each; first_block is set by the call); the learning rate is *lr_dev when lr_dev is non-null (device
+ * scalar: a captured iteration follows the scheduler) else lr_host; *step_dev is the number of steps taken BEFORE this one (device float;
+ * the caller increments it afterwards).  Arithmetic of torch.optim.AdamW(fused=True): decoupled weight decay, bias corrections from
+ * step + 1, no amsgrad. */
+#define KPF_ADAMW_BATCH 80
+typedef struct kpf_adamw_desc {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  long n;
+  int first_block, reserved;
+} kpf_adamw_desc;
+int kpf_adamw_step_multi(const kpf_adamw_desc* descs, int n, const float* lr_dev, float lr_host, const float* step_dev, double beta1, double beta2, float eps,
+                         float weight_decay, void* stream);
+
 int kpf_conv_num_tile_cfgs(void);
 
 const char* kpf_last_error(void);
 /* Library/ABI version, bumped when a signature or the meaning of an argument changes (KPF_ABI_VERSION is what this header
  * describes; the Python binding refuses a library that reports another). */
-#define KPF_ABI_VERSION 7
+#define KPF_ABI_VERSION 8
 int kpf_abi_version(void);
 
 #ifdef __cplusplus

@@ -1379,3 +1379,99 @@ extern "C" int kpf_loss_tail_backward(const float* const* joints4, const float* 
                      dsw2[0], dsw2[1], g, djoints4[0], djoints4[1], djoints4[2], djoints4[3], gdense2);
   return kpf_check_launch("kpf_loss_tail_backward");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// AdamW (train.py:84-91: torch.optim.AdamW, weight_decay 0.01) over every parameter of the model in a handful of launches: the library's
+// fused multi-tensor kernel takes ~30 launches of 40 us for the ~300 tensors of a ConvNeXt-T KPFusion (4 KB of kernel arguments each, a
+// few tensors per launch, 0.5 TB/s); here a launch carries KPF_ADAMW_BATCH descriptors by value (read from the kernel-argument segment with
+// scalar loads), a workgroup owns 4096 consecutive elements of one tensor, and the learning rate and the step count are DEVICE scalars (a
+// captured iteration keeps following the scheduler).  Arithmetic as torch's fused kernel (ADAMW mode, no amsgrad):
+//   p -= lr*wd*p;  m += (1-b1)(g-m);  v = b2 v + (1-b2) g^2;  p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps),  t = step + 1.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+struct AdamwBatch {
+  kpf_adamw_desc d[KPF_ADAMW_BATCH];
+  const float* lr_dev;
+  const float* step_dev;
+  float lr_host, beta1, beta2, omb1, omb2, eps, wd;  // omb = 1 - beta, rounded from the double difference (1.f - 0.999f is 4.7e-5 off)
+  int nd;
+};
+typedef const __attribute__((address_space(4))) AdamwBatch* adamw_kernarg_t;
+constexpr int ADAMW_PER_BLOCK = 4096;
+
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwBatch) {
+  adamw_kernarg_t bp = (adamw_kernarg_t)__builtin_amdgcn_kernarg_segment_ptr();  // (indexing the by-value struct would copy it to scratch)
+  const int nd = bp->nd;
+  int lo = 0, hi = nd - 1;
+  while (lo < hi) {  // last descriptor whose first_block <= blockIdx.x
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)blockIdx.x >= bp->d[mid].first_block) lo = mid;
+    else hi = mid - 1;
+  }
+  float* p = bp->d[lo].p;
+  const float* g = bp->d[lo].g;
+  float* m = bp->d[lo].m;
+  float* v = bp->d[lo].v;
+  const long n = bp->d[lo].n;
+  const long base = (long)((int)blockIdx.x - bp->d[lo].first_block) * ADAMW_PER_BLOCK;
+  const float lr = bp->lr_dev ? bp->lr_dev[0] : bp->lr_host;
+  const double t = (double)bp->step_dev[0] + 1.0;
+  const float b1 = bp->beta1, b2 = bp->beta2, eps = bp->eps, omb1 = bp->omb1, omb2 = bp->omb2;
+  const float bc1 = (float)(1.0 - pow((double)b1, t));
+  const float bc2s = (float)sqrt(1.0 - pow((double)b2, t));
+  const float step_size = lr / bc1, decay = lr * bp->wd;
+  const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15u) == 0;
+#pragma unroll
+  for (int it = 0; it < ADAMW_PER_BLOCK / 1024; ++it) {
+    const long i = base + (long)it * 1024 + 4 * threadIdx.x;
+    if (i >= n) break;
+    if (vec && i + 4 <= n) {
+      f32x4 pp = *reinterpret_cast<const f32x4*>(p + i), gg = *reinterpret_cast<const f32x4*>(g + i);
+      f32x4 mm = *reinterpret_cast<const f32x4*>(m + i), vv = *reinterpret_cast<const f32x4*>(v + i);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        pp[c] -= decay * pp[c];
+        mm[c] += omb1 * (gg[c] - mm[c]);
+        vv[c] = b2 * vv[c] + omb2 * gg[c] * gg[c];
+        pp[c] -= step_size * mm[c] / (sqrtf(vv[c]) / bc2s + eps);
+      }
+      *reinterpret_cast<f32x4*>(p + i) = pp;
+      *reinterpret_cast<f32x4*>(m + i) = mm;
+      *reinterpret_cast<f32x4*>(v + i) = vv;
+    } else {
+      for (long e = i; e < i + 4 && e < n; ++e) {
+        float pp = p[e], mm = m[e], vv = v[e];
+        const float gg = g[e];
+        pp -= decay * pp;
+        mm += omb1 * (gg - mm);
+        vv = b2 * vv + omb2 * gg * gg;
+        pp -= step_size * mm / (sqrtf(vv) / bc2s + eps);
+        p[e] = pp, m[e] = mm, v[e] = vv;
+      }
+    }
+  }
+}
+}  // namespace
+
+extern "C" int kpf_adamw_step_multi(const kpf_adamw_desc* descs, int n, const float* lr_dev, float lr_host, const float* step_dev, double beta1, double beta2,
+                                    float eps, float weight_decay, void* stream) {
+  KPF_REQUIRE(n >= 0 && (descs || n == 0) && step_dev, "kpf_adamw_step_multi: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  for (int base = 0; base < n; base += KPF_ADAMW_BATCH) {
+    AdamwBatch b;
+    b.nd = n - base < KPF_ADAMW_BATCH ? n - base : KPF_ADAMW_BATCH;
+    long blocks = 0;
+    for (int k = 0; k < b.nd; ++k) {
+      b.d[k] = descs[base + k];
+      KPF_REQUIRE(b.d[k].p && b.d[k].g && b.d[k].m && b.d[k].v && b.d[k].n > 0, "kpf_adamw_step_multi: bad descriptor %d", base + k);
+      b.d[k].first_block = (int)blocks;
+      blocks += (b.d[k].n + ADAMW_PER_BLOCK - 1) / ADAMW_PER_BLOCK;
+    }
+    KPF_REQUIRE(blocks < (1L << 31), "kpf_adamw_step_multi: too many elements");
+    b.lr_dev = lr_dev, b.step_dev = step_dev, b.lr_host = lr_host, b.beta1 = (float)beta1, b.beta2 = (float)beta2, b.omb1 = (float)(1.0 - beta1), b.omb2 = (float)(1.0 - beta2), b.eps = eps, b.wd = weight_decay;
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, st, b);
+    const int rc = kpf_check_launch("kpf_adamw_step_multi");
+    if (rc != KPF_OK) return rc;
+  }
+  return KPF_OK;
+}

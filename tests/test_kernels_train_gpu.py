@@ -521,3 +521,44 @@ def test_fused_loss_matches_the_torch_schedule(epoch):
             continue
         d = float((a.grad.cpu().double() - want).abs().max())
         assert d <= 3e-5 * float(want.abs().max()) + 1e-12, (i, d, float(want.abs().max()))
+
+
+def test_fused_adamw_matches_torch_adamw_and_exchanges_state():
+    """training.FusedAdamW (kpf_adamw_step_multi) against torch.optim.AdamW(fused=True, capturable=True) over several steps: parameters and
+    both moments, odd sizes (scalar tail, > one workgroup, more tensors than one launch carries), a parameter without a gradient, a
+    learning rate that changes between steps (device scalar), and a state_dict() that the library class loads and continues from."""
+    from keypointfusion_amd import training as T
+    g = torch.Generator().manual_seed(11)
+    shapes = [(1,), (5,), (4099,), (33, 7), (64, 64, 3, 3), (8193,)] + [(17 + i,) for i in range(90)]
+    ref_p = [torch.nn.Parameter(torch.randn(*s, generator=g).cuda()) for s in shapes]
+    our_p = [torch.nn.Parameter(p.detach().clone()) for p in ref_p]
+    dead_r, dead_o = torch.nn.Parameter(torch.ones(3).cuda()), torch.nn.Parameter(torch.ones(3).cuda())
+    lr_r, lr_o = torch.tensor(8e-4, device="cuda"), torch.tensor(8e-4, device="cuda")
+    ref = torch.optim.AdamW(ref_p + [dead_r], lr=lr_r, weight_decay=0.01, capturable=True, fused=True)
+    our = T.FusedAdamW(our_p + [dead_o], lr=lr_o, weight_decay=0.01, capturable=True)
+    for it in range(6):
+        if it == 3:
+            lr_r.fill_(8e-5), lr_o.fill_(8e-5)
+        for a, b in zip(ref_p, our_p):
+            gr = torch.randn(a.shape, generator=g).cuda() * (10.0 ** (it % 3 - 1))
+            a.grad, b.grad = gr.clone(), gr.clone()
+        ref.step(), our.step()
+    torch.cuda.synchronize()
+    assert dead_o.grad is None and torch.equal(dead_o, dead_r) and not our.state.get(dead_o)
+    for a, b in zip(ref_p, our_p):
+        assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()) + 1e-9, a.shape
+        for k in ("exp_avg", "exp_avg_sq"):
+            x, y = ref.state[a][k], our.state[b][k]
+            assert float((x - y).abs().max()) <= 2e-6 * float(x.abs().max()) + 1e-12, (a.shape, k)
+        assert float(our.state[b]["step"]) == float(ref.state[a]["step"]) == 6.0
+    # the library class continues from our state
+    cont = torch.optim.AdamW([torch.nn.Parameter(p.detach().clone()) for p in our_p] + [torch.nn.Parameter(torch.ones(3).cuda())], lr=torch.tensor(8e-5, device="cuda"),
+                             weight_decay=0.01, capturable=True, fused=True)
+    cont.load_state_dict(our.state_dict())
+    cp = cont.param_groups[0]["params"]
+    for a, b, c in zip(ref_p, our_p, cp):
+        gr = torch.randn(a.shape, generator=g).cuda()
+        a.grad, c.grad = gr.clone(), gr.clone()
+    ref.step(), cont.step()
+    for a, c in zip(ref_p, cp):
+        assert float((a - c).abs().max()) <= 4e-6 * float(a.abs().max()) + 1e-9, a.shape
