@@ -251,6 +251,190 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// (1b) wgrad_h16_kernel — the same GEMM for 16-bit dY / X (mixed-precision step) on v_mfma_f32_16x16x32_{bf16,f16}.  The MFMA wants 8
+// consecutive REDUCTION indices (pixels) per lane, the operands are stored pixel-major — a transpose.  LDS holds the tiles as they lie in
+// memory ([32 pixels][128 channels] = 256-byte rows, filled by LDS-DMA, 16-byte chunks XOR-swizzled by the row so that both the DMA
+// writes and the reads are conflict-free) and ds_read_b64_tr_b16 delivers them column-major: two reads give a lane its 8 pixels of one
+// channel.  Workgroup tile 128 (n) x 128 (k), wave tile 64 x 64 (16 MFMAs + 16 transposed reads per 32-pixel stage), 3-stage DMA ring
+// with a counted vmcnt (two stages in flight).  Products of 16-bit values are exact in fp32 and the accumulation is fp32, as in the
+// widening form this replaces (which ran the fp32 MFMA at 16x fewer FLOP per instruction); partial tiles and wgrad_reduce_kernel as above.
+// ---------------------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+
+constexpr int HB = 128;   // tile edge: one 256-byte LDS row of 16-bit channels
+constexpr int HNS = 3;    // LDS ring stages (RB pixels x (A + B) rows of 256 B = 16 KB each)
+
+__device__ __forceinline__ int h16_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+__device__ __forceinline__ f32x4 mfma_h16(const s16x8 x, const s16x8 y, const f32x4 c, bf16_t) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_h16(const s16x8 x, const s16x8 y, const f32x4 c, f16_t) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), c, 0, 0, 0);
+}
+__device__ __forceinline__ float sum8(const s16x8 v, bf16_t) {
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s += __uint_as_float(((unsigned)(unsigned short)v[e]) << 16);
+  return s;
+}
+__device__ __forceinline__ float sum8(const s16x8 v, f16_t) {
+  const f16x8 h = __builtin_bit_cast(f16x8, v);
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s += (float)h[e];
+  return s;
+}
+
+template <typename TIN>
+__global__ __launch_bounds__(256) void wgrad_h16_kernel(const WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char hl[];  // [HNS][A 8 KB | B 8 KB]
+  constexpr int STAGE = 2 * RB * 256;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 1, wk = wave >> 1;
+  const int nt = blockIdx.x / a.tilesK, kt = blockIdx.x % a.tilesK;
+  const int n0 = nt * HB, k0 = kt * HB;
+  const int split = blockIdx.y;
+  const int total_stages = (a.M + RB - 1) / RB;
+  const int s_begin = split * a.stages_per_split;
+  const int ns = min(a.stages_per_split, total_stages - s_begin);
+  const int m_begin = s_begin * RB;
+  const TIN* dyh = static_cast<const TIN*>(a.dy);
+  const TIN* xh = static_cast<const TIN*>(a.x);
+  const int ohw = a.OH * a.OW;
+
+  // --- staging: DMA instruction d (0..7 per operand) fills LDS rows 4d .. 4d+3 (1 KB, lane-linear); lane -> row 4d + lane/16, and the
+  // 16-byte slot lane%16 of that row receives global chunk (lane%16) ^ swz(row).  A wave issues d = 2*wave + i, i = 0, 1, per operand.
+  const int jr = lane >> 4, jc = lane & 15;
+  const TIN* a_src[2];
+  bool a_ok[2], b_ok[2];
+  int b_cch[2], b_ky[2], b_kx[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 8 * wave + 4 * i + jr;
+    const int gc = jc ^ h16_swz(row);
+    const int n = n0 + 8 * gc;
+    a_ok[i] = n < a.N;
+    a_src[i] = dyh + n;
+    const int kcol = k0 + 8 * gc;
+    b_ok[i] = kcol < a.K;
+    const int tap = kcol / a.Cin;
+    b_cch[i] = kcol - tap * a.Cin;
+    b_ky[i] = tap / a.KW;
+    b_kx[i] = tap - b_ky[i] * a.KW;
+  }
+  auto stage = [&](int s) {
+    char* buf = hl + (s % HNS) * STAGE;
+    const int mb = m_begin + s * RB;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = mb + 8 * wave + 4 * i + jr;
+      const void* src = (a_ok[i] && m < a.M) ? (const void*)(a_src[i] + (size_t)m * a.ldy) : (const void*)a.zero;
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(buf + (2 * wave + i) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = mb + 8 * wave + 4 * i + jr;
+      const void* src = (const void*)a.zero;
+      if (b_ok[i] && m < a.M) {
+        if (a.is1x1) {
+          src = xh + (size_t)m * a.ldx + b_cch[i];
+        } else {
+          const int b = m / ohw, r = m - b * ohw;
+          const int oy = r / a.OW, ox = r - oy * a.OW;
+          const int iy = oy * a.sh + b_ky[i] - a.ph, ix = ox * a.sw + b_kx[i] - a.pw;
+          if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) src = xh + ((size_t)(b * a.H + iy) * a.W + ix) * a.ldx + b_cch[i];
+        }
+      }
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(buf + RB * 256 + (2 * wave + i) * 1024), 16, 0, 0);
+    }
+  };
+
+  // --- fragment addresses: k-group g = lane/16 owns pixels 8g .. 8g+7; lane 4q+p of the group addresses row 8g + 4h + q, columns 4p .. 4p+3
+  // of the 16-channel block (two 16-byte chunks c0, c0+1) — ds_read_b64_tr_b16 hands lane i of the group channel i of those 4 rows
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  int addrA[4][2], addrB[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = 8 * g + 4 * h + q, sw = h16_swz(row);
+      addrA[i][h] = row * 256 + 16 * ((wn * 8 + 2 * i + (pp >> 1)) ^ sw) + 8 * (pp & 1);
+      addrB[i][h] = RB * 256 + row * 256 + 16 * ((wk * 8 + 2 * i + (pp >> 1)) ^ sw) + 8 * (pp & 1);
+    }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dbs[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool want_db = a.dbpart != nullptr && kt == 0 && wk == 0;
+
+  if (ns > 0) stage(0);
+  if (ns > 1) stage(1);
+  for (int s = 0; s < ns; ++s) {
+    if (s + 1 < ns) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // stage s has landed; stage s+1 (4 DMAs per wave) may still fly
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave's part of stage s is in LDS, and every wave is done reading stage s-1
+    asm volatile("" ::: "memory");
+    if (s + 2 < ns) stage(s + 2);  // into the buffer of stage s-1
+    const char* cur = hl + (s % HNS) * STAGE;
+    s16x8 af[4], bf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(cur + addrA[i][0]));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(cur + addrA[i][1]));
+      af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(cur + addrB[j][0]));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(cur + addrB[j][1]));
+      bf[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+    if (want_db) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dbs[i] += sum8(af[i], TIN());
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = mfma_h16(af[i], bf[j], acc[i][j], TIN());
+  }
+
+  // --- partial tile -> workspace: lane holds for tile (i, j), r = 0..3: n = 16 i + 4 g + r, k = 16 j + lane%16 ---
+  float* part = a.part + (size_t)split * a.N * a.K;
+  const int idx = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + wn * 64 + 16 * i + 4 * g + r;
+      if (n < a.N) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = k0 + wk * 64 + 16 * j + idx;
+          if (k < a.K) part[(size_t)n * a.K + k] = acc[i][j][r];
+        }
+      }
+    }
+  if (want_db) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = dbs[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int n = n0 + wn * 64 + 16 * i + idx;
+      if (g == 0 && n < a.N) a.dbpart[(size_t)split * a.N + n] = v;
+    }
+  }
+}
+
 // Fixed-order sum of S partial arrays of n floats: a workgroup owns 64 consecutive outputs, its four waves sum the partials
 // p = w, w+4, w+8, ... (four independent chains each) and the four wave sums are combined through LDS — the same order every run.
 __device__ __forceinline__ float sum_partials(const float* __restrict__ part, long n, int S, long i, float (*red)[64]) {
@@ -396,6 +580,22 @@ Plan plan_wgrad(long M, int N, int K) {
   return best;
 }
 
+// 128 x 128 tiles of wgrad_h16_kernel: S fills the chip (two 48-KB workgroups per CU) with at least four stages per workgroup
+Plan plan_wgrad_h16(long M, int N, int K) {
+  Plan p{};
+  p.vn = p.vk = 4;
+  p.tilesN = (N + HB - 1) / HB;
+  p.tilesK = (K + HB - 1) / HB;
+  const int total = (int)((M + RB - 1) / RB);
+  const int tiles = p.tilesN * p.tilesK;
+  int S = (640 + tiles - 1) / tiles;
+  const int smax = (total + 3) / 4;
+  if (S > smax) S = smax < 1 ? 1 : smax;
+  p.sps = (total + S - 1) / S;
+  p.S = (total + p.sps - 1) / p.sps;
+  return p;
+}
+
 const float* zero_page() {
   static std::atomic<const float*> cache[KPF_MAX_DEVICES];
   int dev = 0;
@@ -438,8 +638,9 @@ extern "C" {
 
 long kpf_conv2d_wgrad_ws_floats(long M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  const Plan p = plan_wgrad(M, N, K);
-  return (long)p.S * N * K + (long)p.S * N;
+  const Plan p = plan_wgrad(M, N, K), h = plan_wgrad_h16(M, N, K);  // (either kernel may take the call: room for the larger split count)
+  const int S = p.S > h.S ? p.S : h.S;
+  return (long)S * N * K + (long)S * N;
 }
 
 static int conv2d_wgrad_impl(const void* dy, const void* x, int dtype, float* dw, float* db, float* ws, long ws_floats, int B, int H, int W,
@@ -457,7 +658,9 @@ static int conv2d_wgrad_impl(const void* dy, const void* x, int dtype, float* dw
   const long M = (long)B * OH * OW;
   const long K = (long)KH * KW * Cin;
   KPF_REQUIRE(M < (1L << 31) && K < (1L << 24) && (long)B * H * W < (1L << 31), "kpf_conv2d_wgrad_f32: problem too large");
-  const Plan p = plan_wgrad(M, N, (int)K);
+  static const int h16_widen = []() { const char* e = getenv("KPF_WGRAD_H16_WIDEN"); return e ? atoi(e) : 0; }();  // tuning aid: the old widening kernel
+  const bool h16 = dtype != KPF_DT_F32 && !h16_widen;
+  const Plan p = h16 ? plan_wgrad_h16(M, N, (int)K) : plan_wgrad(M, N, (int)K);
   KPF_REQUIRE(ws_floats >= (long)p.S * N * K + (long)p.S * N, "kpf_conv2d_wgrad_f32: workspace too small (%ld floats, need %ld)", ws_floats,
               (long)p.S * N * K + (long)p.S * N);
   WgradArgs a;
@@ -468,8 +671,15 @@ static int conv2d_wgrad_impl(const void* dy, const void* x, int dtype, float* dw
   a.sh = sh, a.sw = sw, a.ph = ph, a.pw = pw, a.M = (int)M, a.K = (int)K, a.tilesK = p.tilesK, a.stages_per_split = p.sps;
   a.is1x1 = KH == 1 && KW == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0 && OH == H && OW == W;
   hipStream_t st = (hipStream_t)stream;
-  const int rc = dtype == KPF_DT_F32 ? launch_wgrad_any<float>(a, p, st)
-                 : (dtype == KPF_DT_BF16 ? launch_wgrad_any<bf16_t>(a, p, st) : launch_wgrad_any<f16_t>(a, p, st));
+  int rc;
+  if (h16) {
+    if (dtype == KPF_DT_BF16) hipLaunchKernelGGL((wgrad_h16_kernel<bf16_t>), dim3(p.tilesN * p.tilesK, p.S), dim3(256), HNS * 2 * RB * 256, st, a);
+    else hipLaunchKernelGGL((wgrad_h16_kernel<f16_t>), dim3(p.tilesN * p.tilesK, p.S), dim3(256), HNS * 2 * RB * 256, st, a);
+    rc = kpf_check_launch("kpf_conv2d_wgrad_h16");
+  } else {
+    rc = dtype == KPF_DT_F32 ? launch_wgrad_any<float>(a, p, st)
+                             : (dtype == KPF_DT_BF16 ? launch_wgrad_any<bf16_t>(a, p, st) : launch_wgrad_any<f16_t>(a, p, st));
+  }
   if (rc != KPF_OK) return rc;
   const long NK = (long)N * K;
   const int nkb = (int)((NK + 63) / 64);
