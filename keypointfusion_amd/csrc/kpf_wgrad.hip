@@ -553,8 +553,19 @@ struct Plan { int vn, vk, tilesN, tilesK, S, sps; };
 // Tile shape and split count from a small cost model: MFMA time of the padded tiles, L2 -> LDS bytes (every dY row is staged once
 // per K tile column, every X row once per N tile row), and the workspace round trip of S partial outputs; S fills the chip
 // (~3 workgroups per CU) with at least four stages per workgroup.
-Plan plan_wgrad(long M, int N, int K) {
+// direct (1x1 convolution / Linear over at most 128 rows): one workgroup per 64 x 64 tile walks the (<= 4) stages and writes dW itself
+// — the partial layout [N][K] IS dW's for a 1x1 — without a reduce launch.  (Tried up to 24 stages for the 21-token stacks of the fusion
+// head, M = 21 B = 672: the serial walk costs 19 us against 8 + 6 for split + reduce.)
+constexpr int DIRECT_MAX_STAGES = 4;
+Plan plan_wgrad(long M, int N, int K, bool direct_ok = false) {
   const int total = (int)((M + RB - 1) / RB);
+  if (direct_ok && total <= DIRECT_MAX_STAGES) {
+    Plan p{};
+    p.vn = p.vk = 2;
+    p.tilesN = (N + 63) / 64, p.tilesK = (K + 63) / 64;
+    p.S = 1, p.sps = total;
+    return p;
+  }
   Plan best{};
   double best_t = 1e30;
   for (int vn = 2; vn <= 4; vn += 2)
@@ -588,8 +599,10 @@ Plan plan_wgrad_h16(long M, int N, int K) {
   p.tilesK = (K + HB - 1) / HB;
   const int total = (int)((M + RB - 1) / RB);
   const int tiles = p.tilesN * p.tilesK;
-  int S = (640 + tiles - 1) / tiles;
-  const int smax = (total + 3) / 4;
+  static const int target = []() { const char* e = getenv("KPF_WG16_TARGET"); return e ? atoi(e) : 640; }();   // tuning aids
+  static const int minst = []() { const char* e = getenv("KPF_WG16_MINSTAGES"); return e ? atoi(e) : 4; }();
+  int S = (target + tiles - 1) / tiles;
+  const int smax = (total + minst - 1) / minst;
   if (S > smax) S = smax < 1 ? 1 : smax;
   p.sps = (total + S - 1) / S;
   p.S = (total + p.sps - 1) / p.sps;
@@ -660,11 +673,13 @@ static int conv2d_wgrad_impl(const void* dy, const void* x, int dtype, float* dw
   KPF_REQUIRE(M < (1L << 31) && K < (1L << 24) && (long)B * H * W < (1L << 31), "kpf_conv2d_wgrad_f32: problem too large");
   static const int h16_widen = []() { const char* e = getenv("KPF_WGRAD_H16_WIDEN"); return e ? atoi(e) : 0; }();  // tuning aid: the old widening kernel
   const bool h16 = dtype != KPF_DT_F32 && !h16_widen;
-  const Plan p = h16 ? plan_wgrad_h16(M, N, (int)K) : plan_wgrad(M, N, (int)K);
+  const bool one = KH == 1 && KW == 1;
+  const Plan p = h16 ? plan_wgrad_h16(M, N, (int)K) : plan_wgrad(M, N, (int)K, one);
+  const bool direct = one && p.S == 1;  // the single partial array is dW
   KPF_REQUIRE(ws_floats >= (long)p.S * N * K + (long)p.S * N, "kpf_conv2d_wgrad_f32: workspace too small (%ld floats, need %ld)", ws_floats,
               (long)p.S * N * K + (long)p.S * N);
   WgradArgs a;
-  a.dy = dy, a.x = x, a.part = ws, a.dbpart = db ? ws + (size_t)p.S * N * K : nullptr;
+  a.dy = dy, a.x = x, a.part = direct ? dw : ws, a.dbpart = db ? (direct ? db : ws + (size_t)p.S * N * K) : nullptr;
   a.zero = zero_page();
   KPF_REQUIRE(a.zero, "kpf_conv2d_wgrad_f32: cannot resolve the zero page");
   a.H = H, a.W = W, a.Cin = Cin, a.ldx = ldx, a.OH = OH, a.OW = OW, a.N = N, a.ldy = ldy, a.KH = KH, a.KW = KW;
@@ -680,7 +695,7 @@ static int conv2d_wgrad_impl(const void* dy, const void* x, int dtype, float* dw
     rc = dtype == KPF_DT_F32 ? launch_wgrad_any<float>(a, p, st)
                              : (dtype == KPF_DT_BF16 ? launch_wgrad_any<bf16_t>(a, p, st) : launch_wgrad_any<f16_t>(a, p, st));
   }
-  if (rc != KPF_OK) return rc;
+  if (rc != KPF_OK || direct) return rc;
   const long NK = (long)N * K;
   const int nkb = (int)((NK + 63) / 64);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nkb + (db ? (N + 63) / 64 : 0)), dim3(256), 0, st, ws, a.dbpart, dw, db, p.S, N, (int)K, Cin,

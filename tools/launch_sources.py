@@ -44,5 +44,5 @@ with Mode():
     it()
 torch.cuda.synchronize()
 print("ATen ops (non-view) in one iteration:", sum(cnt.values()))
-for (name, where), c in cnt.most_common(90):
+for (name, where), c in cnt.most_common(400):
     print("%5d  %-30s %s" % (c, name, where))
