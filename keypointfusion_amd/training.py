@@ -8,12 +8,16 @@ What exists here
                         (train.py:222-223: the coordinate loss back-propagates through the soft-argmax into the dense maps).
   * `joint2heatmap`     GFM.joint2heatmap (util/generateFeature.py:584-600).
   * `SmoothL1Loss`      model/loss.py:3-26 (quadratic below 0.01, linear above; mean over the last dim, then over the rest).
-  * `kpfusion_loss`     the stage-typed schedule of train.py:211-261 (stage_type [1,1,2,3,2,3], coord 100, deconv 1, spatial 10, sigma 3/2).
-  * `make_optimizer`    AdamW(lr 8e-4, wd 0.01) + StepLR(10, 0.1) (train.py:84-91,120; config.py).
+  * `kpfusion_loss`     the stage-typed schedule of train.py:211-261 (stage_type [1,1,2,3,2,3], coord 100, deconv 1, spatial 10, sigma 3/2);
+                        on CUDA tensors it is ONE autograd node, `FusedLoss` (kpf_dense_loss_* + kpf_loss_tail_*: 4 launches forward,
+                        3 backward); the functions above are its torch restatement (CPU tests, custom l1, other schedules).
+  * `make_optimizer`    AdamW(lr 8e-4, wd 0.01) + StepLR(10, 0.1) (train.py:84-91,120; config.py); `FusedAdamW` = the same optimiser
+                        stepping all parameters in ~14 launches (kpf_adamw_step_multi), learning rate and step count on the device.
   * `Conv2dNHWC`        torch.autograd.Function: forward and data-gradient on kpf_conv2d_f32 / _h16 (dgrad = the forward kernel on
                         flipped / transposed weights, of the stride-dilated dY for strided convolutions; patchify convolutions: a
-                        GEMM + pixel un-shuffle), weight and bias gradient on kpf_conv2d_wgrad_f32 / _h16 (f32 MFMA, pixel index
-                        as the reduction dimension, fixed-order split reduction).
+                        GEMM + pixel un-shuffle), weight and bias gradient on kpf_conv2d_wgrad_f32 / _h16 (fp32 MFMA, or the 16-bit MFMA
+                        fed by transposed LDS reads for 16-bit dY / X; pixel index as the reduction dimension, fixed-order split
+                        reduction, fp32 accumulation either way).
   * `DwConv7NHWC`, `BatchNormReLU`, `Upsample2xNHWC`, `MaxPool3x3s2NHWC`, `RowGather`: depthwise 7x7, train-mode BatchNorm(+ReLU),
                         bilinear x2, max-pool and the weighted row gathers with hand-written, run-to-run deterministic backward
                         kernels (csrc/kpf_wgrad.hip, csrc/kpf_train.hip).
@@ -21,8 +25,10 @@ What exists here
                         RCCL -> graph B for data parallelism).
 These are torch tensors in, torch tensors out (autograd and the optimiser are PyTorch-ROCm's: host-side plumbing, as BASELINE.json's
 north_star puts it).  Mixed precision ("bf16"): 16-bit GEMM operands, fp32 master weights / statistics / loss / weight gradients.
-Still on torch autograd: LayerNorm / GELU / softmax / the 21-token attention and the loss codec (elementwise ops and reductions
-over B x 105 x 32 x 32 maps).  See DESIGN.md §8.
+  * `LayerNormRows`, `GeluRows`, `Attn21`, `BmmSmallK`, `layer_scale_residual`: the element-wise tail of the ConvNeXt block and the
+                        21-token stacks' LayerNorm / GELU / attention core on HIP kernels with fixed-order parameter gradients.
+Still on torch autograd: the residual / gate arithmetic of the fusion head, hidden dropout, zero-padding of odd channel
+counts, gradient accumulation at fan-outs.
 """
 import ctypes as C
 
