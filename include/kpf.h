@@ -434,12 +434,28 @@ typedef struct kpf_adamw_desc {
 int kpf_adamw_step_multi(const kpf_adamw_desc* descs, int n, const float* lr_dev, float lr_host, const float* step_dev, double beta1, double beta2, float eps,
                          float weight_decay, void* stream);
 
+/* Training: the weight (and bias) gradients of MANY Linear layers over few rows in one launch per KPF_WGRAD_GROUP_BATCH problems:
+ * dw[N][K] = dy[M][N]^T x[M][K], db[N] = column sums of dy (db nullable), fp32, N % 4 == K % 4 == 0, rows contiguous.  A workgroup owns a
+ * 64 x 64 tile of one problem and walks all M rows (no split, no reduce launch) — meant for M up to ~1000 (the 21-token stacks of the
+ * fusion head: M = 21 B), where a launch pair per layer costs more than the arithmetic; the row range is still summed in the splits of
+ * kpf_conv2d_wgrad_f32 and the split sums in split order, so both forms return the same bits.  descs: HOST array. */
+#define KPF_WGRAD_GROUP_BATCH 64
+typedef struct kpf_wgrad_group_desc {
+  const float* dy;
+  const float* x;
+  float* dw;
+  float* db;
+  int M, N, K, first_block; /* (first_block, sps: set by the call) */
+  int sps, reserved;
+} kpf_wgrad_group_desc;
+int kpf_linear_wgrad_grouped(const kpf_wgrad_group_desc* descs, int n, void* stream);
+
 int kpf_conv_num_tile_cfgs(void);
 
 const char* kpf_last_error(void);
 /* Library/ABI version, bumped when a signature or the meaning of an argument changes (KPF_ABI_VERSION is what this header
  * describes; the Python binding refuses a library that reports another). */
-#define KPF_ABI_VERSION 8
+#define KPF_ABI_VERSION 9
 int kpf_abi_version(void);
 
 #ifdef __cplusplus

@@ -36,6 +36,7 @@ struct WgradArgs {
   int H, W, Cin, ldx, OH, OW, N, ldy, KH, KW, sh, sw, ph, pw;
   int M, K, tilesK, stages_per_split;
   int is1x1;
+  int emul_sps;  // grouped form only: stages per split of the split + reduce form whose summation order it reproduces
 };
 
 constexpr int RB = 32;  // pixels (reduction rows) per LDS stage
@@ -57,8 +58,8 @@ __device__ __forceinline__ void unpack8(const uint4, float, f32x4&, f32x4&) {}  
 // 16-byte global loads of 8 values into registers while the previous tile is multiplied, widened to fp32 on the way into LDS — the
 // MFMAs, accumulation and reduction are the fp32 ones (the master weight's gradient is not rounded), and the separate
 // 16-bit -> fp32 passes over dY and X disappear.
-template <int VN, int VK, typename TIN>
-__global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradArgs a) {
+template <int VN, int VK, typename TIN, bool GROUPED = false>
+__device__ __forceinline__ void wgrad_f32_body(const WgradArgs& a, const int bx, const int split) {
   constexpr bool DMA = std::is_same<TIN, float>::value;
   constexpr int BN = 32 * VN, BK = 32 * VK;     // output tile; 2 x 2 waves, wave tile (16 VN) x (16 VK)
   constexpr int GA = BN / 4, GB = BK / 4;       // 16-byte granules per staged row
@@ -69,9 +70,8 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave & 1, wk = wave >> 1;
-  const int nt = blockIdx.x / a.tilesK, kt = blockIdx.x % a.tilesK;
+  const int nt = bx / a.tilesK, kt = bx % a.tilesK;
   const int n0 = nt * BN, k0 = kt * BK;
-  const int split = blockIdx.y;
   const int total_stages = (a.M + RB - 1) / RB;
   const int s_begin = split * a.stages_per_split;
   const int ns = min(a.stages_per_split, total_stages - s_begin);
@@ -126,6 +126,31 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradArgs a) {
     for (int j = 0; j < VK; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   fvn dbs = 0.f;
   const bool want_db = a.dbpart != nullptr && kt == 0 && wk == 0;
+  // GROUPED (one workgroup walks every stage): the stages are still summed split by split — a fresh accumulator per emul_sps stages, the
+  // split sums added in split order — which is exactly what the split kernels + wgrad_reduce_kernel compute: same bits either way
+  f32x4 tot[VN][VK];
+  float dbt[VN];
+#pragma unroll
+  for (int i = 0; i < VN; ++i) {
+    dbt[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < VK; ++j) tot[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  auto fold = [&]() {
+#pragma unroll
+    for (int i = 0; i < VN; ++i) {
+#pragma unroll
+      for (int j = 0; j < VK; ++j) {
+        tot[i][j] += acc[i][j];
+        acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      float v = dbs[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      dbt[i] += v;
+      dbs[i] = 0.f;
+    }
+  };
 
   const int fr = lane >> 4, fc = lane & 15;  // fragment row inside a 4-pixel k-step / 16-lane column index
   const int a_off = fr * BN + wn * (16 * VN) + VN * fc;
@@ -203,6 +228,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradArgs a) {
     }
   }
   for (int s = 0; s < ns; ++s) {
+    if (GROUPED && s > 0 && s % a.emul_sps == 0) fold();
     __syncthreads();  // tile s is in LDS (DMA: the barrier's fence drains it); every wave is done with tile s-1
     float* cur = lds + (s & 1) * TILE;
     if (s + 1 < ns) {
@@ -224,6 +250,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradArgs a) {
     }
   }
 
+  if (GROUPED) fold();
   // --- partial tile -> workspace: lane holds, for tile (i, j) and r = 0..3: n = 4*(4*fr + r) + i (VN-interleaved), k = VK*fc + j ---
   float* part = a.part + (size_t)split * a.N * a.K;
   const int kk = k0 + wk * (16 * VK) + VK * fc;
@@ -235,7 +262,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradArgs a) {
       if (n < a.N && kk < a.K) {
         fvk v;
 #pragma unroll
-        for (int j = 0; j < VK; ++j) v[j] = acc[i][j][r];
+        for (int j = 0; j < VK; ++j) v[j] = GROUPED ? tot[i][j][r] : acc[i][j][r];
         *reinterpret_cast<fvk*>(part + (size_t)n * a.K + kk) = v;
       }
     }
@@ -243,12 +270,53 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < VN; ++i) {
       float v = dbs[i];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
+      if (GROUPED) {
+        v = dbt[i];
+      } else {
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+      }
       const int n = n0 + wn * (16 * VN) + VN * fc + i;
       if (fr == 0 && n < a.N) a.dbpart[(size_t)split * a.N + n] = v;
     }
   }
+}
+
+template <int VN, int VK, typename TIN>
+__global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradArgs a) {
+  wgrad_f32_body<VN, VK, TIN>(a, blockIdx.x, blockIdx.y);
+}
+
+// Grouped form for Linear layers over few rows (the 21-token stacks of the fusion head: M = 21 B): ~80 such weight gradients per
+// iteration cost 8 us + a 6-us reduce launch EACH as separate launches, for 0.1 GFLOP in all.  Here one launch carries up to
+// KPF_WGRAD_GROUP_BATCH problems (descriptors by value, read from the kernel-argument segment); a workgroup owns one 64 x 64 tile of
+// one problem, walks all its pixel stages (no split, no reduce: for a 1x1 the tile IS a piece of dW) and every problem's tiles run side
+// by side.  Issued once after backward by training.GroupedLinearWgrad with the (dY, X) pairs it kept alive.
+struct WgradGroupBatch {
+  kpf_wgrad_group_desc d[KPF_WGRAD_GROUP_BATCH];
+  const float* zero;
+  int nd;
+};
+typedef const __attribute__((address_space(4))) WgradGroupBatch* wgrad_group_kernarg_t;
+
+__global__ __launch_bounds__(256) void wgrad_grouped_kernel(const WgradGroupBatch) {
+  wgrad_group_kernarg_t bp = (wgrad_group_kernarg_t)__builtin_amdgcn_kernarg_segment_ptr();
+  const int nd = bp->nd;
+  int lo = 0, hi = nd - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)blockIdx.x >= bp->d[mid].first_block) lo = mid;
+    else hi = mid - 1;
+  }
+  WgradArgs a;
+  a.dy = bp->d[lo].dy, a.x = bp->d[lo].x, a.part = bp->d[lo].dw, a.dbpart = bp->d[lo].db, a.zero = bp->zero;
+  a.M = bp->d[lo].M, a.N = bp->d[lo].N, a.K = bp->d[lo].K;
+  a.H = 1, a.W = a.M, a.Cin = a.K, a.ldx = a.K, a.OH = 1, a.OW = a.M, a.ldy = a.N, a.KH = 1, a.KW = 1, a.sh = 1, a.sw = 1, a.ph = 0, a.pw = 0;
+  a.tilesK = (a.K + 63) / 64;
+  a.stages_per_split = (a.M + RB - 1) / RB;
+  a.is1x1 = 1;
+  a.emul_sps = bp->d[lo].sps;
+  wgrad_f32_body<2, 2, float, true>(a, (int)blockIdx.x - bp->d[lo].first_block, 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -435,45 +503,40 @@ __global__ __launch_bounds__(256) void wgrad_h16_kernel(const WgradArgs a) {
   }
 }
 
-// Fixed-order sum of S partial arrays of n floats: a workgroup owns 64 consecutive outputs, its four waves sum the partials
-// p = w, w+4, w+8, ... (four independent chains each) and the four wave sums are combined through LDS — the same order every run.
-__device__ __forceinline__ float sum_partials(const float* __restrict__ part, long n, int S, long i, float (*red)[64]) {
-  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+// Fixed-order sum of S partial arrays of n floats: output i = ((part[0][i] + part[1][i]) + part[2][i]) + ... in split order — eight
+// independent loads in flight, the adds in sequence (S <= a few dozen).  The order is the one wgrad_grouped_kernel reproduces inside a
+// single workgroup, so a layer's gradient has the same bits whichever of the two forms computed it.
+__device__ __forceinline__ float sum_partials(const float* __restrict__ part, long n, int S, long i) {
+  float s = 0.f;
   if (i < n) {
-    int p = g;
-    for (; p + 12 < S; p += 16) {
-      s0 += part[(size_t)p * n + i];
-      s1 += part[(size_t)(p + 4) * n + i];
-      s2 += part[(size_t)(p + 8) * n + i];
-      s3 += part[(size_t)(p + 12) * n + i];
+    int p = 0;
+    for (; p + 8 <= S; p += 8) {
+      const float v0 = part[(size_t)p * n + i], v1 = part[(size_t)(p + 1) * n + i], v2 = part[(size_t)(p + 2) * n + i], v3 = part[(size_t)(p + 3) * n + i];
+      const float v4 = part[(size_t)(p + 4) * n + i], v5 = part[(size_t)(p + 5) * n + i], v6 = part[(size_t)(p + 6) * n + i], v7 = part[(size_t)(p + 7) * n + i];
+      s = (((((((s + v0) + v1) + v2) + v3) + v4) + v5) + v6) + v7;
     }
-    for (; p < S; p += 4) s0 += part[(size_t)p * n + i];
+    for (; p < S; ++p) s += part[(size_t)p * n + i];
   }
-  red[g][o] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  return (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
+  return s;
 }
 
 // dw[n][c][ky][kx] = sum_s part[s][n][(ky,kx,c)];  db[n] = sum_s dbpart[s][n]   (blocks [0, nkb) reduce dw, the rest db)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbpart,
                                                            float* __restrict__ dw, float* __restrict__ db, int S, int N, int K, int Cin,
                                                            int KHW, int nkb) {
-  __shared__ float red[4][64];
-  const int o = threadIdx.x & 63;
   if ((int)blockIdx.x < nkb) {
     const long NK = (long)N * K;
-    const long i = (long)blockIdx.x * 64 + o;
-    const float v = sum_partials(part, NK, S, i, red);
-    if (threadIdx.x < 64 && i < NK) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const float v = sum_partials(part, NK, S, i);
+    if (i < NK) {
       const int n = (int)(i / K), k = (int)(i - (long)n * K);
       const int tap = k / Cin, c = k - tap * Cin;
       dw[((size_t)n * Cin + c) * KHW + tap] = v;
     }
   } else {
-    const long i = (long)(blockIdx.x - nkb) * 64 + o;
-    const float v = sum_partials(dbpart, N, S, i, red);
-    if (threadIdx.x < 64 && i < N) db[i] = v;
+    const long i = (long)(blockIdx.x - nkb) * 256 + threadIdx.x;
+    const float v = sum_partials(dbpart, N, S, i);
+    if (i < N) db[i] = v;
   }
 }
 
@@ -531,20 +594,18 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const float* __restr
 // dw[c][tap] = sum_s part[s][tap][c];  db[c] = sum_s dbpart[s][c]
 __global__ __launch_bounds__(256) void dwconv7_wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbpart,
                                                                    float* __restrict__ dw, float* __restrict__ db, int S, int C, int nkb) {
-  __shared__ float red[4][64];
-  const int o = threadIdx.x & 63;
   if ((int)blockIdx.x < nkb) {
     const long n = 49L * C;
-    const long i = (long)blockIdx.x * 64 + o;
-    const float v = sum_partials(part, n, S, i, red);
-    if (threadIdx.x < 64 && i < n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const float v = sum_partials(part, n, S, i);
+    if (i < n) {
       const int tap = (int)(i / C), c = (int)(i - (long)tap * C);
       dw[c * 49 + tap] = v;
     }
   } else {
-    const long i = (long)(blockIdx.x - nkb) * 64 + o;
-    const float v = sum_partials(dbpart, C, S, i, red);
-    if (threadIdx.x < 64 && i < C) db[i] = v;
+    const long i = (long)(blockIdx.x - nkb) * 256 + threadIdx.x;
+    const float v = sum_partials(dbpart, C, S, i);
+    if (i < C) db[i] = v;
   }
 }
 
@@ -685,6 +746,7 @@ static int conv2d_wgrad_impl(const void* dy, const void* x, int dtype, float* dw
   a.H = H, a.W = W, a.Cin = Cin, a.ldx = ldx, a.OH = OH, a.OW = OW, a.N = N, a.ldy = ldy, a.KH = KH, a.KW = KW;
   a.sh = sh, a.sw = sw, a.ph = ph, a.pw = pw, a.M = (int)M, a.K = (int)K, a.tilesK = p.tilesK, a.stages_per_split = p.sps;
   a.is1x1 = KH == 1 && KW == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0 && OH == H && OW == W;
+  a.emul_sps = 0;
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (h16) {
@@ -697,8 +759,8 @@ static int conv2d_wgrad_impl(const void* dy, const void* x, int dtype, float* dw
   }
   if (rc != KPF_OK || direct) return rc;
   const long NK = (long)N * K;
-  const int nkb = (int)((NK + 63) / 64);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nkb + (db ? (N + 63) / 64 : 0)), dim3(256), 0, st, ws, a.dbpart, dw, db, p.S, N, (int)K, Cin,
+  const int nkb = (int)((NK + 255) / 256);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nkb + (db ? (N + 255) / 256 : 0)), dim3(256), 0, st, ws, a.dbpart, dw, db, p.S, N, (int)K, Cin,
                      KH * KW, nkb);
   return kpf_check_launch("kpf_conv2d_wgrad_f32 (reduce)");
 }
@@ -712,6 +774,32 @@ int kpf_conv2d_wgrad_h16(const void* dy, const void* x, int dtype, float* dw, fl
                          int ldx, int OH, int OW, int N, int ldy, int KH, int KW, int sh, int sw, int ph, int pw, void* stream) {
   KPF_REQUIRE(dtype == KPF_DT_BF16 || dtype == KPF_DT_F16, "kpf_conv2d_wgrad_h16: dtype must be KPF_DT_BF16 or KPF_DT_F16");
   return conv2d_wgrad_impl(dy, x, dtype, dw, db, ws, ws_floats, B, H, W, Cin, ldx, OH, OW, N, ldy, KH, KW, sh, sw, ph, pw, stream);
+}
+
+int kpf_linear_wgrad_grouped(const kpf_wgrad_group_desc* descs, int n, void* stream) {
+  KPF_REQUIRE(n >= 0 && (descs || n == 0), "kpf_linear_wgrad_grouped: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  for (int base = 0; base < n; base += KPF_WGRAD_GROUP_BATCH) {
+    WgradGroupBatch b;
+    b.nd = n - base < KPF_WGRAD_GROUP_BATCH ? n - base : KPF_WGRAD_GROUP_BATCH;
+    long blocks = 0;
+    for (int k = 0; k < b.nd; ++k) {
+      b.d[k] = descs[base + k];
+      const kpf_wgrad_group_desc& d = b.d[k];
+      KPF_REQUIRE(d.dy && d.x && d.dw && d.M > 0 && d.N > 0 && d.K > 0 && d.N % 4 == 0 && d.K % 4 == 0, "kpf_linear_wgrad_grouped: bad descriptor %d (N, K multiples of 4)",
+                  base + k);
+      KPF_REQUIRE(kpf_aligned16(d.dy) && kpf_aligned16(d.x) && kpf_aligned16(d.dw), "kpf_linear_wgrad_grouped: dy, x, dw must be 16-byte aligned (descriptor %d)", base + k);
+      b.d[k].first_block = (int)blocks;
+      b.d[k].sps = plan_wgrad(d.M, d.N, d.K, true).sps;  // (the split the per-layer form would use: its summation order is reproduced)
+      blocks += (long)((d.N + 63) / 64) * ((d.K + 63) / 64);
+    }
+    b.zero = zero_page();
+    KPF_REQUIRE(b.zero, "kpf_linear_wgrad_grouped: cannot resolve the zero page");
+    hipLaunchKernelGGL(wgrad_grouped_kernel, dim3((unsigned)blocks), dim3(256), 2 * RB * 32 * (2 + 2) * 4, st, b);
+    const int rc = kpf_check_launch("kpf_linear_wgrad_grouped");
+    if (rc != KPF_OK) return rc;
+  }
+  return KPF_OK;
 }
 
 long kpf_dwconv7_wgrad_ws_floats(int B, int H, int C) {
@@ -734,8 +822,8 @@ int kpf_dwconv7_wgrad_f32(const float* dy, const float* x, float* dw, float* db,
   hipLaunchKernelGGL(dwconv7_wgrad_kernel, dim3((7 * (C / 4) + 255) / 256, S), dim3(256), 0, st, dy, x, ws, dbpart, B, H, W, C, rpc);
   int rc = kpf_check_launch("kpf_dwconv7_wgrad_f32");
   if (rc != KPF_OK) return rc;
-  const int nkb = (49 * C + 63) / 64;
-  hipLaunchKernelGGL(dwconv7_wgrad_reduce_kernel, dim3(nkb + (db ? (C + 63) / 64 : 0)), dim3(256), 0, st, ws, dbpart, dw, db, S, C, nkb);
+  const int nkb = (49 * C + 255) / 256;
+  hipLaunchKernelGGL(dwconv7_wgrad_reduce_kernel, dim3(nkb + (db ? (C + 255) / 256 : 0)), dim3(256), 0, st, ws, dbpart, dw, db, S, C, nkb);
   return kpf_check_launch("kpf_dwconv7_wgrad_f32 (reduce)");
 }
 

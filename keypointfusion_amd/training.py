@@ -612,6 +612,71 @@ def _conv_any(pc, x4, prec):
     return out.buf.view(out.B, out.H, out.W, out.C)
 
 
+class GroupedLinearWgrad:
+    """Weight gradients of the small Linear layers of one backward pass in ONE launch per 80 layers after it (kpf_linear_wgrad_grouped)
+    instead of a GEMM launch + a reduce launch behind each of ~80 layers of 21 B rows.  While active, Conv2dNHWC.backward of an fp32 1x1 /
+    Linear over at most MAX_ROWS rows whose weight IS a parameter (or a stride-preserving view of one: PackCache key without ':')
+    keeps (dY, X) alive, returns dW / db tensors that are still UNWRITTEN and registers them; autograd only moves those tensors
+    (AccumulateGrad adopts a parameter's first gradient without reading it), `flush()` fills them.  Anything that would read such a
+    gradient earlier must not take this path: a second use of the same weight in one forward is refused here, slices / pads /
+    concatenations of weights never pass a plain key, gradient hooks are not used by GraphedTrainStep (the only caller).  flush()
+    checks on every eager pass that each dW became the parameter's .grad itself (a parameter outside the optimiser whose stale .grad
+    made autograd add instead of adopt is how the `live_parameters` name bug of round 3 surfaced)."""
+    active = None
+    MAX_ROWS = 1024
+
+    def __init__(self, named_params=None):
+        self.named = named_params
+        self.items, self.seen = [], set()
+
+    def __enter__(self):
+        assert GroupedLinearWgrad.active is None
+        GroupedLinearWgrad.active = self
+        return self
+
+    def __exit__(self, et, ev, tb):
+        GroupedLinearWgrad.active = None
+        if et is None:
+            self.flush()
+        else:
+            self.items, self.seen = [], set()
+        return False
+
+    @staticmethod
+    def wants(key, cache, dy, x, kh, kw, stride, pad):
+        g = GroupedLinearWgrad.active
+        if g is None or cache is None or not isinstance(key, str) or ":" in key:
+            return None
+        rows = x.numel() // x.shape[-1]
+        ok = (kh == 1 and kw == 1 and stride == 1 and pad == 0 and rows <= g.MAX_ROWS and dy.dtype == torch.float32 and x.dtype == torch.float32
+              and x.shape[-1] % 4 == 0 and dy.shape[-1] % 4 == 0)
+        return g if ok else None
+
+    def add(self, key, dy, x, dw, db):
+        if key in self.seen:
+            raise RuntimeError("GroupedLinearWgrad: parameter %r receives a second gradient in one backward pass" % (key,))
+        self.seen.add(key)
+        # (dY, X) stay referenced until flush; of dW / db only the addresses are kept — a second reference would make AccumulateGrad
+        # copy the unwritten tensor instead of adopting it
+        self.items.append((key, dy, x, dw.data_ptr(), None if db is None else db.data_ptr(), x.numel() // x.shape[-1], dy.shape[-1], x.shape[-1]))
+
+    def flush(self):
+        from . import lib as L
+        items, self.items, self.seen = self.items, [], set()
+        if not items:
+            return
+        arr = (L.WgradGroupDesc * len(items))()
+        for d, (key, dy, x, pw, pb, M, N, K) in zip(arr, items):
+            d.dy, d.x, d.dw, d.db, d.M, d.N, d.K = dy.data_ptr(), x.data_ptr(), pw, pb, M, N, K
+        L.check(L.load().kpf_linear_wgrad_grouped(arr, len(items), torch.cuda.current_stream().cuda_stream), "kpf_linear_wgrad_grouped")
+        if self.named is not None:
+            for key, _, _, pw, _, _, _, _ in items:
+                p = self.named.get(key)
+                if p is not None and (p.grad is None or p.grad.data_ptr() != pw):
+                    raise RuntimeError("GroupedLinearWgrad: the gradient of %r was copied before it was written (autograd did not adopt the tensor: "
+                                       "is the parameter outside the optimiser's zero_grad, hooked, or used twice?)" % key)
+
+
 def conv_wgrad_hip(dy, x, wshape, stride, pad, want_db=True):
     """(dW in OIHW, db or None) of a convolution from NHWC dY [B,OH,OW,N] and X [B,H,W,Cin]: kpf_conv2d_wgrad_f32 / _h16 (f32 MFMA GEMM
     with the pixel index as the reduction dimension, split over workgroups, fixed-order reduce)."""
@@ -1090,7 +1155,15 @@ class Conv2dNHWC(torch.autograd.Function):
         if ctx.needs_input_grad[1] and Cin % 4 == 0 and N % 4 == 0:
             # hand-written split-K weight gradient (fp32 products and accumulation in every precision mode: the master weight's
             # gradient is not rounded to 16 bits; 16-bit dY / X are read as stored), bias gradient from the same pass
-            dw, db = conv_wgrad_hip(dy, x, weight.shape, stride, pad, has_bias and ctx.needs_input_grad[2])
+            want_db = has_bias and ctx.needs_input_grad[2]
+            grp = GroupedLinearWgrad.wants(ctx.pack[0], ctx.pack[1], dy, x, KH, KW, stride, pad)
+            if grp is not None:  # small Linear layer: its weight gradient joins the grouped launch after backward
+                dyc, xc = dy.contiguous(), x.contiguous()
+                dw = torch.empty(tuple(weight.shape), device=x.device, dtype=torch.float32)
+                db = torch.empty(N, device=x.device, dtype=torch.float32) if want_db else None
+                grp.add(ctx.pack[0], dyc, xc, dw, db)
+            else:
+                dw, db = conv_wgrad_hip(dy, x, weight.shape, stride, pad, want_db)
             return dx, dw, db, None, None, None, None, None, None
         if ctx.needs_input_grad[1]:
             xw = x if prec == "f32" else x.to(_TDT[prec])  # weight gradient in the compute precision, handed to the fp32 master weight
@@ -1148,6 +1221,9 @@ class GraphedTrainStep:
         assert_replay_is_sound(next(iter(batch.values())).device)  # (once per process: refuses a runtime that mis-replays reductions)
         self.static = {k: v.detach().clone() for k, v in batch.items()}
         self.params = [p for p in (params if params is not None else model.parameters()) if p.requires_grad]
+        self._named = dict(model.named_parameters())
+        mine = {id(p) for g in optimizer.param_groups for p in g["params"]}
+        self._outside = [p for p in model.parameters() if id(p) not in mine]
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
@@ -1191,8 +1267,11 @@ class GraphedTrainStep:
 
     def _forward_backward(self):
         self.opt.zero_grad(set_to_none=True)
-        loss = self.loss_fn(self.model, self.static)
-        loss.backward()
+        for p in self._outside:  # (parameters that get a gradient but are not the optimiser's: their stale .grad would be added to, not replaced)
+            p.grad = None
+        with GroupedLinearWgrad(self._named):  # the small Linear layers' weight gradients: one launch after backward
+            loss = self.loss_fn(self.model, self.static)
+            loss.backward()
         return loss.detach()
 
     def _reduce_eager(self):

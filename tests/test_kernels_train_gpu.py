@@ -563,3 +563,62 @@ def test_fused_adamw_matches_torch_adamw_and_exchanges_state():
     ref.step(), cont.step()
     for a, c in zip(ref_p, cp):
         assert float((a - c).abs().max()) <= 4e-6 * float(a.abs().max()) + 1e-9, a.shape
+
+
+def test_grouped_linear_weight_gradients_after_backward():
+    """training.GroupedLinearWgrad (kpf_linear_wgrad_grouped): the weight / bias gradients of many small Linear layers in one launch per 80
+    layers after backward, against fp64 — more layers than one launch carries, ragged row counts (1, 21, 672, 1000), widths that are not
+    whole tiles, layers without bias; every dW must have been ADOPTED as the parameter's .grad (no copy of the unwritten tensor); layers
+    outside the rule (too many rows, sliced weight key) take the immediate path inside the same pass; a weight used twice is refused."""
+    from keypointfusion_amd import training as T
+    g = torch.Generator().manual_seed(5)
+    cache = T.PackCache()
+    layers, named = [], {}
+    for i in range(90):
+        rows, k, n = [(672, 128, 128), (21, 132, 64), (1000, 64, 516), (1, 8, 4), (672, 512, 128), (2048, 32, 32)][i % 6]
+        w = torch.nn.Parameter((torch.randn(n, k, generator=g) * 0.1).cuda())
+        b = torch.nn.Parameter(torch.randn(n, generator=g).cuda()) if i % 4 else None
+        x = torch.randn(rows, k, generator=g).cuda().requires_grad_(True)
+        named["l%d" % i] = w
+        layers.append((w, b, x))
+
+    def run(grouped):
+        for w, b, x in layers:
+            w.grad = x.grad = None
+            if b is not None:
+                b.grad = None
+        ctx = T.GroupedLinearWgrad(named) if grouped else __import__("contextlib").nullcontext()
+        with ctx as grp:
+            tot = 0
+            for i, (w, b, x) in enumerate(layers):
+                tot = tot + T.linear_hip(x, w, b, "f32", None, "l%d" % i, cache).square().sum()
+            tot.backward()
+            n_grouped = len(grp.items) if grouped else 0
+        torch.cuda.synchronize()
+        return n_grouped
+
+    assert run(False) == 0
+    imm = [(w.grad.clone(), None if b is None else b.grad.clone()) for w, b, x in layers]
+    assert run(True) == 75  # (the 2048-row layers take the immediate path)
+    for i, ((w, b, x), (gw, gb)) in enumerate(zip(layers, imm)):  # same bits as the per-layer split + reduce form (same summation order)
+        assert torch.equal(w.grad, gw), (i, float((w.grad - gw).abs().max()))
+        assert b is None or torch.equal(b.grad, gb), i
+    for i, (w, b, x) in enumerate(layers):
+        xr, wr = x.detach().double().cpu(), w.detach().double().cpu()
+        y = xr @ wr.t() + (b.detach().double().cpu() if b is not None else 0)
+        dy = 2 * y
+        rw, rb = dy.t() @ xr, dy.sum(0)
+        assert float((w.grad.cpu().double() - rw).abs().max()) <= 2e-5 * float(rw.abs().max()), i
+        if b is not None:
+            assert float((b.grad.cpu().double() - rb).abs().max()) <= 2e-5 * max(float(rb.abs().max()), 1.0), i
+        assert float((x.grad.cpu().double() - dy @ wr).abs().max()) <= 2e-5 * float((dy @ wr).abs().max()), i
+    with pytest.raises(RuntimeError, match="second gradient"):
+        with T.GroupedLinearWgrad(named):
+            w, b, x = layers[0]
+            (T.linear_hip(x, w, b, "f32", None, "l0", cache).sum() + T.linear_hip(x, w, b, "f32", None, "l0", cache).sum()).backward()
+    assert T.GroupedLinearWgrad.active is None
+    w, b, x = layers[0]
+    w.grad = torch.zeros_like(w)  # a stale gradient: autograd adds to it instead of adopting the new tensor -> refused loudly
+    with pytest.raises(RuntimeError, match="copied before it was written"):
+        with T.GroupedLinearWgrad(named):
+            T.linear_hip(x, w, b, "f32", None, "l0", cache).sum().backward()
