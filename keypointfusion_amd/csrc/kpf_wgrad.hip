@@ -503,40 +503,54 @@ __global__ __launch_bounds__(256) void wgrad_h16_kernel(const WgradArgs a) {
   }
 }
 
-// Fixed-order sum of S partial arrays of n floats: output i = ((part[0][i] + part[1][i]) + part[2][i]) + ... in split order — eight
-// independent loads in flight, the adds in sequence (S <= a few dozen).  The order is the one wgrad_grouped_kernel reproduces inside a
-// single workgroup, so a layer's gradient has the same bits whichever of the two forms computed it.
-__device__ __forceinline__ float sum_partials(const float* __restrict__ part, long n, int S, long i) {
-  float s = 0.f;
-  if (i < n) {
-    int p = 0;
-    for (; p + 8 <= S; p += 8) {
-      const float v0 = part[(size_t)p * n + i], v1 = part[(size_t)(p + 1) * n + i], v2 = part[(size_t)(p + 2) * n + i], v3 = part[(size_t)(p + 3) * n + i];
-      const float v4 = part[(size_t)(p + 4) * n + i], v5 = part[(size_t)(p + 5) * n + i], v6 = part[(size_t)(p + 6) * n + i], v7 = part[(size_t)(p + 7) * n + i];
-      s = (((((((s + v0) + v1) + v2) + v3) + v4) + v5) + v6) + v7;
-    }
-    for (; p < S; ++p) s += part[(size_t)p * n + i];
+// Fixed-order sum of S partial arrays of n floats: a workgroup owns 64 consecutive outputs, its four waves sum the partials
+// p = w, w+4, w+8, ... (four independent chains each) and the four wave sums are combined through LDS — the same order every run.
+// Up to SEQ_SPLITS partials are simply added in split order by the first wave: that is the order wgrad_grouped_kernel reproduces inside one
+// workgroup (its problems have at most 8 splits), so a small layer's gradient has the same bits whichever form computed it.
+constexpr int SEQ_SPLITS = 8;
+__device__ __forceinline__ float sum_partials(const float* __restrict__ part, long n, int S, long i, float (*red)[64]) {
+  if (S <= SEQ_SPLITS) {
+    float s = 0.f;
+    if (i < n && threadIdx.x < 64)
+      for (int p = 0; p < S; ++p) s += part[(size_t)p * n + i];
+    return s;
   }
-  return s;
+  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n) {
+    int p = g;
+    for (; p + 12 < S; p += 16) {
+      s0 += part[(size_t)p * n + i];
+      s1 += part[(size_t)(p + 4) * n + i];
+      s2 += part[(size_t)(p + 8) * n + i];
+      s3 += part[(size_t)(p + 12) * n + i];
+    }
+    for (; p < S; p += 4) s0 += part[(size_t)p * n + i];
+  }
+  red[g][o] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  return (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
 }
 
 // dw[n][c][ky][kx] = sum_s part[s][n][(ky,kx,c)];  db[n] = sum_s dbpart[s][n]   (blocks [0, nkb) reduce dw, the rest db)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbpart,
                                                            float* __restrict__ dw, float* __restrict__ db, int S, int N, int K, int Cin,
                                                            int KHW, int nkb) {
+  __shared__ float red[4][64];
+  const int o = threadIdx.x & 63;
   if ((int)blockIdx.x < nkb) {
     const long NK = (long)N * K;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const float v = sum_partials(part, NK, S, i);
-    if (i < NK) {
+    const long i = (long)blockIdx.x * 64 + o;
+    const float v = sum_partials(part, NK, S, i, red);
+    if (threadIdx.x < 64 && i < NK) {
       const int n = (int)(i / K), k = (int)(i - (long)n * K);
       const int tap = k / Cin, c = k - tap * Cin;
       dw[((size_t)n * Cin + c) * KHW + tap] = v;
     }
   } else {
-    const long i = (long)(blockIdx.x - nkb) * 256 + threadIdx.x;
-    const float v = sum_partials(dbpart, N, S, i);
-    if (i < N) db[i] = v;
+    const long i = (long)(blockIdx.x - nkb) * 64 + o;
+    const float v = sum_partials(dbpart, N, S, i, red);
+    if (threadIdx.x < 64 && i < N) db[i] = v;
   }
 }
 
@@ -594,18 +608,20 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const float* __restr
 // dw[c][tap] = sum_s part[s][tap][c];  db[c] = sum_s dbpart[s][c]
 __global__ __launch_bounds__(256) void dwconv7_wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbpart,
                                                                    float* __restrict__ dw, float* __restrict__ db, int S, int C, int nkb) {
+  __shared__ float red[4][64];
+  const int o = threadIdx.x & 63;
   if ((int)blockIdx.x < nkb) {
     const long n = 49L * C;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const float v = sum_partials(part, n, S, i);
-    if (i < n) {
+    const long i = (long)blockIdx.x * 64 + o;
+    const float v = sum_partials(part, n, S, i, red);
+    if (threadIdx.x < 64 && i < n) {
       const int tap = (int)(i / C), c = (int)(i - (long)tap * C);
       dw[c * 49 + tap] = v;
     }
   } else {
-    const long i = (long)(blockIdx.x - nkb) * 256 + threadIdx.x;
-    const float v = sum_partials(dbpart, C, S, i);
-    if (i < C) db[i] = v;
+    const long i = (long)(blockIdx.x - nkb) * 64 + o;
+    const float v = sum_partials(dbpart, C, S, i, red);
+    if (threadIdx.x < 64 && i < C) db[i] = v;
   }
 }
 
@@ -759,8 +775,8 @@ static int conv2d_wgrad_impl(const void* dy, const void* x, int dtype, float* dw
   }
   if (rc != KPF_OK || direct) return rc;
   const long NK = (long)N * K;
-  const int nkb = (int)((NK + 255) / 256);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nkb + (db ? (N + 255) / 256 : 0)), dim3(256), 0, st, ws, a.dbpart, dw, db, p.S, N, (int)K, Cin,
+  const int nkb = (int)((NK + 63) / 64);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nkb + (db ? (N + 63) / 64 : 0)), dim3(256), 0, st, ws, a.dbpart, dw, db, p.S, N, (int)K, Cin,
                      KH * KW, nkb);
   return kpf_check_launch("kpf_conv2d_wgrad_f32 (reduce)");
 }
@@ -822,8 +838,8 @@ int kpf_dwconv7_wgrad_f32(const float* dy, const float* x, float* dw, float* db,
   hipLaunchKernelGGL(dwconv7_wgrad_kernel, dim3((7 * (C / 4) + 255) / 256, S), dim3(256), 0, st, dy, x, ws, dbpart, B, H, W, C, rpc);
   int rc = kpf_check_launch("kpf_dwconv7_wgrad_f32");
   if (rc != KPF_OK) return rc;
-  const int nkb = (49 * C + 255) / 256;
-  hipLaunchKernelGGL(dwconv7_wgrad_reduce_kernel, dim3(nkb + (db ? (C + 255) / 256 : 0)), dim3(256), 0, st, ws, dbpart, dw, db, S, C, nkb);
+  const int nkb = (49 * C + 63) / 64;
+  hipLaunchKernelGGL(dwconv7_wgrad_reduce_kernel, dim3(nkb + (db ? (C + 63) / 64 : 0)), dim3(256), 0, st, ws, dbpart, dw, db, S, C, nkb);
   return kpf_check_launch("kpf_dwconv7_wgrad_f32 (reduce)");
 }
 
