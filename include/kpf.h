@@ -450,6 +450,23 @@ typedef struct kpf_wgrad_group_desc {
 } kpf_wgrad_group_desc;
 int kpf_linear_wgrad_grouped(const kpf_wgrad_group_desc* descs, int n, void* stream);
 
+/* Training: the column-sum reduce behind every LayerNorm / layer-scale backward (d gamma, d beta) for many layers in one launch.  The
+ * _partial forms of kpf_ln_train_backward / kpf_layer_scale_backward run everything but that reduce, leave the per-workgroup partial sums
+ * in `ws` (which must stay alive) and fill `desc`; kpf_colsum_reduce_grouped(descs: HOST array) performs them KPF_COLSUM_BATCH per
+ * launch with the arithmetic of the immediate form (same bits). */
+#define KPF_COLSUM_BATCH 96
+typedef struct kpf_colsum_desc {
+  const float* part; /* [nblk][2][C] */
+  float* dw;         /* column sums of plane 0 */
+  float* db;         /* column sums of plane 1 */
+  int nblk, C, first_block, reserved;
+} kpf_colsum_desc;
+int kpf_ln_train_backward_partial(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd, const float* w, float* dx, float* dw,
+                                  float* db, float* ws, long ws_floats, long rows, int C, kpf_colsum_desc* desc, void* stream);
+int kpf_layer_scale_backward_partial(const float* g, const void* y, int y_dtype, const float* gamma, void* dy, float* dgamma, float* ws, long ws_floats,
+                                     long rows, int C, kpf_colsum_desc* desc, void* stream);
+int kpf_colsum_reduce_grouped(const kpf_colsum_desc* descs, int n, void* stream);
+
 int kpf_conv_num_tile_cfgs(void);
 
 const char* kpf_last_error(void);

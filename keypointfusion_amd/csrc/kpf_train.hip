@@ -637,10 +637,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, 
 
 // 64 columns x 8 segments per workgroup: segment g adds the partials of workgroups g*per .. (g+1)*per - 1 in order, the eight segment
 // sums are added in segment order through LDS (fixed order, 8 x fewer dependent loads per thread than one thread per column)
-__global__ __launch_bounds__(512) void ln_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nblk, int C) {
+__device__ __forceinline__ void ln_bwd_reduce_body(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nblk, int C, int bx) {
   __shared__ float seg[8][64];
   const int col = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + col;
+  const int i = bx * 64 + col;
   const int per = (nblk + 7) / 8;
   float s = 0.f;
   if (i < 2 * C) {
@@ -663,6 +663,31 @@ __global__ __launch_bounds__(512) void ln_bwd_reduce_kernel(const float* __restr
     const int which = i / C, c = i - which * C;
     (which ? db : dw)[c] = t;
   }
+}
+
+__global__ __launch_bounds__(512) void ln_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nblk, int C) {
+  ln_bwd_reduce_body(part, dw, db, nblk, C, blockIdx.x);
+}
+
+// The same reduce for MANY layers in one launch (descriptors by value, read from the kernel-argument segment): a training iteration runs
+// ~115 of these 5-us launches, one behind every LayerNorm / layer-scale backward; the _partial entry points skip it and describe it, and
+// training.DeferredParamGrads issues them together after backward.  Same arithmetic per column: same bits.
+struct ColsumBatch {
+  kpf_colsum_desc d[KPF_COLSUM_BATCH];
+  int nd;
+};
+typedef const __attribute__((address_space(4))) ColsumBatch* colsum_kernarg_t;
+
+__global__ __launch_bounds__(512) void colsum_reduce_grouped_kernel(const ColsumBatch) {
+  colsum_kernarg_t bp = (colsum_kernarg_t)__builtin_amdgcn_kernarg_segment_ptr();
+  const int nd = bp->nd;
+  int lo = 0, hi = nd - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)blockIdx.x >= bp->d[mid].first_block) lo = mid;
+    else hi = mid - 1;
+  }
+  ln_bwd_reduce_body(bp->d[lo].part, bp->d[lo].dw, bp->d[lo].db, bp->d[lo].nblk, bp->d[lo].C, (int)blockIdx.x - bp->d[lo].first_block);
 }
 
 __device__ __forceinline__ float gelu_exact(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
@@ -709,8 +734,8 @@ extern "C" int kpf_ln_train_forward(const float* x, const float* w, const float*
   return kpf_check_launch("kpf_ln_train_forward");
 }
 
-extern "C" int kpf_ln_train_backward(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd, const float* w, float* dx, float* dw,
-                                     float* db, float* ws, long ws_floats, long rows, int C, void* stream) {
+static int ln_train_backward_impl(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd, const float* w, float* dx, float* dw,
+                                  float* db, float* ws, long ws_floats, long rows, int C, void* stream, kpf_colsum_desc* defer) {
   KPF_REQUIRE(dy && x && mean && rstd && w && dx && dw && db && ws && rows > 0 && C > 0 && C % 4 == 0 && C <= 256 * LN_MAXQ, "kpf_ln_train_backward: bad arguments");
   const int nblk = ln_blocks(rows);
   KPF_REQUIRE(ws_floats >= (long)nblk * 2 * C, "kpf_ln_train_backward: workspace too small");
@@ -725,8 +750,43 @@ extern "C" int kpf_ln_train_backward(const void* dy, int dy_dtype, const float* 
   }
   int rc = kpf_check_launch("kpf_ln_train_backward");
   if (rc != KPF_OK) return rc;
+  if (defer) {
+    defer->part = ws, defer->dw = dw, defer->db = db, defer->nblk = nblk, defer->C = C, defer->first_block = 0, defer->reserved = 0;
+    return KPF_OK;
+  }
   hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * C + 63) / 64), dim3(512), 0, st, ws, dw, db, nblk, C);
   return kpf_check_launch("kpf_ln_train_backward (reduce)");
+}
+
+extern "C" int kpf_ln_train_backward(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd, const float* w, float* dx, float* dw,
+                                     float* db, float* ws, long ws_floats, long rows, int C, void* stream) {
+  return ln_train_backward_impl(dy, dy_dtype, x, mean, rstd, w, dx, dw, db, ws, ws_floats, rows, C, stream, nullptr);
+}
+
+extern "C" int kpf_ln_train_backward_partial(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd, const float* w, float* dx, float* dw,
+                                             float* db, float* ws, long ws_floats, long rows, int C, kpf_colsum_desc* desc, void* stream) {
+  KPF_REQUIRE(desc, "kpf_ln_train_backward_partial: desc missing");
+  return ln_train_backward_impl(dy, dy_dtype, x, mean, rstd, w, dx, dw, db, ws, ws_floats, rows, C, stream, desc);
+}
+
+extern "C" int kpf_colsum_reduce_grouped(const kpf_colsum_desc* descs, int n, void* stream) {
+  KPF_REQUIRE(n >= 0 && (descs || n == 0), "kpf_colsum_reduce_grouped: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  for (int base = 0; base < n; base += KPF_COLSUM_BATCH) {
+    ColsumBatch b;
+    b.nd = n - base < KPF_COLSUM_BATCH ? n - base : KPF_COLSUM_BATCH;
+    long blocks = 0;
+    for (int k = 0; k < b.nd; ++k) {
+      b.d[k] = descs[base + k];
+      KPF_REQUIRE(b.d[k].part && b.d[k].dw && b.d[k].db && b.d[k].nblk > 0 && b.d[k].C > 0, "kpf_colsum_reduce_grouped: bad descriptor %d", base + k);
+      b.d[k].first_block = (int)blocks;
+      blocks += (2 * b.d[k].C + 63) / 64;
+    }
+    hipLaunchKernelGGL(colsum_reduce_grouped_kernel, dim3((unsigned)blocks), dim3(512), 0, st, b);
+    const int rc = kpf_check_launch("kpf_colsum_reduce_grouped");
+    if (rc != KPF_OK) return rc;
+  }
+  return KPF_OK;
 }
 
 namespace {
@@ -1012,13 +1072,18 @@ int layer_scale_fwd_launch(const float* x, const void* y, const float* gamma, fl
   return kpf_check_launch("kpf_layer_scale_forward");
 }
 template <typename T>
-int layer_scale_bwd_launch(const float* g, const void* y, const float* gamma, void* dy, float* dgamma, float* ws, long rows, int C, void* stream) {
+int layer_scale_bwd_launch(const float* g, const void* y, const float* gamma, void* dy, float* dgamma, float* ws, long rows, int C, void* stream,
+                           kpf_colsum_desc* defer = nullptr) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int nblk = ln_blocks(rows);
   hipLaunchKernelGGL(layer_scale_bwd_kernel<T>, dim3(nblk), dim3(256), (size_t)4 * C * sizeof(float), st, g, static_cast<const T*>(y), gamma, static_cast<T*>(dy), ws,
                      rows, C / 4);
   int rc = kpf_check_launch("kpf_layer_scale_backward");
   if (rc != KPF_OK) return rc;
+  if (defer) {
+    defer->part = ws, defer->dw = dgamma, defer->db = ws + (long)nblk * 2 * C, defer->nblk = nblk, defer->C = C, defer->first_block = 0, defer->reserved = 0;
+    return KPF_OK;
+  }
   hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * C + 63) / 64), dim3(512), 0, st, ws, dgamma, ws + (long)nblk * 2 * C, nblk, C);
   return kpf_check_launch("kpf_layer_scale_backward (reduce)");
 }
@@ -1039,6 +1104,15 @@ extern "C" int kpf_layer_scale_backward(const float* g, const void* y, int y_dty
   KPF_REQUIRE(ws_floats >= kpf_layer_scale_ws_floats(rows, C), "kpf_layer_scale_backward: workspace too small");
 #define CALL(T) layer_scale_bwd_launch<T>(g, y, gamma, dy, dgamma, ws, rows, C, stream)
   KPF_DISPATCH_DT(y_dtype, "kpf_layer_scale_backward", CALL);
+#undef CALL
+}
+
+extern "C" int kpf_layer_scale_backward_partial(const float* g, const void* y, int y_dtype, const float* gamma, void* dy, float* dgamma, float* ws, long ws_floats,
+                                                long rows, int C, kpf_colsum_desc* desc, void* stream) {
+  KPF_REQUIRE(g && y && gamma && dy && dgamma && ws && desc && rows > 0 && C > 0 && C % 4 == 0 && C <= 256 * LN_MAXQ, "kpf_layer_scale_backward_partial: bad arguments");
+  KPF_REQUIRE(ws_floats >= kpf_layer_scale_ws_floats(rows, C), "kpf_layer_scale_backward_partial: workspace too small");
+#define CALL(T) layer_scale_bwd_launch<T>(g, y, gamma, dy, dgamma, ws, rows, C, stream, desc)
+  KPF_DISPATCH_DT(y_dtype, "kpf_layer_scale_backward_partial", CALL);
 #undef CALL
 }
 

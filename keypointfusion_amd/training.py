@@ -165,8 +165,16 @@ class _LayerScaleResidual(torch.autograd.Function):
         dgamma = torch.empty(Cc, device=y.device, dtype=torch.float32)
         nws = lib.kpf_layer_scale_ws_floats(rows, Cc)
         ws = torch.empty(nws, device=y.device, dtype=torch.float32)
-        L.check(lib.kpf_layer_scale_backward(g.data_ptr(), y.data_ptr(), _KDT[y.dtype], gm.data_ptr(), dy.data_ptr(), dgamma.data_ptr(), ws.data_ptr(), nws, rows, Cc,
-                                             torch.cuda.current_stream().cuda_stream), "kpf_layer_scale_backward")
+        st = torch.cuda.current_stream().cuda_stream
+        grp = DeferredParamGrads.wants_colsum(gm)
+        if grp is not None:  # d gamma: reduced with every other layer's after backward
+            desc = L.ColsumDesc()
+            L.check(lib.kpf_layer_scale_backward_partial(g.data_ptr(), y.data_ptr(), _KDT[y.dtype], gm.data_ptr(), dy.data_ptr(), dgamma.data_ptr(), ws.data_ptr(), nws,
+                                                         rows, Cc, C.byref(desc), st), "kpf_layer_scale_backward_partial")
+            grp.add_colsum(gm, desc, ws, dgamma)
+        else:
+            L.check(lib.kpf_layer_scale_backward(g.data_ptr(), y.data_ptr(), _KDT[y.dtype], gm.data_ptr(), dy.data_ptr(), dgamma.data_ptr(), ws.data_ptr(), nws, rows, Cc,
+                                                 st), "kpf_layer_scale_backward")
         return g, dgamma, dy
 
 
@@ -612,7 +620,7 @@ def _conv_any(pc, x4, prec):
     return out.buf.view(out.B, out.H, out.W, out.C)
 
 
-class GroupedLinearWgrad:
+class DeferredParamGrads:
     """Weight gradients of the small Linear layers of one backward pass in ONE launch per 80 layers after it (kpf_linear_wgrad_grouped)
     instead of a GEMM launch + a reduce launch behind each of ~80 layers of 21 B rows.  While active, Conv2dNHWC.backward of an fp32 1x1 /
     Linear over at most MAX_ROWS rows whose weight IS a parameter (or a stride-preserving view of one: PackCache key without ':')
@@ -627,24 +635,42 @@ class GroupedLinearWgrad:
 
     def __init__(self, named_params=None):
         self.named = named_params
-        self.items, self.seen = [], set()
+        self.by_ptr = {p.data_ptr(): p for p in (named_params or {}).values()}
+        self.items, self.colsums, self.seen = [], [], set()
 
     def __enter__(self):
-        assert GroupedLinearWgrad.active is None
-        GroupedLinearWgrad.active = self
+        assert DeferredParamGrads.active is None
+        DeferredParamGrads.active = self
         return self
 
     def __exit__(self, et, ev, tb):
-        GroupedLinearWgrad.active = None
+        DeferredParamGrads.active = None
         if et is None:
             self.flush()
         else:
-            self.items, self.seen = [], set()
+            self.items, self.colsums, self.seen = [], [], set()
         return False
 
     @staticmethod
+    def wants_colsum(weight):
+        """The d gamma / d beta column sums behind a LayerNorm / layer-scale backward (kpf_colsum_reduce_grouped): deferred when `weight`
+        is a whole parameter of the model (same storage address and size)."""
+        g = DeferredParamGrads.active
+        if g is None:
+            return None
+        p = g.by_ptr.get(weight.data_ptr())
+        return g if (p is not None and p.numel() == weight.numel()) else None
+
+    def add_colsum(self, weight, desc, ws, out):
+        key = ("colsum", weight.data_ptr())
+        if key in self.seen:
+            raise RuntimeError("DeferredParamGrads: a normalisation parameter receives a second gradient in one backward pass")
+        self.seen.add(key)
+        self.colsums.append((desc, ws, weight.data_ptr(), out.data_ptr()))  # (ws stays referenced; of the output only the address)
+
+    @staticmethod
     def wants(key, cache, dy, x, kh, kw, stride, pad):
-        g = GroupedLinearWgrad.active
+        g = DeferredParamGrads.active
         if g is None or cache is None or not isinstance(key, str) or ":" in key:
             return None
         rows = x.numel() // x.shape[-1]
@@ -654,7 +680,7 @@ class GroupedLinearWgrad:
 
     def add(self, key, dy, x, dw, db):
         if key in self.seen:
-            raise RuntimeError("GroupedLinearWgrad: parameter %r receives a second gradient in one backward pass" % (key,))
+            raise RuntimeError("DeferredParamGrads: parameter %r receives a second gradient in one backward pass" % (key,))
         self.seen.add(key)
         # (dY, X) stay referenced until flush; of dW / db only the addresses are kept — a second reference would make AccumulateGrad
         # copy the unwritten tensor instead of adopting it
@@ -662,19 +688,30 @@ class GroupedLinearWgrad:
 
     def flush(self):
         from . import lib as L
-        items, self.items, self.seen = self.items, [], set()
-        if not items:
-            return
-        arr = (L.WgradGroupDesc * len(items))()
-        for d, (key, dy, x, pw, pb, M, N, K) in zip(arr, items):
-            d.dy, d.x, d.dw, d.db, d.M, d.N, d.K = dy.data_ptr(), x.data_ptr(), pw, pb, M, N, K
-        L.check(L.load().kpf_linear_wgrad_grouped(arr, len(items), torch.cuda.current_stream().cuda_stream), "kpf_linear_wgrad_grouped")
+        items, colsums, self.items, self.colsums, self.seen = self.items, self.colsums, [], [], set()
+        st = torch.cuda.current_stream().cuda_stream
+        if items:
+            arr = (L.WgradGroupDesc * len(items))()
+            for d, (key, dy, x, pw, pb, M, N, K) in zip(arr, items):
+                d.dy, d.x, d.dw, d.db, d.M, d.N, d.K = dy.data_ptr(), x.data_ptr(), pw, pb, M, N, K
+            L.check(L.load().kpf_linear_wgrad_grouped(arr, len(items), st), "kpf_linear_wgrad_grouped")
+        if colsums:
+            arr = (L.ColsumDesc * len(colsums))(*[c[0] for c in colsums])
+            L.check(L.load().kpf_colsum_reduce_grouped(arr, len(colsums), st), "kpf_colsum_reduce_grouped")
         if self.named is not None:
+            msg = ("DeferredParamGrads: the gradient of %s was copied before it was written (autograd did not adopt the tensor: is the parameter outside "
+                   "the optimiser's zero_grad, hooked, or used twice?)")
             for key, _, _, pw, _, _, _, _ in items:
                 p = self.named.get(key)
                 if p is not None and (p.grad is None or p.grad.data_ptr() != pw):
-                    raise RuntimeError("GroupedLinearWgrad: the gradient of %r was copied before it was written (autograd did not adopt the tensor: "
-                                       "is the parameter outside the optimiser's zero_grad, hooked, or used twice?)" % key)
+                    raise RuntimeError(msg % repr(key))
+            for _, _, wptr, optr in colsums:
+                p = self.by_ptr.get(wptr)
+                if p is not None and (p.grad is None or p.grad.data_ptr() != optr):
+                    raise RuntimeError(msg % ("a %s normalisation parameter" % (tuple(p.shape),)))
+
+
+GroupedLinearWgrad = DeferredParamGrads  # (the name the first form of this class had)
 
 
 def conv_wgrad_hip(dy, x, wshape, stride, pad, want_db=True):
@@ -870,9 +907,17 @@ class LayerNormRows(torch.autograd.Function):
         dwb = torch.empty(2, Cc, device=x.device, dtype=torch.float32)
         nws = lib.kpf_ln_ws_floats(rows, Cc)
         ws = torch.empty(nws, device=x.device, dtype=torch.float32)
-        L.check(lib.kpf_ln_train_backward(dy.data_ptr(), _KDT[dy.dtype], x.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), w.data_ptr(), dx.data_ptr(),
-                                          dwb[0].data_ptr(), dwb[1].data_ptr(), ws.data_ptr(), nws, rows, Cc, torch.cuda.current_stream().cuda_stream),
-                "kpf_ln_train_backward")
+        st = torch.cuda.current_stream().cuda_stream
+        grp = DeferredParamGrads.wants_colsum(w)
+        if grp is not None:  # d gamma / d beta: reduced with every other layer's after backward
+            desc = L.ColsumDesc()
+            L.check(lib.kpf_ln_train_backward_partial(dy.data_ptr(), _KDT[dy.dtype], x.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), w.data_ptr(),
+                                                      dx.data_ptr(), dwb[0].data_ptr(), dwb[1].data_ptr(), ws.data_ptr(), nws, rows, Cc, C.byref(desc), st),
+                    "kpf_ln_train_backward_partial")
+            grp.add_colsum(w, desc, ws, dwb)
+        else:
+            L.check(lib.kpf_ln_train_backward(dy.data_ptr(), _KDT[dy.dtype], x.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), w.data_ptr(), dx.data_ptr(),
+                                              dwb[0].data_ptr(), dwb[1].data_ptr(), ws.data_ptr(), nws, rows, Cc, st), "kpf_ln_train_backward")
         return dx, dwb[0], dwb[1], None, None
 
 
@@ -1156,7 +1201,7 @@ class Conv2dNHWC(torch.autograd.Function):
             # hand-written split-K weight gradient (fp32 products and accumulation in every precision mode: the master weight's
             # gradient is not rounded to 16 bits; 16-bit dY / X are read as stored), bias gradient from the same pass
             want_db = has_bias and ctx.needs_input_grad[2]
-            grp = GroupedLinearWgrad.wants(ctx.pack[0], ctx.pack[1], dy, x, KH, KW, stride, pad)
+            grp = DeferredParamGrads.wants(ctx.pack[0], ctx.pack[1], dy, x, KH, KW, stride, pad)
             if grp is not None:  # small Linear layer: its weight gradient joins the grouped launch after backward
                 dyc, xc = dy.contiguous(), x.contiguous()
                 dw = torch.empty(tuple(weight.shape), device=x.device, dtype=torch.float32)
@@ -1269,7 +1314,7 @@ class GraphedTrainStep:
         self.opt.zero_grad(set_to_none=True)
         for p in self._outside:  # (parameters that get a gradient but are not the optimiser's: their stale .grad would be added to, not replaced)
             p.grad = None
-        with GroupedLinearWgrad(self._named):  # the small Linear layers' weight gradients: one launch after backward
+        with DeferredParamGrads(self._named):  # small Linear layers' weight gradients, LayerNorm / layer-scale parameter sums: grouped launches after backward
             loss = self.loss_fn(self.model, self.static)
             loss.backward()
         return loss.detach()

@@ -622,3 +622,48 @@ def test_grouped_linear_weight_gradients_after_backward():
     with pytest.raises(RuntimeError, match="copied before it was written"):
         with T.GroupedLinearWgrad(named):
             T.linear_hip(x, w, b, "f32", None, "l0", cache).sum().backward()
+
+
+def test_deferred_layernorm_and_layer_scale_parameter_sums_are_bit_identical():
+    """training.DeferredParamGrads, column-sum half (kpf_ln_train_backward_partial / kpf_layer_scale_backward_partial +
+    kpf_colsum_reduce_grouped): d gamma / d beta of many LayerNorm and layer-scale layers reduced in grouped launches after backward —
+    same bits as the per-layer reduce, more layers than one launch carries, both storage types; parameters the model does not own
+    (not in the name map) keep the immediate path."""
+    from keypointfusion_amd import training as T
+    g = torch.Generator().manual_seed(9)
+    lns, lss, named = [], [], {}
+    for i in range(70):
+        rows, c = [(672, 128), (2048, 96), (21, 512), (4096, 384)][i % 4]
+        w, b = torch.nn.Parameter((torch.rand(c, generator=g) + 0.5).cuda()), torch.nn.Parameter(torch.randn(c, generator=g).cuda())
+        lns.append((w, b, torch.randn(rows, c, generator=g).cuda().requires_grad_(True)))
+        if i < 66:
+            named["ln%d.weight" % i], named["ln%d.bias" % i] = w, b
+    for i in range(40):
+        rows, c = [(1024, 96), (256, 768)][i % 2]
+        gm = torch.nn.Parameter((torch.rand(c, generator=g) * 0.1).cuda())
+        dt = torch.bfloat16 if i % 3 == 0 else torch.float32
+        lss.append((gm, torch.randn(rows, c, generator=g).cuda().requires_grad_(True), torch.randn(rows, c, generator=g).cuda().to(dt).requires_grad_(True)))
+        named["ls%d.gamma" % i] = gm
+
+    def run(deferred):
+        for w, b, x in lns:
+            w.grad = b.grad = x.grad = None
+        for gm, x, y in lss:
+            gm.grad = x.grad = y.grad = None
+        ctx = T.DeferredParamGrads(named) if deferred else __import__("contextlib").nullcontext()
+        with ctx as grp:
+            tot = 0
+            for w, b, x in lns:
+                tot = tot + T.layer_norm_rows(x, w, b, 1e-6).square().sum()
+            for gm, x, y in lss:
+                tot = tot + T.layer_scale_residual(x, gm, y).square().sum()
+            tot.backward()
+            n = len(grp.colsums) if deferred else 0
+        torch.cuda.synchronize()
+        return n, [t.grad.clone() for w, b, x in lns for t in (w, b, x)] + [t.grad.clone() for gm, x, y in lss for t in (gm, x, y)]
+
+    n0, ref = run(False)
+    n1, got = run(True)
+    assert n0 == 0 and n1 == 66 + 40  # (the four LayerNorms outside the name map reduce at once)
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert torch.equal(a, b), (i, float((a.float() - b.float()).abs().max()))
