@@ -5,8 +5,8 @@ import csv, glob, re, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 marks = [i for i, r in enumerate(rows) if "pack_weights_multi" in r["Kernel_Name"]]
-k = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-it = rows[marks[-k - 1]:marks[-k]]
+spans = [rows[a:b] for a, b in zip(marks, marks[1:])]
+it = min(spans[-6:], key=len) if len(sys.argv) <= 3 else spans[-int(sys.argv[3])]  # default: the shortest of the last spans = a graph replay
 t0 = int(it[0]["Start_Timestamp"])
 with open(sys.argv[2], "w") as o:
     for r in it:
