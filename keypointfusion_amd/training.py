@@ -689,6 +689,8 @@ class DeferredParamGrads:
     def flush(self):
         from . import lib as L
         items, colsums, self.items, self.colsums, self.seen = self.items, self.colsums, [], [], set()
+        if not items and not colsums:
+            return
         st = torch.cuda.current_stream().cuda_stream
         if items:
             arr = (L.WgradGroupDesc * len(items))()

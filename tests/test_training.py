@@ -71,6 +71,32 @@ def test_optimizer_setup():
     assert sched.step_size == 10 and sched.gamma == 0.1
 
 
+def test_host_side_of_the_fused_optimizer_and_deferred_gradients_without_a_gpu():
+    """FusedAdamW hands anything its kernel does not cover to torch.optim.AdamW (here: CPU parameters — identical steps), and
+    DeferredParamGrads declines every tensor when it is not active or the weight is not a whole parameter of the model."""
+    torch.manual_seed(0)
+    a = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7))]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    ours, ref = T.FusedAdamW(a, lr=8e-4, weight_decay=0.01), torch.optim.AdamW(b, lr=8e-4, weight_decay=0.01)
+    for _ in range(3):
+        for p, q in zip(a, b):
+            g = torch.randn(p.shape)
+            p.grad, q.grad = g.clone(), g.clone()
+        ours.step(), ref.step()
+    assert all(torch.equal(p, q) for p, q in zip(a, b))
+    w = torch.nn.Parameter(torch.ones(8))
+    assert T.DeferredParamGrads.wants_colsum(w) is None  # (not active)
+    x = torch.zeros(4, 8)
+    assert T.DeferredParamGrads.wants("k", object(), x, x, 1, 1, 1, 0) is None
+    with T.DeferredParamGrads({"w": w}) as d:
+        assert T.DeferredParamGrads.wants_colsum(w) is d
+        assert T.DeferredParamGrads.wants_colsum(torch.ones(8)) is None and T.DeferredParamGrads.wants_colsum(w[:4]) is None  # not / not all of a parameter
+        assert T.DeferredParamGrads.wants("k:q", object(), x, x, 1, 1, 1, 0) is None and T.DeferredParamGrads.wants("k", None, x, x, 1, 1, 1, 0) is None
+        assert T.DeferredParamGrads.wants("k", object(), x, x, 3, 3, 1, 1) is None and T.DeferredParamGrads.wants("k", object(), x.half(), x.half(), 1, 1, 1, 0) is None
+        assert T.DeferredParamGrads.wants("k", object(), x, x, 1, 1, 1, 0) is d
+    assert T.DeferredParamGrads.active is None  # (nothing was registered: flush() had nothing to launch)
+
+
 def _ddp_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
