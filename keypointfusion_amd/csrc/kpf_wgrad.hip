@@ -333,7 +333,6 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
 
 constexpr int HB = 128;   // tile edge: one 256-byte LDS row of 16-bit channels
-constexpr int HNS = 3;    // LDS ring stages (RB pixels x (A + B) rows of 256 B = 16 KB each)
 
 __device__ __forceinline__ int h16_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
@@ -357,7 +356,7 @@ __device__ __forceinline__ float sum8(const s16x8 v, f16_t) {
   return s;
 }
 
-template <typename TIN>
+template <typename TIN, int HNS>  // HNS: LDS ring stages (RB pixels x (A + B) rows of 256 B = 16 KB each), HNS - 1 of them in flight
 __global__ __launch_bounds__(256) void wgrad_h16_kernel(const WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char hl[];  // [HNS][A 8 KB | B 8 KB]
   constexpr int STAGE = 2 * RB * 256;
@@ -443,14 +442,17 @@ __global__ __launch_bounds__(256) void wgrad_h16_kernel(const WgradArgs a) {
   float dbs[4] = {0.f, 0.f, 0.f, 0.f};
   const bool want_db = a.dbpart != nullptr && kt == 0 && wk == 0;
 
-  if (ns > 0) stage(0);
-  if (ns > 1) stage(1);
+#pragma unroll
+  for (int i = 0; i < HNS - 1; ++i)
+    if (ns > i) stage(i);
   for (int s = 0; s < ns; ++s) {
-    if (s + 1 < ns) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // stage s has landed; stage s+1 (4 DMAs per wave) may still fly
+    // stage s has landed; the younger stages (4 DMAs per wave each) may still fly
+    if (HNS > 3 && s + 2 < ns) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (s + 1 < ns) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave's part of stage s is in LDS, and every wave is done reading stage s-1
     asm volatile("" ::: "memory");
-    if (s + 2 < ns) stage(s + 2);  // into the buffer of stage s-1
+    if (s + HNS - 1 < ns) stage(s + HNS - 1);  // into the buffer of stage s-1
     const char* cur = hl + (s % HNS) * STAGE;
     s16x8 af[4], bf[4];
 #pragma unroll
@@ -766,8 +768,15 @@ static int conv2d_wgrad_impl(const void* dy, const void* x, int dtype, float* dw
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (h16) {
-    if (dtype == KPF_DT_BF16) hipLaunchKernelGGL((wgrad_h16_kernel<bf16_t>), dim3(p.tilesN * p.tilesK, p.S), dim3(256), HNS * 2 * RB * 256, st, a);
-    else hipLaunchKernelGGL((wgrad_h16_kernel<f16_t>), dim3(p.tilesN * p.tilesK, p.S), dim3(256), HNS * 2 * RB * 256, st, a);
+    static const int ring = []() { const char* e = getenv("KPF_WG16_RING"); return e ? atoi(e) : 3; }();  // tuning aid: 3 or 4 stages
+    const dim3 grid(p.tilesN * p.tilesK, p.S);
+    if (ring == 4) {
+      if (dtype == KPF_DT_BF16) hipLaunchKernelGGL((wgrad_h16_kernel<bf16_t, 4>), grid, dim3(256), 4 * 2 * RB * 256, st, a);
+      else hipLaunchKernelGGL((wgrad_h16_kernel<f16_t, 4>), grid, dim3(256), 4 * 2 * RB * 256, st, a);
+    } else {
+      if (dtype == KPF_DT_BF16) hipLaunchKernelGGL((wgrad_h16_kernel<bf16_t, 3>), grid, dim3(256), 3 * 2 * RB * 256, st, a);
+      else hipLaunchKernelGGL((wgrad_h16_kernel<f16_t, 3>), grid, dim3(256), 3 * 2 * RB * 256, st, a);
+    }
     rc = kpf_check_launch("kpf_conv2d_wgrad_h16");
   } else {
     rc = dtype == KPF_DT_F32 ? launch_wgrad_any<float>(a, p, st)
