@@ -1,6 +1,7 @@
 """Training-step slice: loss codec, SmoothL1Loss, the loss schedule of train.py:211-261 and its first-step gradients
 against fixtures generated from the imported reference (tests/golden/gen_golden_train.py); the bucketed gradient all-reduce over gloo
 (world size 2) driven by the product's own hooks; the HIP convolution autograd Function against torch autograd (GPU)."""
+import math
 import os
 import sys
 
@@ -359,6 +360,48 @@ def _train_fixture(net, B, dev, seed=5):
         return T.kpfusion_loss(results, sws, bt["img"], bt["uvd_gt"], bt["xyz_gt"], epoch=0)[0]
 
     return sd, batch, loss_fn
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_graphed_training_with_the_fused_optimizer_fits_a_fixed_batch(prec):
+    """The captured iteration as bench.py runs it (FusedLoss, FusedAdamW, grouped / deferred parameter gradients, two streams) driven for 30
+    replays on one batch: the loss must fall steadily and stay finite — a parameter whose deferred gradient were never written, or an
+    optimiser state that did not advance, shows up here — and eager iterations (per-layer kernels, no deferral) with the same optimiser
+    class from the same start must produce the SAME losses bit for bit: every kernel adds in a fixed order and the grouped forms
+    reproduce the per-layer summation order."""
+    from keypointfusion_amd.parallel import live_parameters
+    dev = torch.device("cuda:0")
+    net = "KPFusion-convnext-tiny"
+    sd, batch, loss_fn = _train_fixture(net, 4, dev)
+    traj = {}
+    for mode in ("graphed", "eager"):
+        torch.manual_seed(0)
+        m = _fresh(net, sd).to(dev).train()
+        m.train_dropout = 0.0
+        m.precision = prec
+        live = live_parameters(m)
+        if mode == "graphed":
+            opt, _ = T.make_optimizer(live, lr=2e-4, capturable=True)
+            assert isinstance(opt, T.FusedAdamW)
+            step = T.GraphedTrainStep(m, opt, loss_fn, batch, warmup=2, params=live)  # (the warm-up iterations already step the optimiser)
+            traj[mode] = [float(step(batch)) for _ in range(30)]
+        else:
+            opt, _ = T.make_optimizer(live, lr=2e-4, capturable=True)
+            out = []
+            for _ in range(6):
+                opt.zero_grad(set_to_none=True)
+                loss = loss_fn(m, batch)
+                loss.backward()
+                opt.step()
+                out.append(float(loss))
+            traj[mode] = out
+        del m, opt
+    g, e = traj["graphed"], traj["eager"]
+    assert all(math.isfinite(v) for v in g), g
+    assert g[-1] < 0.6 * g[0] and sum(b < a for a, b in zip(g, g[1:])) >= 24, g
+    # graphed replay k is optimiser step k + 2 (two warm-up steps): the overlapping part of the two trajectories
+    assert g[:4] == e[2:6], (g[:6], e)
 
 
 @pytest.mark.gpu
