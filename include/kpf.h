@@ -467,12 +467,20 @@ int kpf_layer_scale_backward_partial(const float* g, const void* y, int y_dtype,
                                      long rows, int C, kpf_colsum_desc* desc, void* stream);
 int kpf_colsum_reduce_grouped(const kpf_colsum_desc* descs, int n, void* stream);
 
+/* Training: the two analytic maps of a fusion block (model/model.py:300-336) with their gradients towards the joints, one launch each:
+ * hm[b][j][y][x] = GFM.joint2heatmap(uvd[..., :2], std, F, sigma) (util/generateFeature.py:584-600), duvd [B][J][3] (z component 0);
+ * gam[b][j][p] = 1 / (10 |pix_xyz[b][p] - joint_xyz[b][j]|^2 + 1) (dataloader/loader.py:791-819), djoint [B][J][3].  fp32, contiguous. */
+int kpf_joint_heatmap_forward(const float* uvd, float* hm, int B, int J, int F, float std_, float sigma, void* stream);
+int kpf_joint_heatmap_backward(const float* uvd, const float* dhm, float* duvd, int B, int J, int F, float std_, float sigma, void* stream);
+int kpf_geom_gate_forward(const float* pix_xyz, const float* joint_xyz, float* gam, int B, int J, int P, void* stream);
+int kpf_geom_gate_backward(const float* pix_xyz, const float* joint_xyz, const float* dgam, float* djoint, int B, int J, int P, void* stream);
+
 int kpf_conv_num_tile_cfgs(void);
 
 const char* kpf_last_error(void);
 /* Library/ABI version, bumped when a signature or the meaning of an argument changes (KPF_ABI_VERSION is what this header
  * describes; the Python binding refuses a library that reports another). */
-#define KPF_ABI_VERSION 9
+#define KPF_ABI_VERSION 10
 int kpf_abi_version(void);
 
 #ifdef __cplusplus

@@ -1549,3 +1549,103 @@ extern "C" int kpf_adamw_step_multi(const kpf_adamw_desc* descs, int n, const fl
   }
   return KPF_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The two analytic maps a fusion block derives from its first joint estimate (model/model.py:300-336 in train mode): the Gaussian heat map
+// of the joints' (u, v) (GFM.joint2heatmap, util/generateFeature.py:584-600) and the geometry adjacency 1 / (10 |pixel_xyz - joint_xyz|^2 + 1)
+// (dataloader/loader.py:791-819), each with its gradient towards the joints — one kernel each way, one workgroup per (joint, sample),
+// instead of ~20 element-wise launches each way over B x 21 x 1024 (x 3) intermediates.  The pixel sums of the backward are block
+// reductions in a fixed order.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+// MODE 0: hm[b][j][p];  MODE 1: duv[b][j][0..2] = (d/du, d/dv, 0) of sum_p dhm * hm
+template <int MODE>
+__global__ __launch_bounds__(256) void joint_heatmap_kernel(const float* __restrict__ uvd, const float* __restrict__ dhm, float* __restrict__ out, int J, int F,
+                                                            float std_, float sigma) {
+  __shared__ float red[4];
+  const int j = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int P = F * F;
+  const long bj = (long)b * J + j;
+  const float jx = hm_center(uvd[bj * 3 + 0], F), jy = hm_center(uvd[bj * 3 + 1], F);
+  const float inv2s = 1.f / (2.f * sigma * sigma);
+  float gu = 0.f, gv = 0.f;
+  for (int p = tid; p < P; p += 256) {
+    const int py = p / F, px = p - py * F;
+    const float tx = ((float)px + 0.5f - jx) / std_, ty = ((float)py + 0.5f - jy) / std_;
+    const float h = expf(-(tx * tx + ty * ty) * inv2s);
+    if (MODE == 0) {
+      out[bj * P + p] = h;
+    } else {
+      const float g = dhm[bj * P + p] * h;
+      gu += g * tx;
+      gv += g * ty;
+    }
+  }
+  if (MODE == 1) {
+    // d h / d u = h * (2 tx inv2s) * (1 / std) * (F / 2)      (jx = (u + 1) / 2 * F enters tx with a minus sign, the exponent with another)
+    const float k = 2.f * inv2s / std_ * 0.5f * (float)F;
+    gu = block_sum256(gu, red) * k;
+    gv = block_sum256(gv, red) * k;
+    if (tid == 0) {
+      out[bj * 3 + 0] = gu;
+      out[bj * 3 + 1] = gv;
+      out[bj * 3 + 2] = 0.f;
+    }
+  }
+}
+
+// MODE 0: gam[b][j][p] = 1 / (10 |ix[b][p] - jx[b][j]|^2 + 1);  MODE 1: djx[b][j][c] = sum_p dgam * (-20 gam^2 (jx_c - ix_c))
+template <int MODE>
+__global__ __launch_bounds__(256) void geom_gate_kernel(const float* __restrict__ ix, const float* __restrict__ jx, const float* __restrict__ dgam,
+                                                        float* __restrict__ out, int J, int P) {
+  __shared__ float red[4];
+  const int j = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const long bj = (long)b * J + j;
+  const float x0 = jx[bj * 3 + 0], x1 = jx[bj * 3 + 1], x2 = jx[bj * 3 + 2];
+  const float* ib = ix + (long)b * P * 3;
+  float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+  for (int p = tid; p < P; p += 256) {
+    const float d0 = ib[p * 3 + 0] - x0, d1 = ib[p * 3 + 1] - x1, d2 = ib[p * 3 + 2] - x2;
+    const float gam = 1.f / (10.f * ((d0 * d0 + d1 * d1) + d2 * d2) + 1.f);
+    if (MODE == 0) {
+      out[bj * P + p] = gam;
+    } else {
+      const float k = dgam[bj * P + p] * 20.f * gam * gam;  // d gam / d jx_c = -gam^2 * 10 * 2 (jx_c - ix_c) = 20 gam^2 (ix_c - jx_c)
+      g0 += k * d0;
+      g1 += k * d1;
+      g2 += k * d2;
+    }
+  }
+  if (MODE == 1) {
+    g0 = block_sum256(g0, red);
+    g1 = block_sum256(g1, red);
+    g2 = block_sum256(g2, red);
+    if (tid == 0) {
+      out[bj * 3 + 0] = g0;
+      out[bj * 3 + 1] = g1;
+      out[bj * 3 + 2] = g2;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int kpf_joint_heatmap_forward(const float* uvd, float* hm, int B, int J, int F, float std_, float sigma, void* stream) {
+  KPF_REQUIRE(uvd && hm && B > 0 && J > 0 && F > 0 && std_ > 0.f && sigma > 0.f, "kpf_joint_heatmap_forward: bad arguments");
+  hipLaunchKernelGGL(joint_heatmap_kernel<0>, dim3(J, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), uvd, (const float*)nullptr, hm, J, F, std_, sigma);
+  return kpf_check_launch("kpf_joint_heatmap_forward");
+}
+extern "C" int kpf_joint_heatmap_backward(const float* uvd, const float* dhm, float* duvd, int B, int J, int F, float std_, float sigma, void* stream) {
+  KPF_REQUIRE(uvd && dhm && duvd && B > 0 && J > 0 && F > 0 && std_ > 0.f && sigma > 0.f, "kpf_joint_heatmap_backward: bad arguments");
+  hipLaunchKernelGGL(joint_heatmap_kernel<1>, dim3(J, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), uvd, dhm, duvd, J, F, std_, sigma);
+  return kpf_check_launch("kpf_joint_heatmap_backward");
+}
+extern "C" int kpf_geom_gate_forward(const float* pix_xyz, const float* joint_xyz, float* gam, int B, int J, int P, void* stream) {
+  KPF_REQUIRE(pix_xyz && joint_xyz && gam && B > 0 && J > 0 && P > 0, "kpf_geom_gate_forward: bad arguments");
+  hipLaunchKernelGGL(geom_gate_kernel<0>, dim3(J, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pix_xyz, joint_xyz, (const float*)nullptr, gam, J, P);
+  return kpf_check_launch("kpf_geom_gate_forward");
+}
+extern "C" int kpf_geom_gate_backward(const float* pix_xyz, const float* joint_xyz, const float* dgam, float* djoint, int B, int J, int P, void* stream) {
+  KPF_REQUIRE(pix_xyz && joint_xyz && dgam && djoint && B > 0 && J > 0 && P > 0, "kpf_geom_gate_backward: bad arguments");
+  hipLaunchKernelGGL(geom_gate_kernel<1>, dim3(J, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pix_xyz, joint_xyz, dgam, djoint, J, P);
+  return kpf_check_launch("kpf_geom_gate_backward");
+}

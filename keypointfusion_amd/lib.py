@@ -20,7 +20,7 @@ KPF_IN_SPLIT = 128
 KPF_OUT_SPLIT = 256
 KPF_W_SPLIT = 512
 KPF_DT_F32, KPF_DT_BF16, KPF_DT_F16 = 0, 1, 2
-ABI_VERSION = 9  # KPF_ABI_VERSION of include/kpf.h: load() refuses a library built from another revision of the interface
+ABI_VERSION = 10  # KPF_ABI_VERSION of include/kpf.h: load() refuses a library built from another revision of the interface
 
 
 class ConvDesc(C.Structure):
@@ -101,6 +101,10 @@ _SIGS = {
     "kpf_row_gather_fwd_f32": [_P] * 4 + [C.c_int] * 5 + [_P],
     "kpf_pack_conv_weight": [_P, C.c_int, _P, C.c_int] + [C.c_int] * 7 + [_P],
     "kpf_pack_conv_weights_multi": [_P, C.c_int, C.c_int, _P],
+    "kpf_joint_heatmap_forward": [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P],
+    "kpf_joint_heatmap_backward": [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P],
+    "kpf_geom_gate_forward": [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_geom_gate_backward": [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P],
     "kpf_linear_wgrad_grouped": [C.POINTER(WgradGroupDesc), C.c_int, _P],
     "kpf_adamw_step_multi": [C.POINTER(AdamwDesc), C.c_int, _P, C.c_float, _P, C.c_double, C.c_double, C.c_float, C.c_float, _P],
     "kpf_ln_train_forward": [_P, _P, _P, _P, C.c_int, _P, _P, C.c_long, C.c_int, C.c_float, _P],

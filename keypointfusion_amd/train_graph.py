@@ -439,7 +439,7 @@ class TrainGraph:
 
     def block(self, p, img_feat, img_feat_rgb, pcl, joint_xyz, clos, idx, img_offset, prev_feat, img_down, center, Minv, cube, cam,
               img_size, flip):
-        from .training import joint2heatmap
+        from .training import GeomGate, JointHeatmap, joint2heatmap
         B, C, H, W = img_feat.shape
         pcl_off = self.pcl_joint2offset(joint_xyz, pcl, 0.8).detach()
         pf = self.gather_interp(img_feat, idx, clos)
@@ -454,11 +454,14 @@ class TrainGraph:
         jf = self.desa(p + ".FA", x, jf, pcl, joint_xyz.detach())
         h_init, r3d = self.kp_interaction_tr(p + ".init_TR", jf)
         r3d = r3d.float()  # geometry, heat map and the returned joints are fp32 in every precision
-        hm = joint2heatmap(r3d[:, :, :2], 0.8, H, sigma=1)
+        hm = JointHeatmap.apply(r3d, 0.8, H, 1.0) if r3d.is_cuda else joint2heatmap(r3d[:, :, :2], 0.8, H, sigma=1)
         # geometry adjacency map (dataloader/loader.py:791-819): the joints go through the uvd -> xyz map again, like the pixels
         ix = self.img_xyz  # pixel positions of the depth map (dataloader/loader.py:936-955): written by kpf_img2pcl_top4_f32, once per forward
         jx = self.uvd2xyz(r3d, center, Minv, cube, cam, img_size, flip)
-        gam = (1 / (10 * torch.sum(torch.pow(ix.unsqueeze(1) - jx.unsqueeze(2), 2), dim=-1) + 1)).view(B, J, H, W)
+        if ix.is_cuda:
+            gam = GeomGate.apply(ix, jx).view(B, J, H, W)
+        else:
+            gam = (1 / (10 * torch.sum(torch.pow(ix.unsqueeze(1) - jx.unsqueeze(2), 2), dim=-1) + 1)).view(B, J, H, W)
         # Conv2d(128 + 21 -> 21, k = 1) (model/model.py:262,336): rows of 149 channels, input and output channel counts zero-padded to
         # whole quads so that forward, data- and weight-gradient all run on the HIP kernels (fixed summation order)
         sw_in = torch.cat([img_feat_rgb.permute(0, 2, 3, 1).float(), hm.permute(0, 2, 3, 1)], -1).reshape(B * H * W, C + J)

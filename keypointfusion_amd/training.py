@@ -99,6 +99,63 @@ def joint2heatmap(joint_uv, std, heatmap_size, sigma=1.5):
     return torch.exp(-(torch.pow((xs - jx) / std, 2) + torch.pow((ys - jy) / std, 2)) / (2 * pow(sigma, 2)))
 
 
+class JointHeatmap(torch.autograd.Function):
+    """GFM.joint2heatmap(uvd[..., :2], std, F, sigma) (util/generateFeature.py:584-600) with its gradient towards the joints:
+    kpf_joint_heatmap_forward / _backward, one launch each (torch: ~16 element-wise launches forward, ~20 backward).  uvd [B, J, 3]."""
+
+    @staticmethod
+    def forward(ctx, uvd, std, size, sigma):
+        from . import lib as L
+        u = uvd.detach().float().contiguous()
+        B, J, _ = u.shape
+        hm = torch.empty(B, J, size, size, device=u.device, dtype=torch.float32)
+        L.check(L.load().kpf_joint_heatmap_forward(u.data_ptr(), hm.data_ptr(), B, J, size, float(std), float(sigma), torch.cuda.current_stream().cuda_stream),
+                "kpf_joint_heatmap_forward")
+        ctx.save_for_backward(u)
+        ctx.cfg = (size, float(std), float(sigma), uvd.dtype)
+        return hm
+
+    @staticmethod
+    def backward(ctx, dhm):
+        from . import lib as L
+        (u,) = ctx.saved_tensors
+        size, std, sigma, dt = ctx.cfg
+        B, J, _ = u.shape
+        d = torch.empty_like(u)
+        L.check(L.load().kpf_joint_heatmap_backward(u.data_ptr(), dhm.float().contiguous().data_ptr(), d.data_ptr(), B, J, size, std, sigma,
+                                                    torch.cuda.current_stream().cuda_stream), "kpf_joint_heatmap_backward")
+        return d.to(dt), None, None, None
+
+
+class GeomGate(torch.autograd.Function):
+    """The geometry adjacency map of a fusion block, gam[b, j, p] = 1 / (10 |pix_xyz[b, p] - joint_xyz[b, j]|^2 + 1)
+    (dataloader/loader.py:791-819; model/model.py:318-326), with its gradient towards the joints: kpf_geom_gate_forward / _backward
+    (torch: 6 launches forward and ~10 backward over [B, J, P, 3] intermediates).  pix_xyz [B, P, 3] (data), joint_xyz [B, J, 3]."""
+
+    @staticmethod
+    def forward(ctx, pix_xyz, joint_xyz):
+        from . import lib as L
+        ix, jx = pix_xyz.detach().float().contiguous(), joint_xyz.detach().float().contiguous()
+        B, P, _ = ix.shape
+        J = jx.shape[1]
+        gam = torch.empty(B, J, P, device=ix.device, dtype=torch.float32)
+        L.check(L.load().kpf_geom_gate_forward(ix.data_ptr(), jx.data_ptr(), gam.data_ptr(), B, J, P, torch.cuda.current_stream().cuda_stream), "kpf_geom_gate_forward")
+        ctx.save_for_backward(ix, jx)
+        ctx.dt = joint_xyz.dtype
+        return gam
+
+    @staticmethod
+    def backward(ctx, dgam):
+        from . import lib as L
+        ix, jx = ctx.saved_tensors
+        B, P, _ = ix.shape
+        J = jx.shape[1]
+        d = torch.empty_like(jx)
+        L.check(L.load().kpf_geom_gate_backward(ix.data_ptr(), jx.data_ptr(), dgam.float().contiguous().data_ptr(), d.data_ptr(), B, J, P,
+                                                torch.cuda.current_stream().cuda_stream), "kpf_geom_gate_backward")
+        return None, d.to(ctx.dt)
+
+
 class _SmoothL1(torch.autograd.Function):
     """model/loss.py:3-26 as one autograd node: the forward is the reference's own operation sequence (bit-identical values), the
     backward is the closed form dL/dz = scale * (z if |z| < 0.01 else 0.01 sign(z)) in four launches instead of the ~15 that autograd

@@ -667,3 +667,32 @@ def test_deferred_layernorm_and_layer_scale_parameter_sums_are_bit_identical():
     assert n0 == 0 and n1 == 66 + 40  # (the four LayerNorms outside the name map reduce at once)
     for i, (a, b) in enumerate(zip(ref, got)):
         assert torch.equal(a, b), (i, float((a.float() - b.float()).abs().max()))
+
+
+def test_joint_heatmap_and_geometry_gate_match_torch():
+    """training.JointHeatmap / training.GeomGate (one launch each way) against the torch expressions they replace in the fusion block
+    (GFM.joint2heatmap; 1 / (10 |pixel - joint|^2 + 1)) in float64: values and the gradients towards the joints, joints on / off the map."""
+    from keypointfusion_amd import training as T
+    g = torch.Generator().manual_seed(4)
+    B, J, F_ = 3, 21, 32
+    uvd = torch.rand(B, J, 3, generator=g) * 2.4 - 1.2
+    w = torch.randn(B, J, F_, F_, generator=g)
+    ur = uvd.clone().double().requires_grad_(True)
+    hr = T.joint2heatmap(ur[:, :, :2], 0.8, F_, sigma=1)
+    (hr * w.double()).sum().backward()
+    ud = uvd.cuda().requires_grad_(True)
+    hd = T.JointHeatmap.apply(ud, 0.8, F_, 1.0)
+    (hd * w.cuda()).sum().backward()
+    assert float((hd.detach().cpu().double() - hr.detach()).abs().max()) <= 2e-6
+    assert float((ud.grad.cpu().double() - ur.grad).abs().max()) <= 2e-5 * float(ur.grad.abs().max()) and float(ud.grad[..., 2].abs().max()) == 0.0
+    ix = torch.randn(B, F_ * F_, 3, generator=g) * 0.5
+    jx = torch.randn(B, J, 3, generator=g) * 0.5
+    wg = torch.randn(B, J, F_ * F_, generator=g)
+    jr = jx.clone().double().requires_grad_(True)
+    gr = 1 / (10 * torch.sum(torch.pow(ix.double().unsqueeze(1) - jr.unsqueeze(2), 2), dim=-1) + 1)
+    (gr * wg.double()).sum().backward()
+    jd = jx.cuda().requires_grad_(True)
+    gd = T.GeomGate.apply(ix.cuda(), jd)
+    (gd * wg.cuda()).sum().backward()
+    assert float((gd.detach().cpu().double() - gr.detach()).abs().max()) <= 2e-6
+    assert float((jd.grad.cpu().double() - jr.grad).abs().max()) <= 2e-5 * float(jr.grad.abs().max())
