@@ -284,6 +284,8 @@ int kpf_conv2d_wgrad_h16(const void* dy, const void* x, int dtype, float* dw, fl
 /* Depthwise 7x7 (pad 3) + bias alone, y = dwconv(x): the ConvNeXt block's first op with its output kept for the LayerNorm backward,
  * and its data gradient (dx = the same convolution of dy with w_dw's taps mirrored, zero bias).  w_dw [49][C], x != y. */
 int kpf_dwconv7_f32(const float* x, const float* w_dw, const float* b_dw, float* y, int B, int H, int W, int C, void* stream);
+/* the same + addend (y's shape) on the output: the data gradient of a ConvNeXt block with the skip path's gradient folded in */
+int kpf_dwconv7_add_f32(const float* x, const float* w_dw, const float* b_dw, const float* addend, float* y, int B, int H, int W, int C, void* stream);
 /* The same for the ConvNeXt block's depthwise 7x7 (pad 3): dw [C][7][7] (= PyTorch's [C][1][7][7]), db [C] or NULL; dy, x dense NHWC
  * [B][H][W][C], C % 4 == 0; ws >= kpf_dwconv7_wgrad_ws_floats(B, H, C) floats. */
 long kpf_dwconv7_wgrad_ws_floats(int B, int H, int C);
@@ -307,6 +309,10 @@ int kpf_bn_train_forward(const void* x, int x_dtype, const float* w, const float
                          void* stream);
 int kpf_bn_train_backward(const void* dy, const void* x, const void* y, int x_dtype, int y_dtype, const float* mean, const float* invstd,
                           const float* w, void* dx, float* dw, float* db, int relu, float* ws, long ws_floats, long M, int C, void* stream);
+/* the same with dx += addend (x's type and shape; nullable): a second gradient of x — the skip path of a Residual block — folded in */
+int kpf_bn_train_backward_add(const void* dy, const void* x, const void* y, int x_dtype, int y_dtype, const float* mean, const float* invstd,
+                              const float* w, const void* addend, void* dx, float* dw, float* db, int relu, float* ws, long ws_floats, long M, int C,
+                              void* stream);
 int kpf_bn_train_forward_f32(const float* x, const float* w, const float* b, float* y, float* mean, float* invstd, float* running_mean,
                              float* running_var, float momentum, float eps, int relu, float* ws, long ws_floats, long M, int C,
                              void* stream);
@@ -480,7 +486,7 @@ int kpf_conv_num_tile_cfgs(void);
 const char* kpf_last_error(void);
 /* Library/ABI version, bumped when a signature or the meaning of an argument changes (KPF_ABI_VERSION is what this header
  * describes; the Python binding refuses a library that reports another). */
-#define KPF_ABI_VERSION 10
+#define KPF_ABI_VERSION 11
 int kpf_abi_version(void);
 
 #ifdef __cplusplus

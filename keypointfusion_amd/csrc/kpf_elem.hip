@@ -118,7 +118,8 @@ __device__ __forceinline__ unsigned xcd_contiguous_block_id() {
 template <typename TA, bool WLDS, int PX>
 __global__ __launch_bounds__(256) void dwconv7_kernel(const TA* __restrict__ x, const float* __restrict__ wdw,
                                                       const float* __restrict__ bdw, TA* __restrict__ y, int B, int H, int W, int C,
-                                                      int xstrips, int ypairs) {
+                                                      int xstrips, int ypairs, const TA* __restrict__ addend = nullptr) {
+  // addend (nullable, y's shape): added to the output — the data gradient of a ConvNeXt block picks up the skip path's gradient here
   extern __shared__ __attribute__((aligned(16))) float wl[];  // [49][C] when WLDS
   const int C4 = C >> 2;
   if (WLDS) {
@@ -180,11 +181,13 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const TA* __restrict__ x, 
     }
   }
   TA* yb = y + (long)b * H * W * C + 4 * q;
+  const TA* ab = addend ? addend + (long)b * H * W * C + 4 * q : nullptr;
 #pragma unroll
   for (int t = 0; t < PX; ++t) {
     if (x0 + t < W) {
-      kpf_st4(yb + ((long)y0 * W + x0 + t) * C, acc0[t]);
-      if (y0 + 1 < H) kpf_st4(yb + ((long)(y0 + 1) * W + x0 + t) * C, acc1[t]);
+      const long o0 = ((long)y0 * W + x0 + t) * C, o1 = ((long)(y0 + 1) * W + x0 + t) * C;
+      kpf_st4(yb + o0, ab ? acc0[t] + kpf_ld4(ab + o0) : acc0[t]);
+      if (y0 + 1 < H) kpf_st4(yb + o1, ab ? acc1[t] + kpf_ld4(ab + o1) : acc1[t]);
     }
   }
 }
@@ -856,18 +859,28 @@ static int dwconv7_ln_impl(const TA* x, const float* w_dw, const float* b_dw, co
 
 // depthwise 7x7 + bias alone (training: forward of the ConvNeXt block's dwconv with the pre-norm activation kept for backward, and
 // its data gradient = the same convolution of dY with the taps mirrored)
-extern "C" int kpf_dwconv7_f32(const float* x, const float* w_dw, const float* b_dw, float* y, int B, int H, int W, int C, void* stream) {
+static int dwconv7_impl(const float* x, const float* w_dw, const float* b_dw, const float* addend, float* y, int B, int H, int W, int C, void* stream) {
   KPF_REQUIRE(x && w_dw && b_dw && y && x != y, "kpf_dwconv7_f32: null pointer or in-place call");
   KPF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "kpf_dwconv7_f32: bad shape (C %% 4 == 0)");
-  KPF_REQUIRE(kpf_aligned16(x) && kpf_aligned16(y) && kpf_aligned16(w_dw) && kpf_aligned16(b_dw), "kpf_dwconv7_f32: pointers must be 16-byte aligned");
+  KPF_REQUIRE(kpf_aligned16(x) && kpf_aligned16(y) && kpf_aligned16(w_dw) && kpf_aligned16(b_dw) && kpf_aligned16(addend),
+              "kpf_dwconv7_f32: pointers must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const int xstrips = (W + 7) / 8, ypairs = (H + 1) / 2;
   const long total = (long)B * ypairs * xstrips * (C / 4);
   const size_t wbytes = (size_t)49 * C * sizeof(float);
   const dim3 grid((unsigned)((total + 255) / 256));
-  if (wbytes <= 48 * 1024) hipLaunchKernelGGL((dwconv7_kernel<float, true, 8>), grid, dim3(256), wbytes, st, x, w_dw, b_dw, y, B, H, W, C, xstrips, ypairs);
-  else hipLaunchKernelGGL((dwconv7_kernel<float, false, 8>), grid, dim3(256), 0, st, x, w_dw, b_dw, y, B, H, W, C, xstrips, ypairs);
+  if (wbytes <= 48 * 1024) hipLaunchKernelGGL((dwconv7_kernel<float, true, 8>), grid, dim3(256), wbytes, st, x, w_dw, b_dw, y, B, H, W, C, xstrips, ypairs, addend);
+  else hipLaunchKernelGGL((dwconv7_kernel<float, false, 8>), grid, dim3(256), 0, st, x, w_dw, b_dw, y, B, H, W, C, xstrips, ypairs, addend);
   return kpf_check_launch("kpf_dwconv7_f32");
+}
+
+extern "C" int kpf_dwconv7_f32(const float* x, const float* w_dw, const float* b_dw, float* y, int B, int H, int W, int C, void* stream) {
+  return dwconv7_impl(x, w_dw, b_dw, nullptr, y, B, H, W, C, stream);
+}
+
+extern "C" int kpf_dwconv7_add_f32(const float* x, const float* w_dw, const float* b_dw, const float* addend, float* y, int B, int H, int W, int C, void* stream) {
+  KPF_REQUIRE(addend && addend != y, "kpf_dwconv7_add_f32: addend missing or aliasing the output");
+  return dwconv7_impl(x, w_dw, b_dw, addend, y, B, H, W, C, stream);
 }
 
 extern "C" int kpf_dwconv7_ln_f32(const float* x, const float* w_dw, const float* b_dw, const float* ln_w, const float* ln_b,

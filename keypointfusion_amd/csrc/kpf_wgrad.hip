@@ -994,7 +994,8 @@ __global__ __launch_bounds__(256) void bn_elem_kernel(const TX* __restrict__ x, 
                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
                                                       const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ coef,
                                                       typename std::conditional<MODE == 0, TY, TX>::type* __restrict__ out, long M, int C,
-                                                      int rows_per_block) {
+                                                      int rows_per_block, const TX* __restrict__ addend = nullptr) {
+  // addend (MODE 1, nullable): a second gradient of x — the skip path of a Residual block — added here instead of by a separate launch
   const BnGeom g = bn_geom(C);
   const int ql = threadIdx.x % g.QL, rl = threadIdx.x / g.QL;
   const int q = blockIdx.y * 64 + ql;
@@ -1023,6 +1024,7 @@ __global__ __launch_bounds__(256) void bn_elem_kernel(const TX* __restrict__ x, 
         for (int e = 0; e < 4; ++e) d[e] = yv[e] > 0.f ? d[e] : 0.f;
       }
       o = a * (d - t0 - xv * t1);
+      if (addend) o += kpf_ld4(addend + r * C + 4 * q);
     }
     kpf_st4(out + r * C + 4 * q, o);
   }
@@ -1077,7 +1079,8 @@ static int bn_forward_impl(const void* xv, const float* w, const float* b, void*
 
 template <typename TX, typename TY>
 static int bn_backward_impl(const void* dyv, const void* xv, const void* yv, const float* mean, const float* invstd, const float* w, void* dxv,
-                            float* dw, float* db, int relu, float* ws, long ws_floats, long M, int C, void* stream) {
+                            float* dw, float* db, int relu, float* ws, long ws_floats, long M, int C, void* stream, const void* addv) {
+  const TX* addend = static_cast<const TX*>(addv);
   const TY* dy = static_cast<const TY*>(dyv);
   const TY* y = static_cast<const TY*>(yv);
   const TX* x = static_cast<const TX*>(xv);
@@ -1093,10 +1096,10 @@ static int bn_backward_impl(const void* dyv, const void* xv, const void* yv, con
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64 * BN_FW), 0, st, ws, S, M, C, invstd, dw, db, coef);
   if (relu)
     hipLaunchKernelGGL((bn_elem_kernel<1, true, TX, TY>), dim3(S, cg), dim3(256), 0, st, x, dy, y, mean, invstd, w, (const float*)nullptr, coef, dx, M,
-                       C, rpc);
+                       C, rpc, addend);
   else
     hipLaunchKernelGGL((bn_elem_kernel<1, false, TX, TY>), dim3(S, cg), dim3(256), 0, st, x, dy, (const TY*)nullptr, mean, invstd, w,
-                       (const float*)nullptr, coef, dx, M, C, rpc);
+                       (const float*)nullptr, coef, dx, M, C, rpc, addend);
   return kpf_check_launch("kpf_bn_train_backward");
 }
 
@@ -1130,13 +1133,25 @@ int kpf_bn_train_forward(const void* x, int x_dtype, const float* w, const float
                   stream);
 }
 
-int kpf_bn_train_backward(const void* dy, const void* x, const void* y, int x_dtype, int y_dtype, const float* mean, const float* invstd,
-                          const float* w, void* dx, float* dw, float* db, int relu, float* ws, long ws_floats, long M, int C, void* stream) {
+static int bn_train_backward_any(const void* dy, const void* x, const void* y, int x_dtype, int y_dtype, const float* mean, const float* invstd,
+                                 const float* w, void* dx, float* dw, float* db, int relu, float* ws, long ws_floats, long M, int C, void* stream,
+                                 const void* addend) {
   KPF_REQUIRE(dy && x && mean && invstd && w && dx && ws && (!relu || y), "kpf_bn_train_backward: null pointer");
   KPF_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "kpf_bn_train_backward: bad shape (C %% 4 == 0)");
-  KPF_REQUIRE(kpf_aligned16(dy) && kpf_aligned16(x) && kpf_aligned16(dx) && kpf_aligned16(ws) && (!relu || kpf_aligned16(y)),
+  KPF_REQUIRE(kpf_aligned16(dy) && kpf_aligned16(x) && kpf_aligned16(dx) && kpf_aligned16(ws) && (!relu || kpf_aligned16(y)) && kpf_aligned16(addend),
               "kpf_bn_train_backward: pointers must be 16-byte aligned");
-  KPF_BN_DISPATCH(bn_backward_impl, x_dtype, y_dtype, dy, x, y, mean, invstd, w, dx, dw, db, relu, ws, ws_floats, M, C, stream);
+  KPF_BN_DISPATCH(bn_backward_impl, x_dtype, y_dtype, dy, x, y, mean, invstd, w, dx, dw, db, relu, ws, ws_floats, M, C, stream, addend);
+}
+
+int kpf_bn_train_backward(const void* dy, const void* x, const void* y, int x_dtype, int y_dtype, const float* mean, const float* invstd,
+                          const float* w, void* dx, float* dw, float* db, int relu, float* ws, long ws_floats, long M, int C, void* stream) {
+  return bn_train_backward_any(dy, x, y, x_dtype, y_dtype, mean, invstd, w, dx, dw, db, relu, ws, ws_floats, M, C, stream, nullptr);
+}
+
+int kpf_bn_train_backward_add(const void* dy, const void* x, const void* y, int x_dtype, int y_dtype, const float* mean, const float* invstd,
+                              const float* w, const void* addend, void* dx, float* dw, float* db, int relu, float* ws, long ws_floats, long M, int C,
+                              void* stream) {
+  return bn_train_backward_any(dy, x, y, x_dtype, y_dtype, mean, invstd, w, dx, dw, db, relu, ws, ws_floats, M, C, stream, addend);
 }
 
 int kpf_bn_train_forward_f32(const float* x, const float* w, const float* b, float* y, float* mean, float* invstd, float* running_mean,

@@ -20,7 +20,7 @@ KPF_IN_SPLIT = 128
 KPF_OUT_SPLIT = 256
 KPF_W_SPLIT = 512
 KPF_DT_F32, KPF_DT_BF16, KPF_DT_F16 = 0, 1, 2
-ABI_VERSION = 10  # KPF_ABI_VERSION of include/kpf.h: load() refuses a library built from another revision of the interface
+ABI_VERSION = 11  # KPF_ABI_VERSION of include/kpf.h: load() refuses a library built from another revision of the interface
 
 
 class ConvDesc(C.Structure):
@@ -90,9 +90,11 @@ _SIGS = {
     "kpf_conv2d_wgrad_f32": [_P] * 5 + [C.c_long] + [C.c_int] * 15 + [_P],
     "kpf_bn_train_forward": [_P, C.c_int, _P, _P, _P, C.c_int, _P, _P, _P, _P, C.c_float, C.c_float, C.c_int, _P, C.c_long, C.c_long, C.c_int, _P],
     "kpf_bn_train_backward": [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P, C.c_long, C.c_long, C.c_int, _P],
+    "kpf_bn_train_backward_add": [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, C.c_long, C.c_long, C.c_int, _P],
     "kpf_bn_train_forward_f32": [_P] * 8 + [C.c_float, C.c_float, C.c_int, _P, C.c_long, C.c_long, C.c_int, _P],
     "kpf_bn_train_backward_f32": [_P] * 9 + [C.c_int, _P, C.c_long, C.c_long, C.c_int, _P],
     "kpf_dwconv7_f32": [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_dwconv7_add_f32": [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
     "kpf_conv2d_wgrad_h16": [_P, _P, C.c_int] + [_P] * 3 + [C.c_long] + [C.c_int] * 15 + [_P],
     "kpf_dwconv7_wgrad_f32": [_P] * 5 + [C.c_long] + [C.c_int] * 4 + [_P],
     "kpf_upsample2x_bwd": [_P, _P] + [C.c_int] * 5 + [_P],

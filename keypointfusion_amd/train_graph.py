@@ -142,8 +142,9 @@ class TrainGraph:
             return conv2d_nhwc(x.contiguous(), w, b, stride, pad, self.prec, None, None if cpad else p_w, self.packs)
         return F.conv2d(x.permute(0, 3, 1, 2), w, b, stride=stride, padding=pad).permute(0, 2, 3, 1).contiguous()
 
-    def bn_l(self, x, p, eps=1e-5, relu=False, out16=True):
-        """BatchNorm2d (batch statistics) [+ ReLU] on NHWC: the HIP kernels for fp32 rows, F.batch_norm otherwise."""
+    def bn_l(self, x, p, eps=1e-5, relu=False, out16=True, alias=False):
+        """BatchNorm2d (batch statistics) [+ ReLU] on NHWC: the HIP kernels for fp32 rows, F.batch_norm otherwise.  alias: returns (y, x')
+        with x' = x for a second consumer of x whose gradient the BatchNorm backward kernel then adds itself (training.BatchNormReLU)."""
         shp = x.shape
         rows = x.reshape(-1, shp[-1])
         if shp[-1] % 4 == 0 and rows.is_cuda:
@@ -151,15 +152,16 @@ class TrainGraph:
             # type the following convolution reads — no cast passes on either side
             from .training import _TDT
             y = batchnorm_relu_rows(rows, self.t[p + ".weight"], self.t[p + ".bias"], self.t[p + ".running_mean"], self.t[p + ".running_var"],
-                                    self.momentum, eps, relu, _TDT[self.prec] if (self.prec != "f32" and out16) else None)
+                                    self.momentum, eps, relu, _TDT[self.prec] if (self.prec != "f32" and out16) else None, alias)
             self.nbt.append(self.t[p + ".num_batches_tracked"])
-            return y.view(shp)
+            return (y[0].view(shp), y[1].view(shp)) if alias else y.view(shp)
         y = self.bn(rows, p, eps).view(shp)
-        return F.relu(y) if relu else y
+        y = F.relu(y) if relu else y
+        return (y, x) if alias else y
 
     def residual(self, p, x):
         cin = x.shape[-1]
-        out = self.bn_l(x, p + ".bn1", relu=True)
+        out, x = self.bn_l(x, p + ".bn1", relu=True, alias=True)  # (x: the skip path's handle on the input, see bn_l)
         out = self.conv_l(out, p + ".conv1.conv.weight", p + ".conv1.conv.bias")
         out = self.bn_l(out, p + ".bn2", relu=True)
         out = self.conv_l(out, p + ".conv2.conv.weight", p + ".conv2.conv.bias", pad=1)
@@ -171,7 +173,7 @@ class TrainGraph:
 
     def convnext_block(self, p, x):
         c = x.shape[-1]
-        y = dwconv7_nhwc(x.float(), self.t[p + ".dwconv.weight"], self.t[p + ".dwconv.bias"], p + ".dwconv.weight", self.packs)
+        y, x = dwconv7_nhwc(x.float(), self.t[p + ".dwconv.weight"], self.t[p + ".dwconv.bias"], p + ".dwconv.weight", self.packs, True)  # (x: the skip path's handle)
         y = self.ln(y, p + ".norm.weight", p + ".norm.bias", 1e-6, to_gemm=True)
         y = self.gelu(self.linear(y, p + ".pwconv1.weight", p + ".pwconv1.bias"))
         y = self.linear(y, p + ".pwconv2.weight", p + ".pwconv2.bias")

@@ -807,7 +807,9 @@ class DwConv7NHWC(torch.autograd.Function):
     forward kpf_dwconv7_f32; backward: dX = the same kernel on dY with mirrored taps, dW / db = kpf_dwconv7_wgrad_f32."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, key=None, cache=None):
+    def forward(ctx, x, weight, bias, key=None, cache=None, alias=False):
+        """alias: also return x itself — the ConvNeXt block adds its input back at the end; routed through the alias, that skip path's
+        gradient arrives in THIS backward and kpf_dwconv7_add_f32 folds it into dx (no separate accumulation launch)."""
         from . import lib as L
         lib = L.load()
         x = x.contiguous()
@@ -819,14 +821,16 @@ class DwConv7NHWC(torch.autograd.Function):
         L.check(lib.kpf_dwconv7_f32(x.data_ptr(), wt.data_ptr(), bias.detach().contiguous().data_ptr(), y.data_ptr(), B, H, W, Cc,
                                     torch.cuda.current_stream().cuda_stream), "kpf_dwconv7_f32")
         ctx.save_for_backward(x, weight)
-        return y
+        return (y, x.view(B, H, W, Cc)) if alias else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, g_alias=None):
         from . import lib as L
         lib = L.load()
         x, weight = ctx.saved_tensors
         B, H, W, Cc = x.shape
+        if dy is None:  # (only the alias was used)
+            return (g_alias,) + (None,) * 5
         dy = dy.contiguous()
         st = torch.cuda.current_stream().cuda_stream
         dx = dw = db = None
@@ -834,7 +838,11 @@ class DwConv7NHWC(torch.autograd.Function):
             wf = _dw_taps(weight, True, ctx.pack)  # taps mirrored, [49][C]
             dx = torch.empty_like(x)
             zb = _zero_bias(Cc, x.device)
-            L.check(lib.kpf_dwconv7_f32(dy.data_ptr(), wf.data_ptr(), zb.data_ptr(), dx.data_ptr(), B, H, W, Cc, st), "kpf_dwconv7_f32")
+            if g_alias is not None:
+                add = g_alias.float().contiguous()
+                L.check(lib.kpf_dwconv7_add_f32(dy.data_ptr(), wf.data_ptr(), zb.data_ptr(), add.data_ptr(), dx.data_ptr(), B, H, W, Cc, st), "kpf_dwconv7_add_f32")
+            else:
+                L.check(lib.kpf_dwconv7_f32(dy.data_ptr(), wf.data_ptr(), zb.data_ptr(), dx.data_ptr(), B, H, W, Cc, st), "kpf_dwconv7_f32")
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             nws = lib.kpf_dwconv7_wgrad_ws_floats(B, H, Cc)
             ws = torch.empty(nws, device=x.device, dtype=torch.float32)
@@ -842,7 +850,7 @@ class DwConv7NHWC(torch.autograd.Function):
             db = torch.empty(Cc, device=x.device, dtype=torch.float32)
             L.check(lib.kpf_dwconv7_wgrad_f32(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nws, B, H, W, Cc, st),
                     "kpf_dwconv7_wgrad_f32")
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 _ZERO_BIAS = {}
@@ -875,8 +883,8 @@ def _dw_taps(weight, mirrored, pack=(None, None)):
     return out
 
 
-def dwconv7_nhwc(x, weight, bias, key=None, cache=None):
-    return DwConv7NHWC.apply(x, weight, bias, key, cache)
+def dwconv7_nhwc(x, weight, bias, key=None, cache=None, alias=False):
+    return DwConv7NHWC.apply(x, weight, bias, key, cache, alias)
 
 
 _KDT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}  # KPF_DT_* of include/kpf.h
@@ -888,7 +896,10 @@ class BatchNormReLU(torch.autograd.Function):
     Same arithmetic as F.batch_norm(training=True): biased variance for normalisation, unbiased for the running estimate."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, out_dtype=None):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, out_dtype=None, alias=False):
+        """alias: also return x itself as a second output.  A Residual block feeds x to this BatchNorm AND to its skip path; routing the
+        skip path through the alias hands its gradient to THIS backward, where kpf_bn_train_backward_add folds it into dx — otherwise
+        autograd adds the two gradients of x with a separate launch over the whole activation."""
         from . import lib as L
         lib = L.load()
         x = x.contiguous()
@@ -908,28 +919,31 @@ class BatchNormReLU(torch.autograd.Function):
         ctx.save_for_backward(x, y if relu else None, stats, weight)
         ctx.relu = bool(relu)
         ctx.out_dtype = out_dtype
-        return y
+        return (y, x.view(M, Cc)) if alias else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, g_alias=None):
         from . import lib as L
         lib = L.load()
         x, y, stats, weight = ctx.saved_tensors
         M, Cc = x.shape
+        if dy is None:  # (only the alias was used)
+            return (g_alias,) + (None,) * 9
         dy = dy.to(ctx.out_dtype).contiguous()
+        add = None if g_alias is None else g_alias.to(x.dtype).contiguous()
         dx = torch.empty_like(x)
         dwb = torch.empty(2, Cc, device=x.device, dtype=torch.float32)
         nws = lib.kpf_bn_ws_floats(M, Cc)
         ws = torch.empty(nws, device=x.device, dtype=torch.float32)
-        L.check(lib.kpf_bn_train_backward(dy.data_ptr(), x.data_ptr(), y.data_ptr() if ctx.relu else None, _KDT[x.dtype], _KDT[ctx.out_dtype],
-                                          stats[0].data_ptr(), stats[1].data_ptr(), weight.detach().contiguous().data_ptr(), dx.data_ptr(),
-                                          dwb[0].data_ptr(), dwb[1].data_ptr(), int(ctx.relu), ws.data_ptr(), nws, M, Cc,
-                                          torch.cuda.current_stream().cuda_stream), "kpf_bn_train_backward")
-        return dx, dwb[0], dwb[1], None, None, None, None, None, None
+        L.check(lib.kpf_bn_train_backward_add(dy.data_ptr(), x.data_ptr(), y.data_ptr() if ctx.relu else None, _KDT[x.dtype], _KDT[ctx.out_dtype],
+                                              stats[0].data_ptr(), stats[1].data_ptr(), weight.detach().contiguous().data_ptr(),
+                                              None if add is None else add.data_ptr(), dx.data_ptr(), dwb[0].data_ptr(), dwb[1].data_ptr(), int(ctx.relu),
+                                              ws.data_ptr(), nws, M, Cc, torch.cuda.current_stream().cuda_stream), "kpf_bn_train_backward_add")
+        return dx, dwb[0], dwb[1], None, None, None, None, None, None, None
 
 
-def batchnorm_relu_rows(x, weight, bias, running_mean, running_var, momentum=0.1, eps=1e-5, relu=True, out_dtype=None):
-    return BatchNormReLU.apply(x, weight, bias, running_mean, running_var, momentum, eps, relu, out_dtype)
+def batchnorm_relu_rows(x, weight, bias, running_mean, running_var, momentum=0.1, eps=1e-5, relu=True, out_dtype=None, alias=False):
+    return BatchNormReLU.apply(x, weight, bias, running_mean, running_var, momentum, eps, relu, out_dtype, alias)
 
 
 class LayerNormRows(torch.autograd.Function):

@@ -696,3 +696,45 @@ def test_joint_heatmap_and_geometry_gate_match_torch():
     (gd * wg.cuda()).sum().backward()
     assert float((gd.detach().cpu().double() - gr.detach()).abs().max()) <= 2e-6
     assert float((jd.grad.cpu().double() - jr.grad).abs().max()) <= 2e-5 * float(jr.grad.abs().max())
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_skip_path_gradient_is_folded_into_the_producing_backward_kernel(dt):
+    """BatchNormReLU / DwConv7NHWC with alias=True return their input a second time; the gradient that reaches the alias (the skip path of a
+    Residual / ConvNeXt block) is added to dx by kpf_bn_train_backward_add / kpf_dwconv7_add_f32 inside the backward kernel.  Against
+    torch in float64 on the same (rounded) operands: y, dx = layer gradient + skip gradient, parameter gradients; alias unused or used
+    alone also work."""
+    from keypointfusion_amd import training as T
+    g = torch.Generator().manual_seed(6)
+    M, Cc = 1500, 48
+    x = (torch.randn(M, Cc, generator=g) * 1.5 + 0.3).to(dt)
+    w, b = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g)
+    c1, c2 = torch.randn(M, Cc, generator=g), torch.randn(M, Cc, generator=g)
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = F.relu(F.batch_norm(xr, None, None, wr, br, True, 0.1, 1e-5))
+    ((yr * c1.double()).sum() + (xr * c2.double()).sum()).backward()
+    xd, wd, bd = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    y, xa = T.batchnorm_relu_rows(xd, wd, bd, torch.zeros(Cc).cuda(), torch.ones(Cc).cuda(), 0.1, 1e-5, True, None, True)
+    assert xa.data_ptr() == xd.data_ptr() and y.dtype == dt
+    ((y.float() * c1.cuda()).sum() + (xa.float() * c2.cuda()).sum()).backward()
+    eps = 3e-5 if dt == torch.float32 else 2.0 ** -7
+    rel = lambda a, r: float((a.detach().cpu().double() - r.detach()).abs().max()) / max(float(r.detach().abs().max()), 1e-3)
+    ptol = 2e-4 if dt == torch.float32 else 6e-3  # (16-bit: dy itself is rounded to the storage type on the way in)
+    assert rel(y, yr) <= eps and rel(xd.grad, xr.grad) <= 1.5 * eps and rel(wd.grad, wr.grad) <= ptol and rel(bd.grad, br.grad) <= ptol
+    # alias alone / alias unused
+    xd2 = x.cuda().requires_grad_(True)
+    y2, xa2 = T.batchnorm_relu_rows(xd2, wd, bd, None, None, 0.1, 1e-5, True, None, True)
+    (xa2.float() * c2.cuda()).sum().backward()
+    assert rel(xd2.grad, c2.double()) <= eps
+    if dt == torch.float32:
+        B, H, W_, C2 = 2, 9, 11, 32
+        xi = torch.randn(B, H, W_, C2, generator=g)
+        wk, bk = torch.randn(C2, 1, 7, 7, generator=g) * 0.1, torch.randn(C2, generator=g)
+        d1, d2 = torch.randn(B, H, W_, C2, generator=g), torch.randn(B, H, W_, C2, generator=g)
+        xr2, wr2, br2 = xi.double().requires_grad_(True), wk.double().requires_grad_(True), bk.double().requires_grad_(True)
+        yr2 = F.conv2d(xr2.permute(0, 3, 1, 2), wr2, br2, padding=3, groups=C2).permute(0, 2, 3, 1)
+        ((yr2 * d1.double()).sum() + (xr2 * d2.double()).sum()).backward()
+        xd3, wd3, bd3 = xi.cuda().requires_grad_(True), wk.cuda().requires_grad_(True), bk.cuda().requires_grad_(True)
+        y3, xa3 = T.dwconv7_nhwc(xd3, wd3, bd3, None, None, True)
+        ((y3 * d1.cuda()).sum() + (xa3 * d2.cuda()).sum()).backward()
+        assert rel(y3, yr2) <= 3e-5 and rel(xd3.grad, xr2.grad) <= 3e-5 and rel(wd3.grad, wr2.grad) <= 1e-4 and rel(bd3.grad, br2.grad) <= 1e-4
