@@ -331,6 +331,22 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const WgradGroupBatc
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+typedef __attribute__((address_space(3))) char lds_char_t;
+
+// The transposed read as inline asm, with the wait placed by hand (tr_wait8): through the compiler builtin the waitcnt pass cannot tell
+// the read from the LDS-DMAs still in flight into the OTHER ring buffers and puts `s_waitcnt vmcnt(0)` in front of the first read of
+// every stage — the stage just issued is then waited for as well and the ring never overlaps anything (seen in the .s of both kernels;
+// cdna_hip_programming.md "three .s-level traps").  The asm reads are invisible to that pass; the counted vmcnt in the loop is the
+// only wait on the DMA queue.
+__device__ __forceinline__ s16x4 tr_read(const char* p) {
+  s16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"((unsigned)(size_t)(lds_char_t*)p));
+  return v;
+}
+// lgkmcnt(0) with the eight 64-bit results tied to it, so that nothing that consumes them can be scheduled above the wait
+__device__ __forceinline__ void tr_wait8(s16x4& a, s16x4& b, s16x4& c, s16x4& d, s16x4& e, s16x4& f, s16x4& g, s16x4& h) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+}
 
 constexpr int HB = 128;   // tile edge: one 256-byte LDS row of 16-bit channels
 
@@ -454,18 +470,24 @@ __global__ __launch_bounds__(256) void wgrad_h16_kernel(const WgradArgs a) {
     asm volatile("" ::: "memory");
     if (s + HNS - 1 < ns) stage(s + HNS - 1);  // into the buffer of stage s-1
     const char* cur = hl + (s % HNS) * STAGE;
-    s16x8 af[4], bf[4];
+    s16x4 ra[4][2], rb[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(cur + addrA[i][0]));
-      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(cur + addrA[i][1]));
-      af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      ra[i][0] = tr_read(cur + addrA[i][0]);
+      ra[i][1] = tr_read(cur + addrA[i][1]);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(cur + addrB[j][0]));
-      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(cur + addrB[j][1]));
-      bf[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      rb[j][0] = tr_read(cur + addrB[j][0]);
+      rb[j][1] = tr_read(cur + addrB[j][1]);
+    }
+    tr_wait8(ra[0][0], ra[0][1], ra[1][0], ra[1][1], ra[2][0], ra[2][1], ra[3][0], ra[3][1]);
+    tr_wait8(rb[0][0], rb[0][1], rb[1][0], rb[1][1], rb[2][0], rb[2][1], rb[3][0], rb[3][1]);
+    s16x8 af[4], bf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      af[i] = __builtin_shufflevector(ra[i][0], ra[i][1], 0, 1, 2, 3, 4, 5, 6, 7);
+      bf[i] = __builtin_shufflevector(rb[i][0], rb[i][1], 0, 1, 2, 3, 4, 5, 6, 7);
     }
     if (want_db) {
 #pragma unroll
@@ -502,6 +524,185 @@ __global__ __launch_bounds__(256) void wgrad_h16_kernel(const WgradArgs a) {
       const int n = n0 + wn * 64 + 16 * i + idx;
       if (g == 0 && n < a.N) a.dbpart[(size_t)split * a.N + n] = v;
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// (1c) wgrad_h16s_kernel — the same product with a 64 x 64 output tile whose PIXEL range is split over the four waves.  The 128-tile
+// form above fills the chip with ~512 workgroups of 64 KB partial tile each: 33 MB of partial sums written and read back per layer,
+// whatever its shape (~9 GB per training iteration) — more than the operands.  Here a stage is 128 pixels, wave w stages and consumes
+// rows 32 w .. 32 w + 31 of it (its own DMA, its own 8-KB slice of every LDS buffer: NO barrier in the main loop, only counted
+// vmcnt), every wave accumulates the whole 64 x 64 tile for its pixels, and the four wave tiles are added through LDS once at the end:
+// 16 KB of partial sums per workgroup (4 x less traffic at equal parallelism), and output tiles four times as many, so large
+// layers need no split at all (1x1: the tile goes straight into dW, no reduce launch).  LDS rows are 128 B (64 channels); 16-byte
+// chunk c of row r lives in slot c ^ f(r), f(r) = 2 ((r >> 1 & 1) | (r >> 3 & 1) << 1): a half-wave's transposed read covers 8 rows in 8
+// distinct 32-byte bank groups.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int HS_TB = 64;    // tile edge
+constexpr int HS_SP = 128;   // pixels per stage (32 per wave)
+constexpr int HS_NS = 3;     // LDS ring: per wave and buffer 32 rows x 128 B x (A + B) = 8 KB
+
+__device__ __forceinline__ int hs_swz(int row) { return 2 * (((row >> 1) & 1) | (((row >> 3) & 1) << 1)); }
+
+template <typename TIN>
+__global__ __launch_bounds__(256) void wgrad_h16s_kernel(const WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char hl[];  // [4 waves][HS_NS][A 4 KB | B 4 KB]; reused for the final cross-wave sum
+  constexpr int WBUF = 2 * 32 * 128;           // one wave's A + B rows of one stage
+  constexpr int WREG = HS_NS * WBUF;           // one wave's region (24 KB)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nt = blockIdx.x / a.tilesK, kt = blockIdx.x % a.tilesK;
+  const int n0 = nt * HS_TB, k0 = kt * HS_TB;
+  const int split = blockIdx.y;
+  const int total_stages = (a.M + HS_SP - 1) / HS_SP;
+  const int s_begin = split * a.stages_per_split;
+  const int ns = min(a.stages_per_split, total_stages - s_begin);
+  const int m_begin = s_begin * HS_SP + 32 * wave;  // this wave's first pixel
+  const TIN* dyh = static_cast<const TIN*>(a.dy);
+  const TIN* xh = static_cast<const TIN*>(a.x);
+  const int ohw = a.OH * a.OW;
+  char* mine = hl + wave * WREG;
+
+  // --- staging: wave-DMA i (0..3 per operand) fills rows 8 i .. 8 i + 7 of the wave's 32 (1 KB, lane-linear): lane -> row 8 i + lane / 8,
+  // slot lane % 8 of that row receives global chunk (lane % 8) ^ f(row)
+  const int jr = lane >> 3, jc = lane & 7;
+  const TIN* a_src[4];
+  bool a_ok[4], b_ok[4];
+  int b_cch[4], b_ky[4], b_kx[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 8 * i + jr;
+    const int gc = jc ^ hs_swz(row);
+    const int n = n0 + 8 * gc;
+    a_ok[i] = n < a.N;
+    a_src[i] = dyh + n;
+    const int kcol = k0 + 8 * gc;
+    b_ok[i] = kcol < a.K;
+    const int tap = kcol / a.Cin;
+    b_cch[i] = kcol - tap * a.Cin;
+    b_ky[i] = tap / a.KW;
+    b_kx[i] = tap - b_ky[i] * a.KW;
+  }
+  auto stage = [&](int s) {
+    char* buf = mine + (s % HS_NS) * WBUF;
+    const int mb = m_begin + s * HS_SP;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mb + 8 * i + jr;
+      const void* src = (a_ok[i] && m < a.M) ? (const void*)(a_src[i] + (size_t)m * a.ldy) : (const void*)a.zero;
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(buf + i * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mb + 8 * i + jr;
+      const void* src = (const void*)a.zero;
+      if (b_ok[i] && m < a.M) {
+        if (a.is1x1) {
+          src = xh + (size_t)m * a.ldx + b_cch[i];
+        } else {
+          const int b = m / ohw, r = m - b * ohw;
+          const int oy = r / a.OW, ox = r - oy * a.OW;
+          const int iy = oy * a.sh + b_ky[i] - a.ph, ix = ox * a.sw + b_kx[i] - a.pw;
+          if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) src = xh + ((size_t)(b * a.H + iy) * a.W + ix) * a.ldx + b_cch[i];
+        }
+      }
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(buf + 4096 + i * 1024), 16, 0, 0);
+    }
+  };
+
+  // --- fragment addresses inside a wave buffer: k-group g = lane / 16 owns pixels 8 g .. 8 g + 7 of the wave's 32
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  int addrA[4][2], addrB[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = 8 * g + 4 * h + q;
+      const int off = row * 128 + 16 * ((2 * i + (pp >> 1)) ^ hs_swz(row)) + 8 * (pp & 1);
+      addrA[i][h] = off;
+      addrB[i][h] = 4096 + off;
+    }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dbs[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool want_db = a.dbpart != nullptr && kt == 0;
+
+#pragma unroll
+  for (int i = 0; i < HS_NS - 1; ++i)
+    if (ns > i) stage(i);
+  for (int s = 0; s < ns; ++s) {
+    // this wave's rows of stage s have landed (8 DMAs per wave and stage; one younger stage may still fly)
+    if (s + 1 < ns) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const char* cur = mine + (s % HS_NS) * WBUF;
+    s16x4 ra[4][2], rb[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i][0] = tr_read(cur + addrA[i][0]);
+      ra[i][1] = tr_read(cur + addrA[i][1]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      rb[j][0] = tr_read(cur + addrB[j][0]);
+      rb[j][1] = tr_read(cur + addrB[j][1]);
+    }
+    tr_wait8(ra[0][0], ra[0][1], ra[1][0], ra[1][1], ra[2][0], ra[2][1], ra[3][0], ra[3][1]);
+    tr_wait8(rb[0][0], rb[0][1], rb[1][0], rb[1][1], rb[2][0], rb[2][1], rb[3][0], rb[3][1]);
+    s16x8 af[4], bf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      af[i] = __builtin_shufflevector(ra[i][0], ra[i][1], 0, 1, 2, 3, 4, 5, 6, 7);
+      bf[i] = __builtin_shufflevector(rb[i][0], rb[i][1], 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+    // the buffer of stage s-1 is free (its reads fed last iteration's MFMAs): refill it while this stage is multiplied
+    if (s + HS_NS - 1 < ns) stage(s + HS_NS - 1);
+    if (want_db) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dbs[i] += sum8(af[i], TIN());
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = mfma_h16(af[i], bf[j], acc[i][j], TIN());
+  }
+
+  // --- the four wave tiles -> LDS ([wave][64 n][64 k] floats in the wave's own region), added in wave order, -> workspace / dW ---
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  float* wt = reinterpret_cast<float*>(mine);
+  const int idx = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wt[(16 * i + 4 * g + r) * 64 + 16 * j + idx] = acc[i][j][r];
+  float* dbl = wt + 64 * 64;  // [64] column sums of this wave's pixels
+  if (want_db) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = dbs[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (g == 0) dbl[16 * i + idx] = v;
+    }
+  }
+  __syncthreads();
+  const float* w0 = reinterpret_cast<const float*>(hl);
+  constexpr int WF = WREG / 4;  // floats between two waves' regions
+  float* part = a.part + (size_t)split * a.N * a.K;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int o = tid + 256 * e;
+    const int n = n0 + (o >> 6), k = k0 + (o & 63);
+    if (n < a.N && k < a.K) part[(size_t)n * a.K + k] = (w0[o] + w0[WF + o]) + (w0[2 * WF + o] + w0[3 * WF + o]);
+  }
+  if (want_db && tid < 64) {
+    const int n = n0 + tid;
+    if (n < a.N) a.dbpart[(size_t)split * a.N + n] = (w0[4096 + tid] + w0[WF + 4096 + tid]) + (w0[2 * WF + 4096 + tid] + w0[3 * WF + 4096 + tid]);
   }
 }
 
@@ -688,6 +889,24 @@ Plan plan_wgrad_h16(long M, int N, int K) {
   return p;
 }
 
+// 64 x 64 tiles of wgrad_h16s_kernel (one 96-KB workgroup per CU): S brings the grid to ~2 workgroups per CU, at least two stages each
+Plan plan_wgrad_h16s(long M, int N, int K) {
+  Plan p{};
+  p.vn = p.vk = 2;
+  p.tilesN = (N + HS_TB - 1) / HS_TB;
+  p.tilesK = (K + HS_TB - 1) / HS_TB;
+  const int total = (int)((M + HS_SP - 1) / HS_SP);
+  const int tiles = p.tilesN * p.tilesK;
+  static const int target = []() { const char* e = getenv("KPF_WG16S_TARGET"); return e ? atoi(e) : 512; }();  // tuning aid
+  int S = (target + tiles - 1) / tiles;
+  if (tiles >= target / 2) S = 1;  // enough tiles: no split, no reduce launch for a 1x1
+  const int smax = (total + 1) / 2;
+  if (S > smax) S = smax < 1 ? 1 : smax;
+  p.sps = (total + S - 1) / S;
+  p.S = (total + p.sps - 1) / p.sps;
+  return p;
+}
+
 const float* zero_page() {
   static std::atomic<const float*> cache[KPF_MAX_DEVICES];
   int dev = 0;
@@ -730,8 +949,8 @@ extern "C" {
 
 long kpf_conv2d_wgrad_ws_floats(long M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  const Plan p = plan_wgrad(M, N, K), h = plan_wgrad_h16(M, N, K);  // (either kernel may take the call: room for the larger split count)
-  const int S = p.S > h.S ? p.S : h.S;
+  const Plan p = plan_wgrad(M, N, K), h = plan_wgrad_h16(M, N, K), hs = plan_wgrad_h16s(M, N, K);  // (any of the kernels may take the call)
+  const int S = p.S > h.S ? (p.S > hs.S ? p.S : hs.S) : (h.S > hs.S ? h.S : hs.S);
   return (long)S * N * K + (long)S * N;
 }
 
@@ -751,9 +970,15 @@ static int conv2d_wgrad_impl(const void* dy, const void* x, int dtype, float* dw
   const long K = (long)KH * KW * Cin;
   KPF_REQUIRE(M < (1L << 31) && K < (1L << 24) && (long)B * H * W < (1L << 31), "kpf_conv2d_wgrad_f32: problem too large");
   static const int h16_widen = []() { const char* e = getenv("KPF_WGRAD_H16_WIDEN"); return e ? atoi(e) : 0; }();  // tuning aid: the old widening kernel
+  // 16-bit operands: the 64-tile form where its tiles alone fill the chip (1x1 layers with N K >= 256 tiles: no split, the tile goes
+  // straight into dW, no reduce launch: 18 vs 31-34 us on 512 x 3072 x 768), the 128-tile form elsewhere (its three workgroups per CU hide the
+  // DMA latency better than the one 96-KB workgroup of the 64-tile form: 15.7 vs 20.5 us per launch over the model's shapes).
+  // KPF_WG16_FORM=64 / 128 forces one of them (tuning aid).
+  static const int h16_form = []() { const char* e = getenv("KPF_WG16_FORM"); return e ? atoi(e) : 0; }();
   const bool h16 = dtype != KPF_DT_F32 && !h16_widen;
   const bool one = KH == 1 && KW == 1;
-  const Plan p = h16 ? plan_wgrad_h16(M, N, (int)K) : plan_wgrad(M, N, (int)K, one);
+  const bool h16s = h16 && (h16_form == 64 || (h16_form != 128 && one && plan_wgrad_h16s(M, N, (int)K).S == 1));
+  const Plan p = h16s ? plan_wgrad_h16s(M, N, (int)K) : (h16 ? plan_wgrad_h16(M, N, (int)K) : plan_wgrad(M, N, (int)K, one));
   const bool direct = one && p.S == 1;  // the single partial array is dW
   KPF_REQUIRE(ws_floats >= (long)p.S * N * K + (long)p.S * N, "kpf_conv2d_wgrad_f32: workspace too small (%ld floats, need %ld)", ws_floats,
               (long)p.S * N * K + (long)p.S * N);
@@ -767,7 +992,19 @@ static int conv2d_wgrad_impl(const void* dy, const void* x, int dtype, float* dw
   a.emul_sps = 0;
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if (h16) {
+  if (h16s) {
+    static std::atomic<bool> lds_ok[2][KPF_MAX_DEVICES];
+    const dim3 grid(p.tilesN * p.tilesK, p.S);
+    constexpr int LDSB = 4 * HS_NS * 2 * 32 * 128;
+    if (dtype == KPF_DT_BF16) {
+      KPF_REQUIRE(kpf_raise_lds_limit(reinterpret_cast<const void*>(&wgrad_h16s_kernel<bf16_t>), lds_ok[0]), "kpf_conv2d_wgrad_h16: cannot raise the LDS limit");
+      hipLaunchKernelGGL((wgrad_h16s_kernel<bf16_t>), grid, dim3(256), LDSB, st, a);
+    } else {
+      KPF_REQUIRE(kpf_raise_lds_limit(reinterpret_cast<const void*>(&wgrad_h16s_kernel<f16_t>), lds_ok[1]), "kpf_conv2d_wgrad_h16: cannot raise the LDS limit");
+      hipLaunchKernelGGL((wgrad_h16s_kernel<f16_t>), grid, dim3(256), LDSB, st, a);
+    }
+    rc = kpf_check_launch("kpf_conv2d_wgrad_h16");
+  } else if (h16) {
     static const int ring = []() { const char* e = getenv("KPF_WG16_RING"); return e ? atoi(e) : 3; }();  // tuning aid: 3 or 4 stages
     const dim3 grid(p.tilesN * p.tilesK, p.S);
     if (ring == 4) {

@@ -121,7 +121,8 @@ def test_batchnorm_relu_rows_matches_torch(M, Cc, relu):
 @pytest.mark.parametrize("tdt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", [(2, 8, 8, 384, 1536, 1, 1, 0), (4, 16, 16, 64, 64, 3, 1, 1), (3, 5, 7, 8, 16, 3, 1, 1), (2, 16, 16, 96, 192, 2, 2, 0),
                                   (1, 1, 21, 128, 512, 1, 1, 0), (2, 16, 16, 144, 72, 1, 1, 0), (32, 32, 32, 48, 128, 1, 1, 0),
-                                  (2, 9, 9, 264, 136, 1, 1, 0), (2, 14, 14, 8, 64, 7, 2, 3), (1, 3, 3, 8, 8, 1, 1, 0)])
+                                  (2, 9, 9, 264, 136, 1, 1, 0), (2, 14, 14, 8, 64, 7, 2, 3), (1, 3, 3, 8, 8, 1, 1, 0),
+                                  (2, 4, 4, 768, 1536, 1, 1, 0), (1, 5, 5, 1096, 1032, 1, 1, 0)])  # (the last two: >= 256 tiles of 64 x 64 -> the unsplit 64-tile form)
 def test_conv_wgrad_16bit_operands_match_fp64_on_the_rounded_values(case, tdt):
     """kpf_conv2d_wgrad_h16: dY and X in 16-bit storage, fp32 products and sums — equal to the fp64 gradient of the ROUNDED operands to
     fp32 accumulation accuracy (nothing else is rounded)."""
