@@ -540,13 +540,12 @@ __global__ __launch_bounds__(256) void wgrad_h16_kernel(const WgradArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int HS_TB = 64;    // tile edge
 constexpr int HS_SP = 128;   // pixels per stage (32 per wave)
-constexpr int HS_NS = 3;     // LDS ring: per wave and buffer 32 rows x 128 B x (A + B) = 8 KB
 
 __device__ __forceinline__ int hs_swz(int row) { return 2 * (((row >> 1) & 1) | (((row >> 3) & 1) << 1)); }
 
-template <typename TIN>
+template <typename TIN, int HS_NS>  // HS_NS: LDS ring depth; per wave and buffer 32 rows x 128 B x (A + B) = 8 KB (3: 96 KB per workgroup, 2: 64 KB)
 __global__ __launch_bounds__(256) void wgrad_h16s_kernel(const WgradArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char hl[];  // [4 waves][HS_NS][A 4 KB | B 4 KB]; reused for the final cross-wave sum
+  extern __shared__ __attribute__((aligned(16))) char hl[];  // [4 waves][HS_NS][A 4 KB | B 4 KB] + 1 KB; reused for the final cross-wave sum
   constexpr int WBUF = 2 * 32 * 128;           // one wave's A + B rows of one stage
   constexpr int WREG = HS_NS * WBUF;           // one wave's region (24 KB)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -635,8 +634,8 @@ __global__ __launch_bounds__(256) void wgrad_h16s_kernel(const WgradArgs a) {
   for (int i = 0; i < HS_NS - 1; ++i)
     if (ns > i) stage(i);
   for (int s = 0; s < ns; ++s) {
-    // this wave's rows of stage s have landed (8 DMAs per wave and stage; one younger stage may still fly)
-    if (s + 1 < ns) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    // this wave's rows of stage s have landed (8 DMAs per wave and stage; with three buffers one younger stage may still fly)
+    if (HS_NS > 2 && s + 1 < ns) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const char* cur = mine + (s % HS_NS) * WBUF;
     s16x4 ra[4][2], rb[4][2];
@@ -680,7 +679,7 @@ __global__ __launch_bounds__(256) void wgrad_h16s_kernel(const WgradArgs a) {
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int j = 0; j < 4; ++j) wt[(16 * i + 4 * g + r) * 64 + 16 * j + idx] = acc[i][j][r];
-  float* dbl = wt + 64 * 64;  // [64] column sums of this wave's pixels
+  float* dbl = reinterpret_cast<float*>(hl + 4 * WREG) + 64 * wave;  // [64] column sums of this wave's pixels (behind the four regions)
   if (want_db) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -702,7 +701,8 @@ __global__ __launch_bounds__(256) void wgrad_h16s_kernel(const WgradArgs a) {
   }
   if (want_db && tid < 64) {
     const int n = n0 + tid;
-    if (n < a.N) a.dbpart[(size_t)split * a.N + n] = (w0[4096 + tid] + w0[WF + 4096 + tid]) + (w0[2 * WF + 4096 + tid] + w0[3 * WF + 4096 + tid]);
+    const float* d0 = reinterpret_cast<const float*>(hl + 4 * WREG);
+    if (n < a.N) a.dbpart[(size_t)split * a.N + n] = (d0[tid] + d0[64 + tid]) + (d0[128 + tid] + d0[192 + tid]);
   }
 }
 
@@ -889,7 +889,7 @@ Plan plan_wgrad_h16(long M, int N, int K) {
   return p;
 }
 
-// 64 x 64 tiles of wgrad_h16s_kernel (one 96-KB workgroup per CU): S brings the grid to ~2 workgroups per CU, at least two stages each
+// 64 x 64 tiles of wgrad_h16s_kernel (two 64-KB workgroups per CU): S brings the grid to ~1.5 workgroups per CU, at least two stages each
 Plan plan_wgrad_h16s(long M, int N, int K) {
   Plan p{};
   p.vn = p.vk = 2;
@@ -897,7 +897,7 @@ Plan plan_wgrad_h16s(long M, int N, int K) {
   p.tilesK = (K + HS_TB - 1) / HS_TB;
   const int total = (int)((M + HS_SP - 1) / HS_SP);
   const int tiles = p.tilesN * p.tilesK;
-  static const int target = []() { const char* e = getenv("KPF_WG16S_TARGET"); return e ? atoi(e) : 512; }();  // tuning aid
+  static const int target = []() { const char* e = getenv("KPF_WG16S_TARGET"); return e ? atoi(e) : 384; }();  // tuning aid (256 / 384 / 512 / 768: 3.13 / 3.01 / 3.19 / 3.40 ms of GEMM + reduce per iteration)
   int S = (target + tiles - 1) / tiles;
   if (tiles >= target / 2) S = 1;  // enough tiles: no split, no reduce launch for a 1x1
   const int smax = (total + 1) / 2;
@@ -970,14 +970,13 @@ static int conv2d_wgrad_impl(const void* dy, const void* x, int dtype, float* dw
   const long K = (long)KH * KW * Cin;
   KPF_REQUIRE(M < (1L << 31) && K < (1L << 24) && (long)B * H * W < (1L << 31), "kpf_conv2d_wgrad_f32: problem too large");
   static const int h16_widen = []() { const char* e = getenv("KPF_WGRAD_H16_WIDEN"); return e ? atoi(e) : 0; }();  // tuning aid: the old widening kernel
-  // 16-bit operands: the 64-tile form where its tiles alone fill the chip (1x1 layers with N K >= 256 tiles: no split, the tile goes
-  // straight into dW, no reduce launch: 18 vs 31-34 us on 512 x 3072 x 768), the 128-tile form elsewhere (its three workgroups per CU hide the
-  // DMA latency better than the one 96-KB workgroup of the 64-tile form: 15.7 vs 20.5 us per launch over the model's shapes).
-  // KPF_WG16_FORM=64 / 128 forces one of them (tuning aid).
-  static const int h16_form = []() { const char* e = getenv("KPF_WG16_FORM"); return e ? atoi(e) : 0; }();
+  // 16-bit operands: the 64-tile form (wgrad_h16s_kernel, two buffers = two workgroups per CU) — GEMM + reduce of a ConvNeXt-T iteration
+  // 3.01 ms against 3.51 for the 128-tile form (a quarter of the partial-sum traffic, no split at all for the layers whose tiles fill the
+  // chip); with three buffers (one workgroup per CU) it loses (3.61).  KPF_WG16_FORM=128 selects the 128-tile form (tuning aid).
+  static const int h16_form = []() { const char* e = getenv("KPF_WG16_FORM"); return e ? atoi(e) : 64; }();
   const bool h16 = dtype != KPF_DT_F32 && !h16_widen;
   const bool one = KH == 1 && KW == 1;
-  const bool h16s = h16 && (h16_form == 64 || (h16_form != 128 && one && plan_wgrad_h16s(M, N, (int)K).S == 1));
+  const bool h16s = h16 && h16_form != 128;
   const Plan p = h16s ? plan_wgrad_h16s(M, N, (int)K) : (h16 ? plan_wgrad_h16(M, N, (int)K) : plan_wgrad(M, N, (int)K, one));
   const bool direct = one && p.S == 1;  // the single partial array is dW
   KPF_REQUIRE(ws_floats >= (long)p.S * N * K + (long)p.S * N, "kpf_conv2d_wgrad_f32: workspace too small (%ld floats, need %ld)", ws_floats,
@@ -994,14 +993,18 @@ static int conv2d_wgrad_impl(const void* dy, const void* x, int dtype, float* dw
   int rc;
   if (h16s) {
     static std::atomic<bool> lds_ok[2][KPF_MAX_DEVICES];
+    static const int sring = []() { const char* e = getenv("KPF_WG16S_RING"); return e ? atoi(e) : 2; }();  // tuning aid: 2 (default) or 3 buffers
     const dim3 grid(p.tilesN * p.tilesK, p.S);
-    constexpr int LDSB = 4 * HS_NS * 2 * 32 * 128;
-    if (dtype == KPF_DT_BF16) {
-      KPF_REQUIRE(kpf_raise_lds_limit(reinterpret_cast<const void*>(&wgrad_h16s_kernel<bf16_t>), lds_ok[0]), "kpf_conv2d_wgrad_h16: cannot raise the LDS limit");
-      hipLaunchKernelGGL((wgrad_h16s_kernel<bf16_t>), grid, dim3(256), LDSB, st, a);
+    constexpr int WB = 4 * 2 * 32 * 128;  // one buffer of the four waves
+    if (sring == 2) {
+      if (dtype == KPF_DT_BF16) hipLaunchKernelGGL((wgrad_h16s_kernel<bf16_t, 2>), grid, dim3(256), 2 * WB + 1024, st, a);
+      else hipLaunchKernelGGL((wgrad_h16s_kernel<f16_t, 2>), grid, dim3(256), 2 * WB + 1024, st, a);
+    } else if (dtype == KPF_DT_BF16) {
+      KPF_REQUIRE(kpf_raise_lds_limit(reinterpret_cast<const void*>(&wgrad_h16s_kernel<bf16_t, 3>), lds_ok[0]), "kpf_conv2d_wgrad_h16: cannot raise the LDS limit");
+      hipLaunchKernelGGL((wgrad_h16s_kernel<bf16_t, 3>), grid, dim3(256), 3 * WB + 1024, st, a);
     } else {
-      KPF_REQUIRE(kpf_raise_lds_limit(reinterpret_cast<const void*>(&wgrad_h16s_kernel<f16_t>), lds_ok[1]), "kpf_conv2d_wgrad_h16: cannot raise the LDS limit");
-      hipLaunchKernelGGL((wgrad_h16s_kernel<f16_t>), grid, dim3(256), LDSB, st, a);
+      KPF_REQUIRE(kpf_raise_lds_limit(reinterpret_cast<const void*>(&wgrad_h16s_kernel<f16_t, 3>), lds_ok[1]), "kpf_conv2d_wgrad_h16: cannot raise the LDS limit");
+      hipLaunchKernelGGL((wgrad_h16s_kernel<f16_t, 3>), grid, dim3(256), 3 * WB + 1024, st, a);
     }
     rc = kpf_check_launch("kpf_conv2d_wgrad_h16");
   } else if (h16) {
