@@ -1,3 +1,5 @@
+"""Average duration of the weight-gradient kernels (16-bit forms, reduce) in a rocprofv3 kernel trace of tools/wgrad_bench.py or bench.py.
+  python3 tools/parse_wgrad_trace.py <trace dir>"""
 import csv,glob,sys,collections
 f=glob.glob(sys.argv[1]+"/**/*kernel_trace.csv",recursive=True)[0]
 rows=sorted(csv.DictReader(open(f)),key=lambda r:int(r["Start_Timestamp"]))
