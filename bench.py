@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Benchmark of the KPFusion forward hot path on MI355X (driver contract: see the task statement).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]          (N>1: launched once per rank by torch.distributed.run)
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1: either launched once per rank by torch.distributed.run (the driver's form; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the
+environment) or plainly as `python bench.py --gpus N`, in which case this process starts the N ranks itself as a child torchrun job
+(before any HIP call) and relays their one JSON line and exit code.
 
 Workload = BASELINE.json configs[1]: B=64 synthetic 256x256 RGB-D crops per GPU, KPFusion-convnext-tiny, both UNet
 backbones (depth + RGB) forward-only, fp32, eval.  (The fusion head only exists at 128x128 in the reference — SURVEY D1
@@ -20,6 +24,10 @@ One JSON line is printed by rank 0 with, besides the contract fields:
                  offline and committed (profiles/r03_traffic.json, tools/collect_traffic.py): `traffic_source` says so.
   split_f16x3  : SECONDARY record, not the headline and not IEEE fp32: the same workload with KPF_GEMM=split (the ConvNeXt-block GEMMs
                  as 3 x f16 MFMA on hi/lo-split operands with a pack-time range proof; everything else stays on the f32 MFMA).
+  extra        : (default run, N = 1) one timed record per further BASELINE config that fits one GPU — `cnb512_f16` (configs[4]: ConvNeXt-B,
+                 512x512, f16, B=64), `full128_bf16` (configs[2]: full model, B=32, bf16), `train128_bf16` (configs[3]: one training
+                 iteration, B=32, bf16) — each measured by this script as a child process on that workload, with its own `roofline`.
+  world_size   : ranks that took part (dist.get_world_size()), `collective_backend` the RCCL version when a process group exists.
   cpu_baseline : the CPU oracle (oracle/kpf_oracle.py, torch-CPU fp32 = the reference's own arithmetic) on the host
                  cores of this box, median of 5 passes over a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -68,6 +76,58 @@ def cpu_model():
     return "unknown"
 
 
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(n):
+    """Start `python -m torch.distributed.run --nproc-per-node n bench.py <same arguments>` as a child, relay its output, return its rc."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver: RCCL needs it across processes
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: launching %d rank(s): %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    sys.stdout.write(proc.stdout)
+    sys.stdout.flush()
+    return proc.returncode
+
+
+# Secondary workloads of the default run (N = 1): each is this same script as a child process on its own workload — its own model,
+# capture and `roofline` — after the headline has been timed, so the driver's one invocation carries a timed record for every
+# BASELINE config that runs on one GPU.  (workload, steps, warmup)
+EXTRA_WORKLOADS = (("cnb512_f16", 6, 2), ("full128_bf16", 30, 5), ("train128_bf16", 12, 3))
+
+
+def run_extra(workload, steps, warmup, timeout):
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", str(steps), "--warmup", str(warmup),
+           "--no-cpu-baseline", "--no-extra"]
+    t0 = time.perf_counter()
+    try:
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"error": "timed out after %d s" % timeout}
+    rec = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{"):
+            try:
+                rec = json.loads(ln)
+            except ValueError:
+                pass
+    if proc.returncode != 0 or rec is None:
+        return {"error": "rc %d: %s" % (proc.returncode, proc.stderr[-400:])}
+    keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "launch", "roofline", "world_size")
+    out = {k: rec.get(k) for k in keep}
+    out["workload"] = rec["config"]["workload"]
+    out["wall_s"] = round(time.perf_counter() - t0, 1)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,9 +142,11 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="issue the launches of a step from Python instead of replaying the captured "
                     "hipGraph (the default; same device time, but the step then depends on the host keeping up)")
     ap.add_argument("--per-launch", default="", help="write a per-launch table of the MFMA kernels to this file")
-    ap.add_argument("--cpu-sample", type=int, default=8, help="images in the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=16, help="images in the CPU-baseline sample")
     ap.add_argument("--gemm", default="f32", choices=["f32", "split"], help="GEMM arithmetic of the headline run (default f32 = IEEE fp32)")
     ap.add_argument("--no-split-record", action="store_true", help="skip the secondary KPF_GEMM=split timing")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workload records (cnb512_f16, full128_bf16, train128_bf16) "
+                    "that the default run adds under `extra`")
     ap.add_argument("--in-flight", type=int, default=2, help="full-model eval workloads: batches in flight (serving.PipelinedEval: independent "
                     "hipGraph slots on their own streams, the latency-bound fusion head of one batch beside the backbones of the next); "
                     "1 = one synchronous forward per step")
@@ -93,8 +155,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("KPF_BENCH_FORCE_DIST")):
+        # `python bench.py --gpus N` by itself: become the launcher.  No HIP call has been made yet (importing torch and parsing
+        # arguments do not initialise the runtime), so the ranks are started as CHILD processes of this one (never an exec) — one
+        # per GPU over RCCL — their output is relayed and their exit code returned.  Replaces train.py:81 / demo_RGBD.py:49
+        # (`DataParallel(net).cuda()`: one command, all GPUs).  KPF_BENCH_FORCE_DIST=1 takes the same route with --gpus 1 (a one-rank
+        # RCCL group on a one-GPU box).
+        return self_launch(args.gpus)
     if args.gpus > 1 and world != args.gpus:
-        sys.exit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
     if world > 1 or os.environ.get("KPF_BENCH_FORCE_DIST"):  # (the env switch exercises the RCCL path on a 1-GPU box)
         import torch.distributed as dist
@@ -349,19 +418,52 @@ def main():
             else:
                 O.kpfusion_forward(sd, cb["img_rgb"], cb["img"], cb["pcl"], cb["center"], cb["M"], cb["cube"], cb["cam_para"], 0.8)
 
-        cpu_step()  # warm-up (oneDNN primitive caches)
+        # Thread count: all hardware threads is not the fastest setting for a batch this small (8 images on 128 SMT threads
+        # oversubscribes the convolution's work split: round 3 reported 2.66 img/s that way, below an 8-vCPU box), so the pass is timed
+        # at several counts and the best one is the baseline; which, and the whole sweep, are stated in `sample`.
+        ncpu = os.cpu_count() or 1
+        cands = sorted({t for t in (16, 32, 64, 128, ncpu) if t <= ncpu}) or [1]
+        if args.workload == "cnb512_f16":
+            cands = cands[-2:]
+        sweep = {}
+        for t in cands:
+            torch.set_num_threads(t)
+            cpu_step()  # warm-up (oneDNN primitive caches, thread pool)
+            t1 = time.perf_counter()
+            cpu_step()
+            sweep[t] = time.perf_counter() - t1
+        best_t = min(sweep, key=sweep.get)
+        torch.set_num_threads(best_t)
         times = []
-        for _ in range(3 if args.workload == "cnb512_f16" else 5):
+        for _ in range(3):
             t1 = time.perf_counter()
             cpu_step()
             times.append(time.perf_counter() - t1)
-        med = statistics.median(times)
-        cpu = {"value": round(n / med, 2), "unit": "img/s", "cores": threads, "kind": "port",
-               "sample": "median of 3-5 passes over %d images of the same synthetic batch, oracle/kpf_oracle.py (torch-CPU fp32), %d threads; "
-                         "min/max %.2f/%.2f img/s" % (n, threads, n / max(times), n / min(times)),
+        torch.set_num_threads(threads)
+        med = statistics.median(times + [sweep[best_t]])
+        cpu = {"value": round(n / med, 2), "unit": "img/s", "cores": best_t, "kind": "port",
+               "sample": "median of 4 passes over %d images of the same synthetic batch, oracle/kpf_oracle.py (torch-CPU fp32) at the best thread "
+                         "count of the sweep {%s} img/s; min/max at %d threads %.2f/%.2f img/s" % (
+                             n, ", ".join("%d: %.2f" % (t, n / sweep[t]) for t in cands), best_t, n / max(times), n / min(times)),
                "host": "%s, nproc %d" % (cpu_model(), os.cpu_count() or 0)}
 
+    extra = None
+    if rank == 0 and world == 1 and dist is None and args.workload == "backbones256" and not args.no_extra and not args.batch:
+        # the headline's buffers are no longer needed: give the memory back before the children build their own models
+        pipe[0] = None
+        model._plans.clear()
+        torch.cuda.empty_cache()
+        extra = {}
+        for wl, k, w in EXTRA_WORKLOADS:
+            extra[wl] = run_extra(wl, k, w, timeout=420)
+
     if rank == 0:
+        rccl = None
+        if dist is not None:
+            try:
+                rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:  # noqa: BLE001
+                rccl = "unknown"
         line = {
             "metric": "RGB-D img/sec fwd (B=64, 256x256)" if args.workload == "backbones256" else
                       "RGB-D img/sec trained (fwd + loss + bwd + AdamW, B=%d, %dx%d, %s)" % (B, S, S, precision) if train else
@@ -378,7 +480,11 @@ def main():
                                                    else "KPF_GEMM=split")},
             "roofline": roofline, "cpu_baseline": cpu, "split_f16x3": split_rec, "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 3),
             "launch": launch_mode,
+            "world_size": dist.get_world_size() if dist is not None else 1,  # ranks that ran (N > 1: one process per GPU over RCCL)
+            "collective_backend": ("rccl " + rccl) if dist is not None else None,
         }
+        if extra is not None:
+            line["extra"] = extra
         if single is not None:
             line["single_step_into_idle_gpu"] = single
         print(json.dumps(line), flush=True)
@@ -388,4 +494,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
