@@ -289,12 +289,18 @@ def upsample2x(x, out):
 
 def crop_inverse(M):
     """M^-1 [B][3][3] on the device, in the rounding order of the reference's PyTorch-CPU forward on this host (torch.linalg.inv ->
-    MKL getrf / getrs, dataloader/loader.py:781; inv3x3.host_mode picks the fused or the separately rounded variant, a fixed one if
-    the host's library is neither).  No host round trip: capturable in a hipGraph on every host."""
+    MKL getrf / getrs, dataloader/loader.py:781; inv3x3.host_mode picks the fused or the separately rounded variant).  No host round
+    trip on hosts whose library follows one of the two known orders (every box seen so far), and never under stream capture."""
     from .inv3x3 import host_mode
     B = M.shape[0]
+    mode = host_mode()
+    if mode < 0:  # a host library that follows neither known order
+        if not torch.cuda.is_current_stream_capturing():
+            # eager: the reference's own call on the host (dataloader/loader.py:781) — exact, at the price of a synchronisation
+            return torch.linalg.inv(M.detach().float().cpu().view(B, 1, 3, 3)).view(B, 3, 3).to(M.device)
+        mode = 0  # under capture M must not leave the device
     out = torch.empty(B, 3, 3, device=M.device, dtype=torch.float32)
-    L.check(L.load().kpf_inv3x3_f32(_ptr(M.detach().float().contiguous()), _ptr(out), B, host_mode(), _stream()), "kpf_inv3x3_f32")
+    L.check(L.load().kpf_inv3x3_f32(_ptr(M.detach().float().contiguous()), _ptr(out), B, mode, _stream()), "kpf_inv3x3_f32")
     return out
 
 

@@ -2,7 +2,9 @@
 util/generateFeature.py:166-195 (feature2joint -> offset2joint_weight), :676-703 (rigid_align); util/eval_utils.py:38-81).
 
 The decode of the two dense stages (masked soft-argmax + un-crop/back-projection) runs in the HIP library (the same kernel the
-forward uses for its own initial joints); the metrics are host-side numpy like the reference's (they consume B x 21 x 3 arrays).
+forward uses for its own initial joints); the per-joint errors and the Procrustes alignment are batched tensor expressions on the
+device (one 3 x 3 SVD batch per stage, no per-sample host loop); only PCK / AUC, which consume the accumulated error lists of a whole
+evaluation, are numpy.
 """
 import ctypes as C
 
@@ -38,58 +40,66 @@ def decode_stage(result, stage_type, img, center, M, cube, cam_para, kernel=0.8,
     return xyz
 
 
+def _as_tensor(t, like=None):
+    if torch.is_tensor(t):
+        return t.detach()
+    return torch.as_tensor(np.asarray(t), device=like.device if like is not None else None)
+
+
 def xyz2error(pred, gt, center, cube):
-    """train.py:470-488 — per-joint Euclidean error in mm: |(pred - gt) * cube/2|, B x J."""
-    pred, gt, center, cube = (np.asarray(t.detach().cpu() if hasattr(t, "detach") else t, dtype=np.float32) for t in (pred, gt, center, cube))
-    B, J, _ = pred.shape
-    c = np.tile(center.reshape(B, 1, -1), [1, J, 1])
-    s = np.tile(cube.reshape(B, 1, -1), [1, J, 1])
-    a = pred * s / 2 + c
-    b = gt * s / 2 + c
-    e = (a - b) * (a - b)
-    if J == 23:  # reference's NYU subset selection
-        e = e[:, [0, 2, 4, 6, 8, 10, 12, 14, 16, 17, 18, 21, 22, 20], :]
-    return np.sqrt(np.sum(e, axis=2))
+    """Per-joint Euclidean error in mm, B x J (what train.py:470-488 computes): normalised joints are scaled by cube / 2; the crop
+    centre the reference adds to both sides cancels in the difference, so it is not added here (no 700 mm + 0.01 mm cancellation in
+    fp32).  Tensors stay on their device; numpy in -> numpy out."""
+    was_np = not torch.is_tensor(pred)
+    p = _as_tensor(pred).float()
+    g = _as_tensor(gt, p).to(p).float()
+    half = _as_tensor(cube, p).to(p).float().reshape(p.shape[0], 1, -1) / 2
+    e = torch.linalg.vector_norm((p - g) * half, dim=-1)
+    return e.cpu().numpy() if was_np else e
 
 
-def rigid_transform_3d(A, B):
-    """util/generateFeature.py:676-696 — similarity transform (scale, rotation, translation) of A onto B (Umeyama)."""
-    n, _ = A.shape
-    ca, cb = np.mean(A, axis=0), np.mean(B, axis=0)
-    H = np.dot(np.transpose(A - ca), B - cb) / n
-    U, s, V = np.linalg.svd(H)
-    R = np.dot(np.transpose(V), np.transpose(U))
-    if np.linalg.det(R) < 0:
-        s[-1] = -s[-1]
-        V[2] = -V[2]
-        R = np.dot(np.transpose(V), np.transpose(U))
-    var = np.var(A, axis=0).sum()
-    c = 1 / var * np.sum(s)
-    t = -np.dot(c * R, np.transpose(ca)) + np.transpose(cb)
-    return c, R, t
+def similarity_align(A, B):
+    """Batched similarity Procrustes (Umeyama 1991; the result of util/generateFeature.py:676-703 `rigid_align` for every sample at once):
+    scale c, rotation R, translation t minimising |c R a_j + t - b_j|^2 over the J points of each sample, applied to A.
+    A, B: [N, J, 3] tensors on any device (fp32 or fp64); one batched 3 x 3 SVD instead of a host loop over samples.
+    Reflections: when det(V U^T) < 0 the smallest singular direction is flipped (and its singular value counted negative in the scale)."""
+    J = A.shape[1]
+    ca, cb = A.mean(1, keepdim=True), B.mean(1, keepdim=True)
+    A0, B0 = A - ca, B - cb
+    H = A0.transpose(1, 2) @ B0 / J                                  # cross-covariance, [N, 3, 3]
+    U, S, Vh = torch.linalg.svd(H)
+    d = torch.sign(torch.linalg.det(Vh.transpose(1, 2) @ U.transpose(1, 2)))
+    flip = torch.ones_like(S)
+    flip[:, 2] = d
+    R = (Vh.transpose(1, 2) * flip.unsqueeze(1)) @ U.transpose(1, 2)  # V diag(1, 1, d) U^T
+    scale = (S * flip).sum(-1) / (A0.pow(2).sum((1, 2)) / J)          # trace(D S) / total variance of A
+    return scale.view(-1, 1, 1) * (A0 @ R.transpose(1, 2)) + cb
 
 
 def rigid_align(A, B):
-    """util/generateFeature.py:698-703."""
-    c, R, t = rigid_transform_3d(A, B)
-    return np.transpose(np.dot(c * R, np.transpose(A))) + t
+    """One sample (J x 3) or a batch (N x J x 3); numpy in -> numpy out (float64 kept), tensor in -> tensor out."""
+    was_np = not torch.is_tensor(A)
+    a = _as_tensor(A)
+    b = _as_tensor(B, a).to(a)
+    single = a.dim() == 2
+    out = similarity_align(a[None] if single else a, b[None] if single else b)
+    out = out[0] if single else out
+    return out.cpu().numpy() if was_np else out
 
 
 def evaluate_batch(results, img, xyz_gt, center, M, cube, cam_para, stage_type=STAGE_TYPE, kernel=0.8, img_size=128, flip=1):
     """One iteration of Trainer.test (train.py:326-383): per stage the B x 21 joint errors (mm), their batch mean, and the
-    Procrustes-aligned mean error."""
+    Procrustes-aligned mean error.  Everything up to the three scalars per stage is computed on the device for the whole batch (the
+    reference aligns sample by sample in numpy on the host, train.py:346-357: a synchronisation and B small SVDs per stage); one
+    device -> host transfer per stage at the end."""
     out = []
-    gt = xyz_gt.detach().cpu().numpy()
+    gt = xyz_gt.detach().float()
     for i, st in enumerate(stage_type):
-        xyz = decode_stage(results[i], st, img, center, M, cube, cam_para, kernel, img_size, flip)
-        err = xyz2error(xyz, xyz_gt, center, cube)
-        pa = 0.0
-        xn = xyz.detach().cpu().numpy()
-        for b in range(xn.shape[0]):
-            al = rigid_align(xn[b], gt[b])
-            pa = pa + xyz2error(al[None], gt[b][None], center[b:b + 1], cube[b:b + 1])
-        pa = pa / xn.shape[0]
-        out.append({"joint_errors": err, "mean_error": float(np.mean(np.mean(err, axis=-1))), "pa_mean_error": float(np.mean(pa))})
+        xyz = decode_stage(results[i], st, img, center, M, cube, cam_para, kernel, img_size, flip).float()
+        err = xyz2error(xyz, gt, center, cube)
+        pa = xyz2error(similarity_align(xyz.double(), gt.double()).float(), gt, center, cube)
+        packed = torch.cat((err.reshape(-1), err.mean().reshape(1), pa.mean().reshape(1))).cpu().numpy()
+        out.append({"joint_errors": packed[:-2].reshape(tuple(err.shape)), "mean_error": float(packed[-2]), "pa_mean_error": float(packed[-1])})
     return out
 
 

@@ -89,7 +89,8 @@ _lock = threading.Lock()
 
 def host_mode():
     """The rounding order the device uses for M^-1: 1 / 0 = this host's torch.linalg.inv follows the fused / separately rounded order;
-    0 with a one-time warning if it follows neither; KPF_INV3X3_MODE overrides (see module docstring).  Never negative."""
+    -1 (with a one-time warning) if it follows neither — engine.crop_inverse then inverts on the host in eager forwards (bit-exact, one
+    synchronisation) and uses order 0 only under stream capture; KPF_INV3X3_MODE=0|1 overrides (see module docstring)."""
     global _mode
     if _mode is None:
         with _lock:
@@ -97,15 +98,17 @@ def host_mode():
                 import os
                 env = os.environ.get("KPF_INV3X3_MODE")
                 if env is not None:
-                    assert env in ("0", "1"), "KPF_INV3X3_MODE must be 0 or 1"
+                    if env not in ("0", "1"):
+                        raise ValueError("KPF_INV3X3_MODE must be 0 or 1, got %r" % (env,))
                     _mode = int(env)
                     return _mode
                 mode = probe_host()
                 if mode < 0:
                     import warnings
-                    warnings.warn("keypointfusion_amd: this host's torch.linalg.inv follows neither known 3x3 rounding order; the device uses the "
-                                  "separately rounded LU order (last-bit differences from this host's CPU inverse are possible)")
-                    mode = 0
+                    warnings.warn("keypointfusion_amd: this host's torch.linalg.inv follows neither known 3x3 rounding order: eager forwards invert "
+                                  "the crop matrix on the host (exact, one synchronisation per forward); captured forwards use the separately "
+                                  "rounded LU order on the device (last-bit differences from this host's CPU inverse are possible).  "
+                                  "KPF_INV3X3_MODE=0|1 pins an order.")
                 _mode = mode
     return _mode
 

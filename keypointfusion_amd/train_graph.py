@@ -52,11 +52,13 @@ class TrainGraph:
         # normalisation statistics, softmaxes, geometry and loss
         self.prec = getattr(module, "precision", "f32")
         self.cmul = 4 if self.prec == "f32" else 8
-        # parity-test hook: ball-query index tensors to use instead of the computed ones (the sets are integer decisions taken around
-        # network outputs; a test that compares gradients with the reference's must compare on equal decisions) + a flip counter
+        # DEBUG hook, off unless a test sets `module._debug_ball_override` (a list of index tensors): ball-query sets to use instead of
+        # the computed ones — the sets are integer decisions taken around network outputs, and a test that compares gradients with the
+        # reference's must compare on equal decisions — plus a count of the sets that differed, kept on the device.  The default path
+        # touches neither.
         self.attn_calls = 0
         self.nbt = []  # BatchNorm num_batches_tracked counters touched by this forward: incremented by ONE multi-tensor launch at its end
-        self.ball_override = list(getattr(module, "_ball_override", None) or [])
+        self.ball_override = list(getattr(module, "_debug_ball_override", None) or [])  # None / empty in every product path
         self.ball_flips = 0
         # kernel-layout operands of every convolution / Linear whose source is parameter storage: persistent buffers, rewritten from the
         # current parameter values by one multi-tensor launch here (training.PackCache); mixed precision rounds the fp32 master to the
@@ -78,18 +80,16 @@ class TrainGraph:
         w = self.t[p_w]
         b = self.t[p_b] if p_b is not None else None
         n, cin = w.shape
-        if x.is_cuda:
-            npad, cpad = (-n) % 4, (-cin) % self.cmul
-            if npad == 0 and cpad == 0:
-                return linear_hip(x.contiguous(), w, b, self.prec, None, p_w, self.packs)
-            # odd widths — the 3-wide joint heads and the 131-wide input of final_TR (model/model.py:99-104, 349): zero rows / columns up
-            # to whole channel groups so that forward, data- and weight-gradient all stay on the HIP kernels (the library's GEMM for an
-            # M = 3 weight gradient takes 220 us); autograd slices the gradients back
-            wp = F.pad(w, (0, cpad, 0, npad))
-            bp = F.pad(b, (0, npad)) if (b is not None and npad) else b
-            xp = F.pad(x, (0, cpad)) if cpad else x
-            return linear_hip(xp.contiguous(), wp, bp, self.prec)[..., :n]
-        return F.linear(x, w, b)
+        npad, cpad = (-n) % 4, (-cin) % self.cmul
+        if npad == 0 and cpad == 0:
+            return linear_hip(x.contiguous(), w, b, self.prec, None, p_w, self.packs)
+        # odd widths — the 3-wide joint heads and the 131-wide input of final_TR (model/model.py:99-104, 349): zero rows / columns up
+        # to whole channel groups so that forward, data- and weight-gradient all stay on the HIP kernels (the library's GEMM for an
+        # M = 3 weight gradient takes 220 us); autograd slices the gradients back
+        wp = F.pad(w, (0, cpad, 0, npad))
+        bp = F.pad(b, (0, npad)) if (b is not None and npad) else b
+        xp = F.pad(x, (0, cpad)) if cpad else x
+        return linear_hip(xp.contiguous(), wp, bp, self.prec)[..., :n]
 
     def bn(self, x, p, eps=1e-5):
         rm, rv = self.t[p + ".running_mean"], self.t[p + ".running_var"]
@@ -101,14 +101,14 @@ class TrainGraph:
         """LayerNorm over the last axis on the HIP kernels (C % 4 == 0, C <= 1024), torch otherwise; to_gemm: the output feeds a GEMM, so under
         mixed precision it is written in the 16-bit operand type directly."""
         c = x.shape[-1]
-        if x.is_cuda and c % 4 == 0 and c <= 1024:
+        if c % 4 == 0 and c <= 1024:  # (the kernel's shape limits; ConvNeXt-L's 1536-wide norms take the library's LayerNorm)
             from .training import _TDT
             return layer_norm_rows(x, self.t[p_w], self.t[p_b], eps, _TDT[self.prec] if (to_gemm and self.prec != "f32") else None)
         return F.layer_norm(x, (c,), self.t[p_w], self.t[p_b], eps)
 
     @staticmethod
     def gelu(x):
-        return gelu_rows(x) if (x.is_cuda and x.numel() % 4 == 0 and x.dtype in (torch.float32, torch.bfloat16, torch.float16)) else F.gelu(x)
+        return gelu_rows(x)
 
     def attention(self, q, k, v, heads, scale):
         """The 21-token attention core on the HIP kernel; its dropout masks come from the module's device-resident (seed, counter) pair,
@@ -135,19 +135,19 @@ class TrainGraph:
         b = self.t[p_b] if p_b is not None else None
         cin, k = w.shape[1], w.shape[2]
         patch = stride == k and pad == 0 and stride > 1
-        if w.shape[2] == w.shape[3]:  # every square kernel, any stride / padding: forward, data- and weight-gradient on the HIP kernels
-            cpad = (-cin) % self.cmul
-            if cpad:  # the 3- / 1-channel images of the stems: zero channels on both operands (the weight's gradient is sliced back)
-                x, w = F.pad(x, (0, cpad)), F.pad(w, (0, 0, 0, 0, 0, cpad))
-            return conv2d_nhwc(x.contiguous(), w, b, stride, pad, self.prec, None, None if cpad else p_w, self.packs)
-        return F.conv2d(x.permute(0, 3, 1, 2), w, b, stride=stride, padding=pad).permute(0, 2, 3, 1).contiguous()
+        assert w.shape[2] == w.shape[3], "square kernels only (every convolution of the model)"
+        # any stride / padding: forward, data- and weight-gradient on the HIP kernels
+        cpad = (-cin) % self.cmul
+        if cpad:  # the 3- / 1-channel images of the stems: zero channels on both operands (the weight's gradient is sliced back)
+            x, w = F.pad(x, (0, cpad)), F.pad(w, (0, 0, 0, 0, 0, cpad))
+        return conv2d_nhwc(x.contiguous(), w, b, stride, pad, self.prec, None, None if cpad else p_w, self.packs)
 
     def bn_l(self, x, p, eps=1e-5, relu=False, out16=True, alias=False):
         """BatchNorm2d (batch statistics) [+ ReLU] on NHWC: the HIP kernels for fp32 rows, F.batch_norm otherwise.  alias: returns (y, x')
         with x' = x for a second consumer of x whose gradient the BatchNorm backward kernel then adds itself (training.BatchNormReLU)."""
         shp = x.shape
         rows = x.reshape(-1, shp[-1])
-        if shp[-1] % 4 == 0 and rows.is_cuda:
+        if shp[-1] % 4 == 0:  # (every BatchNorm of the model; other widths take the library's batch_norm below)
             # mixed precision: 16-bit rows are read as stored (fp32 statistics and arithmetic) and the output is written in the compute
             # type the following convolution reads — no cast passes on either side
             from .training import _TDT
@@ -278,25 +278,6 @@ class TrainGraph:
         c = 2.0 * (torch.arange(Fs, device=dev).float() + 0.5) / Fs - 1.0
         return c.view(1, Fs).expand(Fs, Fs).reshape(-1), c.view(Fs, 1).expand(Fs, Fs).reshape(-1)
 
-    @staticmethod
-    def ball_query(radius, nsample, xyz, new_xyz):
-        """pointnet2_ops.ball_query semantics (first `nsample` indices in index order with d^2 < r^2, unfilled slots repeat the first
-        hit) — indices only, no gradient."""
-        with torch.no_grad():
-            B, N, _ = xyz.shape
-            S = new_xyz.shape[1]
-            d = new_xyz.unsqueeze(2) - xyz.unsqueeze(1)
-            d2 = d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1] + d[..., 2] * d[..., 2]
-            import numpy as np
-            within = d2 < float(np.float32(radius) * np.float32(radius))  # r^2 rounded in fp32 like the extension's kernel
-            rank = torch.cumsum(within.long(), -1) - 1
-            first = torch.argmax(within.long(), -1)
-            idx = (first * within.any(-1).long()).unsqueeze(-1).repeat(1, 1, nsample)
-            sel = within & (rank < nsample)
-            b, s, n = torch.nonzero(sel, as_tuple=True)
-            idx[b, s, rank[b, s, n]] = n
-            return idx
-
     # ---- fusion head (model/model.py:129-351, model/transfusion_head.py:137-173) -----------------------------------------------------------
     def linear_rows(self, rows, w, b, key=None):
         """nn.Linear / Conv1d(k=1) / Conv2d(k=1) over rows [M, Cin] on the HIP GEMM (forward, data- and weight-gradient); input widths
@@ -321,10 +302,8 @@ class TrainGraph:
         B, C = feat.shape[:2]
         N, K = idx.shape[1:]
         rows = feat.permute(0, 2, 3, 1).reshape(B, -1, C)
-        if C % 4 == 0 and rows.is_cuda:
-            return row_gather(rows.float(), idx.int(), clos)
-        g = torch.gather(rows, 1, idx.reshape(B, N * K, 1).expand(-1, -1, C)).view(B, N, K, C)
-        return torch.sum(g * clos.unsqueeze(-1), 2)
+        return row_gather(rows.float(), idx.int(), clos)  # (C % 4 != 0 — the 21 weight-logit channels, detached by the caller — and
+        #                                                    shapes beyond the backward kernel's limits: torch.gather inside row_gather)
 
     @staticmethod
     def pcl_joint2offset(joint, pcl, kernel):
@@ -358,19 +337,17 @@ class TrainGraph:
         xyz = torch.cat((pcl_xyz, node_xyz), 1)
         feat = torch.cat((pcl_feat, node_feat), 1)
         outs = []
-        hip_idx = self.ball_query_hip(pcl_xyz, node_xyz, pcl_feat, node_feat) if (C == 128 and not self.ball_override) else None
+        assert C == 128, "DESA runs on the model's 128-channel features (model/model.py:166-204)"
+        hip_idx = self.ball_query_hip(pcl_xyz, node_xyz, pcl_feat, node_feat)
         for i, r in enumerate((0.1, 0.2, 0.4)):
-            idx = hip_idx[i] if hip_idx is not None else self.ball_query(r, 64, xyz, node_xyz)
-            if self.ball_override:
+            idx = hip_idx[i]
+            if self.ball_override:  # debug hook of the gradient-parity tests only (KPFusion._debug_ball_override, see __init__)
                 given = self.ball_override.pop(0).to(idx.device).long()
-                self.ball_flips += int((given != idx).any(-1).sum())
+                self.ball_flips = self.ball_flips + (given != idx).any(-1).sum()  # a device scalar: no host synchronisation here either
                 idx = given
             flat = idx.reshape(B, Jn * 64)
             gx = torch.gather(xyz, 1, flat.unsqueeze(-1).expand(-1, -1, 3)).view(B, Jn, 64, 3) - node_xyz.unsqueeze(2)
-            if C % 4 == 0 and feat.is_cuda:  # group_points with a deterministic (gather-form) backward
-                gf = row_gather(feat.float(), flat.int().unsqueeze(-1)).view(B, Jn, 64, C) - node_feat.unsqueeze(2)
-            else:
-                gf = torch.gather(feat, 1, flat.unsqueeze(-1).expand(-1, -1, C)).view(B, Jn, 64, C) - node_feat.unsqueeze(2)
+            gf = row_gather(feat.float(), flat.int().unsqueeze(-1)).view(B, Jn, 64, C) - node_feat.unsqueeze(2)  # group_points, gather-form backward
             # the three 1x1 Conv2d + BatchNorm2d of a scale (model/model.py:176-192) on rows [B*J*64, .]
             q = lambda name, k: self.t[p + ".%s.%d%s" % (name, i, k)]
 
@@ -395,12 +372,8 @@ class TrainGraph:
             return self.linear(h, p + ".attention.self.%s.weight" % n, p + ".attention.self.%s.bias" % n)
 
         q, k, v = proj("query"), proj("key"), proj("value")
-        if T == 21 and hd == 32 and h.is_cuda:  # one fused launch per layer (heads read in place, dropout on the probabilities inside)
-            ctx = self.attention(q, k, v, heads, 1.0 / math.sqrt(hd))
-        else:
-            q, k, v = (t.view(B, T, heads, hd).transpose(1, 2) for t in (q, k, v))
-            a = self.drop(torch.softmax(torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(hd), -1))
-            ctx = torch.matmul(a, v).transpose(1, 2).reshape(B, T, C)
+        assert T == 21 and hd == 32, "the fusion head's stacks are 21 tokens x 4 heads x 32 (config/config.json)"
+        ctx = self.attention(q, k, v, heads, 1.0 / math.sqrt(hd))  # one fused launch per layer (heads read in place, dropout on the probabilities inside)
         o = self.drop(self.linear(ctx, p + ".attention.output.dense.weight", p + ".attention.output.dense.bias"))
         h1 = self.ln(o + h, p + ".attention.output.LayerNorm.weight", p + ".attention.output.LayerNorm.bias", 1e-12)
         it = self.gelu(self.linear(h1, p + ".intermediate.dense.weight", p + ".intermediate.dense.bias"))
@@ -426,14 +399,8 @@ class TrainGraph:
         q = linear_hip(qe.contiguous(), W[:C], bqkv[:C], self.prec, None, ipw + ":q", self.packs) * (float(hd) ** -0.5)
         k = linear_hip(ke.contiguous(), W[C:2 * C], bqkv[C:2 * C], self.prec, None, ipw + ":k", self.packs)
         v = linear_hip(ke.contiguous(), W[2 * C:], bqkv[2 * C:], self.prec, None, ipw + ":v", self.packs)
-        if T == 21 and hd == 32 and query.is_cuda:
-            ctx = self.attention(q, k, v, heads, 1.0)  # (q carries the 1/sqrt(hd) factor already: model/transfusion_head.py:468)
-        else:
-            q = q.view(B, T, heads, hd).transpose(1, 2)
-            k = k.view(B, T, heads, hd).transpose(1, 2)
-            v = v.view(B, T, heads, hd).transpose(1, 2)
-            a = self.drop(torch.softmax(torch.matmul(q, k.transpose(-1, -2)), -1))
-            ctx = torch.matmul(a, v).transpose(1, 2).reshape(B, T, C)
+        assert T == 21 and hd == 32
+        ctx = self.attention(q, k, v, heads, 1.0)  # (q carries the 1/sqrt(hd) factor already: model/transfusion_head.py:468)
         o = self.linear(ctx, p + ".multihead_attn.out_proj.weight", p + ".multihead_attn.out_proj.bias")
         x = self.ln(query + self.drop(o), p + ".norm2.weight", p + ".norm2.bias", 1e-5)
         f = self.linear(self.drop(F.relu(self.linear(x, p + ".linear1.weight", p + ".linear1.bias"))), p + ".linear2.weight", p + ".linear2.bias")
@@ -441,7 +408,7 @@ class TrainGraph:
 
     def block(self, p, img_feat, img_feat_rgb, pcl, joint_xyz, clos, idx, img_offset, prev_feat, img_down, center, Minv, cube, cam,
               img_size, flip):
-        from .training import GeomGate, JointHeatmap, joint2heatmap
+        from .training import GeomGate, JointHeatmap
         B, C, H, W = img_feat.shape
         pcl_off = self.pcl_joint2offset(joint_xyz, pcl, 0.8).detach()
         pf = self.gather_interp(img_feat, idx, clos)
@@ -451,19 +418,16 @@ class TrainGraph:
         x = F.relu(x)
         x = F.relu(x + self.emb1d(p + ".pcl_feat_emb_RGB", pf_rgb))
         att = F.softmax(pw.permute(0, 2, 1), -1)
-        jf = bmm_small_k(att, x) if (x.is_cuda and x.shape[-1] % 4 == 0) else torch.matmul(att, x)
+        jf = bmm_small_k(att, x)
         jf = F.relu(self.emb1d(p + ".joint_feat_emb", jf) + self.emb1d(p + ".joint_xyz_emb", joint_xyz.detach()))
         jf = self.desa(p + ".FA", x, jf, pcl, joint_xyz.detach())
         h_init, r3d = self.kp_interaction_tr(p + ".init_TR", jf)
         r3d = r3d.float()  # geometry, heat map and the returned joints are fp32 in every precision
-        hm = JointHeatmap.apply(r3d, 0.8, H, 1.0) if r3d.is_cuda else joint2heatmap(r3d[:, :, :2], 0.8, H, sigma=1)
+        hm = JointHeatmap.apply(r3d, 0.8, H, 1.0)
         # geometry adjacency map (dataloader/loader.py:791-819): the joints go through the uvd -> xyz map again, like the pixels
         ix = self.img_xyz  # pixel positions of the depth map (dataloader/loader.py:936-955): written by kpf_img2pcl_top4_f32, once per forward
         jx = self.uvd2xyz(r3d, center, Minv, cube, cam, img_size, flip)
-        if ix.is_cuda:
-            gam = GeomGate.apply(ix, jx).view(B, J, H, W)
-        else:
-            gam = (1 / (10 * torch.sum(torch.pow(ix.unsqueeze(1) - jx.unsqueeze(2), 2), dim=-1) + 1)).view(B, J, H, W)
+        gam = GeomGate.apply(ix, jx).view(B, J, H, W)
         # Conv2d(128 + 21 -> 21, k = 1) (model/model.py:262,336): rows of 149 channels, input and output channel counts zero-padded to
         # whole quads so that forward, data- and weight-gradient all run on the HIP kernels (fixed summation order)
         sw_in = torch.cat([img_feat_rgb.permute(0, 2, 3, 1).float(), hm.permute(0, 2, 3, 1)], -1).reshape(B * H * W, C + J)
@@ -479,7 +443,7 @@ class TrainGraph:
         wsp = self.t[p + ".fc_spatial2joint_feature.weight"].view(1, 1, -1)
         frows = F.relu(img_feat_rgb.float()).permute(0, 2, 3, 1).reshape(B, H * W, C)
         gw = g.reshape(B, J, H * W) * wsp
-        fj = (bmm_small_k(gw, frows) if (frows.is_cuda and C % 4 == 0) else torch.bmm(gw, frows)) + self.t[p + ".fc_spatial2joint_feature.bias"]
+        fj = bmm_small_k(gw, frows) + self.t[p + ".fc_spatial2joint_feature.bias"]
         if prev_feat is not None:
             fj = F.relu((fj + prev_feat) / 2)
         dec = self.decoder_layer(p + ".crossTR.decoder.3", fj, h_init)
@@ -550,7 +514,8 @@ class TrainGraph:
             result += [r3d, r2d]
             sws.append(sw)
             joint_xyz = r2d
-        self.m.__dict__["_last_ball_flips"] = self.ball_flips
+        if torch.is_tensor(self.ball_flips):  # (debug hook only)
+            self.m.__dict__["_debug_ball_flips"] = self.ball_flips
         if self.nbt:
             torch._foreach_add_(self.nbt, 1)
         if self.pd > 0 and self.m.__dict__.get("_drop_rng") is not None:

@@ -3,14 +3,12 @@ set-up, and autograd Functions that put convolution / Linear forward and data-gr
 forward that uses them is keypointfusion_amd/train_graph.py (reached through `KPFusion.forward` under `.train()`).
 
 What exists here
-  * `joint2offset`      GFM.joint2offset (util/generateFeature.py:59-84): ground-truth offset / heat maps B x 4J x F x F.
-  * `offset2joint_weight`  the differentiable decode of GFM.offset2joint_weight (util/generateFeature.py:166-195) used INSIDE the loss
-                        (train.py:222-223: the coordinate loss back-propagates through the soft-argmax into the dense maps).
-  * `joint2heatmap`     GFM.joint2heatmap (util/generateFeature.py:584-600).
   * `SmoothL1Loss`      model/loss.py:3-26 (quadratic below 0.01, linear above; mean over the last dim, then over the rest).
   * `kpfusion_loss`     the stage-typed schedule of train.py:211-261 (stage_type [1,1,2,3,2,3], coord 100, deconv 1, spatial 10, sigma 3/2);
-                        on CUDA tensors it is ONE autograd node, `FusedLoss` (kpf_dense_loss_* + kpf_loss_tail_*: 4 launches forward,
-                        3 backward); the functions above are its torch restatement (CPU tests, custom l1, other schedules).
+                        ONE autograd node, `FusedLoss` (kpf_dense_loss_* + kpf_loss_tail_*: 4 launches forward, 3 backward), which
+                        computes GFM.joint2offset / offset2joint_weight / joint2heatmap (util/generateFeature.py:59-84,166-195,584-600)
+                        inside the kernels.  There is no library-op fallback: the torch restatement of the codec and of the schedule is
+                        test infrastructure and lives in oracle/train_oracle.py.
   * `make_optimizer`    AdamW(lr 8e-4, wd 0.01) + StepLR(10, 0.1) (train.py:84-91,120; config.py); `FusedAdamW` = the same optimiser
                         stepping all parameters in ~14 launches (kpf_adamw_step_multi), learning rate and step count on the device.
   * `Conv2dNHWC`        torch.autograd.Function: forward and data-gradient on kpf_conv2d_f32 / _h16 (dgrad = the forward kernel on
@@ -39,64 +37,6 @@ STAGE_TYPE = (1, 1, 2, 3, 2, 3)  # config.py: depth backbone, RGB backbone, (RGB
 COORD_WEIGHT, DECONV_WEIGHT = 100.0, 1.0
 SPATIAL_WEIGHT, SPATIAL_EPOCH = (10.0, 10.0, 10.0), (24, 24, 24)
 FEATURE_PARA = 0.8  # kernel size of the 'weight_offset' feature
-
-
-def _pixel_grid(Fs, device):
-    c = 2.0 * (torch.arange(Fs, device=device).float() + 0.5) / Fs - 1.0
-    return c.view(1, Fs).expand(Fs, Fs), c.view(Fs, 1).expand(Fs, Fs)  # u (column), v (row)
-
-
-def joint2offset(joint, img, kernel_size, feature_size):
-    """util/generateFeature.py:59-84.  joint B x J x 3 (normalised uvd), img B x 1 x S x S -> B x 4J x F x F: per joint the unit
-    offset (3 maps) from every pixel's (u, v, depth) to the joint and the closeness heat map, both masked to pixels within
-    `kernel_size` of the joint on the hand (depth < 0.99)."""
-    B = joint.shape[0]
-    Fs = feature_size
-    img = F.interpolate(img, size=[Fs, Fs])
-    J = joint.reshape(B, -1, 3).shape[1]
-    jf = joint.reshape(B, -1, 1, 1).repeat(1, 1, Fs, Fs)
-    u, v = _pixel_grid(Fs, joint.device)
-    coords = torch.stack((u, v), 0).unsqueeze(0).repeat(B, 1, 1, 1)
-    coords = torch.cat((coords, img), 1).repeat(1, J, 1, 1)
-    offset = (jf - coords).view(B, J, 3, Fs, Fs)
-    dist = torch.sqrt(torch.sum(torch.pow(offset, 2), dim=2) + 1e-8)
-    offset_norm = offset / dist.unsqueeze(2)
-    heatmap = (kernel_size - dist) / kernel_size
-    mask = heatmap.ge(0).float() * img.lt(0.99).float().view(B, 1, Fs, Fs)
-    offset_norm_mask = (offset_norm * mask.unsqueeze(2)).view(B, -1, Fs, Fs).float()
-    return torch.cat((offset_norm_mask, heatmap * mask), 1)
-
-
-def offset2joint_weight(offset, depth, kernel_size):
-    """util/generateFeature.py:166-195 with autograd intact (the inference path decodes with kpf_offset2joint_f32; the loss needs the
-    gradient of the soft-argmax).  offset B x 5J x F x F, depth B x 1 x S x S -> B x J x 3."""
-    B, ch, Fs, _ = offset.shape
-    J = ch // 5
-    if depth.shape[-1] != Fs:
-        depth = F.interpolate(depth, size=[Fs, Fs])
-    unit = offset[:, :J * 3].contiguous()
-    heat = offset[:, J * 3:J * 4].contiguous()
-    weight = offset[:, J * 4:].contiguous()
-    u, v = _pixel_grid(Fs, offset.device)
-    coords = torch.stack((u, v), 0).unsqueeze(0).repeat(B, 1, 1, 1)
-    coords = torch.cat((coords, depth), 1).repeat(1, J, 1, 1).view(B, J, 3, -1)
-    mask = depth.lt(0.99).float()
-    offset_mask = (unit * mask).view(B, J, 3, -1)
-    heat_mask = (heat * mask).view(B, J, -1)
-    w = F.softmax(weight.masked_fill(depth.gt(0.99), -1e8).view(B, J, -1), dim=-1)
-    dist = kernel_size - heat_mask * kernel_size
-    return torch.sum((offset_mask * dist.unsqueeze(2).repeat(1, 1, 3, 1) + coords) * w.unsqueeze(2).repeat(1, 1, 3, 1), dim=-1)
-
-
-def joint2heatmap(joint_uv, std, heatmap_size, sigma=1.5):
-    """util/generateFeature.py:584-600: Gaussian of the joint's (u, v) on the pixel-centre grid."""
-    B, J, _ = joint_uv.shape
-    dev = joint_uv.device
-    xs = (torch.arange(heatmap_size, device=dev).float() + 0.5).view(1, 1, 1, heatmap_size).repeat(B, J, heatmap_size, 1)
-    ys = (torch.arange(heatmap_size, device=dev).float() + 0.5).view(1, 1, heatmap_size, 1).repeat(B, J, 1, heatmap_size)
-    jx = ((joint_uv[:, :, 0] + 1) / 2 * heatmap_size).view(B, J, 1, 1).float()
-    jy = ((joint_uv[:, :, 1] + 1) / 2 * heatmap_size).view(B, J, 1, 1).float()
-    return torch.exp(-(torch.pow((xs - jx) / std, 2) + torch.pow((ys - jy) / std, 2)) / (2 * pow(sigma, 2)))
 
 
 class JointHeatmap(torch.autograd.Function):
@@ -235,7 +175,16 @@ class _LayerScaleResidual(torch.autograd.Function):
         return g, dgamma, dy
 
 
+LAYER_SCALE_MAX_C = 1024   # kpf_layer_scale_backward: a lane holds up to 4 channel quads (csrc/kpf_train.hip LN_MAXQ)
+ROW_GATHER_MAX_E = 8192    # kpf_row_gather_bwd_f32: entries (R * G) per image that one workgroup sorts (csrc/kpf_train.hip GATHER_MAX_E)
+ROW_GATHER_MAX_P = 2048    # ... and source rows per image (GATHER_MAX_P)
+
+
 def layer_scale_residual(x, gamma, y):
+    """x + gamma * y.  The backward kernel's limit is checked HERE, before autograd records a node: widths it does not cover (ConvNeXt-L's
+    1536-channel stage) take the library expression forward and backward instead of failing in backward."""
+    if x.shape[-1] > LAYER_SCALE_MAX_C or x.shape[-1] % 4:
+        return x.float() + gamma * y.float()
     return _LayerScaleResidual.apply(x, gamma, y)
 
 
@@ -386,42 +335,10 @@ def kpfusion_loss(results, spatial_weight, img, uvd_gt, xyz_gt, epoch=0, stage_t
             if sw is not None and (torch.is_tensor(epoch) or epoch <= SPATIAL_EPOCH[t]):
                 parts["loss_spatial_%d" % t] = out[9 + t]
         return loss, parts
-    custom_l1 = l1
-    l1 = l1 or SmoothL1Loss()
-    loss = 0
-    parts = {}
-    feature_size = None
-    for index, st in enumerate(stage_type):
-        if st == 1:  # dense stage: pixel-wise maps + decoded joints (both streams decode with the DEPTH image, train.py:221)
-            pixel_pd = results[index]
-            feature_size = pixel_pd.size(-1)
-            if pixel_pd.is_cuda and custom_l1 is None and feature_size * feature_size <= 1024 and img.shape[-1] % feature_size == 0:
-                lp, lc = DenseStageLoss.apply(pixel_pd, img, uvd_gt, FEATURE_PARA)  # the same arithmetic in one HIP kernel each way
-                loss_pixel, loss_coord = lp * DECONV_WEIGHT, lc * COORD_WEIGHT
-            else:
-                pixel_gt = joint2offset(uvd_gt, img, FEATURE_PARA, feature_size)
-                joint_uvd = offset2joint_weight(pixel_pd, img, FEATURE_PARA)
-                loss_pixel = l1(pixel_pd[:, :pixel_gt.size(1)], pixel_gt) * DECONV_WEIGHT
-                loss_coord = l1(joint_uvd, uvd_gt) * COORD_WEIGHT
-            loss = loss + (loss_pixel + loss_coord)
-            parts["loss_pixel_%d" % index], parts["loss_coord_%d" % index] = loss_pixel, loss_coord
-        elif st in (2, 3):
-            loss_coord = l1(results[index], xyz_gt) * COORD_WEIGHT
-            loss = loss + loss_coord
-            parts["loss_coord_%d" % index] = loss_coord
-    for index, sw in enumerate(spatial_weight):
-        # `epoch` may be a device scalar (hipGraph replay: the host-side `if` of train.py:251 would be frozen at capture time);
-        # the spatial term is then multiplied by the gate (epoch <= SPATIAL_EPOCH) on the device
-        on_dev = torch.is_tensor(epoch)
-        if sw is not None and (on_dev or epoch <= SPATIAL_EPOCH[index]):
-            hm_gt = joint2heatmap(uvd_gt[:, :, :2], FEATURE_PARA, feature_size, sigma=3 if index == 0 else 2)
-            gt = hm_gt / hm_gt.max()
-            ls = l1(sw, gt) * SPATIAL_WEIGHT[index]
-            if on_dev:
-                ls = ls * (epoch <= SPATIAL_EPOCH[index]).to(ls.dtype)
-            loss = loss + ls
-            parts["loss_spatial_%d" % index] = ls
-    return loss, parts
+    raise ValueError("kpfusion_loss: the fused HIP loss covers the reference's schedule (train.py:211-261: stage_type %s, the module's "
+                     "SmoothL1Loss, fp32 CUDA tensors, F*F <= 1024 feature maps) and nothing else; got device %s, stage_type %s, custom l1: %s.  "
+                     "(The torch restatement used as its checker lives in oracle/train_oracle.py.)"
+                     % (STAGE_TYPE, results[0].device, tuple(stage_type), l1 is not None))
 
 
 class FusedAdamW(torch.optim.AdamW):
@@ -690,10 +607,16 @@ class DeferredParamGrads:
     active = None
     MAX_ROWS = 1024
 
-    def __init__(self, named_params=None):
-        self.named = named_params
-        self.by_ptr = {p.data_ptr(): p for p in (named_params or {}).values()}
-        self.items, self.colsums, self.seen = [], [], set()
+    def __init__(self, named_params):
+        """named_params: {PackCache key (= parameter name): Parameter} of the parameters whose gradients may be deferred — mandatory:
+        a gradient is only ever deferred for a parameter this map knows, whose `.grad` is None when its backward node runs (so that
+        AccumulateGrad adopts the tensor instead of adding to it), and flush() verifies the adoption of every one of them BEFORE it
+        writes through the recorded addresses."""
+        if named_params is None:
+            raise TypeError("DeferredParamGrads needs the {name: Parameter} map of the parameters it may defer (None defers nothing safely)")
+        self.named = dict(named_params)
+        self.by_ptr = {p.data_ptr(): p for p in self.named.values()}
+        self.items, self.colsums, self.biases, self.seen = [], [], [], set()
 
     def __enter__(self):
         assert DeferredParamGrads.active is None
@@ -705,7 +628,7 @@ class DeferredParamGrads:
         if et is None:
             self.flush()
         else:
-            self.items, self.colsums, self.seen = [], [], set()
+            self.items, self.colsums, self.biases, self.seen = [], [], [], set()
         return False
 
     @staticmethod
@@ -716,7 +639,8 @@ class DeferredParamGrads:
         if g is None:
             return None
         p = g.by_ptr.get(weight.data_ptr())
-        return g if (p is not None and p.numel() == weight.numel()) else None
+        # (a parameter that already holds a gradient would make AccumulateGrad ADD the still-unwritten tensor: not deferred)
+        return g if (p is not None and p.numel() == weight.numel() and p.grad is None) else None
 
     def add_colsum(self, weight, desc, ws, out):
         key = ("colsum", weight.data_ptr())
@@ -730,24 +654,46 @@ class DeferredParamGrads:
         g = DeferredParamGrads.active
         if g is None or cache is None or not isinstance(key, str) or ":" in key:
             return None
+        p = g.named.get(key)
+        if p is None or p.grad is not None:  # unknown to the map, or AccumulateGrad would add instead of adopt: the per-layer kernels
+            return None
         rows = x.numel() // x.shape[-1]
         ok = (kh == 1 and kw == 1 and stride == 1 and pad == 0 and rows <= g.MAX_ROWS and dy.dtype == torch.float32 and x.dtype == torch.float32
               and x.shape[-1] % 4 == 0 and dy.shape[-1] % 4 == 0)
         return g if ok else None
 
-    def add(self, key, dy, x, dw, db):
+    def add(self, key, dy, x, dw, db, bias_ptr=None):
         if key in self.seen:
             raise RuntimeError("DeferredParamGrads: parameter %r receives a second gradient in one backward pass" % (key,))
         self.seen.add(key)
         # (dY, X) stay referenced until flush; of dW / db only the addresses are kept — a second reference would make AccumulateGrad
         # copy the unwritten tensor instead of adopting it
         self.items.append((key, dy, x, dw.data_ptr(), None if db is None else db.data_ptr(), x.numel() // x.shape[-1], dy.shape[-1], x.shape[-1]))
+        if db is not None:
+            self.biases.append((key, bias_ptr, db.data_ptr()))
 
     def flush(self):
         from . import lib as L
-        items, colsums, self.items, self.colsums, self.seen = self.items, self.colsums, [], [], set()
+        items, colsums, biases, self.items, self.colsums, self.biases, self.seen = self.items, self.colsums, self.biases, [], [], [], set()
         if not items and not colsums:
             return
+        # Adoption is verified BEFORE anything is written: the recorded addresses are only valid while the tensors handed to autograd
+        # live on as the parameters' .grad.  If one was copied instead (hook, second reference) its storage may already belong to
+        # someone else: raise without launching.
+        msg = ("DeferredParamGrads: the gradient of %s was copied before it was written (autograd did not adopt the tensor: is the parameter "
+               "hooked, referenced twice, or used twice in one forward?); nothing was written")
+        for key, _, _, pw, _, _, _, _ in items:
+            p = self.named.get(key)
+            if p is None or p.grad is None or p.grad.data_ptr() != pw:
+                raise RuntimeError(msg % repr(key))
+        for _, _, wptr, optr in colsums:
+            p = self.by_ptr.get(wptr)
+            if p is None or p.grad is None or p.grad.data_ptr() != optr:
+                raise RuntimeError(msg % ("a normalisation parameter" if p is None else "a %s normalisation parameter" % (tuple(p.shape),)))
+        for key, bptr, optr in biases:
+            p = self.by_ptr.get(bptr)
+            if p is None or p.grad is None or p.grad.data_ptr() != optr:
+                raise RuntimeError(msg % ("the bias beside %r" % (key,)))
         st = torch.cuda.current_stream().cuda_stream
         if items:
             arr = (L.WgradGroupDesc * len(items))()
@@ -757,17 +703,6 @@ class DeferredParamGrads:
         if colsums:
             arr = (L.ColsumDesc * len(colsums))(*[c[0] for c in colsums])
             L.check(L.load().kpf_colsum_reduce_grouped(arr, len(colsums), st), "kpf_colsum_reduce_grouped")
-        if self.named is not None:
-            msg = ("DeferredParamGrads: the gradient of %s was copied before it was written (autograd did not adopt the tensor: is the parameter outside "
-                   "the optimiser's zero_grad, hooked, or used twice?)")
-            for key, _, _, pw, _, _, _, _ in items:
-                p = self.named.get(key)
-                if p is not None and (p.grad is None or p.grad.data_ptr() != pw):
-                    raise RuntimeError(msg % repr(key))
-            for _, _, wptr, optr in colsums:
-                p = self.by_ptr.get(wptr)
-                if p is not None and (p.grad is None or p.grad.data_ptr() != optr):
-                    raise RuntimeError(msg % ("a %s normalisation parameter" % (tuple(p.shape),)))
 
 
 GroupedLinearWgrad = DeferredParamGrads  # (the name the first form of this class had)
@@ -1203,6 +1138,14 @@ def maxpool3x3s2_nhwc(x):
 
 
 def row_gather(src, idx, w=None):
+    """Weighted row gather (RowGather).  Shapes outside the backward kernel's limits (more than 8192 gathered entries or 2048 source rows per
+    image: 256x256 inputs, > 2048 points) are decided HERE, before autograd records a node, and take torch.gather — whose backward
+    (index_add) is correct but adds with atomics, i.e. is not run-to-run bit-reproducible; the reference's sizes never get there."""
+    B, P, Cc = src.shape
+    _, R, G = idx.shape
+    if R * G > ROW_GATHER_MAX_E or P > ROW_GATHER_MAX_P or Cc % 4:
+        g = torch.gather(src, 1, idx.long().reshape(B, R * G, 1).expand(-1, -1, Cc)).view(B, R, G, Cc)
+        return (g * w.unsqueeze(-1)).sum(2) if w is not None else g.sum(2)
     return RowGather.apply(src, idx, w)
 
 
@@ -1238,6 +1181,7 @@ class Conv2dNHWC(torch.autograd.Function):
         ctx.w16 = w16 if use16 else None
         ctx.x_dtype = x.dtype
         ctx.conf = (stride, pad, patch, bias is not None, prec)
+        ctx.bias_ptr = bias.data_ptr() if bias is not None else None  # (identifies the bias PARAMETER for DeferredParamGrads' adoption check)
         return y
 
     @staticmethod
@@ -1275,11 +1219,15 @@ class Conv2dNHWC(torch.autograd.Function):
             # gradient is not rounded to 16 bits; 16-bit dY / X are read as stored), bias gradient from the same pass
             want_db = has_bias and ctx.needs_input_grad[2]
             grp = DeferredParamGrads.wants(ctx.pack[0], ctx.pack[1], dy, x, KH, KW, stride, pad)
+            if grp is not None and want_db:  # the bias gradient is handed over unwritten too: same conditions as for the weight
+                bp = grp.by_ptr.get(ctx.bias_ptr)
+                if bp is None or bp.numel() != N or bp.grad is not None:
+                    grp = None
             if grp is not None:  # small Linear layer: its weight gradient joins the grouped launch after backward
                 dyc, xc = dy.contiguous(), x.contiguous()
                 dw = torch.empty(tuple(weight.shape), device=x.device, dtype=torch.float32)
                 db = torch.empty(N, device=x.device, dtype=torch.float32) if want_db else None
-                grp.add(ctx.pack[0], dyc, xc, dw, db)
+                grp.add(ctx.pack[0], dyc, xc, dw, db, ctx.bias_ptr if want_db else None)
             else:
                 dw, db = conv_wgrad_hip(dy, x, weight.shape, stride, pad, want_db)
             return dx, dw, db, None, None, None, None, None, None

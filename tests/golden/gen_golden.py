@@ -212,6 +212,14 @@ if __name__ == "__main__":
             continue
         run(net)
         run_backbone(net)
+    # round 4: the remaining families the model constructor accepts (convNeXT/resnetUnet.py:40-45 depths [3,3,27,3] for base — the
+    # network of BASELINE configs[4] —, model/resnetUnet.py for resnet-101): backbones at S=64, and the full model for convnext-base
+    for net in ("KPFusion-convnext-base", "KPFusion-convnext-small", "KPFusion-convnext-large", "KPFusion-resnet-101"):
+        if only and net not in only:
+            continue
+        run_backbone(net)
+    if not only or "KPFusion-convnext-base" in only:
+        run("KPFusion-convnext-base")
     for net in ("KPFusion-convnext-tiny", "KPFusion-convnext-base", "KPFusion-resnet-18", "KPFusion-resnet-50", "KPFusion-resnet-101"):
         if only and net not in only:
             continue

@@ -47,17 +47,21 @@ def test_hip_inverse_equals_torch_linalg_inv_bitwise():
         assert np.array_equal(out.cpu().numpy(), want)
 
 
-def test_unknown_host_library_selects_a_fixed_device_order_and_warns(monkeypatch):
-    """Third branch: a host whose torch.linalg.inv follows neither pinned order.  The device must then use a fixed order
-    and say so — never a host copy of M per forward (that would abort a hipGraph capture)."""
+def test_unknown_host_library_is_reported_and_the_environment_pins_an_order(monkeypatch):
+    """Third branch: a host whose torch.linalg.inv follows neither pinned order.  host_mode() says so (-1, one
+    warning): eager forwards then invert on the host (exact), captured ones use the fixed device order (engine.crop_inverse)."""
     monkeypatch.setattr(I, "_mode", None)
     monkeypatch.setattr(I, "probe_host", lambda: -1)
     monkeypatch.delenv("KPF_INV3X3_MODE", raising=False)
     with pytest.warns(UserWarning, match="neither known 3x3 rounding order"):
-        assert I.host_mode() == 0
+        assert I.host_mode() == -1
     monkeypatch.setattr(I, "_mode", None)
     monkeypatch.setenv("KPF_INV3X3_MODE", "1")
     assert I.host_mode() == 1  # pinned by the environment whatever the host
+    monkeypatch.setattr(I, "_mode", None)
+    monkeypatch.setenv("KPF_INV3X3_MODE", "fused")
+    with pytest.raises(ValueError, match="KPF_INV3X3_MODE"):  # (a raised error, not an assert that `python -O` strips)
+        I.host_mode()
 
 
 @pytest.mark.gpu
@@ -72,7 +76,9 @@ def test_crop_inverse_is_capturable_on_an_unknown_host(monkeypatch):
     Ms = I.crop_matrices(32, seed=8)
     M = torch.from_numpy(Ms).to(dev)
     with pytest.warns(UserWarning):
-        E.crop_inverse(M)
+        eager = E.crop_inverse(M)
+    # eager on such a host: the reference's own call on the host, bit for bit
+    assert np.array_equal(eager.cpu().numpy(), torch.linalg.inv(torch.from_numpy(Ms).view(-1, 1, 3, 3)).view(-1, 3, 3).numpy())
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         out = E.crop_inverse(M)

@@ -469,9 +469,10 @@ def test_dense_stage_loss_kernel_matches_the_torch_codec(seed):
     gt[0, 0] = torch.tensor([3.0, 3.0, 3.0])  # farther than the kernel size from every pixel
     pr = pd.clone().double().requires_grad_(True)
     l1 = T.SmoothL1Loss()
-    pg = T.joint2offset(gt.double(), img.double(), 0.8, 32)
+    from oracle import train_oracle as TO
+    pg = TO.joint2offset(gt.double(), img.double(), 0.8, 32)
     lp_r = l1(pr[:, :84], pg)
-    lc_r = l1(T.offset2joint_weight(pr, img.double(), 0.8), gt.double())
+    lc_r = l1(TO.offset2joint_weight(pr, img.double(), 0.8), gt.double())
     (lp_r * 1.0 + lc_r * 100.0).backward()
     pdd = pd.cuda().requires_grad_(True)
     lp, lc = T.DenseStageLoss.apply(pdd, img.cuda(), gt.cuda(), 0.8)
@@ -484,7 +485,7 @@ def test_dense_stage_loss_kernel_matches_the_torch_codec(seed):
 @pytest.mark.parametrize("epoch", [0, 25, "dev0", "dev25"])
 def test_fused_loss_matches_the_torch_schedule(epoch):
     """training.FusedLoss (the whole loss of train.py:211-261 as one autograd node: kpf_dense_loss_* + kpf_loss_tail_*) against
-    kpfusion_loss's torch restatement in float64 on the CPU (itself pinned to the reference's train_loss.npz): the total, every named
+    oracle/train_oracle.py::kpfusion_loss (the torch restatement) in float64 on the CPU (itself pinned to the reference's train_loss.npz): the total, every named
     term and the gradient of all six results and both spatial weights; host epoch gate (term present / absent) and device epoch gate;
     spatial weights in the permuted [B, H, W, J] memory the model produces."""
     from keypointfusion_amd import training as T
@@ -499,7 +500,8 @@ def test_fused_loss_matches_the_torch_schedule(epoch):
     ep_host = int(epoch[3:]) if isinstance(epoch, str) else epoch
 
     ref_in = [r.clone().double().requires_grad_(True) for r in res + sws]
-    lr, pr = T.kpfusion_loss(ref_in[:6], ref_in[6:], img.double(), uvd.double(), xyz.double(), epoch=ep_host, l1=T.SmoothL1Loss())
+    from oracle import train_oracle as TO
+    lr, pr = TO.kpfusion_loss(ref_in[:6], ref_in[6:], img.double(), uvd.double(), xyz.double(), epoch=ep_host)
     lr.backward()
     dev_in = [r.cuda().requires_grad_(True) for r in res]
     dev_sw = [torch.empty(B, Fs, Fs, J, device="cuda").copy_(s.permute(0, 2, 3, 1)).permute(0, 3, 1, 2).requires_grad_(True) for s in sws]
@@ -679,7 +681,8 @@ def test_joint_heatmap_and_geometry_gate_match_torch():
     uvd = torch.rand(B, J, 3, generator=g) * 2.4 - 1.2
     w = torch.randn(B, J, F_, F_, generator=g)
     ur = uvd.clone().double().requires_grad_(True)
-    hr = T.joint2heatmap(ur[:, :, :2], 0.8, F_, sigma=1)
+    from oracle import train_oracle as TO
+    hr = TO.joint2heatmap(ur[:, :, :2], 0.8, F_, sigma=1)
     (hr * w.double()).sum().backward()
     ud = uvd.cuda().requires_grad_(True)
     hd = T.JointHeatmap.apply(ud, 0.8, F_, 1.0)

@@ -13,7 +13,8 @@ from keypointfusion_amd.spec import kpfusion_spec
 from oracle import kpf_oracle as O
 
 ATOL, RTOL = 2e-5, 1e-4  # fp32 CPU restatement vs reference; integer tensors exact
-NETS = ["convnext-tiny", "resnet-18", "resnet-50"]
+NETS = ["convnext-tiny", "resnet-18", "resnet-50", "convnext-base"]  # full-model fixtures (convnext-base: the network of BASELINE configs[4])
+BACKBONE_NETS = ["convnext-tiny", "convnext-small", "convnext-base", "convnext-large", "resnet-18", "resnet-50", "resnet-101"]
 
 
 def close(a, b, atol=ATOL, rtol=RTOL):
@@ -68,7 +69,7 @@ def test_full_forward_matches_reference_fixture(net):
     assert np.array_equal(sws[1].reshape(2, 21, -1).argmax(-1).numpy(), z["argmax_sw2"])
 
 
-@pytest.mark.parametrize("net", NETS)
+@pytest.mark.parametrize("net", BACKBONE_NETS)
 def test_backbones_other_size(net):
     z = np.load(os.path.join(GOLDEN, "backbone_%s_B1_S64.npz" % net))
     sd = synthetic_sd("KPFusion-" + net)

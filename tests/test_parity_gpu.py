@@ -204,7 +204,7 @@ def test_backbones_match_oracle(net, B, S):
         assert e < 1e-3, "%s: rel err %.2e" % (name, e)  # north_star tolerance
         assert e < 2e-4, "%s: rel err %.2e (regression guard)" % (name, e)
     # against the committed reference-generated fixture as well (S=64 fixture holds full img_offset tensors)
-    if S == 64 and net in ("convnext-tiny", "resnet-18", "resnet-50"):
+    if S == 64:  # (round 4: every family has a fixture — convnext tiny/small/base/large, resnet-18/50/101)
         z = np.load(os.path.join(GOLDEN, "backbone_%s_B1_S64.npz" % net))
         assert rel_err(out[0], torch.from_numpy(z["img_offset"])) < 1e-3
         assert rel_err(out[2], torch.from_numpy(z["img_offset_rgb"])) < 1e-3
@@ -243,7 +243,7 @@ def test_forward_kernel_argument_reaches_only_the_decode():
 
 
 @pytest.mark.parametrize("net,B,seed", [("convnext-tiny", 2, 1), ("resnet-18", 2, 1), ("convnext-tiny", 1, 1), ("convnext-tiny", 3, 7),
-                                        ("resnet-50", 2, 1)])
+                                        ("resnet-50", 2, 1), ("convnext-base", 2, 1)])
 def test_full_forward_matches_oracle(net, B, seed):
     """End-to-end: all 6 results and both spatial weights within 1e-3 relative of the oracle, joints within 0.05 mm.
     The top-4 pixel index tensor must EQUAL the oracle's (asserted inside oracle_with_device_decisions); ball-query sets are taken
