@@ -50,6 +50,7 @@ struct ConvArgs {
   unsigned flags;
   int tilesN, nblk;
   int vec;  // 1: output/residual rows are 16-byte aligned -> float4 epilogue
+  int dbg;  // tuning aid (KPF_G8_DBG, gemm16_8ph_kernel only): 1 = no activation, 2 = no global stores, 4 = no main loop
 };
 
 // GELU(x) = x/2 * (1 + erf(x/sqrt2)) with erfc(z) = t*(a1 + t*(a2 + ...)) * exp(-z^2), t = 1/(1 + p z)  (Abramowitz-Stegun 7.1.26,
@@ -806,6 +807,300 @@ double cfg_cost(const Cfg& c, long M, long N) {
 }
 
 #ifdef KPF_CONV_H16
+// ---------------------------------------------------------------------------------------------------------------------------------
+// gemm16_8ph_kernel: 256 x 256 x 64 tiles, eight phases per two K tiles, for the dense 1x1 layers of the 16-bit path (round 4).
+//
+// The structure of cdna_hip_programming.md's "256^2 8-phase template", written for this library's operands and epilogues:
+//  * 8 waves = 2 (pixel halves, wr) x 4 (channel quarters, wc); a wave owns 128 pixels x 64 channels = 32 accumulator tiles (128 registers), in four
+//    QUADRANTS of 64 pixels x 32 channels; one phase = the 16 MFMAs (v_mfma_f32_16x16x32_{bf16,f16}) of one quadrant over one 64-deep K tile.
+//  * Waves 4-7 run ONE barrier behind waves 0-3 (a stagger): every SIMD hosts one wave of each group, and while one issues its 16 MFMAs the other reads
+//    its fragments from LDS and issues its share of the LDS-DMA — the matrix pipe of a SIMD alternates between its two waves and never waits for a read.
+//  * Two K-tile buffers of 64 KB; a K tile is staged as four 16-KB HALF-TILES, one per phase, each = the rows one phase reads: A half s = pixel rows
+//    {wr*128 + s*64 + [0,64)} of both wr, B half s = channels {wc*64 + s*32 + [0,32)} of all four wc (the LDS row <-> tile row permutation lives in the
+//    DMA's source addresses).  A half-tile is re-staged two phases after its last read (one phase after for the B half whose reads a counted
+//    lgkmcnt(8) retires before the barrier), so three half-tiles are always in flight; the only vmcnt in the loop is a counted vmcnt(6) once per K
+//    tile, four phases before the first read of the data it covers.  LDS image and XOR swizzle are the ones igemm_body uses (128-byte rows, 16-byte
+//    chunk c of row r at c ^ ((r >> 1) & 7): conflict-free ds_read_b128 fragments), so both kernels read the same packed weights.
+//  Schedule of K tile t (buffer b = t & 1), per wave:
+//    q1: read B-sub0 (4 x b128) then A-sub0 (8) | DMA A-half1 of tile t+1 -> buffer b^1 | lgkmcnt(8) | barrier | 16 MFMA quadrant (0,0) | barrier
+//    q2: read B-sub1 (4)                         | DMA B-half0 of tile t+2 -> buffer b                 | barrier | 16 MFMA quadrant (0,1) | barrier
+//    q3: read A-sub1 (8)                         | DMA A-half0 of tile t+2 -> buffer b                 | barrier | 16 MFMA quadrant (1,1) | barrier
+//    q4:                                           DMA B-half1 of tile t+2 -> buffer b | vmcnt(6)      | barrier | 16 MFMA quadrant (1,0) | barrier
+//  Requirements (the dispatcher checks them): dense 1x1, K % 128 == 0 (an even number of K tiles), N % 256 == 0, 16-byte aligned rows.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int G8_BUF = 65536, G8_HALF = 16384, G8_B = 32768;  // bytes: K-tile buffer, half-tile, offset of the B halves inside a buffer
+template <int V> using ic = std::integral_constant<int, V>;
+
+// GELU for 16-bit outputs: x * sigmoid(x (c1 + c3 x^2 + c5 x^4)), a minimax fit of x Phi(x) with |error| <= 2.6e-5 absolute over the whole real line
+// (tools/gelu_fit.py) — below half an f16 ulp wherever |gelu| >= 0.06 and 30 x below a bf16 ulp — in 9 VALU operations (2 transcendental) where the
+// fp32-accurate form above takes 14: on a K = 512 layer the GELU of a 256 x 256 tile is a third of the tile's time.
+__device__ __forceinline__ float gelu_h16(float x) {
+  const float x2 = x * x;
+  const float p = x * fmaf(x2, fmaf(x2, -7.03033577e-04f, 7.40112920e-02f), 1.59501577f);
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * p);
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+template <int EPI, int ARITH>
+__global__ __launch_bounds__(512, 2) void gemm16_8ph_kernel(const ConvArgs a) {
+  using TH = typename std::conditional<ARITH == ARITH_BF16, bf16_t, f16_t>::type;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* const LB = reinterpret_cast<char*>(lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  int bid = blockIdx.x;
+  {  // XCD-aware bijective remap (igemm_body): an XCD gets a contiguous range of tiles, channel tiles fastest
+    const int nb = a.nblk, q = nb >> 3, r = nb & 7, x = bid & 7, i = bid >> 3;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+  }
+  const int nt = bid % a.tilesN, mt = bid / a.tilesN;
+  const int m0 = mt * 256, n0 = nt * 256;
+
+  // ---- staging: thread -> (row lr of a 64-row DMA block, chunk position cp); a half-tile is two DMA instructions per wave ----
+  const int lr = tid >> 3, cp = tid & 7;
+  const int kc = ((cp ^ ((lr >> 1) & 7)) << 2);  // logical k offset (4-byte words) this lane fetches: the swizzle is applied to the SOURCE
+  const float* pa[2][2];
+  const float* pb[2][2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int m = m0 + i * 128 + s * 64 + lr;  // LDS row i*64 + lr of A half s
+      m = m < a.M ? m : a.M - 1;           // (rows beyond M: products land in accumulators that are never stored)
+      pa[s][i] = a.in + (long)m * a.in_ld + a.in_coff + kc;
+      const int n = n0 + (2 * i + (lr >> 5)) * 64 + s * 32 + (lr & 31);  // LDS row i*64 + lr of B half s
+      pb[s][i] = a.w + (long)n * a.Kp + kc;
+    }
+  const int dma_row = wave * 8 * 128;  // this wave's 8 rows of a 64-row DMA block (bytes)
+  auto stage_A = [&](auto BUF, auto S, int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(pa[decltype(S)::value][i] + kt * BK),
+                                       (lds_void_t*)(LB + decltype(BUF)::value * G8_BUF + decltype(S)::value * G8_HALF + i * 8192 + dma_row), 16, 0, 0);
+  };
+  auto stage_B = [&](auto BUF, auto S, int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(pb[decltype(S)::value][i] + kt * BK),
+                                       (lds_void_t*)(LB + decltype(BUF)::value * G8_BUF + G8_B + decltype(S)::value * G8_HALF + i * 8192 + dma_row), 16, 0, 0);
+  };
+
+  // ---- fragments ----
+  const int fr = lane & 15, fg = lane >> 4, rsw = (fr >> 1) & 7;
+  const int ch0 = ((fg ^ rsw) << 4), ch1 = (((4 + fg) ^ rsw) << 4);  // byte offsets of this lane's chunk in k-step 0 / 1 of a row
+  const char* const a_rd = LB + (wr * 64 + fr) * 128;
+  const char* const b_rd = LB + G8_B + (wc * 32 + fr) * 128;
+  f16x8 xa[2][4];     // [k-step][pixel tile]      of the current A sub-tile
+  f16x8 wb[2][2][2];  // [sub][k-step][channel tile]
+  f32x4 acc[2][2][2][4];  // [channel sub][channel tile][pixel sub][pixel tile]
+#pragma unroll
+  for (int i = 0; i < 16; ++i) (&acc[0][0][0][0])[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 16; i < 32; ++i) (&acc[0][0][0][0])[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto read_A = [&](auto BUF, auto S) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      xa[0][j] = *reinterpret_cast<const f16x8*>(a_rd + decltype(BUF)::value * G8_BUF + decltype(S)::value * G8_HALF + j * 2048 + ch0);
+      xa[1][j] = *reinterpret_cast<const f16x8*>(a_rd + decltype(BUF)::value * G8_BUF + decltype(S)::value * G8_HALF + j * 2048 + ch1);
+    }
+  };
+  auto read_B = [&](auto BUF, auto S) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      wb[decltype(S)::value][0][i] = *reinterpret_cast<const f16x8*>(b_rd + decltype(BUF)::value * G8_BUF + decltype(S)::value * G8_HALF + i * 2048 + ch0);
+      wb[decltype(S)::value][1][i] = *reinterpret_cast<const f16x8*>(b_rd + decltype(BUF)::value * G8_BUF + decltype(S)::value * G8_HALF + i * 2048 + ch1);
+    }
+  };
+  auto mma = [&](auto SM, auto SN) {
+    constexpr int sm = decltype(SM)::value, sn = decltype(SN)::value;
+    __builtin_amdgcn_s_setprio(1);  // (keeps hipcc from moving the cluster across the barriers: cdna_hip_programming T5)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if constexpr (ARITH == ARITH_BF16)
+            acc[sn][i][sm][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wb[sn][ks][i]), __builtin_bit_cast(bf16x8, xa[ks][j]), acc[sn][i][sm][j], 0, 0, 0);
+          else
+            acc[sn][i][sm][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[sn][ks][i], xa[ks][j], acc[sn][i][sm][j], 0, 0, 0);
+        }
+    __builtin_amdgcn_s_setprio(0);
+  };
+#define G8_BAR() __builtin_amdgcn_s_barrier()
+#define G8_FENCE() __builtin_amdgcn_sched_barrier(0)
+  // one K tile = four phases; ST1: tile t+1 exists (its A half 1 is staged here), ST2: tile t+2 exists
+  auto ktile = [&](auto BUF, auto ST1, auto ST2, int t) {
+    constexpr int B = decltype(BUF)::value;
+    constexpr bool st1 = decltype(ST1)::value != 0, st2 = decltype(ST2)::value != 0;
+    // q1
+    read_B(ic<B>{}, ic<0>{});
+    G8_FENCE();  // (issue order pinned: the lgkmcnt(8) below must retire exactly the four B reads)
+    read_A(ic<B>{}, ic<0>{});
+    if constexpr (st1) stage_A(ic<B ^ 1>{}, ic<1>{}, t + 1);
+    G8_FENCE();
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // B-sub0 is in registers: B half 0 of this buffer may be re-staged in the NEXT phase
+    G8_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    G8_FENCE();
+    mma(ic<0>{}, ic<0>{});
+    G8_FENCE();
+    G8_BAR();
+    // q2
+    read_B(ic<B>{}, ic<1>{});
+    if constexpr (st2) stage_B(ic<B>{}, ic<0>{}, t + 2);
+    G8_FENCE();
+    G8_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    G8_FENCE();
+    mma(ic<0>{}, ic<1>{});
+    G8_FENCE();
+    G8_BAR();
+    // q3
+    read_A(ic<B>{}, ic<1>{});
+    if constexpr (st2) stage_A(ic<B>{}, ic<0>{}, t + 2);
+    G8_FENCE();
+    G8_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    G8_FENCE();
+    mma(ic<1>{}, ic<1>{});
+    G8_FENCE();
+    G8_BAR();
+    // q4: the wait that retires tile t+1 (first read one phase later, behind two more barriers)
+    if constexpr (st2) {
+      stage_B(ic<B>{}, ic<1>{}, t + 2);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else if constexpr (st1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    G8_FENCE();
+    G8_BAR();
+    G8_FENCE();
+    mma(ic<1>{}, ic<0>{});
+    G8_FENCE();
+    G8_BAR();
+  };
+
+  const int nk = a.Kp / BK;  // even, >= 2
+  stage_B(ic<0>{}, ic<0>{}, 0);
+  stage_A(ic<0>{}, ic<0>{}, 0);
+  stage_B(ic<0>{}, ic<1>{}, 0);
+  stage_A(ic<0>{}, ic<1>{}, 0);
+  stage_B(ic<1>{}, ic<0>{}, 1);
+  stage_A(ic<1>{}, ic<0>{}, 1);
+  stage_B(ic<1>{}, ic<1>{}, 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // tile 0 has landed (this wave's part; the barrier makes it everyone's)
+  G8_BAR();
+  if (wr == 1) G8_BAR();  // the stagger: waves 4-7 run one barrier behind
+  int t = (a.dbg & 4) ? nk - 2 : 0;
+  for (; t + 3 < nk; t += 2) {
+    ktile(ic<0>{}, ic<1>{}, ic<1>{}, t);
+    ktile(ic<1>{}, ic<1>{}, ic<1>{}, t + 1);
+  }
+  ktile(ic<0>{}, ic<1>{}, ic<0>{}, t);
+  ktile(ic<1>{}, ic<0>{}, ic<0>{}, t + 1);
+  if (wr == 0) G8_BAR();  // (both groups have executed the same number of barriers; nobody reads the K buffers any more)
+#undef G8_BAR
+#undef G8_FENCE
+
+  // ---- epilogue: lane (fr, fg) holds channels 4 fg .. 4 fg + 3 of channel tile (sn, i) for pixel fr of pixel tile (sm, j) ----
+  const unsigned fl = a.flags;
+  f32x4 bvv[2][2], gvv[2][2];
+#pragma unroll
+  for (int sn = 0; sn < 2; ++sn)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int n = n0 + wc * 64 + sn * 32 + i * 16 + fg * 4;
+      bvv[sn][i] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+      gvv[sn][i] = (EPI == EPI_RES && (fl & KPF_RES_GAMMA)) ? *reinterpret_cast<const f32x4*>(a.gamma + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  if constexpr (EPI == EPI_RES) {
+    // residual layers (pwconv2): the skip rows are read in the accumulator layout, all rows of a pixel sub-tile requested before its first store
+    TH* const ob = reinterpret_cast<TH*>(a.out);
+    const TH* const rb = reinterpret_cast<const TH*>(a.res);
+#pragma unroll
+    for (int sm = 0; sm < 2; ++sm) {
+      f32x4 rv[4][2][2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const long m = m0 + wr * 128 + sm * 64 + j * 16 + fr;
+        const long mr = m < a.M ? m : a.M - 1;
+#pragma unroll
+        for (int sn = 0; sn < 2; ++sn)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) rv[j][sn][i] = kpf_ld4(rb + mr * a.res_ld + a.res_coff + n0 + wc * 64 + sn * 32 + i * 16 + fg * 4);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const long m = m0 + wr * 128 + sm * 64 + j * 16 + fr;
+#pragma unroll
+        for (int sn = 0; sn < 2; ++sn)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            f32x4 v = acc[sn][i][sm][j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float y = v[e] + bvv[sn][i][e];
+              if (fl & KPF_RES_GAMMA) y *= gvv[sn][i][e];
+              y += rv[j][sn][i][e];
+              if (fl & KPF_RELU_AFTER_RES) y = fmaxf(y, 0.f);
+              v[e] = y;
+            }
+            if (m < a.M) kpf_st4(ob + m * a.out_ld + a.out_coff + n0 + wc * 64 + sn * 32 + i * 16 + fg * 4, v);
+          }
+      }
+    }
+  } else {
+    // linear / ReLU / GELU: results go through a per-wave LDS staging area ([128 pixels][64 channels], 144-byte rows) so that the global stores are whole
+    // 128-byte rows (8 lanes x 16 bytes), 8 rows per instruction
+    constexpr int RS = 72;  // staging row stride in elements
+    TH* const stg = reinterpret_cast<TH*>(LB) + wave * 128 * RS;
+#pragma unroll
+    for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int sn = 0; sn < 2; ++sn)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            f32x4 v = acc[sn][i][sm][j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float y = v[e] + bvv[sn][i][e];
+              if (EPI == EPI_GELU) v[e] = (a.dbg & 1) ? y : gelu_h16(y);
+              else v[e] = (fl & KPF_ACT_RELU) ? fmaxf(y, 0.f) : ((fl & KPF_ACT_LEAKY) ? fmaxf(y, 0.01f * y) : y);
+            }
+            kpf_st4(stg + (sm * 64 + j * 16 + fr) * RS + sn * 32 + i * 16 + fg * 4, v);
+          }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (own region only: no barrier)
+    TH* const ob = reinterpret_cast<TH*>(a.out) + (long)(m0 + wr * 128) * a.out_ld + a.out_coff + n0 + wc * 64;
+    const int prow = lane >> 3, pch = (lane & 7) * 8;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int px = r * 8 + prow;
+      const f32x4 q = *reinterpret_cast<const f32x4*>(stg + px * RS + pch);
+      if (m0 + wr * 128 + px < a.M && !(a.dbg & 2)) *reinterpret_cast<f32x4*>(ob + (long)px * a.out_ld + pch) = q;
+    }
+  }
+}
+
+template <int ARITH>
+int launch_8ph(ConvArgs& a, hipStream_t st) {
+  const bool res = a.flags & KPF_RES_ADD, gelu = a.flags & KPF_ACT_GELU;
+  a.tilesN = a.N / 256;
+  a.nblk = ((a.M + 255) / 256) * a.tilesN;
+  void (*kern)(const ConvArgs) = res ? gemm16_8ph_kernel<EPI_RES, ARITH> : (gelu ? gemm16_8ph_kernel<EPI_GELU, ARITH> : gemm16_8ph_kernel<EPI_LIN, ARITH>);
+  static std::atomic<bool> lds_opt_in[3][KPF_MAX_DEVICES];
+  if (!kpf_raise_lds_limit(reinterpret_cast<const void*>(kern), lds_opt_in[res ? 2 : (gelu ? 1 : 0)])) {
+    kpf_set_error("kpf_conv2d_h16: cannot raise the dynamic LDS limit");
+    return KPF_ELAUNCH;
+  }
+  const size_t lds = res ? 2 * G8_BUF : (8 * 128 * 72 * 2 > 2 * G8_BUF ? 8 * 128 * 72 * 2 : 2 * G8_BUF);  // K buffers (128 KB) / staging area (144 KB)
+  hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(512), lds, st, a);
+  return kpf_check_launch("kpf_conv2d_h16");
+}
+
 // ---- 16-bit storage path (kpf_conv16.hip compiles this file with KPF_CONV_H16) ----
 template <int TM, int TN, int WM, int WN, int ARITH, int NS>
 int launch_arith_h16(ConvArgs& a, bool fast1x1, bool pointwise, hipStream_t st) {
@@ -891,6 +1186,10 @@ extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void
   }
   a.flags = fl; a.tilesN = 0; a.nblk = 0; a.w_unscale = 1.0f;
   a.vec = (d->out_ld % 4 == 0 && d->out_coff % 4 == 0 && (!(fl & KPF_RES_ADD) || (d->res_ld % 4 == 0 && d->res_coff % 4 == 0))) ? 1 : 0;
+  {
+    static const int dbg = []() { const char* e = getenv("KPF_G8_DBG"); return e ? atoi(e) : 0; }();
+    a.dbg = dbg;
+  }
   const bool pointwise = d->KH == 1 && d->KW == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0 && d->IH == d->OH && d->IW == d->OW;
   const bool fast1x1 = pointwise && d->Cin % 64 == 0 && d->Kp == d->Cin;  // whole 64-element K tiles, no K mask
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -912,8 +1211,14 @@ extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void
   // 256 x 256 tiles, 8 waves of 128 x 64 (the geometry of cdna_hip_programming's 256^2 template, two-phase loop, s_setprio around the
   // MFMA cluster): +24 % over case 20 on 65536 x 512 x 2048 (841 vs 679 TFLOP/s), 1049 vs 935 on 16384 x 1024 x 4096
   if ((fl & KPF_RES_ADD) && fast1x1 && a.Kp * 2 >= 2048 && a.M >= 16384 && a.N >= 256 && a.N % 256 == 0) best = 26;
+  // Round 4: the eight-phase 256 x 256 kernel (gemm16_8ph_kernel) for every dense 1x1 layer it covers with at least one full round of tiles
+  const bool ok8 = fast1x1 && d->Kp % 128 == 0 && a.N % 256 == 0 && !pro_scale && !(fl & KPF_OUT_NCHW) && a.vec && d->out_ld % 8 == 0 && d->out_coff % 8 == 0 &&
+                   (!(fl & KPF_RES_ADD) || (d->res_ld % 4 == 0 && d->res_coff % 4 == 0));
+  static const bool no8 = getenv("KPF_NO_8PH") != nullptr;  // tuning aid: A/B against the round-3 tile shapes
+  if (ok8 && !no8 && (long)((a.M + 255) / 256) * (a.N / 256) >= 224) best = 30;
   static const int forced = []() { const char* e = getenv("KPF_FORCE_CFG16"); return e ? atoi(e) : -1; }();  // tuning aid only
-  if (forced >= 0) best = forced;
+  if (forced >= 0 && (forced != 30 || ok8)) best = forced;
+  if (best == 30) return dtype == KPF_DT_BF16 ? launch_8ph<ARITH_BF16>(a, st) : launch_8ph<ARITH_F16>(a, st);
   switch (best) {
     case 0: return occ ? launch_cfg_h16<4, 4, 2, 2, 1>(a, fast1x1, pointwise, dtype, st) : launch_cfg_h16<4, 4, 2, 2, 2>(a, fast1x1, pointwise, dtype, st);
     case 1: return launch_cfg_h16<4, 3, 2, 2, 2>(a, fast1x1, pointwise, dtype, st);  // 128 x 96
@@ -974,7 +1279,7 @@ extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const flo
     }
     a.zero = zero_of_dev[dev];
   }
-  a.flags = fl; a.tilesN = 0; a.nblk = 0;
+  a.flags = fl; a.tilesN = 0; a.nblk = 0; a.dbg = 0;
   a.w_unscale = (fl & (KPF_IN_SPLIT | KPF_W_SPLIT)) ? d->w_unscale : 1.0f;
   if (fl & (KPF_IN_SPLIT | KPF_W_SPLIT))
     KPF_REQUIRE(d->w_unscale > 0.f && d->Cin % 32 == 0 && d->in_coff % 4 == 0, "kpf_conv2d_f32: split operands need w_unscale > 0 and Cin %% 32 == 0 (Cin=%d)", d->Cin);
