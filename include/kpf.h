@@ -106,6 +106,15 @@ int kpf_convnext_mlp_split_f32(const float* y_split, const float* x, const float
                                const float* w2_split_perm, const float* b2, float w2_unscale, const float* gamma, float* out, long M,
                                int C, void* stream);
 int kpf_convnext_mlp_split_supported(int C);
+/* The same block on 16-bit storage (round 4; replaces the kpf_conv2d_h16 pair pwconv1 + GELU / pwconv2 + layer scale + residual of
+ * convNeXT/convnext.py:44-51 where the hidden tensor's HBM round trip dominates — C = 128 / 256, the first two stages of ConvNeXt-B): y, x,
+ * out [M][C] and w1 [4C][C] in the storage type `dtype` (KPF_DT_BF16 / KPF_DT_F16), fp32 biases and layer scale, fp32 accumulation and
+ * arithmetic, one rounding of the result.  w2_chunks is pwconv2's weight [C][4C] repacked chunk-major, [4C/32][C][32], with the hidden index
+ * inside each 32-block in the order k = 8g + j -> hidden 16*(j>>2) + 4g + (j&3) (the order of kpf_convnext_mlp_split_f32).  GELU is evaluated as
+ * x * sigmoid(x (c1 + c3 x^2 + c5 x^4)), |error| <= 2.6e-5 absolute: below the rounding of a 16-bit result.  out may alias x. */
+int kpf_convnext_mlp_h16(const void* y, const void* x, const void* w1, const float* b1, const void* w2_chunks, const float* b2,
+                         const float* gamma, void* out, long M, int C, int dtype, void* stream);
+int kpf_convnext_mlp_h16_supported(int C);
 
 /*
  * LayerNorm over the channel dimension of `rows` pixels (biased variance, (x-u)/sqrt(var+eps)*w+b).
@@ -486,7 +495,7 @@ int kpf_conv_num_tile_cfgs(void);
 const char* kpf_last_error(void);
 /* Library/ABI version, bumped when a signature or the meaning of an argument changes (KPF_ABI_VERSION is what this header
  * describes; the Python binding refuses a library that reports another). */
-#define KPF_ABI_VERSION 11
+#define KPF_ABI_VERSION 12
 int kpf_abi_version(void);
 
 #ifdef __cplusplus

@@ -17,6 +17,7 @@
 //     ds_read_b128 fragment reads of 16 consecutive rows hit 16 different bank groups.
 #include "kpf_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -381,6 +382,229 @@ __global__ __launch_bounds__(64 * NW) void convnext_mlp_split_kernel(const MlpSp
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// 16-bit storage (bf16 / f16 activations and weights, fp32 accumulate): kpf_convnext_mlp_h16 (round 4).
+//
+// The stage-1/2 blocks of ConvNeXt-B at 512^2 (C = 128 / 256, 10^6 / 2.6 10^5 pixels) are HBM-bound as two GEMM launches: the 4C-wide hidden
+// tensor is written and read back (2.1 GB per block at C = 128 against 0.8 GB for y, x and out together), and the ablation of the
+// eight-phase GEMM (profiles/r04_g8_ablation.txt) shows that a tile's stores cannot be hidden behind its own matrix work.  Fused, the
+// hidden tensor never leaves registers — same dataflow as convnext_mlp_split_kernel above, one MFMA per product:
+//   * 4 waves per workgroup, two workgroups per CU (<= 256 registers, <= 80 KB of LDS): one workgroup's GELU (vector ALU), prologue and
+//     epilogue run under the other's MFMAs; a wave owns PT pixel tiles of 16 for ALL hidden and output channels.
+//   * y fragments come straight from global memory once per tile and stay in registers; the LDS holds only the weight ring: chunks of 32
+//     hidden units = [32 x C] rows of W1 + [C x 32] of W2 (chunk-major, hidden order permuted per 32-block exactly like the split kernel's:
+//     k-slot 8g + j <-> hidden 16 (j >> 2) + 4g + (j & 3)), R stages filled by LDS-DMA with a counted vmcnt (R - 2 chunks stay in flight
+//     across the one raw barrier per chunk); every weight fragment read feeds PT MFMAs.
+//   * per chunk and wave: GEMM1 2 x PT x C/32 MFMAs -> bias + GELU on 8 PT registers -> packed in place as GEMM2's B operand -> C/16 x PT MFMAs.
+//   * epilogue: out = x + gamma * (acc + b2) in fp32 (x read in the accumulator layout), rounded once, staged through the wave's share of
+//     the idle ring so that the global stores are whole 2C-byte rows.
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct Mlp16Args {
+  const void* y;     // [M][C] LayerNorm output, 16-bit
+  const void* x;     // [M][C] block input (residual), 16-bit
+  const void* w1;    // [4C][C] 16-bit
+  const float* b1;
+  const void* w2c;   // [4C/32][C][32] 16-bit: chunk-major, permuted hidden order inside a chunk
+  const float* b2;
+  const float* gamma;
+  void* out;         // [M][C] 16-bit (may alias x)
+  int M;
+};
+
+__device__ __forceinline__ float gelu_h16m(float x) {  // x * sigmoid(x (c1 + c3 x^2 + c5 x^4)): |error| <= 2.6e-5 (kpf_conv.hip gelu_h16, tools/gelu_fit.py)
+  const float x2 = x * x;
+  const float p = x * fmaf(x2, fmaf(x2, -7.03033577e-04f, 7.40112920e-02f), 1.59501577f);
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * p);
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+template <int C, int PT, int R, bool BF>
+__global__ __launch_bounds__(256, 2) void convnext_mlp_h16_kernel(const Mlp16Args a) {
+  using TH = typename std::conditional<BF, bf16_t, f16_t>::type;
+  constexpr int NW = 4, NT = 256;
+  constexpr int KC = C / 32;        // K steps of GEMM1
+  constexpr int NCT = C / 16;       // output-channel tiles of GEMM2
+  constexpr int NCH = 4 * C / 32;   // chunks of 32 hidden units
+  constexpr int W1B = 32 * C * 2;   // bytes of a chunk's W1 rows (32 rows of 2C bytes)
+  constexpr int W2B = C * 64;       // bytes of a chunk's W2 rows (C rows of 64 bytes)
+  constexpr int CHB = W1B + W2B;    // one ring stage
+  constexpr int G = CHB / (NT * 16);  // DMA instructions per wave per chunk
+  constexpr int RC1 = C / 8;        // 16-byte chunks per W1 row
+  constexpr int BM = 16 * PT * NW;
+  static_assert(C % 128 == 0 && R >= 2 && R <= 4 && W1B % (NT * 16) == 0 && W2B % (NT * 16) == 0, "shape");
+
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* const LB = reinterpret_cast<char*>(lds);
+  float* const B1s = reinterpret_cast<float*>(LB + R * CHB);
+  float* const B2s = B1s + 4 * C;
+  float* const Gs = B2s + C;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const long m0 = (long)blockIdx.x * BM;
+
+  // ---- this lane's y fragments (B operand of GEMM1: k = 32 ks + 8 fg .. + 7 of pixel fr), once per tile, and the small tables ----
+  f16x8 yf[KC][PT];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    long m = m0 + (wave * PT + pt) * 16 + fr;
+    m = m < a.M ? m : a.M - 1;  // (rows beyond M repeat the last row; their results are never stored)
+    const TH* yrow = reinterpret_cast<const TH*>(a.y) + m * C + 8 * fg;
+#pragma unroll
+    for (int ks = 0; ks < KC; ++ks) yf[ks][pt] = *reinterpret_cast<const f16x8*>(yrow + 32 * ks);
+  }
+  for (int i = tid; i < 4 * C; i += NT) B1s[i] = a.b1[i];
+  for (int i = tid; i < C; i += NT) {
+    B2s[i] = a.b2[i];
+    Gs[i] = a.gamma[i];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ordinary loads are done before the first LDS-DMA is issued: from here on vmcnt counts DMAs only
+
+  // ---- weight ring ----
+  // W1 image: row r (0..31) of 2C bytes, 16-byte chunk c at position c ^ (r & 15) (low four bits); W2 image: row r (0..C-1) of 64 bytes, chunk c at
+  // c ^ ((r >> 2) & 3).  The DMA writes LDS linearly, so the permutation is applied to each lane's SOURCE address.
+  const TH* const w1g = reinterpret_cast<const TH*>(a.w1);
+  const TH* const w2g = reinterpret_cast<const TH*>(a.w2c);
+  // element offsets of this lane's sources inside a chunk: pass p moves LDS slots p * 256 + tid.  W1 (rows of RC1 chunks): row r = p * 256 / RC1 +
+  // tid / RC1, so with RC1 = 16 the swizzle term (r & 15) does not depend on p, with RC1 = 32 it alternates between two values; W2 (4 chunks per row):
+  // row r = 64 p + tid / 4 and ((r >> 2) & 3) does not depend on p.  So one or two offsets per image plus compile-time strides.
+  constexpr int P1 = W1B / (NT * 16), P2 = W2B / (NT * 16), RPP1 = NT / RC1;  // passes; W1 rows per pass
+  const int r1 = tid / RC1, cp1 = tid % RC1;
+  const int s1a = r1 * C + 8 * (cp1 ^ (r1 & 15)), s1b = r1 * C + 8 * (cp1 ^ ((r1 + RPP1) & 15));  // even / odd passes (equal when RPP1 = 16)
+  const int s2 = (tid >> 2) * 32 + 8 * ((tid & 3) ^ ((tid >> 4) & 3));
+  auto stage = [&](int ch, int slot) {
+    char* dst = LB + slot * CHB + wave * 1024;
+    const TH* const g1 = w1g + (long)ch * 32 * C;
+    const TH* const g2 = w2g + (long)ch * C * 32;
+#pragma unroll
+    for (int p = 0; p < P1; ++p)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(g1 + ((p & 1) ? s1b : s1a) + p * RPP1 * C), (lds_void_t*)(dst + p * NT * 16), 16, 0, 0);
+#pragma unroll
+    for (int p = 0; p < P2; ++p)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(g2 + s2 + p * 64 * 32), (lds_void_t*)(dst + W1B + p * NT * 16), 16, 0, 0);
+  };
+#pragma unroll
+  for (int c = 0; c < R - 1; ++c) stage(c, c);
+
+  f32x4 acc[NCT][PT];
+#pragma unroll
+  for (int n = 0; n < NCT; ++n)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) acc[n][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // fragment read offsets (bytes inside a stage): W1 row 16 ht + fr, chunk (4 ks + fg) ^ fr; W2 row 16 ct + fr, chunk fg ^ ((fr >> 2) & 3)
+  const int w1_rd = fr * (2 * C), w2_rd = W1B + fr * 64 + ((fg ^ ((fr >> 2) & 3)) << 4);
+
+  auto chunk = [&](int ch, auto SLOT) {
+    constexpr int slot = decltype(SLOT)::value;
+    // chunk ch has landed once at most the younger chunks' DMAs are outstanding: R - 2 in steady state, fewer at the tail
+    const int younger = NCH - 1 - ch;
+    if (younger >= R - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * G) : "memory");
+    else if (R > 3 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // everyone's part of chunk ch is in LDS; everyone has finished reading chunk ch - 1's stage
+    if (ch + R - 1 < NCH) stage(ch + R - 1, (slot + R - 1) % R);
+    const char* const sb = LB + slot * CHB;
+    f32x4 d1[2][PT];
+#pragma unroll
+    for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) d1[ht][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KC; ++ks)
+#pragma unroll
+      for (int ht = 0; ht < 2; ++ht) {
+        const f16x8 w = *reinterpret_cast<const f16x8*>(sb + w1_rd + ht * 16 * (2 * C) + ((((4 * ks + fg) ^ fr) & (RC1 - 1)) << 4));
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+          if constexpr (BF) d1[ht][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, yf[ks][pt]), d1[ht][pt], 0, 0, 0);
+          else d1[ht][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, yf[ks][pt], d1[ht][pt], 0, 0, 0);
+        }
+      }
+    // bias + GELU; the lane's 8 values of a pixel (hidden 16 ht + 4 fg + e) are one B-operand fragment of GEMM2 in the packed hidden order
+    const f32x4 bv0 = *reinterpret_cast<const f32x4*>(B1s + ch * 32 + 4 * fg);
+    const f32x4 bv1 = *reinterpret_cast<const f32x4*>(B1s + ch * 32 + 16 + 4 * fg);
+    f16x8 hf[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      typename std::conditional<BF, bf16x8, f16x8>::type h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        h[e] = (TH)gelu_h16m(d1[0][pt][e] + bv0[e]);
+        h[4 + e] = (TH)gelu_h16m(d1[1][pt][e] + bv1[e]);
+      }
+      hf[pt] = __builtin_bit_cast(f16x8, h);
+    }
+#pragma unroll
+    for (int n = 0; n < NCT; ++n) {
+      const f16x8 w = *reinterpret_cast<const f16x8*>(sb + w2_rd + n * 16 * 64);
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        if constexpr (BF) acc[n][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, hf[pt]), acc[n][pt], 0, 0, 0);
+        else acc[n][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, hf[pt], acc[n][pt], 0, 0, 0);
+      }
+    }
+  };
+  static_assert(NCH % R == 0, "whole ring revolutions");
+  for (int cb = 0; cb < NCH; cb += R) {
+    chunk(cb, std::integral_constant<int, 0>{});
+    chunk(cb + 1, std::integral_constant<int, 1 % R>{});
+    if constexpr (R > 2) chunk(cb + 2, std::integral_constant<int, 2 % R>{});
+    if constexpr (R > 3) chunk(cb + 3, std::integral_constant<int, 3 % R>{});
+  }
+  __builtin_amdgcn_s_barrier();  // every wave is done with the ring (no DMA in flight: the last chunk waited vmcnt(0)): it becomes the staging area
+
+  // ---- epilogue ----
+  const TH* const xg = reinterpret_cast<const TH*>(a.x);
+  TH* const og = reinterpret_cast<TH*>(a.out);
+  constexpr int ROWB = 2 * C;  // staging row (bytes), chunk index XOR-swizzled by (row & 15) in its low four bits
+  char* const stg = LB + wave * (PT * 16 * ROWB);
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    const long m = m0 + (wave * PT + pt) * 16 + fr;
+    const long mr = m < a.M ? m : a.M - 1;
+    f32x4 xv[NCT];
+#pragma unroll
+    for (int n = 0; n < NCT; ++n) xv[n] = kpf_ld4(xg + mr * C + n * 16 + 4 * fg);
+#pragma unroll
+    for (int n = 0; n < NCT; ++n) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(B2s + n * 16 + 4 * fg);
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(Gs + n * 16 + 4 * fg);
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = xv[n][e] + gv[e] * (acc[n][pt][e] + bv[e]);
+      const int row = pt * 16 + fr, cidx = 2 * n + (fg >> 1);
+      kpf_st4(reinterpret_cast<TH*>(stg + row * ROWB + ((cidx ^ fr) << 4) + (fg & 1) * 8), v);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (own region only)
+  constexpr int CPR = ROWB / 16, RPI = 64 / CPR;  // chunks per row, rows per store instruction
+  const int rl = lane / CPR, p = lane % CPR;
+#pragma unroll
+  for (int it = 0; it < PT * 16 / RPI; ++it) {
+    const int row = it * RPI + rl;
+    const int c = p ^ (row & 15);
+    const f32x4 q = *reinterpret_cast<const f32x4*>(stg + row * ROWB + (p << 4));
+    const long m = m0 + wave * PT * 16 + row;
+    if (m < a.M) *reinterpret_cast<f32x4*>(og + m * C + 8 * c) = q;
+  }
+}
+
+template <int C, int PT, int R>
+int launch_mlp_h16(const Mlp16Args& a, int dtype, hipStream_t st) {
+  constexpr int CHB = 32 * C * 2 + C * 64, BM = 16 * PT * 4;
+  const size_t lds = (size_t)R * CHB + 6 * C * sizeof(float);
+  static_assert(4 * PT * 16 * 2 * C <= R * CHB, "the staging area lives in the ring");
+  void (*kern)(const Mlp16Args) = dtype == KPF_DT_BF16 ? convnext_mlp_h16_kernel<C, PT, R, true> : convnext_mlp_h16_kernel<C, PT, R, false>;
+  static std::atomic<bool> lds_opt_in[2][KPF_MAX_DEVICES];
+  if (!kpf_raise_lds_limit(reinterpret_cast<const void*>(kern), lds_opt_in[dtype == KPF_DT_BF16 ? 1 : 0])) {
+    kpf_set_error("kpf_convnext_mlp_h16: cannot raise the dynamic LDS limit");
+    return KPF_ELAUNCH;
+  }
+  const long tiles = ((long)a.M + BM - 1) / BM;
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, st, a);
+  return kpf_check_launch("kpf_convnext_mlp_h16");
+}
+
 template <int NC, int HT, int NW, bool YLDS, int TM>
 int launch_mlp_split(MlpSplitArgs& a, hipStream_t st) {
   constexpr int C = 16 * NC, HC = 16 * HT, BM = 16 * TM * NW;
@@ -459,6 +683,24 @@ static const float* mlp_zero_page() {
     zero_of_dev[dev] = static_cast<const float*>(p);
   }
   return zero_of_dev[dev];
+}
+
+extern "C" int kpf_convnext_mlp_h16_supported(int C) { return C == 128 || C == 256; }
+
+extern "C" int kpf_convnext_mlp_h16(const void* y, const void* x, const void* w1, const float* b1, const void* w2_chunks, const float* b2,
+                                    const float* gamma, void* out, long M, int C, int dtype, void* stream) {
+  KPF_REQUIRE(y && x && w1 && b1 && w2_chunks && b2 && gamma && out && M > 0, "kpf_convnext_mlp_h16: null pointer / empty");
+  KPF_REQUIRE(kpf_convnext_mlp_h16_supported(C), "kpf_convnext_mlp_h16: C=%d not supported (128, 256)", C);
+  KPF_REQUIRE(dtype == KPF_DT_BF16 || dtype == KPF_DT_F16, "kpf_convnext_mlp_h16: dtype must be KPF_DT_BF16 or KPF_DT_F16");
+  KPF_REQUIRE(M < (1l << 31), "kpf_convnext_mlp_h16: too many rows");
+  KPF_REQUIRE(kpf_aligned16(y) && kpf_aligned16(x) && kpf_aligned16(w1) && kpf_aligned16(w2_chunks) && kpf_aligned16(out) && kpf_aligned16(b1) &&
+                  kpf_aligned16(b2) && kpf_aligned16(gamma),
+              "kpf_convnext_mlp_h16: pointers must be 16-byte aligned");
+  Mlp16Args a;
+  a.y = y; a.x = x; a.w1 = w1; a.b1 = b1; a.w2c = w2_chunks; a.b2 = b2; a.gamma = gamma; a.out = out; a.M = (int)M;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (C == 128) return launch_mlp_h16<128, 3, 4>(a, dtype, st);  // 48 pixels per wave, 4-stage ring of 16-KB chunks (67 KB of LDS)
+  return launch_mlp_h16<256, 2, 2>(a, dtype, st);                 // 32 pixels per wave, 2 stages of 32 KB (70 KB)
 }
 
 extern "C" int kpf_convnext_mlp_split_supported(int C) { return C == 96 || C == 128 || C == 192 || C == 256; }

@@ -15,6 +15,7 @@ from .engine import Act, PackedConv, _launch, _ptr, _stream, bn_scale_shift, con
 from .spec import CONVNEXT, parse_net
 
 DTYPES = {"bf16": (torch.bfloat16, L.KPF_DT_BF16), "f16": (torch.float16, L.KPF_DT_F16)}
+FORCE_UNFUSED_MLP16 = bool(int(__import__("os").environ.get("KPF_UNFUSED_MLP16", "0")))  # A/B switch for tuning
 
 
 def empty16(B, H, W, Cc, device, tdt):
@@ -109,10 +110,26 @@ class Block16:
         self.bdw, self.lnw, self.lnb, self.gamma = f32(".dwconv.bias"), f32(".norm.weight"), f32(".norm.bias"), f32(".gamma")
         self.pw1 = Packed16(PackedConv(sd[p + ".pwconv1.weight"], sd[p + ".pwconv1.bias"], device), tdt)
         self.pw2 = Packed16(PackedConv(sd[p + ".pwconv2.weight"], sd[p + ".pwconv2.bias"], device), tdt)
+        # fused MLP (kpf_convnext_mlp_h16: the 4C-wide hidden tensor never reaches HBM) where the library has it: pwconv2's weight chunk-major
+        # [4C/32][C][32] with the hidden index of a 32-block in the order GEMM1's accumulator registers form GEMM2's operand
+        self.fused = (not FORCE_UNFUSED_MLP16) and bool(L.load().kpf_convnext_mlp_h16_supported(c))
+        if self.fused:
+            from .engine import MLP_HIDDEN_PERM
+            w2 = sd[p + ".pwconv2.weight"].detach().float().reshape(c, 4 * c)
+            perm = torch.tensor(MLP_HIDDEN_PERM, dtype=torch.long)
+            w2c = w2.view(c, 4 * c // 32, 32)[:, :, perm].permute(1, 0, 2).contiguous()  # [chunk][c][k-slot]
+            self.w2c = w2c.to(tdt).to(device)
+            self.c = c
 
     def __call__(self, x, y, h, kdt):
         L.check(L.load().kpf_dwconv7_ln_h16(_ptr(x.buf), _ptr(self.wdw), _ptr(self.bdw), _ptr(self.lnw), _ptr(self.lnb), _ptr(y.buf), x.B, x.H,
                                             x.W, x.C, 1e-6, kdt, _stream()), "kpf_dwconv7_ln_h16")
+        if self.fused and x.ld == x.C and x.coff == 0 and y.ld == y.C and y.coff == 0:
+            M, c = x.B * x.H * x.W, self.c
+            _launch("convnext_mlp_h16_kernel", 16.0 * M * c * c, 2.0 * (3 * M * c + 8 * c * c), (M, c, 4 * c, 1, 1),
+                    lambda: L.check(L.load().kpf_convnext_mlp_h16(_ptr(y.buf), _ptr(x.buf), _ptr(self.pw1.w), _ptr(self.pw1.pc.b), _ptr(self.w2c), _ptr(self.pw2.pc.b),
+                                                                  _ptr(self.gamma), _ptr(x.buf), M, c, kdt, _stream()), "kpf_convnext_mlp_h16"))
+            return x
         conv16(self.pw1, y, kdt, out=h, flags=L.KPF_ACT_GELU)
         conv16(self.pw2, h, kdt, out=x, gamma=self.gamma, res=x)
         return x

@@ -20,7 +20,7 @@ KPF_IN_SPLIT = 128
 KPF_OUT_SPLIT = 256
 KPF_W_SPLIT = 512
 KPF_DT_F32, KPF_DT_BF16, KPF_DT_F16 = 0, 1, 2
-ABI_VERSION = 11  # KPF_ABI_VERSION of include/kpf.h: load() refuses a library built from another revision of the interface
+ABI_VERSION = 12  # KPF_ABI_VERSION of include/kpf.h: load() refuses a library built from another revision of the interface
 
 
 class ConvDesc(C.Structure):
@@ -78,6 +78,8 @@ _SIGS = {
     "kpf_convnext_mlp_supported": [C.c_int],
     "kpf_convnext_mlp_split_f32": [_P, _P, _P, _P, C.c_float, _P, _P, C.c_float, _P, _P, C.c_long, C.c_int, _P],
     "kpf_convnext_mlp_split_supported": [C.c_int],
+    "kpf_convnext_mlp_h16": [_P] * 8 + [C.c_long, C.c_int, C.c_int, _P],
+    "kpf_convnext_mlp_h16_supported": [C.c_int],
     "kpf_cbam_channel_gate_f32": [_P] * 7 + [C.c_int] * 4 + [_P],
     "kpf_cbam_spatial_gate_f32": [_P, _P, _P, C.c_float, C.c_float, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
     "kpf_cbam_apply_f32": [_P] * 5 + [C.c_int] * 3 + [_P],

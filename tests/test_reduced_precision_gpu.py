@@ -131,6 +131,55 @@ def test_dwconv7_ln_and_layernorm_h16(shape, prec):
         assert float((z.float().cpu().double() - want).abs().max() / want.abs().max()) < 1.5 * eps
 
 
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+@pytest.mark.parametrize("C,M", [(128, 1000), (128, 4096 + 48), (256, 777), (256, 2048)])
+def test_fused_convnext_mlp_h16(C, M, prec):
+    """kpf_convnext_mlp_h16 (out = x + gamma * (W2 GELU(W1 y + b1) + b2), convNeXT/convnext.py:44-51, hidden tensor in registers) against
+    float64 on the SAME 16-bit-rounded operands with the exact erf GELU: what is lost is the rounding of the hidden activations to the
+    storage type (they are GEMM2's operand), the 2.6e-5 of the 9-operation GELU and the output rounding.  Ragged M (last tile partial),
+    in place (out aliases x) like the engine calls it, and equal to the two-GEMM path within the same tolerance."""
+    import ctypes as C_
+    from keypointfusion_amd import engine as E, lib as L
+    from keypointfusion_amd.engine import MLP_HIDDEN_PERM
+    from keypointfusion_amd.engine16 import DTYPES, Packed16, conv16
+    dev = _dev()
+    tdt, ulp = PREC[prec]
+    kdt = DTYPES[prec][1]
+    g = torch.Generator().manual_seed(C + M)
+    y = torch.randn(M, C, generator=g).to(tdt)
+    x = (torch.randn(M, C, generator=g) * 2).to(tdt)
+    w1 = (torch.randn(4 * C, C, generator=g) / C ** 0.5).to(tdt)
+    w2 = (torch.randn(C, 4 * C, generator=g) / (4 * C) ** 0.5).to(tdt)
+    b1, b2 = torch.randn(4 * C, generator=g) * 0.3, torch.randn(C, generator=g) * 0.3
+    gamma = torch.rand(C, generator=g) + 0.5
+    hid = y.double() @ w1.double().t() + b1.double()
+    hid = 0.5 * hid * (1 + torch.erf(hid / 2 ** 0.5))
+    ref = x.double() + gamma.double() * (hid @ w2.double().t() + b2.double())
+    perm = torch.tensor(MLP_HIDDEN_PERM)
+    w2c = w2.view(C, 4 * C // 32, 32)[:, :, perm].permute(1, 0, 2).contiguous().to(dev)
+    yd, xd, w1d = y.to(dev), x.to(dev).clone(), w1.to(dev)
+    b1d, b2d, gd = b1.to(dev), b2.to(dev), gamma.to(dev)
+    P = lambda t: C_.c_void_p(t.data_ptr())
+    L.check(L.load().kpf_convnext_mlp_h16(P(yd), P(xd), P(w1d), P(b1d), P(w2c), P(b2d), P(gd), P(xd), M, C, kdt, E._stream()), "kpf_convnext_mlp_h16")
+    torch.cuda.synchronize()
+    got = xd.double().cpu()
+    assert bool(torch.isfinite(got).all())
+    err = float(((got - ref).abs() / (ref.abs() + 1.0)).max())
+    # hidden rounding: 4C products with relative error <= ulp/2 each, random signs -> ~ulp * |w2 row| * rms(hidden) ~ 1 ulp of an O(1) sum
+    assert err < 3.0 * ulp + 1e-4, err
+    # the unfused pair on the same operands (hidden tensor through HBM, fp32-accurate GELU): same numbers up to the same roundings
+    pc1 = Packed16(E.PackedConv(w1.float(), b1, dev), tdt)
+    pc2 = Packed16(E.PackedConv(w2.float(), b2, dev), tdt)
+    ya = E.Act(yd.reshape(-1), 1, 1, M, C)
+    ha = E.Act(torch.empty(M * 4 * C, device=dev, dtype=tdt), 1, 1, M, 4 * C)
+    xa = E.Act(x.to(dev).reshape(-1).clone(), 1, 1, M, C)
+    conv16(pc1, ya, kdt, out=ha, flags=L.KPF_ACT_GELU)
+    conv16(pc2, ha, kdt, out=xa, gamma=gd, res=xa)
+    torch.cuda.synchronize()
+    two = xa.buf.view(M, C).double().cpu()
+    assert float(((got - two).abs() / (ref.abs() + 1.0)).max()) < 4.0 * ulp + 1e-4
+
+
 def _model(net, prec):
     from keypointfusion_amd.model.model import KPFusion
     m = KPFusion("KPFusion-" + net, "", 21, "dexycb", "")
