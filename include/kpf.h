@@ -117,6 +117,20 @@ int kpf_convnext_mlp_h16(const void* y, const void* x, const void* w1, const flo
 int kpf_convnext_mlp_h16_supported(int C);
 
 /*
+ * Depthwise 7x7 + bias as a pure stencil that also emits LayerNorm statistics, and the LayerNorm from those statistics (round 4; together they
+ * replace kpf_dwconv7_ln_h16 = convNeXT/convnext.py:41-44 on 16-bit storage for C % 64 == 0 and maps of at least 16 x 16):
+ *   kpf_dwconv7_stats_h16   y = dwconv7(x) + b (un-normalised, storage type `dtype`), stats[pixel][C/64][2] = (mean, sum of centred squares) of
+ *                           every 64-channel chunk of the fp32 result;  kpf_dwconv7_stats_floats = the floats `stats` needs.
+ *   kpf_ln_apply_stats_h16  y <- (y - mean) * rstd * ln_w + ln_b in place, (mean, rstd) merged from the chunk statistics (Chan's update, fixed
+ *                           order).  (The statistics are laid out for the following GEMM to consume them instead: out = rstd * (W'y - mean * s) + b'.)
+ */
+int kpf_dwconv7_stats_h16(const void* x, const float* w_dw, const float* b_dw, void* y, float* stats, int B, int H, int W, int C, int dtype,
+                          void* stream);
+int kpf_dwconv7_stats_supported(int H, int W, int C);
+long kpf_dwconv7_stats_floats(int B, int H, int W, int C);
+int kpf_ln_apply_stats_h16(void* y, const float* stats, const float* ln_w, const float* ln_b, long rows, int C, float eps, int dtype, void* stream);
+
+/*
  * LayerNorm over the channel dimension of `rows` pixels (biased variance, (x-u)/sqrt(var+eps)*w+b).
  * Replaces convNeXT/convnext.py:205-214 in both data formats (stem/downsample norms).  In-place allowed.
  */

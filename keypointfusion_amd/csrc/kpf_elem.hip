@@ -1,6 +1,7 @@
 // HBM-bound kernels of the backbone path: depthwise 7x7 + LayerNorm (fused), LayerNorm, bilinear x2 upsample,
 // layout repacks, max-pool.  All fp32, NHWC, 16-byte vector accesses (float4 over channels), wave64 reductions.
 #include "kpf_common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -736,6 +737,211 @@ __global__ __launch_bounds__(256) void cast_f32_h16_kernel(const float* __restri
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) kpf_st4(dst + i * 4, kpf_ld4(src + i * 4));
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 4: depthwise 7x7 as a pure LDS-tiled stencil that also emits LayerNorm statistics (16-bit storage), and the LayerNorm as a light second
+// pass over them (kpf_dwconv7_stats_h16 / kpf_ln_apply_stats_h16; the statistics can alternatively be consumed by the following GEMM).
+//
+// Why: the one-pass kernels above hold a pixel's whole channel vector (x 16 pixels) in one workgroup's registers — 182 VGPRs, two waves per SIMD,
+// every input row fetched through the texture path by 14 dependent 8-byte loads — and run 5.5 x over the vector-ALU floor of the stencil
+// (49 FMA per output element: 25 us for 64 x 32 x 32 x 512 at the chip's full fp32 rate; measured 138 us in f16).  Here:
+//  * a workgroup owns a 16 x 16-pixel tile of ONE 64-channel chunk: the (16+6) x (16+6) halo tile (62 KB) is filled once by LDS-DMA (zero page outside
+//    the image), so every input element crosses L2 -> LDS 1.9 x and is then read from LDS at 256 B/clk (ds_read_b64 of a channel quad);
+//  * a thread owns one channel quad of one 8-pixel strip of one row: 32 accumulators, 14 packed input quads and 7 weight quads per filter row —
+//    under 100 registers, so four to five waves per SIMD cover each other's LDS latencies; f16 inputs feed v_fma_mix_f32 straight from the
+//    packed registers (no conversion instructions, fp32 accumulation);
+//  * the 16 lanes that hold a pixel's 64 channels of the chunk reduce (mean, centred sum of squares) by DPP shuffles; chunk statistics go to a
+//    side buffer [pixels][C/64][2] (6 % of the tensor) and are merged with Chan's update where they are consumed — no cancellation for |mean| >> sigma.
+//  LDS rows are padded to 23 pixels so that the two strips a 32-lane half reads (same columns, neighbouring rows) sit in opposite halves of the
+//  256-byte bank row.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int DS_T = 16, DS_HW = DS_T + 6, DS_ROW = DS_HW + 1, DS_CH = 64;  // tile edge, halo edge, padded LDS row (pixels), channels per chunk
+typedef __attribute__((address_space(3))) void ds_lds_void_t;
+typedef __attribute__((address_space(1))) void ds_gbl_void_t;
+__device__ __attribute__((aligned(16))) float kpf_elem_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+template <typename TA>
+__global__ __launch_bounds__(512, 2) void dwconv7_stats_kernel(const TA* __restrict__ x, const float* __restrict__ wdw, const float* __restrict__ bdw,
+                                                               TA* __restrict__ y, float* __restrict__ stats, int H, int W, int C, int tiles_x,
+                                                               int tiles_y, const float* __restrict__ zero, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) float dsl[];
+  char* const LB = reinterpret_cast<char*>(dsl);
+  constexpr int SLOTS = DS_HW * DS_ROW * 8;                // 16-byte pieces of the halo tile (128 bytes per pixel)
+  constexpr int HALO_B = (SLOTS + 63) / 64 * 1024;         // rounded up to whole 1-KiB DMA instructions: the last one writes past the tile
+  float* const Ws = reinterpret_cast<float*>(LB + HALO_B);  // [49][64] taps of the chunk, then [64] bias
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nchunk = C / DS_CH;
+  long r = xcd_contiguous_block_id();
+  const int chunk = (int)(r % nchunk);  // chunks of one tile run back to back on one XCD: the stats rows of a pixel are written together
+  r /= nchunk;
+  const int tx = (int)(r % tiles_x);
+  r /= tiles_x;
+  const int ty = (int)(r % tiles_y);
+  const int b = (int)(r / tiles_y);
+  const int x0 = tx * DS_T, y0 = ty * DS_T, c0 = chunk * DS_CH;
+
+  // ---- halo tile by LDS-DMA: slot = (pixel of the padded tile, 16-byte piece); LDS is linear in slots, the source is per lane ----
+  const TA* const xb = x + (long)b * H * W * C + c0;
+#pragma unroll 1
+  for (int s0 = (dbg & 2) ? SLOTS : 0; s0 < SLOTS; s0 += 512) {
+    const int slot = s0 + tid;
+    const int px = slot >> 3, pc = slot & 7;
+    const int hy = px / DS_ROW, hx = px - hy * DS_ROW;
+    const int iy = y0 + hy - 3, ix = x0 + hx - 3;
+    const bool in = slot < SLOTS && hx < DS_HW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    const void* src = in ? static_cast<const void*>(xb + ((long)iy * W + ix) * C + pc * 8) : static_cast<const void*>(zero);
+    if (s0 + wave * 64 < SLOTS)  // (wave-uniform; the last pass is partial)
+      __builtin_amdgcn_global_load_lds((ds_gbl_void_t*)src, (ds_lds_void_t*)(LB + (s0 + wave * 64) * 16), 16, 0, 0);
+  }
+  for (int i = tid; i < 49 * 16; i += 512) {
+    const int tap = i >> 4, q4 = i & 15;
+    *reinterpret_cast<f32x4*>(Ws + tap * 64 + 4 * q4) = *reinterpret_cast<const f32x4*>(wdw + (long)tap * C + c0 + 4 * q4);
+  }
+  if (tid < 16) *reinterpret_cast<f32x4*>(Ws + 49 * 64 + 4 * tid) = *reinterpret_cast<const f32x4*>(bdw + c0 + 4 * tid);
+  __syncthreads();  // (its fence drains the DMA: vmcnt(0))
+
+  // ---- thread = channel quad q of strip (sx, row): lanes 0-15 / 16-31 of a half-wave are rows 2k / 2k+1 of the same strip column ----
+  const int q = tid & 15, sid = tid >> 4;
+  const int row = ((sid >> 2) << 1) | (sid & 1), sx = (sid >> 1) & 1;
+  f32x4 acc[8];
+  {
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(Ws + 49 * 64 + 4 * q);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = bias;
+  }
+  const char* const ib = LB + ((row * DS_ROW + sx * 8) * DS_CH + 4 * q) * 2;
+  // The multiply-adds are written as instructions: left to itself hipcc converts the inputs to fp32 (56 v_cvt per filter row) and SLP-packs the
+  // products into v_pk_fma_f32, which issues at half the rate of two v_fma_f32 here (measured: 2.6 x the vector-ALU floor).  f16: v_fma_mix_f32 takes
+  // the half straight from the packed register (fp32 weight, fp32 accumulator); bf16: widening is a shift / mask, then v_fma_f32.
+  if (!(dbg & 1))
+#pragma unroll
+  for (int ky = 0; ky < 7; ++ky) {
+    uint2 in[14];  // four packed 16-bit channels of 14 input pixels
+#pragma unroll
+    for (int i = 0; i < 14; ++i) in[i] = *reinterpret_cast<const uint2*>(ib + (ky * DS_ROW + i) * (DS_CH * 2));
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(Ws + (ky * 7 + kx) * 64 + 4 * q);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const uint2 v = in[t + kx];
+        if constexpr (sizeof(TA) == 2 && std::is_same<TA, f16_t>::value) {
+          asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc[t][0]) : "v"(v.x), "v"(wv[0]));
+          asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[t][1]) : "v"(v.x), "v"(wv[1]));
+          asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc[t][2]) : "v"(v.y), "v"(wv[2]));
+          asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[t][3]) : "v"(v.y), "v"(wv[3]));
+        } else {
+          const float f0 = __uint_as_float(v.x << 16), f1 = __uint_as_float(v.x & 0xffff0000u);
+          const float f2 = __uint_as_float(v.y << 16), f3 = __uint_as_float(v.y & 0xffff0000u);
+          asm("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[t][0]) : "v"(f0), "v"(wv[0]));
+          asm("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[t][1]) : "v"(f1), "v"(wv[1]));
+          asm("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[t][2]) : "v"(f2), "v"(wv[2]));
+          asm("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[t][3]) : "v"(f3), "v"(wv[3]));
+        }
+      }
+    }
+  }
+
+  // ---- outputs + chunk statistics ----
+  // The 16 lanes q = 0..15 of a strip hold the 64 channels of each of its 8 pixels.  Sum and sum of squares are reduced by a TRANSPOSED butterfly:
+  // at distance 8 a lane hands over four pixels' partials and keeps four, at distance 4 two, at distance 2 one, and a last exchange at distance 1
+  // completes them — 2 x (4 + 2 + 1 + 1) = 16 cross-lane operations per thread instead of 64 (a 16-us item of a 75-us kernel when every pixel was
+  // reduced on its own).  Pixel t ends up complete in lanes q with (q >> 1) == bit-reversed-ish index below; lane pairs hold the same total.
+  // M2 = S2 - S1^2 / 64 in fp32: the cancellation error is 2^-24 (mean / sigma)^2 of M2, harmless up to |mean| ~ 100 sigma inside a 64-channel chunk.
+  const int oy = y0 + row;
+  TA* const yb = y + ((long)b * H + oy) * W * C + c0 + 4 * q;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    s1[t] = (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
+    s2[t] = fmaf(acc[t][0], acc[t][0], acc[t][1] * acc[t][1]) + fmaf(acc[t][2], acc[t][2], acc[t][3] * acc[t][3]);
+    if (oy < H && x0 + sx * 8 + t < W && !(dbg & 8)) kpf_st4(yb + (long)(x0 + sx * 8 + t) * C, acc[t]);
+  }
+  if (!(dbg & 4)) {
+    // distance 8: lanes with (q & 8) == 0 keep pixels 0-3, the others pixels 4-7
+    float a1[4], a2[4];
+    {
+      const bool up = q & 8;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float give1 = up ? s1[i] : s1[4 + i], give2 = up ? s2[i] : s2[4 + i];
+        const float keep1 = up ? s1[4 + i] : s1[i], keep2 = up ? s2[4 + i] : s2[i];
+        a1[i] = keep1 + __shfl_xor(give1, 8, 64);
+        a2[i] = keep2 + __shfl_xor(give2, 8, 64);
+      }
+    }
+    float b1[2], b2[2];
+    {
+      const bool up = q & 4;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float give1 = up ? a1[i] : a1[2 + i], give2 = up ? a2[i] : a2[2 + i];
+        const float keep1 = up ? a1[2 + i] : a1[i], keep2 = up ? a2[2 + i] : a2[i];
+        b1[i] = keep1 + __shfl_xor(give1, 4, 64);
+        b2[i] = keep2 + __shfl_xor(give2, 4, 64);
+      }
+    }
+    float c1, c2;
+    {
+      const bool up = q & 2;
+      const float give1 = up ? b1[0] : b1[1], give2 = up ? b2[0] : b2[1];
+      c1 = (up ? b1[1] : b1[0]) + __shfl_xor(give1, 2, 64);
+      c2 = (up ? b2[1] : b2[0]) + __shfl_xor(give2, 2, 64);
+    }
+    c1 += __shfl_xor(c1, 1, 64);
+    c2 += __shfl_xor(c2, 1, 64);
+    // this lane pair owns pixel t = 4 * bit3(q) + 2 * bit2(q) + bit1(q)
+    const int t = ((q >> 3) & 1) * 4 + ((q >> 2) & 1) * 2 + ((q >> 1) & 1);
+    const int ox = x0 + sx * 8 + t;
+    if (!(q & 1) && oy < H && ox < W && !(dbg & 16)) {
+      const float mean = c1 * (1.0f / DS_CH);
+      const float m2 = fmaxf(c2 - c1 * mean, 0.f);
+      *reinterpret_cast<float2*>(stats + (((long)b * H + oy) * W + ox) * (2 * nchunk) + 2 * chunk) = make_float2(mean, m2);
+    }
+  }
+}
+
+// LayerNorm from the chunk statistics, in place on the stencil's output.  A workgroup takes 64 pixels: 64 threads merge the C/64 (mean, M2) pairs of
+// one pixel each in a fixed order (equal counts: mean = average of the chunk means, M2 = sum M2_c + 64 sum (mean_c - mean)^2) into LDS, then all
+// threads stream the 64 x C block once (8 channels = 16 bytes per lane).
+template <typename TA>
+__global__ __launch_bounds__(256) void ln_apply_stats_kernel(TA* __restrict__ y, const float* __restrict__ stats, const float* __restrict__ lw,
+                                                             const float* __restrict__ lb, long rows, int C, float eps) {
+  __shared__ float2 mr[64];
+  const int nchunk = C / DS_CH, C8 = C >> 3;
+  const long p0 = (long)blockIdx.x * 64;
+  if (threadIdx.x < 64 && p0 + threadIdx.x < rows) {
+    const float* sp = stats + (p0 + threadIdx.x) * (2 * nchunk);
+    float mean = 0.f;
+    for (int c = 0; c < nchunk; ++c) mean += sp[2 * c];
+    mean *= 1.0f / (float)nchunk;
+    float m2 = 0.f;
+    for (int c = 0; c < nchunk; ++c) {
+      const float d = sp[2 * c] - mean;
+      m2 += sp[2 * c + 1] + (float)DS_CH * d * d;
+    }
+    mr[threadIdx.x] = make_float2(mean, 1.0f / sqrtf(m2 / (float)C + eps));
+  }
+  __syncthreads();
+  const int n = (int)((rows - p0) < 64 ? (rows - p0) : 64) * C8;
+  TA* const yb = y + p0 * C;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int px = i / C8, q = i - px * C8;
+    const float2 s = mr[px];
+    const f32x4 v0 = kpf_ld4(yb + (long)i * 8), v1 = kpf_ld4(yb + (long)i * 8 + 4);
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(lw + 8 * q), g1 = *reinterpret_cast<const f32x4*>(lw + 8 * q + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(lb + 8 * q), b1 = *reinterpret_cast<const f32x4*>(lb + 8 * q + 4);
+    f32x4 o0, o1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o0[e] = (v0[e] - s.x) * s.y * g0[e] + b0[e];
+      o1[e] = (v1[e] - s.x) * s.y * g1[e] + b1[e];
+    }
+    kpf_st4(yb + (long)i * 8, o0);
+    kpf_st4(yb + (long)i * 8 + 4, o1);
+  }
+}
+
 inline int grid_for(long total, int block = 256, int cap = 256 * 16) {
   long g = (total + block - 1) / block;
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -1026,4 +1232,65 @@ extern "C" int kpf_maxpool3x3s2_f32(const float* src, float* dst, int B, int H, 
   hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst, B, H,
                      W, OH, OW, C / 4);
   return kpf_check_launch("kpf_maxpool3x3s2_f32");
+}
+
+// ---- round 4: stencil + statistics, LayerNorm from statistics (16-bit storage) ----
+extern "C" int kpf_dwconv7_stats_supported(int H, int W, int C) { return C % 64 == 0 && C <= 2048 && H >= 16 && W >= 16; }
+extern "C" long kpf_dwconv7_stats_floats(int B, int H, int W, int C) { return (long)B * H * W * (C / 64) * 2; }
+
+template <typename TA>
+static int dwconv7_stats_impl(const TA* x, const float* w_dw, const float* b_dw, TA* y, float* stats, int B, int H, int W, int C, void* stream) {
+  const int tiles_x = (W + DS_T - 1) / DS_T, tiles_y = (H + DS_T - 1) / DS_T;
+  const long blocks = (long)B * tiles_y * tiles_x * (C / DS_CH);
+  KPF_REQUIRE(blocks < (1l << 31), "kpf_dwconv7_stats_h16: grid too large");
+  static const float* zero_of_dev[KPF_MAX_DEVICES] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= KPF_MAX_DEVICES) dev = 0;
+  if (!zero_of_dev[dev]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(kpf_elem_zero16)) != hipSuccess || !p) {
+      kpf_set_error("kpf_dwconv7_stats_h16: cannot resolve the zero page");
+      return KPF_ELAUNCH;
+    }
+    zero_of_dev[dev] = static_cast<const float*>(p);
+  }
+  const size_t lds = (size_t)(DS_HW * DS_ROW * 8 + 63) / 64 * 1024 + (49 * 64 + 64) * sizeof(float);
+  auto kern = dwconv7_stats_kernel<TA>;
+  static std::atomic<bool> lds_opt_in[KPF_MAX_DEVICES];
+  if (!kpf_raise_lds_limit(reinterpret_cast<const void*>(kern), lds_opt_in)) {
+    kpf_set_error("kpf_dwconv7_stats_h16: cannot raise the dynamic LDS limit");
+    return KPF_ELAUNCH;
+  }
+  static const int dbg = []() { const char* e = getenv("KPF_DWS_DBG"); return e ? atoi(e) : 0; }();  // tuning aid (ablation bits: see the kernel)
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), x, w_dw, b_dw, y, stats, H, W, C, tiles_x, tiles_y,
+                     zero_of_dev[dev], dbg);
+  return kpf_check_launch("kpf_dwconv7_stats_h16");
+}
+
+extern "C" int kpf_dwconv7_stats_h16(const void* x, const float* w_dw, const float* b_dw, void* y, float* stats, int B, int H, int W, int C, int dtype,
+                                     void* stream) {
+  KPF_REQUIRE(x && w_dw && b_dw && y && stats && x != y, "kpf_dwconv7_stats_h16: null pointer or in-place call");
+  KPF_REQUIRE(B > 0 && kpf_dwconv7_stats_supported(H, W, C), "kpf_dwconv7_stats_h16: shape B=%d H=%d W=%d C=%d not supported (C %% 64 == 0, H, W >= 16)", B, H, W, C);
+  KPF_REQUIRE(kpf_aligned16(x) && kpf_aligned16(y) && kpf_aligned16(w_dw) && kpf_aligned16(b_dw) && kpf_aligned16(stats), "kpf_dwconv7_stats_h16: unaligned pointer");
+  if (dtype == KPF_DT_BF16) return dwconv7_stats_impl<bf16_t>(static_cast<const bf16_t*>(x), w_dw, b_dw, static_cast<bf16_t*>(y), stats, B, H, W, C, stream);
+  if (dtype == KPF_DT_F16) return dwconv7_stats_impl<f16_t>(static_cast<const f16_t*>(x), w_dw, b_dw, static_cast<f16_t*>(y), stats, B, H, W, C, stream);
+  kpf_set_error("kpf_dwconv7_stats_h16: dtype must be KPF_DT_BF16 or KPF_DT_F16");
+  return KPF_EINVAL;
+}
+
+extern "C" int kpf_ln_apply_stats_h16(void* y, const float* stats, const float* ln_w, const float* ln_b, long rows, int C, float eps, int dtype, void* stream) {
+  KPF_REQUIRE(y && stats && ln_w && ln_b && rows > 0 && C > 0 && C % 64 == 0, "kpf_ln_apply_stats_h16: bad arguments (C %% 64 == 0)");
+  KPF_REQUIRE(kpf_aligned16(y) && kpf_aligned16(ln_w) && kpf_aligned16(ln_b), "kpf_ln_apply_stats_h16: unaligned pointer");
+  KPF_REQUIRE((rows + 63) / 64 < (1l << 31), "kpf_ln_apply_stats_h16: too many rows");
+  const dim3 grid((unsigned)((rows + 63) / 64));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == KPF_DT_BF16)
+    hipLaunchKernelGGL(ln_apply_stats_kernel<bf16_t>, grid, dim3(256), 0, st, static_cast<bf16_t*>(y), stats, ln_w, ln_b, rows, C, eps);
+  else if (dtype == KPF_DT_F16)
+    hipLaunchKernelGGL(ln_apply_stats_kernel<f16_t>, grid, dim3(256), 0, st, static_cast<f16_t*>(y), stats, ln_w, ln_b, rows, C, eps);
+  else {
+    kpf_set_error("kpf_ln_apply_stats_h16: dtype must be KPF_DT_BF16 or KPF_DT_F16");
+    return KPF_EINVAL;
+  }
+  return kpf_check_launch("kpf_ln_apply_stats_h16");
 }

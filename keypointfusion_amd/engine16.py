@@ -16,6 +16,8 @@ from .spec import CONVNEXT, parse_net
 
 DTYPES = {"bf16": (torch.bfloat16, L.KPF_DT_BF16), "f16": (torch.float16, L.KPF_DT_F16)}
 FORCE_UNFUSED_MLP16 = bool(int(__import__("os").environ.get("KPF_UNFUSED_MLP16", "0")))  # A/B switch for tuning
+DW_STATS = bool(int(__import__("os").environ.get("KPF_DW_STATS", "1")))  # depthwise stencil + statistics pair instead of the one-pass dw+LN kernels
+DW_STATS_MIN_C = int(__import__("os").environ.get("KPF_DW_STATS_MIN_C", "256"))  # (at C = 128 the one-pass wave kernel is still faster: 311 vs 363 us)
 
 
 def empty16(B, H, W, Cc, device, tdt):
@@ -121,9 +123,18 @@ class Block16:
             self.w2c = w2c.to(tdt).to(device)
             self.c = c
 
-    def __call__(self, x, y, h, kdt):
-        L.check(L.load().kpf_dwconv7_ln_h16(_ptr(x.buf), _ptr(self.wdw), _ptr(self.bdw), _ptr(self.lnw), _ptr(self.lnb), _ptr(y.buf), x.B, x.H,
-                                            x.W, x.C, 1e-6, kdt, _stream()), "kpf_dwconv7_ln_h16")
+    def __call__(self, x, y, h, kdt, st=None):
+        lib = L.load()
+        if st is not None:
+            # round 4: LDS-tiled stencil + per-chunk LayerNorm statistics, then the normalisation from them (two launches that together take
+            # 0.5-0.65 of the one-pass kernel's time at C >= 256: tools/dw_stats_bench.py)
+            L.check(lib.kpf_dwconv7_stats_h16(_ptr(x.buf), _ptr(self.wdw), _ptr(self.bdw), _ptr(y.buf), _ptr(st), x.B, x.H, x.W, x.C, kdt, _stream()),
+                    "kpf_dwconv7_stats_h16")
+            L.check(lib.kpf_ln_apply_stats_h16(_ptr(y.buf), _ptr(st), _ptr(self.lnw), _ptr(self.lnb), x.B * x.H * x.W, x.C, 1e-6, kdt, _stream()),
+                    "kpf_ln_apply_stats_h16")
+        else:
+            L.check(lib.kpf_dwconv7_ln_h16(_ptr(x.buf), _ptr(self.wdw), _ptr(self.bdw), _ptr(self.lnw), _ptr(self.lnb), _ptr(y.buf), x.B, x.H,
+                                           x.W, x.C, 1e-6, kdt, _stream()), "kpf_dwconv7_ln_h16")
         if self.fused and x.ld == x.C and x.coff == 0 and y.ld == y.C and y.coff == 0:
             M, c = x.B * x.H * x.W, self.c
             _launch("convnext_mlp_h16_kernel", 16.0 * M * c * c, 2.0 * (3 * M * c + 8 * c * c), (M, c, 4 * c, 1, 1),
@@ -225,9 +236,14 @@ class UNetPlan16:
                 t = self._ln(cur, self.down_ln[i], empty16(cur.B, cur.H, cur.W, cur.C, dev, tdt), kdt)
                 cur = conv16(self.down[i], t, kdt)
             y = empty16(cur.B, cur.H, cur.W, cur.C, dev, tdt)
-            h = empty16(cur.B, cur.H, cur.W, 4 * cur.C, dev, tdt)
+            fused = all(blk.fused for blk in self.stages[i])
+            h = None if fused else empty16(cur.B, cur.H, cur.W, 4 * cur.C, dev, tdt)  # (the fused MLP keeps the 4C-wide hidden tensor in registers)
+            lib = L.load()
+            st = None
+            if DW_STATS and cur.C >= DW_STATS_MIN_C and lib.kpf_dwconv7_stats_supported(cur.H, cur.W, cur.C):
+                st = torch.empty(lib.kpf_dwconv7_stats_floats(cur.B, cur.H, cur.W, cur.C), device=dev, dtype=torch.float32)
             for blk in self.stages[i]:
-                blk(cur, y, h, kdt)
+                blk(cur, y, h, kdt, st)
             feats.append(cur)
         return feats
 

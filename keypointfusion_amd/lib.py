@@ -80,6 +80,9 @@ _SIGS = {
     "kpf_convnext_mlp_split_supported": [C.c_int],
     "kpf_convnext_mlp_h16": [_P] * 8 + [C.c_long, C.c_int, C.c_int, _P],
     "kpf_convnext_mlp_h16_supported": [C.c_int],
+    "kpf_dwconv7_stats_h16": [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_dwconv7_stats_supported": [C.c_int, C.c_int, C.c_int],
+    "kpf_ln_apply_stats_h16": [_P, _P, _P, _P, C.c_long, C.c_int, C.c_float, C.c_int, _P],
     "kpf_cbam_channel_gate_f32": [_P] * 7 + [C.c_int] * 4 + [_P],
     "kpf_cbam_spatial_gate_f32": [_P, _P, _P, C.c_float, C.c_float, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
     "kpf_cbam_apply_f32": [_P] * 5 + [C.c_int] * 3 + [_P],
@@ -137,6 +140,7 @@ _LONG_SIGS = {  # entries returning a long
     "kpf_row_gather_ws_ints": [C.c_int] * 4,
     "kpf_ln_ws_floats": [C.c_long, C.c_int],
     "kpf_layer_scale_ws_floats": [C.c_long, C.c_int],
+    "kpf_dwconv7_stats_floats": [C.c_int] * 4,
 }
 EXPORTS = sorted(list(_SIGS) + list(_LONG_SIGS) + ["kpf_last_error", "kpf_abi_version"])
 

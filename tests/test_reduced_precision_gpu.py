@@ -132,6 +132,48 @@ def test_dwconv7_ln_and_layernorm_h16(shape, prec):
 
 
 @pytest.mark.parametrize("prec", ["bf16", "f16"])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64), (1, 32, 32, 128), (2, 20, 24, 192), (1, 16, 16, 512), (3, 40, 17, 256), (1, 64, 64, 128)])
+def test_dwconv7_stats_and_ln_apply_h16(shape, prec):
+    """kpf_dwconv7_stats_h16 + kpf_ln_apply_stats_h16 (LDS-tiled stencil with per-chunk LayerNorm statistics, then the normalisation from them)
+    against float64 on the same rounded input (convNeXT/convnext.py:41-44): the un-normalised output up to its rounding, the chunk statistics
+    against their definition, the normalised result within the two roundings of the pair; ragged tiles (H, W not multiples of 16) and a
+    large common offset (|mean| >> sigma: the statistics must not cancel)."""
+    from keypointfusion_amd import lib as L
+    from keypointfusion_amd.engine import _ptr, _stream
+    from keypointfusion_amd.engine16 import DTYPES
+    dev = _dev()
+    lib = L.load()
+    tdt, ulp = PREC[prec]
+    kdt = DTYPES[prec][1]
+    B, H, W, Cc = shape
+    assert lib.kpf_dwconv7_stats_supported(H, W, Cc)
+    g = torch.Generator().manual_seed(Cc + H + W)
+    x = (torch.randn(B, H, W, Cc, generator=g) * 2 + 0.3).to(tdt)
+    wdw, bdw = torch.randn(49, Cc, generator=g) / 7, torch.randn(Cc, generator=g) * 0.1 + (5.0 if H == 20 else 0.0)  # (one case with a big offset)
+    lw, lb = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.1
+    d = [t.to(dev).contiguous() for t in (x, wdw, bdw, lw, lb)]
+    y = torch.full_like(d[0], float("nan"))
+    st = torch.full((lib.kpf_dwconv7_stats_floats(B, H, W, Cc),), float("nan"), device=dev)
+    L.check(lib.kpf_dwconv7_stats_h16(_ptr(d[0]), _ptr(d[1]), _ptr(d[2]), _ptr(y), _ptr(st), B, H, W, Cc, kdt, _stream()), "dwstats")
+    xr = x.float().permute(0, 3, 1, 2).double()
+    conv = F.conv2d(xr, wdw.t().reshape(Cc, 1, 7, 7).double(), bdw.double(), padding=3, groups=Cc).permute(0, 2, 3, 1)  # B H W C
+    raw = y.float().cpu().double()
+    assert bool(torch.isfinite(raw).all())
+    assert float((raw - conv).abs().max() / conv.abs().max()) < 1.05 * ulp  # fp32 accumulation, one rounding (half an ulp is up to 2^-8 / 2^-11 relative)
+    chunks = conv.reshape(B, H, W, Cc // 64, 64)
+    sm = st.view(B, H, W, Cc // 64, 2).cpu().double()
+    assert float((sm[..., 0] - chunks.mean(-1)).abs().max()) < 2e-5 * float(conv.abs().max())
+    m2 = ((chunks - chunks.mean(-1, keepdim=True)) ** 2).sum(-1)
+    assert float(((sm[..., 1] - m2).abs() / (m2 + 1e-3)).max()) < 1e-4
+    L.check(lib.kpf_ln_apply_stats_h16(_ptr(y), _ptr(st), _ptr(d[3]), _ptr(d[4]), B * H * W, Cc, 1e-6, kdt, _stream()), "lnapply")
+    ref = F.layer_norm(conv, (Cc,), lw.double(), lb.double(), 1e-6)
+    got = y.float().cpu().double()
+    # two roundings: the stored un-normalised value (relative ulp/2 of |conv|, amplified by |conv| / sigma on normalisation) and the result
+    amp = float((conv.abs().amax(-1) / conv.std(-1)).max())
+    assert float((got - ref).abs().max() / ref.abs().max()) < (1.0 + 0.5 * amp) * ulp, (float((got - ref).abs().max() / ref.abs().max()), amp)
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
 @pytest.mark.parametrize("C,M", [(128, 1000), (128, 4096 + 48), (256, 777), (256, 2048)])
 def test_fused_convnext_mlp_h16(C, M, prec):
     """kpf_convnext_mlp_h16 (out = x + gamma * (W2 GELU(W1 y + b1) + b2), convNeXT/convnext.py:44-51, hidden tensor in registers) against
