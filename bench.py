@@ -487,6 +487,9 @@ def main():
             line["extra"] = extra
         if single is not None:
             line["single_step_into_idle_gpu"] = single
+        if train and gstep[0] is not None and dist is not None:
+            line["dp_graph"] = {"mode": gstep[0].dp_mode, "payload_bytes_per_rank": gstep[0].payload_bytes(), "grad_payload": gstep[0].grad_payload,
+                                "collective": gstep[0].collective}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -111,6 +111,7 @@ class GradBucketReducer:
             self._pending[bi] = len(slots)
             self._work[bi] = None
             flat.zero_()
+        self._flags = [[0.0] * len(slots) for _, slots in self.buckets]
         self._seen = set()
 
     def _on_grad(self, p):
@@ -120,14 +121,16 @@ class GradBucketReducer:
         bi, off, n = self._slot[id(p)]
         flat, slots = self.buckets[bi]
         flat[off:off + n].copy_(p.grad.reshape(-1))
-        flat[flat.numel() - len(slots) + self._index[id(p)]] = 1.0
+        self._flags[bi][self._index[id(p)]] = 1.0  # (host side: the hook runs on the host; one copy per bucket at launch, not one fill per parameter)
         self._pending[bi] -= 1
         if self._pending[bi] == 0:
             self._launch(bi)
 
     def _launch(self, bi):
         if self.world > 1:
-            self._work[bi] = self.dist.all_reduce(self.buckets[bi][0], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+            flat, slots = self.buckets[bi]
+            flat[flat.numel() - len(slots):].copy_(torch.tensor(self._flags[bi], dtype=flat.dtype), non_blocking=True)
+            self._work[bi] = self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self):
         """Wait for every bucket, average, and write the result back into the parameters' .grad."""
@@ -135,10 +138,16 @@ class GradBucketReducer:
             if self._pending[bi] > 0:  # some parameters of this bucket got no gradient this step: reduce what is there (zeros for them)
                 self._pending[bi] = 0
                 self._launch(bi)
+        for w in self._work:
+            if w is not None:
+                w.wait()
+        seen_all = None
+        if self.world > 1:  # one device -> host transfer for the flags of every bucket (> 0: some rank produced a gradient)
+            seen_all = torch.cat([flat[flat.numel() - len(slots):] for flat, slots in self.buckets]).tolist()
+        pos = 0
         for bi, (flat, slots) in enumerate(self.buckets):
-            if self._work[bi] is not None:
-                self._work[bi].wait()
-            seen = flat[flat.numel() - len(slots):].tolist() if self.world > 1 else None  # > 0: some rank produced a gradient
+            seen = seen_all[pos:pos + len(slots)] if seen_all is not None else None
+            pos += len(slots)
             if self.world > 1:
                 flat.div_(self.world)
             for i, (p, off, n) in enumerate(slots):

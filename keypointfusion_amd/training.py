@@ -675,6 +675,9 @@ class DeferredParamGrads:
     def flush(self):
         from . import lib as L
         items, colsums, biases, self.items, self.colsums, self.biases, self.seen = self.items, self.colsums, self.biases, [], [], [], set()
+        # the parameters whose gradients this pass deferred (GraphedTrainStep keeps them out of the buckets that are reduced DURING backward)
+        self.last_deferred = ([self.named[k] for k, *_ in items if k in self.named] + [self.by_ptr[c[2]] for c in colsums if c[2] in self.by_ptr] +
+                              [self.by_ptr[b[1]] for b in biases if b[1] in self.by_ptr])
         if not items and not colsums:
             return
         # Adoption is verified BEFORE anything is written: the recorded addresses are only valid while the tensors handed to autograd
@@ -1280,9 +1283,26 @@ class GraphedTrainStep:
     the eager iteration would spend 3x the whole step on launch overhead.
     usage:  step = GraphedTrainStep(model, optimizer, loss_fn, example_batch[, dist_mod=dist, params=live]);  loss = step(batch)"""
 
-    def __init__(self, model, optimizer, loss_fn, batch, warmup=3, dist_mod=None, params=None, bucket_mb=64.0, group=None):
+    def __init__(self, model, optimizer, loss_fn, batch, warmup=3, dist_mod=None, params=None, bucket_mb=64.0, group=None, dp_mode=None,
+                 grad_payload="f32", collective="allreduce"):
+        """dp_mode (data parallel only): "overlap" — ONE graph in which each bucket's collective is a node on RCCL's stream, launched by a
+        post-accumulate-grad hook the moment the bucket's last gradient exists, so the reduction runs under the rest of backward (what
+        DistributedDataParallel does under CUDA graphs; the replacement of train.py:263-265's DataParallel reduce); "split" — graph A,
+        eager collectives, graph B (the only form a backend that cannot be captured allows: gloo).  None: "overlap" for the nccl backend
+        unless KPF_DP_GRAPH=split, and a fallback to "split" if the capture with collectives fails.
+        grad_payload "f32" | "bf16": the type the gradients travel in (bf16 halves the bytes on xGMI: 134 MB for ConvNeXt-T; the mean is then
+        the mean of bf16-rounded gradients — not bit-equal to the fp32 form).  collective "allreduce" | "rs_ag": one all-reduce per bucket,
+        or reduce-scatter + all-gather of the (padded) bucket — the same bytes per link on the xGMI mesh, two schedulable halves."""
         self.model, self.opt, self.loss_fn = model, optimizer, loss_fn
         self.dist, self.group = dist_mod, group
+        assert grad_payload in ("f32", "bf16") and collective in ("allreduce", "rs_ag")
+        self.grad_payload, self.collective = grad_payload, collective
+        if dist_mod is not None and dp_mode is None:
+            import os
+            be = dist_mod.get_backend(group)
+            dp_mode = "overlap" if (be == "nccl" and os.environ.get("KPF_DP_GRAPH", "overlap") != "split") else "split"
+        self.dp_mode = dp_mode if dist_mod is not None else None
+        self._deferred_ids = set()
         from .graphs import assert_replay_is_sound
         assert_replay_is_sound(next(iter(batch.values())).device)  # (once per process: refuses a runtime that mis-replays reductions)
         self.static = {k: v.detach().clone() for k, v in batch.items()}
@@ -1318,6 +1338,18 @@ class GraphedTrainStep:
                 self.opt.step()
             return
         self.world = self.dist.get_world_size(group)
+        if self.dp_mode == "overlap":
+            try:
+                self._capture_overlap(bucket_mb)
+                return
+            except Exception as e:  # noqa: BLE001 — a runtime / RCCL build that cannot capture collectives: the two-graph form still works
+                import warnings
+                warnings.warn("GraphedTrainStep: capturing the bucket collectives failed (%s: %s); using the two-graph form" % (type(e).__name__, e))
+                self._remove_hooks()
+                self.dp_mode = "split"
+                torch.cuda.synchronize()
+                self.opt.zero_grad(set_to_none=True)
+                self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = self._forward_backward()
             self._make_buckets(bucket_mb)  # (the gradients now exist: static tensors of the graph's pool)
@@ -1335,10 +1367,97 @@ class GraphedTrainStep:
         self.opt.zero_grad(set_to_none=True)
         for p in self._outside:  # (parameters that get a gradient but are not the optimiser's: their stale .grad would be added to, not replaced)
             p.grad = None
-        with DeferredParamGrads(self._named):  # small Linear layers' weight gradients, LayerNorm / layer-scale parameter sums: grouped launches after backward
+        dpg = DeferredParamGrads(self._named)
+        with dpg:  # small Linear layers' weight gradients, LayerNorm / layer-scale parameter sums: grouped launches after backward
             loss = self.loss_fn(self.model, self.static)
             loss.backward()
+        self._deferred_ids = {id(p) for p in getattr(dpg, "last_deferred", [])}
         return loss.detach()
+
+    # ---- data parallel, one graph: bucket collectives as graph nodes, launched from gradient hooks during backward ----
+    def _flat_bucket(self, plist):
+        pdt = torch.bfloat16 if self.grad_payload == "bf16" else plist[0].grad.dtype
+        n = sum(p.numel() for p in plist)
+        pad = (-n) % self.world if self.collective == "rs_ag" else 0  # (reduce-scatter wants equal shards)
+        flat = torch.zeros(n + pad, dtype=pdt, device=plist[0].device)
+        offs, off = [], 0
+        for q in plist:
+            offs.append(off)
+            off += q.numel()
+        shard = torch.empty((n + pad) // self.world, dtype=pdt, device=flat.device) if self.collective == "rs_ag" else None
+        return {"flat": flat, "params": plist, "offs": offs, "shard": shard, "pending": len(plist), "work": None}
+
+    def _launch_bucket(self, b):
+        if self.collective == "rs_ag":
+            self.dist.reduce_scatter_tensor(b["shard"], b["flat"], op=self.dist.ReduceOp.SUM, group=self.group)
+            b["work"] = self.dist.all_gather_into_tensor(b["flat"], b["shard"], group=self.group, async_op=True)
+        else:
+            b["work"] = self.dist.all_reduce(b["flat"], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _on_grad(self, p):
+        slot = self._slot.get(id(p))
+        if slot is None or not self._hooks_armed:
+            return
+        b, i = slot
+        n = p.numel()
+        b["flat"][b["offs"][i]:b["offs"][i] + n].copy_(p.grad.reshape(-1))  # (casts when the payload is bf16)
+        b["pending"] -= 1
+        if b["pending"] == 0:
+            self._launch_bucket(b)
+
+    def _remove_hooks(self):
+        for h in getattr(self, "_hooks", []):
+            h.remove()
+        self._hooks = []
+        self._hooks_armed = False
+
+    def _capture_overlap(self, bucket_mb):
+        """Bucket composition is taken from the warm-up iterations: parameters that received a gradient, in reverse registration order
+        (the order backward produces them); those whose gradient DeferredParamGrads fills only after backward (the small Linear layers, the
+        LayerNorm / layer-scale sums) go to late buckets that are reduced after the flush — they are a few MB of the payload."""
+        cap = int(bucket_mb * 1024 * 1024)
+        live = [p for p in reversed(self.params) if p.grad is not None]
+        early = [p for p in live if id(p) not in self._deferred_ids]
+        late = [p for p in live if id(p) in self._deferred_ids]
+
+        def split(plist):
+            out, cur, nb = [], [], 0
+            for q in plist:
+                b = q.numel() * (2 if self.grad_payload == "bf16" else q.grad.element_size())
+                if cur and (nb + b > cap or cur[0].grad.dtype != q.grad.dtype):
+                    out.append(cur)
+                    cur, nb = [], 0
+                cur.append(q)
+                nb += b
+            if cur:
+                out.append(cur)
+            return out
+
+        self._early = [self._flat_bucket(pl) for pl in split(early)]
+        self._late = [self._flat_bucket(pl) for pl in split(late)]
+        self.buckets = [(b["flat"], None, None) for b in self._early + self._late]  # (payload_bytes() / introspection)
+        self._slot = {id(q): (b, i) for b in self._early for i, q in enumerate(b["params"])}
+        self._hooks = [q.register_post_accumulate_grad_hook(self._on_grad) for b in self._early for q in b["params"]]
+        self._hooks_armed = True
+        inv = 1.0 / self.world
+        self.opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.loss = self._forward_backward()  # hooks pack and launch the early buckets while backward runs
+            self._hooks_armed = False
+            for b in self._late:  # written by the grouped launches that closed backward
+                torch._foreach_copy_([b["flat"][o:o + q.numel()].view_as(q.grad) for o, q in zip(b["offs"], b["params"])], [q.grad for q in b["params"]])
+                self._launch_bucket(b)
+            for b in self._early:
+                if b["pending"] > 0:  # a parameter of the bucket got no gradient in this pass although the warm-up saw one: reduce what is there
+                    self._launch_bucket(b)
+            for b in self._early + self._late:
+                if b["work"] is not None:
+                    b["work"].wait()
+                if self.world > 1:
+                    b["flat"].mul_(inv)
+                torch._foreach_copy_([q.grad for q in b["params"]], [b["flat"][o:o + q.numel()].view_as(q.grad) for o, q in zip(b["offs"], b["params"])])
+            self.opt.step()
+        self._remove_hooks()  # the captured graph no longer needs them (replays do not run Python)
 
     def _reduce_eager(self):
         """Warm-up iterations only: per-parameter all-reduce (keeps the replicas in step before the capture)."""
@@ -1374,12 +1493,12 @@ class GraphedTrainStep:
             close(cur)
 
     def payload_bytes(self):
-        return sum(f.numel() * f.element_size() for f, _, _ in self.buckets) if self.dist is not None else 0
+        return sum(f.numel() * f.element_size() for f, _, _ in self.buckets) if self.dist is not None else 0  # (per iteration and rank, either form)
 
     def __call__(self, batch):
         for k, v in batch.items():
             self.static[k].copy_(v)
-        self.graph.replay()
+        self.graph.replay()  # (dp_mode "overlap": the collectives are nodes of this graph)
         if self.graph_b is not None:
             works = [self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True) for flat, _, _ in self.buckets]
             for w in works:

