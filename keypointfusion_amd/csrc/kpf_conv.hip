@@ -69,6 +69,25 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return fmaxf(x, 0.f) - fabsf(q);
 }
 
+// GELU for bf16 outputs: x * sigmoid(x (c1 + c3 x^2 + c5 x^4)), a minimax fit of x Phi(x) with |error| <= 2.6e-5 absolute over the whole real line
+// (tools/gelu_fit.py): 30 x below a bf16 ulp of an O(1) value, in 9 VALU operations (2 transcendental) where the fp32-accurate form above takes 14 —
+// on a K = 512 layer the GELU of a 256 x 256 tile is a fifth of the tile's time.  NOT used for f16 outputs: measured against an f16 ulp with a floor
+// at 1e-3 of the tensor's range the fit is off by up to two ulps in the negative tail (tests/test_reduced_precision_gpu.py), so f16 keeps gelu_erf.
+__device__ __forceinline__ float gelu_h16(float x) {
+  const float x2 = x * x;
+  const float p = x * fmaf(x2, fmaf(x2, -7.03033577e-04f, 7.40112920e-02f), 1.59501577f);
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * p);
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+enum { ARITH_F32 = 0, ARITH_SPLIT = 1, ARITH_SPLIT_W = 2, ARITH_BF16 = 3, ARITH_F16 = 4 };
+// the GELU every epilogue of one arithmetic uses (all tile shapes of a storage type must agree bit for bit: a sample's result must not depend on
+// which kernel its batch size selects)
+template <int ARITH>
+__device__ __forceinline__ float gelu_of(float x) {
+  if constexpr (ARITH == ARITH_BF16) return gelu_h16(x);
+  else return gelu_erf(x);
+}
+
 enum { EPI_LIN = 0, EPI_GELU = 1, EPI_RES = 2 };
 #ifndef STORE4
 #define STORE4(p, v) *reinterpret_cast<f32x4*>(p) = (v)
@@ -102,8 +121,6 @@ constexpr int BK = 32;  // K-tile depth: 8 chunks of 16 B per staged row
 // elements per 128-byte K tile, so the staging is byte-identical again; the two 32-deep k-steps of a tile are one
 // v_mfma_f32_16x16x32_{bf16,f16} each.  All staging-side fields of ConvArgs (Cin, in_ld, in_coff, K, Kp) then count 4-byte words
 // (= 2 elements), all output-side fields elements.
-enum { ARITH_F32 = 0, ARITH_SPLIT = 1, ARITH_SPLIT_W = 2, ARITH_BF16 = 3, ARITH_F16 = 4 };
-
 // NS = LDS stages.  NS = 2: the DMA of tile k+1 flies under the MFMAs of tile k, one __syncthreads per K tile (its fence drains the
 // DMA).  NS > 2 (split arithmetic, where a K tile's MFMAs are shorter than the DMA latency): a ring with NS-1 tiles in flight — a
 // counted s_waitcnt vmcnt leaves the younger tiles' DMAs outstanding across a raw s_barrier; every wave issues the same number of DMA
@@ -611,7 +628,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
           }
         } else if (EPI == EPI_GELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e] + bv[e]);
+          for (int e = 0; e < 4; ++e) v[e] = gelu_of<ARITH>(v[e] + bv[e]);
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -661,7 +678,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
       for (int e = 0; e < 4; ++e) {
         if (n + e >= a.N) continue;
         float y = (SPLIT ? acc[i][j][e] * a.w_unscale : acc[i][j][e]) + (a.bias ? a.bias[n + e] : 0.f);
-        if (EPI == EPI_GELU) y = gelu_erf(y);
+        if (EPI == EPI_GELU) y = gelu_of<ARITH>(y);
         if (EPI == EPI_LIN && (fl & KPF_ACT_RELU)) y = fmaxf(y, 0.f);
         if (EPI == EPI_LIN && (fl & KPF_ACT_LEAKY)) y = fmaxf(y, 0.01f * y);
         if (EPI == EPI_RES) {
@@ -830,16 +847,6 @@ double cfg_cost(const Cfg& c, long M, long N) {
 // ---------------------------------------------------------------------------------------------------------------------------------
 constexpr int G8_BUF = 65536, G8_HALF = 16384, G8_B = 32768;  // bytes: K-tile buffer, half-tile, offset of the B halves inside a buffer
 template <int V> using ic = std::integral_constant<int, V>;
-
-// GELU for 16-bit outputs: x * sigmoid(x (c1 + c3 x^2 + c5 x^4)), a minimax fit of x Phi(x) with |error| <= 2.6e-5 absolute over the whole real line
-// (tools/gelu_fit.py) — below half an f16 ulp wherever |gelu| >= 0.06 and 30 x below a bf16 ulp — in 9 VALU operations (2 transcendental) where the
-// fp32-accurate form above takes 14: on a K = 512 layer the GELU of a 256 x 256 tile is a third of the tile's time.
-__device__ __forceinline__ float gelu_h16(float x) {
-  const float x2 = x * x;
-  const float p = x * fmaf(x2, fmaf(x2, -7.03033577e-04f, 7.40112920e-02f), 1.59501577f);
-  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * p);
-  return x * __builtin_amdgcn_rcpf(1.0f + e);
-}
 
 template <int EPI, int ARITH>
 __global__ __launch_bounds__(512, 2) void gemm16_8ph_kernel(const ConvArgs a) {
@@ -1068,7 +1075,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_8ph_kernel(const ConvArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const float y = v[e] + bvv[sn][i][e];
-              if (EPI == EPI_GELU) v[e] = (a.dbg & 1) ? y : gelu_h16(y);
+              if (EPI == EPI_GELU) v[e] = (a.dbg & 1) ? y : gelu_of<ARITH>(y);
               else v[e] = (fl & KPF_ACT_RELU) ? fmaxf(y, 0.f) : ((fl & KPF_ACT_LEAKY) ? fmaxf(y, 0.01f * y) : y);
             }
             kpf_st4(stg + (sm * 64 + j * 16 + fr) * RS + sn * 32 + i * 16 + fg * 4, v);

@@ -458,6 +458,7 @@ __global__ __launch_bounds__(256, 2) void convnext_mlp_h16_kernel(const Mlp16Arg
     B2s[i] = a.b2[i];
     Gs[i] = a.gamma[i];
   }
+  __syncthreads();  // the tables are visible to every wave (a raw s_barrier, as used in the ring below, would NOT wait for these ds_writes: lgkmcnt)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ordinary loads are done before the first LDS-DMA is issued: from here on vmcnt counts DMAs only
 
   // ---- weight ring ----

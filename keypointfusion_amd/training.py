@@ -632,22 +632,31 @@ class DeferredParamGrads:
         return False
 
     @staticmethod
-    def wants_colsum(weight):
+    def wants_colsum(weight, bias_ptr=None):
         """The d gamma / d beta column sums behind a LayerNorm / layer-scale backward (kpf_colsum_reduce_grouped): deferred when `weight`
-        is a whole parameter of the model (same storage address and size)."""
+        (and the bias at `bias_ptr`, for a LayerNorm: its gradient is the second row of the same deferred tensor) is a whole parameter of
+        the model (same storage address and size) that holds no gradient yet."""
         g = DeferredParamGrads.active
         if g is None:
             return None
         p = g.by_ptr.get(weight.data_ptr())
         # (a parameter that already holds a gradient would make AccumulateGrad ADD the still-unwritten tensor: not deferred)
-        return g if (p is not None and p.numel() == weight.numel() and p.grad is None) else None
+        if not (p is not None and p.numel() == weight.numel() and p.grad is None):
+            return None
+        if bias_ptr is not None:
+            bp = g.by_ptr.get(bias_ptr)
+            if bp is None or bp.numel() != weight.numel() or bp.grad is not None:
+                return None
+        return g
 
-    def add_colsum(self, weight, desc, ws, out):
+    def add_colsum(self, weight, desc, ws, out, bias_ptr=None, bias_out_ptr=None):
         key = ("colsum", weight.data_ptr())
         if key in self.seen:
             raise RuntimeError("DeferredParamGrads: a normalisation parameter receives a second gradient in one backward pass")
         self.seen.add(key)
         self.colsums.append((desc, ws, weight.data_ptr(), out.data_ptr()))  # (ws stays referenced; of the output only the address)
+        if bias_ptr is not None:
+            self.biases.append(("a LayerNorm", bias_ptr, bias_out_ptr))  # (adoption of the bias row is verified like a Linear's bias)
 
     @staticmethod
     def wants(key, cache, dy, x, kh, kw, stride, pad):
@@ -902,6 +911,7 @@ class LayerNormRows(torch.autograd.Function):
         L.check(L.load().kpf_ln_train_forward(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), _KDT[out_dtype], stats[0].data_ptr(), stats[1].data_ptr(),
                                               rows, Cc, float(eps), torch.cuda.current_stream().cuda_stream), "kpf_ln_train_forward")
         ctx.save_for_backward(x, stats, w)
+        ctx.bias_ptr = b.data_ptr()  # (identifies the bias PARAMETER for DeferredParamGrads: its gradient is deferred together with the weight's)
         return y
 
     @staticmethod
@@ -919,13 +929,13 @@ class LayerNormRows(torch.autograd.Function):
         nws = lib.kpf_ln_ws_floats(rows, Cc)
         ws = torch.empty(nws, device=x.device, dtype=torch.float32)
         st = torch.cuda.current_stream().cuda_stream
-        grp = DeferredParamGrads.wants_colsum(w)
+        grp = DeferredParamGrads.wants_colsum(w, ctx.bias_ptr)
         if grp is not None:  # d gamma / d beta: reduced with every other layer's after backward
             desc = L.ColsumDesc()
             L.check(lib.kpf_ln_train_backward_partial(dy.data_ptr(), _KDT[dy.dtype], x.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), w.data_ptr(),
                                                       dx.data_ptr(), dwb[0].data_ptr(), dwb[1].data_ptr(), ws.data_ptr(), nws, rows, Cc, C.byref(desc), st),
                     "kpf_ln_train_backward_partial")
-            grp.add_colsum(w, desc, ws, dwb)
+            grp.add_colsum(w, desc, ws, dwb, ctx.bias_ptr, dwb[1].data_ptr())
         else:
             L.check(lib.kpf_ln_train_backward(dy.data_ptr(), _KDT[dy.dtype], x.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), w.data_ptr(), dx.data_ptr(),
                                               dwb[0].data_ptr(), dwb[1].data_ptr(), ws.data_ptr(), nws, rows, Cc, st), "kpf_ln_train_backward")
@@ -1320,6 +1330,10 @@ class GraphedTrainStep:
                 self.opt.step()
         cur.wait_stream(side)
         torch.cuda.synchronize()
+        # what the warm-up iterations established (the one-graph data-parallel form fixes its buckets before backward is captured): the
+        # parameters that receive a gradient, in the order backward produces them, and those whose gradient is deferred past backward
+        self._warm_live = [p for p in reversed(self.params) if p.grad is not None]
+        self._warm_deferred = set(self._deferred_ids)
         self.opt.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
         self.graph_b = None
@@ -1376,7 +1390,7 @@ class GraphedTrainStep:
 
     # ---- data parallel, one graph: bucket collectives as graph nodes, launched from gradient hooks during backward ----
     def _flat_bucket(self, plist):
-        pdt = torch.bfloat16 if self.grad_payload == "bf16" else plist[0].grad.dtype
+        pdt = torch.bfloat16 if self.grad_payload == "bf16" else plist[0].dtype  # (gradients have their parameter's type)
         n = sum(p.numel() for p in plist)
         pad = (-n) % self.world if self.collective == "rs_ag" else 0  # (reduce-scatter wants equal shards)
         flat = torch.zeros(n + pad, dtype=pdt, device=plist[0].device)
@@ -1416,15 +1430,17 @@ class GraphedTrainStep:
         (the order backward produces them); those whose gradient DeferredParamGrads fills only after backward (the small Linear layers, the
         LayerNorm / layer-scale sums) go to late buckets that are reduced after the flush — they are a few MB of the payload."""
         cap = int(bucket_mb * 1024 * 1024)
-        live = [p for p in reversed(self.params) if p.grad is not None]
-        early = [p for p in live if id(p) not in self._deferred_ids]
-        late = [p for p in live if id(p) in self._deferred_ids]
+        live = self._warm_live
+        if not live:
+            raise RuntimeError("no parameter received a gradient in the warm-up iterations")
+        early = [p for p in live if id(p) not in self._warm_deferred]
+        late = [p for p in live if id(p) in self._warm_deferred]
 
         def split(plist):
             out, cur, nb = [], [], 0
             for q in plist:
-                b = q.numel() * (2 if self.grad_payload == "bf16" else q.grad.element_size())
-                if cur and (nb + b > cap or cur[0].grad.dtype != q.grad.dtype):
+                b = q.numel() * (2 if self.grad_payload == "bf16" else q.element_size())
+                if cur and (nb + b > cap or cur[0].dtype != q.dtype):
                     out.append(cur)
                     cur, nb = [], 0
                 cur.append(q)
