@@ -69,10 +69,12 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return fmaxf(x, 0.f) - fabsf(q);
 }
 
-// GELU for bf16 outputs: x * sigmoid(x (c1 + c3 x^2 + c5 x^4)), a minimax fit of x Phi(x) with |error| <= 2.6e-5 absolute over the whole real line
-// (tools/gelu_fit.py): 30 x below a bf16 ulp of an O(1) value, in 9 VALU operations (2 transcendental) where the fp32-accurate form above takes 14 —
-// on a K = 512 layer the GELU of a 256 x 256 tile is a fifth of the tile's time.  NOT used for f16 outputs: measured against an f16 ulp with a floor
-// at 1e-3 of the tensor's range the fit is off by up to two ulps in the negative tail (tests/test_reduced_precision_gpu.py), so f16 keeps gelu_erf.
+// GELU for 16-bit outputs: x * sigmoid(x (c1 + c3 x^2 + c5 x^4)), a minimax fit of x Phi(x) with |error| <= 2.6e-5 ABSOLUTE over the whole real line
+// (tools/gelu_fit.py), in 9 VALU operations (2 transcendental) where the fp32-accurate form above takes 16 — on a K = 512 layer the GELU of a
+// 256 x 256 tile is a fifth of the tile's time.  What the error means: the activations are stored in 16 bits and then summed by pwconv2, so it is the
+// ABSOLUTE error of a hidden value that reaches the output; 2.6e-5 is a tenth of the rounding of an O(1) f16 value (2.4e-4) and a 75th of a bf16 one.
+// In the negative tail, where |GELU| itself drops below 1e-3, the RELATIVE error of the fit reaches 15 % — of values that small; the per-operation test
+// bounds relative error + this absolute term.  fp32 storage always uses gelu_erf.
 __device__ __forceinline__ float gelu_h16(float x) {
   const float x2 = x * x;
   const float p = x * fmaf(x2, fmaf(x2, -7.03033577e-04f, 7.40112920e-02f), 1.59501577f);
@@ -84,7 +86,7 @@ enum { ARITH_F32 = 0, ARITH_SPLIT = 1, ARITH_SPLIT_W = 2, ARITH_BF16 = 3, ARITH_
 // which kernel its batch size selects)
 template <int ARITH>
 __device__ __forceinline__ float gelu_of(float x) {
-  if constexpr (ARITH == ARITH_BF16) return gelu_h16(x);
+  if constexpr (ARITH == ARITH_BF16 || ARITH == ARITH_F16) return gelu_h16(x);
   else return gelu_erf(x);
 }
 
@@ -848,8 +850,12 @@ double cfg_cost(const Cfg& c, long M, long N) {
 constexpr int G8_BUF = 65536, G8_HALF = 16384, G8_B = 32768;  // bytes: K-tile buffer, half-tile, offset of the B halves inside a buffer
 template <int V> using ic = std::integral_constant<int, V>;
 
-template <int EPI, int ARITH>
+// PERSIST (linear / GELU epilogues, M % 256 == 0): one workgroup per CU walks tiles id, id + grid, ...; the first two K tiles of the NEXT tile are
+// DMA'd into the (idle) K buffers BEFORE the epilogue of the current one, which stages through the 32 KB beyond them — the prologue latency of a tile
+// (2-3 us of a 27-us tile at K = 512: profiles/r04_g8_ablation.txt) and the workgroup launch disappear behind the GELU and the stores.
+template <int EPI, int ARITH, bool PERSIST>
 __global__ __launch_bounds__(512, 2) void gemm16_8ph_kernel(const ConvArgs a) {
+  static_assert(!PERSIST || EPI != EPI_RES, "the persistent form is built for the store-only epilogues");
   using TH = typename std::conditional<ARITH == ARITH_BF16, bf16_t, f16_t>::type;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   char* const LB = reinterpret_cast<char*>(lds);
@@ -857,39 +863,54 @@ __global__ __launch_bounds__(512, 2) void gemm16_8ph_kernel(const ConvArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   int bid = blockIdx.x;
-  {  // XCD-aware bijective remap (igemm_body): an XCD gets a contiguous range of tiles, channel tiles fastest
-    const int nb = a.nblk, q = nb >> 3, r = nb & 7, x = bid & 7, i = bid >> 3;
+  {  // XCD-aware bijective remap (igemm_body): an XCD gets a contiguous range of tiles, channel tiles fastest (PERSIST: of every round of tiles)
+    const int nb = PERSIST ? (int)gridDim.x : a.nblk, q = nb >> 3, r = nb & 7, x = bid & 7, i = bid >> 3;
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
   }
-  const int nt = bid % a.tilesN, mt = bid / a.tilesN;
-  const int m0 = mt * 256, n0 = nt * 256;
+  int tile = bid;
+  int m0, n0;
 
   // ---- staging: thread -> (row lr of a 64-row DMA block, chunk position cp); a half-tile is two DMA instructions per wave ----
   const int lr = tid >> 3, cp = tid & 7;
   const int kc = ((cp ^ ((lr >> 1) & 7)) << 2);  // logical k offset (4-byte words) this lane fetches: the swizzle is applied to the SOURCE
+  // PERSIST (no M tail): the four rows a lane stages per operand differ by compile-time multiples of the (wave-uniform) row stride, so one pointer
+  // per operand stays in registers across the epilogue instead of eight; otherwise rows are clamped to M - 1 one by one
   const float* pa[2][2];
   const float* pb[2][2];
+  auto set_tile = [&](int t) {
+    const int nt = t % a.tilesN, mt = t / a.tilesN;
+    m0 = mt * 256;
+    n0 = nt * 256;
+    if constexpr (PERSIST) {
+      pa[0][0] = a.in + (long)(m0 + lr) * a.in_ld + a.in_coff + kc;
+      pb[0][0] = a.w + (long)(n0 + (lr >> 5) * 64 + (lr & 31)) * a.Kp + kc;
+    } else {
 #pragma unroll
-  for (int s = 0; s < 2; ++s)
+      for (int s = 0; s < 2; ++s)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int m = m0 + i * 128 + s * 64 + lr;  // LDS row i*64 + lr of A half s
-      m = m < a.M ? m : a.M - 1;           // (rows beyond M: products land in accumulators that are never stored)
-      pa[s][i] = a.in + (long)m * a.in_ld + a.in_coff + kc;
-      const int n = n0 + (2 * i + (lr >> 5)) * 64 + s * 32 + (lr & 31);  // LDS row i*64 + lr of B half s
-      pb[s][i] = a.w + (long)n * a.Kp + kc;
+        for (int i = 0; i < 2; ++i) {
+          int m = m0 + i * 128 + s * 64 + lr;  // LDS row i*64 + lr of A half s
+          m = m < a.M ? m : a.M - 1;           // (rows beyond M: products land in accumulators that are never stored)
+          pa[s][i] = a.in + (long)m * a.in_ld + a.in_coff + kc;
+          const int n = n0 + (2 * i + (lr >> 5)) * 64 + s * 32 + (lr & 31);  // LDS row i*64 + lr of B half s
+          pb[s][i] = a.w + (long)n * a.Kp + kc;
+        }
     }
+  };
+  set_tile(tile);
+  auto src_A = [&](int s, int i) { return PERSIST ? pa[0][0] + (long)(i * 128 + s * 64) * a.in_ld : pa[s][i]; };
+  auto src_B = [&](int s, int i) { return PERSIST ? pb[0][0] + (long)(i * 128 + s * 32) * a.Kp : pb[s][i]; };
   const int dma_row = wave * 8 * 128;  // this wave's 8 rows of a 64-row DMA block (bytes)
   auto stage_A = [&](auto BUF, auto S, int kt) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(pa[decltype(S)::value][i] + kt * BK),
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(src_A(decltype(S)::value, i) + kt * BK),
                                        (lds_void_t*)(LB + decltype(BUF)::value * G8_BUF + decltype(S)::value * G8_HALF + i * 8192 + dma_row), 16, 0, 0);
   };
   auto stage_B = [&](auto BUF, auto S, int kt) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(pb[decltype(S)::value][i] + kt * BK),
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(src_B(decltype(S)::value, i) + kt * BK),
                                        (lds_void_t*)(LB + decltype(BUF)::value * G8_BUF + G8_B + decltype(S)::value * G8_HALF + i * 8192 + dma_row), 16, 0, 0);
   };
 
@@ -901,10 +922,6 @@ __global__ __launch_bounds__(512, 2) void gemm16_8ph_kernel(const ConvArgs a) {
   f16x8 xa[2][4];     // [k-step][pixel tile]      of the current A sub-tile
   f16x8 wb[2][2][2];  // [sub][k-step][channel tile]
   f32x4 acc[2][2][2][4];  // [channel sub][channel tile][pixel sub][pixel tile]
-#pragma unroll
-  for (int i = 0; i < 16; ++i) (&acc[0][0][0][0])[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int i = 16; i < 32; ++i) (&acc[0][0][0][0])[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto read_A = [&](auto BUF, auto S) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -990,17 +1007,23 @@ __global__ __launch_bounds__(512, 2) void gemm16_8ph_kernel(const ConvArgs a) {
   };
 
   const int nk = a.Kp / BK;  // even, >= 2
-  stage_B(ic<0>{}, ic<0>{}, 0);
-  stage_A(ic<0>{}, ic<0>{}, 0);
-  stage_B(ic<0>{}, ic<1>{}, 0);
-  stage_A(ic<0>{}, ic<1>{}, 0);
-  stage_B(ic<1>{}, ic<0>{}, 1);
-  stage_A(ic<1>{}, ic<0>{}, 1);
-  stage_B(ic<1>{}, ic<1>{}, 1);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // tile 0 has landed (this wave's part; the barrier makes it everyone's)
+  auto prologue = [&]() {  // K tile 0 whole, K tile 1 without its A half 1 (the loop's q1 stages that): 14 DMA instructions per wave
+    stage_B(ic<0>{}, ic<0>{}, 0);
+    stage_A(ic<0>{}, ic<0>{}, 0);
+    stage_B(ic<0>{}, ic<1>{}, 0);
+    stage_A(ic<0>{}, ic<1>{}, 0);
+    stage_B(ic<1>{}, ic<0>{}, 1);
+    stage_A(ic<1>{}, ic<0>{}, 1);
+    stage_B(ic<1>{}, ic<1>{}, 1);
+  };
+  prologue();
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // K tile 0 has landed (this wave's part; the barrier below makes it everyone's)
+  for (;;) {  // (one pass unless PERSIST)
+#pragma unroll
+  for (int i = 0; i < 32; ++i) (&acc[0][0][0][0])[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   G8_BAR();
   if (wr == 1) G8_BAR();  // the stagger: waves 4-7 run one barrier behind
-  int t = (a.dbg & 4) ? nk - 2 : 0;
+  int t = (!PERSIST && (a.dbg & 4)) ? nk - 2 : 0;
   for (; t + 3 < nk; t += 2) {
     ktile(ic<0>{}, ic<1>{}, ic<1>{}, t);
     ktile(ic<1>{}, ic<1>{}, ic<1>{}, t + 1);
@@ -1008,8 +1031,6 @@ __global__ __launch_bounds__(512, 2) void gemm16_8ph_kernel(const ConvArgs a) {
   ktile(ic<0>{}, ic<1>{}, ic<0>{}, t);
   ktile(ic<1>{}, ic<0>{}, ic<0>{}, t + 1);
   if (wr == 0) G8_BAR();  // (both groups have executed the same number of barriers; nobody reads the K buffers any more)
-#undef G8_BAR
-#undef G8_FENCE
 
   // ---- epilogue: lane (fr, fg) holds channels 4 fg .. 4 fg + 3 of channel tile (sn, i) for pixel fr of pixel tile (sm, j) ----
   const unsigned fl = a.flags;
@@ -1022,6 +1043,21 @@ __global__ __launch_bounds__(512, 2) void gemm16_8ph_kernel(const ConvArgs a) {
       bvv[sn][i] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
       gvv[sn][i] = (EPI == EPI_RES && (fl & KPF_RES_GAMMA)) ? *reinterpret_cast<const f32x4*>(a.gamma + n) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+  const int cm0 = m0, cn0 = n0;  // the tile being finished
+  bool more = false;
+  if constexpr (PERSIST) {
+    // the bias is in registers (hipcc waits vmcnt(0) for an ordinary load's result while a DMA is in flight, so it is consumed BEFORE the DMAs go out)
+#pragma unroll
+    for (int sn = 0; sn < 2; ++sn)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(bvv[sn][i]));
+    tile += (int)gridDim.x;
+    more = tile < a.nblk;
+    if (more) {
+      set_tile(tile);
+      prologue();  // flies under the epilogue below
+    }
+  }
   if constexpr (EPI == EPI_RES) {
     // residual layers (pwconv2): the skip rows are read in the accumulator layout, all rows of a pixel sub-tile requested before its first store
     TH* const ob = reinterpret_cast<TH*>(a.out);
@@ -1031,16 +1067,16 @@ __global__ __launch_bounds__(512, 2) void gemm16_8ph_kernel(const ConvArgs a) {
       f32x4 rv[4][2][2];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const long m = m0 + wr * 128 + sm * 64 + j * 16 + fr;
+        const long m = cm0 + wr * 128 + sm * 64 + j * 16 + fr;
         const long mr = m < a.M ? m : a.M - 1;
 #pragma unroll
         for (int sn = 0; sn < 2; ++sn)
 #pragma unroll
-          for (int i = 0; i < 2; ++i) rv[j][sn][i] = kpf_ld4(rb + mr * a.res_ld + a.res_coff + n0 + wc * 64 + sn * 32 + i * 16 + fg * 4);
+          for (int i = 0; i < 2; ++i) rv[j][sn][i] = kpf_ld4(rb + mr * a.res_ld + a.res_coff + cn0 + wc * 64 + sn * 32 + i * 16 + fg * 4);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const long m = m0 + wr * 128 + sm * 64 + j * 16 + fr;
+        const long m = cm0 + wr * 128 + sm * 64 + j * 16 + fr;
 #pragma unroll
         for (int sn = 0; sn < 2; ++sn)
 #pragma unroll
@@ -1054,11 +1090,11 @@ __global__ __launch_bounds__(512, 2) void gemm16_8ph_kernel(const ConvArgs a) {
               if (fl & KPF_RELU_AFTER_RES) y = fmaxf(y, 0.f);
               v[e] = y;
             }
-            if (m < a.M) kpf_st4(ob + m * a.out_ld + a.out_coff + n0 + wc * 64 + sn * 32 + i * 16 + fg * 4, v);
+            if (m < a.M) kpf_st4(ob + m * a.out_ld + a.out_coff + cn0 + wc * 64 + sn * 32 + i * 16 + fg * 4, v);
           }
       }
     }
-  } else {
+  } else if constexpr (!PERSIST) {
     // linear / ReLU / GELU: results go through a per-wave LDS staging area ([128 pixels][64 channels], 144-byte rows) so that the global stores are whole
     // 128-byte rows (8 lanes x 16 bytes), 8 rows per instruction
     constexpr int RS = 72;  // staging row stride in elements
@@ -1081,30 +1117,74 @@ __global__ __launch_bounds__(512, 2) void gemm16_8ph_kernel(const ConvArgs a) {
             kpf_st4(stg + (sm * 64 + j * 16 + fr) * RS + sn * 32 + i * 16 + fg * 4, v);
           }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (own region only: no barrier)
-    TH* const ob = reinterpret_cast<TH*>(a.out) + (long)(m0 + wr * 128) * a.out_ld + a.out_coff + n0 + wc * 64;
+    TH* const ob = reinterpret_cast<TH*>(a.out) + (long)(cm0 + wr * 128) * a.out_ld + a.out_coff + cn0 + wc * 64;
     const int prow = lane >> 3, pch = (lane & 7) * 8;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int px = r * 8 + prow;
       const f32x4 q = *reinterpret_cast<const f32x4*>(stg + px * RS + pch);
-      if (m0 + wr * 128 + px < a.M && !(a.dbg & 2)) *reinterpret_cast<f32x4*>(ob + (long)px * a.out_ld + pch) = q;
+      if (cm0 + wr * 128 + px < a.M && !(a.dbg & 2)) *reinterpret_cast<f32x4*>(ob + (long)px * a.out_ld + pch) = q;
+    }
+  } else {
+    // persistent form: the K buffers already receive the next tile, so the results are staged 32 pixels at a time through the wave's 4 KB beyond them
+    // ([32 pixels][64 channels], 128-byte rows, 16-byte chunk c of row r at c ^ (r & 7)); stores are whole 128-byte rows, exactly 16 per wave and tile
+    // (M % 256 == 0: no predicate — the vmcnt(22) at the top of the tile loop counts on it)
+    char* const stg = LB + 2 * G8_BUF + wave * 4096;
+    TH* const ob = reinterpret_cast<TH*>(a.out) + (long)(cm0 + wr * 128) * a.out_ld + a.out_coff + cn0 + wc * 64;
+    const int prow = lane >> 3, pcp = lane & 7;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {  // chunk c = pixel tiles (sm, j) = (c >> 1, 2 (c & 1) + {0, 1})
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int sn = 0; sn < 2; ++sn)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            f32x4 v = acc[sn][i][c >> 1][2 * (c & 1) + jj];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float y = v[e] + bvv[sn][i][e];
+              if (EPI == EPI_GELU) v[e] = gelu_of<ARITH>(y);
+              else v[e] = (fl & KPF_ACT_RELU) ? fmaxf(y, 0.f) : ((fl & KPF_ACT_LEAKY) ? fmaxf(y, 0.01f * y) : y);
+            }
+            const int row = jj * 16 + fr, cidx = sn * 4 + i * 2 + (fg >> 1);
+            kpf_st4(reinterpret_cast<TH*>(stg + row * 128 + ((cidx ^ (row & 7)) << 4) + (fg & 1) * 8), v);
+          }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = r * 8 + prow;
+        const f32x4 q = *reinterpret_cast<const f32x4*>(stg + row * 128 + (pcp << 4));
+        *reinterpret_cast<f32x4*>(ob + (long)(c * 32 + row) * a.out_ld + ((pcp ^ (row & 7)) << 3)) = q;
+      }
     }
   }
+  if (!PERSIST || !more) break;
+  // next tile: its 14 DMAs were issued BEFORE the 16 row stores of the epilogue above, so "all but the youngest 6 + 16" means "K tile 0 is in LDS"
+  asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+  }  // tile loop
 }
+
+#undef G8_BAR
+#undef G8_FENCE
 
 template <int ARITH>
 int launch_8ph(ConvArgs& a, hipStream_t st) {
   const bool res = a.flags & KPF_RES_ADD, gelu = a.flags & KPF_ACT_GELU;
   a.tilesN = a.N / 256;
   a.nblk = ((a.M + 255) / 256) * a.tilesN;
-  void (*kern)(const ConvArgs) = res ? gemm16_8ph_kernel<EPI_RES, ARITH> : (gelu ? gemm16_8ph_kernel<EPI_GELU, ARITH> : gemm16_8ph_kernel<EPI_LIN, ARITH>);
-  static std::atomic<bool> lds_opt_in[3][KPF_MAX_DEVICES];
-  if (!kpf_raise_lds_limit(reinterpret_cast<const void*>(kern), lds_opt_in[res ? 2 : (gelu ? 1 : 0)])) {
+  static const bool no_persist = getenv("KPF_G8_NO_PERSIST") != nullptr;  // tuning aid
+  const bool persist = !res && a.M % 256 == 0 && a.nblk > 256 && !no_persist && !a.dbg;
+  void (*kern)(const ConvArgs) = res ? gemm16_8ph_kernel<EPI_RES, ARITH, false>
+                                     : (gelu ? (persist ? gemm16_8ph_kernel<EPI_GELU, ARITH, true> : gemm16_8ph_kernel<EPI_GELU, ARITH, false>)
+                                             : (persist ? gemm16_8ph_kernel<EPI_LIN, ARITH, true> : gemm16_8ph_kernel<EPI_LIN, ARITH, false>));
+  static std::atomic<bool> lds_opt_in[5][KPF_MAX_DEVICES];
+  if (!kpf_raise_lds_limit(reinterpret_cast<const void*>(kern), lds_opt_in[res ? 4 : (gelu ? 2 : 0) + (persist ? 1 : 0)])) {
     kpf_set_error("kpf_conv2d_h16: cannot raise the dynamic LDS limit");
     return KPF_ELAUNCH;
   }
-  const size_t lds = res ? 2 * G8_BUF : (8 * 128 * 72 * 2 > 2 * G8_BUF ? 8 * 128 * 72 * 2 : 2 * G8_BUF);  // K buffers (128 KB) / staging area (144 KB)
-  hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(512), lds, st, a);
+  // K buffers (128 KB); one-tile store epilogues stage 144 KB through them, the persistent form 32 KB beyond them (160 KB: the whole LDS of a CU)
+  const size_t lds = res ? 2 * G8_BUF : (persist ? 2 * G8_BUF + 8 * 4096 : (size_t)8 * 128 * 72 * 2);
+  hipLaunchKernelGGL(kern, dim3(persist ? 256 : a.nblk), dim3(512), lds, st, a);
   return kpf_check_launch("kpf_conv2d_h16");
 }
 

@@ -96,6 +96,12 @@ def test_conv2d_h16_is_the_fp32_conv_of_the_rounded_operands(case, prec):
         o = conv16(p16, xa, kdt, flags=flags, **kw)
         got = o.buf.view(B, OH, OW, N).permute(0, 3, 1, 2).float().cpu().double()
         tol = 1.01 * eps
+    if kind == "gelu":
+        # 16-bit outputs use the 9-operation GELU (csrc/kpf_conv.hip gelu_h16): |error| <= 2.6e-5 ABSOLUTE (what reaches pwconv2's sums), on top of
+        # the output rounding — bounded as an absolute term, not against the 1e-3-of-range floor of the other epilogues
+        bad = (got - ref).abs() - (1.3 * tol * ref.abs() + 3.5e-5)
+        assert float(bad.max()) <= 0, (case, prec, float(bad.max()))
+        return
     err = float(((got - ref).abs() / (ref.abs() + ref.abs().max() * 1e-3)).max()) if kind != "nchw" else rel(got, ref)
     assert err < 2.5 * tol + 1e-6, (case, prec, err)  # elementwise relative (floor at 1e-3 of the range): output rounding only
 
@@ -251,10 +257,24 @@ def test_full_model_reduced_precision_tolerance_in_mm(net, prec, mean_tol, final
     assert all(t.dtype == torch.float32 and bool(torch.isfinite(t).all()) for t in res + sws)
     for k in (0, 1):
         assert rel(res[k], ref[k]) < map_tol, (prec, k, rel(res[k], ref[k]))
-    mm = [float((res[k].cpu() - ref[k]).norm(dim=-1).max()) * 125.0 for k in range(2, 6)]  # cube 250 mm: x * 125 mm
-    mean_mm = [float((res[k].cpu() - ref[k]).norm(dim=-1).mean()) * 125.0 for k in range(2, 6)]
-    print("reduced precision %s %s: max joint deviation per stage %s mm, mean %s mm" % (net, prec, ["%.3f" % v for v in mm], ["%.3f" % v for v in mean_mm]))
-    assert max(mean_mm) < mean_tol and mean_mm[3] < final_tol and max(mm) < 60.0, (prec, mean_mm, mm)
+    dev_mm = [(res[k].cpu() - ref[k]).norm(dim=-1).reshape(-1) * 125.0 for k in range(2, 6)]  # cube 250 mm: x * 125 mm; B * 21 joints per stage
+    mm = [float(d.max()) for d in dev_mm]
+    mean_mm = [float(d.mean()) for d in dev_mm]
+    med_mm = [float(d.median()) for d in dev_mm]
+    p90_mm = [float(d.kthvalue(int(0.9 * d.numel()))[0]) for d in dev_mm]
+    jumps = [int((d > 5.0).sum()) for d in dev_mm]
+    print("reduced precision %s %s per stage: mean %s  median %s  p90 %s  max %s mm; joints > 5 mm: %s of %d" % (
+        net, prec, ["%.3f" % v for v in mean_mm], ["%.3f" % v for v in med_mm], ["%.3f" % v for v in p90_mm], ["%.2f" % v for v in mm], jumps, dev_mm[0].numel()))
+    assert max(mean_mm) < mean_tol and mean_mm[3] < final_tol, (prec, mean_mm, mm)
+    # Flip-aware bounds instead of a loose maximum (tools/bf16_sensitivity.py): the deviation has a continuous part — bounded through the
+    # median — and JUMPS of single joints by 5-25 mm when a ball-query neighbourhood or a top-4 pixel set changes by one point (discrete decisions
+    # taken around network outputs; with untrained weights the intermediate 3-D estimate of block 2, which is decoded around block 1's refined
+    # joints, jumps for 4-12 % of the joints, whichever layers are rounded).  Jumps are counted, not averaged away; the FINAL estimate (what the
+    # accuracy metric of BASELINE.json is computed on) must not jump at all.
+    med_tol, fin_p90 = (1.5, 2.5) if prec == "bf16" else (0.7, 2.0)
+    assert max(med_mm) < med_tol, (prec, med_mm)
+    assert max(jumps) <= int(0.15 * dev_mm[0].numel()), (prec, jumps)
+    assert jumps[3] == 0 and mm[3] < 5.0 and p90_mm[3] < fin_p90, (prec, jumps, mm, p90_mm)
 
 
 def test_full_model_bf16_at_the_stated_batch_of_configs2():
