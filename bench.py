@@ -21,7 +21,7 @@ One JSON line is printed by rank 0 with, besides the contract fields:
                  launches in one step / summed device time of those launches (HIP events recorded on the launch stream in an
                  instrumented pass after the timed region, both backbones on ONE stream), against the dense f32-input MFMA peak
                  157.3 TFLOP/s.  `traffic` = HBM bytes per launch from the rocprofv3 PMC passes of this same command, collected
-                 offline and committed (profiles/r03_traffic.json, tools/collect_traffic.py): `traffic_source` says so.
+                 offline and committed (profiles/r04_traffic.json, tools/collect_traffic.py): `traffic_source` says so.
   split_f16x3  : SECONDARY record, not the headline and not IEEE fp32: the same workload with KPF_GEMM=split (the ConvNeXt-block GEMMs
                  as 3 x f16 MFMA on hi/lo-split operands with a pack-time range proof; everything else stays on the f32 MFMA).
   extra        : (default run, N = 1) one timed record per further BASELINE config that fits one GPU — `cnb512_f16` (configs[4]: ConvNeXt-B,
@@ -61,7 +61,7 @@ WORKLOADS = {
 
 
 def kernel_peak(name):
-    if "h16" in name:
+    if "h16" in name or "gemm16" in name:
         return PEAK_F16_MFMA_TFLOPS
     return PEAK_SPLIT_TFLOPS if "split" in name else PEAK_F32_MFMA_TFLOPS
 
@@ -320,7 +320,7 @@ def main():
         ach = fl / (t_ms * 1e-3) / 1e12
         traffic, tsrc = None, None
         tpath = os.path.join(ROOT, "profiles", traffic_file) if traffic_file else None
-        if tpath and args.workload == "backbones256" and B == 64 and os.path.exists(tpath):
+        if tpath and args.workload in ("backbones256", "cnb512_f16") and B == 64 and os.path.exists(tpath):
             tj = json.load(open(tpath))
             if dom.startswith(tj.get("kernel", "~")):
                 traffic = round(tj["hbm_bytes_per_launch"])
@@ -330,7 +330,7 @@ def main():
         return {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc,
                 "peak_note": ("algorithmic-FLOP roof of the 3 x f16 split scheme = dense f16 MFMA peak 2500 / 3; executed MFMA rate = %.0f TFLOP/s"
-                              % (3 * ach)) if "split" in dom else ("dense 16-bit MFMA peak (v_mfma_f32_16x16x32_bf16 / _f16)" if "h16" in dom
+                              % (3 * ach)) if "split" in dom else ("dense 16-bit MFMA peak (v_mfma_f32_16x16x32_bf16 / _f16)" if ("h16" in dom or "gemm16" in dom)
                                                                     else "dense f32-input MFMA peak (v_mfma_f32_16x16x4_f32)"),
                 "algo_bytes_per_launch": round(nb / n), "algo_hbm_gbps": round(nb / (t_ms * 1e-3) / 1e9, 1), "hbm_frac_of_8000": round(nb / (t_ms * 1e-3) / 8e12, 4),
                 "launches_per_step": n, "avg_launch_ms": round(t_ms / n, 4),
@@ -382,7 +382,8 @@ def main():
                 for name, e0, e1, fl_i, nb, shp in recs:
                     ms = e0.elapsed_time(e1)
                     f.write("%s,%d,%d,%d,%d,%d,%.4f,%.1f\n" % ((name,) + tuple(shp) + (ms, fl_i / ms / 1e9)))
-        roofline = roofline_of(recs, ms_per_step, "r03_traffic.json" if args.gemm == "f32" else "r03_traffic_split.json")
+        roofline = roofline_of(recs, ms_per_step, {"backbones256": "r04_traffic.json" if args.gemm == "f32" else "r04_traffic_split.json",
+                                                   "cnb512_f16": "r04_traffic_cnb512.json"}.get(args.workload))
 
     # ---- secondary record: split (3 x f16) arithmetic where a range proof exists; NOT the headline, NOT IEEE fp32 ----
     split_rec = None
@@ -397,7 +398,7 @@ def main():
                          "note": "SECONDARY, not IEEE fp32: ConvNeXt-block GEMMs as 3 x v_mfma_f32_16x16x32_f16 on f16 hi+lo operands (22-bit "
                                  "significands, f16 range, operands proven in range at pack time and pre-scaled), fp32 accumulate; all "
                                  "other GEMMs on the f32-input MFMA"}
-            split_rec["roofline"] = roofline_of(instrumented(), dts / args.steps * 1e3, "r03_traffic_split.json")
+            split_rec["roofline"] = roofline_of(instrumented(), dts / args.steps * 1e3, "r04_traffic_split.json")
         finally:
             E.GEMM_MODE = args.gemm
             fresh_plan()

@@ -270,6 +270,9 @@ int kpf_mano_forward_f32(const float* pose6d, int ld6, const float* betas, int l
  * heads).  The split-operand flags do not apply. */
 int kpf_conv2d_h16(const kpf_conv_desc* desc, const void* in, const void* w, const float* bias, const float* pro_scale,
                    const float* pro_shift, const float* gamma, const void* res, void* out, int dtype, void* stream);
+/* 1 when kpf_conv2d_h16 runs `d` on the eight-phase 256 x 256 kernel (gemm16_8ph_kernel: dense 1x1, K % 128 == 0, N % 256 == 0, at least 224 tiles), 0 when
+ * on igemm_h16_kernel — for callers that label per-kernel measurements (bench.py's roofline); has_prologue: pro_scale != NULL. */
+int kpf_conv2d_h16_uses_8ph(const kpf_conv_desc* d, int has_prologue);
 
 /* kpf_dwconv7_ln_f32 with 16-bit activations in and out (fp32 taps, fp32 accumulation and LayerNorm statistics). */
 int kpf_dwconv7_ln_h16(const void* x, const float* w_dw, const float* b_dw, const float* ln_w, const float* ln_b, void* y, int B,

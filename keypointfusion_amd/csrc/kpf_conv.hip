@@ -1225,6 +1225,24 @@ int launch_cfg_h16(ConvArgs& a, bool fast1x1, bool pointwise, int dtype, hipStre
 }  // namespace
 
 #ifdef KPF_CONV_H16
+// which launches take gemm16_8ph_kernel (one rule for the dispatcher and for callers that label their profiles: kpf_conv2d_h16_kernel)
+static bool g8_applies(const kpf_conv_desc* d, bool has_prologue) {
+  const unsigned fl = d->flags;
+  const bool pointwise = d->KH == 1 && d->KW == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0 && d->IH == d->OH && d->IW == d->OW;
+  const bool fast1x1 = pointwise && d->Cin % 64 == 0 && d->Kp == d->Cin;
+  const bool vec = d->out_ld % 4 == 0 && d->out_coff % 4 == 0 && (!(fl & KPF_RES_ADD) || (d->res_ld % 4 == 0 && d->res_coff % 4 == 0));
+  return fast1x1 && d->Kp % 128 == 0 && d->N % 256 == 0 && !has_prologue && !(fl & KPF_OUT_NCHW) && vec && d->out_ld % 8 == 0 && d->out_coff % 8 == 0;
+}
+static bool g8_preferred(const kpf_conv_desc* d) {
+  const long M = (long)d->B * d->OH * d->OW;
+  return ((M + 255) / 256) * (d->N / 256) >= 224;
+}
+/* 1 when kpf_conv2d_h16 runs this descriptor on gemm16_8ph_kernel, 0 when on igemm_h16_kernel (profile labels; same rule as the dispatcher) */
+extern "C" int kpf_conv2d_h16_uses_8ph(const kpf_conv_desc* d, int has_prologue) {
+  static const bool no8 = getenv("KPF_NO_8PH") != nullptr;
+  return d && !no8 && g8_applies(d, has_prologue != 0) && g8_preferred(d) ? 1 : 0;
+}
+
 extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void* w, const float* bias, const float* pro_scale,
                               const float* pro_shift, const float* gamma, const void* res, void* out, int dtype, void* stream) {
   KPF_REQUIRE(d && in && w && out, "kpf_conv2d_h16: null pointer");
@@ -1299,10 +1317,9 @@ extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void
   // MFMA cluster): +24 % over case 20 on 65536 x 512 x 2048 (841 vs 679 TFLOP/s), 1049 vs 935 on 16384 x 1024 x 4096
   if ((fl & KPF_RES_ADD) && fast1x1 && a.Kp * 2 >= 2048 && a.M >= 16384 && a.N >= 256 && a.N % 256 == 0) best = 26;
   // Round 4: the eight-phase 256 x 256 kernel (gemm16_8ph_kernel) for every dense 1x1 layer it covers with at least one full round of tiles
-  const bool ok8 = fast1x1 && d->Kp % 128 == 0 && a.N % 256 == 0 && !pro_scale && !(fl & KPF_OUT_NCHW) && a.vec && d->out_ld % 8 == 0 && d->out_coff % 8 == 0 &&
-                   (!(fl & KPF_RES_ADD) || (d->res_ld % 4 == 0 && d->res_coff % 4 == 0));
+  const bool ok8 = g8_applies(d, pro_scale != nullptr);
   static const bool no8 = getenv("KPF_NO_8PH") != nullptr;  // tuning aid: A/B against the round-3 tile shapes
-  if (ok8 && !no8 && (long)((a.M + 255) / 256) * (a.N / 256) >= 224) best = 30;
+  if (ok8 && !no8 && g8_preferred(d)) best = 30;
   static const int forced = []() { const char* e = getenv("KPF_FORCE_CFG16"); return e ? atoi(e) : -1; }();  // tuning aid only
   if (forced >= 0 && (forced != 30 || ok8)) best = forced;
   if (best == 30) return dtype == KPF_DT_BF16 ? launch_8ph<ARITH_BF16>(a, st) : launch_8ph<ARITH_F16>(a, st);

@@ -409,6 +409,7 @@ struct Mlp16Args {
   const float* gamma;
   void* out;         // [M][C] 16-bit (may alias x)
   int M;
+  int dbg;           // tuning aid (KPF_MLP16_DBG): 1 = no GELU, 2 = no epilogue stores, 4 = no weight DMA / waits (garbage weights)
 };
 
 __device__ __forceinline__ float gelu_h16m(float x) {  // x * sigmoid(x (c1 + c3 x^2 + c5 x^4)): |error| <= 2.6e-5 (kpf_conv.hip gelu_h16, tools/gelu_fit.py)
@@ -418,8 +419,8 @@ __device__ __forceinline__ float gelu_h16m(float x) {  // x * sigmoid(x (c1 + c3
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
-template <int C, int PT, int R, bool BF>
-__global__ __launch_bounds__(256, 2) void convnext_mlp_h16_kernel(const Mlp16Args a) {
+template <int C, int PT, int R, bool BF, int WPS = 2>
+__global__ __launch_bounds__(256, WPS) void convnext_mlp_h16_kernel(const Mlp16Args a) {
   using TH = typename std::conditional<BF, bf16_t, f16_t>::type;
   constexpr int NW = 4, NT = 256;
   constexpr int KC = C / 32;        // K steps of GEMM1
@@ -484,8 +485,9 @@ __global__ __launch_bounds__(256, 2) void convnext_mlp_h16_kernel(const Mlp16Arg
     for (int p = 0; p < P2; ++p)
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(g2 + s2 + p * 64 * 32), (lds_void_t*)(dst + W1B + p * NT * 16), 16, 0, 0);
   };
+  if (!(a.dbg & 4))
 #pragma unroll
-  for (int c = 0; c < R - 1; ++c) stage(c, c);
+    for (int c = 0; c < R - 1; ++c) stage(c, c);
 
   f32x4 acc[NCT][PT];
 #pragma unroll
@@ -499,11 +501,12 @@ __global__ __launch_bounds__(256, 2) void convnext_mlp_h16_kernel(const Mlp16Arg
     constexpr int slot = decltype(SLOT)::value;
     // chunk ch has landed once at most the younger chunks' DMAs are outstanding: R - 2 in steady state, fewer at the tail
     const int younger = NCH - 1 - ch;
-    if (younger >= R - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * G) : "memory");
+    if (a.dbg & 4) {
+    } else if (younger >= R - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * G) : "memory");
     else if (R > 3 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // everyone's part of chunk ch is in LDS; everyone has finished reading chunk ch - 1's stage
-    if (ch + R - 1 < NCH) stage(ch + R - 1, (slot + R - 1) % R);
+    if (ch + R - 1 < NCH && !(a.dbg & 4)) stage(ch + R - 1, (slot + R - 1) % R);
     const char* const sb = LB + slot * CHB;
     f32x4 d1[2][PT];
 #pragma unroll
@@ -530,8 +533,8 @@ __global__ __launch_bounds__(256, 2) void convnext_mlp_h16_kernel(const Mlp16Arg
       typename std::conditional<BF, bf16x8, f16x8>::type h;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        h[e] = (TH)gelu_h16m(d1[0][pt][e] + bv0[e]);
-        h[4 + e] = (TH)gelu_h16m(d1[1][pt][e] + bv1[e]);
+        h[e] = (TH)((a.dbg & 1) ? d1[0][pt][e] + bv0[e] : gelu_h16m(d1[0][pt][e] + bv0[e]));
+        h[4 + e] = (TH)((a.dbg & 1) ? d1[1][pt][e] + bv1[e] : gelu_h16m(d1[1][pt][e] + bv1[e]));
       }
       hf[pt] = __builtin_bit_cast(f16x8, h);
     }
@@ -586,16 +589,16 @@ __global__ __launch_bounds__(256, 2) void convnext_mlp_h16_kernel(const Mlp16Arg
     const int c = p ^ (row & 15);
     const f32x4 q = *reinterpret_cast<const f32x4*>(stg + row * ROWB + (p << 4));
     const long m = m0 + wave * PT * 16 + row;
-    if (m < a.M) *reinterpret_cast<f32x4*>(og + m * C + 8 * c) = q;
+    if (m < a.M && !(a.dbg & 2)) *reinterpret_cast<f32x4*>(og + m * C + 8 * c) = q;
   }
 }
 
-template <int C, int PT, int R>
+template <int C, int PT, int R, int WPS = 2>
 int launch_mlp_h16(const Mlp16Args& a, int dtype, hipStream_t st) {
   constexpr int CHB = 32 * C * 2 + C * 64, BM = 16 * PT * 4;
   const size_t lds = (size_t)R * CHB + 6 * C * sizeof(float);
   static_assert(4 * PT * 16 * 2 * C <= R * CHB, "the staging area lives in the ring");
-  void (*kern)(const Mlp16Args) = dtype == KPF_DT_BF16 ? convnext_mlp_h16_kernel<C, PT, R, true> : convnext_mlp_h16_kernel<C, PT, R, false>;
+  void (*kern)(const Mlp16Args) = dtype == KPF_DT_BF16 ? convnext_mlp_h16_kernel<C, PT, R, true, WPS> : convnext_mlp_h16_kernel<C, PT, R, false, WPS>;
   static std::atomic<bool> lds_opt_in[2][KPF_MAX_DEVICES];
   if (!kpf_raise_lds_limit(reinterpret_cast<const void*>(kern), lds_opt_in[dtype == KPF_DT_BF16 ? 1 : 0])) {
     kpf_set_error("kpf_convnext_mlp_h16: cannot raise the dynamic LDS limit");
@@ -699,7 +702,12 @@ extern "C" int kpf_convnext_mlp_h16(const void* y, const void* x, const void* w1
               "kpf_convnext_mlp_h16: pointers must be 16-byte aligned");
   Mlp16Args a;
   a.y = y; a.x = x; a.w1 = w1; a.b1 = b1; a.w2c = w2_chunks; a.b2 = b2; a.gamma = gamma; a.out = out; a.M = (int)M;
+  static const int dbg = []() { const char* e = getenv("KPF_MLP16_DBG"); return e ? atoi(e) : 0; }();
+  a.dbg = dbg;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  static const int cfg = []() { const char* e = getenv("KPF_MLP16_CFG"); return e ? atoi(e) : 0; }();  // tuning aid
+  if (C == 128 && cfg == 1) return launch_mlp_h16<128, 2, 2, 3>(a, dtype, st);  // 32 pixels per wave, 2 stages (35 KB): three workgroups per CU
+  if (C == 128 && cfg == 2) return launch_mlp_h16<128, 2, 4, 2>(a, dtype, st);
   if (C == 128) return launch_mlp_h16<128, 3, 4>(a, dtype, st);  // 48 pixels per wave, 4-stage ring of 16-KB chunks (67 KB of LDS)
   return launch_mlp_h16<256, 2, 2>(a, dtype, st);                 // 32 pixels per wave, 2 stages of 32 KB (70 KB)
 }

@@ -20,6 +20,11 @@ DW_STATS = bool(int(__import__("os").environ.get("KPF_DW_STATS", "1")))  # depth
 DW_STATS_MIN_C = int(__import__("os").environ.get("KPF_DW_STATS_MIN_C", "256"))  # (at C = 128 the one-pass wave kernel is still faster: 311 vs 363 us)
 
 
+def PROFILE_LABELS():
+    from . import engine as _E
+    return _E.PROFILE is not None  # (the label lookup is a library call: only when bench.py is collecting per-launch events)
+
+
 def empty16(B, H, W, Cc, device, tdt):
     a = Act(torch.empty(B * H * W * Cc, device=device, dtype=tdt), B, H, W, Cc)
     return a
@@ -72,7 +77,8 @@ def conv16(p16, x, kdt, out=None, flags=0, gamma=None, res=None, out_nchw=None):
     d.flags = flags
     M = B * OH * OW
     nbytes = 2.0 * (B * IH * IW * pc.Cin + pc.N * pc.K + M * pc.N * (2 if res is not None else 1))
-    _launch("igemm_h16_kernel", pc.flops(M), nbytes, (M, pc.N, pc.K, pc.KH, pc.KW),
+    name = "gemm16_8ph_kernel" if (PROFILE_LABELS() and lib.kpf_conv2d_h16_uses_8ph(C.byref(d), 1 if pc.ps is not None else 0)) else "igemm_h16_kernel"
+    _launch(name, pc.flops(M), nbytes, (M, pc.N, pc.K, pc.KH, pc.KW),
             lambda: L.check(lib.kpf_conv2d_h16(C.byref(d), _ptr(x.buf), _ptr(p16.w), _ptr(pc.b), _ptr(pc.ps), _ptr(pc.pt), _ptr(gamma),
                                                _ptr(res.buf if res is not None else None), _ptr(optr), kdt, _stream()), "kpf_conv2d_h16"))
     return out

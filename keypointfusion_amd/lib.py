@@ -69,6 +69,7 @@ _SIGS = {
     "kpf_tr_encoder_f32": [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, _P],
     "kpf_xattn_layer_f32": [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P],
     "kpf_conv2d_h16": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P],
+    "kpf_conv2d_h16_uses_8ph": [C.POINTER(ConvDesc), C.c_int],
     "kpf_dwconv7_ln_h16": [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _P],
     "kpf_layernorm_h16": [_P, C.c_int, _P, _P, _P, C.c_int, C.c_long, C.c_int, C.c_float, _P],
     "kpf_upsample2x_h16": [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P],

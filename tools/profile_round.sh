@@ -1,8 +1,8 @@
 #!/bin/bash
-# Collects the rocprofv3 evidence of a round on the GPU box (run through gpurun from the repo root):  bash tools/profile_round.sh r03
+# Collects the rocprofv3 evidence of a round on the GPU box (run through gpurun from the repo root):  bash tools/profile_round.sh r04
 # kernel-trace statistics of the headline command (both backbones on one stream, so per-kernel durations are each kernel's own) and the
 # two PMC passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass) of the same command; summaries land in gpurun_out/<tag>_*.
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
@@ -13,6 +13,11 @@ cp $(find $OUT/prof_${TAG}_f32 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_${TAG}_fetch -- python3 $CMD --steps 3 --warmup 1 > $OUT/pmc_${TAG}_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_${TAG}_write -- python3 $CMD --steps 3 --warmup 1 > $OUT/pmc_${TAG}_write.log 2>&1
 python3 $ROOT/tools/collect_traffic.py $OUT/pmc_${TAG}_fetch $OUT/pmc_${TAG}_write $OUT/${TAG}_traffic.json igemm_f32_kernel
+# configs[4]: HBM traffic of the dominant 16-bit kernel (gemm16_8ph_kernel), same two PMC passes
+CMD4="$ROOT/bench.py --workload cnb512_f16 --serial-streams --no-cpu-baseline"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_${TAG}_fetch4 -- python3 $CMD4 --steps 2 --warmup 1 > $OUT/pmc_${TAG}_fetch4.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_${TAG}_write4 -- python3 $CMD4 --steps 2 --warmup 1 > $OUT/pmc_${TAG}_write4.log 2>&1
+python3 $ROOT/tools/collect_traffic.py $OUT/pmc_${TAG}_fetch4 $OUT/pmc_${TAG}_write4 $OUT/${TAG}_traffic_cnb512.json gemm16_8ph_kernel
 for W in full128 full128_bf16 cnb512_f16; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_$W -- python3 $ROOT/bench.py --workload $W --serial-streams --no-cpu-baseline --no-split-record --steps 10 > $OUT/prof_${TAG}_$W.log 2>&1
   cp $(find $OUT/prof_${TAG}_$W -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_${W}_kernel_stats.csv
@@ -23,12 +28,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_train12
 cp $(find $OUT/prof_${TAG}_train128_bf16 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_train128_bf16_kernel_stats.csv
 # the bench lines of the same build, without the profiler
 cd $ROOT
-python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+python3 bench.py --no-extra > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 for W in full128 full128_bf16 cnb512_f16 train128 train128_bf16; do
   python3 bench.py --workload $W --no-cpu-baseline > $OUT/${TAG}_bench_$W.json 2> $OUT/${TAG}_bench_$W.err
 done
 # keep the merge small: the raw traces stay on the box
-for d in $OUT/prof_${TAG}_* $OUT/pmc_${TAG}_fetch $OUT/pmc_${TAG}_write; do [ -d "$d" ] && rm -rf "$d"; done
+for d in $OUT/prof_${TAG}_* $OUT/pmc_${TAG}_fetch $OUT/pmc_${TAG}_write $OUT/pmc_${TAG}_fetch4 $OUT/pmc_${TAG}_write4; do [ -d "$d" ] && rm -rf "$d"; done
 python3 tools/shape_table.py > $OUT/${TAG}_shape_table.txt 2>/dev/null
 [ -x tools/bin/mfma_issue_rate2 ] && tools/bin/mfma_issue_rate2 > $OUT/${TAG}_mfma_issue_rate2.txt
 ls -la $OUT | grep ${TAG}_
