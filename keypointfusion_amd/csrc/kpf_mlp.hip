@@ -398,6 +398,12 @@ __global__ __launch_bounds__(64 * NW) void convnext_mlp_split_kernel(const MlpSp
 //   * per chunk and wave: GEMM1 2 x PT x C/32 MFMAs -> bias + GELU on 8 PT registers -> packed in place as GEMM2's B operand -> C/16 x PT MFMAs.
 //   * epilogue: out = x + gamma * (acc + b2) in fp32 (x read in the accumulator layout), rounded once, staged through the wave's share of
 //     the idle ring so that the global stores are whole 2C-byte rows.
+// Measured and not adopted (round 4, C = 128, 10^6 pixels, tools/mlp16_bench.py; ablation with KPF_MLP16_DBG: of 484 us the GELU takes 114 — its
+// vector-ALU floor —, the chunk-boundary waits / DMA issue 94, the stores 29): (i) a producer / consumer split (8 waves: waves 0-3 GEMM1 + GELU,
+// handing the packed operand to waves 4-7 through LDS lane for lane, which run GEMM2 of the previous chunk; one register array reinterpreted per role):
+// correct, 578 us — the producer's vector work issues at the single-wave rate (4 cycles per instruction) and the per-step barrier couples the two
+// roles; (ii) 8 waves per workgroup (384 pixels, half the weight DMA per pixel, one workgroup per CU): 495 us; (iii) 2 pixel tiles per wave at 3
+// workgroups per CU: 490 us, at 2 workgroups: 533 us.  The 4-wave, 3-tile, 2-workgroup form below stays (451-467 us, 590-610 TFLOP/s).
 // ---------------------------------------------------------------------------------------------------------------------------------
 struct Mlp16Args {
   const void* y;     // [M][C] LayerNorm output, 16-bit
@@ -594,221 +600,6 @@ __global__ __launch_bounds__(64 * NW, WPS) void convnext_mlp_h16_kernel(const Ml
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// Producer / consumer form of the same fusion (round 4, second step).  The ablation of convnext_mlp_h16_kernel (tools/mlp16_bench.py, KPF_MLP16_DBG:
-// C = 128, 10^6 pixels, 484 us) showed the GELU running at its vector-ALU floor (114 us) and the chunk-boundary waits (94 us) fully EXPOSED: inside
-// one wave GEMM1 -> GELU -> GEMM2 is a dependent chain, and the only overlap came from the other workgroup's wave on the same SIMD.  Here a workgroup
-// has 8 waves in two roles, one of each per SIMD:
-//   waves 0-3 (A): GEMM1 of chunk s (W1 rows x the pixels' y fragments, resident in registers) -> bias + GELU -> the packed 16-bit B-operand
-//                  fragment of GEMM2, written to a hand-off buffer in LDS — lane l of A writes 16 bytes that lane l of its partner reads: the
-//                  accumulator layout of GEMM1 IS the operand layout of GEMM2 (same permuted hidden order as above), so the image is lane-linear;
-//   waves 4-7 (B): GEMM2 of chunk s-1 (W2 rows x the fragments A left in the other half of the hand-off buffer) into the output accumulators, and
-//                  at the end the epilogue (residual, layer scale, staged whole-row stores).
-// One raw barrier per step orders the hand-off and the weight ring together; A's vector work (264 VALU per chunk) now runs under B's MFMAs on the same
-// SIMD instead of in front of its own.  Registers: A ~ 110, B ~ 130.
-// ---------------------------------------------------------------------------------------------------------------------------------
-template <int C, int PT, int R, bool BF>
-__global__ __launch_bounds__(512, 2) void convnext_mlp_h16_ab_kernel(const Mlp16Args a) {
-  using TH = typename std::conditional<BF, bf16_t, f16_t>::type;
-  constexpr int NT = 512;
-  constexpr int KC = C / 32, NCT = C / 16, NCH = 4 * C / 32;
-  constexpr int W1B = 32 * C * 2, W2B = C * 64, CHB = W1B + W2B;
-  constexpr int G = CHB / (NT * 16);  // DMA instructions per wave per chunk
-  constexpr int RC1 = C / 8;
-  constexpr int BM = 16 * PT * 4;
-  constexpr int HFB = 4 * PT * 1024;  // one half of the hand-off buffer: [pixel group][pixel tile][lane] x 16 bytes
-  static_assert(C % 128 == 0 && R >= 3 && R <= 4 && W1B % (NT * 16) == 0 && W2B % (NT * 16) == 0, "shape");
-
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  char* const LB = reinterpret_cast<char*>(lds);
-  char* const HF = LB + R * CHB;
-  float* const B1s = reinterpret_cast<float*>(HF + 2 * HFB);
-  float* const B2s = B1s + 4 * C;
-  float* const Gs = B2s + C;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int role = wave >> 2, grp = wave & 3;  // role 0 = A (GEMM1 + GELU), 1 = B (GEMM2 + epilogue); both of pixel group grp
-  const int fr = lane & 15, fg = lane >> 4;
-  const long m0 = (long)blockIdx.x * BM;
-
-  for (int i = tid; i < 4 * C; i += NT) B1s[i] = a.b1[i];
-  for (int i = tid; i < C; i += NT) {
-    B2s[i] = a.b2[i];
-    Gs[i] = a.gamma[i];
-  }
-  // ONE register array for the role's long-lived state (the compiler cannot see that a wave only ever takes one role, so separate arrays would all
-  // be allocated: 256 registers and spills): B's output accumulators acc[n][pt] = S[n * PT + pt]; A's y fragments yf[ks][pt] = the same registers
-  // reinterpreted (16 bytes each), entries ks * PT + pt
-  f32x4 S[NCT * PT];
-  static_assert(KC <= NCT, "the y fragments fit in the accumulator registers");
-  if (role == 0) {
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-      long m = m0 + (grp * PT + pt) * 16 + fr;
-      m = m < a.M ? m : a.M - 1;
-      const TH* yrow = reinterpret_cast<const TH*>(a.y) + m * C + 8 * fg;
-#pragma unroll
-      for (int ks = 0; ks < KC; ++ks) S[ks * PT + pt] = *reinterpret_cast<const f32x4*>(yrow + 32 * ks);
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < NCT * PT; ++i) S[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  __syncthreads();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // from here on vmcnt counts weight DMAs only
-
-  const TH* const w1g = reinterpret_cast<const TH*>(a.w1);
-  const TH* const w2g = reinterpret_cast<const TH*>(a.w2c);
-  constexpr int P1 = W1B / (NT * 16), P2 = W2B / (NT * 16), RPP1 = NT / RC1;
-  const int r1 = tid / RC1, cp1 = tid % RC1;
-  const int s1a = r1 * C + 8 * (cp1 ^ (r1 & 15)), s1b = r1 * C + 8 * (cp1 ^ ((r1 + RPP1) & 15));
-  const int s2 = (tid >> 2) * 32 + 8 * ((tid & 3) ^ ((tid >> 4) & 3));
-  auto stage = [&](int ch, int slot) {
-    char* dst = LB + slot * CHB + wave * 1024;
-    const TH* const g1 = w1g + (long)ch * 32 * C;
-    const TH* const g2 = w2g + (long)ch * C * 32;
-#pragma unroll
-    for (int p = 0; p < P1; ++p)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(g1 + ((p & 1) ? s1b : s1a) + p * RPP1 * C), (lds_void_t*)(dst + p * NT * 16), 16, 0, 0);
-#pragma unroll
-    for (int p = 0; p < P2; ++p)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(g2 + s2 + p * 128 * 32), (lds_void_t*)(dst + W1B + p * NT * 16), 16, 0, 0);
-  };
-#pragma unroll
-  for (int c = 0; c < R - 2; ++c) stage(c, c);
-
-  const int w1_rd = fr * (2 * C), w2_rd = W1B + fr * 64 + ((fg ^ ((fr >> 2) & 3)) << 4);
-  char* const hf_me = HF + (grp * PT) * 1024 + lane * 16;  // + half * HFB + pt * 1024
-
-  // step s: A works on chunk s (s < NCH), B on chunk s - 1 (s >= 1); chunk s + R - 2 is staged into the slot chunk s - 2 has left
-  auto step = [&](int s, auto SLOT) {
-    constexpr int slot = decltype(SLOT)::value;
-    // chunk s has landed once at most the younger chunks' DMAs are outstanding: R - 3 in steady state (chunks s+1 .. s+R-3)
-    const int last_issued = s + R - 3 < NCH - 1 ? s + R - 3 : NCH - 1;
-    const int younger = last_issued - s;
-    if (R > 3 && younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's hand-off writes of the previous step are in LDS
-    __builtin_amdgcn_s_barrier();
-    if (s + R - 2 < NCH) stage(s + R - 2, (slot + R - 2) % R);
-    if (role == 0) {
-      if (s < NCH) {
-        const char* const sb = LB + slot * CHB;
-        f32x4 d1[2][PT];
-#pragma unroll
-        for (int ht = 0; ht < 2; ++ht)
-#pragma unroll
-          for (int pt = 0; pt < PT; ++pt) d1[ht][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < KC; ++ks)
-#pragma unroll
-          for (int ht = 0; ht < 2; ++ht) {
-            const f16x8 w = *reinterpret_cast<const f16x8*>(sb + w1_rd + ht * 16 * (2 * C) + ((((4 * ks + fg) ^ fr) & (RC1 - 1)) << 4));
-#pragma unroll
-            for (int pt = 0; pt < PT; ++pt) {
-              if constexpr (BF) d1[ht][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, S[ks * PT + pt]), d1[ht][pt], 0, 0, 0);
-              else d1[ht][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, __builtin_bit_cast(f16x8, S[ks * PT + pt]), d1[ht][pt], 0, 0, 0);
-            }
-          }
-        const f32x4 bv0 = *reinterpret_cast<const f32x4*>(B1s + s * 32 + 4 * fg);
-        const f32x4 bv1 = *reinterpret_cast<const f32x4*>(B1s + s * 32 + 16 + 4 * fg);
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) {
-          typename std::conditional<BF, bf16x8, f16x8>::type h;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            h[e] = (TH)gelu_h16m(d1[0][pt][e] + bv0[e]);
-            h[4 + e] = (TH)gelu_h16m(d1[1][pt][e] + bv1[e]);
-          }
-          *reinterpret_cast<f16x8*>(hf_me + (s & 1) * HFB + pt * 1024) = __builtin_bit_cast(f16x8, h);
-        }
-      }
-    } else {
-      if (s >= 1) {
-        constexpr int pslot = (slot + R - 1) % R;  // the slot of chunk s - 1
-        const char* const sb = LB + pslot * CHB;
-        f16x8 hf[PT];
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) hf[pt] = *reinterpret_cast<const f16x8*>(hf_me + ((s - 1) & 1) * HFB + pt * 1024);
-#pragma unroll
-        for (int n = 0; n < NCT; ++n) {
-          const f16x8 w = *reinterpret_cast<const f16x8*>(sb + w2_rd + n * 16 * 64);
-#pragma unroll
-          for (int pt = 0; pt < PT; ++pt) {
-            if constexpr (BF) S[n * PT + pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, hf[pt]), S[n * PT + pt], 0, 0, 0);
-            else S[n * PT + pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, hf[pt], S[n * PT + pt], 0, 0, 0);
-          }
-        }
-      }
-    }
-  };
-  static_assert(NCH % R == 0, "whole ring revolutions");
-  for (int sb = 0; sb < NCH; sb += R) {
-    step(sb, std::integral_constant<int, 0>{});
-    step(sb + 1, std::integral_constant<int, 1>{});
-    step(sb + 2, std::integral_constant<int, 2>{});
-    if constexpr (R > 3) step(sb + 3, std::integral_constant<int, 3>{});
-  }
-  step(NCH, std::integral_constant<int, 0>{});  // B's last chunk (NCH % R == 0: chunk NCH - 1 sits in slot R - 1 = the "previous" slot of slot 0)
-  __builtin_amdgcn_s_barrier();  // the ring is idle (no DMA in flight: the last steps waited vmcnt(0)): it becomes B's staging area
-  if (role == 0) return;
-
-  // ---- epilogue (B waves): out = x + gamma * (acc + b2), staged through the wave's share of the ring for whole-row stores ----
-  const TH* const xg = reinterpret_cast<const TH*>(a.x);
-  TH* const og = reinterpret_cast<TH*>(a.out);
-  constexpr int ROWB = 2 * C;
-  char* const stg = LB + grp * (PT * 16 * ROWB);
-#pragma unroll
-  for (int pt = 0; pt < PT; ++pt) {
-    const long m = m0 + (grp * PT + pt) * 16 + fr;
-    const long mr = m < a.M ? m : a.M - 1;
-#pragma unroll
-    for (int n0 = 0; n0 < NCT; n0 += 8) {  // (eight residual quads in flight at a time: all NCT would not fit beside the accumulators at C = 256)
-      f32x4 xv[8];
-#pragma unroll
-      for (int n = 0; n < 8; ++n) xv[n] = kpf_ld4(xg + mr * C + (n0 + n) * 16 + 4 * fg);
-#pragma unroll
-      for (int nn = 0; nn < 8; ++nn) {
-        const int n = n0 + nn;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(B2s + n * 16 + 4 * fg);
-        const f32x4 gv = *reinterpret_cast<const f32x4*>(Gs + n * 16 + 4 * fg);
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = xv[nn][e] + gv[e] * (S[n * PT + pt][e] + bv[e]);
-        const int row = pt * 16 + fr, cidx = 2 * n + (fg >> 1);
-        kpf_st4(reinterpret_cast<TH*>(stg + row * ROWB + ((cidx ^ fr) << 4) + (fg & 1) * 8), v);
-      }
-    }
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  constexpr int CPR = ROWB / 16, RPI = 64 / CPR;
-  const int rl = lane / CPR, p = lane % CPR;
-#pragma unroll
-  for (int it = 0; it < PT * 16 / RPI; ++it) {
-    const int row = it * RPI + rl;
-    const int c = p ^ (row & 15);
-    const f32x4 q = *reinterpret_cast<const f32x4*>(stg + row * ROWB + (p << 4));
-    const long m = m0 + grp * PT * 16 + row;
-    if (m < a.M) *reinterpret_cast<f32x4*>(og + m * C + 8 * c) = q;
-  }
-}
-
-template <int C, int PT, int R>
-int launch_mlp_h16_ab(const Mlp16Args& a, int dtype, hipStream_t st) {
-  constexpr int CHB = 32 * C * 2 + C * 64, BM = 16 * PT * 4;
-  const size_t lds = (size_t)R * CHB + 2 * 4 * PT * 1024 + 6 * C * sizeof(float);
-  static_assert(4 * PT * 16 * 2 * C <= R * CHB, "the staging area lives in the ring");
-  void (*kern)(const Mlp16Args) = dtype == KPF_DT_BF16 ? convnext_mlp_h16_ab_kernel<C, PT, R, true> : convnext_mlp_h16_ab_kernel<C, PT, R, false>;
-  static std::atomic<bool> lds_opt_in[2][KPF_MAX_DEVICES];
-  if (!kpf_raise_lds_limit(reinterpret_cast<const void*>(kern), lds_opt_in[dtype == KPF_DT_BF16 ? 1 : 0])) {
-    kpf_set_error("kpf_convnext_mlp_h16: cannot raise the dynamic LDS limit");
-    return KPF_ELAUNCH;
-  }
-  const long tiles = ((long)a.M + BM - 1) / BM;
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), lds, st, a);
-  return kpf_check_launch("kpf_convnext_mlp_h16");
-}
-
 template <int C, int PT, int R, int WPS = 2, int NW = 4>
 int launch_mlp_h16(const Mlp16Args& a, int dtype, hipStream_t st) {
   constexpr int CHB = 32 * C * 2 + C * 64, BM = 16 * PT * NW;
@@ -922,14 +713,7 @@ extern "C" int kpf_convnext_mlp_h16(const void* y, const void* x, const void* w1
   a.dbg = dbg;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   static const int cfg = []() { const char* e = getenv("KPF_MLP16_CFG"); return e ? atoi(e) : 0; }();  // tuning aid
-  if (C == 128 && cfg == 3) return launch_mlp_h16_ab<128, 3, 4>(a, dtype, st);  // producer / consumer waves, 192 pixels per workgroup
-  if (C == 128 && cfg == 4) return launch_mlp_h16_ab<128, 4, 4>(a, dtype, st);  // ... 256 pixels per workgroup
-  if (C == 256 && cfg == 3) return launch_mlp_h16_ab<256, 2, 4>(a, dtype, st);
-  if (C == 128 && cfg == 6) return launch_mlp_h16<128, 2, 4, 2, 8>(a, dtype, st);  // (PT = 2: the staging area equals the ring)
-  if (C == 128 && cfg == 5) return launch_mlp_h16<128, 3, 4, 2, 8>(a, dtype, st);  // 8 waves, 384 pixels per workgroup, one workgroup per CU
-  if (C == 256 && cfg == 5) return launch_mlp_h16<256, 2, 4, 2, 8>(a, dtype, st);  // 8 waves, 256 pixels, 4 stages of 32 KB
-  if (C == 128 && cfg == 1) return launch_mlp_h16<128, 2, 2, 3>(a, dtype, st);  // 32 pixels per wave, 2 stages (35 KB): three workgroups per CU
-  if (C == 128 && cfg == 2) return launch_mlp_h16<128, 2, 4, 2>(a, dtype, st);
+  if (C == 128 && cfg == 5) return launch_mlp_h16<128, 3, 4, 2, 8>(a, dtype, st);  // 8 waves, 384 pixels per workgroup, one workgroup per CU: slower (495 vs 451 us)
   if (C == 128) return launch_mlp_h16<128, 3, 4>(a, dtype, st);  // 48 pixels per wave, 4-stage ring of 16-KB chunks (67 KB of LDS)
   return launch_mlp_h16<256, 2, 2>(a, dtype, st);                 // 32 pixels per wave, 2 stages of 32 KB (70 KB)
 }
