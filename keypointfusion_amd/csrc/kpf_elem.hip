@@ -633,13 +633,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
 // ---------------------------------------------------------------------------------------------------------------
 // bilinear x2, align_corners = False:  src = (dst + 0.5) / 2 - 0.5 clamped at 0 ; i1 = min(i0 + 1, n - 1)
 // ---------------------------------------------------------------------------------------------------------------
-template <typename TA>
+// NQ channel quads per thread: 1 (16 bytes of fp32 / 8 bytes of 16-bit storage) or 2 for 16-bit storage (16-byte accesses: the 8-byte form moved the
+// B x 128 x 128 x 128 f16 map of ConvNeXt-B's decoder at 1.8 TB/s)
+template <typename TA, int NQ = 1>
 __global__ __launch_bounds__(256) void upsample2x_kernel(const TA* __restrict__ src, TA* __restrict__ dst, int B, int H,
                                                          int W, int C4, int dst_ld, int dst_coff) {
-  const long total = (long)B * 2 * H * 2 * W * C4;
+  const int CQ = C4 / NQ;
+  const long total = (long)B * 2 * H * 2 * W * CQ;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int q = (int)(i % C4);
-    long p = i / C4;
+    const int q = (int)(i % CQ) * NQ;
+    long p = i / CQ;
     const int ox = (int)(p % (2 * W));
     p /= (2 * W);
     const int oy = (int)(p % (2 * H));
@@ -653,14 +656,26 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const TA* __restrict__ 
     const float ly = fy - (float)y0, lx = fx - (float)x0;
     const float hy = 1.f - ly, hx = 1.f - lx;
     const TA* sb = src + (long)b * H * W * C4 * 4 + 4 * q;
-    const f32x4 v00 = kpf_ld4(sb + ((long)y0 * W + x0) * C4 * 4);
-    const f32x4 v01 = kpf_ld4(sb + ((long)y0 * W + x1) * C4 * 4);
-    const f32x4 v10 = kpf_ld4(sb + ((long)y1 * W + x0) * C4 * 4);
-    const f32x4 v11 = kpf_ld4(sb + ((long)y1 * W + x1) * C4 * 4);
-    f32x4 o;
+    const TA* p00 = sb + ((long)y0 * W + x0) * C4 * 4;
+    const TA* p01 = sb + ((long)y0 * W + x1) * C4 * 4;
+    const TA* p10 = sb + ((long)y1 * W + x0) * C4 * 4;
+    const TA* p11 = sb + ((long)y1 * W + x1) * C4 * 4;
+    TA* po = dst + (((long)b * 2 * H + oy) * 2 * W + ox) * dst_ld + dst_coff + 4 * q;
+    f32x4 v00[NQ], v01[NQ], v10[NQ], v11[NQ];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e]);
-    kpf_st4(dst + (((long)b * 2 * H + oy) * 2 * W + ox) * dst_ld + dst_coff + 4 * q, o);
+    for (int u = 0; u < NQ; ++u) {
+      v00[u] = kpf_ld4(p00 + 4 * u);
+      v01[u] = kpf_ld4(p01 + 4 * u);
+      v10[u] = kpf_ld4(p10 + 4 * u);
+      v11[u] = kpf_ld4(p11 + 4 * u);
+    }
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = hy * (hx * v00[u][e] + lx * v01[u][e]) + ly * (hx * v10[u][e] + lx * v11[u][e]);
+      kpf_st4(po + 4 * u, o);
+    }
   }
 }
 
@@ -1162,8 +1177,12 @@ static int upsample2x_impl(const TA* src, TA* dst, int B, int H, int W, int C, i
   KPF_REQUIRE(src && dst && B > 0 && H > 0 && W > 0, "kpf_upsample2x: null pointer / empty");
   KPF_REQUIRE(C % 4 == 0 && dst_ld % 4 == 0 && dst_coff % 4 == 0 && dst_coff + C <= dst_ld, "kpf_upsample2x: bad channel slice");
   const long total = (long)B * 4 * H * W * (C / 4);
-  hipLaunchKernelGGL(upsample2x_kernel<TA>, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst, B, H, W, C / 4,
-                     dst_ld, dst_coff);
+  if (sizeof(TA) == 2 && C % 8 == 0 && dst_ld % 8 == 0 && dst_coff % 8 == 0)  // 16-byte accesses
+    hipLaunchKernelGGL((upsample2x_kernel<TA, 2>), dim3(grid_for(total / 2, 256, 256 * 32)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst, B, H, W,
+                       C / 4, dst_ld, dst_coff);
+  else
+    hipLaunchKernelGGL((upsample2x_kernel<TA, 1>), dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst, B, H, W, C / 4,
+                       dst_ld, dst_coff);
   return kpf_check_launch("kpf_upsample2x");
 }
 extern "C" int kpf_upsample2x_f32(const float* src, float* dst, int B, int H, int W, int C, int dst_ld, int dst_coff,
