@@ -26,8 +26,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_train12
 cp $(find $OUT/prof_${TAG}_train128 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_train128_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_train128_bf16 -- python3 $ROOT/bench.py --workload train128_bf16 --no-cpu-baseline --steps 10 --warmup 3 > $OUT/prof_${TAG}_train128_bf16.log 2>&1
 cp $(find $OUT/prof_${TAG}_train128_bf16 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_train128_bf16_kernel_stats.csv
-# the bench lines of the same build, without the profiler
+# the bench lines of the same build, without the profiler (the traffic files just collected are what `roofline.traffic` quotes)
 cd $ROOT
+cp $OUT/${TAG}_traffic.json $OUT/${TAG}_traffic_cnb512.json $ROOT/profiles/ 2>/dev/null
 python3 bench.py --no-extra > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 for W in full128 full128_bf16 cnb512_f16 train128 train128_bf16; do
   python3 bench.py --workload $W --no-cpu-baseline > $OUT/${TAG}_bench_$W.json 2> $OUT/${TAG}_bench_$W.err
