@@ -54,6 +54,12 @@ typedef struct kpf_conv_desc {
   float w_unscale;         /* split operands only: weights were packed as w * 2^s, the accumulator is scaled by 2^-s */
   int tile_cfg;            /* 0: tile shape chosen by the built-in cost model; i+1: use configuration i < kpf_conv_num_tile_cfgs()
                               (the host side times the candidates once per shape and passes the fastest) */
+  int groups;              /* 0 / 1: one convolution.  G > 1 (ABI 13): G independent convolutions of this shape in ONE launch (grid.y = group) —
+                              group g consumes input channels [in_coff + g*Cin, +Cin) of the same pixels, multiplies by the weights at
+                              w + g*w_gstride (bias[g*N + n]) and writes output channels [out_coff + g*N, +N): a grouped convolution over
+                              channel-stacked activations.  The training step runs the depth and the RGB backbone (same architecture, two weight
+                              sets: model/model.py:287-306) this way; no residual / prologue / NCHW / split operands in a grouped launch. */
+  long w_gstride;          /* elements between the groups' packed weight matrices (multiple of 4; 8 for 16-bit weights) */
 } kpf_conv_desc;
 
 /*
@@ -307,6 +313,13 @@ int kpf_conv2d_wgrad_f32(const float* dy, const float* x, float* dw, float* db, 
  * on the way into LDS, products and sums are the fp32 ones (the master weight's gradient is not rounded).  Cin, N, ldx, ldy % 8 == 0. */
 int kpf_conv2d_wgrad_h16(const void* dy, const void* x, int dtype, float* dw, float* db, float* ws, long ws_floats, int B, int H, int W, int Cin,
                          int ldx, int OH, int OW, int N, int ldy, int KH, int KW, int sh, int sw, int ph, int pw, void* stream);
+
+/* G channel-stacked weight gradients in one launch (ABI 13; the data-parallel twin of kpf_conv_desc::groups): group g multiplies
+ * dy[.., g*N + n] (pixel stride ldy >= G*N) with x[.., g*Cin + c] (pixel stride ldx >= G*Cin) and writes dw[g][N][Cin][KH][KW], db[g][N]
+ * (db may be NULL).  Same kernels, split and summation order as G separate kpf_conv2d_wgrad_f32 / _h16 calls on the channel slices
+ * (bit-identical results); ws_floats >= G * kpf_conv2d_wgrad_ws_floats(M, N, K).  dtype: KPF_DT_F32 / _BF16 / _F16 (both operands). */
+int kpf_conv2d_wgrad_groups(const void* dy, const void* x, int dtype, float* dw, float* db, float* ws, long ws_floats, int groups, int B, int H, int W, int Cin,
+                            int ldx, int OH, int OW, int N, int ldy, int KH, int KW, int sh, int sw, int ph, int pw, void* stream);
 /* Depthwise 7x7 (pad 3) + bias alone, y = dwconv(x): the ConvNeXt block's first op with its output kept for the LayerNorm backward,
  * and its data gradient (dx = the same convolution of dy with w_dw's taps mirrored, zero bias).  w_dw [49][C], x != y. */
 int kpf_dwconv7_f32(const float* x, const float* w_dw, const float* b_dw, float* y, int B, int H, int W, int C, void* stream);
@@ -495,6 +508,20 @@ typedef struct kpf_colsum_desc {
 } kpf_colsum_desc;
 int kpf_ln_train_backward_partial(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd, const float* w, float* dx, float* dw,
                                   float* db, float* ws, long ws_floats, long rows, int C, kpf_colsum_desc* desc, void* stream);
+
+/* LayerNorm with G parameter sets (ABI 13): row r is normalised with set r % G, i.e. w, b, dw, db hold [G][C] — what a LayerNorm over each of
+ * the G channel groups of a [pixels][G*C] tensor is when that tensor is read as [pixels*G][C] rows (the paired backbones of the training
+ * step).  G in {1, 2, 4}, rows % G == 0; G = 1 is kpf_ln_train_forward / _backward.  ws_floats >= kpf_ln_ws_floats(rows, G*C).
+ * desc != NULL: the column-sum reduce is described instead of launched (kpf_ln_train_backward_partial's contract, C -> G*C). */
+int kpf_ln_train_forward_g(const float* x, const float* w, const float* b, void* y, int y_dtype, float* mean, float* rstd, long rows, int C, int G,
+                           float eps, void* stream);
+int kpf_ln_train_backward_g(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd, const float* w, float* dx, float* dw,
+                            float* db, float* ws, long ws_floats, long rows, int C, int G, kpf_colsum_desc* desc, void* stream);
+/* The layer-scale backward with G parameter sets (same row-view convention as kpf_ln_train_backward_g: rows counts [rows][C] rows of a
+ * [rows / G][G*C] tensor, gamma / dgamma hold [G][C]); ws_floats >= kpf_layer_scale_ws_floats(rows, G*C).  The forward needs no twin
+ * (kpf_layer_scale_forward with C := G*C). */
+int kpf_layer_scale_backward_g(const float* g, const void* y, int y_dtype, const float* gamma, void* dy, float* dgamma, float* ws, long ws_floats,
+                               long rows, int C, int G, void* stream);
 int kpf_layer_scale_backward_partial(const float* g, const void* y, int y_dtype, const float* gamma, void* dy, float* dgamma, float* ws, long ws_floats,
                                      long rows, int C, kpf_colsum_desc* desc, void* stream);
 int kpf_colsum_reduce_grouped(const kpf_colsum_desc* descs, int n, void* stream);
@@ -512,7 +539,7 @@ int kpf_conv_num_tile_cfgs(void);
 const char* kpf_last_error(void);
 /* Library/ABI version, bumped when a signature or the meaning of an argument changes (KPF_ABI_VERSION is what this header
  * describes; the Python binding refuses a library that reports another). */
-#define KPF_ABI_VERSION 12
+#define KPF_ABI_VERSION 13
 int kpf_abi_version(void);
 
 #ifdef __cplusplus

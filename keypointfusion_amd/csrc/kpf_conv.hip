@@ -51,7 +51,22 @@ struct ConvArgs {
   int tilesN, nblk;
   int vec;  // 1: output/residual rows are 16-byte aligned -> float4 epilogue
   int dbg;  // tuning aid (KPF_G8_DBG, gemm16_8ph_kernel only): 1 = no activation, 2 = no global stores, 4 = no main loop
+  // grouped launch (kpf_conv_desc::groups > 1, grid.y = group): group g consumes input channels from in_coff + g * g_in (staging units), uses the weights at
+  // w + g * g_w (4-byte words) and bias[g * g_out + n], and writes output channels from out_coff + g * g_out (g_out = N).  All zero for an ordinary launch.
+  int groups, g_in, g_out;
+  long g_w;
 };
+
+// The group's view of the launch arguments (grid.y = group; blockIdx.y is 0 for ordinary launches, whose steps are 0 too): scalar arithmetic only.
+__device__ __forceinline__ ConvArgs kpf_group_args(const ConvArgs& a0) {
+  ConvArgs a = a0;
+  const int g = blockIdx.y;
+  a.in_coff += g * a.g_in;
+  a.out_coff += g * a.g_out;
+  a.w += (long)g * a.g_w;
+  if (a.bias) a.bias += g * a.g_out;
+  return a;
+}
 
 // GELU(x) = x/2 * (1 + erf(x/sqrt2)) with erfc(z) = t*(a1 + t*(a2 + ...)) * exp(-z^2), t = 1/(1 + p z)  (Abramowitz-Stegun 7.1.26,
 // |error| <= 1.5e-7 absolute on erf, i.e. fp32 rounding level) written on the erfc side so the negative tail does not
@@ -710,28 +725,28 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
 // on split operands (ARITH 1: activations pre-split in memory, 2: split in registers).
 template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO, int EPI, int NS>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const ConvArgs a) {
-  igemm_body<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH_F32, NS>(a);
+  igemm_body<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH_F32, NS>(kpf_group_args(a));
 }
 template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO, int EPI, int ARITH, int NS>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_split_kernel(const ConvArgs a) {
-  igemm_body<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH, NS>(a);
+  igemm_body<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH, NS>(kpf_group_args(a));
 }
 // Single LDS stage, registers capped for 4 waves per SIMD: with the MFMA phase of a K tile this short, four or five co-resident
 // workgroups hide each other's DMA / LDS / barrier latencies better than double buffering inside two (tools/split_probe.hip: 600 vs
 // 430-490 TFLOP/s for the bare loop).
 template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO, int EPI, int ARITH>
 __global__ __launch_bounds__(64 * WM * WN, 4) void igemm_split_occ_kernel(const ConvArgs a) {
-  igemm_body<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH, 1>(a);
+  igemm_body<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH, 1>(kpf_group_args(a));
 }
 
 // 16-bit storage (bf16 / f16) GEMMs: igemm_h16_kernel (two LDS stages) / igemm_h16_occ_kernel (one stage, 4 waves per SIMD)
 template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO, int EPI, int ARITH, int NS>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_h16_kernel(const ConvArgs a) {
-  igemm_body<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH, NS>(a);
+  igemm_body<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH, NS>(kpf_group_args(a));
 }
 template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO, int EPI, int ARITH>
 __global__ __launch_bounds__(64 * WM * WN, 4) void igemm_h16_occ_kernel(const ConvArgs a) {
-  igemm_body<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH, 1>(a);
+  igemm_body<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH, 1>(kpf_group_args(a));
 }
 
 template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO, int EPI, int ARITH, int NS>
@@ -765,7 +780,7 @@ int launch_one(const ConvArgs& a, hipStream_t st) {
     kpf_set_error("kpf_conv2d_f32: operand prologue too long for LDS (Kp=%d)", a.Kp);
     return KPF_EINVAL;
   }
-  hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(64 * WM * WN), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(a.nblk, a.groups > 1 ? a.groups : 1), dim3(64 * WM * WN), lds, st, a);
   return kpf_check_launch("kpf_conv2d_f32");
 }
 
@@ -1240,7 +1255,7 @@ static bool g8_preferred(const kpf_conv_desc* d) {
 /* 1 when kpf_conv2d_h16 runs this descriptor on gemm16_8ph_kernel, 0 when on igemm_h16_kernel (profile labels; same rule as the dispatcher) */
 extern "C" int kpf_conv2d_h16_uses_8ph(const kpf_conv_desc* d, int has_prologue) {
   static const bool no8 = getenv("KPF_NO_8PH") != nullptr;
-  return d && !no8 && g8_applies(d, has_prologue != 0) && g8_preferred(d) ? 1 : 0;
+  return d && !no8 && d->groups <= 1 && g8_applies(d, has_prologue != 0) && g8_preferred(d) ? 1 : 0;
 }
 
 extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void* w, const float* bias, const float* pro_scale,
@@ -1291,6 +1306,14 @@ extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void
   }
   a.flags = fl; a.tilesN = 0; a.nblk = 0; a.w_unscale = 1.0f;
   a.vec = (d->out_ld % 4 == 0 && d->out_coff % 4 == 0 && (!(fl & KPF_RES_ADD) || (d->res_ld % 4 == 0 && d->res_coff % 4 == 0))) ? 1 : 0;
+  a.groups = d->groups > 1 ? d->groups : 1; a.g_in = a.g_out = 0; a.g_w = 0;
+  if (a.groups > 1) {  // grouped launch: see ConvArgs
+    KPF_REQUIRE(!(fl & (KPF_RES_ADD | KPF_OUT_NCHW)) && !pro_scale && d->w_gstride % 8 == 0 && d->N % 2 == 0,
+                "kpf_conv2d_h16: a grouped launch takes no residual / prologue / NCHW output, and needs w_gstride %% 8 == 0, N %% 2 == 0");
+    KPF_REQUIRE(d->in_coff + d->groups * d->Cin <= d->in_ld && d->out_coff + d->groups * d->N <= d->out_ld, "kpf_conv2d_h16: the groups' channel slices exceed the pixel stride");
+    a.g_in = d->Cin / 2; a.g_out = d->N; a.g_w = d->w_gstride / 2;
+    if ((d->out_coff + d->N) % 8) a.vec = 0;  // (the staged epilogue stores 16-byte pieces of every group's slice)
+  }
   {
     static const int dbg = []() { const char* e = getenv("KPF_G8_DBG"); return e ? atoi(e) : 0; }();
     a.dbg = dbg;
@@ -1319,7 +1342,7 @@ extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void
   // Round 4: the eight-phase 256 x 256 kernel (gemm16_8ph_kernel) for every dense 1x1 layer it covers with at least one full round of tiles
   const bool ok8 = g8_applies(d, pro_scale != nullptr);
   static const bool no8 = getenv("KPF_NO_8PH") != nullptr;  // tuning aid: A/B against the round-3 tile shapes
-  if (ok8 && !no8 && g8_preferred(d)) best = 30;
+  if (ok8 && !no8 && g8_preferred(d) && a.groups == 1) best = 30;
   static const int forced = []() { const char* e = getenv("KPF_FORCE_CFG16"); return e ? atoi(e) : -1; }();  // tuning aid only
   if (forced >= 0 && (forced != 30 || ok8)) best = forced;
   if (best == 30) return dtype == KPF_DT_BF16 ? launch_8ph<ARITH_BF16>(a, st) : launch_8ph<ARITH_F16>(a, st);
@@ -1392,6 +1415,14 @@ extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const flo
     KPF_REQUIRE(d->N % 32 == 0 && d->out_coff % 32 == 0 && d->out_ld % 32 == 0 && !(fl & KPF_OUT_NCHW),
                 "kpf_conv2d_f32: split output needs N, out_ld, out_coff multiples of 32 (N=%d ld=%d coff=%d)", d->N, d->out_ld, d->out_coff);
   a.vec = (d->out_ld % 4 == 0 && d->out_coff % 4 == 0 && (!(fl & KPF_RES_ADD) || (d->res_ld % 4 == 0 && d->res_coff % 4 == 0))) ? 1 : 0;
+  a.groups = d->groups > 1 ? d->groups : 1; a.g_in = a.g_out = 0; a.g_w = 0;
+  if (a.groups > 1) {  // grouped launch: see ConvArgs
+    KPF_REQUIRE(!(fl & (KPF_RES_ADD | KPF_OUT_NCHW | KPF_IN_SPLIT | KPF_W_SPLIT | KPF_OUT_SPLIT)) && !pro_scale && d->w_gstride % 4 == 0,
+                "kpf_conv2d_f32: a grouped launch takes no residual / prologue / NCHW output / split operands, and needs w_gstride %% 4 == 0");
+    KPF_REQUIRE(d->in_coff + d->groups * d->Cin <= d->in_ld && d->out_coff + d->groups * d->N <= d->out_ld, "kpf_conv2d_f32: the groups' channel slices exceed the pixel stride");
+    a.g_in = d->Cin; a.g_out = d->N; a.g_w = d->w_gstride;
+    if ((d->out_coff + d->N) % 4) a.vec = 0;
+  }
   // the dense-1x1 fast path also needs whole K tiles (its staging reads 32 channels at a time without a K mask)
   const bool is1x1 = d->KH == 1 && d->KW == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0 &&
                      d->IH == d->OH && d->IW == d->OW && d->Cin % 32 == 0 && d->Kp == d->Cin;

@@ -526,9 +526,12 @@ constexpr int LN_MAXQ = 4;  // channel quads per lane: C <= 64 * 4 * LN_MAXQ = 1
 
 template <typename TY>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, TY* __restrict__ y,
-                                                     float* __restrict__ mean, float* __restrict__ rstd, long rows, int C4, float eps) {
+                                                     float* __restrict__ mean, float* __restrict__ rstd, long rows, int C4, float eps, int G) {
+  // G > 1 (kpf_ln_train_forward_g): row r is normalised with parameter set r % G (w, b hold G sets of C) — channel-stacked groups seen as rows
   const int lane = threadIdx.x & 63;
   const float invC = 1.0f / (float)(4 * C4);
+  const int po = (int)(((long)blockIdx.x * 4 + (threadIdx.x >> 6)) % G) * 4 * C4;  // (the row stride is a multiple of 4: one parameter set per wave)
+  w += po, b += po;
   for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * 4) {
     f32x4 v[LN_MAXQ];
     float s = 0.f;
@@ -572,10 +575,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 template <typename TD>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ w, float* __restrict__ dx, float* __restrict__ part,
-                                                     long rows, int C4) {
+                                                     long rows, int C4, int G) {
   extern __shared__ float ln_lds[];  // [4 waves][2][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int C = 4 * C4;
+  w += (wave % G) * C;  // G > 1: parameter set r % G per row; a wave's rows are 4 * gridDim.x apart, i.e. all of one set
   const float invC = 1.0f / (float)C;
   f32x4 aw[LN_MAXQ], ab[LN_MAXQ], g[LN_MAXQ];
 #pragma unroll
@@ -626,12 +630,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, 
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += 256) {
-    const int which = i / C, c = i - which * C;
+  const int GC = G * C;  // part: [gridDim.x][2][G][C]
+  for (int i = threadIdx.x; i < 2 * GC; i += 256) {
+    const int which = i / GC, cc = i - which * GC;
+    const int grp = cc / C, c = cc - grp * C;
     float s = 0.f;
-#pragma unroll
-    for (int wv = 0; wv < 4; ++wv) s += ln_lds[(wv * 2 + which) * C + c];
-    part[((long)blockIdx.x * 2 + which) * C + c] = s;
+    for (int wv = grp; wv < 4; wv += G) s += ln_lds[(wv * 2 + which) * C + c];  // (G = 1: waves 0..3 in order)
+    part[((long)blockIdx.x * 2 + which) * GC + cc] = s;
   }
 }
 
@@ -719,14 +724,15 @@ inline int ln_blocks(long rows) {  // ~4 rows per wave at least: few partials to
 
 extern "C" long kpf_ln_ws_floats(long rows, int C) { return (long)ln_blocks(rows) * 2 * C; }
 
-extern "C" int kpf_ln_train_forward(const float* x, const float* w, const float* b, void* y, int y_dtype, float* mean, float* rstd, long rows, int C, float eps,
-                                    void* stream) {
+extern "C" int kpf_ln_train_forward_g(const float* x, const float* w, const float* b, void* y, int y_dtype, float* mean, float* rstd, long rows, int C, int G,
+                                      float eps, void* stream) {
   KPF_REQUIRE(x && w && b && y && mean && rstd && rows > 0 && C > 0 && C % 4 == 0 && C <= 256 * LN_MAXQ, "kpf_ln_train_forward: bad arguments (C %% 4 == 0, C <= 1024)");
+  KPF_REQUIRE((G == 1 || G == 2 || G == 4) && rows % G == 0, "kpf_ln_train_forward_g: G must be 1, 2 or 4 and divide the row count");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const dim3 grid(grid_for(rows, 4, 256 * 16));
-  if (y_dtype == KPF_DT_F32) hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, dim3(256), 0, st, x, w, b, static_cast<float*>(y), mean, rstd, rows, C / 4, eps);
-  else if (y_dtype == KPF_DT_BF16) hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, x, w, b, static_cast<bf16_t*>(y), mean, rstd, rows, C / 4, eps);
-  else if (y_dtype == KPF_DT_F16) hipLaunchKernelGGL(ln_fwd_kernel<f16_t>, grid, dim3(256), 0, st, x, w, b, static_cast<f16_t*>(y), mean, rstd, rows, C / 4, eps);
+  if (y_dtype == KPF_DT_F32) hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, dim3(256), 0, st, x, w, b, static_cast<float*>(y), mean, rstd, rows, C / 4, eps, G);
+  else if (y_dtype == KPF_DT_BF16) hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, x, w, b, static_cast<bf16_t*>(y), mean, rstd, rows, C / 4, eps, G);
+  else if (y_dtype == KPF_DT_F16) hipLaunchKernelGGL(ln_fwd_kernel<f16_t>, grid, dim3(256), 0, st, x, w, b, static_cast<f16_t*>(y), mean, rstd, rows, C / 4, eps, G);
   else {
     kpf_set_error("kpf_ln_train_forward: unknown y_dtype %d", y_dtype);
     return KPF_EINVAL;
@@ -734,16 +740,23 @@ extern "C" int kpf_ln_train_forward(const float* x, const float* w, const float*
   return kpf_check_launch("kpf_ln_train_forward");
 }
 
+extern "C" int kpf_ln_train_forward(const float* x, const float* w, const float* b, void* y, int y_dtype, float* mean, float* rstd, long rows, int C, float eps,
+                                    void* stream) {
+  return kpf_ln_train_forward_g(x, w, b, y, y_dtype, mean, rstd, rows, C, 1, eps, stream);
+}
+
 static int ln_train_backward_impl(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd, const float* w, float* dx, float* dw,
-                                  float* db, float* ws, long ws_floats, long rows, int C, void* stream, kpf_colsum_desc* defer) {
+                                  float* db, float* ws, long ws_floats, long rows, int C, void* stream, kpf_colsum_desc* defer, int G = 1) {
+  // G > 1: w, dw, db hold G parameter sets of C; row r belongs to set r % G
   KPF_REQUIRE(dy && x && mean && rstd && w && dx && dw && db && ws && rows > 0 && C > 0 && C % 4 == 0 && C <= 256 * LN_MAXQ, "kpf_ln_train_backward: bad arguments");
+  KPF_REQUIRE((G == 1 || G == 2 || G == 4) && rows % G == 0, "kpf_ln_train_backward_g: G must be 1, 2 or 4 and divide the row count");
   const int nblk = ln_blocks(rows);
-  KPF_REQUIRE(ws_floats >= (long)nblk * 2 * C, "kpf_ln_train_backward: workspace too small");
+  KPF_REQUIRE(ws_floats >= (long)nblk * 2 * C * G, "kpf_ln_train_backward: workspace too small");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const size_t lds = (size_t)8 * C * sizeof(float);
-  if (dy_dtype == KPF_DT_F32) hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nblk), dim3(256), lds, st, static_cast<const float*>(dy), x, mean, rstd, w, dx, ws, rows, C / 4);
-  else if (dy_dtype == KPF_DT_BF16) hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(nblk), dim3(256), lds, st, static_cast<const bf16_t*>(dy), x, mean, rstd, w, dx, ws, rows, C / 4);
-  else if (dy_dtype == KPF_DT_F16) hipLaunchKernelGGL(ln_bwd_kernel<f16_t>, dim3(nblk), dim3(256), lds, st, static_cast<const f16_t*>(dy), x, mean, rstd, w, dx, ws, rows, C / 4);
+  if (dy_dtype == KPF_DT_F32) hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nblk), dim3(256), lds, st, static_cast<const float*>(dy), x, mean, rstd, w, dx, ws, rows, C / 4, G);
+  else if (dy_dtype == KPF_DT_BF16) hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(nblk), dim3(256), lds, st, static_cast<const bf16_t*>(dy), x, mean, rstd, w, dx, ws, rows, C / 4, G);
+  else if (dy_dtype == KPF_DT_F16) hipLaunchKernelGGL(ln_bwd_kernel<f16_t>, dim3(nblk), dim3(256), lds, st, static_cast<const f16_t*>(dy), x, mean, rstd, w, dx, ws, rows, C / 4, G);
   else {
     kpf_set_error("kpf_ln_train_backward: unknown dy_dtype %d", dy_dtype);
     return KPF_EINVAL;
@@ -751,11 +764,16 @@ static int ln_train_backward_impl(const void* dy, int dy_dtype, const float* x, 
   int rc = kpf_check_launch("kpf_ln_train_backward");
   if (rc != KPF_OK) return rc;
   if (defer) {
-    defer->part = ws, defer->dw = dw, defer->db = db, defer->nblk = nblk, defer->C = C, defer->first_block = 0, defer->reserved = 0;
+    defer->part = ws, defer->dw = dw, defer->db = db, defer->nblk = nblk, defer->C = G * C, defer->first_block = 0, defer->reserved = 0;
     return KPF_OK;
   }
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * C + 63) / 64), dim3(512), 0, st, ws, dw, db, nblk, C);
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * G * C + 63) / 64), dim3(512), 0, st, ws, dw, db, nblk, G * C);
   return kpf_check_launch("kpf_ln_train_backward (reduce)");
+}
+
+extern "C" int kpf_ln_train_backward_g(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd, const float* w, float* dx, float* dw,
+                                       float* db, float* ws, long ws_floats, long rows, int C, int G, kpf_colsum_desc* desc, void* stream) {
+  return ln_train_backward_impl(dy, dy_dtype, x, mean, rstd, w, dx, dw, db, ws, ws_floats, rows, C, stream, desc, G);
 }
 
 extern "C" int kpf_ln_train_backward(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd, const float* w, float* dx, float* dw,
@@ -1026,10 +1044,11 @@ __global__ __launch_bounds__(256) void layer_scale_fwd_kernel(const float* __res
 
 template <typename TY>
 __global__ __launch_bounds__(256) void layer_scale_bwd_kernel(const float* __restrict__ g, const TY* __restrict__ y, const float* __restrict__ gamma,
-                                                              TY* __restrict__ dy, float* __restrict__ part, long rows, int C4) {
+                                                              TY* __restrict__ dy, float* __restrict__ part, long rows, int C4, int G) {
   extern __shared__ float ls_lds[];  // [4 waves][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int C = 4 * C4;
+  gamma += (wave % G) * C;  // G > 1 (kpf_layer_scale_backward_g): row r uses parameter set r % G; a wave's rows are all of one set (see ln_bwd_kernel)
   f32x4 acc[LN_MAXQ], gm[LN_MAXQ];
 #pragma unroll
   for (int i = 0; i < LN_MAXQ; ++i) {
@@ -1056,12 +1075,13 @@ __global__ __launch_bounds__(256) void layer_scale_bwd_kernel(const float* __res
   for (int i = 0; i < LN_MAXQ; ++i)
     if (lane + 64 * i < C4) kpf_st4(ls_lds + wave * C + 4 * (lane + 64 * i), acc[i]);
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
+  const int GC = G * C;
+  for (int cc = threadIdx.x; cc < GC; cc += 256) {
+    const int grp = cc / C, c = cc - grp * C;
     float s = 0.f;
-#pragma unroll
-    for (int wv = 0; wv < 4; ++wv) s += ls_lds[wv * C + c];
-    part[((long)blockIdx.x * 2) * C + c] = s;  // (slot layout of ln_bwd_reduce_kernel: [block][2][C]; the second plane is unused here)
-    part[((long)blockIdx.x * 2 + 1) * C + c] = 0.f;
+    for (int wv = grp; wv < 4; wv += G) s += ls_lds[wv * C + c];  // (G = 1: waves 0..3 in order)
+    part[((long)blockIdx.x * 2) * GC + cc] = s;  // (slot layout of ln_bwd_reduce_kernel: [block][2][G*C]; the second plane is unused here)
+    part[((long)blockIdx.x * 2 + 1) * GC + cc] = 0.f;
   }
 }
 
@@ -1073,18 +1093,19 @@ int layer_scale_fwd_launch(const float* x, const void* y, const float* gamma, fl
 }
 template <typename T>
 int layer_scale_bwd_launch(const float* g, const void* y, const float* gamma, void* dy, float* dgamma, float* ws, long rows, int C, void* stream,
-                           kpf_colsum_desc* defer = nullptr) {
+                           kpf_colsum_desc* defer = nullptr, int G = 1) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int nblk = ln_blocks(rows);
+  const int GC = G * C;  // (G > 1: rows counts the [rows][C] view of a [rows / G][G*C] tensor; gamma, dgamma hold G sets)
   hipLaunchKernelGGL(layer_scale_bwd_kernel<T>, dim3(nblk), dim3(256), (size_t)4 * C * sizeof(float), st, g, static_cast<const T*>(y), gamma, static_cast<T*>(dy), ws,
-                     rows, C / 4);
+                     rows, C / 4, G);
   int rc = kpf_check_launch("kpf_layer_scale_backward");
   if (rc != KPF_OK) return rc;
   if (defer) {
-    defer->part = ws, defer->dw = dgamma, defer->db = ws + (long)nblk * 2 * C, defer->nblk = nblk, defer->C = C, defer->first_block = 0, defer->reserved = 0;
+    defer->part = ws, defer->dw = dgamma, defer->db = ws + (long)nblk * 2 * GC, defer->nblk = nblk, defer->C = GC, defer->first_block = 0, defer->reserved = 0;
     return KPF_OK;
   }
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * C + 63) / 64), dim3(512), 0, st, ws, dgamma, ws + (long)nblk * 2 * C, nblk, C);
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * GC + 63) / 64), dim3(512), 0, st, ws, dgamma, ws + (long)nblk * 2 * GC, nblk, GC);
   return kpf_check_launch("kpf_layer_scale_backward (reduce)");
 }
 }  // namespace
@@ -1104,6 +1125,16 @@ extern "C" int kpf_layer_scale_backward(const float* g, const void* y, int y_dty
   KPF_REQUIRE(ws_floats >= kpf_layer_scale_ws_floats(rows, C), "kpf_layer_scale_backward: workspace too small");
 #define CALL(T) layer_scale_bwd_launch<T>(g, y, gamma, dy, dgamma, ws, rows, C, stream)
   KPF_DISPATCH_DT(y_dtype, "kpf_layer_scale_backward", CALL);
+#undef CALL
+}
+
+extern "C" int kpf_layer_scale_backward_g(const float* g, const void* y, int y_dtype, const float* gamma, void* dy, float* dgamma, float* ws, long ws_floats,
+                                          long rows, int C, int G, void* stream) {
+  KPF_REQUIRE(g && y && gamma && dy && dgamma && ws && rows > 0 && C > 0 && C % 4 == 0 && C <= 256 * LN_MAXQ, "kpf_layer_scale_backward_g: bad arguments (C <= 1024)");
+  KPF_REQUIRE((G == 1 || G == 2 || G == 4) && rows % G == 0, "kpf_layer_scale_backward_g: G must be 1, 2 or 4 and divide the row count");
+  KPF_REQUIRE(ws_floats >= kpf_layer_scale_ws_floats(rows, G * C), "kpf_layer_scale_backward_g: workspace too small");
+#define CALL(T) layer_scale_bwd_launch<T>(g, y, gamma, dy, dgamma, ws, rows, C, stream, nullptr, G)
+  KPF_DISPATCH_DT(y_dtype, "kpf_layer_scale_backward_g", CALL);
 #undef CALL
 }
 

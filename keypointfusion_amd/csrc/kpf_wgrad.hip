@@ -37,7 +37,22 @@ struct WgradArgs {
   int M, K, tilesK, stages_per_split;
   int is1x1;
   int emul_sps;  // grouped form only: stages per split of the split + reduce form whose summation order it reproduces
+  // channel-grouped launch (kpf_conv2d_wgrad_groups, grid.z = group): group g reads dy + g*g_dy / x + g*g_x (elements) and writes part + g*g_part,
+  // dbpart + g*g_db (floats).  All zero for an ordinary launch (blockIdx.z is 0 there).
+  int groups, g_dy, g_x;
+  long g_part, g_db;
 };
+
+template <typename TIN>
+__device__ __forceinline__ WgradArgs wg_group_args(const WgradArgs& a0) {
+  WgradArgs a = a0;
+  const int g = blockIdx.z;
+  a.dy = static_cast<const TIN*>(a0.dy) + g * a0.g_dy;
+  a.x = static_cast<const TIN*>(a0.x) + g * a0.g_x;
+  a.part += g * a0.g_part;
+  if (a.dbpart) a.dbpart += g * a0.g_db;
+  return a;
+}
 
 constexpr int RB = 32;  // pixels (reduction rows) per LDS stage
 
@@ -284,7 +299,7 @@ __device__ __forceinline__ void wgrad_f32_body(const WgradArgs& a, const int bx,
 
 template <int VN, int VK, typename TIN>
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradArgs a) {
-  wgrad_f32_body<VN, VK, TIN>(a, blockIdx.x, blockIdx.y);
+  wgrad_f32_body<VN, VK, TIN>(wg_group_args<TIN>(a), blockIdx.x, blockIdx.y);
 }
 
 // Grouped form for Linear layers over few rows (the 21-token stacks of the fusion head: M = 21 B): ~80 such weight gradients per
@@ -312,6 +327,7 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const WgradGroupBatc
   a.dy = bp->d[lo].dy, a.x = bp->d[lo].x, a.part = bp->d[lo].dw, a.dbpart = bp->d[lo].db, a.zero = bp->zero;
   a.M = bp->d[lo].M, a.N = bp->d[lo].N, a.K = bp->d[lo].K;
   a.H = 1, a.W = a.M, a.Cin = a.K, a.ldx = a.K, a.OH = 1, a.OW = a.M, a.ldy = a.N, a.KH = 1, a.KW = 1, a.sh = 1, a.sw = 1, a.ph = 0, a.pw = 0;
+  a.groups = 1, a.g_dy = a.g_x = 0, a.g_part = a.g_db = 0;
   a.tilesK = (a.K + 63) / 64;
   a.stages_per_split = (a.M + RB - 1) / RB;
   a.is1x1 = 1;
@@ -373,7 +389,8 @@ __device__ __forceinline__ float sum8(const s16x8 v, f16_t) {
 }
 
 template <typename TIN, int HNS>  // HNS: LDS ring stages (RB pixels x (A + B) rows of 256 B = 16 KB each), HNS - 1 of them in flight
-__global__ __launch_bounds__(256) void wgrad_h16_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256) void wgrad_h16_kernel(const WgradArgs a0) {
+  const WgradArgs a = wg_group_args<TIN>(a0);
   extern __shared__ __attribute__((aligned(16))) char hl[];  // [HNS][A 8 KB | B 8 KB]
   constexpr int STAGE = 2 * RB * 256;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -544,7 +561,8 @@ constexpr int HS_SP = 128;   // pixels per stage (32 per wave)
 __device__ __forceinline__ int hs_swz(int row) { return 2 * (((row >> 1) & 1) | (((row >> 3) & 1) << 1)); }
 
 template <typename TIN, int HS_NS>  // HS_NS: LDS ring depth; per wave and buffer 32 rows x 128 B x (A + B) = 8 KB (3: 96 KB per workgroup, 2: 64 KB)
-__global__ __launch_bounds__(256) void wgrad_h16s_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256) void wgrad_h16s_kernel(const WgradArgs a0) {
+  const WgradArgs a = wg_group_args<TIN>(a0);
   extern __shared__ __attribute__((aligned(16))) char hl[];  // [4 waves][HS_NS][A 4 KB | B 4 KB] + 1 KB; reused for the final cross-wave sum
   constexpr int WBUF = 2 * 32 * 128;           // one wave's A + B rows of one stage
   constexpr int WREG = HS_NS * WBUF;           // one wave's region (24 KB)
@@ -738,7 +756,10 @@ __device__ __forceinline__ float sum_partials(const float* __restrict__ part, lo
 // dw[n][c][ky][kx] = sum_s part[s][n][(ky,kx,c)];  db[n] = sum_s dbpart[s][n]   (blocks [0, nkb) reduce dw, the rest db)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbpart,
                                                            float* __restrict__ dw, float* __restrict__ db, int S, int N, int K, int Cin,
-                                                           int KHW, int nkb) {
+                                                           int KHW, int nkb, long g_ws) {
+  // (grid.y = channel group of a grouped launch: its partial sums start g_ws floats further, its dw / db N*K / N floats further)
+  part += blockIdx.y * g_ws, dw += (long)blockIdx.y * N * K;
+  if (dbpart) dbpart += blockIdx.y * g_ws, db += blockIdx.y * N;
   __shared__ float red[4][64];
   const int o = threadIdx.x & 63;
   if ((int)blockIdx.x < nkb) {
@@ -922,7 +943,7 @@ const float* zero_page() {
 template <int VN, int VK, typename TIN>
 int launch_wgrad(const WgradArgs& a, const Plan& p, hipStream_t st) {
   constexpr int LDS = 2 * RB * 32 * (VN + VK) * 4;
-  hipLaunchKernelGGL((wgrad_f32_kernel<VN, VK, TIN>), dim3(p.tilesN * p.tilesK, p.S), dim3(256), LDS, st, a);
+  hipLaunchKernelGGL((wgrad_f32_kernel<VN, VK, TIN>), dim3(p.tilesN * p.tilesK, p.S, a.groups), dim3(256), LDS, st, a);
   return kpf_check_launch("kpf_conv2d_wgrad");
 }
 
@@ -956,7 +977,8 @@ long kpf_conv2d_wgrad_ws_floats(long M, int N, int K) {
 
 static int conv2d_wgrad_impl(const void* dy, const void* x, int dtype, float* dw, float* db, float* ws, long ws_floats, int B, int H, int W,
                              int Cin, int ldx, int OH, int OW, int N, int ldy, int KH, int KW, int sh, int sw, int ph, int pw,
-                             void* stream) {
+                             void* stream, int groups = 1) {
+  KPF_REQUIRE(groups >= 1 && (long)groups * Cin <= ldx && (long)groups * N <= ldy, "kpf_conv2d_wgrad: %d groups of %d / %d channels exceed the pixel strides %d / %d", groups, Cin, N, ldx, ldy);
   KPF_REQUIRE(dy && x && dw && ws, "kpf_conv2d_wgrad_f32: null pointer");
   KPF_REQUIRE(dtype == KPF_DT_F32 || dtype == KPF_DT_BF16 || dtype == KPF_DT_F16, "kpf_conv2d_wgrad: unknown dtype %d", dtype);
   if (dtype != KPF_DT_F32)
@@ -979,10 +1001,12 @@ static int conv2d_wgrad_impl(const void* dy, const void* x, int dtype, float* dw
   const bool h16s = h16 && h16_form != 128;
   const Plan p = h16s ? plan_wgrad_h16s(M, N, (int)K) : (h16 ? plan_wgrad_h16(M, N, (int)K) : plan_wgrad(M, N, (int)K, one));
   const bool direct = one && p.S == 1;  // the single partial array is dW
-  KPF_REQUIRE(ws_floats >= (long)p.S * N * K + (long)p.S * N, "kpf_conv2d_wgrad_f32: workspace too small (%ld floats, need %ld)", ws_floats,
-              (long)p.S * N * K + (long)p.S * N);
+  const long wsg = (long)p.S * N * K + (long)p.S * N;  // one group's workspace
+  KPF_REQUIRE(ws_floats >= groups * wsg, "kpf_conv2d_wgrad_f32: workspace too small (%ld floats, need %ld)", ws_floats, groups * wsg);
   WgradArgs a;
   a.dy = dy, a.x = x, a.part = direct ? dw : ws, a.dbpart = db ? (direct ? db : ws + (size_t)p.S * N * K) : nullptr;
+  a.groups = groups, a.g_dy = groups > 1 ? N : 0, a.g_x = groups > 1 ? Cin : 0;
+  a.g_part = groups > 1 ? (direct ? (long)N * K : wsg) : 0, a.g_db = groups > 1 ? (direct ? (long)N : wsg) : 0;
   a.zero = zero_page();
   KPF_REQUIRE(a.zero, "kpf_conv2d_wgrad_f32: cannot resolve the zero page");
   a.H = H, a.W = W, a.Cin = Cin, a.ldx = ldx, a.OH = OH, a.OW = OW, a.N = N, a.ldy = ldy, a.KH = KH, a.KW = KW;
@@ -994,7 +1018,7 @@ static int conv2d_wgrad_impl(const void* dy, const void* x, int dtype, float* dw
   if (h16s) {
     static std::atomic<bool> lds_ok[2][KPF_MAX_DEVICES];
     static const int sring = []() { const char* e = getenv("KPF_WG16S_RING"); return e ? atoi(e) : 2; }();  // tuning aid: 2 (default) or 3 buffers
-    const dim3 grid(p.tilesN * p.tilesK, p.S);
+    const dim3 grid(p.tilesN * p.tilesK, p.S, groups);
     constexpr int WB = 4 * 2 * 32 * 128;  // one buffer of the four waves
     if (sring == 2) {
       if (dtype == KPF_DT_BF16) hipLaunchKernelGGL((wgrad_h16s_kernel<bf16_t, 2>), grid, dim3(256), 2 * WB + 1024, st, a);
@@ -1009,7 +1033,7 @@ static int conv2d_wgrad_impl(const void* dy, const void* x, int dtype, float* dw
     rc = kpf_check_launch("kpf_conv2d_wgrad_h16");
   } else if (h16) {
     static const int ring = []() { const char* e = getenv("KPF_WG16_RING"); return e ? atoi(e) : 3; }();  // tuning aid: 3 or 4 stages
-    const dim3 grid(p.tilesN * p.tilesK, p.S);
+    const dim3 grid(p.tilesN * p.tilesK, p.S, groups);
     if (ring == 4) {
       if (dtype == KPF_DT_BF16) hipLaunchKernelGGL((wgrad_h16_kernel<bf16_t, 4>), grid, dim3(256), 4 * 2 * RB * 256, st, a);
       else hipLaunchKernelGGL((wgrad_h16_kernel<f16_t, 4>), grid, dim3(256), 4 * 2 * RB * 256, st, a);
@@ -1025,8 +1049,8 @@ static int conv2d_wgrad_impl(const void* dy, const void* x, int dtype, float* dw
   if (rc != KPF_OK || direct) return rc;
   const long NK = (long)N * K;
   const int nkb = (int)((NK + 63) / 64);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nkb + (db ? (N + 63) / 64 : 0)), dim3(256), 0, st, ws, a.dbpart, dw, db, p.S, N, (int)K, Cin,
-                     KH * KW, nkb);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nkb + (db ? (N + 63) / 64 : 0), groups), dim3(256), 0, st, ws, a.dbpart, dw, db, p.S, N, (int)K, Cin,
+                     KH * KW, nkb, wsg);
   return kpf_check_launch("kpf_conv2d_wgrad_f32 (reduce)");
 }
 
@@ -1039,6 +1063,12 @@ int kpf_conv2d_wgrad_h16(const void* dy, const void* x, int dtype, float* dw, fl
                          int ldx, int OH, int OW, int N, int ldy, int KH, int KW, int sh, int sw, int ph, int pw, void* stream) {
   KPF_REQUIRE(dtype == KPF_DT_BF16 || dtype == KPF_DT_F16, "kpf_conv2d_wgrad_h16: dtype must be KPF_DT_BF16 or KPF_DT_F16");
   return conv2d_wgrad_impl(dy, x, dtype, dw, db, ws, ws_floats, B, H, W, Cin, ldx, OH, OW, N, ldy, KH, KW, sh, sw, ph, pw, stream);
+}
+
+int kpf_conv2d_wgrad_groups(const void* dy, const void* x, int dtype, float* dw, float* db, float* ws, long ws_floats, int groups, int B, int H, int W, int Cin,
+                            int ldx, int OH, int OW, int N, int ldy, int KH, int KW, int sh, int sw, int ph, int pw, void* stream) {
+  KPF_REQUIRE(groups >= 1 && groups <= 64, "kpf_conv2d_wgrad_groups: 1..64 groups");
+  return conv2d_wgrad_impl(dy, x, dtype, dw, db, ws, ws_floats, B, H, W, Cin, ldx, OH, OW, N, ldy, KH, KW, sh, sw, ph, pw, stream, groups);
 }
 
 int kpf_linear_wgrad_grouped(const kpf_wgrad_group_desc* descs, int n, void* stream) {

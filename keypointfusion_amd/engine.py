@@ -224,6 +224,7 @@ def conv(pc, x, out=None, flags=0, gamma=None, res=None, out_nchw=None, out_spli
     elif out is not None and out_nchw is None:
         out.split = False
     d.flags = flags
+    d.groups, d.w_gstride = getattr(pc, "groups", 0), getattr(pc, "w_gstride", 0)  # (grouped launch: training.GroupedPack; 0 = one convolution)
     M = B * OH * OW
     if AUTOTUNE:
         key = (M, IH, IW, flags, in_ld, in_coff, d.out_ld, d.out_coff, d.res_ld, d.res_coff)
@@ -235,7 +236,8 @@ def conv(pc, x, out=None, flags=0, gamma=None, res=None, out_nchw=None, out_spli
         d.tile_cfg = FORCE_TILE
     # algorithmic bytes: input pixels once, weights once, output once (+ residual once)
     nbytes = 4.0 * (B * IH * IW * pc.Cin + pc.N * pc.K + M * pc.N * (2 if res is not None else 1))
-    _launch("igemm_split_kernel" if flags & (L.KPF_IN_SPLIT | L.KPF_W_SPLIT) else "igemm_f32_kernel", pc.flops(M), nbytes, (M, pc.N, pc.K, pc.KH, pc.KW),
+    ng = max(1, d.groups)
+    _launch("igemm_split_kernel" if flags & (L.KPF_IN_SPLIT | L.KPF_W_SPLIT) else "igemm_f32_kernel", pc.flops(M) * ng, nbytes * ng, (M, pc.N, pc.K, pc.KH, pc.KW),
             lambda: L.check(lib.kpf_conv2d_f32(C.byref(d), _ptr(x.buf), _ptr(w), _ptr(pc.b), _ptr(pc.ps), _ptr(pc.pt), _ptr(gamma),
                                                _ptr(res.buf if res is not None else None), _ptr(optr), _stream()), "kpf_conv2d_f32"))
     return out

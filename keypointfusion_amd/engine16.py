@@ -75,10 +75,12 @@ def conv16(p16, x, kdt, out=None, flags=0, gamma=None, res=None, out_nchw=None):
     if gamma is not None:
         flags |= L.KPF_RES_GAMMA
     d.flags = flags
+    d.groups, d.w_gstride = getattr(pc, "groups", 0), getattr(pc, "w_gstride", 0)  # (grouped launch: training.GroupedPack; 0 = one convolution)
     M = B * OH * OW
     nbytes = 2.0 * (B * IH * IW * pc.Cin + pc.N * pc.K + M * pc.N * (2 if res is not None else 1))
     name = "gemm16_8ph_kernel" if (PROFILE_LABELS() and lib.kpf_conv2d_h16_uses_8ph(C.byref(d), 1 if pc.ps is not None else 0)) else "igemm_h16_kernel"
-    _launch(name, pc.flops(M), nbytes, (M, pc.N, pc.K, pc.KH, pc.KW),
+    ng = max(1, d.groups)
+    _launch(name, pc.flops(M) * ng, nbytes * ng, (M, pc.N, pc.K, pc.KH, pc.KW),
             lambda: L.check(lib.kpf_conv2d_h16(C.byref(d), _ptr(x.buf), _ptr(p16.w), _ptr(pc.b), _ptr(pc.ps), _ptr(pc.pt), _ptr(gamma),
                                                _ptr(res.buf if res is not None else None), _ptr(optr), kdt, _stream()), "kpf_conv2d_h16"))
     return out

@@ -20,13 +20,13 @@ KPF_IN_SPLIT = 128
 KPF_OUT_SPLIT = 256
 KPF_W_SPLIT = 512
 KPF_DT_F32, KPF_DT_BF16, KPF_DT_F16 = 0, 1, 2
-ABI_VERSION = 12  # KPF_ABI_VERSION of include/kpf.h: load() refuses a library built from another revision of the interface
+ABI_VERSION = 13  # KPF_ABI_VERSION of include/kpf.h: load() refuses a library built from another revision of the interface
 
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "B", "IH", "IW", "Cin", "in_ld", "in_coff", "OH", "OW", "N", "KH", "KW", "sh", "sw", "ph", "pw", "Kp",
-        "out_ld", "out_coff", "res_ld", "res_coff")] + [("flags", C.c_uint), ("w_unscale", C.c_float), ("tile_cfg", C.c_int)]
+        "out_ld", "out_coff", "res_ld", "res_coff")] + [("flags", C.c_uint), ("w_unscale", C.c_float), ("tile_cfg", C.c_int), ("groups", C.c_int), ("w_gstride", C.c_long)]
 
 
 class PackDesc(C.Structure):  # kpf_pack_desc (include/kpf.h)
@@ -102,6 +102,9 @@ _SIGS = {
     "kpf_dwconv7_f32": [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
     "kpf_dwconv7_add_f32": [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
     "kpf_conv2d_wgrad_h16": [_P, _P, C.c_int] + [_P] * 3 + [C.c_long] + [C.c_int] * 15 + [_P],
+    "kpf_conv2d_wgrad_groups": [_P, _P, C.c_int] + [_P] * 3 + [C.c_long] + [C.c_int] * 16 + [_P],
+    "kpf_ln_train_forward_g": [_P, _P, _P, _P, C.c_int, _P, _P, C.c_long, C.c_int, C.c_int, C.c_float, _P],
+    "kpf_ln_train_backward_g": [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, C.c_long, C.c_long, C.c_int, C.c_int, C.POINTER(ColsumDesc), _P],
     "kpf_dwconv7_wgrad_f32": [_P] * 5 + [C.c_long] + [C.c_int] * 4 + [_P],
     "kpf_upsample2x_bwd": [_P, _P] + [C.c_int] * 5 + [_P],
     "kpf_maxpool3x3s2_fwd": [_P, _P, _P] + [C.c_int] * 5 + [_P],
@@ -124,6 +127,7 @@ _SIGS = {
     "kpf_loss_tail_backward": [_P] * 11 + [C.c_int] * 3 + [_P],
     "kpf_layer_scale_forward": [_P, _P, C.c_int, _P, _P, C.c_long, C.c_int, _P],
     "kpf_layer_scale_backward": [_P, _P, C.c_int, _P, _P, _P, _P, C.c_long, C.c_long, C.c_int, _P],
+    "kpf_layer_scale_backward_g": [_P, _P, C.c_int, _P, _P, _P, _P, C.c_long, C.c_long, C.c_int, C.c_int, _P],
     "kpf_layer_scale_backward_partial": [_P, _P, C.c_int, _P, _P, _P, _P, C.c_long, C.c_long, C.c_int, C.POINTER(ColsumDesc), _P],
     "kpf_ln_train_backward_partial": [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, C.c_long, C.c_long, C.c_int, C.POINTER(ColsumDesc), _P],
     "kpf_colsum_reduce_grouped": [C.POINTER(ColsumDesc), C.c_int, _P],

@@ -33,9 +33,15 @@ import torch.nn.functional as F
 from . import lib as L
 from .engine import _ptr, _stream, crop_inverse
 from .training import (attn21, batchnorm_relu_rows, bmm_small_k, conv2d_nhwc, dwconv7_nhwc, gelu_rows, layer_norm_rows, layer_scale_residual, linear_hip, maxpool3x3s2_nhwc,
-                       row_gather, upsample2x_nhwc)
+                       pair_params, pair_storage, row_gather, upsample2x_nhwc)
 
-_N_STREAMS = int(os.environ.get("KPF_TRAIN_STREAMS", "2"))  # 2: the RGB backbone (forward and backward) on a side stream
+_N_STREAMS = int(os.environ.get("KPF_TRAIN_STREAMS", "2"))  # 2: the RGB backbone (forward and backward) on a side stream (unpaired backbones only)
+# 1 (default): the two ConvNeXt backbones — same architecture, two weight sets, independent until the fusion head (model/model.py:287-306) — run as ONE
+# network over channel-stacked activations [B, H, W, 2C]: every convolution / Linear is a 2-group launch (kpf_conv_desc::groups), every LayerNorm /
+# layer scale a 2-set launch, every per-channel kernel (BatchNorm, depthwise 7x7, GELU, bilinear x2) simply sees 2C channels.  Half the launches of
+# the backbones, each twice as large — a captured iteration is latency-bound on ~3000 launches of 3-15 us.  0: two separate passes.
+PAIR_BACKBONES = bool(int(os.environ.get("KPF_TRAIN_PAIR", "1")))
+PAIR = "PAIR."  # parameter-name prefix that stands for ("backbone_rgb.", "backbone_d.") while a paired pass is built
 
 J = 21
 
@@ -56,6 +62,7 @@ class TrainGraph:
         # the computed ones — the sets are integer decisions taken around network outputs, and a test that compares gradients with the
         # reference's must compare on equal decisions — plus a count of the sets that differed, kept on the device.  The default path
         # touches neither.
+        self.G = 1  # > 1 while the paired backbones are being built (names under PAIR resolve to both parameter sets)
         self.attn_calls = 0
         self.nbt = []  # BatchNorm num_batches_tracked counters touched by this forward: incremented by ONE multi-tensor launch at its end
         self.ball_override = list(getattr(module, "_debug_ball_override", None) or [])  # None / empty in every product path
@@ -74,15 +81,40 @@ class TrainGraph:
 
     # ---- primitives ---------------------------------------------------------------------------------------------------------------
     def has(self, name):
-        return name in self.t
+        return (("backbone_rgb." + name[len(PAIR):]) if name.startswith(PAIR) else name) in self.t
+
+    def w(self, name):
+        """A parameter / buffer by name.  Under PAIR: the RGB and the depth backbone's tensors of that name as one group-major tensor
+        [2*n, ...] over their (re-homed, adjacent) storage — differentiable towards both (training.pair_params)."""
+        if not name.startswith(PAIR):
+            return self.t[name]
+        a, b = self.t["backbone_rgb." + name[len(PAIR):]], self.t["backbone_d." + name[len(PAIR):]]
+        reg = self.m.__dict__.setdefault("_pair_registry", {})
+        if a.requires_grad:
+            t = pair_params(reg, name, a, b)
+        else:
+            t = pair_storage(reg, name, a, b)
+            t = torch.stack((a, b), 0) if t is None else t
+        return t.reshape((2 * a.shape[0],) + tuple(a.shape[1:]))
+
+    def groups_of(self, name):
+        return self.G if name.startswith(PAIR) else 1
+
+    @staticmethod
+    def key_of(name):
+        """PackCache key of a weight: the parameter name; a paired weight's key carries a ':' (never a DeferredParamGrads candidate: its
+        gradient is one tensor for two parameters)."""
+        return ("pair:" + name[len(PAIR):]) if name.startswith(PAIR) else name
 
     def linear(self, x, p_w, p_b=None):
-        w = self.t[p_w]
-        b = self.t[p_b] if p_b is not None else None
-        n, cin = w.shape
-        npad, cpad = (-n) % 4, (-cin) % self.cmul
+        w = self.w(p_w)
+        b = self.w(p_b) if p_b is not None else None
+        G = self.groups_of(p_w)
+        n, cin = w.shape[0] // G, w.shape[1]
+        npad, cpad = (-n) % (4 if G == 1 else self.cmul), (-cin) % self.cmul
         if npad == 0 and cpad == 0:
-            return linear_hip(x.contiguous(), w, b, self.prec, None, p_w, self.packs)
+            return linear_hip(x.contiguous(), w, b, self.prec, None, self.key_of(p_w), self.packs, G)
+        assert G == 1, "paired Linear layers have whole channel groups"
         # odd widths — the 3-wide joint heads and the 131-wide input of final_TR (model/model.py:99-104, 349): zero rows / columns up
         # to whole channel groups so that forward, data- and weight-gradient all stay on the HIP kernels (the library's GEMM for an
         # M = 3 weight gradient takes 220 us); autograd slices the gradients back
@@ -100,10 +132,15 @@ class TrainGraph:
     def ln(self, x, p_w, p_b, eps, to_gemm=False):
         """LayerNorm over the last axis on the HIP kernels (C % 4 == 0, C <= 1024), torch otherwise; to_gemm: the output feeds a GEMM, so under
         mixed precision it is written in the 16-bit operand type directly."""
-        c = x.shape[-1]
+        G = self.groups_of(p_w)
+        c = x.shape[-1] // G
         if c % 4 == 0 and c <= 1024:  # (the kernel's shape limits; ConvNeXt-L's 1536-wide norms take the library's LayerNorm)
             from .training import _TDT
-            return layer_norm_rows(x, self.t[p_w], self.t[p_b], eps, _TDT[self.prec] if (to_gemm and self.prec != "f32") else None)
+            return layer_norm_rows(x, self.w(p_w), self.w(p_b), eps, _TDT[self.prec] if (to_gemm and self.prec != "f32") else None, G)
+        if G > 1:
+            shp = x.shape
+            y = F.layer_norm(x.reshape(shp[:-1] + (G, c)), (c,), None, None, eps) * self.w(p_w).view(G, c) + self.w(p_b).view(G, c)
+            return y.reshape(shp)
         return F.layer_norm(x, (c,), self.t[p_w], self.t[p_b], eps)
 
     @staticmethod
@@ -131,16 +168,17 @@ class TrainGraph:
     # (bilinear upsample, max-pool, the few library convolutions) see the same memory as a channels_last view: no layout copies.
     def conv_l(self, x, p_w, p_b=None, stride=1, pad=0):
         """NHWC in / out."""
-        w = self.t[p_w]
-        b = self.t[p_b] if p_b is not None else None
+        w = self.w(p_w)
+        b = self.w(p_b) if p_b is not None else None
+        G = self.groups_of(p_w)
         cin, k = w.shape[1], w.shape[2]
-        patch = stride == k and pad == 0 and stride > 1
         assert w.shape[2] == w.shape[3], "square kernels only (every convolution of the model)"
         # any stride / padding: forward, data- and weight-gradient on the HIP kernels
         cpad = (-cin) % self.cmul
         if cpad:  # the 3- / 1-channel images of the stems: zero channels on both operands (the weight's gradient is sliced back)
+            assert G == 1
             x, w = F.pad(x, (0, cpad)), F.pad(w, (0, 0, 0, 0, 0, cpad))
-        return conv2d_nhwc(x.contiguous(), w, b, stride, pad, self.prec, None, None if cpad else p_w, self.packs)
+        return conv2d_nhwc(x.contiguous(), w, b, stride, pad, self.prec, None, None if cpad else self.key_of(p_w), self.packs, G)
 
     def bn_l(self, x, p, eps=1e-5, relu=False, out16=True, alias=False):
         """BatchNorm2d (batch statistics) [+ ReLU] on NHWC: the HIP kernels for fp32 rows, F.batch_norm otherwise.  alias: returns (y, x')
@@ -151,40 +189,49 @@ class TrainGraph:
             # mixed precision: 16-bit rows are read as stored (fp32 statistics and arithmetic) and the output is written in the compute
             # type the following convolution reads — no cast passes on either side
             from .training import _TDT
-            y = batchnorm_relu_rows(rows, self.t[p + ".weight"], self.t[p + ".bias"], self.t[p + ".running_mean"], self.t[p + ".running_var"],
+            y = batchnorm_relu_rows(rows, self.w(p + ".weight"), self.w(p + ".bias"), self.w(p + ".running_mean"), self.w(p + ".running_var"),
                                     self.momentum, eps, relu, _TDT[self.prec] if (self.prec != "f32" and out16) else None, alias)
-            self.nbt.append(self.t[p + ".num_batches_tracked"])
+            if p.startswith(PAIR):  # (per-channel statistics: the stacked tensor's BatchNorm IS the two backbones' BatchNorms)
+                self.nbt += [self.t[q + p[len(PAIR):] + ".num_batches_tracked"] for q in ("backbone_rgb.", "backbone_d.")]
+            else:
+                self.nbt.append(self.t[p + ".num_batches_tracked"])
             return (y[0].view(shp), y[1].view(shp)) if alias else y.view(shp)
+        assert not p.startswith(PAIR)
         y = self.bn(rows, p, eps).view(shp)
         y = F.relu(y) if relu else y
         return (y, x) if alias else y
 
     def residual(self, p, x):
-        cin = x.shape[-1]
+        G = self.groups_of(p)
+        cin = x.shape[-1] // G
         out, x = self.bn_l(x, p + ".bn1", relu=True, alias=True)  # (x: the skip path's handle on the input, see bn_l)
         out = self.conv_l(out, p + ".conv1.conv.weight", p + ".conv1.conv.bias")
         out = self.bn_l(out, p + ".bn2", relu=True)
         out = self.conv_l(out, p + ".conv2.conv.weight", p + ".conv2.conv.bias", pad=1)
         out = self.bn_l(out, p + ".bn3", relu=True)
         out = self.conv_l(out, p + ".conv3.conv.weight", p + ".conv3.conv.bias")
-        if cin != out.shape[-1]:
+        if cin != out.shape[-1] // G:
             x = self.conv_l(x, p + ".skip_layer.conv.weight", p + ".skip_layer.conv.bias")
         return out + x
 
     def convnext_block(self, p, x):
-        c = x.shape[-1]
-        y, x = dwconv7_nhwc(x.float(), self.t[p + ".dwconv.weight"], self.t[p + ".dwconv.bias"], p + ".dwconv.weight", self.packs, True)  # (x: the skip path's handle)
+        y, x = dwconv7_nhwc(x.float(), self.w(p + ".dwconv.weight"), self.w(p + ".dwconv.bias"), self.key_of(p + ".dwconv.weight"), self.packs, True)  # (x: the skip path's handle)
         y = self.ln(y, p + ".norm.weight", p + ".norm.bias", 1e-6, to_gemm=True)
         y = self.gelu(self.linear(y, p + ".pwconv1.weight", p + ".pwconv1.bias"))
         y = self.linear(y, p + ".pwconv2.weight", p + ".pwconv2.bias")
-        return layer_scale_residual(x, self.t[p + ".gamma"], y)  # (drop_path_rate is 0 in the reference's constructor call: identity)
+        return layer_scale_residual(x, self.w(p + ".gamma"), y, self.groups_of(p))  # (drop_path_rate is 0 in the reference's constructor call: identity)
 
     def convnext_features(self, p, x):
         feats = []
         i = 0
         while self.has(p + ".downsample_layers.%d.0.weight" % i):
             q = p + ".downsample_layers.%d" % i
-            if i == 0:
+            if i == 0 and p.startswith(PAIR):
+                # the stems read different images (3 / 1 channels): two convolutions, their outputs stacked on the channel axis from here on
+                rest = q[len(PAIR):]
+                x = torch.cat([self.conv_l(xi, pre + rest + ".0.weight", pre + rest + ".0.bias", stride=4) for pre, xi in zip(("backbone_rgb.", "backbone_d."), x)], -1)
+                x = self.ln(x, q + ".1.weight", q + ".1.bias", 1e-6)
+            elif i == 0:
                 x = self.conv_l(x, q + ".0.weight", q + ".0.bias", stride=4)
                 x = self.ln(x, q + ".1.weight", q + ".1.bias", 1e-6)
             else:
@@ -227,6 +274,20 @@ class TrainGraph:
         """The three 1x1 heads (convNeXT/resnetUnet.py:95-97) as ONE convolution over the concatenated weights, output channels
         zero-padded to a multiple of 4 (the forward, data- and weight-gradient kernels take whole channel quads); autograd hands each
         head's slice of the gradient back to its own parameter."""
+        G = self.groups_of(p + ".")
+        if G > 1:  # paired: [2, n_i, C, 1, 1] per head -> [2, 112, C, 1, 1] (whole 8-channel groups per backbone); returns [B, H, W, 2, n]
+            ws = [self.w(p + ".finals.%d.weight" % i) for i in range(3)]
+            bs = [self.w(p + ".finals.%d.bias" % i) for i in range(3)]
+            ws = [w.view((G, w.shape[0] // G) + tuple(w.shape[1:])) for w in ws]
+            bs = [b.view(G, -1) for b in bs]
+            n = sum(w.shape[1] for w in ws)
+            npad = (n + 7) // 8 * 8
+            if npad != n:
+                ws.append(ws[0].new_zeros((G, npad - n) + tuple(ws[0].shape[2:])))
+                bs.append(bs[0].new_zeros(G, npad - n))
+            w, b = torch.cat(ws, 1), torch.cat(bs, 1)
+            y = conv2d_nhwc(feat.contiguous(), w.view((G * npad,) + tuple(w.shape[2:])), b.view(-1), 1, 0, self.prec, None, None, None, G)
+            return y.view(y.shape[:-1] + (G, npad))[..., :n]
         ws = [self.t[p + ".finals.%d.weight" % i] for i in range(3)]
         bs = [self.t[p + ".finals.%d.bias" % i] for i in range(3)]
         n = sum(w.shape[0] for w in ws)
@@ -240,20 +301,30 @@ class TrainGraph:
     def unet(self, p, img):
         """img NCHW (the module boundary); returns (res, feat) NCHW-shaped views of NHWC memory."""
         convnext = self.has(p + ".backbone.downsample_layers.0.0.weight")
-        x = img.permute(0, 2, 3, 1)
+        G = self.groups_of(p + ".")
+        x = [i.permute(0, 2, 3, 1) for i in img] if G > 1 else img.permute(0, 2, 3, 1)
         c1, c2, c3, c4 = self.convnext_features(p + ".backbone", x) if convnext else self.resnet_features(p + ".backbone", x)
 
         up = upsample2x_nhwc  # bilinear x2 on NHWC rows (HIP forward + deterministic gather-form backward)
 
+        def cat(a, b):  # channel concatenation (per group when the activations are channel-stacked: [.., G, Ca] + [.., G, Cb] -> [.., G*(Ca+Cb)])
+            if G == 1:
+                return torch.cat((a, b), -1)
+            s = a.shape[:-1]
+            return torch.cat((a.reshape(s + (G, -1)), b.reshape(s + (G, -1))), -1).reshape(s + (-1,))
+
         c4_up = up(self.residual(p + ".up4.0", c4))
-        c3_f = self.residual(p + ".fusion_layer4", torch.cat((c4_up, self.residual(p + ".skip_layer4", c3)), -1))
+        c3_f = self.residual(p + ".fusion_layer4", cat(c4_up, self.residual(p + ".skip_layer4", c3)))
         c3_up = up(self.residual(p + ".up3.0", c3_f))
-        c2_f = self.residual(p + ".fusion_layer3", torch.cat((c3_up, self.residual(p + ".skip_layer3", c2)), -1))
+        c2_f = self.residual(p + ".fusion_layer3", cat(c3_up, self.residual(p + ".skip_layer3", c2)))
         c2_up = up(self.residual(p + ".up2.0", c2_f))
-        feat = self.residual(p + ".fusion_layer2", torch.cat((c2_up, self.residual(p + ".skip_layer2", c1)), -1))
+        feat = self.residual(p + ".fusion_layer2", cat(c2_up, self.residual(p + ".skip_layer2", c1)))
         if convnext:
             feat = self.residual(p + ".result_emb", feat)
         res = self.heads(p, feat)
+        if G > 1:  # -> ((res_rgb, feat_rgb), (res_d, feat_d)): each backbone's channel slice of the stacked maps, NHWC (strided views)
+            fs = feat.view(feat.shape[:-1] + (G, -1))
+            return tuple((res[..., g, :], fs[..., g, :]) for g in range(G))
         return res.permute(0, 3, 1, 2), feat.permute(0, 3, 1, 2)  # channels_last views: the consumers below gather pixel rows
 
     # ---- geometry -------------------------------------------------------------------------------------------------------------------
@@ -472,16 +543,26 @@ class TrainGraph:
         # way, inside a captured iteration too (fork / join are event nodes of the graph).  At 128^2 / B = 32 most launches are far
         # too small to fill 256 CUs, which is what the overlap buys back.
         main = torch.cuda.current_stream(dev)
-        side = self._side_stream(dev) if _N_STREAMS > 1 else main
         from .training import _TDT
         amp = (lambda: torch.autocast("cuda", dtype=_TDT[self.prec])) if self.prec != "f32" else contextlib.nullcontext
-        side.wait_stream(main) if side is not main else None
-        with torch.cuda.stream(side), amp():
-            img_offset_rgb, img_feat_rgb = self.unet("backbone_rgb", img_rgb)
-            img_offset_rgb, img_feat_rgb = img_offset_rgb.float(), img_feat_rgb.float()
-        with amp():
-            img_offset, img_feat = self.unet("backbone_d", img)
-        img_feat = img_feat.float()
+        paired = PAIR_BACKBONES and self.has("backbone_rgb.backbone.downsample_layers.0.0.weight") and self.has("backbone_d.backbone.downsample_layers.0.0.weight")
+        side = self._side_stream(dev) if (_N_STREAMS > 1 and not paired) else main
+        if paired:  # both ConvNeXt backbones as one grouped network (PAIR_BACKBONES above)
+            self.G = 2
+            with amp():
+                (img_offset_rgb, img_feat_rgb), (img_offset, img_feat) = self.unet(PAIR[:-1], (img_rgb, img))
+            self.G = 1
+            # one dense fp32 copy per map (the slices are strided, 16-bit under mixed precision), then the channels_last view the head's consumers expect
+            nchw = lambda t: t.float().contiguous().permute(0, 3, 1, 2)
+            img_offset_rgb, img_feat_rgb, img_offset, img_feat = nchw(img_offset_rgb), nchw(img_feat_rgb), nchw(img_offset), nchw(img_feat)
+        else:
+            side.wait_stream(main) if side is not main else None
+            with torch.cuda.stream(side), amp():
+                img_offset_rgb, img_feat_rgb = self.unet("backbone_rgb", img_rgb)
+                img_offset_rgb, img_feat_rgb = img_offset_rgb.float(), img_feat_rgb.float()
+            with amp():
+                img_offset, img_feat = self.unet("backbone_d", img)
+            img_feat = img_feat.float()
         if side is not main:
             main.wait_stream(side)
             for t in (img_offset_rgb, img_feat_rgb):  # produced on the side stream, consumed by the head on the caller's

@@ -137,8 +137,10 @@ class _LayerScaleResidual(torch.autograd.Function):
     residual stream), y in the GEMM's storage type (no casts under mixed precision); dgamma added in a fixed order."""
 
     @staticmethod
-    def forward(ctx, x, gamma, y):
+    def forward(ctx, x, gamma, y, groups=1):
+        """groups = G > 1: x / y [..., G*C] channel-stacked, gamma [G*C] group-major (the paired backbones)."""
         from . import lib as L
+        ctx.groups = groups
         x, y = x.float().contiguous(), y.contiguous()
         Cc = x.shape[-1]
         rows = x.numel() // Cc
@@ -160,9 +162,14 @@ class _LayerScaleResidual(torch.autograd.Function):
         g = g.float().contiguous()
         dy = torch.empty_like(y)
         dgamma = torch.empty(Cc, device=y.device, dtype=torch.float32)
-        nws = lib.kpf_layer_scale_ws_floats(rows, Cc)
+        nws = lib.kpf_layer_scale_ws_floats(rows * ctx.groups, Cc)  # (grouped: the kernel walks rows * G rows of C / G)
         ws = torch.empty(nws, device=y.device, dtype=torch.float32)
         st = torch.cuda.current_stream().cuda_stream
+        if ctx.groups > 1:
+            G = ctx.groups
+            L.check(lib.kpf_layer_scale_backward_g(g.data_ptr(), y.data_ptr(), _KDT[y.dtype], gm.data_ptr(), dy.data_ptr(), dgamma.data_ptr(), ws.data_ptr(), nws,
+                                                   rows * G, Cc // G, G, st), "kpf_layer_scale_backward_g")
+            return g, dgamma, dy, None
         grp = DeferredParamGrads.wants_colsum(gm)
         if grp is not None:  # d gamma: reduced with every other layer's after backward
             desc = L.ColsumDesc()
@@ -172,7 +179,7 @@ class _LayerScaleResidual(torch.autograd.Function):
         else:
             L.check(lib.kpf_layer_scale_backward(g.data_ptr(), y.data_ptr(), _KDT[y.dtype], gm.data_ptr(), dy.data_ptr(), dgamma.data_ptr(), ws.data_ptr(), nws, rows, Cc,
                                                  st), "kpf_layer_scale_backward")
-        return g, dgamma, dy
+        return g, dgamma, dy, None
 
 
 LAYER_SCALE_MAX_C = 1024   # kpf_layer_scale_backward: a lane holds up to 4 channel quads (csrc/kpf_train.hip LN_MAXQ)
@@ -180,12 +187,14 @@ ROW_GATHER_MAX_E = 8192    # kpf_row_gather_bwd_f32: entries (R * G) per image t
 ROW_GATHER_MAX_P = 2048    # ... and source rows per image (GATHER_MAX_P)
 
 
-def layer_scale_residual(x, gamma, y):
+def layer_scale_residual(x, gamma, y, groups=1):
     """x + gamma * y.  The backward kernel's limit is checked HERE, before autograd records a node: widths it does not cover (ConvNeXt-L's
-    1536-channel stage) take the library expression forward and backward instead of failing in backward."""
-    if x.shape[-1] > LAYER_SCALE_MAX_C or x.shape[-1] % 4:
+    1536-channel stage) take the library expression forward and backward instead of failing in backward.  groups: channel-stacked
+    parameter sets (the limit then applies to one group's width)."""
+    c = x.shape[-1] // groups
+    if c > LAYER_SCALE_MAX_C or c % 4:
         return x.float() + gamma * y.float()
-    return _LayerScaleResidual.apply(x, gamma, y)
+    return _LayerScaleResidual.apply(x, gamma, y, groups)
 
 
 class DenseStageLoss(torch.autograd.Function):
@@ -582,16 +591,67 @@ class PackCache:
 
 
 def _conv_any(pc, x4, prec):
-    """engine.conv (fp32) or engine16.conv16 (bf16 / f16) on an NHWC tensor [B, H, W, C]; returns the NHWC output tensor."""
+    """engine.conv (fp32) or engine16.conv16 (bf16 / f16) on an NHWC tensor [B, H, W, C]; returns the NHWC output tensor.  A GroupedPack
+    (G convolutions over channel-stacked activations, one launch): x4 is [B, H, W, G*Cin], the result [B, OH, OW, G*N]."""
     from .engine import Act, conv
     B, H, W, Cc = x4.shape
-    if prec == "f32":
-        out = conv(pc, Act(x4.contiguous().view(-1), B, H, W, Cc))
-    else:
+    G = getattr(pc, "groups", 1)
+    tdt = kdt = None
+    if prec != "f32":
         from .engine16 import DTYPES, conv16
         tdt, kdt = DTYPES[prec]
-        out = conv16(pc.as16(tdt), Act(x4.to(tdt).contiguous().view(-1), B, H, W, Cc), kdt)
+    xb = (x4 if prec == "f32" else x4.to(tdt)).contiguous().view(-1)
+    if G > 1:
+        assert Cc == G * pc.Cin and pc.merge == 1, (Cc, G, pc.Cin)
+        OH, OW = (H + 2 * pc.ph - pc.KH) // pc.sh + 1, (W + 2 * pc.pw - pc.KW) // pc.sw + 1
+        xa = Act(xb, B, H, W, pc.Cin, ld=Cc)
+        ob = torch.empty(B * OH * OW * G * pc.N, device=x4.device, dtype=xb.dtype)
+        oa = Act(ob, B, OH, OW, pc.N, ld=G * pc.N)
+        conv(pc, xa, out=oa) if prec == "f32" else conv16(pc.as16(tdt), xa, kdt, out=oa)
+        return ob.view(B, OH, OW, G * pc.N)
+    if prec == "f32":
+        out = conv(pc, Act(xb, B, H, W, Cc))
+    else:
+        out = conv16(pc.as16(tdt), Act(xb, B, H, W, Cc), kdt)
     return out.buf.view(out.B, out.H, out.W, out.C)
+
+
+class GroupedPack:
+    """G kernel-layout operands of the same shape as ONE launch descriptor (kpf_conv_desc::groups): the attributes of group 0's DevPack plus
+    the element distance to the next group's packed matrix (the G buffers are separate allocations; they only have to be equally spaced)."""
+
+    def __init__(self, pcs, bias):
+        p0 = pcs[0]
+        self.__dict__.update({k: getattr(p0, k) for k in ("KH", "KW", "Cin", "sh", "sw", "ph", "pw", "merge", "N", "K", "Kp", "w", "w16")})
+        self.ps = self.pt = None
+        self.split_allowed = False
+        self.tuned = {}
+        self.groups = len(pcs)
+        self.pcs = pcs  # (keeps the G operands alive)
+        bufs = [pc.w if pc.w is not None else pc.w16 for pc in pcs]
+        es = bufs[0].element_size()
+        step = (bufs[1].data_ptr() - bufs[0].data_ptr()) // es
+        for a, b in zip(bufs, bufs[1:]):
+            assert a.shape == b.shape and a.dtype == b.dtype and (b.data_ptr() - a.data_ptr()) == step * es and step % 8 == 0, "GroupedPack: operands are not equally spaced"
+        self.w_gstride = step
+        self.b = bias.detach().float().contiguous() if bias is not None else None  # [G*N]
+
+    def flops(self, M):
+        return 2.0 * M * self.N * self.K
+
+    def as16(self, tdt):
+        assert self.w16 is not None and self.w16.dtype == tdt
+        return type("P16", (), {"pc": self, "Kp": self.w16.shape[1], "w": self.w16})()
+
+
+def _grouped_pack(cache, key, weight, bias, G, mode, prec, **kw):
+    """The GroupedPack of a paired weight [G*N, Cin, KH, KW]: one (cached) operand per group slice."""
+    n = weight.shape[0] // G
+    if cache is not None and key is not None:
+        pcs = [cache.get((key, mode, g), weight[g * n:(g + 1) * n], None, mode, prec, **kw) for g in range(G)]
+    else:
+        pcs = [DevPack.packed(weight[g * n:(g + 1) * n], None, mode, prec, **kw) for g in range(G)]
+    return GroupedPack(pcs, bias)
 
 
 class DeferredParamGrads:
@@ -720,7 +780,7 @@ class DeferredParamGrads:
 GroupedLinearWgrad = DeferredParamGrads  # (the name the first form of this class had)
 
 
-def conv_wgrad_hip(dy, x, wshape, stride, pad, want_db=True):
+def conv_wgrad_hip(dy, x, wshape, stride, pad, want_db=True, groups=1):
     """(dW in OIHW, db or None) of a convolution from NHWC dY [B,OH,OW,N] and X [B,H,W,Cin]: kpf_conv2d_wgrad_f32 / _h16 (f32 MFMA GEMM
     with the pixel index as the reduction dimension, split over workgroups, fixed-order reduce)."""
     from . import lib as L
@@ -728,17 +788,24 @@ def conv_wgrad_hip(dy, x, wshape, stride, pad, want_db=True):
     B, H, W, Cin = x.shape
     _, OH, OW, N = dy.shape
     KH, KW = int(wshape[2]), int(wshape[3])
+    ldx, ldy = Cin, N
+    Cin, N = Cin // groups, N // groups  # (groups > 1: channel-stacked operands, wshape = [G*N, Cin, KH, KW]: kpf_conv2d_wgrad_groups)
     # both operands in the same 16-bit storage type (mixed-precision step) and whole 8-element granules: kpf_conv2d_wgrad_h16 reads them
     # as they are (fp32 products and sums); anything else is widened to fp32 first
     h16 = dy.dtype == x.dtype and dy.dtype in (torch.bfloat16, torch.float16) and Cin % 8 == 0 and N % 8 == 0
     if not h16:
         dy, x = dy.float(), x.float()
     dy, x = dy.contiguous(), x.contiguous()
-    nws = lib.kpf_conv2d_wgrad_ws_floats(B * OH * OW, N, KH * KW * Cin)
+    nws = lib.kpf_conv2d_wgrad_ws_floats(B * OH * OW, N, KH * KW * Cin) * groups
     ws = torch.empty(nws, device=x.device, dtype=torch.float32)
     dw = torch.empty(tuple(wshape), device=x.device, dtype=torch.float32)
-    db = torch.empty(N, device=x.device, dtype=torch.float32) if want_db else None
+    db = torch.empty(N * groups, device=x.device, dtype=torch.float32) if want_db else None
     st = torch.cuda.current_stream().cuda_stream
+    if groups > 1:
+        dt = (L.KPF_DT_BF16 if dy.dtype == torch.bfloat16 else L.KPF_DT_F16) if h16 else L.KPF_DT_F32
+        L.check(lib.kpf_conv2d_wgrad_groups(dy.data_ptr(), x.data_ptr(), dt, dw.data_ptr(), db.data_ptr() if want_db else None, ws.data_ptr(), nws, groups,
+                                            B, H, W, Cin, ldx, OH, OW, N, ldy, KH, KW, stride, stride, pad, pad, st), "kpf_conv2d_wgrad_groups")
+        return dw, db
     if h16:
         L.check(lib.kpf_conv2d_wgrad_h16(dy.data_ptr(), x.data_ptr(), L.KPF_DT_BF16 if dy.dtype == torch.bfloat16 else L.KPF_DT_F16, dw.data_ptr(),
                                          db.data_ptr() if want_db else None, ws.data_ptr(), nws, B, H, W, Cin, Cin, OH, OW, N, N, KH, KW,
@@ -837,6 +904,52 @@ def dwconv7_nhwc(x, weight, bias, key=None, cache=None, alias=False):
 _KDT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}  # KPF_DT_* of include/kpf.h
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# paired parameters: the two backbones as ONE network with grouped convolutions
+# ----------------------------------------------------------------------------------------------------------------
+class _PairParams(torch.autograd.Function):
+    """(a, b) -> the [2, ...] tensor whose halves ARE a's and b's storage (pair_params keeps them adjacent): no copy forward; backward hands
+    each parameter its half of the gradient as a view (AccumulateGrad adopts it)."""
+
+    @staticmethod
+    def forward(ctx, a, b, both):
+        return both.detach().view(both.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        return g[0], g[1], None
+
+
+def pair_storage(registry, name, a, b):
+    """The [2, *shape] tensor over the storage of tensors a and b (parameters or buffers of identical shape and type), re-homing them side by
+    side the first time (and again if something moved them apart, e.g. module.to()): `a.data` / `b.data` become views of one allocation,
+    values preserved.  Optimiser state, state dicts and gradients are per tensor as before; only the addresses change — so this must run
+    before anything records them (it does: the first eager forward, ahead of any graph capture)."""
+    if a.numel() % 4:  # (the second half would not start 16-byte aligned: not paired; pair_params concatenates)
+        return None
+    both = registry.get(name)
+    es = a.element_size()
+    if (both is None or both.data_ptr() != a.data_ptr() or both.data_ptr() + a.numel() * es != b.data_ptr() or both.device != a.device or both.dtype != a.dtype):
+        assert a.shape == b.shape and a.dtype == b.dtype and a.device == b.device, "pair_storage: %s: the two tensors differ in shape / type" % name
+        assert not (a.is_cuda and torch.cuda.is_current_stream_capturing()), "pair_storage: parameters must be paired before a graph capture"
+        both = torch.empty((2,) + tuple(a.shape), device=a.device, dtype=a.dtype)
+        with torch.no_grad():
+            both[0].copy_(a.detach())
+            both[1].copy_(b.detach())
+        a.data, b.data = both[0], both[1]
+        registry[name] = both
+    return both
+
+
+def pair_params(registry, name, a, b):
+    """Two parameters of the paired backbones as one differentiable [2, ...] tensor (group-major: rows of a, then rows of b)."""
+    both = pair_storage(registry, name, a, b)
+    if both is None:  # (odd sizes: a real concatenation)
+        return torch.stack((a, b), 0)
+    return _PairParams.apply(a, b, both) if (a.requires_grad or b.requires_grad) else both
+
+
 class BatchNormReLU(torch.autograd.Function):
     """Train-mode BatchNorm (+ ReLU) on rows [M, C] (NHWC pixels): kpf_bn_train_forward / kpf_bn_train_backward.  x may be fp32 or the
     16-bit storage type of the mixed-precision step, y is written in `out_dtype` (default: x's); statistics and arithmetic are fp32.
@@ -899,18 +1012,21 @@ class LayerNormRows(torch.autograd.Function):
     follows (`out_dtype`); statistics and gradients are fp32, parameter gradients are added in a fixed order."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, out_dtype=None):
+    def forward(ctx, x, weight, bias, eps, out_dtype=None, groups=1):
+        """groups = G > 1: x [..., G*C] holds G channel groups, each normalised on its own with its own parameter set (weight, bias [G*C]
+        group-major: the paired backbones' LayerNorms, pair_params) — kpf_ln_train_forward_g on the [rows*G, C] view."""
         from . import lib as L
         x = x.float().contiguous()
-        Cc = x.shape[-1]
+        Cc = x.shape[-1] // groups
         rows = x.numel() // Cc
         out_dtype = out_dtype or torch.float32
         y = torch.empty(x.shape, device=x.device, dtype=out_dtype)
         stats = torch.empty(2, rows, device=x.device, dtype=torch.float32)
         w, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
-        L.check(L.load().kpf_ln_train_forward(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), _KDT[out_dtype], stats[0].data_ptr(), stats[1].data_ptr(),
-                                              rows, Cc, float(eps), torch.cuda.current_stream().cuda_stream), "kpf_ln_train_forward")
+        L.check(L.load().kpf_ln_train_forward_g(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), _KDT[out_dtype], stats[0].data_ptr(), stats[1].data_ptr(),
+                                                rows, Cc, groups, float(eps), torch.cuda.current_stream().cuda_stream), "kpf_ln_train_forward_g")
         ctx.save_for_backward(x, stats, w)
+        ctx.groups = groups
         ctx.bias_ptr = b.data_ptr()  # (identifies the bias PARAMETER for DeferredParamGrads: its gradient is deferred together with the weight's)
         return y
 
@@ -919,16 +1035,21 @@ class LayerNormRows(torch.autograd.Function):
         from . import lib as L
         lib = L.load()
         x, stats, w = ctx.saved_tensors
-        Cc = x.shape[-1]
+        G = ctx.groups
+        Cc = x.shape[-1] // G
         rows = x.numel() // Cc
         dy = dy.contiguous()
         if dy.dtype not in _KDT:
             dy = dy.float()
         dx = torch.empty_like(x)
-        dwb = torch.empty(2, Cc, device=x.device, dtype=torch.float32)
-        nws = lib.kpf_ln_ws_floats(rows, Cc)
+        dwb = torch.empty(2, G * Cc, device=x.device, dtype=torch.float32)
+        nws = lib.kpf_ln_ws_floats(rows, G * Cc)
         ws = torch.empty(nws, device=x.device, dtype=torch.float32)
         st = torch.cuda.current_stream().cuda_stream
+        if G > 1:
+            L.check(lib.kpf_ln_train_backward_g(dy.data_ptr(), _KDT[dy.dtype], x.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), w.data_ptr(), dx.data_ptr(),
+                                                dwb[0].data_ptr(), dwb[1].data_ptr(), ws.data_ptr(), nws, rows, Cc, G, None, st), "kpf_ln_train_backward_g")
+            return dx, dwb[0], dwb[1], None, None, None
         grp = DeferredParamGrads.wants_colsum(w, ctx.bias_ptr)
         if grp is not None:  # d gamma / d beta: reduced with every other layer's after backward
             desc = L.ColsumDesc()
@@ -939,7 +1060,7 @@ class LayerNormRows(torch.autograd.Function):
         else:
             L.check(lib.kpf_ln_train_backward(dy.data_ptr(), _KDT[dy.dtype], x.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), w.data_ptr(), dx.data_ptr(),
                                               dwb[0].data_ptr(), dwb[1].data_ptr(), ws.data_ptr(), nws, rows, Cc, st), "kpf_ln_train_backward")
-        return dx, dwb[0], dwb[1], None, None
+        return dx, dwb[0], dwb[1], None, None, None
 
 
 class GeluRows(torch.autograd.Function):
@@ -1034,8 +1155,8 @@ def bmm_small_k(A, X):
     return BmmSmallK.apply(A, X)
 
 
-def layer_norm_rows(x, weight, bias, eps, out_dtype=None):
-    return LayerNormRows.apply(x, weight, bias, eps, out_dtype)
+def layer_norm_rows(x, weight, bias, eps, out_dtype=None, groups=1):
+    return LayerNormRows.apply(x, weight, bias, eps, out_dtype, groups)
 
 
 def gelu_rows(x):
@@ -1173,17 +1294,25 @@ class Conv2dNHWC(torch.autograd.Function):
     Linear layers are the 1x1 case on a [rows, 1, 1, K] view."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, prec="f32", w16=None, key=None, cache=None):
+    def forward(ctx, x, weight, bias, stride, pad, prec="f32", w16=None, key=None, cache=None, groups=1):
         """prec "bf16" / "f16": operands rounded to 16 bits, fp32 accumulation on the 16-bit MFMA (kpf_conv2d_h16), 16-bit output;
         the weight stays the fp32 master copy and receives an fp32 gradient.  w16: the weight already rounded to the compute type
-        (same shape; TrainGraph casts all of them once per step) — the packs are then built from it without per-layer casts."""
+        (same shape; TrainGraph casts all of them once per step) — the packs are then built from it without per-layer casts.
+        groups = G > 1: G convolutions in one launch each way — x [B, H, W, G*Cin] channel-stacked, weight [G*N, Cin, KH, KW] and bias
+        [G*N] group-major (the paired backbones' parameters: pair_params), output [B, OH, OW, G*N]."""
         assert x.is_cuda and x.dim() == 4
         B, H, W, Cin = x.shape
         N, Cw, KH, KW = weight.shape
-        assert Cw == Cin and Cin % (4 if prec == "f32" else 8) == 0, "Conv2dNHWC: input channels must match and be a multiple of 4 (8 for 16-bit)"
+        cm = 4 if prec == "f32" else 8
+        assert Cw * groups == Cin and Cw % cm == 0, "Conv2dNHWC: input channels must match and be a multiple of 4 (8 for 16-bit)"
         patch = stride == KH == KW and pad == 0 and stride > 1
         use16 = prec != "f32" and w16 is not None
-        if cache is not None and key is not None:  # persistent operand, refreshed once per iteration for all layers (PackCache)
+        ctx.groups = groups
+        if groups > 1:
+            assert w16 is None and (N // groups) % cm == 0, "grouped Conv2dNHWC: whole channel groups per group"
+            patch = False  # (the kx-merging GEMM view of a patchify convolution does not survive channel stacking: general strided form)
+            pc = _grouped_pack(cache, key, weight, bias, groups, 0, prec, stride=stride, pad=pad, patchify=False)
+        elif cache is not None and key is not None:  # persistent operand, refreshed once per iteration for all layers (PackCache)
             pc = cache.get((key, 0), weight, bias, 0, prec, stride=stride, pad=pad, patchify=patch)
         else:
             pc = DevPack.packed(w16 if use16 else weight, bias, 0, prec, stride=stride, pad=pad, patchify=patch)
@@ -1207,6 +1336,24 @@ class Conv2dNHWC(torch.autograd.Function):
         OH, OW = dy.shape[1], dy.shape[2]
         dx = dw = db = None
         cmul = 4 if prec == "f32" else 8  # channel granularity of the GEMM's activation operand
+        G = ctx.groups
+        if G > 1:  # channel-stacked groups: the same three GEMMs, one launch each for all groups
+            key, cache = ctx.pack
+            n, wd = N // G, weight.detach()
+            if ctx.needs_input_grad[0]:
+                dyc = dy if prec == "f32" else dy.to(_TDT[prec])
+                if stride == KH == KW and pad == 0 and stride > 1:  # patchify: rows of dY @ W[n][(ky,kx,c)] per group, then the pixel un-shuffle
+                    g = _conv_any(_grouped_pack(cache, key, wd, None, G, 2, prec, n_pad=n), dyc, prec).view(B, OH, OW, G, KH, KW, Cin // G)
+                    dx = g.permute(0, 1, 4, 2, 5, 3, 6).reshape(B, OH * KH, OW * KW, Cin)
+                    if dx.shape[1] != H or dx.shape[2] != W:
+                        dx = F.pad(dx, (0, 0, 0, W - dx.shape[2], 0, H - dx.shape[1]))
+                else:
+                    assert stride == 1, "grouped Conv2dNHWC: stride 1 or patchify"
+                    dx = _conv_any(_grouped_pack(cache, key, wd, None, G, 1, prec, pad=pad, n_pad=n), dyc, prec).view(B, H, W, Cin)
+                dx = dx.to(ctx.x_dtype)
+            if ctx.needs_input_grad[1]:
+                dw, db = conv_wgrad_hip(dy, x, weight.shape, stride, pad, has_bias and ctx.needs_input_grad[2], groups=G)
+            return dx, dw, db, None, None, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             wsrc = ctx.w16 if ctx.w16 is not None else weight.detach()
             npad = (N + cmul - 1) // cmul * cmul
@@ -1243,7 +1390,7 @@ class Conv2dNHWC(torch.autograd.Function):
                 grp.add(ctx.pack[0], dyc, xc, dw, db, ctx.bias_ptr if want_db else None)
             else:
                 dw, db = conv_wgrad_hip(dy, x, weight.shape, stride, pad, want_db)
-            return dx, dw, db, None, None, None, None, None, None
+            return dx, dw, db, None, None, None, None, None, None, None
         if ctx.needs_input_grad[1]:
             xw = x if prec == "f32" else x.to(_TDT[prec])  # weight gradient in the compute precision, handed to the fp32 master weight
             dyw = dy if prec == "f32" else dy.to(_TDT[prec])
@@ -1253,7 +1400,7 @@ class Conv2dNHWC(torch.autograd.Function):
                 dw = torch.nn.grad.conv2d_weight(xw.permute(0, 3, 1, 2), weight.shape, dyw.permute(0, 3, 1, 2), stride=stride, padding=pad).float()
         if has_bias and ctx.needs_input_grad[2]:
             db = dy.float().view(-1, N).sum(0)
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
 def _dgrad_pack(ctx, wsrc, mode, prec, **kw):
@@ -1263,15 +1410,17 @@ def _dgrad_pack(ctx, wsrc, mode, prec, **kw):
     return DevPack.packed(wsrc, None, mode, prec, **kw)
 
 
-def conv2d_nhwc(x, weight, bias=None, stride=1, pad=0, prec="f32", w16=None, key=None, cache=None):
-    return Conv2dNHWC.apply(x, weight, bias, stride, pad, prec, w16, key, cache)
+def conv2d_nhwc(x, weight, bias=None, stride=1, pad=0, prec="f32", w16=None, key=None, cache=None, groups=1):
+    return Conv2dNHWC.apply(x, weight, bias, stride, pad, prec, w16, key, cache, groups)
 
 
-def linear_hip(x, weight, bias=None, prec="f32", w16=None, key=None, cache=None):
-    """nn.Linear on rows [..., K] through the same Function (a 1x1 convolution over a [rows, 1, 1, K] view)."""
+def linear_hip(x, weight, bias=None, prec="f32", w16=None, key=None, cache=None, groups=1):
+    """nn.Linear on rows [..., K] through the same Function (a 1x1 convolution over a [rows, 1, 1, K] view); groups: see Conv2dNHWC
+    (x [..., G*K], weight [G*N, K])."""
     K = x.shape[-1]
-    y = Conv2dNHWC.apply(x.reshape(-1, 1, 1, K), weight.reshape(weight.shape[0], K, 1, 1), bias, 1, 0, prec,
-                         w16.reshape(weight.shape[0], K, 1, 1) if w16 is not None else None, key, cache)
+    Kw = weight.shape[-1]
+    y = Conv2dNHWC.apply(x.reshape(-1, 1, 1, K), weight.reshape(weight.shape[0], Kw, 1, 1), bias, 1, 0, prec,
+                         w16.reshape(weight.shape[0], Kw, 1, 1) if w16 is not None else None, key, cache, groups)
     return y.view(*x.shape[:-1], weight.shape[0])
 
 

@@ -754,3 +754,113 @@ def test_skip_path_gradient_is_folded_into_the_producing_backward_kernel(dt):
         y3, xa3 = T.dwconv7_nhwc(xd3, wd3, bd3, None, None, True)
         ((y3 * d1.cuda()).sum() + (xa3 * d2.cuda()).sum()).backward()
         assert rel(y3, yr2) <= 3e-5 and rel(xd3.grad, xr2.grad) <= 3e-5 and rel(wd3.grad, wr2.grad) <= 1e-4 and rel(bd3.grad, br2.grad) <= 1e-4
+
+
+# ---- round 4: channel-stacked groups (the paired backbones of the training step: kpf_conv_desc::groups, kpf_conv2d_wgrad_groups,
+# kpf_ln_train_*_g, kpf_layer_scale_backward_g).  Same kernels, tile choice and summation order per group as the ungrouped calls on the
+# channel slices, so the comparison is BIT-EXACT, forward and every gradient.
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("case", [(4, 16, 16, 96, 384, 1, 1, 0), (4, 16, 16, 384, 96, 1, 1, 0), (3, 8, 8, 64, 64, 3, 1, 1), (2, 16, 16, 96, 192, 2, 2, 0),
+                                  (2, 4, 4, 128, 112, 1, 1, 0), (32, 4, 4, 768, 3072, 1, 1, 0)])
+def test_grouped_convolution_is_bit_identical_to_per_group_calls(case, prec):
+    from keypointfusion_amd import training as T
+    B, H, W, Cin, N, k, stride, pad = case
+    G = 2
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(sum(case))
+    tdt = torch.float32 if prec == "f32" else torch.bfloat16
+    x = torch.randn(B, H, W, G * Cin, generator=g).to(dev).to(tdt)
+    w = (torch.randn(G * N, Cin, k, k, generator=g) * (Cin * k * k) ** -0.5).to(dev)
+    b = torch.randn(G * N, generator=g).to(dev)
+    xg, wg, bg = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = T.conv2d_nhwc(xg, wg, bg, stride, pad, prec, None, None, None, G)
+    dy = torch.randn(y.shape, generator=g).to(dev).to(y.dtype)
+    y.backward(dy)
+    for i in range(G):
+        xi = x[..., i * Cin:(i + 1) * Cin].contiguous().requires_grad_(True)
+        wi, bi = w[i * N:(i + 1) * N].clone().requires_grad_(True), b[i * N:(i + 1) * N].clone().requires_grad_(True)
+        yi = T.conv2d_nhwc(xi, wi, bi, stride, pad, prec)
+        yi.backward(dy[..., i * N:(i + 1) * N].contiguous())
+        assert torch.equal(y[..., i * N:(i + 1) * N], yi), "forward, group %d" % i
+        assert torch.equal(xg.grad[..., i * Cin:(i + 1) * Cin], xi.grad), "data gradient, group %d" % i
+        assert torch.equal(wg.grad[i * N:(i + 1) * N], wi.grad), "weight gradient, group %d" % i
+        assert torch.equal(bg.grad[i * N:(i + 1) * N], bi.grad), "bias gradient, group %d" % i
+
+
+@pytest.mark.parametrize("ydt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(4, 16, 16, 96), (2, 4, 4, 768), (3, 5, 7, 192), (32, 32, 32, 96)])
+def test_grouped_layer_norm_and_layer_scale_match_per_group_calls(shape, ydt):
+    from keypointfusion_amd import training as T
+    dev = torch.device("cuda:0")
+    G, Cc = 2, shape[-1]
+    g = torch.Generator().manual_seed(Cc + shape[0])
+    x = torch.randn(shape[:-1] + (G * Cc,), generator=g).to(dev)
+    w, b = (1 + 0.1 * torch.randn(G * Cc, generator=g)).to(dev), (0.1 * torch.randn(G * Cc, generator=g)).to(dev)
+    dy = torch.randn(x.shape, generator=g).to(dev)
+    xg, wg, bg = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = T.layer_norm_rows(xg, wg, bg, 1e-6, ydt, G)
+    y.backward(dy.to(ydt))
+    # layer scale: out = x + gamma * y2
+    y2 = torch.randn(x.shape, generator=g).to(dev).to(ydt)
+    xs, gs, ys = x.clone().requires_grad_(True), w.clone().requires_grad_(True), y2.clone().requires_grad_(True)
+    o = T.layer_scale_residual(xs, gs, ys, G)
+    o.backward(dy)
+    for i in range(G):
+        sl = slice(i * Cc, (i + 1) * Cc)
+        xi, wi, bi = x[..., sl].contiguous().requires_grad_(True), w[sl].clone().requires_grad_(True), b[sl].clone().requires_grad_(True)
+        yi = T.layer_norm_rows(xi, wi, bi, 1e-6, ydt)
+        yi.backward(dy[..., sl].contiguous().to(ydt))
+        assert torch.equal(y[..., sl], yi) and torch.equal(xg.grad[..., sl], xi.grad), "LayerNorm output / input gradient, group %d" % i
+        # parameter gradients: column sums over the same rows, but the grouped launch cuts them into workgroup partials differently
+        for a, r in ((wg.grad[sl], wi.grad), (bg.grad[sl], bi.grad)):
+            assert float((a - r).abs().max()) <= 2e-5 * max(1.0, float(r.abs().max())), "LayerNorm parameter gradient, group %d" % i
+        xi2, gi, yi2 = x[..., sl].contiguous().requires_grad_(True), w[sl].clone().requires_grad_(True), y2[..., sl].contiguous().requires_grad_(True)
+        oi = T.layer_scale_residual(xi2, gi, yi2)
+        oi.backward(dy[..., sl].contiguous())
+        assert torch.equal(o[..., sl], oi) and torch.equal(ys.grad[..., sl], yi2.grad) and torch.equal(xs.grad[..., sl], xi2.grad), "layer scale, group %d" % i
+        assert float((gs.grad[sl] - gi.grad).abs().max()) <= 2e-5 * max(1.0, float(gi.grad.abs().max())), "layer-scale gamma gradient, group %d" % i
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_paired_backbones_match_the_two_pass_training_graph(prec, monkeypatch):
+    """KPF_TRAIN_PAIR: the two ConvNeXt backbones as one grouped network against the two separate passes — same loss, same gradients for every
+    parameter (bit-identical GEMMs per group; the per-channel column sums of LayerNorm / layer scale are cut into different partials)."""
+    from conftest import synthetic_sd
+    from keypointfusion_amd import train_graph as TG
+    from keypointfusion_amd import training as T
+    from keypointfusion_amd.model.model import KPFusion
+    from keypointfusion_amd.weights import synthetic_batch
+    net, B, dev = "KPFusion-convnext-tiny", 4, torch.device("cuda:0")
+    batch = {k: torch.from_numpy(v).to(dev) for k, v in synthetic_batch(B, 128, seed=5).items()}
+    g = torch.Generator().manual_seed(1)
+    uvd, xyz = (torch.rand(B, 21, 3, generator=g) * 1.2 - 0.6).to(dev), (torch.rand(B, 21, 3, generator=g) * 1.2 - 0.6).to(dev)
+
+    class Loader:
+        img_size, flip = 128, 1
+
+    def run(pair):
+        monkeypatch.setattr(TG, "PAIR_BACKBONES", pair)
+        m = KPFusion(net, "", 21, "dexycb", "")
+        m.load_state_dict(synthetic_sd(net), strict=True)
+        m = m.to(dev).train()
+        m.train_dropout, m.precision = 0.0, prec
+        r, s, _ = m(batch["img_rgb"], batch["img"], batch["pcl"], Loader(), batch["center"], batch["M"], batch["cube"], batch["cam_para"], 0.8)
+        loss = T.kpfusion_loss(r, s, batch["img"], uvd, xyz, epoch=0)[0]
+        loss.backward()
+        bufs = {k: v.detach().clone() for k, v in m.named_buffers()}
+        return float(loss), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}, bufs, [t.detach().clone() for t in r]
+
+    l0, g0, b0, r0 = run(False)
+    l1, g1, b1, r1 = run(True)
+    # Not bit-identical: BatchNorm / LayerNorm statistics are cut into different partial sums over 2C-wide rows and the patchify convolutions
+    # take the general strided form; fp32 agrees to rounding, bf16 to the size of a few rounding flips of 16-bit activations.
+    f32 = prec == "f32"
+    rel = lambda a, b: float((a.float() - b.float()).abs().max()) / max(float(a.float().abs().max()), 1e-6)
+    for i, (a, b) in enumerate(zip(r0, r1)):  # (bf16: the joint estimates behind the ball queries may jump where a point crosses a radius, DESIGN 4.3c)
+        assert rel(a, b) <= (1e-4 if f32 else (5e-2 if i < 2 else 0.25)), (i, rel(a, b))
+    assert abs(l0 - l1) <= (1e-4 if f32 else 2e-2) * abs(l0), (l0, l1)
+    assert set(g0) == set(g1)
+    errs = sorted((rel(g0[k], g1[k]), k) for k in g0)
+    assert errs[len(errs) // 2][0] <= (1e-3 if f32 else 3e-2) and errs[-1][0] <= (5e-2 if f32 else 0.3), (errs[len(errs) // 2], errs[-8:])
+    for k in b0:
+        assert torch.allclose(b0[k].float(), b1[k].float(), rtol=1e-4 if f32 else 2e-2, atol=1e-5 if f32 else 2e-3), k
