@@ -319,7 +319,13 @@ int kpf_conv2d_wgrad_h16(const void* dy, const void* x, int dtype, float* dw, fl
  * (db may be NULL).  Same kernels, split and summation order as G separate kpf_conv2d_wgrad_f32 / _h16 calls on the channel slices
  * (bit-identical results); ws_floats >= G * kpf_conv2d_wgrad_ws_floats(M, N, K).  dtype: KPF_DT_F32 / _BF16 / _F16 (both operands). */
 int kpf_conv2d_wgrad_groups(const void* dy, const void* x, int dtype, float* dw, float* db, float* ws, long ws_floats, int groups, int B, int H, int W, int Cin,
-                            int ldx, int OH, int OW, int N, int ldy, int KH, int KW, int sh, int sw, int ph, int pw, void* stream);
+                            int ldx, int OH, int OW, int N, int ldy, int KH, int KW, int sh, int sw, int ph, int pw, int cin_valid, int n_valid, void* stream);
+/* cin_valid / n_valid (0 = Cin / N): the operands carry zero channels up to whole channel groups (the 3-, 105-, 131-, 149-wide layers of the fusion
+ * head, model/model.py:99-104, 254-262) and dw [n_valid][cin_valid][KH][KW], db [n_valid] are written without them. */
+
+/* Row pad / column-slice copy / type change in one launch, and the pose tokens of a fusion block at their padded width (csrc/kpf_train.hip). */
+int kpf_pad_rows(const void* src, int src_dtype, void* dst, int dst_dtype, long rows, int C, int src_ld, int Cp, void* stream);
+int kpf_pose_tokens_f32(const float* pw, const float* joint, const float* pcl, float* out, int B, int N, int J, int ld, float kernel, void* stream);
 /* Depthwise 7x7 (pad 3) + bias alone, y = dwconv(x): the ConvNeXt block's first op with its output kept for the LayerNorm backward,
  * and its data gradient (dx = the same convolution of dy with w_dw's taps mirrored, zero bias).  w_dw [49][C], x != y. */
 int kpf_dwconv7_f32(const float* x, const float* w_dw, const float* b_dw, float* y, int B, int H, int W, int C, void* stream);
@@ -533,6 +539,14 @@ int kpf_joint_heatmap_forward(const float* uvd, float* hm, int B, int J, int F, 
 int kpf_joint_heatmap_backward(const float* uvd, const float* dhm, float* duvd, int B, int J, int F, float std_, float sigma, void* stream);
 int kpf_geom_gate_forward(const float* pix_xyz, const float* joint_xyz, float* gam, int B, int J, int P, void* stream);
 int kpf_geom_gate_backward(const float* pix_xyz, const float* joint_xyz, const float* dgam, float* djoint, int B, int J, int P, void* stream);
+
+/* The same map with the joints given in crop coordinates uvd in [-1, 1]^3 (ABI 13): the uvd -> camera -> cube-normalised xyz transform of
+ * dataloader/loader.py:775-789 (half_size = img_size / 2, flip = +-1) runs inside the kernel and the backward returns d/d(uvd).
+ * par16 [B][16] = [M^-1 rows 0 and 1 (6) | fx fy u0 v0 (4) | centre xyz (3) | cube xyz (3)] per sample.  Replaces model/model.py:318-326. */
+int kpf_geom_gate_uvd_forward(const float* pix_xyz, const float* joint_uvd, const float* par16, float* gam, int B, int J, int P, float half_size, float flip,
+                              void* stream);
+int kpf_geom_gate_uvd_backward(const float* pix_xyz, const float* joint_uvd, const float* par16, const float* dgam, float* djoint_uvd, int B, int J, int P,
+                               float half_size, float flip, void* stream);
 
 int kpf_conv_num_tile_cfgs(void);
 

@@ -1628,11 +1628,27 @@ __global__ __launch_bounds__(256) void joint_heatmap_kernel(const float* __restr
 // MODE 0: gam[b][j][p] = 1 / (10 |ix[b][p] - jx[b][j]|^2 + 1);  MODE 1: djx[b][j][c] = sum_p dgam * (-20 gam^2 (jx_c - ix_c))
 template <int MODE>
 __global__ __launch_bounds__(256) void geom_gate_kernel(const float* __restrict__ ix, const float* __restrict__ jx, const float* __restrict__ dgam,
-                                                        float* __restrict__ out, int J, int P) {
+                                                        float* __restrict__ out, int J, int P, const float* __restrict__ par = nullptr, float half_size = 0.f,
+                                                        float flip = 1.f) {
+  // par != nullptr (kpf_geom_gate_uvd_*): jx holds the joints as crop coordinates uvd in [-1, 1]^3 and par the sample's 16 numbers
+  // [M^-1 rows 0-1 (6) | fx fy u0 v0 | centre xyz | cube xyz]; the joint goes through dataloader/loader.py:775-789 (uvd -> pixel -> camera ->
+  // cube-normalised xyz) here, and the backward multiplies by that map's Jacobian — ~25 element-wise launches each way in the torch expression.
   __shared__ float red[4];
   const int j = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const long bj = (long)b * J + j;
-  const float x0 = jx[bj * 3 + 0], x1 = jx[bj * 3 + 1], x2 = jx[bj * 3 + 2];
+  float x0 = jx[bj * 3 + 0], x1 = jx[bj * 3 + 1], x2 = jx[bj * 3 + 2];
+  float tx = 0.f, ty = 0.f, dep = 0.f;
+  const float* pp = par ? par + (long)b * 16 : nullptr;
+  if (pp) {
+    const float u = (x0 + 1.f) * half_size, v = (x1 + 1.f) * half_size;
+    dep = x2 * (pp[15] * 0.5f) + pp[12];
+    tx = pp[0] * u + pp[1] * v + pp[2];
+    ty = pp[3] * u + pp[4] * v + pp[5];
+    const float cx = (tx - pp[8]) * dep / pp[6], cy = flip * (ty - pp[9]) * dep / pp[7];
+    x0 = (cx - pp[10]) / (pp[13] * 0.5f);
+    x1 = (cy - pp[11]) / (pp[14] * 0.5f);
+    x2 = (dep - pp[12]) / (pp[15] * 0.5f);
+  }
   const float* ib = ix + (long)b * P * 3;
   float g0 = 0.f, g1 = 0.f, g2 = 0.f;
   for (int p = tid; p < P; p += 256) {
@@ -1652,6 +1668,13 @@ __global__ __launch_bounds__(256) void geom_gate_kernel(const float* __restrict_
     g1 = block_sum256(g1, red);
     g2 = block_sum256(g2, red);
     if (tid == 0) {
+      if (pp) {  // d/d(uvd) = J^T d/d(xyz_normalised)
+        const float gx = g0 / (pp[13] * 0.5f), gy = g1 / (pp[14] * 0.5f), gz = g2 / (pp[15] * 0.5f);
+        const float ax = dep / pp[6] * half_size, ay = flip * dep / pp[7] * half_size, hz = pp[15] * 0.5f;
+        g0 = gx * pp[0] * ax + gy * pp[3] * ay;
+        g1 = gx * pp[1] * ax + gy * pp[4] * ay;
+        g2 = (gx * (tx - pp[8]) / pp[6] + gy * flip * (ty - pp[9]) / pp[7] + gz) * hz;
+      }
       out[bj * 3 + 0] = g0;
       out[bj * 3 + 1] = g1;
       out[bj * 3 + 2] = g2;
@@ -1679,4 +1702,98 @@ extern "C" int kpf_geom_gate_backward(const float* pix_xyz, const float* joint_x
   KPF_REQUIRE(pix_xyz && joint_xyz && dgam && djoint && B > 0 && J > 0 && P > 0, "kpf_geom_gate_backward: bad arguments");
   hipLaunchKernelGGL(geom_gate_kernel<1>, dim3(J, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pix_xyz, joint_xyz, dgam, djoint, J, P);
   return kpf_check_launch("kpf_geom_gate_backward");
+}
+extern "C" int kpf_geom_gate_uvd_forward(const float* pix_xyz, const float* joint_uvd, const float* par16, float* gam, int B, int J, int P, float half_size,
+                                         float flip, void* stream) {
+  KPF_REQUIRE(pix_xyz && joint_uvd && par16 && gam && B > 0 && J > 0 && P > 0 && half_size > 0.f, "kpf_geom_gate_uvd_forward: bad arguments");
+  hipLaunchKernelGGL(geom_gate_kernel<0>, dim3(J, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pix_xyz, joint_uvd, (const float*)nullptr, gam, J, P, par16,
+                     half_size, flip);
+  return kpf_check_launch("kpf_geom_gate_uvd_forward");
+}
+extern "C" int kpf_geom_gate_uvd_backward(const float* pix_xyz, const float* joint_uvd, const float* par16, const float* dgam, float* djoint_uvd, int B, int J, int P,
+                                          float half_size, float flip, void* stream) {
+  KPF_REQUIRE(pix_xyz && joint_uvd && par16 && dgam && djoint_uvd && B > 0 && J > 0 && P > 0 && half_size > 0.f, "kpf_geom_gate_uvd_backward: bad arguments");
+  hipLaunchKernelGGL(geom_gate_kernel<1>, dim3(J, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pix_xyz, joint_uvd, dgam, djoint_uvd, J, P, par16, half_size,
+                     flip);
+  return kpf_check_launch("kpf_geom_gate_uvd_backward");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round 4: the small producers around the odd-width Linear layers of the fusion head (3-d coordinates, the 105 pose channels, the 149-channel
+// gate input, the 3-wide joint heads): a row pad in ONE launch (F.pad is a fill plus a strided copy, and its autograd twin a zero fill plus a
+// copy) and the pose tokens of model/model.py:308-316 written directly at the padded width.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void pad_rows_kernel(const TS* __restrict__ src, TD* __restrict__ dst, long rows, int C, int src_ld, int Cp) {
+  const long total = rows * Cp;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / Cp;
+    const int c = (int)(i - r * Cp);
+    dst[i] = c < C ? (TD)(float)src[r * src_ld + c] : (TD)0.f;
+  }
+}
+
+// thread = (point, joint): unit offset joint - point (3), closeness (kernel - |offset|) / kernel, both masked by closeness >= 0 and point depth < 0.99
+__global__ __launch_bounds__(256) void pose_tokens_kernel(const float* __restrict__ pw, const float* __restrict__ joint, const float* __restrict__ pcl,
+                                                          float* __restrict__ out, long total, int N, int J, int ld, float kernel) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const long bn = t / J;
+  const int j = (int)(t - bn * J);
+  const int b = (int)(bn / N);
+  const float* pt = pcl + bn * 3;
+  const float* jt = joint + ((long)b * J + j) * 3;
+  const float o0 = jt[0] - pt[0], o1 = jt[1] - pt[1], o2 = jt[2] - pt[2];
+  const float dis = sqrtf((o0 * o0 + o1 * o1) + o2 * o2);
+  const float inv = 1.0f / (dis + 1e-8f);
+  float clos = (kernel - dis) / kernel;
+  const float m = (clos >= 0.f && pt[2] < 0.99f) ? 1.f : 0.f;
+  float* o = out + bn * ld;
+  int base = 0;
+  if (pw) {
+    o[j] = pw[bn * J + j];
+    base = J;
+  }
+  o[base + 3 * j + 0] = o0 * inv * m;
+  o[base + 3 * j + 1] = o1 * inv * m;
+  o[base + 3 * j + 2] = o2 * inv * m;
+  o[base + 3 * J + j] = clos * m;
+  const int used = base + 4 * J;
+  if (j < ld - used) o[used + j] = 0.f;  // (zero padding up to the row stride: fewer than J channels)
+}
+}  // namespace
+
+/* dst[r][c] = c < C ? src[r * src_ld + c] : 0 for c < Cp (Cp >= C): a zero pad of the last axis — or, with Cp == C < src_ld, a dense copy of a column slice —
+ * with an optional type change (KPF_DT_*). */
+extern "C" int kpf_pad_rows(const void* src, int src_dtype, void* dst, int dst_dtype, long rows, int C, int src_ld, int Cp, void* stream) {
+  KPF_REQUIRE(src && dst && rows > 0 && C > 0 && Cp >= C && src_ld >= C, "kpf_pad_rows: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid(grid_for(rows * Cp));
+#define PR(TS, TD) hipLaunchKernelGGL((pad_rows_kernel<TS, TD>), grid, dim3(256), 0, st, static_cast<const TS*>(src), static_cast<TD*>(dst), rows, C, src_ld, Cp)
+  if (src_dtype == KPF_DT_F32 && dst_dtype == KPF_DT_F32) PR(float, float);
+  else if (src_dtype == KPF_DT_F32 && dst_dtype == KPF_DT_BF16) PR(float, bf16_t);
+  else if (src_dtype == KPF_DT_F32 && dst_dtype == KPF_DT_F16) PR(float, f16_t);
+  else if (src_dtype == KPF_DT_BF16 && dst_dtype == KPF_DT_BF16) PR(bf16_t, bf16_t);
+  else if (src_dtype == KPF_DT_F16 && dst_dtype == KPF_DT_F16) PR(f16_t, f16_t);
+  else if (src_dtype == KPF_DT_BF16 && dst_dtype == KPF_DT_F32) PR(bf16_t, float);
+  else if (src_dtype == KPF_DT_F16 && dst_dtype == KPF_DT_F32) PR(f16_t, float);
+  else {
+    kpf_set_error("kpf_pad_rows: unsupported type pair %d -> %d", src_dtype, dst_dtype);
+    return KPF_EINVAL;
+  }
+#undef PR
+  return kpf_check_launch("kpf_pad_rows");
+}
+
+/* The pose tokens of a fusion block (model/model.py:308-316, 417): out[b][n] = [pw[b][n][0..J) | unit offsets (j, xyz) 3J | closeness J | zeros up to ld];
+ * pw (the J weight logits sampled at the point, may be NULL: then the row starts with the offsets), joint [B][J][3], pcl [B][N][3]; no gradient (the
+ * reference detaches all three).  ld >= 5J (4J without pw), ld - 5J < J. */
+extern "C" int kpf_pose_tokens_f32(const float* pw, const float* joint, const float* pcl, float* out, int B, int N, int J, int ld, float kernel, void* stream) {
+  const int used = (pw ? 5 : 4) * J;
+  KPF_REQUIRE(joint && pcl && out && B > 0 && N > 0 && J > 0 && ld >= used && ld - used < J && kernel > 0.f, "kpf_pose_tokens_f32: bad arguments");
+  const long total = (long)B * N * J;
+  hipLaunchKernelGGL(pose_tokens_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pw, joint, pcl, out, total, N, J,
+                     ld, kernel);
+  return kpf_check_launch("kpf_pose_tokens_f32");
 }

@@ -756,10 +756,11 @@ __device__ __forceinline__ float sum_partials(const float* __restrict__ part, lo
 // dw[n][c][ky][kx] = sum_s part[s][n][(ky,kx,c)];  db[n] = sum_s dbpart[s][n]   (blocks [0, nkb) reduce dw, the rest db)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbpart,
                                                            float* __restrict__ dw, float* __restrict__ db, int S, int N, int K, int Cin,
-                                                           int KHW, int nkb, long g_ws) {
-  // (grid.y = channel group of a grouped launch: its partial sums start g_ws floats further, its dw / db N*K / N floats further)
-  part += blockIdx.y * g_ws, dw += (long)blockIdx.y * N * K;
-  if (dbpart) dbpart += blockIdx.y * g_ws, db += blockIdx.y * N;
+                                                           int KHW, int nkb, long g_ws, int Cin_out, int N_out) {
+  // (grid.y = channel group of a grouped launch: its partial sums start g_ws floats further, its dw / db N_out*K_out / N_out floats further.
+  //  Cin_out <= Cin, N_out <= N: the operands carried zero channels up to whole channel groups; dw [N_out][Cin_out][KH][KW] drops them)
+  part += blockIdx.y * g_ws, dw += (long)blockIdx.y * N_out * Cin_out * KHW;
+  if (dbpart) dbpart += blockIdx.y * g_ws, db += blockIdx.y * N_out;
   __shared__ float red[4][64];
   const int o = threadIdx.x & 63;
   if ((int)blockIdx.x < nkb) {
@@ -769,12 +770,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (threadIdx.x < 64 && i < NK) {
       const int n = (int)(i / K), k = (int)(i - (long)n * K);
       const int tap = k / Cin, c = k - tap * Cin;
-      dw[((size_t)n * Cin + c) * KHW + tap] = v;
+      if (c < Cin_out && n < N_out) dw[((size_t)n * Cin_out + c) * KHW + tap] = v;
     }
   } else {
     const long i = (long)(blockIdx.x - nkb) * 64 + o;
     const float v = sum_partials(dbpart, N, S, i, red);
-    if (threadIdx.x < 64 && i < N) db[i] = v;
+    if (threadIdx.x < 64 && i < N_out) db[i] = v;
   }
 }
 
@@ -977,7 +978,11 @@ long kpf_conv2d_wgrad_ws_floats(long M, int N, int K) {
 
 static int conv2d_wgrad_impl(const void* dy, const void* x, int dtype, float* dw, float* db, float* ws, long ws_floats, int B, int H, int W,
                              int Cin, int ldx, int OH, int OW, int N, int ldy, int KH, int KW, int sh, int sw, int ph, int pw,
-                             void* stream, int groups = 1) {
+                             void* stream, int groups = 1, int cin_valid = 0, int n_valid = 0) {
+  if (cin_valid <= 0) cin_valid = Cin;
+  if (n_valid <= 0) n_valid = N;
+  KPF_REQUIRE(cin_valid <= Cin && n_valid <= N, "kpf_conv2d_wgrad: cin_valid / n_valid exceed Cin / N");
+  const bool trimmed = cin_valid != Cin || n_valid != N;
   KPF_REQUIRE(groups >= 1 && (long)groups * Cin <= ldx && (long)groups * N <= ldy, "kpf_conv2d_wgrad: %d groups of %d / %d channels exceed the pixel strides %d / %d", groups, Cin, N, ldx, ldy);
   KPF_REQUIRE(dy && x && dw && ws, "kpf_conv2d_wgrad_f32: null pointer");
   KPF_REQUIRE(dtype == KPF_DT_F32 || dtype == KPF_DT_BF16 || dtype == KPF_DT_F16, "kpf_conv2d_wgrad: unknown dtype %d", dtype);
@@ -1000,7 +1005,7 @@ static int conv2d_wgrad_impl(const void* dy, const void* x, int dtype, float* dw
   const bool one = KH == 1 && KW == 1;
   const bool h16s = h16 && h16_form != 128;
   const Plan p = h16s ? plan_wgrad_h16s(M, N, (int)K) : (h16 ? plan_wgrad_h16(M, N, (int)K) : plan_wgrad(M, N, (int)K, one));
-  const bool direct = one && p.S == 1;  // the single partial array is dW
+  const bool direct = one && p.S == 1 && !trimmed;  // the single partial array is dW
   const long wsg = (long)p.S * N * K + (long)p.S * N;  // one group's workspace
   KPF_REQUIRE(ws_floats >= groups * wsg, "kpf_conv2d_wgrad_f32: workspace too small (%ld floats, need %ld)", ws_floats, groups * wsg);
   WgradArgs a;
@@ -1050,7 +1055,7 @@ static int conv2d_wgrad_impl(const void* dy, const void* x, int dtype, float* dw
   const long NK = (long)N * K;
   const int nkb = (int)((NK + 63) / 64);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nkb + (db ? (N + 63) / 64 : 0), groups), dim3(256), 0, st, ws, a.dbpart, dw, db, p.S, N, (int)K, Cin,
-                     KH * KW, nkb, wsg);
+                     KH * KW, nkb, wsg, cin_valid, n_valid);
   return kpf_check_launch("kpf_conv2d_wgrad_f32 (reduce)");
 }
 
@@ -1066,9 +1071,9 @@ int kpf_conv2d_wgrad_h16(const void* dy, const void* x, int dtype, float* dw, fl
 }
 
 int kpf_conv2d_wgrad_groups(const void* dy, const void* x, int dtype, float* dw, float* db, float* ws, long ws_floats, int groups, int B, int H, int W, int Cin,
-                            int ldx, int OH, int OW, int N, int ldy, int KH, int KW, int sh, int sw, int ph, int pw, void* stream) {
+                            int ldx, int OH, int OW, int N, int ldy, int KH, int KW, int sh, int sw, int ph, int pw, int cin_valid, int n_valid, void* stream) {
   KPF_REQUIRE(groups >= 1 && groups <= 64, "kpf_conv2d_wgrad_groups: 1..64 groups");
-  return conv2d_wgrad_impl(dy, x, dtype, dw, db, ws, ws_floats, B, H, W, Cin, ldx, OH, OW, N, ldy, KH, KW, sh, sw, ph, pw, stream, groups);
+  return conv2d_wgrad_impl(dy, x, dtype, dw, db, ws, ws_floats, B, H, W, Cin, ldx, OH, OW, N, ldy, KH, KW, sh, sw, ph, pw, stream, groups, cin_valid, n_valid);
 }
 
 int kpf_linear_wgrad_grouped(const kpf_wgrad_group_desc* descs, int n, void* stream) {

@@ -102,7 +102,9 @@ _SIGS = {
     "kpf_dwconv7_f32": [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
     "kpf_dwconv7_add_f32": [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
     "kpf_conv2d_wgrad_h16": [_P, _P, C.c_int] + [_P] * 3 + [C.c_long] + [C.c_int] * 15 + [_P],
-    "kpf_conv2d_wgrad_groups": [_P, _P, C.c_int] + [_P] * 3 + [C.c_long] + [C.c_int] * 16 + [_P],
+    "kpf_conv2d_wgrad_groups": [_P, _P, C.c_int] + [_P] * 3 + [C.c_long] + [C.c_int] * 18 + [_P],
+    "kpf_pad_rows": [_P, C.c_int, _P, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_pose_tokens_f32": [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P],
     "kpf_ln_train_forward_g": [_P, _P, _P, _P, C.c_int, _P, _P, C.c_long, C.c_int, C.c_int, C.c_float, _P],
     "kpf_ln_train_backward_g": [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, C.c_long, C.c_long, C.c_int, C.c_int, C.POINTER(ColsumDesc), _P],
     "kpf_dwconv7_wgrad_f32": [_P] * 5 + [C.c_long] + [C.c_int] * 4 + [_P],
@@ -116,6 +118,8 @@ _SIGS = {
     "kpf_joint_heatmap_backward": [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P],
     "kpf_geom_gate_forward": [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P],
     "kpf_geom_gate_backward": [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_geom_gate_uvd_forward": [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P],
+    "kpf_geom_gate_uvd_backward": [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P],
     "kpf_linear_wgrad_grouped": [C.POINTER(WgradGroupDesc), C.c_int, _P],
     "kpf_adamw_step_multi": [C.POINTER(AdamwDesc), C.c_int, _P, C.c_float, _P, C.c_double, C.c_double, C.c_float, C.c_float, _P],
     "kpf_ln_train_forward": [_P, _P, _P, _P, C.c_int, _P, _P, C.c_long, C.c_int, C.c_float, _P],

@@ -111,17 +111,10 @@ class TrainGraph:
         b = self.w(p_b) if p_b is not None else None
         G = self.groups_of(p_w)
         n, cin = w.shape[0] // G, w.shape[1]
-        npad, cpad = (-n) % (4 if G == 1 else self.cmul), (-cin) % self.cmul
-        if npad == 0 and cpad == 0:
-            return linear_hip(x.contiguous(), w, b, self.prec, None, self.key_of(p_w), self.packs, G)
-        assert G == 1, "paired Linear layers have whole channel groups"
-        # odd widths — the 3-wide joint heads and the 131-wide input of final_TR (model/model.py:99-104, 349): zero rows / columns up
-        # to whole channel groups so that forward, data- and weight-gradient all stay on the HIP kernels (the library's GEMM for an
-        # M = 3 weight gradient takes 220 us); autograd slices the gradients back
-        wp = F.pad(w, (0, cpad, 0, npad))
-        bp = F.pad(b, (0, npad)) if (b is not None and npad) else b
-        xp = F.pad(x, (0, cpad)) if cpad else x
-        return linear_hip(xp.contiguous(), wp, bp, self.prec)[..., :n]
+        assert G == 1 or (n % self.cmul == 0 and cin % self.cmul == 0), "paired Linear layers have whole channel groups"
+        # (odd widths — the 3-wide joint heads, the 131-wide input of final_TR, model/model.py:99-104, 349 — are handled inside Conv2dNHWC: one pad
+        #  launch on the activation / output gradient, weight gradient trimmed in its reduce; everything stays on the HIP kernels)
+        return linear_hip(x.contiguous(), w, b, self.prec, None, self.key_of(p_w), self.packs, G)
 
     def bn(self, x, p, eps=1e-5):
         rm, rv = self.t[p + ".running_mean"], self.t[p + ".running_var"]
@@ -290,13 +283,7 @@ class TrainGraph:
             return y.view(y.shape[:-1] + (G, npad))[..., :n]
         ws = [self.t[p + ".finals.%d.weight" % i] for i in range(3)]
         bs = [self.t[p + ".finals.%d.bias" % i] for i in range(3)]
-        n = sum(w.shape[0] for w in ws)
-        npad = (n + 3) // 4 * 4
-        if npad != n:
-            ws.append(ws[0].new_zeros((npad - n,) + tuple(ws[0].shape[1:])))
-            bs.append(bs[0].new_zeros(npad - n))
-        y = conv2d_nhwc(feat.contiguous(), torch.cat(ws, 0), torch.cat(bs, 0), 1, 0, self.prec)
-        return y[..., :n]
+        return conv2d_nhwc(feat.contiguous(), torch.cat(ws, 0), torch.cat(bs, 0), 1, 0, self.prec)  # (105 output channels: the odd-width form)
 
     def unet(self, p, img):
         """img NCHW (the module boundary); returns (res, feat) NCHW-shaped views of NHWC memory."""
@@ -352,12 +339,8 @@ class TrainGraph:
     # ---- fusion head (model/model.py:129-351, model/transfusion_head.py:137-173) -----------------------------------------------------------
     def linear_rows(self, rows, w, b, key=None):
         """nn.Linear / Conv1d(k=1) / Conv2d(k=1) over rows [M, Cin] on the HIP GEMM (forward, data- and weight-gradient); input widths
-        that are not whole channel groups (3-d coordinates, the 105 pose channels) are zero-padded together with the weight."""
-        cin = rows.shape[-1]
-        pad = (-cin) % self.cmul
-        if pad:
-            rows, w = F.pad(rows, (0, pad)), F.pad(w, (0, pad))
-        return linear_hip(rows.contiguous(), w, b, self.prec, None, None if pad else key, self.packs)
+        that are not whole channel groups (3-d coordinates, the 105 pose channels, the 149-channel gate input) see training.Conv2dNHWC."""
+        return linear_hip(rows, w, b, self.prec, None, key, self.packs)  # (rows may arrive at the padded width: Conv2dNHWC's odd-width form)
 
     def emb1d(self, p, x):
         """Conv1d(k=1) + BatchNorm1d over (B, N) (model/model.py:254-259) on rows."""
@@ -388,6 +371,19 @@ class TrainGraph:
         clos = clos * mask
         unit = unit * mask.view(B, Jn, 1, N).expand(B, Jn, 3, N).reshape(B, -1, N)
         return torch.cat((unit, clos), 1).permute(0, 2, 1)
+
+    def pose_tokens(self, pw, joint, pcl, kernel):
+        """[B, N, 108]: the point's 21 weight logits, pcl_joint2offset above (63 unit offsets + 21 closenesses) and three zero channels — the
+        input of pcl_pose_emb at the width its GEMM reads (kpf_pose_tokens_f32: one launch for ~25 element-wise ones; no gradient, like the
+        reference's detach calls, model/model.py:308-316)."""
+        B, N, _ = pcl.shape
+        Jn = joint.shape[1]
+        ld = (5 * Jn + 3) // 4 * 4
+        out = torch.empty(B, N, ld, device=pcl.device, dtype=torch.float32)
+        with torch.no_grad():
+            L.check(L.load().kpf_pose_tokens_f32(_ptr(pw.detach().float().contiguous()), _ptr(joint.detach().float().contiguous()), _ptr(pcl.float().contiguous()),
+                                                 _ptr(out), B, N, Jn, ld, float(kernel), _stream()), "kpf_pose_tokens_f32")
+        return out
 
     def ball_query_hip(self, pcl_xyz, node_xyz, pcl_feat, node_feat):
         """The three ball-query index tensors of DESA from the inference path's kernel (kpf_ball_group_f32: same semantics as
@@ -479,13 +475,13 @@ class TrainGraph:
 
     def block(self, p, img_feat, img_feat_rgb, pcl, joint_xyz, clos, idx, img_offset, prev_feat, img_down, center, Minv, cube, cam,
               img_size, flip):
-        from .training import GeomGate, JointHeatmap
+        from .training import GeomGateUVD, JointHeatmap
         B, C, H, W = img_feat.shape
-        pcl_off = self.pcl_joint2offset(joint_xyz, pcl, 0.8).detach()
         pf = self.gather_interp(img_feat, idx, clos)
         pf_rgb = self.gather_interp(img_feat_rgb, idx, clos)
         pw = self.gather_interp(img_offset[:, J * 4:], idx, clos).detach()
-        x = self.emb1d(p + ".pcl_feat_emb", pf) + self.emb1d(p + ".pcl_xyz_emb", pcl) + self.emb1d(p + ".pcl_pose_emb", torch.cat((pw, pcl_off), -1))
+        tok = self.pose_tokens(pw, joint_xyz, pcl, 0.8)  # [pw | pcl_joint2offset(joint, pcl) | 0 0 0]: 105 channels at the GEMM's width 108, no gradient
+        x = self.emb1d(p + ".pcl_feat_emb", pf) + self.emb1d(p + ".pcl_xyz_emb", self.pcl4) + self.emb1d(p + ".pcl_pose_emb", tok)
         x = F.relu(x)
         x = F.relu(x + self.emb1d(p + ".pcl_feat_emb_RGB", pf_rgb))
         att = F.softmax(pw.permute(0, 2, 1), -1)
@@ -497,14 +493,12 @@ class TrainGraph:
         hm = JointHeatmap.apply(r3d, 0.8, H, 1.0)
         # geometry adjacency map (dataloader/loader.py:791-819): the joints go through the uvd -> xyz map again, like the pixels
         ix = self.img_xyz  # pixel positions of the depth map (dataloader/loader.py:936-955): written by kpf_img2pcl_top4_f32, once per forward
-        jx = self.uvd2xyz(r3d, center, Minv, cube, cam, img_size, flip)
-        gam = GeomGate.apply(ix, jx).view(B, J, H, W)
+        gam = GeomGateUVD.apply(ix, r3d, self.par16, img_size, flip).view(B, J, H, W)  # (uvd2xyz above, inside the kernel)
         # Conv2d(128 + 21 -> 21, k = 1) (model/model.py:262,336): rows of 149 channels, input and output channel counts zero-padded to
-        # whole quads so that forward, data- and weight-gradient all run on the HIP kernels (fixed summation order)
-        sw_in = torch.cat([img_feat_rgb.permute(0, 2, 3, 1).float(), hm.permute(0, 2, 3, 1)], -1).reshape(B * H * W, C + J)
-        w_sp, b_sp = self.t[p + ".atten_spatial.weight"].flatten(1), self.t[p + ".atten_spatial.bias"]
-        npad = (-J) % 4
-        sw = self.linear_rows(sw_in, F.pad(w_sp, (0, 0, 0, npad)), F.pad(b_sp, (0, npad)))[:, :J].float()
+        # whole quads so that forward, data- and weight-gradient all run on the HIP kernels (fixed summation order): the three zero channels ride in
+        # the concatenation, the 21 outputs are Conv2dNHWC's odd-width form
+        sw_in = torch.cat([img_feat_rgb.permute(0, 2, 3, 1).float(), hm.permute(0, 2, 3, 1), self.zpad3], -1).reshape(B * H * W, -1)
+        sw = self.linear_rows(sw_in, self.t[p + ".atten_spatial.weight"].flatten(1), self.t[p + ".atten_spatial.bias"], p + ".atten_spatial.weight").float()
         sw = torch.sigmoid(sw.view(B, H, W, J).permute(0, 3, 1, 2))
         wd = torch.sigmoid(self.t[p + ".weight_dis"])
         g = wd * gam + (1 - wd) * sw
@@ -586,7 +580,11 @@ class TrainGraph:
         L.check(lib.kpf_img2pcl_top4_f32(_ptr(pcl), _ptr(img), _ptr(center), _ptr(Minv), _ptr(cube), _ptr(cam), _ptr(clos), _ptr(index), _ptr(self.img_xyz),
                                          B, N, S, Fs, int(img_size), int(flip), _stream()), "kpf_img2pcl_top4_f32")
         idx = index.long()
-        img_down = F.interpolate(img, [Fs, Fs])
+        self.par16 = torch.cat((Minv.reshape(B, 9)[:, :6], cam.reshape(B, -1)[:, :4], center.reshape(B, 3), cube.reshape(B, 3)), 1)  # GeomGateUVD's per-sample numbers
+        from .training import pad_rows
+        self.pcl4 = pad_rows(pcl, 4)                                         # the points at the width pcl_xyz_emb's GEMM reads (both blocks)
+        self.zpad3 = torch.zeros(B, Fs, Fs, 3, device=dev)                   # the gate input's three zero channels (149 -> 152, both blocks)
+        img_down = None  # (F.interpolate(img, [Fs, Fs]) in the reference, model/model.py:401: computed there and never read)
         sws = []
         prev = None
         for i in (1, 2):

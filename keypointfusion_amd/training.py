@@ -96,6 +96,36 @@ class GeomGate(torch.autograd.Function):
         return None, d.to(ctx.dt)
 
 
+class GeomGateUVD(torch.autograd.Function):
+    """GeomGate with the joints given as crop coordinates uvd: the uvd -> xyz map of dataloader/loader.py:775-789 (TrainGraph.uvd2xyz, ~25
+    element-wise launches each way on [B, 21, 3] tensors) runs inside kpf_geom_gate_uvd_forward / _backward.  par16 [B, 16]: see include/kpf.h."""
+
+    @staticmethod
+    def forward(ctx, pix_xyz, joint_uvd, par16, img_size, flip):
+        from . import lib as L
+        ix, ju, par = pix_xyz.detach().float().contiguous(), joint_uvd.detach().float().contiguous(), par16.detach().float().contiguous()
+        B, P, _ = ix.shape
+        J = ju.shape[1]
+        gam = torch.empty(B, J, P, device=ix.device, dtype=torch.float32)
+        ctx.conf = (float(img_size) / 2.0, float(flip))
+        L.check(L.load().kpf_geom_gate_uvd_forward(ix.data_ptr(), ju.data_ptr(), par.data_ptr(), gam.data_ptr(), B, J, P, ctx.conf[0], ctx.conf[1],
+                                                   torch.cuda.current_stream().cuda_stream), "kpf_geom_gate_uvd_forward")
+        ctx.save_for_backward(ix, ju, par)
+        ctx.dt = joint_uvd.dtype
+        return gam
+
+    @staticmethod
+    def backward(ctx, dgam):
+        from . import lib as L
+        ix, ju, par = ctx.saved_tensors
+        B, P, _ = ix.shape
+        J = ju.shape[1]
+        d = torch.empty_like(ju)
+        L.check(L.load().kpf_geom_gate_uvd_backward(ix.data_ptr(), ju.data_ptr(), par.data_ptr(), dgam.float().contiguous().data_ptr(), d.data_ptr(), B, J, P,
+                                                    ctx.conf[0], ctx.conf[1], torch.cuda.current_stream().cuda_stream), "kpf_geom_gate_uvd_backward")
+        return None, d.to(ctx.dt), None, None, None
+
+
 class _SmoothL1(torch.autograd.Function):
     """model/loss.py:3-26 as one autograd node: the forward is the reference's own operation sequence (bit-identical values), the
     backward is the closed form dL/dz = scale * (z if |z| < 0.01 else 0.01 sign(z)) in four launches instead of the ~15 that autograd
@@ -590,12 +620,26 @@ class PackCache:
         L.check(lib.kpf_pack_conv_weights_multi(self.table.data_ptr(), len(self.entries), self.total_blocks, st), "kpf_pack_conv_weights_multi")
 
 
-def _conv_any(pc, x4, prec):
+def _conv_any(pc, x4, prec, out_ld=None):
     """engine.conv (fp32) or engine16.conv16 (bf16 / f16) on an NHWC tensor [B, H, W, C]; returns the NHWC output tensor.  A GroupedPack
-    (G convolutions over channel-stacked activations, one launch): x4 is [B, H, W, G*Cin], the result [B, OH, OW, G*N]."""
+    (G convolutions over channel-stacked activations, one launch): x4 is [B, H, W, G*Cin], the result [B, OH, OW, G*N].  out_ld > N: the result
+    is [B, OH, OW, out_ld] with only the first N channels written."""
     from .engine import Act, conv
     B, H, W, Cc = x4.shape
     G = getattr(pc, "groups", 1)
+    if out_ld is not None and out_ld != pc.N:
+        assert G == 1 and pc.merge == 1
+        tdt, kdt = (None, None) if prec == "f32" else __import__("keypointfusion_amd.engine16", fromlist=["DTYPES"]).DTYPES[prec]
+        xb = (x4 if prec == "f32" else x4.to(tdt)).contiguous().view(-1)
+        OH, OW = (H + 2 * pc.ph - pc.KH) // pc.sh + 1, (W + 2 * pc.pw - pc.KW) // pc.sw + 1
+        ob = torch.empty(B * OH * OW * out_ld, device=x4.device, dtype=xb.dtype)
+        oa = Act(ob, B, OH, OW, pc.N, ld=out_ld)
+        if prec == "f32":
+            conv(pc, Act(xb, B, H, W, Cc), out=oa)
+        else:
+            from .engine16 import conv16
+            conv16(pc.as16(tdt), Act(xb, B, H, W, Cc), kdt, out=oa)
+        return ob.view(B, OH, OW, out_ld)
     tdt = kdt = None
     if prec != "f32":
         from .engine16 import DTYPES, conv16
@@ -614,6 +658,42 @@ def _conv_any(pc, x4, prec):
     else:
         out = conv16(pc.as16(tdt), Act(xb, B, H, W, Cc), kdt)
     return out.buf.view(out.B, out.H, out.W, out.C)
+
+
+def pad_rows(src, width, dtype=None):
+    """src [..., C] (any strides on the leading axes collapse to rows of stride src_ld: a contiguous tensor or a column slice of one) -> dense
+    [..., width] with zero columns beyond C (width >= C), optionally in another storage type: kpf_pad_rows, ONE launch (F.pad: fill + copy)."""
+    from . import lib as L
+    Cc = src.shape[-1]
+    s2 = src.reshape(-1, Cc)  # (a view whenever the leading axes collapse to one row stride — contiguous tensors, column slices of them)
+    if s2.stride(1) != 1:
+        s2 = s2.contiguous()
+    rows = s2.shape[0]
+    ld = s2.stride(0) if rows > 1 else Cc
+    dtype = dtype or src.dtype
+    out = torch.empty(tuple(src.shape[:-1]) + (width,), device=src.device, dtype=dtype)
+    L.check(L.load().kpf_pad_rows(s2.data_ptr(), _KDT[s2.dtype], out.data_ptr(), _KDT[dtype], rows, Cc, ld, width, torch.cuda.current_stream().cuda_stream), "kpf_pad_rows")
+    return out
+
+
+class _OddPack:
+    """A Linear operand whose input width is not a whole channel group, seen by the GEMM at the padded width: the packed rows [N][Kp] are zero
+    beyond K anyway (Kp >= the padded width), so only the descriptor changes — the activation rows carry the matching zero channels."""
+
+    def __init__(self, pc, cin_pad):
+        self.__dict__.update(pc.__dict__)
+        self.Cin = self.K = cin_pad
+        self.tuned = {}
+        self._base = pc
+
+    split_allowed = False
+    ps = pt = None
+
+    def flops(self, M):
+        return 2.0 * M * self.N * self.K
+
+    def as16(self, tdt):
+        return type("P16", (), {"pc": self, "Kp": self.w16.shape[1], "w": self.w16})()
 
 
 class GroupedPack:
@@ -804,7 +884,7 @@ def conv_wgrad_hip(dy, x, wshape, stride, pad, want_db=True, groups=1):
     if groups > 1:
         dt = (L.KPF_DT_BF16 if dy.dtype == torch.bfloat16 else L.KPF_DT_F16) if h16 else L.KPF_DT_F32
         L.check(lib.kpf_conv2d_wgrad_groups(dy.data_ptr(), x.data_ptr(), dt, dw.data_ptr(), db.data_ptr() if want_db else None, ws.data_ptr(), nws, groups,
-                                            B, H, W, Cin, ldx, OH, OW, N, ldy, KH, KW, stride, stride, pad, pad, st), "kpf_conv2d_wgrad_groups")
+                                            B, H, W, Cin, ldx, OH, OW, N, ldy, KH, KW, stride, stride, pad, pad, 0, 0, st), "kpf_conv2d_wgrad_groups")
         return dw, db
     if h16:
         L.check(lib.kpf_conv2d_wgrad_h16(dy.data_ptr(), x.data_ptr(), L.KPF_DT_BF16 if dy.dtype == torch.bfloat16 else L.KPF_DT_F16, dw.data_ptr(),
@@ -1304,10 +1384,32 @@ class Conv2dNHWC(torch.autograd.Function):
         B, H, W, Cin = x.shape
         N, Cw, KH, KW = weight.shape
         cm = 4 if prec == "f32" else 8
-        assert Cw * groups == Cin and Cw % cm == 0, "Conv2dNHWC: input channels must match and be a multiple of 4 (8 for 16-bit)"
         patch = stride == KH == KW and pad == 0 and stride > 1
         use16 = prec != "f32" and w16 is not None
         ctx.groups = groups
+        ctx.odd = None
+        if groups == 1 and KH == 1 and KW == 1 and stride == 1 and pad == 0 and w16 is None and (Cw % cm or N % cm):
+            # A Linear whose widths are not whole channel groups (the 3-d coordinates, 105 pose channels, 131- / 149-wide inputs and 3- / 21-wide
+            # outputs of the fusion head: model/model.py:99-104, 254-262, 336).  The GEMM sees the input at the padded width cpad: x either arrives
+            # padded (a producer that writes the zero channels itself, e.g. kpf_pose_tokens_f32) or is padded here in one launch; the packed
+            # weight rows are zero beyond K already; the output is dense [.., N].  backward pads dY likewise and trims dW / db in the reduce.
+            cpad, npad = (Cw + cm - 1) // cm * cm, (N + cm - 1) // cm * cm
+            assert Cin in (Cw, cpad), "Conv2dNHWC: input width %d matches neither the weight's %d nor its padded width %d" % (Cin, Cw, cpad)
+            tdt = torch.float32 if prec == "f32" else _TDT[prec]
+            xc = pad_rows(x, cpad, tdt) if Cin != cpad else (x.to(tdt).contiguous())
+            if cache is not None and key is not None:
+                pc = cache.get((key, 0), weight, bias, 0, prec, stride=1, pad=0, patchify=False)
+            else:
+                pc = DevPack.packed(weight, bias, 0, prec, stride=1, pad=0, patchify=False)
+            y = _conv_any(_OddPack(pc, cpad), xc, prec)
+            ctx.pack = (key, cache)
+            ctx.odd = (Cin, cpad, npad)
+            ctx.save_for_backward(xc, weight)
+            ctx.w16, ctx.x_dtype = None, x.dtype
+            ctx.conf = (stride, pad, False, bias is not None, prec)
+            ctx.bias_ptr = bias.data_ptr() if bias is not None else None
+            return y
+        assert Cw * groups == Cin and Cw % cm == 0, "Conv2dNHWC: input channels must match and be a multiple of 4 (8 for 16-bit)"
         if groups > 1:
             assert w16 is None and (N // groups) % cm == 0, "grouped Conv2dNHWC: whole channel groups per group"
             patch = False  # (the kx-merging GEMM view of a patchify convolution does not survive channel stacking: general strided form)
@@ -1337,6 +1439,28 @@ class Conv2dNHWC(torch.autograd.Function):
         dx = dw = db = None
         cmul = 4 if prec == "f32" else 8  # channel granularity of the GEMM's activation operand
         G = ctx.groups
+        if ctx.odd is not None:  # odd-width Linear (see forward): x is the padded operand [M, 1, 1, cpad]
+            from . import lib as L
+            cin_given, cpad, npad = ctx.odd
+            Cw = weight.shape[1]
+            tdt = torch.float32 if prec == "f32" else _TDT[prec]
+            dyp = pad_rows(dy, npad, tdt) if npad != N else dy.to(tdt).contiguous()
+            if ctx.needs_input_grad[0]:
+                # dX = dY W: rows of the transposed weight; written at the width the caller's x had (its zero channels receive nothing: a producer
+                # that padded x itself never reads them back — concatenations slice their own columns out)
+                dx = _conv_any(_dgrad_pack(ctx, weight.detach(), 1, prec, pad=0, n_pad=npad), dyp, prec, out_ld=cin_given).view(B, H, W, cin_given).to(ctx.x_dtype)
+            if ctx.needs_input_grad[1]:
+                lib = L.load()
+                want_db = has_bias and ctx.needs_input_grad[2]
+                M = B * H * W
+                nws = lib.kpf_conv2d_wgrad_ws_floats(M, npad, cpad)
+                ws = torch.empty(nws, device=x.device, dtype=torch.float32)
+                dw = torch.empty(tuple(weight.shape), device=x.device, dtype=torch.float32)
+                db = torch.empty(N, device=x.device, dtype=torch.float32) if want_db else None
+                L.check(lib.kpf_conv2d_wgrad_groups(dyp.data_ptr(), x.data_ptr(), _KDT[tdt], dw.data_ptr(), db.data_ptr() if want_db else None, ws.data_ptr(), nws, 1,
+                                                    B, H, W, cpad, cpad, H, W, npad, npad, 1, 1, 1, 1, 0, 0, Cw, N, torch.cuda.current_stream().cuda_stream),
+                        "kpf_conv2d_wgrad_groups")
+            return dx, dw, db, None, None, None, None, None, None, None
         if G > 1:  # channel-stacked groups: the same three GEMMs, one launch each for all groups
             key, cache = ctx.pack
             n, wd = N // G, weight.detach()

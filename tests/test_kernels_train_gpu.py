@@ -864,3 +864,74 @@ def test_paired_backbones_match_the_two_pass_training_graph(prec, monkeypatch):
     assert errs[len(errs) // 2][0] <= (1e-3 if f32 else 3e-2) and errs[-1][0] <= (5e-2 if f32 else 0.3), (errs[len(errs) // 2], errs[-8:])
     for k in b0:
         assert torch.allclose(b0[k].float(), b1[k].float(), rtol=1e-4 if f32 else 2e-2, atol=1e-5 if f32 else 2e-3), k
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("case", [(672, 131, 128, False), (672, 128, 3, False), (32768, 149, 21, True), (32768, 105, 128, True), (1344, 3, 64, True), (50, 7, 5, False)])
+def test_odd_width_linear_matches_torch(case, prec):
+    """Conv2dNHWC's odd-width form (round 4): input / output widths that are not whole channel groups, x given unpadded or already padded by its
+    producer; forward, dX, dW, db against torch on the (rounded) operands."""
+    from keypointfusion_amd import training as T
+    M, K, N, prepadded = case
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(M + K + N)
+    tdt = torch.float32 if prec == "f32" else torch.bfloat16
+    cm = 4 if prec == "f32" else 8
+    x = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    dy = torch.randn(M, N, generator=g).to(dev)
+    rd = lambda t: t.to(tdt).double()
+    xr, wr = rd(x).requires_grad_(True), rd(w).requires_grad_(True)
+    br = b.double().requires_grad_(True)
+    yr = xr @ wr.t() + br
+    yr.backward(rd(dy))
+    xin = x.clone()
+    if prepadded:
+        xin = torch.cat([x, torch.zeros(M, (-K) % cm, device=dev)], 1)
+    xg, wg, bg = xin.requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = T.linear_hip(xg, wg, bg, prec)
+    assert y.shape == (M, N)
+    y.backward(dy.to(y.dtype))
+    tol = 2e-5 if prec == "f32" else 1.5e-2
+    chk = lambda a, r, what: (float((a.double() - r).abs().max()) <= tol * max(float(r.abs().max()), 1.0), what)
+    for ok, what in (chk(y, yr, "y"), chk(xg.grad[:, :K], xr.grad, "dx"), chk(wg.grad, wr.grad, "dw"), chk(bg.grad, br.grad, "db")):
+        assert ok, what
+    assert wg.grad.shape == (N, K) and bg.grad.shape == (N,)
+
+
+def test_pose_tokens_and_geometry_gate_from_uvd_match_torch():
+    from keypointfusion_amd import train_graph as TG
+    from keypointfusion_amd import training as T
+    from keypointfusion_amd import lib as L
+    dev = torch.device("cuda:0")
+    B, N, J, P, S = 3, 257, 21, 1024, 128
+    g = torch.Generator().manual_seed(11)
+    pcl = (torch.rand(B, N, 3, generator=g) * 2 - 1).to(dev)
+    pcl[:, ::7, 2] = 0.995  # (points beyond the depth gate)
+    joint = (torch.rand(B, J, 3, generator=g) * 1.2 - 0.6).to(dev)
+    pw = torch.randn(B, N, J, generator=g).to(dev)
+    ref = torch.cat((pw, TG.TrainGraph.pcl_joint2offset(joint, pcl, 0.8)), -1)
+    out = torch.empty(B, N, 108, device=dev)
+    L.check(L.load().kpf_pose_tokens_f32(pw.data_ptr(), joint.data_ptr(), pcl.data_ptr(), out.data_ptr(), B, N, J, 108, 0.8, torch.cuda.current_stream().cuda_stream), "pose")
+    assert float((out[..., :105] - ref).abs().max()) <= 2e-6 and float(out[..., 105:].abs().max()) == 0.0
+    # geometry gate with the uvd -> xyz map inside the kernel, against the torch expression (TrainGraph.uvd2xyz + GeomGate)
+    ix = (torch.rand(B, P, 3, generator=g) * 2 - 1).to(dev)
+    uvd = (torch.rand(B, J, 3, generator=g) * 1.6 - 0.8).to(dev).requires_grad_(True)
+    center = (torch.tensor([[10.0, -20.0, 600.0]]) + torch.randn(B, 3, generator=g) * 20).to(dev)
+    cube = torch.tensor([[250.0, 250.0, 250.0]]).repeat(B, 1).to(dev)
+    cam = torch.tensor([[615.0, 615.0, 320.0, 240.0]]).repeat(B, 1).to(dev)
+    Minv = (torch.eye(3).view(1, 3, 3) + 0.05 * torch.randn(B, 3, 3, generator=g)).to(dev)
+    Minv[:, :2, 2] += 100.0
+    flip = -1
+    jx = TG.TrainGraph.uvd2xyz(uvd, center, Minv, cube, cam, S, flip)
+    gam_ref = T.GeomGate.apply(ix, jx)
+    dg = torch.randn(B, J, P, generator=g).to(dev)
+    gam_ref.backward(dg)
+    gref = uvd.grad.clone()
+    uvd.grad = None
+    par = torch.cat((Minv.reshape(B, 9)[:, :6], cam, center, cube), 1)
+    gam = T.GeomGateUVD.apply(ix, uvd, par, S, flip)
+    gam.backward(dg)
+    assert float((gam - gam_ref).abs().max()) <= 2e-6
+    assert float((uvd.grad - gref).abs().max()) <= 2e-5 * max(1.0, float(gref.abs().max()))
