@@ -407,6 +407,11 @@ int kpf_attn21_forward(const float* q, const float* k, const float* v, float* ct
                        float scale, float p_drop, const long* rng, int call_id, void* stream);
 int kpf_attn21_backward(const float* dctx, const float* q, const float* k, const float* v, const float* P, const unsigned char* M, float* dq, float* dk,
                         float* dv, int B, int T, int H, int hd, int ld, float scale, float p_drop, void* stream);
+/* The same pair with q / k / v (dq / dk / dv) at row stride ld and ctx (dctx) at its own row stride ldc (ABI 13). */
+int kpf_attn21_forward_ld(const float* q, const float* k, const float* v, float* ctx, float* P, unsigned char* M, int B, int T, int H, int hd, int ld, int ldc,
+                          float scale, float p_drop, const long* rng, int call_id, void* stream);
+int kpf_attn21_backward_ld(const float* dctx, const float* q, const float* k, const float* v, const float* P, const unsigned char* M, float* dq, float* dk,
+                           float* dv, int B, int T, int H, int hd, int ld, int ldc, float scale, float p_drop, void* stream);
 
 /* Training: dX[b] (P x C) = A[b]^T (P x J) @ dOut[b] (J x C) for small J (<= 64; J = 21 joints): the operand gradient of the per-sample
  * products of model/model.py:318-320 and 336-341 (a K = J batched GEMM the library handles badly).  fp32, C % 4 == 0, J * C * 4 B <= 64 KB. */
@@ -464,7 +469,8 @@ typedef struct kpf_pack_desc {
   const void* src;
   void* dst;
   int N, Cin, KH, KW, mode, n_pad, Kp, rows;
-  int src_dtype, dst_dtype, first_block, reserved;
+  int src_dtype, dst_dtype, first_block, reserved; /* reserved (ABI 13): 0, or the destination's row stride in elements when it exceeds Kp (the operand
+                                                      is a column range of a wider stacked matrix); mode 4 (ABI 13): a vector of N elements, rows = 1 */
 } kpf_pack_desc;
 int kpf_pack_conv_weights_multi(const kpf_pack_desc* descs_device, int ndesc, int total_blocks, void* stream);
 
@@ -497,7 +503,7 @@ typedef struct kpf_wgrad_group_desc {
   float* dw;
   float* db;
   int M, N, K, first_block; /* (first_block, sps: set by the call) */
-  int sps, reserved;
+  int sps, ldy;             /* ldy: floats between rows of dy (0 = N; ABI 13: dy may be a column slice of a wider matrix, e.g. one of q | k | v) */
 } kpf_wgrad_group_desc;
 int kpf_linear_wgrad_grouped(const kpf_wgrad_group_desc* descs, int n, void* stream);
 
@@ -523,6 +529,15 @@ int kpf_ln_train_forward_g(const float* x, const float* w, const float* b, void*
                            float eps, void* stream);
 int kpf_ln_train_backward_g(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd, const float* w, float* dx, float* dw,
                             float* db, float* ws, long ws_floats, long rows, int C, int G, kpf_colsum_desc* desc, void* stream);
+
+/* y = LayerNorm(h + dropout(o)) in one launch each way (ABI 13; model/model.py:30-126: dense -> dropout -> residual add -> LayerNorm, both halves of a
+ * BERT layer).  fp32 rows of C (C % 4 == 0, C <= 1024); xs = h + dropout(o) [rows][C], the keep mask [rows][C] bytes (NULL when p_drop == 0) and
+ * mean / rstd [rows] are kept for the backward; rng: the device-resident (seed, counter) pair of kpf_attn21_forward, call_id a per-site constant.
+ * backward: dh = d xs, d_o = d xs * mask / (1 - p), dw / db [C]; ws_floats >= kpf_ln_ws_floats(rows, C); desc as kpf_ln_train_backward_partial. */
+int kpf_drop_add_ln_forward(const float* o, const float* h, const float* w, const float* b, float* xs, float* y, unsigned char* mask, float* mean, float* rstd,
+                            long rows, int C, float eps, float p_drop, const long* rng, int call_id, void* stream);
+int kpf_drop_add_ln_backward(const float* dy, const float* xs, const float* mean, const float* rstd, const float* w, const unsigned char* mask, float* dh,
+                             float* d_o, float* dw, float* db, float* ws, long ws_floats, long rows, int C, float p_drop, kpf_colsum_desc* desc, void* stream);
 /* The layer-scale backward with G parameter sets (same row-view convention as kpf_ln_train_backward_g: rows counts [rows][C] rows of a
  * [rows / G][G*C] tensor, gamma / dgamma hold [G][C]); ws_floats >= kpf_layer_scale_ws_floats(rows, G*C).  The forward needs no twin
  * (kpf_layer_scale_forward with C := G*C). */

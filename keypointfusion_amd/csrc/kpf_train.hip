@@ -453,6 +453,7 @@ __device__ __forceinline__ float pack_value(const TS* __restrict__ w, const kpf_
     const int n = k % d.n_pad, t = k / d.n_pad;
     return (t < T && n < d.N) ? (float)w[((long)n * d.Cin + row) * T + (T - 1 - t)] : 0.f;
   }
+  if (d.mode == 4) return k < d.N ? (float)w[k] : 0.f;  // a vector (bias) copied into a slot of a stacked operand: rows = 1, Kp = slot length
   const int c = row % d.Cin, t = row / d.Cin;
   return k < d.N ? (float)w[((long)k * d.Cin + c) * T + (d.mode == 3 ? T - 1 - t : t)] : 0.f;
 }
@@ -466,6 +467,9 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const kpf_pack_
     else hi = mid - 1;
   }
   const kpf_pack_desc d = descs[lo];
+  // d.reserved != 0: the destination rows are `reserved` elements apart (> Kp) — this operand fills a column range [dst, dst + Kp) of a wider,
+  // stacked matrix (the q | k | v data-gradient operand of training.SelfAttention21); only those Kp columns are written.
+  const long dld = d.reserved ? d.reserved : d.Kp;
   if (d.mode == 1 && d.KH * d.KW == 1 && d.src_dtype == KPF_DT_F32) {
     // 1x1 data-gradient operand = the transpose of the weight: 32 x 32 tiles through LDS, both sides coalesced
     // (blocks of such a descriptor: ceil(rows / 32) * ceil(Kp / 32), see training.PackCache)
@@ -485,7 +489,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const kpf_pack_
       const int c = tr * 32 + y8 + 8 * p, k = tc * 32 + x;  // write dst[c][k = n]: k fastest
       if (c < d.rows && k < d.Kp) {
         const float v = tl[x][y8 + 8 * p];
-        const long i = (long)c * d.Kp + k;
+        const long i = (long)c * dld + k;
         if (d.dst_dtype == KPF_DT_F32) static_cast<float*>(d.dst)[i] = v;
         else if (d.dst_dtype == KPF_DT_BF16) static_cast<bf16_t*>(d.dst)[i] = (bf16_t)v;
         else static_cast<f16_t*>(d.dst)[i] = (f16_t)v;
@@ -500,9 +504,10 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const kpf_pack_
     if (d.src_dtype == KPF_DT_F32) v = pack_value(static_cast<const float*>(d.src), d, row, k);
     else if (d.src_dtype == KPF_DT_BF16) v = pack_value(static_cast<const bf16_t*>(d.src), d, row, k);
     else v = pack_value(static_cast<const f16_t*>(d.src), d, row, k);
-    if (d.dst_dtype == KPF_DT_F32) static_cast<float*>(d.dst)[i] = v;
-    else if (d.dst_dtype == KPF_DT_BF16) static_cast<bf16_t*>(d.dst)[i] = (bf16_t)v;
-    else static_cast<f16_t*>(d.dst)[i] = (f16_t)v;
+    const long o = (long)row * dld + k;
+    if (d.dst_dtype == KPF_DT_F32) static_cast<float*>(d.dst)[o] = v;
+    else if (d.dst_dtype == KPF_DT_BF16) static_cast<bf16_t*>(d.dst)[o] = (bf16_t)v;
+    else static_cast<f16_t*>(d.dst)[o] = (f16_t)v;
   }
 }
 }  // namespace
@@ -859,7 +864,7 @@ __device__ __forceinline__ unsigned hash32(unsigned x) {  // "lowbias32" integer
 
 __global__ __launch_bounds__(64) void attn21_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, float* __restrict__ ctx,
                                                         float* __restrict__ P, unsigned char* __restrict__ M, int H, int ld, float scale, float p_drop,
-                                                        const long* __restrict__ rng, int call_id) {
+                                                        const long* __restrict__ rng, int call_id, int ldc) {
   __shared__ float sq[AT_T][AT_HD + 1], sk[AT_T][AT_HD + 1], sv[AT_T][AT_HD + 1], sp[AT_T][AT_T + 1];
   const int b = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
   const long row0 = (long)b * AT_T;
@@ -911,14 +916,14 @@ __global__ __launch_bounds__(64) void attn21_fwd_kernel(const float* __restrict_
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < AT_T; ++j) s = fmaf(sp[i][j], sv[j][d], s);
-    ctx[(row0 + i) * ld + h * AT_HD + d] = s;
+    ctx[(row0 + i) * ldc + h * AT_HD + d] = s;  // (ldc: the context's own row stride — q / k / v may be column slices of one [rows][3C] projection)
   }
 }
 
 __global__ __launch_bounds__(64) void attn21_bwd_kernel(const float* __restrict__ dctx, const float* __restrict__ q, const float* __restrict__ k,
                                                         const float* __restrict__ v, const float* __restrict__ P, const unsigned char* __restrict__ M,
                                                         float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv, int H, int ld, float scale,
-                                                        float p_drop) {
+                                                        float p_drop, int ldc) {
   __shared__ float sq[AT_T][AT_HD + 1], sk[AT_T][AT_HD + 1], sv[AT_T][AT_HD + 1], sg[AT_T][AT_HD + 1], sp[AT_T][AT_T + 1], sd[AT_T][AT_T + 1];
   const int b = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
   const long row0 = (long)b * AT_T;
@@ -928,7 +933,7 @@ __global__ __launch_bounds__(64) void attn21_bwd_kernel(const float* __restrict_
     sq[t][d] = q[off];
     sk[t][d] = k[off];
     sv[t][d] = v[off];
-    sg[t][d] = dctx[off];
+    sg[t][d] = dctx[(row0 + t) * ldc + h * AT_HD + d];
   }
   const long pbase = (long)blockIdx.x * AT_T * AT_T;
   const float keep_scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
@@ -977,14 +982,30 @@ extern "C" int kpf_attn21_forward(const float* q, const float* k, const float* v
                                   float scale, float p_drop, const long* rng, int call_id, void* stream) {
   KPF_REQUIRE(q && k && v && ctx && P && M && B > 0 && T == AT_T && hd == AT_HD && H > 0 && ld >= H * hd, "kpf_attn21_forward: needs 21 tokens and 32-wide heads");
   KPF_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || rng), "kpf_attn21_forward: dropout needs 0 <= p < 1 and the rng state");
-  hipLaunchKernelGGL(attn21_fwd_kernel, dim3(B * H), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), q, k, v, ctx, P, M, H, ld, scale, p_drop, rng, call_id);
+  hipLaunchKernelGGL(attn21_fwd_kernel, dim3(B * H), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), q, k, v, ctx, P, M, H, ld, scale, p_drop, rng, call_id, ld);
   return kpf_check_launch("kpf_attn21_forward");
+}
+
+/* q / k / v (and dq / dk / dv) with row stride ld, ctx (and dctx) with its own row stride ldc: the three projections as column slices of ONE
+ * [rows][3C] GEMM output (training.SelfAttention21: one projection launch, one data-gradient launch per layer instead of three each). */
+extern "C" int kpf_attn21_forward_ld(const float* q, const float* k, const float* v, float* ctx, float* P, unsigned char* M, int B, int T, int H, int hd, int ld,
+                                     int ldc, float scale, float p_drop, const long* rng, int call_id, void* stream) {
+  KPF_REQUIRE(q && k && v && ctx && P && M && B > 0 && T == AT_T && hd == AT_HD && H > 0 && ld >= H * hd && ldc >= H * hd, "kpf_attn21_forward_ld: needs 21 tokens and 32-wide heads");
+  KPF_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || rng), "kpf_attn21_forward_ld: dropout needs 0 <= p < 1 and the rng state");
+  hipLaunchKernelGGL(attn21_fwd_kernel, dim3(B * H), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), q, k, v, ctx, P, M, H, ld, scale, p_drop, rng, call_id, ldc);
+  return kpf_check_launch("kpf_attn21_forward_ld");
+}
+extern "C" int kpf_attn21_backward_ld(const float* dctx, const float* q, const float* k, const float* v, const float* P, const unsigned char* M, float* dq, float* dk,
+                                      float* dv, int B, int T, int H, int hd, int ld, int ldc, float scale, float p_drop, void* stream) {
+  KPF_REQUIRE(dctx && q && k && v && P && M && dq && dk && dv && B > 0 && T == AT_T && hd == AT_HD && H > 0 && ld >= H * hd && ldc >= H * hd, "kpf_attn21_backward_ld: bad arguments");
+  hipLaunchKernelGGL(attn21_bwd_kernel, dim3(B * H), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), dctx, q, k, v, P, M, dq, dk, dv, H, ld, scale, p_drop, ldc);
+  return kpf_check_launch("kpf_attn21_backward_ld");
 }
 
 extern "C" int kpf_attn21_backward(const float* dctx, const float* q, const float* k, const float* v, const float* P, const unsigned char* M, float* dq, float* dk,
                                    float* dv, int B, int T, int H, int hd, int ld, float scale, float p_drop, void* stream) {
   KPF_REQUIRE(dctx && q && k && v && P && M && dq && dk && dv && B > 0 && T == AT_T && hd == AT_HD && H > 0 && ld >= H * hd, "kpf_attn21_backward: bad arguments");
-  hipLaunchKernelGGL(attn21_bwd_kernel, dim3(B * H), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), dctx, q, k, v, P, M, dq, dk, dv, H, ld, scale, p_drop);
+  hipLaunchKernelGGL(attn21_bwd_kernel, dim3(B * H), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), dctx, q, k, v, P, M, dq, dk, dv, H, ld, scale, p_drop, ld);
   return kpf_check_launch("kpf_attn21_backward");
 }
 
@@ -1796,4 +1817,179 @@ extern "C" int kpf_pose_tokens_f32(const float* pw, const float* joint, const fl
   hipLaunchKernelGGL(pose_tokens_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pw, joint, pcl, out, total, N, J,
                      ld, kernel);
   return kpf_check_launch("kpf_pose_tokens_f32");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round 4: y = LayerNorm(h + dropout(o)) in one launch each way — the tail of both halves of a BERT layer (model/model.py:30-126: dense -> dropout ->
+// residual add -> LayerNorm) and of the decoder layer's feed-forward.  Same wave-per-row arithmetic as ln_fwd_kernel / ln_bwd_kernel on the sum
+// xs = h + dropout(o), which is kept for the backward together with the dropout mask (one byte per element; the mask is drawn from the hash of
+// (seed, counter, call, element) like the attention probabilities').  Backward: d h = LayerNorm's input gradient, d o = the same times the mask.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void drop_add_ln_fwd_kernel(const float* __restrict__ o, const float* __restrict__ h, const float* __restrict__ w,
+                                                              const float* __restrict__ b, float* __restrict__ xs, float* __restrict__ y,
+                                                              unsigned char* __restrict__ mask, float* __restrict__ mean, float* __restrict__ rstd, long rows, int C4,
+                                                              float eps, float p_drop, const long* __restrict__ rng, int call_id) {
+  const int lane = threadIdx.x & 63;
+  const int C = 4 * C4;
+  const float invC = 1.0f / (float)C;
+  const float ks = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+  const unsigned thr = p_drop > 0.f ? (unsigned)fminf(p_drop * 4294967296.0f, 4294967295.0f) : 0u;
+  const unsigned seed = rng ? (unsigned)rng[0] : 0u, ctr = rng ? (unsigned)rng[1] : 0u;
+  const unsigned base = hash32(seed ^ (ctr * 0x9e3779b9U));
+  for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * 4) {
+    f32x4 v[LN_MAXQ];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXQ; ++i) {
+      const int q = lane + 64 * i;
+      v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (q < C4) {
+        const long e0 = r * C + 4 * q;
+        const f32x4 ov = kpf_ld4(o + e0), hv = kpf_ld4(h + e0);
+        unsigned char m[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          m[e] = p_drop > 0.f ? (hash32(base ^ hash32((unsigned)call_id * 0x85ebca6bU + (unsigned)(e0 + e))) >= thr) : 1;
+          v[i][e] = hv[e] + (m[e] ? ov[e] * ks : 0.f);
+        }
+        if (mask) *reinterpret_cast<uchar4*>(mask + e0) = uchar4{m[0], m[1], m[2], m[3]};
+        kpf_st4(xs + e0, v[i]);
+      }
+      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mu = wave_sum(s) * invC;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXQ; ++i)
+      if (lane + 64 * i < C4)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = v[i][e] - mu;
+          sq = fmaf(d, d, sq);
+        }
+    const float rs = 1.0f / sqrtf(wave_sum(sq) * invC + eps);
+    if (lane == 0) {
+      mean[r] = mu;
+      rstd[r] = rs;
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAXQ; ++i) {
+      const int q = lane + 64 * i;
+      if (q < C4) {
+        const f32x4 g = kpf_ld4(w + 4 * q), be = kpf_ld4(b + 4 * q);
+        f32x4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov[e] = (v[i][e] - mu) * rs * g[e] + be[e];
+        kpf_st4(y + r * C + 4 * q, ov);
+      }
+    }
+  }
+}
+
+// ln_bwd_kernel on xs with a second output d o = d xs * mask * keep_scale (mask == nullptr: no dropout, d o = d xs); part as ln_bwd_kernel (G = 1)
+__global__ __launch_bounds__(256) void drop_add_ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, const float* __restrict__ w, const unsigned char* __restrict__ mask,
+                                                              float* __restrict__ dx, float* __restrict__ dov, float* __restrict__ part, long rows, int C4, float ks) {
+  extern __shared__ float ln_lds[];  // [4 waves][2][C]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C = 4 * C4;
+  const float invC = 1.0f / (float)C;
+  f32x4 aw[LN_MAXQ], ab[LN_MAXQ], g[LN_MAXQ];
+#pragma unroll
+  for (int i = 0; i < LN_MAXQ; ++i) {
+    aw[i] = ab[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    g[i] = lane + 64 * i < C4 ? kpf_ld4(w + 4 * (lane + 64 * i)) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+    const float m = mean[r], rs = rstd[r];
+    f32x4 xh[LN_MAXQ], d[LN_MAXQ];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXQ; ++i) {
+      const int q = lane + 64 * i;
+      xh[i] = d[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (q < C4) {
+        const f32x4 xv = kpf_ld4(x + r * C + 4 * q);
+        d[i] = kpf_ld4(dy + r * C + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[i][e] = (xv[e] - m) * rs;
+          const float gd = d[i][e] * g[i][e];
+          s1 += gd;
+          s2 = fmaf(gd, xh[i][e], s2);
+          aw[i][e] = fmaf(d[i][e], xh[i][e], aw[i][e]);
+          ab[i][e] += d[i][e];
+        }
+      }
+    }
+    const float m1 = wave_sum(s1) * invC, m2 = wave_sum(s2) * invC;
+#pragma unroll
+    for (int i = 0; i < LN_MAXQ; ++i) {
+      const int q = lane + 64 * i;
+      if (q < C4) {
+        const long e0 = r * C + 4 * q;
+        f32x4 o, od;
+        uchar4 mk = uchar4{1, 1, 1, 1};
+        if (mask) mk = *reinterpret_cast<const uchar4*>(mask + e0);
+        const unsigned char mm[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = rs * (d[i][e] * g[i][e] - m1 - xh[i][e] * m2);
+          od[e] = mm[e] ? o[e] * ks : 0.f;
+        }
+        kpf_st4(dx + e0, o);
+        kpf_st4(dov + e0, od);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < LN_MAXQ; ++i) {
+    const int q = lane + 64 * i;
+    if (q < C4) {
+      kpf_st4(ln_lds + (wave * 2 + 0) * C + 4 * q, aw[i]);
+      kpf_st4(ln_lds + (wave * 2 + 1) * C + 4 * q, ab[i]);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const int which = i / C, c = i - which * C;
+    float s = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) s += ln_lds[(wv * 2 + which) * C + c];
+    part[((long)blockIdx.x * 2 + which) * C + c] = s;
+  }
+}
+}  // namespace
+
+/* y = LayerNorm(h + dropout(o)) over the last axis (fp32 rows of C, C % 4 == 0, C <= 1024): xs = h + dropout(o) and the keep mask (one byte per
+ * element; may be NULL when p_drop == 0) are kept for the backward; rng = the device-resident (seed, counter) pair of kpf_attn21_forward. */
+extern "C" int kpf_drop_add_ln_forward(const float* o, const float* h, const float* w, const float* b, float* xs, float* y, unsigned char* mask, float* mean,
+                                       float* rstd, long rows, int C, float eps, float p_drop, const long* rng, int call_id, void* stream) {
+  KPF_REQUIRE(o && h && w && b && xs && y && mean && rstd && rows > 0 && C > 0 && C % 4 == 0 && C <= 256 * LN_MAXQ, "kpf_drop_add_ln_forward: bad arguments (C %% 4 == 0, C <= 1024)");
+  KPF_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || (rng && mask)), "kpf_drop_add_ln_forward: dropout needs 0 <= p < 1, the rng state and a mask buffer");
+  hipLaunchKernelGGL(drop_add_ln_fwd_kernel, dim3(grid_for(rows, 4, 256 * 16)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), o, h, w, b, xs, y, mask, mean, rstd,
+                     rows, C / 4, eps, p_drop, rng, call_id);
+  return kpf_check_launch("kpf_drop_add_ln_forward");
+}
+
+/* dh = d xs, d_o = d xs * mask / (1 - p); dw / db as kpf_ln_train_backward (desc != NULL: the column-sum reduce is described, not launched). */
+extern "C" int kpf_drop_add_ln_backward(const float* dy, const float* xs, const float* mean, const float* rstd, const float* w, const unsigned char* mask, float* dh,
+                                        float* d_o, float* dw, float* db, float* ws, long ws_floats, long rows, int C, float p_drop, kpf_colsum_desc* desc,
+                                        void* stream) {
+  KPF_REQUIRE(dy && xs && mean && rstd && w && dh && d_o && dw && db && ws && rows > 0 && C > 0 && C % 4 == 0 && C <= 256 * LN_MAXQ, "kpf_drop_add_ln_backward: bad arguments");
+  KPF_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || mask), "kpf_drop_add_ln_backward: dropout needs the mask");
+  const int nblk = ln_blocks(rows);
+  KPF_REQUIRE(ws_floats >= (long)nblk * 2 * C, "kpf_drop_add_ln_backward: workspace too small");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(drop_add_ln_bwd_kernel, dim3(nblk), dim3(256), (size_t)8 * C * sizeof(float), st, dy, xs, mean, rstd, w, p_drop > 0.f ? mask : nullptr, dh, d_o, ws,
+                     rows, C / 4, p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f);
+  int rc = kpf_check_launch("kpf_drop_add_ln_backward");
+  if (rc != KPF_OK) return rc;
+  if (desc) {
+    desc->part = ws, desc->dw = dw, desc->db = db, desc->nblk = nblk, desc->C = C, desc->first_block = 0, desc->reserved = 0;
+    return KPF_OK;
+  }
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * C + 63) / 64), dim3(512), 0, st, ws, dw, db, nblk, C);
+  return kpf_check_launch("kpf_drop_add_ln_backward (reduce)");
 }

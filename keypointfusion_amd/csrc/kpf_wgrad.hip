@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const WgradGroupBatc
   WgradArgs a;
   a.dy = bp->d[lo].dy, a.x = bp->d[lo].x, a.part = bp->d[lo].dw, a.dbpart = bp->d[lo].db, a.zero = bp->zero;
   a.M = bp->d[lo].M, a.N = bp->d[lo].N, a.K = bp->d[lo].K;
-  a.H = 1, a.W = a.M, a.Cin = a.K, a.ldx = a.K, a.OH = 1, a.OW = a.M, a.ldy = a.N, a.KH = 1, a.KW = 1, a.sh = 1, a.sw = 1, a.ph = 0, a.pw = 0;
+  a.H = 1, a.W = a.M, a.Cin = a.K, a.ldx = a.K, a.OH = 1, a.OW = a.M, a.ldy = bp->d[lo].ldy ? bp->d[lo].ldy : a.N, a.KH = 1, a.KW = 1, a.sh = 1, a.sw = 1, a.ph = 0, a.pw = 0;
   a.groups = 1, a.g_dy = a.g_x = 0, a.g_part = a.g_db = 0;
   a.tilesK = (a.K + 63) / 64;
   a.stages_per_split = (a.M + RB - 1) / RB;
@@ -1089,6 +1089,7 @@ int kpf_linear_wgrad_grouped(const kpf_wgrad_group_desc* descs, int n, void* str
       KPF_REQUIRE(d.dy && d.x && d.dw && d.M > 0 && d.N > 0 && d.K > 0 && d.N % 4 == 0 && d.K % 4 == 0, "kpf_linear_wgrad_grouped: bad descriptor %d (N, K multiples of 4)",
                   base + k);
       KPF_REQUIRE(kpf_aligned16(d.dy) && kpf_aligned16(d.x) && kpf_aligned16(d.dw), "kpf_linear_wgrad_grouped: dy, x, dw must be 16-byte aligned (descriptor %d)", base + k);
+      KPF_REQUIRE(d.ldy == 0 || (d.ldy >= d.N && d.ldy % 4 == 0), "kpf_linear_wgrad_grouped: ldy must be 0 or a multiple of 4 >= N (descriptor %d)", base + k);
       b.d[k].first_block = (int)blocks;
       b.d[k].sps = plan_wgrad(d.M, d.N, d.K, true).sps;  // (the split the per-layer form would use: its summation order is reproduced)
       blocks += (long)((d.N + 63) / 64) * ((d.K + 63) / 64);

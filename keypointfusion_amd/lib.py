@@ -39,7 +39,7 @@ class AdamwDesc(C.Structure):  # kpf_adamw_desc (include/kpf.h)
 
 
 class WgradGroupDesc(C.Structure):  # kpf_wgrad_group_desc (include/kpf.h)
-    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("first_block", C.c_int), ("sps", C.c_int), ("reserved", C.c_int)]
+    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("first_block", C.c_int), ("sps", C.c_int), ("ldy", C.c_int)]
 
 
 class ColsumDesc(C.Structure):  # kpf_colsum_desc (include/kpf.h)
@@ -131,6 +131,8 @@ _SIGS = {
     "kpf_loss_tail_backward": [_P] * 11 + [C.c_int] * 3 + [_P],
     "kpf_layer_scale_forward": [_P, _P, C.c_int, _P, _P, C.c_long, C.c_int, _P],
     "kpf_layer_scale_backward": [_P, _P, C.c_int, _P, _P, _P, _P, C.c_long, C.c_long, C.c_int, _P],
+    "kpf_drop_add_ln_forward": [_P] * 9 + [C.c_long, C.c_int, C.c_float, C.c_float, _P, C.c_int, _P],
+    "kpf_drop_add_ln_backward": [_P] * 11 + [C.c_long, C.c_long, C.c_int, C.c_float, C.c_void_p, _P],
     "kpf_layer_scale_backward_g": [_P, _P, C.c_int, _P, _P, _P, _P, C.c_long, C.c_long, C.c_int, C.c_int, _P],
     "kpf_layer_scale_backward_partial": [_P, _P, C.c_int, _P, _P, _P, _P, C.c_long, C.c_long, C.c_int, C.POINTER(ColsumDesc), _P],
     "kpf_ln_train_backward_partial": [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, C.c_long, C.c_long, C.c_int, C.POINTER(ColsumDesc), _P],
@@ -138,6 +140,8 @@ _SIGS = {
     "kpf_bmm_small_k_dx": [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
     "kpf_attn21_forward": [_P] * 6 + [C.c_int] * 5 + [C.c_float, C.c_float, _P, C.c_int, _P],
     "kpf_attn21_backward": [_P] * 9 + [C.c_int] * 5 + [C.c_float, C.c_float, _P],
+    "kpf_attn21_forward_ld": [_P] * 6 + [C.c_int] * 6 + [C.c_float, C.c_float, _P, C.c_int, _P],
+    "kpf_attn21_backward_ld": [_P] * 9 + [C.c_int] * 6 + [C.c_float, C.c_float, _P],
     "kpf_gelu_backward": [_P, _P, _P, C.c_int, C.c_long, _P],
     "kpf_row_gather_bwd_f32": [_P] * 5 + [C.c_long] + [C.c_int] * 5 + [_P],
 }

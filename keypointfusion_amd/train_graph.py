@@ -33,7 +33,7 @@ import torch.nn.functional as F
 from . import lib as L
 from .engine import _ptr, _stream, crop_inverse
 from .training import (attn21, batchnorm_relu_rows, bmm_small_k, conv2d_nhwc, dwconv7_nhwc, gelu_rows, layer_norm_rows, layer_scale_residual, linear_hip, maxpool3x3s2_nhwc,
-                       pair_params, pair_storage, row_gather, upsample2x_nhwc)
+                       drop_add_ln, pair_params, pair_storage, row_gather, self_attention21, upsample2x_nhwc)
 
 _N_STREAMS = int(os.environ.get("KPF_TRAIN_STREAMS", "2"))  # 2: the RGB backbone (forward and backward) on a side stream (unpaired backbones only)
 # 1 (default): the two ConvNeXt backbones — same architecture, two weight sets, independent until the fusion head (model/model.py:287-306) — run as ONE
@@ -143,13 +143,22 @@ class TrainGraph:
     def attention(self, q, k, v, heads, scale):
         """The 21-token attention core on the HIP kernel; its dropout masks come from the module's device-resident (seed, counter) pair,
         advanced once per forward (so every replay of a captured iteration draws new masks)."""
-        rng = None
-        if self.pd > 0:
-            rng = self.m.__dict__.get("_drop_rng")
-            if rng is None or rng.device != q.device:
-                rng = self.m.__dict__["_drop_rng"] = torch.tensor([torch.initial_seed() & 0x7fffffff, 0], dtype=torch.int64, device=q.device)
         self.attn_calls += 1
-        return attn21(q, k, v, heads, scale, self.pd, rng, self.attn_calls)
+        return attn21(q, k, v, heads, scale, self.pd, self.rng(q.device), self.attn_calls)
+
+    def rng(self, dev):
+        """The module's device-resident (seed, counter) pair behind every HIP dropout mask (None when dropout is off)."""
+        if self.pd <= 0:
+            return None
+        rng = self.m.__dict__.get("_drop_rng")
+        if rng is None or rng.device != dev:
+            rng = self.m.__dict__["_drop_rng"] = torch.tensor([torch.initial_seed() & 0x7fffffff, 0], dtype=torch.int64, device=dev)
+        return rng
+
+    def dropout_add_ln(self, o, h, p_w, p_b, eps):
+        """LayerNorm(h + dropout(o)) as one launch each way (training.DropAddLN)."""
+        self.attn_calls += 1
+        return drop_add_ln(o, h, self.t[p_w], self.t[p_b], eps, self.pd, self.rng(h.device), self.attn_calls)
 
     def drop(self, x):
         return F.dropout(x, self.pd, True) if self.pd > 0 else x
@@ -435,17 +444,17 @@ class TrainGraph:
         B, T, C = h.shape
         hd = C // heads
 
-        def proj(n):
-            return self.linear(h, p + ".attention.self.%s.weight" % n, p + ".attention.self.%s.bias" % n)
-
-        q, k, v = proj("query"), proj("key"), proj("value")
         assert T == 21 and hd == 32, "the fusion head's stacks are 21 tokens x 4 heads x 32 (config/config.json)"
-        ctx = self.attention(q, k, v, heads, 1.0 / math.sqrt(hd))  # one fused launch per layer (heads read in place, dropout on the probabilities inside)
-        o = self.drop(self.linear(ctx, p + ".attention.output.dense.weight", p + ".attention.output.dense.bias"))
-        h1 = self.ln(o + h, p + ".attention.output.LayerNorm.weight", p + ".attention.output.LayerNorm.bias", 1e-12)
+        # q | k | v as one projection, the attention core on its column slices (dropout on the probabilities inside), one data-gradient GEMM back
+        names = tuple(p + ".attention.self.%s.weight" % n for n in ("query", "key", "value"))
+        wb = [self.t[p + ".attention.self.%s.%s" % (n, k)] for n in ("query", "key", "value") for k in ("weight", "bias")]
+        self.attn_calls += 1
+        ctx = self_attention21(h, *wb, names, self.packs, heads, 1.0 / math.sqrt(hd), self.pd, self.rng(h.device), self.attn_calls)
+        o = self.linear(ctx, p + ".attention.output.dense.weight", p + ".attention.output.dense.bias")
+        h1 = self.dropout_add_ln(o, h, p + ".attention.output.LayerNorm.weight", p + ".attention.output.LayerNorm.bias", 1e-12)
         it = self.gelu(self.linear(h1, p + ".intermediate.dense.weight", p + ".intermediate.dense.bias"))
-        o2 = self.drop(self.linear(it, p + ".output.dense.weight", p + ".output.dense.bias"))
-        return self.ln(o2 + h1, p + ".output.LayerNorm.weight", p + ".output.LayerNorm.bias", 1e-12)
+        o2 = self.linear(it, p + ".output.dense.weight", p + ".output.dense.bias")
+        return self.dropout_add_ln(o2, h1, p + ".output.LayerNorm.weight", p + ".output.LayerNorm.bias", 1e-12)
 
     def kp_interaction_tr(self, p, x):
         T = x.shape[1]
@@ -595,6 +604,7 @@ class TrainGraph:
             joint_xyz = r2d
         if torch.is_tensor(self.ball_flips):  # (debug hook only)
             self.m.__dict__["_debug_ball_flips"] = self.ball_flips
+        self.packs.build_table()  # (operands registered by this forward join the one-launch refresh from the next forward on — and a capture that follows)
         if self.nbt:
             torch._foreach_add_(self.nbt, 1)
         if self.pd > 0 and self.m.__dict__.get("_drop_rng") is not None:

@@ -590,6 +590,80 @@ class PackCache:
         pc.b = bias.detach().float().contiguous() if bias is not None else None
         return pc
 
+    def get_stacked(self, names, weights, biases):
+        """q | k | v: three fp32 Linear weights [C, K] (and biases [C]) of the same shape as ONE forward operand [3C][Kp], ONE data-gradient
+        operand [K][3C] and one bias vector [3C] — persistent buffers, each parameter packed into its rows / columns / slot by the refresh launch
+        (kpf_pack_desc::reserved, mode 4).  Returns a StackedPack (attributes of a DevPack with N = 3C; .dgrad = the data-gradient operand)."""
+        from . import lib as L
+        key = ("stack",) + tuple(names)
+        srcs = tuple(t.detach().data_ptr() for t in list(weights) + list(biases))
+        ent = self.entries.get(key + (0, 0))
+        if ent is not None and ent["srcs"] == srcs:
+            return ent["sp"]
+        assert not torch.cuda.is_current_stream_capturing(), "PackCache.get_stacked: register the operand in an eager iteration, before a capture"
+        n, (Cn, K) = len(weights), weights[0].shape
+        dev = weights[0].device
+        assert all(w.shape == (Cn, K) and w.dtype == torch.float32 and w.is_contiguous() for w in weights) and Cn % 32 == 0 and K % 4 == 0
+        kp = (K + 31) // 32 * 32
+        buf0 = torch.zeros(n * Cn, kp, device=dev)
+        buf1 = torch.zeros(K, n * Cn, device=dev)
+        bufb = torch.zeros(n * Cn, device=dev)
+        sp = type("StackedPack", (), {})()
+        sp.KH = sp.KW = sp.sh = sp.sw = sp.merge = 1
+        sp.ph = sp.pw = 0
+        sp.Cin, sp.K, sp.Kp, sp.N, sp.w, sp.w16, sp.b, sp.ps, sp.pt, sp.tuned, sp.split_allowed = K, K, kp, n * Cn, buf0, None, bufb, None, None, {}, False
+        sp.flops = lambda M: 2.0 * M * n * Cn * K
+        dg = type("StackedPack", (), {})()
+        dg.KH = dg.KW = dg.sh = dg.sw = dg.merge = 1
+        dg.ph = dg.pw = 0
+        dg.Cin, dg.K, dg.Kp, dg.N, dg.w, dg.w16, dg.b, dg.ps, dg.pt, dg.tuned, dg.split_allowed = n * Cn, n * Cn, n * Cn, K, buf1, None, None, None, None, {}, False
+        dg.flops = lambda M: 2.0 * M * n * Cn * K
+        sp.dgrad = dg
+        new = []
+        for i, (w, b) in enumerate(zip(weights, biases)):
+            w, b = w.detach(), b.detach()
+            new.append((key + (0, i), {"srcs": srcs, "sp": sp, "keep": w, "desc": (w.data_ptr(), buf0.data_ptr() + i * Cn * kp * 4, Cn, K, 1, 1, 0, Cn, kp, Cn, 0, 0)}))
+            new.append((key + (1, i), {"keep": w, "desc": (w.data_ptr(), buf1.data_ptr() + i * Cn * 4, Cn, K, 1, 1, 1, Cn, Cn, K, 0, 0, n * Cn)}))
+            new.append((key + (4, i), {"keep": b, "desc": (b.data_ptr(), bufb.data_ptr() + i * Cn * 4, Cn, 1, 1, 1, 4, Cn, Cn, 1, 0, 0)}))
+        # fill them now (one launch from a temporary table), then they are part of every refresh
+        arr = (L.PackDesc * len(new))()
+        blk = 0
+        for a, (_, e) in zip(arr, new):
+            d = e["desc"]
+            a.src, a.dst = d[0], d[1]
+            a.N, a.Cin, a.KH, a.KW, a.mode, a.n_pad, a.Kp, a.rows = d[2:10]
+            a.src_dtype, a.dst_dtype, a.first_block, a.reserved = d[10], d[11], blk, (d[12] if len(d) > 12 else 0)
+            blk += ((d[9] + 31) // 32) * ((d[8] + 31) // 32) if (d[6] == 1) else (d[8] * d[9] + 1023) // 1024
+        table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        L.check(L.load().kpf_pack_conv_weights_multi(table.data_ptr(), len(new), blk, torch.cuda.current_stream().cuda_stream), "kpf_pack_conv_weights_multi")
+        sp._table = table  # (alive until the launch has run)
+        for k, e in new:
+            self.entries[k] = e
+        self.dirty = True
+        return sp
+
+    def build_table(self):
+        """(Re)build the device-resident descriptor table when operands were registered since the last one — a host -> device upload, so not
+        inside a graph capture (TrainGraph calls this at the end of every eager forward; a capture then starts with a current table)."""
+        if not self.dirty or not self.entries or torch.cuda.is_current_stream_capturing():
+            return
+        from . import lib as L
+        arr = (L.PackDesc * len(self.entries))()
+        blk = 0
+        for i, ent in enumerate(self.entries.values()):
+            d = ent["desc"]
+            arr[i].src, arr[i].dst = d[0], d[1]
+            arr[i].N, arr[i].Cin, arr[i].KH, arr[i].KW, arr[i].mode, arr[i].n_pad, arr[i].Kp, arr[i].rows = d[2:10]
+            arr[i].src_dtype, arr[i].dst_dtype, arr[i].first_block = d[10], d[11], blk
+            arr[i].reserved = d[12] if len(d) > 12 else 0  # (destination row stride of an operand that is a column range of a stacked matrix)
+            if d[6] == 1 and d[4] * d[5] == 1 and d[10] == 0:  # 1x1 data-gradient operand: 32 x 32 transpose tiles (csrc/kpf_train.hip)
+                blk += ((d[9] + 31) // 32) * ((d[8] + 31) // 32)
+            else:
+                blk += (d[8] * d[9] + 1023) // 1024
+        dev = next(iter(self.entries.values()))["keep"].device
+        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        self.total_blocks, self.dirty = blk, False
+
     def refresh(self):
         """Rewrite every registered operand from the current parameter values (call at the start of a forward)."""
         if not self.entries:
@@ -597,26 +671,15 @@ class PackCache:
         from . import lib as L
         lib = L.load()
         st = torch.cuda.current_stream().cuda_stream
+        self.build_table()
         if self.dirty:
             if torch.cuda.is_current_stream_capturing():  # no host -> device table upload inside a capture: one launch per operand
                 for ent in self.entries.values():
                     d = ent["desc"]
+                    if len(d) > 12 or d[6] == 4:
+                        raise RuntimeError("PackCache: a stacked operand was registered during a graph capture (run one eager iteration first)")
                     L.check(lib.kpf_pack_conv_weight(d[0], d[10], d[1], d[11], d[2], d[3], d[4], d[5], d[6], d[7], d[8], st), "kpf_pack_conv_weight")
                 return
-            arr = (L.PackDesc * len(self.entries))()
-            blk = 0
-            for i, ent in enumerate(self.entries.values()):
-                d = ent["desc"]
-                arr[i].src, arr[i].dst = d[0], d[1]
-                arr[i].N, arr[i].Cin, arr[i].KH, arr[i].KW, arr[i].mode, arr[i].n_pad, arr[i].Kp, arr[i].rows = d[2:10]
-                arr[i].src_dtype, arr[i].dst_dtype, arr[i].first_block = d[10], d[11], blk
-                if d[6] == 1 and d[4] * d[5] == 1 and d[10] == 0:  # 1x1 data-gradient operand: 32 x 32 transpose tiles (csrc/kpf_train.hip)
-                    blk += ((d[9] + 31) // 32) * ((d[8] + 31) // 32)
-                else:
-                    blk += (d[8] * d[9] + 1023) // 1024
-            dev = next(iter(self.entries.values()))["keep"].device
-            self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
-            self.total_blocks, self.dirty = blk, False
         L.check(lib.kpf_pack_conv_weights_multi(self.table.data_ptr(), len(self.entries), self.total_blocks, st), "kpf_pack_conv_weights_multi")
 
 
@@ -811,13 +874,14 @@ class DeferredParamGrads:
               and x.shape[-1] % 4 == 0 and dy.shape[-1] % 4 == 0)
         return g if ok else None
 
-    def add(self, key, dy, x, dw, db, bias_ptr=None):
+    def add(self, key, dy, x, dw, db, bias_ptr=None, ldy=0):
+        """ldy: floats between the rows of dy when it is a column slice of a wider matrix (0: dense)."""
         if key in self.seen:
             raise RuntimeError("DeferredParamGrads: parameter %r receives a second gradient in one backward pass" % (key,))
         self.seen.add(key)
         # (dY, X) stay referenced until flush; of dW / db only the addresses are kept — a second reference would make AccumulateGrad
         # copy the unwritten tensor instead of adopting it
-        self.items.append((key, dy, x, dw.data_ptr(), None if db is None else db.data_ptr(), x.numel() // x.shape[-1], dy.shape[-1], x.shape[-1]))
+        self.items.append((key, dy, x, dw.data_ptr(), None if db is None else db.data_ptr(), x.numel() // x.shape[-1], dy.shape[-1], x.shape[-1], int(ldy)))
         if db is not None:
             self.biases.append((key, bias_ptr, db.data_ptr()))
 
@@ -834,7 +898,7 @@ class DeferredParamGrads:
         # someone else: raise without launching.
         msg = ("DeferredParamGrads: the gradient of %s was copied before it was written (autograd did not adopt the tensor: is the parameter "
                "hooked, referenced twice, or used twice in one forward?); nothing was written")
-        for key, _, _, pw, _, _, _, _ in items:
+        for key, _, _, pw, _, _, _, _, _ in items:
             p = self.named.get(key)
             if p is None or p.grad is None or p.grad.data_ptr() != pw:
                 raise RuntimeError(msg % repr(key))
@@ -849,8 +913,8 @@ class DeferredParamGrads:
         st = torch.cuda.current_stream().cuda_stream
         if items:
             arr = (L.WgradGroupDesc * len(items))()
-            for d, (key, dy, x, pw, pb, M, N, K) in zip(arr, items):
-                d.dy, d.x, d.dw, d.db, d.M, d.N, d.K = dy.data_ptr(), x.data_ptr(), pw, pb, M, N, K
+            for d, (key, dy, x, pw, pb, M, N, K, ldy) in zip(arr, items):
+                d.dy, d.x, d.dw, d.db, d.M, d.N, d.K, d.ldy = dy.data_ptr(), x.data_ptr(), pw, pb, M, N, K, ldy
             L.check(L.load().kpf_linear_wgrad_grouped(arr, len(items), st), "kpf_linear_wgrad_grouped")
         if colsums:
             arr = (L.ColsumDesc * len(colsums))(*[c[0] for c in colsums])
@@ -1203,6 +1267,123 @@ class Attn21(torch.autograd.Function):
 
 def attn21(q, k, v, heads, scale, p_drop=0.0, rng=None, call_id=0):
     return Attn21.apply(q, k, v, heads, scale, p_drop, rng, call_id)
+
+
+class SelfAttention21(torch.autograd.Function):
+    """The self-attention of a BERT layer of the 21-token stacks (model/model.py:30-70) from its input: q | k | v as ONE projection GEMM
+    (N = 3C; the three parameters packed into one operand by PackCache.get_stacked), the attention core reading the three column slices
+    where that GEMM left them (kpf_attn21_forward_ld), and in the backward ONE data-gradient GEMM over [dq | dk | dv].  The three weight /
+    bias gradients join the grouped launch after backward (DeferredParamGrads, dy = a column slice: kpf_wgrad_group_desc::ldy) or take
+    kpf_conv2d_wgrad_f32 with ldy = 3C.  7 launches per layer and direction fewer than three Linears + Attn21, and the input's gradient
+    arrives as one tensor instead of three to add."""
+
+    @staticmethod
+    def forward(ctx, h, wq, bq, wk, bk, wv, bv, names, cache, heads, scale, p_drop, rng, call_id):
+        from . import lib as L
+        B, T, Cc = h.shape
+        M = B * T
+        hc = h.float().contiguous()
+        sp = cache.get_stacked(names, (wq, wk, wv), (bq, bk, bv))
+        qkv = _conv_any(sp, hc.view(M, 1, 1, Cc), "f32").view(M, 3 * Cc)
+        out = torch.empty(B, T, Cc, device=h.device, dtype=torch.float32)
+        P = torch.empty(B, heads, T, T, device=h.device, dtype=torch.float32)
+        Mk = torch.empty(B, heads, T, T, device=h.device, dtype=torch.uint8)
+        q = qkv.data_ptr()
+        L.check(L.load().kpf_attn21_forward_ld(q, q + 4 * Cc, q + 8 * Cc, out.data_ptr(), P.data_ptr(), Mk.data_ptr(), B, T, heads, Cc // heads, 3 * Cc, Cc,
+                                               float(scale), float(p_drop), rng.data_ptr() if rng is not None else None, int(call_id),
+                                               torch.cuda.current_stream().cuda_stream), "kpf_attn21_forward_ld")
+        ctx.save_for_backward(hc, qkv, P, Mk, wq, wk, wv)
+        ctx.conf = (sp, names, cache, heads, float(scale), float(p_drop), tuple(b.data_ptr() for b in (bq, bk, bv)))
+        return out
+
+    @staticmethod
+    def backward(ctx, dctx):
+        from . import lib as L
+        lib = L.load()
+        hc, qkv, P, Mk, wq, wk, wv = ctx.saved_tensors
+        sp, names, cache, heads, scale, p_drop, bias_ptrs = ctx.conf
+        B, T, Cc = hc.shape
+        M = B * T
+        st = torch.cuda.current_stream().cuda_stream
+        dctx = dctx.float().contiguous()
+        dqkv = torch.empty(M, 3 * Cc, device=hc.device, dtype=torch.float32)
+        q, dq = qkv.data_ptr(), dqkv.data_ptr()
+        L.check(lib.kpf_attn21_backward_ld(dctx.data_ptr(), q, q + 4 * Cc, q + 8 * Cc, P.data_ptr(), Mk.data_ptr(), dq, dq + 4 * Cc, dq + 8 * Cc, B, T, heads, Cc // heads,
+                                           3 * Cc, Cc, scale, p_drop, st), "kpf_attn21_backward_ld")
+        dh = _conv_any(sp.dgrad, dqkv.view(M, 1, 1, 3 * Cc), "f32").view(B, T, Cc) if ctx.needs_input_grad[0] else None
+        grads = []
+        for i, (w, name) in enumerate(zip((wq, wk, wv), names)):
+            dyi = dqkv[:, i * Cc:(i + 1) * Cc]
+            grp = DeferredParamGrads.wants(name, cache, dyi, hc, 1, 1, 1, 0)
+            if grp is not None:
+                bp = grp.by_ptr.get(bias_ptrs[i])
+                if bp is None or bp.numel() != Cc or bp.grad is not None:
+                    grp = None
+            dw = torch.empty(tuple(w.shape), device=hc.device, dtype=torch.float32)
+            db = torch.empty(Cc, device=hc.device, dtype=torch.float32)
+            if grp is not None:
+                grp.add(name, dyi, hc, dw, db, bias_ptrs[i], ldy=3 * Cc)
+            else:
+                nws = lib.kpf_conv2d_wgrad_ws_floats(M, Cc, Cc)
+                ws = torch.empty(nws, device=hc.device, dtype=torch.float32)
+                L.check(lib.kpf_conv2d_wgrad_f32(dyi.data_ptr(), hc.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nws, M, 1, 1, Cc, Cc, 1, 1, Cc, 3 * Cc,
+                                                 1, 1, 1, 1, 0, 0, st), "kpf_conv2d_wgrad_f32")
+            grads += [dw, db]
+        return (dh,) + tuple(grads) + (None,) * 7
+
+
+def self_attention21(h, wq, bq, wk, bk, wv, bv, names, cache, heads, scale, p_drop=0.0, rng=None, call_id=0):
+    return SelfAttention21.apply(h, wq, bq, wk, bk, wv, bv, names, cache, heads, scale, p_drop, rng, call_id)
+
+
+class DropAddLN(torch.autograd.Function):
+    """y = LayerNorm(h + dropout(o)) over the last axis, fp32, one launch each way (kpf_drop_add_ln_forward / _backward): the `dense -> dropout ->
+    + residual -> LayerNorm` tail of both halves of a BERT layer (model/model.py:72-126) — the library path is a dropout, an add and the
+    LayerNorm forward, and a dropout backward plus the LayerNorm backward on the way back."""
+
+    @staticmethod
+    def forward(ctx, o, h, weight, bias, eps, p_drop, rng, call_id):
+        from . import lib as L
+        o, h = o.float().contiguous(), h.float().contiguous()
+        Cc = h.shape[-1]
+        rows = h.numel() // Cc
+        y, xs = torch.empty_like(h), torch.empty_like(h)
+        stats = torch.empty(2, rows, device=h.device, dtype=torch.float32)
+        mask = torch.empty(h.shape, device=h.device, dtype=torch.uint8) if p_drop > 0 else None
+        w, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        L.check(L.load().kpf_drop_add_ln_forward(o.data_ptr(), h.data_ptr(), w.data_ptr(), b.data_ptr(), xs.data_ptr(), y.data_ptr(),
+                                                 mask.data_ptr() if mask is not None else None, stats[0].data_ptr(), stats[1].data_ptr(), rows, Cc, float(eps),
+                                                 float(p_drop), rng.data_ptr() if rng is not None else None, int(call_id), torch.cuda.current_stream().cuda_stream),
+                "kpf_drop_add_ln_forward")
+        ctx.save_for_backward(xs, stats, w, mask)
+        ctx.p_drop = float(p_drop)
+        ctx.bias_ptr = b.data_ptr()
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import lib as L
+        lib = L.load()
+        xs, stats, w, mask = ctx.saved_tensors
+        Cc = xs.shape[-1]
+        rows = xs.numel() // Cc
+        dy = dy.float().contiguous()
+        dh, do = torch.empty_like(xs), torch.empty_like(xs)
+        dwb = torch.empty(2, Cc, device=xs.device, dtype=torch.float32)
+        nws = lib.kpf_ln_ws_floats(rows, Cc)
+        ws = torch.empty(nws, device=xs.device, dtype=torch.float32)
+        grp = DeferredParamGrads.wants_colsum(w, ctx.bias_ptr)
+        desc = L.ColsumDesc() if grp is not None else None
+        L.check(lib.kpf_drop_add_ln_backward(dy.data_ptr(), xs.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), w.data_ptr(), mask.data_ptr() if mask is not None else None,
+                                             dh.data_ptr(), do.data_ptr(), dwb[0].data_ptr(), dwb[1].data_ptr(), ws.data_ptr(), nws, rows, Cc, ctx.p_drop,
+                                             C.byref(desc) if desc is not None else None, torch.cuda.current_stream().cuda_stream), "kpf_drop_add_ln_backward")
+        if grp is not None:
+            grp.add_colsum(w, desc, ws, dwb, ctx.bias_ptr, dwb[1].data_ptr())
+        return do, dh, dwb[0], dwb[1], None, None, None, None
+
+
+def drop_add_ln(o, h, weight, bias, eps, p_drop=0.0, rng=None, call_id=0):
+    return DropAddLN.apply(o, h, weight, bias, eps, p_drop, rng, call_id)
 
 
 class BmmSmallK(torch.autograd.Function):
@@ -1619,6 +1800,8 @@ class GraphedTrainStep:
             gc.enable()
 
     def _capture(self, bucket_mb, group):
+        for cache in getattr(self.model, "__dict__", {}).get("_pack_cache", {}).values():
+            cache.build_table()  # (operands the warm-up iterations' backward registered: the capture's refresh is then the one-launch form)
         if self.dist is None:
             with torch.cuda.graph(self.graph):
                 self.loss = self._forward_backward()
