@@ -316,8 +316,9 @@ int kpf_conv2d_wgrad_h16(const void* dy, const void* x, int dtype, float* dw, fl
 
 /* G channel-stacked weight gradients in one launch (ABI 13; the data-parallel twin of kpf_conv_desc::groups): group g multiplies
  * dy[.., g*N + n] (pixel stride ldy >= G*N) with x[.., g*Cin + c] (pixel stride ldx >= G*Cin) and writes dw[g][N][Cin][KH][KW], db[g][N]
- * (db may be NULL).  Same kernels, split and summation order as G separate kpf_conv2d_wgrad_f32 / _h16 calls on the channel slices
- * (bit-identical results); ws_floats >= G * kpf_conv2d_wgrad_ws_floats(M, N, K).  dtype: KPF_DT_F32 / _BF16 / _F16 (both operands). */
+ * (db may be NULL).  Same kernels as G separate kpf_conv2d_wgrad_f32 / _h16 calls on the channel slices; fp32 operands also keep their split and
+ * summation order (bit-identical results), 16-bit operands split the pixel range for 1/G of the chip each (same sums, another order).
+ * ws_floats >= G * kpf_conv2d_wgrad_ws_floats(M, N, K).  dtype: KPF_DT_F32 / _BF16 / _F16 (both operands). */
 int kpf_conv2d_wgrad_groups(const void* dy, const void* x, int dtype, float* dw, float* db, float* ws, long ws_floats, int groups, int B, int H, int W, int Cin,
                             int ldx, int OH, int OW, int N, int ldy, int KH, int KW, int sh, int sw, int ph, int pw, int cin_valid, int n_valid, void* stream);
 /* cin_valid / n_valid (0 = Cin / N): the operands carry zero channels up to whole channel groups (the 3-, 105-, 131-, 149-wide layers of the fusion

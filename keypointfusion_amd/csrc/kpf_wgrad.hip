@@ -912,7 +912,7 @@ Plan plan_wgrad_h16(long M, int N, int K) {
 }
 
 // 64 x 64 tiles of wgrad_h16s_kernel (two 64-KB workgroups per CU): S brings the grid to ~1.5 workgroups per CU, at least two stages each
-Plan plan_wgrad_h16s(long M, int N, int K) {
+Plan plan_wgrad_h16s(long M, int N, int K, int groups = 1) {
   Plan p{};
   p.vn = p.vk = 2;
   p.tilesN = (N + HS_TB - 1) / HS_TB;
@@ -920,8 +920,11 @@ Plan plan_wgrad_h16s(long M, int N, int K) {
   const int total = (int)((M + HS_SP - 1) / HS_SP);
   const int tiles = p.tilesN * p.tilesK;
   static const int target = []() { const char* e = getenv("KPF_WG16S_TARGET"); return e ? atoi(e) : 384; }();  // tuning aid (256 / 384 / 512 / 768: 3.13 / 3.01 / 3.19 / 3.40 ms of GEMM + reduce per iteration)
-  int S = (target + tiles - 1) / tiles;
-  if (tiles >= target / 2) S = 1;  // enough tiles: no split, no reduce launch for a 1x1
+  // (a grouped launch runs `groups` problems side by side: each gets its share of the chip — train128_bf16 with the paired backbones: 18.65 ms per
+  //  iteration with every problem split for the whole chip, 18.36 with the share)
+  const int tgt = target / (groups > 1 ? groups : 1);
+  int S = (tgt + tiles - 1) / tiles;
+  if (tiles >= tgt / 2) S = 1;  // enough tiles: no split, no reduce launch for a 1x1
   const int smax = (total + 1) / 2;
   if (S > smax) S = smax < 1 ? 1 : smax;
   p.sps = (total + S - 1) / S;
@@ -1004,7 +1007,7 @@ static int conv2d_wgrad_impl(const void* dy, const void* x, int dtype, float* dw
   const bool h16 = dtype != KPF_DT_F32 && !h16_widen;
   const bool one = KH == 1 && KW == 1;
   const bool h16s = h16 && h16_form != 128;
-  const Plan p = h16s ? plan_wgrad_h16s(M, N, (int)K) : (h16 ? plan_wgrad_h16(M, N, (int)K) : plan_wgrad(M, N, (int)K, one));
+  const Plan p = h16s ? plan_wgrad_h16s(M, N, (int)K, groups) : (h16 ? plan_wgrad_h16(M, N, (int)K) : plan_wgrad(M, N, (int)K, one));
   const bool direct = one && p.S == 1 && !trimmed;  // the single partial array is dW
   const long wsg = (long)p.S * N * K + (long)p.S * N;  // one group's workspace
   KPF_REQUIRE(ws_floats >= groups * wsg, "kpf_conv2d_wgrad_f32: workspace too small (%ld floats, need %ld)", ws_floats, groups * wsg);

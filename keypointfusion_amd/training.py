@@ -30,6 +30,8 @@ counts, gradient accumulation at fan-outs.
 """
 import ctypes as C
 
+import os
+
 import torch
 import torch.nn.functional as F
 

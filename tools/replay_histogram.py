@@ -10,7 +10,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 marks = [i for i, r in enumerate(rows) if "pack_weights_multi" in r["Kernel_Name"]]
 spans = [(int(rows[b - 1]["End_Timestamp"]) - int(rows[a]["Start_Timestamp"]), a, b) for a, b in zip(marks, marks[1:])]
 print("iterations in the trace (launches, span ms):", [(b - a, round(s / 1e6, 1)) for s, a, b in spans], file=sys.stderr)
-_, a, b = min(spans)  # the shortest one is a graph replay (eager iterations and the capture are slower)
+_, a, b = min(x for x in spans if x[2] - x[1] >= 500)  # the shortest full iteration is a graph replay (eager ones and the capture are slower; short runs are operand registrations)
 it = rows[a:b]
 def short(n):
     n = re.sub(r"\(anonymous namespace\)::", "", n)
