@@ -58,7 +58,8 @@ typedef struct kpf_conv_desc {
                               group g consumes input channels [in_coff + g*Cin, +Cin) of the same pixels, multiplies by the weights at
                               w + g*w_gstride (bias[g*N + n]) and writes output channels [out_coff + g*N, +N): a grouped convolution over
                               channel-stacked activations.  The training step runs the depth and the RGB backbone (same architecture, two weight
-                              sets: model/model.py:287-306) this way; no residual / prologue / NCHW / split operands in a grouped launch. */
+                              sets: model/model.py:287-306) this way; a residual is stacked like the output (res_coff + g*N); no layer scale /
+                              prologue / NCHW / split operands in a grouped launch. */
   long w_gstride;          /* elements between the groups' packed weight matrices (multiple of 4; 8 for 16-bit weights) */
 } kpf_conv_desc;
 

@@ -63,6 +63,7 @@ __device__ __forceinline__ ConvArgs kpf_group_args(const ConvArgs& a0) {
   const int g = blockIdx.y;
   a.in_coff += g * a.g_in;
   a.out_coff += g * a.g_out;
+  a.res_coff += g * a.g_out;  // (a residual, when present, is stacked like the output)
   a.w += (long)g * a.g_w;
   if (a.bias) a.bias += g * a.g_out;
   return a;
@@ -1308,11 +1309,12 @@ extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void
   a.vec = (d->out_ld % 4 == 0 && d->out_coff % 4 == 0 && (!(fl & KPF_RES_ADD) || (d->res_ld % 4 == 0 && d->res_coff % 4 == 0))) ? 1 : 0;
   a.groups = d->groups > 1 ? d->groups : 1; a.g_in = a.g_out = 0; a.g_w = 0;
   if (a.groups > 1) {  // grouped launch: see ConvArgs
-    KPF_REQUIRE(!(fl & (KPF_RES_ADD | KPF_OUT_NCHW)) && !pro_scale && d->w_gstride % 8 == 0 && d->N % 2 == 0,
-                "kpf_conv2d_h16: a grouped launch takes no residual / prologue / NCHW output, and needs w_gstride %% 8 == 0, N %% 2 == 0");
+    KPF_REQUIRE(!(fl & (KPF_RES_GAMMA | KPF_OUT_NCHW)) && !pro_scale && d->w_gstride % 8 == 0 && d->N % 2 == 0,
+                "kpf_conv2d_h16: a grouped launch takes no layer scale / prologue / NCHW output, and needs w_gstride %% 8 == 0, N %% 2 == 0");
     KPF_REQUIRE(d->in_coff + d->groups * d->Cin <= d->in_ld && d->out_coff + d->groups * d->N <= d->out_ld, "kpf_conv2d_h16: the groups' channel slices exceed the pixel stride");
+    KPF_REQUIRE(!(fl & KPF_RES_ADD) || d->res_coff + d->groups * d->N <= d->res_ld, "kpf_conv2d_h16: the groups' residual slices exceed the pixel stride");
     a.g_in = d->Cin / 2; a.g_out = d->N; a.g_w = d->w_gstride / 2;
-    if ((d->out_coff + d->N) % 8) a.vec = 0;  // (the staged epilogue stores 16-byte pieces of every group's slice)
+    if ((d->out_coff + d->N) % 8 || ((fl & KPF_RES_ADD) && (d->res_coff + d->N) % 8)) a.vec = 0;  // (the staged epilogue stores 16-byte pieces of every group's slice)
   }
   {
     static const int dbg = []() { const char* e = getenv("KPF_G8_DBG"); return e ? atoi(e) : 0; }();
@@ -1417,11 +1419,12 @@ extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const flo
   a.vec = (d->out_ld % 4 == 0 && d->out_coff % 4 == 0 && (!(fl & KPF_RES_ADD) || (d->res_ld % 4 == 0 && d->res_coff % 4 == 0))) ? 1 : 0;
   a.groups = d->groups > 1 ? d->groups : 1; a.g_in = a.g_out = 0; a.g_w = 0;
   if (a.groups > 1) {  // grouped launch: see ConvArgs
-    KPF_REQUIRE(!(fl & (KPF_RES_ADD | KPF_OUT_NCHW | KPF_IN_SPLIT | KPF_W_SPLIT | KPF_OUT_SPLIT)) && !pro_scale && d->w_gstride % 4 == 0,
-                "kpf_conv2d_f32: a grouped launch takes no residual / prologue / NCHW output / split operands, and needs w_gstride %% 4 == 0");
+    KPF_REQUIRE(!(fl & (KPF_RES_GAMMA | KPF_OUT_NCHW | KPF_IN_SPLIT | KPF_W_SPLIT | KPF_OUT_SPLIT)) && !pro_scale && d->w_gstride % 4 == 0,
+                "kpf_conv2d_f32: a grouped launch takes no layer scale / prologue / NCHW output / split operands, and needs w_gstride %% 4 == 0");
     KPF_REQUIRE(d->in_coff + d->groups * d->Cin <= d->in_ld && d->out_coff + d->groups * d->N <= d->out_ld, "kpf_conv2d_f32: the groups' channel slices exceed the pixel stride");
+    KPF_REQUIRE(!(fl & KPF_RES_ADD) || d->res_coff + d->groups * d->N <= d->res_ld, "kpf_conv2d_f32: the groups' residual slices exceed the pixel stride");
     a.g_in = d->Cin; a.g_out = d->N; a.g_w = d->w_gstride;
-    if ((d->out_coff + d->N) % 4) a.vec = 0;
+    if ((d->out_coff + d->N) % 4 || ((fl & KPF_RES_ADD) && (d->res_coff + d->N) % 4)) a.vec = 0;
   }
   // the dense-1x1 fast path also needs whole K tiles (its staging reads 32 channels at a time without a K mask)
   const bool is1x1 = d->KH == 1 && d->KW == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0 &&

@@ -168,8 +168,8 @@ class TrainGraph:
     # BatchNorm2d over (B, H, W) is F.batch_norm on the [pixels, C] view, the channels-first LayerNorms of the ConvNeXt stem /
     # downsample layers are F.layer_norm over the last axis (same biased variance, eps inside the root), and the ops that want NCHW
     # (bilinear upsample, max-pool, the few library convolutions) see the same memory as a channels_last view: no layout copies.
-    def conv_l(self, x, p_w, p_b=None, stride=1, pad=0):
-        """NHWC in / out."""
+    def conv_l(self, x, p_w, p_b=None, stride=1, pad=0, res=None):
+        """NHWC in / out.  res: added in the convolution's epilogue (the skip path of a Residual block)."""
         w = self.w(p_w)
         b = self.w(p_b) if p_b is not None else None
         G = self.groups_of(p_w)
@@ -180,7 +180,7 @@ class TrainGraph:
         if cpad:  # the 3- / 1-channel images of the stems: zero channels on both operands (the weight's gradient is sliced back)
             assert G == 1
             x, w = F.pad(x, (0, cpad)), F.pad(w, (0, 0, 0, 0, 0, cpad))
-        return conv2d_nhwc(x.contiguous(), w, b, stride, pad, self.prec, None, None if cpad else self.key_of(p_w), self.packs, G)
+        return conv2d_nhwc(x.contiguous(), w, b, stride, pad, self.prec, None, None if cpad else self.key_of(p_w), self.packs, G, res)
 
     def bn_l(self, x, p, eps=1e-5, relu=False, out16=True, alias=False):
         """BatchNorm2d (batch statistics) [+ ReLU] on NHWC: the HIP kernels for fp32 rows, F.batch_norm otherwise.  alias: returns (y, x')
@@ -211,10 +211,9 @@ class TrainGraph:
         out = self.bn_l(out, p + ".bn2", relu=True)
         out = self.conv_l(out, p + ".conv2.conv.weight", p + ".conv2.conv.bias", pad=1)
         out = self.bn_l(out, p + ".bn3", relu=True)
-        out = self.conv_l(out, p + ".conv3.conv.weight", p + ".conv3.conv.bias")
-        if cin != out.shape[-1] // G:
+        if cin != self.t[("backbone_rgb." + p[len(PAIR):] if p.startswith(PAIR) else p) + ".conv3.conv.weight"].shape[0]:
             x = self.conv_l(x, p + ".skip_layer.conv.weight", p + ".skip_layer.conv.bias")
-        return out + x
+        return self.conv_l(out, p + ".conv3.conv.weight", p + ".conv3.conv.bias", res=x)  # (conv3 + skip: the add rides in the GEMM's epilogue)
 
     def convnext_block(self, p, x):
         y, x = dwconv7_nhwc(x.float(), self.w(p + ".dwconv.weight"), self.w(p + ".dwconv.bias"), self.key_of(p + ".dwconv.weight"), self.packs, True)  # (x: the skip path's handle)

@@ -685,7 +685,7 @@ class PackCache:
         L.check(lib.kpf_pack_conv_weights_multi(self.table.data_ptr(), len(self.entries), self.total_blocks, st), "kpf_pack_conv_weights_multi")
 
 
-def _conv_any(pc, x4, prec, out_ld=None):
+def _conv_any(pc, x4, prec, out_ld=None, res=None):
     """engine.conv (fp32) or engine16.conv16 (bf16 / f16) on an NHWC tensor [B, H, W, C]; returns the NHWC output tensor.  A GroupedPack
     (G convolutions over channel-stacked activations, one launch): x4 is [B, H, W, G*Cin], the result [B, OH, OW, G*N].  out_ld > N: the result
     is [B, OH, OW, out_ld] with only the first N channels written."""
@@ -716,12 +716,16 @@ def _conv_any(pc, x4, prec, out_ld=None):
         xa = Act(xb, B, H, W, pc.Cin, ld=Cc)
         ob = torch.empty(B * OH * OW * G * pc.N, device=x4.device, dtype=xb.dtype)
         oa = Act(ob, B, OH, OW, pc.N, ld=G * pc.N)
-        conv(pc, xa, out=oa) if prec == "f32" else conv16(pc.as16(tdt), xa, kdt, out=oa)
+        ra = None if res is None else Act(res.to(xb.dtype).contiguous().view(-1), B, OH, OW, pc.N, ld=G * pc.N)  # (out = conv + res: the residual epilogue)
+        conv(pc, xa, out=oa, res=ra) if prec == "f32" else conv16(pc.as16(tdt), xa, kdt, out=oa, res=ra)
         return ob.view(B, OH, OW, G * pc.N)
+    ra = None
+    if res is not None:
+        ra = Act(res.to(xb.dtype).contiguous().view(-1), res.shape[0], res.shape[1], res.shape[2], res.shape[3])
     if prec == "f32":
-        out = conv(pc, Act(xb, B, H, W, Cc))
+        out = conv(pc, Act(xb, B, H, W, Cc), res=ra)
     else:
-        out = conv16(pc.as16(tdt), Act(xb, B, H, W, Cc), kdt)
+        out = conv16(pc.as16(tdt), Act(xb, B, H, W, Cc), kdt, res=ra)
     return out.buf.view(out.B, out.H, out.W, out.C)
 
 
@@ -1557,12 +1561,14 @@ class Conv2dNHWC(torch.autograd.Function):
     Linear layers are the 1x1 case on a [rows, 1, 1, K] view."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, prec="f32", w16=None, key=None, cache=None, groups=1):
+    def forward(ctx, x, weight, bias, stride, pad, prec="f32", w16=None, key=None, cache=None, groups=1, res=None):
         """prec "bf16" / "f16": operands rounded to 16 bits, fp32 accumulation on the 16-bit MFMA (kpf_conv2d_h16), 16-bit output;
         the weight stays the fp32 master copy and receives an fp32 gradient.  w16: the weight already rounded to the compute type
         (same shape; TrainGraph casts all of them once per step) — the packs are then built from it without per-layer casts.
         groups = G > 1: G convolutions in one launch each way — x [B, H, W, G*Cin] channel-stacked, weight [G*N, Cin, KH, KW] and bias
-        [G*N] group-major (the paired backbones' parameters: pair_params), output [B, OH, OW, G*N]."""
+        [G*N] group-major (the paired backbones' parameters: pair_params), output [B, OH, OW, G*N].
+        res: a tensor of the output's shape added in the GEMM's epilogue (y = conv(x) + b + res: the skip path of a Residual block,
+        model/hourglass.py:106-119) — one launch less than a separate add; its gradient is dY itself."""
         assert x.is_cuda and x.dim() == 4
         B, H, W, Cin = x.shape
         N, Cw, KH, KW = weight.shape
@@ -1586,6 +1592,7 @@ class Conv2dNHWC(torch.autograd.Function):
                 pc = DevPack.packed(weight, bias, 0, prec, stride=1, pad=0, patchify=False)
             y = _conv_any(_OddPack(pc, cpad), xc, prec)
             ctx.pack = (key, cache)
+            assert res is None
             ctx.odd = (Cin, cpad, npad)
             ctx.save_for_backward(xc, weight)
             ctx.w16, ctx.x_dtype = None, x.dtype
@@ -1603,7 +1610,8 @@ class Conv2dNHWC(torch.autograd.Function):
             pc = DevPack.packed(w16 if use16 else weight, bias, 0, prec, stride=stride, pad=pad, patchify=patch)
         ctx.pack = (key, cache)
         xc = x.float() if prec == "f32" else x.to(_TDT[prec])  # the operand as the GEMM sees it — also what the weight gradient multiplies
-        y = _conv_any(pc, xc, prec)
+        y = _conv_any(pc, xc, prec, res=res)
+        ctx.res_dtype = None if res is None else res.dtype
         ctx.save_for_backward(xc, weight)
         ctx.w16 = w16 if use16 else None
         ctx.x_dtype = x.dtype
@@ -1622,6 +1630,7 @@ class Conv2dNHWC(torch.autograd.Function):
         dx = dw = db = None
         cmul = 4 if prec == "f32" else 8  # channel granularity of the GEMM's activation operand
         G = ctx.groups
+        dres = dy.to(ctx.res_dtype) if (getattr(ctx, "res_dtype", None) is not None and ctx.needs_input_grad[10]) else None
         if ctx.odd is not None:  # odd-width Linear (see forward): x is the padded operand [M, 1, 1, cpad]
             from . import lib as L
             cin_given, cpad, npad = ctx.odd
@@ -1643,7 +1652,7 @@ class Conv2dNHWC(torch.autograd.Function):
                 L.check(lib.kpf_conv2d_wgrad_groups(dyp.data_ptr(), x.data_ptr(), _KDT[tdt], dw.data_ptr(), db.data_ptr() if want_db else None, ws.data_ptr(), nws, 1,
                                                     B, H, W, cpad, cpad, H, W, npad, npad, 1, 1, 1, 1, 0, 0, Cw, N, torch.cuda.current_stream().cuda_stream),
                         "kpf_conv2d_wgrad_groups")
-            return dx, dw, db, None, None, None, None, None, None, None
+            return dx, dw, db, None, None, None, None, None, None, None, None
         if G > 1:  # channel-stacked groups: the same three GEMMs, one launch each for all groups
             key, cache = ctx.pack
             n, wd = N // G, weight.detach()
@@ -1660,7 +1669,7 @@ class Conv2dNHWC(torch.autograd.Function):
                 dx = dx.to(ctx.x_dtype)
             if ctx.needs_input_grad[1]:
                 dw, db = conv_wgrad_hip(dy, x, weight.shape, stride, pad, has_bias and ctx.needs_input_grad[2], groups=G)
-            return dx, dw, db, None, None, None, None, None, None, None
+            return dx, dw, db, None, None, None, None, None, None, None, dres
         if ctx.needs_input_grad[0]:
             wsrc = ctx.w16 if ctx.w16 is not None else weight.detach()
             npad = (N + cmul - 1) // cmul * cmul
@@ -1697,7 +1706,7 @@ class Conv2dNHWC(torch.autograd.Function):
                 grp.add(ctx.pack[0], dyc, xc, dw, db, ctx.bias_ptr if want_db else None)
             else:
                 dw, db = conv_wgrad_hip(dy, x, weight.shape, stride, pad, want_db)
-            return dx, dw, db, None, None, None, None, None, None, None
+            return dx, dw, db, None, None, None, None, None, None, None, dres
         if ctx.needs_input_grad[1]:
             xw = x if prec == "f32" else x.to(_TDT[prec])  # weight gradient in the compute precision, handed to the fp32 master weight
             dyw = dy if prec == "f32" else dy.to(_TDT[prec])
@@ -1707,7 +1716,7 @@ class Conv2dNHWC(torch.autograd.Function):
                 dw = torch.nn.grad.conv2d_weight(xw.permute(0, 3, 1, 2), weight.shape, dyw.permute(0, 3, 1, 2), stride=stride, padding=pad).float()
         if has_bias and ctx.needs_input_grad[2]:
             db = dy.float().view(-1, N).sum(0)
-        return dx, dw, db, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, dres
 
 
 def _dgrad_pack(ctx, wsrc, mode, prec, **kw):
@@ -1717,8 +1726,8 @@ def _dgrad_pack(ctx, wsrc, mode, prec, **kw):
     return DevPack.packed(wsrc, None, mode, prec, **kw)
 
 
-def conv2d_nhwc(x, weight, bias=None, stride=1, pad=0, prec="f32", w16=None, key=None, cache=None, groups=1):
-    return Conv2dNHWC.apply(x, weight, bias, stride, pad, prec, w16, key, cache, groups)
+def conv2d_nhwc(x, weight, bias=None, stride=1, pad=0, prec="f32", w16=None, key=None, cache=None, groups=1, res=None):
+    return Conv2dNHWC.apply(x, weight, bias, stride, pad, prec, w16, key, cache, groups, res)
 
 
 def linear_hip(x, weight, bias=None, prec="f32", w16=None, key=None, cache=None, groups=1):
@@ -1727,7 +1736,7 @@ def linear_hip(x, weight, bias=None, prec="f32", w16=None, key=None, cache=None,
     K = x.shape[-1]
     Kw = weight.shape[-1]
     y = Conv2dNHWC.apply(x.reshape(-1, 1, 1, K), weight.reshape(weight.shape[0], Kw, 1, 1), bias, 1, 0, prec,
-                         w16.reshape(weight.shape[0], Kw, 1, 1) if w16 is not None else None, key, cache, groups)
+                         w16.reshape(weight.shape[0], Kw, 1, 1) if w16 is not None else None, key, cache, groups, None)
     return y.view(*x.shape[:-1], weight.shape[0])
 
 

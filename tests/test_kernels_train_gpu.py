@@ -1016,3 +1016,27 @@ def test_drop_add_ln_matches_torch_with_the_drawn_mask(p):
     yr.backward(dy.double())
     for a, r, what in ((y, yr, "y"), (og.grad, od.grad, "do"), (hgr.grad, hd.grad, "dh"), (wg.grad, wd.grad, "dw"), (bg.grad, bd.grad, "db")):
         assert float((a.double() - r).abs().max()) <= 3e-5 * max(1.0, float(r.abs().max())), what
+
+
+@pytest.mark.parametrize("prec,G", [("f32", 1), ("bf16", 1), ("f32", 2), ("bf16", 2)])
+def test_conv_with_residual_epilogue_matches_conv_plus_add(prec, G):
+    """Conv2dNHWC(res=...): y = conv(x) + b + res in the GEMM's epilogue, the residual's gradient = dY (round 4: Residual.conv3 + skip)."""
+    from keypointfusion_amd import training as T
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    B, H, W, Cin, N = 4, 16, 16, 64, 128
+    tdt = torch.float32 if prec == "f32" else torch.bfloat16
+    x = torch.randn(B, H, W, G * Cin, generator=g).to(dev).to(tdt)
+    r = torch.randn(B, H, W, G * N, generator=g).to(dev).to(tdt)
+    w = (torch.randn(G * N, Cin, 1, 1, generator=g) * Cin ** -0.5).to(dev)
+    b = torch.randn(G * N, generator=g).to(dev)
+    dy = torch.randn(B, H, W, G * N, generator=g).to(dev).to(tdt)
+    outs = []
+    for fused in (True, False):
+        xg, rg, wg, bg = x.clone().requires_grad_(True), r.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = T.conv2d_nhwc(xg, wg, bg, 1, 0, prec, None, None, None, G, rg) if fused else T.conv2d_nhwc(xg, wg, bg, 1, 0, prec, None, None, None, G) + rg
+        y.backward(dy)
+        outs.append((y.detach(), xg.grad, rg.grad, wg.grad, bg.grad))
+    tol = 1e-6 if prec == "f32" else 1e-2  # (bf16: the fused form rounds once, conv + add rounds twice)
+    for a, r_, what in zip(outs[0], outs[1], ("y", "dx", "dres", "dw", "db")):
+        assert float((a.float() - r_.float()).abs().max()) <= tol * max(1.0, float(r_.float().abs().max())), what
