@@ -33,7 +33,7 @@ import torch.nn.functional as F
 from . import lib as L
 from .engine import _ptr, _stream, crop_inverse
 from .training import (attn21, batchnorm_relu_rows, bmm_small_k, conv2d_nhwc, dwconv7_nhwc, gelu_rows, layer_norm_rows, layer_scale_residual, linear_hip, maxpool3x3s2_nhwc,
-                       drop_add_ln, pair_params, pair_storage, row_gather, self_attention21, upsample2x_nhwc)
+                       ball_group, drop_add_ln, pair_params, pair_storage, row_gather, self_attention21, upsample2x_nhwc)
 
 _N_STREAMS = int(os.environ.get("KPF_TRAIN_STREAMS", "2"))  # 2: the RGB backbone (forward and backward) on a side stream (unpaired backbones only)
 # 1 (default): the two ConvNeXt backbones — same architecture, two weight sets, independent until the fusion head (model/model.py:287-306) — run as ONE
@@ -409,24 +409,30 @@ class TrainGraph:
 
     def desa(self, p, pcl_feat, node_feat, pcl_xyz, node_xyz):
         B, Jn, C = node_feat.shape
-        xyz = torch.cat((pcl_xyz, node_xyz), 1)
-        feat = torch.cat((pcl_feat, node_feat), 1)
         outs = []
         assert C == 128, "DESA runs on the model's 128-channel features (model/model.py:166-204)"
-        hip_idx = self.ball_query_hip(pcl_xyz, node_xyz, pcl_feat, node_feat)
+        grouped = None
+        if self.ball_override:  # the debug hook of the gradient-parity tests (given index sets): the op-by-op form below
+            xyz = torch.cat((pcl_xyz, node_xyz), 1)
+            feat = torch.cat((pcl_feat, node_feat), 1)
+            hip_idx = self.ball_query_hip(pcl_xyz, node_xyz, pcl_feat, node_feat)
+        else:  # ball query + grouping + centring + scaling of all three radii: one launch (training.BallGroup)
+            grouped = ball_group(pcl_xyz, node_xyz, pcl_feat, node_feat)
         for i, r in enumerate((0.1, 0.2, 0.4)):
-            idx = hip_idx[i]
-            if self.ball_override:  # debug hook of the gradient-parity tests only (KPFusion._debug_ball_override, see __init__)
-                given = self.ball_override.pop(0).to(idx.device).long()
+            if grouped is not None:
+                gf, gxr = grouped[2 * i], grouped[2 * i + 1]  # [B*J*64, 128] and [B*J*64, 4] = (offsets / r | 0)
+            else:
+                idx = hip_idx[i]
+                given = self.ball_override.pop(0).to(idx.device).long()  # (KPFusion._debug_ball_override, see __init__)
                 self.ball_flips = self.ball_flips + (given != idx).any(-1).sum()  # a device scalar: no host synchronisation here either
-                idx = given
-            flat = idx.reshape(B, Jn * 64)
-            gx = torch.gather(xyz, 1, flat.unsqueeze(-1).expand(-1, -1, 3)).view(B, Jn, 64, 3) - node_xyz.unsqueeze(2)
-            gf = row_gather(feat.float(), flat.int().unsqueeze(-1)).view(B, Jn, 64, C) - node_feat.unsqueeze(2)  # group_points, gather-form backward
+                flat = given.reshape(B, Jn * 64)
+                gx = torch.gather(xyz, 1, flat.unsqueeze(-1).expand(-1, -1, 3)).view(B, Jn, 64, 3) - node_xyz.unsqueeze(2)
+                gf = row_gather(feat.float(), flat.int().unsqueeze(-1)).view(B, Jn, 64, C) - node_feat.unsqueeze(2)  # group_points, gather-form backward
+                gxr = (gx / r).reshape(-1, 3)
             # the three 1x1 Conv2d + BatchNorm2d of a scale (model/model.py:176-192) on rows [B*J*64, .]
             q = lambda name, k: self.t[p + ".%s.%d%s" % (name, i, k)]
 
-            loc = self.bn_l(self.linear_rows((gx / r).reshape(-1, 3), q("conv_l0_blocks", ".weight").flatten(1), q("conv_l0_blocks", ".bias"),
+            loc = self.bn_l(self.linear_rows(gxr, q("conv_l0_blocks", ".weight").flatten(1), q("conv_l0_blocks", ".bias"),
                                              p + ".conv_l0_blocks.%d.weight" % i), p + ".bn_l0_blocks.%d" % i, out16=False)
             ft = self.bn_l(self.linear_rows(gf.reshape(-1, C), q("conv_f0_blocks", ".weight").flatten(1), q("conv_f0_blocks", ".bias"),
                                             p + ".conv_f0_blocks.%d.weight" % i), p + ".bn_f0_blocks.%d" % i, out16=False)

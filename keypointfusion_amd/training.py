@@ -709,7 +709,12 @@ def _conv_any(pc, x4, prec, out_ld=None, res=None):
     if prec != "f32":
         from .engine16 import DTYPES, conv16
         tdt, kdt = DTYPES[prec]
-    xb = (x4 if prec == "f32" else x4.to(tdt)).contiguous().view(-1)
+    xld = Cc
+    if prec == "f32" and G == 1 and H == 1 and W == 1 and x4.dtype == torch.float32 and not x4.is_contiguous() and x4.stride(-1) == 1 and x4.stride(0) % 4 == 0 \
+            and x4.stride(0) > Cc and x4.data_ptr() % 16 == 0:
+        xb, xld = x4, x4.stride(0)  # rows that are a column slice of a wider matrix (BallGroup's outputs): read in place (in_ld), no copy
+    else:
+        xb = (x4 if prec == "f32" else x4.to(tdt)).contiguous().view(-1)
     if G > 1:
         assert Cc == G * pc.Cin and pc.merge == 1, (Cc, G, pc.Cin)
         OH, OW = (H + 2 * pc.ph - pc.KH) // pc.sh + 1, (W + 2 * pc.pw - pc.KW) // pc.sw + 1
@@ -723,7 +728,7 @@ def _conv_any(pc, x4, prec, out_ld=None, res=None):
     if res is not None:
         ra = Act(res.to(xb.dtype).contiguous().view(-1), res.shape[0], res.shape[1], res.shape[2], res.shape[3])
     if prec == "f32":
-        out = conv(pc, Act(xb, B, H, W, Cc), res=ra)
+        out = conv(pc, Act(xb, B, H, W, Cc, ld=xld), res=ra)
     else:
         out = conv16(pc.as16(tdt), Act(xb, B, H, W, Cc), kdt, res=ra)
     return out.buf.view(out.B, out.H, out.W, out.C)
@@ -945,7 +950,11 @@ def conv_wgrad_hip(dy, x, wshape, stride, pad, want_db=True, groups=1):
     h16 = dy.dtype == x.dtype and dy.dtype in (torch.bfloat16, torch.float16) and Cin % 8 == 0 and N % 8 == 0
     if not h16:
         dy, x = dy.float(), x.float()
-    dy, x = dy.contiguous(), x.contiguous()
+    if groups == 1 and H == 1 and W == 1 and not x.is_contiguous() and x.stride(-1) == 1 and x.stride(0) % 4 == 0 and x.stride(0) > Cin and x.data_ptr() % 16 == 0 and not h16:
+        ldx = x.stride(0)  # (rows that are a column slice of a wider matrix: read in place)
+    else:
+        x = x.contiguous()
+    dy = dy.contiguous()
     nws = lib.kpf_conv2d_wgrad_ws_floats(B * OH * OW, N, KH * KW * Cin) * groups
     ws = torch.empty(nws, device=x.device, dtype=torch.float32)
     dw = torch.empty(tuple(wshape), device=x.device, dtype=torch.float32)
@@ -962,7 +971,7 @@ def conv_wgrad_hip(dy, x, wshape, stride, pad, want_db=True, groups=1):
                                          stride, stride, pad, pad, st), "kpf_conv2d_wgrad_h16")
     else:
         L.check(lib.kpf_conv2d_wgrad_f32(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr() if want_db else None, ws.data_ptr(), nws,
-                                         B, H, W, Cin, Cin, OH, OW, N, N, KH, KW, stride, stride, pad, pad, st), "kpf_conv2d_wgrad_f32")
+                                         B, H, W, Cin, ldx, OH, OW, N, N, KH, KW, stride, stride, pad, pad, st), "kpf_conv2d_wgrad_f32")
     return dw, db
 
 
@@ -1491,6 +1500,63 @@ class MaxPool3x3s2NHWC(torch.autograd.Function):
         L.check(L.load().kpf_maxpool3x3s2_bwd(dy.data_ptr(), tap.data_ptr(), dx.data_ptr(), _KDT[dy.dtype], B, H, W, Cc,
                                               torch.cuda.current_stream().cuda_stream), "kpf_maxpool3x3s2_bwd")
         return dx
+
+
+class BallGroup(torch.autograd.Function):
+    """DESA's grouping at its three radii (model/model.py:166-175: ball query around every joint among points + joints, group_points, centre
+    subtraction, offsets / radius) from ONE launch of the inference path's kpf_ball_group_f32.  Returns, per radius, the grouped feature
+    differences [B*J*64, 128] and the scaled offsets [B*J*64, 4] (3 + a zero channel: the width their GEMM reads) — column slices of the kernel's
+    [.., 132]-wide rows, read in place by the Linears — and the index sets.  Gradient towards the point / joint features only (the reference
+    detaches the coordinates): the gather's backward through kpf_row_gather_bwd_f32 (fixed order) minus the group sums for the centres."""
+
+    @staticmethod
+    def forward(ctx, pcl_xyz, node_xyz, pcl_feat, node_feat):
+        from . import lib as L
+        B, N, _ = pcl_xyz.shape
+        Jn, Cc = node_feat.shape[1], node_feat.shape[2]
+        assert Cc == 128
+        dev = pcl_xyz.device
+        X, JF = pcl_feat.detach().float().contiguous(), node_feat.detach().float().contiguous()
+        G = torch.empty(3, B * Jn * 64, Cc + 4, device=dev)
+        idx = torch.empty(3, B * Jn, 64, device=dev, dtype=torch.int32)
+        L.check(L.load().kpf_ball_group_f32(pcl_xyz.detach().float().contiguous().data_ptr(), node_xyz.detach().float().contiguous().data_ptr(), X.data_ptr(),
+                                            JF.data_ptr(), Cc, G.data_ptr(), idx.data_ptr(), B, N, 0.1, 0.2, 0.4, torch.cuda.current_stream().cuda_stream),
+                "kpf_ball_group_f32")
+        ctx.save_for_backward(idx)
+        ctx.shape = (B, N, Jn, Cc)
+        outs = []
+        for i in range(3):
+            outs += [G[i][:, :Cc], G[i][:, Cc:]]
+        ctx.mark_non_differentiable(outs[1], outs[3], outs[5], idx)
+        return tuple(outs) + (idx,)
+
+    @staticmethod
+    def backward(ctx, d0, _a, d1, _b, d2, _c, _d):
+        from . import lib as L
+        lib = L.load()
+        (idx,) = ctx.saved_tensors
+        B, N, Jn, Cc = ctx.shape
+        P, R = N + Jn, Jn * 64
+        st = torch.cuda.current_stream().cuda_stream
+        nws = lib.kpf_row_gather_ws_ints(B, P, R, 1)
+        dsrc = centre = None
+        for i, d in enumerate((d0, d1, d2)):
+            if d is None:
+                continue
+            d = d.float().contiguous()
+            ws = torch.empty(nws, device=d.device, dtype=torch.int32)
+            ds = torch.empty(B, P, Cc, device=d.device, dtype=torch.float32)
+            L.check(lib.kpf_row_gather_bwd_f32(d.data_ptr(), idx[i].data_ptr(), None, ds.data_ptr(), ws.data_ptr(), nws, B, P, R, 1, Cc, st), "kpf_row_gather_bwd_f32")
+            dsrc = ds if dsrc is None else dsrc + ds
+            centre = d if centre is None else centre + d
+        if dsrc is None:
+            return None, None, None, None
+        dnode = dsrc[:, N:] - centre.view(B, Jn, 64, Cc).sum(2)
+        return None, None, dsrc[:, :N], dnode
+
+
+def ball_group(pcl_xyz, node_xyz, pcl_feat, node_feat):
+    return BallGroup.apply(pcl_xyz, node_xyz, pcl_feat, node_feat)
 
 
 class RowGather(torch.autograd.Function):

@@ -1040,3 +1040,36 @@ def test_conv_with_residual_epilogue_matches_conv_plus_add(prec, G):
     tol = 1e-6 if prec == "f32" else 1e-2  # (bf16: the fused form rounds once, conv + add rounds twice)
     for a, r_, what in zip(outs[0], outs[1], ("y", "dx", "dres", "dw", "db")):
         assert float((a.float() - r_.float()).abs().max()) <= tol * max(1.0, float(r_.float().abs().max())), what
+
+
+def test_ball_group_matches_the_op_by_op_grouping_on_its_own_index_sets():
+    """training.BallGroup (round 4): grouped feature differences, scaled offsets and the gradients towards point / joint features against the
+    torch expression of model/model.py:166-175 evaluated on the index sets the kernel chose; and a Linear reading the strided outputs in place."""
+    from keypointfusion_amd import training as T
+    dev = torch.device("cuda:0")
+    B, N, Jn, Cc = 3, 512, 21, 128
+    g = torch.Generator().manual_seed(21)
+    pcl = (torch.rand(B, N, 3, generator=g) * 1.0 - 0.5).to(dev)
+    node = (torch.rand(B, Jn, 3, generator=g) * 0.8 - 0.4).to(dev)
+    pf = torch.randn(B, N, Cc, generator=g).to(dev).requires_grad_(True)
+    nf = torch.randn(B, Jn, Cc, generator=g).to(dev).requires_grad_(True)
+    outs = T.ball_group(pcl, node, pf, nf)
+    idx = outs[6]
+    w = (torch.randn(64, Cc, generator=g) * Cc ** -0.5).to(dev).requires_grad_(True)
+    ys = [T.linear_hip(outs[2 * i], w) for i in range(3)]  # (reads the [.., 132]-strided rows in place, forward and weight gradient)
+    dys = [torch.randn(B * Jn * 64, 64, generator=g).to(dev) for _ in range(3)]
+    torch.autograd.backward(ys, dys)
+    gp, gn, gw = pf.grad.clone(), nf.grad.clone(), w.grad.clone()
+    pf.grad = nf.grad = w.grad = None
+    xyz, feat = torch.cat((pcl, node), 1).double(), torch.cat((pf, nf), 1).double()
+    ref_ys = []
+    for i, r in enumerate((0.1, 0.2, 0.4)):
+        flat = idx[i].view(B, Jn * 64).long()
+        gx = torch.gather(xyz, 1, flat.unsqueeze(-1).expand(-1, -1, 3)).view(B, Jn, 64, 3) - node.double().unsqueeze(2)
+        gf = torch.gather(feat, 1, flat.unsqueeze(-1).expand(-1, -1, Cc)).view(B, Jn, 64, Cc) - nf.double().unsqueeze(2)
+        assert float((outs[2 * i].double() - gf.reshape(-1, Cc)).abs().max()) <= 1e-6
+        assert float((outs[2 * i + 1][:, :3].double() - (gx / r).reshape(-1, 3)).abs().max()) <= 1e-5 and float(outs[2 * i + 1][:, 3].abs().max()) == 0.0
+        ref_ys.append(gf.reshape(-1, Cc) @ w.double().t())
+    torch.autograd.backward(ref_ys, [d.double() for d in dys])
+    for a, r_, what in ((ys[0], ref_ys[0], "y"), (gp, pf.grad, "d point features"), (gn, nf.grad, "d joint features"), (gw, w.grad, "dw")):
+        assert float((a.double() - r_.double()).abs().max()) <= 3e-5 * max(1.0, float(r_.abs().max())), what
