@@ -1524,6 +1524,7 @@ class BallGroup(torch.autograd.Function):
                 "kpf_ball_group_f32")
         ctx.save_for_backward(idx)
         ctx.shape = (B, N, Jn, Cc)
+        ctx.set_materialize_grads(False)  # (no zero tensors for the outputs nothing differentiates: offsets, indices)
         outs = []
         for i in range(3):
             outs += [G[i][:, :Cc], G[i][:, Cc:]]
