@@ -106,7 +106,13 @@ __device__ __forceinline__ float gelu_of(float x) {
   else return gelu_erf(x);
 }
 
-enum { EPI_LIN = 0, EPI_GELU = 1, EPI_RES = 2 };
+enum { EPI_LIN = 0, EPI_GELU = 1, EPI_RES = 2, EPI_GGRAD = 3 };  // EPI_GGRAD (KPF_RES_GELU_GRAD): y = (acc + bias) * gelu'(res) — the data gradient of
+// `Linear(gelu(z))` with respect to z in the GEMM's epilogue (training step; res = z).  A separate epilogue value: the residual epilogues of the inference
+// kernels keep their code and registers.
+__device__ __forceinline__ float gelu_grad_erf(float v) {  // d/dv [v Phi(v)] = Phi(v) + v phi(v)  (csrc/kpf_train.hip gelu_grad: same expression)
+  const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+  return cdf + v * 0.3989422804014327f * __expf(-0.5f * v * v);
+}
 #ifndef STORE4
 #define STORE4(p, v) *reinterpret_cast<f32x4*>(p) = (v)
 #endif
@@ -606,12 +612,13 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
     // 16-bit output without residual, 64-channel wave tiles: the results go through LDS so that the global stores are whole 128-byte
     // rows (a lane's 4 channels are 8 bytes: stored directly, a pixel row would be written in 32-byte pieces by four different
     // instructions — the GELU layers of the 16-bit path write 4C-wide tensors and were bound by exactly that)
-    constexpr bool STAGED = H16 && EPI != EPI_RES && TN == 4;
+    constexpr bool HAS_RES = EPI == EPI_RES || EPI == EPI_GGRAD;  // the epilogue reads a second operand tile
+    constexpr bool STAGED = H16 && !HAS_RES && TN == 4;
     constexpr int RS = TN * 16 + 8;  // staging row stride in elements (144 B: the 8-byte writes of a fragment column spread over the banks)
     TH* stg = reinterpret_cast<TH*>(lds) + wave * (TM * 16) * RS;
     if constexpr (STAGED) __syncthreads();  // every wave is done reading the last K tile: LDS becomes the staging area
-    f32x4 rvv[EPI == EPI_RES ? TM : 1][TN];
-    if (EPI == EPI_RES) {
+    f32x4 rvv[HAS_RES ? TM : 1][TN];
+    if (HAS_RES) {
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const long m = m0 + (wm * TM + j) * 16 + fr;
@@ -640,10 +647,13 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
           for (int e = 0; e < 4; ++e) {
             float y = v[e] + bv[e];
             if (fl & KPF_RES_GAMMA) y *= gv[e];
-            y += rvv[EPI == EPI_RES ? j : 0][i][e];
+            y += rvv[HAS_RES ? j : 0][i][e];
             if (fl & KPF_RELU_AFTER_RES) y = fmaxf(y, 0.f);
             v[e] = y;
           }
+        } else if (EPI == EPI_GGRAD) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (v[e] + bv[e]) * gelu_grad_erf(rvv[HAS_RES ? j : 0][i][e]);
         } else if (EPI == EPI_GELU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = gelu_of<ARITH>(v[e] + bv[e]);
@@ -705,6 +715,10 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
           else y += a.res[(long)m * a.res_ld + a.res_coff + n + e];
           if (fl & KPF_RELU_AFTER_RES) y = fmaxf(y, 0.f);
         }
+        if (EPI == EPI_GGRAD) {
+          if constexpr (H16) y *= gelu_grad_erf((float)reinterpret_cast<const TH*>(a.res)[(long)m * a.res_ld + a.res_coff + n + e]);
+          else y *= gelu_grad_erf(a.res[(long)m * a.res_ld + a.res_coff + n + e]);
+        }
         if (fl & KPF_OUT_NCHW) {
           a.out[((long)b * a.N + n + e) * a.ohow + pix] = y;  // (fp32 also on the 16-bit path: the heads' output)
         } else if constexpr (H16) {
@@ -757,7 +771,7 @@ int launch_one(const ConvArgs& a, hipStream_t st) {
   constexpr int BMR = WHOLE ? (BM + RPP - 1) / RPP * RPP : BM, BNR = WHOLE ? (BN + RPP - 1) / RPP * RPP : BN;
   constexpr bool H16 = ARITH == ARITH_BF16 || ARITH == ARITH_F16;
   size_t lds = (size_t)(NS * (BMR + BNR) * BK + (HAS_PRO ? 2 * a.Kp * (H16 ? 2 : 1) : 0)) * sizeof(float);
-  if (H16 && EPI != EPI_RES && TN == 4) {  // LDS-staged epilogue of the 16-bit path (igemm_body: STAGED)
+  if (H16 && EPI != EPI_RES && EPI != EPI_GGRAD && TN == 4) {  // LDS-staged epilogue of the 16-bit path (igemm_body: STAGED)
     const size_t stg = (size_t)WM * WN * TM * 16 * (TN * 16 + 8) * 2;
     if (stg > lds) lds = stg;
   }
@@ -806,6 +820,14 @@ int launch_arith(ConvArgs& a, bool is1x1, hipStream_t st) {
       return KPF_EINVAL;
     }
     return launch_one<TM, TN, WM, WN, true, false, EPI_GELU, ARITH, NS>(a, st);
+  }
+  if (a.flags & KPF_RES_GELU_GRAD) {
+    if constexpr (ARITH == ARITH_F32 && NS == 2) {
+      if (a.KH == 1 && a.KW == 1 && a.sh == 1 && a.sw == 1)
+        return is1x1 ? launch_one<TM, TN, WM, WN, true, false, EPI_GGRAD, ARITH, NS>(a, st) : launch_one<TM, TN, WM, WN, false, false, EPI_GGRAD, ARITH, NS>(a, st);
+    }
+    kpf_set_error("kpf_conv2d_f32: KPF_RES_GELU_GRAD needs a 1x1 stride-1 convolution in fp32 arithmetic");
+    return KPF_EINVAL;
   }
   if (is1x1) return res ? launch_one<TM, TN, WM, WN, true, false, EPI_RES, ARITH, NS>(a, st) : launch_one<TM, TN, WM, WN, true, false, EPI_LIN, ARITH, NS>(a, st);
   return res ? launch_one<TM, TN, WM, WN, false, false, EPI_RES, ARITH, NS>(a, st) : launch_one<TM, TN, WM, WN, false, false, EPI_LIN, ARITH, NS>(a, st);
@@ -1222,6 +1244,13 @@ int launch_arith_h16(ConvArgs& a, bool fast1x1, bool pointwise, hipStream_t st) 
     }
     return fast1x1 ? launch_one<TM, TN, WM, WN, true, false, EPI_GELU, ARITH, NS>(a, st) : launch_one<TM, TN, WM, WN, false, false, EPI_GELU, ARITH, NS>(a, st);
   }
+  if (a.flags & KPF_RES_GELU_GRAD) {
+    if constexpr (NS == 2) {
+      if (pointwise) return fast1x1 ? launch_one<TM, TN, WM, WN, true, false, EPI_GGRAD, ARITH, NS>(a, st) : launch_one<TM, TN, WM, WN, false, false, EPI_GGRAD, ARITH, NS>(a, st);
+    }
+    kpf_set_error("kpf_conv2d_h16: KPF_RES_GELU_GRAD needs a 1x1 stride-1 convolution on a two-stage tile");
+    return KPF_EINVAL;
+  }
   if (fast1x1) return res ? launch_one<TM, TN, WM, WN, true, false, EPI_RES, ARITH, NS>(a, st) : launch_one<TM, TN, WM, WN, true, false, EPI_LIN, ARITH, NS>(a, st);
   return res ? launch_one<TM, TN, WM, WN, false, false, EPI_RES, ARITH, NS>(a, st) : launch_one<TM, TN, WM, WN, false, false, EPI_LIN, ARITH, NS>(a, st);
 }
@@ -1256,7 +1285,7 @@ static bool g8_preferred(const kpf_conv_desc* d) {
 /* 1 when kpf_conv2d_h16 runs this descriptor on gemm16_8ph_kernel, 0 when on igemm_h16_kernel (profile labels; same rule as the dispatcher) */
 extern "C" int kpf_conv2d_h16_uses_8ph(const kpf_conv_desc* d, int has_prologue) {
   static const bool no8 = getenv("KPF_NO_8PH") != nullptr;
-  return d && !no8 && d->groups <= 1 && g8_applies(d, has_prologue != 0) && g8_preferred(d) ? 1 : 0;
+  return d && !no8 && d->groups <= 1 && !(d->flags & KPF_RES_GELU_GRAD) && g8_applies(d, has_prologue != 0) && g8_preferred(d) ? 1 : 0;
 }
 
 extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void* w, const float* bias, const float* pro_scale,
@@ -1281,6 +1310,7 @@ extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void
   KPF_REQUIRE(((fl & KPF_ACT_RELU) != 0) + ((fl & KPF_ACT_GELU) != 0) + ((fl & KPF_ACT_LEAKY) != 0) <= 1, "kpf_conv2d_h16: one activation only");
   KPF_REQUIRE(!((fl & KPF_RES_ADD) && (fl & (KPF_ACT_RELU | KPF_ACT_GELU | KPF_ACT_LEAKY))), "kpf_conv2d_h16: activation before a residual add is not supported");
   KPF_REQUIRE(!(fl & KPF_RELU_AFTER_RES) || (fl & KPF_RES_ADD), "kpf_conv2d_h16: RELU_AFTER_RES needs RES_ADD");
+  KPF_REQUIRE(!(fl & KPF_RES_GELU_GRAD) || ((fl & KPF_RES_ADD) && !(fl & (KPF_RES_GAMMA | KPF_RELU_AFTER_RES | KPF_OUT_NCHW))), "kpf_conv2d_h16: RES_GELU_GRAD goes with RES_ADD alone");
   KPF_REQUIRE((long)d->B * d->OH * d->OW < (1l << 31) && (long)d->B * d->IH * d->IW < (1l << 31), "kpf_conv2d_h16: too many pixels");
 
   ConvArgs a;  // staging-side fields in 4-byte words (2 elements), output-side fields in elements (see ARITH_BF16 above)
@@ -1337,14 +1367,15 @@ extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void
   }
   if (a.M >= 4096 && a.N >= 256 && a.N % 128 == 0) best = 0;  // (the round model over-rates the narrow tiles at these sizes)
   const bool occ = !(fl & KPF_RES_ADD) && !pro_scale;
-  if ((fl & KPF_RES_ADD) && fast1x1 && a.Kp * 2 >= 2048 && a.M >= 32768 && a.N >= 256 && a.N % 128 == 0) best = 20;
+  const bool plain_res = (fl & KPF_RES_ADD) && !(fl & KPF_RES_GELU_GRAD);  // (the GELU-gradient epilogue exists on the two-stage tiles only)
+  if (plain_res && fast1x1 && a.Kp * 2 >= 2048 && a.M >= 32768 && a.N >= 256 && a.N % 128 == 0) best = 20;
   // 256 x 256 tiles, 8 waves of 128 x 64 (the geometry of cdna_hip_programming's 256^2 template, two-phase loop, s_setprio around the
   // MFMA cluster): +24 % over case 20 on 65536 x 512 x 2048 (841 vs 679 TFLOP/s), 1049 vs 935 on 16384 x 1024 x 4096
-  if ((fl & KPF_RES_ADD) && fast1x1 && a.Kp * 2 >= 2048 && a.M >= 16384 && a.N >= 256 && a.N % 256 == 0) best = 26;
+  if (plain_res && fast1x1 && a.Kp * 2 >= 2048 && a.M >= 16384 && a.N >= 256 && a.N % 256 == 0) best = 26;
   // Round 4: the eight-phase 256 x 256 kernel (gemm16_8ph_kernel) for every dense 1x1 layer it covers with at least one full round of tiles
   const bool ok8 = g8_applies(d, pro_scale != nullptr);
   static const bool no8 = getenv("KPF_NO_8PH") != nullptr;  // tuning aid: A/B against the round-3 tile shapes
-  if (ok8 && !no8 && g8_preferred(d) && a.groups == 1) best = 30;
+  if (ok8 && !no8 && g8_preferred(d) && a.groups == 1 && !(fl & KPF_RES_GELU_GRAD)) best = 30;
   static const int forced = []() { const char* e = getenv("KPF_FORCE_CFG16"); return e ? atoi(e) : -1; }();  // tuning aid only
   if (forced >= 0 && (forced != 30 || ok8)) best = forced;
   if (best == 30) return dtype == KPF_DT_BF16 ? launch_8ph<ARITH_BF16>(a, st) : launch_8ph<ARITH_F16>(a, st);
@@ -1385,6 +1416,7 @@ extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const flo
   KPF_REQUIRE(!((fl & KPF_RES_ADD) && (fl & (KPF_ACT_RELU | KPF_ACT_GELU | KPF_ACT_LEAKY))), "kpf_conv2d_f32: activation before a residual add is not supported");
   KPF_REQUIRE(!((fl & KPF_ACT_LEAKY) && pro_scale), "kpf_conv2d_f32: LeakyReLU is not combined with an operand prologue");
   KPF_REQUIRE(!(fl & KPF_RELU_AFTER_RES) || (fl & KPF_RES_ADD), "kpf_conv2d_f32: RELU_AFTER_RES needs RES_ADD");
+  KPF_REQUIRE(!(fl & KPF_RES_GELU_GRAD) || ((fl & KPF_RES_ADD) && !(fl & (KPF_RES_GAMMA | KPF_RELU_AFTER_RES | KPF_OUT_NCHW))), "kpf_conv2d_f32: RES_GELU_GRAD goes with RES_ADD alone");
   KPF_REQUIRE((long)d->B * d->OH * d->OW < (1l << 31) && (long)d->B * d->IH * d->IW < (1l << 31), "kpf_conv2d_f32: too many pixels");
 
   ConvArgs a;

@@ -685,7 +685,7 @@ class PackCache:
         L.check(lib.kpf_pack_conv_weights_multi(self.table.data_ptr(), len(self.entries), self.total_blocks, st), "kpf_pack_conv_weights_multi")
 
 
-def _conv_any(pc, x4, prec, out_ld=None, res=None):
+def _conv_any(pc, x4, prec, out_ld=None, res=None, flags=0):
     """engine.conv (fp32) or engine16.conv16 (bf16 / f16) on an NHWC tensor [B, H, W, C]; returns the NHWC output tensor.  A GroupedPack
     (G convolutions over channel-stacked activations, one launch): x4 is [B, H, W, G*Cin], the result [B, OH, OW, G*N].  out_ld > N: the result
     is [B, OH, OW, out_ld] with only the first N channels written."""
@@ -722,15 +722,15 @@ def _conv_any(pc, x4, prec, out_ld=None, res=None):
         ob = torch.empty(B * OH * OW * G * pc.N, device=x4.device, dtype=xb.dtype)
         oa = Act(ob, B, OH, OW, pc.N, ld=G * pc.N)
         ra = None if res is None else Act(res.to(xb.dtype).contiguous().view(-1), B, OH, OW, pc.N, ld=G * pc.N)  # (out = conv + res: the residual epilogue)
-        conv(pc, xa, out=oa, res=ra) if prec == "f32" else conv16(pc.as16(tdt), xa, kdt, out=oa, res=ra)
+        conv(pc, xa, out=oa, res=ra, flags=flags) if prec == "f32" else conv16(pc.as16(tdt), xa, kdt, out=oa, res=ra, flags=flags)
         return ob.view(B, OH, OW, G * pc.N)
     ra = None
     if res is not None:
         ra = Act(res.to(xb.dtype).contiguous().view(-1), res.shape[0], res.shape[1], res.shape[2], res.shape[3])
     if prec == "f32":
-        out = conv(pc, Act(xb, B, H, W, Cc, ld=xld), res=ra)
+        out = conv(pc, Act(xb, B, H, W, Cc, ld=xld), res=ra, flags=flags)
     else:
-        out = conv16(pc.as16(tdt), Act(xb, B, H, W, Cc), kdt, res=ra)
+        out = conv16(pc.as16(tdt), Act(xb, B, H, W, Cc), kdt, res=ra, flags=flags)
     return out.buf.view(out.B, out.H, out.W, out.C)
 
 
@@ -1628,14 +1628,17 @@ class Conv2dNHWC(torch.autograd.Function):
     Linear layers are the 1x1 case on a [rows, 1, 1, K] view."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, prec="f32", w16=None, key=None, cache=None, groups=1, res=None):
+    def forward(ctx, x, weight, bias, stride, pad, prec="f32", w16=None, key=None, cache=None, groups=1, res=None, gelu_in=False):
         """prec "bf16" / "f16": operands rounded to 16 bits, fp32 accumulation on the 16-bit MFMA (kpf_conv2d_h16), 16-bit output;
         the weight stays the fp32 master copy and receives an fp32 gradient.  w16: the weight already rounded to the compute type
         (same shape; TrainGraph casts all of them once per step) — the packs are then built from it without per-layer casts.
         groups = G > 1: G convolutions in one launch each way — x [B, H, W, G*Cin] channel-stacked, weight [G*N, Cin, KH, KW] and bias
         [G*N] group-major (the paired backbones' parameters: pair_params), output [B, OH, OW, G*N].
         res: a tensor of the output's shape added in the GEMM's epilogue (y = conv(x) + b + res: the skip path of a Residual block,
-        model/hourglass.py:106-119) — one launch less than a separate add; its gradient is dY itself."""
+        model/hourglass.py:106-119) — one launch less than a separate add; its gradient is dY itself.
+        gelu_in: the layer is Linear(gelu(x)) (pwconv2 of a ConvNeXt block, output.dense of a BERT layer: convNeXT/convnext.py:45-46, model/model.py:
+        97-104) with x the PRE-activation: gelu runs here (kpf_gelu_forward; its output is also what the weight gradient multiplies) and the backward
+        returns d x = (dY W) * gelu'(x) from the data-gradient GEMM's own epilogue (KPF_RES_GELU_GRAD) — no separate GELU-backward pass."""
         assert x.is_cuda and x.dim() == 4
         B, H, W, Cin = x.shape
         N, Cw, KH, KW = weight.shape
@@ -1659,9 +1662,9 @@ class Conv2dNHWC(torch.autograd.Function):
                 pc = DevPack.packed(weight, bias, 0, prec, stride=1, pad=0, patchify=False)
             y = _conv_any(_OddPack(pc, cpad), xc, prec)
             ctx.pack = (key, cache)
-            assert res is None
+            assert res is None and not gelu_in
             ctx.odd = (Cin, cpad, npad)
-            ctx.save_for_backward(xc, weight)
+            ctx.save_for_backward(xc, weight, None)
             ctx.w16, ctx.x_dtype = None, x.dtype
             ctx.conf = (stride, pad, False, bias is not None, prec)
             ctx.bias_ptr = bias.data_ptr() if bias is not None else None
@@ -1677,9 +1680,16 @@ class Conv2dNHWC(torch.autograd.Function):
             pc = DevPack.packed(w16 if use16 else weight, bias, 0, prec, stride=stride, pad=pad, patchify=patch)
         ctx.pack = (key, cache)
         xc = x.float() if prec == "f32" else x.to(_TDT[prec])  # the operand as the GEMM sees it — also what the weight gradient multiplies
+        z = None
+        if gelu_in:
+            from . import lib as L
+            assert KH == 1 and KW == 1 and stride == 1 and pad == 0 and xc.numel() % 4 == 0, "gelu_in: Linear layers"
+            z = xc.contiguous()
+            xc = torch.empty_like(z)
+            L.check(L.load().kpf_gelu_forward(z.data_ptr(), xc.data_ptr(), _KDT[z.dtype], z.numel(), torch.cuda.current_stream().cuda_stream), "kpf_gelu_forward")
         y = _conv_any(pc, xc, prec, res=res)
         ctx.res_dtype = None if res is None else res.dtype
-        ctx.save_for_backward(xc, weight)
+        ctx.save_for_backward(xc, weight, z)
         ctx.w16 = w16 if use16 else None
         ctx.x_dtype = x.dtype
         ctx.conf = (stride, pad, patch, bias is not None, prec)
@@ -1688,8 +1698,10 @@ class Conv2dNHWC(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        x, weight, z = ctx.saved_tensors
         stride, pad, patch, has_bias, prec = ctx.conf
+        from . import lib as L
+        gg = dict(res=z, flags=L.KPF_RES_GELU_GRAD) if z is not None else {}  # (gelu_in: the data gradient's epilogue multiplies by gelu'(z))
         B, H, W, Cin = x.shape
         N, _, KH, KW = weight.shape
         dy = dy.contiguous()
@@ -1719,7 +1731,7 @@ class Conv2dNHWC(torch.autograd.Function):
                 L.check(lib.kpf_conv2d_wgrad_groups(dyp.data_ptr(), x.data_ptr(), _KDT[tdt], dw.data_ptr(), db.data_ptr() if want_db else None, ws.data_ptr(), nws, 1,
                                                     B, H, W, cpad, cpad, H, W, npad, npad, 1, 1, 1, 1, 0, 0, Cw, N, torch.cuda.current_stream().cuda_stream),
                         "kpf_conv2d_wgrad_groups")
-            return dx, dw, db, None, None, None, None, None, None, None, None
+            return dx, dw, db, None, None, None, None, None, None, None, None, None
         if G > 1:  # channel-stacked groups: the same three GEMMs, one launch each for all groups
             key, cache = ctx.pack
             n, wd = N // G, weight.detach()
@@ -1732,11 +1744,11 @@ class Conv2dNHWC(torch.autograd.Function):
                         dx = F.pad(dx, (0, 0, 0, W - dx.shape[2], 0, H - dx.shape[1]))
                 else:
                     assert stride == 1, "grouped Conv2dNHWC: stride 1 or patchify"
-                    dx = _conv_any(_grouped_pack(cache, key, wd, None, G, 1, prec, pad=pad, n_pad=n), dyc, prec).view(B, H, W, Cin)
+                    dx = _conv_any(_grouped_pack(cache, key, wd, None, G, 1, prec, pad=pad, n_pad=n), dyc, prec, **gg).view(B, H, W, Cin)
                 dx = dx.to(ctx.x_dtype)
             if ctx.needs_input_grad[1]:
                 dw, db = conv_wgrad_hip(dy, x, weight.shape, stride, pad, has_bias and ctx.needs_input_grad[2], groups=G)
-            return dx, dw, db, None, None, None, None, None, None, None, dres
+            return dx, dw, db, None, None, None, None, None, None, None, dres, None
         if ctx.needs_input_grad[0]:
             wsrc = ctx.w16 if ctx.w16 is not None else weight.detach()
             npad = (N + cmul - 1) // cmul * cmul
@@ -1755,7 +1767,7 @@ class Conv2dNHWC(torch.autograd.Function):
                     dil = dy_in.new_zeros(B, hz, wz, npad)
                     dil[:, :(OH - 1) * stride + 1:stride, :(OW - 1) * stride + 1:stride] = dy_in
                     dy_in = dil
-                dx = _conv_any(_dgrad_pack(ctx, wsrc, 1, prec, pad=pad, n_pad=npad), dy_in, prec).view(B, H, W, Cin)
+                dx = _conv_any(_dgrad_pack(ctx, wsrc, 1, prec, pad=pad, n_pad=npad), dy_in, prec, **gg).view(B, H, W, Cin)
             dx = dx.to(ctx.x_dtype)
         if ctx.needs_input_grad[1] and Cin % 4 == 0 and N % 4 == 0:
             # hand-written split-K weight gradient (fp32 products and accumulation in every precision mode: the master weight's
@@ -1773,7 +1785,7 @@ class Conv2dNHWC(torch.autograd.Function):
                 grp.add(ctx.pack[0], dyc, xc, dw, db, ctx.bias_ptr if want_db else None)
             else:
                 dw, db = conv_wgrad_hip(dy, x, weight.shape, stride, pad, want_db)
-            return dx, dw, db, None, None, None, None, None, None, None, dres
+            return dx, dw, db, None, None, None, None, None, None, None, dres, None
         if ctx.needs_input_grad[1]:
             xw = x if prec == "f32" else x.to(_TDT[prec])  # weight gradient in the compute precision, handed to the fp32 master weight
             dyw = dy if prec == "f32" else dy.to(_TDT[prec])
@@ -1783,7 +1795,7 @@ class Conv2dNHWC(torch.autograd.Function):
                 dw = torch.nn.grad.conv2d_weight(xw.permute(0, 3, 1, 2), weight.shape, dyw.permute(0, 3, 1, 2), stride=stride, padding=pad).float()
         if has_bias and ctx.needs_input_grad[2]:
             db = dy.float().view(-1, N).sum(0)
-        return dx, dw, db, None, None, None, None, None, None, None, dres
+        return dx, dw, db, None, None, None, None, None, None, None, dres, None
 
 
 def _dgrad_pack(ctx, wsrc, mode, prec, **kw):
@@ -1794,16 +1806,16 @@ def _dgrad_pack(ctx, wsrc, mode, prec, **kw):
 
 
 def conv2d_nhwc(x, weight, bias=None, stride=1, pad=0, prec="f32", w16=None, key=None, cache=None, groups=1, res=None):
-    return Conv2dNHWC.apply(x, weight, bias, stride, pad, prec, w16, key, cache, groups, res)
+    return Conv2dNHWC.apply(x, weight, bias, stride, pad, prec, w16, key, cache, groups, res, False)
 
 
-def linear_hip(x, weight, bias=None, prec="f32", w16=None, key=None, cache=None, groups=1):
+def linear_hip(x, weight, bias=None, prec="f32", w16=None, key=None, cache=None, groups=1, gelu_in=False):
     """nn.Linear on rows [..., K] through the same Function (a 1x1 convolution over a [rows, 1, 1, K] view); groups: see Conv2dNHWC
     (x [..., G*K], weight [G*N, K])."""
     K = x.shape[-1]
     Kw = weight.shape[-1]
     y = Conv2dNHWC.apply(x.reshape(-1, 1, 1, K), weight.reshape(weight.shape[0], Kw, 1, 1), bias, 1, 0, prec,
-                         w16.reshape(weight.shape[0], Kw, 1, 1) if w16 is not None else None, key, cache, groups, None)
+                         w16.reshape(weight.shape[0], Kw, 1, 1) if w16 is not None else None, key, cache, groups, None, gelu_in)
     return y.view(*x.shape[:-1], weight.shape[0])
 
 

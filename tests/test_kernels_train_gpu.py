@@ -1073,3 +1073,31 @@ def test_ball_group_matches_the_op_by_op_grouping_on_its_own_index_sets():
     torch.autograd.backward(ref_ys, [d.double() for d in dys])
     for a, r_, what in ((ys[0], ref_ys[0], "y"), (gp, pf.grad, "d point features"), (gn, nf.grad, "d joint features"), (gw, w.grad, "dw")):
         assert float((a.double() - r_.double()).abs().max()) <= 3e-5 * max(1.0, float(r_.abs().max())), what
+
+
+@pytest.mark.parametrize("prec,G", [("f32", 1), ("bf16", 1), ("bf16", 2), ("f32", 2)])
+def test_linear_of_gelu_with_the_gelu_gradient_in_the_data_gradient_epilogue(prec, G):
+    """Conv2dNHWC(gelu_in=True) (round 4: KPF_RES_GELU_GRAD): y = Linear(gelu(z)), d z = (dY W) * gelu'(z) from the GEMM's epilogue, against
+    gelu_rows + linear_hip (the two-launch form) and, in fp32, against torch."""
+    from keypointfusion_amd import training as T
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(17)
+    M, K, N = 2048, 384, 96
+    tdt = torch.float32 if prec == "f32" else torch.bfloat16
+    z = (1.5 * torch.randn(M, G * K, generator=g)).to(dev).to(tdt)
+    w = (torch.randn(G * N, K, generator=g) * K ** -0.5).to(dev)
+    b = torch.randn(G * N, generator=g).to(dev)
+    dy = torch.randn(M, G * N, generator=g).to(dev).to(tdt)
+    res = []
+    for fused in (True, False):
+        zg, wg, bg = z.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = T.linear_hip(zg, wg, bg, prec, None, None, None, G, True) if fused else T.linear_hip(T.gelu_rows(zg), wg, bg, prec, None, None, None, G)
+        y.backward(dy)
+        res.append((y.detach(), zg.grad, wg.grad, bg.grad))
+    tol = 2e-6 if prec == "f32" else 1e-2  # (bf16: the fused form rounds d z once)
+    for a, r, what in zip(res[0], res[1], ("y", "dz", "dw", "db")):
+        assert float((a.float() - r.float()).abs().max()) <= tol * max(1.0, float(r.float().abs().max())), what
+    if prec == "f32" and G == 1:
+        zr, wr = z.double().requires_grad_(True), w.double().requires_grad_(True)
+        (F.gelu(zr) @ wr.t() + b.double()).backward(dy.double())
+        assert float((res[0][1].double() - zr.grad).abs().max()) <= 2e-5 * float(zr.grad.abs().max())
