@@ -330,6 +330,10 @@ int kpf_conv2d_wgrad_groups(const void* dy, const void* x, int dtype, float* dw,
 /* Row pad / column-slice copy / type change in one launch, and the pose tokens of a fusion block at their padded width (csrc/kpf_train.hip). */
 int kpf_pad_rows(const void* src, int src_dtype, void* dst, int dst_dtype, long rows, int C, int src_ld, int Cp, void* stream);
 int kpf_pose_tokens_f32(const float* pw, const float* joint, const float* pcl, float* out, int B, int N, int J, int ld, float kernel, void* stream);
+/* out = relu(scale * (a + b + c)) (b, c nullable; fp32, n % 4 == 0) and d = out > 0 ? scale * dy : 0 — the gradient of every addend (ABI 13;
+ * model/model.py:190, 417-422). */
+int kpf_add_relu_forward(const float* a, const float* b, const float* c, float* out, long n, float scale, void* stream);
+int kpf_add_relu_backward(const float* dy, const float* out, float* dx, long n, float scale, void* stream);
 /* Depthwise 7x7 (pad 3) + bias alone, y = dwconv(x): the ConvNeXt block's first op with its output kept for the LayerNorm backward,
  * and its data gradient (dx = the same convolution of dy with w_dw's taps mirrored, zero bias).  w_dw [49][C], x != y. */
 int kpf_dwconv7_f32(const float* x, const float* w_dw, const float* b_dw, float* y, int B, int H, int W, int C, void* stream);

@@ -1993,3 +1993,36 @@ extern "C" int kpf_drop_add_ln_backward(const float* dy, const float* xs, const 
   hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * C + 63) / 64), dim3(512), 0, st, ws, dw, db, nblk, C);
   return kpf_check_launch("kpf_drop_add_ln_backward (reduce)");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// out = relu(scale * (a + b [+ c])) and its backward d = (out > 0) ? scale * dy : 0 (the same tensor for every addend): the embedding sums of a
+// fusion block (model/model.py:417-422) and DESA's relu(loc + feat) (model/model.py:190) — two or three library launches each way otherwise.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void add_relu_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c, float* __restrict__ out,
+                                                           long n4, float scale) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    f32x4 v = kpf_ld4(a + 4 * i);
+    if (b) v = v + kpf_ld4(b + 4 * i);
+    if (c) v = v + kpf_ld4(c + 4 * i);
+    kpf_st4(out + 4 * i, f32x4{fmaxf(v[0] * scale, 0.f), fmaxf(v[1] * scale, 0.f), fmaxf(v[2] * scale, 0.f), fmaxf(v[3] * scale, 0.f)});
+  }
+}
+__global__ __launch_bounds__(256) void relu_scale_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ out, float* __restrict__ dx, long n4, float scale) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 g = kpf_ld4(dy + 4 * i), o = kpf_ld4(out + 4 * i);
+    kpf_st4(dx + 4 * i, f32x4{o[0] > 0.f ? g[0] * scale : 0.f, o[1] > 0.f ? g[1] * scale : 0.f, o[2] > 0.f ? g[2] * scale : 0.f, o[3] > 0.f ? g[3] * scale : 0.f});
+  }
+}
+}  // namespace
+
+extern "C" int kpf_add_relu_forward(const float* a, const float* b, const float* c, float* out, long n, float scale, void* stream) {
+  KPF_REQUIRE(a && out && n > 0 && n % 4 == 0 && (b || !c), "kpf_add_relu_forward: bad arguments (n %% 4 == 0; c only with b)");
+  hipLaunchKernelGGL(add_relu_fwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, b, c, out, n / 4, scale);
+  return kpf_check_launch("kpf_add_relu_forward");
+}
+extern "C" int kpf_add_relu_backward(const float* dy, const float* out, float* dx, long n, float scale, void* stream) {
+  KPF_REQUIRE(dy && out && dx && n > 0 && n % 4 == 0, "kpf_add_relu_backward: bad arguments (n %% 4 == 0)");
+  hipLaunchKernelGGL(relu_scale_bwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, out, dx, n / 4, scale);
+  return kpf_check_launch("kpf_add_relu_backward");
+}

@@ -32,7 +32,7 @@ import torch.nn.functional as F
 
 from . import lib as L
 from .engine import _ptr, _stream, crop_inverse
-from .training import (attn21, batchnorm_relu_rows, bmm_small_k, conv2d_nhwc, dwconv7_nhwc, gelu_rows, layer_norm_rows, layer_scale_residual, linear_hip, maxpool3x3s2_nhwc,
+from .training import (add_relu, attn21, batchnorm_relu_rows, bmm_small_k, conv2d_nhwc, dwconv7_nhwc, gelu_rows, layer_norm_rows, layer_scale_residual, linear_hip, maxpool3x3s2_nhwc,
                        ball_group, drop_add_ln, pair_params, pair_storage, row_gather, self_attention21, upsample2x_nhwc)
 
 _N_STREAMS = int(os.environ.get("KPF_TRAIN_STREAMS", "2"))  # 2: the RGB backbone (forward and backward) on a side stream (unpaired backbones only)
@@ -106,7 +106,7 @@ class TrainGraph:
         gradient is one tensor for two parameters)."""
         return ("pair:" + name[len(PAIR):]) if name.startswith(PAIR) else name
 
-    def linear(self, x, p_w, p_b=None, gelu_in=False):
+    def linear(self, x, p_w, p_b=None, gelu_in=False, alias=False):
         w = self.w(p_w)
         b = self.w(p_b) if p_b is not None else None
         G = self.groups_of(p_w)
@@ -114,7 +114,7 @@ class TrainGraph:
         assert G == 1 or (n % self.cmul == 0 and cin % self.cmul == 0), "paired Linear layers have whole channel groups"
         # (odd widths — the 3-wide joint heads, the 131-wide input of final_TR, model/model.py:99-104, 349 — are handled inside Conv2dNHWC: one pad
         #  launch on the activation / output gradient, weight gradient trimmed in its reduce; everything stays on the HIP kernels)
-        return linear_hip(x.contiguous(), w, b, self.prec, None, self.key_of(p_w), self.packs, G, gelu_in)
+        return linear_hip(x.contiguous(), w, b, self.prec, None, self.key_of(p_w), self.packs, G, gelu_in, alias)
 
     def bn(self, x, p, eps=1e-5):
         rm, rv = self.t[p + ".running_mean"], self.t[p + ".running_var"]
@@ -436,7 +436,7 @@ class TrainGraph:
                                              p + ".conv_l0_blocks.%d.weight" % i), p + ".bn_l0_blocks.%d" % i, out16=False)
             ft = self.bn_l(self.linear_rows(gf.reshape(-1, C), q("conv_f0_blocks", ".weight").flatten(1), q("conv_f0_blocks", ".bias"),
                                             p + ".conv_f0_blocks.%d.weight" % i), p + ".bn_f0_blocks.%d" % i, out16=False)
-            g = F.relu(loc + ft)
+            g = add_relu(loc, ft)
             g = self.bn_l(self.linear_rows(g, q("conv_blocks", ".0.weight").flatten(1), q("conv_blocks", ".0.bias"), p + ".conv_blocks.%d.0.weight" % i),
                           p + ".bn_blocks.%d.0" % i, relu=True)
             outs.append(g.view(B, Jn, 64, -1).max(2)[0])  # B x J x 128
@@ -454,10 +454,12 @@ class TrainGraph:
         names = tuple(p + ".attention.self.%s.weight" % n for n in ("query", "key", "value"))
         wb = [self.t[p + ".attention.self.%s.%s" % (n, k)] for n in ("query", "key", "value") for k in ("weight", "bias")]
         self.attn_calls += 1
-        ctx = self_attention21(h, *wb, names, self.packs, heads, 1.0 / math.sqrt(hd), self.pd, self.rng(h.device), self.attn_calls)
+        # (h / h1 reach their residual adds through the aliases the first consumer returns: the residual's gradient is folded into that consumer's
+        #  data-gradient GEMM instead of a separate accumulation launch)
+        ctx, h = self_attention21(h, *wb, names, self.packs, heads, 1.0 / math.sqrt(hd), self.pd, self.rng(h.device), self.attn_calls)
         o = self.linear(ctx, p + ".attention.output.dense.weight", p + ".attention.output.dense.bias")
         h1 = self.dropout_add_ln(o, h, p + ".attention.output.LayerNorm.weight", p + ".attention.output.LayerNorm.bias", 1e-12)
-        it = self.linear(h1, p + ".intermediate.dense.weight", p + ".intermediate.dense.bias")
+        it, h1 = self.linear(h1, p + ".intermediate.dense.weight", p + ".intermediate.dense.bias", alias=True)
         o2 = self.linear(it, p + ".output.dense.weight", p + ".output.dense.bias", gelu_in=True)  # output.dense(gelu(.))
         return self.dropout_add_ln(o2, h1, p + ".output.LayerNorm.weight", p + ".output.LayerNorm.bias", 1e-12)
 
@@ -495,12 +497,11 @@ class TrainGraph:
         pf_rgb = self.gather_interp(img_feat_rgb, idx, clos)
         pw = self.gather_interp(img_offset[:, J * 4:], idx, clos).detach()
         tok = self.pose_tokens(pw, joint_xyz, pcl, 0.8)  # [pw | pcl_joint2offset(joint, pcl) | 0 0 0]: 105 channels at the GEMM's width 108, no gradient
-        x = self.emb1d(p + ".pcl_feat_emb", pf) + self.emb1d(p + ".pcl_xyz_emb", self.pcl4) + self.emb1d(p + ".pcl_pose_emb", tok)
-        x = F.relu(x)
-        x = F.relu(x + self.emb1d(p + ".pcl_feat_emb_RGB", pf_rgb))
+        x = add_relu(self.emb1d(p + ".pcl_feat_emb", pf), self.emb1d(p + ".pcl_xyz_emb", self.pcl4), self.emb1d(p + ".pcl_pose_emb", tok))
+        x = add_relu(x, self.emb1d(p + ".pcl_feat_emb_RGB", pf_rgb))
         att = F.softmax(pw.permute(0, 2, 1), -1)
         jf = bmm_small_k(att, x)
-        jf = F.relu(self.emb1d(p + ".joint_feat_emb", jf) + self.emb1d(p + ".joint_xyz_emb", joint_xyz.detach()))
+        jf = add_relu(self.emb1d(p + ".joint_feat_emb", jf), self.emb1d(p + ".joint_xyz_emb", joint_xyz.detach()))
         jf = self.desa(p + ".FA", x, jf, pcl, joint_xyz.detach())
         h_init, r3d = self.kp_interaction_tr(p + ".init_TR", jf)
         r3d = r3d.float()  # geometry, heat map and the returned joints are fp32 in every precision
@@ -524,7 +525,7 @@ class TrainGraph:
         gw = g.reshape(B, J, H * W) * wsp
         fj = bmm_small_k(gw, frows) + self.t[p + ".fc_spatial2joint_feature.bias"]
         if prev_feat is not None:
-            fj = F.relu((fj + prev_feat) / 2)
+            fj = add_relu(fj, prev_feat, scale=0.5)
         dec = self.decoder_layer(p + ".crossTR.decoder.3", fj, h_init)
         _, r2d = self.kp_interaction_tr(p + ".final_TR", torch.cat([r3d, dec.float()], 2))
         return r3d, r2d.float(), fj, sw.float()

@@ -1309,13 +1309,18 @@ class SelfAttention21(torch.autograd.Function):
                                                torch.cuda.current_stream().cuda_stream), "kpf_attn21_forward_ld")
         ctx.save_for_backward(hc, qkv, P, Mk, wq, wk, wv)
         ctx.conf = (sp, names, cache, heads, float(scale), float(p_drop), tuple(b.data_ptr() for b in (bq, bk, bv)))
-        return out
+        ctx.set_materialize_grads(False)
+        # second output: h itself, for the residual path of the layer (LayerNorm(h + ...)) — routed through this alias, the residual's gradient arrives in
+        # THIS backward and rides in the data-gradient GEMM's residual epilogue instead of a separate accumulation launch (the BatchNormReLU / DwConv7 trick)
+        return out, hc.view(B, T, Cc)
 
     @staticmethod
-    def backward(ctx, dctx):
+    def backward(ctx, dctx, g_alias=None):
         from . import lib as L
         lib = L.load()
         hc, qkv, P, Mk, wq, wk, wv = ctx.saved_tensors
+        if dctx is None:  # (only the alias was used)
+            return (g_alias,) + (None,) * 13
         sp, names, cache, heads, scale, p_drop, bias_ptrs = ctx.conf
         B, T, Cc = hc.shape
         M = B * T
@@ -1325,7 +1330,10 @@ class SelfAttention21(torch.autograd.Function):
         q, dq = qkv.data_ptr(), dqkv.data_ptr()
         L.check(lib.kpf_attn21_backward_ld(dctx.data_ptr(), q, q + 4 * Cc, q + 8 * Cc, P.data_ptr(), Mk.data_ptr(), dq, dq + 4 * Cc, dq + 8 * Cc, B, T, heads, Cc // heads,
                                            3 * Cc, Cc, scale, p_drop, st), "kpf_attn21_backward_ld")
-        dh = _conv_any(sp.dgrad, dqkv.view(M, 1, 1, 3 * Cc), "f32").view(B, T, Cc) if ctx.needs_input_grad[0] else None
+        dh = None
+        if ctx.needs_input_grad[0]:
+            ga = None if g_alias is None else g_alias.float().contiguous().view(M, 1, 1, Cc)
+            dh = _conv_any(sp.dgrad, dqkv.view(M, 1, 1, 3 * Cc), "f32", res=ga).view(B, T, Cc)  # (+ the residual path's gradient, in the epilogue)
         grads = []
         for i, (w, name) in enumerate(zip((wq, wk, wv), names)):
             dyi = dqkv[:, i * Cc:(i + 1) * Cc]
@@ -1348,6 +1356,7 @@ class SelfAttention21(torch.autograd.Function):
 
 
 def self_attention21(h, wq, bq, wk, bk, wv, bv, names, cache, heads, scale, p_drop=0.0, rng=None, call_id=0):
+    """-> (context, h_alias): feed h_alias (== h) to the residual path of the layer, see SelfAttention21.forward."""
     return SelfAttention21.apply(h, wq, bq, wk, bk, wv, bv, names, cache, heads, scale, p_drop, rng, call_id)
 
 
@@ -1399,6 +1408,37 @@ class DropAddLN(torch.autograd.Function):
 
 def drop_add_ln(o, h, weight, bias, eps, p_drop=0.0, rng=None, call_id=0):
     return DropAddLN.apply(o, h, weight, bias, eps, p_drop, rng, call_id)
+
+
+class AddRelu(torch.autograd.Function):
+    """relu(scale * (a + b [+ c])) on fp32 tensors of one shape, one launch each way (kpf_add_relu_forward / _backward); every addend receives the
+    same gradient tensor."""
+
+    @staticmethod
+    def forward(ctx, scale, a, b=None, c=None):
+        from . import lib as L
+        ts = [t.float().contiguous() for t in (a, b, c) if t is not None]
+        assert all(t.shape == ts[0].shape for t in ts) and ts[0].numel() % 4 == 0
+        out = torch.empty_like(ts[0])
+        L.check(L.load().kpf_add_relu_forward(ts[0].data_ptr(), ts[1].data_ptr() if len(ts) > 1 else None, ts[2].data_ptr() if len(ts) > 2 else None, out.data_ptr(),
+                                              out.numel(), float(scale), torch.cuda.current_stream().cuda_stream), "kpf_add_relu_forward")
+        ctx.save_for_backward(out)
+        ctx.conf = (float(scale), len(ts))
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import lib as L
+        (out,) = ctx.saved_tensors
+        scale, n = ctx.conf
+        dy = dy.float().contiguous()
+        dx = torch.empty_like(out)
+        L.check(L.load().kpf_add_relu_backward(dy.data_ptr(), out.data_ptr(), dx.data_ptr(), out.numel(), scale, torch.cuda.current_stream().cuda_stream), "kpf_add_relu_backward")
+        return (None,) + (dx,) * n + (None,) * (3 - n)
+
+
+def add_relu(a, b=None, c=None, scale=1.0):
+    return AddRelu.apply(scale, a, b, c)
 
 
 class BmmSmallK(torch.autograd.Function):
@@ -1628,7 +1668,7 @@ class Conv2dNHWC(torch.autograd.Function):
     Linear layers are the 1x1 case on a [rows, 1, 1, K] view."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, prec="f32", w16=None, key=None, cache=None, groups=1, res=None, gelu_in=False):
+    def forward(ctx, x, weight, bias, stride, pad, prec="f32", w16=None, key=None, cache=None, groups=1, res=None, gelu_in=False, alias=False):
         """prec "bf16" / "f16": operands rounded to 16 bits, fp32 accumulation on the 16-bit MFMA (kpf_conv2d_h16), 16-bit output;
         the weight stays the fp32 master copy and receives an fp32 gradient.  w16: the weight already rounded to the compute type
         (same shape; TrainGraph casts all of them once per step) — the packs are then built from it without per-layer casts.
@@ -1638,7 +1678,9 @@ class Conv2dNHWC(torch.autograd.Function):
         model/hourglass.py:106-119) — one launch less than a separate add; its gradient is dY itself.
         gelu_in: the layer is Linear(gelu(x)) (pwconv2 of a ConvNeXt block, output.dense of a BERT layer: convNeXT/convnext.py:45-46, model/model.py:
         97-104) with x the PRE-activation: gelu runs here (kpf_gelu_forward; its output is also what the weight gradient multiplies) and the backward
-        returns d x = (dY W) * gelu'(x) from the data-gradient GEMM's own epilogue (KPF_RES_GELU_GRAD) — no separate GELU-backward pass."""
+        returns d x = (dY W) * gelu'(x) from the data-gradient GEMM's own epilogue (KPF_RES_GELU_GRAD) — no separate GELU-backward pass.
+        alias: also return x itself; a second consumer of x (the residual path around a feed-forward) that reads the alias hands its gradient to THIS
+        backward, where it rides in the data-gradient GEMM's residual epilogue (dense stride-1 layers without gelu_in)."""
         assert x.is_cuda and x.dim() == 4
         B, H, W, Cin = x.shape
         N, Cw, KH, KW = weight.shape
@@ -1662,7 +1704,7 @@ class Conv2dNHWC(torch.autograd.Function):
                 pc = DevPack.packed(weight, bias, 0, prec, stride=1, pad=0, patchify=False)
             y = _conv_any(_OddPack(pc, cpad), xc, prec)
             ctx.pack = (key, cache)
-            assert res is None and not gelu_in
+            assert res is None and not gelu_in and not alias
             ctx.odd = (Cin, cpad, npad)
             ctx.save_for_backward(xc, weight, None)
             ctx.w16, ctx.x_dtype = None, x.dtype
@@ -1689,16 +1731,27 @@ class Conv2dNHWC(torch.autograd.Function):
             L.check(L.load().kpf_gelu_forward(z.data_ptr(), xc.data_ptr(), _KDT[z.dtype], z.numel(), torch.cuda.current_stream().cuda_stream), "kpf_gelu_forward")
         y = _conv_any(pc, xc, prec, res=res)
         ctx.res_dtype = None if res is None else res.dtype
+        ctx.alias = bool(alias)
+        if alias:
+            assert not gelu_in and stride == 1 and not patch and groups == 1
+            ctx.set_materialize_grads(False)
         ctx.save_for_backward(xc, weight, z)
         ctx.w16 = w16 if use16 else None
         ctx.x_dtype = x.dtype
         ctx.conf = (stride, pad, patch, bias is not None, prec)
         ctx.bias_ptr = bias.data_ptr() if bias is not None else None  # (identifies the bias PARAMETER for DeferredParamGrads' adoption check)
-        return y
+        return (y, x.view(x.shape)) if alias else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, g_alias=None):
         x, weight, z = ctx.saved_tensors
+        if dy is None:  # (only the alias was used)
+            return (g_alias,) + (None,) * 12
+        if g_alias is not None:
+            assert z is None
+            gg_alias = dict(res=g_alias.to(x.dtype).contiguous().view(x.shape))
+        else:
+            gg_alias = {}
         stride, pad, patch, has_bias, prec = ctx.conf
         from . import lib as L
         gg = dict(res=z, flags=L.KPF_RES_GELU_GRAD) if z is not None else {}  # (gelu_in: the data gradient's epilogue multiplies by gelu'(z))
@@ -1731,7 +1784,7 @@ class Conv2dNHWC(torch.autograd.Function):
                 L.check(lib.kpf_conv2d_wgrad_groups(dyp.data_ptr(), x.data_ptr(), _KDT[tdt], dw.data_ptr(), db.data_ptr() if want_db else None, ws.data_ptr(), nws, 1,
                                                     B, H, W, cpad, cpad, H, W, npad, npad, 1, 1, 1, 1, 0, 0, Cw, N, torch.cuda.current_stream().cuda_stream),
                         "kpf_conv2d_wgrad_groups")
-            return dx, dw, db, None, None, None, None, None, None, None, None, None
+            return dx, dw, db, None, None, None, None, None, None, None, None, None, None
         if G > 1:  # channel-stacked groups: the same three GEMMs, one launch each for all groups
             key, cache = ctx.pack
             n, wd = N // G, weight.detach()
@@ -1748,7 +1801,7 @@ class Conv2dNHWC(torch.autograd.Function):
                 dx = dx.to(ctx.x_dtype)
             if ctx.needs_input_grad[1]:
                 dw, db = conv_wgrad_hip(dy, x, weight.shape, stride, pad, has_bias and ctx.needs_input_grad[2], groups=G)
-            return dx, dw, db, None, None, None, None, None, None, None, dres, None
+            return dx, dw, db, None, None, None, None, None, None, None, dres, None, None
         if ctx.needs_input_grad[0]:
             wsrc = ctx.w16 if ctx.w16 is not None else weight.detach()
             npad = (N + cmul - 1) // cmul * cmul
@@ -1767,7 +1820,7 @@ class Conv2dNHWC(torch.autograd.Function):
                     dil = dy_in.new_zeros(B, hz, wz, npad)
                     dil[:, :(OH - 1) * stride + 1:stride, :(OW - 1) * stride + 1:stride] = dy_in
                     dy_in = dil
-                dx = _conv_any(_dgrad_pack(ctx, wsrc, 1, prec, pad=pad, n_pad=npad), dy_in, prec, **gg).view(B, H, W, Cin)
+                dx = _conv_any(_dgrad_pack(ctx, wsrc, 1, prec, pad=pad, n_pad=npad), dy_in, prec, **gg, **gg_alias).view(B, H, W, Cin)
             dx = dx.to(ctx.x_dtype)
         if ctx.needs_input_grad[1] and Cin % 4 == 0 and N % 4 == 0:
             # hand-written split-K weight gradient (fp32 products and accumulation in every precision mode: the master weight's
@@ -1785,7 +1838,7 @@ class Conv2dNHWC(torch.autograd.Function):
                 grp.add(ctx.pack[0], dyc, xc, dw, db, ctx.bias_ptr if want_db else None)
             else:
                 dw, db = conv_wgrad_hip(dy, x, weight.shape, stride, pad, want_db)
-            return dx, dw, db, None, None, None, None, None, None, None, dres, None
+            return dx, dw, db, None, None, None, None, None, None, None, dres, None, None
         if ctx.needs_input_grad[1]:
             xw = x if prec == "f32" else x.to(_TDT[prec])  # weight gradient in the compute precision, handed to the fp32 master weight
             dyw = dy if prec == "f32" else dy.to(_TDT[prec])
@@ -1795,7 +1848,7 @@ class Conv2dNHWC(torch.autograd.Function):
                 dw = torch.nn.grad.conv2d_weight(xw.permute(0, 3, 1, 2), weight.shape, dyw.permute(0, 3, 1, 2), stride=stride, padding=pad).float()
         if has_bias and ctx.needs_input_grad[2]:
             db = dy.float().view(-1, N).sum(0)
-        return dx, dw, db, None, None, None, None, None, None, None, dres, None
+        return dx, dw, db, None, None, None, None, None, None, None, dres, None, None
 
 
 def _dgrad_pack(ctx, wsrc, mode, prec, **kw):
@@ -1806,16 +1859,18 @@ def _dgrad_pack(ctx, wsrc, mode, prec, **kw):
 
 
 def conv2d_nhwc(x, weight, bias=None, stride=1, pad=0, prec="f32", w16=None, key=None, cache=None, groups=1, res=None):
-    return Conv2dNHWC.apply(x, weight, bias, stride, pad, prec, w16, key, cache, groups, res, False)
+    return Conv2dNHWC.apply(x, weight, bias, stride, pad, prec, w16, key, cache, groups, res, False, False)
 
 
-def linear_hip(x, weight, bias=None, prec="f32", w16=None, key=None, cache=None, groups=1, gelu_in=False):
+def linear_hip(x, weight, bias=None, prec="f32", w16=None, key=None, cache=None, groups=1, gelu_in=False, alias=False):
     """nn.Linear on rows [..., K] through the same Function (a 1x1 convolution over a [rows, 1, 1, K] view); groups: see Conv2dNHWC
     (x [..., G*K], weight [G*N, K])."""
     K = x.shape[-1]
     Kw = weight.shape[-1]
     y = Conv2dNHWC.apply(x.reshape(-1, 1, 1, K), weight.reshape(weight.shape[0], Kw, 1, 1), bias, 1, 0, prec,
-                         w16.reshape(weight.shape[0], Kw, 1, 1) if w16 is not None else None, key, cache, groups, None, gelu_in)
+                         w16.reshape(weight.shape[0], Kw, 1, 1) if w16 is not None else None, key, cache, groups, None, gelu_in, alias)
+    if alias:
+        return y[0].view(*x.shape[:-1], weight.shape[0]), y[1].view(x.shape)
     return y.view(*x.shape[:-1], weight.shape[0])
 
 

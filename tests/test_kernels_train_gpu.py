@@ -971,9 +971,12 @@ def test_self_attention21_matches_three_linears_and_the_attention_core():
     hg = h.clone().requires_grad_(True)
     wg, bg = [torch.nn.Parameter(w.clone()) for w in ws], [torch.nn.Parameter(b.clone()) for b in bs]
     cache = T.PackCache()
-    out = T.self_attention21(hg, wg[0], bg[0], wg[1], bg[1], wg[2], bg[2], ("q.weight", "k.weight", "v.weight"), cache, H, 32 ** -0.5)
-    out.backward(dctx)
-    assert torch.equal(out, ref)
+    out, h_alias = T.self_attention21(hg, wg[0], bg[0], wg[1], bg[1], wg[2], bg[2], ("q.weight", "k.weight", "v.weight"), cache, H, 32 ** -0.5)
+    # the alias carries a second consumer's gradient (the layer's residual path) into the same backward: d h = data gradient + that gradient
+    g2 = torch.randn(B, Tn, Cc, generator=g).to(dev)
+    torch.autograd.backward([out, h_alias], [dctx, g2])
+    hr.grad += g2
+    assert torch.equal(out, ref) and torch.equal(h_alias, h)
     rel = lambda a, r: float((a - r).abs().max()) / max(float(r.abs().max()), 1e-6)
     assert rel(hg.grad, hr.grad) <= 2e-6
     for a, r in zip(wg + bg, wr + br):
@@ -984,7 +987,7 @@ def test_self_attention21_matches_three_linears_and_the_attention_core():
             p_.mul_(0.5)
             r_.mul_(0.5)
     cache.refresh()
-    out2 = T.self_attention21(h, wg[0], bg[0], wg[1], bg[1], wg[2], bg[2], ("q.weight", "k.weight", "v.weight"), cache, H, 32 ** -0.5)
+    out2 = T.self_attention21(h, wg[0], bg[0], wg[1], bg[1], wg[2], bg[2], ("q.weight", "k.weight", "v.weight"), cache, H, 32 ** -0.5)[0]
     q, k, v = (T.linear_hip(h, w, b) for w, b in zip(wr, br))
     assert torch.equal(out2, T.attn21(q, k, v, H, 32 ** -0.5))
 
@@ -1101,3 +1104,42 @@ def test_linear_of_gelu_with_the_gelu_gradient_in_the_data_gradient_epilogue(pre
         zr, wr = z.double().requires_grad_(True), w.double().requires_grad_(True)
         (F.gelu(zr) @ wr.t() + b.double()).backward(dy.double())
         assert float((res[0][1].double() - zr.grad).abs().max()) <= 2e-5 * float(zr.grad.abs().max())
+
+
+def test_linear_alias_folds_the_residual_gradient_into_the_data_gradient():
+    """linear_hip(alias=True): y and x itself; a gradient arriving through the alias is added in the data-gradient GEMM's residual epilogue."""
+    from keypointfusion_amd import training as T
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(7, 21, 128, generator=g).to(dev)
+    w, b = (torch.randn(512, 128, generator=g) * 128 ** -0.5).to(dev), torch.randn(512, generator=g).to(dev)
+    dy, g2 = torch.randn(7, 21, 512, generator=g).to(dev), torch.randn(7, 21, 128, generator=g).to(dev)
+    xa, wa, ba = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y, xal = T.linear_hip(xa, wa, ba, alias=True)
+    torch.autograd.backward([y, xal], [dy, g2])
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = T.linear_hip(xr, wr, br)
+    torch.autograd.backward([yr, xr * 1.0], [dy, g2])
+    assert torch.equal(y, yr) and torch.equal(xal, x) and torch.equal(wa.grad, wr.grad) and torch.equal(ba.grad, br.grad)
+    assert float((xa.grad - xr.grad).abs().max()) <= 2e-6 * float(xr.grad.abs().max())
+    x2 = x.clone().requires_grad_(True)  # only the alias used
+    T.linear_hip(x2, w, b, alias=True)[1].backward(g2)
+    assert torch.equal(x2.grad, g2)
+
+
+def test_add_relu_matches_torch():
+    from keypointfusion_amd import training as T
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(2)
+    ts = [torch.randn(5, 33, 128, generator=g).to(dev) for _ in range(3)]
+    dy = torch.randn(5, 33, 128, generator=g).to(dev)
+    for n, scale in ((2, 1.0), (3, 1.0), (2, 0.5), (1, 1.0)):
+        a = [t.clone().requires_grad_(True) for t in ts[:n]]
+        r = [t.clone().requires_grad_(True) for t in ts[:n]]
+        y = T.add_relu(*a, scale=scale)
+        y.backward(dy)
+        yr = F.relu(sum(r) * scale)
+        yr.backward(dy)
+        assert torch.allclose(y, yr, rtol=0, atol=1e-6)
+        for x, xr in zip(a, r):
+            assert torch.allclose(x.grad, xr.grad, rtol=0, atol=1e-6)

@@ -26,6 +26,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_train12
 cp $(find $OUT/prof_${TAG}_train128 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_train128_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_train128_bf16 -- python3 $ROOT/bench.py --workload train128_bf16 --no-cpu-baseline --steps 10 --warmup 3 > $OUT/prof_${TAG}_train128_bf16.log 2>&1
 cp $(find $OUT/prof_${TAG}_train128_bf16 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_train128_bf16_kernel_stats.csv
+# ONE graph replay of the training iteration cut out of the same traces: launches, kernel time, library share (tools/replay_histogram.py)
+python3 $ROOT/tools/replay_histogram.py $OUT/prof_${TAG}_train128_bf16 $OUT/${TAG}_train128_bf16_replay_hist.txt 2> /dev/null
+python3 $ROOT/tools/replay_histogram.py $OUT/prof_${TAG}_train128 $OUT/${TAG}_train128_replay_hist.txt 2> /dev/null
 # the bench lines of the same build, without the profiler (the traffic files just collected are what `roofline.traffic` quotes)
 cd $ROOT
 cp $OUT/${TAG}_traffic.json $OUT/${TAG}_traffic_cnb512.json $ROOT/profiles/ 2>/dev/null
