@@ -465,7 +465,8 @@ class TrainGraph:
 
     def kp_interaction_tr(self, p, x):
         T = x.shape[1]
-        h = self.linear(x, p + ".bert.img_embedding.weight", p + ".bert.img_embedding.bias") + self.t[p + ".bert.position_embeddings.weight"][:T]
+        from .training import PrefixRows
+        h = self.linear(x, p + ".bert.img_embedding.weight", p + ".bert.img_embedding.bias") + PrefixRows.apply(self.t[p + ".bert.position_embeddings.weight"], T)
         h = self.drop(h)  # TR_Encoder applies the embedding dropout (model/model.py:84)
         for l in range(4):
             h = self.bert_layer(p + ".bert.encoder.layer.%d" % l, h)
@@ -475,19 +476,22 @@ class TrainGraph:
     def decoder_layer(self, p, query, key, heads=4):
         B, T, C = query.shape
         hd = C // heads
-        qe = query + self.t[p + ".self_posembed.weight"][:T]
-        ke = key + self.t[p + ".cross_posembed.weight"][:T]
-        W, bqkv = self.t[p + ".multihead_attn.in_proj_weight"], self.t[p + ".multihead_attn.in_proj_bias"]
+        from .training import PrefixRows, SplitRows
+        qe = query + PrefixRows.apply(self.t[p + ".self_posembed.weight"], T)
+        ke = key + PrefixRows.apply(self.t[p + ".cross_posembed.weight"], T)
         ipw = p + ".multihead_attn.in_proj_weight"
-        q = linear_hip(qe.contiguous(), W[:C], bqkv[:C], self.prec, None, ipw + ":q", self.packs) * (float(hd) ** -0.5)
-        k = linear_hip(ke.contiguous(), W[C:2 * C], bqkv[C:2 * C], self.prec, None, ipw + ":k", self.packs)
-        v = linear_hip(ke.contiguous(), W[2 * C:], bqkv[2 * C:], self.prec, None, ipw + ":v", self.packs)
+        Wq, Wk, Wv = SplitRows.apply(self.t[ipw], 3)  # (views of the packed parameter; their gradients come back as one concatenation)
+        bq, bk, bv = SplitRows.apply(self.t[p + ".multihead_attn.in_proj_bias"], 3)
+        q = linear_hip(qe.contiguous(), Wq, bq, self.prec, None, ipw + ":q", self.packs)
+        k = linear_hip(ke.contiguous(), Wk, bk, self.prec, None, ipw + ":k", self.packs)
+        v = linear_hip(ke.contiguous(), Wv, bv, self.prec, None, ipw + ":v", self.packs)
         assert T == 21 and hd == 32
-        ctx = self.attention(q, k, v, heads, 1.0)  # (q carries the 1/sqrt(hd) factor already: model/transfusion_head.py:468)
+        # (model/transfusion_head.py:468 scales q by 1/sqrt(hd) before the product: the same factor on the logits, inside the attention kernel)
+        ctx = self.attention(q, k, v, heads, float(hd) ** -0.5)
         o = self.linear(ctx, p + ".multihead_attn.out_proj.weight", p + ".multihead_attn.out_proj.bias")
-        x = self.ln(query + self.drop(o), p + ".norm2.weight", p + ".norm2.bias", 1e-5)
+        x = self.dropout_add_ln(o, query, p + ".norm2.weight", p + ".norm2.bias", 1e-5)
         f = self.linear(self.drop(F.relu(self.linear(x, p + ".linear1.weight", p + ".linear1.bias"))), p + ".linear2.weight", p + ".linear2.bias")
-        return self.ln(x + self.drop(f), p + ".norm3.weight", p + ".norm3.bias", 1e-5)
+        return self.dropout_add_ln(f, x, p + ".norm3.weight", p + ".norm3.bias", 1e-5)
 
     def block(self, p, img_feat, img_feat_rgb, pcl, joint_xyz, clos, idx, img_offset, prev_feat, img_down, center, Minv, cube, cam,
               img_size, flip):

@@ -1410,6 +1410,41 @@ def drop_add_ln(o, h, weight, bias, eps, p_drop=0.0, rng=None, call_id=0):
     return DropAddLN.apply(o, h, weight, bias, eps, p_drop, rng, call_id)
 
 
+class SplitRows(torch.autograd.Function):
+    """w [n*C, ...] -> n row blocks of C (views); the backward concatenates the n gradients in ONE launch — autograd's own slicing backward is a zero
+    fill plus a copy per block and n - 1 adds (the packed in_proj weight / bias of nn.MultiheadAttention, model/transfusion_head.py:437-470)."""
+
+    @staticmethod
+    def forward(ctx, w, n):
+        c = w.shape[0] // n
+        ctx.meta = ((c,) + tuple(w.shape[1:]), w.dtype, w.device)
+        return tuple(w[i * c:(i + 1) * c] for i in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        shp, dt, dev = ctx.meta
+        gs = [g.contiguous() if g is not None else torch.zeros(shp, dtype=dt, device=dev) for g in gs]
+        return torch.cat(gs, 0), None
+
+
+class PrefixRows(torch.autograd.Function):
+    """w[:T] of an embedding table [L, C]; backward = the gradient zero-extended to L rows in one launch (kpf_pad_rows) instead of a fill and a copy."""
+
+    @staticmethod
+    def forward(ctx, w, T):
+        ctx.shape = tuple(w.shape)
+        return w[:T]
+
+    @staticmethod
+    def backward(ctx, g):
+        L_, Cc = ctx.shape[0], 1
+        for d in ctx.shape[1:]:
+            Cc *= d
+        if g.shape[0] == L_:
+            return g, None
+        return pad_rows(g.contiguous().view(1, -1), L_ * Cc).view(ctx.shape), None
+
+
 class AddRelu(torch.autograd.Function):
     """relu(scale * (a + b [+ c])) on fp32 tensors of one shape, one launch each way (kpf_add_relu_forward / _backward); every addend receives the
     same gradient tensor."""
