@@ -334,6 +334,12 @@ int kpf_pose_tokens_f32(const float* pw, const float* joint, const float* pcl, f
  * model/model.py:190, 417-422). */
 int kpf_add_relu_forward(const float* a, const float* b, const float* c, float* out, long n, float scale, void* stream);
 int kpf_add_relu_backward(const float* dy, const float* out, float* dx, long n, float scale, void* stream);
+/* The gate of a fusion block around its two maps (ABI 13; model/model.py:334-341): sw = sigmoid(logits) (returned to the loss), gw = (sigmoid(weight_dis) * gam +
+ * (1 - sigmoid(weight_dis)) * sw) * w_fc[p].  logits [B*P][J] (the rows of the atten_spatial GEMM), gam / sw / gw [B][J][P], weight_dis [1], w_fc [P].
+ * backward: d_sw nullable; ws >= B*J floats; parameter gradients summed in a fixed order. */
+int kpf_gate_mix_forward(const float* logits, const float* gam, const float* weight_dis, const float* w_fc, float* sw, float* gw, int B, int J, int P, void* stream);
+int kpf_gate_mix_backward(const float* sw, const float* gam, const float* weight_dis, const float* w_fc, const float* d_sw, const float* d_gw, float* d_gam,
+                          float* d_logits, float* d_w_fc, float* d_weight_dis, float* ws, int B, int J, int P, void* stream);
 /* Depthwise 7x7 (pad 3) + bias alone, y = dwconv(x): the ConvNeXt block's first op with its output kept for the LayerNorm backward,
  * and its data gradient (dx = the same convolution of dy with w_dw's taps mirrored, zero bias).  w_dw [49][C], x != y. */
 int kpf_dwconv7_f32(const float* x, const float* w_dw, const float* b_dw, float* y, int B, int H, int W, int C, void* stream);

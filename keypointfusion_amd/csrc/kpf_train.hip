@@ -2026,3 +2026,94 @@ extern "C" int kpf_add_relu_backward(const float* dy, const float* out, float* d
   hipLaunchKernelGGL(relu_scale_bwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, out, dx, n / 4, scale);
   return kpf_check_launch("kpf_add_relu_backward");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The gate of a fusion block (model/model.py:334-341) around its two maps: sw = sigmoid(logits), g = sigmoid(weight_dis) * gam + (1 - sigmoid(weight_dis)) * sw,
+// gw = g * w_fc[p] — one launch forward (sigmoid x 2, 1 - x, two products, a sum, the product with the pooling weight and the [B, P, J] -> [B, J, P]
+// transpose of the logits otherwise), two backward (element-wise part + per-row partial sums; then the two parameter reductions in a fixed order).
+// logits [B*P][J] (rows of the atten_spatial GEMM), gam / sw / gw [B][J][P]; weight_dis a scalar parameter, w_fc [P].
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void gate_mix_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ gam, const float* __restrict__ wdis,
+                                                           const float* __restrict__ wfc, float* __restrict__ sw, float* __restrict__ gw, int J, int P) {
+  const int j = blockIdx.x, b = blockIdx.y;
+  const float wd = 1.0f / (1.0f + __expf(-wdis[0]));
+  const long row = ((long)b * J + j) * P;
+  for (int p = threadIdx.x; p < P; p += 256) {
+    const float s = 1.0f / (1.0f + __expf(-logits[((long)b * P + p) * J + j]));
+    sw[row + p] = s;
+    gw[row + p] = (wd * gam[row + p] + (1.0f - wd) * s) * wfc[p];
+  }
+}
+
+__global__ __launch_bounds__(256) void gate_mix_bwd_kernel(const float* __restrict__ sw, const float* __restrict__ gam, const float* __restrict__ wdis,
+                                                           const float* __restrict__ wfc, const float* __restrict__ dsw, const float* __restrict__ dgw,
+                                                           float* __restrict__ dgam, float* __restrict__ dlogits, float* __restrict__ part, int J, int P) {
+  __shared__ float red[4];
+  const int j = blockIdx.x, b = blockIdx.y;
+  const float wd = 1.0f / (1.0f + __expf(-wdis[0]));
+  const long row = ((long)b * J + j) * P;
+  float acc = 0.f;
+  for (int p = threadIdx.x; p < P; p += 256) {
+    const float t = dgw[row + p] * wfc[p];  // d g
+    const float s = sw[row + p], ga = gam[row + p];
+    dgam[row + p] = t * wd;
+    const float ds = (dsw ? dsw[row + p] : 0.f) + t * (1.0f - wd);
+    dlogits[((long)b * P + p) * J + j] = ds * s * (1.0f - s);
+    acc = fmaf(t, ga - s, acc);
+  }
+  acc = block_sum256(acc, red);
+  if (threadIdx.x == 0) part[(long)b * J + j] = acc;
+}
+
+// blocks [0, ceil(P / 32)): d w_fc[p] = sum over the B*J rows of dgw * g — 32 columns x 8 row groups per block (rows r = group, group + 8, ...: coalesced 128-byte
+// reads, 84 iterations instead of 672), the eight group sums added in group order;  the last block: d weight_dis = wd (1 - wd) * sum of the row partials
+__global__ __launch_bounds__(256) void gate_mix_params_kernel(const float* __restrict__ sw, const float* __restrict__ gam, const float* __restrict__ wdis,
+                                                              const float* __restrict__ dgw, const float* __restrict__ part, float* __restrict__ dwfc,
+                                                              float* __restrict__ dwdis, int R, int P) {
+  __shared__ float red[8][32];
+  const float wd = 1.0f / (1.0f + __expf(-wdis[0]));
+  const int nb = (P + 31) / 32;
+  if ((int)blockIdx.x < nb) {
+    const int pl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int p = blockIdx.x * 32 + pl;
+    float acc = 0.f;
+    if (p < P)
+      for (int r = rg; r < R; r += 8) {
+        const long i = (long)r * P + p;
+        acc = fmaf(dgw[i], wd * gam[i] + (1.0f - wd) * sw[i], acc);
+      }
+    red[rg][pl] = acc;
+    __syncthreads();
+    if (rg == 0 && p < P) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += red[k][pl];
+      dwfc[p] = t;
+    }
+  } else {
+    float acc = 0.f;
+    for (int r = threadIdx.x; r < R; r += 256) acc += part[r];
+    acc = block_sum256(acc, &red[0][0]);
+    if (threadIdx.x == 0) dwdis[0] = acc * wd * (1.0f - wd);
+  }
+}
+}  // namespace
+
+extern "C" int kpf_gate_mix_forward(const float* logits, const float* gam, const float* weight_dis, const float* w_fc, float* sw, float* gw, int B, int J, int P,
+                                    void* stream) {
+  KPF_REQUIRE(logits && gam && weight_dis && w_fc && sw && gw && B > 0 && J > 0 && P > 0, "kpf_gate_mix_forward: bad arguments");
+  hipLaunchKernelGGL(gate_mix_fwd_kernel, dim3(J, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), logits, gam, weight_dis, w_fc, sw, gw, J, P);
+  return kpf_check_launch("kpf_gate_mix_forward");
+}
+/* d_sw may be NULL; ws >= B*J floats; writes d_gam [B][J][P], d_logits [B*P][J], d_w_fc [P], d_weight_dis [1] */
+extern "C" int kpf_gate_mix_backward(const float* sw, const float* gam, const float* weight_dis, const float* w_fc, const float* d_sw, const float* d_gw, float* d_gam,
+                                     float* d_logits, float* d_w_fc, float* d_weight_dis, float* ws, int B, int J, int P, void* stream) {
+  KPF_REQUIRE(sw && gam && weight_dis && w_fc && d_gw && d_gam && d_logits && d_w_fc && d_weight_dis && ws && B > 0 && J > 0 && P > 0, "kpf_gate_mix_backward: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(gate_mix_bwd_kernel, dim3(J, B), dim3(256), 0, st, sw, gam, weight_dis, w_fc, d_sw, d_gw, d_gam, d_logits, ws, J, P);
+  int rc = kpf_check_launch("kpf_gate_mix_backward");
+  if (rc != KPF_OK) return rc;
+  hipLaunchKernelGGL(gate_mix_params_kernel, dim3((P + 31) / 32 + 1), dim3(256), 0, st, sw, gam, weight_dis, d_gw, ws, d_w_fc, d_weight_dis, B * J, P);
+  return kpf_check_launch("kpf_gate_mix_backward (parameters)");
+}

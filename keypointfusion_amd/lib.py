@@ -106,6 +106,8 @@ _SIGS = {
     "kpf_conv2d_wgrad_groups": [_P, _P, C.c_int] + [_P] * 3 + [C.c_long] + [C.c_int] * 18 + [_P],
     "kpf_add_relu_forward": [_P, _P, _P, _P, C.c_long, C.c_float, _P],
     "kpf_add_relu_backward": [_P, _P, _P, C.c_long, C.c_float, _P],
+    "kpf_gate_mix_forward": [_P] * 6 + [C.c_int] * 3 + [_P],
+    "kpf_gate_mix_backward": [_P] * 11 + [C.c_int] * 3 + [_P],
     "kpf_pad_rows": [_P, C.c_int, _P, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, _P],
     "kpf_pose_tokens_f32": [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P],
     "kpf_ln_train_forward_g": [_P, _P, _P, _P, C.c_int, _P, _P, C.c_long, C.c_int, C.c_int, C.c_float, _P],

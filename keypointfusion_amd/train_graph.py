@@ -495,7 +495,7 @@ class TrainGraph:
 
     def block(self, p, img_feat, img_feat_rgb, pcl, joint_xyz, clos, idx, img_offset, prev_feat, img_down, center, Minv, cube, cam,
               img_size, flip):
-        from .training import GeomGateUVD, JointHeatmap
+        from .training import GateMix, GeomGateUVD, JointHeatmap
         B, C, H, W = img_feat.shape
         pf = self.gather_interp(img_feat, idx, clos)
         pf_rgb = self.gather_interp(img_feat_rgb, idx, clos)
@@ -517,17 +517,16 @@ class TrainGraph:
         # whole quads so that forward, data- and weight-gradient all run on the HIP kernels (fixed summation order): the three zero channels ride in
         # the concatenation, the 21 outputs are Conv2dNHWC's odd-width form
         sw_in = torch.cat([img_feat_rgb.permute(0, 2, 3, 1).float(), hm.permute(0, 2, 3, 1), self.zpad3], -1).reshape(B * H * W, -1)
-        sw = self.linear_rows(sw_in, self.t[p + ".atten_spatial.weight"].flatten(1), self.t[p + ".atten_spatial.bias"], p + ".atten_spatial.weight").float()
-        sw = torch.sigmoid(sw.view(B, H, W, J).permute(0, 3, 1, 2))
-        wd = torch.sigmoid(self.t[p + ".weight_dis"])
-        g = wd * gam + (1 - wd) * sw
+        logits = self.linear_rows(sw_in, self.t[p + ".atten_spatial.weight"].flatten(1), self.t[p + ".atten_spatial.bias"], p + ".atten_spatial.weight")
+        # sw = sigmoid(logits) [B, J, H, W]; gw = (sigmoid(weight_dis) * gam + (1 - sigmoid(weight_dis)) * sw) * w_fc: one launch (training.GateMix)
+        sw, gw = GateMix.apply(logits, gam.reshape(B, J, H * W), self.t[p + ".weight_dis"], self.t[p + ".fc_spatial2joint_feature.weight"])
+        sw = sw.view(B, J, H, W)
         # model/model.py:386-388: fj[b,j,c] = sum_hw relu(g[b,j,hw] * f[b,c,hw]) * w[hw] + bias.  g >= 0 (a convex mix of a positive
         # kernel and a sigmoid), so relu(g*f) == g*relu(f) exactly and the B x J x C x HW intermediate (352 MB at B = 32) collapses
         # into one batched GEMM [J x HW] @ [HW x C] — the same identity the inference kernel (kpf_gate_reduce_f32) uses
-        wsp = self.t[p + ".fc_spatial2joint_feature.weight"].view(1, 1, -1)
-        frows = F.relu(img_feat_rgb.float()).permute(0, 2, 3, 1).reshape(B, H * W, C)
-        gw = g.reshape(B, J, H * W) * wsp
-        fj = bmm_small_k(gw, frows) + self.t[p + ".fc_spatial2joint_feature.bias"]
+        if self.frows is None:  # relu(RGB features) as rows: the same operand in both blocks
+            self.frows = F.relu(img_feat_rgb.float()).permute(0, 2, 3, 1).reshape(B, H * W, C)
+        fj = bmm_small_k(gw, self.frows) + self.t[p + ".fc_spatial2joint_feature.bias"]
         if prev_feat is not None:
             fj = add_relu(fj, prev_feat, scale=0.5)
         dec = self.decoder_layer(p + ".crossTR.decoder.3", fj, h_init)
@@ -603,6 +602,7 @@ class TrainGraph:
         from .training import pad_rows
         self.pcl4 = pad_rows(pcl, 4)                                         # the points at the width pcl_xyz_emb's GEMM reads (both blocks)
         self.zpad3 = torch.zeros(B, Fs, Fs, 3, device=dev)                   # the gate input's three zero channels (149 -> 152, both blocks)
+        self.frows = None
         img_down = None  # (F.interpolate(img, [Fs, Fs]) in the reference, model/model.py:401: computed there and never read)
         sws = []
         prev = None

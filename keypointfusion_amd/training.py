@@ -1410,6 +1410,44 @@ def drop_add_ln(o, h, weight, bias, eps, p_drop=0.0, rng=None, call_id=0):
     return DropAddLN.apply(o, h, weight, bias, eps, p_drop, rng, call_id)
 
 
+class GateMix(torch.autograd.Function):
+    """(sw, gw) of a fusion block's gate from the atten_spatial logits [B*P, J], the geometry map gam [B, J, P], the scalar weight_dis and the pooling
+    weight w_fc [1, P] (kpf_gate_mix_forward / _backward; model/model.py:334-341): sw = sigmoid(logits) as [B, J, P], gw = (sig(wd) gam + (1 - sig(wd)) sw) w_fc."""
+
+    @staticmethod
+    def forward(ctx, logits, gam, weight_dis, w_fc):
+        from . import lib as L
+        B, J_, P = gam.shape
+        lg, ga = logits.float().contiguous(), gam.float().contiguous()
+        wd, wf = weight_dis.detach().float().contiguous(), w_fc.detach().float().contiguous()
+        assert lg.numel() == B * P * J_ and wf.numel() == P and wd.numel() == 1
+        sw, gw = torch.empty_like(ga), torch.empty_like(ga)
+        L.check(L.load().kpf_gate_mix_forward(lg.data_ptr(), ga.data_ptr(), wd.data_ptr(), wf.data_ptr(), sw.data_ptr(), gw.data_ptr(), B, J_, P,
+                                              torch.cuda.current_stream().cuda_stream), "kpf_gate_mix_forward")
+        ctx.save_for_backward(sw, ga, wd, wf)
+        ctx.shapes = (tuple(logits.shape), tuple(weight_dis.shape), tuple(w_fc.shape))
+        ctx.set_materialize_grads(False)
+        return sw, gw
+
+    @staticmethod
+    def backward(ctx, d_sw, d_gw):
+        from . import lib as L
+        sw, ga, wd, wf = ctx.saved_tensors
+        B, J_, P = ga.shape
+        if d_gw is None:
+            d_gw = torch.zeros_like(ga)
+        d_gw = d_gw.float().contiguous()
+        d_sw = d_sw.float().contiguous() if d_sw is not None else None
+        dgam, dlog = torch.empty_like(ga), torch.empty(B * P, J_, device=ga.device, dtype=torch.float32)
+        dwf, dwd = torch.empty(P, device=ga.device, dtype=torch.float32), torch.empty(1, device=ga.device, dtype=torch.float32)
+        ws = torch.empty(B * J_, device=ga.device, dtype=torch.float32)
+        L.check(L.load().kpf_gate_mix_backward(sw.data_ptr(), ga.data_ptr(), wd.data_ptr(), wf.data_ptr(), d_sw.data_ptr() if d_sw is not None else None, d_gw.data_ptr(),
+                                               dgam.data_ptr(), dlog.data_ptr(), dwf.data_ptr(), dwd.data_ptr(), ws.data_ptr(), B, J_, P,
+                                               torch.cuda.current_stream().cuda_stream), "kpf_gate_mix_backward")
+        ls, ds_, fs = ctx.shapes
+        return dlog.view(ls), dgam, dwd.view(ds_), dwf.view(fs)
+
+
 class SplitRows(torch.autograd.Function):
     """w [n*C, ...] -> n row blocks of C (views); the backward concatenates the n gradients in ONE launch — autograd's own slicing backward is a zero
     fill plus a copy per block and n - 1 adds (the packed in_proj weight / bias of nn.MultiheadAttention, model/transfusion_head.py:437-470)."""

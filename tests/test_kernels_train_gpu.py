@@ -1143,3 +1143,26 @@ def test_add_relu_matches_torch():
         assert torch.allclose(y, yr, rtol=0, atol=1e-6)
         for x, xr in zip(a, r):
             assert torch.allclose(x.grad, xr.grad, rtol=0, atol=1e-6)
+
+
+def test_gate_mix_matches_torch():
+    from keypointfusion_amd import training as T
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(31)
+    B, J, P = 3, 21, 1024
+    logits = torch.randn(B * P, J, generator=g).to(dev)
+    gam = torch.rand(B, J, P, generator=g).to(dev)
+    wd = torch.tensor([0.3]).to(dev)
+    wf = (0.05 * torch.randn(1, P, generator=g)).to(dev)
+    d_sw, d_gw = torch.randn(B, J, P, generator=g).to(dev), torch.randn(B, J, P, generator=g).to(dev)
+    a = [t.clone().requires_grad_(True) for t in (logits, gam, wd, wf)]
+    sw, gw = T.GateMix.apply(*a)
+    torch.autograd.backward([sw, gw], [d_sw, d_gw])
+    r = [t.double().clone().requires_grad_(True) for t in (logits, gam, wd, wf)]
+    swr = torch.sigmoid(r[0].view(B, P, J).permute(0, 2, 1))
+    w = torch.sigmoid(r[2])
+    gwr = (w * r[1] + (1 - w) * swr) * r[3].view(1, 1, P)
+    torch.autograd.backward([swr, gwr], [d_sw.double(), d_gw.double()])
+    assert float((sw.double() - swr).abs().max()) <= 1e-6 and float((gw.double() - gwr).abs().max()) <= 1e-6
+    for x, xr, what in zip(a, r, ("d logits", "d gam", "d weight_dis", "d w_fc")):
+        assert float((x.grad.double() - xr.grad).abs().max()) <= 3e-5 * max(1.0, float(xr.grad.abs().max())), what
