@@ -25,6 +25,7 @@ SKIP = {"aten::view", "aten::_unsafe_view", "aten::permute", "aten::transpose", 
         "aten::unsqueeze", "aten::squeeze", "aten::alias", "aten::as_strided", "aten::select", "aten::empty", "aten::empty_like", "aten::empty_strided",
         "aten::narrow", "aten::unbind", "aten::split", "aten::view_as", "aten::_reshape_alias", "aten::size", "aten::stride", "aten::is_contiguous", "aten::unfold"}
 cnt = collections.Counter()
+COPIES = len(sys.argv) > 2 and sys.argv[2] == "copies"
 class Mode(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = func._schema.name
@@ -38,6 +39,12 @@ class Mode(TorchDispatchMode):
                     if "keypointfusion_amd" in fr.filename:
                         where = "%s:%d %s" % (os.path.basename(fr.filename), fr.lineno, fr.name)
                         break
+            if COPIES and name in ("aten::clone", "aten::_to_copy", "aten::copy_", "aten::contiguous"):
+                src = args[1] if name == "aten::copy_" else args[0]
+                if torch.is_tensor(src) and (not src.is_contiguous() or (name == "aten::copy_" and not args[0].is_contiguous())):
+                    fr = [f for f in traceback.extract_stack(limit=18) if "keypointfusion_amd" in f.filename]
+                    loc = "%s:%d" % (os.path.basename(fr[-1].filename), fr[-1].lineno) if fr else "?"
+                    cnt[("STRIDED " + name, "%s %s %s numel %d" % (where, loc, tuple(src.shape), src.numel()))] += 1
             cnt[(name, where)] += 1
         return func(*args, **(kwargs or {}))
 with Mode():
