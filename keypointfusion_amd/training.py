@@ -1977,6 +1977,7 @@ class GraphedTrainStep:
         or reduce-scatter + all-gather of the (padded) bucket — the same bytes per link on the xGMI mesh, two schedulable halves."""
         self.model, self.opt, self.loss_fn = model, optimizer, loss_fn
         self.dist, self.group = dist_mod, group
+        bucket_mb = float(os.environ.get("KPF_DP_BUCKET_MB", bucket_mb))  # (tuning aid)
         assert grad_payload in ("f32", "bf16") and collective in ("allreduce", "rs_ag")
         self.grad_payload, self.collective = grad_payload, collective
         if dist_mod is not None and dp_mode is None:
@@ -1995,9 +1996,17 @@ class GraphedTrainStep:
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
+        self._acc_counts = {}
         with torch.cuda.stream(side):
-            for _ in range(warmup):
+            for it in range(warmup):
+                count_hooks = []
+                if it == warmup - 1 and self.dp_mode == "overlap":  # how many times each parameter's gradient is accumulated in one backward pass
+                    self._acc_counts = {}
+                    bump = lambda q: self._acc_counts.__setitem__(id(q), self._acc_counts.get(id(q), 0) + 1)
+                    count_hooks = [q.register_post_accumulate_grad_hook(bump) for q in self.params]
                 self._forward_backward()
+                for h in count_hooks:
+                    h.remove()
                 self._reduce_eager()
                 self.opt.step()
         cur.wait_stream(side)
@@ -2073,7 +2082,10 @@ class GraphedTrainStep:
             offs.append(off)
             off += q.numel()
         shard = torch.empty((n + pad) // self.world, dtype=pdt, device=flat.device) if self.collective == "rs_ag" else None
-        return {"flat": flat, "params": plist, "offs": offs, "shard": shard, "pending": len(plist), "work": None}
+        # pending: accumulation events still to come before the bucket is complete (a parameter used twice in the forward is accumulated twice: its
+        # gradient is only final after the second event — counted in the last warm-up iteration)
+        pending = sum(max(1, getattr(self, "_acc_counts", {}).get(id(q), 1)) for q in plist)
+        return {"flat": flat, "params": plist, "offs": offs, "shard": shard, "pending": pending, "work": None}
 
     def _launch_bucket(self, b):
         if self.collective == "rs_ag":
@@ -2087,11 +2099,21 @@ class GraphedTrainStep:
         if slot is None or not self._hooks_armed:
             return
         b, i = slot
-        n = p.numel()
-        b["flat"][b["offs"][i]:b["offs"][i] + n].copy_(p.grad.reshape(-1))  # (casts when the payload is bf16)
         b["pending"] -= 1
-        if b["pending"] == 0:
+        cur = torch.cuda.current_stream(p.device)
+        b.setdefault("streams", {})[cur.cuda_stream] = cur  # (backward nodes run on their forward's stream: the unpaired backbones use two)
+        if b["pending"] == 0:  # the bucket's last gradient exists: pack it (one multi-tensor copy, not one copy per parameter) and start its collective
+            for st in b["streams"].values():  # gradients enqueued on other streams must be complete before this stream reads them
+                if st.cuda_stream != cur.cuda_stream:
+                    cur.wait_stream(st)
+            self._pack_bucket(b)
             self._launch_bucket(b)
+
+    @staticmethod
+    def _pack_bucket(b):
+        have = [(o, q) for o, q in zip(b["offs"], b["params"]) if q.grad is not None]
+        if have:
+            torch._foreach_copy_([b["flat"][o:o + q.numel()].view_as(q.grad) for o, q in have], [q.grad for _, q in have])  # (casts when the payload is bf16)
 
     def _remove_hooks(self):
         for h in getattr(self, "_hooks", []):
@@ -2139,13 +2161,23 @@ class GraphedTrainStep:
                 self._launch_bucket(b)
             for b in self._early:
                 if b["pending"] > 0:  # a parameter of the bucket got no gradient in this pass although the warm-up saw one: reduce what is there
+                    for st in b.get("streams", {}).values():
+                        torch.cuda.current_stream().wait_stream(st)
+                    self._pack_bucket(b)
                     self._launch_bucket(b)
             for b in self._early + self._late:
                 if b["work"] is not None:
                     b["work"].wait()
                 if self.world > 1:
                     b["flat"].mul_(inv)
-                torch._foreach_copy_([q.grad for q in b["params"]], [b["flat"][o:o + q.numel()].view_as(q.grad) for o, q in zip(b["offs"], b["params"])])
+                if b["flat"].dtype == b["params"][0].dtype:
+                    # the reduced gradients stay where the collective left them: `.grad` becomes a view of the bucket (what the optimiser nodes of the graph
+                    # read from here on; backward keeps writing the tensors it was captured with, the pack above moves them) — no unpack copy
+                    for o, q in zip(b["offs"], b["params"]):
+                        if q.grad is not None:
+                            q.grad = b["flat"][o:o + q.numel()].view_as(q.grad)
+                else:  # bf16 payload: back to the parameters' type
+                    torch._foreach_copy_([q.grad for q in b["params"]], [b["flat"][o:o + q.numel()].view_as(q.grad) for o, q in zip(b["offs"], b["params"])])
             self.opt.step()
         self._remove_hooks()  # the captured graph no longer needs them (replays do not run Python)
 
