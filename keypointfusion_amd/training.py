@@ -1981,7 +1981,6 @@ class GraphedTrainStep:
         assert grad_payload in ("f32", "bf16") and collective in ("allreduce", "rs_ag")
         self.grad_payload, self.collective = grad_payload, collective
         if dist_mod is not None and dp_mode is None:
-            import os
             be = dist_mod.get_backend(group)
             dp_mode = "overlap" if (be == "nccl" and os.environ.get("KPF_DP_GRAPH", "overlap") != "split") else "split"
         self.dp_mode = dp_mode if dist_mod is not None else None
