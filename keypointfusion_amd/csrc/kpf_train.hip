@@ -271,13 +271,38 @@ __global__ __launch_bounds__(256) void row_gather_accum_kernel(const float* __re
     for (int q = q0; q < (halves ? 32 : C4 + 63 - (C4 + 63) % 64); q += (halves ? 32 : 64)) {
       const bool live = q < C4;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      for (int a = s0 + phase; a < s1; a += nph) {
-        const int e = lb[a];
-        const float ww = wb ? wb[e] : 1.f;
-        if (live) {
-          const f32x4 g = kpf_ld4(dout + (((long)b * E + e) / G) * C4 * 4 + 4 * q);
+      // The list is walked 64 positions at a time: every lane fetches ONE index (and weight) of the chunk, the wave then broadcasts them position by
+      // position (no dependent index load in front of every row load), four row loads in flight, added in position order (same sums as a plain walk).
+      for (int c0 = s0; c0 < s1; c0 += 64) {
+        const int m = min(64, s1 - c0);
+        const int ev = lane < m ? lb[c0 + lane] : 0;
+        const float wv = (wb && lane < m) ? wb[ev] : 1.f;
+        int k = phase;
+        for (; (k - phase) + 4 * nph - 1 < m; k += 4 * nph) {  // (the same trip count for both half-waves: every shuffle runs with the whole wave active)
+          int e[4];
+          float ww[4];
+          f32x4 g[4];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) acc[k] += ww * g[k];
+          for (int u = 0; u < 4; ++u) {
+            e[u] = __shfl(ev, k + u * nph, 64);
+            ww[u] = __shfl(wv, k + u * nph, 64);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) g[u] = live ? kpf_ld4(dout + (((long)b * E + e[u]) / G) * C4 * 4 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] += ww[u] * g[u][t];
+        }
+        for (; k < m + phase; k += nph) {  // (uniform trip count for both half-waves: the shuffles are executed by all lanes; positions >= m add nothing)
+          const int kk = min(k, m - 1);
+          const int e1 = __shfl(ev, kk, 64);
+          const float w1 = __shfl(wv, kk, 64);
+          if (live && k < m) {
+            const f32x4 g1 = kpf_ld4(dout + (((long)b * E + e1) / G) * C4 * 4 + 4 * q);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] += w1 * g1[t];
+          }
         }
       }
       if (halves) {
