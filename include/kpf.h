@@ -399,6 +399,10 @@ int kpf_row_gather_fwd_f32(const float* src, const int* idx, const float* w, flo
 long kpf_row_gather_ws_ints(int B, int P, int R, int G);
 int kpf_row_gather_bwd_f32(const float* dout, const int* idx, const float* w, float* dsrc, int* ws, long ws_ints, int B, int P, int R, int G, int C,
                            void* stream);
+/* Its two halves as separate calls (ABI 13): invert an index tensor once, accumulate for every gather that used it (start = ws, list = ws + B*(P+1);
+ * a sub-range of the images is addressed by offsetting both). */
+int kpf_row_gather_invert(const int* idx, int* ws, long ws_ints, int B, int P, int R, int G, void* stream);
+int kpf_row_gather_accum_f32(const float* dout, const int* start, const int* list, const float* w, float* dsrc, int B, int P, int R, int G, int C, void* stream);
 
 /* Training: LayerNorm over the last axis (nn.LayerNorm / F.layer_norm of convNeXT/convnext.py:43,199-214 and the fusion head's post-LN
  * layers) and GELU(erf) (convNeXT/convnext.py:33), forward and backward.  x [rows][C] fp32, C % 4 == 0, C <= 1024; y in y_dtype (fp32 or the

@@ -403,6 +403,28 @@ extern "C" int kpf_row_gather_bwd_f32(const float* dout, const int* idx, const f
   return kpf_check_launch("kpf_row_gather_bwd_f32");
 }
 
+/* The two halves of kpf_row_gather_bwd_f32 on their own (ABI 13): several gathers that share one index tensor (the point sampling of both feature maps in both
+ * fusion blocks; the three radii of DESA as 3B "images") invert it ONCE.  ws: [B*(P+1)] row starts, then [B*R*G] entry lists (kpf_row_gather_ws_ints). */
+extern "C" int kpf_row_gather_invert(const int* idx, int* ws, long ws_ints, int B, int P, int R, int G, void* stream) {
+  KPF_REQUIRE(idx && ws && B > 0 && P > 0 && R > 0 && G > 0, "kpf_row_gather_invert: bad arguments");
+  const long E = (long)R * G;
+  KPF_REQUIRE(E <= GATHER_MAX_E && P <= GATHER_MAX_P, "kpf_row_gather_invert: at most %d gathered entries and %d source rows per image", GATHER_MAX_E, GATHER_MAX_P);
+  KPF_REQUIRE(ws_ints >= kpf_row_gather_ws_ints(B, P, R, G), "kpf_row_gather_invert: workspace too small");
+  const size_t inv_lds = (size_t)(INV_W * P + P + INV_W) * sizeof(int);
+  static std::atomic<bool> lds_opt_in[KPF_MAX_DEVICES];
+  KPF_REQUIRE(inv_lds <= 64 * 1024 || kpf_raise_lds_limit(reinterpret_cast<const void*>(&row_gather_invert_kernel), lds_opt_in),
+              "kpf_row_gather_invert: cannot raise the dynamic LDS limit");
+  hipLaunchKernelGGL(row_gather_invert_kernel, dim3(B), dim3(64 * INV_W), inv_lds, reinterpret_cast<hipStream_t>(stream), idx, ws, ws + (long)B * (P + 1), P, (int)E);
+  return kpf_check_launch("kpf_row_gather_invert");
+}
+extern "C" int kpf_row_gather_accum_f32(const float* dout, const int* start, const int* list, const float* w, float* dsrc, int B, int P, int R, int G, int C,
+                                        void* stream) {
+  KPF_REQUIRE(dout && start && list && dsrc && B > 0 && P > 0 && R > 0 && G > 0 && C > 0 && C % 4 == 0, "kpf_row_gather_accum_f32: bad arguments");
+  hipLaunchKernelGGL(row_gather_accum_kernel, dim3(grid_for((long)B * P, 4, 256 * 32)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dout, start, list, w, dsrc,
+                     B, P, R * G, G, C / 4);
+  return kpf_check_launch("kpf_row_gather_accum_f32");
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Weight packing for the training step: the reference-layout OIHW master weight -> the kernel operand of the implicit GEMM, ONE launch
 // per operand (the torch expressions this replaces were flip + permute-clone + pad [+ cast]: 3-4 small launches per convolution per

@@ -148,6 +148,8 @@ _SIGS = {
     "kpf_attn21_forward_ld": [_P] * 6 + [C.c_int] * 6 + [C.c_float, C.c_float, _P, C.c_int, _P],
     "kpf_attn21_backward_ld": [_P] * 9 + [C.c_int] * 6 + [C.c_float, C.c_float, _P],
     "kpf_gelu_backward": [_P, _P, _P, C.c_int, C.c_long, _P],
+    "kpf_row_gather_invert": [_P, _P, C.c_long] + [C.c_int] * 4 + [_P],
+    "kpf_row_gather_accum_f32": [_P] * 5 + [C.c_int] * 5 + [_P],
     "kpf_row_gather_bwd_f32": [_P] * 5 + [C.c_long] + [C.c_int] * 5 + [_P],
 }
 _LONG_SIGS = {  # entries returning a long

@@ -357,14 +357,14 @@ class TrainGraph:
         return self.bn_l(y.view(B, N, -1), p + ".1", out16=False)  # (summed with the other embeddings: kept fp32)
 
     @staticmethod
-    def gather_interp(feat, idx, clos):
+    def gather_interp(feat, idx, clos, inv=None):
         """feat [B, C, H, W] (channels_last memory: the row view below is free) -> [B, N, C]: the 4 nearest pixels' feature rows
         weighted by clos (model/model.py:368-376).  Feature maps with whole channel quads go through kpf_row_gather_fwd/_bwd_f32 (the
         backward adds in a fixed order); the 21 weight-logit channels (no gradient: detached by the caller) use torch.gather."""
         B, C = feat.shape[:2]
         N, K = idx.shape[1:]
         rows = feat.permute(0, 2, 3, 1).reshape(B, -1, C)
-        return row_gather(rows.float(), idx.int(), clos)  # (C % 4 != 0 — the 21 weight-logit channels, detached by the caller — and
+        return row_gather(rows.float(), idx.int(), clos, inv)  # (C % 4 != 0 — the 21 weight-logit channels, detached by the caller — and
         #                                                    shapes beyond the backward kernel's limits: torch.gather inside row_gather)
 
     @staticmethod
@@ -497,8 +497,8 @@ class TrainGraph:
               img_size, flip):
         from .training import GateMix, GeomGateUVD, JointHeatmap
         B, C, H, W = img_feat.shape
-        pf = self.gather_interp(img_feat, idx, clos)
-        pf_rgb = self.gather_interp(img_feat_rgb, idx, clos)
+        pf = self.gather_interp(img_feat, idx, clos, self.idx_inv)  # (the four feature samplings of a forward share one index tensor: inverted once)
+        pf_rgb = self.gather_interp(img_feat_rgb, idx, clos, self.idx_inv)
         pw = self.gather_interp(img_offset[:, J * 4:], idx, clos).detach()
         tok = self.pose_tokens(pw, joint_xyz, pcl, 0.8)  # [pw | pcl_joint2offset(joint, pcl) | 0 0 0]: 105 channels at the GEMM's width 108, no gradient
         x = add_relu(self.emb1d(p + ".pcl_feat_emb", pf), self.emb1d(p + ".pcl_xyz_emb", self.pcl4), self.emb1d(p + ".pcl_pose_emb", tok))
@@ -603,6 +603,8 @@ class TrainGraph:
         self.pcl4 = pad_rows(pcl, 4)                                         # the points at the width pcl_xyz_emb's GEMM reads (both blocks)
         self.zpad3 = torch.zeros(B, Fs, Fs, 3, device=dev)                   # the gate input's three zero channels (149 -> 152, both blocks)
         self.frows = None
+        from .training import ROW_GATHER_MAX_E, ROW_GATHER_MAX_P, row_gather_invert
+        self.idx_inv = row_gather_invert(index, Fs * Fs) if (N * 4 <= ROW_GATHER_MAX_E and Fs * Fs <= ROW_GATHER_MAX_P) else None
         img_down = None  # (F.interpolate(img, [Fs, Fs]) in the reference, model/model.py:401: computed there and never read)
         sws = []
         prev = None

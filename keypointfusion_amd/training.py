@@ -1652,15 +1652,17 @@ class BallGroup(torch.autograd.Function):
         B, N, Jn, Cc = ctx.shape
         P, R = N + Jn, Jn * 64
         st = torch.cuda.current_stream().cuda_stream
-        nws = lib.kpf_row_gather_ws_ints(B, P, R, 1)
+        nws = lib.kpf_row_gather_ws_ints(3 * B, P, R, 1)
+        ws = torch.empty(nws, device=idx.device, dtype=torch.int32)  # the three radii's index sets as 3B images: ONE inversion
+        L.check(lib.kpf_row_gather_invert(idx.data_ptr(), ws.data_ptr(), nws, 3 * B, P, R, 1, st), "kpf_row_gather_invert")
         dsrc = centre = None
         for i, d in enumerate((d0, d1, d2)):
             if d is None:
                 continue
             d = d.float().contiguous()
-            ws = torch.empty(nws, device=d.device, dtype=torch.int32)
             ds = torch.empty(B, P, Cc, device=d.device, dtype=torch.float32)
-            L.check(lib.kpf_row_gather_bwd_f32(d.data_ptr(), idx[i].data_ptr(), None, ds.data_ptr(), ws.data_ptr(), nws, B, P, R, 1, Cc, st), "kpf_row_gather_bwd_f32")
+            L.check(lib.kpf_row_gather_accum_f32(d.data_ptr(), ws.data_ptr() + 4 * i * B * (P + 1), ws.data_ptr() + 4 * (3 * B * (P + 1) + i * B * R), None, ds.data_ptr(),
+                                                 B, P, R, 1, Cc, st), "kpf_row_gather_accum_f32")
             dsrc = ds if dsrc is None else dsrc + ds
             centre = d if centre is None else centre + d
         if dsrc is None:
@@ -1680,7 +1682,8 @@ class RowGather(torch.autograd.Function):
     reference either): kpf_row_gather_bwd_f32 inverts the index list per image and adds in entry order — no atomics."""
 
     @staticmethod
-    def forward(ctx, src, idx, w):
+    def forward(ctx, src, idx, w, inv=None):
+        """inv: the index tensor's inversion (row_gather_invert(idx, P)) when several gathers share it — the backward then skips its own."""
         from . import lib as L
         src = src.contiguous()
         idx = idx.contiguous()
@@ -1691,23 +1694,28 @@ class RowGather(torch.autograd.Function):
         out = torch.empty(B, R, Cc, device=src.device, dtype=torch.float32)
         L.check(L.load().kpf_row_gather_fwd_f32(src.data_ptr(), idx.data_ptr(), w.data_ptr() if w is not None else None, out.data_ptr(), B, P, R, G, Cc,
                                                 torch.cuda.current_stream().cuda_stream), "kpf_row_gather_fwd_f32")
-        ctx.save_for_backward(idx, w)
+        ctx.save_for_backward(idx, w, inv)
         ctx.shape = (B, P, R, G, Cc)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         from . import lib as L
-        idx, w = ctx.saved_tensors
+        idx, w, inv = ctx.saved_tensors
         B, P, R, G, Cc = ctx.shape
         dout = dout.float().contiguous()
         dsrc = torch.empty(B, P, Cc, device=dout.device, dtype=torch.float32)
         lib = L.load()
+        st = torch.cuda.current_stream().cuda_stream
+        if inv is not None:
+            L.check(lib.kpf_row_gather_accum_f32(dout.data_ptr(), inv.data_ptr(), inv.data_ptr() + 4 * B * (P + 1), w.data_ptr() if w is not None else None, dsrc.data_ptr(),
+                                                 B, P, R, G, Cc, st), "kpf_row_gather_accum_f32")
+            return dsrc, None, None, None
         nws = lib.kpf_row_gather_ws_ints(B, P, R, G)
         ws = torch.empty(nws, device=dout.device, dtype=torch.int32)
         L.check(lib.kpf_row_gather_bwd_f32(dout.data_ptr(), idx.data_ptr(), w.data_ptr() if w is not None else None, dsrc.data_ptr(), ws.data_ptr(), nws,
-                                           B, P, R, G, Cc, torch.cuda.current_stream().cuda_stream), "kpf_row_gather_bwd_f32")
-        return dsrc, None, None
+                                           B, P, R, G, Cc, st), "kpf_row_gather_bwd_f32")
+        return dsrc, None, None, None
 
 
 def upsample2x_nhwc(x):
@@ -1718,7 +1726,21 @@ def maxpool3x3s2_nhwc(x):
     return MaxPool3x3s2NHWC.apply(x)
 
 
-def row_gather(src, idx, w=None):
+def row_gather_invert(idx, P):
+    """The inversion of an index tensor [B, R, G] over P source rows (kpf_row_gather_invert) for RowGather(inv=...): per image, the list of
+    gathered entries per source row in ascending entry order."""
+    from . import lib as L
+    lib = L.load()
+    idx = idx.contiguous()
+    B, R, G = idx.shape
+    assert idx.dtype == torch.int32
+    nws = lib.kpf_row_gather_ws_ints(B, P, R, G)
+    ws = torch.empty(nws, device=idx.device, dtype=torch.int32)
+    L.check(lib.kpf_row_gather_invert(idx.data_ptr(), ws.data_ptr(), nws, B, P, R, G, torch.cuda.current_stream().cuda_stream), "kpf_row_gather_invert")
+    return ws
+
+
+def row_gather(src, idx, w=None, inv=None):
     """Weighted row gather (RowGather).  Shapes outside the backward kernel's limits (more than 8192 gathered entries or 2048 source rows per
     image: 256x256 inputs, > 2048 points) are decided HERE, before autograd records a node, and take torch.gather — whose backward
     (index_add) is correct but adds with atomics, i.e. is not run-to-run bit-reproducible; the reference's sizes never get there."""
@@ -1727,7 +1749,7 @@ def row_gather(src, idx, w=None):
     if R * G > ROW_GATHER_MAX_E or P > ROW_GATHER_MAX_P or Cc % 4:
         g = torch.gather(src, 1, idx.long().reshape(B, R * G, 1).expand(-1, -1, Cc)).view(B, R, G, Cc)
         return (g * w.unsqueeze(-1)).sum(2) if w is not None else g.sum(2)
-    return RowGather.apply(src, idx, w)
+    return RowGather.apply(src, idx, w, inv)
 
 
 class Conv2dNHWC(torch.autograd.Function):

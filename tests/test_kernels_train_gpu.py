@@ -1166,3 +1166,22 @@ def test_gate_mix_matches_torch():
     assert float((sw.double() - swr).abs().max()) <= 1e-6 and float((gw.double() - gwr).abs().max()) <= 1e-6
     for x, xr, what in zip(a, r, ("d logits", "d gam", "d weight_dis", "d w_fc")):
         assert float((x.grad.double() - xr.grad).abs().max()) <= 3e-5 * max(1.0, float(xr.grad.abs().max())), what
+
+
+def test_row_gather_with_a_shared_inversion_is_bit_identical():
+    """RowGather(inv=row_gather_invert(idx, P)): the backward that reuses one inversion for several gathers returns the same bits as the one that inverts itself."""
+    from keypointfusion_amd import training as T
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(8)
+    B, P, R, G, Cc = 3, 1024, 700, 4, 128
+    src = torch.randn(B, P, Cc, generator=g).to(dev)
+    idx = torch.randint(0, P, (B, R, G), generator=g, dtype=torch.int32).to(dev)
+    w = torch.rand(B, R, G, generator=g).to(dev)
+    dout = torch.randn(B, R, Cc, generator=g).to(dev)
+    inv = T.row_gather_invert(idx, P)
+    grads = []
+    for use in (None, inv):
+        s_ = src.clone().requires_grad_(True)
+        T.row_gather(s_, idx, w, use).backward(dout)
+        grads.append(s_.grad)
+    assert torch.equal(grads[0], grads[1])
