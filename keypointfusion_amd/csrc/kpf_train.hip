@@ -914,6 +914,8 @@ extern "C" int kpf_gelu_backward(const void* dy, const void* x, void* dx, int dt
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 constexpr int AT_T = 21, AT_HD = 32;
+constexpr int AT_NT = 256;  // threads per (sample, head): every phase is a loop over 441 or 672 independent outputs, each computed by ONE thread in the same
+                            // sequential order whatever the thread count (round 4: 64 -> 256 threads; the kernels are latency chains of five phases)
 
 __device__ __forceinline__ unsigned hash32(unsigned x) {  // "lowbias32" integer hash: full avalanche in three multiplies
   x ^= x >> 16;
@@ -924,13 +926,13 @@ __device__ __forceinline__ unsigned hash32(unsigned x) {  // "lowbias32" integer
   return x;
 }
 
-__global__ __launch_bounds__(64) void attn21_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, float* __restrict__ ctx,
+__global__ __launch_bounds__(AT_NT) void attn21_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, float* __restrict__ ctx,
                                                         float* __restrict__ P, unsigned char* __restrict__ M, int H, int ld, float scale, float p_drop,
                                                         const long* __restrict__ rng, int call_id, int ldc) {
   __shared__ float sq[AT_T][AT_HD + 1], sk[AT_T][AT_HD + 1], sv[AT_T][AT_HD + 1], sp[AT_T][AT_T + 1];
   const int b = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
   const long row0 = (long)b * AT_T;
-  for (int i = lane; i < AT_T * AT_HD; i += 64) {
+  for (int i = lane; i < AT_T * AT_HD; i += AT_NT) {
     const int t = i / AT_HD, d = i % AT_HD;
     const long off = (row0 + t) * ld + h * AT_HD + d;
     sq[t][d] = q[off];
@@ -938,7 +940,7 @@ __global__ __launch_bounds__(64) void attn21_fwd_kernel(const float* __restrict_
     sv[t][d] = v[off];
   }
   __syncthreads();
-  for (int e = lane; e < AT_T * AT_T; e += 64) {
+  for (int e = lane; e < AT_T * AT_T; e += AT_NT) {
     const int i = e / AT_T, j = e % AT_T;
     float s = 0.f;
 #pragma unroll
@@ -963,7 +965,7 @@ __global__ __launch_bounds__(64) void attn21_fwd_kernel(const float* __restrict_
   const float keep_scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
   const unsigned thr = p_drop > 0.f ? (unsigned)fminf(p_drop * 4294967296.0f, 4294967295.0f) : 0u;
   const unsigned seed = rng ? (unsigned)rng[0] : 0u, ctr = rng ? (unsigned)rng[1] : 0u;
-  for (int e = lane; e < AT_T * AT_T; e += 64) {
+  for (int e = lane; e < AT_T * AT_T; e += AT_NT) {
     const int i = e / AT_T, j = e % AT_T;
     const float pv = sp[i][j];
     P[pbase + e] = pv;
@@ -973,7 +975,7 @@ __global__ __launch_bounds__(64) void attn21_fwd_kernel(const float* __restrict_
     sp[i][j] = keep ? pv * keep_scale : 0.f;
   }
   __syncthreads();
-  for (int e = lane; e < AT_T * AT_HD; e += 64) {
+  for (int e = lane; e < AT_T * AT_HD; e += AT_NT) {
     const int i = e / AT_HD, d = e % AT_HD;
     float s = 0.f;
 #pragma unroll
@@ -982,14 +984,14 @@ __global__ __launch_bounds__(64) void attn21_fwd_kernel(const float* __restrict_
   }
 }
 
-__global__ __launch_bounds__(64) void attn21_bwd_kernel(const float* __restrict__ dctx, const float* __restrict__ q, const float* __restrict__ k,
+__global__ __launch_bounds__(AT_NT) void attn21_bwd_kernel(const float* __restrict__ dctx, const float* __restrict__ q, const float* __restrict__ k,
                                                         const float* __restrict__ v, const float* __restrict__ P, const unsigned char* __restrict__ M,
                                                         float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv, int H, int ld, float scale,
                                                         float p_drop, int ldc) {
   __shared__ float sq[AT_T][AT_HD + 1], sk[AT_T][AT_HD + 1], sv[AT_T][AT_HD + 1], sg[AT_T][AT_HD + 1], sp[AT_T][AT_T + 1], sd[AT_T][AT_T + 1];
   const int b = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
   const long row0 = (long)b * AT_T;
-  for (int i = lane; i < AT_T * AT_HD; i += 64) {
+  for (int i = lane; i < AT_T * AT_HD; i += AT_NT) {
     const int t = i / AT_HD, d = i % AT_HD;
     const long off = (row0 + t) * ld + h * AT_HD + d;
     sq[t][d] = q[off];
@@ -1001,7 +1003,7 @@ __global__ __launch_bounds__(64) void attn21_bwd_kernel(const float* __restrict_
   const float keep_scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
   __syncthreads();
   // dP' = dctx V^T ; dP = dP' * mask ; sd <- dP, sp <- P' (dropped probabilities, for dV)
-  for (int e = lane; e < AT_T * AT_T; e += 64) {
+  for (int e = lane; e < AT_T * AT_T; e += AT_NT) {
     const int i = e / AT_T, j = e % AT_T;
     float s = 0.f;
 #pragma unroll
@@ -1012,7 +1014,7 @@ __global__ __launch_bounds__(64) void attn21_bwd_kernel(const float* __restrict_
   }
   __syncthreads();
   // dV[j][d] = sum_i P'[i][j] dctx[i][d]
-  for (int e = lane; e < AT_T * AT_HD; e += 64) {
+  for (int e = lane; e < AT_T * AT_HD; e += AT_NT) {
     const int j = e / AT_HD, d = e % AT_HD;
     float s = 0.f;
 #pragma unroll
@@ -1026,7 +1028,7 @@ __global__ __launch_bounds__(64) void attn21_bwd_kernel(const float* __restrict_
     for (int j = 0; j < AT_T; ++j) sd[lane][j] = sp[lane][j] * (sd[lane][j] - dot) * scale;
   }
   __syncthreads();
-  for (int e = lane; e < AT_T * AT_HD; e += 64) {
+  for (int e = lane; e < AT_T * AT_HD; e += AT_NT) {
     const int i = e / AT_HD, d = e % AT_HD;
     float a = 0.f, c = 0.f;
 #pragma unroll
@@ -1044,7 +1046,7 @@ extern "C" int kpf_attn21_forward(const float* q, const float* k, const float* v
                                   float scale, float p_drop, const long* rng, int call_id, void* stream) {
   KPF_REQUIRE(q && k && v && ctx && P && M && B > 0 && T == AT_T && hd == AT_HD && H > 0 && ld >= H * hd, "kpf_attn21_forward: needs 21 tokens and 32-wide heads");
   KPF_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || rng), "kpf_attn21_forward: dropout needs 0 <= p < 1 and the rng state");
-  hipLaunchKernelGGL(attn21_fwd_kernel, dim3(B * H), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), q, k, v, ctx, P, M, H, ld, scale, p_drop, rng, call_id, ld);
+  hipLaunchKernelGGL(attn21_fwd_kernel, dim3(B * H), dim3(AT_NT), 0, reinterpret_cast<hipStream_t>(stream), q, k, v, ctx, P, M, H, ld, scale, p_drop, rng, call_id, ld);
   return kpf_check_launch("kpf_attn21_forward");
 }
 
@@ -1054,20 +1056,20 @@ extern "C" int kpf_attn21_forward_ld(const float* q, const float* k, const float
                                      int ldc, float scale, float p_drop, const long* rng, int call_id, void* stream) {
   KPF_REQUIRE(q && k && v && ctx && P && M && B > 0 && T == AT_T && hd == AT_HD && H > 0 && ld >= H * hd && ldc >= H * hd, "kpf_attn21_forward_ld: needs 21 tokens and 32-wide heads");
   KPF_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || rng), "kpf_attn21_forward_ld: dropout needs 0 <= p < 1 and the rng state");
-  hipLaunchKernelGGL(attn21_fwd_kernel, dim3(B * H), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), q, k, v, ctx, P, M, H, ld, scale, p_drop, rng, call_id, ldc);
+  hipLaunchKernelGGL(attn21_fwd_kernel, dim3(B * H), dim3(AT_NT), 0, reinterpret_cast<hipStream_t>(stream), q, k, v, ctx, P, M, H, ld, scale, p_drop, rng, call_id, ldc);
   return kpf_check_launch("kpf_attn21_forward_ld");
 }
 extern "C" int kpf_attn21_backward_ld(const float* dctx, const float* q, const float* k, const float* v, const float* P, const unsigned char* M, float* dq, float* dk,
                                       float* dv, int B, int T, int H, int hd, int ld, int ldc, float scale, float p_drop, void* stream) {
   KPF_REQUIRE(dctx && q && k && v && P && M && dq && dk && dv && B > 0 && T == AT_T && hd == AT_HD && H > 0 && ld >= H * hd && ldc >= H * hd, "kpf_attn21_backward_ld: bad arguments");
-  hipLaunchKernelGGL(attn21_bwd_kernel, dim3(B * H), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), dctx, q, k, v, P, M, dq, dk, dv, H, ld, scale, p_drop, ldc);
+  hipLaunchKernelGGL(attn21_bwd_kernel, dim3(B * H), dim3(AT_NT), 0, reinterpret_cast<hipStream_t>(stream), dctx, q, k, v, P, M, dq, dk, dv, H, ld, scale, p_drop, ldc);
   return kpf_check_launch("kpf_attn21_backward_ld");
 }
 
 extern "C" int kpf_attn21_backward(const float* dctx, const float* q, const float* k, const float* v, const float* P, const unsigned char* M, float* dq, float* dk,
                                    float* dv, int B, int T, int H, int hd, int ld, float scale, float p_drop, void* stream) {
   KPF_REQUIRE(dctx && q && k && v && P && M && dq && dk && dv && B > 0 && T == AT_T && hd == AT_HD && H > 0 && ld >= H * hd, "kpf_attn21_backward: bad arguments");
-  hipLaunchKernelGGL(attn21_bwd_kernel, dim3(B * H), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), dctx, q, k, v, P, M, dq, dk, dv, H, ld, scale, p_drop, ld);
+  hipLaunchKernelGGL(attn21_bwd_kernel, dim3(B * H), dim3(AT_NT), 0, reinterpret_cast<hipStream_t>(stream), dctx, q, k, v, P, M, dq, dk, dv, H, ld, scale, p_drop, ld);
   return kpf_check_launch("kpf_attn21_backward");
 }
 
