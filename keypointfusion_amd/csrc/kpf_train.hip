@@ -1104,7 +1104,7 @@ __global__ __launch_bounds__(256) void bmm21_dx_kernel(const float* __restrict__
 extern "C" int kpf_bmm_small_k_dx(const float* A, const float* dOut, float* dX, int B, int J, int P, int C, void* stream) {
   KPF_REQUIRE(A && dOut && dX && B > 0 && J > 0 && J <= 64 && P > 0 && C > 0 && C % 4 == 0 && (long)J * C * 4 <= 64 * 1024, "kpf_bmm_small_k_dx: bad arguments");
   int gx = (int)(((long)P * (C / 4) + 255) / 256);
-  gx = gx > 32 ? 32 : gx;
+  gx = gx > 128 ? 128 : gx;  // (round 4: 32 -> 128 column blocks per sample: the kernel is a latency chain of 21 dependent row loads per output)
   hipLaunchKernelGGL(bmm21_dx_kernel, dim3(gx, B), dim3(256), (size_t)J * C * sizeof(float), reinterpret_cast<hipStream_t>(stream), A, dOut, dX, J, P, C);
   return kpf_check_launch("kpf_bmm_small_k_dx");
 }
