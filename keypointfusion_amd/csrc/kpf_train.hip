@@ -783,8 +783,8 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const TA* __restrict__ dy
   }
 }
 
-inline int ln_blocks(long rows) {  // ~4 rows per wave at least: few partials to add for the small (B x 21)-row tensors of the fusion head
-  long g = (rows + 15) / 16;
+inline int ln_blocks(long rows) {  // one row per wave for the small (B x 21)-row tensors of the fusion head (a row is a dependent chain of two wave
+  long g = (rows + 3) / 4;          // reductions: round 4 went from four rows per wave to one), at most 256 workgroups' partials to add
   return (int)(g < 1 ? 1 : (g > 256 ? 256 : g));
 }
 }  // namespace
