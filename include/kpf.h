@@ -41,6 +41,8 @@ extern "C" {
 #define KPF_W_SPLIT 512u       /* only `w` is split: fp32 activations are split in registers (any conv shape with Cin % 32 == 0)  */
 #define KPF_OUT_SPLIT 256u     /* `out` is written in the split format (N, out_ld, out_coff multiples of 32)                     */
 #define KPF_OUT_NCHW 32u       /* store out[b][n][oy][ox] (dense), ignoring out_ld/out_coff */
+#define KPF_ACT_GELU_SAVE 2048u /* with KPF_ACT_GELU (ABI 13): also store the pre-activation acc + bias to the buffer passed in the `res` slot (res_ld / res_coff describe
+                                  it; no residual is read) and use the exact erf GELU — the forward of a training Linear + GELU in one launch */
 #define KPF_RES_GELU_GRAD 1024u /* with KPF_RES_ADD (ABI 13): y = (acc + bias) * gelu'(res) instead of the sum — the data gradient of Linear(gelu(z)) towards z
                                   in the GEMM's epilogue, res = z (training step: pwconv2 / output.dense backward; dense 1x1 only) */
 

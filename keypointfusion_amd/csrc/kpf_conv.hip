@@ -106,9 +106,12 @@ __device__ __forceinline__ float gelu_of(float x) {
   else return gelu_erf(x);
 }
 
-enum { EPI_LIN = 0, EPI_GELU = 1, EPI_RES = 2, EPI_GGRAD = 3 };  // EPI_GGRAD (KPF_RES_GELU_GRAD): y = (acc + bias) * gelu'(res) — the data gradient of
+enum { EPI_LIN = 0, EPI_GELU = 1, EPI_RES = 2, EPI_GGRAD = 3, EPI_GELU2 = 4 };  // EPI_GELU2 (KPF_ACT_GELU_SAVE): out = gelu(z) AND z = acc + bias to a second buffer
+// (passed in the `res` slot): the forward of a training Linear whose GELU's backward needs the pre-activation — one launch instead of GEMM + GELU pass.
+//  // EPI_GGRAD (KPF_RES_GELU_GRAD): y = (acc + bias) * gelu'(res) — the data gradient of
 // `Linear(gelu(z))` with respect to z in the GEMM's epilogue (training step; res = z).  A separate epilogue value: the residual epilogues of the inference
 // kernels keep their code and registers.
+__device__ __forceinline__ float gelu_exact_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }  // (csrc/kpf_train.hip gelu_exact)
 __device__ __forceinline__ float gelu_grad_erf(float v) {  // d/dv [v Phi(v)] = Phi(v) + v phi(v)  (csrc/kpf_train.hip gelu_grad: same expression)
   const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
   return cdf + v * 0.3989422804014327f * __expf(-0.5f * v * v);
@@ -657,6 +660,17 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
         } else if (EPI == EPI_GELU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = gelu_of<ARITH>(v[e] + bv[e]);
+        } else if (EPI == EPI_GELU2) {
+          f32x4 z;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) z[e] = v[e] + bv[e];
+          if constexpr (H16) kpf_st4(reinterpret_cast<TH*>(const_cast<float*>(a.res)) + m * a.res_ld + a.res_coff + n, z);
+          else STORE4(const_cast<float*>(a.res) + m * a.res_ld + a.res_coff + n, z);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if constexpr (H16) z[e] = (float)(TH)z[e];  // (gelu of the value as stored: what a separate pass over the 16-bit tensor computes)
+            v[e] = gelu_exact_erf(z[e]);
+          }
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -707,6 +721,15 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
         if (n + e >= a.N) continue;
         float y = (SPLIT ? acc[i][j][e] * a.w_unscale : acc[i][j][e]) + (a.bias ? a.bias[n + e] : 0.f);
         if (EPI == EPI_GELU) y = gelu_of<ARITH>(y);
+        if (EPI == EPI_GELU2) {
+          if constexpr (H16) {
+            reinterpret_cast<TH*>(const_cast<float*>(a.res))[(long)m * a.res_ld + a.res_coff + n + e] = (TH)y;
+            y = (float)(TH)y;
+          } else {
+            const_cast<float*>(a.res)[(long)m * a.res_ld + a.res_coff + n + e] = y;
+          }
+          y = gelu_exact_erf(y);
+        }
         if (EPI == EPI_LIN && (fl & KPF_ACT_RELU)) y = fmaxf(y, 0.f);
         if (EPI == EPI_LIN && (fl & KPF_ACT_LEAKY)) y = fmaxf(y, 0.01f * y);
         if (EPI == EPI_RES) {
@@ -817,6 +840,11 @@ int launch_arith(ConvArgs& a, bool is1x1, hipStream_t st) {
   if (gelu) {
     if (!is1x1 || res) {
       kpf_set_error("kpf_conv2d_f32: GELU is only supported on 1x1 convolutions (Cin %% 32 == 0) without residual");
+      return KPF_EINVAL;
+    }
+    if (a.flags & KPF_ACT_GELU_SAVE) {
+      if constexpr (ARITH == ARITH_F32 && NS == 2) return launch_one<TM, TN, WM, WN, true, false, EPI_GELU2, ARITH, NS>(a, st);
+      kpf_set_error("kpf_conv2d_f32: KPF_ACT_GELU_SAVE needs fp32 arithmetic");
       return KPF_EINVAL;
     }
     return launch_one<TM, TN, WM, WN, true, false, EPI_GELU, ARITH, NS>(a, st);
@@ -1242,6 +1270,8 @@ int launch_arith_h16(ConvArgs& a, bool fast1x1, bool pointwise, hipStream_t st) 
       kpf_set_error("kpf_conv2d_h16: GELU is only supported on 1x1 convolutions without residual");
       return KPF_EINVAL;
     }
+    if (a.flags & KPF_ACT_GELU_SAVE)
+      return fast1x1 ? launch_one<TM, TN, WM, WN, true, false, EPI_GELU2, ARITH, NS>(a, st) : launch_one<TM, TN, WM, WN, false, false, EPI_GELU2, ARITH, NS>(a, st);
     return fast1x1 ? launch_one<TM, TN, WM, WN, true, false, EPI_GELU, ARITH, NS>(a, st) : launch_one<TM, TN, WM, WN, false, false, EPI_GELU, ARITH, NS>(a, st);
   }
   if (a.flags & KPF_RES_GELU_GRAD) {
@@ -1285,7 +1315,7 @@ static bool g8_preferred(const kpf_conv_desc* d) {
 /* 1 when kpf_conv2d_h16 runs this descriptor on gemm16_8ph_kernel, 0 when on igemm_h16_kernel (profile labels; same rule as the dispatcher) */
 extern "C" int kpf_conv2d_h16_uses_8ph(const kpf_conv_desc* d, int has_prologue) {
   static const bool no8 = getenv("KPF_NO_8PH") != nullptr;
-  return d && !no8 && d->groups <= 1 && !(d->flags & KPF_RES_GELU_GRAD) && g8_applies(d, has_prologue != 0) && g8_preferred(d) ? 1 : 0;
+  return d && !no8 && d->groups <= 1 && !(d->flags & (KPF_RES_GELU_GRAD | KPF_ACT_GELU_SAVE)) && g8_applies(d, has_prologue != 0) && g8_preferred(d) ? 1 : 0;
 }
 
 extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void* w, const float* bias, const float* pro_scale,
@@ -1311,6 +1341,8 @@ extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void
   KPF_REQUIRE(!((fl & KPF_RES_ADD) && (fl & (KPF_ACT_RELU | KPF_ACT_GELU | KPF_ACT_LEAKY))), "kpf_conv2d_h16: activation before a residual add is not supported");
   KPF_REQUIRE(!(fl & KPF_RELU_AFTER_RES) || (fl & KPF_RES_ADD), "kpf_conv2d_h16: RELU_AFTER_RES needs RES_ADD");
   KPF_REQUIRE(!(fl & KPF_RES_GELU_GRAD) || ((fl & KPF_RES_ADD) && !(fl & (KPF_RES_GAMMA | KPF_RELU_AFTER_RES | KPF_OUT_NCHW))), "kpf_conv2d_h16: RES_GELU_GRAD goes with RES_ADD alone");
+  KPF_REQUIRE(!(fl & KPF_ACT_GELU_SAVE) || ((fl & KPF_ACT_GELU) && !(fl & (KPF_RES_ADD | KPF_OUT_NCHW)) && res && kpf_aligned16(res) && d->res_coff >= 0 && d->res_coff + d->N <= d->res_ld),
+              "kpf_conv2d_h16: ACT_GELU_SAVE goes with ACT_GELU and a second output buffer in the res slot (res_ld / res_coff describe it)");
   KPF_REQUIRE((long)d->B * d->OH * d->OW < (1l << 31) && (long)d->B * d->IH * d->IW < (1l << 31), "kpf_conv2d_h16: too many pixels");
 
   ConvArgs a;  // staging-side fields in 4-byte words (2 elements), output-side fields in elements (see ARITH_BF16 above)
@@ -1375,7 +1407,7 @@ extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void
   // Round 4: the eight-phase 256 x 256 kernel (gemm16_8ph_kernel) for every dense 1x1 layer it covers with at least one full round of tiles
   const bool ok8 = g8_applies(d, pro_scale != nullptr);
   static const bool no8 = getenv("KPF_NO_8PH") != nullptr;  // tuning aid: A/B against the round-3 tile shapes
-  if (ok8 && !no8 && g8_preferred(d) && a.groups == 1 && !(fl & KPF_RES_GELU_GRAD)) best = 30;
+  if (ok8 && !no8 && g8_preferred(d) && a.groups == 1 && !(fl & (KPF_RES_GELU_GRAD | KPF_ACT_GELU_SAVE))) best = 30;
   static const int forced = []() { const char* e = getenv("KPF_FORCE_CFG16"); return e ? atoi(e) : -1; }();  // tuning aid only
   if (forced >= 0 && (forced != 30 || ok8)) best = forced;
   if (best == 30) return dtype == KPF_DT_BF16 ? launch_8ph<ARITH_BF16>(a, st) : launch_8ph<ARITH_F16>(a, st);
@@ -1417,6 +1449,8 @@ extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const flo
   KPF_REQUIRE(!((fl & KPF_ACT_LEAKY) && pro_scale), "kpf_conv2d_f32: LeakyReLU is not combined with an operand prologue");
   KPF_REQUIRE(!(fl & KPF_RELU_AFTER_RES) || (fl & KPF_RES_ADD), "kpf_conv2d_f32: RELU_AFTER_RES needs RES_ADD");
   KPF_REQUIRE(!(fl & KPF_RES_GELU_GRAD) || ((fl & KPF_RES_ADD) && !(fl & (KPF_RES_GAMMA | KPF_RELU_AFTER_RES | KPF_OUT_NCHW))), "kpf_conv2d_f32: RES_GELU_GRAD goes with RES_ADD alone");
+  KPF_REQUIRE(!(fl & KPF_ACT_GELU_SAVE) || ((fl & KPF_ACT_GELU) && !(fl & (KPF_RES_ADD | KPF_OUT_NCHW)) && res && kpf_aligned16(res) && d->res_coff >= 0 && d->res_coff + d->N <= d->res_ld),
+              "kpf_conv2d_f32: ACT_GELU_SAVE goes with ACT_GELU and a second output buffer in the res slot (res_ld / res_coff describe it)");
   KPF_REQUIRE((long)d->B * d->OH * d->OW < (1l << 31) && (long)d->B * d->IH * d->IW < (1l << 31), "kpf_conv2d_f32: too many pixels");
 
   ConvArgs a;

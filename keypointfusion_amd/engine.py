@@ -179,7 +179,7 @@ class PackedConv:
         return float(self.w.abs().sum(1).max())
 
 
-def conv(pc, x, out=None, flags=0, gamma=None, res=None, out_nchw=None, out_split=False):
+def conv(pc, x, out=None, flags=0, gamma=None, res=None, out_nchw=None, out_split=False, out2=None):
     """Launch kpf_conv2d_f32.  x: Act; out: Act (or None to allocate dense); res: Act."""
     lib = L.load()
     B = x.B
@@ -209,6 +209,11 @@ def conv(pc, x, out=None, flags=0, gamma=None, res=None, out_nchw=None, out_spli
     if res is not None:
         flags |= L.KPF_RES_ADD
         d.res_ld, d.res_coff = res.ld, res.coff
+    if out2 is not None:  # KPF_ACT_GELU_SAVE: the pre-activation goes to a second buffer, passed in the residual's slot (nothing is read from it)
+        assert res is None and (flags & L.KPF_ACT_GELU)
+        flags |= L.KPF_ACT_GELU_SAVE
+        d.res_ld, d.res_coff = out2.ld, out2.coff
+        res = out2
     if gamma is not None:
         flags |= L.KPF_RES_GAMMA
     w = pc.w

@@ -41,7 +41,7 @@ class Packed16:
         self.w = w.to(tdt).contiguous()
 
 
-def conv16(p16, x, kdt, out=None, flags=0, gamma=None, res=None, out_nchw=None):
+def conv16(p16, x, kdt, out=None, flags=0, gamma=None, res=None, out_nchw=None, out2=None):
     """kpf_conv2d_h16: x / out / res are 16-bit Acts (out_nchw: fp32 NCHW tensor)."""
     lib = L.load()
     pc = p16.pc
@@ -72,6 +72,11 @@ def conv16(p16, x, kdt, out=None, flags=0, gamma=None, res=None, out_nchw=None):
     if res is not None:
         flags |= L.KPF_RES_ADD
         d.res_ld, d.res_coff = res.ld, res.coff
+    if out2 is not None:  # KPF_ACT_GELU_SAVE: the pre-activation goes to a second buffer, passed in the residual's slot (nothing is read from it)
+        assert res is None and (flags & L.KPF_ACT_GELU)
+        flags |= L.KPF_ACT_GELU_SAVE
+        d.res_ld, d.res_coff = out2.ld, out2.coff
+        res = out2
     if gamma is not None:
         flags |= L.KPF_RES_GAMMA
     d.flags = flags

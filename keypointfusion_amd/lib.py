@@ -15,6 +15,7 @@ KPF_RES_ADD = 4
 KPF_RES_GAMMA = 8
 KPF_RELU_AFTER_RES = 16
 KPF_RES_GELU_GRAD = 1024
+KPF_ACT_GELU_SAVE = 2048
 KPF_OUT_NCHW = 32
 KPF_ACT_LEAKY = 64
 KPF_IN_SPLIT = 128

@@ -106,7 +106,7 @@ class TrainGraph:
         gradient is one tensor for two parameters)."""
         return ("pair:" + name[len(PAIR):]) if name.startswith(PAIR) else name
 
-    def linear(self, x, p_w, p_b=None, gelu_in=False, alias=False):
+    def linear(self, x, p_w, p_b=None, gelu_in=False, alias=False, gelu_out=False, g_pre=None):
         w = self.w(p_w)
         b = self.w(p_b) if p_b is not None else None
         G = self.groups_of(p_w)
@@ -114,7 +114,7 @@ class TrainGraph:
         assert G == 1 or (n % self.cmul == 0 and cin % self.cmul == 0), "paired Linear layers have whole channel groups"
         # (odd widths — the 3-wide joint heads, the 131-wide input of final_TR, model/model.py:99-104, 349 — are handled inside Conv2dNHWC: one pad
         #  launch on the activation / output gradient, weight gradient trimmed in its reduce; everything stays on the HIP kernels)
-        return linear_hip(x.contiguous(), w, b, self.prec, None, self.key_of(p_w), self.packs, G, gelu_in, alias)
+        return linear_hip(x.contiguous(), w, b, self.prec, None, self.key_of(p_w), self.packs, G, gelu_in, alias, gelu_out, g_pre)
 
     def bn(self, x, p, eps=1e-5):
         rm, rv = self.t[p + ".running_mean"], self.t[p + ".running_var"]
@@ -218,8 +218,10 @@ class TrainGraph:
     def convnext_block(self, p, x):
         y, x = dwconv7_nhwc(x.float(), self.w(p + ".dwconv.weight"), self.w(p + ".dwconv.bias"), self.key_of(p + ".dwconv.weight"), self.packs, True)  # (x: the skip path's handle)
         y = self.ln(y, p + ".norm.weight", p + ".norm.bias", 1e-6, to_gemm=True)
-        y = self.linear(y, p + ".pwconv1.weight", p + ".pwconv1.bias")
-        y = self.linear(y, p + ".pwconv2.weight", p + ".pwconv2.bias", gelu_in=True)  # pwconv2(gelu(.)): GELU forward here, GELU' in the data gradient's epilogue
+        # pwconv1 -> GELU -> pwconv2: the GELU forward rides in pwconv1's epilogue (pre-activation kept as a second output), its backward in pwconv2's
+        # data-gradient epilogue — no element-wise pass in either direction
+        z, g = self.linear(y, p + ".pwconv1.weight", p + ".pwconv1.bias", gelu_out=True)
+        y = self.linear(z, p + ".pwconv2.weight", p + ".pwconv2.bias", gelu_in=True, g_pre=g)
         return layer_scale_residual(x, self.w(p + ".gamma"), y, self.groups_of(p))  # (drop_path_rate is 0 in the reference's constructor call: identity)
 
     def convnext_features(self, p, x):
@@ -459,8 +461,8 @@ class TrainGraph:
         ctx, h = self_attention21(h, *wb, names, self.packs, heads, 1.0 / math.sqrt(hd), self.pd, self.rng(h.device), self.attn_calls)
         o = self.linear(ctx, p + ".attention.output.dense.weight", p + ".attention.output.dense.bias")
         h1 = self.dropout_add_ln(o, h, p + ".attention.output.LayerNorm.weight", p + ".attention.output.LayerNorm.bias", 1e-12)
-        it, h1 = self.linear(h1, p + ".intermediate.dense.weight", p + ".intermediate.dense.bias", alias=True)
-        o2 = self.linear(it, p + ".output.dense.weight", p + ".output.dense.bias", gelu_in=True)  # output.dense(gelu(.))
+        it, g, h1 = self.linear(h1, p + ".intermediate.dense.weight", p + ".intermediate.dense.bias", alias=True, gelu_out=True)
+        o2 = self.linear(it, p + ".output.dense.weight", p + ".output.dense.bias", gelu_in=True, g_pre=g)  # output.dense(gelu(.)): GELU in both GEMMs' epilogues
         return self.dropout_add_ln(o2, h1, p + ".output.LayerNorm.weight", p + ".output.LayerNorm.bias", 1e-12)
 
     def kp_interaction_tr(self, p, x):

@@ -685,7 +685,7 @@ class PackCache:
         L.check(lib.kpf_pack_conv_weights_multi(self.table.data_ptr(), len(self.entries), self.total_blocks, st), "kpf_pack_conv_weights_multi")
 
 
-def _conv_any(pc, x4, prec, out_ld=None, res=None, flags=0):
+def _conv_any(pc, x4, prec, out_ld=None, res=None, flags=0, out2=None):
     """engine.conv (fp32) or engine16.conv16 (bf16 / f16) on an NHWC tensor [B, H, W, C]; returns the NHWC output tensor.  A GroupedPack
     (G convolutions over channel-stacked activations, one launch): x4 is [B, H, W, G*Cin], the result [B, OH, OW, G*N].  out_ld > N: the result
     is [B, OH, OW, out_ld] with only the first N channels written."""
@@ -722,15 +722,17 @@ def _conv_any(pc, x4, prec, out_ld=None, res=None, flags=0):
         ob = torch.empty(B * OH * OW * G * pc.N, device=x4.device, dtype=xb.dtype)
         oa = Act(ob, B, OH, OW, pc.N, ld=G * pc.N)
         ra = None if res is None else Act(res.to(xb.dtype).contiguous().view(-1), B, OH, OW, pc.N, ld=G * pc.N)  # (out = conv + res: the residual epilogue)
-        conv(pc, xa, out=oa, res=ra, flags=flags) if prec == "f32" else conv16(pc.as16(tdt), xa, kdt, out=oa, res=ra, flags=flags)
+        o2 = None if out2 is None else Act(out2.view(-1), B, OH, OW, pc.N, ld=G * pc.N)  # (second output of a GELU epilogue: the pre-activation)
+        conv(pc, xa, out=oa, res=ra, flags=flags, out2=o2) if prec == "f32" else conv16(pc.as16(tdt), xa, kdt, out=oa, res=ra, flags=flags, out2=o2)
         return ob.view(B, OH, OW, G * pc.N)
     ra = None
     if res is not None:
         ra = Act(res.to(xb.dtype).contiguous().view(-1), res.shape[0], res.shape[1], res.shape[2], res.shape[3])
+    o2 = None if out2 is None else Act(out2.view(-1), out2.shape[0], out2.shape[1], out2.shape[2], out2.shape[3])
     if prec == "f32":
-        out = conv(pc, Act(xb, B, H, W, Cc, ld=xld), res=ra, flags=flags)
+        out = conv(pc, Act(xb, B, H, W, Cc, ld=xld), res=ra, flags=flags, out2=o2)
     else:
-        out = conv16(pc.as16(tdt), Act(xb, B, H, W, Cc), kdt, res=ra, flags=flags)
+        out = conv16(pc.as16(tdt), Act(xb, B, H, W, Cc), kdt, res=ra, flags=flags, out2=o2)
     return out.buf.view(out.B, out.H, out.W, out.C)
 
 
@@ -1763,7 +1765,8 @@ class Conv2dNHWC(torch.autograd.Function):
     Linear layers are the 1x1 case on a [rows, 1, 1, K] view."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, prec="f32", w16=None, key=None, cache=None, groups=1, res=None, gelu_in=False, alias=False):
+    def forward(ctx, x, weight, bias, stride, pad, prec="f32", w16=None, key=None, cache=None, groups=1, res=None, gelu_in=False, alias=False, gelu_out=False,
+                g_pre=None):
         """prec "bf16" / "f16": operands rounded to 16 bits, fp32 accumulation on the 16-bit MFMA (kpf_conv2d_h16), 16-bit output;
         the weight stays the fp32 master copy and receives an fp32 gradient.  w16: the weight already rounded to the compute type
         (same shape; TrainGraph casts all of them once per step) — the packs are then built from it without per-layer casts.
@@ -1775,7 +1778,9 @@ class Conv2dNHWC(torch.autograd.Function):
         97-104) with x the PRE-activation: gelu runs here (kpf_gelu_forward; its output is also what the weight gradient multiplies) and the backward
         returns d x = (dY W) * gelu'(x) from the data-gradient GEMM's own epilogue (KPF_RES_GELU_GRAD) — no separate GELU-backward pass.
         alias: also return x itself; a second consumer of x (the residual path around a feed-forward) that reads the alias hands its gradient to THIS
-        backward, where it rides in the data-gradient GEMM's residual epilogue (dense stride-1 layers without gelu_in)."""
+        backward, where it rides in the data-gradient GEMM's residual epilogue (dense stride-1 layers without gelu_in).
+        gelu_out: returns (z, gelu(z)) with z = x W^T + b from ONE launch (KPF_ACT_GELU_SAVE: the GEMM's epilogue stores both); gelu(z) carries no
+        gradient — hand it to the following layer as g_pre together with gelu_in=True (that layer then skips its own GELU pass and returns d z)."""
         assert x.is_cuda and x.dim() == 4
         B, H, W, Cin = x.shape
         N, Cw, KH, KW = weight.shape
@@ -1799,9 +1804,10 @@ class Conv2dNHWC(torch.autograd.Function):
                 pc = DevPack.packed(weight, bias, 0, prec, stride=1, pad=0, patchify=False)
             y = _conv_any(_OddPack(pc, cpad), xc, prec)
             ctx.pack = (key, cache)
-            assert res is None and not gelu_in and not alias
+            assert res is None and not gelu_in and not alias and not gelu_out
             ctx.odd = (Cin, cpad, npad)
             ctx.save_for_backward(xc, weight, None)
+            ctx.alias = ctx.gelu_out = False
             ctx.w16, ctx.x_dtype = None, x.dtype
             ctx.conf = (stride, pad, False, bias is not None, prec)
             ctx.bias_ptr = bias.data_ptr() if bias is not None else None
@@ -1822,8 +1828,27 @@ class Conv2dNHWC(torch.autograd.Function):
             from . import lib as L
             assert KH == 1 and KW == 1 and stride == 1 and pad == 0 and xc.numel() % 4 == 0, "gelu_in: Linear layers"
             z = xc.contiguous()
-            xc = torch.empty_like(z)
-            L.check(L.load().kpf_gelu_forward(z.data_ptr(), xc.data_ptr(), _KDT[z.dtype], z.numel(), torch.cuda.current_stream().cuda_stream), "kpf_gelu_forward")
+            if g_pre is not None:  # gelu(z) came out of the producing GEMM's epilogue (gelu_out there)
+                assert g_pre.shape == z.shape and g_pre.dtype == z.dtype
+                xc = g_pre.detach().contiguous()
+            else:
+                xc = torch.empty_like(z)
+                L.check(L.load().kpf_gelu_forward(z.data_ptr(), xc.data_ptr(), _KDT[z.dtype], z.numel(), torch.cuda.current_stream().cuda_stream), "kpf_gelu_forward")
+        if gelu_out:
+            from . import lib as L
+            assert KH == 1 and KW == 1 and stride == 1 and pad == 0 and res is None and groups * 0 == 0, "gelu_out: Linear layers"
+            zo = torch.empty(B, H, W, N, device=x.device, dtype=xc.dtype)
+            y = _conv_any(pc, xc, prec, flags=L.KPF_ACT_GELU, out2=zo)
+            ctx.res_dtype, ctx.alias, ctx.gelu_out = None, bool(alias), True
+            ctx.save_for_backward(xc, weight, z)
+            ctx.w16 = w16 if use16 else None
+            ctx.x_dtype = x.dtype
+            ctx.conf = (stride, pad, patch, bias is not None, prec)
+            ctx.bias_ptr = bias.data_ptr() if bias is not None else None
+            ctx.mark_non_differentiable(y)
+            ctx.set_materialize_grads(False)
+            return (zo, y, x.view(x.shape)) if alias else (zo, y)
+        ctx.gelu_out = False
         y = _conv_any(pc, xc, prec, res=res)
         ctx.res_dtype = None if res is None else res.dtype
         ctx.alias = bool(alias)
@@ -1838,10 +1863,11 @@ class Conv2dNHWC(torch.autograd.Function):
         return (y, x.view(x.shape)) if alias else y
 
     @staticmethod
-    def backward(ctx, dy, g_alias=None):
+    def backward(ctx, dy, g2=None, g3=None):
+        g_alias = (g3 if getattr(ctx, "gelu_out", False) else g2) if ctx.alias else None  # (outputs: y [, gelu(y) without gradient] [, the alias of x])
         x, weight, z = ctx.saved_tensors
         if dy is None:  # (only the alias was used)
-            return (g_alias,) + (None,) * 12
+            return (g_alias,) + (None,) * 14
         if g_alias is not None:
             assert z is None
             gg_alias = dict(res=g_alias.to(x.dtype).contiguous().view(x.shape))
@@ -1879,7 +1905,7 @@ class Conv2dNHWC(torch.autograd.Function):
                 L.check(lib.kpf_conv2d_wgrad_groups(dyp.data_ptr(), x.data_ptr(), _KDT[tdt], dw.data_ptr(), db.data_ptr() if want_db else None, ws.data_ptr(), nws, 1,
                                                     B, H, W, cpad, cpad, H, W, npad, npad, 1, 1, 1, 1, 0, 0, Cw, N, torch.cuda.current_stream().cuda_stream),
                         "kpf_conv2d_wgrad_groups")
-            return dx, dw, db, None, None, None, None, None, None, None, None, None, None
+            return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None, None
         if G > 1:  # channel-stacked groups: the same three GEMMs, one launch each for all groups
             key, cache = ctx.pack
             n, wd = N // G, weight.detach()
@@ -1896,7 +1922,7 @@ class Conv2dNHWC(torch.autograd.Function):
                 dx = dx.to(ctx.x_dtype)
             if ctx.needs_input_grad[1]:
                 dw, db = conv_wgrad_hip(dy, x, weight.shape, stride, pad, has_bias and ctx.needs_input_grad[2], groups=G)
-            return dx, dw, db, None, None, None, None, None, None, None, dres, None, None
+            return dx, dw, db, None, None, None, None, None, None, None, dres, None, None, None, None
         if ctx.needs_input_grad[0]:
             wsrc = ctx.w16 if ctx.w16 is not None else weight.detach()
             npad = (N + cmul - 1) // cmul * cmul
@@ -1933,7 +1959,7 @@ class Conv2dNHWC(torch.autograd.Function):
                 grp.add(ctx.pack[0], dyc, xc, dw, db, ctx.bias_ptr if want_db else None)
             else:
                 dw, db = conv_wgrad_hip(dy, x, weight.shape, stride, pad, want_db)
-            return dx, dw, db, None, None, None, None, None, None, None, dres, None, None
+            return dx, dw, db, None, None, None, None, None, None, None, dres, None, None, None, None
         if ctx.needs_input_grad[1]:
             xw = x if prec == "f32" else x.to(_TDT[prec])  # weight gradient in the compute precision, handed to the fp32 master weight
             dyw = dy if prec == "f32" else dy.to(_TDT[prec])
@@ -1943,7 +1969,7 @@ class Conv2dNHWC(torch.autograd.Function):
                 dw = torch.nn.grad.conv2d_weight(xw.permute(0, 3, 1, 2), weight.shape, dyw.permute(0, 3, 1, 2), stride=stride, padding=pad).float()
         if has_bias and ctx.needs_input_grad[2]:
             db = dy.float().view(-1, N).sum(0)
-        return dx, dw, db, None, None, None, None, None, None, None, dres, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, dres, None, None, None, None
 
 
 def _dgrad_pack(ctx, wsrc, mode, prec, **kw):
@@ -1954,16 +1980,20 @@ def _dgrad_pack(ctx, wsrc, mode, prec, **kw):
 
 
 def conv2d_nhwc(x, weight, bias=None, stride=1, pad=0, prec="f32", w16=None, key=None, cache=None, groups=1, res=None):
-    return Conv2dNHWC.apply(x, weight, bias, stride, pad, prec, w16, key, cache, groups, res, False, False)
+    return Conv2dNHWC.apply(x, weight, bias, stride, pad, prec, w16, key, cache, groups, res, False, False, False, None)
 
 
-def linear_hip(x, weight, bias=None, prec="f32", w16=None, key=None, cache=None, groups=1, gelu_in=False, alias=False):
+def linear_hip(x, weight, bias=None, prec="f32", w16=None, key=None, cache=None, groups=1, gelu_in=False, alias=False, gelu_out=False, g_pre=None):
     """nn.Linear on rows [..., K] through the same Function (a 1x1 convolution over a [rows, 1, 1, K] view); groups: see Conv2dNHWC
     (x [..., G*K], weight [G*N, K])."""
     K = x.shape[-1]
     Kw = weight.shape[-1]
     y = Conv2dNHWC.apply(x.reshape(-1, 1, 1, K), weight.reshape(weight.shape[0], Kw, 1, 1), bias, 1, 0, prec,
-                         w16.reshape(weight.shape[0], Kw, 1, 1) if w16 is not None else None, key, cache, groups, None, gelu_in, alias)
+                         w16.reshape(weight.shape[0], Kw, 1, 1) if w16 is not None else None, key, cache, groups, None, gelu_in, alias, gelu_out,
+                         g_pre.reshape(-1, 1, 1, K) if g_pre is not None else None)
+    if gelu_out:
+        outs = (y[0].view(*x.shape[:-1], weight.shape[0]), y[1].view(*x.shape[:-1], weight.shape[0]))
+        return outs + (y[2].view(x.shape),) if alias else outs
     if alias:
         return y[0].view(*x.shape[:-1], weight.shape[0]), y[1].view(x.shape)
     return y.view(*x.shape[:-1], weight.shape[0])

@@ -1185,3 +1185,31 @@ def test_row_gather_with_a_shared_inversion_is_bit_identical():
         T.row_gather(s_, idx, w, use).backward(dout)
         grads.append(s_.grad)
     assert torch.equal(grads[0], grads[1])
+
+
+@pytest.mark.parametrize("prec,G", [("f32", 1), ("bf16", 1), ("bf16", 2)])
+def test_linear_with_gelu_forward_in_its_epilogue(prec, G):
+    """Conv2dNHWC(gelu_out=True) (round 4: KPF_ACT_GELU_SAVE): (z, gelu(z)) from one GEMM launch; chained with the next layer's gelu_in / g_pre the pair
+    Linear -> GELU -> Linear equals the three-launch form, forward and every gradient."""
+    from keypointfusion_amd import training as T
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(19)
+    M, K, Hd = 2048, 96, 384
+    tdt = torch.float32 if prec == "f32" else torch.bfloat16
+    x = torch.randn(M, G * K, generator=g).to(dev).to(tdt)
+    w1, b1 = (torch.randn(G * Hd, K, generator=g) * K ** -0.5).to(dev), torch.randn(G * Hd, generator=g).to(dev)
+    w2, b2 = (torch.randn(G * K, Hd, generator=g) * Hd ** -0.5).to(dev), torch.randn(G * K, generator=g).to(dev)
+    dy = torch.randn(M, G * K, generator=g).to(dev).to(tdt)
+    res = []
+    for fused in (True, False):
+        t = [v.clone().requires_grad_(True) for v in (x, w1, b1, w2, b2)]
+        if fused:
+            z, gz = T.linear_hip(t[0], t[1], t[2], prec, None, None, None, G, False, False, True)
+            y = T.linear_hip(z, t[3], t[4], prec, None, None, None, G, True, False, False, gz)
+        else:
+            y = T.linear_hip(T.gelu_rows(T.linear_hip(t[0], t[1], t[2], prec, None, None, None, G)), t[3], t[4], prec, None, None, None, G)
+        y.backward(dy)
+        res.append([y.detach()] + [v.grad for v in t])
+    tol = 3e-6 if prec == "f32" else 1.5e-2
+    for a, r, what in zip(res[0], res[1], ("y", "dx", "dw1", "db1", "dw2", "db2")):
+        assert float((a.float() - r.float()).abs().max()) <= tol * max(1.0, float(r.float().abs().max())), what
