@@ -562,7 +562,7 @@ int kpf_drop_add_ln_backward(const float* dy, const float* xs, const float* mean
  * [rows / G][G*C] tensor, gamma / dgamma hold [G][C]); ws_floats >= kpf_layer_scale_ws_floats(rows, G*C).  The forward needs no twin
  * (kpf_layer_scale_forward with C := G*C). */
 int kpf_layer_scale_backward_g(const float* g, const void* y, int y_dtype, const float* gamma, void* dy, float* dgamma, float* ws, long ws_floats,
-                               long rows, int C, int G, void* stream);
+                               long rows, int C, int G, kpf_colsum_desc* desc /* nullable: as kpf_layer_scale_backward_partial */, void* stream);
 int kpf_layer_scale_backward_partial(const float* g, const void* y, int y_dtype, const float* gamma, void* dy, float* dgamma, float* ws, long ws_floats,
                                      long rows, int C, kpf_colsum_desc* desc, void* stream);
 int kpf_colsum_reduce_grouped(const kpf_colsum_desc* descs, int n, void* stream);

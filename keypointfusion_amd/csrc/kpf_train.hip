@@ -1214,11 +1214,11 @@ extern "C" int kpf_layer_scale_backward(const float* g, const void* y, int y_dty
 }
 
 extern "C" int kpf_layer_scale_backward_g(const float* g, const void* y, int y_dtype, const float* gamma, void* dy, float* dgamma, float* ws, long ws_floats,
-                                          long rows, int C, int G, void* stream) {
+                                          long rows, int C, int G, kpf_colsum_desc* desc, void* stream) {
   KPF_REQUIRE(g && y && gamma && dy && dgamma && ws && rows > 0 && C > 0 && C % 4 == 0 && C <= 256 * LN_MAXQ, "kpf_layer_scale_backward_g: bad arguments (C <= 1024)");
   KPF_REQUIRE((G == 1 || G == 2 || G == 4) && rows % G == 0, "kpf_layer_scale_backward_g: G must be 1, 2 or 4 and divide the row count");
   KPF_REQUIRE(ws_floats >= kpf_layer_scale_ws_floats(rows, G * C), "kpf_layer_scale_backward_g: workspace too small");
-#define CALL(T) layer_scale_bwd_launch<T>(g, y, gamma, dy, dgamma, ws, rows, C, stream, nullptr, G)
+#define CALL(T) layer_scale_bwd_launch<T>(g, y, gamma, dy, dgamma, ws, rows, C, stream, desc, G)
   KPF_DISPATCH_DT(y_dtype, "kpf_layer_scale_backward_g", CALL);
 #undef CALL
 }

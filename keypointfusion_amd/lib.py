@@ -139,7 +139,7 @@ _SIGS = {
     "kpf_layer_scale_backward": [_P, _P, C.c_int, _P, _P, _P, _P, C.c_long, C.c_long, C.c_int, _P],
     "kpf_drop_add_ln_forward": [_P] * 9 + [C.c_long, C.c_int, C.c_float, C.c_float, _P, C.c_int, _P],
     "kpf_drop_add_ln_backward": [_P] * 11 + [C.c_long, C.c_long, C.c_int, C.c_float, C.c_void_p, _P],
-    "kpf_layer_scale_backward_g": [_P, _P, C.c_int, _P, _P, _P, _P, C.c_long, C.c_long, C.c_int, C.c_int, _P],
+    "kpf_layer_scale_backward_g": [_P, _P, C.c_int, _P, _P, _P, _P, C.c_long, C.c_long, C.c_int, C.c_int, C.c_void_p, _P],
     "kpf_layer_scale_backward_partial": [_P, _P, C.c_int, _P, _P, _P, _P, C.c_long, C.c_long, C.c_int, C.POINTER(ColsumDesc), _P],
     "kpf_ln_train_backward_partial": [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, C.c_long, C.c_long, C.c_int, C.POINTER(ColsumDesc), _P],
     "kpf_colsum_reduce_grouped": [C.POINTER(ColsumDesc), C.c_int, _P],

@@ -199,8 +199,12 @@ class _LayerScaleResidual(torch.autograd.Function):
         st = torch.cuda.current_stream().cuda_stream
         if ctx.groups > 1:
             G = ctx.groups
+            grp = DeferredParamGrads.wants_colsum(gm)
+            desc = L.ColsumDesc() if grp is not None else None
             L.check(lib.kpf_layer_scale_backward_g(g.data_ptr(), y.data_ptr(), _KDT[y.dtype], gm.data_ptr(), dy.data_ptr(), dgamma.data_ptr(), ws.data_ptr(), nws,
-                                                   rows * G, Cc // G, G, st), "kpf_layer_scale_backward_g")
+                                                   rows * G, Cc // G, G, C.byref(desc) if desc is not None else None, st), "kpf_layer_scale_backward_g")
+            if grp is not None:
+                grp.add_colsum(gm, desc, ws, dgamma)
             return g, dgamma, dy, None
         grp = DeferredParamGrads.wants_colsum(gm)
         if grp is not None:  # d gamma: reduced with every other layer's after backward
@@ -855,24 +859,42 @@ class DeferredParamGrads:
         g = DeferredParamGrads.active
         if g is None:
             return None
-        p = g.by_ptr.get(weight.data_ptr())
-        # (a parameter that already holds a gradient would make AccumulateGrad ADD the still-unwritten tensor: not deferred)
-        if not (p is not None and p.numel() == weight.numel() and p.grad is None):
+
+        def whole(ptr):
+            """the parameter(s) that make up weight.numel() elements from `ptr` on: one parameter, or the adjacent parameters of a paired tensor
+            (training.pair_params: the halves of the gradient are adopted as views of the one deferred tensor) — all without a gradient yet"""
+            n, got, ps = weight.numel(), 0, []
+            while got < n:
+                q = g.by_ptr.get(ptr + 4 * got)
+                # (a parameter that already holds a gradient would make AccumulateGrad ADD the still-unwritten tensor: not deferred)
+                if q is None or q.grad is not None or q.dtype != torch.float32 or got + q.numel() > n:
+                    return None
+                ps.append(q)
+                got += q.numel()
+            return ps
+
+        if whole(weight.data_ptr()) is None or (bias_ptr is not None and whole(bias_ptr) is None):
             return None
-        if bias_ptr is not None:
-            bp = g.by_ptr.get(bias_ptr)
-            if bp is None or bp.numel() != weight.numel() or bp.grad is not None:
-                return None
         return g
+
+    def _parts(self, ptr, n):
+        """[(parameter, byte offset)] covering n fp32 elements of parameter storage from ptr on (see wants_colsum)."""
+        out, got = [], 0
+        while got < n:
+            q = self.by_ptr[ptr + 4 * got]
+            out.append((q, 4 * got))
+            got += q.numel()
+        return out
 
     def add_colsum(self, weight, desc, ws, out, bias_ptr=None, bias_out_ptr=None):
         key = ("colsum", weight.data_ptr())
         if key in self.seen:
             raise RuntimeError("DeferredParamGrads: a normalisation parameter receives a second gradient in one backward pass")
         self.seen.add(key)
-        self.colsums.append((desc, ws, weight.data_ptr(), out.data_ptr()))  # (ws stays referenced; of the output only the address)
+        self.colsums.append((desc, ws, weight.data_ptr(), out.data_ptr(), weight.numel()))  # (ws stays referenced; of the output only the address)
         if bias_ptr is not None:
-            self.biases.append(("a LayerNorm", bias_ptr, bias_out_ptr))  # (adoption of the bias row is verified like a Linear's bias)
+            for q, off in self._parts(bias_ptr, weight.numel()):  # (adoption of the bias row is verified like a Linear's bias; a paired bias: per half)
+                self.biases.append(("a LayerNorm", q.data_ptr(), bias_out_ptr + off))
 
     @staticmethod
     def wants(key, cache, dy, x, kh, kw, stride, pad):
@@ -902,7 +924,7 @@ class DeferredParamGrads:
         from . import lib as L
         items, colsums, biases, self.items, self.colsums, self.biases, self.seen = self.items, self.colsums, self.biases, [], [], [], set()
         # the parameters whose gradients this pass deferred (GraphedTrainStep keeps them out of the buckets that are reduced DURING backward)
-        self.last_deferred = ([self.named[k] for k, *_ in items if k in self.named] + [self.by_ptr[c[2]] for c in colsums if c[2] in self.by_ptr] +
+        self.last_deferred = ([self.named[k] for k, *_ in items if k in self.named] + [q for c in colsums if c[2] in self.by_ptr for q, _ in self._parts(c[2], c[4])] +
                               [self.by_ptr[b[1]] for b in biases if b[1] in self.by_ptr])
         if not items and not colsums:
             return
@@ -915,10 +937,10 @@ class DeferredParamGrads:
             p = self.named.get(key)
             if p is None or p.grad is None or p.grad.data_ptr() != pw:
                 raise RuntimeError(msg % repr(key))
-        for _, _, wptr, optr in colsums:
-            p = self.by_ptr.get(wptr)
-            if p is None or p.grad is None or p.grad.data_ptr() != optr:
-                raise RuntimeError(msg % ("a normalisation parameter" if p is None else "a %s normalisation parameter" % (tuple(p.shape),)))
+        for _, _, wptr, optr, n in colsums:
+            for p, off in (self._parts(wptr, n) if wptr in self.by_ptr else [(None, 0)]):
+                if p is None or p.grad is None or p.grad.data_ptr() != optr + off:
+                    raise RuntimeError(msg % ("a normalisation parameter" if p is None else "a %s normalisation parameter" % (tuple(p.shape),)))
         for key, bptr, optr in biases:
             p = self.by_ptr.get(bptr)
             if p is None or p.grad is None or p.grad.data_ptr() != optr:
@@ -1208,8 +1230,13 @@ class LayerNormRows(torch.autograd.Function):
         ws = torch.empty(nws, device=x.device, dtype=torch.float32)
         st = torch.cuda.current_stream().cuda_stream
         if G > 1:
+            grp = DeferredParamGrads.wants_colsum(w, ctx.bias_ptr)  # (paired parameters: both halves are checked and adopted)
+            desc = L.ColsumDesc() if grp is not None else None
             L.check(lib.kpf_ln_train_backward_g(dy.data_ptr(), _KDT[dy.dtype], x.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), w.data_ptr(), dx.data_ptr(),
-                                                dwb[0].data_ptr(), dwb[1].data_ptr(), ws.data_ptr(), nws, rows, Cc, G, None, st), "kpf_ln_train_backward_g")
+                                                dwb[0].data_ptr(), dwb[1].data_ptr(), ws.data_ptr(), nws, rows, Cc, G, C.byref(desc) if desc is not None else None, st),
+                    "kpf_ln_train_backward_g")
+            if grp is not None:
+                grp.add_colsum(w, desc, ws, dwb, ctx.bias_ptr, dwb[1].data_ptr())
             return dx, dwb[0], dwb[1], None, None, None
         grp = DeferredParamGrads.wants_colsum(w, ctx.bias_ptr)
         if grp is not None:  # d gamma / d beta: reduced with every other layer's after backward
