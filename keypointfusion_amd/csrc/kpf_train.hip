@@ -517,29 +517,35 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const kpf_pack_
   // d.reserved != 0: the destination rows are `reserved` elements apart (> Kp) — this operand fills a column range [dst, dst + Kp) of a wider,
   // stacked matrix (the q | k | v data-gradient operand of training.SelfAttention21); only those Kp columns are written.
   const long dld = d.reserved ? d.reserved : d.Kp;
-  if (d.mode == 1 && d.KH * d.KW == 1 && d.src_dtype == KPF_DT_F32) {
-    // 1x1 data-gradient operand = the transpose of the weight: 32 x 32 tiles through LDS, both sides coalesced
-    // (blocks of such a descriptor: ceil(rows / 32) * ceil(Kp / 32), see training.PackCache)
-    __shared__ float tl[32][33];
-    const int tiles_k = (d.Kp + 31) / 32;
+  if (d.mode == 1 && d.KH * d.KW == 1 && d.src_dtype == KPF_DT_F32 && (d.Cin & 3) == 0 && (d.Kp & 3) == 0) {
+    // 1x1 data-gradient operand = the transpose of the weight: 64 x 64 tiles through LDS, 16-byte reads of the weight's rows, 4-element (8- / 16-byte)
+    // writes of the operand's rows (blocks of such a descriptor: ceil(rows / 64) * ceil(Kp / 64), see training.PackCache; round 4: 32 x 32 tiles
+    // with scalar accesses before — 128 us of the refresh launch for the 260 operands of a ConvNeXt-T iteration)
+    __shared__ float tl[64][65];
+    const int tiles_k = (d.Kp + 63) / 64;
     const int t = b - d.first_block, tr = t / tiles_k, tc = t - tr * tiles_k;
-    const int x = threadIdx.x & 31, y8 = threadIdx.x >> 5;
+    const int q = threadIdx.x & 15, r16 = threadIdx.x >> 4;
     const float* w = static_cast<const float*>(d.src);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const int n = tc * 32 + y8 + 8 * p, c = tr * 32 + x;  // read w[n][c]: c fastest
-      tl[y8 + 8 * p][x] = (n < d.N && c < d.Cin) ? w[(long)n * d.Cin + c] : 0.f;
+      const int n = tc * 64 + r16 + 16 * p, c = tr * 64 + 4 * q;  // read w[n][c .. c+3]
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (n < d.N && c < d.Cin) v = *reinterpret_cast<const f32x4*>(w + (long)n * d.Cin + c);
+      tl[r16 + 16 * p][4 * q + 0] = v[0];
+      tl[r16 + 16 * p][4 * q + 1] = v[1];
+      tl[r16 + 16 * p][4 * q + 2] = v[2];
+      tl[r16 + 16 * p][4 * q + 3] = v[3];
     }
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const int c = tr * 32 + y8 + 8 * p, k = tc * 32 + x;  // write dst[c][k = n]: k fastest
+      const int c = tr * 64 + r16 + 16 * p, k = tc * 64 + 4 * q;  // write dst[c][k .. k+3], k = n
       if (c < d.rows && k < d.Kp) {
-        const float v = tl[x][y8 + 8 * p];
+        const f32x4 v = {tl[4 * q + 0][r16 + 16 * p], tl[4 * q + 1][r16 + 16 * p], tl[4 * q + 2][r16 + 16 * p], tl[4 * q + 3][r16 + 16 * p]};
         const long i = (long)c * dld + k;
-        if (d.dst_dtype == KPF_DT_F32) static_cast<float*>(d.dst)[i] = v;
-        else if (d.dst_dtype == KPF_DT_BF16) static_cast<bf16_t*>(d.dst)[i] = (bf16_t)v;
-        else static_cast<f16_t*>(d.dst)[i] = (f16_t)v;
+        if (d.dst_dtype == KPF_DT_F32) *reinterpret_cast<f32x4*>(static_cast<float*>(d.dst) + i) = v;
+        else if (d.dst_dtype == KPF_DT_BF16) kpf_st4(static_cast<bf16_t*>(d.dst) + i, v);
+        else kpf_st4(static_cast<f16_t*>(d.dst) + i, v);
       }
     }
     return;
