@@ -483,7 +483,7 @@ int kpf_pack_conv_weight(const void* w, int src_dtype, void* dst, int dst_dtype,
                          void* stream);
 
 /* All operands of an iteration in ONE launch: `descs_device` is an array of `ndesc` descriptors in DEVICE memory, sorted by
- * first_block; descriptor i owns workgroups [first_block, first_block + ceil(rows * Kp / 1024)) of the `total_blocks` launched.
+ * first_block; descriptor i owns workgroups [first_block, first_block + kpf_pack_desc_blocks(i)) of the `total_blocks` launched.
  * Fields as the arguments of kpf_pack_conv_weight (rows = destination rows: n_pad / Cin / KH*KW*Cin for mode 0 / 1 / 2-3). */
 typedef struct kpf_pack_desc {
   const void* src;
@@ -493,6 +493,9 @@ typedef struct kpf_pack_desc {
                                                       is a column range of a wider stacked matrix); mode 4 (ABI 13): a vector of N elements, rows = 1 */
 } kpf_pack_desc;
 int kpf_pack_conv_weights_multi(const kpf_pack_desc* descs_device, int ndesc, int total_blocks, void* stream);
+/* workgroups descriptor d occupies in that launch (first_block of the next descriptor = first_block + this; ABI 13: the kernel serves 1x1 transposes,
+ * k x k rows, tap tables and k x k data-gradient rows with LDS-staged forms of their own geometry) */
+long kpf_pack_desc_blocks(const kpf_pack_desc* d);
 
 /* Training: AdamW (train.py:84-91) over many tensors in ceil(n / KPF_ADAMW_BATCH) launches.  descs: HOST array (p, m, v updated in place;
  * g read; all fp32, n elements each; first_block is set by the call); the learning rate is *lr_dev when lr_dev is non-null (device

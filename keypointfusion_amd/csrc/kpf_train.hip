@@ -505,6 +505,30 @@ __device__ __forceinline__ float pack_value(const TS* __restrict__ w, const kpf_
   return k < d.N ? (float)w[((long)k * d.Cin + c) * T + (d.mode == 3 ? T - 1 - t : t)] : 0.f;
 }
 
+// Which form of the refresh kernel serves a descriptor (ONE rule for the kernel and for the host's block count: kpf_pack_desc_blocks)
+enum { PACK_GENERIC = 0, PACK_T_1X1 = 1, PACK_DGRAD_KXK = 4 };
+__host__ __device__ inline int pack_form(const kpf_pack_desc& d) {
+  const int T = d.KH * d.KW;
+  if (d.src_dtype != KPF_DT_F32) return PACK_GENERIC;
+  if (d.mode == 1 && T == 1 && (d.Cin & 3) == 0 && (d.Kp & 3) == 0) return PACK_T_1X1;
+  // (LDS-staged forms of the k x k forward rows and of the depthwise tap tables were measured too: 26 -> 57 us and 31 -> 31 us — their element-per-thread
+  //  reads already hit the same cache lines from neighbouring threads — and removed)
+  if (d.mode == 1 && T > 1 && T <= 16 && d.reserved == 0) return PACK_DGRAD_KXK;
+  return PACK_GENERIC;
+}
+__host__ __device__ inline long pack_blocks(const kpf_pack_desc& d) {
+  switch (pack_form(d)) {
+    case PACK_T_1X1: return (long)((d.rows + 63) / 64) * ((d.Kp + 63) / 64);
+    case PACK_DGRAD_KXK: return (long)((d.Cin + 7) / 8) * ((d.n_pad + 31) / 32);
+    default: return ((long)d.rows * d.Kp + 1023) / 1024;
+  }
+}
+__device__ __forceinline__ void pack_store(const kpf_pack_desc& d, long i, float v) {
+  if (d.dst_dtype == KPF_DT_F32) static_cast<float*>(d.dst)[i] = v;
+  else if (d.dst_dtype == KPF_DT_BF16) static_cast<bf16_t*>(d.dst)[i] = (bf16_t)v;
+  else static_cast<f16_t*>(d.dst)[i] = (f16_t)v;
+}
+
 __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const kpf_pack_desc* __restrict__ descs, int ndesc) {
   int lo = 0, hi = ndesc - 1;
   const int b = blockIdx.x;
@@ -513,15 +537,16 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const kpf_pack_
     if (descs[mid].first_block <= b) lo = mid;
     else hi = mid - 1;
   }
+  __shared__ float pack_lds[64 * 65];  // ONE staging buffer for the two LDS-staged forms (16.6 KB: separate arrays per form cost every form its occupancy)
   const kpf_pack_desc d = descs[lo];
   // d.reserved != 0: the destination rows are `reserved` elements apart (> Kp) — this operand fills a column range [dst, dst + Kp) of a wider,
   // stacked matrix (the q | k | v data-gradient operand of training.SelfAttention21); only those Kp columns are written.
   const long dld = d.reserved ? d.reserved : d.Kp;
-  if (d.mode == 1 && d.KH * d.KW == 1 && d.src_dtype == KPF_DT_F32 && (d.Cin & 3) == 0 && (d.Kp & 3) == 0) {
+  if (pack_form(d) == PACK_T_1X1) {
     // 1x1 data-gradient operand = the transpose of the weight: 64 x 64 tiles through LDS, 16-byte reads of the weight's rows, 4-element (8- / 16-byte)
     // writes of the operand's rows (blocks of such a descriptor: ceil(rows / 64) * ceil(Kp / 64), see training.PackCache; round 4: 32 x 32 tiles
     // with scalar accesses before — 128 us of the refresh launch for the 260 operands of a ConvNeXt-T iteration)
-    __shared__ float tl[64][65];
+    float (*tl)[65] = reinterpret_cast<float (*)[65]>(pack_lds);
     const int tiles_k = (d.Kp + 63) / 64;
     const int t = b - d.first_block, tr = t / tiles_k, tc = t - tr * tiles_k;
     const int q = threadIdx.x & 15, r16 = threadIdx.x >> 4;
@@ -565,6 +590,32 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const kpf_pack_
     }
     return;
   }
+  if (pack_form(d) == PACK_DGRAD_KXK) {
+    const int T = d.KH * d.KW;
+    // data-gradient rows of a k x k layer: dst[c][t'*n_pad + n] = w[n][c][T-1-t'].  A block = (8 input channels, 32 output channels): per output channel
+    // 8*T contiguous source floats through LDS, then 8*T runs of 32 consecutive destination elements
+    float (*sm)[8 * 16 + 1] = reinterpret_cast<float (*)[8 * 16 + 1]>(pack_lds);
+    const int nchunks = (d.n_pad + 31) / 32;
+    const int t = b - d.first_block, cc = t / nchunks, c0 = cc * 8, n0 = (t - cc * nchunks) * 32;
+    const int cw = min(8, d.Cin - c0);
+    const float* w = static_cast<const float*>(d.src);
+    for (int i = threadIdx.x; i < 32 * cw * T; i += 256) {
+      const int nl = i / (cw * T), r = i - nl * (cw * T);
+      sm[nl][r] = (n0 + nl) < d.N ? w[((long)(n0 + nl) * d.Cin + c0) * T + r] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cw * T * 32; i += 256) {
+      const int nl = i & 31, ct = i >> 5;  // ct = cl * T + t'
+      const int cl = ct / T, tp = ct - cl * T;
+      if (n0 + nl < d.n_pad) pack_store(d, (long)(c0 + cl) * dld + (long)tp * d.n_pad + n0 + nl, sm[nl][cl * T + (T - 1 - tp)]);
+    }
+    if (n0 == 0)
+      for (int i = threadIdx.x; i < cw * (d.Kp - T * d.n_pad); i += 256) {
+        const int cl = i / (d.Kp - T * d.n_pad), k = T * d.n_pad + (i - cl * (d.Kp - T * d.n_pad));
+        pack_store(d, (long)(c0 + cl) * dld + k, 0.f);
+      }
+    return;
+  }
   const long total = (long)d.rows * d.Kp;
   for (long i = (long)(b - d.first_block) * 1024 + threadIdx.x; i < total && i < (long)(b - d.first_block + 1) * 1024; i += 256) {
     const int k = (int)(i % d.Kp), row = (int)(i / d.Kp);
@@ -579,6 +630,9 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const kpf_pack_
   }
 }
 }  // namespace
+
+/* workgroups a descriptor occupies in kpf_pack_conv_weights_multi (its first_block spacing): the host builds the table with this */
+extern "C" long kpf_pack_desc_blocks(const kpf_pack_desc* d) { return d ? pack_blocks(*d) : 0; }
 
 extern "C" int kpf_pack_conv_weights_multi(const kpf_pack_desc* descs_device, int ndesc, int total_blocks, void* stream) {
   KPF_REQUIRE(descs_device && ndesc > 0 && total_blocks > 0, "kpf_pack_conv_weights_multi: bad arguments");

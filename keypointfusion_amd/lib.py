@@ -162,6 +162,7 @@ _LONG_SIGS = {  # entries returning a long
     "kpf_ln_ws_floats": [C.c_long, C.c_int],
     "kpf_layer_scale_ws_floats": [C.c_long, C.c_int],
     "kpf_dwconv7_stats_floats": [C.c_int] * 4,
+    "kpf_pack_desc_blocks": [C.POINTER(PackDesc)],
 }
 EXPORTS = sorted(list(_SIGS) + list(_LONG_SIGS) + ["kpf_last_error", "kpf_abi_version"])
 

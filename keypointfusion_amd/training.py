@@ -639,7 +639,7 @@ class PackCache:
             a.src, a.dst = d[0], d[1]
             a.N, a.Cin, a.KH, a.KW, a.mode, a.n_pad, a.Kp, a.rows = d[2:10]
             a.src_dtype, a.dst_dtype, a.first_block, a.reserved = d[10], d[11], blk, (d[12] if len(d) > 12 else 0)
-            blk += ((d[9] + 63) // 64) * ((d[8] + 63) // 64) if (d[6] == 1) else (d[8] * d[9] + 1023) // 1024
+            blk += int(L.load().kpf_pack_desc_blocks(C.byref(a)))
         table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
         L.check(L.load().kpf_pack_conv_weights_multi(table.data_ptr(), len(new), blk, torch.cuda.current_stream().cuda_stream), "kpf_pack_conv_weights_multi")
         sp._table = table  # (alive until the launch has run)
@@ -662,10 +662,7 @@ class PackCache:
             arr[i].N, arr[i].Cin, arr[i].KH, arr[i].KW, arr[i].mode, arr[i].n_pad, arr[i].Kp, arr[i].rows = d[2:10]
             arr[i].src_dtype, arr[i].dst_dtype, arr[i].first_block = d[10], d[11], blk
             arr[i].reserved = d[12] if len(d) > 12 else 0  # (destination row stride of an operand that is a column range of a stacked matrix)
-            if d[6] == 1 and d[4] * d[5] == 1 and d[10] == 0 and d[3] % 4 == 0 and d[8] % 4 == 0:  # 1x1 data-gradient operand: 64 x 64 transpose tiles (csrc/kpf_train.hip)
-                blk += ((d[9] + 63) // 64) * ((d[8] + 63) // 64)
-            else:
-                blk += (d[8] * d[9] + 1023) // 1024
+            blk += int(L.load().kpf_pack_desc_blocks(C.byref(arr[i])))  # (the kernel's own rule: LDS-staged forms per operand geometry, csrc/kpf_train.hip)
         dev = next(iter(self.entries.values()))["keep"].device
         self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
         self.total_blocks, self.dirty = blk, False

@@ -1213,3 +1213,31 @@ def test_linear_with_gelu_forward_in_its_epilogue(prec, G):
     tol = 3e-6 if prec == "f32" else 1.5e-2
     for a, r, what in zip(res[0], res[1], ("y", "dx", "dw1", "db1", "dw2", "db2")):
         assert float((a.float() - r.float()).abs().max()) <= tol * max(1.0, float(r.float().abs().max())), what
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_operand_refresh_forms_equal_the_single_operand_kernel(prec):
+    """PackCache's one-launch refresh (kpf_pack_conv_weights_multi: LDS-staged forms per operand geometry, round 4) against kpf_pack_conv_weight (one element per
+    thread) for every mode and a spread of shapes: bit-identical operands, padding included."""
+    from keypointfusion_amd import training as T
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(41)
+    cases = [((96, 48, 3, 3), 0, {}), ((128, 256, 3, 3), 1, dict(pad=1, n_pad=128)), ((100, 40, 3, 3), 1, dict(pad=1, n_pad=104)), ((192, 96, 2, 2), 0, dict(stride=2)),
+             ((192, 96, 2, 2), 2, dict(n_pad=192)), ((384, 1, 7, 7), 2, dict(n_pad=384)), ((200, 1, 7, 7), 3, dict(n_pad=200)), ((64, 8, 4, 4), 0, dict(stride=4)),
+             ((384, 96, 1, 1), 0, {}), ((384, 96, 1, 1), 1, dict(n_pad=384)), ((3, 128, 1, 1), 1, dict(n_pad=4)), ((105, 128, 1, 1), 0, {}), ((64, 20, 5, 5), 0, dict(pad=2))]
+    cache = T.PackCache()
+    ws, refs = [], []
+    for i, (shape, mode, kw) in enumerate(cases):
+        w = torch.randn(shape, generator=g).to(dev)
+        ws.append(w)
+        pc = cache.get(("k%d" % i, mode), w, None, mode, prec, **kw)           # registered: packed by the single-operand kernel
+        refs.append((pc.w if pc.w is not None else pc.w16).clone())
+    for e in cache.entries.values():                                            # poison the operands, then let the one-launch refresh rewrite them
+        d = e["desc"]
+        buf = e["pc"].w if e["pc"].w is not None else e["pc"].w16
+        buf.fill_(float("nan"))
+    cache.refresh()
+    torch.cuda.synchronize()
+    for (shape, mode, kw), e, r in zip(cases, cache.entries.values(), refs):
+        buf = e["pc"].w if e["pc"].w is not None else e["pc"].w16
+        assert torch.equal(buf.view(torch.int16 if buf.dtype != torch.float32 else torch.int32), r.view(torch.int16 if r.dtype != torch.float32 else torch.int32)), (shape, mode)
