@@ -21,7 +21,9 @@ One JSON line is printed by rank 0 with, besides the contract fields:
                  launches in one step / summed device time of those launches (HIP events recorded on the launch stream in an
                  instrumented pass after the timed region, both backbones on ONE stream), against the dense f32-input MFMA peak
                  157.3 TFLOP/s.  `traffic` = HBM bytes per launch from the rocprofv3 PMC passes of this same command, collected
-                 offline and committed (profiles/r04_traffic.json, tools/collect_traffic.py): `traffic_source` says so.
+                 offline and committed (profiles/r05_traffic*.json, tools/collect_traffic.py): `traffic_source` says so; a figure
+                 below 0.9 x the algorithmic bytes, or one whose launch count is not a whole number of this run's steps, is refused
+                 (`traffic: null` + `traffic_rejected`).
   split_f16x3  : SECONDARY record, not the headline and not IEEE fp32: the same workload with KPF_GEMM=split (the ConvNeXt-block GEMMs
                  as 3 x f16 MFMA on hi/lo-split operands with a pack-time range proof; everything else stays on the f32 MFMA).
   extra        : (default run, N = 1) one timed record per further BASELINE config that fits one GPU — `cnb512_f16` (configs[4]: ConvNeXt-B,
@@ -29,7 +31,8 @@ One JSON line is printed by rank 0 with, besides the contract fields:
                  iteration, B=32, bf16) — each measured by this script as a child process on that workload, with its own `roofline`.
   world_size   : ranks that took part (dist.get_world_size()), `collective_backend` the RCCL version when a process group exists.
   cpu_baseline : the CPU oracle (oracle/kpf_oracle.py, torch-CPU fp32 = the reference's own arithmetic) on the host
-                 cores of this box, median of 5 passes over a bounded sample of the same workload (rank 0, N=1 only).
+                 cores of this box: thread-count sweep, then 5 timed passes at the best count over a bounded sample of the same
+                 workload — `value` is their median, the best pass is stated beside it (rank 0, N=1 only).
 """
 import argparse
 import json
@@ -60,6 +63,17 @@ WORKLOADS = {
 }
 
 
+# committed PMC traffic figures (tools/profile_round.sh -> tools/collect_traffic.py), per workload; quoted only for the stated batch
+TRAFFIC_FILES = {"backbones256": "r05_traffic.json", "cnb512_f16": "r05_traffic_cnb512.json", "full128_bf16": "r05_traffic_full128_bf16.json",
+                 "train128_bf16": "r05_traffic_train128_bf16.json"}
+
+
+def under_profiler():
+    """True when a rocprofiler tool library is preloaded into this process (children would inherit it and write their own trace files
+    into the same output directory: VERDICT r04)."""
+    return any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_LIBRARY"))
+
+
 def kernel_peak(name):
     if "h16" in name or "gemm16" in name:
         return PEAK_F16_MFMA_TFLOPS
@@ -83,15 +97,24 @@ def free_port():
         return so.getsockname()[1]
 
 
+def launch_command(n, argv, port=None):
+    """The child job `python bench.py --gpus n` starts: the driver's own form (one rank per GPU, rendezvous on 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(port or free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_env(environ):
+    env = dict(environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver: RCCL needs it across processes
+    return env
+
+
 def self_launch(n):
     """Start `python -m torch.distributed.run --nproc-per-node n bench.py <same arguments>` as a child, relay its output, return its rc."""
     import subprocess
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver: RCCL needs it across processes
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    cmd = launch_command(n, sys.argv[1:])
     print("bench.py: launching %d rank(s): %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    proc = subprocess.run(cmd, env=launch_env(os.environ), stdout=subprocess.PIPE, text=True)
     sys.stdout.write(proc.stdout)
     sys.stdout.flush()
     return proc.returncode
@@ -318,17 +341,25 @@ def main():
         all_fl = sum(v[2] for v in per.values())
         all_ms = sum(v[1] for v in per.values())
         ach = fl / (t_ms * 1e-3) / 1e12
-        traffic, tsrc = None, None
+        traffic, tsrc, trej = None, None, None
         tpath = os.path.join(ROOT, "profiles", traffic_file) if traffic_file else None
-        if tpath and args.workload in ("backbones256", "cnb512_f16") and B == 64 and os.path.exists(tpath):
+        if tpath and B == B0 and os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if dom.startswith(tj.get("kernel", "~")):
-                traffic = round(tj["hbm_bytes_per_launch"])
-                tsrc = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, collected offline "
-                        "(tools/collect_traffic.py; FETCH_SIZE doubled per the gfx950 note for 16-B/lane reads)" % traffic_file)
+            t_b, t_n = tj["hbm_bytes_per_launch"], int(tj.get("launches_profiled", 0))
+            if not dom.startswith(tj.get("kernel", "~")):
+                trej = "%s describes %s, the dominant kernel here is %s" % (traffic_file, tj.get("kernel"), dom)
+            elif t_n == 0 or t_n % n:
+                trej = "%s averages %d launches, not a whole number of this run's %d-launch steps" % (traffic_file, t_n, n)
+            elif t_b < 0.9 * nb / n:
+                trej = "%s: %.1f MB per launch is below the algorithmic %.1f MB (a kernel cannot move less than its compulsory bytes)" % (
+                    traffic_file, t_b / 1e6, nb / n / 1e6)
+            else:
+                traffic = round(t_b)
+                tsrc = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (%d launches = %d steps), collected offline "
+                        "(tools/collect_traffic.py; FETCH_SIZE doubled per the gfx950 note for 16-B/lane reads)" % (traffic_file, t_n, t_n // n))
         peak = kernel_peak(dom)
         return {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc,
+                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc, "traffic_rejected": trej,
                 "peak_note": ("algorithmic-FLOP roof of the 3 x f16 split scheme = dense f16 MFMA peak 2500 / 3; executed MFMA rate = %.0f TFLOP/s"
                               % (3 * ach)) if "split" in dom else ("dense 16-bit MFMA peak (v_mfma_f32_16x16x32_bf16 / _f16)" if ("h16" in dom or "gemm16" in dom)
                                                                     else "dense f32-input MFMA peak (v_mfma_f32_16x16x4_f32)"),
@@ -382,8 +413,7 @@ def main():
                 for name, e0, e1, fl_i, nb, shp in recs:
                     ms = e0.elapsed_time(e1)
                     f.write("%s,%d,%d,%d,%d,%d,%.4f,%.1f\n" % ((name,) + tuple(shp) + (ms, fl_i / ms / 1e9)))
-        roofline = roofline_of(recs, ms_per_step, {"backbones256": "r04_traffic.json" if args.gemm == "f32" else "r04_traffic_split.json",
-                                                   "cnb512_f16": "r04_traffic_cnb512.json"}.get(args.workload))
+        roofline = roofline_of(recs, ms_per_step, TRAFFIC_FILES.get(args.workload) if args.gemm == "f32" else None)
 
     # ---- secondary record: split (3 x f16) arithmetic where a range proof exists; NOT the headline, NOT IEEE fp32 ----
     split_rec = None
@@ -398,7 +428,7 @@ def main():
                          "note": "SECONDARY, not IEEE fp32: ConvNeXt-block GEMMs as 3 x v_mfma_f32_16x16x32_f16 on f16 hi+lo operands (22-bit "
                                  "significands, f16 range, operands proven in range at pack time and pre-scaled), fp32 accumulate; all "
                                  "other GEMMs on the f32-input MFMA"}
-            split_rec["roofline"] = roofline_of(instrumented(), dts / args.steps * 1e3, "r04_traffic_split.json")
+            split_rec["roofline"] = roofline_of(instrumented(), dts / args.steps * 1e3, None)
         finally:
             E.GEMM_MODE = args.gemm
             fresh_plan()
@@ -435,21 +465,25 @@ def main():
             sweep[t] = time.perf_counter() - t1
         best_t = min(sweep, key=sweep.get)
         torch.set_num_threads(best_t)
+        cpu_step()  # (the sweep left the pool at another size: one untimed pass at the chosen count)
         times = []
-        for _ in range(3):
+        for _ in range(5):
             t1 = time.perf_counter()
             cpu_step()
             times.append(time.perf_counter() - t1)
         torch.set_num_threads(threads)
-        med = statistics.median(times + [sweep[best_t]])
-        cpu = {"value": round(n / med, 2), "unit": "img/s", "cores": best_t, "kind": "port",
-               "sample": "median of 4 passes over %d images of the same synthetic batch, oracle/kpf_oracle.py (torch-CPU fp32) at the best thread "
-                         "count of the sweep {%s} img/s; min/max at %d threads %.2f/%.2f img/s" % (
-                             n, ", ".join("%d: %.2f" % (t, n / sweep[t]) for t in cands), best_t, n / max(times), n / min(times)),
+        med = statistics.median(times)
+        cpu = {"value": round(n / med, 2), "best": round(n / min(times), 2), "unit": "img/s", "cores": best_t, "kind": "port",
+               "sample": "median (`value`) and best (`best`) of 5 passes over %d images of the same synthetic batch, oracle/kpf_oracle.py (torch-CPU "
+                         "fp32) at the best thread count of a one-pass sweep {%s} img/s; the 5 passes at %d threads: %s img/s%s" % (
+                             n, ", ".join("%d: %.2f" % (t, n / sweep[t]) for t in cands), best_t, " ".join("%.2f" % (n / t) for t in times),
+                             " (forward only: the reference's training iteration is not restated on the CPU side)" if train else ""),
                "host": "%s, nproc %d" % (cpu_model(), os.cpu_count() or 0)}
 
     extra = None
-    if rank == 0 and world == 1 and dist is None and args.workload == "backbones256" and not args.no_extra and not args.batch:
+    if rank == 0 and world == 1 and dist is None and args.workload == "backbones256" and not args.no_extra and not args.batch and under_profiler():
+        print("bench.py: a profiler is preloaded; the secondary workloads are not started as children of a profiled run", file=sys.stderr)
+    elif rank == 0 and world == 1 and dist is None and args.workload == "backbones256" and not args.no_extra and not args.batch:
         # the headline's buffers are no longer needed: give the memory back before the children build their own models
         pipe[0] = None
         model._plans.clear()
@@ -473,8 +507,10 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": (precision + " storage, f32 accumulate") if precision != "f32" else
                      ("f32" if args.gemm == "f32" else "f32 storage, ConvNeXt-block GEMM products as 3 x f16 split MFMA (not IEEE fp32)"), "data": "synthetic",
-            "config": {"workload": "%s, %s forward, B=%d/GPU %dx%d %s (BASELINE %s)" % (
-                           NET, "depth+RGB UNet backbones" if backbones_only else "full model (backbones + fusion head)", B, S, S, precision, cfg_name),
+            "config": {"workload": "%s, %s, B=%d/GPU %dx%d %s (BASELINE %s)" % (
+                           NET, "depth+RGB UNet backbones forward" if backbones_only else
+                           "full model (backbones + fusion head) training iteration (forward, loss, backward, AdamW)" if train else
+                           "full model (backbones + fusion head) forward", B, S, S, precision, cfg_name),
                        "batch_per_gpu": B, "global_batch": B * world, "input": "%dx%d" % (S, S), "parallelism": "dp%d (batch shards, no collective)" % world,
                        "gemm_arithmetic": ("16-bit (%s) operands and activations in HBM, fp32 accumulate on v_mfma_f32_16x16x32_%s; fusion head fp32" % (precision, precision))
                        if precision != "f32" else ("IEEE fp32: v_mfma_f32_16x16x4_f32 (fp32 operands, fp32 accumulate) for every GEMM" if args.gemm == "f32"

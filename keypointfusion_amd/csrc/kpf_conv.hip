@@ -1306,7 +1306,10 @@ static bool g8_applies(const kpf_conv_desc* d, bool has_prologue) {
   const bool pointwise = d->KH == 1 && d->KW == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0 && d->IH == d->OH && d->IW == d->OW;
   const bool fast1x1 = pointwise && d->Cin % 64 == 0 && d->Kp == d->Cin;
   const bool vec = d->out_ld % 4 == 0 && d->out_coff % 4 == 0 && (!(fl & KPF_RES_ADD) || (d->res_ld % 4 == 0 && d->res_coff % 4 == 0));
-  return fast1x1 && d->Kp % 128 == 0 && d->N % 256 == 0 && !has_prologue && !(fl & KPF_OUT_NCHW) && vec && d->out_ld % 8 == 0 && d->out_coff % 8 == 0;
+  // (the eight-phase kernel has no grouped form and none of the training step's two epilogues: part of the rule, so a forced
+  //  KPF_FORCE_CFG16=30 cannot route such a launch to it either)
+  const bool plain = d->groups <= 1 && !(fl & (KPF_RES_GELU_GRAD | KPF_ACT_GELU_SAVE));
+  return plain && fast1x1 && d->Kp % 128 == 0 && d->N % 256 == 0 && !has_prologue && !(fl & KPF_OUT_NCHW) && vec && d->out_ld % 8 == 0 && d->out_coff % 8 == 0;
 }
 static bool g8_preferred(const kpf_conv_desc* d) {
   const long M = (long)d->B * d->OH * d->OW;
@@ -1315,7 +1318,7 @@ static bool g8_preferred(const kpf_conv_desc* d) {
 /* 1 when kpf_conv2d_h16 runs this descriptor on gemm16_8ph_kernel, 0 when on igemm_h16_kernel (profile labels; same rule as the dispatcher) */
 extern "C" int kpf_conv2d_h16_uses_8ph(const kpf_conv_desc* d, int has_prologue) {
   static const bool no8 = getenv("KPF_NO_8PH") != nullptr;
-  return d && !no8 && d->groups <= 1 && !(d->flags & (KPF_RES_GELU_GRAD | KPF_ACT_GELU_SAVE)) && g8_applies(d, has_prologue != 0) && g8_preferred(d) ? 1 : 0;
+  return d && !no8 && g8_applies(d, has_prologue != 0) && g8_preferred(d) ? 1 : 0;
 }
 
 extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void* w, const float* bias, const float* pro_scale,
@@ -1374,7 +1377,8 @@ extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void
     KPF_REQUIRE(!(fl & (KPF_RES_GAMMA | KPF_OUT_NCHW)) && !pro_scale && d->w_gstride % 8 == 0 && d->N % 2 == 0,
                 "kpf_conv2d_h16: a grouped launch takes no layer scale / prologue / NCHW output, and needs w_gstride %% 8 == 0, N %% 2 == 0");
     KPF_REQUIRE(d->in_coff + d->groups * d->Cin <= d->in_ld && d->out_coff + d->groups * d->N <= d->out_ld, "kpf_conv2d_h16: the groups' channel slices exceed the pixel stride");
-    KPF_REQUIRE(!(fl & KPF_RES_ADD) || d->res_coff + d->groups * d->N <= d->res_ld, "kpf_conv2d_h16: the groups' residual slices exceed the pixel stride");
+    KPF_REQUIRE(!(fl & (KPF_RES_ADD | KPF_ACT_GELU_SAVE)) || d->res_coff + d->groups * d->N <= d->res_ld,
+                "kpf_conv2d_h16: the groups' residual / saved pre-activation slices exceed the pixel stride");
     a.g_in = d->Cin / 2; a.g_out = d->N; a.g_w = d->w_gstride / 2;
     if ((d->out_coff + d->N) % 8 || ((fl & KPF_RES_ADD) && (d->res_coff + d->N) % 8)) a.vec = 0;  // (the staged epilogue stores 16-byte pieces of every group's slice)
   }
@@ -1407,7 +1411,7 @@ extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void
   // Round 4: the eight-phase 256 x 256 kernel (gemm16_8ph_kernel) for every dense 1x1 layer it covers with at least one full round of tiles
   const bool ok8 = g8_applies(d, pro_scale != nullptr);
   static const bool no8 = getenv("KPF_NO_8PH") != nullptr;  // tuning aid: A/B against the round-3 tile shapes
-  if (ok8 && !no8 && g8_preferred(d) && a.groups == 1 && !(fl & (KPF_RES_GELU_GRAD | KPF_ACT_GELU_SAVE))) best = 30;
+  if (ok8 && !no8 && g8_preferred(d)) best = 30;
   static const int forced = []() { const char* e = getenv("KPF_FORCE_CFG16"); return e ? atoi(e) : -1; }();  // tuning aid only
   if (forced >= 0 && (forced != 30 || ok8)) best = forced;
   if (best == 30) return dtype == KPF_DT_BF16 ? launch_8ph<ARITH_BF16>(a, st) : launch_8ph<ARITH_F16>(a, st);
@@ -1488,7 +1492,8 @@ extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const flo
     KPF_REQUIRE(!(fl & (KPF_RES_GAMMA | KPF_OUT_NCHW | KPF_IN_SPLIT | KPF_W_SPLIT | KPF_OUT_SPLIT)) && !pro_scale && d->w_gstride % 4 == 0,
                 "kpf_conv2d_f32: a grouped launch takes no layer scale / prologue / NCHW output / split operands, and needs w_gstride %% 4 == 0");
     KPF_REQUIRE(d->in_coff + d->groups * d->Cin <= d->in_ld && d->out_coff + d->groups * d->N <= d->out_ld, "kpf_conv2d_f32: the groups' channel slices exceed the pixel stride");
-    KPF_REQUIRE(!(fl & KPF_RES_ADD) || d->res_coff + d->groups * d->N <= d->res_ld, "kpf_conv2d_f32: the groups' residual slices exceed the pixel stride");
+    KPF_REQUIRE(!(fl & (KPF_RES_ADD | KPF_ACT_GELU_SAVE)) || d->res_coff + d->groups * d->N <= d->res_ld,
+                "kpf_conv2d_f32: the groups' residual / saved pre-activation slices exceed the pixel stride");
     a.g_in = d->Cin; a.g_out = d->N; a.g_w = d->w_gstride;
     if ((d->out_coff + d->N) % 4 || ((fl & KPF_RES_ADD) && (d->res_coff + d->N) % 4)) a.vec = 0;
   }

@@ -14,6 +14,7 @@ import torch
 from . import lib as L
 
 STAGE_TYPE = (1, 1, 2, 3, 2, 3)  # config.py:74 — depth backbone, RGB backbone, (3D, 2D) x 2 fusion blocks
+NYU_SCORED_JOINTS = (0, 2, 4, 6, 8, 10, 12, 14, 16, 17, 18, 21, 22, 20)  # train.py:484-486: of NYU's 23 predicted joints these 14 are scored, in this order
 
 
 def decode_stage(result, stage_type, img, center, M, cube, cam_para, kernel=0.8, img_size=128, flip=1):
@@ -47,7 +48,8 @@ def _as_tensor(t, like=None):
 
 
 def xyz2error(pred, gt, center, cube):
-    """Per-joint Euclidean error in mm, B x J (what train.py:470-488 computes): normalised joints are scaled by cube / 2; the crop
+    """Per-joint Euclidean error in mm (what train.py:470-488 computes): B x J, or B x 14 for NYU's 23-joint predictions, of which the
+    reference scores the 14 joints of `NYU_SCORED_JOINTS` (train.py:484-486).  Normalised joints are scaled by cube / 2; the crop
     centre the reference adds to both sides cancels in the difference, so it is not added here (no 700 mm + 0.01 mm cancellation in
     fp32).  Tensors stay on their device; numpy in -> numpy out."""
     was_np = not torch.is_tensor(pred)
@@ -55,6 +57,8 @@ def xyz2error(pred, gt, center, cube):
     g = _as_tensor(gt, p).to(p).float()
     half = _as_tensor(cube, p).to(p).float().reshape(p.shape[0], 1, -1) / 2
     e = torch.linalg.vector_norm((p - g) * half, dim=-1)
+    if p.shape[1] == 23:
+        e = e[:, list(NYU_SCORED_JOINTS)]
     return e.cpu().numpy() if was_np else e
 
 

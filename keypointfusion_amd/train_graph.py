@@ -94,7 +94,10 @@ class TrainGraph:
             t = pair_params(reg, name, a, b)
         else:
             t = pair_storage(reg, name, a, b)
-            t = torch.stack((a, b), 0) if t is None else t
+            if t is None:
+                # a buffer (BatchNorm running statistics) is updated IN PLACE by the kernels: a stacked copy would silently drop the update
+                raise ValueError("paired backbones: buffer %r has %d elements, not a multiple of 4, so its two halves cannot share one 16-byte-"
+                                 "aligned allocation; run this network with KPF_TRAIN_PAIR=0 (two passes)" % (name[len(PAIR):], a.numel()))
         return t.reshape((2 * a.shape[0],) + tuple(a.shape[1:]))
 
     def groups_of(self, name):

@@ -2111,17 +2111,27 @@ class GraphedTrainStep:
             return
         self.world = self.dist.get_world_size(group)
         if self.dp_mode == "overlap":
+            err = None
             try:
                 self._capture_overlap(bucket_mb)
-                return
             except Exception as e:  # noqa: BLE001 — a runtime / RCCL build that cannot capture collectives: the two-graph form still works
-                import warnings
-                warnings.warn("GraphedTrainStep: capturing the bucket collectives failed (%s: %s); using the two-graph form" % (type(e).__name__, e))
-                self._remove_hooks()
-                self.dp_mode = "split"
-                torch.cuda.synchronize()
-                self.opt.zero_grad(set_to_none=True)
-                self.graph = torch.cuda.CUDAGraph()
+                err = e
+            # The form is agreed on by the whole group (a capture only records, so nothing has been exchanged yet): if ANY rank failed,
+            # every rank takes the two-graph form — ranks replaying collectives as graph nodes beside ranks issuing eager all-reduces
+            # between two graphs would be a mismatched collective sequence (a hang, or silently mixed gradients).
+            ok = torch.tensor([0 if err is not None else 1], device=next(iter(self.params)).device, dtype=torch.int32)
+            if self.world > 1:
+                self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN, group=group)
+            if int(ok.item()) == 1:
+                return
+            import warnings
+            warnings.warn("GraphedTrainStep: capturing the bucket collectives failed on %s (%s); every rank uses the two-graph form" % (
+                "this rank" if err is not None else "another rank", "%s: %s" % (type(err).__name__, err) if err is not None else "see its log"))
+            self._remove_hooks()
+            self.dp_mode = "split"
+            torch.cuda.synchronize()
+            self.opt.zero_grad(set_to_none=True)
+            self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = self._forward_backward()
             self._make_buckets(bucket_mb)  # (the gradients now exist: static tensors of the graph's pool)

@@ -1,0 +1,33 @@
+"""Copy the rocprofv3 kernel_stats.csv of the process that ran the expected kernel (never `head -1` of several per-process files).
+usage: pick_stats.py <rocprof-output-dir> <kernel-substring> <out.csv> [bench-log]
+With a bench log (the JSON line the profiled command printed) the call count is checked as well: eager --serial-streams runs issue
+launches_per_step x (steps + warmup + 2 instrumented passes) launches of the dominant kernel."""
+import csv, glob, json, shutil, sys
+
+d, sub, out = sys.argv[1:4]
+log = sys.argv[4] if len(sys.argv) > 4 else None
+cands = []
+for f in glob.glob(d + "/**/*kernel_stats.csv", recursive=True):
+    calls = sum(int(r["Calls"]) for r in csv.DictReader(open(f)) if sub in r["Name"])
+    if calls:
+        cands.append((calls, f))
+if len(cands) != 1:
+    sys.exit("pick_stats: %d kernel_stats files under %s contain %s (expected exactly 1): %s" % (len(cands), d, sub, cands))
+calls, f = cands[0]
+if log:
+    rec = None
+    for ln in open(log, errors="replace"):
+        if ln.startswith("{"):
+            try:
+                rec = json.loads(ln)
+            except ValueError:
+                pass
+    if rec is None:
+        sys.exit("pick_stats: no JSON line in %s" % log)
+    roof = rec["roofline"]
+    if sub in roof["kernel"] and "eager" in rec.get("launch", ""):
+        want = int(roof["launches_per_step"]) * (rec["steps"] + rec["warmup"] + 2)
+        if calls != want:
+            sys.exit("pick_stats: %s has %d launches of %s, the command issued %d" % (f, calls, sub, want))
+shutil.copy(f, out)
+print("pick_stats: %s -> %s (%d launches of %s)" % (f, out, calls, sub))
