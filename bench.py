@@ -144,7 +144,7 @@ def run_extra(workload, steps, warmup, timeout):
                 pass
     if proc.returncode != 0 or rec is None:
         return {"error": "rc %d: %s" % (proc.returncode, proc.stderr[-400:])}
-    keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "launch", "roofline", "world_size")
+    keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "launch", "roofline", "world_size", "single_batch_latency", "single_step_into_idle_gpu")
     out = {k: rec.get(k) for k in keep}
     out["workload"] = rec["config"]["workload"]
     out["wall_s"] = round(time.perf_counter() - t0, 1)
@@ -397,6 +397,31 @@ def main():
             iss.append(t1 - t0)
             tot.append(time.perf_counter() - t0)
         single = {"issue_ms": round(min(iss) * 1e3, 3), "total_ms": round(min(tot) * 1e3, 3)}
+    latency = None
+    if not train and not backbones_only and rank == 0:
+        # the same forward ONE batch at a time (module forward, hipGraph replay when graphs are on): the latency a caller of model(...) sees, beside the
+        # throughput of the pipelined loop above; and the library entry points one eager forward calls (a handful issue two kernels)
+        model.use_graphs = graph_on[0]
+        fwd = lambda: model(batch["img_rgb"], batch["img"], batch["pcl"], _Loader(), batch["center"], batch["M"], batch["cube"], batch["cam_para"], 0.8)
+        with torch.no_grad():
+            for _ in range(3):
+                fwd()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(20):
+                t0 = time.perf_counter()
+                fwd()
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            model.use_graphs = False
+            c0 = L.CALLS[0]
+            fwd()
+            torch.cuda.synchronize()
+            calls = L.CALLS[0] - c0
+            model.use_graphs = graph_on[0]
+        latency = {"median_ms": round(statistics.median(ts), 3), "min_ms": round(min(ts), 3), "img_per_s_one_batch_at_a_time": round(B / statistics.median(ts) * 1e3, 1),
+                   "library_calls_per_forward": calls,
+                   "note": "model(...) on one batch, synchronised after every call (%s); `value` above is the pipelined loop" % ("hipGraph replay" if graph_on[0] else "eager")}
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -524,6 +549,8 @@ def main():
             line["extra"] = extra
         if single is not None:
             line["single_step_into_idle_gpu"] = single
+        if latency is not None:
+            line["single_batch_latency"] = latency
         if train and gstep[0] is not None and dist is not None:
             line["dp_graph"] = {"mode": gstep[0].dp_mode, "payload_bytes_per_rank": gstep[0].payload_bytes(), "grad_payload": gstep[0].grad_payload,
                                 "collective": gstep[0].collective}

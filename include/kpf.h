@@ -436,6 +436,11 @@ int kpf_attn21_backward_ld(const float* dctx, const float* q, const float* k, co
 /* Training: dX[b] (P x C) = A[b]^T (P x J) @ dOut[b] (J x C) for small J (<= 64; J = 21 joints): the operand gradient of the per-sample
  * products of model/model.py:318-320 and 336-341 (a K = J batched GEMM the library handles badly).  fp32, C % 4 == 0, J * C * 4 B <= 64 KB. */
 int kpf_bmm_small_k_dx(const float* A, const float* dOut, float* dX, int B, int J, int P, int C, void* stream);
+/* round 5 (ABI 14): the other two products of the pair — out[b] = A[b] (J x P) @ X[b] (P x C) (J <= 24, C % 4 == 0) and dA[b] = dOut[b] (J x C) @ X[b]^T — what
+   torch.bmm computed in `joint_feat = img2joint @ img_feat` (model/model.py:318-320) and the gated reduction (model/model.py:336-341) of the training step and in
+   their autograd backward; fixed summation order. */
+int kpf_bmm_small_k_fwd(const float* A, const float* X, float* out, int B, int J, int P, int C, void* stream);
+int kpf_bmm_small_k_da(const float* dOut, const float* X, float* dA, int B, int J, int P, int C, void* stream);
 
 /* Training: layer scale + residual of the ConvNeXt block, out = x + gamma * y (convNeXT/convnext.py:48-51): x / out / g fp32 [rows][C], y / dy in
  * y_dtype (fp32 or the 16-bit GEMM storage type), gamma / dgamma [C].  backward: dy = g * gamma, dgamma = column sums of g * y added in a
@@ -591,7 +596,7 @@ int kpf_conv_num_tile_cfgs(void);
 const char* kpf_last_error(void);
 /* Library/ABI version, bumped when a signature or the meaning of an argument changes (KPF_ABI_VERSION is what this header
  * describes; the Python binding refuses a library that reports another). */
-#define KPF_ABI_VERSION 13
+#define KPF_ABI_VERSION 14
 int kpf_abi_version(void);
 
 #ifdef __cplusplus

@@ -200,27 +200,34 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
   // K-tile offset — the per-tile address arithmetic is two VALU ops per DMA.  Rows beyond M / channels beyond N are clamped to
   // the last valid row (their products land in accumulator rows/columns the epilogue never stores), so no zero page is needed.
   // General convolution: receptive-field origin per staged row, tap decoded per K tile, zero page outside the image / K range.
+  // General convolution: per staged row the address of its receptive field's origin and the origin's image coordinates; per lane the tap
+  // (ky, kx) and channel offset of ITS 16-byte chunk of the current K tile, advanced incrementally from K tile to K tile — BK = q * Cin + r
+  // words per step with q, r uniform: c += r, one conditional wrap, tap += q + wrap; ky = tap / KW through a 16-bit reciprocal (tap <= 49) —
+  // so that a K tile costs ~10 VALU operations of decode instead of two integer divisions (round 5: at 16-bit storage a 128 x 128 K tile is 512
+  // matrix-pipe cycles per wave, and the ~130 VALU instructions of the division form were as long as the MFMAs they feed).  Zero page outside
+  // the image / K range.  Any Cin % 4 == 0 and any KH x KW: a lane's chunk never straddles a tap (taps start at multiples of Cin, chunks at
+  // multiples of 4 words), different lanes of a K tile may sit in different taps.
   const float* pa[AP];
   const float* pb[BP];
-  int rbase[AP], riy[AP], rix[AP];
+  int riy[AP], rix[AP];
 #pragma unroll
   for (int p = 0; p < AP; ++p) {
     const int m = m0 + lr + RPP * p;
     if (IS1X1) {
       const int mc = m < a.M ? m : a.M - 1;
       pa[p] = a.in + (long)mc * a.in_ld + a.in_coff + kc;
-      rbase[p] = riy[p] = rix[p] = 0;
+      riy[p] = rix[p] = 0;
     } else if (m < a.M && lr + RPP * p < BM) {  // (ring mode stages whole passes: rows beyond BM read the zero page)
       const int b = m / a.ohow;
       const int r = m - b * a.ohow;
       const int oy = r / a.OW;
       const int ox = r - oy * a.OW;
-      rbase[p] = b * a.IH * a.IW;
       riy[p] = oy * a.sh - a.ph;
       rix[p] = ox * a.sw - a.pw;
+      pa[p] = a.in + ((long)b * a.IH * a.IW + (long)riy[p] * a.IW + rix[p]) * a.in_ld + a.in_coff;
     } else {
-      rbase[p] = -1;
-      riy[p] = 0;
+      pa[p] = a.zero;
+      riy[p] = -(1 << 20);  // (never inside the image)
       rix[p] = 0;
     }
   }
@@ -229,6 +236,14 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
     const int n = n0 + lr + RPP * p;
     const int nc = n < a.N ? n : a.N - 1;
     pb[p] = a.w + (long)nc * a.Kp + kc;
+  }
+  // this lane's chunk of the K tile that was staged last (general convolution only)
+  int s_kt = 0, s_tap = 0, s_c = 0;
+  const int s_q = IS1X1 ? 0 : BK / a.Cin, s_r = IS1X1 ? 0 : BK - s_q * a.Cin;   // uniform
+  const int s_rcp = IS1X1 ? 0 : (65536 + a.KW - 1) / a.KW;                     // uniform: tap / KW == (tap * s_rcp) >> 16 for tap < 2^16 / KW
+  if (!IS1X1) {
+    s_tap = kc / a.Cin;
+    s_c = kc - s_tap * a.Cin;
   }
 
   auto stage = [&](int kt, int buf) {
@@ -240,19 +255,23 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
         if (WHOLE || RPP * p + 8 * wave < BM)  // wave-uniform
           __builtin_amdgcn_global_load_lds((gbl_void_t*)(pa[p] + kt * BK), (lds_void_t*)(As + (RPP * p + 8 * wave) * BK), 16, 0, 0);
     } else {
-      const int k = kt * BK + kc;
-      const bool kvalid = k < a.K;
-      const int tap = k / a.Cin;
-      const int c = k - tap * a.Cin;
-      const int ky = tap / a.KW;
-      const int kx = tap - ky * a.KW;
+      // K tiles are staged in order (every caller passes kt == the previous kt, or the previous kt + 1; the first call is kt = 0)
+      const bool adv = kt != s_kt;
+      s_kt = kt;
+      s_c += adv ? s_r : 0;
+      const bool wrap = s_c >= a.Cin;
+      s_c -= wrap ? a.Cin : 0;
+      s_tap += adv ? s_q + (wrap ? 1 : 0) : 0;
+      const int ky = (s_tap * s_rcp) >> 16;
+      const int kx = s_tap - ky * a.KW;
+      const bool kvalid = s_tap < a.KH * a.KW;  // (K padding: chunks beyond the last tap)
+      const int toff = (ky * a.IW + kx) * a.in_ld + s_c;
 #pragma unroll
       for (int p = 0; p < AP; ++p) {
         if (WHOLE || RPP * p + 8 * wave < BM) {  // wave-uniform
           const int iy = riy[p] + ky, ix = rix[p] + kx;
-          const bool v = kvalid && rbase[p] >= 0 && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
-          const long off = ((long)rbase[p] + (long)iy * a.IW + ix) * a.in_ld + a.in_coff + c;
-          const float* src = v ? a.in + off : a.zero;
+          const bool v = kvalid && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+          const float* src = v ? pa[p] + toff : a.zero;
           __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(As + (RPP * p + 8 * wave) * BK), 16, 0, 0);
         }
       }
@@ -1412,8 +1431,22 @@ extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void
   const bool ok8 = g8_applies(d, pro_scale != nullptr);
   static const bool no8 = getenv("KPF_NO_8PH") != nullptr;  // tuning aid: A/B against the round-3 tile shapes
   if (ok8 && !no8 && g8_preferred(d)) best = 30;
+  // Round 5: grids that do not fill the chip with a long K (B = 32 at 128 x 128: pwconv2 / 3x3 / concatenation layers of stages 3-4 and of the
+  // low-resolution decoder levels).  With <= 2 workgroups per CU and two LDS stages the K loop runs at one DMA latency per K tile; a 4-stage ring of
+  // 64 x 64 tiles (64 KB: two workgroups per CU, three K tiles in flight each) or, below 128 tiles, an 8-stage ring of 32 x 64 tiles shortens it
+  // (tools/h16_small_sweep.py, graph replay: 512 x 768 x 3072 23.8 -> 13.3 us, 8192 x 192 x 1728 3x3 21.8 -> 16.9, 2048 x 384 x 1152 9.3 -> 7.7;
+  // wide-N short-K layers lose and keep the two-stage tiles).  Same k order in every tile shape: results stay bit-identical.
+  static const bool no_ring = getenv("KPF_NO_RING16") != nullptr;  // tuning aid
+  if (!no_ring && best != 30 && !pro_scale && !(fl & KPF_RES_GELU_GRAD)) {
+    const long nk = a.Kp / BK, b64 = (((long)a.M + 63) / 64) * (((long)a.N + 63) / 64);
+    if (nk >= 6 && 4L * a.Kp >= a.N) {  // (Kp counts 4-byte words: K >= N / 2 elements — every measured winner; wide-N short-K layers are not)
+      if (b64 <= 128) best = 44;
+      else if (b64 <= 512) best = 41;
+    }
+  }
   static const int forced = []() { const char* e = getenv("KPF_FORCE_CFG16"); return e ? atoi(e) : -1; }();  // tuning aid only
   if (forced >= 0 && (forced != 30 || ok8)) best = forced;
+  if (d->tile_cfg > 0 && (d->tile_cfg != 31 || ok8)) best = d->tile_cfg - 1;  // the caller's choice (tools/h16_small_sweep.py): case index + 1
   if (best == 30) return dtype == KPF_DT_BF16 ? launch_8ph<ARITH_BF16>(a, st) : launch_8ph<ARITH_F16>(a, st);
   switch (best) {
     case 0: return occ ? launch_cfg_h16<4, 4, 2, 2, 1>(a, fast1x1, pointwise, dtype, st) : launch_cfg_h16<4, 4, 2, 2, 2>(a, fast1x1, pointwise, dtype, st);
@@ -1426,6 +1459,11 @@ extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void
     case 21: return launch_cfg_h16<4, 4, 2, 2, 3>(a, fast1x1, pointwise, dtype, st);  // 128 x 128, 3-stage ring (96 KB)
     case 22: return launch_cfg_h16<4, 4, 2, 2, 4>(a, fast1x1, pointwise, dtype, st);  // 128 x 128, 4-stage ring (128 KB)
     case 26: return launch_cfg_h16<8, 4, 2, 4, 2>(a, fast1x1, pointwise, dtype, st);  // 256 x 256, 8 waves of 128 x 64 (2 per SIMD), 128 KB of LDS
+    // round 5: LDS rings for launches whose grid does not fill the chip (selection rule above).  Also measured and not kept: 64 x 64 with an 8-stage
+    // ring (128 KB, one workgroup per CU: 57 us where the 4-stage form takes 10), 64 x 128 with 3 / 6 stages, 128 x 64 with 6 (all slower than the two
+    // below or than the two-stage tiles on every shape of tools/h16_small_sweep.py).
+    case 41: return launch_cfg_h16<2, 2, 2, 2, 4>(a, fast1x1, pointwise, dtype, st);  // 64 x 64, 4-stage ring (64 KB: two per CU)
+    case 44: return launch_cfg_h16<2, 1, 1, 4, 8>(a, fast1x1, pointwise, dtype, st);  // 32 x 64, 8-stage ring (96 KB)
     default: return launch_cfg_h16<2, 1, 1, 4, 2>(a, fast1x1, pointwise, dtype, st);  // 32 x 64
   }
 }

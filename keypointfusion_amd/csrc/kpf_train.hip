@@ -1170,6 +1170,96 @@ extern "C" int kpf_bmm_small_k_dx(const float* A, const float* dOut, float* dX, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The other two products of the same pair (round 5: they sat on the library's batched GEMM): out[b] = A[b] (J x P) @ X[b] (P x C), and
+// dA[b] = dOut[b] (J x C) @ X[b]^T.  Few rows (J = 21), so neither is a matrix-core problem: the forward is a 1024-long reduction per
+// output with X[b] read exactly once per channel block, the A-gradient a C-long dot product per output with dOut[b] in LDS.  Fixed
+// summation orders (per-lane strided partial sums, xor-shuffle tree, waves combined in order): run-to-run deterministic.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int BMM_J = 24;  // accumulator rows held per thread (J <= 24)
+// grid (C / 32, B), 256 threads = 8 channel quads x 32 row lanes; thread (q, pl) adds rows p = pl, pl + 32, ... for all J outputs of its quad
+__global__ __launch_bounds__(256) void bmm21_fwd_kernel(const float* __restrict__ A, const float* __restrict__ X, float* __restrict__ out, int J, int P, int C) {
+  __shared__ float red[4][BMM_J][32];
+  const int b = blockIdx.y, c0 = blockIdx.x * 32;
+  const int q = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const float* Ab = A + (long)b * J * P;
+  const float* Xb = X + (long)b * P * C + c0 + 4 * q;
+  f32x4 acc[BMM_J];
+#pragma unroll
+  for (int j = 0; j < BMM_J; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool cv = c0 + 4 * q < C;  // (C % 4 == 0: a quad is inside or outside)
+  for (int p = pl; p < P; p += 32) {
+    const f32x4 x = cv ? *reinterpret_cast<const f32x4*>(Xb + (long)p * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < BMM_J; ++j)
+      if (j < J) {
+        const float a = Ab[j * P + p];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(a, x[e], acc[j][e]);
+      }
+  }
+  // the 8 row lanes of a wave (lane bits 3..5), then the 4 waves through LDS, in a fixed order
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < BMM_J; ++j)
+    if (j < J) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = acc[j][e];
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        acc[j][e] = v;
+      }
+      if (lane < 8) *reinterpret_cast<f32x4*>(&red[wave][j][4 * lane]) = acc[j];
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < J * 32; i += 256) {
+    const int j = i >> 5, c = i & 31;
+    if (c0 + c < C) out[((long)b * J + j) * C + c0 + c] = (red[0][j][c] + red[1][j][c]) + (red[2][j][c] + red[3][j][c]);
+  }
+}
+// grid (ceil(P / 256), B), 256 threads: thread = one row p of X[b]; dOut[b] ([J][C]) in LDS, the row streamed once in float4 pieces
+__global__ __launch_bounds__(256) void bmm21_da_kernel(const float* __restrict__ dOut, const float* __restrict__ X, float* __restrict__ dA, int J, int P, int C) {
+  extern __shared__ float sd[];  // dOut[b]: [J][C]
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < J * C; i += 256) sd[i] = dOut[(long)b * J * C + i];
+  __syncthreads();
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const float* xr = X + ((long)b * P + p) * C;
+  float acc[BMM_J];
+#pragma unroll
+  for (int j = 0; j < BMM_J; ++j) acc[j] = 0.f;
+  for (int c = 0; c < C; c += 4) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(xr + c);
+#pragma unroll
+    for (int j = 0; j < BMM_J; ++j)
+      if (j < J) {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(sd + j * C + c);  // (same address across the wave: an LDS broadcast)
+        acc[j] = fmaf(x[3], d[3], fmaf(x[2], d[2], fmaf(x[1], d[1], fmaf(x[0], d[0], acc[j]))));
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < BMM_J; ++j)
+    if (j < J) dA[((long)b * J + j) * P + p] = acc[j];
+}
+}  // namespace
+
+extern "C" int kpf_bmm_small_k_fwd(const float* A, const float* X, float* out, int B, int J, int P, int C, void* stream) {
+  KPF_REQUIRE(A && X && out && B > 0 && J > 0 && J <= BMM_J && P > 0 && C > 0 && C % 4 == 0 && kpf_aligned16(X), "kpf_bmm_small_k_fwd: bad arguments (J <= 24, C %% 4 == 0)");
+  hipLaunchKernelGGL(bmm21_fwd_kernel, dim3((C + 31) / 32, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), A, X, out, J, P, C);
+  return kpf_check_launch("kpf_bmm_small_k_fwd");
+}
+
+extern "C" int kpf_bmm_small_k_da(const float* dOut, const float* X, float* dA, int B, int J, int P, int C, void* stream) {
+  KPF_REQUIRE(dOut && X && dA && B > 0 && J > 0 && J <= BMM_J && P > 0 && C > 0 && C % 4 == 0 && (long)J * C * 4 <= 64 * 1024 && kpf_aligned16(X) && kpf_aligned16(dOut),
+              "kpf_bmm_small_k_da: bad arguments (J <= 24, C %% 4 == 0)");
+  hipLaunchKernelGGL(bmm21_da_kernel, dim3((P + 255) / 256, B), dim3(256), (size_t)J * C * sizeof(float), reinterpret_cast<hipStream_t>(stream), dOut, X, dA, J, P, C);
+  return kpf_check_launch("kpf_bmm_small_k_da");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Layer scale + residual of the ConvNeXt block, out = x + gamma * y (convNeXT/convnext.py:48-51), forward and backward.  x, out and the
 // incoming gradient are fp32 (the residual stream), y / dy are in the GEMM's storage type (fp32, or 16-bit under mixed precision: the
 // torch expression needs a cast on either side).  dgamma = column sums of g * y: per-workgroup partial sums in registers (a lane owns up

@@ -22,7 +22,7 @@ KPF_IN_SPLIT = 128
 KPF_OUT_SPLIT = 256
 KPF_W_SPLIT = 512
 KPF_DT_F32, KPF_DT_BF16, KPF_DT_F16 = 0, 1, 2
-ABI_VERSION = 13  # KPF_ABI_VERSION of include/kpf.h: load() refuses a library built from another revision of the interface
+ABI_VERSION = 14  # KPF_ABI_VERSION of include/kpf.h: load() refuses a library built from another revision of the interface
 
 
 class ConvDesc(C.Structure):
@@ -144,6 +144,8 @@ _SIGS = {
     "kpf_ln_train_backward_partial": [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, C.c_long, C.c_long, C.c_int, C.POINTER(ColsumDesc), _P],
     "kpf_colsum_reduce_grouped": [C.POINTER(ColsumDesc), C.c_int, _P],
     "kpf_bmm_small_k_dx": [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_bmm_small_k_fwd": [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_bmm_small_k_da": [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
     "kpf_attn21_forward": [_P] * 6 + [C.c_int] * 5 + [C.c_float, C.c_float, _P, C.c_int, _P],
     "kpf_attn21_backward": [_P] * 9 + [C.c_int] * 5 + [C.c_float, C.c_float, _P],
     "kpf_attn21_forward_ld": [_P] * 6 + [C.c_int] * 6 + [C.c_float, C.c_float, _P, C.c_int, _P],
@@ -199,6 +201,10 @@ def load():
     return lib
 
 
+CALLS = [0]  # entry-point calls checked so far (bench.py reports the difference over one step: "library calls per step")
+
+
 def check(rc, what=""):
+    CALLS[0] += 1
     if rc != 0:
         raise KpfError("%s failed (%d): %s" % (what, rc, load().kpf_last_error().decode()))

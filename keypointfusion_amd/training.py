@@ -1541,28 +1541,38 @@ def add_relu(a, b=None, c=None, scale=1.0):
 
 
 class BmmSmallK(torch.autograd.Function):
-    """out[b] = A[b] (J x P) @ X[b] (P x C) with few rows J (the 21 joints): forward and dA on the library's batched GEMM (10-12 us),
-    dX = A^T dOut — a K = J product the library takes 443 us for — on kpf_bmm_small_k_dx."""
+    """out[b] = A[b] (J x P) @ X[b] (P x C) with few rows J (the 21 joints; model/model.py:318-320, 336-341): all three products on the HIP kernels —
+    forward kpf_bmm_small_k_fwd, dA = dOut X^T kpf_bmm_small_k_da, dX = A^T dOut kpf_bmm_small_k_dx (a K = J batched GEMM the library takes 443 us for;
+    the other two sat on torch.bmm until round 5).  Fixed summation orders: replays are bit-identical."""
 
     @staticmethod
     def forward(ctx, A, X):
+        from . import lib as L
         A, X = A.float().contiguous(), X.float().contiguous()
+        B, J, P = A.shape
+        Cc = X.shape[-1]
+        assert X.shape[:2] == (B, P) and J <= 24 and Cc % 4 == 0, "bmm_small_k: A [B, J <= 24, P] @ X [B, P, C % 4 == 0]"
         ctx.save_for_backward(A, X)
-        return torch.bmm(A, X)
+        out = torch.empty(B, J, Cc, device=A.device, dtype=torch.float32)
+        L.check(L.load().kpf_bmm_small_k_fwd(A.data_ptr(), X.data_ptr(), out.data_ptr(), B, J, P, Cc, torch.cuda.current_stream().cuda_stream), "kpf_bmm_small_k_fwd")
+        return out
 
     @staticmethod
     def backward(ctx, dout):
         from . import lib as L
+        lib = L.load()
         A, X = ctx.saved_tensors
         B, J, P = A.shape
         Cc = X.shape[-1]
         dout = dout.float().contiguous()
-        dA = torch.bmm(dout, X.transpose(1, 2)) if ctx.needs_input_grad[0] else None
-        dX = None
+        st = torch.cuda.current_stream().cuda_stream
+        dA = dX = None
+        if ctx.needs_input_grad[0]:
+            dA = torch.empty_like(A)
+            L.check(lib.kpf_bmm_small_k_da(dout.data_ptr(), X.data_ptr(), dA.data_ptr(), B, J, P, Cc, st), "kpf_bmm_small_k_da")
         if ctx.needs_input_grad[1]:
             dX = torch.empty_like(X)
-            L.check(L.load().kpf_bmm_small_k_dx(A.data_ptr(), dout.data_ptr(), dX.data_ptr(), B, J, P, Cc, torch.cuda.current_stream().cuda_stream),
-                    "kpf_bmm_small_k_dx")
+            L.check(lib.kpf_bmm_small_k_dx(A.data_ptr(), dout.data_ptr(), dX.data_ptr(), B, J, P, Cc, st), "kpf_bmm_small_k_dx")
         return dA, dX
 
 

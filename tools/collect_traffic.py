@@ -10,6 +10,11 @@ Guards (a child workload's file was averaged into the headline's fi
 import collections, csv, glob, json, sys
 
 
+def has(sub, name):
+    """bench.py labels both forms of the 16-bit implicit GEMM `igemm_h16_kernel`; rocprofv3 sees igemm_h16_kernel<...> and igemm_h16_occ_kernel<...>"""
+    return sub in name or (sub == "igemm_h16_kernel" and "igemm_h16_occ_kernel" in name)
+
+
 def totals(d, name, sub):
     per = collections.defaultdict(lambda: [0.0, 0])
     files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
@@ -17,7 +22,7 @@ def totals(d, name, sub):
         sys.exit("collect_traffic: no counter_collection.csv under %s" % d)
     for f in files:
         for r in csv.DictReader(open(f)):
-            if sub in r["Kernel_Name"] and r["Counter_Name"] == name:
+            if has(sub, r["Kernel_Name"]) and r["Counter_Name"] == name:
                 p = per[(f, r.get("Process_Id", "?"))]
                 p[0] += float(r["Counter_Value"])
                 p[1] += 1

@@ -4,11 +4,17 @@ With a bench log (the JSON line the profiled command printed) the call count is 
 launches_per_step x (steps + warmup + 2 instrumented passes) launches of the dominant kernel."""
 import csv, glob, json, shutil, sys
 
+
+def has(sub, name):
+    """bench.py labels both forms of the 16-bit implicit GEMM `igemm_h16_kernel`; rocprofv3 sees igemm_h16_kernel<...> and igemm_h16_occ_kernel<...>"""
+    return sub in name or (sub == "igemm_h16_kernel" and "igemm_h16_occ_kernel" in name)
+
+
 d, sub, out = sys.argv[1:4]
 log = sys.argv[4] if len(sys.argv) > 4 else None
 cands = []
 for f in glob.glob(d + "/**/*kernel_stats.csv", recursive=True):
-    calls = sum(int(r["Calls"]) for r in csv.DictReader(open(f)) if sub in r["Name"])
+    calls = sum(int(r["Calls"]) for r in csv.DictReader(open(f)) if has(sub, r["Name"]))
     if calls:
         cands.append((calls, f))
 if len(cands) != 1:

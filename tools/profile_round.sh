@@ -1,43 +1,62 @@
 #!/bin/bash
-# Collects the rocprofv3 evidence of a round on the GPU box (run through gpurun from the repo root):  bash tools/profile_round.sh r04
+# Collects the rocprofv3 evidence of a round on the GPU box (run through gpurun from the repo root):  bash tools/profile_round.sh r05 [quick]
+# Every profiled command is ONE process (--no-extra: bench.py also refuses to start its secondary workloads under a profiler), the file
+# that is copied is the one whose rows contain the expected kernel with the expected launch count (tools/pick_stats.py), and the PMC
+# passes are checked the same way (tools/collect_traffic.py): VERDICT r04 found a child workload's files behind the headline's labels.
 # kernel-trace statistics of the headline command (both backbones on one stream, so per-kernel durations are each kernel's own) and the
 # two PMC passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass) of the same command; summaries land in gpurun_out/<tag>_*.
-TAG=${1:-r04}
+TAG=${1:-r05}
+MODE=${2:-full}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="$ROOT/bench.py --serial-streams --no-cpu-baseline --no-split-record"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_f32 -- python3 $CMD --steps 15 > $OUT/prof_${TAG}_f32.log 2>&1
-cp $(find $OUT/prof_${TAG}_f32 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats.csv
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_${TAG}_fetch -- python3 $CMD --steps 3 --warmup 1 > $OUT/pmc_${TAG}_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_${TAG}_write -- python3 $CMD --steps 3 --warmup 1 > $OUT/pmc_${TAG}_write.log 2>&1
-python3 $ROOT/tools/collect_traffic.py $OUT/pmc_${TAG}_fetch $OUT/pmc_${TAG}_write $OUT/${TAG}_traffic.json igemm_f32_kernel
-# configs[4]: HBM traffic of the dominant 16-bit kernel (gemm16_8ph_kernel), same two PMC passes
-CMD4="$ROOT/bench.py --workload cnb512_f16 --serial-streams --no-cpu-baseline"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_${TAG}_fetch4 -- python3 $CMD4 --steps 2 --warmup 1 > $OUT/pmc_${TAG}_fetch4.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_${TAG}_write4 -- python3 $CMD4 --steps 2 --warmup 1 > $OUT/pmc_${TAG}_write4.log 2>&1
-python3 $ROOT/tools/collect_traffic.py $OUT/pmc_${TAG}_fetch4 $OUT/pmc_${TAG}_write4 $OUT/${TAG}_traffic_cnb512.json gemm16_8ph_kernel
-for W in full128 full128_bf16 cnb512_f16; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_$W -- python3 $ROOT/bench.py --workload $W --serial-streams --no-cpu-baseline --no-split-record --steps 10 > $OUT/prof_${TAG}_$W.log 2>&1
-  cp $(find $OUT/prof_${TAG}_$W -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_${W}_kernel_stats.csv
-done
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_train128 -- python3 $ROOT/bench.py --workload train128 --no-cpu-baseline --steps 10 --warmup 3 > $OUT/prof_${TAG}_train128.log 2>&1
-cp $(find $OUT/prof_${TAG}_train128 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_train128_kernel_stats.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_train128_bf16 -- python3 $ROOT/bench.py --workload train128_bf16 --no-cpu-baseline --steps 10 --warmup 3 > $OUT/prof_${TAG}_train128_bf16.log 2>&1
-cp $(find $OUT/prof_${TAG}_train128_bf16 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_train128_bf16_kernel_stats.csv
-# ONE graph replay of the training iteration cut out of the same traces: launches, kernel time, library share (tools/replay_histogram.py)
-python3 $ROOT/tools/replay_histogram.py $OUT/prof_${TAG}_train128_bf16 $OUT/${TAG}_train128_bf16_replay_hist.txt 2> /dev/null
-python3 $ROOT/tools/replay_histogram.py $OUT/prof_${TAG}_train128 $OUT/${TAG}_train128_replay_hist.txt 2> /dev/null
+stats() {  # stats <name> <kernel> <bench args...>: rocprofv3 --kernel-trace --stats of one bench.py command -> <tag>_<name>_kernel_stats.csv
+  local name=$1 kern=$2; shift 2
+  rm -rf $OUT/prof_${TAG}_$name
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_$name -- python3 $ROOT/bench.py "$@" > $OUT/prof_${TAG}_$name.log 2> $OUT/prof_${TAG}_$name.err
+  python3 $ROOT/tools/pick_stats.py $OUT/prof_${TAG}_$name $kern $OUT/${TAG}_${name}_kernel_stats.csv $OUT/prof_${TAG}_$name.log
+}
+traffic() {  # traffic <name> <kernel> <bench args...>: two PMC passes of one bench.py command -> <tag>_traffic<name>.json
+  local name=$1 kern=$2; shift 2
+  rm -rf $OUT/pmc_${TAG}_fetch$name $OUT/pmc_${TAG}_write$name
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_${TAG}_fetch$name -- python3 $ROOT/bench.py "$@" > $OUT/pmc_${TAG}_fetch$name.log 2> $OUT/pmc_${TAG}_fetch$name.err
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_${TAG}_write$name -- python3 $ROOT/bench.py "$@" > $OUT/pmc_${TAG}_write$name.log 2> $OUT/pmc_${TAG}_write$name.err
+  python3 $ROOT/tools/collect_traffic.py $OUT/pmc_${TAG}_fetch$name $OUT/pmc_${TAG}_write$name $OUT/${TAG}_traffic$name.json $kern $OUT/pmc_${TAG}_fetch$name.log \
+    && cp $OUT/${TAG}_traffic$name.json $ROOT/profiles/
+  rm -rf $OUT/pmc_${TAG}_fetch$name $OUT/pmc_${TAG}_write$name
+}
+HEAD="--serial-streams --no-cpu-baseline --no-split-record --no-extra"
+# configs[1], the headline: 136 igemm_f32_kernel launches per step
+stats bench igemm_f32_kernel $HEAD --steps 15
+traffic "" igemm_f32_kernel $HEAD --steps 3 --warmup 1
+# configs[4]
+stats cnb512_f16 gemm16_8ph_kernel --workload cnb512_f16 $HEAD --steps 6 --warmup 2
+traffic _cnb512 gemm16_8ph_kernel --workload cnb512_f16 $HEAD --steps 2 --warmup 1
+# configs[2]
+stats full128_bf16 igemm_h16_kernel --workload full128_bf16 $HEAD --steps 10
+traffic _full128_bf16 igemm_h16_kernel --workload full128_bf16 $HEAD --steps 3 --warmup 1
+if [ "$MODE" != quick ]; then
+  stats full128 igemm_f32_kernel --workload full128 $HEAD --steps 10
+  # configs[3]: the PMC passes run the iteration eagerly (--no-graph: counters are collected per dispatch), the trace replays the graph
+  traffic _train128_bf16 auto --workload train128_bf16 --no-graph --no-cpu-baseline --no-extra --steps 3 --warmup 1
+  for W in train128 train128_bf16; do
+    rm -rf $OUT/prof_${TAG}_$W
+    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_$W -- python3 $ROOT/bench.py --workload $W --no-cpu-baseline --no-extra --steps 10 --warmup 3 > $OUT/prof_${TAG}_$W.log 2> $OUT/prof_${TAG}_$W.err
+    python3 $ROOT/tools/pick_stats.py $OUT/prof_${TAG}_$W adamw_multi_kernel $OUT/${TAG}_${W}_kernel_stats.csv
+    # ONE graph replay of the training iteration cut out of the same trace: launches, kernel time, library share
+    python3 $ROOT/tools/replay_histogram.py $OUT/prof_${TAG}_$W $OUT/${TAG}_${W}_replay_hist.txt 2> /dev/null
+  done
+fi
 # the bench lines of the same build, without the profiler (the traffic files just collected are what `roofline.traffic` quotes)
 cd $ROOT
-cp $OUT/${TAG}_traffic.json $OUT/${TAG}_traffic_cnb512.json $ROOT/profiles/ 2>/dev/null
-python3 bench.py --no-extra > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-for W in full128 full128_bf16 cnb512_f16 train128 train128_bf16; do
-  python3 bench.py --workload $W --no-cpu-baseline > $OUT/${TAG}_bench_$W.json 2> $OUT/${TAG}_bench_$W.err
-done
+python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+if [ "$MODE" != quick ]; then
+  for W in full128 full128_bf16 cnb512_f16 train128 train128_bf16; do
+    python3 bench.py --workload $W --no-cpu-baseline > $OUT/${TAG}_bench_$W.json 2> $OUT/${TAG}_bench_$W.err
+  done
+  python3 tools/shape_table.py > $OUT/${TAG}_shape_table.txt 2>/dev/null
+fi
 # keep the merge small: the raw traces stay on the box
-for d in $OUT/prof_${TAG}_* $OUT/pmc_${TAG}_fetch $OUT/pmc_${TAG}_write $OUT/pmc_${TAG}_fetch4 $OUT/pmc_${TAG}_write4; do [ -d "$d" ] && rm -rf "$d"; done
-python3 tools/shape_table.py > $OUT/${TAG}_shape_table.txt 2>/dev/null
-[ -x tools/bin/mfma_issue_rate2 ] && tools/bin/mfma_issue_rate2 > $OUT/${TAG}_mfma_issue_rate2.txt
+for d in $OUT/prof_${TAG}_*; do [ -d "$d" ] && rm -rf "$d"; done
 ls -la $OUT | grep ${TAG}_
