@@ -725,6 +725,43 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
     KPF_STAMP(3);
     return;
   }
+  // NCHW output (the 105-channel heads, model/model.py finals: fp32 planes also on the 16-bit path) when the pixel tile lies inside one image:
+  // the tile is transposed through LDS, 16 * WN channels at a time, and every channel's BM pixels leave as one contiguous run of float4 stores
+  // (the per-element path below writes 64-byte pieces with four scalar stores per lane and quad: 125 us for the 262144 x 105 x 128 head, round 5).
+  if constexpr (EPI == EPI_LIN) {
+    if ((fl & KPF_OUT_NCHW) && a.ohow % BM == 0 && m0 + BM <= a.M && !(fl & KPF_OUT_SPLIT)) {  // workgroup-uniform
+      constexpr int RS = BM + 4;  // row stride in floats: lane groups fg land 16 banks apart
+      static_assert(WN * 16 * RS <= NS * TILE, "the transpose staging fits the K buffers");
+      const int b = m0 / a.ohow, pix0 = m0 - b * a.ohow;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        __syncthreads();  // every wave is done with the K tiles (first pass) / with the previous pass's staging rows
+        const int nq = n0 + (wn * TN + i) * 16 + fg * 4;
+        float bq[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bq[e] = (a.bias && nq + e < a.N) ? a.bias[nq + e] : 0.f;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          const int ml = (wm * TM + j) * 16 + fr;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float y = (SPLIT ? acc[i][j][e] * a.w_unscale : acc[i][j][e]) + bq[e];
+            if (fl & KPF_ACT_RELU) y = fmaxf(y, 0.f);
+            if (fl & KPF_ACT_LEAKY) y = fmaxf(y, 0.01f * y);
+            lds[(wn * 16 + fg * 4 + e) * RS + ml] = y;
+          }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < WN * 16 * (BM / 4); idx += 64 * NW) {
+          const int r = idx / (BM / 4), c4 = idx - r * (BM / 4);
+          const int n = n0 + ((r >> 4) * TN + i) * 16 + (r & 15);
+          if (n < a.N) STORE4(a.out + ((long)b * a.N + n) * a.ohow + pix0 + 4 * c4, *reinterpret_cast<const f32x4*>(lds + r * RS + 4 * c4));
+        }
+      }
+      KPF_STAMP(3);
+      return;
+    }
+  }
   // edge / NCHW / unaligned path: per-element guards
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
@@ -1273,6 +1310,227 @@ int launch_8ph(ConvArgs& a, hipStream_t st) {
   return kpf_check_launch("kpf_conv2d_h16");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// gemm16_dfe_kernel (round 5): 256 x 128 tiles, persistent, with a DEFERRED epilogue — the answer to profiles/r04_g8_ablation.txt, where a K = 512
+// GELU layer spends 60 % of a tile's time in its epilogue (GELU on the vector ALU, 128 KB of stores) with the matrix pipe idle, and where stores
+// issued from inside the main loop bought nothing because they sit in the same in-order vmcnt queue as the LDS-DMA.  Here
+//  * a tile's raw accumulators (64 registers: 8 waves = 4 pixel quarters x 2 channel halves, wave tile 64 x 64) are parked in a second register set
+//    when its K loop ends, and its epilogue runs INSIDE the next tile's K loop, one 16-row strip per wave every second K tile: bias + activation ->
+//    storage type -> a 16-KB LDS staging area (64 rows x 128 channels, 16-byte chunks XOR-swizzled by the row) -> whole 256-byte rows to memory;
+//  * memory duties are split by wave so that no wave's vmcnt queue mixes loads and stores: waves 0-3 issue ALL LDS-DMA (12 instructions per K tile
+//    each) and wait on it with a counted vmcnt(12); waves 4-7 issue ALL global stores and never wait for them inside the loop (the staged data is in
+//    registers before the store is issued).  Every wave multiplies; a SIMD hosts one wave of each kind;
+//  * the K-tile stream is continuous across output tiles: a 3-stage ring of 48-KB buffers (A 256 rows + B 128 rows of 64 elements), two K tiles in
+//    flight, the first K tiles of the next output tile staged under the last MFMAs of the current one; one barrier per K tile;
+//  * the bias is fetched with scalar loads (s_load: lgkmcnt) and selected per lane, so that no wave needs a vector load whose result the compiler
+//    would guard with vmcnt(0).
+// Same LDS row image, swizzle, packed weights and k order as igemm_body / gemm16_8ph_kernel: results are bit-identical to theirs.
+// Requirements (dfe_applies): dense 1x1, K % 64 == 0 with at least 8 K tiles, N % 128 == 0, M % 256 == 0, linear / ReLU / GELU epilogue, 16-byte rows.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int DF_A = 32768, DF_BUF = 49152, DF_STG = 3 * DF_BUF;  // bytes: A region of a K-tile buffer, a K-tile buffer, offset of the staging area
+
+template <int EPI, int ARITH>
+__global__ __launch_bounds__(512, 2) void gemm16_dfe_kernel(const ConvArgs a) {
+  using TH = typename std::conditional<ARITH == ARITH_BF16, bf16_t, f16_t>::type;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* const LB = reinterpret_cast<char*>(lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wq = wave & 3, wc = wave >> 2;  // pixel quarter, channel half; waves wq and wq + 4 share a SIMD
+  const bool dma_wave = wc == 0;            // waves 0-3: LDS-DMA; waves 4-7: global stores
+  const int G = (int)gridDim.x;
+  int bid = blockIdx.x;
+  {  // XCD-aware bijective remap of every round of G tiles (igemm_body): an XCD gets a contiguous range, channel tiles fastest
+    const int q = G >> 3, r = G & 7, x = bid & 7, i = bid >> 3;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+  }
+  const int nk = a.Kp / BK;
+  const int mine = (a.nblk - bid + G - 1) / G;  // output tiles of this workgroup: bid, bid + G, ...
+  const int total = mine * nk;                  // K tiles it multiplies
+
+  // ---- staging cursor (runs two K tiles ahead of the multiply cursor, across output tiles) ----
+  const int r8 = lane >> 3, cp = lane & 7, x4 = lane >> 4;
+  const int kce = ((cp ^ x4) << 2), kco = (((cp ^ x4) ^ 4) << 2);  // logical k offset (words) of this lane's chunk in even / odd 8-row groups: (row >> 1) & 7 = (4 t + x4) & 7
+  int s_tile = bid, s_kt = 0, s_g = 0;
+  const float *pae = a.in, *pao = a.in, *pbe = a.w, *pbo = a.w;
+  auto s_set = [&]() {
+    const int nt = s_tile % a.tilesN, mt = s_tile / a.tilesN;
+    const float* pa = a.in + (long)(mt * 256 + wq * 64 + r8) * a.in_ld + a.in_coff;
+    const float* pb = a.w + (long)(nt * 128 + wq * 32 + r8) * a.Kp;
+    pae = pa + kce; pao = pa + kco; pbe = pb + kce; pbo = pb + kco;
+  };
+  s_set();
+  auto stage_next = [&]() {  // DMA waves: the 12 DMAs of K tile (s_tile, s_kt) into ring slot s_g % 3, then advance
+    char* const dst = LB + (s_g % 3) * DF_BUF;
+    const int ko = s_kt * BK;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(((t & 1) ? pao : pae) + (long)(8 * t) * a.in_ld + ko), (lds_void_t*)(dst + (wq * 64 + 8 * t) * 128), 16, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(((t & 1) ? pbo : pbe) + (long)(8 * t) * a.Kp + ko), (lds_void_t*)(dst + DF_A + (wq * 32 + 8 * t) * 128), 16, 0, 0);
+    ++s_g;
+    if (++s_kt == nk) {
+      s_kt = 0;
+      s_tile += G;
+      s_set();
+    }
+  };
+
+  // ---- fragments / accumulators ----
+  const int fr = lane & 15, fg = lane >> 4, rsw = (fr >> 1) & 7;
+  const int ch0 = ((fg ^ rsw) << 4), ch1 = (((4 + fg) ^ rsw) << 4);
+  const char* const a_rd = LB + (wq * 64 + fr) * 128;
+  const char* const b_rd = LB + DF_A + (wc * 64 + fr) * 128;
+  f32x4 acc[4][4], prev[4][4];  // [channel tile i][pixel tile j]
+  f32x4 bq[4];                  // bias of the PARKED tile: channels wc * 64 + i * 16 + fg * 4 + e
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    bq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = prev[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  int c_tile = bid, m0 = (c_tile / a.tilesN) * 256, n0 = (c_tile % a.tilesN) * 128;
+  int pm0 = 0, pn0 = 0;
+  bool has_prev = false;
+  const unsigned fl = a.flags;
+
+  // ---- deferred epilogue pieces ----
+  auto write_piece = [&](auto J) {  // every wave: strip J of its parked tile -> staging rows wq * 16 + fr
+    constexpr int j = decltype(J)::value;
+    const int sr = wq * 16 + fr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x4 v = prev[i][j];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float y = v[e] + bq[i][e];
+        if (EPI == EPI_GELU) v[e] = gelu_of<ARITH>(y);
+        else v[e] = (fl & KPF_ACT_RELU) ? fmaxf(y, 0.f) : ((fl & KPF_ACT_LEAKY) ? fmaxf(y, 0.01f * y) : y);
+      }
+      kpf_st4(reinterpret_cast<TH*>(LB + DF_STG + sr * 256 + (((wc * 8 + i * 2 + (fg >> 1)) ^ (sr & 15)) << 4) + (fg & 1) * 8), v);
+    }
+  };
+  auto store_piece = [&](auto J) {  // store waves: 16 staging rows each, whole 256-byte rows (16 lanes x 16 bytes), 4 rows per instruction
+    constexpr int j = decltype(J)::value;
+    if (!dma_wave) {
+      TH* const ob = reinterpret_cast<TH*>(a.out) + a.out_coff + pn0 + (lane & 15) * 8;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int sr = wq * 16 + u * 4 + (lane >> 4);
+        const f32x4 q = *reinterpret_cast<const f32x4*>(LB + DF_STG + sr * 256 + (((lane & 15) ^ (sr & 15)) << 4));
+        *reinterpret_cast<f32x4*>(ob + (long)(pm0 + (sr >> 4) * 64 + j * 16 + (sr & 15)) * a.out_ld) = q;
+      }
+    }
+  };
+  auto load_bias = [&](int n_base) {  // scalar loads (lgkmcnt, not vmcnt) of the wave's 64 bias values, selected per lane group
+    if (a.bias) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float* bp = a.bias + n_base + wc * 64 + i * 16;
+        f32x4 b0, b1, b2, b3;
+        asm volatile("s_load_dwordx4 %0, %4, 0x0\n\ts_load_dwordx4 %1, %4, 0x10\n\ts_load_dwordx4 %2, %4, 0x20\n\ts_load_dwordx4 %3, %4, 0x30\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(b0), "=&s"(b1), "=&s"(b2), "=&s"(b3) : "s"(bp) : "memory");
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bq[i][e] = fg == 0 ? b0[e] : (fg == 1 ? b1[e] : (fg == 2 ? b2[e] : b3[e]));
+      }
+    }
+  };
+
+  // ---- the K-tile stream ----
+  if (dma_wave) {
+    stage_next();
+    if (total > 1) stage_next();
+  }
+  int kt = 0;
+  for (int g = 0; g < total; ++g) {
+    if (dma_wave) {
+      if (g + 1 < total) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // K tile g has landed (g + 1 may be in flight)
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();  // K tile g is everyone's; everyone has read K tile g - 1 (ring slot (g + 2) % 3) and the staging area is in its next phase
+    __builtin_amdgcn_sched_barrier(0);
+    if (dma_wave && g + 2 < total) stage_next();
+    const char* const ab = a_rd + (g % 3) * DF_BUF;
+    const char* const bb = b_rd + (g % 3) * DF_BUF;
+    f16x8 x0[4], w0[4], x1[4], w1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x0[j] = *reinterpret_cast<const f16x8*>(ab + j * 2048 + ch0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w0[i] = *reinterpret_cast<const f16x8*>(bb + i * 2048 + ch0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x1[j] = *reinterpret_cast<const f16x8*>(ab + j * 2048 + ch1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w1[i] = *reinterpret_cast<const f16x8*>(bb + i * 2048 + ch1);
+    if (has_prev) {  // one step of the parked tile's epilogue per K tile: strip kt / 2 written (even kt) / stored (odd kt)
+      switch (kt) {
+        case 0: write_piece(ic<0>{}); break;
+        case 1: store_piece(ic<0>{}); break;
+        case 2: write_piece(ic<1>{}); break;
+        case 3: store_piece(ic<1>{}); break;
+        case 4: write_piece(ic<2>{}); break;
+        case 5: store_piece(ic<2>{}); break;
+        case 6: write_piece(ic<3>{}); break;
+        case 7: store_piece(ic<3>{}); break;
+        default: break;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (ARITH == ARITH_BF16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w0[i]), __builtin_bit_cast(bf16x8, x0[j]), acc[i][j], 0, 0, 0);
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[i], x0[j], acc[i][j], 0, 0, 0);
+      }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (ARITH == ARITH_BF16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w1[i]), __builtin_bit_cast(bf16x8, x1[j]), acc[i][j], 0, 0, 0);
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[i], x1[j], acc[i][j], 0, 0, 0);
+      }
+    if (++kt == nk) {  // the output tile is complete: park it, start the next one
+      kt = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          prev[i][j] = acc[i][j];
+          acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      load_bias(n0);
+      pm0 = m0;
+      pn0 = n0;
+      has_prev = true;
+      c_tile += G;
+      m0 = (c_tile / a.tilesN) * 256;
+      n0 = (c_tile % a.tilesN) * 128;
+    }
+  }
+  // ---- drain: the last tile's epilogue ----
+  __syncthreads();
+  write_piece(ic<0>{}); __syncthreads(); store_piece(ic<0>{}); __syncthreads();
+  write_piece(ic<1>{}); __syncthreads(); store_piece(ic<1>{}); __syncthreads();
+  write_piece(ic<2>{}); __syncthreads(); store_piece(ic<2>{}); __syncthreads();
+  write_piece(ic<3>{}); __syncthreads(); store_piece(ic<3>{});
+}
+
+template <int ARITH>
+int launch_dfe(ConvArgs& a, hipStream_t st) {
+  const bool gelu = a.flags & KPF_ACT_GELU;
+  a.tilesN = a.N / 128;
+  a.nblk = (a.M / 256) * a.tilesN;
+  void (*kern)(const ConvArgs) = gelu ? gemm16_dfe_kernel<EPI_GELU, ARITH> : gemm16_dfe_kernel<EPI_LIN, ARITH>;
+  static std::atomic<bool> lds_opt_in[2][KPF_MAX_DEVICES];
+  if (!kpf_raise_lds_limit(reinterpret_cast<const void*>(kern), lds_opt_in[gelu ? 1 : 0])) {
+    kpf_set_error("kpf_conv2d_h16: cannot raise the dynamic LDS limit");
+    return KPF_ELAUNCH;
+  }
+  const int grid = a.nblk < 256 ? a.nblk : 256;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), (size_t)(DF_STG + 16384), st, a);
+  return kpf_check_launch("kpf_conv2d_h16");
+}
+
 // ---- 16-bit storage path (kpf_conv16.hip compiles this file with KPF_CONV_H16) ----
 template <int TM, int TN, int WM, int WN, int ARITH, int NS>
 int launch_arith_h16(ConvArgs& a, bool fast1x1, bool pointwise, hipStream_t st) {
@@ -1329,6 +1587,12 @@ static bool g8_applies(const kpf_conv_desc* d, bool has_prologue) {
   //  KPF_FORCE_CFG16=30 cannot route such a launch to it either)
   const bool plain = d->groups <= 1 && !(fl & (KPF_RES_GELU_GRAD | KPF_ACT_GELU_SAVE));
   return plain && fast1x1 && d->Kp % 128 == 0 && d->N % 256 == 0 && !has_prologue && !(fl & KPF_OUT_NCHW) && vec && d->out_ld % 8 == 0 && d->out_coff % 8 == 0;
+}
+// which launches gemm16_dfe_kernel covers (the 256 x 128 deferred-epilogue kernel: linear / ReLU / GELU layers of at least 8 K tiles)
+static bool dfe_applies(const kpf_conv_desc* d, bool has_prologue) {
+  const unsigned fl = d->flags;
+  const long M = (long)d->B * d->OH * d->OW;
+  return g8_applies(d, has_prologue) && !(fl & KPF_RES_ADD) && d->N % 128 == 0 && M % 256 == 0 && d->Kp >= 512 && (M / 256) * (d->N / 128) >= 512;
 }
 static bool g8_preferred(const kpf_conv_desc* d) {
   const long M = (long)d->B * d->OH * d->OW;
@@ -1447,7 +1711,15 @@ extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void
   static const int forced = []() { const char* e = getenv("KPF_FORCE_CFG16"); return e ? atoi(e) : -1; }();  // tuning aid only
   if (forced >= 0 && (forced != 30 || ok8)) best = forced;
   if (d->tile_cfg > 0 && (d->tile_cfg != 31 || ok8)) best = d->tile_cfg - 1;  // the caller's choice (tools/h16_small_sweep.py): case index + 1
+  static const int use_dfe = []() { const char* e = getenv("KPF_DFE"); return e ? atoi(e) : 0; }();  // tuning switch until the default is measured
+  const bool okd = dfe_applies(d, pro_scale != nullptr);
+  if (best == 30 && okd && use_dfe) best = 50;
+  if (best == 50 && !okd) best = ok8 ? 30 : 0;
+  if (best == 50) return dtype == KPF_DT_BF16 ? launch_dfe<ARITH_BF16>(a, st) : launch_dfe<ARITH_F16>(a, st);
   if (best == 30) return dtype == KPF_DT_BF16 ? launch_8ph<ARITH_BF16>(a, st) : launch_8ph<ARITH_F16>(a, st);
+#ifdef KPF_FAST_BUILD  // tuning aid: one tile shape only (asm inspection / quick syntax builds), never shipped
+  return launch_cfg_h16<4, 4, 2, 2, 2>(a, fast1x1, pointwise, dtype, st);
+#endif
   switch (best) {
     case 0: return occ ? launch_cfg_h16<4, 4, 2, 2, 1>(a, fast1x1, pointwise, dtype, st) : launch_cfg_h16<4, 4, 2, 2, 2>(a, fast1x1, pointwise, dtype, st);
     case 1: return launch_cfg_h16<4, 3, 2, 2, 2>(a, fast1x1, pointwise, dtype, st);  // 128 x 96

@@ -20,11 +20,6 @@ DW_STATS = bool(int(__import__("os").environ.get("KPF_DW_STATS", "1")))  # depth
 DW_STATS_MIN_C = int(__import__("os").environ.get("KPF_DW_STATS_MIN_C", "256"))  # (at C = 128 the one-pass wave kernel is still faster: 311 vs 363 us)
 
 
-# Unfused MLP (C >= 512: stages 3-4 of ConvNeXt-B) in row chunks: pwconv1 -> pwconv2 per chunk of the batch, so that the 4C-wide hidden tensor
-# of a chunk is still in the 256-MiB Infinity Cache when pwconv2 reads it (at B = 64, 512 x 512 the whole hidden tensor is 268 MB + 134 MB of x / y).
-# 0 = choose per shape (hidden bytes per chunk <= MLP16_CHUNK_MB), 1 = never
-MLP16_CHUNKS = int(__import__("os").environ.get("KPF_MLP16_CHUNKS", "0"))
-MLP16_CHUNK_MB = float(__import__("os").environ.get("KPF_MLP16_CHUNK_MB", "0"))  # 0: chunking off by default until measured
 FORCE_TILE16 = 0  # tuning aid (tools/h16_small_sweep.py): tile case + 1 for every kpf_conv2d_h16 launch, 0 = the library's choice
 
 
@@ -163,22 +158,6 @@ class Block16:
             _launch("convnext_mlp_h16_kernel", 16.0 * M * c * c, 2.0 * (3 * M * c + 8 * c * c), (M, c, 4 * c, 1, 1),
                     lambda: L.check(L.load().kpf_convnext_mlp_h16(_ptr(y.buf), _ptr(x.buf), _ptr(self.pw1.w), _ptr(self.pw1.pc.b), _ptr(self.w2c), _ptr(self.pw2.pc.b),
                                                                   _ptr(self.gamma), _ptr(x.buf), M, c, kdt, _stream()), "kpf_convnext_mlp_h16"))
-            return x
-        nch = MLP16_CHUNKS
-        if nch == 0 and MLP16_CHUNK_MB > 0:
-            hid_mb = x.B * x.H * x.W * 4 * x.C * 2 / 1e6
-            nch = 1
-            while hid_mb / nch > MLP16_CHUNK_MB and x.B % (2 * nch) == 0:
-                nch *= 2
-        if nch > 1 and x.B % nch == 0 and x.ld == x.C and x.coff == 0:
-            bc = x.B // nch
-            rows = bc * x.H * x.W
-            sub = lambda a, i: Act(a.buf[i * rows * a.C:(i + 1) * rows * a.C], bc, a.H, a.W, a.C)
-            hc = Act(h.buf[:rows * h.C], bc, h.H, h.W, h.C)  # one chunk's hidden rows, rewritten by every chunk
-            for i in range(nch):
-                conv16(self.pw1, sub(y, i), kdt, out=hc, flags=L.KPF_ACT_GELU)
-                xi = sub(x, i)
-                conv16(self.pw2, hc, kdt, out=xi, gamma=self.gamma, res=xi)
             return x
         conv16(self.pw1, y, kdt, out=h, flags=L.KPF_ACT_GELU)
         conv16(self.pw2, h, kdt, out=x, gamma=self.gamma, res=x)

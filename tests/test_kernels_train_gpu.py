@@ -864,7 +864,12 @@ def test_paired_backbones_match_the_two_pass_training_graph(prec, monkeypatch):
         for a, b in zip(r0, r1):
             assert rel(a, b) <= 1e-4, rel(a, b)
         assert abs(l0 - l1) <= 1e-4 * abs(l0), (l0, l1)
-        errs = sorted((rel(g0[k], g1[k]), k) for k in g0)
+        # (biases in front of a batch-statistics BatchNorm — FA.conv_l0_blocks.*.bias, *_emb.0.bias — have an exactly zero gradient: what the two passes
+        #  hold there is rounding noise of ~1e-8, whose RELATIVE difference means nothing; every tensor is therefore measured against at least 1e-5 of the
+        #  largest gradient of the model)
+        floor = 1e-5 * max(float(v.float().abs().max()) for v in g0.values())
+        relf = lambda a, b: float((a.float() - b.float()).abs().max()) / max(float(a.float().abs().max()), floor)
+        errs = sorted((relf(g0[k], g1[k]), k) for k in g0)
         assert errs[len(errs) // 2][0] <= 1e-3 and errs[-1][0] <= 5e-2, (errs[len(errs) // 2], errs[-8:])
         for k in b0:
             assert torch.allclose(b0[k], b1[k], rtol=1e-4, atol=1e-5), k
