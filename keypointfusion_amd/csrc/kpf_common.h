@@ -82,7 +82,12 @@ __device__ __forceinline__ f32x4 kpf_ld4(const bf16_t* p) {  // bf16 -> fp32 is 
 }
 __device__ __forceinline__ void kpf_st4(float* p, const f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 __device__ __forceinline__ void kpf_st4(f16_t* p, const f32x4 v) {
-  *reinterpret_cast<f16x4*>(p) = f16x4{(f16_t)v[0], (f16_t)v[1], (f16_t)v[2], (f16_t)v[3]};
+  // The value is pinned as an fp32 register first: left to itself the compiler fuses the multiply / add that produced it with the conversion
+  // (v_fma_mixlo_f16: ONE rounding) in some instantiations and not in others (v_mul_f32 + v_cvt_pk_f16_f32: two) — 3e-5 of the elements then differ
+  // by an ulp between two kernels that compute the same layer, and a sample's result must not depend on which kernel its batch size selects.
+  f32x4 u = v;
+  asm("" : "+v"(u));
+  *reinterpret_cast<f16x4*>(p) = f16x4{(f16_t)u[0], (f16_t)u[1], (f16_t)u[2], (f16_t)u[3]};
 }
 __device__ __forceinline__ void kpf_st4(bf16_t* p, const f32x4 v) {  // round to nearest even (v_cvt_pk_bf16_f32)
   *reinterpret_cast<bf16x4*>(p) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};

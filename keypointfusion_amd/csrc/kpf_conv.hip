@@ -1314,20 +1314,28 @@ int launch_8ph(ConvArgs& a, hipStream_t st) {
 // gemm16_dfe_kernel (round 5): 256 x 128 tiles, persistent, with a DEFERRED epilogue — the answer to profiles/r04_g8_ablation.txt, where a K = 512
 // GELU layer spends 60 % of a tile's time in its epilogue (GELU on the vector ALU, 128 KB of stores) with the matrix pipe idle, and where stores
 // issued from inside the main loop bought nothing because they sit in the same in-order vmcnt queue as the LDS-DMA.  Here
-//  * a tile's raw accumulators (64 registers: 8 waves = 4 pixel quarters x 2 channel halves, wave tile 64 x 64) are parked in a second register set
-//    when its K loop ends, and its epilogue runs INSIDE the next tile's K loop, one 16-row strip per wave every second K tile: bias + activation ->
-//    storage type -> a 16-KB LDS staging area (64 rows x 128 channels, 16-byte chunks XOR-swizzled by the row) -> whole 256-byte rows to memory;
+//  * a tile's raw accumulators (64 registers: 8 waves = 4 pixel quarters x 2 channel groups, wave tile 64 x 64) are parked in a second register set
+//    when its K loop ends, and its epilogue runs INSIDE the next tile's K loop in eight equal steps, one per K tile: a half-strip (16 rows x 32
+//    channels per wave) gets bias + activation, is rounded to the storage type and written to one of two 8-KB LDS staging slots; one K tile later the
+//    store waves send it to memory as whole 128-byte row halves.  The vector-ALU work (8 GELUs per lane and K tile) is spread evenly under the MFMAs;
 //  * memory duties are split by wave so that no wave's vmcnt queue mixes loads and stores: waves 0-3 issue ALL LDS-DMA (12 instructions per K tile
 //    each) and wait on it with a counted vmcnt(12); waves 4-7 issue ALL global stores and never wait for them inside the loop (the staged data is in
 //    registers before the store is issued).  Every wave multiplies; a SIMD hosts one wave of each kind;
 //  * the K-tile stream is continuous across output tiles: a 3-stage ring of 48-KB buffers (A 256 rows + B 128 rows of 64 elements), two K tiles in
-//    flight, the first K tiles of the next output tile staged under the last MFMAs of the current one; one barrier per K tile;
+//    flight, the first K tiles of the next output tile staged under the last MFMAs of the current one; one barrier per K tile; the fragments of a
+//    32-deep k-step are read one step ahead of the MFMAs that consume them (the second k-step of K tile g multiplies at the top of iteration g + 1),
+//    so no MFMA waits for an LDS read issued in its own iteration;
+//  * a wave's four channel tiles are {0-15, 16-31} + 32 wc and 64 + the same (wc = channel group), so that the tiles of one epilogue step of both
+//    channel groups form 64 contiguous channels;
 //  * the bias is fetched with scalar loads (s_load: lgkmcnt) and selected per lane, so that no wave needs a vector load whose result the compiler
 //    would guard with vmcnt(0).
 // Same LDS row image, swizzle, packed weights and k order as igemm_body / gemm16_8ph_kernel: results are bit-identical to theirs.
 // Requirements (dfe_applies): dense 1x1, K % 64 == 0 with at least 8 K tiles, N % 128 == 0, M % 256 == 0, linear / ReLU / GELU epilogue, 16-byte rows.
 // ---------------------------------------------------------------------------------------------------------------------------------
-constexpr int DF_A = 32768, DF_BUF = 49152, DF_STG = 3 * DF_BUF;  // bytes: A region of a K-tile buffer, a K-tile buffer, offset of the staging area
+#ifndef DFE_INTERLEAVE
+#define DFE_INTERLEAVE 0
+#endif
+constexpr int DF_A = 32768, DF_BUF = 49152, DF_STG = 3 * DF_BUF;  // bytes: A region of a K-tile buffer, a K-tile buffer, offset of the two 8-KB staging slots
 
 template <int EPI, int ARITH>
 __global__ __launch_bounds__(512, 2) void gemm16_dfe_kernel(const ConvArgs a) {
@@ -1336,7 +1344,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_dfe_kernel(const ConvArgs a) {
   char* const LB = reinterpret_cast<char*>(lds);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wq = wave & 3, wc = wave >> 2;  // pixel quarter, channel half; waves wq and wq + 4 share a SIMD
+  const int wq = wave & 3, wc = wave >> 2;  // pixel quarter, channel group; waves wq and wq + 4 share a SIMD
   const bool dma_wave = wc == 0;            // waves 0-3: LDS-DMA; waves 4-7: global stores
   const int G = (int)gridDim.x;
   int bid = blockIdx.x;
@@ -1351,168 +1359,240 @@ __global__ __launch_bounds__(512, 2) void gemm16_dfe_kernel(const ConvArgs a) {
   // ---- staging cursor (runs two K tiles ahead of the multiply cursor, across output tiles) ----
   const int r8 = lane >> 3, cp = lane & 7, x4 = lane >> 4;
   const int kce = ((cp ^ x4) << 2), kco = (((cp ^ x4) ^ 4) << 2);  // logical k offset (words) of this lane's chunk in even / odd 8-row groups: (row >> 1) & 7 = (4 t + x4) & 7
-  int s_tile = bid, s_kt = 0, s_g = 0;
-  const float *pae = a.in, *pao = a.in, *pbe = a.w, *pbo = a.w;
+  int s_tile = bid, s_kt = 0;
+  // source address of a piece = a wave-uniform base (SGPR pair: tile row block, K tile) + a per-lane 32-bit byte offset (row within the 8-row piece,
+  // swizzled chunk): the scalar-base form of global_load_lds needs no address VGPRs per piece (twelve 64-bit lane addresses spilled to scratch)
+  const unsigned voa_e = (unsigned)(r8 * a.in_ld + kce) * 4u, voa_o = (unsigned)(r8 * a.in_ld + kco) * 4u;
+  const unsigned vob_e = (unsigned)(r8 * a.Kp + kce) * 4u, vob_o = (unsigned)(r8 * a.Kp + kco) * 4u;
+  const char *sa = reinterpret_cast<const char*>(a.in), *sb = reinterpret_cast<const char*>(a.w);
   auto s_set = [&]() {
     const int nt = s_tile % a.tilesN, mt = s_tile / a.tilesN;
-    const float* pa = a.in + (long)(mt * 256 + wq * 64 + r8) * a.in_ld + a.in_coff;
-    const float* pb = a.w + (long)(nt * 128 + wq * 32 + r8) * a.Kp;
-    pae = pa + kce; pao = pa + kco; pbe = pb + kce; pbo = pb + kco;
+    sa = reinterpret_cast<const char*>(a.in + (long)(mt * 256 + wq * 64) * a.in_ld + a.in_coff);
+    sb = reinterpret_cast<const char*>(a.w + (long)(nt * 128 + wq * 32) * a.Kp);
   };
   s_set();
-  auto stage_next = [&]() {  // DMA waves: the 12 DMAs of K tile (s_tile, s_kt) into ring slot s_g % 3, then advance
-    char* const dst = LB + (s_g % 3) * DF_BUF;
-    const int ko = s_kt * BK;
+  // DMA waves: the 12 DMAs of K tile (s_tile, s_kt) into ring slot s_g % 3 in two parts of six (each part rides between the MFMAs of one k-step), then advance
+  auto stage_part = [&](int slot3, auto HALF) {
+    constexpr int half = decltype(HALF)::value;
+    char* const dst = LB + slot3 * DF_BUF;
+    const long ko = (long)s_kt * BK * 4;
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(((t & 1) ? pao : pae) + (long)(8 * t) * a.in_ld + ko), (lds_void_t*)(dst + (wq * 64 + 8 * t) * 128), 16, 0, 0);
+    for (int t = (half ? 6 : 0); t < (half ? 8 : 6); ++t)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(sa + ((long)(8 * t) * a.in_ld * 4 + ko) + ((t & 1) ? voa_o : voa_e)), (lds_void_t*)(dst + (wq * 64 + 8 * t) * 128), 16, 0, 0);
+    if constexpr (half == 1) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(((t & 1) ? pbo : pbe) + (long)(8 * t) * a.Kp + ko), (lds_void_t*)(dst + DF_A + (wq * 32 + 8 * t) * 128), 16, 0, 0);
-    ++s_g;
-    if (++s_kt == nk) {
-      s_kt = 0;
-      s_tile += G;
-      s_set();
+      for (int t = 0; t < 4; ++t)
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(sb + ((long)(8 * t) * a.Kp * 4 + ko) + ((t & 1) ? vob_o : vob_e)), (lds_void_t*)(dst + DF_A + (wq * 32 + 8 * t) * 128), 16, 0, 0);
+      if (++s_kt == nk) {
+        s_kt = 0;
+        s_tile += G;
+        s_set();
+      }
     }
   };
 
   // ---- fragments / accumulators ----
   const int fr = lane & 15, fg = lane >> 4, rsw = (fr >> 1) & 7;
   const int ch0 = ((fg ^ rsw) << 4), ch1 = (((4 + fg) ^ rsw) << 4);
-  const char* const a_rd = LB + (wq * 64 + fr) * 128;
-  const char* const b_rd = LB + DF_A + (wc * 64 + fr) * 128;
-  f32x4 acc[4][4], prev[4][4];  // [channel tile i][pixel tile j]
-  f32x4 bq[4];                  // bias of the PARKED tile: channels wc * 64 + i * 16 + fg * 4 + e
+  const char* const a_rd = LB + (wq * 64 + fr) * 128;           // pixel tile j: + j * 2048
+  const char* const b_rd = LB + DF_A + (wc * 32 + fr) * 128;    // channel tile i (local channels (i >> 1) * 64 + wc * 32 + (i & 1) * 16): + (i >> 1) * 8192 + (i & 1) * 2048
+  f32x4 acc[4][4], prev[4][4];  // [channel tile i][pixel tile j]; prev = the parked tile's sums + bias
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    bq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = prev[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
   int c_tile = bid, m0 = (c_tile / a.tilesN) * 256, n0 = (c_tile % a.tilesN) * 128;
-  int pm0 = 0, pn0 = 0;
+  int pm0 = 0, pn0 = 0;          // the parked tile
   bool has_prev = false;
+  int q_pend = 0, q_row = 0, q_col = 0;  // a half-strip waits in a staging slot: its first output row (+ (sr >> 4) * 64 + (sr & 15)) and column
   const unsigned fl = a.flags;
+  constexpr bool ileave = DFE_INTERLEAVE;  // DMA pieces between the MFMAs (needs more registers than the kernel has: spills; kept for the record, off)
 
-  // ---- deferred epilogue pieces ----
-  auto write_piece = [&](auto J) {  // every wave: strip J of its parked tile -> staging rows wq * 16 + fr
-    constexpr int j = decltype(J)::value;
-    const int sr = wq * 16 + fr;
+  // ---- deferred epilogue steps (ring and staging slots are compile-time constants everywhere: with run-time LDS offsets hipcc cannot tell a ds_read
+  //      from the LDS-DMA still in flight into ANOTHER slot and guards it with vmcnt(0), which would serialise the whole pipeline) ----
+  int oz = 0;  // an opaque zero, renewed every K tile: address arithmetic that includes it is recomputed where it is used (a handful of VALU operations) instead of
+               // being hoisted out of the loop into registers that live across it — the hoisted form needed 20 more VGPRs than exist and spilled (scratch reloads
+               // are VMEM operations: they would sit in the DMA waves' vmcnt queue)
+  auto write_half = [&](auto J, auto IH, auto SLOT) {  // every wave: rows j * 16 + fr of its quarter, channel tiles 2 ih and 2 ih + 1 -> staging rows wq * 16 + fr
+    constexpr int j = decltype(J)::value, ih = decltype(IH)::value, slot = decltype(SLOT)::value;
+    const int sr = wq * 16 + fr + oz;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      f32x4 v = prev[i][j];
+    for (int ii = 0; ii < 2; ++ii) {
+      f32x4 v = prev[2 * ih + ii][j];  // (sum + bias: added when the tile was parked)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float y = v[e] + bq[i][e];
-        if (EPI == EPI_GELU) v[e] = gelu_of<ARITH>(y);
-        else v[e] = (fl & KPF_ACT_RELU) ? fmaxf(y, 0.f) : ((fl & KPF_ACT_LEAKY) ? fmaxf(y, 0.01f * y) : y);
+        if (EPI == EPI_GELU) v[e] = gelu_of<ARITH>(v[e]);
+        else v[e] = (fl & KPF_ACT_RELU) ? fmaxf(v[e], 0.f) : ((fl & KPF_ACT_LEAKY) ? fmaxf(v[e], 0.01f * v[e]) : v[e]);
       }
-      kpf_st4(reinterpret_cast<TH*>(LB + DF_STG + sr * 256 + (((wc * 8 + i * 2 + (fg >> 1)) ^ (sr & 15)) << 4) + (fg & 1) * 8), v);
+      kpf_st4(reinterpret_cast<TH*>(LB + DF_STG + slot * 8192 + sr * 128 + (((wc * 4 + ii * 2 + (fg >> 1)) ^ ((sr >> 1) & 7)) << 4) + (fg & 1) * 8), v);
     }
+    q_pend = 1;
+    q_row = pm0 + j * 16;
+    q_col = pn0 + ih * 64;
   };
-  auto store_piece = [&](auto J) {  // store waves: 16 staging rows each, whole 256-byte rows (16 lanes x 16 bytes), 4 rows per instruction
-    constexpr int j = decltype(J)::value;
-    if (!dma_wave) {
-      TH* const ob = reinterpret_cast<TH*>(a.out) + a.out_coff + pn0 + (lane & 15) * 8;
+  auto store_half = [&](auto SLOT) {  // store waves: 16 staging rows each as 128-byte row halves (8 lanes x 16 bytes), 8 rows per instruction
+    constexpr int slot = decltype(SLOT)::value;
+    if (q_pend && !dma_wave) {
+      TH* const ob = reinterpret_cast<TH*>(a.out) + a.out_coff + q_col + (lane & 7) * 8;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int sr = wq * 16 + u * 4 + (lane >> 4);
-        const f32x4 q = *reinterpret_cast<const f32x4*>(LB + DF_STG + sr * 256 + (((lane & 15) ^ (sr & 15)) << 4));
-        *reinterpret_cast<f32x4*>(ob + (long)(pm0 + (sr >> 4) * 64 + j * 16 + (sr & 15)) * a.out_ld) = q;
+      for (int u = 0; u < 2; ++u) {
+        const int sr = wq * 16 + u * 8 + (lane >> 3) + oz;
+        const f32x4 q = *reinterpret_cast<const f32x4*>(LB + DF_STG + slot * 8192 + sr * 128 + (((lane & 7) ^ ((sr >> 1) & 7)) << 4));
+        *reinterpret_cast<f32x4*>(ob + (long)(q_row + (sr >> 4) * 64 + (sr & 15)) * a.out_ld) = q;
       }
     }
+    q_pend = 0;
   };
-  auto load_bias = [&](int n_base) {  // scalar loads (lgkmcnt, not vmcnt) of the wave's 64 bias values, selected per lane group
-    if (a.bias) {
+  auto park = [&]() {  // the output tile whose last MFMAs were just issued: sums + bias to the second register set, its position; next tile
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float* bp = a.bias + n_base + wc * 64 + i * 16;
+    for (int i = 0; i < 4; ++i) {
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (a.bias) {  // scalar loads (lgkmcnt, not vmcnt) of the channel tile's 16 bias values, selected per lane group
+        const float* bp = a.bias + n0 + (i >> 1) * 64 + wc * 32 + (i & 1) * 16;
         f32x4 b0, b1, b2, b3;
         asm volatile("s_load_dwordx4 %0, %4, 0x0\n\ts_load_dwordx4 %1, %4, 0x10\n\ts_load_dwordx4 %2, %4, 0x20\n\ts_load_dwordx4 %3, %4, 0x30\n\ts_waitcnt lgkmcnt(0)"
                      : "=&s"(b0), "=&s"(b1), "=&s"(b2), "=&s"(b3) : "s"(bp) : "memory");
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bq[i][e] = fg == 0 ? b0[e] : (fg == 1 ? b1[e] : (fg == 2 ? b2[e] : b3[e]));
+        for (int e = 0; e < 4; ++e) bv[e] = fg == 0 ? b0[e] : (fg == 1 ? b1[e] : (fg == 2 ? b2[e] : b3[e]));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) prev[i][j][e] = acc[i][j][e] + bv[e];
+        acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
+    pm0 = m0;
+    pn0 = n0;
+    has_prev = true;
+    c_tile += G;
+    m0 = (c_tile / a.tilesN) * 256;
+    n0 = (c_tile % a.tilesN) * 128;
   };
-
-  // ---- the K-tile stream ----
-  if (dma_wave) {
-    stage_next();
-    if (total > 1) stage_next();
-  }
+  f16x8 x0[4], w0[4], x1[4], w1[4];  // fragments of k-step 0 / 1 of the K tile being multiplied
+  auto read_step = [&](int slot3, int chunk, f16x8(&x)[4], f16x8(&w)[4]) {
+    const char* const ab = a_rd + slot3 * DF_BUF + chunk;
+    const char* const bb = b_rd + slot3 * DF_BUF + chunk;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = *reinterpret_cast<const f16x8*>(ab + j * 2048);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = *reinterpret_cast<const f16x8*>(bb + (i >> 1) * 8192 + (i & 1) * 2048);
+  };
+  auto mma_raw = [&](const f16x8(&x)[4], const f16x8(&w)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (ARITH == ARITH_BF16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[i]), __builtin_bit_cast(bf16x8, x[j]), acc[i][j], 0, 0, 0);
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[i], x[j], acc[i][j], 0, 0, 0);
+      }
+  };
+  auto mma = [&](const f16x8(&x)[4], const f16x8(&w)[4]) {
+    __builtin_amdgcn_s_setprio(1);
+    mma_raw(x, w);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // a k-step's 16 MFMAs with six LDS-DMA pieces between them (DMA waves): an LDS-DMA piece costs its wave ~60-100 issue cycles (MI355X_MICROARCH "LDS-DMA
+  // piece issue cost"); twelve in a row in front of the MFMAs made the four DMA waves the critical path of every K tile (2700 cycles per K tile against
+  // 1024 of MFMA: profiles/r05_dfe_ablation.txt); two MFMAs, one piece, ... lets the SIMD's matrix pipe run meanwhile
+  auto mma_dma = [&](const f16x8(&x)[4], const f16x8(&w)[4], int slot3, auto HALF) {
+    __builtin_amdgcn_sched_barrier(0);
+    stage_part(slot3, HALF);
+    mma_raw(x, w);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
   int kt = 0;
-  for (int g = 0; g < total; ++g) {
+  // one K tile: ring slot `slot` = g % 3 is multiplied, slot (slot + 2) % 3 is refilled with K tile g + 2
+  auto ktile = [&](int slot, int g) {
+    const int nslot = slot == 0 ? 2 : slot - 1;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (this wave's fragment reads of K tile g - 1 are in registers: its ring slot may be refilled after the barrier)
     if (dma_wave) {
       if (g + 1 < total) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // K tile g has landed (g + 1 may be in flight)
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();  // K tile g is everyone's; everyone has read K tile g - 1 (ring slot (g + 2) % 3) and the staging area is in its next phase
+    __builtin_amdgcn_s_barrier();  // K tile g is everyone's; everyone has read K tile g - 1 (slot nslot); the staging slots are in their next phase
     __builtin_amdgcn_sched_barrier(0);
-    if (dma_wave && g + 2 < total) stage_next();
-    const char* const ab = a_rd + (g % 3) * DF_BUF;
-    const char* const bb = b_rd + (g % 3) * DF_BUF;
-    f16x8 x0[4], w0[4], x1[4], w1[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) x0[j] = *reinterpret_cast<const f16x8*>(ab + j * 2048 + ch0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w0[i] = *reinterpret_cast<const f16x8*>(bb + i * 2048 + ch0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) x1[j] = *reinterpret_cast<const f16x8*>(ab + j * 2048 + ch1);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w1[i] = *reinterpret_cast<const f16x8*>(bb + i * 2048 + ch1);
-    if (has_prev) {  // one step of the parked tile's epilogue per K tile: strip kt / 2 written (even kt) / stored (odd kt)
+    const bool staging = dma_wave && g + 2 < total;  // this wave stages K tile g + 2 in this iteration
+    asm volatile("" : "+v"(oz));
+    read_step(slot, ch0, x0, w0);
+    if (staging && !ileave) {
+      stage_part(nslot, ic<0>{});
+      stage_part(nslot, ic<1>{});
+    }
+    if (staging && ileave) mma_dma(x1, w1, nslot, ic<0>{});  // second k-step of K tile g - 1
+    else mma(x1, w1);
+    if (kt == 0) park();  // ... which completed an output tile
+    if (has_prev) {  // one step of the parked tile's epilogue per K tile: the half-strip of the previous step leaves, the next one is staged
       switch (kt) {
-        case 0: write_piece(ic<0>{}); break;
-        case 1: store_piece(ic<0>{}); break;
-        case 2: write_piece(ic<1>{}); break;
-        case 3: store_piece(ic<1>{}); break;
-        case 4: write_piece(ic<2>{}); break;
-        case 5: store_piece(ic<2>{}); break;
-        case 6: write_piece(ic<3>{}); break;
-        case 7: store_piece(ic<3>{}); break;
+        case 0: store_half(ic<1>{}); write_half(ic<0>{}, ic<0>{}, ic<0>{}); break;
+        case 1: store_half(ic<0>{}); write_half(ic<0>{}, ic<1>{}, ic<1>{}); break;
+        case 2: store_half(ic<1>{}); write_half(ic<1>{}, ic<0>{}, ic<0>{}); break;
+        case 3: store_half(ic<0>{}); write_half(ic<1>{}, ic<1>{}, ic<1>{}); break;
+        case 4: store_half(ic<1>{}); write_half(ic<2>{}, ic<0>{}, ic<0>{}); break;
+        case 5: store_half(ic<0>{}); write_half(ic<2>{}, ic<1>{}, ic<1>{}); break;
+        case 6: store_half(ic<1>{}); write_half(ic<3>{}, ic<0>{}, ic<0>{}); break;
+        case 7: store_half(ic<0>{}); write_half(ic<3>{}, ic<1>{}, ic<1>{}); break;
+        case 8: store_half(ic<1>{}); break;
         default: break;
       }
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if constexpr (ARITH == ARITH_BF16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w0[i]), __builtin_bit_cast(bf16x8, x0[j]), acc[i][j], 0, 0, 0);
-        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[i], x0[j], acc[i][j], 0, 0, 0);
-      }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if constexpr (ARITH == ARITH_BF16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w1[i]), __builtin_bit_cast(bf16x8, x1[j]), acc[i][j], 0, 0, 0);
-        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[i], x1[j], acc[i][j], 0, 0, 0);
-      }
-    if (++kt == nk) {  // the output tile is complete: park it, start the next one
-      kt = 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          prev[i][j] = acc[i][j];
-          acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      load_bias(n0);
-      pm0 = m0;
-      pn0 = n0;
-      has_prev = true;
-      c_tile += G;
-      m0 = (c_tile / a.tilesN) * 256;
-      n0 = (c_tile % a.tilesN) * 128;
+    read_step(slot, ch1, x1, w1);
+    if (staging && ileave) mma_dma(x0, w0, nslot, ic<1>{});  // first k-step of K tile g
+    else mma(x0, w0);
+    if (++kt == nk) kt = 0;
+  };
+
+  // ---- the K-tile stream ----
+  if (dma_wave) {
+    stage_part(0, ic<0>{});
+    stage_part(0, ic<1>{});
+    if (total > 1) {
+      stage_part(1, ic<0>{});
+      stage_part(1, ic<1>{});
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
   }
-  // ---- drain: the last tile's epilogue ----
+  __builtin_amdgcn_s_barrier();  // K tile 0 is everyone's
+  __builtin_amdgcn_sched_barrier(0);
+  if (dma_wave && total > 2) {
+    stage_part(2, ic<0>{});
+    stage_part(2, ic<1>{});
+  }
+  read_step(0, ch0, x0, w0);
+  read_step(0, ch1, x1, w1);
+  mma(x0, w0);
+  kt = 1;  // (nk >= 8)
+  {
+    int slot = 1;
+    for (int g = 1; g < total; ++g) {
+      ktile(slot, g);
+      slot = slot == 2 ? 0 : slot + 1;
+    }
+  }
+  // ---- drain: the last K tile's second k-step, then the last tile's whole epilogue ----
+  mma(x1, w1);
   __syncthreads();
-  write_piece(ic<0>{}); __syncthreads(); store_piece(ic<0>{}); __syncthreads();
-  write_piece(ic<1>{}); __syncthreads(); store_piece(ic<1>{}); __syncthreads();
-  write_piece(ic<2>{}); __syncthreads(); store_piece(ic<2>{}); __syncthreads();
-  write_piece(ic<3>{}); __syncthreads(); store_piece(ic<3>{});
+  if (kt == 0 || nk > 8) store_half(ic<1>{});  // (the half-strip staged last went to slot 1: step 7; with kt in 1..8 of an 8-K-tile tile it was slot (kt - 1) & 1)
+  else if ((kt - 1) & 1) store_half(ic<1>{});
+  else store_half(ic<0>{});
+  park();
+  __syncthreads();
+  write_half(ic<0>{}, ic<0>{}, ic<0>{}); __syncthreads(); store_half(ic<0>{}); __syncthreads();
+  write_half(ic<0>{}, ic<1>{}, ic<1>{}); __syncthreads(); store_half(ic<1>{}); __syncthreads();
+  write_half(ic<1>{}, ic<0>{}, ic<0>{}); __syncthreads(); store_half(ic<0>{}); __syncthreads();
+  write_half(ic<1>{}, ic<1>{}, ic<1>{}); __syncthreads(); store_half(ic<1>{}); __syncthreads();
+  write_half(ic<2>{}, ic<0>{}, ic<0>{}); __syncthreads(); store_half(ic<0>{}); __syncthreads();
+  write_half(ic<2>{}, ic<1>{}, ic<1>{}); __syncthreads(); store_half(ic<1>{}); __syncthreads();
+  write_half(ic<3>{}, ic<0>{}, ic<0>{}); __syncthreads(); store_half(ic<0>{}); __syncthreads();
+  write_half(ic<3>{}, ic<1>{}, ic<1>{}); __syncthreads(); store_half(ic<1>{});
 }
 
 template <int ARITH>
@@ -1673,6 +1753,9 @@ extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void
   const bool fast1x1 = pointwise && d->Cin % 64 == 0 && d->Kp == d->Cin;  // whole 64-element K tiles, no K mask
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
+#ifdef KPF_ONLY_DFE  // tuning aid: a translation unit with nothing but gemm16_dfe_kernel (ISA inspection in seconds), never shipped
+  return dtype == KPF_DT_BF16 ? launch_dfe<ARITH_BF16>(a, st) : launch_dfe<ARITH_F16>(a, st);
+#else
   // Tile choice (tools/gemm16_bench.py on the ConvNeXt-B 512^2 shapes): the 16-bit GEMMs are bound by HBM traffic, staging and
   // barriers, not by the matrix pipe, and 128 x 128 tiles with several workgroups per CU beat 256 x 128 (one workgroup per CU) on
   // every heavy shape (65536 x 2048 x 512 + GELU: 585 vs 425 TFLOP/s); non-residual layers take the single-stage, 4-waves-per-SIMD
@@ -1738,6 +1821,7 @@ extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void
     case 44: return launch_cfg_h16<2, 1, 1, 4, 8>(a, fast1x1, pointwise, dtype, st);  // 32 x 64, 8-stage ring (96 KB)
     default: return launch_cfg_h16<2, 1, 1, 4, 2>(a, fast1x1, pointwise, dtype, st);  // 32 x 64
   }
+#endif  // KPF_ONLY_DFE
 }
 #else
 extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const float* w, const float* bias,
