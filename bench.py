@@ -28,7 +28,8 @@ One JSON line is printed by rank 0 with, besides the contract fields:
                  as 3 x f16 MFMA on hi/lo-split operands with a pack-time range proof; everything else stays on the f32 MFMA).
   extra        : (default run, N = 1) one timed record per further BASELINE config that fits one GPU — `cnb512_f16` (configs[4]: ConvNeXt-B,
                  512x512, f16, B=64), `full128_bf16` (configs[2]: full model, B=32, bf16), `train128_bf16` (configs[3]: one training
-                 iteration, B=32, bf16) — each measured by this script as a child process on that workload, with its own `roofline`.
+                 iteration, B=32, bf16) — and `full256` (the FULL model at the headline's batch and crop size: the labelled wide extension,
+                 not a reference configuration), each measured by this script as a child process on that workload, with its own `roofline`.
   world_size   : ranks that took part (dist.get_world_size()), `collective_backend` the RCCL version when a process group exists.
   cpu_baseline : the CPU oracle (oracle/kpf_oracle.py, torch-CPU fp32 = the reference's own arithmetic) on the host
                  cores of this box: thread-count sweep, then 5 timed passes at the best count over a bounded sample of the same
@@ -55,6 +56,9 @@ WORKLOADS = {
     "backbones256": ("KPFusion-convnext-tiny", 256, 64, "f32", "backbones", "configs[1]"),
     "full128": ("KPFusion-convnext-tiny", 128, 64, "f32", "full", "full model at configs[1]'s batch"),
     "full128_bf16": ("KPFusion-convnext-tiny", 128, 32, "bf16", "full", "configs[2]"),
+    # the full model at the crop size BASELINE's metric is quoted on: the labelled wide extension (KPFusion(..., crop_size=256): fc_spatial2joint_feature sized
+    # for the 64 x 64 feature map; the reference hard-codes 32 x 32 and cannot run this size) — not a reference configuration
+    "full256": ("KPFusion-convnext-tiny", 256, 64, "f32", "full", "full model at configs[1]'s batch and crop size: wide extension, not a reference configuration"),
     "cnb512_f16": ("KPFusion-convnext-base", 512, 64, "f16", "backbones", "configs[4]"),
     # one training iteration of train.py:209-265 (forward in train mode, loss, backward, gradient all-reduce over RCCL when N > 1, AdamW
     # step); fp32 — bf16 training is not built, so this is configs[3]'s schedule, not its precision
@@ -123,7 +127,7 @@ def self_launch(n):
 # Secondary workloads of the default run (N = 1): each is this same script as a child process on its own workload — its own model,
 # capture and `roofline` — after the headline has been timed, so the driver's one invocation carries a timed record for every
 # BASELINE config that runs on one GPU.  (workload, steps, warmup)
-EXTRA_WORKLOADS = (("cnb512_f16", 6, 2), ("full128_bf16", 30, 5), ("train128_bf16", 12, 3))
+EXTRA_WORKLOADS = (("cnb512_f16", 6, 2), ("full128_bf16", 30, 5), ("train128_bf16", 12, 3), ("full256", 8, 3))
 
 
 def run_extra(workload, steps, warmup, timeout):
@@ -215,8 +219,9 @@ def main():
         args.no_split_record = True  # (the split record belongs to the fp32 workloads)
         if args.workload == "cnb512_f16":
             args.cpu_sample = min(args.cpu_sample, 1)  # 373 GFLOP per image on the CPU
-    model = KPFusion(NET, "", 21, "dexycb", "")
-    sd = {k: torch.from_numpy(v) for k, v in synthetic_state_dict(NET, 0).items()}
+    crop = 128 if backbones_only else S  # (backbones-only workloads run any size through forward_backbones: the reference-sized module)
+    model = KPFusion(NET, "", 21, "dexycb", "", crop_size=crop)
+    sd = {k: torch.from_numpy(v) for k, v in synthetic_state_dict(NET, 0, crop_size=crop).items()}
     model.load_state_dict(sd, strict=True)
     model = model.to(dev).eval()
     model.precision = precision
@@ -243,7 +248,7 @@ def main():
         gstep = [None]
 
     class _Loader:
-        img_size, flip = 128, 1
+        img_size, flip = (128 if backbones_only else S), 1
 
     graph_on = [not args.no_graph and not args.serial_streams]
     pipe, pending = [None], []
@@ -468,11 +473,11 @@ def main():
         def cpu_step():
             if train:  # the reference's arithmetic for a training iteration is not restated on the CPU side: forward only, said in `sample`
                 with torch.no_grad():
-                    O.kpfusion_forward(sd, cb["img_rgb"], cb["img"], cb["pcl"], cb["center"], cb["M"], cb["cube"], cb["cam_para"], 0.8)
+                    O.kpfusion_forward(sd, cb["img_rgb"], cb["img"], cb["pcl"], cb["center"], cb["M"], cb["cube"], cb["cam_para"], 0.8, img_size=S)
             elif backbones_only:
                 O.backbones_forward(sd, cb["img_rgb"], cb["img"])
             else:
-                O.kpfusion_forward(sd, cb["img_rgb"], cb["img"], cb["pcl"], cb["center"], cb["M"], cb["cube"], cb["cam_para"], 0.8)
+                O.kpfusion_forward(sd, cb["img_rgb"], cb["img"], cb["pcl"], cb["center"], cb["M"], cb["cube"], cb["cam_para"], 0.8, img_size=S)
 
         # Thread count: all hardware threads is not the fastest setting for a batch this small (8 images on 128 SMT threads
         # oversubscribes the convolution's work split: round 3 reported 2.66 img/s that way, below an 8-vCPU box), so the pass is timed

@@ -22,10 +22,15 @@ from ._base import _Node, _attach  # noqa: F401  (shared with the stand-alone he
 
 
 class KPFusion(nn.Module):
-    def __init__(self, net, pretrain, joint_num, dataset, mano_dir, kernel_size=1, seed=0):
+    def __init__(self, net, pretrain, joint_num, dataset, mano_dir, kernel_size=1, seed=0, crop_size=128):
+        """Positional arguments as the reference's (model/model.py:355).  Two keyword-only-in-practice extensions: `seed` of the initial weights, and
+        `crop_size` — 128 is the reference, whose fusion block hard-codes a 32 x 32 feature map (nn.Linear(32 * 32, 1), model/model.py:264); another
+        multiple of 32 (256: the crop size BASELINE's metric is quoted on) builds the WIDE extension SURVEY section 0 allows: identical architecture and
+        kernels, `block{1,2}.fc_spatial2joint_feature.weight` sized [1, (crop_size / 4)^2] — a checkpoint of the reference loads into everything else."""
         super().__init__()
         if joint_num != 21:
             raise ValueError("KPFusion is wired for 21 joints (Block_KPFusion, model/model.py:209)")
+        self.crop_size = int(crop_size)
         self.net = net
         self.joint_num = joint_num
         self.kernel_size = kernel_size
@@ -34,7 +39,7 @@ class KPFusion(nn.Module):
         self.family, self.size = parse_net(net)
         import numpy as np
         import zlib
-        for name, shape, dtype, init in kpfusion_spec(net):
+        for name, shape, dtype, init in kpfusion_spec(net, self.crop_size):
             rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
             val = torch.from_numpy(np.asarray(_draw(rng, shape, init)).copy()).reshape(shape)
             is_buffer = name.endswith(("running_mean", "running_var", "num_batches_tracked"))
@@ -116,11 +121,11 @@ class KPFusion(nn.Module):
 
     def forward(self, img_rgb, img, pcl, loader, center, M, cube, cam_para, kernel=0.8, writer=None, ii=0):
         self._require_gpu(img)
-        if img.shape[-1] != 128:
-            # the reference hard-codes nn.Linear(32*32, 1) (model/model.py:264): the full model exists at S=128 only
-            raise RuntimeError("mat1 and mat2 shapes cannot be multiplied: the fusion block needs 128x128 crops "
-                               "(got %d); use forward_backbones() for other sizes" % img.shape[-1])
-        img_size = int(getattr(loader, "img_size", 128))
+        if img.shape[-1] != self.crop_size:
+            # the reference hard-codes nn.Linear(32*32, 1) (model/model.py:264): the full model exists at the size it was built for only
+            raise RuntimeError("mat1 and mat2 shapes cannot be multiplied: the fusion block needs %dx%d crops (got %d); use forward_backbones() for "
+                               "other sizes, or build KPFusion(..., crop_size=%d)" % (self.crop_size, self.crop_size, img.shape[-1], img.shape[-1]))
+        img_size = int(getattr(loader, "img_size", self.crop_size))
         flip = int(getattr(loader, "flip", 1))
         if self.training:
             # train mode: batch-statistics BatchNorm, dropout, autograd-connected outputs on the module's own

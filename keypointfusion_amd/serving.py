@@ -29,8 +29,8 @@ class PipelinedEval:
         if m.training:
             raise RuntimeError("PipelinedEval is an eval-mode loop: call model.eval() first")
         m._require_gpu(img)
-        if img.shape[-1] != 128:
-            raise RuntimeError("PipelinedEval: the full model exists at 128x128 crops only (got %d)" % img.shape[-1])
+        if img.shape[-1] != m.crop_size:
+            raise RuntimeError("PipelinedEval: this model was built for %dx%d crops (got %d)" % (m.crop_size, m.crop_size, img.shape[-1]))
         dev = img.device
         plan = m._plan(dev)
         if self._streams is None or self._streams[0].device != dev:
@@ -40,7 +40,7 @@ class PipelinedEval:
         st = self._streams[slot]
         st.wait_stream(torch.cuda.current_stream(dev))  # the inputs were produced on the caller's stream
         with torch.no_grad(), torch.cuda.device(dev), torch.cuda.stream(st):
-            res, sws, _ = plan.forward_graphed(img_rgb, img, pcl, center, M, cube, cam_para, float(kernel), int(getattr(loader, "img_size", 128)),
+            res, sws, _ = plan.forward_graphed(img_rgb, img, pcl, center, M, cube, cam_para, float(kernel), int(getattr(loader, "img_size", m.crop_size)),
                                                int(getattr(loader, "flip", 1)), slot=slot)
             ev = torch.cuda.Event()
             ev.record(st)

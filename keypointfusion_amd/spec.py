@@ -179,7 +179,7 @@ def _tr(s, p, din):
     s.linear(p + ".residual", 3, din, init="head3")
 
 
-def _block(s, p):
+def _block(s, p, fmap=1024):
     s.add(p + ".weight_dis", (1,), "weight_dis")
     s.linear(p + ".sampling_offsets", 8, 128, init="dead")
     s.linear(p + ".attention_weights", 4, 128, init="dead")
@@ -217,14 +217,18 @@ def _block(s, p):
         s.conv1d(p + "." + n + ".0", 128, cin)
         s.bn(p + "." + n + ".1", 128)
     s.conv(p + ".atten_spatial", 21, 149, 1, 1)
-    s.linear(p + ".fc_spatial2joint_feature", 1, 1024, init="fc_spatial")
+    s.linear(p + ".fc_spatial2joint_feature", 1, fmap, init="fc_spatial")  # nn.Linear(32 * 32, 1) in the reference (model/model.py:264): F^2 pixels of the feature map
     s.linear(p + ".reduction_joint_feature", 128, 256, init="dead")
     s.conv1d(p + ".reduction_joint_feature_update", 21, 63, init="dead")
     s.linear(p + ".cls_head", 3, 128, init="dead")
 
 
-def kpfusion_spec(net):
-    """Ordered list of (key, shape, dtype, init) for KPFusion(net, ...)."""
+def kpfusion_spec(net, crop_size=128):
+    """Ordered list of (key, shape, dtype, init) for KPFusion(net, ...).  crop_size = 128 is the reference (its fusion block hard-codes a 32 x 32
+    feature map: model/model.py:264); any other multiple of 32 is the labelled WIDE extension of SURVEY section 0 — the same architecture with
+    `fc_spatial2joint_feature` sized for (crop_size / 4)^2 pixels, every other key unchanged (not checkpoint-compatible in those two tensors)."""
+    if crop_size % 32 or crop_size < 64:
+        raise ValueError("crop_size must be a multiple of 32, at least 64 (got %r)" % (crop_size,))
     fam, size = parse_net(net)
     s = _Spec()
     if fam == "convnext":
@@ -233,8 +237,8 @@ def kpfusion_spec(net):
     else:
         _resnet_unet(s, "backbone_rgb", size, 3)
         _resnet_unet(s, "backbone_d", size, 1)
-    _block(s, "block1")
-    _block(s, "block2")
+    _block(s, "block1", (crop_size // 4) ** 2)
+    _block(s, "block2", (crop_size // 4) ** 2)
     return list(s)
 
 

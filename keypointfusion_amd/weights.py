@@ -68,10 +68,10 @@ def _draw(rng, shape, init):
     raise ValueError(init)
 
 
-def synthetic_state_dict(net, seed=0):
-    """dict key -> numpy array, for every key of the reference's state dict."""
+def synthetic_state_dict(net, seed=0, crop_size=128):
+    """dict key -> numpy array, for every key of the reference's state dict (crop_size != 128: the wide extension, spec.kpfusion_spec)."""
     out = {}
-    for name, shape, dtype, init in kpfusion_spec(net):
+    for name, shape, dtype, init in kpfusion_spec(net, crop_size):
         rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
         out[name] = _draw(rng, shape, init)
     return out

@@ -5,13 +5,13 @@ import torch
 from . import kpf_oracle as O
 
 
-def oracle_with_device_decisions(sd, b, ctx, kernel=0.8):
+def oracle_with_device_decisions(sd, b, ctx, kernel=0.8, img_size=128):
     """Runs the oracle.  Asserts that the device's top-4 pixel indices equal the oracle's.  Where the device's ball-query sets differ
     from the oracle's own, checks that every difference sits on the radius boundary and re-runs the oracle with the device's
     decisions injected.  Returns (ref_results, ref_spatial, aux, report)."""
     aux = {}
     args = (sd, b["img_rgb"], b["img"], b["pcl"], b["center"], b["M"], b["cube"], b["cam_para"], kernel)
-    ref, rsw = O.kpfusion_forward(*args, aux=aux)
+    ref, rsw = O.kpfusion_forward(*args, img_size=img_size, aux=aux)
     B = b["img"].shape[0]
     report = {"top4_flips": 0, "ball_flips": 0}
     overrides = {}
@@ -21,7 +21,7 @@ def oracle_with_device_decisions(sd, b, ctx, kernel=0.8):
     idx_dev = ctx["index"].cpu().long()
     mism = (idx_dev != aux["pcl_index"]).any(-1)
     if bool(mism.any()):
-        img_xyz = O.img_xyz_grid(aux["img_down"], b["center"], b["M"], b["cube"], b["cam_para"])
+        img_xyz = O.img_xyz_grid(aux["img_down"], b["center"], b["M"], b["cube"], b["cam_para"], img_size=img_size)
         dist = torch.sum(torch.pow(b["pcl"].unsqueeze(2) - img_xyz.unsqueeze(1), 2), dim=-1)
         same_dist = torch.equal(torch.gather(dist, 2, idx_dev), torch.gather(dist, 2, aux["pcl_index"]))
         assert same_dist, "top-4 indices differ from the oracle's on %d points (identical raw inputs: must be bit-exact)" % int(mism.sum())
@@ -38,14 +38,14 @@ def oracle_with_device_decisions(sd, b, ctx, kernel=0.8):
         overrides["ball"] = ball
     if overrides:
         aux = {}
-        ref, rsw = O.kpfusion_forward(*args, aux=aux, overrides=overrides)
+        ref, rsw = O.kpfusion_forward(*args, img_size=img_size, aux=aux, overrides=overrides)
         # a block-1 flip changes block 2's inputs: make sure the injected run is self-consistent for block 2 as well
         if "ball" in overrides and 2 not in overrides["ball"]:
             dev2 = [ctx["aux"][1]["ball_idx"][r].cpu().long().view(B, 21, 64) for r in range(3)]
             if any(not torch.equal(dev2[r], aux["block2"]["ball_idx"][r]) for r in range(3)):
                 overrides["ball"][2] = dev2
                 aux = {}
-                ref, rsw = O.kpfusion_forward(*args, aux=aux, overrides=overrides)
+                ref, rsw = O.kpfusion_forward(*args, img_size=img_size, aux=aux, overrides=overrides)
     if "ball" in overrides:  # every injected ball-query difference must sit on the radius boundary (or be the slot shift it causes)
         _check_ball_flips(b, aux, overrides["ball"], B)
     return ref, rsw, aux, report

@@ -144,3 +144,29 @@ def test_dropin_model_package_resolves_the_reference_import_lines(tmp_path):
             "import keypointfusion_amd.model.model as M; assert KPFusion is M.KPFusion; print('ok')") % (ROOT, os.path.join(ROOT, "dropin"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path))
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr[-2000:]
+
+
+def test_wide_extension_changes_two_tensors_and_nothing_else():
+    """crop_size=256 (the labelled wide extension): same keys in the same order as the reference's state dict, only `fc_spatial2joint_feature.weight` of the
+    two blocks resized to (crop_size / 4)^2 inputs; crop_size=128 IS the reference's spec; sizes the architecture cannot take are refused."""
+    import pytest
+    import torch
+    from keypointfusion_amd.model.model import KPFusion
+    from keypointfusion_amd.spec import kpfusion_spec
+    ref, wide = kpfusion_spec("KPFusion-resnet-18"), kpfusion_spec("KPFusion-resnet-18", 256)
+    assert kpfusion_spec("KPFusion-resnet-18", 128) == ref and [r[0] for r in ref] == [w[0] for w in wide]
+    diff = [(r[0], r[1], w[1]) for r, w in zip(ref, wide) if r != w]
+    assert diff == [("block1.fc_spatial2joint_feature.weight", (1, 1024), (1, 4096)), ("block2.fc_spatial2joint_feature.weight", (1, 1024), (1, 4096))]
+    for bad in (100, 32, 250):
+        with pytest.raises(ValueError):
+            kpfusion_spec("KPFusion-resnet-18", bad)
+    m = KPFusion("KPFusion-resnet-18", "", 21, "dexycb", "", crop_size=256)
+    assert m.crop_size == 256 and tuple(m.state_dict()["block2.fc_spatial2joint_feature.weight"].shape) == (1, 4096)
+    # a reference-sized checkpoint loads into everything but those two tensors (train.py:100-107 loads by key intersection and shape errors are the caller's:
+    # here the mismatch is reported by load_state_dict itself)
+    sd = KPFusion("KPFusion-resnet-18", "", 21, "dexycb", "").state_dict()
+    with pytest.raises(RuntimeError, match="fc_spatial2joint_feature"):
+        m.load_state_dict(sd, strict=True)
+    keep = {k: v for k, v in sd.items() if "fc_spatial2joint_feature.weight" not in k}
+    missing, unexpected = m.load_state_dict(keep, strict=False)
+    assert sorted(missing) == ["block1.fc_spatial2joint_feature.weight", "block2.fc_spatial2joint_feature.weight"] and not unexpected

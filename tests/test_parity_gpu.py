@@ -228,6 +228,49 @@ def _run_full(net, B, seed=1, kernel=0.8):
     return b, ref, rsw, aux, out, sws, ctx, report
 
 
+def test_wide_model_at_256x256_matches_the_oracle():
+    """KPFusion(..., crop_size=256): the labelled WIDE extension of SURVEY section 0 — the reference's architecture with `fc_spatial2joint_feature` sized for
+    the 64 x 64 feature map of a 256 x 256 crop (the reference hard-codes nn.Linear(32 * 32, 1), model/model.py:264, so it cannot run BASELINE's crop size at
+    all).  Same kernels, F = 64 everywhere (4096-pixel gates, top-4 search over 4096 pixels): every output against the oracle at that size, same bars as at 128."""
+    from keypointfusion_amd.model.model import KPFusion
+    from keypointfusion_amd.weights import synthetic_state_dict
+    from oracle.compare import oracle_with_device_decisions
+    net, dev = "KPFusion-convnext-tiny", _dev()
+    sd = {k: torch.from_numpy(v) for k, v in synthetic_state_dict(net, 0, crop_size=256).items()}
+    assert tuple(sd["block1.fc_spatial2joint_feature.weight"].shape) == (1, 4096)
+    ref_sd = synthetic_sd(net)
+    assert list(sd) == list(ref_sd) and [k for k in sd if sd[k].shape != ref_sd[k].shape] == ["block1.fc_spatial2joint_feature.weight", "block2.fc_spatial2joint_feature.weight"]
+    m = KPFusion(net, "", 21, "dexycb", "", crop_size=256)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).eval()
+    b = {k: torch.from_numpy(v) for k, v in synthetic_batch(2, 256, seed=4).items()}
+    d = {k: v.to(dev) for k, v in b.items()}
+    with torch.no_grad():
+        out, sws, ctx = m._plan(dev).forward(d["img_rgb"], d["img"], d["pcl"], d["center"], d["M"], d["cube"], d["cam_para"], 0.8, 256, 1, want_aux=True)
+    torch.cuda.synchronize()
+    ref, rsw, aux, report = oracle_with_device_decisions(sd, b, ctx, img_size=256)
+    assert report["top4_flips"] == 0, report
+    assert tuple(out[0].shape) == (2, 105, 64, 64) and tuple(sws[0].shape) == (2, 21, 64, 64)
+    for o, r in list(zip(out, ref)) + list(zip(sws, rsw)):
+        assert rel_err(o, r) < 1e-3
+    for k in range(2, 6):
+        assert float((out[k].cpu() - ref[k]).abs().max()) * 125.0 < 0.05
+
+    class Loader:
+        img_size, flip = 256, 1
+
+    with torch.no_grad():
+        res, sw2, _ = m(d["img_rgb"], d["img"], d["pcl"], Loader(), d["center"], d["M"], d["cube"], d["cam_para"], 0.8)
+        assert all(torch.equal(a, c) for a, c in zip(res + sw2, out + sws))
+        m.use_graphs = True  # hipGraph replay of the wide forward
+        res_g = m(d["img_rgb"], d["img"], d["pcl"], Loader(), d["center"], d["M"], d["cube"], d["cam_para"], 0.8)[0]
+        assert all(torch.equal(a, c) for a, c in zip(res_g, out))
+        with pytest.raises(RuntimeError, match="needs 256x256 crops"):
+            m(d["img_rgb"][..., :128, :128], d["img"][..., :128, :128], d["pcl"], Loader(), d["center"], d["M"], d["cube"], d["cam_para"], 0.8)
+        with pytest.raises(RuntimeError, match="needs 128x128 crops"):  # the reference-sized model keeps refusing other sizes, like the reference's shape error
+            _model("convnext-tiny")(d["img_rgb"], d["img"], d["pcl"], Loader(), d["center"], d["M"], d["cube"], d["cam_para"], 0.8)
+
+
 def test_forward_kernel_argument_reaches_only_the_decode():
     """forward(..., kernel=0.6): the reference applies `kernel` in offset2joint_weight only; Block_KPFusion hard-codes
     pcl_joint2offset(joint_xyz, pcl, 0.8) (model/model.py:294).  A caller passing another kernel must still match the oracle."""
