@@ -171,10 +171,11 @@ __global__ __launch_bounds__(256) void row_gather_fwd_kernel(const float* __rest
 // among its 64 lanes (shuffle + ballot), a lane's slot is its row's next free slot + the number of lower lanes with the same row.
 // The lists therefore hold ascending entry numbers whatever the timing: the summation order below is fixed.
 // (2) row_gather_accum_kernel, one wave per source row: lanes over channel quads; with C <= 128 the two half-waves take alternate list
-// positions (two accumulators, added lower + upper at the end: still one fixed order).  E <= 8192 entries, P <= 2048 rows per image.
-constexpr int GATHER_MAX_E = 8192, GATHER_MAX_P = 2048;
+// positions (two accumulators, added lower + upper at the end: still one fixed order).  E <= 8192 entries, P <= 4096 rows per image (round 5: the 64 x 64
+// feature map of the wide model; 16 waves per image up to 2048 rows, 8 beyond — the per-wave count table is INV_W * P ints of LDS).
+constexpr int GATHER_MAX_E = 8192, GATHER_MAX_P = 4096;
 
-constexpr int INV_W = 16;  // waves per image in the inversion
+template <int INV_W>  // waves per image in the inversion
 __global__ __launch_bounds__(64 * INV_W) void row_gather_invert_kernel(const int* __restrict__ idx, int* __restrict__ start, int* __restrict__ list, int P,
                                                                       int E) {
   extern __shared__ int inv_lds[];  // cnt[INV_W][P] (per-wave counts, then per-wave next-free slots) | tot[P] | wsum[INV_W]
@@ -380,6 +381,28 @@ extern "C" int kpf_row_gather_fwd_f32(const float* src, const int* idx, const fl
   return kpf_check_launch("kpf_row_gather_fwd_f32");
 }
 
+
+// the inversion's launch: 16 waves per image while the count table fits (P <= 2048), 8 beyond
+static int launch_row_gather_invert(const int* idx, int* start, int* list, int B, int P, int E, hipStream_t st, const char* who) {
+  static std::atomic<bool> lds_opt_in[2][KPF_MAX_DEVICES];
+  if (P <= 2048) {
+    const size_t inv_lds = (size_t)(16 * P + P + 16) * sizeof(int);
+    if (inv_lds > 64 * 1024 && !kpf_raise_lds_limit(reinterpret_cast<const void*>(&row_gather_invert_kernel<16>), lds_opt_in[0])) {
+      kpf_set_error("%s: cannot raise the dynamic LDS limit", who);
+      return KPF_ELAUNCH;
+    }
+    hipLaunchKernelGGL(row_gather_invert_kernel<16>, dim3(B), dim3(64 * 16), inv_lds, st, idx, start, list, P, E);
+  } else {
+    const size_t inv_lds = (size_t)(8 * P + P + 8) * sizeof(int);
+    if (!kpf_raise_lds_limit(reinterpret_cast<const void*>(&row_gather_invert_kernel<8>), lds_opt_in[1])) {
+      kpf_set_error("%s: cannot raise the dynamic LDS limit", who);
+      return KPF_ELAUNCH;
+    }
+    hipLaunchKernelGGL(row_gather_invert_kernel<8>, dim3(B), dim3(64 * 8), inv_lds, st, idx, start, list, P, E);
+  }
+  return kpf_check_launch(who);
+}
+
 extern "C" long kpf_row_gather_ws_ints(int B, int P, int R, int G) { return (long)B * (P + 1) + (long)B * R * G; }
 
 extern "C" int kpf_row_gather_bwd_f32(const float* dout, const int* idx, const float* w, float* dsrc, int* ws, long ws_ints, int B, int P, int R, int G, int C,
@@ -392,12 +415,7 @@ extern "C" int kpf_row_gather_bwd_f32(const float* dout, const int* idx, const f
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int* start = ws;
   int* list = ws + (long)B * (P + 1);
-  const size_t inv_lds = (size_t)(INV_W * P + P + INV_W) * sizeof(int);
-  static std::atomic<bool> lds_opt_in[KPF_MAX_DEVICES];
-  KPF_REQUIRE(inv_lds <= 64 * 1024 || kpf_raise_lds_limit(reinterpret_cast<const void*>(&row_gather_invert_kernel), lds_opt_in),
-              "kpf_row_gather_bwd_f32: cannot raise the dynamic LDS limit");
-  hipLaunchKernelGGL(row_gather_invert_kernel, dim3(B), dim3(64 * INV_W), inv_lds, st, idx, start, list, P, (int)E);
-  int rc = kpf_check_launch("kpf_row_gather_bwd_f32 (invert)");
+  int rc = launch_row_gather_invert(idx, start, list, B, P, (int)E, st, "kpf_row_gather_bwd_f32 (invert)");
   if (rc != KPF_OK) return rc;
   hipLaunchKernelGGL(row_gather_accum_kernel, dim3(grid_for((long)B * P, 4, 256 * 32)), dim3(256), 0, st, dout, start, list, w, dsrc, B, P, (int)E, G, C / 4);
   return kpf_check_launch("kpf_row_gather_bwd_f32");
@@ -410,12 +428,7 @@ extern "C" int kpf_row_gather_invert(const int* idx, int* ws, long ws_ints, int 
   const long E = (long)R * G;
   KPF_REQUIRE(E <= GATHER_MAX_E && P <= GATHER_MAX_P, "kpf_row_gather_invert: at most %d gathered entries and %d source rows per image", GATHER_MAX_E, GATHER_MAX_P);
   KPF_REQUIRE(ws_ints >= kpf_row_gather_ws_ints(B, P, R, G), "kpf_row_gather_invert: workspace too small");
-  const size_t inv_lds = (size_t)(INV_W * P + P + INV_W) * sizeof(int);
-  static std::atomic<bool> lds_opt_in[KPF_MAX_DEVICES];
-  KPF_REQUIRE(inv_lds <= 64 * 1024 || kpf_raise_lds_limit(reinterpret_cast<const void*>(&row_gather_invert_kernel), lds_opt_in),
-              "kpf_row_gather_invert: cannot raise the dynamic LDS limit");
-  hipLaunchKernelGGL(row_gather_invert_kernel, dim3(B), dim3(64 * INV_W), inv_lds, reinterpret_cast<hipStream_t>(stream), idx, ws, ws + (long)B * (P + 1), P, (int)E);
-  return kpf_check_launch("kpf_row_gather_invert");
+  return launch_row_gather_invert(idx, ws, ws + (long)B * (P + 1), B, P, (int)E, reinterpret_cast<hipStream_t>(stream), "kpf_row_gather_invert");
 }
 extern "C" int kpf_row_gather_accum_f32(const float* dout, const int* start, const int* list, const float* w, float* dsrc, int B, int P, int R, int G, int C,
                                         void* stream) {
@@ -1387,13 +1400,14 @@ extern "C" int kpf_layer_scale_backward_partial(const float* g, const void* y, i
 // :166-195 offset2joint_weight; model/loss.py:3-26): for stage output pd [B][5J][F][F] (3J unit offsets (j, xyz), J heat maps, J weight
 // logits), the depth crop and the ground-truth joints uvd_gt [B][J][3]
 //     loss_pixel = mean SmoothL1(pd[:, :4J] - joint2offset(uvd_gt))          loss_coord = mean SmoothL1(decode(pd) - uvd_gt)
-// where decode is the masked soft-argmax.  One workgroup per (joint, sample): the F*F = 1024 pixels are 4 per thread, the softmax and the
+// where decode is the masked soft-argmax.  One workgroup per (joint, sample): the F*F pixels are 4 per thread (256 threads up to F = 32, 1024 threads up to
+// F = 64: the wide model), the softmax and the
 // three weighted sums are block reductions, the target maps are computed on the fly (never materialised); it writes the two partial
 // sums of its (sample, joint) and, backward, the gradient of its five channels — every element of d pd is written exactly once.
 // The library path was ~200 element-wise launches per iteration over B x 105 x 32 x 32 maps.
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
-constexpr int LS_PX = 4;  // pixels per thread: F * F <= 1024
+constexpr int LS_PX = 4;  // pixels per thread: F * F <= 4 * threads
 
 __device__ __forceinline__ float block_sum256(float v, float* red) {
   v = wave_sum(v);
@@ -1409,6 +1423,31 @@ __device__ __forceinline__ float block_max256(float v, float* red) {
   __syncthreads();
   return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
+// the same reductions over NT / 64 waves (NT = 256: the expressions above, bit for bit; NT = 1024: four such groups, added in order)
+template <int NT>
+__device__ __forceinline__ float block_sum_nt(float v, float* red) {
+  if constexpr (NT == 256) return block_sum256(v, red);
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < NT / 256; ++q) s += (red[4 * q] + red[4 * q + 1]) + (red[4 * q + 2] + red[4 * q + 3]);
+  return s;
+}
+template <int NT>
+__device__ __forceinline__ float block_max_nt(float v, float* red) {
+  if constexpr (NT == 256) return block_max256(v, red);
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float m = red[0];
+#pragma unroll
+  for (int q = 1; q < NT / 64; ++q) m = fmaxf(m, red[q]);
+  return m;
+}
 __device__ __forceinline__ float sl1(float z) {  // model/loss.py: quadratic below 0.01, 0.01 (|z| - 0.005) from there on
   const float a = fabsf(z);
   return a < 0.01f ? 0.5f * z * z : 0.01f * (a - 0.005f);
@@ -1416,11 +1455,11 @@ __device__ __forceinline__ float sl1(float z) {  // model/loss.py: quadratic bel
 __device__ __forceinline__ float sl1_grad(float z) { return fabsf(z) < 0.01f ? z : (z > 0.f ? 0.01f : (z < 0.f ? -0.01f : 0.f)); }
 
 // MODE 0: forward (part[b][j] = {pixel sum, coord sum});  MODE 1: backward (dpd), scaled by gp = dL/dloss_pixel / n_pix, gc = dL/dloss_coord / n_coord
-template <int MODE>
-__global__ __launch_bounds__(256) void dense_loss_kernel(const float* __restrict__ pd, const float* __restrict__ img, const float* __restrict__ gt,
+template <int MODE, int NT>
+__global__ __launch_bounds__(NT) void dense_loss_kernel(const float* __restrict__ pd, const float* __restrict__ img, const float* __restrict__ gt,
                                                          float* __restrict__ part, float* __restrict__ dpd, const float* __restrict__ gscale, int J, int F, int S,
                                                          float ks, float pix_w, float coord_w) {
-  __shared__ float red[4];
+  __shared__ float red[NT / 64];
   const int j = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int P = F * F, st = S / F;
   const float* pdb = pd + (long)b * 5 * J * P;
@@ -1430,7 +1469,7 @@ __global__ __launch_bounds__(256) void dense_loss_kernel(const float* __restrict
   float mx = -INFINITY;
 #pragma unroll
   for (int k = 0; k < LS_PX; ++k) {
-    const int p = tid + 256 * k;
+    const int p = tid + NT * k;
     const bool in = p < P;
     const int py = in ? p / F : 0, px = in ? p - py * F : 0;
     d[k] = in ? imb[(long)(py * st) * S + px * st] : 1.f;  // F.interpolate(nearest): source index = floor(dst * S / F)
@@ -1440,19 +1479,19 @@ __global__ __launch_bounds__(256) void dense_loss_kernel(const float* __restrict
     lg[k] = in ? (d[k] > 0.99f ? -1e8f : pdb[(long)(4 * J + j) * P + p]) : -INFINITY;
     mx = fmaxf(mx, lg[k]);
   }
-  mx = block_max256(mx, red);
+  mx = block_max_nt<NT>(mx, red);
   float w[LS_PX], se = 0.f;
 #pragma unroll
   for (int k = 0; k < LS_PX; ++k) {
-    w[k] = tid + 256 * k < P ? __expf(lg[k] - mx) : 0.f;
+    w[k] = tid + NT * k < P ? __expf(lg[k] - mx) : 0.f;
     se += w[k];
   }
-  se = block_sum256(se, red);
+  se = block_sum_nt<NT>(se, red);
   const float inv = 1.0f / se;
   float heat[LS_PX], dist[LS_PX], un[3][LS_PX], val[3][LS_PX], Jc[3];
 #pragma unroll
   for (int k = 0; k < LS_PX; ++k) {
-    const int p = tid + 256 * k;
+    const int p = tid + NT * k;
     w[k] *= inv;
     heat[k] = p < P ? pdb[(long)(3 * J + j) * P + p] : 0.f;
     dist[k] = ks - heat[k] * m[k] * ks;
@@ -1462,13 +1501,13 @@ __global__ __launch_bounds__(256) void dense_loss_kernel(const float* __restrict
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < LS_PX; ++k) {
-      const int p = tid + 256 * k;
+      const int p = tid + NT * k;
       un[c][k] = p < P ? pdb[(long)(3 * j + c) * P + p] : 0.f;
       const float coord = c == 0 ? u[k] : (c == 1 ? v[k] : d[k]);
       val[c][k] = un[c][k] * m[k] * dist[k] + coord;
       s = fmaf(val[c][k], w[k], s);
     }
-    Jc[c] = block_sum256(s, red);
+    Jc[c] = block_sum_nt<NT>(s, red);
   }
   const float zc[3] = {Jc[0] - gx, Jc[1] - gy, Jc[2] - gz};
   if (MODE == 0) {
@@ -1476,14 +1515,14 @@ __global__ __launch_bounds__(256) void dense_loss_kernel(const float* __restrict
     float ps = 0.f;
 #pragma unroll
     for (int k = 0; k < LS_PX; ++k) {
-      if (tid + 256 * k >= P) continue;
+      if (tid + NT * k >= P) continue;
       const float ox = gx - u[k], oy = gy - v[k], oz = gz - d[k];
       const float dg = sqrtf(ox * ox + oy * oy + oz * oz + 1e-8f);
       const float hm = (ks - dg) / ks;
       const float mg = (hm >= 0.f ? 1.f : 0.f) * m[k];
       ps += sl1(un[0][k] - ox / dg * mg) + sl1(un[1][k] - oy / dg * mg) + sl1(un[2][k] - oz / dg * mg) + sl1(heat[k] - hm * mg);
     }
-    ps = block_sum256(ps, red);
+    ps = block_sum_nt<NT>(ps, red);
     if (tid == 0) {
       part[((long)b * J + j) * 2 + 0] = ps;
       part[((long)b * J + j) * 2 + 1] = sl1(zc[0]) + sl1(zc[1]) + sl1(zc[2]);
@@ -1494,7 +1533,7 @@ __global__ __launch_bounds__(256) void dense_loss_kernel(const float* __restrict
     float* db = dpd + (long)b * 5 * J * P;
 #pragma unroll
     for (int k = 0; k < LS_PX; ++k) {
-      const int p = tid + 256 * k;
+      const int p = tid + NT * k;
       if (p >= P) continue;
       const float ox = gx - u[k], oy = gy - v[k], oz = gz - d[k];
       const float dg = sqrtf(ox * ox + oy * oy + oz * oz + 1e-8f);
@@ -1517,18 +1556,26 @@ __global__ __launch_bounds__(256) void dense_loss_kernel(const float* __restrict
 
 extern "C" int kpf_dense_loss_forward(const float* pd, const float* img, const float* uvd_gt, float* part, int B, int J, int F, int S, float kernel_size,
                                       void* stream) {
-  KPF_REQUIRE(pd && img && uvd_gt && part && B > 0 && J > 0 && F > 0 && F * F <= 256 * LS_PX && S % F == 0, "kpf_dense_loss_forward: bad arguments (F*F <= 1024)");
-  hipLaunchKernelGGL(dense_loss_kernel<0>, dim3(J, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pd, img, uvd_gt, part, (float*)nullptr,
-                     (const float*)nullptr, J, F, S, kernel_size, 0.f, 0.f);
+  KPF_REQUIRE(pd && img && uvd_gt && part && B > 0 && J > 0 && F > 0 && F * F <= 1024 * LS_PX && S % F == 0, "kpf_dense_loss_forward: bad arguments (F*F <= 4096)");
+  if (F * F <= 256 * LS_PX)
+    hipLaunchKernelGGL((dense_loss_kernel<0, 256>), dim3(J, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pd, img, uvd_gt, part, (float*)nullptr,
+                       (const float*)nullptr, J, F, S, kernel_size, 0.f, 0.f);
+  else
+    hipLaunchKernelGGL((dense_loss_kernel<0, 1024>), dim3(J, B), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), pd, img, uvd_gt, part, (float*)nullptr,
+                       (const float*)nullptr, J, F, S, kernel_size, 0.f, 0.f);
   return kpf_check_launch("kpf_dense_loss_forward");
 }
 
 extern "C" int kpf_dense_loss_backward(const float* pd, const float* img, const float* uvd_gt, const float* grad2, float* dpd, int B, int J, int F, int S,
                                        float kernel_size, void* stream) {
-  KPF_REQUIRE(pd && img && uvd_gt && grad2 && dpd && B > 0 && J > 0 && F > 0 && F * F <= 256 * LS_PX && S % F == 0, "kpf_dense_loss_backward: bad arguments");
+  KPF_REQUIRE(pd && img && uvd_gt && grad2 && dpd && B > 0 && J > 0 && F > 0 && F * F <= 1024 * LS_PX && S % F == 0, "kpf_dense_loss_backward: bad arguments (F*F <= 4096)");
   const float pix_w = 1.0f / ((float)B * 4 * J * F * F), coord_w = 1.0f / ((float)B * J * 3);
-  hipLaunchKernelGGL(dense_loss_kernel<1>, dim3(J, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pd, img, uvd_gt, (float*)nullptr, dpd, grad2, J, F, S,
-                     kernel_size, pix_w, coord_w);
+  if (F * F <= 256 * LS_PX)
+    hipLaunchKernelGGL((dense_loss_kernel<1, 256>), dim3(J, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pd, img, uvd_gt, (float*)nullptr, dpd, grad2, J, F, S,
+                       kernel_size, pix_w, coord_w);
+  else
+    hipLaunchKernelGGL((dense_loss_kernel<1, 1024>), dim3(J, B), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), pd, img, uvd_gt, (float*)nullptr, dpd, grad2, J, F, S,
+                       kernel_size, pix_w, coord_w);
   return kpf_check_launch("kpf_dense_loss_backward");
 }
 

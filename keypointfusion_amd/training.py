@@ -220,7 +220,7 @@ class _LayerScaleResidual(torch.autograd.Function):
 
 LAYER_SCALE_MAX_C = 1024   # kpf_layer_scale_backward: a lane holds up to 4 channel quads (csrc/kpf_train.hip LN_MAXQ)
 ROW_GATHER_MAX_E = 8192    # kpf_row_gather_bwd_f32: entries (R * G) per image that one workgroup sorts (csrc/kpf_train.hip GATHER_MAX_E)
-ROW_GATHER_MAX_P = 2048    # ... and source rows per image (GATHER_MAX_P)
+ROW_GATHER_MAX_P = 4096    # ... and source rows per image (GATHER_MAX_P: the 64 x 64 feature map of the wide model)
 
 
 def layer_scale_residual(x, gamma, y, groups=1):
@@ -362,7 +362,7 @@ def _fused_loss_applies(results, spatial_weight, img, stage_type, l1):
     if not (r0.is_cuda and r0.dim() == 4 and results[1].shape == r0.shape and r0.shape[1] % 5 == 0):
         return False
     Fs, J = r0.shape[-1], r0.shape[1] // 5
-    if Fs * Fs > 1024 or img.shape[-1] % Fs or r0.shape[-2] != Fs:
+    if Fs * Fs > 4096 or img.shape[-1] % Fs or r0.shape[-2] != Fs:
         return False
     if any(tuple(r.shape) != (r0.shape[0], J, 3) for r in results[2:]):
         return False
@@ -381,7 +381,7 @@ def kpfusion_loss(results, spatial_weight, img, uvd_gt, xyz_gt, epoch=0, stage_t
                 parts["loss_spatial_%d" % t] = out[9 + t]
         return loss, parts
     raise ValueError("kpfusion_loss: the fused HIP loss covers the reference's schedule (train.py:211-261: stage_type %s, the module's "
-                     "SmoothL1Loss, fp32 CUDA tensors, F*F <= 1024 feature maps) and nothing else; got device %s, stage_type %s, custom l1: %s.  "
+                     "SmoothL1Loss, fp32 CUDA tensors, F*F <= 4096 feature maps) and nothing else; got device %s, stage_type %s, custom l1: %s.  "
                      "(The torch restatement used as its checker lives in oracle/train_oracle.py.)"
                      % (STAGE_TYPE, results[0].device, tuple(stage_type), l1 is not None))
 
@@ -1777,8 +1777,8 @@ def row_gather_invert(idx, P):
 
 
 def row_gather(src, idx, w=None, inv=None):
-    """Weighted row gather (RowGather).  Shapes outside the backward kernel's limits (more than 8192 gathered entries or 2048 source rows per
-    image: 256x256 inputs, > 2048 points) are decided HERE, before autograd records a node, and take torch.gather — whose backward
+    """Weighted row gather (RowGather).  Shapes outside the backward kernel's limits (more than 8192 gathered entries or 4096 source rows per
+    image: crops beyond 256 x 256, > 2048 points) are decided HERE, before autograd records a node, and take torch.gather — whose backward
     (index_add) is correct but adds with atomics, i.e. is not run-to-run bit-reproducible; the reference's sizes never get there."""
     B, P, Cc = src.shape
     _, R, G = idx.shape

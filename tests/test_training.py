@@ -623,3 +623,57 @@ def test_graphed_train_step_data_parallel_two_ranks_on_one_gpu(tmp_path):
         assert losses == [shard_loss[rank]] * 2, (rank, losses, shard_loss)
         assert ngot == len(per_shard[0]) > 100
         assert nbad == 0, "rank %d: %d gradient tensors are not the mean of the two shards' gradients, e.g. %s" % (rank, nbad, bad)
+
+
+@pytest.mark.gpu
+def test_wide_model_trains_at_256x256():
+    """The wide extension (KPFusion(..., crop_size=256)) in .train() mode: one iteration at 256 x 256 — the fused HIP loss agrees with the float64 torch
+    restatement of the loss (oracle/train_oracle.py, pinned to the reference's codec at 128) evaluated on the SAME outputs at F = 64, every live parameter
+    receives a finite gradient, two iterations on the same batch are bit-identical, and an AdamW step lowers the loss."""
+    from keypointfusion_amd.model.model import KPFusion
+    from keypointfusion_amd.parallel import live_parameters
+    from keypointfusion_amd.weights import synthetic_state_dict
+    net, dev, B = "KPFusion-convnext-tiny", torch.device("cuda:0"), 2
+    m = KPFusion(net, "", 21, "dexycb", "", crop_size=256)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state_dict(net, 0, crop_size=256).items()}, strict=True)
+    m = m.to(dev).train()
+    m.train_dropout = 0.0
+    b = {k: torch.from_numpy(v).to(dev) for k, v in synthetic_batch(B, 256, seed=12).items()}
+    g = torch.Generator().manual_seed(2)
+    uvd, xyz = (torch.rand(B, 21, 3, generator=g) * 1.2 - 0.6).to(dev), (torch.rand(B, 21, 3, generator=g) * 1.2 - 0.6).to(dev)
+
+    class Loader:
+        img_size, flip = 256, 1
+
+    def iteration():
+        for p in m.parameters():
+            p.grad = None
+        res, sws, _ = m(b["img_rgb"], b["img"], b["pcl"], Loader(), b["center"], b["M"], b["cube"], b["cam_para"], 0.8)
+        loss, parts = T.kpfusion_loss(res, sws, b["img"], uvd, xyz, epoch=0)
+        loss.backward()
+        return res, sws, loss
+
+    live = live_parameters(m)
+    stats = {k: v.clone() for k, v in m.named_buffers()}  # (BatchNorm running statistics move in train mode: the second iteration starts from the same)
+    res, sws, loss = iteration()
+    assert tuple(res[0].shape) == (B, 105, 64, 64) and tuple(sws[0].shape) == (B, 21, 64, 64)
+    ref, _ = TO.kpfusion_loss([r.detach().double().cpu() for r in res], [s.detach().double().cpu() for s in sws], b["img"].double().cpu(), uvd.double().cpu(),
+                              xyz.double().cpu(), epoch=0)
+    assert abs(float(loss) - float(ref)) < 1e-5 * abs(float(ref)), (float(loss), float(ref))
+    names = {id(p): n for n, p in m.named_parameters()}
+    none = [names[id(p)] for p in live if p.grad is None]
+    # (the identity skips of Residual blocks with equal widths own a convolution the forward never calls — model/hourglass.py:99-104 — exactly as at 128 x 128)
+    assert all(".skip_layer.conv." in n for n in none), [n for n in none if ".skip_layer.conv." not in n][:10]
+    live = [p for p in live if p.grad is not None]
+    g1 = [p.grad.clone() for p in live]
+    assert all(bool(torch.isfinite(x).all()) for x in g1)
+    assert sum(float(x.abs().sum()) > 0 for x in g1) > 0.95 * len(g1)
+    with torch.no_grad():
+        for k, v in m.named_buffers():
+            v.copy_(stats[k])
+    _, _, loss2 = iteration()
+    assert float(loss2) == float(loss) and all(torch.equal(a, p.grad) for a, p in zip(g1, live)), "two iterations on the same batch must give the same bits"
+    opt, _ = T.make_optimizer(live, lr=5e-5, capturable=False)
+    opt.step()
+    _, _, loss3 = iteration()
+    assert float(loss3) < float(loss)
