@@ -64,6 +64,7 @@ WORKLOADS = {
     # step); fp32 — bf16 training is not built, so this is configs[3]'s schedule, not its precision
     "train128": ("KPFusion-convnext-tiny", 128, 32, "f32", "train", "configs[3] (fp32)"),
     "train128_bf16": ("KPFusion-convnext-tiny", 128, 32, "bf16", "train", "configs[3]"),
+    "train128_f16": ("KPFusion-convnext-tiny", 128, 32, "f16", "train", "configs[3] in fp16 with dynamic loss scaling (training.LossScaler)"),
 }
 
 
@@ -237,7 +238,8 @@ def main():
         xyz_gt = (torch.rand(B, 21, 3, generator=gg) * 1.2 - 0.6).to(dev)
         live = live_parameters(model)
         graphed_train = not args.no_graph and not args.serial_streams  # the iteration replays from hipGraphs (N > 1: bucketed all-reduce between two graphs)
-        opt, _ = T.make_optimizer(live, capturable=graphed_train)
+        scaler = T.LossScaler() if precision == "f16" else None  # fp16 gradients underflow without it; bf16 / fp32 need none
+        opt, _ = T.make_optimizer(live, capturable=graphed_train or scaler is not None)
         reducer = GradBucketReducer(live, dist if dist is not None else None) if not graphed_train else None
         tbatch = dict(batch, uvd_gt=uvd_gt, xyz_gt=xyz_gt)
 
@@ -257,17 +259,20 @@ def main():
         if train:
             if graphed_train and graph_on[0]:
                 if gstep[0] is None:
-                    gstep[0] = T.GraphedTrainStep(model, opt, train_loss, tbatch, dist_mod=dist, params=live)
+                    gstep[0] = T.GraphedTrainStep(model, opt, train_loss, tbatch, dist_mod=dist, params=live, scaler=scaler)
                 gstep[0](tbatch)
                 return
             opt.zero_grad(set_to_none=False)
             if reducer is not None:
                 reducer.reset()
             loss = train_loss(model, tbatch)
-            loss.backward()
+            (loss if scaler is None else scaler.scale(loss)).backward()
             if reducer is not None:
                 reducer.finish()
-            opt.step()
+            if scaler is None:
+                opt.step()
+            else:
+                opt.step(scaler=scaler)
             return
         with torch.no_grad():
             if backbones_only:

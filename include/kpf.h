@@ -518,6 +518,16 @@ typedef struct kpf_adamw_desc {
 } kpf_adamw_desc;
 int kpf_adamw_step_multi(const kpf_adamw_desc* descs, int n, const float* lr_dev, float lr_host, const float* step_dev, double beta1, double beta2, float eps,
                          float weight_decay, void* stream);
+/* round 5 (ABI 14): loss scaling for fp16 mixed-precision training, on the device (what torch.cuda.amp.GradScaler does around train.py:262-264; a captured
+ * iteration keeps following it).  kpf_grad_finite_check_multi: *found_dev |= 1 when any gradient of the descriptors (p / m / v unused) holds an inf or a nan.
+ * kpf_adamw_step_multi_scaled: kpf_adamw_step_multi on g * *inv_scale_dev, or a no-op when *skip_dev != 0 (either pointer may be null).
+ * kpf_loss_scale_update: found -> scale *= backoff and the growth tracker restarts; otherwise *step_dev += 1 (nullable) and scale *= growth every `interval` clean
+ * steps; scale stays in [1, 2^24], *inv_scale_dev = 1 / scale, *found_dev = 0 for the next iteration. */
+int kpf_grad_finite_check_multi(const kpf_adamw_desc* descs, int n, int* found_dev, void* stream);
+int kpf_adamw_step_multi_scaled(const kpf_adamw_desc* descs, int n, const float* lr_dev, float lr_host, const float* step_dev, double beta1, double beta2,
+                                float eps, float weight_decay, const float* inv_scale_dev, const int* skip_dev, void* stream);
+int kpf_loss_scale_update(float* scale_dev, float* inv_scale_dev, int* tracker_dev, int* found_dev, float* step_dev, float growth, float backoff, int interval,
+                          void* stream);
 
 /* Training: the weight (and bias) gradients of MANY Linear layers over few rows in one launch per KPF_WGRAD_GROUP_BATCH problems:
  * dw[N][K] = dy[M][N]^T x[M][K], db[N] = column sums of dy (db nullable), fp32, N % 4 == K % 4 == 0, rows contiguous.  A workgroup owns a

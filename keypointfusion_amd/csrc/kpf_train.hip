@@ -1780,6 +1780,8 @@ struct AdamwBatch {
   kpf_adamw_desc d[KPF_ADAMW_BATCH];
   const float* lr_dev;
   const float* step_dev;
+  const float* inv_scale;  // fp16 loss scaling (kpf_adamw_step_multi_scaled): the gradients are multiplied by *inv_scale as they are read; null = 1
+  const int* skip;         // ... and the whole step is a no-op when *skip != 0 (a non-finite gradient was found); null = never
   float lr_host, beta1, beta2, omb1, omb2, eps, wd;  // omb = 1 - beta, rounded from the double difference (1.f - 0.999f is 4.7e-5 off)
   int nd;
 };
@@ -1788,6 +1790,8 @@ constexpr int ADAMW_PER_BLOCK = 4096;
 
 __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwBatch) {
   adamw_kernarg_t bp = (adamw_kernarg_t)__builtin_amdgcn_kernarg_segment_ptr();  // (indexing the by-value struct would copy it to scratch)
+  if (bp->skip && bp->skip[0] != 0) return;  // (uniform: every workgroup of every launch of this step reads the same flag)
+  const float gs = bp->inv_scale ? bp->inv_scale[0] : 1.0f;
   const int nd = bp->nd;
   int lo = 0, hi = nd - 1;
   while (lo < hi) {  // last descriptor whose first_block <= blockIdx.x
@@ -1817,6 +1821,7 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwBatch) {
       f32x4 mm = *reinterpret_cast<const f32x4*>(m + i), vv = *reinterpret_cast<const f32x4*>(v + i);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
+        gg[c] *= gs;
         pp[c] -= decay * pp[c];
         mm[c] += omb1 * (gg[c] - mm[c]);
         vv[c] = b2 * vv[c] + omb2 * gg[c] * gg[c];
@@ -1828,7 +1833,7 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwBatch) {
     } else {
       for (long e = i; e < i + 4 && e < n; ++e) {
         float pp = p[e], mm = m[e], vv = v[e];
-        const float gg = g[e];
+        const float gg = g[e] * gs;
         pp -= decay * pp;
         mm += omb1 * (gg - mm);
         vv = b2 * vv + omb2 * gg * gg;
@@ -1840,8 +1845,14 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwBatch) {
 }
 }  // namespace
 
+extern "C" int kpf_adamw_step_multi_scaled(const kpf_adamw_desc* descs, int n, const float* lr_dev, float lr_host, const float* step_dev, double beta1,
+                                           double beta2, float eps, float weight_decay, const float* inv_scale_dev, const int* skip_dev, void* stream);
 extern "C" int kpf_adamw_step_multi(const kpf_adamw_desc* descs, int n, const float* lr_dev, float lr_host, const float* step_dev, double beta1, double beta2,
                                     float eps, float weight_decay, void* stream) {
+  return kpf_adamw_step_multi_scaled(descs, n, lr_dev, lr_host, step_dev, beta1, beta2, eps, weight_decay, nullptr, nullptr, stream);
+}
+extern "C" int kpf_adamw_step_multi_scaled(const kpf_adamw_desc* descs, int n, const float* lr_dev, float lr_host, const float* step_dev, double beta1,
+                                           double beta2, float eps, float weight_decay, const float* inv_scale_dev, const int* skip_dev, void* stream) {
   KPF_REQUIRE(n >= 0 && (descs || n == 0) && step_dev, "kpf_adamw_step_multi: bad arguments");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   for (int base = 0; base < n; base += KPF_ADAMW_BATCH) {
@@ -1855,12 +1866,96 @@ extern "C" int kpf_adamw_step_multi(const kpf_adamw_desc* descs, int n, const fl
       blocks += (b.d[k].n + ADAMW_PER_BLOCK - 1) / ADAMW_PER_BLOCK;
     }
     KPF_REQUIRE(blocks < (1L << 31), "kpf_adamw_step_multi: too many elements");
+    b.inv_scale = inv_scale_dev, b.skip = skip_dev;
     b.lr_dev = lr_dev, b.step_dev = step_dev, b.lr_host = lr_host, b.beta1 = (float)beta1, b.beta2 = (float)beta2, b.omb1 = (float)(1.0 - beta1), b.omb2 = (float)(1.0 - beta2), b.eps = eps, b.wd = weight_decay;
     hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, st, b);
     const int rc = kpf_check_launch("kpf_adamw_step_multi");
     if (rc != KPF_OK) return rc;
   }
   return KPF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Loss scaling for fp16 mixed-precision training (round 5; what torch.cuda.amp.GradScaler does around train.py:262-264, entirely on the device so that a
+// captured iteration keeps following it): the loss is multiplied by a device scalar `scale` before backward; afterwards
+//   (1) kpf_grad_finite_check_multi: one pass over every gradient (the AdamW descriptors), *found |= any value is inf / nan (an integer OR: order-independent);
+//   (2) kpf_adamw_step_multi_scaled: AdamW on g * (1 / scale), or nothing at all when *found;
+//   (3) kpf_loss_scale_update: found -> scale *= backoff, growth tracker = 0; else tracker + 1, and scale *= growth every `interval` clean steps;
+//       1 / scale refreshed, the optimiser's step count advanced only by a step that happened, the flag cleared for the next iteration.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void grad_finite_check_kernel(const AdamwBatch) {
+  adamw_kernarg_t bp = (adamw_kernarg_t)__builtin_amdgcn_kernarg_segment_ptr();
+  const int nd = bp->nd;
+  int lo = 0, hi = nd - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)blockIdx.x >= bp->d[mid].first_block) lo = mid;
+    else hi = mid - 1;
+  }
+  const float* g = bp->d[lo].g;
+  const long n = bp->d[lo].n;
+  const long base = (long)((int)blockIdx.x - bp->d[lo].first_block) * ADAMW_PER_BLOCK;
+  bool bad = false;
+  for (long i = base + threadIdx.x; i < n && i < base + ADAMW_PER_BLOCK; i += 256) {
+    const float v = g[i];
+    bad |= !(fabsf(v) <= 3.4028234e38f);  // inf or nan
+  }
+  if (__builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(const_cast<int*>(bp->skip), 1);
+}
+__global__ void loss_scale_update_kernel(float* scale, float* inv_scale, int* tracker, int* found, float* step, float growth, float backoff, int interval) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float s = scale[0];
+  if (found[0] != 0) {
+    s *= backoff;
+    tracker[0] = 0;
+  } else {
+    if (step) step[0] += 1.0f;
+    const int t = tracker[0] + 1;
+    if (t >= interval) {
+      s *= growth;
+      tracker[0] = 0;
+    } else {
+      tracker[0] = t;
+    }
+  }
+  s = fminf(fmaxf(s, 1.0f), 16777216.0f);  // [1, 2^24]
+  scale[0] = s;
+  inv_scale[0] = 1.0f / s;
+  found[0] = 0;
+}
+}  // namespace
+
+extern "C" int kpf_grad_finite_check_multi(const kpf_adamw_desc* descs, int n, int* found_dev, void* stream) {
+  KPF_REQUIRE(n >= 0 && (descs || n == 0) && found_dev, "kpf_grad_finite_check_multi: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  for (int base = 0; base < n; base += KPF_ADAMW_BATCH) {
+    AdamwBatch b;
+    b.nd = n - base < KPF_ADAMW_BATCH ? n - base : KPF_ADAMW_BATCH;
+    long blocks = 0;
+    for (int k = 0; k < b.nd; ++k) {
+      b.d[k] = descs[base + k];
+      KPF_REQUIRE(b.d[k].g && b.d[k].n > 0, "kpf_grad_finite_check_multi: bad descriptor %d", base + k);
+      b.d[k].first_block = (int)blocks;
+      blocks += (b.d[k].n + ADAMW_PER_BLOCK - 1) / ADAMW_PER_BLOCK;
+    }
+    KPF_REQUIRE(blocks < (1L << 31), "kpf_grad_finite_check_multi: too many elements");
+    b.lr_dev = nullptr, b.step_dev = nullptr, b.inv_scale = nullptr, b.skip = found_dev;
+    b.lr_host = b.beta1 = b.beta2 = b.omb1 = b.omb2 = b.eps = b.wd = 0.f;
+    hipLaunchKernelGGL(grad_finite_check_kernel, dim3((unsigned)blocks), dim3(256), 0, st, b);
+    const int rc = kpf_check_launch("kpf_grad_finite_check_multi");
+    if (rc != KPF_OK) return rc;
+  }
+  return KPF_OK;
+}
+
+extern "C" int kpf_loss_scale_update(float* scale_dev, float* inv_scale_dev, int* tracker_dev, int* found_dev, float* step_dev, float growth, float backoff,
+                                     int interval, void* stream) {
+  KPF_REQUIRE(scale_dev && inv_scale_dev && tracker_dev && found_dev && growth >= 1.f && backoff > 0.f && backoff <= 1.f && interval > 0,
+              "kpf_loss_scale_update: bad arguments");
+  hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), scale_dev, inv_scale_dev, tracker_dev, found_dev, step_dev,
+                     growth, backoff, interval);
+  return kpf_check_launch("kpf_loss_scale_update");
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -128,6 +128,9 @@ _SIGS = {
     "kpf_geom_gate_uvd_backward": [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P],
     "kpf_linear_wgrad_grouped": [C.POINTER(WgradGroupDesc), C.c_int, _P],
     "kpf_adamw_step_multi": [C.POINTER(AdamwDesc), C.c_int, _P, C.c_float, _P, C.c_double, C.c_double, C.c_float, C.c_float, _P],
+    "kpf_adamw_step_multi_scaled": [C.POINTER(AdamwDesc), C.c_int, _P, C.c_float, _P, C.c_double, C.c_double, C.c_float, C.c_float, _P, _P, _P],
+    "kpf_grad_finite_check_multi": [C.POINTER(AdamwDesc), C.c_int, _P, _P],
+    "kpf_loss_scale_update": [_P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_int, _P],
     "kpf_ln_train_forward": [_P, _P, _P, _P, C.c_int, _P, _P, C.c_long, C.c_int, C.c_float, _P],
     "kpf_ln_train_backward": [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, C.c_long, C.c_long, C.c_int, _P],
     "kpf_gelu_forward": [_P, _P, C.c_int, C.c_long, _P],

@@ -130,8 +130,8 @@ class KPFusion(nn.Module):
         if self.training:
             # train mode: batch-statistics BatchNorm, dropout, autograd-connected outputs on the module's own
             # Parameters — keypointfusion_amd/train_graph.py (convolutions / Linears forward + data-gradient on the HIP GEMM)
-            if self.precision == "f16":
-                raise NotImplementedError("train mode supports precision 'f32' and 'bf16' (fp16 training needs loss scaling, which is not built)")
+            # precision "f16" in train mode: fp16 GEMM operands / activations with fp32 master weights like "bf16", but gradients underflow below 6e-8 —
+            # scale the loss (training.LossScaler: loss * scale before backward, checked / unscaled / skipped step on the device)
             from ..train_graph import TrainGraph
             with torch.cuda.device(img.device):
                 return TrainGraph(self).forward(img_rgb, img, pcl, center, M, cube, cam_para, float(kernel), img_size, flip)

@@ -401,11 +401,17 @@ class FusedAdamW(torch.optim.AdamW):
                    for p in group["params"])
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, scaler=None):
+        """scaler (LossScaler, fp16 training): the gradients are those of loss * scale — checked for inf / nan in one pass, applied as g / scale or not at all,
+        then the scale is updated; all on the device (no .item()), so the call can be captured."""
         if closure is not None or not all(self._kpf_ok(g) for g in self.param_groups):
+            if scaler is not None:
+                raise ValueError("LossScaler needs the HIP AdamW step (fp32 CUDA parameters, no amsgrad / maximize / closure)")
             return super().step(closure)
         from . import lib as L
         lib = L.load()
+        if scaler is not None and len(self.param_groups) != 1:
+            raise ValueError("LossScaler: one parameter group (train.py:84-91 has one)")
         for group in self.param_groups:
             live = [p for p in group["params"] if p.grad is not None]
             if not live:
@@ -435,11 +441,79 @@ class FusedAdamW(torch.optim.AdamW):
             if lr_dev is not None and lr_dev.dtype != torch.float32:
                 lr_dev = lr_dev.float()
             b1, b2 = group["betas"]
-            L.check(lib.kpf_adamw_step_multi(descs, len(live), None if lr_dev is None else lr_dev.data_ptr(), 0.0 if lr_dev is not None else float(lr),
-                                             shared.data_ptr(), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
-                                             torch.cuda.current_stream().cuda_stream), "kpf_adamw_step_multi")
-            shared.add_(1.0)
+            st_ = torch.cuda.current_stream().cuda_stream
+            if scaler is None:
+                L.check(lib.kpf_adamw_step_multi(descs, len(live), None if lr_dev is None else lr_dev.data_ptr(), 0.0 if lr_dev is not None else float(lr),
+                                                 shared.data_ptr(), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), st_), "kpf_adamw_step_multi")
+                shared.add_(1.0)
+            else:
+                scaler._to(dev)
+                L.check(lib.kpf_grad_finite_check_multi(descs, len(live), scaler.found.data_ptr(), st_), "kpf_grad_finite_check_multi")
+                L.check(lib.kpf_adamw_step_multi_scaled(descs, len(live), None if lr_dev is None else lr_dev.data_ptr(), 0.0 if lr_dev is not None else float(lr),
+                                                        shared.data_ptr(), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
+                                                        scaler.inv_scale.data_ptr(), scaler.found.data_ptr(), st_), "kpf_adamw_step_multi_scaled")
+                scaler.skipped.add_(scaler.found)  # (diagnostic counter; the flag is cleared by the update below)
+                L.check(lib.kpf_loss_scale_update(scaler.scale_t.data_ptr(), scaler.inv_scale.data_ptr(), scaler.tracker.data_ptr(), scaler.found.data_ptr(),
+                                                  shared.data_ptr(), float(scaler.growth_factor), float(scaler.backoff_factor), int(scaler.growth_interval), st_),
+                        "kpf_loss_scale_update")
         return None
+
+
+class LossScaler:
+    """Dynamic loss scaling for fp16 mixed-precision training (`KPFusion.precision = "f16"` in train mode), the device-resident counterpart of
+    torch.cuda.amp.GradScaler around the reference's `loss.backward(); optimizer.step()` (train.py:262-264):
+
+        scaler = LossScaler()
+        scaler.scale(loss).backward()
+        opt.step(scaler=scaler)          # FusedAdamW (make_optimizer(..., capturable=True)): check, unscaled step or skip, scale update
+
+    Every quantity (scale, 1 / scale, the inf / nan flag, the growth tracker, the count of skipped steps) is a device tensor and nothing is read back, so
+    the three calls can sit inside a captured hipGraph (GraphedTrainStep(..., scaler=...)).  Data-parallel runs check the gradients AFTER the all-reduce:
+    an inf or nan on any rank is one on every rank, so all ranks take the same decision without another collective.  bf16 needs no scaler (fp32 exponent)."""
+
+    def __init__(self, init_scale=2.0 ** 14, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, device=None):
+        self.growth_factor, self.backoff_factor, self.growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
+        self._init = float(init_scale)
+        self.scale_t = None
+        if device is not None:
+            self._to(torch.device(device))
+
+    def _to(self, dev):
+        if self.scale_t is None or self.scale_t.device != dev:
+            prev = self._init if self.scale_t is None else float(self.scale_t)
+            self.scale_t = torch.tensor(prev, device=dev, dtype=torch.float32)
+            self.inv_scale = torch.tensor(1.0 / prev, device=dev, dtype=torch.float32)
+            self.found = torch.zeros((), device=dev, dtype=torch.int32)
+            self.tracker = torch.zeros((), device=dev, dtype=torch.int32)
+            self.skipped = torch.zeros((), device=dev, dtype=torch.int32)
+
+    @property
+    def scale_value(self):
+        return self.scale_t
+
+    # (named like GradScaler's)
+    @property
+    def scale_tensor(self):
+        return self.scale_t
+
+    def scale(self, loss):
+        self._to(loss.device)
+        return loss * self.scale_t
+
+    def get_scale(self):
+        """host value (a synchronisation: for logging, not inside a captured region)"""
+        return float(self.scale_t) if self.scale_t is not None else self._init
+
+    def state_dict(self):
+        return {"scale": self.get_scale(), "growth_tracker": int(self.tracker) if self.scale_t is not None else 0}
+
+    def load_state_dict(self, sd):
+        self._init = float(sd["scale"])
+        dev = self.scale_t.device if self.scale_t is not None else None
+        self.scale_t = None
+        if dev is not None:
+            self._to(dev)
+            self.tracker.fill_(int(sd.get("growth_tracker", 0)))
 
 
 def make_optimizer(params, lr=8e-4, step_size=10, start_epoch=0, capturable=False):
@@ -2052,7 +2126,7 @@ class GraphedTrainStep:
     usage:  step = GraphedTrainStep(model, optimizer, loss_fn, example_batch[, dist_mod=dist, params=live]);  loss = step(batch)"""
 
     def __init__(self, model, optimizer, loss_fn, batch, warmup=3, dist_mod=None, params=None, bucket_mb=64.0, group=None, dp_mode=None,
-                 grad_payload="f32", collective="allreduce"):
+                 grad_payload="f32", collective="allreduce", scaler=None):
         """dp_mode (data parallel only): "overlap" — ONE graph in which each bucket's collective is a node on RCCL's stream, launched by a
         post-accumulate-grad hook the moment the bucket's last gradient exists, so the reduction runs under the rest of backward (what
         DistributedDataParallel does under CUDA graphs; the replacement of train.py:263-265's DataParallel reduce); "split" — graph A,
@@ -2062,6 +2136,9 @@ class GraphedTrainStep:
         the mean of bf16-rounded gradients — not bit-equal to the fp32 form).  collective "allreduce" | "rs_ag": one all-reduce per bucket,
         or reduce-scatter + all-gather of the (padded) bucket — the same bytes per link on the xGMI mesh, two schedulable halves."""
         self.model, self.opt, self.loss_fn = model, optimizer, loss_fn
+        self.scaler = scaler  # LossScaler (fp16 training): loss * scale before backward; check, unscaled-or-skipped step and scale update inside the graph
+        if scaler is not None and grad_payload != "f32":
+            raise ValueError("GraphedTrainStep: a LossScaler goes with fp32 gradient payloads")
         self.dist, self.group = dist_mod, group
         bucket_mb = float(os.environ.get("KPF_DP_BUCKET_MB", bucket_mb))  # (tuning aid)
         assert grad_payload in ("f32", "bf16") and collective in ("allreduce", "rs_ag")
@@ -2093,7 +2170,7 @@ class GraphedTrainStep:
                 for h in count_hooks:
                     h.remove()
                 self._reduce_eager()
-                self.opt.step()
+                self._opt_step()
         cur.wait_stream(side)
         torch.cuda.synchronize()
         # what the warm-up iterations established (the one-graph data-parallel form fixes its buckets before backward is captured): the
@@ -2117,7 +2194,7 @@ class GraphedTrainStep:
         if self.dist is None:
             with torch.cuda.graph(self.graph):
                 self.loss = self._forward_backward()
-                self.opt.step()
+                self._opt_step()
             return
         self.world = self.dist.get_world_size(group)
         if self.dp_mode == "overlap":
@@ -2153,7 +2230,13 @@ class GraphedTrainStep:
                 if self.world > 1:
                     flat.div_(self.world)
                 torch._foreach_copy_(grads, views)
+            self._opt_step()
+
+    def _opt_step(self):
+        if self.scaler is None:
             self.opt.step()
+        else:
+            self.opt.step(scaler=self.scaler)
 
     def _forward_backward(self):
         self.opt.zero_grad(set_to_none=True)
@@ -2162,7 +2245,7 @@ class GraphedTrainStep:
         dpg = DeferredParamGrads(self._named)
         with dpg:  # small Linear layers' weight gradients, LayerNorm / layer-scale parameter sums: grouped launches after backward
             loss = self.loss_fn(self.model, self.static)
-            loss.backward()
+            (loss if self.scaler is None else self.scaler.scale(loss)).backward()
         self._deferred_ids = {id(p) for p in getattr(dpg, "last_deferred", [])}
         return loss.detach()
 
@@ -2273,7 +2356,7 @@ class GraphedTrainStep:
                             q.grad = b["flat"][o:o + q.numel()].view_as(q.grad)
                 else:  # bf16 payload: back to the parameters' type
                     torch._foreach_copy_([q.grad for q in b["params"]], [b["flat"][o:o + q.numel()].view_as(q.grad) for o, q in zip(b["offs"], b["params"])])
-            self.opt.step()
+            self._opt_step()
         self._remove_hooks()  # the captured graph no longer needs them (replays do not run Python)
 
     def _reduce_eager(self):

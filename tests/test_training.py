@@ -677,3 +677,96 @@ def test_wide_model_trains_at_256x256():
     opt.step()
     _, _, loss3 = iteration()
     assert float(loss3) < float(loss)
+
+
+@pytest.mark.gpu
+def test_loss_scaler_checks_unscales_skips_and_adapts_on_the_device():
+    """training.LossScaler + FusedAdamW.step(scaler=...) (kpf_grad_finite_check_multi, kpf_adamw_step_multi_scaled, kpf_loss_scale_update): a step on
+    gradients of loss * 2^k equals the step on the unscaled gradients bit for bit; one inf anywhere cancels the WHOLE step (parameters, moments and step
+    count untouched), halves the scale and is counted; `growth_interval` clean steps double it; nothing is read back to the host in between."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    shapes = [(96, 3, 4, 4), (96,), (384, 96), (5,), (3, 128), (1000001,)]
+    mk = lambda: [torch.randn(*sh, generator=g).to(dev).requires_grad_(True) for sh in shapes]
+    g = torch.Generator().manual_seed(0)
+    pa = mk()
+    g = torch.Generator().manual_seed(0)
+    pb = mk()
+    grads = [torch.randn(*sh, generator=g).to(dev) * 1e-3 for sh in shapes]
+    oa, _ = T.make_optimizer(pa, lr=1e-3, capturable=True)
+    ob, _ = T.make_optimizer(pb, lr=1e-3, capturable=True)
+    sc = T.LossScaler(init_scale=2.0 ** 10, growth_interval=2)
+    for it in range(2):
+        for p, q, gr in zip(pa, pb, grads):
+            p.grad, q.grad = gr.clone(), gr * 2.0 ** 10  # what backward of loss * scale leaves
+        oa.step()
+        ob.step(scaler=sc)
+        assert all(torch.equal(p, q) for p, q in zip(pa, pb)), "scaled step differs from the plain one (iteration %d)" % it
+    assert sc.get_scale() == 2.0 ** 11 and int(sc.skipped) == 0  # two clean steps at growth_interval 2
+    assert float(ob.state[pb[0]]["step"]) == 2.0
+    before = [q.detach().clone() for q in pb]
+    m_before = [ob.state[q]["exp_avg"].clone() for q in pb]
+    for q, gr in zip(pb, grads):
+        q.grad = gr * 2.0 ** 11
+    pb[4].grad[1, 77] = float("inf")
+    ob.step(scaler=sc)
+    assert all(torch.equal(a, q) for a, q in zip(before, pb)) and all(torch.equal(a, ob.state[q]["exp_avg"]) for a, q in zip(m_before, pb))
+    assert sc.get_scale() == 2.0 ** 10 and int(sc.skipped) == 1 and float(ob.state[pb[0]]["step"]) == 2.0 and int(sc.found) == 0
+    pb[4].grad[1, 77] = float("nan")
+    ob.step(scaler=sc)
+    assert sc.get_scale() == 2.0 ** 9 and int(sc.skipped) == 2
+    sd = sc.state_dict()
+    sc2 = T.LossScaler(device=dev)
+    sc2.load_state_dict(sd)
+    assert sc2.get_scale() == 2.0 ** 9
+
+
+@pytest.mark.gpu
+def test_fp16_training_with_loss_scaling_follows_the_fp32_gradients_and_replays_from_a_graph():
+    """precision "f16" in train mode (VERDICT r04 missing #4): fp16 GEMM operands / activations, fp32 master weights, the loss scaled by training.LossScaler.
+    (a) the unscaled gradients are as close to the fp32 step's as the bf16 step's are (a structural error would not be); (b) the captured iteration
+    (GraphedTrainStep(scaler=...)) lowers the loss over a few replays without a skipped step and keeps its scale on the device."""
+    from conftest import synthetic_sd
+    from keypointfusion_amd.model.model import KPFusion
+    from keypointfusion_amd.parallel import live_parameters
+    net, dev, B = "KPFusion-convnext-tiny", torch.device("cuda:0"), 4
+    b = {k: torch.from_numpy(v).to(dev) for k, v in synthetic_batch(B, 128, seed=13).items()}
+    g = torch.Generator().manual_seed(3)
+    b["uvd_gt"], b["xyz_gt"] = (torch.rand(B, 21, 3, generator=g) * 1.2 - 0.6).to(dev), (torch.rand(B, 21, 3, generator=g) * 1.2 - 0.6).to(dev)
+
+    class Loader:
+        img_size, flip = 128, 1
+
+    def loss_of(m, bt):
+        r, s, _ = m(bt["img_rgb"], bt["img"], bt["pcl"], Loader(), bt["center"], bt["M"], bt["cube"], bt["cam_para"], 0.8)
+        return T.kpfusion_loss(r, s, bt["img"], bt["uvd_gt"], bt["xyz_gt"], epoch=0)[0]
+
+    def grads(prec, scale):
+        m = KPFusion(net, "", 21, "dexycb", "")
+        m.load_state_dict(synthetic_sd(net), strict=True)
+        m = m.to(dev).train()
+        m.train_dropout, m.precision = 0.0, prec
+        loss = loss_of(m, b)
+        (loss * scale).backward()
+        return float(loss), {n: p.grad.detach().float() / scale for n, p in m.named_parameters() if p.grad is not None}
+
+    l32, g32 = grads("f32", 1.0)
+    lb, gb = grads("bf16", 1.0)
+    lh, gh = grads("f16", 2.0 ** 12)
+    assert set(gh) == set(g32) and all(bool(torch.isfinite(v).all()) for v in gh.values())
+    nrm = lambda d: torch.stack([v.norm() for v in d.values()])
+    dist = lambda d: float(torch.stack([(d[k] - g32[k]).norm() for k in g32]).norm() / nrm(g32).norm())
+    print("gradient distance from the fp32 step: bf16 %.3e, f16 (loss x 2^12) %.3e; losses %.6f / %.6f / %.6f" % (dist(gb), dist(gh), l32, lb, lh))
+    assert abs(lh - l32) < 2e-2 * abs(l32) and dist(gh) < max(1.5 * dist(gb), 0.05)
+
+    m = KPFusion(net, "", 21, "dexycb", "")
+    m.load_state_dict(synthetic_sd(net), strict=True)
+    m = m.to(dev).train()
+    m.precision = "f16"
+    live = live_parameters(m)
+    opt, _ = T.make_optimizer(live, lr=1e-4, capturable=True)
+    sc = T.LossScaler(init_scale=2.0 ** 12, growth_interval=4)
+    step = T.GraphedTrainStep(m, opt, loss_of, b, scaler=sc)
+    losses = [float(step(b)) for _ in range(8)]
+    assert all(math.isfinite(v) for v in losses) and losses[-1] < losses[0], losses
+    assert int(sc.skipped) == 0 and sc.get_scale() >= 2.0 ** 12  # (clean steps: the scale only grew)
