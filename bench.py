@@ -69,8 +69,9 @@ WORKLOADS = {
 
 
 # committed PMC traffic figures (tools/profile_round.sh -> tools/collect_traffic.py), per workload; quoted only for the stated batch
-TRAFFIC_FILES = {"backbones256": "r05_traffic.json", "cnb512_f16": "r05_traffic_cnb512.json", "full128_bf16": "r05_traffic_full128_bf16.json",
-                 "train128_bf16": "r05_traffic_train128_bf16.json"}
+TRAFFIC_FILES = {"backbones256": "r05_traffic.json", "cnb512_f16": "r05_traffic_cnb512.json", "full128_bf16": "r05_traffic_full128_bf16.json"}
+NO_TRAFFIC_REASON = {"train128_bf16": "rocprofv3 --pmc does not complete on the training iteration on this pool (segmentation fault in the FETCH_SIZE pass, no return from "
+                                      "the WRITE_SIZE pass within 40 min: tools/profile_round.sh, round 5)"}
 
 
 def under_profiler():
@@ -351,7 +352,7 @@ def main():
         all_fl = sum(v[2] for v in per.values())
         all_ms = sum(v[1] for v in per.values())
         ach = fl / (t_ms * 1e-3) / 1e12
-        traffic, tsrc, trej = None, None, None
+        traffic, tsrc, trej = None, None, NO_TRAFFIC_REASON.get(args.workload)
         tpath = os.path.join(ROOT, "profiles", traffic_file) if traffic_file else None
         if tpath and B == B0 and os.path.exists(tpath):
             tj = json.load(open(tpath))

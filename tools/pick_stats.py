@@ -1,7 +1,7 @@
 """Copy the rocprofv3 kernel_stats.csv of the process that ran the expected kernel (never `head -1` of several per-process files).
 usage: pick_stats.py <rocprof-output-dir> <kernel-substring> <out.csv> [bench-log]
 With a bench log (the JSON line the profiled command printed) the call count is checked as well: eager --serial-streams runs issue
-launches_per_step x (steps + warmup + 2 instrumented passes) launches of the dominant kernel."""
+launches_per_step x (steps + warmup + 2 instrumented passes [+ 24 single-batch forwards of the full-model eval workloads]) launches of the dominant kernel."""
 import csv, glob, json, shutil, sys
 
 
@@ -32,7 +32,8 @@ if log:
         sys.exit("pick_stats: no JSON line in %s" % log)
     roof = rec["roofline"]
     if sub in roof["kernel"] and "eager" in rec.get("launch", ""):
-        want = int(roof["launches_per_step"]) * (rec["steps"] + rec["warmup"] + 2)
+        # (full-model eval workloads also time one batch at a time: 3 + 20 + 1 more forwards, bench.py `single_batch_latency`)
+        want = int(roof["launches_per_step"]) * (rec["steps"] + rec["warmup"] + 2 + (24 if rec.get("single_batch_latency") else 0))
         if calls != want:
             sys.exit("pick_stats: %s has %d launches of %s, the command issued %d" % (f, calls, sub, want))
 shutil.copy(f, out)
