@@ -1190,9 +1190,11 @@ extern "C" int kpf_bmm_small_k_dx(const float* A, const float* dOut, float* dX, 
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 constexpr int BMM_J = 24;  // accumulator rows held per thread (J <= 24)
-// grid (C / 32, B), 256 threads = 8 channel quads x 32 row lanes; thread (q, pl) adds rows p = pl, pl + 32, ... for all J outputs of its quad
-__global__ __launch_bounds__(256) void bmm21_fwd_kernel(const float* __restrict__ A, const float* __restrict__ X, float* __restrict__ out, int J, int P, int C) {
-  __shared__ float red[4][BMM_J][32];
+// grid (C / 32, B), 1024 threads = 8 channel quads x 128 row lanes; thread (q, pl) adds rows p = pl, pl + 128, ... for all J outputs of its quad (the loop is a
+// chain of dependent row loads: 8 trips at 1024 threads, 43 -> ~12 us against 32 trips at 256)
+constexpr int BMM_NT = 1024, BMM_PL = BMM_NT / 8, BMM_NW = BMM_NT / 64;
+__global__ __launch_bounds__(BMM_NT) void bmm21_fwd_kernel(const float* __restrict__ A, const float* __restrict__ X, float* __restrict__ out, int J, int P, int C) {
+  __shared__ float red[BMM_NW][BMM_J][32];
   const int b = blockIdx.y, c0 = blockIdx.x * 32;
   const int q = threadIdx.x & 7, pl = threadIdx.x >> 3;
   const float* Ab = A + (long)b * J * P;
@@ -1201,17 +1203,19 @@ __global__ __launch_bounds__(256) void bmm21_fwd_kernel(const float* __restrict_
 #pragma unroll
   for (int j = 0; j < BMM_J; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const bool cv = c0 + 4 * q < C;  // (C % 4 == 0: a quad is inside or outside)
-  for (int p = pl; p < P; p += 32) {
+  // branch-free inner loop: the row index is clamped (accumulators beyond J collect a copy of row J - 1 and are never stored) — a guarded load per
+  // joint compiled into a chain of 24 branches, each exposing its load's latency: 175 us per call where this form takes ~10
+  for (int p = pl; p < P; p += BMM_PL) {
     const f32x4 x = cv ? *reinterpret_cast<const f32x4*>(Xb + (long)p * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+    float av[BMM_J];
+#pragma unroll
+    for (int j = 0; j < BMM_J; ++j) av[j] = Ab[(j < J ? j : J - 1) * P + p];
 #pragma unroll
     for (int j = 0; j < BMM_J; ++j)
-      if (j < J) {
-        const float a = Ab[j * P + p];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(a, x[e], acc[j][e]);
-      }
+      for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(av[j], x[e], acc[j][e]);
   }
-  // the 8 row lanes of a wave (lane bits 3..5), then the 4 waves through LDS, in a fixed order
+  // the 8 row lanes of a wave (lane bits 3..5), then the 16 waves through LDS, in a fixed order
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int j = 0; j < BMM_J; ++j)
@@ -1227,9 +1231,12 @@ __global__ __launch_bounds__(256) void bmm21_fwd_kernel(const float* __restrict_
       if (lane < 8) *reinterpret_cast<f32x4*>(&red[wave][j][4 * lane]) = acc[j];
     }
   __syncthreads();
-  for (int i = threadIdx.x; i < J * 32; i += 256) {
+  for (int i = threadIdx.x; i < J * 32; i += BMM_NT) {
     const int j = i >> 5, c = i & 31;
-    if (c0 + c < C) out[((long)b * J + j) * C + c0 + c] = (red[0][j][c] + red[1][j][c]) + (red[2][j][c] + red[3][j][c]);
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < BMM_NW; w += 4) sum += (red[w][j][c] + red[w + 1][j][c]) + (red[w + 2][j][c] + red[w + 3][j][c]);
+    if (c0 + c < C) out[((long)b * J + j) * C + c0 + c] = sum;
   }
 }
 // grid (ceil(P / 256), B), 256 threads: thread = one row p of X[b]; dOut[b] ([J][C]) in LDS, the row streamed once in float4 pieces
@@ -1247,11 +1254,10 @@ __global__ __launch_bounds__(256) void bmm21_da_kernel(const float* __restrict__
   for (int c = 0; c < C; c += 4) {
     const f32x4 x = *reinterpret_cast<const f32x4*>(xr + c);
 #pragma unroll
-    for (int j = 0; j < BMM_J; ++j)
-      if (j < J) {
-        const f32x4 d = *reinterpret_cast<const f32x4*>(sd + j * C + c);  // (same address across the wave: an LDS broadcast)
-        acc[j] = fmaf(x[3], d[3], fmaf(x[2], d[2], fmaf(x[1], d[1], fmaf(x[0], d[0], acc[j]))));
-      }
+    for (int j = 0; j < BMM_J; ++j) {  // (row index clamped instead of a guard per joint: rows beyond J repeat row J - 1 and are not stored)
+      const f32x4 d = *reinterpret_cast<const f32x4*>(sd + (j < J ? j : J - 1) * C + c);  // (same address across the wave: an LDS broadcast)
+      acc[j] = fmaf(x[3], d[3], fmaf(x[2], d[2], fmaf(x[1], d[1], fmaf(x[0], d[0], acc[j]))));
+    }
   }
 #pragma unroll
   for (int j = 0; j < BMM_J; ++j)
@@ -1261,7 +1267,7 @@ __global__ __launch_bounds__(256) void bmm21_da_kernel(const float* __restrict__
 
 extern "C" int kpf_bmm_small_k_fwd(const float* A, const float* X, float* out, int B, int J, int P, int C, void* stream) {
   KPF_REQUIRE(A && X && out && B > 0 && J > 0 && J <= BMM_J && P > 0 && C > 0 && C % 4 == 0 && kpf_aligned16(X), "kpf_bmm_small_k_fwd: bad arguments (J <= 24, C %% 4 == 0)");
-  hipLaunchKernelGGL(bmm21_fwd_kernel, dim3((C + 31) / 32, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), A, X, out, J, P, C);
+  hipLaunchKernelGGL(bmm21_fwd_kernel, dim3((C + 31) / 32, B), dim3(BMM_NT), 0, reinterpret_cast<hipStream_t>(stream), A, X, out, J, P, C);
   return kpf_check_launch("kpf_bmm_small_k_fwd");
 }
 
