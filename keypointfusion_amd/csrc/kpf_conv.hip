@@ -85,18 +85,8 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return fmaxf(x, 0.f) - fabsf(q);
 }
 
-// GELU for 16-bit outputs: x * sigmoid(x (c1 + c3 x^2 + c5 x^4)), a minimax fit of x Phi(x) with |error| <= 2.6e-5 ABSOLUTE over the whole real line
-// (tools/gelu_fit.py), in 9 VALU operations (2 transcendental) where the fp32-accurate form above takes 16 — on a K = 512 layer the GELU of a
-// 256 x 256 tile is a fifth of the tile's time.  What the error means: the activations are stored in 16 bits and then summed by pwconv2, so it is the
-// ABSOLUTE error of a hidden value that reaches the output; 2.6e-5 is a tenth of the rounding of an O(1) f16 value (2.4e-4) and a 75th of a bf16 one.
-// In the negative tail, where |GELU| itself drops below 1e-3, the RELATIVE error of the fit reaches 15 % — of values that small; the per-operation test
-// bounds relative error + this absolute term.  fp32 storage always uses gelu_erf.
-__device__ __forceinline__ float gelu_h16(float x) {
-  const float x2 = x * x;
-  const float p = x * fmaf(x2, fmaf(x2, -7.03033577e-04f, 7.40112920e-02f), 1.59501577f);
-  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * p);
-  return x * __builtin_amdgcn_rcpf(1.0f + e);
-}
+// GELU for 16-bit outputs: kpf_gelu_h16 (kpf_common.h)
+__device__ __forceinline__ float gelu_h16(float x) { return kpf_gelu_h16(x); }
 enum { ARITH_F32 = 0, ARITH_SPLIT = 1, ARITH_SPLIT_W = 2, ARITH_BF16 = 3, ARITH_F16 = 4 };
 // the GELU every epilogue of one arithmetic uses (all tile shapes of a storage type must agree bit for bit: a sample's result must not depend on
 // which kernel its batch size selects)

@@ -418,12 +418,7 @@ struct Mlp16Args {
   int dbg;           // tuning aid (KPF_MLP16_DBG): 1 = no GELU, 2 = no epilogue stores, 4 = no weight DMA / waits (garbage weights)
 };
 
-__device__ __forceinline__ float gelu_h16m(float x) {  // x * sigmoid(x (c1 + c3 x^2 + c5 x^4)): |error| <= 2.6e-5 (kpf_conv.hip gelu_h16, tools/gelu_fit.py)
-  const float x2 = x * x;
-  const float p = x * fmaf(x2, fmaf(x2, -7.03033577e-04f, 7.40112920e-02f), 1.59501577f);
-  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * p);
-  return x * __builtin_amdgcn_rcpf(1.0f + e);
-}
+__device__ __forceinline__ float gelu_h16m(float x) { return kpf_gelu_h16(x); }  // (kpf_common.h: one definition for every 16-bit kernel)
 
 template <int C, int PT, int R, bool BF, int WPS = 2, int NW = 4>
 __global__ __launch_bounds__(64 * NW, WPS) void convnext_mlp_h16_kernel(const Mlp16Args a) {

@@ -107,6 +107,35 @@ def test_conv2d_h16_is_the_fp32_conv_of_the_rounded_operands(case, prec):
 
 
 @pytest.mark.parametrize("prec", ["bf16", "f16"])
+@pytest.mark.parametrize("M,N,K", [(4096, 2048, 512), (300, 384, 96), (65536, 2048, 512)])
+def test_gelu_of_the_16bit_path_at_large_activations(M, N, K, prec):
+    """The 9-operation GELU of the 16-bit kernels (csrc/kpf_common.h kpf_gelu_h16) far outside the range its polynomial was fitted on.  Until round 5 the
+    polynomial's argument was not clamped: beyond |x| = 11.1 its x^4 term flips the exponent's sign and GELU(12) came out as 0, GELU(-12) as -12 — silent
+    garbage for the outlier activations a trained ConvNeXt's hidden layers do produce (synthetic weights never left |x| < 6, so no test saw it).  Pre-activations
+    here have a standard deviation of ~10 (|x| up to ~50) and go through every tile family the dispatcher picks for these shapes (two-stage 128 x 128, the 32 x 64
+    default, the eight-phase persistent kernel); same bound as the unit-range test: output rounding + 3.5e-5 absolute."""
+    from keypointfusion_amd import lib as L
+    from keypointfusion_amd.engine import Act, PackedConv
+    from keypointfusion_amd.engine16 import DTYPES, Packed16, conv16
+    dev = _dev()
+    tdt, eps = PREC[prec]
+    kdt = DTYPES[prec][1]
+    g = torch.Generator().manual_seed(M + N)
+    x = (torch.randn(M, K, generator=g) * 10.0).to(tdt)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(tdt)
+    bias = torch.randn(N, generator=g)
+    pre = x.double() @ w.double().t() + bias.double()
+    assert float(pre.abs().max()) > 30.0 and float((pre.abs() > 11.1).double().mean()) > 0.1  # the regime the old form got wrong
+    ref = F.gelu(pre)
+    o = conv16(Packed16(PackedConv(w.float().view(N, K, 1, 1), bias, dev), tdt), Act(x.view(-1).to(dev), 1, 1, M, K), kdt, flags=L.KPF_ACT_GELU)
+    got = o.buf.view(M, N).float().cpu().double()
+    assert bool(torch.isfinite(got).all())
+    bad = (got - ref).abs() - (1.3 * 1.01 * eps * ref.abs() + 3.5e-5)
+    assert float(bad.max()) <= 0, (prec, float(bad.max()), float(got[pre > 12].min()), float(got[pre < -12].abs().max()))
+    assert float(got[pre < -12].abs().max()) < 1e-6 and float((got[pre > 12] / pre[pre > 12]).min()) > 0.99
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
 @pytest.mark.parametrize("shape", [(2, 16, 16, 96), (1, 32, 32, 128), (2, 16, 16, 192), (1, 8, 8, 384), (1, 4, 4, 768), (1, 16, 16, 256), (1, 8, 8, 1024)])
 def test_dwconv7_ln_and_layernorm_h16(shape, prec):
     from keypointfusion_amd import lib as L
