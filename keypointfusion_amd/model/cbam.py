@@ -19,8 +19,10 @@ class CBAM(SpecModule):
 
     def forward(self, x):
         self._require_gpu(x)
-        if self.training:
-            raise NotImplementedError("keypointfusion_amd CBAM implements the inference forward: call .eval()")
+        if self.training:  # autograd-connected outputs on this module's Parameters (keypointfusion_amd/heads_train.py: convolutions / Linears on the HIP GEMM)
+            from ..heads_train import cbam_train_forward
+            with torch.cuda.device(x.device):
+                return cbam_train_forward(self, x)
         from ..engine import nchw_to_nhwc, nhwc_to_nchw
         from ..heads import CbamPlan
         plan = self._plan(x.device, lambda sd, dev: CbamPlan(sd, dev))

@@ -19,8 +19,12 @@ class PoseNet(SpecModule):
 
     def forward(self, img):
         self._require_gpu(img)
-        if self.training:
-            raise NotImplementedError("keypointfusion_amd PoseNet implements the inference forward: call .eval()")
+        if self.training:  # autograd-connected outputs on this module's Parameters (keypointfusion_amd/heads_train.py: convolutions / Linears on the HIP GEMM)
+            if img.shape[-1] % 64 or img.shape[-2] % 64:
+                raise RuntimeError("PoseNet needs H and W divisible by 64 (stride-4 stem + 4 pooling levels), got %s" % (tuple(img.shape),))
+            from ..heads_train import posenet_train_forward
+            with torch.cuda.device(img.device):
+                return posenet_train_forward(self, img)
         if img.shape[-1] % 64 or img.shape[-2] % 64:
             raise RuntimeError("PoseNet needs H and W divisible by 64 (stride-4 stem + 4 pooling levels), got %s" % (tuple(img.shape),))
         from ..engine import nhwc_to_nchw

@@ -73,8 +73,10 @@ class mano_regHead(SpecModule):
 
     def forward(self, features):
         self._require_gpu(features)
-        if self.training:
-            raise NotImplementedError("keypointfusion_amd mano_regHead implements the inference forward: call .eval()")
+        if self.training:  # autograd-connected outputs on this module's Parameters (keypointfusion_amd/heads_train.py: convolutions / Linears on the HIP GEMM)
+            from ..heads_train import mano_head_train_forward
+            with torch.cuda.device(features.device):
+                return mano_head_train_forward(self, features)
         from ..heads import ManoHeadPlan
         plan = self._plan(features.device, lambda sd, dev: ManoHeadPlan(sd, dev))
         with torch.cuda.device(features.device):
