@@ -168,6 +168,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial-streams", action="store_true", help="issue both backbones on one stream (per-kernel profiling: rocprofv3 "
                     "durations of overlapped kernels are otherwise shared-GPU durations)")
+    ap.add_argument("--one-stream-graph", action="store_true", help="eval workloads: capture both backbones on ONE stream (the graph stays on; a single-stream "
+                    "graph replays on the runtime's batched path, a forked one node by node)")
     ap.add_argument("--no-graph", action="store_true", help="issue the launches of a step from Python instead of replaying the captured "
                     "hipGraph (the default; same device time, but the step then depends on the host keeping up)")
     ap.add_argument("--per-launch", default="", help="write a per-launch table of the MFMA kernels to this file")
@@ -306,7 +308,7 @@ def main():
         pipe[0] = None
         del pending[:]
         if not train:
-            model._plan(dev).serial_streams = bool(args.serial_streams)
+            model._plan(dev).serial_streams = bool(args.serial_streams or args.one_stream_graph)
 
     def timed(K, W):
         """W untimed steps, then exactly K steps between barrier + synchronize pairs; returns (seconds, host issue seconds)."""
@@ -335,7 +337,7 @@ def main():
                 recs = E.PROFILE
         finally:
             E.PROFILE = None
-            plan.serial_streams = bool(args.serial_streams)
+            plan.serial_streams = bool(args.serial_streams or args.one_stream_graph)
             graph_on[0] = g
         return recs
 
