@@ -169,6 +169,17 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: LDS-DMA destinations (M0) become scalar arithmetic
   const int wm = wave % WM, wn = wave / WM;
   KPF_STAMP(0);
+  if constexpr (ARITH == ARITH_F32 && NS == 2) {
+    // Start skew between the two workgroups that share a CU (a.dbg = microseconds, 0 = off): launched together and equally long, they run
+    // their main loops together (each at half the matrix pipe's rate) and their epilogues together (the pipe idle).  The workgroup in the odd
+    // slot of a CU sleeps before its first tile; equal tile times keep the offset through the following rounds, and one workgroup's
+    // prologue / epilogue then lies under the other's MFMAs.
+    if (a.dbg > 0 && (int)blockIdx.x < 512 && blockIdx.y == 0) {
+      const unsigned tg = __builtin_amdgcn_s_getreg(4 | (16 << 6) | (3 << 11));  // HW_ID.TG_ID: this workgroup's slot in its CU
+      if (tg & 1)
+        for (int i = 0; i < a.dbg; ++i) __builtin_amdgcn_s_sleep(32);  // ~2048 clocks
+    }
+  }
 
   // XCD-aware bijective remap: blocks b, b+8, b+16.. share an XCD -> give each XCD a contiguous range of logical tiles.
   int bid = blockIdx.x;
@@ -913,6 +924,11 @@ int launch_cfg(ConvArgs& a, bool is1x1, hipStream_t st) {
   const int tilesM = (a.M + BM - 1) / BM;
   a.tilesN = (a.N + BN - 1) / BN;
   a.nblk = tilesM * a.tilesN;
+  // start skew of co-resident workgroups (igemm_body), in units of 2048 clocks: a fifth of one tile's matrix-pipe time (BM * BN * Kp / 128 clocks), at most 8;
+  // KPF_STAGGER overrides the cap (0 = off).  Short tiles get none.
+  static const int stagger = []() { const char* e = getenv("KPF_STAGGER"); return e ? atoi(e) : 8; }();
+  const long skew = (long)BM * BN * a.Kp / (128L * 5 * 2048);
+  a.dbg = a.nblk >= 512 ? (int)(skew < stagger ? skew : stagger) : 0;
   if (a.flags & KPF_IN_SPLIT) return launch_arith<TM, TN, WM, WN, ARITH_SPLIT, NS_SPLIT>(a, is1x1, st);
   if (a.flags & KPF_W_SPLIT) return launch_arith<TM, TN, WM, WN, ARITH_SPLIT_W, NS_SPLIT>(a, is1x1, st);
   return launch_arith<TM, TN, WM, WN, ARITH_F32, NS_SPLIT == 1 ? 2 : 2>(a, is1x1, st);
