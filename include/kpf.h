@@ -43,6 +43,10 @@ extern "C" {
 #define KPF_OUT_NCHW 32u       /* store out[b][n][oy][ox] (dense), ignoring out_ld/out_coff */
 #define KPF_ACT_GELU_SAVE 2048u /* with KPF_ACT_GELU (ABI 13): also store the pre-activation acc + bias to the buffer passed in the `res` slot (res_ld / res_coff describe
                                   it; no residual is read) and use the exact erf GELU — the forward of a training Linear + GELU in one launch */
+#define KPF_PRO_LN 4096u       /* kpf_conv2d_h16 with KPF_ACT_GELU (ABI 15): the LayerNorm in front of the layer (convNeXT/convnext.py:42-44, pwconv1(norm(x))) is folded
+                                  into the GEMM: `in` is the un-normalised tensor, `w` holds W diag(ln_w), `bias` W ln_b + b, pro_shift s[n] = sum_k w[n][k] (of the
+                                  16-bit weights, in fp32) and pro_scale the (mean, rstd) pair of every pixel (kpf_ln_stats_merge);
+                                  out = gelu(rstd * (acc - mean * s[n]) + bias[n]).  Layers gemm16_8ph_kernel covers only (kpf_conv2d_h16_uses_8ph) */
 #define KPF_RES_GELU_GRAD 1024u /* with KPF_RES_ADD (ABI 13): y = (acc + bias) * gelu'(res) instead of the sum — the data gradient of Linear(gelu(z)) towards z
                                   in the GEMM's epilogue, res = z (training step: pwconv2 / output.dense backward; dense 1x1 only) */
 
@@ -140,6 +144,9 @@ int kpf_dwconv7_stats_h16(const void* x, const float* w_dw, const float* b_dw, v
 int kpf_dwconv7_stats_supported(int H, int W, int C);
 long kpf_dwconv7_stats_floats(int B, int H, int W, int C);
 int kpf_ln_apply_stats_h16(void* y, const float* stats, const float* ln_w, const float* ln_b, long rows, int C, float eps, int dtype, void* stream);
+/* mean_rstd[pixel] = (mean, 1 / sqrt(var + eps)) merged from the chunk statistics of kpf_dwconv7_stats_h16 exactly as kpf_ln_apply_stats_h16 merges them:
+ * the operand statistics of a kpf_conv2d_h16 launch with KPF_PRO_LN (the nn.LayerNorm of convNeXT/convnext.py:42 folded into pwconv1, ABI 15). */
+int kpf_ln_stats_merge(const float* stats, float* mean_rstd, long rows, int C, float eps, void* stream);
 
 /*
  * LayerNorm over the channel dimension of `rows` pixels (biased variance, (x-u)/sqrt(var+eps)*w+b).
@@ -284,6 +291,9 @@ int kpf_conv2d_h16(const kpf_conv_desc* desc, const void* in, const void* w, con
 /* 1 when kpf_conv2d_h16 runs `d` on the eight-phase 256 x 256 kernel (gemm16_8ph_kernel: dense 1x1, K % 128 == 0, N % 256 == 0, at least 224 tiles), 0 when
  * on igemm_h16_kernel — for callers that label per-kernel measurements (bench.py's roofline); has_prologue: pro_scale != NULL. */
 int kpf_conv2d_h16_uses_8ph(const kpf_conv_desc* d, int has_prologue);
+/* 1 when kpf_conv2d_h16 accepts `d` with KPF_PRO_LN (ABI 15): GELU epilogue on a dense 1x1 layer with Cin == Kp, Kp % 128 == 0, N % 256 == 0 — a rule over
+ * the layer's shape, never over its batch (the arithmetic of a sample must not depend on the size of its batch). */
+int kpf_conv2d_h16_ln_fold_supported(const kpf_conv_desc* d);
 
 /* kpf_dwconv7_ln_f32 with 16-bit activations in and out (fp32 taps, fp32 accumulation and LayerNorm statistics). */
 int kpf_dwconv7_ln_h16(const void* x, const float* w_dw, const float* b_dw, const float* ln_w, const float* ln_b, void* y, int B,
@@ -606,7 +616,7 @@ int kpf_conv_num_tile_cfgs(void);
 const char* kpf_last_error(void);
 /* Library/ABI version, bumped when a signature or the meaning of an argument changes (KPF_ABI_VERSION is what this header
  * describes; the Python binding refuses a library that reports another). */
-#define KPF_ABI_VERSION 14
+#define KPF_ABI_VERSION 15
 int kpf_abi_version(void);
 
 #ifdef __cplusplus

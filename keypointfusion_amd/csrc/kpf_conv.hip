@@ -981,9 +981,15 @@ template <int V> using ic = std::integral_constant<int, V>;
 // PERSIST (linear / GELU epilogues, M % 256 == 0): one workgroup per CU walks tiles id, id + grid, ...; the first two K tiles of the NEXT tile are
 // DMA'd into the (idle) K buffers BEFORE the epilogue of the current one, which stages through the 32 KB beyond them — the prologue latency of a tile
 // (2-3 us of a 27-us tile at K = 512: profiles/r04_g8_ablation.txt) and the workgroup launch disappear behind the GELU and the stores.
-template <int EPI, int ARITH, bool PERSIST>
+// LNF (KPF_PRO_LN, GELU epilogue): the operand is the RAW output x of the depthwise stencil and the LayerNorm in front of this layer
+// (convNeXT/convnext.py:42-44: pwconv1(norm(x))) is folded into the GEMM algebraically —
+//     W (gamma * (x - mean_m) * rstd_m + beta) + b  =  rstd_m * (W' x - mean_m * s) + b',   W' = W diag(gamma),  s[n] = sum_k W'[n][k],  b' = W beta + b
+// — so the normalisation costs two fused multiply-adds per accumulator in the epilogue instead of a pass over the tensor: a.w holds W', a.bias b', a.pt s and
+// a.ps the per-row (mean, rstd) pairs (kpf_ln_stats_merge).  The eight pairs of a lane's rows are requested two K tiles before the main loop ends.
+template <int EPI, int ARITH, bool PERSIST, bool LNF = false>
 __global__ __launch_bounds__(512, 2) void gemm16_8ph_kernel(const ConvArgs a) {
   static_assert(!PERSIST || EPI != EPI_RES, "the persistent form is built for the store-only epilogues");
+  static_assert(!LNF || EPI == EPI_GELU, "the folded LayerNorm exists for pwconv1 (GELU epilogue)");
   using TH = typename std::conditional<ARITH == ARITH_BF16, bf16_t, f16_t>::type;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   char* const LB = reinterpret_cast<char*>(lds);
@@ -1156,6 +1162,27 @@ __global__ __launch_bounds__(512, 2) void gemm16_8ph_kernel(const ConvArgs a) {
     ktile(ic<0>{}, ic<1>{}, ic<1>{}, t);
     ktile(ic<1>{}, ic<1>{}, ic<1>{}, t + 1);
   }
+  // LNF: a lane's accumulators cover pixel fr of eight pixel tiles pt = 4 sm + j, the same eight for the four lanes fg = 0..3 that share fr: lane fg requests
+  // the (mean, rstd) pairs of tiles 2 fg and 2 fg + 1 only (4 registers across the last two K tiles instead of 16) and the epilogue fetches a tile's pair from
+  // lane fr + 16 (pt >> 1) with two ds_bpermute
+  float2 mrq[2];
+  if constexpr (LNF) {
+    const float2* const mr = reinterpret_cast<const float2*>(a.ps);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int pt = 2 * (lane >> 4) + q;
+      const int m = m0 + wr * 128 + (pt >> 2) * 64 + (pt & 3) * 16 + (lane & 15);
+      mrq[q] = mr[m < a.M ? m : a.M - 1];
+    }
+  }
+  auto row_stats = [&](int pt) -> float2 {  // (pt: compile-time after unrolling)
+    if constexpr (LNF) {
+      const int src = (lane & 15) + 16 * (pt >> 1);
+      return make_float2(__shfl(mrq[pt & 1].x, src, 64), __shfl(mrq[pt & 1].y, src, 64));
+    } else {
+      return make_float2(0.f, 0.f);
+    }
+  };
   ktile(ic<0>{}, ic<1>{}, ic<0>{}, t);
   ktile(ic<1>{}, ic<0>{}, ic<0>{}, t + 1);
   if (wr == 0) G8_BAR();  // (both groups have executed the same number of barriers; nobody reads the K buffers any more)
@@ -1170,7 +1197,13 @@ __global__ __launch_bounds__(512, 2) void gemm16_8ph_kernel(const ConvArgs a) {
       const int n = n0 + wc * 64 + sn * 32 + i * 16 + fg * 4;
       bvv[sn][i] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
       gvv[sn][i] = (EPI == EPI_RES && (fl & KPF_RES_GAMMA)) ? *reinterpret_cast<const f32x4*>(a.gamma + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (LNF) gvv[sn][i] = *reinterpret_cast<const f32x4*>(a.pt + n);  // (the layer-scale slot is free in this epilogue: s[n])
     }
+  // y = acc + bias, or with the folded LayerNorm rstd * (acc - mean * s) + b'
+  auto pre_act = [&](float acc_v, float b_v, float s_v, float2 mr_v) -> float {
+    if constexpr (LNF) return fmaf(mr_v.y, fmaf(-mr_v.x, s_v, acc_v), b_v);
+    else return acc_v + b_v;
+  };
   const int cm0 = m0, cn0 = n0;  // the tile being finished
   bool more = false;
   if constexpr (PERSIST) {
@@ -1178,7 +1211,11 @@ __global__ __launch_bounds__(512, 2) void gemm16_8ph_kernel(const ConvArgs a) {
 #pragma unroll
     for (int sn = 0; sn < 2; ++sn)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(bvv[sn][i]));
+      for (int i = 0; i < 2; ++i) {
+        asm volatile("" : "+v"(bvv[sn][i]));
+        if constexpr (LNF) asm volatile("" : "+v"(gvv[sn][i]));
+      }
+    if constexpr (LNF) asm volatile("" : "+v"(mrq[0].x), "+v"(mrq[0].y), "+v"(mrq[1].x), "+v"(mrq[1].y));
     tile += (int)gridDim.x;
     more = tile < a.nblk;
     if (more) {
@@ -1230,7 +1267,8 @@ __global__ __launch_bounds__(512, 2) void gemm16_8ph_kernel(const ConvArgs a) {
 #pragma unroll
     for (int sm = 0; sm < 2; ++sm)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j) {
+        const float2 mrv = row_stats(4 * sm + j);
 #pragma unroll
         for (int sn = 0; sn < 2; ++sn)
 #pragma unroll
@@ -1238,12 +1276,13 @@ __global__ __launch_bounds__(512, 2) void gemm16_8ph_kernel(const ConvArgs a) {
             f32x4 v = acc[sn][i][sm][j];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float y = v[e] + bvv[sn][i][e];
+              const float y = pre_act(v[e], bvv[sn][i][e], gvv[sn][i][e], mrv);
               if (EPI == EPI_GELU) v[e] = (a.dbg & 1) ? y : gelu_of<ARITH>(y);
               else v[e] = (fl & KPF_ACT_RELU) ? fmaxf(y, 0.f) : ((fl & KPF_ACT_LEAKY) ? fmaxf(y, 0.01f * y) : y);
             }
             kpf_st4(stg + (sm * 64 + j * 16 + fr) * RS + sn * 32 + i * 16 + fg * 4, v);
           }
+      }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (own region only: no barrier)
     TH* const ob = reinterpret_cast<TH*>(a.out) + (long)(cm0 + wr * 128) * a.out_ld + a.out_coff + cn0 + wc * 64;
     const int prow = lane >> 3, pch = (lane & 7) * 8;
@@ -1263,7 +1302,8 @@ __global__ __launch_bounds__(512, 2) void gemm16_8ph_kernel(const ConvArgs a) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {  // chunk c = pixel tiles (sm, j) = (c >> 1, 2 (c & 1) + {0, 1})
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
+      for (int jj = 0; jj < 2; ++jj) {
+        const float2 mrv = row_stats(4 * (c >> 1) + 2 * (c & 1) + jj);
 #pragma unroll
         for (int sn = 0; sn < 2; ++sn)
 #pragma unroll
@@ -1271,13 +1311,14 @@ __global__ __launch_bounds__(512, 2) void gemm16_8ph_kernel(const ConvArgs a) {
             f32x4 v = acc[sn][i][c >> 1][2 * (c & 1) + jj];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float y = v[e] + bvv[sn][i][e];
+              const float y = pre_act(v[e], bvv[sn][i][e], gvv[sn][i][e], mrv);
               if (EPI == EPI_GELU) v[e] = gelu_of<ARITH>(y);
               else v[e] = (fl & KPF_ACT_RELU) ? fmaxf(y, 0.f) : ((fl & KPF_ACT_LEAKY) ? fmaxf(y, 0.01f * y) : y);
             }
             const int row = jj * 16 + fr, cidx = sn * 4 + i * 2 + (fg >> 1);
             kpf_st4(reinterpret_cast<TH*>(stg + row * 128 + ((cidx ^ (row & 7)) << 4) + (fg & 1) * 8), v);
           }
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = r * 8 + prow;
@@ -1302,11 +1343,13 @@ int launch_8ph(ConvArgs& a, hipStream_t st) {
   a.nblk = ((a.M + 255) / 256) * a.tilesN;
   static const bool no_persist = getenv("KPF_G8_NO_PERSIST") != nullptr;  // tuning aid
   const bool persist = !res && a.M % 256 == 0 && a.nblk > 256 && !no_persist && !a.dbg;
+  const bool lnf = (a.flags & KPF_PRO_LN) != 0;  // (kpf_conv2d_h16 admits it with the GELU epilogue only)
   void (*kern)(const ConvArgs) = res ? gemm16_8ph_kernel<EPI_RES, ARITH, false>
-                                     : (gelu ? (persist ? gemm16_8ph_kernel<EPI_GELU, ARITH, true> : gemm16_8ph_kernel<EPI_GELU, ARITH, false>)
+                                     : (gelu ? (lnf ? (persist ? gemm16_8ph_kernel<EPI_GELU, ARITH, true, true> : gemm16_8ph_kernel<EPI_GELU, ARITH, false, true>)
+                                                    : (persist ? gemm16_8ph_kernel<EPI_GELU, ARITH, true> : gemm16_8ph_kernel<EPI_GELU, ARITH, false>))
                                              : (persist ? gemm16_8ph_kernel<EPI_LIN, ARITH, true> : gemm16_8ph_kernel<EPI_LIN, ARITH, false>));
-  static std::atomic<bool> lds_opt_in[5][KPF_MAX_DEVICES];
-  if (!kpf_raise_lds_limit(reinterpret_cast<const void*>(kern), lds_opt_in[res ? 4 : (gelu ? 2 : 0) + (persist ? 1 : 0)])) {
+  static std::atomic<bool> lds_opt_in[7][KPF_MAX_DEVICES];
+  if (!kpf_raise_lds_limit(reinterpret_cast<const void*>(kern), lds_opt_in[res ? 4 : (gelu ? (lnf ? 5 : 2) : 0) + (persist ? 1 : 0)])) {
     kpf_set_error("kpf_conv2d_h16: cannot raise the dynamic LDS limit");
     return KPF_ELAUNCH;
   }
@@ -1690,6 +1733,12 @@ extern "C" int kpf_conv2d_h16_uses_8ph(const kpf_conv_desc* d, int has_prologue)
   return d && !no8 && g8_applies(d, has_prologue != 0) && g8_preferred(d) ? 1 : 0;
 }
 
+/* 1 when kpf_conv2d_h16 accepts this descriptor with KPF_PRO_LN (a rule over the layer's shape only, never its batch: which arithmetic a sample gets must not
+   depend on how many samples share its launch) */
+extern "C" int kpf_conv2d_h16_ln_fold_supported(const kpf_conv_desc* d) {
+  return d && (d->flags & KPF_ACT_GELU) && !(d->flags & (KPF_RES_ADD | KPF_ACT_GELU_SAVE | KPF_OUT_NCHW)) && g8_applies(d, false) ? 1 : 0;
+}
+
 extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void* w, const float* bias, const float* pro_scale,
                               const float* pro_shift, const float* gamma, const void* res, void* out, int dtype, void* stream) {
   KPF_REQUIRE(d && in && w && out, "kpf_conv2d_h16: null pointer");
@@ -1709,6 +1758,11 @@ extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void
     KPF_REQUIRE(res && kpf_aligned16(res) && d->res_coff >= 0 && d->res_coff + d->N <= d->res_ld, "kpf_conv2d_h16: bad residual");
   if (fl & KPF_RES_GAMMA) KPF_REQUIRE(gamma && (fl & KPF_RES_ADD), "kpf_conv2d_h16: RES_GAMMA needs gamma and RES_ADD");
   KPF_REQUIRE((pro_scale == nullptr) == (pro_shift == nullptr), "kpf_conv2d_h16: prologue needs both scale and shift");
+  if (fl & KPF_PRO_LN)  // folded LayerNorm: pro_scale = (mean, rstd) per pixel, pro_shift = s[n]; the eight-phase kernel's GELU epilogue only
+    KPF_REQUIRE(pro_scale && pro_shift && bias && (fl & KPF_ACT_GELU) && !(fl & (KPF_RES_ADD | KPF_ACT_GELU_SAVE | KPF_OUT_NCHW)) && g8_applies(d, false) &&
+                    reinterpret_cast<uintptr_t>(pro_scale) % 8 == 0 && kpf_aligned16(pro_shift) && kpf_aligned16(bias),
+                "kpf_conv2d_h16: KPF_PRO_LN needs the row statistics, s[n] and b'[n], the GELU epilogue and a layer gemm16_8ph_kernel covers "
+                "(dense 1x1, Cin == Kp, Kp %% 128 == 0, N %% 256 == 0: ask kpf_conv2d_h16_uses_8ph)");
   KPF_REQUIRE(((fl & KPF_ACT_RELU) != 0) + ((fl & KPF_ACT_GELU) != 0) + ((fl & KPF_ACT_LEAKY) != 0) <= 1, "kpf_conv2d_h16: one activation only");
   KPF_REQUIRE(!((fl & KPF_RES_ADD) && (fl & (KPF_ACT_RELU | KPF_ACT_GELU | KPF_ACT_LEAKY))), "kpf_conv2d_h16: activation before a residual add is not supported");
   KPF_REQUIRE(!(fl & KPF_RELU_AFTER_RES) || (fl & KPF_RES_ADD), "kpf_conv2d_h16: RELU_AFTER_RES needs RES_ADD");
@@ -1781,6 +1835,7 @@ extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void
   // MFMA cluster): +24 % over case 20 on 65536 x 512 x 2048 (841 vs 679 TFLOP/s), 1049 vs 935 on 16384 x 1024 x 4096
   if (plain_res && fast1x1 && a.Kp * 2 >= 2048 && a.M >= 16384 && a.N >= 256 && a.N % 256 == 0) best = 26;
   // Round 4: the eight-phase 256 x 256 kernel (gemm16_8ph_kernel) for every dense 1x1 layer it covers with at least one full round of tiles
+  if (fl & KPF_PRO_LN) return dtype == KPF_DT_BF16 ? launch_8ph<ARITH_BF16>(a, st) : launch_8ph<ARITH_F16>(a, st);  // (no other kernel has that epilogue)
   const bool ok8 = g8_applies(d, pro_scale != nullptr);
   static const bool no8 = getenv("KPF_NO_8PH") != nullptr;  // tuning aid: A/B against the round-3 tile shapes
   if (ok8 && !no8 && g8_preferred(d)) best = 30;

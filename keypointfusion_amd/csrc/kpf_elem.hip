@@ -957,6 +957,24 @@ __global__ __launch_bounds__(256) void ln_apply_stats_kernel(TA* __restrict__ y,
   }
 }
 
+// (mean, rstd) of every pixel from its chunk statistics, in the order ln_apply_stats_kernel merges them (same bits): the form the GEMM behind a folded
+// LayerNorm reads (gemm16_8ph_kernel LNF: eight pairs per lane and tile instead of eight times C/64).  One thread per pixel.
+__global__ __launch_bounds__(256) void ln_stats_merge_kernel(const float* __restrict__ stats, float2* __restrict__ mr, long rows, int C, float eps) {
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= rows) return;
+  const int nchunk = C / DS_CH;
+  const float* sp = stats + p * (2 * nchunk);
+  float mean = 0.f;
+  for (int c = 0; c < nchunk; ++c) mean += sp[2 * c];
+  mean *= 1.0f / (float)nchunk;
+  float m2 = 0.f;
+  for (int c = 0; c < nchunk; ++c) {
+    const float d = sp[2 * c] - mean;
+    m2 += sp[2 * c + 1] + (float)DS_CH * d * d;
+  }
+  mr[p] = make_float2(mean, 1.0f / sqrtf(m2 / (float)C + eps));
+}
+
 inline int grid_for(long total, int block = 256, int cap = 256 * 16) {
   long g = (total + block - 1) / block;
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -1295,6 +1313,15 @@ extern "C" int kpf_dwconv7_stats_h16(const void* x, const float* w_dw, const flo
   if (dtype == KPF_DT_F16) return dwconv7_stats_impl<f16_t>(static_cast<const f16_t*>(x), w_dw, b_dw, static_cast<f16_t*>(y), stats, B, H, W, C, stream);
   kpf_set_error("kpf_dwconv7_stats_h16: dtype must be KPF_DT_BF16 or KPF_DT_F16");
   return KPF_EINVAL;
+}
+
+extern "C" int kpf_ln_stats_merge(const float* stats, float* mean_rstd, long rows, int C, float eps, void* stream) {
+  KPF_REQUIRE(stats && mean_rstd && rows > 0 && C > 0 && C % 64 == 0, "kpf_ln_stats_merge: bad arguments (C %% 64 == 0)");
+  KPF_REQUIRE(reinterpret_cast<uintptr_t>(stats) % 8 == 0 && reinterpret_cast<uintptr_t>(mean_rstd) % 8 == 0, "kpf_ln_stats_merge: unaligned pointer");
+  KPF_REQUIRE((rows + 255) / 256 < (1l << 31), "kpf_ln_stats_merge: too many rows");
+  hipLaunchKernelGGL(ln_stats_merge_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), stats,
+                     reinterpret_cast<float2*>(mean_rstd), rows, C, eps);
+  return kpf_check_launch("kpf_ln_stats_merge");
 }
 
 extern "C" int kpf_ln_apply_stats_h16(void* y, const float* stats, const float* ln_w, const float* ln_b, long rows, int C, float eps, int dtype, void* stream) {

@@ -17,6 +17,7 @@ from .spec import CONVNEXT, parse_net
 DTYPES = {"bf16": (torch.bfloat16, L.KPF_DT_BF16), "f16": (torch.float16, L.KPF_DT_F16)}
 FORCE_UNFUSED_MLP16 = bool(int(__import__("os").environ.get("KPF_UNFUSED_MLP16", "0")))  # A/B switch for tuning
 DW_STATS = bool(int(__import__("os").environ.get("KPF_DW_STATS", "1")))  # depthwise stencil + statistics pair instead of the one-pass dw+LN kernels
+LN_FOLD = bool(int(__import__("os").environ.get("KPF_LN_FOLD", "1")))  # LayerNorm folded into pwconv1's epilogue where the eight-phase GEMM takes the layer (KPF_PRO_LN)
 DW_STATS_MIN_C = int(__import__("os").environ.get("KPF_DW_STATS_MIN_C", "256"))  # (at C = 128 the one-pass wave kernel is still faster: 311 vs 363 us)
 
 
@@ -44,8 +45,9 @@ class Packed16:
         self.w = w.to(tdt).contiguous()
 
 
-def conv16(p16, x, kdt, out=None, flags=0, gamma=None, res=None, out_nchw=None, out2=None):
-    """kpf_conv2d_h16: x / out / res are 16-bit Acts (out_nchw: fp32 NCHW tensor)."""
+def conv16(p16, x, kdt, out=None, flags=0, gamma=None, res=None, out_nchw=None, out2=None, ln=None, probe=False):
+    """kpf_conv2d_h16: x / out / res are 16-bit Acts (out_nchw: fp32 NCHW tensor).  ln = (mean_rstd [pixels][2], s [N], b' [N]): KPF_PRO_LN (p16 holds
+    W diag(ln_w)).  probe: no launch — returns whether the library takes this layer with KPF_PRO_LN (a rule over the layer's shape, not its batch)."""
     lib = L.load()
     pc = p16.pc
     B = x.B
@@ -82,16 +84,22 @@ def conv16(p16, x, kdt, out=None, flags=0, gamma=None, res=None, out_nchw=None, 
         res = out2
     if gamma is not None:
         flags |= L.KPF_RES_GAMMA
+    ps, pt, bias = pc.ps, pc.pt, pc.b
+    if ln is not None:
+        flags |= L.KPF_PRO_LN
+        ps, pt, bias = ln
     d.flags = flags
     d.groups, d.w_gstride = getattr(pc, "groups", 0), getattr(pc, "w_gstride", 0)  # (grouped launch: training.GroupedPack; 0 = one convolution)
     if FORCE_TILE16:
         d.tile_cfg = FORCE_TILE16
+    if probe:
+        return bool(lib.kpf_conv2d_h16_ln_fold_supported(C.byref(d)))
     M = B * OH * OW
     nbytes = 2.0 * (B * IH * IW * pc.Cin + pc.N * pc.K + M * pc.N * (2 if res is not None else 1))
-    name = "gemm16_8ph_kernel" if (PROFILE_LABELS() and lib.kpf_conv2d_h16_uses_8ph(C.byref(d), 1 if pc.ps is not None else 0)) else "igemm_h16_kernel"
+    name = "gemm16_8ph_kernel" if (PROFILE_LABELS() and (ln is not None or lib.kpf_conv2d_h16_uses_8ph(C.byref(d), 1 if pc.ps is not None else 0))) else "igemm_h16_kernel"
     ng = max(1, d.groups)
     _launch(name, pc.flops(M) * ng, nbytes * ng, (M, pc.N, pc.K, pc.KH, pc.KW),
-            lambda: L.check(lib.kpf_conv2d_h16(C.byref(d), _ptr(x.buf), _ptr(p16.w), _ptr(pc.b), _ptr(pc.ps), _ptr(pc.pt), _ptr(gamma),
+            lambda: L.check(lib.kpf_conv2d_h16(C.byref(d), _ptr(x.buf), _ptr(p16.w), _ptr(bias), _ptr(ps), _ptr(pt), _ptr(gamma),
                                                _ptr(res.buf if res is not None else None), _ptr(optr), kdt, _stream()), "kpf_conv2d_h16"))
     return out
 
@@ -130,6 +138,14 @@ class Block16:
         self.bdw, self.lnw, self.lnb, self.gamma = f32(".dwconv.bias"), f32(".norm.weight"), f32(".norm.bias"), f32(".gamma")
         self.pw1 = Packed16(PackedConv(sd[p + ".pwconv1.weight"], sd[p + ".pwconv1.bias"], device), tdt)
         self.pw2 = Packed16(PackedConv(sd[p + ".pwconv2.weight"], sd[p + ".pwconv2.bias"], device), tdt)
+        # LayerNorm folded into pwconv1 (KPF_PRO_LN; used when the statistics come from the stencil and gemm16_8ph_kernel takes the layer):
+        #   W (ln_w * xhat + ln_b) + b = rstd * (W' x - mean * s) + b',   W' = W diag(ln_w) rounded to the storage type, s = its row sums in fp32, b' = W ln_b + b
+        w1 = sd[p + ".pwconv1.weight"].detach().double().reshape(4 * c, c)
+        lnw, lnb = sd[p + ".norm.weight"].detach().double(), sd[p + ".norm.bias"].detach().double()
+        self.pw1f = Packed16(PackedConv((w1 * lnw[None, :]).float().reshape(4 * c, c, 1, 1), None, device), tdt)
+        self.pw1f_s = self.pw1f.w[:, :c].double().sum(1).float().contiguous()
+        self.pw1f_b = (w1 @ lnb + sd[p + ".pwconv1.bias"].detach().double()).float().contiguous().to(device)
+        self.mr = None  # (mean, rstd) per pixel, allocated per shape
         # fused MLP (kpf_convnext_mlp_h16: the 4C-wide hidden tensor never reaches HBM) where the library has it: pwconv2's weight chunk-major
         # [4C/32][C][32] with the hidden index of a 32-block in the order GEMM1's accumulator registers form GEMM2's operand
         self.fused = (not FORCE_UNFUSED_MLP16) and bool(L.load().kpf_convnext_mlp_h16_supported(c))
@@ -143,17 +159,27 @@ class Block16:
 
     def __call__(self, x, y, h, kdt, st=None):
         lib = L.load()
+        fused = self.fused and x.ld == x.C and x.coff == 0 and y.ld == y.C and y.coff == 0
         if st is not None:
             # round 4: LDS-tiled stencil + per-chunk LayerNorm statistics, then the normalisation from them (two launches that together take
             # 0.5-0.65 of the one-pass kernel's time at C >= 256: tools/dw_stats_bench.py)
             L.check(lib.kpf_dwconv7_stats_h16(_ptr(x.buf), _ptr(self.wdw), _ptr(self.bdw), _ptr(y.buf), _ptr(st), x.B, x.H, x.W, x.C, kdt, _stream()),
                     "kpf_dwconv7_stats_h16")
-            L.check(lib.kpf_ln_apply_stats_h16(_ptr(y.buf), _ptr(st), _ptr(self.lnw), _ptr(self.lnb), x.B * x.H * x.W, x.C, 1e-6, kdt, _stream()),
+            rows = x.B * x.H * x.W
+            if LN_FOLD and not fused and conv16(self.pw1f, y, kdt, out=h, flags=L.KPF_ACT_GELU, probe=True):
+                # round 5: no normalisation pass — the statistics are merged to (mean, rstd) per pixel (4 us) and pwconv1's epilogue applies them
+                if self.mr is None or self.mr.numel() != 2 * rows or self.mr.device != x.buf.device:
+                    self.mr = torch.empty(2 * rows, device=x.buf.device, dtype=torch.float32)
+                L.check(lib.kpf_ln_stats_merge(_ptr(st), _ptr(self.mr), rows, x.C, 1e-6, _stream()), "kpf_ln_stats_merge")
+                conv16(self.pw1f, y, kdt, out=h, flags=L.KPF_ACT_GELU, ln=(self.mr, self.pw1f_s, self.pw1f_b))
+                conv16(self.pw2, h, kdt, out=x, gamma=self.gamma, res=x)
+                return x
+            L.check(lib.kpf_ln_apply_stats_h16(_ptr(y.buf), _ptr(st), _ptr(self.lnw), _ptr(self.lnb), rows, x.C, 1e-6, kdt, _stream()),
                     "kpf_ln_apply_stats_h16")
         else:
             L.check(lib.kpf_dwconv7_ln_h16(_ptr(x.buf), _ptr(self.wdw), _ptr(self.bdw), _ptr(self.lnw), _ptr(self.lnb), _ptr(y.buf), x.B, x.H,
                                            x.W, x.C, 1e-6, kdt, _stream()), "kpf_dwconv7_ln_h16")
-        if self.fused and x.ld == x.C and x.coff == 0 and y.ld == y.C and y.coff == 0:
+        if fused:
             M, c = x.B * x.H * x.W, self.c
             _launch("convnext_mlp_h16_kernel", 16.0 * M * c * c, 2.0 * (3 * M * c + 8 * c * c), (M, c, 4 * c, 1, 1),
                     lambda: L.check(L.load().kpf_convnext_mlp_h16(_ptr(y.buf), _ptr(x.buf), _ptr(self.pw1.w), _ptr(self.pw1.pc.b), _ptr(self.w2c), _ptr(self.pw2.pc.b),

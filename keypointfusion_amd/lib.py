@@ -16,13 +16,14 @@ KPF_RES_GAMMA = 8
 KPF_RELU_AFTER_RES = 16
 KPF_RES_GELU_GRAD = 1024
 KPF_ACT_GELU_SAVE = 2048
+KPF_PRO_LN = 4096
 KPF_OUT_NCHW = 32
 KPF_ACT_LEAKY = 64
 KPF_IN_SPLIT = 128
 KPF_OUT_SPLIT = 256
 KPF_W_SPLIT = 512
 KPF_DT_F32, KPF_DT_BF16, KPF_DT_F16 = 0, 1, 2
-ABI_VERSION = 14  # KPF_ABI_VERSION of include/kpf.h: load() refuses a library built from another revision of the interface
+ABI_VERSION = 15  # KPF_ABI_VERSION of include/kpf.h: load() refuses a library built from another revision of the interface
 
 
 class ConvDesc(C.Structure):
@@ -72,6 +73,7 @@ _SIGS = {
     "kpf_xattn_layer_f32": [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P],
     "kpf_conv2d_h16": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P],
     "kpf_conv2d_h16_uses_8ph": [C.POINTER(ConvDesc), C.c_int],
+    "kpf_conv2d_h16_ln_fold_supported": [C.POINTER(ConvDesc)],
     "kpf_dwconv7_ln_h16": [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _P],
     "kpf_layernorm_h16": [_P, C.c_int, _P, _P, _P, C.c_int, C.c_long, C.c_int, C.c_float, _P],
     "kpf_upsample2x_h16": [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P],
@@ -86,6 +88,7 @@ _SIGS = {
     "kpf_dwconv7_stats_h16": [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P],
     "kpf_dwconv7_stats_supported": [C.c_int, C.c_int, C.c_int],
     "kpf_ln_apply_stats_h16": [_P, _P, _P, _P, C.c_long, C.c_int, C.c_float, C.c_int, _P],
+    "kpf_ln_stats_merge": [_P, _P, C.c_long, C.c_int, C.c_float, _P],
     "kpf_cbam_channel_gate_f32": [_P] * 7 + [C.c_int] * 4 + [_P],
     "kpf_cbam_spatial_gate_f32": [_P, _P, _P, C.c_float, C.c_float, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
     "kpf_cbam_apply_f32": [_P] * 5 + [C.c_int] * 3 + [_P],

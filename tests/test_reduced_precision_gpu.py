@@ -408,3 +408,100 @@ def test_convnext_base_512_backbones_properties_and_oracle_subset(prec):
         e = rel(a[2:3], r)
         print("convnext-base 512 %s %s: rel err vs fp32 oracle %.2e" % (prec, name, e))
         assert e < tol, (name, e)
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+@pytest.mark.parametrize("C_,M", [(512, 8192), (512, 16384), (512, 8640), (1024, 4096), (512, 1024)])
+def test_layernorm_folded_into_pwconv1_h16(C_, M, prec):
+    """KPF_PRO_LN (convNeXT/convnext.py:42-44: pwconv1(norm(x)) then GELU): the GEMM multiplies the RAW 16-bit tensor by W diag(ln_w) and its epilogue applies
+    rstd * (acc - mean * s) + (W ln_b + b) — against float64 (a) of the same expression on the same rounded operands (the kernel's arithmetic: output rounding
+    only) and (b) of LayerNorm -> Linear -> GELU itself on the same raw tensor (what the fold may lose: the rounding of W diag(ln_w) to the storage type,
+    a relative 2^-9 / 2^-12 per weight, where the two-pass form rounds the normalised activations instead).  kpf_ln_stats_merge against its definition.
+    One-tile-per-workgroup form (256 tiles), persistent form (512 tiles), ragged last row tile, the 1024-channel stage, and fewer tiles than CUs (the
+    fold is a rule over the layer's shape, so small batches take the same kernel)."""
+    from keypointfusion_amd import lib as L
+    from keypointfusion_amd.engine import Act, PackedConv, _ptr, _stream
+    from keypointfusion_amd.engine16 import DTYPES, Packed16, conv16
+    dev = _dev()
+    lib = L.load()
+    tdt, ulp = PREC[prec]
+    kdt = DTYPES[prec][1]
+    g = torch.Generator().manual_seed(C_ + M)
+    N = 4 * C_
+    x = (torch.randn(M, C_, generator=g) * (torch.rand(M, 1, generator=g) * 2 + 0.5) + torch.randn(M, 1, generator=g)).to(tdt)  # rows of different scale and offset
+    w1 = torch.randn(N, C_, generator=g) / C_ ** 0.5
+    b1 = torch.randn(N, generator=g) * 0.3
+    lw, lb = torch.rand(C_, generator=g) + 0.5, torch.randn(C_, generator=g) * 0.2
+    xd = x.double()
+    # chunk statistics as kpf_dwconv7_stats_h16 defines them: (mean, sum of centred squares) of every 64-channel chunk
+    ch = xd.view(M, C_ // 64, 64)
+    st = torch.stack((ch.mean(-1), ((ch - ch.mean(-1, keepdim=True)) ** 2).sum(-1)), -1).float().contiguous().to(dev)
+    mr = torch.full((M, 2), float("nan"), device=dev)
+    L.check(lib.kpf_ln_stats_merge(_ptr(st), _ptr(mr), M, C_, 1e-6, _stream()), "merge")
+    mean, rstd = xd.mean(-1), 1.0 / torch.sqrt(xd.var(-1, unbiased=False) + 1e-6)
+    assert float((mr[:, 0].cpu().double() - mean).abs().max()) < 1e-5 * float(xd.abs().max())
+    assert float(((mr[:, 1].cpu().double() - rstd).abs() / rstd).max()) < 1e-5
+    p16 = Packed16(PackedConv((w1.double() * lw.double()[None, :]).float().reshape(N, C_, 1, 1), None, dev), tdt)
+    s = p16.w[:, :C_].double().sum(1).float().contiguous()
+    bf = (w1.double() @ lb.double() + b1.double()).float().to(dev)
+    xa = Act(x.to(dev).contiguous().view(-1), 1, 1, M, C_)
+    out = Act(torch.full((M * N,), float("nan"), device=dev, dtype=tdt), 1, 1, M, N)
+    assert conv16(p16, xa, kdt, out=out, flags=L.KPF_ACT_GELU, probe=True)
+    conv16(p16, xa, kdt, out=out, flags=L.KPF_ACT_GELU, ln=(mr, s, bf))
+    got = out.buf.view(M, N).float().cpu().double()
+    assert bool(torch.isfinite(got).all())
+    gelu = lambda v: 0.5 * v * (1 + torch.erf(v / 2 ** 0.5))
+    mrd = mr.cpu().double()
+    same = gelu(mrd[:, 1:2] * (xd @ p16.w[:, :C_].cpu().double().t() - mrd[:, 0:1] * s.cpu().double()[None, :]) + bf.cpu().double()[None, :])
+    scale = float(same.abs().max())
+    assert float((got - same).abs().max()) / scale < 1.2 * ulp, float((got - same).abs().max()) / scale  # fp32 accumulation and epilogue, one output rounding
+    true = gelu(F.layer_norm(xd, (C_,), lw.double(), lb.double(), 1e-6) @ w1.double().t() + b1.double())
+    assert float((got - true).abs().max()) / scale < 3 * ulp, float((got - true).abs().max()) / scale
+    # without the statistics the call is refused, as is a layer the eight-phase kernel does not cover
+    d_bad = Packed16(PackedConv(torch.randn(N + 64, C_, 1, 1, generator=g), None, dev), tdt)
+    assert not conv16(d_bad, xa, kdt, flags=L.KPF_ACT_GELU, probe=True)
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+def test_convnext_block16_with_and_without_the_folded_layernorm(prec):
+    """engine16.Block16 at a ConvNeXt-B stage-3 shape (C = 512, 32 x 32 maps): the schedule with the LayerNorm folded into pwconv1 (stencil + statistics,
+    merge, GEMM with KPF_PRO_LN, pwconv2) against the three-pass one (stencil + statistics, normalisation pass, GEMM) and against float64 — the folded form
+    must not be further from float64 than the three-pass form by more than an output rounding."""
+    from keypointfusion_amd import engine16 as E16, lib as L
+    from keypointfusion_amd.engine import Act
+    dev = _dev()
+    lib = L.load()
+    tdt, ulp = PREC[prec]
+    kdt = E16.DTYPES[prec][1]
+    B, H, W, Cc = 8, 32, 32, 512
+    g = torch.Generator().manual_seed(7)
+    sd = {"b.dwconv.weight": torch.randn(Cc, 1, 7, 7, generator=g) / 7, "b.dwconv.bias": torch.randn(Cc, generator=g) * 0.1,
+          "b.norm.weight": torch.rand(Cc, generator=g) + 0.5, "b.norm.bias": torch.randn(Cc, generator=g) * 0.1,
+          "b.pwconv1.weight": torch.randn(4 * Cc, Cc, generator=g) / Cc ** 0.5, "b.pwconv1.bias": torch.randn(4 * Cc, generator=g) * 0.2,
+          "b.pwconv2.weight": torch.randn(Cc, 4 * Cc, generator=g) / (4 * Cc) ** 0.5, "b.pwconv2.bias": torch.randn(Cc, generator=g) * 0.2,
+          "b.gamma": torch.rand(Cc, generator=g) + 0.5}
+    blk = E16.Block16(sd, "b", dev, tdt)
+    assert not blk.fused
+    x0 = (torch.randn(B, H, W, Cc, generator=g) * 1.5).to(tdt)
+    outs = {}
+    keep = E16.LN_FOLD
+    try:
+        for fold in (True, False):
+            E16.LN_FOLD = fold
+            x = Act(x0.to(dev).contiguous().view(-1), B, H, W, Cc)
+            y, h = E16.empty16(B, H, W, Cc, dev, tdt), E16.empty16(B, H, W, 4 * Cc, dev, tdt)
+            st = torch.empty(lib.kpf_dwconv7_stats_floats(B, H, W, Cc), device=dev, dtype=torch.float32)
+            blk(x, y, h, kdt, st)
+            outs[fold] = x.buf.view(B, H, W, Cc).float().cpu().double()
+    finally:
+        E16.LN_FOLD = keep
+    xd = x0.double().permute(0, 3, 1, 2)
+    t = F.conv2d(xd, sd["b.dwconv.weight"].double(), sd["b.dwconv.bias"].double(), padding=3, groups=Cc).permute(0, 2, 3, 1)
+    t = F.layer_norm(t, (Cc,), sd["b.norm.weight"].double(), sd["b.norm.bias"].double(), 1e-6)
+    t = t @ sd["b.pwconv1.weight"].double().t() + sd["b.pwconv1.bias"].double()
+    t = 0.5 * t * (1 + torch.erf(t / 2 ** 0.5))
+    ref = x0.double() + sd["b.gamma"].double() * (t @ sd["b.pwconv2.weight"].double().t() + sd["b.pwconv2.bias"].double())
+    scale = float(ref.abs().max())
+    e_fold, e_three = float((outs[True] - ref).abs().max()) / scale, float((outs[False] - ref).abs().max()) / scale
+    assert e_fold < e_three + ulp and e_fold < 6 * ulp, (e_fold, e_three)
+    assert float((outs[True] - outs[False]).abs().max()) / scale < 6 * ulp
