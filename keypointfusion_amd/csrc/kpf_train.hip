@@ -857,8 +857,11 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const TA* __restrict__ dy
 }
 
 inline int ln_blocks(long rows) {  // one row per wave for the small (B x 21)-row tensors of the fusion head (a row is a dependent chain of two wave
-  long g = (rows + 3) / 4;          // reductions: round 4 went from four rows per wave to one), at most 256 workgroups' partials to add
-  return (int)(g < 1 ? 1 : (g > 256 ? 256 : g));
+  long g = (rows + 3) / 4;          // reductions: round 4 went from four rows per wave to one), at most LN_MAX_BLOCKS workgroups' partials to add
+  // (round 5: 256 -> 1024.  With one workgroup per CU a wave walks rows / 1024 rows one dependent memory round trip at a time: the backward passes of the
+  //  32768 x 192 / 8192 x 384 LayerNorms ran at a quarter of what their traffic takes; four workgroups per CU put four times as many rows in flight.)
+  static const int cap = []() { const char* e = getenv("KPF_LN_MAX_BLOCKS"); return e ? atoi(e) : 1024; }();
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 }  // namespace
 
