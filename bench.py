@@ -129,7 +129,9 @@ def self_launch(n):
 # Secondary workloads of the default run (N = 1): each is this same script as a child process on its own workload — its own model,
 # capture and `roofline` — after the headline has been timed, so the driver's one invocation carries a timed record for every
 # BASELINE config that runs on one GPU.  (workload, steps, warmup)
-EXTRA_WORKLOADS = (("cnb512_f16", 6, 2), ("full128_bf16", 30, 5), ("train128_bf16", 12, 3), ("full256", 8, 3))
+# (order: the launch-bound workloads first, the two that hold the chip at its power limit last — on some boxes the training iteration measured 10 % slower
+#  right behind the ConvNeXt-B run than on its own: 17.6 vs 15.8 ms, profiles/r05_bench.json of the first r05 collection)
+EXTRA_WORKLOADS = (("train128_bf16", 30, 5), ("full128_bf16", 30, 5), ("full256", 8, 3), ("cnb512_f16", 6, 2))
 
 
 def run_extra(workload, steps, warmup, timeout):
