@@ -825,34 +825,37 @@ __global__ __launch_bounds__(512, 2) void dwconv7_stats_kernel(const TA* __restr
     for (int t = 0; t < 8; ++t) acc[t] = bias;
   }
   const char* const ib = LB + ((row * DS_ROW + sx * 8) * DS_CH + 4 * q) * 2;
-  // The multiply-adds are written as instructions: left to itself hipcc converts the inputs to fp32 (56 v_cvt per filter row) and SLP-packs the
-  // products into v_pk_fma_f32, which issues at half the rate of two v_fma_f32 here (measured: 2.6 x the vector-ALU floor).  f16: v_fma_mix_f32 takes
-  // the half straight from the packed register (fp32 weight, fp32 accumulator); bf16: widening is a shift / mask, then v_fma_f32.
   if (!(dbg & 1))
 #pragma unroll
   for (int ky = 0; ky < 7; ++ky) {
     uint2 in[14];  // four packed 16-bit channels of 14 input pixels
 #pragma unroll
     for (int i = 0; i < 14; ++i) in[i] = *reinterpret_cast<const uint2*>(ib + (ky * DS_ROW + i) * (DS_CH * 2));
+    // widen the 14 x 4 inputs ONCE per filter row (56 conversions feed 224 multiply-adds), then plain v_fma_f32.  Round 4 used v_fma_mix_f32 on the packed
+    // halves to save the conversions; tools/valu_rate.hip (round 5) measures that form at 2.4 ns per wave-instruction and SIMD against 1.4 for v_fma_f32 and
+    // 1.5 for a 4 : 16 mix of v_cvt_f32_f16 and v_fma_f32 — the kernel sat at 85 % of the v_fma_mix roof (61 us for 1.64 G multiply-adds).  Same values
+    // (the conversion is exact either way): same bits.  bf16: shift / mask, as before.
+    f32x4 inf[14];
+#pragma unroll
+    for (int i = 0; i < 14; ++i) {
+      if constexpr (std::is_same<TA, f16_t>::value) {
+        typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+        const h2_t lo = __builtin_bit_cast(h2_t, in[i].x), hi = __builtin_bit_cast(h2_t, in[i].y);
+        inf[i] = f32x4{(float)lo[0], (float)lo[1], (float)hi[0], (float)hi[1]};
+      } else {
+        inf[i] = f32x4{__uint_as_float(in[i].x << 16), __uint_as_float(in[i].x & 0xffff0000u), __uint_as_float(in[i].y << 16), __uint_as_float(in[i].y & 0xffff0000u)};
+      }
+    }
 #pragma unroll
     for (int kx = 0; kx < 7; ++kx) {
       const f32x4 wv = *reinterpret_cast<const f32x4*>(Ws + (ky * 7 + kx) * 64 + 4 * q);
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        const uint2 v = in[t + kx];
-        if constexpr (sizeof(TA) == 2 && std::is_same<TA, f16_t>::value) {
-          asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc[t][0]) : "v"(v.x), "v"(wv[0]));
-          asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[t][1]) : "v"(v.x), "v"(wv[1]));
-          asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc[t][2]) : "v"(v.y), "v"(wv[2]));
-          asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[t][3]) : "v"(v.y), "v"(wv[3]));
-        } else {
-          const float f0 = __uint_as_float(v.x << 16), f1 = __uint_as_float(v.x & 0xffff0000u);
-          const float f2 = __uint_as_float(v.y << 16), f3 = __uint_as_float(v.y & 0xffff0000u);
-          asm("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[t][0]) : "v"(f0), "v"(wv[0]));
-          asm("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[t][1]) : "v"(f1), "v"(wv[1]));
-          asm("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[t][2]) : "v"(f2), "v"(wv[2]));
-          asm("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[t][3]) : "v"(f3), "v"(wv[3]));
-        }
+        // (written as instructions: left to itself hipcc SLP-packs the products into v_pk_fma_f32 with register shuffles around them)
+        asm("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[t][0]) : "v"(inf[t + kx][0]), "v"(wv[0]));
+        asm("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[t][1]) : "v"(inf[t + kx][1]), "v"(wv[1]));
+        asm("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[t][2]) : "v"(inf[t + kx][2]), "v"(wv[2]));
+        asm("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[t][3]) : "v"(inf[t + kx][3]), "v"(wv[3]));
       }
     }
   }
