@@ -170,3 +170,31 @@ def test_wide_extension_changes_two_tensors_and_nothing_else():
     keep = {k: v for k, v in sd.items() if "fc_spatial2joint_feature.weight" not in k}
     missing, unexpected = m.load_state_dict(keep, strict=False)
     assert sorted(missing) == ["block1.fc_spatial2joint_feature.weight", "block2.fc_spatial2joint_feature.weight"] and not unexpected
+
+
+def test_layernorm_fold_rule_depends_on_the_layer_not_on_the_batch():
+    """kpf_conv2d_h16_ln_fold_supported (host-side rule, no GPU): pwconv1 of ConvNeXt-B / -T stages 3-4 takes the folded LayerNorm at every batch size — which
+    arithmetic a sample gets must not depend on how many samples share its launch — and layers the eight-phase GEMM does not cover never do."""
+    import ctypes as C
+    from keypointfusion_amd import lib as L
+    lib = L.load()
+
+    def desc(B, HW, Cin, N, flags, Kp=None, k=1):
+        d = L.ConvDesc()
+        d.B, d.IH, d.IW, d.Cin, d.in_ld, d.in_coff = B, HW, HW, Cin, Cin, 0
+        d.OH, d.OW, d.N = HW, HW, N
+        d.KH = d.KW = k
+        d.sh = d.sw = 1
+        d.ph = d.pw = k // 2
+        d.Kp = Kp or k * k * Cin
+        d.out_ld, d.out_coff, d.flags = N, 0, flags
+        return d
+
+    for Cin in (512, 1024, 384, 768):  # ConvNeXt-B stages 3-4, ConvNeXt-T stages 3-4
+        got = {B: lib.kpf_conv2d_h16_ln_fold_supported(C.byref(desc(B, 32, Cin, 4 * Cin, L.KPF_ACT_GELU))) for B in (1, 2, 7, 64)}
+        assert set(got.values()) == {1}, (Cin, got)
+    assert lib.kpf_conv2d_h16_ln_fold_supported(C.byref(desc(8, 32, 512, 2048, 0))) == 0                       # no GELU: not pwconv1
+    assert lib.kpf_conv2d_h16_ln_fold_supported(C.byref(desc(8, 32, 512, 2048, L.KPF_ACT_GELU | L.KPF_RES_ADD))) == 0
+    assert lib.kpf_conv2d_h16_ln_fold_supported(C.byref(desc(8, 32, 96, 384, L.KPF_ACT_GELU, Kp=128))) == 0     # Cin % 64 != 0 / N % 256 != 0 (ConvNeXt-T stage 1)
+    assert lib.kpf_conv2d_h16_ln_fold_supported(C.byref(desc(8, 32, 192, 768, L.KPF_ACT_GELU))) == 0            # Kp % 128 != 0 (stage 2)
+    assert lib.kpf_conv2d_h16_ln_fold_supported(C.byref(desc(8, 32, 512, 2048, L.KPF_ACT_GELU, k=3))) == 0      # not a dense 1x1

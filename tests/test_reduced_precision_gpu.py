@@ -411,7 +411,7 @@ def test_convnext_base_512_backbones_properties_and_oracle_subset(prec):
 
 
 @pytest.mark.parametrize("prec", ["bf16", "f16"])
-@pytest.mark.parametrize("C_,M", [(512, 8192), (512, 16384), (512, 8640), (1024, 4096), (512, 1024)])
+@pytest.mark.parametrize("C_,M", [(512, 8192), (512, 16384), (512, 8640), (1024, 4096), (512, 1024), (384, 16384)])
 def test_layernorm_folded_into_pwconv1_h16(C_, M, prec):
     """KPF_PRO_LN (convNeXT/convnext.py:42-44: pwconv1(norm(x)) then GELU): the GEMM multiplies the RAW 16-bit tensor by W diag(ln_w) and its epilogue applies
     rstd * (acc - mean * s) + (W ln_b + b) — against float64 (a) of the same expression on the same rounded operands (the kernel's arithmetic: output rounding
