@@ -74,3 +74,35 @@ def test_pick_stats_takes_the_file_with_the_kernel_and_checks_the_launch_count(t
     _log(str(log), "igemm_f32_kernel", 5, 1)
     r = _run("pick_stats.py", tmp_path / "prof", "igemm_f32_kernel", tmp_path / "out2.csv", log)
     assert r.returncode != 0 and "the command issued 30" in r.stderr
+
+
+def test_replay_grids_picks_one_replay_and_groups_by_kernel_and_grid(tmp_path):
+    """tools/replay_grids.py: iterations are delimited by pack_weights_multi_kernel, the shortest complete one is the replay, and its launches are grouped by
+    (kernel, workgroups, workgroup size) — the table that showed the LayerNorm backward on one workgroup per CU."""
+    d = tmp_path / "p" / "host"
+    os.makedirs(d)
+    hdr = "Kind,Agent_Id,Queue_Id,Kernel_Name,Workgroup_Size_X,Workgroup_Size_Y,Workgroup_Size_Z,Grid_Size_X,Grid_Size_Y,Grid_Size_Z,Start_Timestamp,End_Timestamp\n"
+    rows, t = [], 0
+
+    def emit(name, wgs, wg, dur):
+        nonlocal t
+        rows.append('KERNEL_DISPATCH,0,1,"%s",%d,1,1,%d,1,1,%d,%d\n' % (name, wg, wgs * wg, t, t + dur))
+        t += dur + 100
+
+    for it, slow in enumerate((3, 1, 1)):  # an eager (slower) iteration, then two replays; a last marker closes the third
+        emit("(anonymous namespace)::pack_weights_multi_kernel(float*)", 64, 256, 1000 * slow)
+        for i in range(600):
+            if i % 3 == 0:
+                emit("void (anonymous namespace)::ln_bwd_kernel<float>(float const*)", 256, 256, 20000 * slow)
+            else:
+                emit("void (anonymous namespace)::igemm_f32_kernel<2, 1, 1, 4>(ConvArgs)", 42, 256, 5000 * slow)
+    emit("(anonymous namespace)::pack_weights_multi_kernel(float*)", 64, 256, 1000)
+    with open(d / "1_kernel_trace.csv", "w") as f:
+        f.write(hdr + "".join(rows))
+    out = tmp_path / "grids.txt"
+    r = _run("replay_grids.py", tmp_path / "p", out)
+    assert r.returncode == 0, r.stderr
+    text = open(out).read().splitlines()
+    assert text[0].startswith("one replay: 601 launches")
+    assert " 200 x    20.0 us" in text[1] and "256 workgroups x  256 threads   ln_bwd_kernel<float>" in text[1]
+    assert " 400 x     5.0 us" in text[2] and "42 workgroups x  256 threads   igemm_f32_kernel<2, 1, 1, 4>" in text[2]
