@@ -432,27 +432,28 @@ def test_layernorm_folded_into_pwconv1_h16(C_, M, prec):
     w1 = torch.randn(N, C_, generator=g) / C_ ** 0.5
     b1 = torch.randn(N, generator=g) * 0.3
     lw, lb = torch.rand(C_, generator=g) + 0.5, torch.randn(C_, generator=g) * 0.2
-    xd = x.double()
+    xd = x.double().to(dev)  # (the float64 references run on the GPU: 17 GFLOP each at the largest case)
+    w1, b1, lw, lb = w1.to(dev), b1.to(dev), lw.to(dev), lb.to(dev)
     # chunk statistics as kpf_dwconv7_stats_h16 defines them: (mean, sum of centred squares) of every 64-channel chunk
     ch = xd.view(M, C_ // 64, 64)
-    st = torch.stack((ch.mean(-1), ((ch - ch.mean(-1, keepdim=True)) ** 2).sum(-1)), -1).float().contiguous().to(dev)
+    st = torch.stack((ch.mean(-1), ((ch - ch.mean(-1, keepdim=True)) ** 2).sum(-1)), -1).float().contiguous()
     mr = torch.full((M, 2), float("nan"), device=dev)
     L.check(lib.kpf_ln_stats_merge(_ptr(st), _ptr(mr), M, C_, 1e-6, _stream()), "merge")
     mean, rstd = xd.mean(-1), 1.0 / torch.sqrt(xd.var(-1, unbiased=False) + 1e-6)
-    assert float((mr[:, 0].cpu().double() - mean).abs().max()) < 1e-5 * float(xd.abs().max())
-    assert float(((mr[:, 1].cpu().double() - rstd).abs() / rstd).max()) < 1e-5
-    p16 = Packed16(PackedConv((w1.double() * lw.double()[None, :]).float().reshape(N, C_, 1, 1), None, dev), tdt)
+    assert float((mr[:, 0].double() - mean).abs().max()) < 1e-5 * float(xd.abs().max())
+    assert float(((mr[:, 1].double() - rstd).abs() / rstd).max()) < 1e-5
+    p16 = Packed16(PackedConv((w1.double() * lw.double()[None, :]).float().cpu().reshape(N, C_, 1, 1), None, dev), tdt)
     s = p16.w[:, :C_].double().sum(1).float().contiguous()
-    bf = (w1.double() @ lb.double() + b1.double()).float().to(dev)
+    bf = (w1.double() @ lb.double() + b1.double()).float()
     xa = Act(x.to(dev).contiguous().view(-1), 1, 1, M, C_)
     out = Act(torch.full((M * N,), float("nan"), device=dev, dtype=tdt), 1, 1, M, N)
     assert conv16(p16, xa, kdt, out=out, flags=L.KPF_ACT_GELU, probe=True)
     conv16(p16, xa, kdt, out=out, flags=L.KPF_ACT_GELU, ln=(mr, s, bf))
-    got = out.buf.view(M, N).float().cpu().double()
+    got = out.buf.view(M, N).double()
     assert bool(torch.isfinite(got).all())
     gelu = lambda v: 0.5 * v * (1 + torch.erf(v / 2 ** 0.5))
-    mrd = mr.cpu().double()
-    same = gelu(mrd[:, 1:2] * (xd @ p16.w[:, :C_].cpu().double().t() - mrd[:, 0:1] * s.cpu().double()[None, :]) + bf.cpu().double()[None, :])
+    mrd = mr.double()
+    same = gelu(mrd[:, 1:2] * (xd @ p16.w[:, :C_].double().t() - mrd[:, 0:1] * s.double()[None, :]) + bf.double()[None, :])
     scale = float(same.abs().max())
     assert float((got - same).abs().max()) / scale < 1.2 * ulp, float((got - same).abs().max()) / scale  # fp32 accumulation and epilogue, one output rounding
     true = gelu(F.layer_norm(xd, (C_,), lw.double(), lb.double(), 1e-6) @ w1.double().t() + b1.double())
