@@ -36,6 +36,7 @@ One JSON line is printed by rank 0 with, besides the contract fields:
                  workload — `value` is their median, the best pass is stated beside it (rank 0, N=1 only).
 """
 import argparse
+import contextlib
 import json
 import os
 import statistics
@@ -170,6 +171,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial-streams", action="store_true", help="issue both backbones on one stream (per-kernel profiling: rocprofv3 "
                     "durations of overlapped kernels are otherwise shared-GPU durations)")
+    ap.add_argument("--stage-pipeline", action="store_true", help="full-model eval workloads: two graphs per batch (backbones of batch i + 1 on one stream beside "
+                    "the head of batch i on another) instead of whole forwards on --in-flight streams")
     ap.add_argument("--one-stream-graph", action="store_true", help="eval workloads: capture both backbones on ONE stream (the graph stays on; a single-stream "
                     "graph replays on the runtime's batched path, a forked one node by node)")
     ap.add_argument("--no-graph", action="store_true", help="issue the launches of a step from Python instead of replaying the captured "
@@ -288,7 +291,7 @@ def main():
             elif graph_on[0] and args.in_flight > 1:
                 if pipe[0] is None:
                     from keypointfusion_amd.serving import PipelinedEval
-                    pipe[0] = PipelinedEval(model, depth=args.in_flight)
+                    pipe[0] = PipelinedEval(model, depth=args.in_flight, stages=args.stage_pipeline)
                 pending.append(pipe[0].submit(batch["img_rgb"], batch["img"], batch["pcl"], _Loader(), batch["center"], batch["M"], batch["cube"],
                                               batch["cam_para"], 0.8))
                 if len(pending) > args.in_flight:  # a real loop consumes the oldest batch's outputs here
@@ -312,17 +315,25 @@ def main():
         if not train:
             model._plan(dev).serial_streams = bool(args.serial_streams or args.one_stream_graph)
 
+    # The pipelined eval loop submits from a stream of its own: an event recorded on the DEFAULT stream (what `stream.wait_stream(default)` does for every
+    # submitted batch) acts as a join over every stream of the device on this runtime and serialises the pipeline (3.35 vs 2.11 ms per B = 32 batch,
+    # tools/exp_overlap3.py); serving.PipelinedEval documents the same for its callers.
+    loop_stream = torch.cuda.Stream(device=dev) if (not train and not backbones_only and graph_on[0] and args.in_flight > 1) else None
+    if loop_stream is not None:
+        loop_stream.wait_stream(torch.cuda.current_stream(dev))  # the synthetic batch was produced on the default stream
+
     def timed(K, W):
         """W untimed steps, then exactly K steps between barrier + synchronize pairs; returns (seconds, host issue seconds)."""
-        for _ in range(W):
-            step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(K):
-            step()
-        t_issue = time.perf_counter() - t0  # host time to enqueue the K steps (close to dt => the step is launch-bound)
-        barrier()
-        return time.perf_counter() - t0, t_issue
+        with torch.cuda.stream(loop_stream) if loop_stream is not None else contextlib.nullcontext():
+            for _ in range(W):
+                step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(K):
+                step()
+            t_issue = time.perf_counter() - t0  # host time to enqueue the K steps (close to dt => the step is launch-bound)
+            barrier()
+            return time.perf_counter() - t0, t_issue
 
     def instrumented():
         """Per-launch HIP events around every MFMA-kernel launch, both backbones on one stream (each duration is the kernel's own)."""
@@ -398,7 +409,8 @@ def main():
             fresh_plan()
     launch_mode = "hipGraph replay" if graph_on[0] else "eager"
     if graph_on[0] and not train and not backbones_only and args.in_flight > 1:
-        launch_mode += ", %d batches in flight (independent graph slots / streams)" % args.in_flight
+        launch_mode += (", %d batches in flight (independent graph slots / streams; the loop submits from its own stream)" % args.in_flight) if not args.stage_pipeline else (
+            ", stage pipeline over %d buffer sets (backbone graphs on one stream beside the head graphs on another)" % args.in_flight)
     dt, t_issue = timed(args.steps, args.warmup)
     single = None
     if train:  # one step issued into an idle GPU: host time of the enqueue vs the step's whole duration (which of the two bounds a replay)

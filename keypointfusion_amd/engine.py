@@ -795,6 +795,35 @@ class ModelPlan:
             graph.replay()
             return [t.clone() for t in res], [t.clone() for t in sws], None
 
+    def staged_graphs(self, img_rgb, img, pcl, center, M, cube, cam, kernel, img_size, flip, slot=0):
+        """The forward as TWO captured hipGraphs over one set of static buffers — A: both backbones, B: everything behind them (reads A's outputs and the
+        static inputs) — for serving.PipelinedEval's stage pipeline: A of batch i + 1 replays on one HIP stream beside B of batch i on another.  Returns
+        (graph_a, graph_b, static inputs in the order (img_rgb, img, pcl, center, M, cube, cam), results, spatial weights); the caller copies the inputs in,
+        orders the replays with events and copies the outputs out.  One entry per (input shapes, slot)."""
+        ins = [t.detach().to(device=self.device, dtype=torch.float32).contiguous() for t in (img_rgb, img, pcl, center, M, cube, cam)]
+        key = ("staged",) + tuple(tuple(t.shape) for t in ins) + (kernel, img_size, flip, slot)
+        with self._graph_lock:
+            ent = self._graphs.get(key)
+            if ent is None:
+                static = [t.clone() for t in ins]
+                cur = torch.cuda.current_stream(self.device)
+                warm = torch.cuda.Stream(device=self.device)
+                warm.wait_stream(cur)
+                with torch.cuda.stream(warm):  # eager warm-up: one-time attribute / symbol lookups must not happen under capture
+                    self.forward(*static, kernel, img_size, flip)
+                    self.forward(*static, kernel, img_size, flip)
+                cur.wait_stream(warm)
+                torch.cuda.synchronize(self.device)
+                s_rgb, s_img, s_pcl, s_center, s_M, s_cube, s_cam = static
+                ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga):
+                    bb = self.backbones(s_img, s_rgb)
+                with torch.cuda.graph(gb):
+                    res, sws, _ = self._head(bb, s_img, s_pcl, s_center, s_M, s_cube, s_cam, kernel, img_size, flip)
+                ent = (ga, gb, static, res, sws, bb)  # (bb: graph A's outputs stay referenced — graph B's kernels hold their addresses)
+                self._graphs[key] = ent
+        return ent[:5], ins
+
     def forward(self, img_rgb, img, pcl, center, M, cube, cam, kernel, img_size, flip, want_aux=False):
         lib = L.load()
         dev = self.device
@@ -802,7 +831,15 @@ class ModelPlan:
         N = pcl.shape[1]
         prep = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
         img, img_rgb, pcl, center, M, cube, cam = map(prep, (img, img_rgb, pcl, center, M, cube, cam))
-        (img_offset, feat_d), (img_offset_rgb, feat_rgb) = self.backbones(img, img_rgb)
+        return self._head(self.backbones(img, img_rgb), img, pcl, center, M, cube, cam, kernel, img_size, flip, want_aux)
+
+    def _head(self, bb, img, pcl, center, M, cube, cam, kernel, img_size, flip, want_aux=False):
+        """Everything behind the backbones (model/model.py:399-426): keypoint decode, pixel / point association, the two fusion blocks.  bb = backbones(...)."""
+        lib = L.load()
+        dev = self.device
+        B, _, S, _ = img.shape
+        N = pcl.shape[1]
+        (img_offset, feat_d), (img_offset_rgb, feat_rgb) = bb
         F = feat_d.H
         P = F * F
         st = _stream()

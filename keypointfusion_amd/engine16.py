@@ -145,7 +145,6 @@ class Block16:
         self.pw1f = Packed16(PackedConv((w1 * lnw[None, :]).float().reshape(4 * c, c, 1, 1), None, device), tdt)
         self.pw1f_s = self.pw1f.w[:, :c].double().sum(1).float().contiguous()
         self.pw1f_b = (w1 @ lnb + sd[p + ".pwconv1.bias"].detach().double()).float().contiguous().to(device)
-        self.mr = None  # (mean, rstd) per pixel, allocated per shape
         # fused MLP (kpf_convnext_mlp_h16: the 4C-wide hidden tensor never reaches HBM) where the library has it: pwconv2's weight chunk-major
         # [4C/32][C][32] with the hidden index of a 32-block in the order GEMM1's accumulator registers form GEMM2's operand
         self.fused = (not FORCE_UNFUSED_MLP16) and bool(L.load().kpf_convnext_mlp_h16_supported(c))
@@ -168,10 +167,9 @@ class Block16:
             rows = x.B * x.H * x.W
             if LN_FOLD and not fused and conv16(self.pw1f, y, kdt, out=h, flags=L.KPF_ACT_GELU, probe=True):
                 # round 5: no normalisation pass — the statistics are merged to (mean, rstd) per pixel (4 us) and pwconv1's epilogue applies them
-                if self.mr is None or self.mr.numel() != 2 * rows or self.mr.device != x.buf.device:
-                    self.mr = torch.empty(2 * rows, device=x.buf.device, dtype=torch.float32)
-                L.check(lib.kpf_ln_stats_merge(_ptr(st), _ptr(self.mr), rows, x.C, 1e-6, _stream()), "kpf_ln_stats_merge")
-                conv16(self.pw1f, y, kdt, out=h, flags=L.KPF_ACT_GELU, ln=(self.mr, self.pw1f_s, self.pw1f_b))
+                mr = torch.empty(2 * rows, device=x.buf.device, dtype=torch.float32)  # (per call, like y / h / st: batches in flight must not share it)
+                L.check(lib.kpf_ln_stats_merge(_ptr(st), _ptr(mr), rows, x.C, 1e-6, _stream()), "kpf_ln_stats_merge")
+                conv16(self.pw1f, y, kdt, out=h, flags=L.KPF_ACT_GELU, ln=(mr, self.pw1f_s, self.pw1f_b))
                 conv16(self.pw2, h, kdt, out=x, gamma=self.gamma, res=x)
                 return x
             L.check(lib.kpf_ln_apply_stats_h16(_ptr(y.buf), _ptr(st), _ptr(self.lnw), _ptr(self.lnb), rows, x.C, 1e-6, kdt, _stream()),

@@ -864,7 +864,8 @@ def test_two_devices_in_one_process_opt_in_per_device():
         assert rel_err(o0, r) < 2e-4 and rel_err(o1, r) < 2e-4
 
 
-def test_pipelined_eval_returns_what_forward_returns():
+@pytest.mark.parametrize("stages", [True, False])
+def test_pipelined_eval_returns_what_forward_returns(stages):
     """serving.PipelinedEval: several batches in flight on independent graph slots / streams must give, batch by batch, exactly the
     tensors the module's own forward gives (same kernels, same order of arithmetic)."""
     from keypointfusion_amd.model.model import KPFusion
@@ -883,11 +884,15 @@ def test_pipelined_eval_returns_what_forward_returns():
     args = lambda b: (b["img_rgb"], b["img"], b["pcl"], Loader(), b["center"], b["M"], b["cube"], b["cam_para"], 0.8)
     with torch.no_grad():
         ref = [m(*args(b)) for b in batches]
-    pe = PipelinedEval(m, depth=2)
-    tickets = [pe.submit(*args(b)) for b in batches]
-    for t, (rres, rsw, _) in zip(tickets, ref):
-        res, sws, _ = pe.collect(t)
-        assert all(torch.equal(a, b) for a, b in zip(res + sws, rres + rsw))
+    pe = PipelinedEval(m, depth=2, stages=stages)
+    for feed in (torch.cuda.current_stream(dev), pe.feed_stream(dev)):  # from the default stream (serialised, correct) and from a loop stream (overlapped)
+        feed.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(feed):
+            tickets = [pe.submit(*args(b)) for b in batches]
+            for t, (rres, rsw, _) in zip(tickets, ref):
+                res, sws, _ = pe.collect(t)
+                assert all(torch.equal(a, b) for a, b in zip(res + sws, rres + rsw))
+        torch.cuda.current_stream(dev).wait_stream(feed)
     with pytest.raises(RuntimeError):
         m.train()
         pe.submit(*args(batches[0]))
