@@ -128,6 +128,17 @@ class Residual16:
         return conv16(self.c3, h, kdt, out=out, res=x)
 
 
+def _ln_fold_shape_ok(c):
+    """kpf_conv2d_h16_ln_fold_supported for pwconv1 of a C-channel ConvNeXt block (any batch, any map: the rule does not look at them)."""
+    d = L.ConvDesc()
+    d.B, d.IH, d.IW, d.Cin, d.in_ld, d.in_coff = 1, 16, 16, c, c, 0
+    d.OH, d.OW, d.N = 16, 16, 4 * c
+    d.KH = d.KW = d.sh = d.sw = 1
+    d.Kp = (c + 63) // 64 * 64
+    d.out_ld, d.out_coff, d.flags = 4 * c, 0, L.KPF_ACT_GELU
+    return bool(L.load().kpf_conv2d_h16_ln_fold_supported(C.byref(d)))
+
+
 class Block16:
     """engine.ConvNeXtBlockPlan on 16-bit storage: dw7x7+LN kernel, pwconv1 GEMM (+GELU), pwconv2 GEMM (+gamma*y + x, in place)."""
 
@@ -140,11 +151,13 @@ class Block16:
         self.pw2 = Packed16(PackedConv(sd[p + ".pwconv2.weight"], sd[p + ".pwconv2.bias"], device), tdt)
         # LayerNorm folded into pwconv1 (KPF_PRO_LN; used when the statistics come from the stencil and gemm16_8ph_kernel takes the layer):
         #   W (ln_w * xhat + ln_b) + b = rstd * (W' x - mean * s) + b',   W' = W diag(ln_w) rounded to the storage type, s = its row sums in fp32, b' = W ln_b + b
-        w1 = sd[p + ".pwconv1.weight"].detach().double().reshape(4 * c, c)
-        lnw, lnb = sd[p + ".norm.weight"].detach().double(), sd[p + ".norm.bias"].detach().double()
-        self.pw1f = Packed16(PackedConv((w1 * lnw[None, :]).float().reshape(4 * c, c, 1, 1), None, device), tdt)
-        self.pw1f_s = self.pw1f.w[:, :c].double().sum(1).float().contiguous()
-        self.pw1f_b = (w1 @ lnb + sd[p + ".pwconv1.bias"].detach().double()).float().contiguous().to(device)
+        self.pw1f = None
+        if LN_FOLD and _ln_fold_shape_ok(c):  # (the rule is over the layer's shape: known here; blocks it does not cover keep one copy of pwconv1)
+            w1 = sd[p + ".pwconv1.weight"].detach().double().reshape(4 * c, c)
+            lnw, lnb = sd[p + ".norm.weight"].detach().double(), sd[p + ".norm.bias"].detach().double()
+            self.pw1f = Packed16(PackedConv((w1 * lnw[None, :]).float().reshape(4 * c, c, 1, 1), None, device), tdt)
+            self.pw1f_s = self.pw1f.w[:, :c].double().sum(1).float().contiguous()
+            self.pw1f_b = (w1 @ lnb + sd[p + ".pwconv1.bias"].detach().double()).float().contiguous().to(device)
         # fused MLP (kpf_convnext_mlp_h16: the 4C-wide hidden tensor never reaches HBM) where the library has it: pwconv2's weight chunk-major
         # [4C/32][C][32] with the hidden index of a 32-block in the order GEMM1's accumulator registers form GEMM2's operand
         self.fused = (not FORCE_UNFUSED_MLP16) and bool(L.load().kpf_convnext_mlp_h16_supported(c))
@@ -165,7 +178,7 @@ class Block16:
             L.check(lib.kpf_dwconv7_stats_h16(_ptr(x.buf), _ptr(self.wdw), _ptr(self.bdw), _ptr(y.buf), _ptr(st), x.B, x.H, x.W, x.C, kdt, _stream()),
                     "kpf_dwconv7_stats_h16")
             rows = x.B * x.H * x.W
-            if LN_FOLD and not fused and conv16(self.pw1f, y, kdt, out=h, flags=L.KPF_ACT_GELU, probe=True):
+            if LN_FOLD and not fused and self.pw1f is not None and conv16(self.pw1f, y, kdt, out=h, flags=L.KPF_ACT_GELU, probe=True):
                 # round 5: no normalisation pass — the statistics are merged to (mean, rstd) per pixel (4 us) and pwconv1's epilogue applies them
                 mr = torch.empty(2 * rows, device=x.buf.device, dtype=torch.float32)  # (per call, like y / h / st: batches in flight must not share it)
                 L.check(lib.kpf_ln_stats_merge(_ptr(st), _ptr(mr), rows, x.C, 1e-6, _stream()), "kpf_ln_stats_merge")
