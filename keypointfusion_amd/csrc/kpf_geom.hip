@@ -483,19 +483,29 @@ __global__ __launch_bounds__(64) void ball_group_kernel(const float* __restrict_
   int cnt = 0;
   sidx[lane] = 0;
   __syncthreads();
-  for (int base = 0; base < NT && cnt < 64; base += 64) {
-    const int i = base + lane;
-    bool hit = false;
-    if (i < NT) {
-      const float* p = i < N ? pcl + ((long)b * N + i) * 3 : joint_xyz + ((long)b * J + (i - N)) * 3;
-      const float dx = qx - p[0], dy = qy - p[1], dz = qz - p[2];
-      const float d2 = (dx * dx + dy * dy) + dz * dz;
-      hit = d2 < rad2;
+  // the distance tests of eight 64-point chunks are requested together, then the chunks are taken in index order (the first 64 members in index order, as before)
+  for (int base0 = 0; base0 < NT && cnt < 64; base0 += 512) {
+    bool hit[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base0 + 64 * u + lane;
+      hit[u] = false;
+      if (i < NT) {
+        const float* p = i < N ? pcl + ((long)b * N + i) * 3 : joint_xyz + ((long)b * J + (i - N)) * 3;
+        const float dx = qx - p[0], dy = qy - p[1], dz = qz - p[2];
+        const float d2 = (dx * dx + dy * dy) + dz * dz;
+        hit[u] = d2 < rad2;
+      }
     }
-    const unsigned long long m = __ballot(hit);
-    const int slot = cnt + __popcll(m & ((1ull << lane) - 1ull));
-    if (hit && slot < 64) sidx[slot] = i;
-    cnt += __popcll(m);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (cnt < 64) {  // (wave-uniform)
+        const unsigned long long m = __ballot(hit[u]);
+        const int slot = cnt + __popcll(m & ((1ull << lane) - 1ull));
+        if (hit[u] && slot < 64) sidx[slot] = base0 + 64 * u + lane;
+        cnt += __popcll(m);
+      }
+    }
   }
   __syncthreads();
   if (cnt > 64) cnt = 64;
@@ -507,21 +517,30 @@ __global__ __launch_bounds__(64) void ball_group_kernel(const float* __restrict_
   __syncthreads();
   const float2 fj = *reinterpret_cast<const float2*>(JF + (long)bj * jf_ld + 2 * lane);
   float* gb = G + (long)ri * g_stride + (long)bj * 64 * G_LD;
-  for (int s = 0; s < 64; ++s) {
-    const int i = sidx[s];
-    const float* fp = i < N ? X + ((long)b * N + i) * 128 : JF + ((long)b * J + (i - N)) * jf_ld;
-    const float2 f = *reinterpret_cast<const float2*>(fp + 2 * lane);
-    float2 o;
-    o.x = f.x - fj.x;
-    o.y = f.y - fj.y;
-    *reinterpret_cast<float2*>(gb + (long)s * G_LD + 2 * lane) = o;
-    if (lane < 4) {
-      float v = 0.f;
+  // eight member rows per step: their loads are all requested before the first store (one member per iteration was a chain of 64 dependent round trips —
+  // 45 of the kernel's 52 us at B = 32; round 5)
+  const float ql = lane < 3 ? qp[lane] : 0.f;
+  for (int s0 = 0; s0 < 64; s0 += 8) {
+    float2 f[8];
+    float pv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = sidx[s0 + u];
+      const float* fp = i < N ? X + ((long)b * N + i) * 128 : JF + ((long)b * J + (i - N)) * jf_ld;
+      f[u] = *reinterpret_cast<const float2*>(fp + 2 * lane);
+      pv[u] = 0.f;
       if (lane < 3) {
         const float* p = i < N ? pcl + ((long)b * N + i) * 3 : joint_xyz + ((long)b * J + (i - N)) * 3;
-        v = (p[lane] - qp[lane]) / radius;
+        pv[u] = p[lane];
       }
-      gb[(long)s * G_LD + 128 + lane] = v;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      float2 o;
+      o.x = f[u].x - fj.x;
+      o.y = f[u].y - fj.y;
+      *reinterpret_cast<float2*>(gb + (long)(s0 + u) * G_LD + 2 * lane) = o;
+      if (lane < 4) gb[(long)(s0 + u) * G_LD + 128 + lane] = lane < 3 ? (pv[u] - ql) / radius : 0.f;
     }
   }
 }
@@ -535,6 +554,37 @@ __global__ __launch_bounds__(128) void group_max_kernel(const float* __restrict_
     float m = -INFINITY;
     for (int s = 0; s < group; ++s) m = fmaxf(m, p[(long)s * C]);
     out[r * out_ld + out_coff + c] = m;
+  }
+}
+
+// C % 4 == 0, C <= 1024, 16-byte aligned rows (round 5): 256 threads = (channel quad, member subgroup), float4 loads — every member row of the group is
+// requested at once instead of one 4-byte load per member and thread (64 x 128 channels: 19.7 -> see DESIGN 4.4) — the subgroups' maxima meet in LDS.
+// max is exact and order-free: same bits as the scalar form.
+__global__ __launch_bounds__(256) void group_max_vec_kernel(const float* __restrict__ in, float* __restrict__ out, int group, int C, int out_ld,
+                                                            int out_coff) {
+  __shared__ f32x4 red[256];
+  const long r = blockIdx.x;
+  const int Q = C >> 2;                 // channel quads
+  const int SG = 256 / Q > 0 ? 256 / Q : 1;  // member subgroups (a power of two when Q is; any Q works)
+  const int q = threadIdx.x % Q, sg = threadIdx.x / Q;
+  f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  if (sg < SG) {
+    const float* p = in + r * group * C + 4 * q;
+    for (int s = sg; s < group; s += SG) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p + (long)s * C);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+    }
+  }
+  red[threadIdx.x] = m;
+  __syncthreads();
+  if (sg == 0) {
+    for (int g = 1; g < SG; ++g) {
+      const f32x4 v = red[g * Q + q];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+    }
+    *reinterpret_cast<f32x4*>(out + r * out_ld + out_coff + 4 * q) = m;
   }
 }
 
@@ -750,7 +800,10 @@ extern "C" int kpf_ball_group_f32(const float* pcl, const float* joint_xyz, cons
 
 extern "C" int kpf_group_max_f32(const float* in, float* out, long rows, int group, int C, int out_ld, int out_coff, void* stream) {
   KPF_REQUIRE(in && out && rows > 0 && group > 0 && C > 0 && out_coff + C <= out_ld, "kpf_group_max_f32: bad arguments");
-  hipLaunchKernelGGL(group_max_kernel, dim3((unsigned)rows), dim3(128), 0, ST(stream), in, out, group, C, out_ld, out_coff);
+  if (C % 4 == 0 && C <= 1024 && C >= 4 && out_ld % 4 == 0 && out_coff % 4 == 0 && kpf_aligned16(in) && kpf_aligned16(out))
+    hipLaunchKernelGGL(group_max_vec_kernel, dim3((unsigned)rows), dim3(256), 0, ST(stream), in, out, group, C, out_ld, out_coff);
+  else
+    hipLaunchKernelGGL(group_max_kernel, dim3((unsigned)rows), dim3(128), 0, ST(stream), in, out, group, C, out_ld, out_coff);
   return kpf_check_launch("kpf_group_max_f32");
 }
 
