@@ -506,3 +506,35 @@ def test_convnext_block16_with_and_without_the_folded_layernorm(prec):
     e_fold, e_three = float((outs[True] - ref).abs().max()) / scale, float((outs[False] - ref).abs().max()) / scale
     assert e_fold < e_three + ulp and e_fold < 6 * ulp, (e_fold, e_three)
     assert float((outs[True] - outs[False]).abs().max()) / scale < 6 * ulp
+
+
+@pytest.mark.parametrize("prec,map_tol", [("f16", 8e-3), ("bf16", 6e-2)])
+def test_convnext_tiny_backbones_at_256_take_the_folded_layernorm(prec, map_tol):
+    """At 256 x 256 crops ConvNeXt-T's stage 3 (16 x 16 maps, C = 384) runs stencil + statistics, and its pwconv1 takes the LayerNorm folded into the GEMM
+    (KPF_PRO_LN) — the same model with the fold switched off (three passes) and the fp32 plan bound it: dense maps and features of both backbones within the
+    16-bit tolerance of the fp32 ones, and the folded and the three-pass results within that tolerance of each other."""
+    from keypointfusion_amd import engine16 as E16, lib as L
+    from keypointfusion_amd.engine import ModelPlan
+    dev = _dev()
+    net = "KPFusion-convnext-tiny"
+    sd = synthetic_sd(net)
+    g = torch.Generator().manual_seed(5)
+    img, rgb = torch.rand(2, 1, 256, 256, generator=g).to(dev) * 2 - 1, torch.rand(2, 3, 256, 256, generator=g).to(dev)
+    assert E16._ln_fold_shape_ok(384) and E16._ln_fold_shape_ok(768) and not E16._ln_fold_shape_ok(96) and not E16._ln_fold_shape_ok(192)
+    assert L.load().kpf_dwconv7_stats_supported(16, 16, 384)
+    outs = {}
+    keep = E16.LN_FOLD
+    try:
+        with torch.no_grad():
+            for mode in ("f32", "fold", "three"):
+                E16.LN_FOLD = mode == "fold"
+                plan = ModelPlan(sd, net, dev, precision="f32" if mode == "f32" else prec)
+                (od, fd), (orgb, frgb) = plan.backbones(img, rgb)
+                outs[mode] = [t.float().cpu() for t in (od, fd.buf.view(-1), orgb, frgb.buf.view(-1))]
+    finally:
+        E16.LN_FOLD = keep
+    for a, b, r in zip(outs["fold"], outs["three"], outs["f32"]):
+        assert bool(torch.isfinite(a).all())
+        assert rel(a, r) < map_tol and rel(b, r) < map_tol, (rel(a, r), rel(b, r))
+        assert rel(a, b) < map_tol
+    assert any(not torch.equal(a, b) for a, b in zip(outs["fold"], outs["three"]))  # (the switch did select two schedules)
