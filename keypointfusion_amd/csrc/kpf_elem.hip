@@ -201,13 +201,17 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const TA* __restrict__ x, 
 // xor-shuffles (mean first, then the centred squares: two-pass variance like ATen's).  One pass over the activation instead of
 // the conv + LayerNorm pair's two.
 // ---------------------------------------------------------------------------------------------------------------
-template <typename TA, int NT, bool SPLIT>
+// ROWS = 2 (default): a 2-row x 8-pixel strip per workgroup.  ROWS = 1 (round 5): one row — for launches that leave the chip mostly idle (B x 8 x 8 x 384 at
+// B = 32: 128 workgroups of two waves, each thread a chain of eight input-row round trips and 3136 multiply-adds): twice the workgroups, seven rows and half the
+// arithmetic per thread.  Same order of operations per output and per LayerNorm sum: same bits.
+template <typename TA, int NT, bool SPLIT, int ROWS = 2>
 __global__ __launch_bounds__(NT) void dwconv7_ln_wide_kernel(const TA* __restrict__ x, const float* __restrict__ wdw,
                                                              const float* __restrict__ bdw, const float* __restrict__ lw,
                                                              const float* __restrict__ lb, TA* __restrict__ y, int B, int H, int W,
                                                              int C, int xstrips, int ypairs, float eps) {
-  __shared__ float red[16 * NT];
-  __shared__ float stat[16];
+  constexpr int NP = 8 * ROWS;  // pixels of the strip
+  __shared__ float red[NP * NT];
+  __shared__ float stat[NP];
   const int C4 = C >> 2;
   const int q = threadIdx.x;
   const bool live = q < C4;
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(NT) void dwconv7_ln_wide_kernel(const TA* __restric
   r /= xstrips;
   const int yp = (int)(r % ypairs);
   const int b = (int)(r / ypairs);
-  const int x0 = xs * 8, y0 = yp * 2;
+  const int x0 = xs * 8, y0 = yp * ROWS;
   f32x4 acc0[8], acc1[8];
   const f32x4 bias = *reinterpret_cast<const f32x4*>(bdw + 4 * qc);
 #pragma unroll
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(NT) void dwconv7_ln_wide_kernel(const TA* __restric
   const TA* xb = x + (long)b * H * W * C + 4 * qc;
   if (live) {
 #pragma unroll 1
-    for (int ir = 0; ir < 8; ++ir) {  // input rows y0-3 .. y0+4
+    for (int ir = 0; ir < 6 + ROWS; ++ir) {  // input rows y0-3 .. y0+2+ROWS
       const int iy = y0 + ir - 3;
       if ((unsigned)iy >= (unsigned)H) continue;
       f32x4 in[14];
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(NT) void dwconv7_ln_wide_kernel(const TA* __restric
             for (int e = 0; e < 4; ++e) acc0[t][e] = fmaf(in[t + kx][e], wv[e], acc0[t][e]);
         }
       }
-      if (ir >= 1) {
+      if (ROWS == 2 && ir >= 1) {
 #pragma unroll
         for (int kx = 0; kx < 7; ++kx) {
           const f32x4 wv = *reinterpret_cast<const f32x4*>(wdw + ((ir - 1) * 7 + kx) * C + 4 * qc);
@@ -264,13 +268,13 @@ __global__ __launch_bounds__(NT) void dwconv7_ln_wide_kernel(const TA* __restric
   }
   // ---- LayerNorm statistics of the strip's 16 pixels across the workgroup ----
   const float invC = 1.0f / (float)C;
-  const int rp = threadIdx.x >> 3, rg = threadIdx.x & 7;  // reducer role (threads 0..127): pixel rp, one of its 8 adders
-  float mean[16];
+  const int rp = threadIdx.x >> 3, rg = threadIdx.x & 7;  // reducer role (threads 0 .. 8 NP - 1): pixel rp, one of its 8 adders
+  float mean[NP];
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-    for (int p = 0; p < 16; ++p) {
-      const f32x4 v = p < 8 ? acc0[p] : acc1[p - 8];
+    for (int p = 0; p < NP; ++p) {
+      const f32x4 v = p < 8 ? acc0[p] : acc1[p & 7];
       float s = 0.f;
       if (live) {
         if (pass == 0) {
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(NT) void dwconv7_ln_wide_kernel(const TA* __restric
       red[p * NT + threadIdx.x] = s;
     }
     __syncthreads();
-    if (threadIdx.x < 128) {
+    if (threadIdx.x < 8 * NP) {
       float s = 0.f;
 #pragma unroll
       for (int j = 0; j < NT / 8; ++j) s += red[rp * NT + rg + 8 * j];
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(NT) void dwconv7_ln_wide_kernel(const TA* __restric
     __syncthreads();
     if (pass == 0) {
 #pragma unroll
-      for (int p = 0; p < 16; ++p) mean[p] = stat[p];
+      for (int p = 0; p < NP; ++p) mean[p] = stat[p];
       __syncthreads();  // stat is rewritten by the second pass
     }
   }
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(NT) void dwconv7_ln_wide_kernel(const TA* __restric
   const f32x4 be = *reinterpret_cast<const f32x4*>(lb + 4 * q);
   TA* yb = y + (long)b * H * W * C;
 #pragma unroll
-  for (int p = 0; p < 16; ++p) {
+  for (int p = 0; p < NP; ++p) {
     const int t = p & 7, rr = p >> 3;
     if (x0 + t < W && y0 + rr < H) {
       const f32x4 v = rr ? acc1[t] : acc0[t];
@@ -1048,23 +1052,33 @@ static int dwconv7_ln_impl(const TA* x, const float* w_dw, const float* b_dw, co
   }
   static const int wide_env = []() { const char* e = getenv("KPF_DW_WIDE"); return e ? atoi(e) : 1; }();  // tuning aid
   if (wide_env && C4 > 64 && C4 <= 256 && H * W >= 16) {
-    const int xstrips = (W + 7) / 8, ypairs = (H + 1) / 2;
+    const int xstrips = (W + 7) / 8;
+    // one-row strips while two-row strips would leave half the CUs without a workgroup (KPF_DW_WIDE_ROWS=1|2 forces a form: tuning aid)
+    static const int rows_env = []() { const char* e = getenv("KPF_DW_WIDE_ROWS"); return e ? atoi(e) : 0; }();
+    const bool one_row = rows_env ? rows_env == 1 : (long)B * ((H + 1) / 2) * xstrips < 256;
+    const int ypairs = one_row ? H : (H + 1) / 2;  // row groups
     const dim3 grid((unsigned)((long)B * ypairs * xstrips));
-#define KPF_DWX(NT)                                                                                                                            \
+#define KPF_DWX2(NT, ROWS)                                                                                                                     \
   do {                                                                                                                                         \
     if constexpr (F32) {                                                                                                                       \
       if (split) {                                                                                                                             \
-        hipLaunchKernelGGL((dwconv7_ln_wide_kernel<TA, NT, true>), grid, dim3(NT), 0, st, x, w_dw, b_dw, ln_w, ln_b, y, B, H, W, C, xstrips,   \
-                           ypairs, eps);                                                                                                       \
+        hipLaunchKernelGGL((dwconv7_ln_wide_kernel<TA, NT, true, ROWS>), grid, dim3(NT), 0, st, x, w_dw, b_dw, ln_w, ln_b, y, B, H, W, C,      \
+                           xstrips, ypairs, eps);                                                                                              \
         break;                                                                                                                                 \
       }                                                                                                                                        \
     }                                                                                                                                          \
-    hipLaunchKernelGGL((dwconv7_ln_wide_kernel<TA, NT, false>), grid, dim3(NT), 0, st, x, w_dw, b_dw, ln_w, ln_b, y, B, H, W, C, xstrips,      \
-                       ypairs, eps);                                                                                                           \
+    hipLaunchKernelGGL((dwconv7_ln_wide_kernel<TA, NT, false, ROWS>), grid, dim3(NT), 0, st, x, w_dw, b_dw, ln_w, ln_b, y, B, H, W, C,         \
+                       xstrips, ypairs, eps);                                                                                                  \
+  } while (0)
+#define KPF_DWX(NT)                                                                                                                            \
+  do {                                                                                                                                         \
+    if (one_row) KPF_DWX2(NT, 1);                                                                                                              \
+    else KPF_DWX2(NT, 2);                                                                                                                      \
   } while (0)
     if (C4 <= 128) KPF_DWX(128);
     else if (C4 <= 192) KPF_DWX(192);
     else KPF_DWX(256);
+#undef KPF_DWX2
 #undef KPF_DWX
     return kpf_check_launch("kpf_dwconv7_ln");
   }

@@ -157,6 +157,35 @@ def test_dwconv7_ln(C, H, W):
     assert rel_err(to_nchw(ya), ref) < 2e-5
 
 
+@pytest.mark.parametrize("C,H,W", [(384, 8, 8), (768, 4, 4), (512, 9, 11)])
+def test_dwconv7_ln_wide_forms_agree_bitwise(C, H, W):
+    """The wide depthwise + LayerNorm kernel takes one-row strips while two-row strips would leave CUs without a workgroup (small batches) and two-row strips
+    otherwise: a sample's result must not depend on the batch it arrives in — image 0 of a 2-image launch (one-row form) and of a 72-image launch (two-row
+    form) are the same bits, in fp32 and in 16-bit storage."""
+    import ctypes
+    from keypointfusion_amd import engine as E, lib as L
+    dev = _dev()
+    lib = L.load()
+    g = torch.Generator().manual_seed(C + H)
+    xb = torch.randn(72, H, W, C, generator=g)
+    wdd = (torch.randn(49, C, generator=g) / 7).to(dev)
+    bdd, lwd, lbd = torch.randn(C, generator=g).to(dev), (torch.rand(C, generator=g) + 0.5).to(dev), torch.randn(C, generator=g).to(dev)
+    for tdt, kdt in ((torch.float32, None), (torch.bfloat16, L.KPF_DT_BF16), (torch.float16, L.KPF_DT_F16)):
+        outs = []
+        for B in (2, 72):
+            x = xb[:B].to(tdt).contiguous().to(dev)
+            y = torch.full_like(x, float("nan"))
+            if kdt is None:
+                L.check(lib.kpf_dwconv7_ln_f32(E._ptr(x), E._ptr(wdd), E._ptr(bdd), E._ptr(lwd), E._ptr(lbd), E._ptr(y), B, H, W, C, 1e-6, E._stream()))
+            else:
+                L.check(lib.kpf_dwconv7_ln_h16(E._ptr(x), E._ptr(wdd), E._ptr(bdd), E._ptr(lwd), E._ptr(lbd), E._ptr(y), B, H, W, C, 1e-6, kdt, E._stream()))
+            outs.append(y[:2].float().cpu())
+        assert bool(torch.isfinite(outs[0]).all()) and torch.equal(outs[0], outs[1]), (C, tdt)
+        ref = F.layer_norm(F.conv2d(xb[:2].to(tdt).float().permute(0, 3, 1, 2), wdd.cpu().t().reshape(C, 1, 7, 7), bdd.cpu(), padding=3, groups=C).permute(0, 2, 3, 1),
+                           (C,), lwd.cpu(), lbd.cpu(), 1e-6)
+        assert rel_err(outs[0], ref) < (2e-5 if kdt is None else (1.2e-2 if tdt == torch.bfloat16 else 2e-3))
+
+
 def test_layernorm_upsample_maxpool_repack():
     from keypointfusion_amd import engine as E
     dev = _dev()
