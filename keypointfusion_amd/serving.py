@@ -75,8 +75,8 @@ class PipelinedEval:
             if self._head_done[slot] is not None:
                 sa.wait_event(self._head_done[slot])  # the batch that used this slot last has read its inputs and the backbones' outputs
             with torch.cuda.stream(sa):
-                for d, t in zip(static, ins):
-                    d.copy_(t)
+                torch._foreach_copy_(static, ins)
+                for t in ins:
                     t.record_stream(sa)
                 ga.replay()
                 ev_bb = torch.cuda.Event()
@@ -84,7 +84,9 @@ class PipelinedEval:
             with torch.cuda.stream(sb):
                 sb.wait_event(ev_bb)
                 gb.replay()
-                res, sws = [t.clone() for t in res], [t.clone() for t in sws]
+                outs = [torch.empty_like(t) for t in res + sws]
+                torch._foreach_copy_(outs, res + sws)
+                res, sws = outs[:len(res)], outs[len(res):]
                 ev = torch.cuda.Event()
                 ev.record(sb)
             self._head_done[slot] = ev
