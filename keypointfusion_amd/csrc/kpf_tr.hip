@@ -150,7 +150,13 @@ __device__ __forceinline__ void attention(const float* q, int ldq, const float* 
     const float* kp = k + j * ldk + h * HD;
     float s = 0.f;
 #pragma unroll
-    for (int d = 0; d < HD; ++d) s = fmaf(qp[d], kp[d], s);
+    for (int d = 0; d < HD; d += 4) {  // (rows are 16-byte aligned: ldq / ldk are multiples of 4 floats; same order of the 32 multiply-adds as one by one)
+      const f32x4 qv = *reinterpret_cast<const f32x4*>(qp + d), kv = *reinterpret_cast<const f32x4*>(kp + d);
+      s = fmaf(qv[0], kv[0], s);
+      s = fmaf(qv[1], kv[1], s);
+      s = fmaf(qv[2], kv[2], s);
+      s = fmaf(qv[3], kv[3], s);
+    }
     S[item] = s * qscale;
   }
   __syncthreads();
@@ -168,13 +174,18 @@ __device__ __forceinline__ void attention(const float* q, int ldq, const float* 
     for (int j = 0; j < T; ++j) sp[j] *= inv;
   }
   __syncthreads();
-  for (int item = threadIdx.x; item < T * H; item += NTHR) {
-    const int i = item / H, c = item - i * H, h = c / HD;
+  for (int item = threadIdx.x; item < T * (H / 4); item += NTHR) {  // four channels per item: one 16-byte read of v per probability (same sums per channel)
+    const int i = item / (H / 4), c = 4 * (item - i * (H / 4)), h = c / HD;
     const float* sp = S + (h * T + i) * T;
-    float a = 0.f;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < T; ++j) a = fmaf(sp[j], v[j * ldv + c], a);
-    ctx[i * ldc + c] = a;
+    for (int j = 0; j < T; ++j) {
+      const float pj = sp[j];
+      const f32x4 vv = *reinterpret_cast<const f32x4*>(v + j * ldv + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] = fmaf(pj, vv[e], a[e]);
+    }
+    *reinterpret_cast<f32x4*>(ctx + i * ldc + c) = a;
   }
   __syncthreads();
 }
