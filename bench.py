@@ -57,6 +57,7 @@ WORKLOADS = {
     "backbones256": ("KPFusion-convnext-tiny", 256, 64, "f32", "backbones", "configs[1]"),
     "full128": ("KPFusion-convnext-tiny", 128, 64, "f32", "full", "full model at configs[1]'s batch"),
     "full128_bf16": ("KPFusion-convnext-tiny", 128, 32, "bf16", "full", "configs[2]"),
+    "full128_bf16_r18": ("KPFusion-resnet-18", 128, 32, "bf16", "full", "configs[2] with the ResNet-18 backbones (SURVEY 8d config 3 names both families)"),
     # the full model at the crop size BASELINE's metric is quoted on: the labelled wide extension (KPFusion(..., crop_size=256): fc_spatial2joint_feature sized
     # for the 64 x 64 feature map; the reference hard-codes 32 x 32 and cannot run this size) — not a reference configuration
     "full256": ("KPFusion-convnext-tiny", 256, 64, "f32", "full", "full model at configs[1]'s batch and crop size: wide extension, not a reference configuration"),
