@@ -59,6 +59,11 @@ class PipelinedEval:
         slot = self._next
         self._next = (self._next + 1) % self.depth
         cur = torch.cuda.current_stream(dev)
+        if cur == torch.cuda.default_stream(dev) and not getattr(self, "_warned_default", False):
+            self._warned_default = True
+            import warnings
+            warnings.warn("PipelinedEval.submit() called on the device's default stream: the batches in flight will run one after the other "
+                          "(use `with torch.cuda.stream(pe.feed_stream(device)):` around the loop; see keypointfusion_amd/serving.py)", RuntimeWarning, stacklevel=2)
         img_size, flip = int(getattr(loader, "img_size", m.crop_size)), int(getattr(loader, "flip", 1))
         if not self.stages:
             st = self._streams[slot]
