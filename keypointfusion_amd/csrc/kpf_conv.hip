@@ -1967,10 +1967,22 @@ extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const flo
   // f32 arithmetic, 128 x 192 tiles (80 KB of LDS: exactly two workgroups per CU): taken when they make the tile count a whole number of
   // 512-workgroup rounds and the cost model's choice does not (stage-4 pwconv1: 4096 x 3072 -> 512 tiles instead of 768 of 128 x 128,
   // which the dispatcher spreads 2..4 per CU)
-  if (!(fl & (KPF_IN_SPLIT | KPF_W_SPLIT)) && !pro_scale && a.M % 128 == 0 && a.N % 192 == 0) {
+  const bool f32_arith = !(fl & (KPF_IN_SPLIT | KPF_W_SPLIT));
+  const bool gelu1x1 = f32_arith && is1x1 && (fl & KPF_ACT_GELU) && !(fl & KPF_ACT_GELU_SAVE) && !pro_scale && d->groups <= 1;
+  if (f32_arith && !gelu1x1 && !pro_scale && a.M % 128 == 0 && a.N % 192 == 0) {
     const long b192 = (long)(a.M / 128) * (a.N / 192);
     const long bb = ((a.M + kCfgs[best].bm - 1) / kCfgs[best].bm) * ((a.N + kCfgs[best].bn - 1) / kCfgs[best].bn);
     if (b192 % 512 == 0 && bb % 512 != 0 && bb > 256) best = 17;
+  }
+  // Round 5 (per-shape search over every launch of the headline, tools/exp_autotune_dump.py, then the rule sets timed in the overlapped step,
+  // tools/exp_rules.sh): (i) the wide GELU layers (pwconv1: N = 4C) take the 256 x 128 eight-wave tile when it gives every CU two tiles, else 128 x 128 —
+  // 16384 x 1536 x 384: 152 us against 174 for the 128 x 192 tile the round rule above used to force, 4096 x 3072 x 768: 157 against 168, 65536 x 768 x 192:
+  // 175 against 183; (ii) a long-K layer whose best tile leaves the chip under one round of workgroups takes 32 x 64 tiles when they make two rounds
+  // (4096 x 384 x 3456 3x3: 117 against 135 us; 4096 x 384 x 768: 30 against 33).  Step: 18.73 -> 18.25 ms.  Same k order in every tile shape: same bits.
+  if (gelu1x1 && a.M >= 4096 && a.N >= 512) best = ((long)((a.M + 255) / 256) * ((a.N + 127) / 128) >= 512) ? 8 : 0;
+  if (f32_arith && best < 9 && a.Kp >= 512 && d->groups <= 1) {
+    const long bb = ((a.M + kCfgs[best].bm - 1) / kCfgs[best].bm) * ((a.N + kCfgs[best].bn - 1) / kCfgs[best].bn);
+    if (bb < 256 && (long)((a.M + 31) / 32) * ((a.N + 63) / 64) >= 512) best = 7;
   }
   // split arithmetic without a residual epilogue: the single-stage, 4-waves-per-SIMD variant of the 128 x 128 tile is 4-10 % faster
   // than the double-buffered 128 x 128 / 256 x 128 ones (its residual epilogue would spill at 128 registers, so those keep two stages)

@@ -32,6 +32,8 @@ F16_MAX = 65504.0
 # timed in isolation it makes the GEMMs 4 % faster (7.63 vs 7.96 ms per step), but with the two backbones overlapped on two streams
 # the step gets slower (10.77 vs 10.42 ms) — the isolated optimum fills the whole chip and leaves nothing for the other stream.
 AUTOTUNE = bool(int(__import__("os").environ.get("KPF_AUTOTUNE", "0")))
+# experiment: per-shape tile overrides "M:N:K:kh=cfg,..." (cfg = configuration index)
+_TILE_RULES = {tuple(int(v) for v in r.split("=")[0].split(":")): int(r.split("=")[1]) + 1 for r in __import__("os").environ.get("KPF_TILE_RULES", "").split(",") if r}
 
 
 # Per-launch profiling hook (bench.py): when PROFILE is a list, every MFMA-kernel launch is bracketed by HIP events recorded on
@@ -237,6 +239,8 @@ def conv(pc, x, out=None, flags=0, gamma=None, res=None, out_nchw=None, out_spli
         if cfg is None and PROFILE is None and not torch.cuda.is_current_stream_capturing():
             cfg = pc.tuned[key] = _autotune(lib, d, x, w, pc, gamma, res, optr, flags)
         d.tile_cfg = cfg or 0
+    if _TILE_RULES and not AUTOTUNE:
+        d.tile_cfg = _TILE_RULES.get((M, pc.N, pc.K, pc.KH), 0)
     if FORCE_TILE:
         d.tile_cfg = FORCE_TILE
     # algorithmic bytes: input pixels once, weights once, output once (+ residual once)
