@@ -1975,11 +1975,19 @@ extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const flo
     if (b192 % 512 == 0 && bb % 512 != 0 && bb > 256) best = 17;
   }
   // Round 5 (per-shape search over every launch of the headline, tools/exp_autotune_dump.py, then the rule sets timed in the overlapped step,
-  // tools/exp_rules.sh): (i) the wide GELU layers (pwconv1: N = 4C) take the 256 x 128 eight-wave tile when it gives every CU two tiles, else 128 x 128 —
+  // tools/exp_rules.sh): (i) the wide GELU layers (pwconv1: N = 4C) choose between 128 x 128 and the 256 x 128 eight-wave tile by whole rounds of the chip —
   // 16384 x 1536 x 384: 152 us against 174 for the 128 x 192 tile the round rule above used to force, 4096 x 3072 x 768: 157 against 168, 65536 x 768 x 192:
   // 175 against 183; (ii) a long-K layer whose best tile leaves the chip under one round of workgroups takes 32 x 64 tiles when they make two rounds
   // (4096 x 384 x 3456 3x3: 117 against 135 us; 4096 x 384 x 768: 30 against 33).  Step: 18.73 -> 18.25 ms.  Same k order in every tile shape: same bits.
-  if (gelu1x1 && a.M >= 4096 && a.N >= 512) best = ((long)((a.M + 255) / 256) * ((a.N + 127) / 128) >= 512) ? 8 : 0;
+  if (gelu1x1 && a.M >= 1024 && a.N >= 512) {
+    // whole-CU-round cost of the two wide tiles; ties go to the smaller one
+    auto rounds_cost = [&](int bm, int bn, double pen) { return (double)((((long)(a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) + 255) / 256) * bm * bn * pen; };
+    // (128 x 192 is left out on purpose: alone it wins where it makes whole rounds — 4096 x 1536 x 384: 45 us against 58, 16384 x 384 x 1536 + residual: 147
+    //  against 153 — and in the overlapped step it loses every time it was tried: its 80 KB of LDS leave no room for the other stream's workgroups;
+    //  headline 3471 against 3508 img/s with it on the stage-3 residual layer, full128 9 800 against 9 970 with it on pwconv1)
+    const double c0 = rounds_cost(128, 128, 1.00), c8 = rounds_cost(256, 128, 0.97);
+    best = c0 <= c8 ? 0 : 8;
+  }
   if (f32_arith && best < 9 && a.Kp >= 512 && d->groups <= 1) {
     const long bb = ((a.M + kCfgs[best].bm - 1) / kCfgs[best].bm) * ((a.N + kCfgs[best].bn - 1) / kCfgs[best].bn);
     if (bb < 256 && (long)((a.M + 31) / 32) * ((a.N + 63) / 64) >= 512) best = 7;

@@ -37,7 +37,8 @@ def tuned(lib_, d, x, w, pc, gamma, res, optr, flags):
 E._autotune = tuned
 plan = E.ModelPlan(synthetic_sd(net), net, dev, precision="f32")
 g = torch.Generator().manual_seed(0)
-img = torch.randn(64, 1, 256, 256, generator=g).to(dev); rgb = torch.randn(64, 3, 256, 256, generator=g).to(dev)
+B, S = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (64, 256)
+img = torch.randn(B, 1, S, S, generator=g).to(dev); rgb = torch.randn(B, 3, S, S, generator=g).to(dev)
 plan.serial_streams = True
 with torch.no_grad():
     plan.backbones(img, rgb)
