@@ -1852,6 +1852,17 @@ extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void
       else if (b64 <= 512) best = 41;
     }
   }
+  // End of round 5 (per-shape search over every 16-bit launch of configs[4], tools/exp_autotune16_dump.py, the picks then timed in the step,
+  // tools/exp_rules16.sh): the k x k convolutions (3 x 3 decoder layers, 2 x 2 downsampling) were left on 128 x 128 tiles; with one round of 256 x 256
+  // (else 256 x 128) tiles available they run 33-58 % faster alone — 16384 x 512 x 4608: 187 -> 79 us, 262144 x 256 x 512 (2 x 2): 219 -> 122,
+  // 65536 x 256 x 2304: 131 -> 80, 262144 x 128 x 1152: 152 -> 104 — and the 64-channel 3 x 3 layers take 128 x 64 (146 -> 127).  Step: 42.6 -> 41.3 ms.
+  static const bool no_kxk = getenv("KPF_NO_KXK16") != nullptr;  // tuning aid
+  if (!no_kxk && !pointwise && !pro_scale && a.groups <= 1 && !(fl & (KPF_RES_GELU_GRAD | KPF_ACT_GELU_SAVE | KPF_OUT_NCHW)) && a.M >= 16384) {
+    const long tm256 = ((long)a.M + 255) / 256;
+    if (a.N % 256 == 0 && tm256 * (a.N / 256) >= 256) best = 26;
+    else if (a.N % 128 == 0 && tm256 * (a.N / 128) >= 256) best = 8;
+    else if (a.N == 64) best = 2;
+  }
   static const int forced = []() { const char* e = getenv("KPF_FORCE_CFG16"); return e ? atoi(e) : -1; }();  // tuning aid only
   if (forced >= 0 && (forced != 30 || ok8)) best = forced;
   if (d->tile_cfg > 0 && (d->tile_cfg != 31 || ok8)) best = d->tile_cfg - 1;  // the caller's choice (tools/h16_small_sweep.py): case index + 1

@@ -21,6 +21,8 @@ LN_FOLD = bool(int(__import__("os").environ.get("KPF_LN_FOLD", "1")))  # LayerNo
 DW_STATS_MIN_C = int(__import__("os").environ.get("KPF_DW_STATS_MIN_C", "256"))  # (at C = 128 the one-pass wave kernel is still faster: 311 vs 363 us)
 
 
+# experiment (tools/exp_rules16.sh): per-shape tile overrides "M:N:K:kh=case,..."
+_TILE_RULES16 = {tuple(int(v) for v in r.split("=")[0].split(":")): int(r.split("=")[1]) + 1 for r in __import__("os").environ.get("KPF_TILE_RULES16", "").split(",") if r}
 FORCE_TILE16 = 0  # tuning aid (tools/h16_small_sweep.py): tile case + 1 for every kpf_conv2d_h16 launch, 0 = the library's choice
 
 
@@ -90,6 +92,8 @@ def conv16(p16, x, kdt, out=None, flags=0, gamma=None, res=None, out_nchw=None, 
         ps, pt, bias = ln
     d.flags = flags
     d.groups, d.w_gstride = getattr(pc, "groups", 0), getattr(pc, "w_gstride", 0)  # (grouped launch: training.GroupedPack; 0 = one convolution)
+    if _TILE_RULES16:
+        d.tile_cfg = _TILE_RULES16.get((B * OH * OW, pc.N, pc.K, pc.KH), 0)
     if FORCE_TILE16:
         d.tile_cfg = FORCE_TILE16
     if probe:
