@@ -1,0 +1,68 @@
+"""Per-shape tile search over the GEMM launches (forward + data gradient) of ONE eager training iteration (B = 32, 128 x 128, bf16 by default): the dispatcher's
+choice against every tile case, isolated launches, with the number of launches per iteration of each shape."""
+import os, sys, collections, ctypes as C
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests")
+import torch
+from conftest import synthetic_sd
+from keypointfusion_amd import training as T, lib as L
+from keypointfusion_amd.model.model import KPFusion
+from keypointfusion_amd.weights import synthetic_batch
+prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+B = 32
+net = "KPFusion-convnext-tiny"; dev = torch.device("cuda:0")
+lib = L.load()
+batch = {k: torch.from_numpy(v).to(dev) for k, v in synthetic_batch(B, 128, seed=5).items()}
+g = torch.Generator().manual_seed(1)
+uvd = (torch.rand(B, 21, 3, generator=g) * 1.2 - 0.6).to(dev); xyz = (torch.rand(B, 21, 3, generator=g) * 1.2 - 0.6).to(dev)
+class Loader: img_size, flip = 128, 1
+m = KPFusion(net, "", 21, "dexycb", ""); m.load_state_dict(synthetic_sd(net), strict=True); m = m.to(dev).train(); m.train_dropout = 0.1
+m.precision = prec
+def it():
+    for p in m.parameters(): p.grad = None
+    r, s, _ = m(batch["img_rgb"], batch["img"], batch["pcl"], Loader(), batch["center"], batch["M"], batch["cube"], batch["cam_para"], 0.8)
+    T.kpfusion_loss(r, s, batch["img"], uvd, xyz, epoch=0)[0].backward()
+it(); it(); torch.cuda.synchronize()
+CASES16 = (0, 1, 2, 5, 6, 8, 20, 21, 22, 26, 41, 44)
+CASES32 = tuple(range(9)) + (17,)
+seen, count = {}, collections.Counter()
+def hook(name, real, cases):
+    def timed(d, *args):
+        rc = real(d, *args)
+        dd = d._obj
+        key = (name, dd.B * dd.OH * dd.OW, dd.N, dd.KH * dd.KW * dd.Cin, dd.KH, dd.flags, max(1, dd.groups))
+        count[key] += 1
+        if key in seen:
+            return rc
+        times, keep = {}, dd.tile_cfg
+        for c in (None,) + cases:
+            dd.tile_cfg = 0 if c is None else c + 1
+            if real(d, *args) != 0:
+                continue
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                real(d, *args)
+            e1.record(); e1.synchronize()
+            times[c] = e0.elapsed_time(e1) / 5 * 1e3
+        dd.tile_cfg = keep
+        seen[key] = times
+        return rc
+    return timed
+lib.kpf_conv2d_h16 = hook("h16", lib.kpf_conv2d_h16, CASES16)
+lib.kpf_conv2d_f32 = hook("f32", lib.kpf_conv2d_f32, CASES32)
+it(); torch.cuda.synchronize()
+tot_d = tot_b = 0.0
+rows = []
+for key, times in seen.items():
+    cand = {c: t for c, t in times.items() if c is not None}
+    if None not in times or not cand:
+        continue
+    best = min(cand, key=cand.get)
+    n = count[key]
+    rows.append((n * (times[None] - cand[best]), key, n, times[None], best, cand[best], cand))
+    tot_d += n * times[None]; tot_b += n * cand[best]
+print("GEMM launches of one iteration: %.2f ms with the dispatcher's tiles, %.2f ms with the isolated best of every shape" % (tot_d / 1e3, tot_b / 1e3))
+for gain, key, n, td, best, tb, cand in sorted(rows, key=lambda r: -r[0])[:40]:
+    print("%-3s M=%-6d N=%-5d K=%-5d k%d fl=%-5d G=%d x%-3d default %6.1f us | best %2d %6.1f us | saves %6.1f us/iter | %s" % (key[0], key[1], key[2], key[3], key[4], key[5], key[6], n, td, best, tb, gain,
+          " ".join("%d:%.0f" % (c, t) for c, t in sorted(cand.items()))))
