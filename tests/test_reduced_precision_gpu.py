@@ -50,6 +50,13 @@ def rel(a, b):
     (4, 1024, 64, 64, 256, 1, 1, 0, "res"),    # M = 16384, long K, N % 256 == 0: the 256 x 256-tile configuration (ConvNeXt-B pwconv2)
     (5, 2048, 60, 60, 512, 1, 1, 0, "res"),    # ... with a ragged last M tile (M = 18000)
     (16, 512, 32, 32, 2048, 1, 1, 0, "gelu"),  # M = 16384, ConvNeXt-B pwconv1 at stage 3
+    # k x k convolutions large enough for the round-5 tile rules (kpf_conv2d_h16: >= 16384 pixels): 64 channels -> 128 x 64 tiles, N % 128 == 0 with a
+    # round of 256 x 128 tiles, N % 256 == 0 with a round of 256 x 256 tiles; a ragged last row tile; the residual epilogue of a ResNet block
+    (4, 64, 64, 64, 64, 3, 1, 1, "relu"),
+    (16, 32, 64, 64, 128, 3, 1, 1, "relu"),
+    (17, 32, 60, 65, 256, 3, 1, 1, "relu"),
+    (16, 64, 64, 64, 256, 3, 1, 1, "res"),
+    (16, 64, 128, 128, 256, 2, 2, 0, "patch"),
 ])
 def test_conv2d_h16_is_the_fp32_conv_of_the_rounded_operands(case, prec):
     from keypointfusion_amd import lib as L
