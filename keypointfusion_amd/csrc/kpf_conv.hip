@@ -1846,7 +1846,10 @@ extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void
   // wide-N short-K layers lose and keep the two-stage tiles).  Same k order in every tile shape: results stay bit-identical.
   static const bool no_ring = getenv("KPF_NO_RING16") != nullptr;  // tuning aid
   if (!no_ring && best != 30 && !pro_scale && !(fl & KPF_RES_GELU_GRAD)) {
-    const long nk = a.Kp / BK, b64 = (((long)a.M + 63) / 64) * (((long)a.N + 63) / 64);
+    const long nk = a.Kp / BK, b64 = (((long)a.M + 63) / 64) * (((long)a.N + 63) / 64) * a.groups;  // (a grouped launch has that many tiles per group:
+                                                                                                     // the training step's paired backbones took the 32 x 64
+                                                                                                     // form where their two groups fill the 64 x 64 one —
+                                                                                                     // 512 x 768 x 3072 x 2: 25 -> 16 us)
     if (nk >= 6 && 4L * a.Kp >= a.N) {  // (Kp counts 4-byte words: K >= N / 2 elements — every measured winner; wide-N short-K layers are not)
       if (b64 <= 128) best = 44;
       else if (b64 <= 512) best = 41;

@@ -34,8 +34,8 @@ def hook(name, real, cases):
         if key in seen:
             return rc
         times, keep = {}, dd.tile_cfg
-        for c in (None,) + cases:
-            dd.tile_cfg = 0 if c is None else c + 1
+        for c in (None,) + cases + ("again",):  # (the dispatcher's choice is timed first AND last: the first launch of a shape is a cold one)
+            dd.tile_cfg = 0 if c in (None, "again") else c + 1
             if real(d, *args) != 0:
                 continue
             torch.cuda.synchronize()
@@ -46,6 +46,8 @@ def hook(name, real, cases):
             e1.record(); e1.synchronize()
             times[c] = e0.elapsed_time(e1) / 5 * 1e3
         dd.tile_cfg = keep
+        if "again" in times:
+            times[None] = min(times[None], times.pop("again"))
         seen[key] = times
         return rc
     return timed
