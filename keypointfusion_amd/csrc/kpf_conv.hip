@@ -946,9 +946,9 @@ struct Cfg {
 static const Cfg kCfgs[] = {{128, 128, 1.00}, {128, 96, 1.03}, {128, 64, 1.10}, {256, 48, 1.10}, {128, 112, 1.03},
                             {64, 128, 1.10},  {64, 64, 1.25},  {32, 64, 1.60},  {256, 128, 0.97}};
 
-double cfg_cost(const Cfg& c, long M, long N) {
+double cfg_cost(const Cfg& c, long M, long N, int groups = 1) {  // (a grouped launch runs `groups` times the tiles in the same rounds of the chip)
   const long tm = (M + c.bm - 1) / c.bm, tn = (N + c.bn - 1) / c.bn;
-  const long blocks = tm * tn;
+  const long blocks = tm * tn * (groups > 1 ? groups : 1);
   const long rounds = (blocks + 255) / 256;
   return (double)rounds * c.bm * c.bn * c.pen;
 }
@@ -1824,6 +1824,7 @@ extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void
   double bc = 1e30;
   static const int allowed[] = {0, 1, 2, 5, 6, 7};
   for (int i : allowed) {
+    // groups not counted here: measured no change on the grouped 16-bit launches of the training step
     const double c = cfg_cost(kCfgs[i], a.M, a.N);
     if (c < bc) { bc = c; best = i; }
   }
@@ -1975,7 +1976,7 @@ extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const flo
   double bc = 1e30;
   static const int forced = []() { const char* e = getenv("KPF_FORCE_CFG"); return e ? atoi(e) : -1; }();  // tuning aid only
   for (int i = 0; i < (int)(sizeof(kCfgs) / sizeof(kCfgs[0])); ++i) {
-    const double c = cfg_cost(kCfgs[i], a.M, a.N);
+    const double c = cfg_cost(kCfgs[i], a.M, a.N, a.groups);
     if (c < bc) { bc = c; best = i; }
   }
   // f32 arithmetic, 128 x 192 tiles (80 KB of LDS: exactly two workgroups per CU): taken when they make the tile count a whole number of
@@ -1983,11 +1984,9 @@ extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const flo
   // which the dispatcher spreads 2..4 per CU)
   const bool f32_arith = !(fl & (KPF_IN_SPLIT | KPF_W_SPLIT));
   const bool gelu1x1 = f32_arith && is1x1 && (fl & KPF_ACT_GELU) && !(fl & KPF_ACT_GELU_SAVE) && !pro_scale && d->groups <= 1;
-  if (f32_arith && !gelu1x1 && !pro_scale && a.M % 128 == 0 && a.N % 192 == 0) {
-    const long b192 = (long)(a.M / 128) * (a.N / 192);
-    const long bb = ((a.M + kCfgs[best].bm - 1) / kCfgs[best].bm) * ((a.N + kCfgs[best].bn - 1) / kCfgs[best].bn);
-    if (b192 % 512 == 0 && bb % 512 != 0 && bb > 256) best = 17;
-  }
+  // (The round rule that forced 128 x 192 tiles wherever they make whole 512-workgroup rounds is gone: the per-shape search found it 13-40 % slower than the cost
+  //  model's own choice on the layers it caught — 16384 x 1536 x 384 + GELU 174 against 152 us, the training step's 32768 x 384 x 96 data gradient 116 against
+  //  70 — and in the overlapped step the tile loses even where it wins alone.  The configuration stays selectable: tile_cfg = 18.)
   // Round 5 (per-shape search over every launch of the headline, tools/exp_autotune_dump.py, then the rule sets timed in the overlapped step,
   // tools/exp_rules.sh): (i) the wide GELU layers (pwconv1: N = 4C) choose between 128 x 128 and the 256 x 128 eight-wave tile by whole rounds of the chip —
   // 16384 x 1536 x 384: 152 us against 174 for the 128 x 192 tile the round rule above used to force, 4096 x 3072 x 768: 157 against 168, 65536 x 768 x 192:
@@ -2002,9 +2001,9 @@ extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const flo
     const double c0 = rounds_cost(128, 128, 1.00), c8 = rounds_cost(256, 128, 0.97);
     best = c0 <= c8 ? 0 : 8;
   }
-  if (f32_arith && best < 9 && a.Kp >= 512 && d->groups <= 1) {
-    const long bb = ((a.M + kCfgs[best].bm - 1) / kCfgs[best].bm) * ((a.N + kCfgs[best].bn - 1) / kCfgs[best].bn);
-    if (bb < 256 && (long)((a.M + 31) / 32) * ((a.N + 63) / 64) >= 512) best = 7;
+  if (f32_arith && best < 9 && a.Kp >= 512) {
+    const long bb = ((a.M + kCfgs[best].bm - 1) / kCfgs[best].bm) * ((a.N + kCfgs[best].bn - 1) / kCfgs[best].bn) * a.groups;
+    if (bb < 256 && (long)((a.M + 31) / 32) * ((a.N + 63) / 64) * a.groups >= 512) best = 7;
   }
   // split arithmetic without a residual epilogue: the single-stage, 4-waves-per-SIMD variant of the 128 x 128 tile is 4-10 % faster
   // than the double-buffered 128 x 128 / 256 x 128 ones (its residual epilogue would spill at 128 registers, so those keep two stages)
