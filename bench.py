@@ -323,9 +323,12 @@ def main():
     if loop_stream is not None:
         loop_stream.wait_stream(torch.cuda.current_stream(dev))  # the synthetic batch was produced on the default stream
 
+    def on_loop_stream():
+        return torch.cuda.stream(loop_stream) if loop_stream is not None else contextlib.nullcontext()
+
     def timed(K, W):
         """W untimed steps, then exactly K steps between barrier + synchronize pairs; returns (seconds, host issue seconds)."""
-        with torch.cuda.stream(loop_stream) if loop_stream is not None else contextlib.nullcontext():
+        with on_loop_stream():
             for _ in range(W):
                 step()
             barrier()
@@ -402,7 +405,8 @@ def main():
     fresh_plan()
     if graph_on[0]:
         try:
-            step()
+            with on_loop_stream():
+                step()
             torch.cuda.synchronize()
         except Exception as e:  # noqa: BLE001
             print("bench.py: hipGraph capture failed (%s: %s); falling back to eager launches" % (type(e).__name__, e), file=sys.stderr)
@@ -474,7 +478,8 @@ def main():
         try:
             E.GEMM_MODE = "split"
             fresh_plan()
-            step()
+            with on_loop_stream():
+                step()
             torch.cuda.synchronize()
             dts, _ = timed(args.steps, max(2, args.warmup))
             split_rec = {"value": round(B * args.steps / dts, 2), "unit": "img/s", "ms_per_step": round(dts / args.steps * 1e3, 3), "launch": launch_mode,
