@@ -12,12 +12,17 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define MIXL(i) "v_fma_mix_f32 %" #i ", %16, %17, %" #i " op_sel_hi:[1,0,0]\n"
 #define MIXH(i) "v_fma_mix_f32 %" #i ", %16, %17, %" #i " op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
 
+#define DOT2H(i) "v_dot2_f32_f16 %" #i ", %16, %17, %" #i "\n"
+#define DOT2B(i) "v_dot2_f32_bf16 %" #i ", %16, %17, %" #i "\n"
+#define PERM(i) "v_perm_b32 %" #i ", %" #i ", %16, %17\n"
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k(float* out, int iters) {
   float c[16];
   for (int i = 0; i < 16; ++i) c[i] = threadIdx.x * 1e-3f + i;
   float a = 1.0f + threadIdx.x * 1e-6f, b = 0.999f;
   unsigned h = 0x3c003c00u + threadIdx.x;  // two halves near 1.0
+  unsigned h2 = 0x3bff3bffu - threadIdx.x;
   f32x2 p[8], pa = {a, a}, pb = {b, b};
   for (int i = 0; i < 8; ++i) p[i] = f32x2{c[2 * i], c[2 * i + 1]};
   for (int it = 0; it < iters; ++it) {
@@ -31,6 +36,16 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
     } else if (MODE == 2) {  // 8 packed FMAs = the same 16 multiply-adds
 #pragma unroll
       for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[i]) : "v"(pa), "v"(pb));
+    } else if (MODE == 4) {  // two f16 x f16 products + an f32 addend per lane and instruction: a depthwise row's 7 taps as 4 of these (tap pairs per channel)
+      asm volatile(R16(DOT2H) : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]), "+v"(c[9]), "+v"(c[10]),
+                   "+v"(c[11]), "+v"(c[12]), "+v"(c[13]), "+v"(c[14]), "+v"(c[15]) : "v"(h), "v"(h2));
+    } else if (MODE == 5) {
+      asm volatile(R16(DOT2B) : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]), "+v"(c[9]), "+v"(c[10]),
+                   "+v"(c[11]), "+v"(c[12]), "+v"(c[13]), "+v"(c[14]), "+v"(c[15]) : "v"(h), "v"(h2));
+    } else if (MODE == 6) {  // the byte permute that would pair taps: (x[w][c0 c1], x[w+1][c0 c1]) -> (x[w][c0] x[w+1][c0])
+      unsigned* u = reinterpret_cast<unsigned*>(c);
+      asm volatile(R16(PERM) : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]), "+v"(u[8]), "+v"(u[9]), "+v"(u[10]),
+                   "+v"(u[11]), "+v"(u[12]), "+v"(u[13]), "+v"(u[14]), "+v"(u[15]) : "v"(h), "v"(0x05040100u));
     } else {  // MODE 3: 4 conversions feed 16 FMAs (the ratio of a 7-tap row: 14 x 4 conversions per 224 FMAs)
       float f0, f1, f2, f3;
       asm volatile("v_cvt_f32_f16 %0, %4\n v_cvt_f32_f16_sdwa %1, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"
@@ -78,6 +93,9 @@ int main() {
     run<1>("v_fma_mix_f32 (f16 lo/hi)", w, 16);
     run<2>("v_pk_fma_f32 (8 = 16 FMAs)", w, 8);
     run<3>("4 v_cvt_f32_f16 + 16 v_fma_f32", w, 20);
+    run<4>("v_dot2_f32_f16 (2 products each)", w, 16);
+    run<5>("v_dot2_f32_bf16 (2 products each)", w, 16);
+    run<6>("v_perm_b32", w, 16);
   }
   return 0;
 }
