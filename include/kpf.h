@@ -595,6 +595,30 @@ int kpf_layer_scale_backward_partial(const float* g, const void* y, int y_dtype,
                                      long rows, int C, kpf_colsum_desc* desc, void* stream);
 int kpf_colsum_reduce_grouped(const kpf_colsum_desc* descs, int n, void* stream);
 
+/* Training (ABI 16): the four BERT layers of a KP_Interaction_TR stack (21 tokens x 128, 4 heads x 32, intermediate 16, GELU-erf, post-LN eps 1e-12,
+ * hidden / attention dropout p_drop) as ONE launch per direction — replaces model/model.py:30-126 (transformers' BertEncoder under .train()) between the
+ * embedding Linear and the cls_head / residual heads.  csrc/kpf_trstack.hip: one workgroup per sample, weights streamed by dedicated loader waves from the
+ * parameter tensors as they lie in memory ([N][K] fp32, 16-byte aligned).
+ *   forward : H[0] = dropout(e + pos), then the four layers; e [B][21][128], pos [21][128]; param_table = DEVICE array of 4 x 16 pointers per layer in the order
+ *             Wq bq Wk bk Wv bv Wo bo ln1.w ln1.b Wi bi Wo2 bo2 ln2.w ln2.b; everything the backward needs goes to `save`
+ *             (kpf_tr_stack_save_floats(B) floats); the stack's output [B][21][128] is save + kpf_tr_stack_out_offset(B).
+ *             rng: the device-resident (seed, counter) pair of kpf_attn21_forward; call0: first of 13 consecutive dropout call ids.
+ *   backward: dh [B][21][128] -> dE [B][21][128] (gradient of e, and of pos after a sum over B); every Linear's dY goes to `dys`
+ *             (kpf_tr_stack_dy_floats(B)) beside the X kept in `save` (kpf_tr_stack_offset(B, layer, which): which 0-3 = X of q|k|v / attention output /
+ *             intermediate / output in `save`, 4-7 = dqkv [M][384] / d(attention output) / d(intermediate) [M][16] / d(output) in `dys`) for
+ *             kpf_linear_wgrad_grouped; LayerNorm parameter gradients leave as per-sample partial sums parts[layer][ln][B][2][128]
+ *             (kpf_tr_stack_part_floats(B); a kpf_colsum_desc with nblk = B, C = 128 each).  Dropout masks are recomputed from the (seed, counter) the
+ *             forward stored in `save`.  Fixed summation order: bit-identical replays. */
+long kpf_tr_stack_save_floats(int B);
+long kpf_tr_stack_out_offset(int B);
+long kpf_tr_stack_dy_floats(int B);
+long kpf_tr_stack_part_floats(int B);
+long kpf_tr_stack_offset(int B, int layer, int which);
+int kpf_tr_stack_train_forward(const float* e, const float* pos, const void* param_table, float* save, long save_floats, int B, float p_drop, const long* rng,
+                               int call0, void* stream);
+int kpf_tr_stack_train_backward(const float* dh, const void* param_table, const float* save, float* dE, float* dys, float* parts, int B, float p_drop,
+                                int call0, void* stream);
+
 /* Training: the two analytic maps of a fusion block (model/model.py:300-336) with their gradients towards the joints, one launch each:
  * hm[b][j][y][x] = GFM.joint2heatmap(uvd[..., :2], std, F, sigma) (util/generateFeature.py:584-600), duvd [B][J][3] (z component 0);
  * gam[b][j][p] = 1 / (10 |pix_xyz[b][p] - joint_xyz[b][j]|^2 + 1) (dataloader/loader.py:791-819), djoint [B][J][3].  fp32, contiguous. */
@@ -616,7 +640,7 @@ int kpf_conv_num_tile_cfgs(void);
 const char* kpf_last_error(void);
 /* Library/ABI version, bumped when a signature or the meaning of an argument changes (KPF_ABI_VERSION is what this header
  * describes; the Python binding refuses a library that reports another). */
-#define KPF_ABI_VERSION 15
+#define KPF_ABI_VERSION 16
 int kpf_abi_version(void);
 
 #ifdef __cplusplus

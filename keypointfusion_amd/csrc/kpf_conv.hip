@@ -51,6 +51,7 @@ struct ConvArgs {
   int tilesN, nblk;
   int vec;  // 1: output/residual rows are 16-byte aligned -> float4 epilogue
   int dbg;  // tuning aid (KPF_G8_DBG, gemm16_8ph_kernel only): 1 = no activation, 2 = no global stores, 4 = no main loop
+  int skew;  // opt-in start skew of the odd workgroup slot of a CU, in units of ~2048 clocks (KPF_STAGGER, fp32 NS = 2 launches; 0 = off, the default)
   // grouped launch (kpf_conv_desc::groups > 1, grid.y = group): group g consumes input channels from in_coff + g * g_in (staging units), uses the weights at
   // w + g * g_w (4-byte words) and bias[g * g_out + n], and writes output channels from out_coff + g * g_out (g_out = N).  All zero for an ordinary launch.
   int groups, g_in, g_out;
@@ -170,14 +171,15 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
   const int wm = wave % WM, wn = wave / WM;
   KPF_STAMP(0);
   if constexpr (ARITH == ARITH_F32 && NS == 2) {
-    // Start skew between the two workgroups that share a CU (a.dbg = microseconds, 0 = off): launched together and equally long, they run
+    // Start skew between the two workgroups that share a CU (a.skew, 0 = off = the default: KPF_STAGGER opts in): launched together and equally long, they run
     // their main loops together (each at half the matrix pipe's rate) and their epilogues together (the pipe idle).  The workgroup in the odd
     // slot of a CU sleeps before its first tile; equal tile times keep the offset through the following rounds, and one workgroup's
-    // prologue / epilogue then lies under the other's MFMAs.
-    if (a.dbg > 0 && (int)blockIdx.x < 512 && blockIdx.y == 0) {
+    // prologue / epilogue then lies under the other's MFMAs.  Measured +0.1-0.3 % on the headline — inside the noise — and TG_ID parity does not
+    // identify "the second workgroup of THIS launch" when another stream's kernel shares the CU, so it is off unless asked for.
+    if (a.skew > 0 && (int)blockIdx.x < 512 && blockIdx.y == 0) {
       const unsigned tg = __builtin_amdgcn_s_getreg(4 | (16 << 6) | (3 << 11));  // HW_ID.TG_ID: this workgroup's slot in its CU
       if (tg & 1)
-        for (int i = 0; i < a.dbg; ++i) __builtin_amdgcn_s_sleep(32);  // ~2048 clocks
+        for (int i = 0; i < a.skew; ++i) __builtin_amdgcn_s_sleep(32);  // ~2048 clocks
     }
   }
 
@@ -925,10 +927,10 @@ int launch_cfg(ConvArgs& a, bool is1x1, hipStream_t st) {
   a.tilesN = (a.N + BN - 1) / BN;
   a.nblk = tilesM * a.tilesN;
   // start skew of co-resident workgroups (igemm_body), in units of 2048 clocks: a fifth of one tile's matrix-pipe time (BM * BN * Kp / 128 clocks), at most 8;
-  // KPF_STAGGER overrides the cap (0 = off).  Short tiles get none.
-  static const int stagger = []() { const char* e = getenv("KPF_STAGGER"); return e ? atoi(e) : 8; }();
+  // KPF_STAGGER = the cap (default 0 = off; 8 was the measured setting).  Short tiles get none.
+  static const int stagger = []() { const char* e = getenv("KPF_STAGGER"); return e ? atoi(e) : 0; }();
   const long skew = (long)BM * BN * a.Kp / (128L * 5 * 2048);
-  a.dbg = a.nblk >= 512 ? (int)(skew < stagger ? skew : stagger) : 0;
+  a.skew = a.nblk >= 512 ? (int)(skew < stagger ? skew : stagger) : 0;
   if (a.flags & KPF_IN_SPLIT) return launch_arith<TM, TN, WM, WN, ARITH_SPLIT, NS_SPLIT>(a, is1x1, st);
   if (a.flags & KPF_W_SPLIT) return launch_arith<TM, TN, WM, WN, ARITH_SPLIT_W, NS_SPLIT>(a, is1x1, st);
   return launch_arith<TM, TN, WM, WN, ARITH_F32, NS_SPLIT == 1 ? 2 : 2>(a, is1x1, st);
@@ -1793,7 +1795,7 @@ extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void
     }
     a.zero = zero_of_dev[dev];
   }
-  a.flags = fl; a.tilesN = 0; a.nblk = 0; a.w_unscale = 1.0f;
+  a.flags = fl; a.tilesN = 0; a.nblk = 0; a.w_unscale = 1.0f; a.skew = 0;
   a.vec = (d->out_ld % 4 == 0 && d->out_coff % 4 == 0 && (!(fl & KPF_RES_ADD) || (d->res_ld % 4 == 0 && d->res_coff % 4 == 0))) ? 1 : 0;
   a.groups = d->groups > 1 ? d->groups : 1; a.g_in = a.g_out = 0; a.g_w = 0;
   if (a.groups > 1) {  // grouped launch: see ConvArgs
@@ -1948,7 +1950,7 @@ extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const flo
     }
     a.zero = zero_of_dev[dev];
   }
-  a.flags = fl; a.tilesN = 0; a.nblk = 0; a.dbg = 0;
+  a.flags = fl; a.tilesN = 0; a.nblk = 0; a.dbg = 0; a.skew = 0;
   a.w_unscale = (fl & (KPF_IN_SPLIT | KPF_W_SPLIT)) ? d->w_unscale : 1.0f;
   if (fl & (KPF_IN_SPLIT | KPF_W_SPLIT))
     KPF_REQUIRE(d->w_unscale > 0.f && d->Cin % 32 == 0 && d->in_coff % 4 == 0, "kpf_conv2d_f32: split operands need w_unscale > 0 and Cin %% 32 == 0 (Cin=%d)", d->Cin);

@@ -3,16 +3,32 @@
 The training iteration is replayed from a captured hipGraph (training.GraphedTrainStep) that contains, besides the product's kernels,
 torch reductions.  ATen's multi-block reductions zero a semaphore with an 8-byte hipMemsetAsync in front of the kernel; on the ROCm 7
 runtime of the MI355X boxes those memset nodes are mis-ordered from the SECOND replay of a graph on when the runtime's packet-capture
-fast path is active (DEBUG_CLR_GRAPH_PACKET_CAPTURE unset or 1): the reduction then returns stale data — silently.  The package sets
-DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 at import (keypointfusion_amd/__init__.py), which only helps if the HIP runtime has not been
-initialised yet; `assert_replay_is_sound()` therefore MEASURES the behaviour once per process and refuses to hand out graphed training
-steps on a runtime that replays them wrongly (no silent wrong gradients)."""
+fast path is active (DEBUG_CLR_GRAPH_PACKET_CAPTURE unset or 1): the reduction then returns stale data — silently (found as wrong
+layer-scale gradients in the captured training iteration; tools/replay_determinism.py).  The product's own kernels need
+no memset nodes; the torch ops around them in the training step do.
+
+`prepare_training_graphs()` sets DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 — a PROCESS-WIDE setting of the HIP runtime, read when the runtime
+initialises, so it only helps before the process's first HIP call.  It is made only on the training side: importing
+`keypointfusion_amd.training` calls it (a training script imports that module at its top, before touching the GPU) and so does
+`GraphedTrainStep.__init__`; the inference path (model, engine, serving) never does — its captured forwards contain no ATen reduction.
+`assert_replay_is_sound()` MEASURES the behaviour once per process and refuses to hand out graphed training steps on a runtime that
+replays them wrongly (no silent wrong gradients), whatever the environment says."""
+import os
 import threading
 
 import torch
 
 _lock = threading.Lock()
 _checked = {}
+ENV = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
+
+
+def prepare_training_graphs():
+    """Switch the runtime's graph packet-capture fast path off for this process unless the host application has chosen a value itself.
+    Returns the value in force.  KPF_KEEP_HIP_ENV=1 makes this a no-op (the canary in `assert_replay_is_sound` still decides)."""
+    if os.environ.get("KPF_KEEP_HIP_ENV", "0") != "1":
+        os.environ.setdefault(ENV, "0")
+    return os.environ.get(ENV)
 
 
 def replay_is_sound(device=None):
@@ -64,9 +80,8 @@ def replay_is_sound(device=None):
 
 def assert_replay_is_sound(device=None):
     if not replay_is_sound(device):
-        import os
         raise RuntimeError(
             "this HIP runtime replays captured graphs with torch reductions wrongly from the second replay on (memset nodes under the graph "
             "packet-capture fast path); DEBUG_CLR_GRAPH_PACKET_CAPTURE is %r in this process — export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before "
-            "the process makes its first HIP call (importing keypointfusion_amd before touching the GPU does it)"
+            "the process makes its first HIP call (importing keypointfusion_amd.training before touching the GPU does it)"
             % os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE"))

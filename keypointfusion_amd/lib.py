@@ -23,7 +23,7 @@ KPF_IN_SPLIT = 128
 KPF_OUT_SPLIT = 256
 KPF_W_SPLIT = 512
 KPF_DT_F32, KPF_DT_BF16, KPF_DT_F16 = 0, 1, 2
-ABI_VERSION = 15  # KPF_ABI_VERSION of include/kpf.h: load() refuses a library built from another revision of the interface
+ABI_VERSION = 16  # KPF_ABI_VERSION of include/kpf.h: load() refuses a library built from another revision of the interface
 
 
 class ConvDesc(C.Structure):
@@ -149,6 +149,8 @@ _SIGS = {
     "kpf_layer_scale_backward_partial": [_P, _P, C.c_int, _P, _P, _P, _P, C.c_long, C.c_long, C.c_int, C.POINTER(ColsumDesc), _P],
     "kpf_ln_train_backward_partial": [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, C.c_long, C.c_long, C.c_int, C.POINTER(ColsumDesc), _P],
     "kpf_colsum_reduce_grouped": [C.POINTER(ColsumDesc), C.c_int, _P],
+    "kpf_tr_stack_train_forward": [_P, _P, _P, _P, C.c_long, C.c_int, C.c_float, _P, C.c_int, _P],
+    "kpf_tr_stack_train_backward": [_P, _P, _P, _P, _P, _P, C.c_int, C.c_float, C.c_int, _P],
     "kpf_bmm_small_k_dx": [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
     "kpf_bmm_small_k_fwd": [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
     "kpf_bmm_small_k_da": [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
@@ -171,6 +173,11 @@ _LONG_SIGS = {  # entries returning a long
     "kpf_layer_scale_ws_floats": [C.c_long, C.c_int],
     "kpf_dwconv7_stats_floats": [C.c_int] * 4,
     "kpf_pack_desc_blocks": [C.POINTER(PackDesc)],
+    "kpf_tr_stack_save_floats": [C.c_int],
+    "kpf_tr_stack_out_offset": [C.c_int],
+    "kpf_tr_stack_dy_floats": [C.c_int],
+    "kpf_tr_stack_part_floats": [C.c_int],
+    "kpf_tr_stack_offset": [C.c_int, C.c_int, C.c_int],
 }
 EXPORTS = sorted(list(_SIGS) + list(_LONG_SIGS) + ["kpf_last_error", "kpf_abi_version"])
 

@@ -32,7 +32,7 @@ import torch.nn.functional as F
 
 from . import lib as L
 from .engine import _ptr, _stream, crop_inverse
-from .training import (add_relu, attn21, batchnorm_relu_rows, bmm_small_k, conv2d_nhwc, dwconv7_nhwc, gelu_rows, layer_norm_rows, layer_scale_residual, linear_hip, maxpool3x3s2_nhwc,
+from .training import (add_relu, attn21, batchnorm_relu_rows, bert_stack21, bmm_small_k, conv2d_nhwc, dwconv7_nhwc, gelu_rows, layer_norm_rows, layer_scale_residual, linear_hip, maxpool3x3s2_nhwc,
                        ball_group, drop_add_ln, pair_params, pair_storage, row_gather, self_attention21, upsample2x_nhwc)
 
 _N_STREAMS = int(os.environ.get("KPF_TRAIN_STREAMS", "2"))  # 2: the RGB backbone (forward and backward) on a side stream (unpaired backbones only)
@@ -41,6 +41,8 @@ _N_STREAMS = int(os.environ.get("KPF_TRAIN_STREAMS", "2"))  # 2: the RGB backbon
 # layer scale a 2-set launch, every per-channel kernel (BatchNorm, depthwise 7x7, GELU, bilinear x2) simply sees 2C channels.  Half the launches of
 # the backbones, each twice as large — a captured iteration is latency-bound on ~3000 launches of 3-15 us.  0: two separate passes.
 PAIR_BACKBONES = bool(int(os.environ.get("KPF_TRAIN_PAIR", "1")))
+# 1 (default): the four BERT layers of a 21-token stack as ONE launch each way (training.BertStack21, csrc/kpf_trstack.hip); 0: layer by layer (bert_layer)
+TR_FUSED = bool(int(os.environ.get("KPF_TR_FUSED", "1")))
 PAIR = "PAIR."  # parameter-name prefix that stands for ("backbone_rgb.", "backbone_d.") while a paired pass is built
 
 J = 21
@@ -471,10 +473,20 @@ class TrainGraph:
     def kp_interaction_tr(self, p, x):
         T = x.shape[1]
         from .training import PrefixRows
-        h = self.linear(x, p + ".bert.img_embedding.weight", p + ".bert.img_embedding.bias") + PrefixRows.apply(self.t[p + ".bert.position_embeddings.weight"], T)
-        h = self.drop(h)  # TR_Encoder applies the embedding dropout (model/model.py:84)
-        for l in range(4):
-            h = self.bert_layer(p + ".bert.encoder.layer.%d" % l, h)
+        if TR_FUSED and T == 21 and self.has(p + ".bert.encoder.layer.3.output.LayerNorm.weight") and not self.has(p + ".bert.encoder.layer.4.output.LayerNorm.weight"):
+            # embedding Linear, then [+ position, embedding dropout, four layers] as one launch each way
+            from .training import BertStack21
+            e = self.linear(x, p + ".bert.img_embedding.weight", p + ".bert.img_embedding.bias")
+            names = [p + ".bert.encoder.layer.%d.%s" % (l, k) for l in range(4) for k in BertStack21.ORDER]
+            call0 = self.attn_calls + 1
+            self.attn_calls += 13
+            h = bert_stack21(e, PrefixRows.apply(self.t[p + ".bert.position_embeddings.weight"], T), names, self.packs, self.pd, self.rng(x.device), call0,
+                             [self.t[n] for n in names])
+        else:
+            h = self.linear(x, p + ".bert.img_embedding.weight", p + ".bert.img_embedding.bias") + PrefixRows.apply(self.t[p + ".bert.position_embeddings.weight"], T)
+            h = self.drop(h)  # TR_Encoder applies the embedding dropout (model/model.py:84)
+            for l in range(4):
+                h = self.bert_layer(p + ".bert.encoder.layer.%d" % l, h)
         score = self.linear(h, p + ".cls_head.weight", p + ".cls_head.bias") + self.linear(x, p + ".residual.weight", p + ".residual.bias")
         return h, score
 

@@ -35,6 +35,10 @@ import os
 import torch
 import torch.nn.functional as F
 
+from .graphs import prepare_training_graphs
+
+prepare_training_graphs()  # DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 unless the host chose a value: process-wide, training side only (graphs.py)
+
 STAGE_TYPE = (1, 1, 2, 3, 2, 3)  # config.py: depth backbone, RGB backbone, (RGB KFAM, depth KFAM) x 2
 COORD_WEIGHT, DECONV_WEIGHT = 100.0, 1.0
 SPATIAL_WEIGHT, SPATIAL_EPOCH = (10.0, 10.0, 10.0), (24, 24, 24)
@@ -415,6 +419,8 @@ class FusedAdamW(torch.optim.AdamW):
         for group in self.param_groups:
             live = [p for p in group["params"] if p.grad is not None]
             if not live:
+                if scaler is not None:  # (a silent `continue` left a latched overflow flag and a stale tracker behind)
+                    raise ValueError("FusedAdamW.step(scaler=...): no parameter carries a gradient — every scaled step must follow scaler.scale(loss).backward()")
                 continue
             dev = live[0].device
             shared = None
@@ -474,18 +480,23 @@ class LossScaler:
     def __init__(self, init_scale=2.0 ** 14, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, device=None):
         self.growth_factor, self.backoff_factor, self.growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
         self._init = float(init_scale)
+        self._pending_tracker = 0  # growth tracker restored by load_state_dict before a device is known
         self.scale_t = None
         if device is not None:
             self._to(torch.device(device))
 
     def _to(self, dev):
-        if self.scale_t is None or self.scale_t.device != dev:
-            prev = self._init if self.scale_t is None else float(self.scale_t)
-            self.scale_t = torch.tensor(prev, device=dev, dtype=torch.float32)
-            self.inv_scale = torch.tensor(1.0 / prev, device=dev, dtype=torch.float32)
+        """Allocates the device state ONCE.  A captured GraphedTrainStep bakes these tensors' addresses into its graph (loss * scale, the finite check, the
+        scaled AdamW, the scale update), so they are never re-homed: later changes (load_state_dict) are made in place, and asking for another device raises."""
+        if self.scale_t is None:
+            self.scale_t = torch.tensor(self._init, device=dev, dtype=torch.float32)
+            self.inv_scale = torch.tensor(1.0 / self._init, device=dev, dtype=torch.float32)
             self.found = torch.zeros((), device=dev, dtype=torch.int32)
-            self.tracker = torch.zeros((), device=dev, dtype=torch.int32)
+            self.tracker = torch.full((), int(self._pending_tracker), device=dev, dtype=torch.int32)
             self.skipped = torch.zeros((), device=dev, dtype=torch.int32)
+            self._pending_tracker = 0
+        elif self.scale_t.device != dev:
+            raise RuntimeError("LossScaler: state lives on %s (possibly inside a captured graph) and cannot move to %s; build one scaler per device" % (self.scale_t.device, dev))
 
     @property
     def scale_value(self):
@@ -505,15 +516,20 @@ class LossScaler:
         return float(self.scale_t) if self.scale_t is not None else self._init
 
     def state_dict(self):
-        return {"scale": self.get_scale(), "growth_tracker": int(self.tracker) if self.scale_t is not None else 0}
+        return {"scale": self.get_scale(), "growth_tracker": int(self.tracker) if self.scale_t is not None else int(self._pending_tracker)}
 
     def load_state_dict(self, sd):
+        """Restores scale and growth tracker IN PLACE: a GraphedTrainStep captured earlier keeps replaying on the same tensors and sees the restored values
+        (re-allocating here orphaned the tensors the graph updates, so a resume on a live step was silently ignored)."""
         self._init = float(sd["scale"])
-        dev = self.scale_t.device if self.scale_t is not None else None
-        self.scale_t = None
-        if dev is not None:
-            self._to(dev)
-            self.tracker.fill_(int(sd.get("growth_tracker", 0)))
+        tracker = int(sd.get("growth_tracker", 0))
+        if self.scale_t is None:
+            self._pending_tracker = tracker  # applied when the first use allocates the device state
+            return
+        self.scale_t.fill_(self._init)
+        self.inv_scale.fill_(1.0 / self._init)
+        self.tracker.fill_(tracker)
+        self.found.zero_()
 
 
 def make_optimizer(params, lr=8e-4, step_size=10, start_epoch=0, capturable=False):
@@ -1460,6 +1476,121 @@ def self_attention21(h, wq, bq, wk, bk, wv, bv, names, cache, heads, scale, p_dr
     return SelfAttention21.apply(h, wq, bq, wk, bk, wv, bv, names, cache, heads, scale, p_drop, rng, call_id)
 
 
+class BertStack21(torch.autograd.Function):
+    """The four BERT layers of a KP_Interaction_TR stack (model/model.py:30-126: transformers' BertEncoder under .train(), 21 tokens x 128) as ONE launch each way
+    (csrc/kpf_trstack.hip: kpf_tr_stack_train_forward / _backward; round 6) — h = layers(dropout(e + pos)) with e the embedding Linear's output.  The unfused
+    form (`TrainGraph.bert_layer`, KPF_TR_FUSED=0) is 7 launches per layer forward and ~10 backward on 21 B rows.  The backward writes every Linear's dY beside
+    the X the forward kept; the 24 weight / bias gradients join the deferred grouped launch after backward (DeferredParamGrads) exactly like the unfused
+    layers' — or one grouped launch right here when no deferral is active — and the 8 LayerNorm parameter gradients leave as per-sample partial sums for the
+    grouped column-sum reduce.  Dropout masks: the device-resident (seed, counter) hash of Attn21 / DropAddLN with call ids call0 .. call0 + 12, recomputed in
+    the backward (nothing stored).  params: 16 tensors per layer in the order of `BertStack21.ORDER`; names: their parameter names (the deferral's keys)."""
+    ORDER = ("attention.self.query.weight", "attention.self.query.bias", "attention.self.key.weight", "attention.self.key.bias",
+             "attention.self.value.weight", "attention.self.value.bias", "attention.output.dense.weight", "attention.output.dense.bias",
+             "attention.output.LayerNorm.weight", "attention.output.LayerNorm.bias", "intermediate.dense.weight", "intermediate.dense.bias",
+             "output.dense.weight", "output.dense.bias", "output.LayerNorm.weight", "output.LayerNorm.bias")
+    # (weight index, X of its weight gradient, dY) per Linear of a layer, as kpf_tr_stack_offset's `which`; (N, K); dY's row stride and column offset
+    LINEARS = ((0, 0, 4, 128, 128, 384, 0), (2, 0, 4, 128, 128, 384, 128), (4, 0, 4, 128, 128, 384, 256), (6, 1, 5, 128, 128, 0, 0), (10, 2, 6, 16, 128, 0, 0),
+               (12, 3, 7, 128, 16, 0, 0))
+    _tables = {}
+
+    @staticmethod
+    def param_table(params):
+        """DEVICE array of the parameters' addresses (the kernels read the weights where they lie: no packed copies).  Cached per address tuple: the warm-up
+        iterations of a GraphedTrainStep build it, the capture finds it."""
+        key = tuple(p.data_ptr() for p in params)
+        t = BertStack21._tables.get(key)
+        if t is None:
+            for p in params:
+                if p.dtype != torch.float32 or not p.is_contiguous() or p.data_ptr() % 16:
+                    raise ValueError("BertStack21: parameters must be contiguous 16-byte-aligned fp32 tensors")
+            if len(BertStack21._tables) > 64:
+                BertStack21._tables.clear()
+            t = BertStack21._tables[key] = torch.tensor(key, dtype=torch.int64, device=params[0].device)
+        return t
+
+    @staticmethod
+    def forward(ctx, e, pos, names, cache, p_drop, rng, call0, *params):
+        from . import lib as L
+        lib = L.load()
+        B, T, Cc = e.shape
+        assert T == 21 and Cc == 128 and len(params) == 64 and len(names) == 64 and tuple(pos.shape) == (21, 128)
+        ec, pc = e.float().contiguous(), pos.float().contiguous()
+        table = BertStack21.param_table(params)
+        n = lib.kpf_tr_stack_save_floats(B)
+        save = torch.empty(n, device=e.device, dtype=torch.float32)
+        L.check(lib.kpf_tr_stack_train_forward(ec.data_ptr(), pc.data_ptr(), table.data_ptr(), save.data_ptr(), n, B, float(p_drop),
+                                               rng.data_ptr() if (rng is not None and p_drop > 0) else None, int(call0), torch.cuda.current_stream().cuda_stream),
+                "kpf_tr_stack_train_forward")
+        ctx.save_for_backward(save, table, *params)
+        ctx.conf = (names, cache, float(p_drop), int(call0), B)
+        off = lib.kpf_tr_stack_out_offset(B)
+        return save[off:off + B * T * Cc].view(B, T, Cc)
+
+    @staticmethod
+    def backward(ctx, dh):
+        from . import lib as L
+        lib = L.load()
+        save, table, *params = ctx.saved_tensors
+        names, cache, p_drop, call0, B = ctx.conf
+        M, dev = B * 21, save.device
+        st = torch.cuda.current_stream().cuda_stream
+        dh = dh.float().contiguous()
+        dE = torch.empty(B, 21, 128, device=dev, dtype=torch.float32)
+        dys = torch.empty(lib.kpf_tr_stack_dy_floats(B), device=dev, dtype=torch.float32)
+        parts = torch.empty(lib.kpf_tr_stack_part_floats(B), device=dev, dtype=torch.float32)
+        L.check(lib.kpf_tr_stack_train_backward(dh.data_ptr(), table.data_ptr(), save.data_ptr(), dE.data_ptr(), dys.data_ptr(), parts.data_ptr(), B, p_drop, call0, st),
+                "kpf_tr_stack_train_backward")
+        grads = [None] * 64
+        now_w, now_c = [], []  # gradients that are not deferred: one grouped launch each, right here
+        for l in range(4):
+            for wi, xw, yw, N, K, ldy, coff in BertStack21.LINEARS:
+                i = 16 * l + wi
+                w, bias, name = params[i], params[i + 1], names[i]
+                xo, yo = lib.kpf_tr_stack_offset(B, l, xw), lib.kpf_tr_stack_offset(B, l, yw)
+                x = save[xo:xo + M * K].view(M, K)
+                dyfull = dys[yo:yo + M * (ldy or N)].view(M, ldy or N)
+                dy = dyfull[:, coff:coff + N] if ldy else dyfull
+                dw = torch.empty(tuple(w.shape), device=dev, dtype=torch.float32)
+                db = torch.empty(N, device=dev, dtype=torch.float32)
+                grp = DeferredParamGrads.wants(name, cache, dy, x, 1, 1, 1, 0)
+                if grp is not None:
+                    bp = grp.by_ptr.get(bias.data_ptr())
+                    if bp is None or bp.numel() != N or bp.grad is not None:
+                        grp = None
+                if grp is not None:
+                    grp.add(name, dy, x, dw, db, bias.data_ptr(), ldy=ldy)
+                else:
+                    now_w.append((dy, x, dw, db, M, N, K, ldy))
+                grads[i], grads[i + 1] = dw, db
+            for ln, wi in ((0, 8), (1, 14)):
+                i = 16 * l + wi
+                w, bias = params[i], params[i + 1]
+                dwb = torch.empty(2, 128, device=dev, dtype=torch.float32)
+                po = ((l * 2 + ln) * B) * 256
+                desc = L.ColsumDesc()
+                desc.part, desc.dw, desc.db, desc.nblk, desc.C, desc.first_block, desc.reserved = parts.data_ptr() + 4 * po, dwb[0].data_ptr(), dwb[1].data_ptr(), B, 128, 0, 0
+                grp = DeferredParamGrads.wants_colsum(w, bias.data_ptr())
+                if grp is not None:
+                    grp.add_colsum(w, desc, parts, dwb, bias.data_ptr(), dwb[1].data_ptr())
+                else:
+                    now_c.append(desc)
+                grads[i], grads[i + 1] = dwb[0], dwb[1]
+        if now_w:
+            arr = (L.WgradGroupDesc * len(now_w))()
+            for d, (dy, x, dw, db, M_, N, K, ldy) in zip(arr, now_w):
+                d.dy, d.x, d.dw, d.db, d.M, d.N, d.K, d.ldy = dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(), M_, N, K, ldy
+            L.check(lib.kpf_linear_wgrad_grouped(arr, len(now_w), st), "kpf_linear_wgrad_grouped")
+        if now_c:
+            arr = (L.ColsumDesc * len(now_c))(*now_c)
+            L.check(lib.kpf_colsum_reduce_grouped(arr, len(now_c), st), "kpf_colsum_reduce_grouped")
+        dpos = dE.sum(0) if ctx.needs_input_grad[1] else None
+        return (dE, dpos, None, None, None, None, None) + tuple(grads)
+
+
+def bert_stack21(e, pos, names, cache, p_drop, rng, call0, params):
+    return BertStack21.apply(e, pos, tuple(names), cache, p_drop, rng, call0, *params)
+
+
 class DropAddLN(torch.autograd.Function):
     """y = LayerNorm(h + dropout(o)) over the last axis, fp32, one launch each way (kpf_drop_add_ln_forward / _backward): the `dense -> dropout ->
     + residual -> LayerNorm` tail of both halves of a BERT layer (model/model.py:72-126) — the library path is a dropout, an add and the
@@ -1651,7 +1782,13 @@ class BmmSmallK(torch.autograd.Function):
 
 
 def bmm_small_k(A, X):
-    return BmmSmallK.apply(A, X)
+    """A [B, J, P] @ X [B, P, C].  The HIP kernels (fixed summation order, bit-identical replays) cover the shapes the model has — J <= 24 rows, C % 4 == 0,
+    one sample's dOut tile J * C * 4 <= 64 KB of LDS (C <= 682 at J = 21); anything wider takes torch.bmm, chosen HERE, before autograd records a node, so a
+    wider head fails nowhere inside backward."""
+    J, Cc = A.shape[1], X.shape[2]
+    if A.is_cuda and J <= 24 and Cc % 4 == 0 and J * Cc * 4 <= 65536:
+        return BmmSmallK.apply(A, X)
+    return torch.bmm(A, X.to(A.dtype))
 
 
 def layer_norm_rows(x, weight, bias, eps, out_dtype=None, groups=1):
@@ -2148,7 +2285,8 @@ class GraphedTrainStep:
             dp_mode = "overlap" if (be == "nccl" and os.environ.get("KPF_DP_GRAPH", "overlap") != "split") else "split"
         self.dp_mode = dp_mode if dist_mod is not None else None
         self._deferred_ids = set()
-        from .graphs import assert_replay_is_sound
+        from .graphs import assert_replay_is_sound, prepare_training_graphs
+        prepare_training_graphs()
         assert_replay_is_sound(next(iter(batch.values())).device)  # (once per process: refuses a runtime that mis-replays reductions)
         self.static = {k: v.detach().clone() for k, v in batch.items()}
         self.params = [p for p in (params if params is not None else model.parameters()) if p.requires_grad]
@@ -2391,6 +2529,29 @@ class GraphedTrainStep:
             cur_bytes += nb
         if cur:
             close(cur)
+
+    def time_collectives(self, time_one):
+        """Diagnostics (bench.py's `collectives` record; EVERY rank must call it): each gradient bucket's collective issued eagerly on the step's own static
+        buffers — the same call the captured graph holds as a node — timed by `time_one(fn, nbytes)`.  The buffers are zeroed first and are rewritten by the
+        next replay's pack, so the step is not disturbed."""
+        if self.dist is None:
+            return []
+        out = []
+        for flat, _, _ in self.buckets:
+            flat.zero_()
+            if self.dp_mode == "overlap" and self.collective == "rs_ag":
+                shard = torch.empty(flat.numel() // self.world, dtype=flat.dtype, device=flat.device)
+
+                def fn(flat=flat, shard=shard):
+                    self.dist.reduce_scatter_tensor(shard, flat, op=self.dist.ReduceOp.SUM, group=self.group)
+                    self.dist.all_gather_into_tensor(flat, shard, group=self.group)
+            else:
+                def fn(flat=flat):
+                    self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
+            rec = time_one(fn, flat.numel() * flat.element_size())
+            rec["dtype"] = str(flat.dtype).replace("torch.", "")
+            out.append(rec)
+        return out
 
     def payload_bytes(self):
         return sum(f.numel() * f.element_size() for f, _, _ in self.buckets) if self.dist is not None else 0  # (per iteration and rank, either form)

@@ -3,7 +3,7 @@ import sys
 
 import pytest
 
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")  # HIP-runtime graph-replay workaround (keypointfusion_amd/__init__.py): before the first HIP call
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")  # HIP-runtime graph-replay workaround (keypointfusion_amd/graphs.py): before the first HIP call
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -62,6 +62,11 @@ def test_self_launched_one_rank_rccl_eval_bench():
     assert rec["world_size"] == 1 and rec["n_gpus"] == 1 and rec["collective_backend"].startswith("rccl")
     assert rec["scaling"] == "weak" and rec["value"] > 0 and rec["roofline"]["kernel"] == "igemm_f32_kernel"
     assert rec["roofline"]["launches_per_step"] == 136
+    # what makes the first N > 1 line diagnosable: every rank's own step time and one measured point of the fabric
+    pr = rec["per_rank_ms_per_step"]
+    assert len(pr["all"]) == 1 and pr["min"] == pr["max"] == pr["all"][0] and abs(pr["max"] - rec["ms_per_step"]) < 1e-2
+    probe = rec["collectives"]["probe_64MiB"]
+    assert probe["bytes"] == 64 * 1024 * 1024 and probe["ms"] > 0 and probe["algbw_GBps"] > 0 and probe["busbw_GBps"] == 0.0  # (one rank: nothing crosses a link)
 
 
 @pytest.mark.gpu
@@ -71,3 +76,7 @@ def test_self_launched_one_rank_rccl_graphed_training_step():
     assert rec["dp_graph"]["mode"] == "overlap"  # forward, loss, backward WITH the bucket collectives, optimiser: one captured graph
     assert rec["dp_graph"]["payload_bytes_per_rank"] > 200e6 and rec["launch"].startswith("hipGraph replay")
     assert "training iteration" in rec["config"]["workload"]
+    co = rec["collectives"]
+    assert len(co["buckets"]) == rec["dp_graph"]["buckets"] >= 2 and all(b["ms"] > 0 and b["bytes"] > 0 for b in co["buckets"])
+    assert co["all_buckets"]["bytes"] == rec["dp_graph"]["payload_bytes_per_rank"]
+    assert len(rec["per_rank_ms_per_step"]["all"]) == 1 and "prediction" in rec["dp_graph"]

@@ -146,6 +146,29 @@ def test_dropin_model_package_resolves_the_reference_import_lines(tmp_path):
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr[-2000:]
 
 
+def test_importing_the_inference_path_leaves_the_environment_alone(tmp_path):
+    """a drop-in library must not change the HIP runtime's behaviour for its host application.  Importing the package and the whole
+    inference path (model, engine, engine16, serving, heads) leaves os.environ as it was; only the TRAINING module makes the one documented process-wide
+    setting (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, graphs.prepare_training_graphs), keeps a value the host exported, and can be told to keep its hands off."""
+    import subprocess
+    import sys
+    var = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
+    env = {k: v for k, v in os.environ.items() if k not in (var, "KPF_KEEP_HIP_ENV")}
+    code = ("import os, sys; sys.path.insert(0, %r); before = dict(os.environ);"
+            "import keypointfusion_amd; from keypointfusion_amd.model.model import KPFusion; from keypointfusion_amd import engine, engine16, serving, heads, lib;"
+            "from keypointfusion_amd.model import cbam, hourglass, mano_head;"
+            "assert dict(os.environ) == before, set(os.environ) ^ set(before);"
+            "from keypointfusion_amd import training;"
+            "print(os.environ.get(%r))") % (ROOT, var)
+    run = lambda e: subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path), env=e)
+    out = run(env)
+    assert out.returncode == 0 and out.stdout.strip() == "0", out.stderr[-2000:]
+    out = run(dict(env, **{var: "1"}))  # the host application's own choice is kept
+    assert out.returncode == 0 and out.stdout.strip() == "1", out.stderr[-2000:]
+    out = run(dict(env, KPF_KEEP_HIP_ENV="1"))
+    assert out.returncode == 0 and out.stdout.strip() == "None", out.stderr[-2000:]
+
+
 def test_wide_extension_changes_two_tensors_and_nothing_else():
     """crop_size=256 (the labelled wide extension): same keys in the same order as the reference's state dict, only `fc_spatial2joint_feature.weight` of the
     two blocks resized to (crop_size / 4)^2 inputs; crop_size=128 IS the reference's spec; sizes the architecture cannot take are refused."""

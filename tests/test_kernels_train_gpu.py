@@ -1246,3 +1246,110 @@ def test_operand_refresh_forms_equal_the_single_operand_kernel(prec):
     for (shape, mode, kw), e, r in zip(cases, cache.entries.values(), refs):
         buf = e["pc"].w if e["pc"].w is not None else e["pc"].w16
         assert torch.equal(buf.view(torch.int16 if buf.dtype != torch.float32 else torch.int32), r.view(torch.int16 if r.dtype != torch.float32 else torch.int32)), (shape, mode)
+
+
+def _bert_stack_reference(e, pos, prm, masks=None):
+    """The four post-LN BERT layers in plain torch (any dtype): model/model.py:30-126 with dropout off, or with given keep masks (None: none)."""
+    B = e.shape[0]
+    h = e + pos
+    for l in range(4):
+        Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, b1, Wi, bi, Wo2, bo2, g2, b2 = prm[16 * l:16 * l + 16]
+        q, k, v = (F.linear(h, W, b_).view(B, 21, 4, 32).transpose(1, 2) for W, b_ in ((Wq, bq), (Wk, bk), (Wv, bv)))
+        p = torch.softmax(q @ k.transpose(-1, -2) / 32 ** 0.5, -1)
+        ctx = (p @ v).transpose(1, 2).reshape(B, 21, 128)
+        h1 = F.layer_norm(h + F.linear(ctx, Wo, bo), (128,), g1, b1, 1e-12)
+        it = F.linear(h1, Wi, bi)
+        g = 0.5 * it * (1 + torch.erf(it / 2 ** 0.5))
+        h = F.layer_norm(h1 + F.linear(g, Wo2, bo2), (128,), g2, b2, 1e-12)
+    return h
+
+
+def _bert_stack_params(gen, dev, scale=1.0):
+    shapes = [(128, 128), (128,), (128, 128), (128,), (128, 128), (128,), (128, 128), (128,), (128,), (128,), (16, 128), (16,), (128, 16), (128,), (128,), (128,)]
+    prm = []
+    for l in range(4):
+        for i, sh in enumerate(shapes):
+            if i in (8, 14):  # LayerNorm weights around 1
+                t = 1.0 + 0.2 * torch.randn(*sh, generator=gen)
+            elif len(sh) == 2:
+                t = torch.randn(*sh, generator=gen) * (scale / sh[1] ** 0.5)
+            else:
+                t = 0.1 * torch.randn(*sh, generator=gen)
+            prm.append(t.to(dev).requires_grad_(True))
+    return prm
+
+
+@pytest.mark.parametrize("B", [1, 3, 32])
+def test_bert_stack21_forward_backward_match_fp64_torch(B):
+    """training.BertStack21 (csrc/kpf_trstack.hip: the four BERT layers of a 21-token stack as one launch each way) against the same layers written out in fp64
+    torch, dropout off: output, input / position gradients and all 64 parameter gradients (24 through the grouped weight-gradient launch, 8 LayerNorm
+    parameter sums through the grouped column-sum reduce), and two calls give the same bits."""
+    from keypointfusion_amd import training as T
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(7 + B)
+    prm = _bert_stack_params(gen, dev, scale=1.5)
+    e = torch.randn(B, 21, 128, generator=gen).to(dev).requires_grad_(True)
+    pos = (0.5 * torch.randn(21, 128, generator=gen)).to(dev).requires_grad_(True)
+    names = ["stack.%d.%s" % (l, k) for l in range(4) for k in T.BertStack21.ORDER]
+    wsum = torch.randn(B, 21, 128, generator=gen).to(dev)
+
+    def run():
+        for t in [e, pos] + prm:
+            t.grad = None
+        out = T.bert_stack21(e, pos, names, None, 0.0, None, 1, prm)
+        (out * wsum).sum().backward()
+        return out.detach().clone(), [t.grad.detach().clone() for t in [e, pos] + prm]
+
+    out, grads = run()
+    out2, grads2 = run()
+    assert torch.equal(out, out2) and all(torch.equal(a, c) for a, c in zip(grads, grads2)), "two calls on the same operands must give the same bits"
+    e64, pos64 = e.detach().double().cpu().requires_grad_(True), pos.detach().double().cpu().requires_grad_(True)
+    prm64 = [t.detach().double().cpu().requires_grad_(True) for t in prm]
+    ref = _bert_stack_reference(e64, pos64, prm64)
+    (ref * wsum.double().cpu()).sum().backward()
+    assert float((out.double().cpu() - ref).abs().max() / ref.abs().max()) < 2e-5
+    for i, (gd, t64) in enumerate(zip(grads, [e64, pos64] + prm64)):
+        err = float((gd.double().cpu() - t64.grad).abs().max() / (t64.grad.abs().max() + 1e-12))
+        assert err < 2e-4, "gradient %d (%s): relative error %.2e" % (i, "e pos".split()[i] if i < 2 else names[i - 2], err)
+
+
+def test_bert_stack21_dropout_masks_are_consistent_between_forward_and_backward():
+    """p = 0.1: (a) about a tenth of H[0] = dropout(e + pos) is zero and the rest is scaled by 1 / 0.9; (b) the same (seed, counter) gives the same bits, another
+    counter another mask; (c) the backward uses the forward's masks: a directional derivative of sum(out * w) along random directions in e and in two weights
+    (central differences with the masks held fixed: they depend on (seed, counter, call, element) only) matches <grad, direction>."""
+    from keypointfusion_amd import training as T
+    dev = torch.device("cuda:0")
+    B = 4
+    gen = torch.Generator().manual_seed(3)
+    prm = _bert_stack_params(gen, dev)
+    e = torch.randn(B, 21, 128, generator=gen).to(dev).requires_grad_(True)
+    pos = (0.5 * torch.randn(21, 128, generator=gen)).to(dev).requires_grad_(True)
+    names = ["stack.%d.%s" % (l, k) for l in range(4) for k in T.BertStack21.ORDER]
+    wsum = torch.randn(B, 21, 128, generator=gen).to(dev)
+    rng = torch.tensor([1234567, 5], dtype=torch.int64, device=dev)
+    f = lambda: T.bert_stack21(e, pos, names, None, 0.1, rng, 1, prm)
+    out = f()
+    (out * wsum).sum().backward()
+    g_e, g_wq, g_wo2 = e.grad.clone(), prm[0].grad.clone(), prm[16 * 2 + 12].grad.clone()
+    assert torch.equal(out, f())
+    rng2 = rng.clone()
+    rng2[1] += 1
+    assert not torch.equal(out, T.bert_stack21(e, pos, names, None, 0.1, rng2, 1, prm))
+    # H[0] is the first block of the saved buffer: zero fraction and scale
+    with torch.no_grad():
+        h0 = out.grad_fn.saved_tensors[0][:B * 21 * 128].view(B, 21, 128)
+        zero = (h0 == 0)
+        assert 0.07 < float(zero.float().mean()) < 0.13
+        assert torch.allclose(h0[~zero], ((e + pos) / 0.9)[~zero], rtol=1e-6, atol=1e-6)
+        for t, g in ((e, g_e), (prm[0], g_wq), (prm[16 * 2 + 12], g_wo2)):
+            d = torch.randn(t.shape, generator=gen).to(dev)
+            d = d / d.norm()
+            eps = 2e-2 * float(t.norm()) / 10
+            base = t.detach().clone()
+            t.copy_(base + eps * d)
+            lp = float((f().double() * wsum.double()).sum())
+            t.copy_(base - eps * d)
+            lm = float((f().double() * wsum.double()).sum())
+            t.copy_(base)
+            fd, an = (lp - lm) / (2 * eps), float((g.double() * d.double()).sum())
+            assert abs(fd - an) < 3e-2 * max(abs(an), abs(fd)) + 1e-3, (fd, an)

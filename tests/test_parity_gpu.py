@@ -278,7 +278,8 @@ def test_wide_model_at_256x256_matches_the_oracle():
         out, sws, ctx = m._plan(dev).forward(d["img_rgb"], d["img"], d["pcl"], d["center"], d["M"], d["cube"], d["cam_para"], 0.8, 256, 1, want_aux=True)
     torch.cuda.synchronize()
     ref, rsw, aux, report = oracle_with_device_decisions(sd, b, ctx, img_size=256)
-    assert report["top4_flips"] == 0, report
+    print("index report wide model: %s" % report)
+    assert report["top4_flips"] == 0 and report["ball_flips"] == 0, report  # frozen to what this seed gives, like the six committed 128 x 128 cases
     assert tuple(out[0].shape) == (2, 105, 64, 64) and tuple(sws[0].shape) == (2, 21, 64, 64)
     for o, r in list(zip(out, ref)) + list(zip(sws, rsw)):
         assert rel_err(o, r) < 1e-3
@@ -312,6 +313,27 @@ def test_forward_kernel_argument_reaches_only_the_decode():
         assert rel_err(o, r) < 1e-3
     b8 = _run_full("convnext-tiny", 2, seed=3, kernel=0.8)
     assert rel_err(out[2], b8[4][2]) > 1e-4, "kernel must change the decoded joints"
+
+
+def test_ball_query_decisions_over_a_seed_sweep():
+    """How often does a ball-query set taken on the device differ from the oracle's, and is every difference a point ON the radius?  (VERDICT r05 item 4;
+    model/model.py:129-204.)  The sets are built around NETWORK OUTPUTS (joints that agree with the oracle's to ~1e-6), so a point whose distance equals the
+    radius to the last bits may change sides; pointnet2_ops' semantics are restated, not pinned.  16 input seeds x B = 4 = 16 x 4 x 21 x 3 x 2 =
+    8064 sets: every differing set is proved to sit on the radius boundary inside `oracle_with_device_decisions` (`_check_ball_flips`: nothing clearly
+    outside, at least one differing point within 1e-3 of r^2) and the outputs still match the oracle with the device's decisions injected.  The count is
+    printed and bounded: a systematic disagreement (another scan order, `<=` for `<`, another slot fill) would flip hundreds of sets, not a handful."""
+    flips, sets, worst = 0, 0, 0.0
+    for seed in range(40, 56):
+        b, ref, rsw, aux, out, sws, ctx, report = _run_full("convnext-tiny", 4, seed)
+        assert report["top4_flips"] == 0, (seed, report)
+        flips += report["ball_flips"]
+        sets += 4 * 21 * 3 * 2
+        for o, r in list(zip(out, ref)) + list(zip(sws, rsw)):
+            assert rel_err(o, r) < 1e-3, (seed, report)
+        worst = max(worst, max(float((out[k].cpu() - ref[k]).abs().max()) * 125.0 for k in range(2, 6)))
+        assert worst < 0.05, (seed, worst)
+    print("ball-query seed sweep: %d of %d sets differ from the oracle's own (all on the radius); max joint deviation %.5f mm" % (flips, sets, worst))
+    assert flips <= sets // 500, (flips, sets)
 
 
 @pytest.mark.parametrize("net,B,seed", [("convnext-tiny", 2, 1), ("resnet-18", 2, 1), ("convnext-tiny", 1, 1), ("convnext-tiny", 3, 7),

@@ -313,8 +313,14 @@ def test_full_model_reduced_precision_tolerance_in_mm(net, prec, mean_tol, final
     assert jumps[3] == 0 and mm[3] < 5.0 and p90_mm[3] < fin_p90, (prec, jumps, mm, p90_mm)
 
 
-@pytest.mark.parametrize("prec,lim", [("bf16", dict(mean=1.3, median=0.9, p90=2.8, vmax=8.0, jump_mid=0.10)), ("f16", dict(mean=0.4, median=0.2, p90=0.9, vmax=5.0, jump_mid=0.02))])
-def test_reduced_precision_deviation_statistics_over_many_batches(prec, lim):
+@pytest.mark.parametrize("net,prec,lim", [("convnext-tiny", "bf16", dict(mean=1.3, median=0.9, p90=2.8, vmax=8.0, jump_mid=0.10, jump_2d=0.005)),
+                                          ("convnext-tiny", "f16", dict(mean=0.4, median=0.2, p90=0.9, vmax=5.0, jump_mid=0.02, jump_2d=0.005)),
+                                          # ResNet-18 (round 6, measured on these 64 crops: bf16 final mean 1.00 / median 0.82 / p90 1.88 / max 4.2 mm, intermediate 3-D estimates
+                                          # jump for 2.6 % / 13.4 % of the joints and block 1's refined estimate for 1.0 % — BatchNorm backbones round harder in bf16 than the
+                                          # LayerNorm ones; the FINAL estimate does not jump)
+                                          ("resnet-18", "bf16", dict(mean=1.5, median=1.2, p90=2.8, vmax=8.0, jump_mid=0.20, jump_2d=0.02)),
+                                          ("resnet-18", "f16", dict(mean=0.5, median=0.3, p90=1.2, vmax=6.0, jump_mid=0.04, jump_2d=0.005))])
+def test_reduced_precision_deviation_statistics_over_many_batches(net, prec, lim):
     """The 16-bit accuracy claim with statistics under it: 8 input seeds x B = 8 = 1344 joints per stage against the fp32 DEVICE forward
     (which the parity tests pin to the oracle within 1e-4 mm), instead of one batch of four.  Bounds from the distribution measured over 16 x 8 crops
     (tools/precision_stats.py -> profiles/r05_precision_stats.txt): final estimate bf16 mean 0.86 +- 0.32 (worst batch 1.69), median 0.58, p90 1.84,
@@ -322,7 +328,7 @@ def test_reduced_precision_deviation_statistics_over_many_batches(prec, lim):
     neighbourhood or top-4 pixel set changed by one point) for 5.2 % (bf16) / 0.7 % (f16) of the joints: counted, and bounded, not averaged away."""
     import numpy as np
     dev = _dev()
-    m32, m16 = _model("convnext-tiny", "f32"), _model("convnext-tiny", prec)
+    m32, m16 = _model(net, "f32"), _model(net, prec)
 
     class Loader:
         img_size, flip = 128, 1
@@ -340,14 +346,46 @@ def test_reduced_precision_deviation_statistics_over_many_batches(prec, lim):
     fin = v[3]
     stats = dict(mean=float(fin.mean()), median=float(np.median(fin)), p90=float(np.percentile(fin, 90)), vmax=float(fin.max()))
     jumps = [float((x > 5.0).mean()) for x in v]
-    print("reduced precision %s over %d joints per stage: final %s; joints > 5 mm per stage %s" % (prec, fin.size, {k: round(x, 3) for k, x in stats.items()}, ["%.3f" % j for j in jumps]))
+    print("reduced precision %s %s over %d joints per stage: final %s; joints > 5 mm per stage %s" % (net, prec, fin.size, {k: round(x, 3) for k, x in stats.items()}, ["%.3f" % j for j in jumps]))
     for k in ("mean", "median", "p90", "vmax"):
         assert stats[k] < lim[k], (prec, k, stats)
-    assert jumps[3] <= 0.005 and jumps[1] <= 0.005, (prec, jumps)          # the 2-D refined estimates (what the metric reads) do not jump
+    assert jumps[3] <= 0.005 and jumps[1] <= lim["jump_2d"], (prec, jumps)    # the final estimate (what the metric reads) does not jump; block 1's refined one rarely
     assert max(jumps[0], jumps[2]) <= lim["jump_mid"], (prec, jumps)          # the intermediate 3-D estimates do, rarely
     # f16 is the recommended reduced-precision mode: its final estimate is at least twice as close as bf16's on the same crops (measured: 4x)
     if prec == "f16":
         assert stats["mean"] < 0.5
+
+
+@pytest.mark.parametrize("net", ["convnext-tiny", "resnet-18"])
+def test_reduced_precision_deviation_on_the_reference_demo_crop(net):
+    """The one REAL crop this repo can hold (BASELINE configs[0]: visualization/box* cropped as demo_RGBD.py does; tests/golden/demo_box_*): the 16-bit
+    forwards against the fp32 device forward on it, in mm, per stage — a real hand's depth statistics instead of the synthetic disc.
+    Weights are still synthetic (no checkpoint exists here), so the bound is the many-batch distribution's, not an accuracy claim."""
+    import numpy as np
+    from test_preprocess import P, _frame
+    dev = _dev()
+    rgb, depth, bbox, cam = _frame()
+    pre = P.prepare_rgbd(rgb, depth, bbox, cam)
+    b = {k: torch.from_numpy(np.ascontiguousarray(pre[k]))[None].to(dev) for k in ("img_rgb", "img", "pcl", "center", "M", "cube", "cam_para")}
+
+    class Loader:
+        img_size, flip = 128, 1
+
+    out = {}
+    for prec in ("f32", "bf16", "f16"):
+        with torch.no_grad():
+            out[prec] = _model(net, prec)(b["img_rgb"], b["img"], b["pcl"], Loader(), b["center"], b["M"], b["cube"], b["cam_para"], 0.8)[0]
+    half = b["cube"].view(1, 1, 3) / 2
+    rep = {}
+    for prec in ("bf16", "f16"):
+        d = [((out[prec][2 + st] - out["f32"][2 + st]) * half).norm(dim=-1).reshape(-1).cpu().numpy() for st in range(4)]
+        rep[prec] = d
+        print("demo crop %s %s vs fp32: per stage mean %s max %s mm" % (net, prec, ["%.3f" % x.mean() for x in d], ["%.3f" % x.max() for x in d]))
+        assert all(np.isfinite(x).all() for x in d)
+    # final estimate (stage 4, what the metric reads): inside the worst single batch of the synthetic distribution (bf16 1.69 mm mean / f16 0.5), no jump
+    assert rep["bf16"][3].mean() < 3.0 and rep["bf16"][3].max() < 8.0, rep["bf16"][3]
+    assert rep["f16"][3].mean() < 0.8 and rep["f16"][3].max() < 5.0, rep["f16"][3]
+    assert rep["f16"][3].mean() <= rep["bf16"][3].mean() + 0.05, "f16 is the recommended reduced-precision mode"
 
 
 def test_full_model_bf16_at_the_stated_batch_of_configs2():

@@ -717,8 +717,18 @@ def test_loss_scaler_checks_unscales_skips_and_adapts_on_the_device():
     assert sc.get_scale() == 2.0 ** 9 and int(sc.skipped) == 2
     sd = sc.state_dict()
     sc2 = T.LossScaler(device=dev)
-    sc2.load_state_dict(sd)
-    assert sc2.get_scale() == 2.0 ** 9
+    addr = (sc2.scale_t.data_ptr(), sc2.inv_scale.data_ptr(), sc2.tracker.data_ptr(), sc2.found.data_ptr(), sc2.skipped.data_ptr())
+    sc2.load_state_dict(dict(sd, growth_tracker=1))
+    assert sc2.get_scale() == 2.0 ** 9 and float(sc2.inv_scale) == 2.0 ** -9 and int(sc2.tracker) == 1
+    # restored IN PLACE: a graph captured on these tensors keeps seeing them
+    assert addr == (sc2.scale_t.data_ptr(), sc2.inv_scale.data_ptr(), sc2.tracker.data_ptr(), sc2.found.data_ptr(), sc2.skipped.data_ptr())
+    sc3 = T.LossScaler()  # no device yet: the tracker waits for the first use
+    sc3.load_state_dict({"scale": 2.0 ** 7, "growth_tracker": 3})
+    assert sc3.state_dict() == {"scale": 2.0 ** 7, "growth_tracker": 3}
+    sc3.scale(torch.ones((), device=dev))
+    assert sc3.get_scale() == 2.0 ** 7 and int(sc3.tracker) == 3
+    with pytest.raises(RuntimeError, match="cannot move"):
+        sc3._to(torch.device("cpu"))
 
 
 @pytest.mark.gpu
@@ -770,3 +780,7 @@ def test_fp16_training_with_loss_scaling_follows_the_fp32_gradients_and_replays_
     losses = [float(step(b)) for _ in range(8)]
     assert all(math.isfinite(v) for v in losses) and losses[-1] < losses[0], losses
     assert int(sc.skipped) == 0 and sc.get_scale() >= 2.0 ** 12  # (clean steps: the scale only grew)
+    # resume on a LIVE captured step: the restored scale and tracker are the ones the next replays run on and update
+    sc.load_state_dict({"scale": 2.0 ** 8, "growth_tracker": 3})
+    float(step(b))
+    assert sc.get_scale() == 2.0 ** 9 and int(sc.tracker) == 0, (sc.get_scale(), int(sc.tracker))  # tracker 3 + one clean step = growth_interval 4: doubled
