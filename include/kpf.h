@@ -222,6 +222,10 @@ int kpf_ball_group_f32(const float* pcl, const float* joint_xyz, const float* X,
 
 /* max over groups of `group` consecutive rows (torch.max(dim=-1), model/model.py:198). */
 int kpf_group_max_f32(const float* in, float* out, long rows, int group, int C, int out_ld, int out_coff, void* stream);
+/* The same grouping with the three radii CHANNEL-STACKED (ABI 16; the training step's grouped DESA launches): GF [B*21*64][3*128] grouped feature
+ * differences, GX [B*21*64][3*4] offsets / radius (3 + a zero channel) — radius i in columns [128 i, 128 i + 128) / [4 i, 4 i + 4). */
+int kpf_ball_group_stacked_f32(const float* pcl, const float* joint_xyz, const float* X, const float* JF, int jf_ld, float* GF, float* GX, int* idx_out,
+                               int B, int N, float r0, float r1, float r2, void* stream);
 
 /* Heat-map, geometry adjacency map, spatial attention, gate (model/model.py:334-338; util/generateFeature.py:584-600;
  * dataloader/loader.py:791-819).  SF [B*P][sf_ld] = feature part of atten_spatial (a GEMM), Wh [21][21] its heat-map part.
@@ -420,6 +424,14 @@ int kpf_row_gather_accum_f32(const float* dout, const int* start, const int* lis
  * layers) and GELU(erf) (convNeXT/convnext.py:33), forward and backward.  x [rows][C] fp32, C % 4 == 0, C <= 1024; y in y_dtype (fp32 or the
  * 16-bit operand type of the following GEMM); mean / rstd [rows] are kept for the backward.  backward: dx fp32, dw / db [C] column sums over
  * all rows added in a fixed order through ws (>= kpf_ln_ws_floats(rows, C) floats).  GELU: element-wise on n % 4 == 0 elements of `dtype`. */
+/* Training (ABI 16): backward of kpf_ball_group_stacked_f32 towards the features, all three radii in one launch: d3 [B*Jn*64][ld3] (radius i in columns
+ * [128 i, 128 i + 128)), start / list = kpf_row_gather_invert of idx [3][B][Jn*64] as 3 B images of P = N + Jn rows (G = 1); dX [B][N][128] for the point
+ * features, dnode [B][Jn][128] for the joint features (their gathered rows minus the group sums of the centre subtraction).  Fixed summation order. */
+int kpf_ball_group_bwd_f32(const float* d3, int ld3, const int* start, const int* list, float* dX, float* dnode, int B, int N, int Jn, void* stream);
+/* Training (ABI 16): y[r][c] = max over the `group` consecutive rows of x [rows*group][C] (model/model.py:192 `.max(2)` over a ball's 64 members), the
+ * first maximum's member index kept in arg [rows][C]; backward: dx[r][m][c] = (m == arg[r][c]) ? dy[r][c] : 0, every element written once. */
+int kpf_group_max_train_forward(const float* x, float* y, unsigned char* arg, long rows, int group, int C, void* stream);
+int kpf_group_max_train_backward(const float* dy, const unsigned char* arg, float* dx, long rows, int group, int C, void* stream);
 long kpf_ln_ws_floats(long rows, int C);
 int kpf_ln_train_forward(const float* x, const float* w, const float* b, void* y, int y_dtype, float* mean, float* rstd, long rows, int C, float eps,
                          void* stream);
@@ -609,6 +621,7 @@ int kpf_colsum_reduce_grouped(const kpf_colsum_desc* descs, int n, void* stream)
  *             kpf_linear_wgrad_grouped; LayerNorm parameter gradients leave as per-sample partial sums parts[layer][ln][B][2][128]
  *             (kpf_tr_stack_part_floats(B); a kpf_colsum_desc with nblk = B, C = 128 each).  Dropout masks are recomputed from the (seed, counter) the
  *             forward stored in `save`.  Fixed summation order: bit-identical replays. */
+int kpf_tr_stack_set_stamps(void* stamps64 /* tuning aid: 64 device uint64 slots for in-kernel wall-clock stamps of workgroup 0; NULL = off */);
 long kpf_tr_stack_save_floats(int B);
 long kpf_tr_stack_out_offset(int B);
 long kpf_tr_stack_dy_floats(int B);

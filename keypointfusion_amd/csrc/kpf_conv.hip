@@ -51,6 +51,7 @@ struct ConvArgs {
   int tilesN, nblk;
   int vec;  // 1: output/residual rows are 16-byte aligned -> float4 epilogue
   int dbg;  // tuning aid (KPF_G8_DBG, gemm16_8ph_kernel only): 1 = no activation, 2 = no global stores, 4 = no main loop
+  int st_policy;  // output stores of the store-only 16-bit GEMM epilogues: 0 plain, 1 `sc1` (write-through: the line is not kept in the XCD's L2), 2 `nt` (KPF_G8_ST)
   int skew;  // opt-in start skew of the odd workgroup slot of a CU, in units of ~2048 clocks (KPF_STAGGER, fp32 NS = 2 launches; 0 = off, the default)
   // grouped launch (kpf_conv_desc::groups > 1, grid.y = group): group g consumes input channels from in_coff + g * g_in (staging units), uses the weights at
   // w + g * g_w (4-byte words) and bias[g * g_out + n], and writes output channels from out_coff + g * g_out (g_out = N).  All zero for an ordinary launch.
@@ -977,6 +978,14 @@ double cfg_cost(const Cfg& c, long M, long N, int groups = 1) {  // (a grouped l
 //    q4:                                           DMA B-half1 of tile t+2 -> buffer b | vmcnt(6)      | barrier | 16 MFMA quadrant (1,0) | barrier
 //  Requirements (the dispatcher checks them): dense 1x1, K % 128 == 0 (an even number of K tiles), N % 256 == 0, 16-byte aligned rows.
 // ---------------------------------------------------------------------------------------------------------------------------------
+// 16-byte output store under a cache policy chosen at launch (wave-uniform branch).  A GEMM whose output is larger than the L2s writes every byte through its XCD's
+// L2 exactly once; with plain stores those lines stay in the L2 and push the weight panels out (M = 65536, N = 2048: 4 MB of results per XCD and round of
+// tiles = the whole L2), so the next round fetches the weights again from the Infinity Cache.  `sc1` stores go to memory without keeping the line.
+__device__ __forceinline__ void g8_store16(void* p, const f32x4 q, const int policy) {
+  if (policy == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(q) : "memory");
+  else if (policy == 2) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(q) : "memory");
+  else *reinterpret_cast<f32x4*>(p) = q;
+}
 constexpr int G8_BUF = 65536, G8_HALF = 16384, G8_B = 32768;  // bytes: K-tile buffer, half-tile, offset of the B halves inside a buffer
 template <int V> using ic = std::integral_constant<int, V>;
 
@@ -1292,7 +1301,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_8ph_kernel(const ConvArgs a) {
     for (int r = 0; r < 16; ++r) {
       const int px = r * 8 + prow;
       const f32x4 q = *reinterpret_cast<const f32x4*>(stg + px * RS + pch);
-      if (cm0 + wr * 128 + px < a.M && !(a.dbg & 2)) *reinterpret_cast<f32x4*>(ob + (long)px * a.out_ld + pch) = q;
+      if (cm0 + wr * 128 + px < a.M && !(a.dbg & 2)) g8_store16(ob + (long)px * a.out_ld + pch, q, a.st_policy);
     }
   } else {
     // persistent form: the K buffers already receive the next tile, so the results are staged 32 pixels at a time through the wave's 4 KB beyond them
@@ -1325,7 +1334,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_8ph_kernel(const ConvArgs a) {
       for (int r = 0; r < 4; ++r) {
         const int row = r * 8 + prow;
         const f32x4 q = *reinterpret_cast<const f32x4*>(stg + row * 128 + (pcp << 4));
-        *reinterpret_cast<f32x4*>(ob + (long)(c * 32 + row) * a.out_ld + ((pcp ^ (row & 7)) << 3)) = q;
+        g8_store16(ob + (long)(c * 32 + row) * a.out_ld + ((pcp ^ (row & 7)) << 3), q, a.st_policy);
       }
     }
   }
@@ -1344,6 +1353,10 @@ int launch_8ph(ConvArgs& a, hipStream_t st) {
   a.tilesN = a.N / 256;
   a.nblk = ((a.M + 255) / 256) * a.tilesN;
   static const bool no_persist = getenv("KPF_G8_NO_PERSIST") != nullptr;  // tuning aid
+  // output stores (store-only epilogues): KPF_G8_ST = 0 plain, 1 sc1, 2 nt; default: sc1 when the output alone is larger than the eight L2s (32 MB) —
+  // g8_store16 above
+  static const int st_env = []() { const char* e = getenv("KPF_G8_ST"); return e ? atoi(e) : -1; }();
+  a.st_policy = res ? 0 : (st_env >= 0 ? st_env : 0);
   const bool persist = !res && a.M % 256 == 0 && a.nblk > 256 && !no_persist && !a.dbg;
   const bool lnf = (a.flags & KPF_PRO_LN) != 0;  // (kpf_conv2d_h16 admits it with the GELU epilogue only)
   void (*kern)(const ConvArgs) = res ? gemm16_8ph_kernel<EPI_RES, ARITH, false>
@@ -1361,306 +1374,8 @@ int launch_8ph(ConvArgs& a, hipStream_t st) {
   return kpf_check_launch("kpf_conv2d_h16");
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// gemm16_dfe_kernel (round 5): 256 x 128 tiles, persistent, with a DEFERRED epilogue — the answer to profiles/r04_g8_ablation.txt, where a K = 512
-// GELU layer spends 60 % of a tile's time in its epilogue (GELU on the vector ALU, 128 KB of stores) with the matrix pipe idle, and where stores
-// issued from inside the main loop bought nothing because they sit in the same in-order vmcnt queue as the LDS-DMA.  Here
-//  * a tile's raw accumulators (64 registers: 8 waves = 4 pixel quarters x 2 channel groups, wave tile 64 x 64) are parked in a second register set
-//    when its K loop ends, and its epilogue runs INSIDE the next tile's K loop in eight equal steps, one per K tile: a half-strip (16 rows x 32
-//    channels per wave) gets bias + activation, is rounded to the storage type and written to one of two 8-KB LDS staging slots; one K tile later the
-//    store waves send it to memory as whole 128-byte row halves.  The vector-ALU work (8 GELUs per lane and K tile) is spread evenly under the MFMAs;
-//  * memory duties are split by wave so that no wave's vmcnt queue mixes loads and stores: waves 0-3 issue ALL LDS-DMA (12 instructions per K tile
-//    each) and wait on it with a counted vmcnt(12); waves 4-7 issue ALL global stores and never wait for them inside the loop (the staged data is in
-//    registers before the store is issued).  Every wave multiplies; a SIMD hosts one wave of each kind;
-//  * the K-tile stream is continuous across output tiles: a 3-stage ring of 48-KB buffers (A 256 rows + B 128 rows of 64 elements), two K tiles in
-//    flight, the first K tiles of the next output tile staged under the last MFMAs of the current one; one barrier per K tile; the fragments of a
-//    32-deep k-step are read one step ahead of the MFMAs that consume them (the second k-step of K tile g multiplies at the top of iteration g + 1),
-//    so no MFMA waits for an LDS read issued in its own iteration;
-//  * a wave's four channel tiles are {0-15, 16-31} + 32 wc and 64 + the same (wc = channel group), so that the tiles of one epilogue step of both
-//    channel groups form 64 contiguous channels;
-//  * the bias is fetched with scalar loads (s_load: lgkmcnt) and selected per lane, so that no wave needs a vector load whose result the compiler
-//    would guard with vmcnt(0).
-// Same LDS row image, swizzle, packed weights and k order as igemm_body / gemm16_8ph_kernel: results are bit-identical to theirs.
-// Requirements (dfe_applies): dense 1x1, K % 64 == 0 with at least 8 K tiles, N % 128 == 0, M % 256 == 0, linear / ReLU / GELU epilogue, 16-byte rows.
-// ---------------------------------------------------------------------------------------------------------------------------------
-#ifndef DFE_INTERLEAVE
-#define DFE_INTERLEAVE 0
-#endif
-constexpr int DF_A = 32768, DF_BUF = 49152, DF_STG = 3 * DF_BUF;  // bytes: A region of a K-tile buffer, a K-tile buffer, offset of the two 8-KB staging slots
-
-template <int EPI, int ARITH>
-__global__ __launch_bounds__(512, 2) void gemm16_dfe_kernel(const ConvArgs a) {
-  using TH = typename std::conditional<ARITH == ARITH_BF16, bf16_t, f16_t>::type;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  char* const LB = reinterpret_cast<char*>(lds);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wq = wave & 3, wc = wave >> 2;  // pixel quarter, channel group; waves wq and wq + 4 share a SIMD
-  const bool dma_wave = wc == 0;            // waves 0-3: LDS-DMA; waves 4-7: global stores
-  const int G = (int)gridDim.x;
-  int bid = blockIdx.x;
-  {  // XCD-aware bijective remap of every round of G tiles (igemm_body): an XCD gets a contiguous range, channel tiles fastest
-    const int q = G >> 3, r = G & 7, x = bid & 7, i = bid >> 3;
-    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
-  }
-  const int nk = a.Kp / BK;
-  const int mine = (a.nblk - bid + G - 1) / G;  // output tiles of this workgroup: bid, bid + G, ...
-  const int total = mine * nk;                  // K tiles it multiplies
-
-  // ---- staging cursor (runs two K tiles ahead of the multiply cursor, across output tiles) ----
-  const int r8 = lane >> 3, cp = lane & 7, x4 = lane >> 4;
-  const int kce = ((cp ^ x4) << 2), kco = (((cp ^ x4) ^ 4) << 2);  // logical k offset (words) of this lane's chunk in even / odd 8-row groups: (row >> 1) & 7 = (4 t + x4) & 7
-  int s_tile = bid, s_kt = 0;
-  // source address of a piece = a wave-uniform base (SGPR pair: tile row block, K tile) + a per-lane 32-bit byte offset (row within the 8-row piece,
-  // swizzled chunk): the scalar-base form of global_load_lds needs no address VGPRs per piece (twelve 64-bit lane addresses spilled to scratch)
-  const unsigned voa_e = (unsigned)(r8 * a.in_ld + kce) * 4u, voa_o = (unsigned)(r8 * a.in_ld + kco) * 4u;
-  const unsigned vob_e = (unsigned)(r8 * a.Kp + kce) * 4u, vob_o = (unsigned)(r8 * a.Kp + kco) * 4u;
-  const char *sa = reinterpret_cast<const char*>(a.in), *sb = reinterpret_cast<const char*>(a.w);
-  auto s_set = [&]() {
-    const int nt = s_tile % a.tilesN, mt = s_tile / a.tilesN;
-    sa = reinterpret_cast<const char*>(a.in + (long)(mt * 256 + wq * 64) * a.in_ld + a.in_coff);
-    sb = reinterpret_cast<const char*>(a.w + (long)(nt * 128 + wq * 32) * a.Kp);
-  };
-  s_set();
-  // DMA waves: the 12 DMAs of K tile (s_tile, s_kt) into ring slot s_g % 3 in two parts of six (each part rides between the MFMAs of one k-step), then advance
-  auto stage_part = [&](int slot3, auto HALF) {
-    constexpr int half = decltype(HALF)::value;
-    char* const dst = LB + slot3 * DF_BUF;
-    const long ko = (long)s_kt * BK * 4;
-#pragma unroll
-    for (int t = (half ? 6 : 0); t < (half ? 8 : 6); ++t)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(sa + ((long)(8 * t) * a.in_ld * 4 + ko) + ((t & 1) ? voa_o : voa_e)), (lds_void_t*)(dst + (wq * 64 + 8 * t) * 128), 16, 0, 0);
-    if constexpr (half == 1) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(sb + ((long)(8 * t) * a.Kp * 4 + ko) + ((t & 1) ? vob_o : vob_e)), (lds_void_t*)(dst + DF_A + (wq * 32 + 8 * t) * 128), 16, 0, 0);
-      if (++s_kt == nk) {
-        s_kt = 0;
-        s_tile += G;
-        s_set();
-      }
-    }
-  };
-
-  // ---- fragments / accumulators ----
-  const int fr = lane & 15, fg = lane >> 4, rsw = (fr >> 1) & 7;
-  const int ch0 = ((fg ^ rsw) << 4), ch1 = (((4 + fg) ^ rsw) << 4);
-  const char* const a_rd = LB + (wq * 64 + fr) * 128;           // pixel tile j: + j * 2048
-  const char* const b_rd = LB + DF_A + (wc * 32 + fr) * 128;    // channel tile i (local channels (i >> 1) * 64 + wc * 32 + (i & 1) * 16): + (i >> 1) * 8192 + (i & 1) * 2048
-  f32x4 acc[4][4], prev[4][4];  // [channel tile i][pixel tile j]; prev = the parked tile's sums + bias
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = prev[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int c_tile = bid, m0 = (c_tile / a.tilesN) * 256, n0 = (c_tile % a.tilesN) * 128;
-  int pm0 = 0, pn0 = 0;          // the parked tile
-  bool has_prev = false;
-  int q_pend = 0, q_row = 0, q_col = 0;  // a half-strip waits in a staging slot: its first output row (+ (sr >> 4) * 64 + (sr & 15)) and column
-  const unsigned fl = a.flags;
-  constexpr bool ileave = DFE_INTERLEAVE;  // DMA pieces between the MFMAs (needs more registers than the kernel has: spills; kept for the record, off)
-
-  // ---- deferred epilogue steps (ring and staging slots are compile-time constants everywhere: with run-time LDS offsets hipcc cannot tell a ds_read
-  //      from the LDS-DMA still in flight into ANOTHER slot and guards it with vmcnt(0), which would serialise the whole pipeline) ----
-  int oz = 0;  // an opaque zero, renewed every K tile: address arithmetic that includes it is recomputed where it is used (a handful of VALU operations) instead of
-               // being hoisted out of the loop into registers that live across it — the hoisted form needed 20 more VGPRs than exist and spilled (scratch reloads
-               // are VMEM operations: they would sit in the DMA waves' vmcnt queue)
-  auto write_half = [&](auto J, auto IH, auto SLOT) {  // every wave: rows j * 16 + fr of its quarter, channel tiles 2 ih and 2 ih + 1 -> staging rows wq * 16 + fr
-    constexpr int j = decltype(J)::value, ih = decltype(IH)::value, slot = decltype(SLOT)::value;
-    const int sr = wq * 16 + fr + oz;
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii) {
-      f32x4 v = prev[2 * ih + ii][j];  // (sum + bias: added when the tile was parked)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (EPI == EPI_GELU) v[e] = gelu_of<ARITH>(v[e]);
-        else v[e] = (fl & KPF_ACT_RELU) ? fmaxf(v[e], 0.f) : ((fl & KPF_ACT_LEAKY) ? fmaxf(v[e], 0.01f * v[e]) : v[e]);
-      }
-      kpf_st4(reinterpret_cast<TH*>(LB + DF_STG + slot * 8192 + sr * 128 + (((wc * 4 + ii * 2 + (fg >> 1)) ^ ((sr >> 1) & 7)) << 4) + (fg & 1) * 8), v);
-    }
-    q_pend = 1;
-    q_row = pm0 + j * 16;
-    q_col = pn0 + ih * 64;
-  };
-  auto store_half = [&](auto SLOT) {  // store waves: 16 staging rows each as 128-byte row halves (8 lanes x 16 bytes), 8 rows per instruction
-    constexpr int slot = decltype(SLOT)::value;
-    if (q_pend && !dma_wave) {
-      TH* const ob = reinterpret_cast<TH*>(a.out) + a.out_coff + q_col + (lane & 7) * 8;
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int sr = wq * 16 + u * 8 + (lane >> 3) + oz;
-        const f32x4 q = *reinterpret_cast<const f32x4*>(LB + DF_STG + slot * 8192 + sr * 128 + (((lane & 7) ^ ((sr >> 1) & 7)) << 4));
-        *reinterpret_cast<f32x4*>(ob + (long)(q_row + (sr >> 4) * 64 + (sr & 15)) * a.out_ld) = q;
-      }
-    }
-    q_pend = 0;
-  };
-  auto park = [&]() {  // the output tile whose last MFMAs were just issued: sums + bias to the second register set, its position; next tile
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-      if (a.bias) {  // scalar loads (lgkmcnt, not vmcnt) of the channel tile's 16 bias values, selected per lane group
-        const float* bp = a.bias + n0 + (i >> 1) * 64 + wc * 32 + (i & 1) * 16;
-        f32x4 b0, b1, b2, b3;
-        asm volatile("s_load_dwordx4 %0, %4, 0x0\n\ts_load_dwordx4 %1, %4, 0x10\n\ts_load_dwordx4 %2, %4, 0x20\n\ts_load_dwordx4 %3, %4, 0x30\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&s"(b0), "=&s"(b1), "=&s"(b2), "=&s"(b3) : "s"(bp) : "memory");
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bv[e] = fg == 0 ? b0[e] : (fg == 1 ? b1[e] : (fg == 2 ? b2[e] : b3[e]));
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) prev[i][j][e] = acc[i][j][e] + bv[e];
-        acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    }
-    pm0 = m0;
-    pn0 = n0;
-    has_prev = true;
-    c_tile += G;
-    m0 = (c_tile / a.tilesN) * 256;
-    n0 = (c_tile % a.tilesN) * 128;
-  };
-  f16x8 x0[4], w0[4], x1[4], w1[4];  // fragments of k-step 0 / 1 of the K tile being multiplied
-  auto read_step = [&](int slot3, int chunk, f16x8(&x)[4], f16x8(&w)[4]) {
-    const char* const ab = a_rd + slot3 * DF_BUF + chunk;
-    const char* const bb = b_rd + slot3 * DF_BUF + chunk;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) x[j] = *reinterpret_cast<const f16x8*>(ab + j * 2048);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = *reinterpret_cast<const f16x8*>(bb + (i >> 1) * 8192 + (i & 1) * 2048);
-  };
-  auto mma_raw = [&](const f16x8(&x)[4], const f16x8(&w)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if constexpr (ARITH == ARITH_BF16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[i]), __builtin_bit_cast(bf16x8, x[j]), acc[i][j], 0, 0, 0);
-        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[i], x[j], acc[i][j], 0, 0, 0);
-      }
-  };
-  auto mma = [&](const f16x8(&x)[4], const f16x8(&w)[4]) {
-    __builtin_amdgcn_s_setprio(1);
-    mma_raw(x, w);
-    __builtin_amdgcn_s_setprio(0);
-  };
-  // a k-step's 16 MFMAs with six LDS-DMA pieces between them (DMA waves): an LDS-DMA piece costs its wave ~60-100 issue cycles (MI355X_MICROARCH "LDS-DMA
-  // piece issue cost"); twelve in a row in front of the MFMAs made the four DMA waves the critical path of every K tile (2700 cycles per K tile against
-  // 1024 of MFMA: profiles/r05_dfe_ablation.txt); two MFMAs, one piece, ... lets the SIMD's matrix pipe run meanwhile
-  auto mma_dma = [&](const f16x8(&x)[4], const f16x8(&w)[4], int slot3, auto HALF) {
-    __builtin_amdgcn_sched_barrier(0);
-    stage_part(slot3, HALF);
-    mma_raw(x, w);
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  int kt = 0;
-  // one K tile: ring slot `slot` = g % 3 is multiplied, slot (slot + 2) % 3 is refilled with K tile g + 2
-  auto ktile = [&](int slot, int g) {
-    const int nslot = slot == 0 ? 2 : slot - 1;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (this wave's fragment reads of K tile g - 1 are in registers: its ring slot may be refilled after the barrier)
-    if (dma_wave) {
-      if (g + 1 < total) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // K tile g has landed (g + 1 may be in flight)
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();  // K tile g is everyone's; everyone has read K tile g - 1 (slot nslot); the staging slots are in their next phase
-    __builtin_amdgcn_sched_barrier(0);
-    const bool staging = dma_wave && g + 2 < total;  // this wave stages K tile g + 2 in this iteration
-    asm volatile("" : "+v"(oz));
-    read_step(slot, ch0, x0, w0);
-    if (staging && !ileave) {
-      stage_part(nslot, ic<0>{});
-      stage_part(nslot, ic<1>{});
-    }
-    if (staging && ileave) mma_dma(x1, w1, nslot, ic<0>{});  // second k-step of K tile g - 1
-    else mma(x1, w1);
-    if (kt == 0) park();  // ... which completed an output tile
-    if (has_prev) {  // one step of the parked tile's epilogue per K tile: the half-strip of the previous step leaves, the next one is staged
-      switch (kt) {
-        case 0: store_half(ic<1>{}); write_half(ic<0>{}, ic<0>{}, ic<0>{}); break;
-        case 1: store_half(ic<0>{}); write_half(ic<0>{}, ic<1>{}, ic<1>{}); break;
-        case 2: store_half(ic<1>{}); write_half(ic<1>{}, ic<0>{}, ic<0>{}); break;
-        case 3: store_half(ic<0>{}); write_half(ic<1>{}, ic<1>{}, ic<1>{}); break;
-        case 4: store_half(ic<1>{}); write_half(ic<2>{}, ic<0>{}, ic<0>{}); break;
-        case 5: store_half(ic<0>{}); write_half(ic<2>{}, ic<1>{}, ic<1>{}); break;
-        case 6: store_half(ic<1>{}); write_half(ic<3>{}, ic<0>{}, ic<0>{}); break;
-        case 7: store_half(ic<0>{}); write_half(ic<3>{}, ic<1>{}, ic<1>{}); break;
-        case 8: store_half(ic<1>{}); break;
-        default: break;
-      }
-    }
-    read_step(slot, ch1, x1, w1);
-    if (staging && ileave) mma_dma(x0, w0, nslot, ic<1>{});  // first k-step of K tile g
-    else mma(x0, w0);
-    if (++kt == nk) kt = 0;
-  };
-
-  // ---- the K-tile stream ----
-  if (dma_wave) {
-    stage_part(0, ic<0>{});
-    stage_part(0, ic<1>{});
-    if (total > 1) {
-      stage_part(1, ic<0>{});
-      stage_part(1, ic<1>{});
-      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-  }
-  __builtin_amdgcn_s_barrier();  // K tile 0 is everyone's
-  __builtin_amdgcn_sched_barrier(0);
-  if (dma_wave && total > 2) {
-    stage_part(2, ic<0>{});
-    stage_part(2, ic<1>{});
-  }
-  read_step(0, ch0, x0, w0);
-  read_step(0, ch1, x1, w1);
-  mma(x0, w0);
-  kt = 1;  // (nk >= 8)
-  {
-    int slot = 1;
-    for (int g = 1; g < total; ++g) {
-      ktile(slot, g);
-      slot = slot == 2 ? 0 : slot + 1;
-    }
-  }
-  // ---- drain: the last K tile's second k-step, then the last tile's whole epilogue ----
-  mma(x1, w1);
-  __syncthreads();
-  if (kt == 0 || nk > 8) store_half(ic<1>{});  // (the half-strip staged last went to slot 1: step 7; with kt in 1..8 of an 8-K-tile tile it was slot (kt - 1) & 1)
-  else if ((kt - 1) & 1) store_half(ic<1>{});
-  else store_half(ic<0>{});
-  park();
-  __syncthreads();
-  write_half(ic<0>{}, ic<0>{}, ic<0>{}); __syncthreads(); store_half(ic<0>{}); __syncthreads();
-  write_half(ic<0>{}, ic<1>{}, ic<1>{}); __syncthreads(); store_half(ic<1>{}); __syncthreads();
-  write_half(ic<1>{}, ic<0>{}, ic<0>{}); __syncthreads(); store_half(ic<0>{}); __syncthreads();
-  write_half(ic<1>{}, ic<1>{}, ic<1>{}); __syncthreads(); store_half(ic<1>{}); __syncthreads();
-  write_half(ic<2>{}, ic<0>{}, ic<0>{}); __syncthreads(); store_half(ic<0>{}); __syncthreads();
-  write_half(ic<2>{}, ic<1>{}, ic<1>{}); __syncthreads(); store_half(ic<1>{}); __syncthreads();
-  write_half(ic<3>{}, ic<0>{}, ic<0>{}); __syncthreads(); store_half(ic<0>{}); __syncthreads();
-  write_half(ic<3>{}, ic<1>{}, ic<1>{}); __syncthreads(); store_half(ic<1>{});
-}
-
-template <int ARITH>
-int launch_dfe(ConvArgs& a, hipStream_t st) {
-  const bool gelu = a.flags & KPF_ACT_GELU;
-  a.tilesN = a.N / 128;
-  a.nblk = (a.M / 256) * a.tilesN;
-  void (*kern)(const ConvArgs) = gelu ? gemm16_dfe_kernel<EPI_GELU, ARITH> : gemm16_dfe_kernel<EPI_LIN, ARITH>;
-  static std::atomic<bool> lds_opt_in[2][KPF_MAX_DEVICES];
-  if (!kpf_raise_lds_limit(reinterpret_cast<const void*>(kern), lds_opt_in[gelu ? 1 : 0])) {
-    kpf_set_error("kpf_conv2d_h16: cannot raise the dynamic LDS limit");
-    return KPF_ELAUNCH;
-  }
-  const int grid = a.nblk < 256 ? a.nblk : 256;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), (size_t)(DF_STG + 16384), st, a);
-  return kpf_check_launch("kpf_conv2d_h16");
-}
+// (round 6: gemm16_dfe_kernel — the 256 x 128 deferred-epilogue form of round 5, bit-identical to this kernel and measured equal or slower on every shape,
+//  profiles/r05_dfe_ablation.txt — was removed from the build; `git show 2d01941:keypointfusion_amd/csrc/kpf_conv.hip` has it.)
 
 // ---- 16-bit storage path (kpf_conv16.hip compiles this file with KPF_CONV_H16) ----
 template <int TM, int TN, int WM, int WN, int ARITH, int NS>
@@ -1718,12 +1433,6 @@ static bool g8_applies(const kpf_conv_desc* d, bool has_prologue) {
   //  KPF_FORCE_CFG16=30 cannot route such a launch to it either)
   const bool plain = d->groups <= 1 && !(fl & (KPF_RES_GELU_GRAD | KPF_ACT_GELU_SAVE));
   return plain && fast1x1 && d->Kp % 128 == 0 && d->N % 256 == 0 && !has_prologue && !(fl & KPF_OUT_NCHW) && vec && d->out_ld % 8 == 0 && d->out_coff % 8 == 0;
-}
-// which launches gemm16_dfe_kernel covers (the 256 x 128 deferred-epilogue kernel: linear / ReLU / GELU layers of at least 8 K tiles)
-static bool dfe_applies(const kpf_conv_desc* d, bool has_prologue) {
-  const unsigned fl = d->flags;
-  const long M = (long)d->B * d->OH * d->OW;
-  return g8_applies(d, has_prologue) && !(fl & KPF_RES_ADD) && d->N % 128 == 0 && M % 256 == 0 && d->Kp >= 512 && (M / 256) * (d->N / 128) >= 512;
 }
 static bool g8_preferred(const kpf_conv_desc* d) {
   const long M = (long)d->B * d->OH * d->OW;
@@ -1795,7 +1504,7 @@ extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void
     }
     a.zero = zero_of_dev[dev];
   }
-  a.flags = fl; a.tilesN = 0; a.nblk = 0; a.w_unscale = 1.0f; a.skew = 0;
+  a.flags = fl; a.tilesN = 0; a.nblk = 0; a.w_unscale = 1.0f; a.skew = 0; a.st_policy = 0;
   a.vec = (d->out_ld % 4 == 0 && d->out_coff % 4 == 0 && (!(fl & KPF_RES_ADD) || (d->res_ld % 4 == 0 && d->res_coff % 4 == 0))) ? 1 : 0;
   a.groups = d->groups > 1 ? d->groups : 1; a.g_in = a.g_out = 0; a.g_w = 0;
   if (a.groups > 1) {  // grouped launch: see ConvArgs
@@ -1815,9 +1524,6 @@ extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void
   const bool fast1x1 = pointwise && d->Cin % 64 == 0 && d->Kp == d->Cin;  // whole 64-element K tiles, no K mask
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
-#ifdef KPF_ONLY_DFE  // tuning aid: a translation unit with nothing but gemm16_dfe_kernel (ISA inspection in seconds), never shipped
-  return dtype == KPF_DT_BF16 ? launch_dfe<ARITH_BF16>(a, st) : launch_dfe<ARITH_F16>(a, st);
-#else
   // Tile choice (tools/gemm16_bench.py on the ConvNeXt-B 512^2 shapes): the 16-bit GEMMs are bound by HBM traffic, staging and
   // barriers, not by the matrix pipe, and 128 x 128 tiles with several workgroups per CU beat 256 x 128 (one workgroup per CU) on
   // every heavy shape (65536 x 2048 x 512 + GELU: 585 vs 425 TFLOP/s); non-residual layers take the single-stage, 4-waves-per-SIMD
@@ -1872,11 +1578,6 @@ extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void
   static const int forced = []() { const char* e = getenv("KPF_FORCE_CFG16"); return e ? atoi(e) : -1; }();  // tuning aid only
   if (forced >= 0 && (forced != 30 || ok8)) best = forced;
   if (d->tile_cfg > 0 && (d->tile_cfg != 31 || ok8)) best = d->tile_cfg - 1;  // the caller's choice (tools/h16_small_sweep.py): case index + 1
-  static const int use_dfe = []() { const char* e = getenv("KPF_DFE"); return e ? atoi(e) : 0; }();  // tuning switch until the default is measured
-  const bool okd = dfe_applies(d, pro_scale != nullptr);
-  if (best == 30 && okd && use_dfe) best = 50;
-  if (best == 50 && !okd) best = ok8 ? 30 : 0;
-  if (best == 50) return dtype == KPF_DT_BF16 ? launch_dfe<ARITH_BF16>(a, st) : launch_dfe<ARITH_F16>(a, st);
   if (best == 30) return dtype == KPF_DT_BF16 ? launch_8ph<ARITH_BF16>(a, st) : launch_8ph<ARITH_F16>(a, st);
 #ifdef KPF_FAST_BUILD  // tuning aid: one tile shape only (asm inspection / quick syntax builds), never shipped
   return launch_cfg_h16<4, 4, 2, 2, 2>(a, fast1x1, pointwise, dtype, st);
@@ -1899,7 +1600,6 @@ extern "C" int kpf_conv2d_h16(const kpf_conv_desc* d, const void* in, const void
     case 44: return launch_cfg_h16<2, 1, 1, 4, 8>(a, fast1x1, pointwise, dtype, st);  // 32 x 64, 8-stage ring (96 KB)
     default: return launch_cfg_h16<2, 1, 1, 4, 2>(a, fast1x1, pointwise, dtype, st);  // 32 x 64
   }
-#endif  // KPF_ONLY_DFE
 }
 #else
 extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const float* w, const float* bias,
@@ -1950,7 +1650,7 @@ extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const flo
     }
     a.zero = zero_of_dev[dev];
   }
-  a.flags = fl; a.tilesN = 0; a.nblk = 0; a.dbg = 0; a.skew = 0;
+  a.flags = fl; a.tilesN = 0; a.nblk = 0; a.dbg = 0; a.skew = 0; a.st_policy = 0;
   a.w_unscale = (fl & (KPF_IN_SPLIT | KPF_W_SPLIT)) ? d->w_unscale : 1.0f;
   if (fl & (KPF_IN_SPLIT | KPF_W_SPLIT))
     KPF_REQUIRE(d->w_unscale > 0.f && d->Cin % 32 == 0 && d->in_coff % 4 == 0, "kpf_conv2d_f32: split operands need w_unscale > 0 and Cin %% 32 == 0 (Cin=%d)", d->Cin);

@@ -469,8 +469,11 @@ constexpr int G_LD = 132;
 
 __global__ __launch_bounds__(64) void ball_group_kernel(const float* __restrict__ pcl, const float* __restrict__ joint_xyz,
                                                         const float* __restrict__ X, const float* __restrict__ JF,
-                                                        float* __restrict__ G, int* __restrict__ idx_out, int N, int jf_ld, long g_stride,
-                                                        float r0, float r1, float r2) {
+                                                        float* __restrict__ GF, float* __restrict__ GX, int* __restrict__ idx_out, int N, int jf_ld,
+                                                        long gf_gs, int gf_ld, long gx_gs, int gx_ld, float r0, float r1, float r2) {
+  // output layout: radius ri's grouped feature differences go to GF + ri * gf_gs with row stride gf_ld, its scaled offsets (3 + a zero channel) to
+  // GX + ri * gx_gs with row stride gx_ld.  kpf_ball_group_f32: [3][rows][132] = [feat 128 | xyz 3 | 0] (gf_ld = gx_ld = 132, GX = GF + 128);
+  // kpf_ball_group_stacked_f32: the three radii CHANNEL-STACKED, [rows][3 * 128] and [rows][3 * 4] (the grouped launches of the training step).
   __shared__ int sidx[64];
   const int lane = threadIdx.x;
   const int bj = blockIdx.x, ri = blockIdx.y;
@@ -516,7 +519,8 @@ __global__ __launch_bounds__(64) void ball_group_kernel(const float* __restrict_
   if (idx_out) idx_out[((long)ri * gridDim.x + bj) * 64 + lane] = mine;
   __syncthreads();
   const float2 fj = *reinterpret_cast<const float2*>(JF + (long)bj * jf_ld + 2 * lane);
-  float* gb = G + (long)ri * g_stride + (long)bj * 64 * G_LD;
+  float* gb = GF + (long)ri * gf_gs + (long)bj * 64 * gf_ld;
+  float* xb = GX + (long)ri * gx_gs + (long)bj * 64 * gx_ld;
   // eight member rows per step: their loads are all requested before the first store (one member per iteration was a chain of 64 dependent round trips —
   // 45 of the kernel's 52 us at B = 32; round 5)
   const float ql = lane < 3 ? qp[lane] : 0.f;
@@ -539,8 +543,8 @@ __global__ __launch_bounds__(64) void ball_group_kernel(const float* __restrict_
       float2 o;
       o.x = f[u].x - fj.x;
       o.y = f[u].y - fj.y;
-      *reinterpret_cast<float2*>(gb + (long)(s0 + u) * G_LD + 2 * lane) = o;
-      if (lane < 4) gb[(long)(s0 + u) * G_LD + 128 + lane] = lane < 3 ? (pv[u] - ql) / radius : 0.f;
+      *reinterpret_cast<float2*>(gb + (long)(s0 + u) * gf_ld + 2 * lane) = o;
+      if (lane < 4) xb[(long)(s0 + u) * gx_ld + lane] = lane < 3 ? (pv[u] - ql) / radius : 0.f;
     }
   }
 }
@@ -793,9 +797,17 @@ extern "C" int kpf_ball_group_f32(const float* pcl, const float* joint_xyz, cons
                                   int* idx_out, int B, int N, float r0, float r1, float r2, void* stream) {
   KPF_REQUIRE(pcl && joint_xyz && X && JF && G && B > 0 && N > 0 && jf_ld >= 128 && jf_ld % 2 == 0, "kpf_ball_group_f32: bad arguments");
   const long g_stride = (long)B * J * 64 * G_LD;
-  hipLaunchKernelGGL(ball_group_kernel, dim3(B * J, 3), dim3(64), 0, ST(stream), pcl, joint_xyz, X, JF, G, idx_out, N, jf_ld, g_stride,
-                     r0, r1, r2);
+  hipLaunchKernelGGL(ball_group_kernel, dim3(B * J, 3), dim3(64), 0, ST(stream), pcl, joint_xyz, X, JF, G, G + 128, idx_out, N, jf_ld, g_stride, G_LD,
+                     g_stride, G_LD, r0, r1, r2);
   return kpf_check_launch("kpf_ball_group_f32");
+}
+
+extern "C" int kpf_ball_group_stacked_f32(const float* pcl, const float* joint_xyz, const float* X, const float* JF, int jf_ld, float* GF, float* GX,
+                                          int* idx_out, int B, int N, float r0, float r1, float r2, void* stream) {
+  KPF_REQUIRE(pcl && joint_xyz && X && JF && GF && GX && B > 0 && N > 0 && jf_ld >= 128 && jf_ld % 2 == 0, "kpf_ball_group_stacked_f32: bad arguments");
+  hipLaunchKernelGGL(ball_group_kernel, dim3(B * J, 3), dim3(64), 0, ST(stream), pcl, joint_xyz, X, JF, GF, GX, idx_out, N, jf_ld, 128L, 3 * 128, 4L, 3 * 4,
+                     r0, r1, r2);
+  return kpf_check_launch("kpf_ball_group_stacked_f32");
 }
 
 extern "C" int kpf_group_max_f32(const float* in, float* out, long rows, int group, int C, int out_ld, int out_coff, void* stream) {

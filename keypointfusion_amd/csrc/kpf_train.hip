@@ -2185,6 +2185,123 @@ extern "C" int kpf_pose_tokens_f32(const float* pw, const float* joint, const fl
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Round 6: DESA's three radii as ONE channel-stacked tensor through the training step (train_graph.TrainGraph.desa: grouped launches instead of three
+// chains of small ones).  (1) the backward of the grouping for all three radii in one launch: d3 [B*R][ld3] holds radius i's gradient of the grouped
+// feature differences in columns [128 i, 128 i + 128); `start` / `list` are kpf_row_gather_invert's lists of idx [3][B][R] taken as 3 B images of P = N + J
+// source rows (image i * B + b).  dX[b][p] (p < N) = sum_i sum_{entries e of row p} d3[b*R + e][128 i + :] — radius ascending, entries ascending: one fixed
+// order — and the joint rows additionally lose the centre's sum: dnode[b][j] = that sum for p = N + j  -  sum_i sum_{m < 64} d3[b*R + 64 j + m][128 i + :].
+// One wave per source row, the two half-waves on alternate list positions (even + odd, always in that order), lanes over the 32 channel quads.
+// (2) max over the 64 members of a group with the winner's index kept (first maximum), and its gather-form backward (every element of dx written once).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void ball_group_bwd_kernel(const float* __restrict__ d3, const int* __restrict__ start, const int* __restrict__ list,
+                                                             float* __restrict__ dX, float* __restrict__ dnode, int B, int N, int Jn, int ld3) {
+  const int lane = threadIdx.x & 63, q = lane & 31, phase = lane >> 5;
+  const int P = N + Jn, R = Jn * 64;
+  const long rows = (long)B * P;
+  for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * 4) {
+    const int b = (int)(r / P), p = (int)(r - (long)b * P);
+    const float* db = d3 + (long)b * R * ld3 + 4 * q;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 3; ++i) {
+      const long img = (long)i * B + b;
+      const int s0 = start[img * (P + 1) + p], s1 = start[img * (P + 1) + p + 1];
+      const int* lb = list + img * R;
+      for (int c0 = s0; c0 < s1; c0 += 64) {
+        const int m = min(64, s1 - c0);
+        const int ev = lane < m ? lb[c0 + lane] : 0;
+        for (int k = phase; k < m + phase; k += 2) {  // (the same trip count for both half-waves: the shuffle runs with the whole wave active)
+          const int e1 = __shfl(ev, min(k, m - 1), 64);
+          if (k < m) {
+            const f32x4 g = kpf_ld4(db + (long)e1 * ld3 + 128 * i);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] += g[t];
+          }
+        }
+      }
+    }
+    f32x4 cen = {0.f, 0.f, 0.f, 0.f};
+    if (p >= N) {  // (wave-uniform)
+      const float* cb = db + (long)(p - N) * 64 * ld3;
+      for (int i = 0; i < 3; ++i)
+#pragma unroll 8
+        for (int m = phase; m < 64; m += 2) {
+          const f32x4 g = kpf_ld4(cb + (long)m * ld3 + 128 * i);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) cen[t] += g[t];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      acc[t] += __shfl_down(acc[t], 32, 64);
+      cen[t] += __shfl_down(cen[t], 32, 64);
+    }
+    if (phase == 0) {
+      if (p < N) kpf_st4(dX + ((long)b * N + p) * 128 + 4 * q, acc);
+      else kpf_st4(dnode + ((long)b * Jn + (p - N)) * 128 + 4 * q, f32x4{acc[0] - cen[0], acc[1] - cen[1], acc[2] - cen[2], acc[3] - cen[3]});
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void group_max_train_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ arg, long n4,
+                                                                  int group, int C4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long r = i / C4;
+    const int q = (int)(i - r * C4);
+    const float* p = x + (r * group * C4 + q) * 4;
+    f32x4 best = kpf_ld4(p);
+    int bi[4] = {0, 0, 0, 0};
+#pragma unroll 8
+    for (int m = 1; m < group; ++m) {
+      const f32x4 v = kpf_ld4(p + (long)m * C4 * 4);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (v[t] > best[t]) {  // strictly greater: the first maximum wins
+          best[t] = v[t];
+          bi[t] = m;
+        }
+    }
+    kpf_st4(y + i * 4, best);
+    *reinterpret_cast<uchar4*>(arg + i * 4) = uchar4{(unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2], (unsigned char)bi[3]};
+  }
+}
+__global__ __launch_bounds__(256) void group_max_train_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg, float* __restrict__ dx,
+                                                                  long n4, int group, int C4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {  // i over [rows][group][C4]
+    const int q = (int)(i % C4);
+    const long rm = i / C4;
+    const int m = (int)(rm % group);
+    const long r = rm / group;
+    const f32x4 g = kpf_ld4(dy + (r * C4 + q) * 4);
+    const uchar4 a = *reinterpret_cast<const uchar4*>(arg + (r * C4 + q) * 4);
+    kpf_st4(dx + i * 4, f32x4{a.x == m ? g[0] : 0.f, a.y == m ? g[1] : 0.f, a.z == m ? g[2] : 0.f, a.w == m ? g[3] : 0.f});
+  }
+}
+}  // namespace
+
+extern "C" int kpf_ball_group_bwd_f32(const float* d3, int ld3, const int* start, const int* list, float* dX, float* dnode, int B, int N, int Jn, void* stream) {
+  KPF_REQUIRE(d3 && start && list && dX && dnode && B > 0 && N > 0 && Jn > 0 && ld3 >= 384 && ld3 % 4 == 0, "kpf_ball_group_bwd_f32: bad arguments");
+  KPF_REQUIRE(kpf_aligned16(d3) && kpf_aligned16(dX) && kpf_aligned16(dnode), "kpf_ball_group_bwd_f32: 16-byte aligned rows");
+  const long rows = (long)B * (N + Jn);
+  hipLaunchKernelGGL(ball_group_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d3, start, list, dX, dnode, B, N,
+                     Jn, ld3);
+  return kpf_check_launch("kpf_ball_group_bwd_f32");
+}
+
+extern "C" int kpf_group_max_train_forward(const float* x, float* y, unsigned char* arg, long rows, int group, int C, void* stream) {
+  KPF_REQUIRE(x && y && arg && rows > 0 && group > 0 && group <= 256 && C > 0 && C % 4 == 0, "kpf_group_max_train_forward: bad arguments (C %% 4 == 0, group <= 256)");
+  const long n4 = rows * (C / 4);
+  hipLaunchKernelGGL(group_max_train_fwd_kernel, dim3(grid_for(n4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, y, arg, n4, group, C / 4);
+  return kpf_check_launch("kpf_group_max_train_forward");
+}
+extern "C" int kpf_group_max_train_backward(const float* dy, const unsigned char* arg, float* dx, long rows, int group, int C, void* stream) {
+  KPF_REQUIRE(dy && arg && dx && rows > 0 && group > 0 && group <= 256 && C > 0 && C % 4 == 0, "kpf_group_max_train_backward: bad arguments");
+  const long n4 = rows * group * (C / 4);
+  hipLaunchKernelGGL(group_max_train_bwd_kernel, dim3(grid_for(n4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, arg, dx, n4, group, C / 4);
+  return kpf_check_launch("kpf_group_max_train_backward");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Round 4: y = LayerNorm(h + dropout(o)) in one launch each way — the tail of both halves of a BERT layer (model/model.py:30-126: dense -> dropout ->
 // residual add -> LayerNorm) and of the decoder layer's feed-forward.  Same wave-per-row arithmetic as ln_fwd_kernel / ln_bwd_kernel on the sum
 // xs = h + dropout(o), which is kept for the backward together with the dropout mask (one byte per element; the mask is drawn from the hash of

@@ -32,7 +32,8 @@ constexpr int NLW = 4;                  // loader waves
 constexpr int NTHR = 64 * (NCW + NLW);  // 768
 constexpr int NCT = 64 * NCW;           // consumer threads
 constexpr int SLOT = 64 * 64;           // floats per ring slot: one 64 x 64 block
-constexpr int NS = 4;                   // ring slots: the block in use + three in flight
+constexpr int NSF = 6;                  // ring slots of the forward kernel: the block in use + five in flight (its token arrays share one LDS region, below)
+constexpr int NSB = 4;                  // ring slots of the backward kernel: the block in use + three in flight
 constexpr int LDA = 136;                // row stride of the 128-wide token arrays (34 x 16 B: conflict-free ds_read_b128 fragments)
 constexpr int LDQ = 392;                // q | k | v rows
 constexpr int LDI = 72;                 // intermediate (16 real columns, zeros up to 64: one block deep)
@@ -40,7 +41,8 @@ constexpr int NLAYER = 4;
 constexpr int CH_PER_LAYER = 20;        // 12 (q | k | v) + 4 (attention output) + 2 (intermediate) + 2 (output)
 constexpr int NCHUNK = NLAYER * CH_PER_LAYER;
 constexpr int SCHED_F = NCHUNK * 6;     // Chunk is 24 bytes
-constexpr int SPAD = 1792;              // 4 x 21 x 21 = 1764 scores, padded
+constexpr int SPAD = 1792;              // 4 x 21 x 21 = 1764 scores, padded (7 x 256: whole DMA instructions)
+constexpr int QPAD = 8448;              // 21 x 392 = 8232 floats of q | k | v, padded to 33 x 256 (backward: the array is filled by LDS-DMA)
 
 struct Chunk {
   const float* src;  // element (0, 0) of the block inside its parameter tensor
@@ -52,6 +54,13 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) void gbl_void_t;
 
 __device__ __attribute__((aligned(16))) float kpf_trs_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+// tuning aid: wall-clock stamps (100 MHz) of workgroup 0's thread 0 at phase boundaries, into a buffer set by kpf_tr_stack_set_stamps (NULL = off, the default)
+__device__ unsigned long long* kpf_trs_stamps = nullptr;
+#define TRS_STAMP(i)                                                                                         \
+  do {                                                                                                       \
+    if (kpf_trs_stamps && blockIdx.x == 0 && threadIdx.x == 0) kpf_trs_stamps[(i)] = wall_clock64();         \
+  } while (0)
 
 __device__ __forceinline__ int swz(int row) { return (row ^ (row >> 2)) & 15; }
 __device__ __forceinline__ void BAR() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -123,6 +132,7 @@ struct Sync {
   bool loader;
 };
 
+template <int NS>
 __device__ __forceinline__ void issue_chunk(const Sync& s, int n) {
   const Chunk ck = s.sched[n];
   float* slot = s.ring + (n % NS) * SLOT;
@@ -139,15 +149,19 @@ __device__ __forceinline__ void issue_chunk(const Sync& s, int n) {
 }
 
 // Every wave calls this once per block, in schedule order: afterwards block s.c is readable in slot s.c % NS and (loaders) block s.c + NS - 1 is in flight.
+template <int NS>
 __device__ __forceinline__ void chunk_sync(Sync& s) {
+  static_assert(NS >= 3 && NS <= 6, "vmcnt immediates below");
   if (s.loader) {
     const int younger = min(NCHUNK - 1 - s.c, NS - 2);  // blocks issued after s.c so far: four DMA instructions per loader wave each
-    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (younger >= 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (younger == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   BAR();  // block s.c has landed for everyone; every consumer is done with block s.c - 1
-  if (s.loader && s.c + NS - 1 < NCHUNK) issue_chunk(s, s.c + NS - 1);
+  if (s.loader && s.c + NS - 1 < NCHUNK) issue_chunk<NS>(s, s.c + NS - 1);
 }
 
 // one 64-deep block of a product: tokens in[t][roff .. roff + 63] times the block in `slot`.  KN = false: out column = block row (forward, W[n][k]);
@@ -178,14 +192,14 @@ __device__ __forceinline__ void mma_chunk(const float* in, int ldin, int roff, c
 
 // nob output blocks of 64 columns, each the sum of nrb 64-deep blocks (schedule order: output block major).  epi(ob, t, col, value) is called for the
 // 21 real tokens; t = token, col = ob * 64 + column within the block.
-template <bool KN, class Epi>
+template <int NS, bool KN, class Epi>
 __device__ __forceinline__ void gemm_op(Sync& s, const float* in, int ldin, int nob, int nrb, Epi&& epi) {
   const int fr = s.lane & 15, fg = s.lane >> 4;
   const int tt = s.wave & 1, ct = (s.wave >> 1) & 3;
   for (int ob = 0; ob < nob; ++ob) {
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     for (int rb = 0; rb < nrb; ++rb) {
-      chunk_sync(s);
+      chunk_sync<NS>(s);
       if (!s.loader) mma_chunk<KN>(in, ldin, rb * 64, s.ring + (s.c % NS) * SLOT, tt, ct, fr, fg, acc0, acc1);
       ++s.c;
     }
@@ -200,16 +214,32 @@ __device__ __forceinline__ void gemm_op(Sync& s, const float* in, int ldin, int 
 }
 
 // ================================================================ forward ================================================================
+// per-layer parameter VECTORS (biases, LayerNorm weights) staged in LDS: an epilogue that fetched its bias from HBM / L2 exposed ~1 us of load latency eleven
+// times per layer.  Layer l + 1's vectors are requested into registers at the top of layer l and written to LDS at its end.
+enum { PV_BQKV = 0, PV_BO = 384, PV_G1 = 512, PV_B1 = 640, PV_BI = 768, PV_BO2 = 784, PV_G2 = 912, PV_B2 = 1040, PV_N = 1168, PV_PAD = 1184 };
+__device__ __forceinline__ float pv_fetch(const float* const* pl, int i) {
+  if (i < PV_BO) return pl[2 * (i >> 7) + 1][i & 127];
+  if (i < PV_G1) return pl[PB_O][i - PV_BO];
+  if (i < PV_B1) return pl[P_G1][i - PV_G1];
+  if (i < PV_BI) return pl[P_B1][i - PV_B1];
+  if (i < PV_BO2) return pl[PB_I][i - PV_BI];
+  if (i < PV_G2) return pl[PB_O2][i - PV_BO2];
+  if (i < PV_B2) return pl[P_G2][i - PV_G2];
+  return pl[P_B2][i - PV_B2];
+}
+
 __global__ __launch_bounds__(NTHR) void tr_stack_fwd_kernel(const float* __restrict__ e, const float* __restrict__ pos, const float* const* __restrict__ P,
                                                           float* __restrict__ save, int B, float p_drop, const long* __restrict__ rng, int call0) {
+  constexpr int NS = NSF;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   Chunk* sched = reinterpret_cast<Chunk*>(sm);
-  float* Hb = sm + SCHED_F;     // [T][LDA] hidden state
-  float* QKV = Hb + T * LDA;    // [T][LDQ]
-  float* CTX = QKV + T * LDQ;   // [T][LDA]
-  float* T1 = CTX + T * LDA;    // [T][LDA] h + dropout(dense(.)), the LayerNorm's input
-  float* IM = T1 + T * LDA;     // [T][LDI] gelu(intermediate), zero beyond column 15
-  float* S = IM + T * LDI;      // [NH][T][T]
+  float* PV = sm + SCHED_F;     // [PV_PAD] this layer's parameter vectors
+  float* Hb = PV + PV_PAD;      // [T][LDA] hidden state
+  float* QKV = Hb + T * LDA;    // [T][LDQ] q | k | v; after the scores exist the q columns hold T1 (the LayerNorm's input), after the attention the k columns held
+  float* T1 = QKV;              //          CTX and the v columns hold IM (gelu(intermediate), 16 real columns, zeros up to 64): same rows, stride LDQ
+  float* CTX = QKV + H;
+  float* IM = QKV + 2 * H;
+  float* S = QKV + T * LDQ;     // [NH][T][T]
   float* ring = S + SPAD;       // [NS][SLOT]   (every token array is followed by >= 11 more rows of LDS: the second MFMA row tile reads them)
   const int tid = threadIdx.x;
   Sync s;
@@ -220,6 +250,7 @@ __global__ __launch_bounds__(NTHR) void tr_stack_fwd_kernel(const float* __restr
   s.sched = sched;
   s.zero = kpf_trs_zero16;
   s.c = 0;
+  const bool work = !s.loader;
   const int b = blockIdx.x;
   Save sv;
   sv.M = (long)B * T;
@@ -244,8 +275,11 @@ __global__ __launch_bounds__(NTHR) void tr_stack_fwd_kernel(const float* __restr
     ru[0] = seed;
     ru[1] = ctr;
   }
-  if (!s.loader) {
-    for (int i = tid; i < T * LDI; i += NCT) IM[i] = 0.f;
+  float pvr[3] = {0.f, 0.f, 0.f};  // this thread's three elements of the NEXT layer's parameter vectors
+  if (work) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+      if (tid + u * NCT < PV_N) PV[tid + u * NCT] = pv_fetch(P, tid + u * NCT);
     // H[0] = dropout(e + pos)  (TR_Encoder: embedding + position, then the embedding dropout; model/model.py:78-84)
     for (int i = tid; i < T * (H / 4); i += NCT) {
       const int t = i >> 5, c = (i & 31) * 4;
@@ -261,24 +295,30 @@ __global__ __launch_bounds__(NTHR) void tr_stack_fwd_kernel(const float* __restr
       kpf_st4(save + sv.Hs(0) + off, v);
     }
   }
-  BAR();  // schedule and H[0] visible
+  BAR();  // schedule, parameter vectors and H[0] visible
   if (s.loader)
-    for (int n = 0; n < NS - 1; ++n) issue_chunk(s, n);
+    for (int n = 0; n < NS - 1; ++n) issue_chunk<NS>(s, n);
 
   for (int l = 0; l < NLAYER; ++l) {
-    const float* const* pl = P + l * P_PER_LAYER;
+    TRS_STAMP(l * 8 + 0);
+    if (work && l + 1 < NLAYER) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+        if (tid + u * NCT < PV_N) pvr[u] = pv_fetch(P + (l + 1) * P_PER_LAYER, tid + u * NCT);
+    }
     // ---- q | k | v = h W^T + b ----
     {
       float* sq = save + sv.qkv(l);
-      gemm_op<false>(s, Hb, LDA, 6, 2, [&](int ob, int t, int col, float acc) {
-        const float v = acc + pl[2 * (ob >> 1) + 1][col & 127];
+      gemm_op<NS, false>(s, Hb, LDA, 6, 2, [&](int, int t, int col, float acc) {
+        const float v = acc + PV[PV_BQKV + col];
         QKV[t * LDQ + col] = v;
         sq[(row0 + t) * 384 + col] = v;
       });
     }
     // ---- attention core: softmax(q k^T / sqrt(32)) -> dropout -> . v ----
     BAR();
-    if (!s.loader) {
+    TRS_STAMP(l * 8 + 1);
+    if (work) {
       for (int item = tid; item < NH * T * T; item += NCT) {
         const int h = item / (T * T), r = item - h * T * T, i = r / T, j = r - i * T;
         const float* qp = QKV + i * LDQ + h * HD;
@@ -296,7 +336,7 @@ __global__ __launch_bounds__(NTHR) void tr_stack_fwd_kernel(const float* __restr
       }
     }
     BAR();
-    if (!s.loader && tid < NH * T) {
+    if (work && tid < NH * T) {
       float* sp = S + tid * T;
       float mx = -INFINITY;
       for (int j = 0; j < T; ++j) mx = fmaxf(mx, sp[j]);
@@ -316,7 +356,7 @@ __global__ __launch_bounds__(NTHR) void tr_stack_fwd_kernel(const float* __restr
       }
     }
     BAR();
-    if (!s.loader) {
+    if (work) {  // (q and k are dead: the context goes to the k columns)
       float* sc = save + sv.ctx(l);
       for (int item = tid; item < T * (H / 4); item += NCT) {
         const int i = item >> 5, c = (item & 31) * 4, h = c / HD;
@@ -329,32 +369,34 @@ __global__ __launch_bounds__(NTHR) void tr_stack_fwd_kernel(const float* __restr
 #pragma unroll
           for (int k = 0; k < 4; ++k) a[k] = fmaf(pj, vv[k], a[k]);
         }
-        *reinterpret_cast<f32x4*>(CTX + i * LDA + c) = a;
+        *reinterpret_cast<f32x4*>(CTX + i * LDQ + c) = a;
         kpf_st4(sc + (row0 + i) * H + c, a);
       }
     }
-    // ---- xs1 = h + dropout(ctx Wo^T + bo) ----
+    // ---- xs1 = h + dropout(ctx Wo^T + bo)  (into the q columns) ----
+    TRS_STAMP(l * 8 + 2);
     {
       float* sx = save + sv.xs1(l);
-      gemm_op<false>(s, CTX, LDA, 2, 2, [&](int, int t, int col, float acc) {
-        const float o = acc + pl[PB_O][col];
+      gemm_op<NS, false>(s, CTX, LDQ, 2, 2, [&](int, int t, int col, float acc) {
+        const float o = acc + PV[PV_BO + col];
         const long idx = (row0 + t) * H + col;
         const float x = Hb[t * LDA + col] + (dr.keep(call0 + 3 * l + 1, (unsigned)idx) ? o * dr.ks : 0.f);
-        T1[t * LDA + col] = x;
+        T1[t * LDQ + col] = x;
         sx[idx] = x;
       });
     }
-    // ---- h1 = LayerNorm(xs1) ----
+    // ---- h1 = LayerNorm(xs1); intermediate; output; h = LayerNorm(xs2) ----
     for (int pass = 0; pass < 2; ++pass) {
       BAR();
-      if (!s.loader) {
-        const float* gw = pl[pass == 0 ? P_G1 : P_G2];
-        const float* gb = pl[pass == 0 ? P_B1 : P_B2];
+      TRS_STAMP(l * 8 + 3 + 3 * pass);
+      if (work) {
+        const float* gw = PV + (pass == 0 ? PV_G1 : PV_G2);
+        const float* gb = PV + (pass == 0 ? PV_B1 : PV_B2);
         float* st = save + (pass == 0 ? sv.st1(l) : sv.st2(l));
         float* hs = save + (pass == 0 ? sv.h1(l) : sv.Hs(l + 1));
         const float w0 = gw[s.lane], w1 = gw[64 + s.lane], b0 = gb[s.lane], b1 = gb[64 + s.lane];
         for (int t = s.wave; t < T; t += NCW) {
-          const float a0 = T1[t * LDA + s.lane], a1 = T1[t * LDA + 64 + s.lane];
+          const float a0 = T1[t * LDQ + s.lane], a1 = T1[t * LDQ + 64 + s.lane];
           const float mean = wave_sum(a0 + a1) * (1.0f / H);
           const float d0 = a0 - mean, d1 = a1 - mean;
           const float rstd = 1.0f / sqrtf(wave_sum(fmaf(d0, d0, d1 * d1)) * (1.0f / H) + 1e-12f);
@@ -368,70 +410,112 @@ __global__ __launch_bounds__(NTHR) void tr_stack_fwd_kernel(const float* __restr
             st[(row0 + t) * 4 + 1] = rstd;
           }
         }
+        if (pass == 0)  // the v columns are dead since the attention: IM's zero padding (columns 16 .. 63 of its block)
+          for (int i = tid; i < T * 48; i += NCT) IM[(i / 48) * LDQ + 16 + i % 48] = 0.f;
       }
       if (pass == 1) break;
       // ---- it = h1 Wi^T + bi; g = gelu(it) ----
+      TRS_STAMP(l * 8 + 4);
       {
         float* si = save + sv.it(l);
         float* sg = save + sv.g(l);
-        gemm_op<false>(s, Hb, LDA, 1, 2, [&](int, int t, int col, float acc) {
+        gemm_op<NS, false>(s, Hb, LDA, 1, 2, [&](int, int t, int col, float acc) {
           if (col < FF) {
-            const float iv = acc + pl[PB_I][col];
+            const float iv = acc + PV[PV_BI + col];
             const float gv = gelu_exact(iv);
-            IM[t * LDI + col] = gv;
+            IM[t * LDQ + col] = gv;
             si[(row0 + t) * FF + col] = iv;
             sg[(row0 + t) * FF + col] = gv;
           }
         });
       }
       // ---- xs2 = h1 + dropout(g Wo2^T + bo2) ----
+      TRS_STAMP(l * 8 + 5);
       {
         float* sx = save + sv.xs2(l);
-        gemm_op<false>(s, IM, LDI, 2, 1, [&](int, int t, int col, float acc) {
-          const float o = acc + pl[PB_O2][col];
+        gemm_op<NS, false>(s, IM, LDQ, 2, 1, [&](int, int t, int col, float acc) {
+          const float o = acc + PV[PV_BO2 + col];
           const long idx = (row0 + t) * H + col;
           const float x = Hb[t * LDA + col] + (dr.keep(call0 + 3 * l + 2, (unsigned)idx) ? o * dr.ks : 0.f);
-          T1[t * LDA + col] = x;
+          T1[t * LDQ + col] = x;
           sx[idx] = x;
         });
       }
+    }
+    // next layer's parameter vectors: every read of this layer's is behind the LayerNorm above; the next layer's first block barrier publishes them
+    BAR();
+    TRS_STAMP(l * 8 + 7);
+    if (work && l + 1 < NLAYER) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+        if (tid + u * NCT < PV_N) PV[tid + u * NCT] = pvr[u];
     }
   }
 }
 
 // ================================================================ backward ===============================================================
-// One LayerNorm backward over the sample's 21 rows (wave per row): dy rows in `dyl` (LDS), x = xs rows (HBM), stats (HBM), gamma.
+// What a LayerNorm backward reads from HBM for the (up to) three rows of a wave — x = xs rows and their (mean, rstd) — is requested into registers one phase
+// EARLIER than it is used (the loads of the next LayerNorm fly under the GEMM blocks in between): a dependent HBM read costs ~1.5 us, and a layer has six.
+struct LnIn {
+  float x0[3], x1[3], mean[3], rstd[3];
+};
+__device__ __forceinline__ void ln_prefetch(const Sync& s, LnIn& in, const float* __restrict__ xs, const float* __restrict__ st, long row0) {
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int t = s.wave + u * NCW;
+    const long r = row0 + (t < T ? t : T - 1);
+    in.x0[u] = xs[r * H + s.lane];
+    in.x1[u] = xs[r * H + 64 + s.lane];
+    in.mean[u] = st[r * 4];
+    in.rstd[u] = st[r * 4 + 1];
+  }
+}
+// Consumer-side LDS-DMA copy of a saved activation into an LDS array, no registers: instruction k fills LDS floats [256 k, 256 k + 256) of dst; a lane's 16 bytes
+// come from row t = f / lld, column c = f % lld of the source (row stride gld floats, ncols valid columns) or from the zero page.  dst must extend to a multiple
+// of 256 floats.  The issuing wave orders its later LDS reads with `s_waitcnt vmcnt(0)` + the workgroup barrier.
+__device__ __forceinline__ void dma_rows(const Sync& s, const float* __restrict__ src, int nrows, int gld, int ncols, float* dst, int lld) {
+  const int ninstr = (nrows * lld + 255) >> 8;
+  for (int k = s.wave; k < ninstr; k += NCW) {
+    const int f = k * 256 + s.lane * 4;
+    const int t = f / lld, c = f - t * lld;
+    const float* g = (t < nrows && c < ncols) ? src + (long)t * gld + c : s.zero;
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)(dst + k * 256), 16, 0, 0);
+  }
+}
+// One LayerNorm backward over the sample's 21 rows (wave per row): dy rows in `dyl` (LDS), x / stats in registers, gamma in LDS.
 //   dxs -> dres (LDS) [the residual branch's gradient] and dout = dxs * keep / (1 - p) -> ddn (LDS) + HBM (the dense layer's dY);
 //   per-sample partial sums of d gamma / d beta -> part[2][128] through `scratch` ([NCW][2][128] floats of LDS).
-__device__ __forceinline__ void ln_backward(const Sync& s, bool work, const float* dyl, const float* __restrict__ xs, const float* __restrict__ st,
-                                            const float* __restrict__ gam, float* dres, float* ddn, float* __restrict__ ddn_g, float* __restrict__ part,
-                                            float* scratch, long row0, const Drop& dr, int call) {
+__device__ __forceinline__ void ln_backward(const Sync& s, bool work, const float* dyl, const LnIn& in, const float* gam, float* dres, float* ddn,
+                                            float* __restrict__ ddn_g, float* __restrict__ part, float* scratch, long row0, const Drop& dr, int call) {
   BAR();
   if (work) {
     const float g0 = gam[s.lane], g1 = gam[64 + s.lane];
     float aw0 = 0.f, aw1 = 0.f, ab0 = 0.f, ab1 = 0.f;
-    for (int t = s.wave; t < T; t += NCW) {
-      const long r = row0 + t;
-      const float mean = st[r * 4], rstd = st[r * 4 + 1];
-      const float x0 = xs[r * H + s.lane], x1 = xs[r * H + 64 + s.lane];
-      const float d0 = dyl[t * LDA + s.lane], d1 = dyl[t * LDA + 64 + s.lane];
-      const float xh0 = (x0 - mean) * rstd, xh1 = (x1 - mean) * rstd;
-      const float gd0 = d0 * g0, gd1 = d1 * g1;
-      const float m1 = wave_sum(gd0 + gd1) * (1.0f / H);
-      const float m2 = wave_sum(fmaf(gd0, xh0, gd1 * xh1)) * (1.0f / H);
-      aw0 = fmaf(d0, xh0, aw0);
-      aw1 = fmaf(d1, xh1, aw1);
-      ab0 += d0;
-      ab1 += d1;
-      const float o0 = rstd * (gd0 - m1 - xh0 * m2), o1 = rstd * (gd1 - m1 - xh1 * m2);
-      dres[t * LDA + s.lane] = o0;
-      dres[t * LDA + 64 + s.lane] = o1;
-      const float q0 = dr.keep(call, (unsigned)(r * H + s.lane)) ? o0 * dr.ks : 0.f;
-      const float q1 = dr.keep(call, (unsigned)(r * H + 64 + s.lane)) ? o1 * dr.ks : 0.f;
-      ddn[t * LDA + s.lane] = q0;
-      ddn[t * LDA + 64 + s.lane] = q1;
-      ddn_g[r * H + s.lane] = q0;
-      ddn_g[r * H + 64 + s.lane] = q1;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int t = s.wave + u * NCW;
+      if (t < T) {
+        const long r = row0 + t;
+        const float mean = in.mean[u], rstd = in.rstd[u];
+        const float d0 = dyl[t * LDA + s.lane], d1 = dyl[t * LDA + 64 + s.lane];
+        const float xh0 = (in.x0[u] - mean) * rstd, xh1 = (in.x1[u] - mean) * rstd;
+        const float gd0 = d0 * g0, gd1 = d1 * g1;
+        const float m1 = wave_sum(gd0 + gd1) * (1.0f / H);
+        const float m2 = wave_sum(fmaf(gd0, xh0, gd1 * xh1)) * (1.0f / H);
+        aw0 = fmaf(d0, xh0, aw0);
+        aw1 = fmaf(d1, xh1, aw1);
+        ab0 += d0;
+        ab1 += d1;
+        const float o0 = rstd * (gd0 - m1 - xh0 * m2), o1 = rstd * (gd1 - m1 - xh1 * m2);
+        dres[t * LDA + s.lane] = o0;
+        dres[t * LDA + 64 + s.lane] = o1;
+        const float q0 = dr.keep(call, (unsigned)(r * H + s.lane)) ? o0 * dr.ks : 0.f;
+        const float q1 = dr.keep(call, (unsigned)(r * H + 64 + s.lane)) ? o1 * dr.ks : 0.f;
+        ddn[t * LDA + s.lane] = q0;
+        ddn[t * LDA + 64 + s.lane] = q1;
+        ddn_g[r * H + s.lane] = q0;
+        ddn_g[r * H + 64 + s.lane] = q1;
+      }
     }
     scratch[(s.wave * 2 + 0) * H + s.lane] = aw0;
     scratch[(s.wave * 2 + 0) * H + 64 + s.lane] = aw1;
@@ -450,14 +534,16 @@ __device__ __forceinline__ void ln_backward(const Sync& s, bool work, const floa
 
 __global__ __launch_bounds__(NTHR) void tr_stack_bwd_kernel(const float* __restrict__ dh, const float* const* __restrict__ P, const float* __restrict__ save,
                                                           float* __restrict__ dE, float* __restrict__ dys, float* __restrict__ parts, int B, float p_drop, int call0) {
+  constexpr int NS = NSB;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   Chunk* sched = reinterpret_cast<Chunk*>(sm);
-  float* G = sm + SCHED_F;     // [T][LDA] gradient of the layer's output, later of its input
+  float* PV = sm + SCHED_F;    // [2][128] LayerNorm weights of this layer (ln1, ln2)
+  float* G = PV + 2 * H;       // [T][LDA] gradient of the layer's output, later of its input
   float* D1 = G + T * LDA;     // [T][LDA]
   float* D2 = D1 + T * LDA;    // [T][LDA]
   float* DI = D2 + T * LDA;    // [T][LDI] d intermediate, zero beyond column 15
   float* QKV = DI + T * LDI;   // [T][LDQ] q | k | v, overwritten by dq | dk | dv
-  float* SP = QKV + T * LDQ;   // [NH][T][T] probabilities (sign = dropped), also the LayerNorm reduce scratch (with SD)
+  float* SP = QKV + QPAD;      // [NH][T][T] probabilities (sign = dropped); before that the LayerNorm reduce scratch (with SD)
   float* SD = SP + SPAD;       // [NH][T][T]
   float* ring = SD + SPAD;
   const int tid = threadIdx.x;
@@ -495,7 +581,11 @@ __global__ __launch_bounds__(NTHR) void tr_stack_bwd_kernel(const float* __restr
     ctr = ru[1];
   }
   const Drop dr = make_drop(p_drop, seed, ctr);
+  LnIn ln2, ln1;
+  float pvr = 0.f;
   if (work) {
+    ln_prefetch(s, ln2, save + sv.xs2(NLAYER - 1), save + sv.st2(NLAYER - 1), row0);
+    if (tid < 2 * H) PV[tid] = (P + (NLAYER - 1) * P_PER_LAYER)[tid < H ? P_G1 : P_G2][tid & 127];
     for (int i = tid; i < T * LDI; i += NCT) DI[i] = 0.f;
     for (int i = tid; i < T * (H / 4); i += NCT) {
       const int t = i >> 5, c = (i & 31) * 4;
@@ -504,10 +594,10 @@ __global__ __launch_bounds__(NTHR) void tr_stack_bwd_kernel(const float* __restr
   }
   BAR();
   if (s.loader)
-    for (int n = 0; n < NS - 1; ++n) issue_chunk(s, n);
+    for (int n = 0; n < NS - 1; ++n) issue_chunk<NS>(s, n);
 
+  const int fr = s.lane & 15, fg = s.lane >> 4, tt = s.wave & 1;
   for (int l = NLAYER - 1; l >= 0; --l) {
-    const float* const* pl = P + l * P_PER_LAYER;
     float* dyl = dys + (long)l * M * DY_LAYER;
     float* d_qkv = dyl;
     float* d_o1 = dyl + 384 * M;
@@ -515,36 +605,45 @@ __global__ __launch_bounds__(NTHR) void tr_stack_bwd_kernel(const float* __restr
     float* d_o2 = dyl + 528 * M;
     float* part1 = parts + (((long)l * 2 + 0) * B + b) * 2 * H;
     float* part2 = parts + (((long)l * 2 + 1) * B + b) * 2 * H;
-    // ---- LayerNorm 2: G -> D1 (d h1, residual branch), D2 (d o2) ----
-    ln_backward(s, work, G, save + sv.xs2(l), save + sv.st2(l), pl[P_G2], D1, D2, d_o2, part2, SP, row0, dr, call0 + 3 * l + 2);
-    // ---- d it = (d o2 . Wo2) * gelu'(it) ----
-    {
-      const float* si = save + sv.it(l);
-      gemm_op<true>(s, D2, LDA, 1, 2, [&](int, int t, int col, float acc) {
-        if (col < FF) {
-          const float v = acc * gelu_grad(si[(row0 + t) * FF + col]);
-          DI[t * LDI + col] = v;
-          d_it[(row0 + t) * FF + col] = v;
-        }
-      });
-    }
-    // ---- d h1 += d it . Wi ----
-    gemm_op<true>(s, DI, LDI, 2, 1, [&](int, int t, int col, float acc) { D1[t * LDA + col] += acc; });
-    // ---- LayerNorm 1: D1 -> G (d h, residual branch), D2 (d o) ----
-    ln_backward(s, work, D1, save + sv.xs1(l), save + sv.st1(l), pl[P_G1], G, D2, d_o1, part1, SP, row0, dr, call0 + 3 * l + 1);
-    // ---- d ctx = d o . Wo -> D1 ----
-    gemm_op<true>(s, D2, LDA, 2, 2, [&](int, int t, int col, float acc) { D1[t * LDA + col] = acc; });
-    // ---- attention backward (in place on QKV) ----
-    BAR();
+    TRS_STAMP(32 + (NLAYER - 1 - l) * 8 + 0);
+    // ---- requests whose data is used one or more phases later ----
+    float rit[4];  // the pre-GELU intermediate of this lane's four rows (epilogue of the first product)
     if (work) {
-      const float* sq = save + sv.qkv(l);
-      for (int i = tid; i < T * (384 / 4); i += NCT) {
-        const int t = i / 96, c = (i - t * 96) * 4;
-        *reinterpret_cast<f32x4*>(QKV + t * LDQ + c) = kpf_ld4(sq + (row0 + t) * 384 + c);
+      const float* si = save + sv.it(l);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int tr = tt * 16 + 4 * fg + u;
+        rit[u] = si[(row0 + (tr < T ? tr : T - 1)) * FF + fr];
       }
-      const float* pg = save + sv.P(l) + (long)b * NH * T * T;
-      for (int i = tid; i < NH * T * T; i += NCT) SP[i] = pg[i];
     }
+    // ---- LayerNorm 2: G -> D1 (d h1, residual branch), D2 (d o2) ----
+    ln_backward(s, work, G, ln2, PV + H, D1, D2, d_o2, part2, SP, row0, dr, call0 + 3 * l + 2);
+    if (work) {
+      ln_prefetch(s, ln1, save + sv.xs1(l), save + sv.st1(l), row0);
+      dma_rows(s, save + sv.qkv(l) + row0 * 384, T, 384, 384, QKV, LDQ);  // (the q | k | v array is idle until the attention phase: every reader of the
+    }                                                                      //  previous layer's last product is behind the barriers of the LayerNorm above)
+    // ---- d it = (d o2 . Wo2) * gelu'(it) ----
+    TRS_STAMP(32 + (NLAYER - 1 - l) * 8 + 1);
+    gemm_op<NS, true>(s, D2, LDA, 1, 2, [&](int, int t, int col, float acc) {
+      if (col < FF) {
+        const float v = acc * gelu_grad(rit[t & 3]);  // (t = tt * 16 + 4 fg + r: r = t & 3)
+        DI[t * LDI + col] = v;
+        d_it[(row0 + t) * FF + col] = v;
+      }
+    });
+    // ---- d h1 += d it . Wi ----
+    gemm_op<NS, true>(s, DI, LDI, 2, 1, [&](int, int t, int col, float acc) { D1[t * LDA + col] += acc; });
+    // ---- LayerNorm 1: D1 -> G (d h, residual branch), D2 (d o) ----
+    TRS_STAMP(32 + (NLAYER - 1 - l) * 8 + 2);
+    ln_backward(s, work, D1, ln1, PV, G, D2, d_o1, part1, SP, row0, dr, call0 + 3 * l + 1);
+    BAR();  // (the reduce scratch in SP / SD has been read)
+    if (work) dma_rows(s, save + sv.P(l) + (long)b * NH * T * T, 1, NH * T * T, NH * T * T, SP, SPAD);
+    // ---- d ctx = d o . Wo -> D1 ----
+    TRS_STAMP(32 + (NLAYER - 1 - l) * 8 + 3);
+    gemm_op<NS, true>(s, D2, LDA, 2, 2, [&](int, int t, int col, float acc) { D1[t * LDA + col] = acc; });
+    // ---- attention backward (in place on QKV) ----
+    TRS_STAMP(32 + (NLAYER - 1 - l) * 8 + 4);
+    if (work) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of q | k | v and P has landed in LDS
     BAR();
     if (work) {  // dP' = d ctx V^T; SD = dP' * keep / (1 - p); SP <- +-P (sign: kept / dropped)
       const long pb0 = (long)b * NH * T * T;
@@ -633,9 +732,16 @@ __global__ __launch_bounds__(NTHR) void tr_stack_bwd_kernel(const float* __restr
         const int t = i / 96, c = (i - t * 96) * 4;
         kpf_st4(d_qkv + (row0 + t) * 384 + c, *reinterpret_cast<const f32x4*>(QKV + t * LDQ + c));
       }
+      if (l > 0) {  // the next (lower) layer's first LayerNorm backward: its operands fly under the twelve blocks below
+        ln_prefetch(s, ln2, save + sv.xs2(l - 1), save + sv.st2(l - 1), row0);
+        if (tid < 2 * H) pvr = (P + (l - 1) * P_PER_LAYER)[tid < H ? P_G1 : P_G2][tid & 127];
+      }
     }
     // ---- d h += d(q | k | v) . [Wq; Wk; Wv] ----
-    gemm_op<true>(s, QKV, LDQ, 2, 6, [&](int, int t, int col, float acc) { G[t * LDA + col] += acc; });
+    TRS_STAMP(32 + (NLAYER - 1 - l) * 8 + 5);
+    gemm_op<NS, true>(s, QKV, LDQ, 2, 6, [&](int, int t, int col, float acc) { G[t * LDA + col] += acc; });
+    TRS_STAMP(32 + (NLAYER - 1 - l) * 8 + 6);
+    if (work && l > 0 && tid < 2 * H) PV[tid] = pvr;  // (this layer's two LayerNorms are done; the next ln_backward opens with a barrier)
   }
   BAR();
   if (work) {  // through the embedding dropout: d(e + pos)
@@ -651,14 +757,19 @@ __global__ __launch_bounds__(NTHR) void tr_stack_bwd_kernel(const float* __restr
   }
 }
 
-constexpr size_t FWD_LDS = (size_t)(SCHED_F + 3 * T * LDA + T * LDQ + T * LDI + SPAD + NS * SLOT) * sizeof(float);
-constexpr size_t BWD_LDS = (size_t)(SCHED_F + 3 * T * LDA + T * LDI + T * LDQ + 2 * SPAD + NS * SLOT) * sizeof(float);
+constexpr size_t FWD_LDS = (size_t)(SCHED_F + PV_PAD + T * LDA + T * LDQ + SPAD + NSF * SLOT) * sizeof(float);
+constexpr size_t BWD_LDS = (size_t)(SCHED_F + 2 * H + 3 * T * LDA + T * LDI + QPAD + 2 * SPAD + NSB * SLOT) * sizeof(float);
 static_assert(FWD_LDS <= 160 * 1024 && BWD_LDS <= 160 * 1024, "the stack kernels' LDS must fit one CU");
 static_assert(sizeof(Chunk) == 24, "Chunk layout");
 static_assert(2 * SPAD >= NCW * 2 * H, "LayerNorm reduce scratch lives in the score arrays");
 
 }  // namespace
 
+/* tuning aid: 64 x 8-byte stamp slots in device memory (NULL switches the stamps off) */
+extern "C" int kpf_tr_stack_set_stamps(void* p) {
+  unsigned long long* q = static_cast<unsigned long long*>(p);
+  return hipMemcpyToSymbol(HIP_SYMBOL(kpf_trs_stamps), &q, sizeof(q)) == hipSuccess ? KPF_OK : KPF_ELAUNCH;
+}
 extern "C" long kpf_tr_stack_save_floats(int B) {
   Save sv;
   sv.M = (long)B * T;

@@ -67,6 +67,10 @@ _SIGS = {
     "kpf_softmax_pool_f32": [_P, _P, _P, _P, C.c_int, C.c_int, _P],
     "kpf_ball_group_f32": [_P, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _P],
     "kpf_group_max_f32": [_P, _P, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_ball_group_stacked_f32": [_P, _P, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _P],
+    "kpf_ball_group_bwd_f32": [_P, C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_group_max_train_forward": [_P, _P, _P, C.c_long, C.c_int, C.c_int, _P],
+    "kpf_group_max_train_backward": [_P, _P, _P, C.c_long, C.c_int, C.c_int, _P],
     "kpf_heat_gam_gate_f32": [_P, _P, _P, C.c_int] + [_P] * 10 + [C.c_int] * 4 + [_P],
     "kpf_gate_reduce_f32": [_P, _P, _P, _P, _P, C.c_int, C.c_int, _P],
     "kpf_tr_encoder_f32": [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, _P],
@@ -149,6 +153,7 @@ _SIGS = {
     "kpf_layer_scale_backward_partial": [_P, _P, C.c_int, _P, _P, _P, _P, C.c_long, C.c_long, C.c_int, C.POINTER(ColsumDesc), _P],
     "kpf_ln_train_backward_partial": [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, C.c_long, C.c_long, C.c_int, C.POINTER(ColsumDesc), _P],
     "kpf_colsum_reduce_grouped": [C.POINTER(ColsumDesc), C.c_int, _P],
+    "kpf_tr_stack_set_stamps": [_P],
     "kpf_tr_stack_train_forward": [_P, _P, _P, _P, C.c_long, C.c_int, C.c_float, _P, C.c_int, _P],
     "kpf_tr_stack_train_backward": [_P, _P, _P, _P, _P, _P, C.c_int, C.c_float, C.c_int, _P],
     "kpf_bmm_small_k_dx": [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],

@@ -32,7 +32,7 @@ import torch.nn.functional as F
 
 from . import lib as L
 from .engine import _ptr, _stream, crop_inverse
-from .training import (add_relu, attn21, batchnorm_relu_rows, bert_stack21, bmm_small_k, conv2d_nhwc, dwconv7_nhwc, gelu_rows, layer_norm_rows, layer_scale_residual, linear_hip, maxpool3x3s2_nhwc,
+from .training import (add_relu, attn21, ball_group3, batchnorm_relu_rows, bert_stack21, bmm_small_k, group_max, group_params, linear_slices, conv2d_nhwc, dwconv7_nhwc, gelu_rows, layer_norm_rows, layer_scale_residual, linear_hip, maxpool3x3s2_nhwc,
                        ball_group, drop_add_ln, pair_params, pair_storage, row_gather, self_attention21, upsample2x_nhwc)
 
 _N_STREAMS = int(os.environ.get("KPF_TRAIN_STREAMS", "2"))  # 2: the RGB backbone (forward and backward) on a side stream (unpaired backbones only)
@@ -43,6 +43,9 @@ _N_STREAMS = int(os.environ.get("KPF_TRAIN_STREAMS", "2"))  # 2: the RGB backbon
 PAIR_BACKBONES = bool(int(os.environ.get("KPF_TRAIN_PAIR", "1")))
 # 1 (default): the four BERT layers of a 21-token stack as ONE launch each way (training.BertStack21, csrc/kpf_trstack.hip); 0: layer by layer (bert_layer)
 TR_FUSED = bool(int(os.environ.get("KPF_TR_FUSED", "1")))
+# 1 (default): DESA's three radii as ONE channel-stacked chain — grouped Linears (G = 3), BatchNorm / add + ReLU / group maximum over 3 x 128 channels, one
+# grouping launch each way (training.BallGroup3 / LinearSlices / GroupMax) — instead of three chains of small launches; 0: radius by radius
+DESA_GROUPED = bool(int(os.environ.get("KPF_DESA_GROUPED", "1")))
 PAIR = "PAIR."  # parameter-name prefix that stands for ("backbone_rgb.", "backbone_d.") while a paired pass is built
 
 J = 21
@@ -101,6 +104,24 @@ class TrainGraph:
                 raise ValueError("paired backbones: buffer %r has %d elements, not a multiple of 4, so its two halves cannot share one 16-byte-"
                                  "aligned allocation; run this network with KPF_TRAIN_PAIR=0 (two passes)" % (name[len(PAIR):], a.numel()))
         return t.reshape((2 * a.shape[0],) + tuple(a.shape[1:]))
+
+    def wg(self, names):
+        """n same-shaped parameters / buffers (DESA's per-radius layers) as one group-major tensor [n * rows, ...] over their (re-homed, adjacent) storage,
+        differentiable towards each (training.group_params)."""
+        ts = [self.t[n] for n in names]
+        reg = self.m.__dict__.setdefault("_pair_registry", {})
+        t = group_params(reg, "grp:" + names[0], ts)
+        if not ts[0].requires_grad and t.data_ptr() != ts[0].data_ptr():
+            raise ValueError("grouped DESA: buffer %r cannot share one aligned allocation with its siblings; run with KPF_DESA_GROUPED=0" % names[0])
+        return t.reshape((len(ts) * ts[0].shape[0],) + tuple(ts[0].shape[1:]))
+
+    def bn_g(self, x, names, eps=1e-5, relu=False):
+        """BatchNorm (batch statistics) [+ ReLU] of n sibling BatchNorm layers over the channel-stacked rows [M, n * C]: per-channel statistics, so the stacked
+        tensor's BatchNorm IS the n layers' BatchNorms (one 3-launch pass instead of n)."""
+        y = batchnorm_relu_rows(x, self.wg([n + ".weight" for n in names]), self.wg([n + ".bias" for n in names]), self.wg([n + ".running_mean" for n in names]),
+                                self.wg([n + ".running_var" for n in names]), self.momentum, eps, relu, None, False)
+        self.nbt += [self.t[n + ".num_batches_tracked"] for n in names]
+        return y
 
     def groups_of(self, name):
         return self.G if name.startswith(PAIR) else 1
@@ -419,6 +440,24 @@ class TrainGraph:
         outs = []
         assert C == 128, "DESA runs on the model's 128-channel features (model/model.py:166-204)"
         grouped = None
+        if DESA_GROUPED and not self.ball_override and self.prec == "f32":
+            # the three radii channel-stacked (round 6): [B*J*64, 3 * 128] rows through grouped launches
+            GF3, GX3, _ = ball_group3(pcl_xyz, node_xyz, pcl_feat, node_feat)
+            n3 = lambda fmt: [p + fmt % i for i in range(3)]
+            wl = n3(".conv_l0_blocks.%d.weight")
+            loc = linear_slices(GX3, wl, self.packs, [self.t[k] for i in range(3) for k in (p + ".conv_l0_blocks.%d.weight" % i, p + ".conv_l0_blocks.%d.bias" % i)])
+            loc = self.bn_g(loc, n3(".bn_l0_blocks.%d"))
+            wf = n3(".conv_f0_blocks.%d.weight")
+            ft = linear_hip(GF3, self.wg(wf).flatten(1), self.wg(n3(".conv_f0_blocks.%d.bias")), "f32", None, "grp:" + wf[0], self.packs, 3)
+            ft = self.bn_g(ft, n3(".bn_f0_blocks.%d"))
+            g = add_relu(loc, ft)
+            wb = n3(".conv_blocks.%d.0.weight")
+            g = linear_hip(g, self.wg(wb).flatten(1), self.wg(n3(".conv_blocks.%d.0.bias")), "f32", None, "grp:" + wb[0], self.packs, 3)
+            g = self.bn_g(g, n3(".bn_blocks.%d.0"), relu=True)
+            mx = group_max(g, 64).view(B, Jn, 3 * C)  # == cat of the three radii's maxima on the channel axis
+            cat = torch.cat((mx, node_feat), -1).reshape(B * Jn, -1)  # rows of 512
+            y = self.linear_rows(cat, self.t[p + ".fusion.0.weight"].flatten(1), self.t[p + ".fusion.0.bias"], p + ".fusion.0.weight")
+            return self.bn_l(y, p + ".fusion.1", relu=True, out16=False).view(B, Jn, -1)
         if self.ball_override:  # the debug hook of the gradient-parity tests (given index sets): the op-by-op form below
             xyz = torch.cat((pcl_xyz, node_xyz), 1)
             feat = torch.cat((pcl_feat, node_feat), 1)

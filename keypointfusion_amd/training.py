@@ -898,6 +898,23 @@ def _grouped_pack(cache, key, weight, bias, G, mode, prec, **kw):
         pcs = [cache.get((key, mode, g), weight[g * n:(g + 1) * n], None, mode, prec, **kw) for g in range(G)]
     else:
         pcs = [DevPack.packed(weight[g * n:(g + 1) * n], None, mode, prec, **kw) for g in range(G)]
+    if G > 2:  # one launch descriptor carries ONE group stride: more than two operands must be equally spaced — re-home them into one allocation (once)
+        attr = "w" if pcs[0].w is not None else "w16"
+        bufs = [getattr(pc, attr) for pc in pcs]
+        es = bufs[0].element_size()
+        step = bufs[1].data_ptr() - bufs[0].data_ptr()
+        if any(b.data_ptr() - a.data_ptr() != step for a, b in zip(bufs, bufs[1:])) or step % (8 * es):
+            assert not torch.cuda.is_current_stream_capturing(), "grouped operands must be registered in an eager iteration, before a capture"
+            big = torch.empty((G,) + tuple(bufs[0].shape), device=bufs[0].device, dtype=bufs[0].dtype)
+            for g, (pc, b) in enumerate(zip(pcs, bufs)):
+                big[g].copy_(b)
+                setattr(pc, attr, big[g])
+                if cache is not None and key is not None:
+                    ent = cache.entries[(key, mode, g)]
+                    d = list(ent["desc"])
+                    d[1] = big[g].data_ptr()  # (the refresh launch writes the operand where the kernels now read it)
+                    ent["desc"] = tuple(d)
+                    cache.dirty = True
     return GroupedPack(pcs, bias)
 
 
@@ -1920,6 +1937,187 @@ class BallGroup(torch.autograd.Function):
 
 def ball_group(pcl_xyz, node_xyz, pcl_feat, node_feat):
     return BallGroup.apply(pcl_xyz, node_xyz, pcl_feat, node_feat)
+
+
+class _GroupParams(torch.autograd.Function):
+    """(t_0 .. t_{n-1}) -> the [n, ...] tensor whose slices ARE their storage (group_storage keeps them adjacent): no copy forward; backward hands each
+    parameter its slice of the gradient as a view (AccumulateGrad adopts it).  The n-tensor form of _PairParams (round 6: DESA's three radii)."""
+
+    @staticmethod
+    def forward(ctx, both, *ts):
+        ctx.n = len(ts)
+        return both.detach().view(both.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        return (None,) + tuple(g[i] for i in range(ctx.n))
+
+
+def group_storage(registry, name, ts):
+    """pair_storage for n tensors of identical shape and type: the [n, *shape] tensor over their (re-homed, adjacent) storage."""
+    a = ts[0]
+    if a.numel() % 4:
+        return None
+    both = registry.get(name)
+    es = a.element_size()
+    ok = both is not None and both.device == a.device and both.dtype == a.dtype and all(t.data_ptr() == both.data_ptr() + i * a.numel() * es for i, t in enumerate(ts))
+    if not ok:
+        assert all(t.shape == a.shape and t.dtype == a.dtype and t.device == a.device for t in ts), "group_storage: %s: the tensors differ in shape / type" % name
+        assert not (a.is_cuda and torch.cuda.is_current_stream_capturing()), "group_storage: parameters must be grouped before a graph capture"
+        both = torch.empty((len(ts),) + tuple(a.shape), device=a.device, dtype=a.dtype)
+        with torch.no_grad():
+            for i, t in enumerate(ts):
+                both[i].copy_(t.detach())
+        for i, t in enumerate(ts):
+            t.data = both[i]
+        registry[name] = both
+    return both
+
+
+def group_params(registry, name, ts):
+    """n parameters (or buffers) as one [n, ...] tensor, group-major, differentiable towards each of them."""
+    both = group_storage(registry, name, ts)
+    if both is None:
+        return torch.stack(tuple(ts), 0)
+    return _GroupParams.apply(both, *ts) if any(t.requires_grad for t in ts) else both
+
+
+class BallGroup3(torch.autograd.Function):
+    """BallGroup with the three radii CHANNEL-STACKED (round 6): returns GF [B*J*64, 3*128] (grouped feature differences, radius i in columns [128 i, 128 i +
+    128)), GX [B*J*64, 3*4] (offsets / radius, 3 + a zero channel per radius) and the index sets — what the grouped launches of TrainGraph.desa read — from
+    ONE launch (kpf_ball_group_stacked_f32); backward: one index inversion + ONE launch for all three radii, both outputs (kpf_ball_group_bwd_f32: gathered
+    rows in radius / entry order, joint rows minus their groups' sums) where BallGroup needed three accumulation launches and ~14 library ops around them."""
+
+    @staticmethod
+    def forward(ctx, pcl_xyz, node_xyz, pcl_feat, node_feat):
+        from . import lib as L
+        B, N, _ = pcl_xyz.shape
+        Jn, Cc = node_feat.shape[1], node_feat.shape[2]
+        assert Cc == 128
+        dev = pcl_xyz.device
+        X, JF = pcl_feat.detach().float().contiguous(), node_feat.detach().float().contiguous()
+        R = B * Jn * 64
+        GF = torch.empty(R, 3 * Cc, device=dev, dtype=torch.float32)
+        GX = torch.empty(R, 12, device=dev, dtype=torch.float32)
+        idx = torch.empty(3, B * Jn, 64, device=dev, dtype=torch.int32)
+        L.check(L.load().kpf_ball_group_stacked_f32(pcl_xyz.detach().float().contiguous().data_ptr(), node_xyz.detach().float().contiguous().data_ptr(), X.data_ptr(),
+                                                    JF.data_ptr(), Cc, GF.data_ptr(), GX.data_ptr(), idx.data_ptr(), B, N, 0.1, 0.2, 0.4,
+                                                    torch.cuda.current_stream().cuda_stream), "kpf_ball_group_stacked_f32")
+        ctx.save_for_backward(idx)
+        ctx.shape = (B, N, Jn, Cc)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(GX, idx)
+        return GF, GX, idx
+
+    @staticmethod
+    def backward(ctx, d3, _a, _b):
+        from . import lib as L
+        if d3 is None:
+            return None, None, None, None
+        lib = L.load()
+        (idx,) = ctx.saved_tensors
+        B, N, Jn, Cc = ctx.shape
+        P, R = N + Jn, Jn * 64
+        st = torch.cuda.current_stream().cuda_stream
+        d3 = d3.float().contiguous()
+        nws = lib.kpf_row_gather_ws_ints(3 * B, P, R, 1)
+        ws = torch.empty(nws, device=idx.device, dtype=torch.int32)
+        L.check(lib.kpf_row_gather_invert(idx.data_ptr(), ws.data_ptr(), nws, 3 * B, P, R, 1, st), "kpf_row_gather_invert")
+        dX = torch.empty(B, N, Cc, device=d3.device, dtype=torch.float32)
+        dnode = torch.empty(B, Jn, Cc, device=d3.device, dtype=torch.float32)
+        L.check(lib.kpf_ball_group_bwd_f32(d3.data_ptr(), 3 * Cc, ws.data_ptr(), ws.data_ptr() + 4 * 3 * B * (P + 1), dX.data_ptr(), dnode.data_ptr(), B, N, Jn, st),
+                "kpf_ball_group_bwd_f32")
+        return None, None, dX, dnode
+
+
+def ball_group3(pcl_xyz, node_xyz, pcl_feat, node_feat):
+    return BallGroup3.apply(pcl_xyz, node_xyz, pcl_feat, node_feat)
+
+
+class GroupMax(torch.autograd.Function):
+    """y = x.view(rows, group, C).max(1)[0] on fp32 rows (model/model.py:192: the maximum over a ball's 64 members) with the winner's member index kept: ONE launch
+    each way (kpf_group_max_train_forward / _backward; the library's max + its backward are a reduction, a zero fill and a scatter)."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        from . import lib as L
+        xc = x.float().contiguous()
+        Cc = xc.shape[-1]
+        rows = xc.numel() // (Cc * group)
+        y = torch.empty(rows, Cc, device=x.device, dtype=torch.float32)
+        arg = torch.empty(rows, Cc, device=x.device, dtype=torch.uint8)
+        L.check(L.load().kpf_group_max_train_forward(xc.data_ptr(), y.data_ptr(), arg.data_ptr(), rows, int(group), Cc, torch.cuda.current_stream().cuda_stream),
+                "kpf_group_max_train_forward")
+        ctx.save_for_backward(arg)
+        ctx.meta = (tuple(x.shape), int(group), x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import lib as L
+        (arg,) = ctx.saved_tensors
+        shape, group, dt = ctx.meta
+        rows, Cc = arg.shape
+        dy = dy.float().contiguous()
+        dx = torch.empty(rows * group, Cc, device=dy.device, dtype=torch.float32)
+        L.check(L.load().kpf_group_max_train_backward(dy.data_ptr(), arg.data_ptr(), dx.data_ptr(), rows, group, Cc, torch.cuda.current_stream().cuda_stream),
+                "kpf_group_max_train_backward")
+        return dx.view(shape).to(dt), None
+
+
+def group_max(x, group):
+    return GroupMax.apply(x, group)
+
+
+class LinearSlices(torch.autograd.Function):
+    """n independent Linear layers with an ODD input width (DESA's Conv2d(3 -> 128) on the offsets of each radius, model/model.py:176-179) over the column blocks
+    of one channel-stacked input: y[:, N i : N i + N] = x[:, Kp i : Kp i + K] W_i^T + b_i, written by n launches into ONE [rows, n N] tensor (so that the
+    BatchNorm behind it is one 3-launch pass over n N channels instead of n passes).  x [rows, n * Kp] with Kp = K rounded up to 4 (the pad columns zero) and no
+    gradient (the offsets are not differentiated); backward = the n weight gradients from dY's column blocks in place (kpf_conv2d_wgrad_groups: ldx, ldy, trim)."""
+
+    @staticmethod
+    def forward(ctx, x, keys, cache, *wb):
+        from .engine import Act, conv
+        n = len(wb) // 2
+        ws, bs = wb[0::2], wb[1::2]
+        N, K = ws[0].shape[0], ws[0][0].numel()
+        Kp = (K + 3) // 4 * 4
+        xc = x.detach().float().contiguous()
+        rows = xc.shape[0]
+        assert xc.shape[1] == n * Kp and N % 4 == 0
+        y = torch.empty(rows, n * N, device=x.device, dtype=torch.float32)
+        for i in range(n):
+            w2 = ws[i].reshape(N, K, 1, 1)
+            pc = cache.get((keys[i], 0), w2, bs[i], 0, "f32", stride=1, pad=0, patchify=False) if cache is not None else DevPack.packed(w2, bs[i], 0, "f32", stride=1, pad=0, patchify=False)
+            conv(_OddPack(pc, Kp), Act(xc.view(-1), 1, 1, rows, Kp, n * Kp, Kp * i), out=Act(y.view(-1), 1, 1, rows, N, n * N, N * i))
+        ctx.save_for_backward(xc, *ws)
+        ctx.meta = (n, N, K, Kp, [b is not None for b in bs])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import lib as L
+        lib = L.load()
+        xc, *ws = ctx.saved_tensors
+        n, N, K, Kp, has_b = ctx.meta
+        rows = xc.shape[0]
+        dy = dy.float().contiguous()
+        st = torch.cuda.current_stream().cuda_stream
+        grads = []
+        nws = lib.kpf_conv2d_wgrad_ws_floats(rows, N, Kp)
+        for i in range(n):
+            wsb = torch.empty(nws, device=xc.device, dtype=torch.float32)
+            dw = torch.empty(tuple(ws[i].shape), device=xc.device, dtype=torch.float32)
+            db = torch.empty(N, device=xc.device, dtype=torch.float32) if has_b[i] else None
+            L.check(lib.kpf_conv2d_wgrad_groups(dy.data_ptr() + 4 * N * i, xc.data_ptr() + 4 * Kp * i, L.KPF_DT_F32, dw.data_ptr(), db.data_ptr() if db is not None else None,
+                                                wsb.data_ptr(), nws, 1, 1, 1, rows, Kp, n * Kp, 1, rows, N, n * N, 1, 1, 1, 1, 0, 0, K, N, st), "kpf_conv2d_wgrad_groups")
+            grads += [dw, db]
+        return (None, None, None) + tuple(grads)
+
+
+def linear_slices(x, keys, cache, wb):
+    return LinearSlices.apply(x, tuple(keys), cache, *wb)
 
 
 class RowGather(torch.autograd.Function):

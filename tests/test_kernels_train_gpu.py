@@ -1307,9 +1307,14 @@ def test_bert_stack21_forward_backward_match_fp64_torch(B):
     prm64 = [t.detach().double().cpu().requires_grad_(True) for t in prm]
     ref = _bert_stack_reference(e64, pos64, prm64)
     (ref * wsum.double().cpu()).sum().backward()
-    assert float((out.double().cpu() - ref).abs().max() / ref.abs().max()) < 2e-5
+    assert float((out.double().cpu() - ref.detach()).abs().max() / ref.detach().abs().max()) < 2e-5
     for i, (gd, t64) in enumerate(zip(grads, [e64, pos64] + prm64)):
-        err = float((gd.double().cpu() - t64.grad).abs().max() / (t64.grad.abs().max() + 1e-12))
+        # (the key biases' gradient is analytically ZERO — a constant added to every key shifts a softmax row uniformly — so the fp64 reference holds 1e-16
+        #  there and the fp32 kernel rounding noise of sums of O(10) terms: checked in absolute terms)
+        if i >= 2 and names[i - 2].endswith("key.bias"):
+            assert float(gd.abs().max()) < 1e-4 and float(t64.grad.abs().max()) < 1e-10, "key bias: zero gradient"
+            continue
+        err = float((gd.double().cpu() - t64.grad).abs().max() / (t64.grad.abs().max() + 1e-4))
         assert err < 2e-4, "gradient %d (%s): relative error %.2e" % (i, "e pos".split()[i] if i < 2 else names[i - 2], err)
 
 
@@ -1329,15 +1334,15 @@ def test_bert_stack21_dropout_masks_are_consistent_between_forward_and_backward(
     rng = torch.tensor([1234567, 5], dtype=torch.int64, device=dev)
     f = lambda: T.bert_stack21(e, pos, names, None, 0.1, rng, 1, prm)
     out = f()
+    h0 = out.grad_fn.saved_tensors[0][:B * 21 * 128].view(B, 21, 128).clone()  # H[0] is the first block of the saved buffer
     (out * wsum).sum().backward()
     g_e, g_wq, g_wo2 = e.grad.clone(), prm[0].grad.clone(), prm[16 * 2 + 12].grad.clone()
     assert torch.equal(out, f())
     rng2 = rng.clone()
     rng2[1] += 1
     assert not torch.equal(out, T.bert_stack21(e, pos, names, None, 0.1, rng2, 1, prm))
-    # H[0] is the first block of the saved buffer: zero fraction and scale
+    # zero fraction and scale of H[0]
     with torch.no_grad():
-        h0 = out.grad_fn.saved_tensors[0][:B * 21 * 128].view(B, 21, 128)
         zero = (h0 == 0)
         assert 0.07 < float(zero.float().mean()) < 0.13
         assert torch.allclose(h0[~zero], ((e + pos) / 0.9)[~zero], rtol=1e-6, atol=1e-6)
@@ -1353,3 +1358,84 @@ def test_bert_stack21_dropout_masks_are_consistent_between_forward_and_backward(
             t.copy_(base)
             fd, an = (lp - lm) / (2 * eps), float((g.double() * d.double()).sum())
             assert abs(fd - an) < 3e-2 * max(abs(an), abs(fd)) + 1e-3, (fd, an)
+
+
+@pytest.mark.parametrize("net", ["convnext-tiny", "resnet-18"])
+def test_grouped_desa_and_fused_stacks_match_the_layer_by_layer_training_graph(net, monkeypatch):
+    """Round 6: DESA's three radii as one channel-stacked chain (KPF_DESA_GROUPED: grouped Linears, BatchNorm / ReLU / group maximum over 3 x 128 channels,
+    BallGroup3 / LinearSlices / GroupMax) and the 21-token stacks as one launch each way (KPF_TR_FUSED: BertStack21) against the radius-by-radius, layer-by-layer
+    graph: same outputs, loss, BatchNorm running statistics and gradients of EVERY parameter to fp32 rounding.  (The reference-gradient test runs with given
+    ball-query sets, which takes the op-by-op DESA: this test is what pins the grouped form, on the computed sets.)"""
+    from conftest import synthetic_sd
+    from keypointfusion_amd import train_graph as TG
+    from keypointfusion_amd import training as T
+    from keypointfusion_amd.model.model import KPFusion
+    from keypointfusion_amd.weights import synthetic_batch
+    net, B, dev = "KPFusion-" + net, 4, torch.device("cuda:0")
+    batch = {k: torch.from_numpy(v).to(dev) for k, v in synthetic_batch(B, 128, seed=6).items()}
+    g = torch.Generator().manual_seed(2)
+    uvd, xyz = (torch.rand(B, 21, 3, generator=g) * 1.2 - 0.6).to(dev), (torch.rand(B, 21, 3, generator=g) * 1.2 - 0.6).to(dev)
+
+    class Loader:
+        img_size, flip = 128, 1
+
+    def run(new):
+        monkeypatch.setattr(TG, "DESA_GROUPED", new)
+        monkeypatch.setattr(TG, "TR_FUSED", new)
+        m = KPFusion(net, "", 21, "dexycb", "")
+        m.load_state_dict(synthetic_sd(net), strict=True)
+        m = m.to(dev).train()
+        m.train_dropout = 0.0
+        r, s, _ = m(batch["img_rgb"], batch["img"], batch["pcl"], Loader(), batch["center"], batch["M"], batch["cube"], batch["cam_para"], 0.8)
+        loss = T.kpfusion_loss(r, s, batch["img"], uvd, xyz, epoch=0)[0]
+        loss.backward()
+        bufs = {k: v.detach().clone() for k, v in m.named_buffers()}
+        return float(loss), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}, bufs, [t.detach().clone() for t in r + s]
+
+    l0, g0, b0, r0 = run(False)
+    l1, g1, b1, r1 = run(True)
+    rel = lambda a, b: float((a.float() - b.float()).abs().max()) / max(float(a.float().abs().max()), 1e-6)
+    assert set(g0) == set(g1), sorted(set(g0) ^ set(g1))[:8]
+    for a, b in zip(r0, r1):
+        assert rel(a, b) <= 1e-4, rel(a, b)
+    assert abs(l0 - l1) <= 1e-4 * abs(l0), (l0, l1)
+    floor = 1e-5 * max(float(v.float().abs().max()) for v in g0.values())  # (biases in front of a batch-statistics BatchNorm have an exactly zero gradient)
+    relf = lambda a, b: float((a.float() - b.float()).abs().max()) / max(float(a.float().abs().max()), floor)
+    errs = sorted((relf(g0[k], g1[k]), k) for k in g0)
+    print("grouped DESA + fused stacks vs layer by layer (%s): loss %.6f / %.6f, gradient error median %.2e, worst %s" % (net, l0, l1, errs[len(errs) // 2][0], errs[-3:]))
+    assert errs[len(errs) // 2][0] <= 1e-3 and errs[-1][0] <= 5e-2, (errs[len(errs) // 2], errs[-8:])
+    for k in b0:
+        assert torch.allclose(b0[k].float(), b1[k].float(), rtol=1e-4, atol=1e-5), k
+
+
+def test_group_max_and_ball_group3_match_torch():
+    """GroupMax (max over 64 consecutive rows with the winner kept) against torch.max and its autograd; BallGroup3 (the three radii channel-stacked, one backward
+    launch) against BallGroup (radius by radius): same grouped rows and offsets, same index sets, same gradients towards the point / joint features."""
+    from keypointfusion_amd import training as T
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(5 * 64, 384, generator=gen).to(dev).requires_grad_(True)
+    w = torch.randn(5, 384, generator=gen).to(dev)
+    y = T.group_max(x, 64)
+    (y * w).sum().backward()
+    x2 = x.detach().clone().requires_grad_(True)
+    y2 = x2.view(5, 64, 384).max(1)[0]
+    (y2 * w).sum().backward()
+    assert torch.equal(y, y2) and torch.equal(x.grad, x2.grad)
+    B, N, J = 3, 1024, 21
+    pcl = (torch.rand(B, N, 3, generator=gen) * 1.2 - 0.6).to(dev)
+    node = (torch.rand(B, J, 3, generator=gen) * 0.8 - 0.4).to(dev)
+    pf = torch.randn(B, N, 128, generator=gen).to(dev).requires_grad_(True)
+    nf = torch.randn(B, J, 128, generator=gen).to(dev).requires_grad_(True)
+    GF3, GX3, idx3 = T.ball_group3(pcl, node, pf, nf)
+    wgt = torch.randn(B * J * 64, 384, generator=gen).to(dev)
+    (GF3 * wgt).sum().backward()
+    g3 = (pf.grad.clone(), nf.grad.clone())
+    pf.grad = nf.grad = None
+    outs = T.ball_group(pcl, node, pf, nf)
+    assert torch.equal(outs[6], idx3)
+    for i in range(3):
+        assert torch.equal(outs[2 * i], GF3[:, 128 * i:128 * i + 128]) and torch.equal(outs[2 * i + 1], GX3[:, 4 * i:4 * i + 4])
+    sum((outs[2 * i] * wgt[:, 128 * i:128 * i + 128]).sum() for i in range(3)).backward()
+    for a, c in zip(g3, (pf.grad, nf.grad)):
+        assert float((a - c).abs().max()) <= 1e-5 * float(c.abs().max()) + 1e-6, float((a - c).abs().max())
