@@ -28,7 +28,7 @@ One JSON line is printed by rank 0 with, besides the contract fields:
                  as 3 x f16 MFMA on hi/lo-split operands with a pack-time range proof; everything else stays on the f32 MFMA).
   extra        : (default run, N = 1) one timed record per further BASELINE config that fits one GPU — `cnb512_f16` (configs[4]: ConvNeXt-B,
                  512x512, f16, B=64), `full128_bf16` (configs[2]: full model, B=32, bf16), `train128_bf16` (configs[3]: one training
-                 iteration, B=32, bf16) — and `full256` (the FULL model at the headline's batch and crop size: the labelled wide extension,
+                 iteration, B=32, bf16), `full128_f16` (configs[2] in the recommended 16-bit mode) — and `full256` (the FULL model at the headline's batch and crop size: the labelled wide extension,
                  not a reference configuration), each measured by this script as a child process on that workload, with its own `roofline`.
   world_size   : ranks that took part (dist.get_world_size()), `collective_backend` the RCCL version when a process group exists.
   cpu_baseline : the CPU oracle (oracle/kpf_oracle.py, torch-CPU fp32 = the reference's own arithmetic) on the host
@@ -57,6 +57,8 @@ WORKLOADS = {
     "backbones256": ("KPFusion-convnext-tiny", 256, 64, "f32", "backbones", "configs[1]"),
     "full128": ("KPFusion-convnext-tiny", 128, 64, "f32", "full", "full model at configs[1]'s batch"),
     "full128_bf16": ("KPFusion-convnext-tiny", 128, 32, "bf16", "full", "configs[2]"),
+    # the same in f16 — the reduced-precision mode the accuracy statistics recommend (f16 deviates 0.2 mm from the fp32 path, bf16 0.9 mm)
+    "full128_f16": ("KPFusion-convnext-tiny", 128, 32, "f16", "full", "configs[2] in f16 (the recommended 16-bit mode)"),
     "full128_bf16_r18": ("KPFusion-resnet-18", 128, 32, "bf16", "full", "configs[2] with the ResNet-18 backbones (SURVEY 8d config 3 names both families)"),
     # the full model at the crop size BASELINE's metric is quoted on: the labelled wide extension (KPFusion(..., crop_size=256): fc_spatial2joint_feature sized
     # for the 64 x 64 feature map; the reference hard-codes 32 x 32 and cannot run this size) — not a reference configuration
@@ -133,7 +135,7 @@ def self_launch(n):
 # BASELINE config that runs on one GPU.  (workload, steps, warmup)
 # (order: the launch-bound workloads first, the two that hold the chip at its power limit last — on some boxes the training iteration measured 10 % slower
 #  right behind the ConvNeXt-B run than on its own: 17.6 vs 15.8 ms, profiles/r05_bench.json of the first r05 collection)
-EXTRA_WORKLOADS = (("train128_bf16", 30, 5), ("full128_bf16", 30, 5), ("full256", 8, 3), ("cnb512_f16", 6, 2))
+EXTRA_WORKLOADS = (("train128_bf16", 30, 5), ("full128_bf16", 30, 5), ("full128_f16", 30, 5), ("full256", 8, 3), ("cnb512_f16", 6, 2))
 
 
 def run_extra(workload, steps, warmup, timeout):

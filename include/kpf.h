@@ -430,6 +430,10 @@ int kpf_row_gather_accum_f32(const float* dout, const int* start, const int* lis
 int kpf_ball_group_bwd_f32(const float* d3, int ld3, const int* start, const int* list, float* dX, float* dnode, int B, int N, int Jn, void* stream);
 /* Training (ABI 16): y[r][c] = max over the `group` consecutive rows of x [rows*group][C] (model/model.py:192 `.max(2)` over a ball's 64 members), the
  * first maximum's member index kept in arg [rows][C]; backward: dx[r][m][c] = (m == arg[r][c]) ? dy[r][c] : 0, every element written once. */
+/* Training (ABI 16): the embedding sums of a fusion block over one channel-stacked tensor y [rows][(n1 + n2) * C]: out [rows][C] = relu(S1) (n2 == 0) or
+ * relu(relu(S1) + S2), S1 / S2 = sums of the first n1 / next n2 column blocks (model/model.py:417-422); backward: dy of the same shape. */
+int kpf_slices_sum_relu_forward(const float* y, float* out, long rows, int C, int n1, int n2, void* stream);
+int kpf_slices_sum_relu_backward(const float* dout, const float* out, const float* y, float* dy, long rows, int C, int n1, int n2, void* stream);
 int kpf_group_max_train_forward(const float* x, float* y, unsigned char* arg, long rows, int group, int C, void* stream);
 int kpf_group_max_train_backward(const float* dy, const unsigned char* arg, float* dx, long rows, int group, int C, void* stream);
 long kpf_ln_ws_floats(long rows, int C);

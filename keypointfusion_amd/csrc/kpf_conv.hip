@@ -1014,7 +1014,6 @@ __global__ __launch_bounds__(512, 2) void gemm16_8ph_kernel(const ConvArgs a) {
   }
   int tile = bid;
   int m0, n0;
-
   // ---- staging: thread -> (row lr of a 64-row DMA block, chunk position cp); a half-tile is two DMA instructions per wave ----
   const int lr = tid >> 3, cp = tid & 7;
   const int kc = ((cp ^ ((lr >> 1) & 7)) << 2);  // logical k offset (4-byte words) this lane fetches: the swizzle is applied to the SOURCE
@@ -1353,11 +1352,14 @@ int launch_8ph(ConvArgs& a, hipStream_t st) {
   a.tilesN = a.N / 256;
   a.nblk = ((a.M + 255) / 256) * a.tilesN;
   static const bool no_persist = getenv("KPF_G8_NO_PERSIST") != nullptr;  // tuning aid
-  // output stores (store-only epilogues): KPF_G8_ST = 0 plain, 1 sc1, 2 nt; default: sc1 when the output alone is larger than the eight L2s (32 MB) —
-  // g8_store16 above
+  // output stores of the persistent form (g8_store16 above): non-temporal by default (KPF_G8_ST = 0 plain, 1 sc1, 2 nt).  Measured per shape, f16, round 6
+  // (profiles/r06_g16_store_policy.txt): FETCH of the K <= 256 GELU layers falls from 3.6 x / 2.4 x their operand bytes to 2.2 x / 1.07 x (sc1: 1.4 x / 1.06 x)
+  // and their time by 5-8 % (sc1: equal); the K >= 512 shapes are unchanged either way (their 4.9 x is not output pollution: it does not move with the
+  // policy nor with a start skew between the workgroups that share a pixel panel).
   static const int st_env = []() { const char* e = getenv("KPF_G8_ST"); return e ? atoi(e) : -1; }();
-  a.st_policy = res ? 0 : (st_env >= 0 ? st_env : 0);
+
   const bool persist = !res && a.M % 256 == 0 && a.nblk > 256 && !no_persist && !a.dbg;
+  a.st_policy = persist ? (st_env >= 0 ? st_env : 2) : 0;
   const bool lnf = (a.flags & KPF_PRO_LN) != 0;  // (kpf_conv2d_h16 admits it with the GELU epilogue only)
   void (*kern)(const ConvArgs) = res ? gemm16_8ph_kernel<EPI_RES, ARITH, false>
                                      : (gelu ? (lnf ? (persist ? gemm16_8ph_kernel<EPI_GELU, ARITH, true, true> : gemm16_8ph_kernel<EPI_GELU, ARITH, false, true>)

@@ -2210,12 +2210,27 @@ __global__ __launch_bounds__(256) void ball_group_bwd_kernel(const float* __rest
       for (int c0 = s0; c0 < s1; c0 += 64) {
         const int m = min(64, s1 - c0);
         const int ev = lane < m ? lb[c0 + lane] : 0;
-        for (int k = phase; k < m + phase; k += 2) {  // (the same trip count for both half-waves: the shuffle runs with the whole wave active)
+        // (lists are very uneven — the slots a small ball leaves unfilled repeat its first member, so a few rows own hundreds of entries: eight row loads in
+        //  flight per half-wave, added in position order, as in row_gather_accum_kernel)
+        int k = phase;
+        for (; (k - phase) + 15 < m; k += 16) {  // (the same trip count for both half-waves: every shuffle runs with the whole wave active)
+          int e[8];
+          f32x4 g[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) e[u] = __shfl(ev, k + 2 * u, 64);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) g[u] = kpf_ld4(db + (long)e[u] * ld3 + 128 * i);
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] += g[u][t];
+        }
+        for (; k < m + phase; k += 2) {
           const int e1 = __shfl(ev, min(k, m - 1), 64);
           if (k < m) {
-            const f32x4 g = kpf_ld4(db + (long)e1 * ld3 + 128 * i);
+            const f32x4 g1 = kpf_ld4(db + (long)e1 * ld3 + 128 * i);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] += g[t];
+            for (int t = 0; t < 4; ++t) acc[t] += g1[t];
           }
         }
       }
@@ -2299,6 +2314,64 @@ extern "C" int kpf_group_max_train_backward(const float* dy, const unsigned char
   const long n4 = rows * group * (C / 4);
   hipLaunchKernelGGL(group_max_train_bwd_kernel, dim3(grid_for(n4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, arg, dx, n4, group, C / 4);
   return kpf_check_launch("kpf_group_max_train_backward");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round 6: the embedding sums of a fusion block over ONE channel-stacked tensor y [rows][n * C] (n sibling Linear + BatchNorm branches written side by side,
+// one BatchNorm pass over n * C channels: training.LinearCat / TrainGraph.bn_g) —  out = relu(S1)  with  S1 = sum of the first n1 blocks   (n2 == 0), or
+// out = relu(relu(S1) + S2)  with  S2 = sum of the next n2 blocks (model/model.py:417-422: relu(feat + xyz + pose), then relu(. + rgb feat)).
+// Backward: dy block i = d for i >= n1, d * (S1 > 0) for i < n1, with d = dout * (out > 0); S1 is recomputed from y.  One launch each way.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void slices_sum_relu_fwd_kernel(const float* __restrict__ y, float* __restrict__ out, long n4, int C4, int n1, int n2) {
+  const int ld4 = C4 * (n1 + n2);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long r = i / C4;
+    const int q = (int)(i - r * C4);
+    const float* p = y + (r * ld4 + q) * 4;
+    f32x4 s1 = kpf_ld4(p);
+    for (int k = 1; k < n1; ++k) s1 += kpf_ld4(p + (long)k * C4 * 4);
+    f32x4 o = {fmaxf(s1[0], 0.f), fmaxf(s1[1], 0.f), fmaxf(s1[2], 0.f), fmaxf(s1[3], 0.f)};
+    if (n2 > 0) {
+      for (int k = n1; k < n1 + n2; ++k) o += kpf_ld4(p + (long)k * C4 * 4);
+      o = f32x4{fmaxf(o[0], 0.f), fmaxf(o[1], 0.f), fmaxf(o[2], 0.f), fmaxf(o[3], 0.f)};
+    }
+    kpf_st4(out + i * 4, o);
+  }
+}
+__global__ __launch_bounds__(256) void slices_sum_relu_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ y,
+                                                                  float* __restrict__ dy, long n4, int C4, int n1, int n2) {
+  const int ld4 = C4 * (n1 + n2);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long r = i / C4;
+    const int q = (int)(i - r * C4);
+    const f32x4 g = kpf_ld4(dout + i * 4), o = kpf_ld4(out + i * 4);
+    const f32x4 d = {o[0] > 0.f ? g[0] : 0.f, o[1] > 0.f ? g[1] : 0.f, o[2] > 0.f ? g[2] : 0.f, o[3] > 0.f ? g[3] : 0.f};
+    f32x4 d1 = d;
+    if (n2 > 0) {
+      const float* p = y + (r * ld4 + q) * 4;
+      f32x4 s1 = kpf_ld4(p);
+      for (int k = 1; k < n1; ++k) s1 += kpf_ld4(p + (long)k * C4 * 4);
+      d1 = f32x4{s1[0] > 0.f ? d[0] : 0.f, s1[1] > 0.f ? d[1] : 0.f, s1[2] > 0.f ? d[2] : 0.f, s1[3] > 0.f ? d[3] : 0.f};
+    }
+    float* w = dy + (r * ld4 + q) * 4;
+    for (int k = 0; k < n1; ++k) kpf_st4(w + (long)k * C4 * 4, d1);
+    for (int k = n1; k < n1 + n2; ++k) kpf_st4(w + (long)k * C4 * 4, d);
+  }
+}
+}  // namespace
+
+extern "C" int kpf_slices_sum_relu_forward(const float* y, float* out, long rows, int C, int n1, int n2, void* stream) {
+  KPF_REQUIRE(y && out && rows > 0 && C > 0 && C % 4 == 0 && n1 >= 1 && n2 >= 0 && n1 + n2 <= 8, "kpf_slices_sum_relu_forward: bad arguments (C %% 4 == 0, 1 <= n1, n1 + n2 <= 8)");
+  const long n4 = rows * (C / 4);
+  hipLaunchKernelGGL(slices_sum_relu_fwd_kernel, dim3(grid_for(n4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), y, out, n4, C / 4, n1, n2);
+  return kpf_check_launch("kpf_slices_sum_relu_forward");
+}
+extern "C" int kpf_slices_sum_relu_backward(const float* dout, const float* out, const float* y, float* dy, long rows, int C, int n1, int n2, void* stream) {
+  KPF_REQUIRE(dout && out && y && dy && rows > 0 && C > 0 && C % 4 == 0 && n1 >= 1 && n2 >= 0 && n1 + n2 <= 8, "kpf_slices_sum_relu_backward: bad arguments");
+  const long n4 = rows * (C / 4);
+  hipLaunchKernelGGL(slices_sum_relu_bwd_kernel, dim3(grid_for(n4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dout, out, y, dy, n4, C / 4, n1, n2);
+  return kpf_check_launch("kpf_slices_sum_relu_backward");
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -69,6 +69,8 @@ _SIGS = {
     "kpf_group_max_f32": [_P, _P, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _P],
     "kpf_ball_group_stacked_f32": [_P, _P, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _P],
     "kpf_ball_group_bwd_f32": [_P, C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_slices_sum_relu_forward": [_P, _P, C.c_long, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_slices_sum_relu_backward": [_P, _P, _P, _P, C.c_long, C.c_int, C.c_int, C.c_int, _P],
     "kpf_group_max_train_forward": [_P, _P, _P, C.c_long, C.c_int, C.c_int, _P],
     "kpf_group_max_train_backward": [_P, _P, _P, C.c_long, C.c_int, C.c_int, _P],
     "kpf_heat_gam_gate_f32": [_P, _P, _P, C.c_int] + [_P] * 10 + [C.c_int] * 4 + [_P],

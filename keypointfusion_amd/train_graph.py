@@ -32,7 +32,7 @@ import torch.nn.functional as F
 
 from . import lib as L
 from .engine import _ptr, _stream, crop_inverse
-from .training import (add_relu, attn21, ball_group3, batchnorm_relu_rows, bert_stack21, bmm_small_k, group_max, group_params, linear_slices, conv2d_nhwc, dwconv7_nhwc, gelu_rows, layer_norm_rows, layer_scale_residual, linear_hip, maxpool3x3s2_nhwc,
+from .training import (add_relu, attn21, ball_group3, linear_cat, slices_sum_relu, batchnorm_relu_rows, bert_stack21, bmm_small_k, group_max, group_params, linear_slices, conv2d_nhwc, dwconv7_nhwc, gelu_rows, layer_norm_rows, layer_scale_residual, linear_hip, maxpool3x3s2_nhwc,
                        ball_group, drop_add_ln, pair_params, pair_storage, row_gather, self_attention21, upsample2x_nhwc)
 
 _N_STREAMS = int(os.environ.get("KPF_TRAIN_STREAMS", "2"))  # 2: the RGB backbone (forward and backward) on a side stream (unpaired backbones only)
@@ -46,6 +46,9 @@ TR_FUSED = bool(int(os.environ.get("KPF_TR_FUSED", "1")))
 # 1 (default): DESA's three radii as ONE channel-stacked chain — grouped Linears (G = 3), BatchNorm / add + ReLU / group maximum over 3 x 128 channels, one
 # grouping launch each way (training.BallGroup3 / LinearSlices / GroupMax) — instead of three chains of small launches; 0: radius by radius
 DESA_GROUPED = bool(int(os.environ.get("KPF_DESA_GROUPED", "1")))
+# 1 (default): the sibling embeddings of a fusion block (Conv1d + BatchNorm1d each, then summed under a ReLU: model/model.py:254-259, 417-422) write ONE
+# channel-stacked tensor — one BatchNorm pass over n x 128 channels, one sum + ReLU launch each way (training.LinearCat / SlicesSumRelu); 0: one by one
+EMB_GROUPED = bool(int(os.environ.get("KPF_EMB_GROUPED", "1")))
 PAIR = "PAIR."  # parameter-name prefix that stands for ("backbone_rgb.", "backbone_d.") while a paired pass is built
 
 J = 21
@@ -384,6 +387,16 @@ class TrainGraph:
         y = self.linear_rows(x.reshape(B * N, Cin), self.t[p + ".0.weight"].flatten(1), self.t[p + ".0.bias"], p + ".0.weight")
         return self.bn_l(y.view(B, N, -1), p + ".1", out16=False)  # (summed with the other embeddings: kept fp32)
 
+    def emb_group(self, names, xs, n1, n2=0):
+        """relu(sum of the first n1 embeddings) [then relu(. + the next n2)] of n sibling Conv1d(k=1) + BatchNorm1d branches over rows [B, N, K_i] (K_i % 4 == 0)."""
+        B, N = xs[0].shape[:2]
+        wb = []
+        for nm in names:
+            wb += [self.t[nm + ".0.weight"].flatten(1), self.t[nm + ".0.bias"]]
+        y = linear_cat([t.reshape(B * N, t.shape[-1]) for t in xs], [nm + ".0.weight" for nm in names], self.packs, wb)
+        y = self.bn_g(y, [nm + ".1" for nm in names])
+        return slices_sum_relu(y, y.shape[1] // len(names), n1, n2).view(B, N, -1)
+
     @staticmethod
     def gather_interp(feat, idx, clos, inv=None):
         """feat [B, C, H, W] (channels_last memory: the row view below is free) -> [B, N, C]: the 4 nearest pixels' feature rows
@@ -557,11 +570,19 @@ class TrainGraph:
         pf_rgb = self.gather_interp(img_feat_rgb, idx, clos, self.idx_inv)
         pw = self.gather_interp(img_offset[:, J * 4:], idx, clos).detach()
         tok = self.pose_tokens(pw, joint_xyz, pcl, 0.8)  # [pw | pcl_joint2offset(joint, pcl) | 0 0 0]: 105 channels at the GEMM's width 108, no gradient
-        x = add_relu(self.emb1d(p + ".pcl_feat_emb", pf), self.emb1d(p + ".pcl_xyz_emb", self.pcl4), self.emb1d(p + ".pcl_pose_emb", tok))
-        x = add_relu(x, self.emb1d(p + ".pcl_feat_emb_RGB", pf_rgb))
+        grouped = EMB_GROUPED and self.prec == "f32"
+        if grouped:  # relu(relu(feat + xyz + pose) + rgb feat): four Linears into one [B*N, 4 x 128] tensor, one BatchNorm pass, one sum + ReLU
+            x = self.emb_group([p + ".pcl_feat_emb", p + ".pcl_xyz_emb", p + ".pcl_pose_emb", p + ".pcl_feat_emb_RGB"], [pf, self.pcl4, tok, pf_rgb], 3, 1)
+        else:
+            x = add_relu(self.emb1d(p + ".pcl_feat_emb", pf), self.emb1d(p + ".pcl_xyz_emb", self.pcl4), self.emb1d(p + ".pcl_pose_emb", tok))
+            x = add_relu(x, self.emb1d(p + ".pcl_feat_emb_RGB", pf_rgb))
         att = F.softmax(pw.permute(0, 2, 1), -1)
         jf = bmm_small_k(att, x)
-        jf = add_relu(self.emb1d(p + ".joint_feat_emb", jf), self.emb1d(p + ".joint_xyz_emb", joint_xyz.detach()))
+        if grouped:
+            from .training import pad_rows
+            jf = self.emb_group([p + ".joint_feat_emb", p + ".joint_xyz_emb"], [jf, pad_rows(joint_xyz.detach(), 4)], 2)
+        else:
+            jf = add_relu(self.emb1d(p + ".joint_feat_emb", jf), self.emb1d(p + ".joint_xyz_emb", joint_xyz.detach()))
         jf = self.desa(p + ".FA", x, jf, pcl, joint_xyz.detach())
         h_init, r3d = self.kp_interaction_tr(p + ".init_TR", jf)
         r3d = r3d.float()  # geometry, heat map and the returned joints are fp32 in every precision

@@ -2120,6 +2120,104 @@ def linear_slices(x, keys, cache, wb):
     return LinearSlices.apply(x, tuple(keys), cache, *wb)
 
 
+class LinearCat(torch.autograd.Function):
+    """n independent Linear layers of the same output width N over n DIFFERENT row tensors, written side by side into ONE [rows, n N] tensor (round 6: the
+    point / joint embeddings of a fusion block, model/model.py:254-259, 417-422 — so that the n BatchNorms behind them are one pass over n N channels and the sum +
+    ReLU one launch, training.slices_sum_relu).  x_i [rows, K_i] fp32 (K_i a multiple of 4: odd widths arrive padded with zero columns, the weight keeps its own
+    width); backward: per layer the weight / bias gradient from dY's column block in place (ldy = n N) and, where x_i requires a gradient, dX_i = dY_i W_i from the
+    data-gradient GEMM reading the same block in place."""
+
+    @staticmethod
+    def forward(ctx, keys, cache, n, *args):
+        from .engine import Act, conv
+        xs, wb = args[:n], args[n:]
+        ws, bs = wb[0::2], wb[1::2]
+        N = ws[0].shape[0]
+        rows = xs[0].shape[0]
+        y = torch.empty(rows, n * N, device=xs[0].device, dtype=torch.float32)
+        xcs, kps = [], []
+        for i in range(n):
+            xc = xs[i].detach().float().contiguous()
+            K = ws[i][0].numel()
+            Kp = xc.shape[1]
+            assert xc.shape[0] == rows and Kp % 4 == 0 and Kp >= K and Kp - K < 4 and ws[i].shape[0] == N and N % 4 == 0
+            w2 = ws[i].reshape(N, K, 1, 1)
+            pc = cache.get((keys[i], 0), w2, bs[i], 0, "f32", stride=1, pad=0, patchify=False) if cache is not None else DevPack.packed(w2, bs[i], 0, "f32", stride=1, pad=0, patchify=False)
+            conv(_OddPack(pc, Kp) if Kp != K else pc, Act(xc.view(-1), 1, 1, rows, Kp), out=Act(y.view(-1), 1, 1, rows, N, n * N, N * i))
+            xcs.append(xc)
+            kps.append((K, Kp))
+        ctx.save_for_backward(*xcs, *ws)
+        ctx.meta = (n, N, kps, [b is not None for b in bs], keys, cache)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import lib as L
+        from .engine import Act, conv
+        lib = L.load()
+        n, N, kps, has_b, keys, cache = ctx.meta
+        xcs, ws = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        rows = xcs[0].shape[0]
+        dy = dy.float().contiguous()
+        st = torch.cuda.current_stream().cuda_stream
+        dxs, grads = [], []
+        for i in range(n):
+            K, Kp = kps[i]
+            dx = None
+            if ctx.needs_input_grad[3 + i]:
+                assert K == Kp, "LinearCat: data gradients for whole channel groups only"
+                w2 = ws[i].detach().reshape(N, K, 1, 1)
+                pc = cache.get((keys[i], 1), w2, None, 1, "f32", pad=0, n_pad=N) if cache is not None else DevPack.packed(w2, None, 1, "f32", pad=0, n_pad=N)
+                dx = torch.empty(rows, K, device=dy.device, dtype=torch.float32)
+                conv(pc, Act(dy.view(-1), 1, 1, rows, N, n * N, N * i), out=Act(dx.view(-1), 1, 1, rows, K))
+            dxs.append(dx)
+            dw = db = None
+            if ctx.needs_input_grad[3 + n + 2 * i]:
+                nws = lib.kpf_conv2d_wgrad_ws_floats(rows, N, Kp)
+                wsb = torch.empty(nws, device=dy.device, dtype=torch.float32)
+                dw = torch.empty(tuple(ws[i].shape), device=dy.device, dtype=torch.float32)
+                db = torch.empty(N, device=dy.device, dtype=torch.float32) if has_b[i] else None
+                L.check(lib.kpf_conv2d_wgrad_groups(dy.data_ptr() + 4 * N * i, xcs[i].data_ptr(), L.KPF_DT_F32, dw.data_ptr(), db.data_ptr() if db is not None else None,
+                                                    wsb.data_ptr(), nws, 1, 1, 1, rows, Kp, Kp, 1, rows, N, n * N, 1, 1, 1, 1, 0, 0, K, N, st), "kpf_conv2d_wgrad_groups")
+            grads += [dw, db]
+        return (None, None, None) + tuple(dxs) + tuple(grads)
+
+
+def linear_cat(xs, keys, cache, wb):
+    return LinearCat.apply(tuple(keys), cache, len(xs), *xs, *wb)
+
+
+class SlicesSumRelu(torch.autograd.Function):
+    """out = relu(S1) or relu(relu(S1) + S2) over the column blocks of y [rows, (n1 + n2) C] (kpf_slices_sum_relu_forward / _backward: one launch each way)."""
+
+    @staticmethod
+    def forward(ctx, y, C_, n1, n2):
+        from . import lib as L
+        yc = y.float().contiguous()
+        rows = yc.shape[0]
+        assert yc.shape[1] == (n1 + n2) * C_
+        out = torch.empty(rows, C_, device=y.device, dtype=torch.float32)
+        L.check(L.load().kpf_slices_sum_relu_forward(yc.data_ptr(), out.data_ptr(), rows, C_, n1, n2, torch.cuda.current_stream().cuda_stream), "kpf_slices_sum_relu_forward")
+        ctx.save_for_backward(yc, out)
+        ctx.meta = (C_, n1, n2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import lib as L
+        yc, out = ctx.saved_tensors
+        C_, n1, n2 = ctx.meta
+        dout = dout.float().contiguous()
+        dy = torch.empty_like(yc)
+        L.check(L.load().kpf_slices_sum_relu_backward(dout.data_ptr(), out.data_ptr(), yc.data_ptr(), dy.data_ptr(), yc.shape[0], C_, n1, n2,
+                                                      torch.cuda.current_stream().cuda_stream), "kpf_slices_sum_relu_backward")
+        return dy, None, None, None
+
+
+def slices_sum_relu(y, C_, n1, n2=0):
+    return SlicesSumRelu.apply(y, C_, n1, n2)
+
+
 class RowGather(torch.autograd.Function):
     """out[b, r] = sum_{g < G} w[b, r, g] * src[b, idx[b, r, g]] over feature rows (fp32): the 4-nearest-pixel sampling of the point
     features (model/model.py:297-306; w = closeness) and DESA's ball-query grouping (model/model.py:174; G = 1, no weights).

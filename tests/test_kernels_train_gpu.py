@@ -1363,7 +1363,8 @@ def test_bert_stack21_dropout_masks_are_consistent_between_forward_and_backward(
 @pytest.mark.parametrize("net", ["convnext-tiny", "resnet-18"])
 def test_grouped_desa_and_fused_stacks_match_the_layer_by_layer_training_graph(net, monkeypatch):
     """Round 6: DESA's three radii as one channel-stacked chain (KPF_DESA_GROUPED: grouped Linears, BatchNorm / ReLU / group maximum over 3 x 128 channels,
-    BallGroup3 / LinearSlices / GroupMax) and the 21-token stacks as one launch each way (KPF_TR_FUSED: BertStack21) against the radius-by-radius, layer-by-layer
+    BallGroup3 / LinearSlices / GroupMax), the sibling point / joint embeddings as one channel-stacked tensor (KPF_EMB_GROUPED: LinearCat, one BatchNorm pass,
+    SlicesSumRelu) and the 21-token stacks as one launch each way (KPF_TR_FUSED: BertStack21) against the radius-by-radius, layer-by-layer
     graph: same outputs, loss, BatchNorm running statistics and gradients of EVERY parameter to fp32 rounding.  (The reference-gradient test runs with given
     ball-query sets, which takes the op-by-op DESA: this test is what pins the grouped form, on the computed sets.)"""
     from conftest import synthetic_sd
@@ -1381,6 +1382,7 @@ def test_grouped_desa_and_fused_stacks_match_the_layer_by_layer_training_graph(n
 
     def run(new):
         monkeypatch.setattr(TG, "DESA_GROUPED", new)
+        monkeypatch.setattr(TG, "EMB_GROUPED", new)
         monkeypatch.setattr(TG, "TR_FUSED", new)
         m = KPFusion(net, "", 21, "dexycb", "")
         m.load_state_dict(synthetic_sd(net), strict=True)
