@@ -631,10 +631,12 @@ long kpf_tr_stack_out_offset(int B);
 long kpf_tr_stack_dy_floats(int B);
 long kpf_tr_stack_part_floats(int B);
 long kpf_tr_stack_offset(int B, int layer, int which);
+/* mma: 0 = fp32 products on v_mfma_f32_16x16x4_f32 (the fp32 step), 1 / 2 = operands rounded to bf16 / f16 in registers, fp32 accumulation (the mixed-precision step:
+ * what torch.autocast does to these Linears); softmax, LayerNorm, GELU, residual sums and everything stored stay fp32. */
 int kpf_tr_stack_train_forward(const float* e, const float* pos, const void* param_table, float* save, long save_floats, int B, float p_drop, const long* rng,
-                               int call0, void* stream);
+                               int call0, int mma, void* stream);
 int kpf_tr_stack_train_backward(const float* dh, const void* param_table, const float* save, float* dE, float* dys, float* parts, int B, float p_drop,
-                                int call0, void* stream);
+                                int call0, int mma, void* stream);
 
 /* Training: the two analytic maps of a fusion block (model/model.py:300-336) with their gradients towards the joints, one launch each:
  * hm[b][j][y][x] = GFM.joint2heatmap(uvd[..., :2], std, F, sigma) (util/generateFeature.py:584-600), duvd [B][J][3] (z component 0);

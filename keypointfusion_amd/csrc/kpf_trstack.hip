@@ -166,7 +166,11 @@ __device__ __forceinline__ void chunk_sync(Sync& s) {
 
 // one 64-deep block of a product: tokens in[t][roff .. roff + 63] times the block in `slot`.  KN = false: out column = block row (forward, W[n][k]);
 // KN = true: out column = block column, reduction over block rows (backward, dX = dY W).
-template <bool KN>
+// MMA: 0 = v_mfma_f32_16x16x4_f32 (exact fp32 products: the fp32 training step and every parity test), 1 / 2 = the operands rounded to bf16 / f16 in registers and ONE
+// v_mfma_f32_16x16x16_{bf16,f16} per 16-deep step, fp32 accumulation — what torch.autocast does to these Linears — for the mixed-precision step: the fp32
+// matrix pipe takes 1024 cycles per block for the two waves of a SIMD (21 tokens padded to 32 rows), which was two thirds of a stack's time.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+template <bool KN, int MMA>
 __device__ __forceinline__ void mma_chunk(const float* in, int ldin, int roff, const float* slot, int tt, int ct, int fr, int fg, f32x4& acc0, f32x4& acc1) {
   const float* ip = in + (tt * 16 + fr) * ldin + roff + 4 * fg;
 #pragma unroll
@@ -183,16 +187,26 @@ __device__ __forceinline__ void mma_chunk(const float* in, int ldin, int roff, c
         b[e] = slot[row * 64 + (((ct * 4 + (fr >> 2)) ^ swz(row)) << 2) + (fr & 3)];
       }
     }
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc0, 0, 0, 0);  // (both operands use k = 16 ks + 4 fg + e: a permutation of the sum)
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc1, 0, 0, 0);
+    if constexpr (MMA == 0) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc0, 0, 0, 0);  // (both operands use k = 16 ks + 4 fg + e: a permutation of the sum)
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc1, 0, 0, 0);
+    } else if constexpr (MMA == 1) {  // lane (l % 16, l / 16) supplies k = 4 (l / 16) .. + 3 of its row / column: exactly the four values it holds
+      const bf16x4 ah = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3]}, bh = {(bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
+      f32x4& acc = (ks & 1) ? acc1 : acc0;
+      acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, ah), __builtin_bit_cast(s16x4, bh), acc, 0, 0, 0);
+    } else {
+      const f16x4 ah = {(f16_t)a[0], (f16_t)a[1], (f16_t)a[2], (f16_t)a[3]}, bh = {(f16_t)b[0], (f16_t)b[1], (f16_t)b[2], (f16_t)b[3]};
+      f32x4& acc = (ks & 1) ? acc1 : acc0;
+      acc = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, acc, 0, 0, 0);
+    }
   }
 }
 
 // nob output blocks of 64 columns, each the sum of nrb 64-deep blocks (schedule order: output block major).  epi(ob, t, col, value) is called for the
 // 21 real tokens; t = token, col = ob * 64 + column within the block.
-template <int NS, bool KN, class Epi>
+template <int NS, bool KN, int MMA, class Epi>
 __device__ __forceinline__ void gemm_op(Sync& s, const float* in, int ldin, int nob, int nrb, Epi&& epi) {
   const int fr = s.lane & 15, fg = s.lane >> 4;
   const int tt = s.wave & 1, ct = (s.wave >> 1) & 3;
@@ -200,7 +214,7 @@ __device__ __forceinline__ void gemm_op(Sync& s, const float* in, int ldin, int 
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     for (int rb = 0; rb < nrb; ++rb) {
       chunk_sync<NS>(s);
-      if (!s.loader) mma_chunk<KN>(in, ldin, rb * 64, s.ring + (s.c % NS) * SLOT, tt, ct, fr, fg, acc0, acc1);
+      if (!s.loader) mma_chunk<KN, MMA>(in, ldin, rb * 64, s.ring + (s.c % NS) * SLOT, tt, ct, fr, fg, acc0, acc1);
       ++s.c;
     }
     if (!s.loader) {
@@ -228,6 +242,7 @@ __device__ __forceinline__ float pv_fetch(const float* const* pl, int i) {
   return pl[P_B2][i - PV_B2];
 }
 
+template <int MMA>
 __global__ __launch_bounds__(NTHR) void tr_stack_fwd_kernel(const float* __restrict__ e, const float* __restrict__ pos, const float* const* __restrict__ P,
                                                           float* __restrict__ save, int B, float p_drop, const long* __restrict__ rng, int call0) {
   constexpr int NS = NSF;
@@ -309,7 +324,7 @@ __global__ __launch_bounds__(NTHR) void tr_stack_fwd_kernel(const float* __restr
     // ---- q | k | v = h W^T + b ----
     {
       float* sq = save + sv.qkv(l);
-      gemm_op<NS, false>(s, Hb, LDA, 6, 2, [&](int, int t, int col, float acc) {
+      gemm_op<NS, false, MMA>(s, Hb, LDA, 6, 2, [&](int, int t, int col, float acc) {
         const float v = acc + PV[PV_BQKV + col];
         QKV[t * LDQ + col] = v;
         sq[(row0 + t) * 384 + col] = v;
@@ -377,7 +392,7 @@ __global__ __launch_bounds__(NTHR) void tr_stack_fwd_kernel(const float* __restr
     TRS_STAMP(l * 8 + 2);
     {
       float* sx = save + sv.xs1(l);
-      gemm_op<NS, false>(s, CTX, LDQ, 2, 2, [&](int, int t, int col, float acc) {
+      gemm_op<NS, false, MMA>(s, CTX, LDQ, 2, 2, [&](int, int t, int col, float acc) {
         const float o = acc + PV[PV_BO + col];
         const long idx = (row0 + t) * H + col;
         const float x = Hb[t * LDA + col] + (dr.keep(call0 + 3 * l + 1, (unsigned)idx) ? o * dr.ks : 0.f);
@@ -419,7 +434,7 @@ __global__ __launch_bounds__(NTHR) void tr_stack_fwd_kernel(const float* __restr
       {
         float* si = save + sv.it(l);
         float* sg = save + sv.g(l);
-        gemm_op<NS, false>(s, Hb, LDA, 1, 2, [&](int, int t, int col, float acc) {
+        gemm_op<NS, false, MMA>(s, Hb, LDA, 1, 2, [&](int, int t, int col, float acc) {
           if (col < FF) {
             const float iv = acc + PV[PV_BI + col];
             const float gv = gelu_exact(iv);
@@ -433,7 +448,7 @@ __global__ __launch_bounds__(NTHR) void tr_stack_fwd_kernel(const float* __restr
       TRS_STAMP(l * 8 + 5);
       {
         float* sx = save + sv.xs2(l);
-        gemm_op<NS, false>(s, IM, LDQ, 2, 1, [&](int, int t, int col, float acc) {
+        gemm_op<NS, false, MMA>(s, IM, LDQ, 2, 1, [&](int, int t, int col, float acc) {
           const float o = acc + PV[PV_BO2 + col];
           const long idx = (row0 + t) * H + col;
           const float x = Hb[t * LDA + col] + (dr.keep(call0 + 3 * l + 2, (unsigned)idx) ? o * dr.ks : 0.f);
@@ -532,6 +547,7 @@ __device__ __forceinline__ void ln_backward(const Sync& s, bool work, const floa
   }
 }
 
+template <int MMA>
 __global__ __launch_bounds__(NTHR) void tr_stack_bwd_kernel(const float* __restrict__ dh, const float* const* __restrict__ P, const float* __restrict__ save,
                                                           float* __restrict__ dE, float* __restrict__ dys, float* __restrict__ parts, int B, float p_drop, int call0) {
   constexpr int NS = NSB;
@@ -624,7 +640,7 @@ __global__ __launch_bounds__(NTHR) void tr_stack_bwd_kernel(const float* __restr
     }                                                                      //  previous layer's last product is behind the barriers of the LayerNorm above)
     // ---- d it = (d o2 . Wo2) * gelu'(it) ----
     TRS_STAMP(32 + (NLAYER - 1 - l) * 8 + 1);
-    gemm_op<NS, true>(s, D2, LDA, 1, 2, [&](int, int t, int col, float acc) {
+    gemm_op<NS, true, MMA>(s, D2, LDA, 1, 2, [&](int, int t, int col, float acc) {
       if (col < FF) {
         const float v = acc * gelu_grad(rit[t & 3]);  // (t = tt * 16 + 4 fg + r: r = t & 3)
         DI[t * LDI + col] = v;
@@ -632,7 +648,7 @@ __global__ __launch_bounds__(NTHR) void tr_stack_bwd_kernel(const float* __restr
       }
     });
     // ---- d h1 += d it . Wi ----
-    gemm_op<NS, true>(s, DI, LDI, 2, 1, [&](int, int t, int col, float acc) { D1[t * LDA + col] += acc; });
+    gemm_op<NS, true, MMA>(s, DI, LDI, 2, 1, [&](int, int t, int col, float acc) { D1[t * LDA + col] += acc; });
     // ---- LayerNorm 1: D1 -> G (d h, residual branch), D2 (d o) ----
     TRS_STAMP(32 + (NLAYER - 1 - l) * 8 + 2);
     ln_backward(s, work, D1, ln1, PV, G, D2, d_o1, part1, SP, row0, dr, call0 + 3 * l + 1);
@@ -640,7 +656,7 @@ __global__ __launch_bounds__(NTHR) void tr_stack_bwd_kernel(const float* __restr
     if (work) dma_rows(s, save + sv.P(l) + (long)b * NH * T * T, 1, NH * T * T, NH * T * T, SP, SPAD);
     // ---- d ctx = d o . Wo -> D1 ----
     TRS_STAMP(32 + (NLAYER - 1 - l) * 8 + 3);
-    gemm_op<NS, true>(s, D2, LDA, 2, 2, [&](int, int t, int col, float acc) { D1[t * LDA + col] = acc; });
+    gemm_op<NS, true, MMA>(s, D2, LDA, 2, 2, [&](int, int t, int col, float acc) { D1[t * LDA + col] = acc; });
     // ---- attention backward (in place on QKV) ----
     TRS_STAMP(32 + (NLAYER - 1 - l) * 8 + 4);
     if (work) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of q | k | v and P has landed in LDS
@@ -739,7 +755,7 @@ __global__ __launch_bounds__(NTHR) void tr_stack_bwd_kernel(const float* __restr
     }
     // ---- d h += d(q | k | v) . [Wq; Wk; Wv] ----
     TRS_STAMP(32 + (NLAYER - 1 - l) * 8 + 5);
-    gemm_op<NS, true>(s, QKV, LDQ, 2, 6, [&](int, int t, int col, float acc) { G[t * LDA + col] += acc; });
+    gemm_op<NS, true, MMA>(s, QKV, LDQ, 2, 6, [&](int, int t, int col, float acc) { G[t * LDA + col] += acc; });
     TRS_STAMP(32 + (NLAYER - 1 - l) * 8 + 6);
     if (work && l > 0 && tid < 2 * H) PV[tid] = pvr;  // (this layer's two LayerNorms are done; the next ln_backward opens with a barrier)
   }
@@ -803,32 +819,36 @@ extern "C" long kpf_tr_stack_offset(int B, int layer, int which) {
 }
 
 extern "C" int kpf_tr_stack_train_forward(const float* e, const float* pos, const void* param_table, float* save, long save_floats, int B, float p_drop,
-                                          const long* rng, int call0, void* stream) {
-  KPF_REQUIRE(e && pos && param_table && save && B > 0, "kpf_tr_stack_train_forward: bad arguments");
+                                          const long* rng, int call0, int mma, void* stream) {
+  KPF_REQUIRE(e && pos && param_table && save && B > 0 && mma >= 0 && mma <= 2, "kpf_tr_stack_train_forward: bad arguments");
   KPF_REQUIRE(save_floats >= kpf_tr_stack_save_floats(B), "kpf_tr_stack_train_forward: save buffer too small");
   KPF_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || rng), "kpf_tr_stack_train_forward: dropout needs 0 <= p < 1 and the rng state");
   KPF_REQUIRE(kpf_aligned16(e) && kpf_aligned16(pos) && kpf_aligned16(save), "kpf_tr_stack_train_forward: e, pos, save must be 16-byte aligned");
-  static std::atomic<bool> lds_opt_in[KPF_MAX_DEVICES];
-  if (!kpf_raise_lds_limit(reinterpret_cast<const void*>(tr_stack_fwd_kernel), lds_opt_in)) {
+  using K = void (*)(const float*, const float*, const float* const*, float*, int, float, const long*, int);
+  const K kern = mma == 0 ? (K)tr_stack_fwd_kernel<0> : (mma == 1 ? (K)tr_stack_fwd_kernel<1> : (K)tr_stack_fwd_kernel<2>);
+  static std::atomic<bool> lds_opt_in[3][KPF_MAX_DEVICES];
+  if (!kpf_raise_lds_limit(reinterpret_cast<const void*>(kern), lds_opt_in[mma])) {
     kpf_set_error("kpf_tr_stack_train_forward: cannot raise the dynamic LDS limit");
     return KPF_ELAUNCH;
   }
-  hipLaunchKernelGGL(tr_stack_fwd_kernel, dim3(B), dim3(NTHR), FWD_LDS, reinterpret_cast<hipStream_t>(stream), e, pos,
-                     static_cast<const float* const*>(param_table), save, B, p_drop, rng, call0);
+  hipLaunchKernelGGL(kern, dim3(B), dim3(NTHR), FWD_LDS, reinterpret_cast<hipStream_t>(stream), e, pos, static_cast<const float* const*>(param_table), save, B, p_drop,
+                     rng, call0);
   return kpf_check_launch("kpf_tr_stack_train_forward");
 }
 
 extern "C" int kpf_tr_stack_train_backward(const float* dh, const void* param_table, const float* save, float* dE, float* dys, float* parts, int B, float p_drop,
-                                           int call0, void* stream) {
-  KPF_REQUIRE(dh && param_table && save && dE && dys && parts && B > 0, "kpf_tr_stack_train_backward: bad arguments");
+                                           int call0, int mma, void* stream) {
+  KPF_REQUIRE(dh && param_table && save && dE && dys && parts && B > 0 && mma >= 0 && mma <= 2, "kpf_tr_stack_train_backward: bad arguments");
   KPF_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "kpf_tr_stack_train_backward: 0 <= p < 1");
   KPF_REQUIRE(kpf_aligned16(dh) && kpf_aligned16(save) && kpf_aligned16(dE) && kpf_aligned16(dys), "kpf_tr_stack_train_backward: dh, save, dE, dys must be 16-byte aligned");
-  static std::atomic<bool> lds_opt_in[KPF_MAX_DEVICES];
-  if (!kpf_raise_lds_limit(reinterpret_cast<const void*>(tr_stack_bwd_kernel), lds_opt_in)) {
+  using K = void (*)(const float*, const float* const*, const float*, float*, float*, float*, int, float, int);
+  const K kern = mma == 0 ? (K)tr_stack_bwd_kernel<0> : (mma == 1 ? (K)tr_stack_bwd_kernel<1> : (K)tr_stack_bwd_kernel<2>);
+  static std::atomic<bool> lds_opt_in[3][KPF_MAX_DEVICES];
+  if (!kpf_raise_lds_limit(reinterpret_cast<const void*>(kern), lds_opt_in[mma])) {
     kpf_set_error("kpf_tr_stack_train_backward: cannot raise the dynamic LDS limit");
     return KPF_ELAUNCH;
   }
-  hipLaunchKernelGGL(tr_stack_bwd_kernel, dim3(B), dim3(NTHR), BWD_LDS, reinterpret_cast<hipStream_t>(stream), dh, static_cast<const float* const*>(param_table),
-                     save, dE, dys, parts, B, p_drop, call0);
+  hipLaunchKernelGGL(kern, dim3(B), dim3(NTHR), BWD_LDS, reinterpret_cast<hipStream_t>(stream), dh, static_cast<const float* const*>(param_table), save, dE, dys, parts,
+                     B, p_drop, call0);
   return kpf_check_launch("kpf_tr_stack_train_backward");
 }

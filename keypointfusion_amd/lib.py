@@ -156,8 +156,8 @@ _SIGS = {
     "kpf_ln_train_backward_partial": [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, C.c_long, C.c_long, C.c_int, C.POINTER(ColsumDesc), _P],
     "kpf_colsum_reduce_grouped": [C.POINTER(ColsumDesc), C.c_int, _P],
     "kpf_tr_stack_set_stamps": [_P],
-    "kpf_tr_stack_train_forward": [_P, _P, _P, _P, C.c_long, C.c_int, C.c_float, _P, C.c_int, _P],
-    "kpf_tr_stack_train_backward": [_P, _P, _P, _P, _P, _P, C.c_int, C.c_float, C.c_int, _P],
+    "kpf_tr_stack_train_forward": [_P, _P, _P, _P, C.c_long, C.c_int, C.c_float, _P, C.c_int, C.c_int, _P],
+    "kpf_tr_stack_train_backward": [_P, _P, _P, _P, _P, _P, C.c_int, C.c_float, C.c_int, C.c_int, _P],
     "kpf_bmm_small_k_dx": [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
     "kpf_bmm_small_k_fwd": [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
     "kpf_bmm_small_k_da": [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],

@@ -43,6 +43,7 @@ _N_STREAMS = int(os.environ.get("KPF_TRAIN_STREAMS", "2"))  # 2: the RGB backbon
 PAIR_BACKBONES = bool(int(os.environ.get("KPF_TRAIN_PAIR", "1")))
 # 1 (default): the four BERT layers of a 21-token stack as ONE launch each way (training.BertStack21, csrc/kpf_trstack.hip); 0: layer by layer (bert_layer)
 TR_FUSED = bool(int(os.environ.get("KPF_TR_FUSED", "1")))
+TR_MMA = os.environ.get("KPF_TR_MMA", "auto")  # GEMM arithmetic of the fused stacks: "auto" = the module's precision; "f32" | "bf16" | "f16" force one
 # 1 (default): DESA's three radii as ONE channel-stacked chain — grouped Linears (G = 3), BatchNorm / add + ReLU / group maximum over 3 x 128 channels, one
 # grouping launch each way (training.BallGroup3 / LinearSlices / GroupMax) — instead of three chains of small launches; 0: radius by radius
 DESA_GROUPED = bool(int(os.environ.get("KPF_DESA_GROUPED", "1")))
@@ -532,8 +533,10 @@ class TrainGraph:
             names = [p + ".bert.encoder.layer.%d.%s" % (l, k) for l in range(4) for k in BertStack21.ORDER]
             call0 = self.attn_calls + 1
             self.attn_calls += 13
+            # (mixed precision: the stack's products take 16-bit operands like the backbones' — what autocast gives the reference's Linears; KPF_TR_MMA=f32 keeps fp32)
+            mma = getattr(self.m, "precision", "f32") if TR_MMA == "auto" else TR_MMA
             h = bert_stack21(e, PrefixRows.apply(self.t[p + ".bert.position_embeddings.weight"], T), names, self.packs, self.pd, self.rng(x.device), call0,
-                             [self.t[n] for n in names])
+                             [self.t[n] for n in names], mma)
         else:
             h = self.linear(x, p + ".bert.img_embedding.weight", p + ".bert.img_embedding.bias") + PrefixRows.apply(self.t[p + ".bert.position_embeddings.weight"], T)
             h = self.drop(h)  # TR_Encoder applies the embedding dropout (model/model.py:84)

@@ -1526,7 +1526,7 @@ class BertStack21(torch.autograd.Function):
         return t
 
     @staticmethod
-    def forward(ctx, e, pos, names, cache, p_drop, rng, call0, *params):
+    def forward(ctx, e, pos, names, cache, p_drop, rng, call0, mma, *params):
         from . import lib as L
         lib = L.load()
         B, T, Cc = e.shape
@@ -1536,10 +1536,10 @@ class BertStack21(torch.autograd.Function):
         n = lib.kpf_tr_stack_save_floats(B)
         save = torch.empty(n, device=e.device, dtype=torch.float32)
         L.check(lib.kpf_tr_stack_train_forward(ec.data_ptr(), pc.data_ptr(), table.data_ptr(), save.data_ptr(), n, B, float(p_drop),
-                                               rng.data_ptr() if (rng is not None and p_drop > 0) else None, int(call0), torch.cuda.current_stream().cuda_stream),
+                                               rng.data_ptr() if (rng is not None and p_drop > 0) else None, int(call0), int(mma), torch.cuda.current_stream().cuda_stream),
                 "kpf_tr_stack_train_forward")
         ctx.save_for_backward(save, table, *params)
-        ctx.conf = (names, cache, float(p_drop), int(call0), B)
+        ctx.conf = (names, cache, float(p_drop), int(call0), B, int(mma))
         off = lib.kpf_tr_stack_out_offset(B)
         return save[off:off + B * T * Cc].view(B, T, Cc)
 
@@ -1548,14 +1548,14 @@ class BertStack21(torch.autograd.Function):
         from . import lib as L
         lib = L.load()
         save, table, *params = ctx.saved_tensors
-        names, cache, p_drop, call0, B = ctx.conf
+        names, cache, p_drop, call0, B, mma = ctx.conf
         M, dev = B * 21, save.device
         st = torch.cuda.current_stream().cuda_stream
         dh = dh.float().contiguous()
         dE = torch.empty(B, 21, 128, device=dev, dtype=torch.float32)
         dys = torch.empty(lib.kpf_tr_stack_dy_floats(B), device=dev, dtype=torch.float32)
         parts = torch.empty(lib.kpf_tr_stack_part_floats(B), device=dev, dtype=torch.float32)
-        L.check(lib.kpf_tr_stack_train_backward(dh.data_ptr(), table.data_ptr(), save.data_ptr(), dE.data_ptr(), dys.data_ptr(), parts.data_ptr(), B, p_drop, call0, st),
+        L.check(lib.kpf_tr_stack_train_backward(dh.data_ptr(), table.data_ptr(), save.data_ptr(), dE.data_ptr(), dys.data_ptr(), parts.data_ptr(), B, p_drop, call0, mma, st),
                 "kpf_tr_stack_train_backward")
         grads = [None] * 64
         now_w, now_c = [], []  # gradients that are not deferred: one grouped launch each, right here
@@ -1601,11 +1601,15 @@ class BertStack21(torch.autograd.Function):
             arr = (L.ColsumDesc * len(now_c))(*now_c)
             L.check(lib.kpf_colsum_reduce_grouped(arr, len(now_c), st), "kpf_colsum_reduce_grouped")
         dpos = dE.sum(0) if ctx.needs_input_grad[1] else None
-        return (dE, dpos, None, None, None, None, None) + tuple(grads)
+        return (dE, dpos, None, None, None, None, None, None) + tuple(grads)
 
 
-def bert_stack21(e, pos, names, cache, p_drop, rng, call0, params):
-    return BertStack21.apply(e, pos, tuple(names), cache, p_drop, rng, call0, *params)
+MMA_MODE = {"f32": 0, "bf16": 1, "f16": 2}
+
+
+def bert_stack21(e, pos, names, cache, p_drop, rng, call0, params, prec="f32"):
+    """prec: the GEMM arithmetic of the stack — "f32" exact fp32 products, "bf16" / "f16" operands rounded in registers, fp32 accumulation (the mixed-precision step)."""
+    return BertStack21.apply(e, pos, tuple(names), cache, p_drop, rng, call0, MMA_MODE[prec], *params)
 
 
 class DropAddLN(torch.autograd.Function):

@@ -1318,6 +1318,39 @@ def test_bert_stack21_forward_backward_match_fp64_torch(B):
         assert err < 2e-4, "gradient %d (%s): relative error %.2e" % (i, "e pos".split()[i] if i < 2 else names[i - 2], err)
 
 
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+def test_bert_stack21_16bit_products_stay_close_to_the_fp32_stack(prec):
+    """The mixed-precision form of the fused stacks (operands of every product rounded to bf16 / f16 in registers, fp32 accumulation, everything else fp32):
+    output and gradients within a few 16-bit ulps (times the depth of the stack) of the fp32 form on the same operands, bit-identical between two calls."""
+    from keypointfusion_amd import training as T
+    dev = torch.device("cuda:0")
+    B = 8
+    gen = torch.Generator().manual_seed(11)
+    prm = _bert_stack_params(gen, dev)
+    e = torch.randn(B, 21, 128, generator=gen).to(dev).requires_grad_(True)
+    pos = (0.5 * torch.randn(21, 128, generator=gen)).to(dev).requires_grad_(True)
+    names = ["stack.%d.%s" % (l, k) for l in range(4) for k in T.BertStack21.ORDER]
+    wsum = torch.randn(B, 21, 128, generator=gen).to(dev)
+
+    def run(p):
+        for t in [e, pos] + prm:
+            t.grad = None
+        out = T.bert_stack21(e, pos, names, None, 0.0, None, 1, prm, p)
+        (out * wsum).sum().backward()
+        return out.detach().clone(), [t.grad.detach().clone() for t in [e, pos] + prm]
+
+    o32, g32 = run("f32")
+    o16, g16 = run(prec)
+    o16b, g16b = run(prec)
+    assert torch.equal(o16, o16b) and all(torch.equal(a, c) for a, c in zip(g16, g16b))
+    ulp = 2.0 ** -8 if prec == "bf16" else 2.0 ** -11
+    rel = lambda a, c: float((a - c).norm() / (c.norm() + 1e-12))
+    assert 1e-6 < rel(o16, o32) < 40 * ulp, rel(o16, o32)  # (not the fp32 kernel by accident; within the rounding of ~25 chained products)
+    errs = sorted(rel(a, c) for i, (a, c) in enumerate(zip(g16, g32)) if not (i >= 2 and names[i - 2].endswith("key.bias")))
+    print("fused stack %s vs fp32: output %.2e, gradients median %.2e max %.2e" % (prec, rel(o16, o32), errs[len(errs) // 2], errs[-1]))
+    assert errs[len(errs) // 2] < 60 * ulp and errs[-1] < 400 * ulp, (errs[len(errs) // 2], errs[-1])
+
+
 def test_bert_stack21_dropout_masks_are_consistent_between_forward_and_backward():
     """p = 0.1: (a) about a tenth of H[0] = dropout(e + pos) is zero and the rest is scaled by 1 / 0.9; (b) the same (seed, counter) gives the same bits, another
     counter another mask; (c) the backward uses the forward's masks: a directional derivative of sum(out * w) along random directions in e and in two weights

@@ -1,11 +1,12 @@
 """GPU box: in-kernel wall-clock stamps of the fused 21-token stack kernels (csrc/kpf_trstack.hip, workgroup 0): where a stack's time goes, phase by phase.
-usage: python tools/trstack_stamps.py [B]"""
+usage: python tools/trstack_stamps.py [B] [f32|bf16|f16]"""
 import os, sys
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests")
 import torch
 from keypointfusion_amd import lib as L, training as T
 from test_kernels_train_gpu import _bert_stack_params
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+PREC = sys.argv[2] if len(sys.argv) > 2 else "f32"
 dev = torch.device("cuda:0")
 gen = torch.Generator().manual_seed(0)
 prm = _bert_stack_params(gen, dev)
@@ -17,7 +18,7 @@ st = torch.zeros(64, dtype=torch.int64, device=dev)
 lib = L.load()
 for it in range(3):
     L.check(lib.kpf_tr_stack_set_stamps(st.data_ptr() if it == 2 else None))
-    out = T.bert_stack21(e, pos, names, None, 0.1, rng, 1, prm)
+    out = T.bert_stack21(e, pos, names, None, 0.1, rng, 1, prm, PREC)
     out.sum().backward()
     torch.cuda.synchronize()
 L.check(lib.kpf_tr_stack_set_stamps(None))
