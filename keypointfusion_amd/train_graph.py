@@ -406,7 +406,7 @@ class TrainGraph:
         B, C = feat.shape[:2]
         N, K = idx.shape[1:]
         rows = feat.permute(0, 2, 3, 1).reshape(B, -1, C)
-        return row_gather(rows.float(), idx.int(), clos, inv)  # (C % 4 != 0 — the 21 weight-logit channels, detached by the caller — and
+        return row_gather(rows.float(), idx if idx.dtype == torch.int32 else idx.int(), clos, inv)  # (C % 4 != 0 — the 21 weight-logit channels, detached by the caller — and
         #                                                    shapes beyond the backward kernel's limits: torch.gather inside row_gather)
 
     @staticmethod
@@ -677,7 +677,7 @@ class TrainGraph:
         self.img_xyz = torch.empty(B, Fs * Fs, 3, device=dev)
         L.check(lib.kpf_img2pcl_top4_f32(_ptr(pcl), _ptr(img), _ptr(center), _ptr(Minv), _ptr(cube), _ptr(cam), _ptr(clos), _ptr(index), _ptr(self.img_xyz),
                                          B, N, S, Fs, int(img_size), int(flip), _stream()), "kpf_img2pcl_top4_f32")
-        idx = index.long()
+        idx = index  # (int32, as kpf_img2pcl_top4_f32 wrote it: the gather kernels read it as it is — six casts per iteration fewer)
         self.par16 = torch.cat((Minv.reshape(B, 9)[:, :6], cam.reshape(B, -1)[:, :4], center.reshape(B, 3), cube.reshape(B, 3)), 1)  # GeomGateUVD's per-sample numbers
         from .training import pad_rows
         self.pcl4 = pad_rows(pcl, 4)                                         # the points at the width pcl_xyz_emb's GEMM reads (both blocks)

@@ -54,13 +54,20 @@ fi
 cd $ROOT
 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 if [ "$MODE" != quick ]; then
-  for W in full128 full128_bf16 cnb512_f16 train128 train128_bf16 train128_f16 full256; do
+  for W in full128 full128_bf16 full128_f16 cnb512_f16 train128 train128_bf16 train128_f16 full256; do
     python3 bench.py --workload $W --no-cpu-baseline --no-extra > $OUT/${TAG}_bench_$W.json 2> $OUT/${TAG}_bench_$W.err
   done
   python3 tools/shape_table.py > $OUT/${TAG}_shape_table.txt 2>/dev/null
   python3 tools/shape_table.py 64 512 f16 KPFusion-convnext-base > $OUT/${TAG}_shape_cnb512.txt 2>/dev/null
   python3 tools/shape_table.py 32 128 bf16 > $OUT/${TAG}_shape_full128_bf16.txt 2>/dev/null
 fi
+# configs[2]: one synchronised forward at a time, cut out of a kernel trace (what bounds the single-batch latency)
+cd /tmp
+rm -rf /tmp/pl_$TAG
+rocprofv3 --kernel-trace --output-format csv -d /tmp/pl_$TAG -- python3 $ROOT/bench.py --workload full128_bf16 --no-cpu-baseline --no-extra --steps 10 --warmup 3 > /dev/null 2>&1
+python3 $ROOT/tools/latency_segments.py /tmp/pl_$TAG $OUT/${TAG}_full128_bf16_latency_segments.txt
+rm -rf /tmp/pl_$TAG
+cd $ROOT
 # keep the merge small: the raw traces stay on the box
 for d in $OUT/prof_${TAG}_*; do [ -d "$d" ] && rm -rf "$d"; done
 ls -la $OUT | grep ${TAG}_
