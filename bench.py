@@ -21,7 +21,7 @@ One JSON line is printed by rank 0 with, besides the contract fields:
                  launches in one step / summed device time of those launches (HIP events recorded on the launch stream in an
                  instrumented pass after the timed region, both backbones on ONE stream), against the dense f32-input MFMA peak
                  157.3 TFLOP/s.  `traffic` = HBM bytes per launch from the rocprofv3 PMC passes of this same command, collected
-                 offline and committed (profiles/r05_traffic*.json, tools/collect_traffic.py): `traffic_source` says so; a figure
+                 offline and committed (profiles/r06_traffic*.json, tools/collect_traffic.py): `traffic_source` says so; a figure
                  below 0.9 x the algorithmic bytes, or one whose launch count is not a whole number of this run's steps, is refused
                  (`traffic: null` + `traffic_rejected`).
   split_f16x3  : SECONDARY record, not the headline and not IEEE fp32: the same workload with KPF_GEMM=split (the ConvNeXt-block GEMMs
@@ -73,7 +73,7 @@ WORKLOADS = {
 
 
 # committed PMC traffic figures (tools/profile_round.sh -> tools/collect_traffic.py), per workload; quoted only for the stated batch
-TRAFFIC_FILES = {"backbones256": "r05_traffic.json", "cnb512_f16": "r05_traffic_cnb512.json", "full128_bf16": "r05_traffic_full128_bf16.json"}
+TRAFFIC_FILES = {"backbones256": "r06_traffic.json", "cnb512_f16": "r06_traffic_cnb512.json", "full128_bf16": "r06_traffic_full128_bf16.json"}
 NO_TRAFFIC_REASON = {"train128_bf16": "rocprofv3 --pmc does not complete on the training iteration on this pool (segmentation fault in the FETCH_SIZE pass, no return from "
                                       "the WRITE_SIZE pass within 40 min: tools/profile_round.sh, round 5)"}
 

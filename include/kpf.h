@@ -435,7 +435,8 @@ int kpf_ball_group_bwd_f32(const float* d3, int ld3, const int* start, const int
 int kpf_slices_sum_relu_forward(const float* y, float* out, long rows, int C, int n1, int n2, void* stream);
 int kpf_slices_sum_relu_backward(const float* dout, const float* out, const float* y, float* dy, long rows, int C, int n1, int n2, void* stream);
 int kpf_group_max_train_forward(const float* x, float* y, unsigned char* arg, long rows, int group, int C, void* stream);
-int kpf_group_max_train_backward(const float* dy, const unsigned char* arg, float* dx, long rows, int group, int C, void* stream);
+int kpf_group_max_train_backward(const float* dy, int dy_ld /* floats between rows of dy: it may be a column slice of a wider matrix */, const unsigned char* arg, float* dx,
+                                 long rows, int group, int C, void* stream);
 long kpf_ln_ws_floats(long rows, int C);
 int kpf_ln_train_forward(const float* x, const float* w, const float* b, void* y, int y_dtype, float* mean, float* rstd, long rows, int C, float eps,
                          void* stream);
@@ -625,6 +626,20 @@ int kpf_colsum_reduce_grouped(const kpf_colsum_desc* descs, int n, void* stream)
  *             kpf_linear_wgrad_grouped; LayerNorm parameter gradients leave as per-sample partial sums parts[layer][ln][B][2][128]
  *             (kpf_tr_stack_part_floats(B); a kpf_colsum_desc with nblk = B, C = 128 each).  Dropout masks are recomputed from the (seed, counter) the
  *             forward stored in `save`.  Fixed summation order: bit-identical replays. */
+/* Training (ABI 16): the decoder layer of the fusion block (updatedDecoder layer 3, model/transfusion_head.py:137-173, 437-554: cross attention of 21 query tokens over 21
+ * key tokens, post-LN eps 1e-5, ReLU feed-forward of width 128, dropout) as one launch each way on the engine of kpf_tr_stack_train_*.  query / key [B][21][128];
+ * param_table: DEVICE array of 14 pointers — in_proj_weight [384][128], in_proj_bias, out_proj.weight, out_proj.bias, norm2.weight, norm2.bias, linear1.weight, linear1.bias,
+ * linear2.weight, linear2.bias, norm3.weight, norm3.bias, self_posembed [21][128], cross_posembed [21][128]; the output is save + kpf_xattn_train_offset(B, 5).
+ * backward: dquery (both paths), dqe / dke = gradients of query + qpos / key + kpos (dkey = dke; the position tables' gradients are their sums over B); dys
+ * (kpf_xattn_train_dy_floats) receives dqkv [M][384] | d out_proj [M][128] | d linear1 | d linear2 for the weight gradients (X operands: kpf_xattn_train_offset
+ * 0 qe, 1 ke, 2 ctx, 3 x, 4 hidden); parts [2][B][2][128] the LayerNorm partial sums (norm2, norm3).  call0: first of 4 consecutive dropout call ids; mma as above. */
+long kpf_xattn_train_save_floats(int B);
+long kpf_xattn_train_dy_floats(int B);
+long kpf_xattn_train_offset(int B, int which);
+int kpf_xattn_train_forward(const float* query, const float* key, const void* param_table, float* save, long save_floats, int B, float p_drop, const long* rng,
+                            int call0, int mma, void* stream);
+int kpf_xattn_train_backward(const float* dout, const void* param_table, const float* save, float* dquery, float* dqe, float* dke, float* dys, float* parts, int B,
+                             float p_drop, int call0, int mma, void* stream);
 int kpf_tr_stack_set_stamps(void* stamps64 /* tuning aid: 64 device uint64 slots for in-kernel wall-clock stamps of workgroup 0; NULL = off */);
 long kpf_tr_stack_save_floats(int B);
 long kpf_tr_stack_out_offset(int B);

@@ -2280,14 +2280,14 @@ __global__ __launch_bounds__(256) void group_max_train_fwd_kernel(const float* _
     *reinterpret_cast<uchar4*>(arg + i * 4) = uchar4{(unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2], (unsigned char)bi[3]};
   }
 }
-__global__ __launch_bounds__(256) void group_max_train_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg, float* __restrict__ dx,
-                                                                  long n4, int group, int C4) {
+__global__ __launch_bounds__(256) void group_max_train_bwd_kernel(const float* __restrict__ dy, int dy_ld4, const unsigned char* __restrict__ arg,
+                                                                  float* __restrict__ dx, long n4, int group, int C4) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {  // i over [rows][group][C4]
     const int q = (int)(i % C4);
     const long rm = i / C4;
     const int m = (int)(rm % group);
     const long r = rm / group;
-    const f32x4 g = kpf_ld4(dy + (r * C4 + q) * 4);
+    const f32x4 g = kpf_ld4(dy + (r * dy_ld4 + q) * 4);  // (dy may be a column slice of a wider matrix: the concatenation behind the maximum)
     const uchar4 a = *reinterpret_cast<const uchar4*>(arg + (r * C4 + q) * 4);
     kpf_st4(dx + i * 4, f32x4{a.x == m ? g[0] : 0.f, a.y == m ? g[1] : 0.f, a.z == m ? g[2] : 0.f, a.w == m ? g[3] : 0.f});
   }
@@ -2309,10 +2309,11 @@ extern "C" int kpf_group_max_train_forward(const float* x, float* y, unsigned ch
   hipLaunchKernelGGL(group_max_train_fwd_kernel, dim3(grid_for(n4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, y, arg, n4, group, C / 4);
   return kpf_check_launch("kpf_group_max_train_forward");
 }
-extern "C" int kpf_group_max_train_backward(const float* dy, const unsigned char* arg, float* dx, long rows, int group, int C, void* stream) {
-  KPF_REQUIRE(dy && arg && dx && rows > 0 && group > 0 && group <= 256 && C > 0 && C % 4 == 0, "kpf_group_max_train_backward: bad arguments");
+extern "C" int kpf_group_max_train_backward(const float* dy, int dy_ld, const unsigned char* arg, float* dx, long rows, int group, int C, void* stream) {
+  KPF_REQUIRE(dy && arg && dx && rows > 0 && group > 0 && group <= 256 && C > 0 && C % 4 == 0 && dy_ld >= C && dy_ld % 4 == 0 && kpf_aligned16(dy),
+              "kpf_group_max_train_backward: bad arguments");
   const long n4 = rows * group * (C / 4);
-  hipLaunchKernelGGL(group_max_train_bwd_kernel, dim3(grid_for(n4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, arg, dx, n4, group, C / 4);
+  hipLaunchKernelGGL(group_max_train_bwd_kernel, dim3(grid_for(n4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, dy_ld / 4, arg, dx, n4, group, C / 4);
   return kpf_check_launch("kpf_group_max_train_backward");
 }
 

@@ -57,6 +57,7 @@ __device__ __attribute__((aligned(16))) float kpf_trs_zero16[4] = {0.f, 0.f, 0.f
 
 // tuning aid: wall-clock stamps (100 MHz) of workgroup 0's thread 0 at phase boundaries, into a buffer set by kpf_tr_stack_set_stamps (NULL = off, the default)
 __device__ unsigned long long* kpf_trs_stamps = nullptr;
+__device__ int kpf_trs_dbg = 0;  // tuning aid (kpf_tr_stack_set_stamps' second argument): 1 = the loaders issue no DMA, 2 = the consumers skip the products
 #define TRS_STAMP(i)                                                                                         \
   do {                                                                                                       \
     if (kpf_trs_stamps && blockIdx.x == 0 && threadIdx.x == 0) kpf_trs_stamps[(i)] = wall_clock64();         \
@@ -127,7 +128,9 @@ struct Sync {
   float* ring;
   const Chunk* sched;
   const float* zero;
-  int c;  // next block of the schedule
+  int ntotal;  // blocks in the schedule
+  int c;       // next block of the schedule
+  int dbg;
   int lane, wave;
   bool loader;
 };
@@ -153,7 +156,7 @@ template <int NS>
 __device__ __forceinline__ void chunk_sync(Sync& s) {
   static_assert(NS >= 3 && NS <= 6, "vmcnt immediates below");
   if (s.loader) {
-    const int younger = min(NCHUNK - 1 - s.c, NS - 2);  // blocks issued after s.c so far: four DMA instructions per loader wave each
+    const int younger = min(s.ntotal - 1 - s.c, NS - 2);  // blocks issued after s.c so far: four DMA instructions per loader wave each
     if (younger >= 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if (younger == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -161,7 +164,7 @@ __device__ __forceinline__ void chunk_sync(Sync& s) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   BAR();  // block s.c has landed for everyone; every consumer is done with block s.c - 1
-  if (s.loader && s.c + NS - 1 < NCHUNK) issue_chunk<NS>(s, s.c + NS - 1);
+  if (s.loader && s.c + NS - 1 < s.ntotal && !(s.dbg & 1)) issue_chunk<NS>(s, s.c + NS - 1);
 }
 
 // one 64-deep block of a product: tokens in[t][roff .. roff + 63] times the block in `slot`.  KN = false: out column = block row (forward, W[n][k]);
@@ -214,7 +217,7 @@ __device__ __forceinline__ void gemm_op(Sync& s, const float* in, int ldin, int 
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     for (int rb = 0; rb < nrb; ++rb) {
       chunk_sync<NS>(s);
-      if (!s.loader) mma_chunk<KN, MMA>(in, ldin, rb * 64, s.ring + (s.c % NS) * SLOT, tt, ct, fr, fg, acc0, acc1);
+      if (!s.loader && !(s.dbg & 2)) mma_chunk<KN, MMA>(in, ldin, rb * 64, s.ring + (s.c % NS) * SLOT, tt, ct, fr, fg, acc0, acc1);
       ++s.c;
     }
     if (!s.loader) {
@@ -223,6 +226,69 @@ __device__ __forceinline__ void gemm_op(Sync& s, const float* in, int ldin, int 
         const int t = tt * 16 + 4 * fg + r;
         if (t < T) epi(ob, t, ob * 64 + ct * 16 + fr, acc0[r] + acc1[r]);
       }
+    }
+  }
+}
+
+// The attention core of one sample, all four heads, on the consumer waves (every wave of the workgroup calls it: the barriers are the workgroup's):
+// S = q k^T / sqrt(32) -> row softmax (saved to Pg, before dropout) -> dropout -> ctx = S v, written to `ctx` (LDS, row stride ldc) and to ctx_g (HBM rows of 128).
+// q | k | v are the column blocks of QKV [T][LDQ]; element numbering of the dropout hash = the unfused kernel's ((b * 4 + h) * 441 + i * 21 + j).
+__device__ __forceinline__ void attention_forward(const Sync& s, bool work, const float* QKV, float* S, float* ctx, int ldc, float* __restrict__ Pg,
+                                                  float* __restrict__ ctx_g, int b, long row0, const Drop& dr, int call) {
+  const int tid = threadIdx.x;
+  BAR();
+  if (work) {
+    for (int item = tid; item < NH * T * T; item += NCT) {
+      const int h = item / (T * T), r = item - h * T * T, i = r / T, j = r - i * T;
+      const float* qp = QKV + i * LDQ + h * HD;
+      const float* kp = QKV + j * LDQ + H + h * HD;
+      float a = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; d += 4) {
+        const f32x4 qv = *reinterpret_cast<const f32x4*>(qp + d), kv = *reinterpret_cast<const f32x4*>(kp + d);
+        a = fmaf(qv[0], kv[0], a);
+        a = fmaf(qv[1], kv[1], a);
+        a = fmaf(qv[2], kv[2], a);
+        a = fmaf(qv[3], kv[3], a);
+      }
+      S[item] = a * 0.17677669529663687f;
+    }
+  }
+  BAR();
+  if (work && tid < NH * T) {
+    float* sp = S + tid * T;
+    float mx = -INFINITY;
+    for (int j = 0; j < T; ++j) mx = fmaxf(mx, sp[j]);
+    float se = 0.f;
+    for (int j = 0; j < T; ++j) {
+      const float ev = __expf(sp[j] - mx);
+      sp[j] = ev;
+      se += ev;
+    }
+    const float inv = 1.0f / se;
+    const long pbase = ((long)b * NH + tid / T) * (T * T) + (tid % T) * T;  // element index of (b, h, i, 0): the unfused kernel's numbering
+    float* pg = Pg + pbase;
+    for (int j = 0; j < T; ++j) {
+      const float pv = sp[j] * inv;
+      pg[j] = pv;
+      sp[j] = dr.keep(call, (unsigned)(pbase + j)) ? pv * dr.ks : 0.f;
+    }
+  }
+  BAR();
+  if (work) {  // (q and k are dead: the context may go to their columns)
+    for (int item = tid; item < T * (H / 4); item += NCT) {
+      const int i = item >> 5, c = (item & 31) * 4, h = c / HD;
+      const float* sp = S + (h * T + i) * T;
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 3
+      for (int j = 0; j < T; ++j) {
+        const float pj = sp[j];
+        const f32x4 vv = *reinterpret_cast<const f32x4*>(QKV + j * LDQ + 2 * H + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = fmaf(pj, vv[k], a[k]);
+      }
+      *reinterpret_cast<f32x4*>(ctx + i * ldc + c) = a;
+      kpf_st4(ctx_g + (row0 + i) * H + c, a);
     }
   }
 }
@@ -265,6 +331,8 @@ __global__ __launch_bounds__(NTHR) void tr_stack_fwd_kernel(const float* __restr
   s.sched = sched;
   s.zero = kpf_trs_zero16;
   s.c = 0;
+  s.ntotal = NCHUNK;
+  s.dbg = kpf_trs_dbg;
   const bool work = !s.loader;
   const int b = blockIdx.x;
   Save sv;
@@ -312,7 +380,8 @@ __global__ __launch_bounds__(NTHR) void tr_stack_fwd_kernel(const float* __restr
   }
   BAR();  // schedule, parameter vectors and H[0] visible
   if (s.loader)
-    for (int n = 0; n < NS - 1; ++n) issue_chunk<NS>(s, n);
+    for (int n = 0; n < NS - 1; ++n)
+      if (!(s.dbg & 1)) issue_chunk<NS>(s, n);
 
   for (int l = 0; l < NLAYER; ++l) {
     TRS_STAMP(l * 8 + 0);
@@ -331,63 +400,8 @@ __global__ __launch_bounds__(NTHR) void tr_stack_fwd_kernel(const float* __restr
       });
     }
     // ---- attention core: softmax(q k^T / sqrt(32)) -> dropout -> . v ----
-    BAR();
     TRS_STAMP(l * 8 + 1);
-    if (work) {
-      for (int item = tid; item < NH * T * T; item += NCT) {
-        const int h = item / (T * T), r = item - h * T * T, i = r / T, j = r - i * T;
-        const float* qp = QKV + i * LDQ + h * HD;
-        const float* kp = QKV + j * LDQ + H + h * HD;
-        float a = 0.f;
-#pragma unroll
-        for (int d = 0; d < HD; d += 4) {
-          const f32x4 qv = *reinterpret_cast<const f32x4*>(qp + d), kv = *reinterpret_cast<const f32x4*>(kp + d);
-          a = fmaf(qv[0], kv[0], a);
-          a = fmaf(qv[1], kv[1], a);
-          a = fmaf(qv[2], kv[2], a);
-          a = fmaf(qv[3], kv[3], a);
-        }
-        S[item] = a * 0.17677669529663687f;
-      }
-    }
-    BAR();
-    if (work && tid < NH * T) {
-      float* sp = S + tid * T;
-      float mx = -INFINITY;
-      for (int j = 0; j < T; ++j) mx = fmaxf(mx, sp[j]);
-      float se = 0.f;
-      for (int j = 0; j < T; ++j) {
-        const float ev = __expf(sp[j] - mx);
-        sp[j] = ev;
-        se += ev;
-      }
-      const float inv = 1.0f / se;
-      const long pbase = ((long)b * NH + tid / T) * (T * T) + (tid % T) * T;  // element index of (b, h, i, 0): the unfused kernel's numbering
-      float* pg = save + sv.P(l) + pbase;
-      for (int j = 0; j < T; ++j) {
-        const float pv = sp[j] * inv;
-        pg[j] = pv;
-        sp[j] = dr.keep(call0 + 3 * l, (unsigned)(pbase + j)) ? pv * dr.ks : 0.f;
-      }
-    }
-    BAR();
-    if (work) {  // (q and k are dead: the context goes to the k columns)
-      float* sc = save + sv.ctx(l);
-      for (int item = tid; item < T * (H / 4); item += NCT) {
-        const int i = item >> 5, c = (item & 31) * 4, h = c / HD;
-        const float* sp = S + (h * T + i) * T;
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 3
-        for (int j = 0; j < T; ++j) {
-          const float pj = sp[j];
-          const f32x4 vv = *reinterpret_cast<const f32x4*>(QKV + j * LDQ + 2 * H + c);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) a[k] = fmaf(pj, vv[k], a[k]);
-        }
-        *reinterpret_cast<f32x4*>(CTX + i * LDQ + c) = a;
-        kpf_st4(sc + (row0 + i) * H + c, a);
-      }
-    }
+    attention_forward(s, work, QKV, S, CTX, LDQ, save + sv.P(l), save + sv.ctx(l), b, row0, dr, call0 + 3 * l);
     // ---- xs1 = h + dropout(ctx Wo^T + bo)  (into the q columns) ----
     TRS_STAMP(l * 8 + 2);
     {
@@ -547,6 +561,104 @@ __device__ __forceinline__ void ln_backward(const Sync& s, bool work, const floa
   }
 }
 
+// Backward of attention_forward for one sample, in place: on entry QKV holds q | k | v and SP the saved probabilities (both brought in by the caller's
+// LDS-DMA: this function waits for the calling wave's share), dctx the context's gradient (LDS, row stride ldd); on exit QKV holds dq | dk | dv, also stored to
+// dqkv_g (HBM rows of 384).  SP's sign carries the dropout decision after the first phase.
+__device__ __forceinline__ void attention_backward(const Sync& s, bool work, float* QKV, float* SP, float* SD, const float* dctx, int ldd,
+                                                   float* __restrict__ dqkv_g, int b, long row0, const Drop& dr, int call) {
+  const int tid = threadIdx.x;
+  if (work) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of q | k | v and P has landed in LDS
+  BAR();
+  if (work) {  // dP' = d ctx V^T; SD = dP' * keep / (1 - p); SP <- +-P (sign: kept / dropped)
+    const long pb0 = (long)b * NH * T * T;
+    for (int item = tid; item < NH * T * T; item += NCT) {
+      const int h = item / (T * T), r = item - h * T * T, i = r / T, j = r - i * T;
+      const float* gp = dctx + i * ldd + h * HD;
+      const float* vp = QKV + j * LDQ + 2 * H + h * HD;
+      float a = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; d += 4) {
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(gp + d), vv = *reinterpret_cast<const f32x4*>(vp + d);
+        a = fmaf(gv[0], vv[0], a);
+        a = fmaf(gv[1], vv[1], a);
+        a = fmaf(gv[2], vv[2], a);
+        a = fmaf(gv[3], vv[3], a);
+      }
+      const bool kp = dr.keep(call, (unsigned)(pb0 + item));
+      SD[item] = kp ? a * dr.ks : 0.f;
+      if (!kp) SP[item] = -SP[item];
+    }
+  }
+  BAR();
+  if (work) {
+    // dV[j][c] = sum_i P'[i][j] d ctx[i][c]  (V is dead after the phase above: written in place)
+    for (int item = tid; item < T * (H / 4); item += NCT) {
+      const int j = item >> 5, c = (item & 31) * 4, h = c / HD;
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 3
+      for (int i = 0; i < T; ++i) {
+        const float pv = fmaxf(SP[(h * T + i) * T + j], 0.f) * dr.ks;
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(dctx + i * ldd + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = fmaf(pv, gv[k], a[k]);
+      }
+      *reinterpret_cast<f32x4*>(QKV + j * LDQ + 2 * H + c) = a;
+    }
+    // dS = P (dP - <dP, P>) / sqrt(32), row by row
+    if (tid < NH * T) {
+      float* sd = SD + tid * T;
+      const float* sp = SP + tid * T;
+      float dot = 0.f;
+      for (int j = 0; j < T; ++j) dot = fmaf(sd[j], fabsf(sp[j]), dot);
+      for (int j = 0; j < T; ++j) sd[j] = fabsf(sp[j]) * (sd[j] - dot) * 0.17677669529663687f;
+    }
+  }
+  BAR();
+  {
+    // dQ[i] = sum_j dS[i][j] K[j], dK[i] = sum_j dS[j][i] Q[j]: into registers, then in place
+    f32x4 rq[2], rk[2];
+    if (work) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int item = tid + u * NCT;
+        rq[u] = rk[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (item < T * (H / 4)) {
+          const int i = item >> 5, c = (item & 31) * 4, h = c / HD;
+#pragma unroll 3
+          for (int j = 0; j < T; ++j) {
+            const float a = SD[(h * T + i) * T + j], bq = SD[(h * T + j) * T + i];
+            const f32x4 kv = *reinterpret_cast<const f32x4*>(QKV + j * LDQ + H + c), qv = *reinterpret_cast<const f32x4*>(QKV + j * LDQ + c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              rq[u][k] = fmaf(a, kv[k], rq[u][k]);
+              rk[u][k] = fmaf(bq, qv[k], rk[u][k]);
+            }
+          }
+        }
+      }
+    }
+    BAR();
+    if (work) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int item = tid + u * NCT;
+        if (item < T * (H / 4)) {
+          const int i = item >> 5, c = (item & 31) * 4;
+          *reinterpret_cast<f32x4*>(QKV + i * LDQ + c) = rq[u];
+          *reinterpret_cast<f32x4*>(QKV + i * LDQ + H + c) = rk[u];
+        }
+      }
+    }
+  }
+  BAR();
+  if (work) {
+    for (int i = tid; i < T * (384 / 4); i += NCT) {
+      const int t = i / 96, c = (i - t * 96) * 4;
+      kpf_st4(dqkv_g + (row0 + t) * 384 + c, *reinterpret_cast<const f32x4*>(QKV + t * LDQ + c));
+    }
+  }
+}
+
 template <int MMA>
 __global__ __launch_bounds__(NTHR) void tr_stack_bwd_kernel(const float* __restrict__ dh, const float* const* __restrict__ P, const float* __restrict__ save,
                                                           float* __restrict__ dE, float* __restrict__ dys, float* __restrict__ parts, int B, float p_drop, int call0) {
@@ -571,6 +683,8 @@ __global__ __launch_bounds__(NTHR) void tr_stack_bwd_kernel(const float* __restr
   s.sched = sched;
   s.zero = kpf_trs_zero16;
   s.c = 0;
+  s.ntotal = NCHUNK;
+  s.dbg = kpf_trs_dbg;
   const bool work = !s.loader;
   const int b = blockIdx.x;
   Save sv;
@@ -610,7 +724,8 @@ __global__ __launch_bounds__(NTHR) void tr_stack_bwd_kernel(const float* __restr
   }
   BAR();
   if (s.loader)
-    for (int n = 0; n < NS - 1; ++n) issue_chunk<NS>(s, n);
+    for (int n = 0; n < NS - 1; ++n)
+      if (!(s.dbg & 1)) issue_chunk<NS>(s, n);
 
   const int fr = s.lane & 15, fg = s.lane >> 4, tt = s.wave & 1;
   for (int l = NLAYER - 1; l >= 0; --l) {
@@ -659,95 +774,8 @@ __global__ __launch_bounds__(NTHR) void tr_stack_bwd_kernel(const float* __restr
     gemm_op<NS, true, MMA>(s, D2, LDA, 2, 2, [&](int, int t, int col, float acc) { D1[t * LDA + col] = acc; });
     // ---- attention backward (in place on QKV) ----
     TRS_STAMP(32 + (NLAYER - 1 - l) * 8 + 4);
-    if (work) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of q | k | v and P has landed in LDS
-    BAR();
-    if (work) {  // dP' = d ctx V^T; SD = dP' * keep / (1 - p); SP <- +-P (sign: kept / dropped)
-      const long pb0 = (long)b * NH * T * T;
-      for (int item = tid; item < NH * T * T; item += NCT) {
-        const int h = item / (T * T), r = item - h * T * T, i = r / T, j = r - i * T;
-        const float* gp = D1 + i * LDA + h * HD;
-        const float* vp = QKV + j * LDQ + 2 * H + h * HD;
-        float a = 0.f;
-#pragma unroll
-        for (int d = 0; d < HD; d += 4) {
-          const f32x4 gv = *reinterpret_cast<const f32x4*>(gp + d), vv = *reinterpret_cast<const f32x4*>(vp + d);
-          a = fmaf(gv[0], vv[0], a);
-          a = fmaf(gv[1], vv[1], a);
-          a = fmaf(gv[2], vv[2], a);
-          a = fmaf(gv[3], vv[3], a);
-        }
-        const bool kp = dr.keep(call0 + 3 * l, (unsigned)(pb0 + item));
-        SD[item] = kp ? a * dr.ks : 0.f;
-        if (!kp) SP[item] = -SP[item];
-      }
-    }
-    BAR();
+    attention_backward(s, work, QKV, SP, SD, D1, LDA, d_qkv, b, row0, dr, call0 + 3 * l);
     if (work) {
-      // dV[j][c] = sum_i P'[i][j] d ctx[i][c]  (V is dead after the phase above: written in place)
-      for (int item = tid; item < T * (H / 4); item += NCT) {
-        const int j = item >> 5, c = (item & 31) * 4, h = c / HD;
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 3
-        for (int i = 0; i < T; ++i) {
-          const float pv = fmaxf(SP[(h * T + i) * T + j], 0.f) * dr.ks;
-          const f32x4 gv = *reinterpret_cast<const f32x4*>(D1 + i * LDA + c);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) a[k] = fmaf(pv, gv[k], a[k]);
-        }
-        *reinterpret_cast<f32x4*>(QKV + j * LDQ + 2 * H + c) = a;
-      }
-      // dS = P (dP - <dP, P>) / sqrt(32), row by row
-      if (tid < NH * T) {
-        float* sd = SD + tid * T;
-        const float* sp = SP + tid * T;
-        float dot = 0.f;
-        for (int j = 0; j < T; ++j) dot = fmaf(sd[j], fabsf(sp[j]), dot);
-        for (int j = 0; j < T; ++j) sd[j] = fabsf(sp[j]) * (sd[j] - dot) * 0.17677669529663687f;
-      }
-    }
-    BAR();
-    {
-      // dQ[i] = sum_j dS[i][j] K[j], dK[i] = sum_j dS[j][i] Q[j]: into registers, then in place
-      f32x4 rq[2], rk[2];
-      if (work) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int item = tid + u * NCT;
-          rq[u] = rk[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (item < T * (H / 4)) {
-            const int i = item >> 5, c = (item & 31) * 4, h = c / HD;
-#pragma unroll 3
-            for (int j = 0; j < T; ++j) {
-              const float a = SD[(h * T + i) * T + j], bq = SD[(h * T + j) * T + i];
-              const f32x4 kv = *reinterpret_cast<const f32x4*>(QKV + j * LDQ + H + c), qv = *reinterpret_cast<const f32x4*>(QKV + j * LDQ + c);
-#pragma unroll
-              for (int k = 0; k < 4; ++k) {
-                rq[u][k] = fmaf(a, kv[k], rq[u][k]);
-                rk[u][k] = fmaf(bq, qv[k], rk[u][k]);
-              }
-            }
-          }
-        }
-      }
-      BAR();
-      if (work) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int item = tid + u * NCT;
-          if (item < T * (H / 4)) {
-            const int i = item >> 5, c = (item & 31) * 4;
-            *reinterpret_cast<f32x4*>(QKV + i * LDQ + c) = rq[u];
-            *reinterpret_cast<f32x4*>(QKV + i * LDQ + H + c) = rk[u];
-          }
-        }
-      }
-    }
-    BAR();
-    if (work) {
-      for (int i = tid; i < T * (384 / 4); i += NCT) {
-        const int t = i / 96, c = (i - t * 96) * 4;
-        kpf_st4(d_qkv + (row0 + t) * 384 + c, *reinterpret_cast<const f32x4*>(QKV + t * LDQ + c));
-      }
       if (l > 0) {  // the next (lower) layer's first LayerNorm backward: its operands fly under the twelve blocks below
         ln_prefetch(s, ln2, save + sv.xs2(l - 1), save + sv.st2(l - 1), row0);
         if (tid < 2 * H) pvr = (P + (l - 1) * P_PER_LAYER)[tid < H ? P_G1 : P_G2][tid & 127];
@@ -773,6 +801,286 @@ __global__ __launch_bounds__(NTHR) void tr_stack_bwd_kernel(const float* __restr
   }
 }
 
+// ================================================ the decoder layer (cross attention) ================================================
+// updatedDecoder layer 3 in train mode (model/transfusion_head.py:137-173, 437-554): q = (query + qpos) Wq^T, k | v = (key + kpos) Wkv^T, attention with dropout,
+// x = LayerNorm(query + dropout(ctx Wo^T)), out = LayerNorm(x + dropout(W2 dropout(relu(W1 x)))), eps 1e-5 — one launch each way on the same engine as the stacks
+// above (24 weight blocks per direction; the unfused form: ~14 launches forward, ~20 backward).  Parameter table (14 pointers): in_proj_weight [384][128],
+// in_proj_bias, out_proj.weight / bias, norm2.weight / bias, linear1.weight / bias, linear2.weight / bias, norm3.weight / bias, qpos [21][128], kpos [21][128].
+// Saved (floats, M = 21 B): qe | ke | qkv [M][384] | P 84 M | ctx | xs2 | st2 [M][4] | x | f1d | xs3 | st3 [M][4] | out | (seed, counter).
+enum { XP_WIN = 0, XP_BIN, XP_WO, XP_BO, XP_G2, XP_B2, XP_W1, XP_BB1, XP_W2, XP_BB2, XP_G3, XP_B3, XP_QPOS, XP_KPOS, XP_N };
+constexpr int XCHUNK = 24;
+struct XSave {
+  long M;
+  __device__ __host__ long qe() const { return 0; }
+  __device__ __host__ long ke() const { return 128 * M; }
+  __device__ __host__ long qkv() const { return 256 * M; }
+  __device__ __host__ long P() const { return 640 * M; }
+  __device__ __host__ long ctx() const { return 724 * M; }
+  __device__ __host__ long xs2() const { return 852 * M; }
+  __device__ __host__ long st2() const { return 980 * M; }
+  __device__ __host__ long x() const { return 984 * M; }
+  __device__ __host__ long f1() const { return 1112 * M; }
+  __device__ __host__ long xs3() const { return 1240 * M; }
+  __device__ __host__ long st3() const { return 1368 * M; }
+  __device__ __host__ long out() const { return 1372 * M; }
+  __device__ __host__ long rng() const { return 1500 * M; }
+  __device__ __host__ long total() const { return 1500 * M + 4; }
+};
+// backward's dY buffer (floats): dqkv [M][384] | do [M][128] | dpre [M][128] | df [M][128]
+enum { XV_BQKV = 0, XV_BO = 384, XV_G2 = 512, XV_B2 = 640, XV_BB1 = 768, XV_BB2 = 896, XV_G3 = 1024, XV_B3 = 1152, XV_N = 1280 };
+
+// LayerNorm over the 128 channels of the sample's 21 rows (wave per row): in (LDS, stride ldi) -> out_l (LDS, stride ldo; nullable) and out_g (HBM rows of 128),
+// (mean, rstd) to st_g [row][4]
+__device__ __forceinline__ void ln_forward(const Sync& s, bool work, const float* in, int ldi, const float* gw, const float* gb, float eps, float* out_l, int ldo,
+                                           float* __restrict__ out_g, float* __restrict__ st_g, long row0) {
+  BAR();
+  if (work) {
+    const float w0 = gw[s.lane], w1 = gw[64 + s.lane], b0 = gb[s.lane], b1 = gb[64 + s.lane];
+    for (int t = s.wave; t < T; t += NCW) {
+      const float a0 = in[t * ldi + s.lane], a1 = in[t * ldi + 64 + s.lane];
+      const float mean = wave_sum(a0 + a1) * (1.0f / H);
+      const float d0 = a0 - mean, d1 = a1 - mean;
+      const float rstd = 1.0f / sqrtf(wave_sum(fmaf(d0, d0, d1 * d1)) * (1.0f / H) + eps);
+      const float y0 = d0 * rstd * w0 + b0, y1 = d1 * rstd * w1 + b1;
+      if (out_l) {
+        out_l[t * ldo + s.lane] = y0;
+        out_l[t * ldo + 64 + s.lane] = y1;
+      }
+      out_g[(row0 + t) * H + s.lane] = y0;
+      out_g[(row0 + t) * H + 64 + s.lane] = y1;
+      if (s.lane == 0) {
+        st_g[(row0 + t) * 4] = mean;
+        st_g[(row0 + t) * 4 + 1] = rstd;
+      }
+    }
+  }
+}
+
+template <int MMA>
+__global__ __launch_bounds__(NTHR) void xattn_train_fwd_kernel(const float* __restrict__ query, const float* __restrict__ key, const float* const* __restrict__ P,
+                                                             float* __restrict__ save, int B, float p_drop, const long* __restrict__ rng, int call0) {
+  constexpr int NS = 4;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  Chunk* sched = reinterpret_cast<Chunk*>(sm);
+  float* PV = sm + SCHED_F;    // [XV_N] parameter vectors
+  float* Q0 = PV + XV_N;       // [T][LDA] query (the residual of the first LayerNorm)
+  float* X1 = Q0 + T * LDA;    // [T][LDA] query + qpos, later the feed-forward's hidden rows
+  float* X2 = X1 + T * LDA;    // [T][LDA] key + kpos, later x = LayerNorm 2's output
+  float* QKV = X2 + T * LDA;   // [T][LDQ] q | k | v; T1 (a LayerNorm's input) in the q columns, the context in the k columns
+  float* T1 = QKV;
+  float* CTX = QKV + H;
+  float* S = QKV + T * LDQ;
+  float* ring = S + SPAD;
+  const int tid = threadIdx.x;
+  Sync s;
+  s.lane = tid & 63;
+  s.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  s.loader = s.wave >= NCW;
+  s.ring = ring;
+  s.sched = sched;
+  s.zero = kpf_trs_zero16;
+  s.c = 0;
+  s.ntotal = XCHUNK;
+  s.dbg = 0;
+  const bool work = !s.loader;
+  const int b = blockIdx.x;
+  XSave sv;
+  sv.M = (long)B * T;
+  const long row0 = (long)b * T;
+  if (tid == 0) {
+    int n = 0;
+    const float* win = P[XP_WIN];
+    for (int ob = 0; ob < 6; ++ob)  // q (2 blocks of 64 outputs), then k | v (4)
+      for (int rb = 0; rb < 2; ++rb) sched[n++] = Chunk{win + (long)ob * 64 * H + rb * 64, H, 64, 64};
+    const int ws[3] = {XP_WO, XP_W1, XP_W2};
+    for (int w = 0; w < 3; ++w)
+      for (int ob = 0; ob < 2; ++ob)
+        for (int rb = 0; rb < 2; ++rb) sched[n++] = Chunk{P[ws[w]] + (long)ob * 64 * H + rb * 64, H, 64, 64};
+  }
+  const unsigned seed = (p_drop > 0.f && rng) ? (unsigned)rng[0] : 0u, ctr = (p_drop > 0.f && rng) ? (unsigned)rng[1] : 0u;
+  const Drop dr = make_drop(p_drop, seed, ctr);
+  if (b == 0 && tid == 0) {
+    unsigned* ru = reinterpret_cast<unsigned*>(save + sv.rng());
+    ru[0] = seed;
+    ru[1] = ctr;
+  }
+  if (work) {
+    for (int i = tid; i < XV_N; i += NCT) {  // in_proj_bias (384) | out_proj.bias | norm2.weight | norm2.bias | linear1.bias | linear2.bias | norm3.weight | norm3.bias
+      const int which = i < XV_BO ? XP_BIN : (i < XV_BB1 ? XP_BO + ((i - XV_BO) >> 7) : (i < XV_BB2 ? XP_BB1 : (i < XV_G3 ? XP_BB2 : (i < XV_B3 ? XP_G3 : XP_B3))));
+      PV[i] = P[which][i < XV_BO ? i : (i & 127)];
+    }
+    const float* qpos = P[XP_QPOS];
+    const float* kpos = P[XP_KPOS];
+    for (int i = tid; i < T * (H / 4); i += NCT) {
+      const int t = i >> 5, c = (i & 31) * 4;
+      const long off = (row0 + t) * H + c;
+      const f32x4 qv = kpf_ld4(query + off), kv = kpf_ld4(key + off);
+      const f32x4 qe = qv + kpf_ld4(qpos + t * H + c), ke = kv + kpf_ld4(kpos + t * H + c);
+      *reinterpret_cast<f32x4*>(Q0 + t * LDA + c) = qv;
+      *reinterpret_cast<f32x4*>(X1 + t * LDA + c) = qe;
+      *reinterpret_cast<f32x4*>(X2 + t * LDA + c) = ke;
+      kpf_st4(save + sv.qe() + off, qe);
+      kpf_st4(save + sv.ke() + off, ke);
+    }
+  }
+  BAR();
+  if (s.loader)
+    for (int n = 0; n < NS - 1; ++n) issue_chunk<NS>(s, n);
+  float* sq = save + sv.qkv();
+  gemm_op<NS, false, MMA>(s, X1, LDA, 2, 2, [&](int, int t, int col, float acc) {
+    const float v = acc + PV[XV_BQKV + col];
+    QKV[t * LDQ + col] = v;
+    sq[(row0 + t) * 384 + col] = v;
+  });
+  gemm_op<NS, false, MMA>(s, X2, LDA, 4, 2, [&](int, int t, int col, float acc) {
+    const float v = acc + PV[XV_BQKV + H + col];
+    QKV[t * LDQ + H + col] = v;
+    sq[(row0 + t) * 384 + H + col] = v;
+  });
+  attention_forward(s, work, QKV, S, CTX, LDQ, save + sv.P(), save + sv.ctx(), b, row0, dr, call0);
+  {
+    float* sx = save + sv.xs2();
+    gemm_op<NS, false, MMA>(s, CTX, LDQ, 2, 2, [&](int, int t, int col, float acc) {
+      const float o = acc + PV[XV_BO + col];
+      const long idx = (row0 + t) * H + col;
+      const float x = Q0[t * LDA + col] + (dr.keep(call0 + 1, (unsigned)idx) ? o * dr.ks : 0.f);
+      T1[t * LDQ + col] = x;
+      sx[idx] = x;
+    });
+  }
+  ln_forward(s, work, T1, LDQ, PV + XV_G2, PV + XV_B2, 1e-5f, X2, LDA, save + sv.x(), save + sv.st2(), row0);
+  {
+    float* sf = save + sv.f1();
+    gemm_op<NS, false, MMA>(s, X2, LDA, 2, 2, [&](int, int t, int col, float acc) {
+      const long idx = (row0 + t) * H + col;
+      const float r = fmaxf(acc + PV[XV_BB1 + col], 0.f);
+      const float v = dr.keep(call0 + 2, (unsigned)idx) ? r * dr.ks : 0.f;
+      X1[t * LDA + col] = v;
+      sf[idx] = v;
+    });
+  }
+  {
+    float* sx = save + sv.xs3();
+    gemm_op<NS, false, MMA>(s, X1, LDA, 2, 2, [&](int, int t, int col, float acc) {
+      const float o = acc + PV[XV_BB2 + col];
+      const long idx = (row0 + t) * H + col;
+      const float x = X2[t * LDA + col] + (dr.keep(call0 + 3, (unsigned)idx) ? o * dr.ks : 0.f);
+      T1[t * LDQ + col] = x;
+      sx[idx] = x;
+    });
+  }
+  ln_forward(s, work, T1, LDQ, PV + XV_G3, PV + XV_B3, 1e-5f, nullptr, 0, save + sv.out(), save + sv.st3(), row0);
+}
+
+template <int MMA>
+__global__ __launch_bounds__(NTHR) void xattn_train_bwd_kernel(const float* __restrict__ dout, const float* const* __restrict__ P, const float* __restrict__ save,
+                                                             float* __restrict__ dquery, float* __restrict__ dqe, float* __restrict__ dke, float* __restrict__ dys,
+                                                             float* __restrict__ parts, int B, float p_drop, int call0) {
+  constexpr int NS = 4;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  Chunk* sched = reinterpret_cast<Chunk*>(sm);
+  float* PV = sm + SCHED_F;   // [2][128] LayerNorm weights (norm2, norm3)
+  float* G = PV + 2 * H;      // [T][LDA] d out, then d pre (the feed-forward's first product), then d query
+  float* D1 = G + T * LDA;
+  float* D2 = D1 + T * LDA;
+  float* QKV = D2 + T * LDA;  // [QPAD]
+  float* SP = QKV + QPAD;
+  float* SD = SP + SPAD;
+  float* ring = SD + SPAD;
+  const int tid = threadIdx.x;
+  Sync s;
+  s.lane = tid & 63;
+  s.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  s.loader = s.wave >= NCW;
+  s.ring = ring;
+  s.sched = sched;
+  s.zero = kpf_trs_zero16;
+  s.c = 0;
+  s.ntotal = XCHUNK;
+  s.dbg = 0;
+  const bool work = !s.loader;
+  const int b = blockIdx.x;
+  XSave sv;
+  sv.M = (long)B * T;
+  const long M = sv.M, row0 = (long)b * T;
+  if (tid == 0) {
+    int n = 0;
+    const int ws[3] = {XP_W2, XP_W1, XP_WO};  // reduction over the rows (n) of each [N][K] tensor, 64 output columns (k) per block
+    for (int w = 0; w < 3; ++w)
+      for (int ob = 0; ob < 2; ++ob)
+        for (int rb = 0; rb < 2; ++rb) sched[n++] = Chunk{P[ws[w]] + (long)rb * 64 * H + ob * 64, H, 64, 64};
+    const float* win = P[XP_WIN];
+    for (int ob = 0; ob < 2; ++ob)
+      for (int rb = 0; rb < 2; ++rb) sched[n++] = Chunk{win + (long)rb * 64 * H + ob * 64, H, 64, 64};          // d qe = dq . Wq
+    for (int ob = 0; ob < 2; ++ob)
+      for (int rb = 0; rb < 4; ++rb) sched[n++] = Chunk{win + (long)(128 + rb * 64) * H + ob * 64, H, 64, 64};  // d ke = d(k | v) . [Wk; Wv]
+  }
+  unsigned seed = 0u, ctr = 0u;
+  if (p_drop > 0.f) {
+    const unsigned* ru = reinterpret_cast<const unsigned*>(save + sv.rng());
+    seed = ru[0];
+    ctr = ru[1];
+  }
+  const Drop dr = make_drop(p_drop, seed, ctr);
+  float* d_qkv = dys;
+  float* d_o = dys + 384 * M;
+  float* d_pre = dys + 512 * M;
+  float* d_f = dys + 640 * M;
+  LnIn ln3, ln2;
+  float rf1[8];  // the dropped ReLU output at this lane's accumulator positions of the feed-forward's first product (its sign is the mask)
+  const int fr = s.lane & 15, fg = s.lane >> 4, tt = s.wave & 1, ct = (s.wave >> 1) & 3;
+  if (work) {
+    ln_prefetch(s, ln3, save + sv.xs3(), save + sv.st3(), row0);
+    if (tid < 2 * H) PV[tid] = P[tid < H ? XP_G2 : XP_G3][tid & 127];
+    for (int i = tid; i < T * (H / 4); i += NCT) {
+      const int t = i >> 5, c = (i & 31) * 4;
+      *reinterpret_cast<f32x4*>(G + t * LDA + c) = kpf_ld4(dout + (row0 + t) * H + c);
+    }
+    const float* sf = save + sv.f1();
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = tt * 16 + 4 * fg + r;
+        rf1[ob * 4 + r] = sf[(row0 + (t < T ? t : T - 1)) * H + ob * 64 + ct * 16 + fr];
+      }
+  }
+  BAR();
+  if (s.loader)
+    for (int n = 0; n < NS - 1; ++n) issue_chunk<NS>(s, n);
+  // ---- LayerNorm 3: G -> D1 (d x, residual branch), D2 (d f) ----
+  ln_backward(s, work, G, ln3, PV + H, D1, D2, d_f, parts + ((long)1 * B + b) * 2 * H, SP, row0, dr, call0 + 3);
+  if (work) {
+    ln_prefetch(s, ln2, save + sv.xs2(), save + sv.st2(), row0);
+    dma_rows(s, save + sv.qkv() + row0 * 384, T, 384, 384, QKV, LDQ);
+  }
+  // ---- d pre = (d f . W2) * (hidden > 0) / (1 - p) -> G ----
+  gemm_op<NS, true, MMA>(s, D2, LDA, 2, 2, [&](int ob, int t, int col, float acc) {
+    const float v = rf1[ob * 4 + (t & 3)] > 0.f ? acc * dr.ks : 0.f;
+    G[t * LDA + col] = v;
+    d_pre[(row0 + t) * H + col] = v;
+  });
+  // ---- d x += d pre . W1 ----
+  gemm_op<NS, true, MMA>(s, G, LDA, 2, 2, [&](int, int t, int col, float acc) { D1[t * LDA + col] += acc; });
+  // ---- LayerNorm 2: D1 -> G (d query, residual branch), D2 (d o) ----
+  ln_backward(s, work, D1, ln2, PV, G, D2, d_o, parts + ((long)0 * B + b) * 2 * H, SP, row0, dr, call0 + 1);
+  BAR();
+  if (work) dma_rows(s, save + sv.P() + (long)b * NH * T * T, 1, NH * T * T, NH * T * T, SP, SPAD);
+  // ---- d ctx = d o . Wo -> D1 ----
+  gemm_op<NS, true, MMA>(s, D2, LDA, 2, 2, [&](int, int t, int col, float acc) { D1[t * LDA + col] = acc; });
+  attention_backward(s, work, QKV, SP, SD, D1, LDA, d_qkv, b, row0, dr, call0);
+  // ---- d qe = dq . Wq (also the query's gradient through the projection); d ke = d(k | v) . [Wk; Wv] ----
+  gemm_op<NS, true, MMA>(s, QKV, LDQ, 2, 2, [&](int, int t, int col, float acc) {
+    dqe[(row0 + t) * H + col] = acc;
+    dquery[(row0 + t) * H + col] = G[t * LDA + col] + acc;
+  });
+  gemm_op<NS, true, MMA>(s, QKV + H, LDQ, 2, 4, [&](int, int t, int col, float acc) { dke[(row0 + t) * H + col] = acc; });
+}
+
+constexpr size_t XF_LDS = (size_t)(SCHED_F + XV_N + 3 * T * LDA + T * LDQ + SPAD + 4 * SLOT) * sizeof(float);
+constexpr size_t XB_LDS = (size_t)(SCHED_F + 2 * H + 3 * T * LDA + QPAD + 2 * SPAD + 4 * SLOT) * sizeof(float);
+static_assert(XF_LDS <= 160 * 1024 && XB_LDS <= 160 * 1024, "the decoder-layer kernels' LDS must fit one CU");
+
 constexpr size_t FWD_LDS = (size_t)(SCHED_F + PV_PAD + T * LDA + T * LDQ + SPAD + NSF * SLOT) * sizeof(float);
 constexpr size_t BWD_LDS = (size_t)(SCHED_F + 2 * H + 3 * T * LDA + T * LDI + QPAD + 2 * SPAD + NSB * SLOT) * sizeof(float);
 static_assert(FWD_LDS <= 160 * 1024 && BWD_LDS <= 160 * 1024, "the stack kernels' LDS must fit one CU");
@@ -784,6 +1092,8 @@ static_assert(2 * SPAD >= NCW * 2 * H, "LayerNorm reduce scratch lives in the sc
 /* tuning aid: 64 x 8-byte stamp slots in device memory (NULL switches the stamps off) */
 extern "C" int kpf_tr_stack_set_stamps(void* p) {
   unsigned long long* q = static_cast<unsigned long long*>(p);
+  static const int dbg = []() { const char* e = getenv("KPF_TRS_DBG"); return e ? atoi(e) : 0; }();  // (ablation bits, read once: see kpf_trs_dbg)
+  if (hipMemcpyToSymbol(HIP_SYMBOL(kpf_trs_dbg), &dbg, sizeof(dbg)) != hipSuccess) return KPF_ELAUNCH;
   return hipMemcpyToSymbol(HIP_SYMBOL(kpf_trs_stamps), &q, sizeof(q)) == hipSuccess ? KPF_OK : KPF_ELAUNCH;
 }
 extern "C" long kpf_tr_stack_save_floats(int B) {
@@ -851,4 +1161,65 @@ extern "C" int kpf_tr_stack_train_backward(const float* dh, const void* param_ta
   hipLaunchKernelGGL(kern, dim3(B), dim3(NTHR), BWD_LDS, reinterpret_cast<hipStream_t>(stream), dh, static_cast<const float* const*>(param_table), save, dE, dys, parts,
                      B, p_drop, call0);
   return kpf_check_launch("kpf_tr_stack_train_backward");
+}
+
+extern "C" long kpf_xattn_train_save_floats(int B) {
+  XSave sv;
+  sv.M = (long)B * T;
+  return sv.total();
+}
+/* which: 0 qe, 1 ke, 2 ctx, 3 x (LayerNorm 2's output), 4 f1 (dropped ReLU rows), 5 out — offsets into `save`; 6 dqkv [M][384], 7 do, 8 dpre, 9 df — offsets into `dys` */
+extern "C" long kpf_xattn_train_offset(int B, int which) {
+  XSave sv;
+  sv.M = (long)B * T;
+  const long M = sv.M;
+  switch (which) {
+    case 0: return sv.qe();
+    case 1: return sv.ke();
+    case 2: return sv.ctx();
+    case 3: return sv.x();
+    case 4: return sv.f1();
+    case 5: return sv.out();
+    case 6: return 0;
+    case 7: return 384 * M;
+    case 8: return 512 * M;
+    case 9: return 640 * M;
+    default: return -1;
+  }
+}
+extern "C" long kpf_xattn_train_dy_floats(int B) { return (long)B * T * 768; }
+
+extern "C" int kpf_xattn_train_forward(const float* query, const float* key, const void* param_table, float* save, long save_floats, int B, float p_drop,
+                                       const long* rng, int call0, int mma, void* stream) {
+  KPF_REQUIRE(query && key && param_table && save && B > 0 && mma >= 0 && mma <= 2, "kpf_xattn_train_forward: bad arguments");
+  KPF_REQUIRE(save_floats >= kpf_xattn_train_save_floats(B), "kpf_xattn_train_forward: save buffer too small");
+  KPF_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || rng), "kpf_xattn_train_forward: dropout needs 0 <= p < 1 and the rng state");
+  KPF_REQUIRE(kpf_aligned16(query) && kpf_aligned16(key) && kpf_aligned16(save), "kpf_xattn_train_forward: query, key, save must be 16-byte aligned");
+  using K = void (*)(const float*, const float*, const float* const*, float*, int, float, const long*, int);
+  const K kern = mma == 0 ? (K)xattn_train_fwd_kernel<0> : (mma == 1 ? (K)xattn_train_fwd_kernel<1> : (K)xattn_train_fwd_kernel<2>);
+  static std::atomic<bool> lds_opt_in[3][KPF_MAX_DEVICES];
+  if (!kpf_raise_lds_limit(reinterpret_cast<const void*>(kern), lds_opt_in[mma])) {
+    kpf_set_error("kpf_xattn_train_forward: cannot raise the dynamic LDS limit");
+    return KPF_ELAUNCH;
+  }
+  hipLaunchKernelGGL(kern, dim3(B), dim3(NTHR), XF_LDS, reinterpret_cast<hipStream_t>(stream), query, key, static_cast<const float* const*>(param_table), save, B,
+                     p_drop, rng, call0);
+  return kpf_check_launch("kpf_xattn_train_forward");
+}
+
+extern "C" int kpf_xattn_train_backward(const float* dout, const void* param_table, const float* save, float* dquery, float* dqe, float* dke, float* dys,
+                                        float* parts, int B, float p_drop, int call0, int mma, void* stream) {
+  KPF_REQUIRE(dout && param_table && save && dquery && dqe && dke && dys && parts && B > 0 && mma >= 0 && mma <= 2, "kpf_xattn_train_backward: bad arguments");
+  KPF_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "kpf_xattn_train_backward: 0 <= p < 1");
+  KPF_REQUIRE(kpf_aligned16(dout) && kpf_aligned16(save) && kpf_aligned16(dys), "kpf_xattn_train_backward: dout, save, dys must be 16-byte aligned");
+  using K = void (*)(const float*, const float* const*, const float*, float*, float*, float*, float*, float*, int, float, int);
+  const K kern = mma == 0 ? (K)xattn_train_bwd_kernel<0> : (mma == 1 ? (K)xattn_train_bwd_kernel<1> : (K)xattn_train_bwd_kernel<2>);
+  static std::atomic<bool> lds_opt_in[3][KPF_MAX_DEVICES];
+  if (!kpf_raise_lds_limit(reinterpret_cast<const void*>(kern), lds_opt_in[mma])) {
+    kpf_set_error("kpf_xattn_train_backward: cannot raise the dynamic LDS limit");
+    return KPF_ELAUNCH;
+  }
+  hipLaunchKernelGGL(kern, dim3(B), dim3(NTHR), XB_LDS, reinterpret_cast<hipStream_t>(stream), dout, static_cast<const float* const*>(param_table), save, dquery, dqe,
+                     dke, dys, parts, B, p_drop, call0);
+  return kpf_check_launch("kpf_xattn_train_backward");
 }

@@ -72,7 +72,7 @@ _SIGS = {
     "kpf_slices_sum_relu_forward": [_P, _P, C.c_long, C.c_int, C.c_int, C.c_int, _P],
     "kpf_slices_sum_relu_backward": [_P, _P, _P, _P, C.c_long, C.c_int, C.c_int, C.c_int, _P],
     "kpf_group_max_train_forward": [_P, _P, _P, C.c_long, C.c_int, C.c_int, _P],
-    "kpf_group_max_train_backward": [_P, _P, _P, C.c_long, C.c_int, C.c_int, _P],
+    "kpf_group_max_train_backward": [_P, C.c_int, _P, _P, C.c_long, C.c_int, C.c_int, _P],
     "kpf_heat_gam_gate_f32": [_P, _P, _P, C.c_int] + [_P] * 10 + [C.c_int] * 4 + [_P],
     "kpf_gate_reduce_f32": [_P, _P, _P, _P, _P, C.c_int, C.c_int, _P],
     "kpf_tr_encoder_f32": [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, _P],
@@ -156,6 +156,8 @@ _SIGS = {
     "kpf_ln_train_backward_partial": [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, C.c_long, C.c_long, C.c_int, C.POINTER(ColsumDesc), _P],
     "kpf_colsum_reduce_grouped": [C.POINTER(ColsumDesc), C.c_int, _P],
     "kpf_tr_stack_set_stamps": [_P],
+    "kpf_xattn_train_forward": [_P, _P, _P, _P, C.c_long, C.c_int, C.c_float, _P, C.c_int, C.c_int, _P],
+    "kpf_xattn_train_backward": [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_float, C.c_int, C.c_int, _P],
     "kpf_tr_stack_train_forward": [_P, _P, _P, _P, C.c_long, C.c_int, C.c_float, _P, C.c_int, C.c_int, _P],
     "kpf_tr_stack_train_backward": [_P, _P, _P, _P, _P, _P, C.c_int, C.c_float, C.c_int, C.c_int, _P],
     "kpf_bmm_small_k_dx": [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
@@ -181,6 +183,9 @@ _LONG_SIGS = {  # entries returning a long
     "kpf_dwconv7_stats_floats": [C.c_int] * 4,
     "kpf_pack_desc_blocks": [C.POINTER(PackDesc)],
     "kpf_tr_stack_save_floats": [C.c_int],
+    "kpf_xattn_train_save_floats": [C.c_int],
+    "kpf_xattn_train_dy_floats": [C.c_int],
+    "kpf_xattn_train_offset": [C.c_int, C.c_int],
     "kpf_tr_stack_out_offset": [C.c_int],
     "kpf_tr_stack_dy_floats": [C.c_int],
     "kpf_tr_stack_part_floats": [C.c_int],

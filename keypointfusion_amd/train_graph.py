@@ -43,6 +43,7 @@ _N_STREAMS = int(os.environ.get("KPF_TRAIN_STREAMS", "2"))  # 2: the RGB backbon
 PAIR_BACKBONES = bool(int(os.environ.get("KPF_TRAIN_PAIR", "1")))
 # 1 (default): the four BERT layers of a 21-token stack as ONE launch each way (training.BertStack21, csrc/kpf_trstack.hip); 0: layer by layer (bert_layer)
 TR_FUSED = bool(int(os.environ.get("KPF_TR_FUSED", "1")))
+XATTN_FUSED = bool(int(os.environ.get("KPF_XATTN_FUSED", "1")))  # the decoder layer as one launch each way (training.XAttnLayer21); 0: op by op
 TR_MMA = os.environ.get("KPF_TR_MMA", "auto")  # GEMM arithmetic of the fused stacks: "auto" = the module's precision; "f32" | "bf16" | "f16" force one
 # 1 (default): DESA's three radii as ONE channel-stacked chain — grouped Linears (G = 3), BatchNorm / add + ReLU / group maximum over 3 x 128 channels, one
 # grouping launch each way (training.BallGroup3 / LinearSlices / GroupMax) — instead of three chains of small launches; 0: radius by radius
@@ -126,6 +127,14 @@ class TrainGraph:
                                 self.wg([n + ".running_var" for n in names]), self.momentum, eps, relu, None, False)
         self.nbt += [self.t[n + ".num_batches_tracked"] for n in names]
         return y
+
+    def zeros(self, shape, dev):
+        """A constant all-zero tensor, kept on the module (zero channels of padded operands: a fill launch per forward otherwise)."""
+        c = self.m.__dict__.setdefault("_zero_cache", {})
+        k = (tuple(shape), dev.type, dev.index)
+        if k not in c:
+            c[k] = torch.zeros(*shape, device=dev)
+        return c[k]
 
     def groups_of(self, name):
         return self.G if name.startswith(PAIR) else 1
@@ -316,8 +325,8 @@ class TrainGraph:
             n = sum(w.shape[1] for w in ws)
             npad = (n + 7) // 8 * 8
             if npad != n:
-                ws.append(ws[0].new_zeros((G, npad - n) + tuple(ws[0].shape[2:])))
-                bs.append(bs[0].new_zeros(G, npad - n))
+                ws.append(self.zeros((G, npad - n) + tuple(ws[0].shape[2:]), ws[0].device))
+                bs.append(self.zeros((G, npad - n), bs[0].device))
             w, b = torch.cat(ws, 1), torch.cat(bs, 1)
             y = conv2d_nhwc(feat.contiguous(), w.view((G * npad,) + tuple(w.shape[2:])), b.view(-1), 1, 0, self.prec, None, None, None, G)
             return y.view(y.shape[:-1] + (G, npad))[..., :n]
@@ -549,6 +558,14 @@ class TrainGraph:
         B, T, C = query.shape
         hd = C // heads
         from .training import PrefixRows, SplitRows
+        if XATTN_FUSED and T == 21 and C == 128:  # the whole layer as one launch each way (training.XAttnLayer21)
+            from .training import XAttnLayer21, xattn_layer21
+            names = [p + "." + k for k in XAttnLayer21.ORDER]
+            call0 = self.attn_calls + 1
+            self.attn_calls += 4
+            mma = getattr(self.m, "precision", "f32") if TR_MMA == "auto" else TR_MMA
+            return xattn_layer21(query, key, PrefixRows.apply(self.t[p + ".self_posembed.weight"], T), PrefixRows.apply(self.t[p + ".cross_posembed.weight"], T), names,
+                                 self.packs, self.pd, self.rng(query.device), call0, [self.t[n] for n in names], mma)
         qe = query + PrefixRows.apply(self.t[p + ".self_posembed.weight"], T)
         ke = key + PrefixRows.apply(self.t[p + ".cross_posembed.weight"], T)
         ipw = p + ".multihead_attn.in_proj_weight"
@@ -681,7 +698,7 @@ class TrainGraph:
         self.par16 = torch.cat((Minv.reshape(B, 9)[:, :6], cam.reshape(B, -1)[:, :4], center.reshape(B, 3), cube.reshape(B, 3)), 1)  # GeomGateUVD's per-sample numbers
         from .training import pad_rows
         self.pcl4 = pad_rows(pcl, 4)                                         # the points at the width pcl_xyz_emb's GEMM reads (both blocks)
-        self.zpad3 = torch.zeros(B, Fs, Fs, 3, device=dev)                   # the gate input's three zero channels (149 -> 152, both blocks)
+        self.zpad3 = self.zeros((B, Fs, Fs, 3), dev)                         # the gate input's three zero channels (149 -> 152, both blocks)
         self.frows = None
         from .training import ROW_GATHER_MAX_E, ROW_GATHER_MAX_P, row_gather_invert
         self.idx_inv = row_gather_invert(index, Fs * Fs) if (N * 4 <= ROW_GATHER_MAX_E and Fs * Fs <= ROW_GATHER_MAX_P) else None

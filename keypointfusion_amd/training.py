@@ -1520,8 +1520,8 @@ class BertStack21(torch.autograd.Function):
             for p in params:
                 if p.dtype != torch.float32 or not p.is_contiguous() or p.data_ptr() % 16:
                     raise ValueError("BertStack21: parameters must be contiguous 16-byte-aligned fp32 tensors")
-            if len(BertStack21._tables) > 64:
-                BertStack21._tables.clear()
+            # (never evicted: a table is 0.5 KB, holds addresses only — valid for as long as those addresses are parameters, whoever owns them — and an eviction
+            #  between a GraphedTrainStep's warm-up and its capture would make the capture build one, a host -> device copy a capture cannot contain)
             t = BertStack21._tables[key] = torch.tensor(key, dtype=torch.int64, device=params[0].device)
         return t
 
@@ -1610,6 +1610,101 @@ MMA_MODE = {"f32": 0, "bf16": 1, "f16": 2}
 def bert_stack21(e, pos, names, cache, p_drop, rng, call0, params, prec="f32"):
     """prec: the GEMM arithmetic of the stack — "f32" exact fp32 products, "bf16" / "f16" operands rounded in registers, fp32 accumulation (the mixed-precision step)."""
     return BertStack21.apply(e, pos, tuple(names), cache, p_drop, rng, call0, MMA_MODE[prec], *params)
+
+
+class XAttnLayer21(torch.autograd.Function):
+    """The decoder layer of a fusion block (updatedDecoder layer 3, model/transfusion_head.py:137-173) in train mode as ONE launch each way
+    (kpf_xattn_train_forward / _backward, csrc/kpf_trstack.hip; round 6): out = LayerNorm(x + dropout(W2 dropout(relu(W1 x)))), x = LayerNorm(query +
+    dropout(attention(query + qpos, key + kpos) Wo^T)).  params (ORDER): in_proj_weight / bias, out_proj.weight / bias, norm2.weight / bias, linear1.weight / bias,
+    linear2.weight / bias, norm3.weight / bias; qpos / kpos [21, 128] are the first rows of the position tables (differentiable).  The packed in_proj gradient is
+    two problems of one grouped weight-gradient launch here (rows 0-127 from (dq, query + qpos), rows 128-383 from (d(k | v), key + kpos)); out_proj / linear1 /
+    linear2 join the deferred grouped launch like any small Linear; the LayerNorm sums leave as per-sample partials."""
+    ORDER = ("multihead_attn.in_proj_weight", "multihead_attn.in_proj_bias", "multihead_attn.out_proj.weight", "multihead_attn.out_proj.bias", "norm2.weight", "norm2.bias",
+             "linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias", "norm3.weight", "norm3.bias")
+
+    @staticmethod
+    def forward(ctx, query, key, qpos, kpos, names, cache, p_drop, rng, call0, mma, *params):
+        from . import lib as L
+        lib = L.load()
+        B, T, Cc = query.shape
+        assert T == 21 and Cc == 128 and len(params) == 12 and tuple(qpos.shape) == (21, 128) and tuple(kpos.shape) == (21, 128)
+        assert tuple(params[0].shape) == (384, 128) and tuple(params[6].shape) == (128, 128) and tuple(params[8].shape) == (128, 128), "decoder layer: d_model 128, feed-forward 128"
+        qc, kc = query.float().contiguous(), key.float().contiguous()
+        qp, kp = qpos.float().contiguous(), kpos.float().contiguous()
+        table = BertStack21.param_table(tuple(params) + (qp, kp))
+        n = lib.kpf_xattn_train_save_floats(B)
+        save = torch.empty(n, device=query.device, dtype=torch.float32)
+        L.check(lib.kpf_xattn_train_forward(qc.data_ptr(), kc.data_ptr(), table.data_ptr(), save.data_ptr(), n, B, float(p_drop),
+                                            rng.data_ptr() if (rng is not None and p_drop > 0) else None, int(call0), int(mma), torch.cuda.current_stream().cuda_stream),
+                "kpf_xattn_train_forward")
+        ctx.save_for_backward(save, table, qp, kp, *params)
+        ctx.conf = (names, cache, float(p_drop), int(call0), B, int(mma))
+        off = lib.kpf_xattn_train_offset(B, 5)
+        return save[off:off + B * T * Cc].view(B, T, Cc)
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import lib as L
+        lib = L.load()
+        save, table, qp, kp, *params = ctx.saved_tensors
+        names, cache, p_drop, call0, B, mma = ctx.conf
+        M, dev = B * 21, save.device
+        st = torch.cuda.current_stream().cuda_stream
+        dout = dout.float().contiguous()
+        new = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)
+        dq, dqe, dke = new(B, 21, 128), new(B, 21, 128), new(B, 21, 128)
+        dys, parts = new(lib.kpf_xattn_train_dy_floats(B)), new(2 * B * 256)
+        L.check(lib.kpf_xattn_train_backward(dout.data_ptr(), table.data_ptr(), save.data_ptr(), dq.data_ptr(), dqe.data_ptr(), dke.data_ptr(), dys.data_ptr(),
+                                             parts.data_ptr(), B, p_drop, call0, mma, st), "kpf_xattn_train_backward")
+        X = lambda which, K: (lambda o: save[o:o + M * K].view(M, K))(lib.kpf_xattn_train_offset(B, which))
+        dqkv = dys[:M * 384].view(M, 384)
+        DY = lambda which: (lambda o: dys[o:o + M * 128].view(M, 128))(lib.kpf_xattn_train_offset(B, which))
+        grads = [None] * 12
+        now_w, now_c = [], []
+        # in_proj: one parameter, two problems (different X): never deferred (a deferred item is one (dY, X) pair per parameter)
+        dwin, dbin = new(384, 128), new(384)
+        now_w.append((dqkv[:, :128], X(0, 128), dwin.data_ptr(), dbin.data_ptr(), M, 128, 128, 384))
+        now_w.append((dqkv[:, 128:], X(1, 128), dwin.data_ptr() + 4 * 128 * 128, dbin.data_ptr() + 4 * 128, M, 256, 128, 384))
+        grads[0], grads[1] = dwin, dbin
+        for wi, xw, yw in ((2, 2, 7), (6, 3, 8), (8, 4, 9)):
+            w, bias, name = params[wi], params[wi + 1], names[wi]
+            x, dy = X(xw, 128), DY(yw)
+            dw, db = new(128, 128), new(128)
+            grp = DeferredParamGrads.wants(name, cache, dy, x, 1, 1, 1, 0)
+            if grp is not None:
+                bp = grp.by_ptr.get(bias.data_ptr())
+                if bp is None or bp.numel() != 128 or bp.grad is not None:
+                    grp = None
+            if grp is not None:
+                grp.add(name, dy, x, dw, db, bias.data_ptr())
+            else:
+                now_w.append((dy, x, dw.data_ptr(), db.data_ptr(), M, 128, 128, 0))
+            grads[wi], grads[wi + 1] = dw, db
+        for ln, wi in ((0, 4), (1, 10)):
+            w, bias = params[wi], params[wi + 1]
+            dwb = new(2, 128)
+            desc = L.ColsumDesc()
+            desc.part, desc.dw, desc.db, desc.nblk, desc.C, desc.first_block, desc.reserved = parts.data_ptr() + 4 * ln * B * 256, dwb[0].data_ptr(), dwb[1].data_ptr(), B, 128, 0, 0
+            grp = DeferredParamGrads.wants_colsum(w, bias.data_ptr())
+            if grp is not None:
+                grp.add_colsum(w, desc, parts, dwb, bias.data_ptr(), dwb[1].data_ptr())
+            else:
+                now_c.append(desc)
+            grads[wi], grads[wi + 1] = dwb[0], dwb[1]
+        arr = (L.WgradGroupDesc * len(now_w))()
+        for d, (dy, x, pw, pb, M_, N, K, ldy) in zip(arr, now_w):
+            d.dy, d.x, d.dw, d.db, d.M, d.N, d.K, d.ldy = dy.data_ptr(), x.data_ptr(), pw, pb, M_, N, K, ldy
+        L.check(lib.kpf_linear_wgrad_grouped(arr, len(now_w), st), "kpf_linear_wgrad_grouped")
+        if now_c:
+            arr = (L.ColsumDesc * len(now_c))(*now_c)
+            L.check(lib.kpf_colsum_reduce_grouped(arr, len(now_c), st), "kpf_colsum_reduce_grouped")
+        dqpos = dqe.sum(0) if ctx.needs_input_grad[2] else None
+        dkpos = dke.sum(0) if ctx.needs_input_grad[3] else None
+        return (dq, dke, dqpos, dkpos, None, None, None, None, None, None) + tuple(grads)
+
+
+def xattn_layer21(query, key, qpos, kpos, names, cache, p_drop, rng, call0, params, prec="f32"):
+    return XAttnLayer21.apply(query, key, qpos, kpos, tuple(names), cache, p_drop, rng, call0, MMA_MODE[prec], *params)
 
 
 class DropAddLN(torch.autograd.Function):
@@ -2063,10 +2158,12 @@ class GroupMax(torch.autograd.Function):
         (arg,) = ctx.saved_tensors
         shape, group, dt = ctx.meta
         rows, Cc = arg.shape
-        dy = dy.float().contiguous()
+        dy = dy.float().reshape(rows, Cc)
+        if not (dy.stride(1) == 1 and dy.stride(0) % 4 == 0 and dy.stride(0) >= Cc and dy.data_ptr() % 16 == 0):
+            dy = dy.contiguous()  # (otherwise read in place: the gradient usually arrives as a column slice of the concatenation's)
         dx = torch.empty(rows * group, Cc, device=dy.device, dtype=torch.float32)
-        L.check(L.load().kpf_group_max_train_backward(dy.data_ptr(), arg.data_ptr(), dx.data_ptr(), rows, group, Cc, torch.cuda.current_stream().cuda_stream),
-                "kpf_group_max_train_backward")
+        L.check(L.load().kpf_group_max_train_backward(dy.data_ptr(), dy.stride(0) if rows > 1 else Cc, arg.data_ptr(), dx.data_ptr(), rows, group, Cc,
+                                                      torch.cuda.current_stream().cuda_stream), "kpf_group_max_train_backward")
         return dx.view(shape).to(dt), None
 
 

@@ -673,10 +673,13 @@ def test_wide_model_trains_at_256x256():
             v.copy_(stats[k])
     _, _, loss2 = iteration()
     assert float(loss2) == float(loss) and all(torch.equal(a, p.grad) for a, p in zip(g1, live)), "two iterations on the same batch must give the same bits"
-    opt, _ = T.make_optimizer(live, lr=5e-5, capturable=False)
+    # (lr: AdamW's first step moves EVERY weight by lr whatever its gradient; from 2e-5 on that is enough to change a ball-query set of block 2 on this batch and
+    #  the loss then jumps by +-5 % in either direction — 5e-5: -0.03 with the op-by-op decoder layer, +0.12 with the fused one; 2e-5: +0.07 / +0.10 — while up to
+    #  1e-5 every variant of the graph falls by the same 0.08-0.12: round 6, NOTES_r06.md section 1)
+    opt, _ = T.make_optimizer(live, lr=3e-6, capturable=False)
     opt.step()
     _, _, loss3 = iteration()
-    assert float(loss3) < float(loss)
+    assert float(loss3) < float(loss) - 0.02, (float(loss3), float(loss))
 
 
 @pytest.mark.gpu
