@@ -367,6 +367,29 @@ long kpf_dwconv7_wgrad_ws_floats(int B, int H, int C);
 int kpf_dwconv7_wgrad_f32(const float* dy, const float* x, float* dw, float* db, float* ws, long ws_floats, int B, int H, int W, int C,
                           void* stream);
 
+/* Split weight gradients with the fixed-order reduce of MANY calls in one launch (ABI 17; `loss.backward()` of train.py:262 issues ~100 weight-gradient
+ * GEMMs whose partial sums each needed a 5-us reduce launch).  kpf_conv2d_wgrad_deferred / kpf_dwconv7_wgrad_deferred are kpf_conv2d_wgrad_groups /
+ * kpf_dwconv7_wgrad_f32 without the reduce: they launch the split GEMM and describe the pending reduce in *reduce (kind < 0: the call wrote dw itself,
+ * nothing is pending).  Until kpf_wgrad_reduce_multi has run on the same stream, dw / db are UNWRITTEN and ws belongs to the pending reduce.
+ * kpf_wgrad_reduce_multi sums in the order the per-call reduce does: the gradients have the same bits either way. */
+#define KPF_WGRAD_REDUCE_BATCH 24
+typedef struct kpf_wgrad_reduce_desc {
+  const float* part;   /* [S][N*K] partial tiles ([S][49][C] for the depthwise form) */
+  const float* dbpart; /* [S][N] or NULL */
+  float* dw;
+  float* db;
+  long g_ws;           /* floats between the workspaces of consecutive channel groups */
+  int S, N, K, Cin, KHW, nkb, ndb, groups, Cin_out, N_out;
+  int kind;            /* 0 convolution / Linear, 1 depthwise 7x7 (N = C), < 0 nothing pending */
+  int first_block;     /* filled by kpf_wgrad_reduce_multi */
+} kpf_wgrad_reduce_desc;
+int kpf_conv2d_wgrad_deferred(const void* dy, const void* x, int dtype, float* dw, float* db, float* ws, long ws_floats, int groups, int B, int H, int W, int Cin,
+                              int ldx, int OH, int OW, int N, int ldy, int KH, int KW, int sh, int sw, int ph, int pw, int cin_valid, int n_valid,
+                              kpf_wgrad_reduce_desc* reduce, void* stream);
+int kpf_dwconv7_wgrad_deferred(const float* dy, const float* x, float* dw, float* db, float* ws, long ws_floats, int B, int H, int W, int C,
+                               kpf_wgrad_reduce_desc* reduce, void* stream);
+int kpf_wgrad_reduce_multi(const kpf_wgrad_reduce_desc* descs, int n, void* stream);
+
 /*
  * BatchNorm with batch statistics (+ optional ReLU) on NHWC rows x [M][C], forward and backward: nn.BatchNorm2d / BatchNorm1d in
  * train mode as the reference's Residual blocks use them (model/hourglass.py:84-119, `BN -> ReLU -> conv`), C % 4 == 0.
@@ -674,7 +697,7 @@ int kpf_conv_num_tile_cfgs(void);
 const char* kpf_last_error(void);
 /* Library/ABI version, bumped when a signature or the meaning of an argument changes (KPF_ABI_VERSION is what this header
  * describes; the Python binding refuses a library that reports another). */
-#define KPF_ABI_VERSION 16
+#define KPF_ABI_VERSION 17
 int kpf_abi_version(void);
 
 #ifdef __cplusplus

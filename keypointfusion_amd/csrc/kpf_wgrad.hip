@@ -724,58 +724,126 @@ __global__ __launch_bounds__(256) void wgrad_h16s_kernel(const WgradArgs a0) {
   }
 }
 
-// Fixed-order sum of S partial arrays of n floats: a workgroup owns 64 consecutive outputs, its four waves sum the partials
-// p = w, w+4, w+8, ... (four independent chains each) and the four wave sums are combined through LDS — the same order every run.
-// Up to SEQ_SPLITS partials are simply added in split order by the first wave: that is the order wgrad_grouped_kernel reproduces inside one
-// workgroup (its problems have at most 8 splits), so a small layer's gradient has the same bits whichever form computed it.
+// Fixed-order sum of S partial arrays of n floats (n % 4 == 0, 16-byte aligned), four consecutive outputs per thread.  S > SEQ_SPLITS: a workgroup
+// owns 256 consecutive outputs, its four waves sum the partials p = w, w+4, w+8, ... (four independent chains each) and the four wave sums are
+// combined through LDS — the same order every run.  Up to SEQ_SPLITS partials are simply added in split order, every wave on its own 256 outputs
+// (1024 per workgroup): that is the order wgrad_grouped_kernel reproduces inside one workgroup (its problems have at most 8 splits), so a small
+// layer's gradient has the same bits whichever form computed it.  (Round 6: float4 per thread instead of one float — a quarter of the workgroups
+// and load instructions for the same additions in the same order; the ~100 reduces of a training iteration took 0.63 ms before.)
 constexpr int SEQ_SPLITS = 8;
-__device__ __forceinline__ float sum_partials(const float* __restrict__ part, long n, int S, long i, float (*red)[64]) {
+inline int reduce_blocks(long n, int S) { return (int)(S <= SEQ_SPLITS ? (n + 1023) / 1024 : (n + 255) / 256); }
+// -> true when this thread holds the sums v of outputs [i, i + 4)
+__device__ __forceinline__ bool sum_partials4(const float* __restrict__ part, long n, int S, int bx, long& i, f32x4& v, f32x4 (*red)[64]) {
+  const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
   if (S <= SEQ_SPLITS) {
-    float s = 0.f;
-    if (i < n && threadIdx.x < 64)
-      for (int p = 0; p < S; ++p) s += part[(size_t)p * n + i];
-    return s;
+    i = ((long)bx * 256 + threadIdx.x) * 4;
+    v = z4;
+    if (i < n)
+      for (int p = 0; p < S; ++p) v += kpf_ld4(part + (size_t)p * n + i);
+    return i < n;
   }
   const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  i = ((long)bx * 64 + o) * 4;
+  f32x4 s0 = z4, s1 = z4, s2 = z4, s3 = z4;
   if (i < n) {
     int p = g;
+#pragma unroll 2
     for (; p + 12 < S; p += 16) {
-      s0 += part[(size_t)p * n + i];
-      s1 += part[(size_t)(p + 4) * n + i];
-      s2 += part[(size_t)(p + 8) * n + i];
-      s3 += part[(size_t)(p + 12) * n + i];
+      s0 += kpf_ld4(part + (size_t)p * n + i);
+      s1 += kpf_ld4(part + (size_t)(p + 4) * n + i);
+      s2 += kpf_ld4(part + (size_t)(p + 8) * n + i);
+      s3 += kpf_ld4(part + (size_t)(p + 12) * n + i);
     }
-    for (; p < S; p += 4) s0 += part[(size_t)p * n + i];
+    for (; p < S; p += 4) s0 += kpf_ld4(part + (size_t)p * n + i);
   }
   red[g][o] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  return (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
+  v = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
+  return g == 0 && i < n;
 }
 
 // dw[n][c][ky][kx] = sum_s part[s][n][(ky,kx,c)];  db[n] = sum_s dbpart[s][n]   (blocks [0, nkb) reduce dw, the rest db)
+// (grp = channel group of a grouped launch: its partial sums start g_ws floats further, its dw / db N_out*K_out / N_out floats further.
+//  Cin_out <= Cin, N_out <= N: the operands carried zero channels up to whole channel groups; dw [N_out][Cin_out][KH][KW] drops them)
+__device__ __forceinline__ void reduce_conv_body(const float* __restrict__ part, const float* __restrict__ dbpart, float* __restrict__ dw, float* __restrict__ db,
+                                                 int S, int N, int K, int Cin, int KHW, int nkb, long g_ws, int Cin_out, int N_out, int bx, int grp,
+                                                 f32x4 (*red)[64]) {
+  part += grp * g_ws, dw += (long)grp * N_out * Cin_out * KHW;
+  if (dbpart) dbpart += grp * g_ws, db += grp * N_out;
+  long i;
+  f32x4 v;
+  if (bx < nkb) {
+    if (sum_partials4(part, (long)N * K, S, bx, i, v, red)) {  // (K % 4 == 0: the four outputs share n and the tap, c .. c + 3)
+      const int n = (int)(i / K), k = (int)(i - (long)n * K);
+      const int tap = k / Cin, c = k - tap * Cin;
+      if (n < N_out) {
+        if (KHW == 1 && Cin_out == Cin) {
+          kpf_st4(dw + (size_t)n * Cin + c, v);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (c + j < Cin_out) dw[((size_t)n * Cin_out + c + j) * KHW + tap] = v[j];
+        }
+      }
+    }
+  } else {
+    if (sum_partials4(dbpart, N, S, bx - nkb, i, v, red)) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (i + j < N_out) db[i + j] = v[j];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbpart,
                                                            float* __restrict__ dw, float* __restrict__ db, int S, int N, int K, int Cin,
                                                            int KHW, int nkb, long g_ws, int Cin_out, int N_out) {
-  // (grid.y = channel group of a grouped launch: its partial sums start g_ws floats further, its dw / db N_out*K_out / N_out floats further.
-  //  Cin_out <= Cin, N_out <= N: the operands carried zero channels up to whole channel groups; dw [N_out][Cin_out][KH][KW] drops them)
-  part += blockIdx.y * g_ws, dw += (long)blockIdx.y * N_out * Cin_out * KHW;
-  if (dbpart) dbpart += blockIdx.y * g_ws, db += blockIdx.y * N_out;
-  __shared__ float red[4][64];
-  const int o = threadIdx.x & 63;
-  if ((int)blockIdx.x < nkb) {
-    const long NK = (long)N * K;
-    const long i = (long)blockIdx.x * 64 + o;
-    const float v = sum_partials(part, NK, S, i, red);
-    if (threadIdx.x < 64 && i < NK) {
-      const int n = (int)(i / K), k = (int)(i - (long)n * K);
-      const int tap = k / Cin, c = k - tap * Cin;
-      if (c < Cin_out && n < N_out) dw[((size_t)n * Cin_out + c) * KHW + tap] = v;
+  __shared__ f32x4 red[4][64];
+  reduce_conv_body(part, dbpart, dw, db, S, N, K, Cin, KHW, nkb, g_ws, Cin_out, N_out, (int)blockIdx.x, (int)blockIdx.y, red);
+}
+
+// depthwise 7x7: dw[c][tap] = sum_s part[s][tap][c];  db[c] = sum_s dbpart[s][c]
+__device__ __forceinline__ void reduce_dw7_body(const float* __restrict__ part, const float* __restrict__ dbpart, float* __restrict__ dw, float* __restrict__ db,
+                                                int S, int C, int nkb, int bx, f32x4 (*red)[64]) {
+  long i;
+  f32x4 v;
+  if (bx < nkb) {
+    if (sum_partials4(part, 49L * C, S, bx, i, v, red)) {
+      const int tap = (int)(i / C), c = (int)(i - (long)tap * C);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dw[(c + j) * 49 + tap] = v[j];
     }
   } else {
-    const long i = (long)(blockIdx.x - nkb) * 64 + o;
-    const float v = sum_partials(dbpart, N, S, i, red);
-    if (threadIdx.x < 64 && i < N_out) db[i] = v;
+    if (sum_partials4(dbpart, C, S, bx - nkb, i, v, red)) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) db[i + j] = v[j];
+    }
+  }
+}
+
+// The reduces of up to KPF_WGRAD_REDUCE_BATCH weight-gradient calls in ONE launch (kpf_wgrad_reduce_multi): a workgroup finds the call it
+// belongs to from the calls' first blocks and runs that call's own reduce body — same order of additions, same bits as the per-call launches.
+struct ReduceBatch {
+  kpf_wgrad_reduce_desc d[KPF_WGRAD_REDUCE_BATCH];
+  int nd;
+};
+typedef const __attribute__((address_space(4))) ReduceBatch* reduce_kernarg_t;
+
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const ReduceBatch) {
+  reduce_kernarg_t bp = (reduce_kernarg_t)__builtin_amdgcn_kernarg_segment_ptr();
+  __shared__ f32x4 red[4][64];
+  const int b = (int)blockIdx.x;
+  int k = 0;
+  const int nd = bp->nd;
+  while (k + 1 < nd && b >= bp->d[k + 1].first_block) ++k;
+  const int local = b - bp->d[k].first_block;
+  const int per = bp->d[k].nkb + bp->d[k].ndb;
+  if (bp->d[k].kind == 1) {
+    reduce_dw7_body(bp->d[k].part, bp->d[k].dbpart, bp->d[k].dw, bp->d[k].db, bp->d[k].S, bp->d[k].N, bp->d[k].nkb, local, red);
+  } else {
+    const int grp = local / per;
+    reduce_conv_body(bp->d[k].part, bp->d[k].dbpart, bp->d[k].dw, bp->d[k].db, bp->d[k].S, bp->d[k].N, bp->d[k].K, bp->d[k].Cin, bp->d[k].KHW, bp->d[k].nkb,
+                     bp->d[k].g_ws, bp->d[k].Cin_out, bp->d[k].N_out, local - grp * per, grp, red);
   }
 }
 
@@ -830,24 +898,10 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const float* __restr
   if (ky == 3) kpf_st4(dbpart + (size_t)blockIdx.y * C + c, dbs);
 }
 
-// dw[c][tap] = sum_s part[s][tap][c];  db[c] = sum_s dbpart[s][c]
 __global__ __launch_bounds__(256) void dwconv7_wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbpart,
                                                                    float* __restrict__ dw, float* __restrict__ db, int S, int C, int nkb) {
-  __shared__ float red[4][64];
-  const int o = threadIdx.x & 63;
-  if ((int)blockIdx.x < nkb) {
-    const long n = 49L * C;
-    const long i = (long)blockIdx.x * 64 + o;
-    const float v = sum_partials(part, n, S, i, red);
-    if (threadIdx.x < 64 && i < n) {
-      const int tap = (int)(i / C), c = (int)(i - (long)tap * C);
-      dw[c * 49 + tap] = v;
-    }
-  } else {
-    const long i = (long)(blockIdx.x - nkb) * 64 + o;
-    const float v = sum_partials(dbpart, C, S, i, red);
-    if (threadIdx.x < 64 && i < C) db[i] = v;
-  }
+  __shared__ f32x4 red[4][64];
+  reduce_dw7_body(part, dbpart, dw, db, S, C, nkb, (int)blockIdx.x, red);
 }
 
 struct Plan { int vn, vk, tilesN, tilesK, S, sps; };
@@ -981,7 +1035,8 @@ long kpf_conv2d_wgrad_ws_floats(long M, int N, int K) {
 
 static int conv2d_wgrad_impl(const void* dy, const void* x, int dtype, float* dw, float* db, float* ws, long ws_floats, int B, int H, int W,
                              int Cin, int ldx, int OH, int OW, int N, int ldy, int KH, int KW, int sh, int sw, int ph, int pw,
-                             void* stream, int groups = 1, int cin_valid = 0, int n_valid = 0) {
+                             void* stream, int groups = 1, int cin_valid = 0, int n_valid = 0, kpf_wgrad_reduce_desc* defer = nullptr) {
+  if (defer) defer->kind = -1;  // (nothing to reduce unless the split path below says so)
   if (cin_valid <= 0) cin_valid = Cin;
   if (n_valid <= 0) n_valid = N;
   KPF_REQUIRE(cin_valid <= Cin && n_valid <= N, "kpf_conv2d_wgrad: cin_valid / n_valid exceed Cin / N");
@@ -1056,8 +1111,14 @@ static int conv2d_wgrad_impl(const void* dy, const void* x, int dtype, float* dw
   }
   if (rc != KPF_OK || direct) return rc;
   const long NK = (long)N * K;
-  const int nkb = (int)((NK + 63) / 64);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nkb + (db ? (N + 63) / 64 : 0), groups), dim3(256), 0, st, ws, a.dbpart, dw, db, p.S, N, (int)K, Cin,
+  const int nkb = reduce_blocks(NK, p.S), ndb = db ? reduce_blocks(N, p.S) : 0;
+  if (defer) {  // the caller batches this reduce with others (kpf_wgrad_reduce_multi): ws stays the caller's until then
+    defer->part = ws, defer->dbpart = a.dbpart, defer->dw = dw, defer->db = db, defer->g_ws = wsg;
+    defer->S = p.S, defer->N = N, defer->K = (int)K, defer->Cin = Cin, defer->KHW = KH * KW, defer->nkb = nkb, defer->ndb = ndb;
+    defer->groups = groups, defer->Cin_out = cin_valid, defer->N_out = n_valid, defer->kind = 0, defer->first_block = 0;
+    return KPF_OK;
+  }
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nkb + ndb, groups), dim3(256), 0, st, ws, a.dbpart, dw, db, p.S, N, (int)K, Cin,
                      KH * KW, nkb, wsg, cin_valid, n_valid);
   return kpf_check_launch("kpf_conv2d_wgrad_f32 (reduce)");
 }
@@ -1077,6 +1138,41 @@ int kpf_conv2d_wgrad_groups(const void* dy, const void* x, int dtype, float* dw,
                             int ldx, int OH, int OW, int N, int ldy, int KH, int KW, int sh, int sw, int ph, int pw, int cin_valid, int n_valid, void* stream) {
   KPF_REQUIRE(groups >= 1 && groups <= 64, "kpf_conv2d_wgrad_groups: 1..64 groups");
   return conv2d_wgrad_impl(dy, x, dtype, dw, db, ws, ws_floats, B, H, W, Cin, ldx, OH, OW, N, ldy, KH, KW, sh, sw, ph, pw, stream, groups, cin_valid, n_valid);
+}
+
+int kpf_conv2d_wgrad_deferred(const void* dy, const void* x, int dtype, float* dw, float* db, float* ws, long ws_floats, int groups, int B, int H, int W, int Cin,
+                              int ldx, int OH, int OW, int N, int ldy, int KH, int KW, int sh, int sw, int ph, int pw, int cin_valid, int n_valid,
+                              kpf_wgrad_reduce_desc* reduce, void* stream) {
+  KPF_REQUIRE(groups >= 1 && groups <= 64, "kpf_conv2d_wgrad_deferred: 1..64 groups");
+  KPF_REQUIRE(reduce, "kpf_conv2d_wgrad_deferred: null descriptor");
+  return conv2d_wgrad_impl(dy, x, dtype, dw, db, ws, ws_floats, B, H, W, Cin, ldx, OH, OW, N, ldy, KH, KW, sh, sw, ph, pw, stream, groups, cin_valid, n_valid, reduce);
+}
+
+int kpf_wgrad_reduce_multi(const kpf_wgrad_reduce_desc* descs, int n, void* stream) {
+  KPF_REQUIRE(n >= 0 && (descs || n == 0), "kpf_wgrad_reduce_multi: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  for (int base = 0; base < n;) {
+    ReduceBatch b;
+    b.nd = 0;
+    long blocks = 0;
+    for (; base < n && b.nd < KPF_WGRAD_REDUCE_BATCH; ++base) {
+      const kpf_wgrad_reduce_desc& d = descs[base];
+      if (d.kind < 0) continue;  // (a call that wrote its gradient directly)
+      KPF_REQUIRE((d.kind == 0 || d.kind == 1) && d.part && d.dw && d.S > 0 && d.N > 0 && d.nkb > 0 && d.ndb >= 0 && (d.ndb == 0 || (d.db && d.dbpart)),
+                  "kpf_wgrad_reduce_multi: bad descriptor %d", base);
+      KPF_REQUIRE(d.kind == 1 || (d.K > 0 && d.Cin > 0 && d.KHW > 0 && d.groups >= 1 && d.Cin_out > 0 && d.N_out > 0), "kpf_wgrad_reduce_multi: bad descriptor %d", base);
+      b.d[b.nd] = d;
+      b.d[b.nd].first_block = (int)blocks;
+      blocks += (long)(d.nkb + d.ndb) * (d.kind == 1 ? 1 : d.groups);
+      KPF_REQUIRE(blocks < (1L << 31), "kpf_wgrad_reduce_multi: too many blocks");
+      ++b.nd;
+    }
+    if (b.nd == 0) break;
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, st, b);
+    const int rc = kpf_check_launch("kpf_wgrad_reduce_multi");
+    if (rc != KPF_OK) return rc;
+  }
+  return KPF_OK;
 }
 
 int kpf_linear_wgrad_grouped(const kpf_wgrad_group_desc* descs, int n, void* stream) {
@@ -1113,8 +1209,9 @@ long kpf_dwconv7_wgrad_ws_floats(int B, int H, int C) {
   return S * 50 * C;
 }
 
-int kpf_dwconv7_wgrad_f32(const float* dy, const float* x, float* dw, float* db, float* ws, long ws_floats, int B, int H, int W, int C,
-                          void* stream) {
+static int dwconv7_wgrad_impl(const float* dy, const float* x, float* dw, float* db, float* ws, long ws_floats, int B, int H, int W, int C,
+                              kpf_wgrad_reduce_desc* defer, void* stream) {
+  if (defer) defer->kind = -1;
   KPF_REQUIRE(dy && x && dw && ws, "kpf_dwconv7_wgrad_f32: null pointer");
   KPF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "kpf_dwconv7_wgrad_f32: bad shape (C %% 4 == 0)");
   KPF_REQUIRE(kpf_aligned16(dy) && kpf_aligned16(x) && kpf_aligned16(ws), "kpf_dwconv7_wgrad_f32: dy, x, ws must be 16-byte aligned");
@@ -1126,9 +1223,26 @@ int kpf_dwconv7_wgrad_f32(const float* dy, const float* x, float* dw, float* db,
   hipLaunchKernelGGL(dwconv7_wgrad_kernel, dim3((7 * (C / 4) + 255) / 256, S), dim3(256), 0, st, dy, x, ws, dbpart, B, H, W, C, rpc);
   int rc = kpf_check_launch("kpf_dwconv7_wgrad_f32");
   if (rc != KPF_OK) return rc;
-  const int nkb = (49 * C + 63) / 64;
-  hipLaunchKernelGGL(dwconv7_wgrad_reduce_kernel, dim3(nkb + (db ? (C + 63) / 64 : 0)), dim3(256), 0, st, ws, dbpart, dw, db, S, C, nkb);
+  const int nkb = reduce_blocks(49L * C, S), ndb = db ? reduce_blocks(C, S) : 0;
+  if (defer) {
+    *defer = kpf_wgrad_reduce_desc{};
+    defer->part = ws, defer->dbpart = dbpart, defer->dw = dw, defer->db = db;
+    defer->S = S, defer->N = C, defer->nkb = nkb, defer->ndb = ndb, defer->groups = 1, defer->kind = 1;
+    return KPF_OK;
+  }
+  hipLaunchKernelGGL(dwconv7_wgrad_reduce_kernel, dim3(nkb + ndb), dim3(256), 0, st, ws, dbpart, dw, db, S, C, nkb);
   return kpf_check_launch("kpf_dwconv7_wgrad_f32 (reduce)");
+}
+
+int kpf_dwconv7_wgrad_f32(const float* dy, const float* x, float* dw, float* db, float* ws, long ws_floats, int B, int H, int W, int C,
+                          void* stream) {
+  return dwconv7_wgrad_impl(dy, x, dw, db, ws, ws_floats, B, H, W, C, nullptr, stream);
+}
+
+int kpf_dwconv7_wgrad_deferred(const float* dy, const float* x, float* dw, float* db, float* ws, long ws_floats, int B, int H, int W, int C,
+                               kpf_wgrad_reduce_desc* reduce, void* stream) {
+  KPF_REQUIRE(reduce, "kpf_dwconv7_wgrad_deferred: null descriptor");
+  return dwconv7_wgrad_impl(dy, x, dw, db, ws, ws_floats, B, H, W, C, reduce, stream);
 }
 
 }  // extern "C"

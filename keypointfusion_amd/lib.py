@@ -23,7 +23,7 @@ KPF_IN_SPLIT = 128
 KPF_OUT_SPLIT = 256
 KPF_W_SPLIT = 512
 KPF_DT_F32, KPF_DT_BF16, KPF_DT_F16 = 0, 1, 2
-ABI_VERSION = 16  # KPF_ABI_VERSION of include/kpf.h: load() refuses a library built from another revision of the interface
+ABI_VERSION = 17  # KPF_ABI_VERSION of include/kpf.h: load() refuses a library built from another revision of the interface
 
 
 class ConvDesc(C.Structure):
@@ -47,6 +47,11 @@ class WgradGroupDesc(C.Structure):  # kpf_wgrad_group_desc (include/kpf.h)
 
 class ColsumDesc(C.Structure):  # kpf_colsum_desc (include/kpf.h)
     _fields_ = [("part", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("nblk", C.c_int), ("C", C.c_int), ("first_block", C.c_int), ("reserved", C.c_int)]
+
+
+class WgradReduceDesc(C.Structure):  # kpf_wgrad_reduce_desc (include/kpf.h)
+    _fields_ = [("part", C.c_void_p), ("dbpart", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("g_ws", C.c_long)] + [
+        (n, C.c_int) for n in "S N K Cin KHW nkb ndb groups Cin_out N_out kind first_block".split()]
 
 
 _P = C.c_void_p
@@ -114,6 +119,9 @@ _SIGS = {
     "kpf_dwconv7_add_f32": [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P],
     "kpf_conv2d_wgrad_h16": [_P, _P, C.c_int] + [_P] * 3 + [C.c_long] + [C.c_int] * 15 + [_P],
     "kpf_conv2d_wgrad_groups": [_P, _P, C.c_int] + [_P] * 3 + [C.c_long] + [C.c_int] * 18 + [_P],
+    "kpf_conv2d_wgrad_deferred": [_P, _P, C.c_int] + [_P] * 3 + [C.c_long] + [C.c_int] * 18 + [C.POINTER(WgradReduceDesc), _P],
+    "kpf_dwconv7_wgrad_deferred": [_P] * 5 + [C.c_long] + [C.c_int] * 4 + [C.POINTER(WgradReduceDesc), _P],
+    "kpf_wgrad_reduce_multi": [C.POINTER(WgradReduceDesc), C.c_int, _P],
     "kpf_add_relu_forward": [_P, _P, _P, _P, C.c_long, C.c_float, _P],
     "kpf_add_relu_backward": [_P, _P, _P, C.c_long, C.c_float, _P],
     "kpf_gate_mix_forward": [_P] * 6 + [C.c_int] * 3 + [_P],

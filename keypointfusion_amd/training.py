@@ -941,10 +941,12 @@ class DeferredParamGrads:
         self.named = dict(named_params)
         self.by_ptr = {p.data_ptr(): p for p in self.named.values()}
         self.items, self.colsums, self.biases, self.seen = [], [], [], set()
+        self.reduces, self.reduce_checks, self.stream, self.n_reduces = [], [], None, 0
 
     def __enter__(self):
         assert DeferredParamGrads.active is None
         DeferredParamGrads.active = self
+        self.stream = torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else None
         return self
 
     def __exit__(self, et, ev, tb):
@@ -953,6 +955,7 @@ class DeferredParamGrads:
             self.flush()
         else:
             self.items, self.colsums, self.biases, self.seen = [], [], [], set()
+            self.reduces, self.reduce_checks = [], []
         return False
 
     @staticmethod
@@ -964,22 +967,63 @@ class DeferredParamGrads:
         if g is None:
             return None
 
-        def whole(ptr):
-            """the parameter(s) that make up weight.numel() elements from `ptr` on: one parameter, or the adjacent parameters of a paired tensor
-            (training.pair_params: the halves of the gradient are adopted as views of the one deferred tensor) — all without a gradient yet"""
-            n, got, ps = weight.numel(), 0, []
-            while got < n:
-                q = g.by_ptr.get(ptr + 4 * got)
-                # (a parameter that already holds a gradient would make AccumulateGrad ADD the still-unwritten tensor: not deferred)
-                if q is None or q.grad is not None or q.dtype != torch.float32 or got + q.numel() > n:
-                    return None
-                ps.append(q)
-                got += q.numel()
-            return ps
-
-        if whole(weight.data_ptr()) is None or (bias_ptr is not None and whole(bias_ptr) is None):
+        if g._whole(weight.data_ptr(), weight.numel()) is None or (bias_ptr is not None and g._whole(bias_ptr, weight.numel()) is None):
             return None
         return g
+
+    def _whole(self, ptr, n):
+        """the parameter(s) that make up n fp32 elements from `ptr` on: one parameter, or the adjacent parameters of a paired tensor
+        (training.pair_params: the halves of the gradient are adopted as views of the one deferred tensor) — all without a gradient yet"""
+        got, ps = 0, []
+        while got < n:
+            q = self.by_ptr.get(ptr + 4 * got)
+            # (a parameter that already holds a gradient would make AccumulateGrad ADD the still-unwritten tensor: not deferred)
+            if q is None or q.grad is not None or q.dtype != torch.float32 or got + q.numel() > n:
+                return None
+            ps.append(q)
+            got += q.numel()
+        return ps
+
+    # ---- the fixed-order reduces behind the split weight-gradient GEMMs of the backbones: one launch per REDUCE_BATCH calls (kpf_wgrad_reduce_multi) ----
+    REDUCE_DEFER = os.environ.get("KPF_REDUCE_DEFER", "1") != "0"  # (tuning aid: 0 = every weight-gradient call launches its own reduce)
+    REDUCE_BATCH = int(os.environ.get("KPF_REDUCE_BATCH", "8"))  # (at most KPF_WGRAD_REDUCE_BATCH of include/kpf.h per launch; more = more launches)
+
+    @staticmethod
+    def wants_reduce(weight, n_bias=0, bias_ptr=None):
+        """The active object when the reduce behind `weight`'s gradient may wait for a batched launch: the weight (and the bias at bias_ptr, n_bias
+        elements) is made of whole parameters that hold no gradient yet and receive none twice in this pass — AccumulateGrad then only adopts
+        the still-unwritten tensor — and the call runs on the stream the pass was opened on (the batched launch is issued there)."""
+        g = DeferredParamGrads.active
+        if g is None or not g.REDUCE_DEFER or torch.cuda.current_stream().cuda_stream != g.stream:
+            return None
+        key = ("reduce", weight.data_ptr())
+        if key in g.seen or g._whole(weight.data_ptr(), weight.numel()) is None or (bias_ptr is not None and g._whole(bias_ptr, n_bias) is None):
+            return None
+        g.seen.add(key)
+        return g
+
+    def add_reduce(self, desc, ws, weight, dw, bias_ptr=None, db=None):
+        """desc: the kpf_wgrad_reduce_desc a *_deferred call filled; ws stays referenced until the batched launch has been issued."""
+        if desc.kind < 0:  # (the call wrote the gradient itself)
+            return
+        self.reduces.append((desc, ws))
+        self.n_reduces += 1
+        self.reduce_checks.append(("a convolution weight", weight.data_ptr(), dw.data_ptr(), dw.numel()))
+        if db is not None:
+            self.reduce_checks.append(("a convolution bias", bias_ptr, db.data_ptr(), db.numel()))
+        if len(self.reduces) >= self.REDUCE_BATCH:
+            self.flush_reduces()
+
+    def flush_reduces(self):
+        """Issue the pending reduces (GraphedTrainStep also calls this before a gradient bucket is packed for its collective)."""
+        if not self.reduces:
+            return
+        from . import lib as L
+        arr = (L.WgradReduceDesc * len(self.reduces))()
+        for i, (d, _) in enumerate(self.reduces):
+            C.memmove(C.byref(arr[i]), C.byref(d), C.sizeof(d))
+        self.reduces = []
+        L.check(L.load().kpf_wgrad_reduce_multi(arr, len(arr), self.stream), "kpf_wgrad_reduce_multi")
 
     def _parts(self, ptr, n):
         """[(parameter, byte offset)] covering n fp32 elements of parameter storage from ptr on (see wants_colsum)."""
@@ -1026,6 +1070,12 @@ class DeferredParamGrads:
 
     def flush(self):
         from . import lib as L
+        self.flush_reduces()
+        checks, self.reduce_checks = self.reduce_checks, []
+        for what, pptr, optr, n in checks:  # (the reduces have been issued by now; a gradient that autograd copied before that holds garbage: say so)
+            for q, off in self._parts(pptr, n):
+                if q.grad is None or q.grad.data_ptr() != optr + off:
+                    raise RuntimeError("DeferredParamGrads: the gradient of %s %s was copied before its reduce had run (autograd did not adopt the tensor)" % (what, tuple(q.shape)))
         items, colsums, biases, self.items, self.colsums, self.biases, self.seen = self.items, self.colsums, self.biases, [], [], [], set()
         # the parameters whose gradients this pass deferred (GraphedTrainStep keeps them out of the buckets that are reduced DURING backward)
         self.last_deferred = ([self.named[k] for k, *_ in items if k in self.named] + [q for c in colsums if c[2] in self.by_ptr for q, _ in self._parts(c[2], c[4])] +
@@ -1063,9 +1113,25 @@ class DeferredParamGrads:
 GroupedLinearWgrad = DeferredParamGrads  # (the name the first form of this class had)
 
 
-def conv_wgrad_hip(dy, x, wshape, stride, pad, want_db=True, groups=1):
+def _wgrad_groups(lib, dy_ptr, x_ptr, dt, dw, db, ws, nws, groups, dims, st, weight=None, bias_ptr=None):
+    """kpf_conv2d_wgrad_groups(dy, x, dt, dw, db, ws, nws, groups, *dims, stream) — or, inside a DeferredParamGrads pass and for a gradient that goes to whole
+    parameters (`weight`, and the bias at `bias_ptr`), kpf_conv2d_wgrad_deferred with the reduce joining a batched launch: dw / db are then still UNWRITTEN."""
+    from . import lib as L
+    dbp = db.data_ptr() if db is not None else None
+    grp = DeferredParamGrads.wants_reduce(weight, 0 if db is None else db.numel(), bias_ptr if db is not None else None) if weight is not None else None
+    if grp is not None and (db is None or bias_ptr is not None):
+        desc = L.WgradReduceDesc()
+        L.check(lib.kpf_conv2d_wgrad_deferred(dy_ptr, x_ptr, dt, dw.data_ptr(), dbp, ws.data_ptr(), nws, groups, *dims, C.byref(desc), st), "kpf_conv2d_wgrad_deferred")
+        grp.add_reduce(desc, ws, weight, dw, bias_ptr if db is not None else None, db)
+    else:
+        L.check(lib.kpf_conv2d_wgrad_groups(dy_ptr, x_ptr, dt, dw.data_ptr(), dbp, ws.data_ptr(), nws, groups, *dims, st), "kpf_conv2d_wgrad_groups")
+
+
+def conv_wgrad_hip(dy, x, wshape, stride, pad, want_db=True, groups=1, weight=None, bias_ptr=None):
     """(dW in OIHW, db or None) of a convolution from NHWC dY [B,OH,OW,N] and X [B,H,W,Cin]: kpf_conv2d_wgrad_f32 / _h16 (f32 MFMA GEMM
-    with the pixel index as the reduction dimension, split over workgroups, fixed-order reduce)."""
+    with the pixel index as the reduction dimension, split over workgroups, fixed-order reduce).  weight (+ bias_ptr): the parameter
+    tensor the gradient is for — inside a DeferredParamGrads pass its reduce may then join a batched launch (wants_reduce): dW / db are
+    returned UNWRITTEN."""
     from . import lib as L
     lib = L.load()
     B, H, W, Cin = x.shape
@@ -1088,8 +1154,15 @@ def conv_wgrad_hip(dy, x, wshape, stride, pad, want_db=True, groups=1):
     dw = torch.empty(tuple(wshape), device=x.device, dtype=torch.float32)
     db = torch.empty(N * groups, device=x.device, dtype=torch.float32) if want_db else None
     st = torch.cuda.current_stream().cuda_stream
+    dt = (L.KPF_DT_BF16 if dy.dtype == torch.bfloat16 else L.KPF_DT_F16) if h16 else L.KPF_DT_F32
+    grp = DeferredParamGrads.wants_reduce(weight, N * groups, bias_ptr if want_db else None) if weight is not None and tuple(weight.shape) == tuple(wshape) else None
+    if grp is not None:
+        desc = L.WgradReduceDesc()
+        L.check(lib.kpf_conv2d_wgrad_deferred(dy.data_ptr(), x.data_ptr(), dt, dw.data_ptr(), db.data_ptr() if want_db else None, ws.data_ptr(), nws, groups,
+                                              B, H, W, Cin, ldx, OH, OW, N, ldy, KH, KW, stride, stride, pad, pad, 0, 0, C.byref(desc), st), "kpf_conv2d_wgrad_deferred")
+        grp.add_reduce(desc, ws, weight, dw, bias_ptr if want_db else None, db)
+        return dw, db
     if groups > 1:
-        dt = (L.KPF_DT_BF16 if dy.dtype == torch.bfloat16 else L.KPF_DT_F16) if h16 else L.KPF_DT_F32
         L.check(lib.kpf_conv2d_wgrad_groups(dy.data_ptr(), x.data_ptr(), dt, dw.data_ptr(), db.data_ptr() if want_db else None, ws.data_ptr(), nws, groups,
                                             B, H, W, Cin, ldx, OH, OW, N, ldy, KH, KW, stride, stride, pad, pad, 0, 0, st), "kpf_conv2d_wgrad_groups")
         return dw, db
@@ -1122,6 +1195,7 @@ class DwConv7NHWC(torch.autograd.Function):
         L.check(lib.kpf_dwconv7_f32(x.data_ptr(), wt.data_ptr(), bias.detach().contiguous().data_ptr(), y.data_ptr(), B, H, W, Cc,
                                     torch.cuda.current_stream().cuda_stream), "kpf_dwconv7_f32")
         ctx.save_for_backward(x, weight)
+        ctx.bias_ptr = bias.data_ptr()
         return (y, x.view(B, H, W, Cc)) if alias else y
 
     @staticmethod
@@ -1149,8 +1223,15 @@ class DwConv7NHWC(torch.autograd.Function):
             ws = torch.empty(nws, device=x.device, dtype=torch.float32)
             dw = torch.empty(Cc, 1, 7, 7, device=x.device, dtype=torch.float32)
             db = torch.empty(Cc, device=x.device, dtype=torch.float32)
-            L.check(lib.kpf_dwconv7_wgrad_f32(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nws, B, H, W, Cc, st),
-                    "kpf_dwconv7_wgrad_f32")
+            grp = DeferredParamGrads.wants_reduce(weight, Cc, ctx.bias_ptr)
+            if grp is not None:
+                desc = L.WgradReduceDesc()
+                L.check(lib.kpf_dwconv7_wgrad_deferred(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nws, B, H, W, Cc, C.byref(desc), st),
+                        "kpf_dwconv7_wgrad_deferred")
+                grp.add_reduce(desc, ws, weight, dw, ctx.bias_ptr, db)
+            else:
+                L.check(lib.kpf_dwconv7_wgrad_f32(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nws, B, H, W, Cc, st),
+                        "kpf_dwconv7_wgrad_f32")
         return dx, dw, db, None, None, None
 
 
@@ -2194,6 +2275,7 @@ class LinearSlices(torch.autograd.Function):
             conv(_OddPack(pc, Kp), Act(xc.view(-1), 1, 1, rows, Kp, n * Kp, Kp * i), out=Act(y.view(-1), 1, 1, rows, N, n * N, N * i))
         ctx.save_for_backward(xc, *ws)
         ctx.meta = (n, N, K, Kp, [b is not None for b in bs])
+        ctx.bias_ptrs = [None if b is None else b.data_ptr() for b in bs]
         return y
 
     @staticmethod
@@ -2211,8 +2293,8 @@ class LinearSlices(torch.autograd.Function):
             wsb = torch.empty(nws, device=xc.device, dtype=torch.float32)
             dw = torch.empty(tuple(ws[i].shape), device=xc.device, dtype=torch.float32)
             db = torch.empty(N, device=xc.device, dtype=torch.float32) if has_b[i] else None
-            L.check(lib.kpf_conv2d_wgrad_groups(dy.data_ptr() + 4 * N * i, xc.data_ptr() + 4 * Kp * i, L.KPF_DT_F32, dw.data_ptr(), db.data_ptr() if db is not None else None,
-                                                wsb.data_ptr(), nws, 1, 1, 1, rows, Kp, n * Kp, 1, rows, N, n * N, 1, 1, 1, 1, 0, 0, K, N, st), "kpf_conv2d_wgrad_groups")
+            _wgrad_groups(lib, dy.data_ptr() + 4 * N * i, xc.data_ptr() + 4 * Kp * i, L.KPF_DT_F32, dw, db, wsb, nws, 1,
+                          (1, 1, rows, Kp, n * Kp, 1, rows, N, n * N, 1, 1, 1, 1, 0, 0, K, N), st, weight=ws[i], bias_ptr=ctx.bias_ptrs[i])
             grads += [dw, db]
         return (None, None, None) + tuple(grads)
 
@@ -2249,6 +2331,7 @@ class LinearCat(torch.autograd.Function):
             kps.append((K, Kp))
         ctx.save_for_backward(*xcs, *ws)
         ctx.meta = (n, N, kps, [b is not None for b in bs], keys, cache)
+        ctx.bias_ptrs = [None if b is None else b.data_ptr() for b in bs]
         return y
 
     @staticmethod
@@ -2278,8 +2361,8 @@ class LinearCat(torch.autograd.Function):
                 wsb = torch.empty(nws, device=dy.device, dtype=torch.float32)
                 dw = torch.empty(tuple(ws[i].shape), device=dy.device, dtype=torch.float32)
                 db = torch.empty(N, device=dy.device, dtype=torch.float32) if has_b[i] else None
-                L.check(lib.kpf_conv2d_wgrad_groups(dy.data_ptr() + 4 * N * i, xcs[i].data_ptr(), L.KPF_DT_F32, dw.data_ptr(), db.data_ptr() if db is not None else None,
-                                                    wsb.data_ptr(), nws, 1, 1, 1, rows, Kp, Kp, 1, rows, N, n * N, 1, 1, 1, 1, 0, 0, K, N, st), "kpf_conv2d_wgrad_groups")
+                _wgrad_groups(lib, dy.data_ptr() + 4 * N * i, xcs[i].data_ptr(), L.KPF_DT_F32, dw, db, wsb, nws, 1,
+                              (1, 1, rows, Kp, Kp, 1, rows, N, n * N, 1, 1, 1, 1, 0, 0, K, N), st, weight=ws[i], bias_ptr=ctx.bias_ptrs[i])
             grads += [dw, db]
         return (None, None, None) + tuple(dxs) + tuple(grads)
 
@@ -2544,9 +2627,8 @@ class Conv2dNHWC(torch.autograd.Function):
                 ws = torch.empty(nws, device=x.device, dtype=torch.float32)
                 dw = torch.empty(tuple(weight.shape), device=x.device, dtype=torch.float32)
                 db = torch.empty(N, device=x.device, dtype=torch.float32) if want_db else None
-                L.check(lib.kpf_conv2d_wgrad_groups(dyp.data_ptr(), x.data_ptr(), _KDT[tdt], dw.data_ptr(), db.data_ptr() if want_db else None, ws.data_ptr(), nws, 1,
-                                                    B, H, W, cpad, cpad, H, W, npad, npad, 1, 1, 1, 1, 0, 0, Cw, N, torch.cuda.current_stream().cuda_stream),
-                        "kpf_conv2d_wgrad_groups")
+                _wgrad_groups(lib, dyp.data_ptr(), x.data_ptr(), _KDT[tdt], dw, db, ws, nws, 1, (B, H, W, cpad, cpad, H, W, npad, npad, 1, 1, 1, 1, 0, 0, Cw, N),
+                              torch.cuda.current_stream().cuda_stream, weight=weight, bias_ptr=ctx.bias_ptr)
             return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None, None
         if G > 1:  # channel-stacked groups: the same three GEMMs, one launch each for all groups
             key, cache = ctx.pack
@@ -2563,7 +2645,7 @@ class Conv2dNHWC(torch.autograd.Function):
                     dx = _conv_any(_grouped_pack(cache, key, wd, None, G, 1, prec, pad=pad, n_pad=n), dyc, prec, **gg).view(B, H, W, Cin)
                 dx = dx.to(ctx.x_dtype)
             if ctx.needs_input_grad[1]:
-                dw, db = conv_wgrad_hip(dy, x, weight.shape, stride, pad, has_bias and ctx.needs_input_grad[2], groups=G)
+                dw, db = conv_wgrad_hip(dy, x, weight.shape, stride, pad, has_bias and ctx.needs_input_grad[2], groups=G, weight=weight, bias_ptr=ctx.bias_ptr)
             return dx, dw, db, None, None, None, None, None, None, None, dres, None, None, None, None
         if ctx.needs_input_grad[0]:
             wsrc = ctx.w16 if ctx.w16 is not None else weight.detach()
@@ -2600,7 +2682,7 @@ class Conv2dNHWC(torch.autograd.Function):
                 db = torch.empty(N, device=x.device, dtype=torch.float32) if want_db else None
                 grp.add(ctx.pack[0], dyc, xc, dw, db, ctx.bias_ptr if want_db else None)
             else:
-                dw, db = conv_wgrad_hip(dy, x, weight.shape, stride, pad, want_db)
+                dw, db = conv_wgrad_hip(dy, x, weight.shape, stride, pad, want_db, weight=weight, bias_ptr=ctx.bias_ptr)
             return dx, dw, db, None, None, None, None, None, None, None, dres, None, None, None, None
         if ctx.needs_input_grad[1]:
             xw = x if prec == "f32" else x.to(_TDT[prec])  # weight gradient in the compute precision, handed to the fp32 master weight
@@ -2816,6 +2898,8 @@ class GraphedTrainStep:
         cur = torch.cuda.current_stream(p.device)
         b.setdefault("streams", {})[cur.cuda_stream] = cur  # (backward nodes run on their forward's stream: the unpaired backbones use two)
         if b["pending"] == 0:  # the bucket's last gradient exists: pack it (one multi-tensor copy, not one copy per parameter) and start its collective
+            if DeferredParamGrads.active is not None:  # (weight gradients whose batched reduce is still pending: issue it, on the pass's own stream)
+                DeferredParamGrads.active.flush_reduces()
             for st in b["streams"].values():  # gradients enqueued on other streams must be complete before this stream reads them
                 if st.cuda_stream != cur.cuda_stream:
                     cur.wait_stream(st)

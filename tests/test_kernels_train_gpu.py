@@ -684,6 +684,67 @@ def test_deferred_layernorm_and_layer_scale_parameter_sums_are_bit_identical():
         assert torch.equal(a, b), (i, float((a.float() - b.float()).abs().max()))
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_batched_weight_gradient_reduces_are_bit_identical(dt):
+    """training.DeferredParamGrads, reduce half (kpf_conv2d_wgrad_deferred / kpf_dwconv7_wgrad_deferred + kpf_wgrad_reduce_multi): the fixed-order
+    reduces behind the split weight-gradient GEMMs of a backward pass issued in one launch per 24 calls — same bits as a reduce launch per
+    call; dense / 3x3 / strided / grouped / depthwise layers, more calls than one launch carries, a paired parameter (two parameters side by
+    side behind one weight tensor) and a parameter outside the name map (keeps its own reduce)."""
+    from keypointfusion_amd import training as T
+    g = torch.Generator().manual_seed(12)
+    prec = "f32" if dt == torch.float32 else "bf16"
+    layers, named = [], {}
+    shapes = [(2, 24, 24, 32, 64, 1, 1, 0, 1), (2, 24, 24, 64, 32, 3, 1, 1, 1), (4, 16, 16, 32, 64, 2, 2, 0, 1), (2, 24, 24, 64, 64, 1, 1, 0, 2),
+              (8, 32, 32, 96, 384, 1, 1, 0, 1), (2, 20, 20, 48, 24, 3, 2, 1, 1)]
+    for i in range(30):
+        B, H, W, cin, n, k, s, pd, G = shapes[i % len(shapes)]
+        w = torch.nn.Parameter((torch.randn(n, cin // G, k, k, generator=g) * 0.1).cuda())
+        b = torch.nn.Parameter(torch.randn(n, generator=g).cuda())
+        x = torch.randn(B, H, W, cin, generator=g).cuda().requires_grad_(True)
+        layers.append(("conv", w, b, x, s, pd, G))
+        if i != 7:
+            named["c%d.weight" % i], named["c%d.bias" % i] = w, b
+    for i in range(6):
+        c = [32, 96][i % 2]
+        w = torch.nn.Parameter((torch.randn(c, 1, 7, 7, generator=g) * 0.1).cuda())
+        b = torch.nn.Parameter(torch.randn(c, generator=g).cuda())
+        layers.append(("dw", w, b, torch.randn(2, 24, 24, c, generator=g).cuda().requires_grad_(True), 1, 3, 1))
+        named["d%d.weight" % i], named["d%d.bias" % i] = w, b
+    reg = {}
+    pa, pb = [torch.nn.Parameter((torch.randn(64, 32, 1, 1, generator=g) * 0.1).cuda()) for _ in range(2)]
+    ba, bb = [torch.nn.Parameter(torch.randn(64, generator=g).cuda()) for _ in range(2)]
+    T.pair_storage(reg, "pw", pa, pb), T.pair_storage(reg, "pbias", ba, bb)
+    named.update({"a.weight": pa, "b.weight": pb, "a.bias": ba, "b.bias": bb})
+    xp = torch.randn(2, 24, 24, 64, generator=g).cuda().requires_grad_(True)
+    params = [t for l in layers for t in l[1:4]] + [pa, pb, ba, bb, xp]
+
+    def run(deferred):
+        for t in params:
+            t.grad = None
+        ctx = T.DeferredParamGrads(named) if deferred else __import__("contextlib").nullcontext()
+        with ctx as grp:
+            tot = 0
+            for kind, w, b, x, s, pd, G in layers:
+                if kind == "conv":
+                    y = T.conv2d_nhwc(x.to(dt) if dt != torch.float32 else x, w, b, stride=s, pad=pd, prec=prec, groups=G)
+                else:
+                    y = T.dwconv7_nhwc(x, w, b)
+                tot = tot + y.float().square().sum()
+            wp = T.pair_params(reg, "pw", pa, pb).view(128, 32, 1, 1)
+            bp = T.pair_params(reg, "pbias", ba, bb).view(128)
+            tot = tot + T.conv2d_nhwc(xp.to(dt) if dt != torch.float32 else xp, wp, bp, prec=prec, groups=2).float().square().sum()
+            tot.backward()
+            n = grp.n_reduces if deferred else 0
+        torch.cuda.synchronize()
+        return n, [t.grad.clone() for t in params]
+
+    n0, ref = run(False)
+    n1, got = run(True)
+    assert n0 == 0 and 25 <= n1 <= 36, n1  # (a call whose tiles fill the chip writes its gradient directly; the unnamed layer reduces at once)
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert torch.equal(a, b), (i, float((a.float() - b.float()).abs().max()))
+
+
 def test_joint_heatmap_and_geometry_gate_match_torch():
     """training.JointHeatmap / training.GeomGate (one launch each way) against the torch expressions they replace in the fusion block
     (GFM.joint2heatmap; 1 / (10 |pixel - joint|^2 + 1)) in float64: values and the gradients towards the joints, joints on / off the map."""
