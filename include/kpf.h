@@ -345,6 +345,11 @@ int kpf_conv2d_wgrad_groups(const void* dy, const void* x, int dtype, float* dw,
 
 /* Row pad / column-slice copy / type change in one launch, and the pose tokens of a fusion block at their padded width (csrc/kpf_train.hip). */
 int kpf_pad_rows(const void* src, int src_dtype, void* dst, int dst_dtype, long rows, int C, int src_ld, int Cp, void* stream);
+/* Training (ABI 17): channel-stacked maps of G <= 4 paired networks <-> one dense fp32 map per network (train_graph.TrainGraph._forward: the seam between the
+ * paired backbones and the fusion head).  src [rows][ld] (KPF_DT_*), group g's C channels at column g * gs; dst [G][rows][C] fp32.  kpf_restack_rows is the
+ * gradient: grads[g] fp32 [rows][C] or NULL (zero) -> dst [rows][ld] of dst_dtype, every column (also the pad columns) written once. */
+int kpf_unstack_rows(const void* src, int src_dtype, float* dst, long rows, int G, int C, int ld, int gs, void* stream);
+int kpf_restack_rows(const float* const* grads, void* dst, int dst_dtype, long rows, int G, int C, int ld, int gs, void* stream);
 int kpf_pose_tokens_f32(const float* pw, const float* joint, const float* pcl, float* out, int B, int N, int J, int ld, float kernel, void* stream);
 /* out = relu(scale * (a + b + c)) (b, c nullable; fp32, n % 4 == 0) and d = out > 0 ? scale * dy : 0 — the gradient of every addend (ABI 13;
  * model/model.py:190, 417-422). */
@@ -435,6 +440,9 @@ int kpf_upsample2x_bwd(const void* dy, void* dx, int dtype, int B, int H, int W,
 int kpf_maxpool3x3s2_fwd(const void* x, void* y, unsigned char* tap, int dtype, int B, int H, int W, int C, void* stream);
 int kpf_maxpool3x3s2_bwd(const void* dy, const unsigned char* tap, void* dx, int dtype, int B, int H, int W, int C, void* stream);
 int kpf_row_gather_fwd_f32(const float* src, const int* idx, const float* w, float* out, int B, int P, int R, int G, int C, void* stream);
+/* ABI 17: the forward alone for a column slice of any width C of rows ld >= C floats apart (out [B][R][C] dense; same sum order over g): the 21 weight-logit
+ * channels the pose tokens sample (model/model.py:372-376, detached there). */
+int kpf_row_gather_cols_f32(const float* src, int ld, const int* idx, const float* w, float* out, int B, int P, int R, int G, int C, void* stream);
 long kpf_row_gather_ws_ints(int B, int P, int R, int G);
 int kpf_row_gather_bwd_f32(const float* dout, const int* idx, const float* w, float* dsrc, int* ws, long ws_ints, int B, int P, int R, int G, int C,
                            void* stream);
@@ -604,7 +612,10 @@ typedef struct kpf_colsum_desc {
   const float* part; /* [nblk][2][C] */
   float* dw;         /* column sums of plane 0 */
   float* db;         /* column sums of plane 1 */
-  int nblk, C, first_block, reserved;
+  int nblk, C, first_block;
+  int reserved;      /* ABI 17: that many floats behind db[C - 1] are set to zero (0: none) — the sum over the batch of a [B][T*C] gradient of the first T rows of an
+                        embedding table [L][C] written as the table's whole gradient: part = the [B][T*C] tensor read as [B][2][T*C/2], dw = the table's gradient,
+                        db = dw + T*C/2, reserved = (L - T) * C (model/model.py:84 position embeddings; model/transfusion_head.py:150-152) */
 } kpf_colsum_desc;
 int kpf_ln_train_backward_partial(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd, const float* w, float* dx, float* dw,
                                   float* db, float* ws, long ws_floats, long rows, int C, kpf_colsum_desc* desc, void* stream);

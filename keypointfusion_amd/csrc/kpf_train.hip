@@ -373,6 +373,30 @@ extern "C" int kpf_maxpool3x3s2_bwd(const void* dy, const unsigned char* tap, vo
 #undef CALL
 }
 
+// the same gather for a COLUMN SLICE of any width (no channel quads, rows ld floats apart): the 21 weight-logit channels of the offset map that the pose tokens
+// sample (model/model.py:372-376; no gradient: the reference detaches them) — one thread per output element; the library path was cast + gather + mul + sum
+namespace {
+__global__ __launch_bounds__(256) void row_gather_cols_kernel(const float* __restrict__ src, const int* __restrict__ idx, const float* __restrict__ w,
+                                                              float* __restrict__ out, long total, int P, int R, int G, int C, int ld) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / C;
+    const int c = (int)(i - r * C);
+    const int b = (int)(r / R);
+    const int* ip = idx + r * G;
+    float acc = 0.f;
+    for (int g = 0; g < G; ++g) acc += (w ? w[r * G + g] : 1.f) * src[((long)b * P + ip[g]) * ld + c];
+    out[i] = acc;
+  }
+}
+}  // namespace
+
+extern "C" int kpf_row_gather_cols_f32(const float* src, int ld, const int* idx, const float* w, float* out, int B, int P, int R, int G, int C, void* stream) {
+  KPF_REQUIRE(src && idx && out && B > 0 && P > 0 && R > 0 && G > 0 && C > 0 && ld >= C, "kpf_row_gather_cols_f32: bad arguments");
+  const long total = (long)B * R * C;
+  hipLaunchKernelGGL(row_gather_cols_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, idx, w, out, total, P, R, G, C, ld);
+  return kpf_check_launch("kpf_row_gather_cols_f32");
+}
+
 extern "C" int kpf_row_gather_fwd_f32(const float* src, const int* idx, const float* w, float* out, int B, int P, int R, int G, int C, void* stream) {
   KPF_REQUIRE(src && idx && out && B > 0 && P > 0 && R > 0 && G > 0 && C > 0 && C % 4 == 0, "kpf_row_gather_fwd_f32: bad arguments");
   const long rows = (long)B * R;
@@ -782,7 +806,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, 
 
 // 64 columns x 8 segments per workgroup: segment g adds the partials of workgroups g*per .. (g+1)*per - 1 in order, the eight segment
 // sums are added in segment order through LDS (fixed order, 8 x fewer dependent loads per thread than one thread per column)
-__device__ __forceinline__ void ln_bwd_reduce_body(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nblk, int C, int bx) {
+// (tail: that many floats behind db's C are set to zero — the gradient of an embedding table of which only a prefix was used, kpf_colsum_desc::reserved)
+__device__ __forceinline__ void ln_bwd_reduce_body(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nblk, int C, int bx, int tail = 0) {
   __shared__ float seg[8][64];
   const int col = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int i = bx * 64 + col;
@@ -807,6 +832,8 @@ __device__ __forceinline__ void ln_bwd_reduce_body(const float* __restrict__ par
     for (int k = 0; k < 8; ++k) t += seg[k][col];
     const int which = i / C, c = i - which * C;
     (which ? db : dw)[c] = t;
+  } else if (g == 0 && i < 2 * C + tail) {
+    db[i - C] = 0.f;
   }
 }
 
@@ -832,7 +859,7 @@ __global__ __launch_bounds__(512) void colsum_reduce_grouped_kernel(const Colsum
     if ((int)blockIdx.x >= bp->d[mid].first_block) lo = mid;
     else hi = mid - 1;
   }
-  ln_bwd_reduce_body(bp->d[lo].part, bp->d[lo].dw, bp->d[lo].db, bp->d[lo].nblk, bp->d[lo].C, (int)blockIdx.x - bp->d[lo].first_block);
+  ln_bwd_reduce_body(bp->d[lo].part, bp->d[lo].dw, bp->d[lo].db, bp->d[lo].nblk, bp->d[lo].C, (int)blockIdx.x - bp->d[lo].first_block, bp->d[lo].reserved);
 }
 
 __device__ __forceinline__ float gelu_exact(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
@@ -939,9 +966,9 @@ extern "C" int kpf_colsum_reduce_grouped(const kpf_colsum_desc* descs, int n, vo
     long blocks = 0;
     for (int k = 0; k < b.nd; ++k) {
       b.d[k] = descs[base + k];
-      KPF_REQUIRE(b.d[k].part && b.d[k].dw && b.d[k].db && b.d[k].nblk > 0 && b.d[k].C > 0, "kpf_colsum_reduce_grouped: bad descriptor %d", base + k);
+      KPF_REQUIRE(b.d[k].part && b.d[k].dw && b.d[k].db && b.d[k].nblk > 0 && b.d[k].C > 0 && b.d[k].reserved >= 0, "kpf_colsum_reduce_grouped: bad descriptor %d", base + k);
       b.d[k].first_block = (int)blocks;
-      blocks += (2 * b.d[k].C + 63) / 64;
+      blocks += (2 * b.d[k].C + b.d[k].reserved + 63) / 64;
     }
     hipLaunchKernelGGL(colsum_reduce_grouped_kernel, dim3((unsigned)blocks), dim3(512), 0, st, b);
     const int rc = kpf_check_launch("kpf_colsum_reduce_grouped");
@@ -2170,6 +2197,70 @@ extern "C" int kpf_pad_rows(const void* src, int src_dtype, void* dst, int dst_d
   }
 #undef PR
   return kpf_check_launch("kpf_pad_rows");
+}
+
+// Round 6: the seam between the paired backbones and the fusion head.  The backbones' maps arrive channel-stacked ([rows][G * gs] in the step's storage type, group
+// g's C channels at column g * gs); the head wants one dense fp32 map per backbone.  Forward: all G maps in ONE launch (dst [G][rows][C] fp32); backward: the G
+// gradients (fp32 [rows][C] each, any of them NULL = zero) back into ONE stacked tensor of the storage type, every element (pad columns included) written once —
+// instead of a strided cast per map forward and cast + zero fill + strided copy + fan-in add per map backward (~15 library launches per iteration).
+namespace {
+struct RestackSrc { const float* g[4]; };
+template <typename TS>
+__global__ __launch_bounds__(256) void unstack_rows_kernel(const TS* __restrict__ src, float* __restrict__ dst, long rows, int G, int C, int ld, int gs) {
+  const long per = rows * C, total = per * G;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int g = (int)(i / per);
+    const long j = i - g * per;
+    const long r = j / C;
+    const int c = (int)(j - r * C);
+    dst[i] = (float)src[r * ld + g * gs + c];
+  }
+}
+template <typename TD>
+__global__ __launch_bounds__(256) void restack_rows_kernel(const RestackSrc s, TD* __restrict__ dst, long rows, int G, int C, int ld, int gs) {
+  const long total = rows * ld;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / ld;
+    const int col = (int)(i - r * ld);
+    const int g = col / gs, c = col - g * gs;
+    float v = 0.f;
+    if (g < G && c < C) {
+      const float* p = s.g[g];
+      if (p) v = p[r * C + c];
+    }
+    dst[i] = (TD)v;
+  }
+}
+}  // namespace
+
+extern "C" int kpf_unstack_rows(const void* src, int src_dtype, float* dst, long rows, int G, int C, int ld, int gs, void* stream) {
+  KPF_REQUIRE(src && dst && rows > 0 && G >= 1 && G <= 4 && C > 0 && gs >= C && ld >= (G - 1) * gs + C, "kpf_unstack_rows: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid(grid_for(rows * C * G));
+  if (src_dtype == KPF_DT_F32) hipLaunchKernelGGL(unstack_rows_kernel<float>, grid, dim3(256), 0, st, static_cast<const float*>(src), dst, rows, G, C, ld, gs);
+  else if (src_dtype == KPF_DT_BF16) hipLaunchKernelGGL(unstack_rows_kernel<bf16_t>, grid, dim3(256), 0, st, static_cast<const bf16_t*>(src), dst, rows, G, C, ld, gs);
+  else if (src_dtype == KPF_DT_F16) hipLaunchKernelGGL(unstack_rows_kernel<f16_t>, grid, dim3(256), 0, st, static_cast<const f16_t*>(src), dst, rows, G, C, ld, gs);
+  else {
+    kpf_set_error("kpf_unstack_rows: unsupported dtype %d", src_dtype);
+    return KPF_EINVAL;
+  }
+  return kpf_check_launch("kpf_unstack_rows");
+}
+
+extern "C" int kpf_restack_rows(const float* const* grads, void* dst, int dst_dtype, long rows, int G, int C, int ld, int gs, void* stream) {
+  KPF_REQUIRE(grads && dst && rows > 0 && G >= 1 && G <= 4 && C > 0 && gs >= C && ld >= (G - 1) * gs + C, "kpf_restack_rows: bad arguments");
+  RestackSrc s{};
+  for (int g = 0; g < G; ++g) s.g[g] = grads[g];
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid(grid_for(rows * ld));
+  if (dst_dtype == KPF_DT_F32) hipLaunchKernelGGL(restack_rows_kernel<float>, grid, dim3(256), 0, st, s, static_cast<float*>(dst), rows, G, C, ld, gs);
+  else if (dst_dtype == KPF_DT_BF16) hipLaunchKernelGGL(restack_rows_kernel<bf16_t>, grid, dim3(256), 0, st, s, static_cast<bf16_t*>(dst), rows, G, C, ld, gs);
+  else if (dst_dtype == KPF_DT_F16) hipLaunchKernelGGL(restack_rows_kernel<f16_t>, grid, dim3(256), 0, st, s, static_cast<f16_t*>(dst), rows, G, C, ld, gs);
+  else {
+    kpf_set_error("kpf_restack_rows: unsupported dtype %d", dst_dtype);
+    return KPF_EINVAL;
+  }
+  return kpf_check_launch("kpf_restack_rows");
 }
 
 /* The pose tokens of a fusion block (model/model.py:308-316, 417): out[b][n] = [pw[b][n][0..J) | unit offsets (j, xyz) 3J | closeness J | zeros up to ld];

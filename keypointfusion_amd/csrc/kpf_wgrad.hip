@@ -36,6 +36,7 @@ struct WgradArgs {
   int H, W, Cin, ldx, OH, OW, N, ldy, KH, KW, sh, sw, ph, pw;
   int M, K, tilesK, stages_per_split;
   int is1x1;
+  int xcd;       // wgrad_h16s_kernel: XCD-aware tile order (xcd_slab_remap)
   int emul_sps;  // grouped form only: stages per split of the split + reduce form whose summation order it reproduces
   // channel-grouped launch (kpf_conv2d_wgrad_groups, grid.z = group): group g reads dy + g*g_dy / x + g*g_x (elements) and writes part + g*g_part,
   // dbpart + g*g_db (floats).  All zero for an ordinary launch (blockIdx.z is 0 there).
@@ -560,6 +561,17 @@ constexpr int HS_SP = 128;   // pixels per stage (32 per wave)
 
 __device__ __forceinline__ int hs_swz(int row) { return 2 * (((row >> 1) & 1) | (((row >> 3) & 1) << 1)); }
 
+// XCD-aware order of the tiles of one (split, group) slab of the grid: workgroups are handed to the 8 XCDs (private 4-MB L2s) round-robin in dispatch
+// order (x fastest, then y, z); the slab's workgroups that land on one XCD get a CONTIGUOUS range of (n tile, k tile) pairs, k tiles fastest — so an XCD
+// reads 1/8 of dY's columns (and all of X) instead of every XCD reading everything.  Bijective on [0, gx) for any gx and slab offset.
+__device__ __forceinline__ int xcd_slab_remap(int x, int gx, int slab) {
+  const int o = (int)(((long)gx * slab) & 7);
+  const int c = (x + o) & 7;
+  int before = 0;
+  for (int cc = 0; cc < c; ++cc) before += (o + gx - cc + 7) / 8 - (o - cc + 7) / 8;
+  return before + (x - ((c - o) & 7)) / 8;
+}
+
 template <typename TIN, int HS_NS>  // HS_NS: LDS ring depth; per wave and buffer 32 rows x 128 B x (A + B) = 8 KB (3: 96 KB per workgroup, 2: 64 KB)
 __global__ __launch_bounds__(256) void wgrad_h16s_kernel(const WgradArgs a0) {
   const WgradArgs a = wg_group_args<TIN>(a0);
@@ -568,7 +580,8 @@ __global__ __launch_bounds__(256) void wgrad_h16s_kernel(const WgradArgs a0) {
   constexpr int WREG = HS_NS * WBUF;           // one wave's region (24 KB)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nt = blockIdx.x / a.tilesK, kt = blockIdx.x % a.tilesK;
+  const int bid = a.xcd ? xcd_slab_remap((int)blockIdx.x, (int)gridDim.x, (int)(blockIdx.y + gridDim.y * blockIdx.z)) : (int)blockIdx.x;
+  const int nt = bid / a.tilesK, kt = bid % a.tilesK;
   const int n0 = nt * HS_TB, k0 = kt * HS_TB;
   const int split = blockIdx.y;
   const int total_stages = (a.M + HS_SP - 1) / HS_SP;
@@ -1076,6 +1089,8 @@ static int conv2d_wgrad_impl(const void* dy, const void* x, int dtype, float* dw
   a.sh = sh, a.sw = sw, a.ph = ph, a.pw = pw, a.M = (int)M, a.K = (int)K, a.tilesK = p.tilesK, a.stages_per_split = p.sps;
   a.is1x1 = KH == 1 && KW == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0 && OH == H && OW == W;
   a.emul_sps = 0;
+  static const int xcd_order = []() { const char* e = getenv("KPF_WG16S_XCD"); return e ? atoi(e) : 1; }();  // tuning aid: 0 = tiles in dispatch order
+  a.xcd = xcd_order;
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (h16s) {

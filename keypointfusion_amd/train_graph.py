@@ -47,6 +47,7 @@ XATTN_FUSED = bool(int(os.environ.get("KPF_XATTN_FUSED", "1")))  # the decoder l
 TR_MMA = os.environ.get("KPF_TR_MMA", "auto")  # GEMM arithmetic of the fused stacks: "auto" = the module's precision; "f32" | "bf16" | "f16" force one
 # 1 (default): DESA's three radii as ONE channel-stacked chain — grouped Linears (G = 3), BatchNorm / add + ReLU / group maximum over 3 x 128 channels, one
 # grouping launch each way (training.BallGroup3 / LinearSlices / GroupMax) — instead of three chains of small launches; 0: radius by radius
+UNSTACK_FUSED = bool(int(os.environ.get("KPF_UNSTACK_FUSED", "1")))  # the paired backbones' maps -> dense fp32 maps in two launches each way (training.UnstackRows)
 DESA_GROUPED = bool(int(os.environ.get("KPF_DESA_GROUPED", "1")))
 # 1 (default): the sibling embeddings of a fusion block (Conv1d + BatchNorm1d each, then summed under a ReLU: model/model.py:254-259, 417-422) write ONE
 # channel-stacked tensor — one BatchNorm pass over n x 128 channels, one sum + ReLU launch each way (training.LinearCat / SlicesSumRelu); 0: one by one
@@ -329,6 +330,8 @@ class TrainGraph:
                 bs.append(self.zeros((G, npad - n), bs[0].device))
             w, b = torch.cat(ws, 1), torch.cat(bs, 1)
             y = conv2d_nhwc(feat.contiguous(), w.view((G * npad,) + tuple(w.shape[2:])), b.view(-1), 1, 0, self.prec, None, None, None, G)
+            if UNSTACK_FUSED:  # (unet() hands the stacked rows to training.unstack_rows: network g's n channels at column g * npad)
+                return y, n, npad
             return y.view(y.shape[:-1] + (G, npad))[..., :n]
         ws = [self.t[p + ".finals.%d.weight" % i] for i in range(3)]
         bs = [self.t[p + ".finals.%d.bias" % i] for i in range(3)]
@@ -358,6 +361,11 @@ class TrainGraph:
         if convnext:
             feat = self.residual(p + ".result_emb", feat)
         res = self.heads(p, feat)
+        if G > 1 and UNSTACK_FUSED:  # -> ((res_rgb, feat_rgb), (res_d, feat_d)): one dense fp32 NHWC map per backbone, two launches for the four maps
+            from .training import unstack_rows
+            y, n, npad = res
+            cf = feat.shape[-1] // G
+            return tuple(zip(unstack_rows(y, G, n, npad), unstack_rows(feat, G, cf, cf)))
         if G > 1:  # -> ((res_rgb, feat_rgb), (res_d, feat_d)): each backbone's channel slice of the stacked maps, NHWC (strided views)
             fs = feat.view(feat.shape[:-1] + (G, -1))
             return tuple((res[..., g, :], fs[..., g, :]) for g in range(G))
@@ -544,8 +552,8 @@ class TrainGraph:
             self.attn_calls += 13
             # (mixed precision: the stack's products take 16-bit operands like the backbones' — what autocast gives the reference's Linears; KPF_TR_MMA=f32 keeps fp32)
             mma = getattr(self.m, "precision", "f32") if TR_MMA == "auto" else TR_MMA
-            h = bert_stack21(e, PrefixRows.apply(self.t[p + ".bert.position_embeddings.weight"], T), names, self.packs, self.pd, self.rng(x.device), call0,
-                             [self.t[n] for n in names], mma)
+            # (the whole position table goes in: the stack reads its first 21 rows and hands back the table's gradient through the grouped column-sum launch)
+            h = bert_stack21(e, self.t[p + ".bert.position_embeddings.weight"], names, self.packs, self.pd, self.rng(x.device), call0, [self.t[n] for n in names], mma)
         else:
             h = self.linear(x, p + ".bert.img_embedding.weight", p + ".bert.img_embedding.bias") + PrefixRows.apply(self.t[p + ".bert.position_embeddings.weight"], T)
             h = self.drop(h)  # TR_Encoder applies the embedding dropout (model/model.py:84)
@@ -564,7 +572,7 @@ class TrainGraph:
             call0 = self.attn_calls + 1
             self.attn_calls += 4
             mma = getattr(self.m, "precision", "f32") if TR_MMA == "auto" else TR_MMA
-            return xattn_layer21(query, key, PrefixRows.apply(self.t[p + ".self_posembed.weight"], T), PrefixRows.apply(self.t[p + ".cross_posembed.weight"], T), names,
+            return xattn_layer21(query, key, self.t[p + ".self_posembed.weight"], self.t[p + ".cross_posembed.weight"], names,
                                  self.packs, self.pd, self.rng(query.device), call0, [self.t[n] for n in names], mma)
         qe = query + PrefixRows.apply(self.t[p + ".self_posembed.weight"], T)
         ke = key + PrefixRows.apply(self.t[p + ".cross_posembed.weight"], T)
@@ -586,9 +594,13 @@ class TrainGraph:
               img_size, flip):
         from .training import GateMix, GeomGateUVD, JointHeatmap
         B, C, H, W = img_feat.shape
-        pf = self.gather_interp(img_feat, idx, clos, self.idx_inv)  # (the four feature samplings of a forward share one index tensor: inverted once)
-        pf_rgb = self.gather_interp(img_feat_rgb, idx, clos, self.idx_inv)
-        pw = self.gather_interp(img_offset[:, J * 4:], idx, clos).detach()
+        if self.samples is None:
+            # the point samplings of the two feature maps and of the weight logits (model/model.py:368-376) read the same maps with the same indices and
+            # weights in both blocks: computed once per forward (the reference recomputes identical tensors), as is the softmax of the logits
+            pw = self.gather_interp(img_offset[:, J * 4:], idx, clos).detach()
+            self.samples = (self.gather_interp(img_feat, idx, clos, self.idx_inv), self.gather_interp(img_feat_rgb, idx, clos, self.idx_inv), pw,
+                            F.softmax(pw.permute(0, 2, 1), -1))
+        pf, pf_rgb, pw, att = self.samples
         tok = self.pose_tokens(pw, joint_xyz, pcl, 0.8)  # [pw | pcl_joint2offset(joint, pcl) | 0 0 0]: 105 channels at the GEMM's width 108, no gradient
         grouped = EMB_GROUPED and self.prec == "f32"
         if grouped:  # relu(relu(feat + xyz + pose) + rgb feat): four Linears into one [B*N, 4 x 128] tensor, one BatchNorm pass, one sum + ReLU
@@ -596,7 +608,6 @@ class TrainGraph:
         else:
             x = add_relu(self.emb1d(p + ".pcl_feat_emb", pf), self.emb1d(p + ".pcl_xyz_emb", self.pcl4), self.emb1d(p + ".pcl_pose_emb", tok))
             x = add_relu(x, self.emb1d(p + ".pcl_feat_emb_RGB", pf_rgb))
-        att = F.softmax(pw.permute(0, 2, 1), -1)
         jf = bmm_small_k(att, x)
         if grouped:
             from .training import pad_rows
@@ -662,7 +673,7 @@ class TrainGraph:
                 (img_offset_rgb, img_feat_rgb), (img_offset, img_feat) = self.unet(PAIR[:-1], (img_rgb, img))
             self.G = 1
             # one dense fp32 copy per map (the slices are strided, 16-bit under mixed precision), then the channels_last view the head's consumers expect
-            nchw = lambda t: t.float().contiguous().permute(0, 3, 1, 2)
+            nchw = (lambda t: t.permute(0, 3, 1, 2)) if UNSTACK_FUSED else (lambda t: t.float().contiguous().permute(0, 3, 1, 2))
             img_offset_rgb, img_feat_rgb, img_offset, img_feat = nchw(img_offset_rgb), nchw(img_feat_rgb), nchw(img_offset), nchw(img_feat)
         else:
             side.wait_stream(main) if side is not main else None
@@ -685,6 +696,7 @@ class TrainGraph:
         N = pcl.shape[1]
         Minv = crop_inverse(M)
         off_d = img_offset.detach().contiguous()  # model/model.py:404-405: the decode and the pose tokens see detached maps
+        off_v = img_offset.detach()  # (the same map as the NCHW-shaped view of its NHWC memory: the pose tokens' gather reads its 21 weight-logit columns in place)
         joint_uvd = torch.empty(B, J, 3, device=dev)
         joint_xyz = torch.empty(B, J, 3, device=dev)
         L.check(lib.kpf_offset2joint_f32(_ptr(off_d), _ptr(img), _ptr(center), _ptr(Minv), _ptr(cube), _ptr(cam), _ptr(joint_uvd), _ptr(joint_xyz),
@@ -699,14 +711,14 @@ class TrainGraph:
         from .training import pad_rows
         self.pcl4 = pad_rows(pcl, 4)                                         # the points at the width pcl_xyz_emb's GEMM reads (both blocks)
         self.zpad3 = self.zeros((B, Fs, Fs, 3), dev)                         # the gate input's three zero channels (149 -> 152, both blocks)
-        self.frows = None
+        self.frows = self.samples = None
         from .training import ROW_GATHER_MAX_E, ROW_GATHER_MAX_P, row_gather_invert
         self.idx_inv = row_gather_invert(index, Fs * Fs) if (N * 4 <= ROW_GATHER_MAX_E and Fs * Fs <= ROW_GATHER_MAX_P) else None
         img_down = None  # (F.interpolate(img, [Fs, Fs]) in the reference, model/model.py:401: computed there and never read)
         sws = []
         prev = None
         for i in (1, 2):
-            r3d, r2d, prev, sw = self.block("block%d" % i, img_feat, img_feat_rgb, pcl, joint_xyz, clos, idx, off_d, prev, img_down, center,
+            r3d, r2d, prev, sw = self.block("block%d" % i, img_feat, img_feat_rgb, pcl, joint_xyz, clos, idx, off_v, prev, img_down, center,
                                             Minv, cube, cam, img_size, flip)
             result += [r3d, r2d]
             sws.append(sw)

@@ -1574,6 +1574,24 @@ def self_attention21(h, wq, bq, wk, bk, wv, bv, names, cache, heads, scale, p_dr
     return SelfAttention21.apply(h, wq, bq, wk, bk, wv, bv, names, cache, heads, scale, p_drop, rng, call_id)
 
 
+def _table_prefix_grad(table, dE, B, now_c):
+    """The gradient of an embedding table [L, C] of which the stacks used the first T rows, from the per-sample gradients dE [B, T, C] of those rows: their sum
+    over the batch, zero behind — ONE descriptor of the grouped column-sum launch (kpf_colsum_desc::reserved) instead of a sum launch and a zero-extending copy.
+    Deferred to the launch after backward when the table is a whole parameter without a gradient yet; appended to now_c otherwise."""
+    from . import lib as L
+    n = dE.numel() // B
+    assert n % 2 == 0 and table.numel() >= n and table.dtype == torch.float32
+    dt = torch.empty(tuple(table.shape), device=dE.device, dtype=torch.float32)
+    desc = L.ColsumDesc()
+    desc.part, desc.dw, desc.db, desc.nblk, desc.C, desc.first_block, desc.reserved = dE.data_ptr(), dt.data_ptr(), dt.data_ptr() + 2 * n, B, n // 2, 0, table.numel() - n
+    grp = DeferredParamGrads.wants_colsum(table)
+    if grp is not None:
+        grp.add_colsum(table, desc, dE, dt)
+    else:
+        now_c.append(desc)
+    return dt
+
+
 class BertStack21(torch.autograd.Function):
     """The four BERT layers of a KP_Interaction_TR stack (model/model.py:30-126: transformers' BertEncoder under .train(), 21 tokens x 128) as ONE launch each way
     (csrc/kpf_trstack.hip: kpf_tr_stack_train_forward / _backward; round 6) — h = layers(dropout(e + pos)) with e the embedding Linear's output.  The unfused
@@ -1611,15 +1629,17 @@ class BertStack21(torch.autograd.Function):
         from . import lib as L
         lib = L.load()
         B, T, Cc = e.shape
-        assert T == 21 and Cc == 128 and len(params) == 64 and len(names) == 64 and tuple(pos.shape) == (21, 128)
+        # pos: the position table [L >= 21, 128] (its first 21 rows are used; the backward returns the whole table's gradient) or exactly the 21 rows
+        assert T == 21 and Cc == 128 and len(params) == 64 and len(names) == 64 and pos.dim() == 2 and pos.shape[0] >= 21 and pos.shape[1] == 128
         ec, pc = e.float().contiguous(), pos.float().contiguous()
+        ctx.pos_rows = pos.shape[0]
         table = BertStack21.param_table(params)
         n = lib.kpf_tr_stack_save_floats(B)
         save = torch.empty(n, device=e.device, dtype=torch.float32)
         L.check(lib.kpf_tr_stack_train_forward(ec.data_ptr(), pc.data_ptr(), table.data_ptr(), save.data_ptr(), n, B, float(p_drop),
                                                rng.data_ptr() if (rng is not None and p_drop > 0) else None, int(call0), int(mma), torch.cuda.current_stream().cuda_stream),
                 "kpf_tr_stack_train_forward")
-        ctx.save_for_backward(save, table, *params)
+        ctx.save_for_backward(save, table, pos, *params)
         ctx.conf = (names, cache, float(p_drop), int(call0), B, int(mma))
         off = lib.kpf_tr_stack_out_offset(B)
         return save[off:off + B * T * Cc].view(B, T, Cc)
@@ -1628,7 +1648,7 @@ class BertStack21(torch.autograd.Function):
     def backward(ctx, dh):
         from . import lib as L
         lib = L.load()
-        save, table, *params = ctx.saved_tensors
+        save, table, pos, *params = ctx.saved_tensors
         names, cache, p_drop, call0, B, mma = ctx.conf
         M, dev = B * 21, save.device
         st = torch.cuda.current_stream().cuda_stream
@@ -1678,10 +1698,10 @@ class BertStack21(torch.autograd.Function):
             for d, (dy, x, dw, db, M_, N, K, ldy) in zip(arr, now_w):
                 d.dy, d.x, d.dw, d.db, d.M, d.N, d.K, d.ldy = dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(), M_, N, K, ldy
             L.check(lib.kpf_linear_wgrad_grouped(arr, len(now_w), st), "kpf_linear_wgrad_grouped")
+        dpos = _table_prefix_grad(pos, dE, B, now_c) if ctx.needs_input_grad[1] else None
         if now_c:
             arr = (L.ColsumDesc * len(now_c))(*now_c)
             L.check(lib.kpf_colsum_reduce_grouped(arr, len(now_c), st), "kpf_colsum_reduce_grouped")
-        dpos = dE.sum(0) if ctx.needs_input_grad[1] else None
         return (dE, dpos, None, None, None, None, None, None) + tuple(grads)
 
 
@@ -1708,7 +1728,8 @@ class XAttnLayer21(torch.autograd.Function):
         from . import lib as L
         lib = L.load()
         B, T, Cc = query.shape
-        assert T == 21 and Cc == 128 and len(params) == 12 and tuple(qpos.shape) == (21, 128) and tuple(kpos.shape) == (21, 128)
+        # qpos / kpos: the position tables [L >= 21, 128] (first 21 rows used; the backward returns whole-table gradients) or exactly the 21 rows
+        assert T == 21 and Cc == 128 and len(params) == 12 and all(t.dim() == 2 and t.shape[0] >= 21 and t.shape[1] == 128 for t in (qpos, kpos))
         assert tuple(params[0].shape) == (384, 128) and tuple(params[6].shape) == (128, 128) and tuple(params[8].shape) == (128, 128), "decoder layer: d_model 128, feed-forward 128"
         qc, kc = query.float().contiguous(), key.float().contiguous()
         qp, kp = qpos.float().contiguous(), kpos.float().contiguous()
@@ -1776,11 +1797,11 @@ class XAttnLayer21(torch.autograd.Function):
         for d, (dy, x, pw, pb, M_, N, K, ldy) in zip(arr, now_w):
             d.dy, d.x, d.dw, d.db, d.M, d.N, d.K, d.ldy = dy.data_ptr(), x.data_ptr(), pw, pb, M_, N, K, ldy
         L.check(lib.kpf_linear_wgrad_grouped(arr, len(now_w), st), "kpf_linear_wgrad_grouped")
+        dqpos = _table_prefix_grad(qp, dqe, B, now_c) if ctx.needs_input_grad[2] else None
+        dkpos = _table_prefix_grad(kp, dke, B, now_c) if ctx.needs_input_grad[3] else None
         if now_c:
             arr = (L.ColsumDesc * len(now_c))(*now_c)
             L.check(lib.kpf_colsum_reduce_grouped(arr, len(now_c), st), "kpf_colsum_reduce_grouped")
-        dqpos = dqe.sum(0) if ctx.needs_input_grad[2] else None
-        dkpos = dke.sum(0) if ctx.needs_input_grad[3] else None
         return (dq, dke, dqpos, dkpos, None, None, None, None, None, None) + tuple(grads)
 
 
@@ -2215,6 +2236,38 @@ def ball_group3(pcl_xyz, node_xyz, pcl_feat, node_feat):
     return BallGroup3.apply(pcl_xyz, node_xyz, pcl_feat, node_feat)
 
 
+class UnstackRows(torch.autograd.Function):
+    """The channel-stacked maps of G paired networks ([..., ld] in the step's storage type, network g's C channels at column g * gs) as G dense fp32 maps
+    [..., C] in one launch (kpf_unstack_rows); backward: the G gradients back into one stacked tensor in one launch (kpf_restack_rows, pad columns zero).
+    Round 6: replaces a strided cast per map forward and cast + zero fill + strided copy + fan-in add per map backward at the seam between the paired
+    backbones and the fusion head."""
+
+    @staticmethod
+    def forward(ctx, y, G, C_, gs):
+        from . import lib as L
+        yc = y.contiguous()
+        ld = yc.shape[-1]
+        rows = yc.numel() // ld
+        out = torch.empty((G,) + tuple(yc.shape[:-1]) + (C_,), device=y.device, dtype=torch.float32)
+        L.check(L.load().kpf_unstack_rows(yc.data_ptr(), _KDT[yc.dtype], out.data_ptr(), rows, G, C_, ld, gs, torch.cuda.current_stream().cuda_stream), "kpf_unstack_rows")
+        ctx.meta = (G, C_, gs, ld, rows, yc.dtype, tuple(yc.shape))
+        return tuple(out[g] for g in range(G))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        from . import lib as L
+        G, C_, gs, ld, rows, dt, shape = ctx.meta
+        gs_ = [None if g is None else g.float().contiguous() for g in grads]
+        ptrs = (C.c_void_p * G)(*[None if g is None else g.data_ptr() for g in gs_])
+        dy = torch.empty(shape, device=next(g for g in gs_ if g is not None).device, dtype=dt)
+        L.check(L.load().kpf_restack_rows(ptrs, dy.data_ptr(), _KDT[dt], rows, G, C_, ld, gs, torch.cuda.current_stream().cuda_stream), "kpf_restack_rows")
+        return dy, None, None, None
+
+
+def unstack_rows(y, G, C_, gs):
+    return UnstackRows.apply(y, G, C_, gs)
+
+
 class GroupMax(torch.autograd.Function):
     """y = x.view(rows, group, C).max(1)[0] on fp32 rows (model/model.py:192: the maximum over a ball's 64 members) with the winner's member index kept: ONE launch
     each way (kpf_group_max_train_forward / _backward; the library's max + its backward are a reduction, a zero fill and a scatter)."""
@@ -2473,6 +2526,15 @@ def row_gather(src, idx, w=None, inv=None):
     (index_add) is correct but adds with atomics, i.e. is not run-to-run bit-reproducible; the reference's sizes never get there."""
     B, P, Cc = src.shape
     _, R, G = idx.shape
+    if (not src.requires_grad and (w is None or not w.requires_grad) and src.is_cuda and src.dtype == torch.float32 and idx.dtype == torch.int32 and src.stride(2) == 1
+            and src.stride(0) == P * src.stride(1) and (Cc % 4 or not src.is_contiguous())):
+        # no gradient and a width / layout the quad kernel does not take (the 21 weight-logit channels: a column slice of the offset map): one forward launch
+        from . import lib as L
+        out = torch.empty(B, R, Cc, device=src.device, dtype=torch.float32)
+        wc = None if w is None else w.float().contiguous()
+        L.check(L.load().kpf_row_gather_cols_f32(src.data_ptr(), src.stride(1), idx.contiguous().data_ptr(), None if wc is None else wc.data_ptr(), out.data_ptr(), B, P, R, G, Cc,
+                                                 torch.cuda.current_stream().cuda_stream), "kpf_row_gather_cols_f32")
+        return out
     if R * G > ROW_GATHER_MAX_E or P > ROW_GATHER_MAX_P or Cc % 4:
         g = torch.gather(src, 1, idx.long().reshape(B, R * G, 1).expand(-1, -1, Cc)).view(B, R, G, Cc)
         return (g * w.unsqueeze(-1)).sum(2) if w is not None else g.sum(2)

@@ -1479,6 +1479,7 @@ def test_grouped_desa_and_fused_stacks_match_the_layer_by_layer_training_graph(n
         monkeypatch.setattr(TG, "EMB_GROUPED", new)
         monkeypatch.setattr(TG, "TR_FUSED", new)
         monkeypatch.setattr(TG, "XATTN_FUSED", new)
+        monkeypatch.setattr(TG, "UNSTACK_FUSED", new)
         m = KPFusion(net, "", 21, "dexycb", "")
         m.load_state_dict(synthetic_sd(net), strict=True)
         m = m.to(dev).train()

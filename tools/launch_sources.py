@@ -26,6 +26,8 @@ SKIP = {"aten::view", "aten::_unsafe_view", "aten::permute", "aten::transpose", 
         "aten::narrow", "aten::unbind", "aten::split", "aten::view_as", "aten::_reshape_alias", "aten::size", "aten::stride", "aten::is_contiguous", "aten::unfold"}
 cnt = collections.Counter()
 COPIES = len(sys.argv) > 2 and sys.argv[2] == "copies"
+ANOMALY = len(sys.argv) > 2 and sys.argv[2] == "anomaly"
+import re
 class Mode(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = func._schema.name
@@ -33,9 +35,17 @@ class Mode(TorchDispatchMode):
             node = torch._C._current_autograd_node()
             if node is not None:
                 where = "BWD " + node.name()
+                if ANOMALY:  # where the forward created this node (anomaly mode keeps the forward traceback in the node's metadata)
+                    tb = node.metadata.get("traceback_", [])
+                    fr = [l.strip().split("\n")[0] for l in tb if "keypointfusion_amd" in l]
+                    if fr:
+                        m = re.search(r'File ".*?([\w.]+)", line (\d+), in (\w+)', fr[-1])
+                        where += "  <- fwd " + ("%s:%s %s" % m.groups() if m else fr[-1][-80:])
+                shp = [tuple(a.shape) for a in args if torch.is_tensor(a)][:2]
+                where += "  " + str(shp)
             else:
                 where = "?"
-                for fr in reversed(traceback.extract_stack(limit=14)):
+                for fr in reversed(traceback.extract_stack(limit=18)):
                     if "keypointfusion_amd" in fr.filename:
                         where = "%s:%d %s" % (os.path.basename(fr.filename), fr.lineno, fr.name)
                         break
@@ -47,8 +57,12 @@ class Mode(TorchDispatchMode):
                     cnt[("STRIDED " + name, "%s %s %s numel %d" % (where, loc, tuple(src.shape), src.numel()))] += 1
             cnt[(name, where)] += 1
         return func(*args, **(kwargs or {}))
-with Mode():
-    it()
+if ANOMALY:
+    with torch.autograd.detect_anomaly(check_nan=False), Mode():
+        it()
+else:
+    with Mode():
+        it()
 torch.cuda.synchronize()
 print("ATen ops (non-view) in one iteration:", sum(cnt.values()))
 for (name, where), c in cnt.most_common(400):
