@@ -911,6 +911,149 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const float* __restr
   if (ky == 3) kpf_st4(dbpart + (size_t)blockIdx.y * C + c, dbs);
 }
 
+// (2b) dwconv7_wgrad_lds_kernel (round 6) — the same sums with the operands staged through LDS.  The kernel above has every (channel quad, tap row) thread
+// fetch its own x and dY rows: each byte of both tensors is requested seven times, and with whole-width channel blocks per workgroup the seven-row window (170 KB
+// at 32 x 192 channels) misses the L1 — the stage-1 layers of the training step ran at 64 us for 50 MB of operands (L2-bound at ~10 x the unique bytes).  Here a
+// workgroup owns CQ channel quads (128-512 B of every pixel) and a chunk of output rows; an 8-slot LDS ring holds the x rows r-3 .. r+4 of that channel block
+// (slot = global row & 7; three zero halo columns either side), two slots hold dY rows r, r+1; per output row ONE new x row and ONE dY row are fetched (registers
+// -> LDS, issued before the row's arithmetic, stored after it), and thread (quad, tap row ky, 8-column segment) reads its 14-pixel window and 8 gradients from LDS.
+// The segments' sums are added in segment order through LDS at the end: partial layout, summation order across chunks and the reduce kernel are unchanged.
+constexpr int DWL_RING = 8;
+struct DwlGeom { int nseg, CQ, Wp, xrow, lds_f4; };
+__host__ __device__ inline DwlGeom dwl_geom(int W, int C) {
+  DwlGeom g;
+  g.nseg = (W + 7) / 8;
+  int cq = 256 / (7 * g.nseg);
+  int p2 = 1;
+  while (p2 * 2 <= cq) p2 *= 2;
+  const int Q = C >> 2;
+  while (p2 > 1 && p2 / 2 >= Q) p2 /= 2;  // (narrow layers: no more quads per workgroup than the layer has, rounded up to a power of two)
+  g.CQ = cq < 1 ? 0 : p2;
+  g.Wp = g.nseg * 8;
+  g.xrow = (g.Wp + 6) * g.CQ;
+  g.xrow += (8 - g.xrow % 16 + 16) % 16;  // row stride = 128 B mod 256 B: the tap rows of a 16-lane LDS pass alternate between the two halves of the banks
+  g.lds_f4 = DWL_RING * g.xrow + 2 * g.Wp * g.CQ;
+  return g;
+}
+
+__global__ __launch_bounds__(256) void dwconv7_wgrad_lds_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part,
+                                                                float* __restrict__ dbpart, int B, int H, int W, int C, int rows_per_chunk) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 dwl_sm[];
+  const DwlGeom gm = dwl_geom(W, C);
+  const int CQ = gm.CQ, nseg = gm.nseg, Wp = gm.Wp, xrow = gm.xrow;
+  f32x4* xs = dwl_sm;                    // [DWL_RING][xrow]: column c of a row at (c + 3) * CQ
+  f32x4* ds = dwl_sm + DWL_RING * xrow;  // [2][Wp * CQ]
+  const int tid = threadIdx.x;
+  const int Q = C >> 2;
+  const int q0 = blockIdx.x * CQ;
+  const long rows = (long)B * H;
+  const long r0 = (long)blockIdx.y * rows_per_chunk;
+  const long r1 = min(rows, r0 + rows_per_chunk);
+  const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < gm.lds_f4; i += 256) dwl_sm[i] = z4;  // halo columns, pad columns of dY, stride padding: zero for the whole kernel
+  __syncthreads();
+  const int nx = W * CQ;  // float4 elements of one staged row of this channel block (x and dY alike)
+  // element e of a row: column e / CQ, quad e % CQ; at most two per thread (W * CQ <= 8 nseg * 256 / (7 nseg) < 512)
+  int e_col[2], e_cq[2];
+  bool e_ok[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int e = tid + 256 * k;
+    e_col[k] = e / CQ, e_cq[k] = e - e_col[k] * CQ;
+    e_ok[k] = e < nx && q0 + e_cq[k] < Q;
+  }
+  auto fetch = [&](const float* __restrict__ src, long rg, f32x4* v) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      v[k] = (e_ok[k] && rg >= 0 && rg < rows) ? kpf_ld4(src + ((size_t)rg * W + e_col[k]) * C + 4 * (q0 + e_cq[k])) : z4;
+  };
+  auto put_x = [&](long rg, const f32x4* v) {
+    f32x4* row = xs + (int)(rg & (DWL_RING - 1)) * xrow;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (tid + 256 * k < nx) row[(e_col[k] + 3) * CQ + e_cq[k]] = v[k];
+  };
+  auto put_d = [&](long rg, const f32x4* v) {
+    f32x4* row = ds + (int)(rg & 1) * Wp * CQ;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (tid + 256 * k < nx) row[e_col[k] * CQ + e_cq[k]] = v[k];
+  };
+  {  // prologue: x rows r0 - 3 .. r0 + 3 and dY row r0
+    f32x4 v[2];
+    for (long rg = r0 - 3; rg <= r0 + 3; ++rg) {
+      fetch(x, rg, v);
+      put_x(rg, v);
+    }
+    fetch(dy, r0, v);
+    put_d(r0, v);
+  }
+  const int cq = tid % CQ, rest = tid / CQ;
+  const int ky = rest % 7, seg = rest / 7;
+  const bool active = seg < nseg;
+  f32x4 acc[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) acc[j] = z4;
+  f32x4 dbs = z4;
+  for (long r = r0; r < r1; ++r) {
+    __syncthreads();  // the rows stored at the end of the last iteration (or by the prologue) are visible; everyone is done with the slots about to be refilled
+    f32x4 nxv[2], ndv[2];
+    const bool more = r + 1 < r1;
+    if (more) {
+      fetch(x, r + 4, nxv);
+      fetch(dy, r + 1, ndv);
+    }
+    if (active) {
+      const int b = (int)(r / H), y = (int)(r - (long)b * H);
+      const int iy = y + ky - 3;
+      const f32x4* dr = ds + (int)(r & 1) * Wp * CQ + (seg * 8) * CQ + cq;
+      f32x4 g[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] = dr[j * CQ];
+      if (ky == 3) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dbs += g[j];
+      }
+      if ((unsigned)iy < (unsigned)H) {
+        const f32x4* xr = xs + (int)((r + ky - 3) & (DWL_RING - 1)) * xrow + (seg * 8) * CQ + cq;
+        f32x4 win[14];
+#pragma unroll
+        for (int j = 0; j < 14; ++j) win[j] = xr[j * CQ];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+          for (int kx = 0; kx < 7; ++kx) acc[kx] += g[j] * win[j + kx];
+      }
+    }
+    if (more) {
+      put_x(r + 4, nxv);
+      put_d(r + 1, ndv);
+    }
+  }
+  // --- the segments' sums, added in segment order: red[seg][ky][kx][cq] over the ring, the bias sums behind them ---
+  __syncthreads();
+  f32x4* red = dwl_sm;
+  f32x4* dred = dwl_sm + nseg * 49 * CQ;
+  if (active) {
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx) red[((seg * 7 + ky) * 7 + kx) * CQ + cq] = acc[kx];
+    if (ky == 3) dred[seg * CQ + cq] = dbs;
+  }
+  __syncthreads();
+  for (int o = tid; o < 49 * CQ; o += 256) {
+    const int c = o % CQ, tap = o / CQ;
+    if (q0 + c >= Q) continue;
+    f32x4 t = red[tap * CQ + c];
+    for (int sg = 1; sg < nseg; ++sg) t += red[(sg * 49 + tap) * CQ + c];
+    kpf_st4(part + ((size_t)blockIdx.y * 49 + tap) * C + 4 * (q0 + c), t);
+  }
+  if (tid < CQ && q0 + tid < Q) {
+    f32x4 t = dred[tid];
+    for (int sg = 1; sg < nseg; ++sg) t += dred[sg * CQ + tid];
+    kpf_st4(dbpart + (size_t)blockIdx.y * C + 4 * (q0 + tid), t);
+  }
+}
+
 __global__ __launch_bounds__(256) void dwconv7_wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbpart,
                                                                    float* __restrict__ dw, float* __restrict__ db, int S, int C, int nkb) {
   __shared__ f32x4 red[4][64];
@@ -1024,6 +1167,19 @@ int launch_wgrad_any(const WgradArgs& a, const Plan& p, hipStream_t st) {
   if (p.vn == 4) return launch_wgrad<4, 2, TIN>(a, p, st);
   if (p.vk == 4) return launch_wgrad<2, 4, TIN>(a, p, st);
   return launch_wgrad<2, 2, TIN>(a, p, st);
+}
+
+// chunks of the LDS form from (B, H, C) alone (the workspace query has no W: a square map is assumed for the estimate — any W gives correct results, the
+// estimate only steers the grid towards ~3 workgroups per CU), at least four output rows per chunk (each chunk fetches six halo rows on top of its own)
+int dwl_chunk_rows(int B, int H, int C) {
+  const DwlGeom g = dwl_geom(H, C);
+  const long rows = (long)B * H;
+  const int cb = g.CQ > 0 ? ((C >> 2) + g.CQ - 1) / g.CQ : 1;
+  long S = (768 + cb - 1) / cb;
+  const long smax = (rows + 3) / 4;
+  if (S > smax) S = smax;
+  if (S < 1) S = 1;
+  return (int)((rows + S - 1) / S);
 }
 
 int dw_chunk_rows(int B, int H, int C) {
@@ -1219,9 +1375,9 @@ int kpf_linear_wgrad_grouped(const kpf_wgrad_group_desc* descs, int n, void* str
 
 long kpf_dwconv7_wgrad_ws_floats(int B, int H, int C) {
   if (B <= 0 || H <= 0 || C <= 0) return 0;
-  const int rpc = dw_chunk_rows(B, H, C);
-  const long S = ((long)B * H + rpc - 1) / rpc;
-  return S * 50 * C;
+  const int rpc = dw_chunk_rows(B, H, C), rpl = dwl_chunk_rows(B, H, C);
+  const long S = ((long)B * H + rpc - 1) / rpc, Sl = ((long)B * H + rpl - 1) / rpl;  // (either kernel may take the call)
+  return (S > Sl ? S : Sl) * 50 * C;
 }
 
 static int dwconv7_wgrad_impl(const float* dy, const float* x, float* dw, float* db, float* ws, long ws_floats, int B, int H, int W, int C,
@@ -1230,12 +1386,18 @@ static int dwconv7_wgrad_impl(const float* dy, const float* x, float* dw, float*
   KPF_REQUIRE(dy && x && dw && ws, "kpf_dwconv7_wgrad_f32: null pointer");
   KPF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "kpf_dwconv7_wgrad_f32: bad shape (C %% 4 == 0)");
   KPF_REQUIRE(kpf_aligned16(dy) && kpf_aligned16(x) && kpf_aligned16(ws), "kpf_dwconv7_wgrad_f32: dy, x, ws must be 16-byte aligned");
-  const int rpc = dw_chunk_rows(B, H, C);
+  static const int lds_form = []() { const char* e = getenv("KPF_DW7_WGRAD_LDS"); return e ? atoi(e) : 1; }();  // tuning aid: 0 = the register-window kernel
+  const DwlGeom gm = dwl_geom(W, C);
+  const bool use_lds = lds_form && gm.CQ >= 1 && (size_t)gm.lds_f4 * 16 <= 64 * 1024 && W * gm.CQ <= 512;
+  const int rpc = use_lds ? dwl_chunk_rows(B, H, C) : dw_chunk_rows(B, H, C);
   const int S = (int)(((long)B * H + rpc - 1) / rpc);
   KPF_REQUIRE(ws_floats >= (long)S * 50 * C, "kpf_dwconv7_wgrad_f32: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   float* dbpart = ws + (size_t)S * 49 * C;
-  hipLaunchKernelGGL(dwconv7_wgrad_kernel, dim3((7 * (C / 4) + 255) / 256, S), dim3(256), 0, st, dy, x, ws, dbpart, B, H, W, C, rpc);
+  if (use_lds)
+    hipLaunchKernelGGL(dwconv7_wgrad_lds_kernel, dim3(((C >> 2) + gm.CQ - 1) / gm.CQ, S), dim3(256), (size_t)gm.lds_f4 * 16, st, dy, x, ws, dbpart, B, H, W, C, rpc);
+  else
+    hipLaunchKernelGGL(dwconv7_wgrad_kernel, dim3((7 * (C / 4) + 255) / 256, S), dim3(256), 0, st, dy, x, ws, dbpart, B, H, W, C, rpc);
   int rc = kpf_check_launch("kpf_dwconv7_wgrad_f32");
   if (rc != KPF_OK) return rc;
   const int nkb = reduce_blocks(49L * C, S), ndb = db ? reduce_blocks(C, S) : 0;

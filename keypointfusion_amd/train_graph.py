@@ -219,7 +219,16 @@ class TrainGraph:
         cpad = (-cin) % self.cmul
         if cpad:  # the 3- / 1-channel images of the stems: zero channels on both operands (the weight's gradient is sliced back)
             assert G == 1
-            x, w = F.pad(x, (0, cpad)), F.pad(w, (0, 0, 0, 0, 0, cpad))
+            from .training import PadRowsFn, nchw_to_nhwc_padded, pad_rows
+            xn = x.permute(0, 3, 1, 2)
+            if x.is_cuda and x.dtype == torch.float32 and not x.requires_grad and xn.is_contiguous():  # the image as the module received it: repack + pad in one launch
+                x = nchw_to_nhwc_padded(xn, cpad)
+            else:
+                x = F.pad(x, (0, cpad))
+            if w.is_cuda and w.dtype == torch.float32 and w.is_contiguous():  # OIHW rows [N, cin * k * k]: the zero channels are the rows' tails — one launch each way
+                w = PadRowsFn.apply(w.reshape(w.shape[0], cin * k * k), (cin + cpad) * k * k).view(w.shape[0], cin + cpad, k, k)
+            else:
+                w = F.pad(w, (0, 0, 0, 0, 0, cpad))
         return conv2d_nhwc(x.contiguous(), w, b, stride, pad, self.prec, None, None if cpad else self.key_of(p_w), self.packs, G, res)
 
     def bn_l(self, x, p, eps=1e-5, relu=False, out16=True, alias=False):

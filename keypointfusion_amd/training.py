@@ -843,6 +843,30 @@ def pad_rows(src, width, dtype=None):
     return out
 
 
+class PadRowsFn(torch.autograd.Function):
+    """pad_rows with a gradient: zero columns appended to the last axis in one launch; backward = the dense copy of the gradient's first C columns (one launch).
+    (F.pad is a fill + a copy, its backward a slice + a copy.)  Round 6: the stem weights [N, 3 or 1, 4, 4] read as rows [N, cin * 16] and padded to the
+    channel group of the GEMM."""
+
+    @staticmethod
+    def forward(ctx, src, width):
+        ctx.C = src.shape[-1]
+        return pad_rows(src, width)
+
+    @staticmethod
+    def backward(ctx, g):
+        return pad_rows(g[..., :ctx.C], ctx.C), None
+
+
+def nchw_to_nhwc_padded(x_nchw, cpad):
+    """Dense NCHW fp32 -> NHWC with `cpad` zero channels appended, one launch (kpf_nchw_to_nhwc_f32); no gradient (the images)."""
+    from . import lib as L
+    B, Cc, H, W = x_nchw.shape
+    out = torch.empty(B, H, W, Cc + cpad, device=x_nchw.device, dtype=torch.float32)
+    L.check(L.load().kpf_nchw_to_nhwc_f32(x_nchw.data_ptr(), out.data_ptr(), B, Cc, H, W, Cc + cpad, torch.cuda.current_stream().cuda_stream), "kpf_nchw_to_nhwc_f32")
+    return out
+
+
 class _OddPack:
     """A Linear operand whose input width is not a whole channel group, seen by the GEMM at the padded width: the packed rows [N][Kp] are zero
     beyond K anyway (Kp >= the padded width), so only the descriptor changes — the activation rows carry the matching zero channels."""
@@ -2699,7 +2723,9 @@ class Conv2dNHWC(torch.autograd.Function):
                 dyc = dy if prec == "f32" else dy.to(_TDT[prec])
                 if stride == KH == KW and pad == 0 and stride > 1:  # patchify: rows of dY @ W[n][(ky,kx,c)] per group, then the pixel un-shuffle
                     g = _conv_any(_grouped_pack(cache, key, wd, None, G, 2, prec, n_pad=n), dyc, prec).view(B, OH, OW, G, KH, KW, Cin // G)
-                    dx = g.permute(0, 1, 4, 2, 5, 3, 6).reshape(B, OH * KH, OW * KW, Cin)
+                    # (the un-shuffle and the change to x's type in ONE strided copy)
+                    dx = torch.empty(B, OH * KH, OW * KW, Cin, device=g.device, dtype=ctx.x_dtype)
+                    dx.view(B, OH, KH, OW, KW, G, Cin // G).copy_(g.permute(0, 1, 4, 2, 5, 3, 6))
                     if dx.shape[1] != H or dx.shape[2] != W:
                         dx = F.pad(dx, (0, 0, 0, W - dx.shape[2], 0, H - dx.shape[1]))
                 else:
@@ -2715,7 +2741,8 @@ class Conv2dNHWC(torch.autograd.Function):
             dy_in = dy if npad == N else F.pad(dy, (0, npad - N))  # the kernel needs whole channel groups: zero channels on dY (and zero weight rows)
             if patch:  # dX[b, oy*s+ky, ox*s+kx, c] = sum_n dY[b,oy,ox,n] W[n,c,ky,kx]: rows of a GEMM, then un-shuffle
                 g = _conv_any(_dgrad_pack(ctx, wsrc, 2, prec, n_pad=npad), dy_in, prec).view(B, OH, OW, KH, KW, Cin)
-                dx = g.permute(0, 1, 3, 2, 4, 5).reshape(B, OH * KH, OW * KW, Cin)
+                dx = torch.empty(B, OH * KH, OW * KW, Cin, device=g.device, dtype=ctx.x_dtype)  # (un-shuffle + x's type in one strided copy)
+                dx.view(B, OH, KH, OW, KW, Cin).copy_(g.permute(0, 1, 3, 2, 4, 5))
                 if dx.shape[1] != H or dx.shape[2] != W:  # rows / columns the strided convolution never read
                     dx = F.pad(dx, (0, 0, 0, W - dx.shape[2], 0, H - dx.shape[1]))
             else:

@@ -66,8 +66,11 @@ def test_conv_wgrad_large_pixel_count():
     assert float((db.cpu().double() - dy.double().view(-1, 128).sum(0)).abs().max()) <= 2e-5 * 2000
 
 
-@pytest.mark.parametrize("shape", [(2, 32, 32, 96), (3, 16, 16, 192), (2, 8, 8, 384), (2, 4, 4, 768), (1, 5, 11, 8)])
+@pytest.mark.parametrize("shape", [(2, 32, 32, 96), (3, 16, 16, 192), (2, 8, 8, 384), (2, 4, 4, 768), (1, 5, 11, 8), (8, 32, 32, 192), (2, 64, 64, 96), (3, 7, 20, 36),
+                                   (1, 3, 70, 12), (5, 9, 24, 100), (1, 2, 150, 8)])
 def test_dwconv7_forward_backward_match_torch(shape):
+    # (the weight gradient: the LDS-staged kernel for maps up to ~144 columns — every width class of its 8-column segments and channel-block sizes, chunks that
+    #  start inside an image — and the register-window kernel beyond)
     from keypointfusion_amd.training import dwconv7_nhwc
     B, H, W, Cc = shape
     g = torch.Generator().manual_seed(B * H + Cc)
