@@ -936,7 +936,7 @@ __host__ __device__ inline DwlGeom dwl_geom(int W, int C) {
   return g;
 }
 
-__global__ __launch_bounds__(256) void dwconv7_wgrad_lds_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void dwconv7_wgrad_lds_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part,
                                                                 float* __restrict__ dbpart, int B, int H, int W, int C, int rows_per_chunk) {
   extern __shared__ __attribute__((aligned(16))) f32x4 dwl_sm[];
   const DwlGeom gm = dwl_geom(W, C);
@@ -979,14 +979,17 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_lds_kernel(const float* __r
     for (int k = 0; k < 2; ++k)
       if (tid + 256 * k < nx) row[e_col[k] * CQ + e_cq[k]] = v[k];
   };
-  {  // prologue: x rows r0 - 3 .. r0 + 3 and dY row r0
-    f32x4 v[2];
-    for (long rg = r0 - 3; rg <= r0 + 3; ++rg) {
-      fetch(x, rg, v);
-      put_x(rg, v);
-    }
-    fetch(dy, r0, v);
-    put_d(r0, v);
+  f32x4 pxv[2], pdv[2];  // the rows in flight: x row r + 4 and dY row r + 1 while row r is being processed (requested one iteration earlier)
+  {  // prologue: x rows r0 - 3 .. r0 + 3 and dY row r0 — all requested before the first is stored — and the first pair in flight
+    f32x4 v[8][2];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) fetch(x, r0 - 3 + i, v[i]);
+    fetch(dy, r0, v[7]);
+    fetch(x, r0 + 4, pxv);
+    fetch(dy, r0 + 1 < r1 ? r0 + 1 : -1, pdv);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) put_x(r0 - 3 + i, v[i]);
+    put_d(r0, v[7]);
   }
   const int cq = tid % CQ, rest = tid / CQ;
   const int ky = rest % 7, seg = rest / 7;
@@ -997,12 +1000,9 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_lds_kernel(const float* __r
   f32x4 dbs = z4;
   for (long r = r0; r < r1; ++r) {
     __syncthreads();  // the rows stored at the end of the last iteration (or by the prologue) are visible; everyone is done with the slots about to be refilled
-    f32x4 nxv[2], ndv[2];
-    const bool more = r + 1 < r1;
-    if (more) {
-      fetch(x, r + 4, nxv);
-      fetch(dy, r + 1, ndv);
-    }
+    f32x4 nxv[2], ndv[2];  // requested now, stored at the end of the NEXT iteration: two iterations for the round trip
+    fetch(x, r + 2 < r1 ? r + 5 : -1, nxv);
+    fetch(dy, r + 2 < r1 ? r + 2 : -1, ndv);
     if (active) {
       const int b = (int)(r / H), y = (int)(r - (long)b * H);
       const int iy = y + ky - 3;
@@ -1025,10 +1025,12 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_lds_kernel(const float* __r
           for (int kx = 0; kx < 7; ++kx) acc[kx] += g[j] * win[j + kx];
       }
     }
-    if (more) {
-      put_x(r + 4, nxv);
-      put_d(r + 1, ndv);
+    if (r + 1 < r1) {
+      put_x(r + 4, pxv);
+      put_d(r + 1, pdv);
     }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) pxv[k] = nxv[k], pdv[k] = ndv[k];
   }
   // --- the segments' sums, added in segment order: red[seg][ky][kx][cq] over the ring, the bias sums behind them ---
   __syncthreads();
@@ -1175,8 +1177,10 @@ int dwl_chunk_rows(int B, int H, int C) {
   const DwlGeom g = dwl_geom(H, C);
   const long rows = (long)B * H;
   const int cb = g.CQ > 0 ? ((C >> 2) + g.CQ - 1) / g.CQ : 1;
-  long S = (768 + cb - 1) / cb;
-  const long smax = (rows + 3) / 4;
+  static const int target = []() { const char* e = getenv("KPF_DW7_TARGET"); return e ? atoi(e) : 768; }();  // tuning aid: workgroups aimed at
+  static const int minrows = []() { const char* e = getenv("KPF_DW7_MINROWS"); return e ? atoi(e) : 4; }();
+  long S = (target + cb - 1) / cb;
+  const long smax = (rows + minrows - 1) / minrows;
   if (S > smax) S = smax;
   if (S < 1) S = 1;
   return (int)((rows + S - 1) / S);
@@ -1388,7 +1392,11 @@ static int dwconv7_wgrad_impl(const float* dy, const float* x, float* dw, float*
   KPF_REQUIRE(kpf_aligned16(dy) && kpf_aligned16(x) && kpf_aligned16(ws), "kpf_dwconv7_wgrad_f32: dy, x, ws must be 16-byte aligned");
   static const int lds_form = []() { const char* e = getenv("KPF_DW7_WGRAD_LDS"); return e ? atoi(e) : 1; }();  // tuning aid: 0 = the register-window kernel
   const DwlGeom gm = dwl_geom(W, C);
-  const bool use_lds = lds_form && gm.CQ >= 1 && (size_t)gm.lds_f4 * 16 <= 64 * 1024 && W * gm.CQ <= 512;
+  bool use_lds = lds_form && gm.CQ >= 1 && (size_t)gm.lds_f4 * 16 <= 80 * 1024 && W * gm.CQ <= 512;  // (80 KB: two workgroups per CU)
+  if (use_lds && (size_t)gm.lds_f4 * 16 > 64 * 1024) {  // the 32-quad channel blocks of the 8 x 8 and 4 x 4 maps: 66.5 KB
+    static std::atomic<bool> lds_ok[KPF_MAX_DEVICES];
+    use_lds = kpf_raise_lds_limit(reinterpret_cast<const void*>(&dwconv7_wgrad_lds_kernel), lds_ok);
+  }
   const int rpc = use_lds ? dwl_chunk_rows(B, H, C) : dw_chunk_rows(B, H, C);
   const int S = (int)(((long)B * H + rpc - 1) / rpc);
   KPF_REQUIRE(ws_floats >= (long)S * 50 * C, "kpf_dwconv7_wgrad_f32: workspace too small");

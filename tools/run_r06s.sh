@@ -5,7 +5,6 @@ cd /tmp
 rm -rf $OUT/prof
 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof -- python3 $GRAFT_REPO_ROOT/bench.py --workload train128_bf16 --no-cpu-baseline --no-extra --steps 10 --warmup 3 > $OUT/prof.log 2> $OUT/prof.err
 python3 $GRAFT_REPO_ROOT/tools/replay_histogram.py $OUT/prof $OUT/hist.txt 2>/dev/null
-python3 $GRAFT_REPO_ROOT/tools/replay_launches.py $OUT/prof wgrad_h16s,wgrad_f32,dwconv7_wgrad,wgrad_reduce $OUT/wgrad_launches.txt
 python3 $GRAFT_REPO_ROOT/tools/replay_launches.py $OUT/prof "" $OUT/all_launches.txt
 head -3 $OUT/hist.txt
 rm -rf $OUT/prof
