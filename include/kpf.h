@@ -565,7 +565,7 @@ long kpf_pack_desc_blocks(const kpf_pack_desc* d);
  * scalar: a captured iteration follows the scheduler) else lr_host; *step_dev is the number of steps taken BEFORE this one (device float;
  * the caller increments it afterwards).  Arithmetic of torch.optim.AdamW(fused=True): decoupled weight decay, bias corrections from
  * step + 1, no amsgrad. */
-#define KPF_ADAMW_BATCH 80
+#define KPF_ADAMW_BATCH 320 /* (round 6: 80 -> 320, a 15-KB kernel-argument segment: the ~1100 tensors of a paired ConvNeXt-T KPFusion take 4 launches instead of 14) */
 typedef struct kpf_adamw_desc {
   float* p;
   const float* g;

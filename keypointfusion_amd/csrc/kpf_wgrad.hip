@@ -1234,8 +1234,13 @@ static int conv2d_wgrad_impl(const void* dy, const void* x, int dtype, float* dw
   static const int h16_form = []() { const char* e = getenv("KPF_WG16_FORM"); return e ? atoi(e) : 64; }();
   const bool h16 = dtype != KPF_DT_F32 && !h16_widen;
   const bool one = KH == 1 && KW == 1;
-  const bool h16s = h16 && h16_form != 128;
-  const Plan p = h16s ? plan_wgrad_h16s(M, N, (int)K, groups) : (h16 ? plan_wgrad_h16(M, N, (int)K) : plan_wgrad(M, N, (int)K, one));
+  // few pixels, many output tiles (the 4 x 4 maps of the last ConvNeXt stage: M = 512, 3072 x 768 outputs per backbone): the 128-tile kernel without a split — a
+  // quarter of the workgroups of the 64-tile form, each walking all pixels, no cross-wave sum — when its tiles alone fill the chip (KPF_WG16_BIG_M: pixel limit)
+  static const int big_m = []() { const char* e = getenv("KPF_WG16_BIG_M"); return e ? atoi(e) : 512; }();
+  const bool big = h16 && one && M <= big_m && (long)((N + HB - 1) / HB) * ((K + HB - 1) / HB) * groups >= 256;
+  const bool h16s = h16 && h16_form != 128 && !big;
+  Plan p = h16s ? plan_wgrad_h16s(M, N, (int)K, groups) : (h16 ? plan_wgrad_h16(M, N, (int)K) : plan_wgrad(M, N, (int)K, one));
+  if (big) p.S = 1, p.sps = (int)((M + RB - 1) / RB);
   const bool direct = one && p.S == 1 && !trimmed;  // the single partial array is dW
   const long wsg = (long)p.S * N * K + (long)p.S * N;  // one group's workspace
   KPF_REQUIRE(ws_floats >= groups * wsg, "kpf_conv2d_wgrad_f32: workspace too small (%ld floats, need %ld)", ws_floats, groups * wsg);

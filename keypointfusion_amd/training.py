@@ -3127,8 +3127,15 @@ class GraphedTrainStep:
         return sum(f.numel() * f.element_size() for f, _, _ in self.buckets) if self.dist is not None else 0  # (per iteration and rank, either form)
 
     def __call__(self, batch):
-        for k, v in batch.items():
-            self.static[k].copy_(v)
+        # the batch into the graph's static inputs: ONE multi-tensor copy per dtype instead of a copy node per tensor (nine 5-us launches per iteration); a tensor
+        # that already IS the static input (the caller filled `self.static[k]` in place) is skipped
+        todo = [(self.static[k], v) for k, v in batch.items() if v is not self.static[k]]
+        same = [(d, v) for d, v in todo if torch.is_tensor(v) and v.device == d.device and v.shape == d.shape]
+        if same:
+            torch._foreach_copy_([d for d, _ in same], [v for _, v in same])
+        for d, v in todo:
+            if not (torch.is_tensor(v) and v.device == d.device and v.shape == d.shape):
+                d.copy_(v)
         self.graph.replay()  # (dp_mode "overlap": the collectives are nodes of this graph)
         if self.graph_b is not None:
             works = [self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True) for flat, _, _ in self.buckets]
