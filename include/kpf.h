@@ -348,8 +348,10 @@ int kpf_pad_rows(const void* src, int src_dtype, void* dst, int dst_dtype, long 
 /* Training (ABI 17): channel-stacked maps of G <= 4 paired networks <-> one dense fp32 map per network (train_graph.TrainGraph._forward: the seam between the
  * paired backbones and the fusion head).  src [rows][ld] (KPF_DT_*), group g's C channels at column g * gs; dst [G][rows][C] fp32.  kpf_restack_rows is the
  * gradient: grads[g] fp32 [rows][C] or NULL (zero) -> dst [rows][ld] of dst_dtype, every column (also the pad columns) written once. */
-int kpf_unstack_rows(const void* src, int src_dtype, float* dst, long rows, int G, int C, int ld, int gs, void* stream);
-int kpf_restack_rows(const float* const* grads, void* dst, int dst_dtype, long rows, int G, int C, int ld, int gs, void* stream);
+int kpf_unstack_rows(const void* src, int src_dtype, float* dst, long rows, int G, int C, int ld, int gs, int hw, void* stream);
+int kpf_restack_rows(const float* const* grads, void* dst, int dst_dtype, long rows, int G, int C, int ld, int gs, int hw, void* stream);
+/* hw > 0 (rows % hw == 0): the dense maps are NCHW — dst [G][rows / hw][C][hw], grads[g] [rows / hw][C][hw] — the layout the reference returns its offset maps
+ * in (model/model.py:425) and the decode / the loss read; hw == 0: rows of C as above. */
 int kpf_pose_tokens_f32(const float* pw, const float* joint, const float* pcl, float* out, int B, int N, int J, int ld, float kernel, void* stream);
 /* out = relu(scale * (a + b + c)) (b, c nullable; fp32, n % 4 == 0) and d = out > 0 ? scale * dy : 0 — the gradient of every addend (ABI 13;
  * model/model.py:190, 417-422). */
@@ -440,9 +442,9 @@ int kpf_upsample2x_bwd(const void* dy, void* dx, int dtype, int B, int H, int W,
 int kpf_maxpool3x3s2_fwd(const void* x, void* y, unsigned char* tap, int dtype, int B, int H, int W, int C, void* stream);
 int kpf_maxpool3x3s2_bwd(const void* dy, const unsigned char* tap, void* dx, int dtype, int B, int H, int W, int C, void* stream);
 int kpf_row_gather_fwd_f32(const float* src, const int* idx, const float* w, float* out, int B, int P, int R, int G, int C, void* stream);
-/* ABI 17: the forward alone for a column slice of any width C of rows ld >= C floats apart (out [B][R][C] dense; same sum order over g): the 21 weight-logit
- * channels the pose tokens sample (model/model.py:372-376, detached there). */
-int kpf_row_gather_cols_f32(const float* src, int ld, const int* idx, const float* w, float* out, int B, int P, int R, int G, int C, void* stream);
+/* ABI 17: the forward alone for a slice of any width C and layout — element (b, p, c) of the source at b * sb + p * sp + c * sc floats (out [B][R][C] dense; same sum
+ * order over g): the 21 weight-logit channels the pose tokens sample (model/model.py:372-376, detached there), read in place from the NCHW offset map. */
+int kpf_row_gather_cols_f32(const float* src, long sb, long sp, long sc, const int* idx, const float* w, float* out, int B, int P, int R, int G, int C, void* stream);
 long kpf_row_gather_ws_ints(int B, int P, int R, int G);
 int kpf_row_gather_bwd_f32(const float* dout, const int* idx, const float* w, float* dsrc, int* ws, long ws_ints, int B, int P, int R, int G, int C,
                            void* stream);

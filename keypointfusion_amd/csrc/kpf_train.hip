@@ -373,27 +373,29 @@ extern "C" int kpf_maxpool3x3s2_bwd(const void* dy, const unsigned char* tap, vo
 #undef CALL
 }
 
-// the same gather for a COLUMN SLICE of any width (no channel quads, rows ld floats apart): the 21 weight-logit channels of the offset map that the pose tokens
+// the same gather for a slice of any width and layout (no channel quads; element (b, p, c) at b * sb + p * sp + c * sc: a column slice of NHWC rows, channel
+// planes of an NCHW map): the 21 weight-logit channels of the offset map that the pose tokens
 // sample (model/model.py:372-376; no gradient: the reference detaches them) — one thread per output element; the library path was cast + gather + mul + sum
 namespace {
 __global__ __launch_bounds__(256) void row_gather_cols_kernel(const float* __restrict__ src, const int* __restrict__ idx, const float* __restrict__ w,
-                                                              float* __restrict__ out, long total, int P, int R, int G, int C, int ld) {
+                                                              float* __restrict__ out, long total, int P, int R, int G, int C, long sb, long sp, long sc) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long r = i / C;
     const int c = (int)(i - r * C);
     const int b = (int)(r / R);
     const int* ip = idx + r * G;
     float acc = 0.f;
-    for (int g = 0; g < G; ++g) acc += (w ? w[r * G + g] : 1.f) * src[((long)b * P + ip[g]) * ld + c];
+    for (int g = 0; g < G; ++g) acc += (w ? w[r * G + g] : 1.f) * src[b * sb + ip[g] * sp + c * sc];
     out[i] = acc;
   }
 }
 }  // namespace
 
-extern "C" int kpf_row_gather_cols_f32(const float* src, int ld, const int* idx, const float* w, float* out, int B, int P, int R, int G, int C, void* stream) {
-  KPF_REQUIRE(src && idx && out && B > 0 && P > 0 && R > 0 && G > 0 && C > 0 && ld >= C, "kpf_row_gather_cols_f32: bad arguments");
+extern "C" int kpf_row_gather_cols_f32(const float* src, long sb, long sp, long sc, const int* idx, const float* w, float* out, int B, int P, int R, int G, int C,
+                                       void* stream) {
+  KPF_REQUIRE(src && idx && out && B > 0 && P > 0 && R > 0 && G > 0 && C > 0 && sb > 0 && sp > 0 && sc > 0, "kpf_row_gather_cols_f32: bad arguments");
   const long total = (long)B * R * C;
-  hipLaunchKernelGGL(row_gather_cols_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, idx, w, out, total, P, R, G, C, ld);
+  hipLaunchKernelGGL(row_gather_cols_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, idx, w, out, total, P, R, G, C, sb, sp, sc);
   return kpf_check_launch("kpf_row_gather_cols_f32");
 }
 
@@ -2206,18 +2208,27 @@ extern "C" int kpf_pad_rows(const void* src, int src_dtype, void* dst, int dst_d
 namespace {
 struct RestackSrc { const float* g[4]; };
 template <typename TS>
-__global__ __launch_bounds__(256) void unstack_rows_kernel(const TS* __restrict__ src, float* __restrict__ dst, long rows, int G, int C, int ld, int gs) {
+__global__ __launch_bounds__(256) void unstack_rows_kernel(const TS* __restrict__ src, float* __restrict__ dst, long rows, int G, int C, int ld, int gs, int hw) {
+  // hw == 0: dst [G][rows][C];  hw > 0: dst [G][rows / hw][C][hw] (dense NCHW maps: what the decode and the loss read), pixel index fastest
   const long per = rows * C, total = per * G;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int g = (int)(i / per);
     const long j = i - g * per;
-    const long r = j / C;
-    const int c = (int)(j - r * C);
+    long r;
+    int c;
+    if (hw == 0) {
+      r = j / C, c = (int)(j - r * C);
+    } else {
+      const long bc = j / hw;
+      const int p = (int)(j - bc * hw);
+      const long b = bc / C;
+      c = (int)(bc - b * C), r = b * hw + p;
+    }
     dst[i] = (float)src[r * ld + g * gs + c];
   }
 }
 template <typename TD>
-__global__ __launch_bounds__(256) void restack_rows_kernel(const RestackSrc s, TD* __restrict__ dst, long rows, int G, int C, int ld, int gs) {
+__global__ __launch_bounds__(256) void restack_rows_kernel(const RestackSrc s, TD* __restrict__ dst, long rows, int G, int C, int ld, int gs, int hw) {
   const long total = rows * ld;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long r = i / ld;
@@ -2226,20 +2237,26 @@ __global__ __launch_bounds__(256) void restack_rows_kernel(const RestackSrc s, T
     float v = 0.f;
     if (g < G && c < C) {
       const float* p = s.g[g];
-      if (p) v = p[r * C + c];
+      if (p) {
+        if (hw == 0) v = p[r * C + c];
+        else {
+          const long b = r / hw;
+          v = p[(b * C + c) * hw + (r - b * hw)];
+        }
+      }
     }
     dst[i] = (TD)v;
   }
 }
 }  // namespace
 
-extern "C" int kpf_unstack_rows(const void* src, int src_dtype, float* dst, long rows, int G, int C, int ld, int gs, void* stream) {
-  KPF_REQUIRE(src && dst && rows > 0 && G >= 1 && G <= 4 && C > 0 && gs >= C && ld >= (G - 1) * gs + C, "kpf_unstack_rows: bad arguments");
+extern "C" int kpf_unstack_rows(const void* src, int src_dtype, float* dst, long rows, int G, int C, int ld, int gs, int hw, void* stream) {
+  KPF_REQUIRE(src && dst && rows > 0 && G >= 1 && G <= 4 && C > 0 && gs >= C && ld >= (G - 1) * gs + C && hw >= 0 && (hw == 0 || rows % hw == 0), "kpf_unstack_rows: bad arguments");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const dim3 grid(grid_for(rows * C * G));
-  if (src_dtype == KPF_DT_F32) hipLaunchKernelGGL(unstack_rows_kernel<float>, grid, dim3(256), 0, st, static_cast<const float*>(src), dst, rows, G, C, ld, gs);
-  else if (src_dtype == KPF_DT_BF16) hipLaunchKernelGGL(unstack_rows_kernel<bf16_t>, grid, dim3(256), 0, st, static_cast<const bf16_t*>(src), dst, rows, G, C, ld, gs);
-  else if (src_dtype == KPF_DT_F16) hipLaunchKernelGGL(unstack_rows_kernel<f16_t>, grid, dim3(256), 0, st, static_cast<const f16_t*>(src), dst, rows, G, C, ld, gs);
+  if (src_dtype == KPF_DT_F32) hipLaunchKernelGGL(unstack_rows_kernel<float>, grid, dim3(256), 0, st, static_cast<const float*>(src), dst, rows, G, C, ld, gs, hw);
+  else if (src_dtype == KPF_DT_BF16) hipLaunchKernelGGL(unstack_rows_kernel<bf16_t>, grid, dim3(256), 0, st, static_cast<const bf16_t*>(src), dst, rows, G, C, ld, gs, hw);
+  else if (src_dtype == KPF_DT_F16) hipLaunchKernelGGL(unstack_rows_kernel<f16_t>, grid, dim3(256), 0, st, static_cast<const f16_t*>(src), dst, rows, G, C, ld, gs, hw);
   else {
     kpf_set_error("kpf_unstack_rows: unsupported dtype %d", src_dtype);
     return KPF_EINVAL;
@@ -2247,15 +2264,15 @@ extern "C" int kpf_unstack_rows(const void* src, int src_dtype, float* dst, long
   return kpf_check_launch("kpf_unstack_rows");
 }
 
-extern "C" int kpf_restack_rows(const float* const* grads, void* dst, int dst_dtype, long rows, int G, int C, int ld, int gs, void* stream) {
-  KPF_REQUIRE(grads && dst && rows > 0 && G >= 1 && G <= 4 && C > 0 && gs >= C && ld >= (G - 1) * gs + C, "kpf_restack_rows: bad arguments");
+extern "C" int kpf_restack_rows(const float* const* grads, void* dst, int dst_dtype, long rows, int G, int C, int ld, int gs, int hw, void* stream) {
+  KPF_REQUIRE(grads && dst && rows > 0 && G >= 1 && G <= 4 && C > 0 && gs >= C && ld >= (G - 1) * gs + C && hw >= 0 && (hw == 0 || rows % hw == 0), "kpf_restack_rows: bad arguments");
   RestackSrc s{};
   for (int g = 0; g < G; ++g) s.g[g] = grads[g];
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const dim3 grid(grid_for(rows * ld));
-  if (dst_dtype == KPF_DT_F32) hipLaunchKernelGGL(restack_rows_kernel<float>, grid, dim3(256), 0, st, s, static_cast<float*>(dst), rows, G, C, ld, gs);
-  else if (dst_dtype == KPF_DT_BF16) hipLaunchKernelGGL(restack_rows_kernel<bf16_t>, grid, dim3(256), 0, st, s, static_cast<bf16_t*>(dst), rows, G, C, ld, gs);
-  else if (dst_dtype == KPF_DT_F16) hipLaunchKernelGGL(restack_rows_kernel<f16_t>, grid, dim3(256), 0, st, s, static_cast<f16_t*>(dst), rows, G, C, ld, gs);
+  if (dst_dtype == KPF_DT_F32) hipLaunchKernelGGL(restack_rows_kernel<float>, grid, dim3(256), 0, st, s, static_cast<float*>(dst), rows, G, C, ld, gs, hw);
+  else if (dst_dtype == KPF_DT_BF16) hipLaunchKernelGGL(restack_rows_kernel<bf16_t>, grid, dim3(256), 0, st, s, static_cast<bf16_t*>(dst), rows, G, C, ld, gs, hw);
+  else if (dst_dtype == KPF_DT_F16) hipLaunchKernelGGL(restack_rows_kernel<f16_t>, grid, dim3(256), 0, st, s, static_cast<f16_t*>(dst), rows, G, C, ld, gs, hw);
   else {
     kpf_set_error("kpf_restack_rows: unsupported dtype %d", dst_dtype);
     return KPF_EINVAL;

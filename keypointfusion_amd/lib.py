@@ -122,9 +122,9 @@ _SIGS = {
     "kpf_conv2d_wgrad_deferred": [_P, _P, C.c_int] + [_P] * 3 + [C.c_long] + [C.c_int] * 18 + [C.POINTER(WgradReduceDesc), _P],
     "kpf_dwconv7_wgrad_deferred": [_P] * 5 + [C.c_long] + [C.c_int] * 4 + [C.POINTER(WgradReduceDesc), _P],
     "kpf_wgrad_reduce_multi": [C.POINTER(WgradReduceDesc), C.c_int, _P],
-    "kpf_row_gather_cols_f32": [_P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P],
-    "kpf_unstack_rows": [_P, C.c_int, _P, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _P],
-    "kpf_restack_rows": [C.POINTER(C.c_void_p), _P, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_row_gather_cols_f32": [_P, C.c_long, C.c_long, C.c_long, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_unstack_rows": [_P, C.c_int, _P, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_restack_rows": [C.POINTER(C.c_void_p), _P, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P],
     "kpf_add_relu_forward": [_P, _P, _P, _P, C.c_long, C.c_float, _P],
     "kpf_add_relu_backward": [_P, _P, _P, C.c_long, C.c_float, _P],
     "kpf_gate_mix_forward": [_P] * 6 + [C.c_int] * 3 + [_P],

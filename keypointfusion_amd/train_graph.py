@@ -374,7 +374,8 @@ class TrainGraph:
             from .training import unstack_rows
             y, n, npad = res
             cf = feat.shape[-1] // G
-            return tuple(zip(unstack_rows(y, G, n, npad), unstack_rows(feat, G, cf, cf)))
+            # (the offset maps leave as dense NCHW — what the decode kernel and the loss read, and the layout the reference returns them in; the features as NHWC rows)
+            return tuple(zip(unstack_rows(y, G, n, npad, True), unstack_rows(feat, G, cf, cf)))
         if G > 1:  # -> ((res_rgb, feat_rgb), (res_d, feat_d)): each backbone's channel slice of the stacked maps, NHWC (strided views)
             fs = feat.view(feat.shape[:-1] + (G, -1))
             return tuple((res[..., g, :], fs[..., g, :]) for g in range(G))
@@ -682,8 +683,11 @@ class TrainGraph:
                 (img_offset_rgb, img_feat_rgb), (img_offset, img_feat) = self.unet(PAIR[:-1], (img_rgb, img))
             self.G = 1
             # one dense fp32 copy per map (the slices are strided, 16-bit under mixed precision), then the channels_last view the head's consumers expect
-            nchw = (lambda t: t.permute(0, 3, 1, 2)) if UNSTACK_FUSED else (lambda t: t.float().contiguous().permute(0, 3, 1, 2))
-            img_offset_rgb, img_feat_rgb, img_offset, img_feat = nchw(img_offset_rgb), nchw(img_feat_rgb), nchw(img_offset), nchw(img_feat)
+            if UNSTACK_FUSED:  # (offset maps: dense NCHW already; features: the NCHW-shaped view of their NHWC rows)
+                img_feat_rgb, img_feat = img_feat_rgb.permute(0, 3, 1, 2), img_feat.permute(0, 3, 1, 2)
+            else:
+                nchw = lambda t: t.float().contiguous().permute(0, 3, 1, 2)
+                img_offset_rgb, img_feat_rgb, img_offset, img_feat = nchw(img_offset_rgb), nchw(img_feat_rgb), nchw(img_offset), nchw(img_feat)
         else:
             side.wait_stream(main) if side is not main else None
             with torch.cuda.stream(side), amp():

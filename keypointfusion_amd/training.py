@@ -2261,35 +2261,37 @@ def ball_group3(pcl_xyz, node_xyz, pcl_feat, node_feat):
 
 
 class UnstackRows(torch.autograd.Function):
-    """The channel-stacked maps of G paired networks ([..., ld] in the step's storage type, network g's C channels at column g * gs) as G dense fp32 maps
-    [..., C] in one launch (kpf_unstack_rows); backward: the G gradients back into one stacked tensor in one launch (kpf_restack_rows, pad columns zero).
-    Round 6: replaces a strided cast per map forward and cast + zero fill + strided copy + fan-in add per map backward at the seam between the paired
-    backbones and the fusion head."""
+    """The channel-stacked maps of G paired networks ([B, H, W, ld] in the step's storage type, network g's C channels at column g * gs) as G dense fp32 maps in
+    one launch (kpf_unstack_rows): NHWC [B, H, W, C] each, or with nchw=True dense NCHW [B, C, H, W] — the layout the reference returns its offset maps in and the
+    decode / the loss read, so that neither needs a transposing copy.  Backward: the G gradients (same layout) back into one stacked tensor in one launch
+    (kpf_restack_rows, pad columns zero).  Round 6: replaces a strided cast per map forward and cast + zero fill + strided copy + fan-in add per map backward at
+    the seam between the paired backbones and the fusion head."""
 
     @staticmethod
-    def forward(ctx, y, G, C_, gs):
+    def forward(ctx, y, G, C_, gs, nchw=False):
         from . import lib as L
         yc = y.contiguous()
-        ld = yc.shape[-1]
-        rows = yc.numel() // ld
-        out = torch.empty((G,) + tuple(yc.shape[:-1]) + (C_,), device=y.device, dtype=torch.float32)
-        L.check(L.load().kpf_unstack_rows(yc.data_ptr(), _KDT[yc.dtype], out.data_ptr(), rows, G, C_, ld, gs, torch.cuda.current_stream().cuda_stream), "kpf_unstack_rows")
-        ctx.meta = (G, C_, gs, ld, rows, yc.dtype, tuple(yc.shape))
+        assert yc.dim() == 4
+        B, H, W, ld = yc.shape
+        rows, hw = B * H * W, (H * W if nchw else 0)
+        out = torch.empty((G, B, C_, H, W) if nchw else (G, B, H, W, C_), device=y.device, dtype=torch.float32)
+        L.check(L.load().kpf_unstack_rows(yc.data_ptr(), _KDT[yc.dtype], out.data_ptr(), rows, G, C_, ld, gs, hw, torch.cuda.current_stream().cuda_stream), "kpf_unstack_rows")
+        ctx.meta = (G, C_, gs, ld, rows, hw, yc.dtype, tuple(yc.shape))
         return tuple(out[g] for g in range(G))
 
     @staticmethod
     def backward(ctx, *grads):
         from . import lib as L
-        G, C_, gs, ld, rows, dt, shape = ctx.meta
+        G, C_, gs, ld, rows, hw, dt, shape = ctx.meta
         gs_ = [None if g is None else g.float().contiguous() for g in grads]
         ptrs = (C.c_void_p * G)(*[None if g is None else g.data_ptr() for g in gs_])
         dy = torch.empty(shape, device=next(g for g in gs_ if g is not None).device, dtype=dt)
-        L.check(L.load().kpf_restack_rows(ptrs, dy.data_ptr(), _KDT[dt], rows, G, C_, ld, gs, torch.cuda.current_stream().cuda_stream), "kpf_restack_rows")
-        return dy, None, None, None
+        L.check(L.load().kpf_restack_rows(ptrs, dy.data_ptr(), _KDT[dt], rows, G, C_, ld, gs, hw, torch.cuda.current_stream().cuda_stream), "kpf_restack_rows")
+        return dy, None, None, None, None
 
 
-def unstack_rows(y, G, C_, gs):
-    return UnstackRows.apply(y, G, C_, gs)
+def unstack_rows(y, G, C_, gs, nchw=False):
+    return UnstackRows.apply(y, G, C_, gs, nchw)
 
 
 class GroupMax(torch.autograd.Function):
@@ -2550,13 +2552,13 @@ def row_gather(src, idx, w=None, inv=None):
     (index_add) is correct but adds with atomics, i.e. is not run-to-run bit-reproducible; the reference's sizes never get there."""
     B, P, Cc = src.shape
     _, R, G = idx.shape
-    if (not src.requires_grad and (w is None or not w.requires_grad) and src.is_cuda and src.dtype == torch.float32 and idx.dtype == torch.int32 and src.stride(2) == 1
-            and src.stride(0) == P * src.stride(1) and (Cc % 4 or not src.is_contiguous())):
-        # no gradient and a width / layout the quad kernel does not take (the 21 weight-logit channels: a column slice of the offset map): one forward launch
+    if not src.requires_grad and (w is None or not w.requires_grad) and src.is_cuda and src.dtype == torch.float32 and idx.dtype == torch.int32 and (Cc % 4 or not src.is_contiguous()):
+        # no gradient and a width / layout the quad kernel does not take (the 21 weight-logit channels: channel planes of the NCHW offset map, or a column slice
+        # of its NHWC form): one forward launch on the tensor where it lies (any strides)
         from . import lib as L
         out = torch.empty(B, R, Cc, device=src.device, dtype=torch.float32)
         wc = None if w is None else w.float().contiguous()
-        L.check(L.load().kpf_row_gather_cols_f32(src.data_ptr(), src.stride(1), idx.contiguous().data_ptr(), None if wc is None else wc.data_ptr(), out.data_ptr(), B, P, R, G, Cc,
+        L.check(L.load().kpf_row_gather_cols_f32(src.data_ptr(), src.stride(0), src.stride(1), src.stride(2), idx.contiguous().data_ptr(), None if wc is None else wc.data_ptr(), out.data_ptr(), B, P, R, G, Cc,
                                                  torch.cuda.current_stream().cuda_stream), "kpf_row_gather_cols_f32")
         return out
     if R * G > ROW_GATHER_MAX_E or P > ROW_GATHER_MAX_P or Cc % 4:
