@@ -711,6 +711,8 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
           kpf_st4(reinterpret_cast<TH*>(a.out) + m * a.out_ld + a.out_coff + n, v);
         else if (fl & KPF_OUT_SPLIT)
           kpf_store_split4(a.out + m * a.out_ld + a.out_coff, n, v);
+        else if (a.st_policy == 2)  // (wave-uniform: large fp32 outputs leave with non-temporal stores, see kpf_conv2d_f32)
+          asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(a.out + m * a.out_ld + a.out_coff + n), "v"(v) : "memory");
         else
           STORE4(a.out + m * a.out_ld + a.out_coff + n, v);
       }
@@ -1653,6 +1655,10 @@ extern "C" int kpf_conv2d_f32(const kpf_conv_desc* d, const float* in, const flo
     a.zero = zero_of_dev[dev];
   }
   a.flags = fl; a.tilesN = 0; a.nblk = 0; a.dbg = 0; a.skew = 0; a.st_policy = 0;
+  {  // tuning aid KPF_F32_ST_MB: outputs of at least that many MB are written with non-temporal stores (0 = never)
+    static const int st_mb = []() { const char* e = getenv("KPF_F32_ST_MB"); return e ? atoi(e) : 0; }();
+    if (st_mb > 0 && (long)d->B * d->OH * d->OW * d->N * 4 >= (long)st_mb * 1000000) a.st_policy = 2;
+  }
   a.w_unscale = (fl & (KPF_IN_SPLIT | KPF_W_SPLIT)) ? d->w_unscale : 1.0f;
   if (fl & (KPF_IN_SPLIT | KPF_W_SPLIT))
     KPF_REQUIRE(d->w_unscale > 0.f && d->Cin % 32 == 0 && d->in_coff % 4 == 0, "kpf_conv2d_f32: split operands need w_unscale > 0 and Cin %% 32 == 0 (Cin=%d)", d->Cin);
