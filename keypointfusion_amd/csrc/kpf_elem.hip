@@ -116,7 +116,9 @@ __device__ __forceinline__ unsigned xcd_contiguous_block_id() {
 // the CU's address unit only carries activations: 7 activation loads per output float4 instead of 12.25 + 6.1 weight loads.
 // No LDS output tile -> occupancy is set by registers only.
 // ---------------------------------------------------------------------------------------------------------------
-template <typename TA, bool WLDS, int PX>
+// R2 = false (round 6): ONE output row per thread (`ypairs` then counts rows) — twice the threads for the small maps of the training step, whose launches
+// were 96 - 384 workgroups of long serial chains on a 256-CU chip.
+template <typename TA, bool WLDS, int PX, bool R2 = true>
 __global__ __launch_bounds__(256) void dwconv7_kernel(const TA* __restrict__ x, const float* __restrict__ wdw,
                                                       const float* __restrict__ bdw, TA* __restrict__ y, int B, int H, int W, int C,
                                                       int xstrips, int ypairs, const TA* __restrict__ addend = nullptr) {
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const TA* __restrict__ x, 
   r /= xstrips;
   const int yp = (int)(r % ypairs);
   const int b = (int)(r / ypairs);
-  const int x0 = xs * PX, y0 = yp * 2;
+  const int x0 = xs * PX, y0 = yp * (R2 ? 2 : 1);
   const float* wsrc = WLDS ? wl : wdw;
   f32x4 acc0[PX], acc1[PX];
   const f32x4 bias = *reinterpret_cast<const f32x4*>(bdw + 4 * q);
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const TA* __restrict__ x, 
   }
   const TA* xb = x + (long)b * H * W * C + 4 * q;
 #pragma unroll 1
-  for (int ir = 0; ir < 8; ++ir) {  // input rows y0-3 .. y0+4
+  for (int ir = 0; ir < (R2 ? 8 : 7); ++ir) {  // input rows y0-3 .. y0+4 (y0+3 for a single output row)
     const int iy = y0 + ir - 3;
     if ((unsigned)iy >= (unsigned)H) continue;
     f32x4 in[PX + 6];
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const TA* __restrict__ x, 
           for (int e = 0; e < 4; ++e) acc0[t][e] = fmaf(in[t + kx][e], wv[e], acc0[t][e]);
       }
     }
-    if (ir >= 1) {  // output row y0+1: tap row ky = ir-1
+    if (R2 && ir >= 1) {  // output row y0+1: tap row ky = ir-1
 #pragma unroll
       for (int kx = 0; kx < 7; ++kx) {
         const f32x4 wv = *reinterpret_cast<const f32x4*>(wsrc + ((ir - 1) * 7 + kx) * C + 4 * q);
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const TA* __restrict__ x, 
     if (x0 + t < W) {
       const long o0 = ((long)y0 * W + x0 + t) * C, o1 = ((long)(y0 + 1) * W + x0 + t) * C;
       kpf_st4(yb + o0, ab ? acc0[t] + kpf_ld4(ab + o0) : acc0[t]);
-      if (y0 + 1 < H) kpf_st4(yb + o1, ab ? acc1[t] + kpf_ld4(ab + o1) : acc1[t]);
+      if (R2 && y0 + 1 < H) kpf_st4(yb + o1, ab ? acc1[t] + kpf_ld4(ab + o1) : acc1[t]);
     }
   }
 }
@@ -1121,12 +1123,31 @@ static int dwconv7_impl(const float* x, const float* w_dw, const float* b_dw, co
   KPF_REQUIRE(kpf_aligned16(x) && kpf_aligned16(y) && kpf_aligned16(w_dw) && kpf_aligned16(b_dw) && kpf_aligned16(addend),
               "kpf_dwconv7_f32: pointers must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  const int xstrips = (W + 7) / 8, ypairs = (H + 1) / 2;
+  // work per thread: 2 rows x 8 pixels while that fills the chip (>= KPF_DW7_MIN_BLOCKS workgroups), else 4 pixels, else 1 row x 4 pixels — the 16 x 16 ... 4 x 4
+  // maps of a training iteration are 96 - 192 workgroups in the widest form (tuning aids: KPF_DW7_PX = 8 | 4, KPF_DW7_ROWS = 2 | 1 force a form)
+  static const int px_env = []() { const char* e = getenv("KPF_DW7_PX"); return e ? atoi(e) : 0; }();
+  static const int rows_env = []() { const char* e = getenv("KPF_DW7_ROWS"); return e ? atoi(e) : 0; }();
+  static const int min_blocks = []() { const char* e = getenv("KPF_DW7_MIN_BLOCKS"); return e ? atoi(e) : 768; }();
+  auto blocks = [&](int px, int rows) { return ((long)B * ((H + rows - 1) / rows) * ((W + px - 1) / px) * (C / 4) + 255) / 256; };
+  int px = 8, rows = 2;
+  if (blocks(8, 2) < min_blocks || W <= 4) px = 4;
+  if (blocks(px, 2) < min_blocks) rows = 1;
+  if (px_env == 4 || px_env == 8) px = px_env;
+  if (rows_env == 1 || rows_env == 2) rows = rows_env;
+  const int xstrips = (W + px - 1) / px, ypairs = (H + rows - 1) / rows;
   const long total = (long)B * ypairs * xstrips * (C / 4);
   const size_t wbytes = (size_t)49 * C * sizeof(float);
   const dim3 grid((unsigned)((total + 255) / 256));
-  if (wbytes <= 48 * 1024) hipLaunchKernelGGL((dwconv7_kernel<float, true, 8>), grid, dim3(256), wbytes, st, x, w_dw, b_dw, y, B, H, W, C, xstrips, ypairs, addend);
-  else hipLaunchKernelGGL((dwconv7_kernel<float, false, 8>), grid, dim3(256), 0, st, x, w_dw, b_dw, y, B, H, W, C, xstrips, ypairs, addend);
+  const bool wl = wbytes <= 48 * 1024;
+#define KPF_DW7(WL, PXV, R2V) hipLaunchKernelGGL((dwconv7_kernel<float, WL, PXV, R2V>), grid, dim3(256), WL ? wbytes : 0, st, x, w_dw, b_dw, y, B, H, W, C, xstrips, ypairs, addend)
+  if (wl) {
+    if (px == 8) { if (rows == 2) KPF_DW7(true, 8, true); else KPF_DW7(true, 8, false); }
+    else { if (rows == 2) KPF_DW7(true, 4, true); else KPF_DW7(true, 4, false); }
+  } else {
+    if (px == 8) { if (rows == 2) KPF_DW7(false, 8, true); else KPF_DW7(false, 8, false); }
+    else { if (rows == 2) KPF_DW7(false, 4, true); else KPF_DW7(false, 4, false); }
+  }
+#undef KPF_DW7
   return kpf_check_launch("kpf_dwconv7_f32");
 }
 
