@@ -1185,32 +1185,47 @@ extern "C" int kpf_attn21_backward(const float* dctx, const float* q, const floa
 // here it is 21 multiply-adds per output with dOut[b] in LDS (the other two products of the pair stay on the library: 10-12 us).
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
+// (round 6) workgroup = 32 rows p x all channels; A[b][:, p0 .. p0+31] and dOut[b] in LDS; thread = (4 rows, channel quad): per joint ONE 16-byte LDS read of
+// four A values (a broadcast across the 32 quad lanes) and one of dOut feed 16 multiply-adds.  The first form read A from global memory once per output and
+// joint (21 load instructions per output quad): 30 us per call at B = 32, P = 1024, C = 128 for 17 MB of results; this one is bound by its stores.
 __global__ __launch_bounds__(256) void bmm21_dx_kernel(const float* __restrict__ A, const float* __restrict__ dOut, float* __restrict__ dX, int J, int P, int C) {
-  extern __shared__ float sd[];  // dOut[b]: [J][C]
-  const int b = blockIdx.y;
+  extern __shared__ __attribute__((aligned(16))) float sd[];  // dOut[b]: [J][C], then A tile [J][32]
+  float* as = sd + J * C;
+  const int b = blockIdx.y, p0 = blockIdx.x * 32;
   for (int i = threadIdx.x; i < J * C; i += 256) sd[i] = dOut[(long)b * J * C + i];
+  const float* Ab = A + (long)b * J * P;
+  for (int i = threadIdx.x; i < J * 32; i += 256) {
+    const int j = i >> 5, pp = i & 31;
+    as[i] = p0 + pp < P ? Ab[(long)j * P + p0 + pp] : 0.f;
+  }
   __syncthreads();
   const int C4 = C >> 2;
-  const float* Ab = A + (long)b * J * P;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < P * C4; i += gridDim.x * 256) {
-    const int p = i / C4, q = i - p * C4;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int pg = threadIdx.x >> 5, ql = threadIdx.x & 31;
+  for (int q = ql; q < C4; q += 32) {
+    f32x4 acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int j = 0; j < J; ++j) {
-      const float a = Ab[j * P + p];
+      const f32x4 a = *reinterpret_cast<const f32x4*>(as + j * 32 + 4 * pg);
       const f32x4 d = *reinterpret_cast<const f32x4*>(sd + j * C + 4 * q);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[e] = fmaf(a, d[e], acc[e]);
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[r][e] = fmaf(a[r], d[e], acc[r][e]);
     }
-    *reinterpret_cast<f32x4*>(dX + ((long)b * P + p) * C + 4 * q) = acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int pr = p0 + 4 * pg + r;
+      if (pr < P) *reinterpret_cast<f32x4*>(dX + ((long)b * P + pr) * C + 4 * q) = acc[r];
+    }
   }
 }
 }  // namespace
 
 extern "C" int kpf_bmm_small_k_dx(const float* A, const float* dOut, float* dX, int B, int J, int P, int C, void* stream) {
-  KPF_REQUIRE(A && dOut && dX && B > 0 && J > 0 && J <= 64 && P > 0 && C > 0 && C % 4 == 0 && (long)J * C * 4 <= 64 * 1024, "kpf_bmm_small_k_dx: bad arguments");
-  int gx = (int)(((long)P * (C / 4) + 255) / 256);
-  gx = gx > 128 ? 128 : gx;  // (round 4: 32 -> 128 column blocks per sample: the kernel is a latency chain of 21 dependent row loads per output)
-  hipLaunchKernelGGL(bmm21_dx_kernel, dim3(gx, B), dim3(256), (size_t)J * C * sizeof(float), reinterpret_cast<hipStream_t>(stream), A, dOut, dX, J, P, C);
+  KPF_REQUIRE(A && dOut && dX && B > 0 && J > 0 && J <= 64 && P > 0 && C > 0 && C % 4 == 0 && (long)J * (C + 32) * 4 <= 64 * 1024 && kpf_aligned16(dOut) && kpf_aligned16(dX),
+              "kpf_bmm_small_k_dx: bad arguments");
+  hipLaunchKernelGGL(bmm21_dx_kernel, dim3((P + 31) / 32, B), dim3(256), (size_t)J * (C + 32) * sizeof(float), reinterpret_cast<hipStream_t>(stream), A, dOut, dX, J, P, C);
   return kpf_check_launch("kpf_bmm_small_k_dx");
 }
 
@@ -1297,16 +1312,113 @@ __global__ __launch_bounds__(256) void bmm21_da_kernel(const float* __restrict__
 }
 }  // namespace
 
+namespace {
+// (round 6) the same product with FOUR rows p per thread and trip: A[b][j][4 pl .. 4 pl + 3] is one 16-byte load, so a trip is 24 + 4 load instructions for
+// 384 multiply-adds (the form above: 24 + 1 for 96 — the address unit, not the memory, bounded it: 32 us per call at B = 32, P = 1024, C = 128 for 17 MB of
+// X).  grid (ceil(C / 16), B), 512 threads = 4 channel quads x 128 row lanes (256 workgroups at C = 128: every CU busy).  P % 4 == 0.
+constexpr int BMM4_NT = 512, BMM4_NW = BMM4_NT / 64;
+__global__ __launch_bounds__(BMM4_NT) void bmm21_fwd4_kernel(const float* __restrict__ A, const float* __restrict__ X, float* __restrict__ out, int J, int P, int C) {
+  __shared__ float red[BMM4_NW][BMM_J][16];
+  const int b = blockIdx.y, c0 = blockIdx.x * 16;
+  const int q = threadIdx.x & 3, pl = threadIdx.x >> 2;
+  const float* Ab = A + (long)b * J * P;
+  const float* Xb = X + (long)b * P * C + c0 + 4 * q;
+  f32x4 acc[BMM_J];
+#pragma unroll
+  for (int j = 0; j < BMM_J; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool cv = c0 + 4 * q < C;
+  for (int p = 4 * pl; p < P; p += 4 * (BMM4_NT / 4)) {
+    f32x4 x[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[r] = cv ? *reinterpret_cast<const f32x4*>(Xb + (long)(p + r) * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < BMM_J; ++j) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(Ab + (long)(j < J ? j : J - 1) * P + p);  // (rows beyond J repeat row J - 1 and are never stored)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(a[r], x[r][e], acc[j][e]);
+    }
+  }
+  // the 16 row lanes of a wave (lane bits 2..5), then the 8 waves through LDS, in a fixed order
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < BMM_J; ++j)
+    if (j < J) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = acc[j][e];
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        acc[j][e] = v;
+      }
+      if (lane < 4) *reinterpret_cast<f32x4*>(&red[wave][j][4 * lane]) = acc[j];
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < J * 16; i += BMM4_NT) {
+    const int j = i >> 4, c = i & 15;
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < BMM4_NW; w += 4) sum += (red[w][j][c] + red[w + 1][j][c]) + (red[w + 2][j][c] + red[w + 3][j][c]);
+    if (c0 + c < C) out[((long)b * J + j) * C + c0 + c] = sum;
+  }
+}
+
+// (round 6) dA with X[b]'s rows staged: workgroup = 32 rows p; the tile X[b][p0 .. p0 + 31][:] goes to LDS with coalesced 16-byte loads (the form above has
+// every lane walk its own 512-byte row: 64 cache lines per load instruction), dOut[b] beside it; thread = (row p, three joints): per channel quad one LDS read
+// of x and three broadcast reads of dOut feed 12 multiply-adds.  LDS: (32 (C + 4) + J C) floats.
+__global__ __launch_bounds__(256) void bmm21_da_lds_kernel(const float* __restrict__ dOut, const float* __restrict__ X, float* __restrict__ dA, int J, int P, int C) {
+  extern __shared__ __attribute__((aligned(16))) float sd[];  // dOut[b]: [J][C] (rows beyond J: zero up to 24), then the X tile [32][C + 4]
+  const int b = blockIdx.y, p0 = blockIdx.x * 32;
+  const int C4 = C >> 2, ldx = C + 4;
+  float* xs = sd + BMM_J * C;
+  for (int i = threadIdx.x; i < BMM_J * C; i += 256) sd[i] = i < J * C ? dOut[(long)b * J * C + i] : 0.f;
+  for (int i = threadIdx.x; i < 32 * C4; i += 256) {
+    const int pp = i / C4, q = i - pp * C4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (p0 + pp < P) v = *reinterpret_cast<const f32x4*>(X + ((long)b * P + p0 + pp) * C + 4 * q);
+    *reinterpret_cast<f32x4*>(xs + pp * ldx + 4 * q) = v;
+  }
+  __syncthreads();
+  const int pp = threadIdx.x & 31, jg = threadIdx.x >> 5;
+  float acc[3] = {0.f, 0.f, 0.f};
+  const float* xr = xs + pp * ldx;
+  const float* dr = sd + 3 * jg * C;
+  for (int q = 0; q < C4; ++q) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(xr + 4 * q);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const f32x4 d = *reinterpret_cast<const f32x4*>(dr + k * C + 4 * q);
+      acc[k] = fmaf(x[3], d[3], fmaf(x[2], d[2], fmaf(x[1], d[1], fmaf(x[0], d[0], acc[k]))));
+    }
+  }
+  if (p0 + pp < P) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (3 * jg + k < J) dA[((long)b * J + 3 * jg + k) * P + p0 + pp] = acc[k];
+  }
+}
+}  // namespace
+
 extern "C" int kpf_bmm_small_k_fwd(const float* A, const float* X, float* out, int B, int J, int P, int C, void* stream) {
   KPF_REQUIRE(A && X && out && B > 0 && J > 0 && J <= BMM_J && P > 0 && C > 0 && C % 4 == 0 && kpf_aligned16(X), "kpf_bmm_small_k_fwd: bad arguments (J <= 24, C %% 4 == 0)");
-  hipLaunchKernelGGL(bmm21_fwd_kernel, dim3((C + 31) / 32, B), dim3(BMM_NT), 0, reinterpret_cast<hipStream_t>(stream), A, X, out, J, P, C);
+  if (P % 4 == 0 && kpf_aligned16(A))
+    hipLaunchKernelGGL(bmm21_fwd4_kernel, dim3((C + 15) / 16, B), dim3(BMM4_NT), 0, reinterpret_cast<hipStream_t>(stream), A, X, out, J, P, C);
+  else
+    hipLaunchKernelGGL(bmm21_fwd_kernel, dim3((C + 31) / 32, B), dim3(BMM_NT), 0, reinterpret_cast<hipStream_t>(stream), A, X, out, J, P, C);
   return kpf_check_launch("kpf_bmm_small_k_fwd");
 }
 
 extern "C" int kpf_bmm_small_k_da(const float* dOut, const float* X, float* dA, int B, int J, int P, int C, void* stream) {
   KPF_REQUIRE(dOut && X && dA && B > 0 && J > 0 && J <= BMM_J && P > 0 && C > 0 && C % 4 == 0 && (long)J * C * 4 <= 64 * 1024 && kpf_aligned16(X) && kpf_aligned16(dOut),
               "kpf_bmm_small_k_da: bad arguments (J <= 24, C %% 4 == 0)");
-  hipLaunchKernelGGL(bmm21_da_kernel, dim3((P + 255) / 256, B), dim3(256), (size_t)J * C * sizeof(float), reinterpret_cast<hipStream_t>(stream), dOut, X, dA, J, P, C);
+  const size_t lds = ((size_t)BMM_J * C + 32 * (size_t)(C + 4)) * sizeof(float);
+  if (lds <= 48 * 1024)  // (C <= 216 at J <= 24: the X tile fits beside dOut)
+    hipLaunchKernelGGL(bmm21_da_lds_kernel, dim3((P + 31) / 32, B), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), dOut, X, dA, J, P, C);
+  else
+    hipLaunchKernelGGL(bmm21_da_kernel, dim3((P + 255) / 256, B), dim3(256), (size_t)J * C * sizeof(float), reinterpret_cast<hipStream_t>(stream), dOut, X, dA, J, P, C);
   return kpf_check_launch("kpf_bmm_small_k_da");
 }
 

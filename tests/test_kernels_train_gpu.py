@@ -418,8 +418,9 @@ def test_attn21_dropout_is_a_bernoulli_mask_consistent_between_forward_and_backw
     assert not torch.equal(out2 != 0, out != 0)
 
 
-@pytest.mark.parametrize("B,J,P,Cc", [(3, 21, 1024, 128), (2, 21, 50, 8)])
+@pytest.mark.parametrize("B,J,P,Cc", [(3, 21, 1024, 128), (2, 21, 50, 8), (5, 21, 52, 36), (2, 24, 260, 200), (1, 7, 33, 128), (2, 21, 64, 400)])
 def test_bmm_small_k_forward_backward_match_torch(B, J, P, Cc):
+    # (P % 4 == 0: the four-rows-per-trip forward; C <= 216: the LDS-staged A-gradient; other shapes: the first forms)
     from keypointfusion_amd.training import bmm_small_k
     g = torch.Generator().manual_seed(P)
     A, X, dout = torch.randn(B, J, P, generator=g), torch.randn(B, P, Cc, generator=g), torch.randn(B, J, Cc, generator=g)
