@@ -886,7 +886,9 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const TA* __restrict__ dy
 }
 
 inline int ln_blocks(long rows) {  // one row per wave for the small (B x 21)-row tensors of the fusion head (a row is a dependent chain of two wave
+  static const int rpw = []() { const char* e = getenv("KPF_LN_ROWS_PER_WAVE"); return e ? atoi(e) : 1; }();  // tuning aid (rows >= 2048 only)
   long g = (rows + 3) / 4;          // reductions: round 4 went from four rows per wave to one), at most LN_MAX_BLOCKS workgroups' partials to add
+  if (rows >= 2048 && rpw > 1) g = (rows + 4 * rpw - 1) / (4 * rpw);
   // (round 5: 256 -> 1024.  With one workgroup per CU a wave walks rows / 1024 rows one dependent memory round trip at a time: the backward passes of the
   //  32768 x 192 / 8192 x 384 LayerNorms ran at a quarter of what their traffic takes; four workgroups per CU put four times as many rows in flight.)
   static const int cap = []() { const char* e = getenv("KPF_LN_MAX_BLOCKS"); return e ? atoi(e) : 1024; }();
@@ -2842,20 +2844,21 @@ __global__ __launch_bounds__(256) void gate_mix_bwd_kernel(const float* __restri
   if (threadIdx.x == 0) part[(long)b * J + j] = acc;
 }
 
-// blocks [0, ceil(P / 32)): d w_fc[p] = sum over the B*J rows of dgw * g — 32 columns x 8 row groups per block (rows r = group, group + 8, ...: coalesced 128-byte
-// reads, 84 iterations instead of 672), the eight group sums added in group order;  the last block: d weight_dis = wd (1 - wd) * sum of the row partials
+// blocks [0, ceil(P / 8)): d w_fc[p] = sum over the B*J rows of dgw * g — 8 columns x 32 row groups per block (rows r = group, group + 32, ...: 21 iterations at
+// B = 32; round 6: 32 columns x 8 groups before — 33 workgroups walking 84 iterations each took 28 us for 8 MB), the 32 group sums added in group order;  the last
+// block: d weight_dis = wd (1 - wd) * sum of the row partials
 __global__ __launch_bounds__(256) void gate_mix_params_kernel(const float* __restrict__ sw, const float* __restrict__ gam, const float* __restrict__ wdis,
                                                               const float* __restrict__ dgw, const float* __restrict__ part, float* __restrict__ dwfc,
                                                               float* __restrict__ dwdis, int R, int P) {
-  __shared__ float red[8][32];
+  __shared__ float red[32][8];
   const float wd = 1.0f / (1.0f + __expf(-wdis[0]));
-  const int nb = (P + 31) / 32;
+  const int nb = (P + 7) / 8;
   if ((int)blockIdx.x < nb) {
-    const int pl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    const int p = blockIdx.x * 32 + pl;
+    const int pl = threadIdx.x & 7, rg = threadIdx.x >> 3;
+    const int p = blockIdx.x * 8 + pl;
     float acc = 0.f;
     if (p < P)
-      for (int r = rg; r < R; r += 8) {
+      for (int r = rg; r < R; r += 32) {
         const long i = (long)r * P + p;
         acc = fmaf(dgw[i], wd * gam[i] + (1.0f - wd) * sw[i], acc);
       }
@@ -2864,7 +2867,7 @@ __global__ __launch_bounds__(256) void gate_mix_params_kernel(const float* __res
     if (rg == 0 && p < P) {
       float t = 0.f;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) t += red[k][pl];
+      for (int k = 0; k < 32; ++k) t += red[k][pl];
       dwfc[p] = t;
     }
   } else {
@@ -2890,6 +2893,6 @@ extern "C" int kpf_gate_mix_backward(const float* sw, const float* gam, const fl
   hipLaunchKernelGGL(gate_mix_bwd_kernel, dim3(J, B), dim3(256), 0, st, sw, gam, weight_dis, w_fc, d_sw, d_gw, d_gam, d_logits, ws, J, P);
   int rc = kpf_check_launch("kpf_gate_mix_backward");
   if (rc != KPF_OK) return rc;
-  hipLaunchKernelGGL(gate_mix_params_kernel, dim3((P + 31) / 32 + 1), dim3(256), 0, st, sw, gam, weight_dis, d_gw, ws, d_w_fc, d_weight_dis, B * J, P);
+  hipLaunchKernelGGL(gate_mix_params_kernel, dim3((P + 7) / 8 + 1), dim3(256), 0, st, sw, gam, weight_dis, d_gw, ws, d_w_fc, d_weight_dis, B * J, P);
   return kpf_check_launch("kpf_gate_mix_backward (parameters)");
 }

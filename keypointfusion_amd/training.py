@@ -1088,7 +1088,20 @@ class DeferredParamGrads:
         self.seen.add(key)
         # (dY, X) stay referenced until flush; of dW / db only the addresses are kept — a second reference would make AccumulateGrad
         # copy the unwritten tensor instead of adopting it
-        self.items.append((key, dy, x, dw.data_ptr(), None if db is None else db.data_ptr(), x.numel() // x.shape[-1], dy.shape[-1], x.shape[-1], int(ldy)))
+        self.items.append((key, dy, x, dw.data_ptr(), None if db is None else db.data_ptr(), x.numel() // x.shape[-1], dy.shape[-1], x.shape[-1], int(ldy), dw.data_ptr()))
+        if db is not None:
+            self.biases.append((key, bias_ptr, db.data_ptr()))
+
+    def add_rows(self, key, parts, dw, db, bias_ptr=None, ldy=0):
+        """ONE parameter whose gradient is several row blocks with different X operands (the packed in_proj of nn.MultiheadAttention: rows 0-127 multiply
+        query + qpos, rows 128-383 key + kpos): parts = [(first row, dY block, X)], each its own problem of the grouped launch, written into its rows of dw / db."""
+        if key in self.seen:
+            raise RuntimeError("DeferredParamGrads: parameter %r receives a second gradient in one backward pass" % (key,))
+        self.seen.add(key)
+        K = dw.shape[-1] if dw.dim() == 2 else dw[0].numel()
+        for r0, dy, x in parts:
+            self.items.append((key, dy, x, dw.data_ptr() + 4 * r0 * K, None if db is None else db.data_ptr() + 4 * r0, x.numel() // x.shape[-1], dy.shape[-1], x.shape[-1], int(ldy),
+                               dw.data_ptr()))
         if db is not None:
             self.biases.append((key, bias_ptr, db.data_ptr()))
 
@@ -1102,7 +1115,7 @@ class DeferredParamGrads:
                     raise RuntimeError("DeferredParamGrads: the gradient of %s %s was copied before its reduce had run (autograd did not adopt the tensor)" % (what, tuple(q.shape)))
         items, colsums, biases, self.items, self.colsums, self.biases, self.seen = self.items, self.colsums, self.biases, [], [], [], set()
         # the parameters whose gradients this pass deferred (GraphedTrainStep keeps them out of the buckets that are reduced DURING backward)
-        self.last_deferred = ([self.named[k] for k, *_ in items if k in self.named] + [q for c in colsums if c[2] in self.by_ptr for q, _ in self._parts(c[2], c[4])] +
+        self.last_deferred = (list({id(self.named[k]): self.named[k] for k, *_ in items if k in self.named}.values()) + [q for c in colsums if c[2] in self.by_ptr for q, _ in self._parts(c[2], c[4])] +
                               [self.by_ptr[b[1]] for b in biases if b[1] in self.by_ptr])
         if not items and not colsums:
             return
@@ -1111,9 +1124,9 @@ class DeferredParamGrads:
         # someone else: raise without launching.
         msg = ("DeferredParamGrads: the gradient of %s was copied before it was written (autograd did not adopt the tensor: is the parameter "
                "hooked, referenced twice, or used twice in one forward?); nothing was written")
-        for key, _, _, pw, _, _, _, _, _ in items:
+        for key, _, _, _, _, _, _, _, _, pbase in items:
             p = self.named.get(key)
-            if p is None or p.grad is None or p.grad.data_ptr() != pw:
+            if p is None or p.grad is None or p.grad.data_ptr() != pbase:
                 raise RuntimeError(msg % repr(key))
         for _, _, wptr, optr, n in colsums:
             for p, off in (self._parts(wptr, n) if wptr in self.by_ptr else [(None, 0)]):
@@ -1126,7 +1139,7 @@ class DeferredParamGrads:
         st = torch.cuda.current_stream().cuda_stream
         if items:
             arr = (L.WgradGroupDesc * len(items))()
-            for d, (key, dy, x, pw, pb, M, N, K, ldy) in zip(arr, items):
+            for d, (key, dy, x, pw, pb, M, N, K, ldy, _) in zip(arr, items):
                 d.dy, d.x, d.dw, d.db, d.M, d.N, d.K, d.ldy = dy.data_ptr(), x.data_ptr(), pw, pb, M, N, K, ldy
             L.check(L.load().kpf_linear_wgrad_grouped(arr, len(items), st), "kpf_linear_wgrad_grouped")
         if colsums:
@@ -1787,10 +1800,18 @@ class XAttnLayer21(torch.autograd.Function):
         DY = lambda which: (lambda o: dys[o:o + M * 128].view(M, 128))(lib.kpf_xattn_train_offset(B, which))
         grads = [None] * 12
         now_w, now_c = [], []
-        # in_proj: one parameter, two problems (different X): never deferred (a deferred item is one (dY, X) pair per parameter)
+        # in_proj: one parameter, two problems (different X): two row blocks of one deferred gradient (add_rows), or two problems of the launch below
         dwin, dbin = new(384, 128), new(384)
-        now_w.append((dqkv[:, :128], X(0, 128), dwin.data_ptr(), dbin.data_ptr(), M, 128, 128, 384))
-        now_w.append((dqkv[:, 128:], X(1, 128), dwin.data_ptr() + 4 * 128 * 128, dbin.data_ptr() + 4 * 128, M, 256, 128, 384))
+        grp = DeferredParamGrads.wants(names[0], cache, dqkv[:, :128], X(0, 128), 1, 1, 1, 0)
+        if grp is not None:
+            bp = grp.by_ptr.get(params[1].data_ptr())
+            if bp is None or bp.numel() != 384 or bp.grad is not None:
+                grp = None
+        if grp is not None:
+            grp.add_rows(names[0], [(0, dqkv[:, :128], X(0, 128)), (128, dqkv[:, 128:], X(1, 128))], dwin, dbin, params[1].data_ptr(), ldy=384)
+        else:
+            now_w.append((dqkv[:, :128], X(0, 128), dwin.data_ptr(), dbin.data_ptr(), M, 128, 128, 384))
+            now_w.append((dqkv[:, 128:], X(1, 128), dwin.data_ptr() + 4 * 128 * 128, dbin.data_ptr() + 4 * 128, M, 256, 128, 384))
         grads[0], grads[1] = dwin, dbin
         for wi, xw, yw in ((2, 2, 7), (6, 3, 8), (8, 4, 9)):
             w, bias, name = params[wi], params[wi + 1], names[wi]
@@ -1817,10 +1838,11 @@ class XAttnLayer21(torch.autograd.Function):
             else:
                 now_c.append(desc)
             grads[wi], grads[wi + 1] = dwb[0], dwb[1]
-        arr = (L.WgradGroupDesc * len(now_w))()
-        for d, (dy, x, pw, pb, M_, N, K, ldy) in zip(arr, now_w):
-            d.dy, d.x, d.dw, d.db, d.M, d.N, d.K, d.ldy = dy.data_ptr(), x.data_ptr(), pw, pb, M_, N, K, ldy
-        L.check(lib.kpf_linear_wgrad_grouped(arr, len(now_w), st), "kpf_linear_wgrad_grouped")
+        if now_w:
+            arr = (L.WgradGroupDesc * len(now_w))()
+            for d, (dy, x, pw, pb, M_, N, K, ldy) in zip(arr, now_w):
+                d.dy, d.x, d.dw, d.db, d.M, d.N, d.K, d.ldy = dy.data_ptr(), x.data_ptr(), pw, pb, M_, N, K, ldy
+            L.check(lib.kpf_linear_wgrad_grouped(arr, len(now_w), st), "kpf_linear_wgrad_grouped")
         dqpos = _table_prefix_grad(qp, dqe, B, now_c) if ctx.needs_input_grad[2] else None
         dkpos = _table_prefix_grad(kp, dke, B, now_c) if ctx.needs_input_grad[3] else None
         if now_c:
