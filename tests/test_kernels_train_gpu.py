@@ -1510,6 +1510,31 @@ def test_grouped_desa_and_fused_stacks_match_the_layer_by_layer_training_graph(n
         assert torch.allclose(b0[k].float(), b1[k].float(), rtol=1e-4, atol=1e-5), k
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(2, 105, 112, 224, True), (2, 128, 128, 256, False), (2, 105, 112, 232, True), (3, 20, 24, 80, False), (2, 7, 7, 14, False), (2, 36, 40, 80, True)])
+def test_unstack_rows_forward_backward(cfg, dt):
+    """training.UnstackRows (kpf_unstack_rows / kpf_restack_rows): the channel-stacked maps of G networks as G dense fp32 maps, NHWC or NCHW, and the gradients back
+    into one stacked tensor with zero pad columns — every form of the kernels (four columns per thread, element per thread, tiled NCHW transposes) against slicing."""
+    from keypointfusion_amd import training as T
+    G, Cc, gs, ld, nchw = cfg
+    g = torch.Generator().manual_seed(Cc + ld)
+    B, H, W = 3, 9, 8
+    y = torch.randn(B, H, W, ld, generator=g).to(dt).cuda().requires_grad_(True)
+    outs = T.unstack_rows(y, G, Cc, gs, nchw)
+    ws = [torch.randn(o.shape, generator=g).cuda() for o in outs]
+    want = [y.detach().float()[..., i * gs:i * gs + Cc] for i in range(G)]
+    if nchw:
+        want = [w_.permute(0, 3, 1, 2) for w_ in want]
+    for o, w_ in zip(outs, want):
+        assert o.dtype == torch.float32 and o.is_contiguous() and torch.equal(o, w_.contiguous())
+    sum((o * w_).sum() for o, w_ in zip(outs[:-1], ws[:-1])).backward()  # (the last map receives no gradient: its columns must come back zero)
+    ref = torch.zeros(B, H, W, ld)
+    for i in range(G - 1):
+        gi = ws[i].cpu()
+        ref[..., i * gs:i * gs + Cc] = gi.permute(0, 2, 3, 1) if nchw else gi
+    assert y.grad.dtype == dt and torch.equal(y.grad.float().cpu(), ref.to(dt).float())
+
+
 def test_group_max_and_ball_group3_match_torch():
     """GroupMax (max over 64 consecutive rows with the winner kept) against torch.max and its autograd; BallGroup3 (the three radii channel-stacked, one backward
     launch) against BallGroup (radius by radius): same grouped rows and offsets, same index sets, same gradients towards the point / joint features."""
