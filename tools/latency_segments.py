@@ -67,3 +67,15 @@ for r in s:
         on = True
     if on:
         print("%9.1f %8.1f  %s" % ((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, short(r["Kernel_Name"])), file=out)
+
+# (round 6) the same forward by (kernel, workgroups): launches that are long although they are small are under-filled, not bandwidth-bound
+agg = collections.defaultdict(list)
+for r in s:
+    try:
+        nb = (int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"]))) * max(1, int(r["Grid_Size_Y"]) // max(1, int(r.get("Workgroup_Size_Y", 1)))) * max(1, int(r["Grid_Size_Z"]) // max(1, int(r.get("Workgroup_Size_Z", 1))))
+    except (KeyError, ValueError):
+        nb = -1
+    agg[(short(r["Kernel_Name"]), nb)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+print("last forward by (kernel, workgroups), by total time:", file=out)
+for (k, nb), v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:45]:
+    print("%4d x avg %7.1f us  tot %8.1f us  workgroups %7d  %s" % (len(v), sum(v) / len(v), sum(v), nb, k), file=out)
