@@ -1616,7 +1616,8 @@ __global__ __launch_bounds__(256) void bn_elem_kernel(const TX* __restrict__ x, 
 int bn_chunks(long M, int C, int* rows_per_chunk) {
   const BnGeom g = bn_geom(C);
   const int cg = (g.Q + 63) / 64;
-  long S = 512 / cg;  // ~2 workgroups per CU
+  static const int target = []() { const char* e = getenv("KPF_BN_TARGET"); return e ? atoi(e) : 1024; }();  // tuning aid: workgroups aimed at (round 6: 512 -> 1024, - 0.1 ms per training iteration)
+  long S = target / cg;  // ~4 workgroups per CU
   const long smax = (M + 4L * g.RL - 1) / (4L * g.RL);  // at least four rows per thread
   if (S > smax) S = smax;
   if (S < 1) S = 1;
