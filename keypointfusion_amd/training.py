@@ -2047,10 +2047,10 @@ class BmmSmallK(torch.autograd.Function):
 
 def bmm_small_k(A, X):
     """A [B, J, P] @ X [B, P, C].  The HIP kernels (fixed summation order, bit-identical replays) cover the shapes the model has — J <= 24 rows, C % 4 == 0,
-    one sample's dOut tile J * C * 4 <= 64 KB of LDS (C <= 682 at J = 21); anything wider takes torch.bmm, chosen HERE, before autograd records a node, so a
+    one sample's dOut tile plus a 32-row A tile J * (C + 32) * 4 <= 64 KB of LDS (C <= 748 at J = 21); anything wider takes torch.bmm, chosen HERE, before autograd records a node, so a
     wider head fails nowhere inside backward."""
     J, Cc = A.shape[1], X.shape[2]
-    if A.is_cuda and J <= 24 and Cc % 4 == 0 and J * Cc * 4 <= 65536:
+    if A.is_cuda and J <= 24 and Cc % 4 == 0 and J * (Cc + 32) * 4 <= 65536:
         return BmmSmallK.apply(A, X)
     return torch.bmm(A, X.to(A.dtype))
 
