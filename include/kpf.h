@@ -418,6 +418,16 @@ int kpf_bn_train_backward(const void* dy, const void* x, const void* y, int x_dt
 int kpf_bn_train_backward_add(const void* dy, const void* x, const void* y, int x_dtype, int y_dtype, const float* mean, const float* invstd,
                               const float* w, const void* addend, void* dx, float* dw, float* db, int relu, float* ws, long ws_floats, long M, int C,
                               void* stream);
+/* Training (ABI 17): out = relu(BN_a(xa) + BN_b(xb)) with batch statistics on fp32 rows [M][C] — DESA's local + feature branches (model/model.py:176-190) — in one
+ * pass over the two pre-activations (statistics: two partial + finalize pairs, then ONE element-wise launch), and its backward (masked gradient, both branches'
+ * sums, both input gradients: four launches).  stats [4][C] receives mean_a, invstd_a, mean_b, invstd_b (kept for the backward); running statistics nullable and
+ * updated like kpf_bn_train_forward's; ws >= kpf_bn2_ws_floats(M, C) floats. */
+long kpf_bn2_ws_floats(long M, int C);
+int kpf_bn2_add_relu_forward(const float* xa, const float* xb, const float* wa, const float* ba, const float* wb, const float* bb, float* out, float* stats,
+                             float* rmean_a, float* rvar_a, float* rmean_b, float* rvar_b, float momentum, float eps, float* ws, long ws_floats, long M, int C,
+                             void* stream);
+int kpf_bn2_add_relu_backward(const float* dy, const float* out, const float* xa, const float* xb, const float* stats, const float* wa, const float* wb, float* dxa,
+                              float* dxb, float* dwa, float* dba, float* dwb, float* dbb, float* ws, long ws_floats, long M, int C, void* stream);
 int kpf_bn_train_forward_f32(const float* x, const float* w, const float* b, float* y, float* mean, float* invstd, float* running_mean,
                              float* running_var, float momentum, float eps, int relu, float* ws, long ws_floats, long M, int C,
                              void* stream);

@@ -1613,6 +1613,98 @@ __global__ __launch_bounds__(256) void bn_elem_kernel(const TX* __restrict__ x, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 6: out = relu(BN_a(xa) + BN_b(xb)) — DESA's `relu(bn_l0(conv_l0(offsets)) + bn_f0(conv_f0(features)))` (model/model.py:176-190) on fp32 rows [M][C] — with the
+// two normalisations, the sum and the ReLU in ONE pass over the two pre-activations (the three-kernel form wrote both normalised tensors and read them back:
+// 264 MB of 43008 x 384 fp32 rows per fusion block), and the backward's masked gradient, both branches' partial sums and both input gradients in two passes
+// instead of seven.  Geometry, chunking and the fixed-order finalize are the BatchNorm kernels' above (their workspaces: [S][2][C] per branch).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn2_add_relu_fwd_kernel(const float* __restrict__ xa, const float* __restrict__ xb, const float* __restrict__ stats /* [4][C]: mean_a, invstd_a, mean_b, invstd_b */,
+                                                               const float* __restrict__ wa, const float* __restrict__ ba, const float* __restrict__ wb, const float* __restrict__ bb,
+                                                               float* __restrict__ out, long M, int C, int rows_per_block) {
+  const BnGeom g = bn_geom(C);
+  const int ql = threadIdx.x % g.QL, rl = threadIdx.x / g.QL;
+  const int q = blockIdx.y * 64 + ql;
+  if (rl >= g.RL || q >= g.Q) return;
+  const f32x4 ma = kpf_ld4(stats + 4 * q), sa = kpf_ld4(stats + C + 4 * q) * kpf_ld4(wa + 4 * q);
+  const f32x4 mb = kpf_ld4(stats + 2 * C + 4 * q), sb = kpf_ld4(stats + 3 * C + 4 * q) * kpf_ld4(wb + 4 * q);
+  const f32x4 t0 = kpf_ld4(ba + 4 * q) + kpf_ld4(bb + 4 * q);
+  const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  for (long r = r0 + rl; r < r1; r += g.RL) {
+    const f32x4 va = kpf_ld4(xa + r * C + 4 * q) - ma, vb = kpf_ld4(xb + r * C + 4 * q) - mb;
+    f32x4 o = va * sa + (vb * sb + t0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+    kpf_st4(out + r * C + 4 * q, o);
+  }
+}
+
+// partial sums of the backward for BOTH branches: dz = out > 0 ? dy : 0;  wsa[chunk] = {sum dz, sum dz (xa - mean_a)}, wsb[chunk] = {sum dz, sum dz (xb - mean_b)}
+__global__ __launch_bounds__(256) void bn2_partial_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ out, const float* __restrict__ xa, const float* __restrict__ xb,
+                                                              const float* __restrict__ stats, float* __restrict__ wsa, float* __restrict__ wsb, long M, int C, int rows_per_chunk) {
+  __shared__ f32x4 red[3][256];
+  const BnGeom g = bn_geom(C);
+  const int ql = threadIdx.x % g.QL, rl = threadIdx.x / g.QL;
+  const int q = blockIdx.y * 64 + ql;
+  const bool active = rl < g.RL && q < g.Q;
+  f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f}, pb = {0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    const long r0 = (long)blockIdx.x * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    const f32x4 ma = kpf_ld4(stats + 4 * q), mb = kpf_ld4(stats + 2 * C + 4 * q);
+    for (long r = r0 + rl; r < r1; r += g.RL) {
+      f32x4 d = kpf_ld4(dy + r * C + 4 * q);
+      const f32x4 o = kpf_ld4(out + r * C + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
+      p0 += d;
+      pa += d * (kpf_ld4(xa + r * C + 4 * q) - ma);
+      pb += d * (kpf_ld4(xb + r * C + 4 * q) - mb);
+    }
+  }
+  red[0][threadIdx.x] = p0;
+  red[1][threadIdx.x] = pa;
+  red[2][threadIdx.x] = pb;
+  __syncthreads();
+  if (rl == 0 && q < g.Q) {
+    f32x4 s0 = red[0][ql], s1 = red[1][ql], s2 = red[2][ql];
+    for (int i = 1; i < g.RL; ++i) {
+      s0 += red[0][i * g.QL + ql];
+      s1 += red[1][i * g.QL + ql];
+      s2 += red[2][i * g.QL + ql];
+    }
+    float* oa = wsa + (size_t)blockIdx.x * 2 * C;
+    float* ob = wsb + (size_t)blockIdx.x * 2 * C;
+    kpf_st4(oa + 4 * q, s0);
+    kpf_st4(oa + C + 4 * q, s1);
+    kpf_st4(ob + 4 * q, s0);
+    kpf_st4(ob + C + 4 * q, s2);
+  }
+}
+
+// dxa = wa invstd_a (dz - c0a - (xa - mean_a) c1a), dxb likewise (coef_* from bn_bwd_finalize_kernel)
+__global__ __launch_bounds__(256) void bn2_elem_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ out, const float* __restrict__ xa, const float* __restrict__ xb,
+                                                           const float* __restrict__ stats, const float* __restrict__ wa, const float* __restrict__ wb,
+                                                           const float* __restrict__ coefa, const float* __restrict__ coefb, float* __restrict__ dxa, float* __restrict__ dxb,
+                                                           long M, int C, int rows_per_block) {
+  const BnGeom g = bn_geom(C);
+  const int ql = threadIdx.x % g.QL, rl = threadIdx.x / g.QL;
+  const int q = blockIdx.y * 64 + ql;
+  if (rl >= g.RL || q >= g.Q) return;
+  const f32x4 ma = kpf_ld4(stats + 4 * q), sa = kpf_ld4(stats + C + 4 * q) * kpf_ld4(wa + 4 * q);
+  const f32x4 mb = kpf_ld4(stats + 2 * C + 4 * q), sb = kpf_ld4(stats + 3 * C + 4 * q) * kpf_ld4(wb + 4 * q);
+  const f32x4 a0 = kpf_ld4(coefa + 4 * q), a1 = kpf_ld4(coefa + C + 4 * q), b0 = kpf_ld4(coefb + 4 * q), b1 = kpf_ld4(coefb + C + 4 * q);
+  const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  for (long r = r0 + rl; r < r1; r += g.RL) {
+    f32x4 d = kpf_ld4(dy + r * C + 4 * q);
+    const f32x4 o = kpf_ld4(out + r * C + 4 * q);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
+    const f32x4 va = kpf_ld4(xa + r * C + 4 * q) - ma, vb = kpf_ld4(xb + r * C + 4 * q) - mb;
+    kpf_st4(dxa + r * C + 4 * q, sa * (d - a0 - va * a1));
+    kpf_st4(dxb + r * C + 4 * q, sb * (d - b0 - vb * b1));
+  }
+}
+
 int bn_chunks(long M, int C, int* rows_per_chunk) {
   const BnGeom g = bn_geom(C);
   const int cg = (g.Q + 63) / 64;
@@ -1634,6 +1726,61 @@ long kpf_bn_ws_floats(long M, int C) {
   int rpc;
   const int S = bn_chunks(M, C, &rpc);
   return (long)S * 2 * C + 2 * C;
+}
+
+
+/* the fused two-branch form (see bn2_add_relu_fwd_kernel): workspace floats */
+long kpf_bn2_ws_floats(long M, int C) {
+  if (M <= 0 || C <= 0) return 0;
+  int rpc;
+  const int S = bn_chunks(M, C, &rpc);
+  return 2 * ((long)S * 2 * C + 2 * C);
+}
+
+int kpf_bn2_add_relu_forward(const float* xa, const float* xb, const float* wa, const float* ba, const float* wb, const float* bb, float* out, float* stats,
+                             float* rmean_a, float* rvar_a, float* rmean_b, float* rvar_b, float momentum, float eps, float* ws, long ws_floats, long M, int C,
+                             void* stream) {
+  KPF_REQUIRE(xa && xb && wa && ba && wb && bb && out && stats && ws && M > 0 && C > 0 && C % 4 == 0, "kpf_bn2_add_relu_forward: bad arguments (C %% 4 == 0)");
+  KPF_REQUIRE(kpf_aligned16(xa) && kpf_aligned16(xb) && kpf_aligned16(out) && kpf_aligned16(stats) && kpf_aligned16(ws), "kpf_bn2_add_relu_forward: pointers must be 16-byte aligned");
+  int rpc;
+  const int S = bn_chunks(M, C, &rpc);
+  KPF_REQUIRE(ws_floats >= (long)S * 2 * C, "kpf_bn2_add_relu_forward: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int cg = (C / 4 + 63) / 64;
+  const float* xs[2] = {xa, xb};
+  float* rm[2] = {rmean_a, rmean_b};
+  float* rv[2] = {rvar_a, rvar_b};
+  for (int k = 0; k < 2; ++k) {  // (the two statistics passes reuse one workspace: same stream)
+    hipLaunchKernelGGL((bn_partial_kernel<0, false, float, float>), dim3(S, cg), dim3(256), 0, st, xs[k], (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, ws, M,
+                       C, rpc);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel<float>, dim3((C + 63) / 64), dim3(64 * BN_FW), 0, st, xs[k], ws, S, M, C, stats + 2 * k * C, stats + (2 * k + 1) * C, rm[k],
+                       rv[k], momentum, eps);
+  }
+  hipLaunchKernelGGL(bn2_add_relu_fwd_kernel, dim3(S, cg), dim3(256), 0, st, xa, xb, stats, wa, ba, wb, bb, out, M, C, rpc);
+  return kpf_check_launch("kpf_bn2_add_relu_forward");
+}
+
+int kpf_bn2_add_relu_backward(const float* dy, const float* out, const float* xa, const float* xb, const float* stats, const float* wa, const float* wb, float* dxa,
+                              float* dxb, float* dwa, float* dba, float* dwb, float* dbb, float* ws, long ws_floats, long M, int C, void* stream) {
+  KPF_REQUIRE(dy && out && xa && xb && stats && wa && wb && dxa && dxb && dwa && dba && dwb && dbb && ws && M > 0 && C > 0 && C % 4 == 0,
+              "kpf_bn2_add_relu_backward: bad arguments (C %% 4 == 0)");
+  KPF_REQUIRE(kpf_aligned16(dy) && kpf_aligned16(out) && kpf_aligned16(xa) && kpf_aligned16(xb) && kpf_aligned16(dxa) && kpf_aligned16(dxb) && kpf_aligned16(ws),
+              "kpf_bn2_add_relu_backward: pointers must be 16-byte aligned");
+  int rpc;
+  const int S = bn_chunks(M, C, &rpc);
+  const long per = (long)S * 2 * C + 2 * C;
+  KPF_REQUIRE(ws_floats >= 2 * per, "kpf_bn2_add_relu_backward: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int cg = (C / 4 + 63) / 64;
+  float* wsa = ws;
+  float* wsb = ws + per;
+  float* coefa = wsa + (size_t)S * 2 * C;
+  float* coefb = wsb + (size_t)S * 2 * C;
+  hipLaunchKernelGGL(bn2_partial_bwd_kernel, dim3(S, cg), dim3(256), 0, st, dy, out, xa, xb, stats, wsa, wsb, M, C, rpc);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64 * BN_FW), 0, st, wsa, S, M, C, stats + C, dwa, dba, coefa);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64 * BN_FW), 0, st, wsb, S, M, C, stats + 3 * C, dwb, dbb, coefb);
+  hipLaunchKernelGGL(bn2_elem_bwd_kernel, dim3(S, cg), dim3(256), 0, st, dy, out, xa, xb, stats, wa, wb, coefa, coefb, dxa, dxb, M, C, rpc);
+  return kpf_check_launch("kpf_bn2_add_relu_backward");
 }
 
 }  // extern "C"

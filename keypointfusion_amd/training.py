@@ -1407,6 +1407,52 @@ class BatchNormReLU(torch.autograd.Function):
         return dx, dwb[0], dwb[1], None, None, None, None, None, None, None
 
 
+class Bn2AddRelu(torch.autograd.Function):
+    """relu(BatchNorm_a(xa) + BatchNorm_b(xb)) with batch statistics on fp32 rows [M, C] (DESA's local + feature branches, model/model.py:176-190; round 6):
+    kpf_bn2_add_relu_forward / _backward — the normalisations, the sum and the ReLU in one pass over the two pre-activations, the backward's masked gradient,
+    both branches' sums and both input gradients in four launches (two BatchNormReLU + AddRelu: seven launches each way and two normalised tensors written and
+    read back).  Same arithmetic per branch as BatchNormReLU; running statistics updated the same way."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, wa, ba, wb, bb, rma, rva, rmb, rvb, momentum, eps):
+        from . import lib as L
+        lib = L.load()
+        xa, xb = xa.contiguous(), xb.contiguous()
+        M, Cc = xa.shape
+        assert xa.dtype == torch.float32 and xb.dtype == torch.float32 and xb.shape == xa.shape and Cc % 4 == 0
+        out = torch.empty_like(xa)
+        stats = torch.empty(4, Cc, device=xa.device, dtype=torch.float32)
+        nws = lib.kpf_bn2_ws_floats(M, Cc)
+        ws = torch.empty(nws, device=xa.device, dtype=torch.float32)
+        f = lambda t: t.detach().contiguous().data_ptr()
+        o = lambda t: None if t is None else t.data_ptr()
+        L.check(lib.kpf_bn2_add_relu_forward(xa.data_ptr(), xb.data_ptr(), f(wa), f(ba), f(wb), f(bb), out.data_ptr(), stats.data_ptr(), o(rma), o(rva), o(rmb), o(rvb),
+                                             float(momentum), float(eps), ws.data_ptr(), nws, M, Cc, torch.cuda.current_stream().cuda_stream), "kpf_bn2_add_relu_forward")
+        ctx.save_for_backward(xa, xb, out, stats, wa, wb)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import lib as L
+        lib = L.load()
+        xa, xb, out, stats, wa, wb = ctx.saved_tensors
+        M, Cc = xa.shape
+        dy = dy.float().contiguous()
+        dxa, dxb = torch.empty_like(xa), torch.empty_like(xb)
+        dwb_a, dwb_b = torch.empty(2, Cc, device=xa.device, dtype=torch.float32), torch.empty(2, Cc, device=xa.device, dtype=torch.float32)
+        nws = lib.kpf_bn2_ws_floats(M, Cc)
+        ws = torch.empty(nws, device=xa.device, dtype=torch.float32)
+        f = lambda t: t.detach().contiguous().data_ptr()
+        L.check(lib.kpf_bn2_add_relu_backward(dy.data_ptr(), out.data_ptr(), xa.data_ptr(), xb.data_ptr(), stats.data_ptr(), f(wa), f(wb), dxa.data_ptr(), dxb.data_ptr(),
+                                              dwb_a[0].data_ptr(), dwb_a[1].data_ptr(), dwb_b[0].data_ptr(), dwb_b[1].data_ptr(), ws.data_ptr(), nws, M, Cc,
+                                              torch.cuda.current_stream().cuda_stream), "kpf_bn2_add_relu_backward")
+        return dxa, dxb, dwb_a[0], dwb_a[1], dwb_b[0], dwb_b[1], None, None, None, None, None, None
+
+
+def bn2_add_relu(xa, xb, wa, ba, wb, bb, rma, rva, rmb, rvb, momentum=0.1, eps=1e-5):
+    return Bn2AddRelu.apply(xa, xb, wa, ba, wb, bb, rma, rva, rmb, rvb, momentum, eps)
+
+
 def batchnorm_relu_rows(x, weight, bias, running_mean, running_var, momentum=0.1, eps=1e-5, relu=True, out_dtype=None, alias=False):
     return BatchNormReLU.apply(x, weight, bias, running_mean, running_var, momentum, eps, relu, out_dtype, alias)
 

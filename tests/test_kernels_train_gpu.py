@@ -1484,6 +1484,7 @@ def test_grouped_desa_and_fused_stacks_match_the_layer_by_layer_training_graph(n
         monkeypatch.setattr(TG, "TR_FUSED", new)
         monkeypatch.setattr(TG, "XATTN_FUSED", new)
         monkeypatch.setattr(TG, "UNSTACK_FUSED", new)
+        monkeypatch.setattr(TG, "BN2_FUSED", new)
         m = KPFusion(net, "", 21, "dexycb", "")
         m.load_state_dict(synthetic_sd(net), strict=True)
         m = m.to(dev).train()
@@ -1533,6 +1534,33 @@ def test_unstack_rows_forward_backward(cfg, dt):
         gi = ws[i].cpu()
         ref[..., i * gs:i * gs + Cc] = gi.permute(0, 2, 3, 1) if nchw else gi
     assert y.grad.dtype == dt and torch.equal(y.grad.float().cpu(), ref.to(dt).float())
+
+
+@pytest.mark.parametrize("M,Cc", [(43008 // 8, 384), (4097, 48), (37, 8)])
+def test_bn2_add_relu_matches_two_batchnorms_an_add_and_a_relu(M, Cc):
+    """training.Bn2AddRelu (kpf_bn2_add_relu_forward / _backward) against relu(F.batch_norm(xa) + F.batch_norm(xb)) in float64: output, both input gradients, all four
+    parameter gradients, both pairs of running statistics."""
+    from keypointfusion_amd import training as T
+    g = torch.Generator().manual_seed(M + Cc)
+    mk = lambda *sh: torch.randn(*sh, generator=g)
+    xa, xb = mk(M, Cc) * 2.0 + 3.0 * mk(Cc), mk(M, Cc) * 0.5 - 2.0 * mk(Cc)
+    wa, ba, wb, bb = torch.rand(Cc, generator=g) + 0.5, mk(Cc), torch.rand(Cc, generator=g) + 0.5, mk(Cc)
+    dy = mk(M, Cc)
+    dev = lambda t: t.cuda().requires_grad_(True)
+    xad, xbd, wad, bad, wbd, bbd = map(dev, (xa, xb, wa, ba, wb, bb))
+    rs = [torch.zeros(Cc).cuda(), torch.ones(Cc).cuda(), torch.zeros(Cc).cuda(), torch.ones(Cc).cuda()]
+    out = T.bn2_add_relu(xad, xbd, wad, bad, wbd, bbd, rs[0], rs[1], rs[2], rs[3], 0.1, 1e-5)
+    out.backward(dy.cuda())
+    ref_in = [t.double().requires_grad_(True) for t in (xa, xb, wa, ba, wb, bb)]
+    rr = [torch.zeros(Cc).double(), torch.ones(Cc).double(), torch.zeros(Cc).double(), torch.ones(Cc).double()]
+    ref = torch.relu(F.batch_norm(ref_in[0], rr[0], rr[1], ref_in[2], ref_in[3], True, 0.1, 1e-5) + F.batch_norm(ref_in[1], rr[2], rr[3], ref_in[4], ref_in[5], True, 0.1, 1e-5))
+    ref.backward(dy.double())
+    rel = lambda a, r: float((a.detach().cpu().double() - r.detach()).abs().max()) / max(float(r.detach().abs().max()), 1e-6)
+    assert rel(out, ref) < 2e-5
+    for got, want in zip((xad, xbd, wad, bad, wbd, bbd), ref_in):
+        assert rel(got.grad, want.grad) < 2e-4, (tuple(want.shape), rel(got.grad, want.grad))
+    for got, want in zip(rs, rr):
+        assert rel(got, want) < 1e-5
 
 
 def test_group_max_and_ball_group3_match_torch():
