@@ -418,6 +418,14 @@ int kpf_bn_train_backward(const void* dy, const void* x, const void* y, int x_dt
 int kpf_bn_train_backward_add(const void* dy, const void* x, const void* y, int x_dtype, int y_dtype, const float* mean, const float* invstd,
                               const float* w, const void* addend, void* dx, float* dw, float* db, int relu, float* ws, long ws_floats, long M, int C,
                               void* stream);
+/* Training (ABI 17): y[g][c] = max over the `group` consecutive rows of relu(BN(x)) (batch statistics; fp32 rows x [M][C], M % group == 0) — DESA's `bn -> ReLU ->
+ * max over a ball's 64 members` (model/model.py:188-192) — in one pass over the pre-activation (the winner's member index in arg [M / group][C]: first maximum);
+ * backward from dmax (rows dmax_ld floats apart): dx dense, dw / db; the BatchNorm sums run over the winners only.  stats [2][C] = mean, invstd. */
+long kpf_bn_relu_gmax_ws_floats(long M, int C);
+int kpf_bn_relu_gmax_forward(const float* x, const float* w, const float* b, float* y, unsigned char* arg, float* stats, float* rmean, float* rvar, float momentum,
+                             float eps, float* ws, long ws_floats, long M, int group, int C, void* stream);
+int kpf_bn_relu_gmax_backward(const float* dmax, int dmax_ld, const float* y, const unsigned char* arg, const float* x, const float* stats, const float* w, float* dx,
+                              float* dw, float* db, float* ws, long ws_floats, long M, int group, int C, void* stream);
 /* Training (ABI 17): out = relu(BN_a(xa) + BN_b(xb)) with batch statistics on fp32 rows [M][C] — DESA's local + feature branches (model/model.py:176-190) — in one
  * pass over the two pre-activations (statistics: two partial + finalize pairs, then ONE element-wise launch), and its backward (masked gradient, both branches'
  * sums, both input gradients: four launches).  stats [4][C] receives mean_a, invstd_a, mean_b, invstd_b (kept for the backward); running statistics nullable and

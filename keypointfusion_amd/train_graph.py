@@ -503,8 +503,15 @@ class TrainGraph:
                 g = add_relu(loc, ft)
             wb = n3(".conv_blocks.%d.0.weight")
             g = linear_hip(g, self.wg(wb).flatten(1), self.wg(n3(".conv_blocks.%d.0.bias")), "f32", None, "grp:" + wb[0], self.packs, 3)
-            g = self.bn_g(g, n3(".bn_blocks.%d.0"), relu=True)
-            mx = group_max(g, 64).view(B, Jn, 3 * C)  # == cat of the three radii's maxima on the channel axis
+            if BN2_FUSED:  # BatchNorm + ReLU + the maximum over the ball in one pass (training.BnReluGroupMax): the normalised tensor is never written
+                from .training import bn_relu_group_max
+                nm = n3(".bn_blocks.%d.0")
+                gw = lambda k: self.wg([n + k for n in nm])
+                mx = bn_relu_group_max(g, gw(".weight"), gw(".bias"), gw(".running_mean"), gw(".running_var"), self.momentum, 1e-5, 64).view(B, Jn, 3 * C)
+                self.nbt += [self.t[n + ".num_batches_tracked"] for n in nm]
+            else:
+                g = self.bn_g(g, n3(".bn_blocks.%d.0"), relu=True)
+                mx = group_max(g, 64).view(B, Jn, 3 * C)  # == cat of the three radii's maxima on the channel axis
             cat = torch.cat((mx, node_feat), -1).reshape(B * Jn, -1)  # rows of 512
             y = self.linear_rows(cat, self.t[p + ".fusion.0.weight"].flatten(1), self.t[p + ".fusion.0.bias"], p + ".fusion.0.weight")
             return self.bn_l(y, p + ".fusion.1", relu=True, out16=False).view(B, Jn, -1)

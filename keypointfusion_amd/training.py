@@ -1407,6 +1407,55 @@ class BatchNormReLU(torch.autograd.Function):
         return dx, dwb[0], dwb[1], None, None, None, None, None, None, None
 
 
+class BnReluGroupMax(torch.autograd.Function):
+    """max over `group` consecutive rows of relu(BatchNorm(x)) with batch statistics on fp32 rows [M, C] (DESA's `bn_blocks -> ReLU -> max over the ball`,
+    model/model.py:188-192; round 6): kpf_bn_relu_gmax_forward / _backward — the normalised tensor is never written, and the backward's BatchNorm sums run over
+    the winners only (BatchNormReLU + GroupMax: eight launches and four more passes over a 43008 x 384 tensor).  The gradient may arrive as a column slice of a
+    wider matrix (the concatenation behind the maximum): read in place."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, rm, rv, momentum, eps, group):
+        from . import lib as L
+        lib = L.load()
+        x = x.contiguous()
+        M, Cc = x.shape
+        assert x.dtype == torch.float32 and Cc % 4 == 0 and M % group == 0 and group <= 256
+        y = torch.empty(M // group, Cc, device=x.device, dtype=torch.float32)
+        arg = torch.empty(M // group, Cc, device=x.device, dtype=torch.uint8)
+        stats = torch.empty(2, Cc, device=x.device, dtype=torch.float32)
+        nws = lib.kpf_bn_relu_gmax_ws_floats(M, Cc)
+        ws = torch.empty(nws, device=x.device, dtype=torch.float32)
+        f = lambda t: t.detach().contiguous().data_ptr()
+        L.check(lib.kpf_bn_relu_gmax_forward(x.data_ptr(), f(w), f(b), y.data_ptr(), arg.data_ptr(), stats.data_ptr(), None if rm is None else rm.data_ptr(),
+                                             None if rv is None else rv.data_ptr(), float(momentum), float(eps), ws.data_ptr(), nws, M, int(group), Cc,
+                                             torch.cuda.current_stream().cuda_stream), "kpf_bn_relu_gmax_forward")
+        ctx.save_for_backward(x, y, arg, stats, w)
+        ctx.group = int(group)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import lib as L
+        lib = L.load()
+        x, y, arg, stats, w = ctx.saved_tensors
+        M, Cc = x.shape
+        dy = dy.float()
+        if not (dy.dim() == 2 and dy.stride(1) == 1 and dy.stride(0) % 4 == 0 and dy.stride(0) >= Cc and dy.data_ptr() % 16 == 0):
+            dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dwb = torch.empty(2, Cc, device=x.device, dtype=torch.float32)
+        nws = lib.kpf_bn_relu_gmax_ws_floats(M, Cc)
+        ws = torch.empty(nws, device=x.device, dtype=torch.float32)
+        L.check(lib.kpf_bn_relu_gmax_backward(dy.data_ptr(), dy.stride(0), y.data_ptr(), arg.data_ptr(), x.data_ptr(), stats.data_ptr(), w.detach().contiguous().data_ptr(),
+                                              dx.data_ptr(), dwb[0].data_ptr(), dwb[1].data_ptr(), ws.data_ptr(), nws, M, ctx.group, Cc,
+                                              torch.cuda.current_stream().cuda_stream), "kpf_bn_relu_gmax_backward")
+        return dx, dwb[0], dwb[1], None, None, None, None, None
+
+
+def bn_relu_group_max(x, w, b, rm, rv, momentum=0.1, eps=1e-5, group=64):
+    return BnReluGroupMax.apply(x, w, b, rm, rv, momentum, eps, group)
+
+
 class Bn2AddRelu(torch.autograd.Function):
     """relu(BatchNorm_a(xa) + BatchNorm_b(xb)) with batch statistics on fp32 rows [M, C] (DESA's local + feature branches, model/model.py:176-190; round 6):
     kpf_bn2_add_relu_forward / _backward — the normalisations, the sum and the ReLU in one pass over the two pre-activations, the backward's masked gradient,

@@ -1563,6 +1563,31 @@ def test_bn2_add_relu_matches_two_batchnorms_an_add_and_a_relu(M, Cc):
         assert rel(got, want) < 1e-5
 
 
+@pytest.mark.parametrize("G,group,Cc,ld", [(672 // 4, 64, 384, 512), (33, 64, 48, 48), (5, 7, 8, 12)])
+def test_bn_relu_group_max_matches_batchnorm_relu_and_max(G, group, Cc, ld):
+    """training.BnReluGroupMax (kpf_bn_relu_gmax_forward / _backward) against F.batch_norm -> relu -> max over `group` consecutive rows in float64: values, the input
+    gradient (dense), the parameter gradients and the running statistics; the incoming gradient is a column slice of a wider matrix (read in place)."""
+    from keypointfusion_amd import training as T
+    g = torch.Generator().manual_seed(G + Cc)
+    M = G * group
+    x = torch.randn(M, Cc, generator=g) * 1.5 + 2.0 * torch.randn(Cc, generator=g)
+    w, b = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) - 0.3
+    w[::5] *= -1.0  # (negative scales: the winner is then the member with the SMALLEST pre-activation)
+    dyw = torch.randn(G, ld, generator=g)
+    xd, wd, bd = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    rm, rv = torch.zeros(Cc).cuda(), torch.ones(Cc).cuda()
+    y = T.bn_relu_group_max(xd, wd, bd, rm, rv, 0.1, 1e-5, group)
+    y.backward(dyw.cuda()[:, :Cc])
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    rmr, rvr = torch.zeros(Cc).double(), torch.ones(Cc).double()
+    yr = torch.relu(F.batch_norm(xr, rmr, rvr, wr, br, True, 0.1, 1e-5)).view(G, group, Cc).max(1)[0]
+    yr.backward(dyw.double()[:, :Cc])
+    rel = lambda a, r: float((a.detach().cpu().double() - r.detach()).abs().max()) / max(float(r.detach().abs().max()), 1e-6)
+    assert rel(y, yr) < 2e-5
+    assert rel(xd.grad, xr.grad) < 2e-4 and rel(wd.grad, wr.grad) < 2e-4 and rel(bd.grad, br.grad) < 2e-4, (rel(xd.grad, xr.grad), rel(wd.grad, wr.grad), rel(bd.grad, br.grad))
+    assert rel(rm, rmr) < 1e-5 and rel(rv, rvr) < 1e-5
+
+
 def test_group_max_and_ball_group3_match_torch():
     """GroupMax (max over 64 consecutive rows with the winner kept) against torch.max and its autograd; BallGroup3 (the three radii channel-stacked, one backward
     launch) against BallGroup (radius by radius): same grouped rows and offsets, same index sets, same gradients towards the point / joint features."""
