@@ -418,6 +418,14 @@ int kpf_bn_train_backward(const void* dy, const void* x, const void* y, int x_dt
 int kpf_bn_train_backward_add(const void* dy, const void* x, const void* y, int x_dtype, int y_dtype, const float* mean, const float* invstd,
                               const float* w, const void* addend, void* dx, float* dw, float* db, int relu, float* ws, long ws_floats, long M, int C,
                               void* stream);
+/* Training (ABI 17): the embedding sums of a fusion block with their BatchNorms (batch statistics) inside: x [rows][n C], n = n1 + n2 <= 4 sibling Linear outputs side by
+ * side (C % 4 == 0, C <= 256), out [rows][C] = relu(S1) (n2 == 0) or relu(relu(S1) + S2) with S1 / S2 the sums of the first n1 / next n2 normalised blocks
+ * (model/model.py:254-259, 417-422) — one pass over the pre-activations forward, two backward; w, b, dw, db, running statistics: [n C]; stats [2][n C] = mean, invstd. */
+long kpf_bn_ssr_ws_floats(long rows, int C, int n);
+int kpf_bn_ssr_forward(const float* x, const float* w, const float* b, float* out, float* stats, float* rmean, float* rvar, float momentum, float eps, float* ws,
+                       long ws_floats, long rows, int C, int n1, int n2, void* stream);
+int kpf_bn_ssr_backward(const float* dout, const float* out, const float* x, const float* stats, const float* w, const float* b, float* dx, float* dw, float* db, float* ws,
+                        long ws_floats, long rows, int C, int n1, int n2, void* stream);
 /* Training (ABI 17): y[g][c] = max over the `group` consecutive rows of relu(BN(x)) (batch statistics; fp32 rows x [M][C], M % group == 0) — DESA's `bn -> ReLU ->
  * max over a ball's 64 members` (model/model.py:188-192) — in one pass over the pre-activation (the winner's member index in arg [M / group][C]: first maximum);
  * backward from dmax (rows dmax_ld floats apart): dx dense, dw / db; the BatchNorm sums run over the winners only.  stats [2][C] = mean, invstd. */

@@ -1787,6 +1787,125 @@ __global__ __launch_bounds__(256) void bn_gmax_elem_bwd_kernel(const float* __re
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 6: the embedding sums of a fusion block with their BatchNorms inside: x [rows][n C] holds n = n1 + n2 <= 4 sibling Linear outputs side by side,
+//   out [rows][C] = relu(S1)  (n2 == 0)   or   relu(relu(S1) + S2),   S1 = sum of BN_k(x_k) for k < n1,  S2 = sum for k >= n1      (model/model.py:254-259, 417-422)
+// in ONE pass over the pre-activations (BatchNorm pass + SlicesSumRelu wrote and re-read the normalised [rows][n C] tensor), and the backward — the masks, every
+// branch's two BatchNorm sums, every branch's input gradient — in two passes.  thread = (row lane, channel quad of C), all n branches; C4 <= 64.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int SSR_MAXN = 4;
+__device__ __forceinline__ void ssr_norm(const float* __restrict__ xr, const float* __restrict__ stats, const float* __restrict__ w, const float* __restrict__ b, int nC, int C, int q,
+                                         int n, f32x4* xc, f32x4* yv) {  // xc = x - mean, yv = BN(x) for the n branches of (row, quad)
+#pragma unroll
+  for (int k = 0; k < SSR_MAXN; ++k)
+    if (k < n) {
+      const int col = k * C + 4 * q;
+      xc[k] = kpf_ld4(xr + col) - kpf_ld4(stats + col);
+      yv[k] = xc[k] * (kpf_ld4(stats + nC + col) * kpf_ld4(w + col)) + kpf_ld4(b + col);
+    }
+}
+__global__ __launch_bounds__(256) void bn_ssr_fwd_kernel(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ w, const float* __restrict__ b,
+                                                         float* __restrict__ out, long n4, int C4, int n1, int n2) {
+  const int C = 4 * C4, n = n1 + n2, nC = n * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long r = i / C4;
+    const int q = (int)(i - r * C4);
+    f32x4 xc[SSR_MAXN], yv[SSR_MAXN];
+    ssr_norm(x + r * nC, stats, w, b, nC, C, q, n, xc, yv);
+    f32x4 s1 = yv[0];
+#pragma unroll
+    for (int k = 1; k < SSR_MAXN; ++k)
+      if (k < n1) s1 += yv[k];
+    f32x4 o = {fmaxf(s1[0], 0.f), fmaxf(s1[1], 0.f), fmaxf(s1[2], 0.f), fmaxf(s1[3], 0.f)};
+    if (n2 > 0) {
+#pragma unroll
+      for (int k = 1; k < SSR_MAXN; ++k)
+        if (k >= n1 && k < n) o += yv[k];
+      o = f32x4{fmaxf(o[0], 0.f), fmaxf(o[1], 0.f), fmaxf(o[2], 0.f), fmaxf(o[3], 0.f)};
+    }
+    kpf_st4(out + i * 4, o);
+  }
+}
+// the gradient of every branch's BN output at (row, quad): d = dout (out > 0); branches < n1 additionally masked by S1 > 0 when n2 > 0
+__device__ __forceinline__ void ssr_masks(const f32x4 g, const f32x4 o, const f32x4* yv, int n1, int n2, f32x4& d, f32x4& d1) {
+  d = f32x4{o[0] > 0.f ? g[0] : 0.f, o[1] > 0.f ? g[1] : 0.f, o[2] > 0.f ? g[2] : 0.f, o[3] > 0.f ? g[3] : 0.f};
+  d1 = d;
+  if (n2 > 0) {
+    f32x4 s1 = yv[0];
+#pragma unroll
+    for (int k = 1; k < SSR_MAXN; ++k)
+      if (k < n1) s1 += yv[k];
+    d1 = f32x4{s1[0] > 0.f ? d[0] : 0.f, s1[1] > 0.f ? d[1] : 0.f, s1[2] > 0.f ? d[2] : 0.f, s1[3] > 0.f ? d[3] : 0.f};
+  }
+}
+// grid (S): 256 threads = C4 quads x RL row lanes (RL = 256 / C4 rounded down); ws[chunk] = [2][n C]
+__global__ __launch_bounds__(256) void bn_ssr_partial_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ x,
+                                                                 const float* __restrict__ stats, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ ws,
+                                                                 long rows, int C4, int n1, int n2, int rows_per_chunk) {
+  extern __shared__ f32x4 ssr_red[];  // [2 n][256]
+  const int C = 4 * C4, n = n1 + n2, nC = n * C;
+  const int RL = 256 / C4;
+  const int q = threadIdx.x % C4, rl = threadIdx.x / C4;
+  const bool active = rl < RL;
+  f32x4 p0[SSR_MAXN], p1[SSR_MAXN];
+#pragma unroll
+  for (int k = 0; k < SSR_MAXN; ++k) p0[k] = p1[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    const long r0 = (long)blockIdx.x * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+    for (long r = r0 + rl; r < r1; r += RL) {
+      f32x4 xc[SSR_MAXN], yv[SSR_MAXN], d, d1;
+      ssr_norm(x + r * nC, stats, w, b, nC, C, q, n, xc, yv);
+      ssr_masks(kpf_ld4(dout + (r * C4 + q) * 4), kpf_ld4(out + (r * C4 + q) * 4), yv, n1, n2, d, d1);
+#pragma unroll
+      for (int k = 0; k < SSR_MAXN; ++k)
+        if (k < n) {
+          const f32x4 dk = k < n1 ? d1 : d;
+          p0[k] += dk;
+          p1[k] += dk * xc[k];
+        }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < SSR_MAXN; ++k)
+    if (k < n) {
+      ssr_red[(2 * k) * 256 + threadIdx.x] = p0[k];
+      ssr_red[(2 * k + 1) * 256 + threadIdx.x] = p1[k];
+    }
+  __syncthreads();
+  if (rl == 0) {
+    float* o = ws + (size_t)blockIdx.x * 2 * nC;
+    for (int k = 0; k < n; ++k) {
+      f32x4 s0 = ssr_red[(2 * k) * 256 + q], s1 = ssr_red[(2 * k + 1) * 256 + q];
+      for (int i = 1; i < RL; ++i) {
+        s0 += ssr_red[(2 * k) * 256 + i * C4 + q];
+        s1 += ssr_red[(2 * k + 1) * 256 + i * C4 + q];
+      }
+      kpf_st4(o + k * C + 4 * q, s0);
+      kpf_st4(o + nC + k * C + 4 * q, s1);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void bn_ssr_elem_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ x,
+                                                              const float* __restrict__ stats, const float* __restrict__ w, const float* __restrict__ b,
+                                                              const float* __restrict__ coef, float* __restrict__ dx, long n4, int C4, int n1, int n2) {
+  const int C = 4 * C4, n = n1 + n2, nC = n * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long r = i / C4;
+    const int q = (int)(i - r * C4);
+    f32x4 xc[SSR_MAXN], yv[SSR_MAXN], d, d1;
+    ssr_norm(x + r * nC, stats, w, b, nC, C, q, n, xc, yv);
+    ssr_masks(kpf_ld4(dout + i * 4), kpf_ld4(out + i * 4), yv, n1, n2, d, d1);
+#pragma unroll
+    for (int k = 0; k < SSR_MAXN; ++k)
+      if (k < n) {
+        const int col = k * C + 4 * q;
+        const f32x4 dk = k < n1 ? d1 : d;
+        const f32x4 sc = kpf_ld4(stats + nC + col) * kpf_ld4(w + col);
+        kpf_st4(dx + r * nC + col, sc * (dk - kpf_ld4(coef + col) - xc[k] * kpf_ld4(coef + nC + col)));
+      }
+  }
+}
+
 int bn_chunks(long M, int C, int* rows_per_chunk) {
   const BnGeom g = bn_geom(C);
   const int cg = (g.Q + 63) / 64;
@@ -1810,6 +1929,65 @@ long kpf_bn_ws_floats(long M, int C) {
   return (long)S * 2 * C + 2 * C;
 }
 
+
+/* the embedding sums with their BatchNorms inside (see bn_ssr_fwd_kernel): workspace floats for either direction */
+static int ssr_chunks(long rows, int C4, int* rpc) {
+  const int RL = 256 / C4;
+  long S = 1024;
+  const long smax = (rows + 2L * RL - 1) / (2L * RL);  // at least two rows per thread
+  if (S > smax) S = smax;
+  if (S < 1) S = 1;
+  *rpc = (int)((rows + S - 1) / S);
+  return (int)((rows + *rpc - 1) / *rpc);
+}
+long kpf_bn_ssr_ws_floats(long rows, int C, int n) {
+  if (rows <= 0 || C <= 0 || n <= 0 || C % 4) return 0;
+  int rpc, rp2;
+  const long S1 = bn_chunks(rows, n * C, &rpc), S2 = ssr_chunks(rows, C / 4, &rp2);
+  return (S1 > S2 ? S1 : S2) * 2 * n * C + 2L * n * C;
+}
+
+int kpf_bn_ssr_forward(const float* x, const float* w, const float* b, float* out, float* stats, float* rmean, float* rvar, float momentum, float eps, float* ws,
+                       long ws_floats, long rows, int C, int n1, int n2, void* stream) {
+  const int n = n1 + n2;
+  KPF_REQUIRE(x && w && b && out && stats && ws && rows > 0 && C > 0 && C % 4 == 0 && C / 4 <= 64 && n1 >= 1 && n2 >= 0 && n <= SSR_MAXN,
+              "kpf_bn_ssr_forward: bad arguments (C %% 4 == 0, C <= 256, 1 <= n1, n1 + n2 <= 4)");
+  KPF_REQUIRE(kpf_aligned16(x) && kpf_aligned16(out) && kpf_aligned16(stats) && kpf_aligned16(ws) && kpf_aligned16(w) && kpf_aligned16(b), "kpf_bn_ssr_forward: pointers must be 16-byte aligned");
+  const int nC = n * C;
+  int rpc;
+  const int S = bn_chunks(rows, nC, &rpc);
+  KPF_REQUIRE(ws_floats >= (long)S * 2 * nC, "kpf_bn_ssr_forward: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int cg = (nC / 4 + 63) / 64;
+  hipLaunchKernelGGL((bn_partial_kernel<0, false, float, float>), dim3(S, cg), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, ws, rows, nC,
+                     rpc);
+  hipLaunchKernelGGL(bn_stats_finalize_kernel<float>, dim3((nC + 63) / 64), dim3(64 * BN_FW), 0, st, x, ws, S, rows, nC, stats, stats + nC, rmean, rvar, momentum, eps);
+  const long n4 = rows * (C / 4);
+  long nb = (n4 + 255) / 256;
+  hipLaunchKernelGGL(bn_ssr_fwd_kernel, dim3((unsigned)(nb > 65535 ? 65535 : nb)), dim3(256), 0, st, x, stats, w, b, out, n4, C / 4, n1, n2);
+  return kpf_check_launch("kpf_bn_ssr_forward");
+}
+
+int kpf_bn_ssr_backward(const float* dout, const float* out, const float* x, const float* stats, const float* w, const float* b, float* dx, float* dw, float* db, float* ws,
+                        long ws_floats, long rows, int C, int n1, int n2, void* stream) {
+  const int n = n1 + n2;
+  KPF_REQUIRE(dout && out && x && stats && w && b && dx && dw && db && ws && rows > 0 && C > 0 && C % 4 == 0 && C / 4 <= 64 && n1 >= 1 && n2 >= 0 && n <= SSR_MAXN,
+              "kpf_bn_ssr_backward: bad arguments");
+  KPF_REQUIRE(kpf_aligned16(dout) && kpf_aligned16(out) && kpf_aligned16(x) && kpf_aligned16(dx) && kpf_aligned16(stats) && kpf_aligned16(ws) && kpf_aligned16(w) && kpf_aligned16(b),
+              "kpf_bn_ssr_backward: pointers must be 16-byte aligned");
+  const int nC = n * C;
+  int rpc;
+  const int S = ssr_chunks(rows, C / 4, &rpc);
+  KPF_REQUIRE(ws_floats >= (long)S * 2 * nC + 2 * nC, "kpf_bn_ssr_backward: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* coef = ws + (size_t)S * 2 * nC;
+  hipLaunchKernelGGL(bn_ssr_partial_bwd_kernel, dim3(S), dim3(256), (size_t)2 * n * 256 * sizeof(f32x4), st, dout, out, x, stats, w, b, ws, rows, C / 4, n1, n2, rpc);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((nC + 63) / 64), dim3(64 * BN_FW), 0, st, ws, S, rows, nC, stats + nC, dw, db, coef);
+  const long n4 = rows * (C / 4);
+  long nb = (n4 + 255) / 256;
+  hipLaunchKernelGGL(bn_ssr_elem_bwd_kernel, dim3((unsigned)(nb > 65535 ? 65535 : nb)), dim3(256), 0, st, dout, out, x, stats, w, b, coef, dx, n4, C / 4, n1, n2);
+  return kpf_check_launch("kpf_bn_ssr_backward");
+}
 
 /* BatchNorm + ReLU + maximum over `group` consecutive rows (see bn_relu_gmax_fwd_kernel): workspace floats for either direction */
 long kpf_bn_relu_gmax_ws_floats(long M, int C) {

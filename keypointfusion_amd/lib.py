@@ -123,6 +123,8 @@ _SIGS = {
     "kpf_dwconv7_wgrad_deferred": [_P] * 5 + [C.c_long] + [C.c_int] * 4 + [C.POINTER(WgradReduceDesc), _P],
     "kpf_wgrad_reduce_multi": [C.POINTER(WgradReduceDesc), C.c_int, _P],
     "kpf_row_gather_cols_f32": [_P, C.c_long, C.c_long, C.c_long, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_bn_ssr_forward": [_P] * 7 + [C.c_float, C.c_float, _P, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, _P],
+    "kpf_bn_ssr_backward": [_P] * 10 + [C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, _P],
     "kpf_bn_relu_gmax_forward": [_P] * 8 + [C.c_float, C.c_float, _P, C.c_long, C.c_long, C.c_int, C.c_int, _P],
     "kpf_bn_relu_gmax_backward": [_P, C.c_int] + [_P] * 9 + [C.c_long, C.c_long, C.c_int, C.c_int, _P],
     "kpf_bn2_add_relu_forward": [_P] * 12 + [C.c_float, C.c_float, _P, C.c_long, C.c_long, C.c_int, _P],
@@ -199,6 +201,7 @@ _LONG_SIGS = {  # entries returning a long
     "kpf_pack_desc_blocks": [C.POINTER(PackDesc)],
     "kpf_tr_stack_save_floats": [C.c_int],
     "kpf_bn2_ws_floats": [C.c_long, C.c_int],
+    "kpf_bn_ssr_ws_floats": [C.c_long, C.c_int, C.c_int],
     "kpf_bn_relu_gmax_ws_floats": [C.c_long, C.c_int],
     "kpf_xattn_train_save_floats": [C.c_int],
     "kpf_xattn_train_dy_floats": [C.c_int],

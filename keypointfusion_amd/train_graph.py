@@ -423,6 +423,13 @@ class TrainGraph:
         for nm in names:
             wb += [self.t[nm + ".0.weight"].flatten(1), self.t[nm + ".0.bias"]]
         y = linear_cat([t.reshape(B * N, t.shape[-1]) for t in xs], [nm + ".0.weight" for nm in names], self.packs, wb)
+        Cc = y.shape[1] // len(names)
+        if BN2_FUSED and Cc % 4 == 0 and Cc <= 256 and len(names) <= 4:  # the BatchNorms inside the sum + ReLU kernel (training.BnSlicesSumRelu)
+            from .training import bn_slices_sum_relu
+            bn = [nm + ".1" for nm in names]
+            gw = lambda k: self.wg([n_ + k for n_ in bn])
+            self.nbt += [self.t[n_ + ".num_batches_tracked"] for n_ in bn]
+            return bn_slices_sum_relu(y, gw(".weight"), gw(".bias"), gw(".running_mean"), gw(".running_var"), self.momentum, 1e-5, Cc, n1, n2).view(B, N, -1)
         y = self.bn_g(y, [nm + ".1" for nm in names])
         return slices_sum_relu(y, y.shape[1] // len(names), n1, n2).view(B, N, -1)
 

@@ -1407,6 +1407,52 @@ class BatchNormReLU(torch.autograd.Function):
         return dx, dwb[0], dwb[1], None, None, None, None, None, None, None
 
 
+class BnSlicesSumRelu(torch.autograd.Function):
+    """The embedding sums of a fusion block with their BatchNorms inside (round 6): x [rows, n C] = n = n1 + n2 <= 4 sibling Linear outputs side by side (LinearCat) ->
+    out [rows, C] = relu(S1) or relu(relu(S1) + S2) over the BatchNorm'd blocks (batch statistics per column), kpf_bn_ssr_forward / _backward: one pass over the
+    pre-activations forward and two backward, where BatchNormReLU + SlicesSumRelu wrote the normalised [rows, n C] tensor and read it back (and its gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, rm, rv, momentum, eps, C_, n1, n2):
+        from . import lib as L
+        lib = L.load()
+        x = x.contiguous()
+        rows, nC = x.shape
+        n = n1 + n2
+        assert x.dtype == torch.float32 and nC == n * C_ and C_ % 4 == 0 and C_ <= 256 and n <= 4
+        out = torch.empty(rows, C_, device=x.device, dtype=torch.float32)
+        stats = torch.empty(2, nC, device=x.device, dtype=torch.float32)
+        nws = lib.kpf_bn_ssr_ws_floats(rows, C_, n)
+        ws = torch.empty(nws, device=x.device, dtype=torch.float32)
+        wc, bc = w.detach().contiguous(), b.detach().contiguous()
+        L.check(lib.kpf_bn_ssr_forward(x.data_ptr(), wc.data_ptr(), bc.data_ptr(), out.data_ptr(), stats.data_ptr(), None if rm is None else rm.data_ptr(),
+                                       None if rv is None else rv.data_ptr(), float(momentum), float(eps), ws.data_ptr(), nws, rows, C_, n1, n2,
+                                       torch.cuda.current_stream().cuda_stream), "kpf_bn_ssr_forward")
+        ctx.save_for_backward(x, out, stats, wc, bc)
+        ctx.meta = (C_, n1, n2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import lib as L
+        lib = L.load()
+        x, out, stats, wc, bc = ctx.saved_tensors
+        C_, n1, n2 = ctx.meta
+        rows, nC = x.shape
+        dout = dout.float().contiguous()
+        dx = torch.empty_like(x)
+        dwb = torch.empty(2, nC, device=x.device, dtype=torch.float32)
+        nws = lib.kpf_bn_ssr_ws_floats(rows, C_, n1 + n2)
+        ws = torch.empty(nws, device=x.device, dtype=torch.float32)
+        L.check(lib.kpf_bn_ssr_backward(dout.data_ptr(), out.data_ptr(), x.data_ptr(), stats.data_ptr(), wc.data_ptr(), bc.data_ptr(), dx.data_ptr(), dwb[0].data_ptr(),
+                                        dwb[1].data_ptr(), ws.data_ptr(), nws, rows, C_, n1, n2, torch.cuda.current_stream().cuda_stream), "kpf_bn_ssr_backward")
+        return dx, dwb[0], dwb[1], None, None, None, None, None, None, None
+
+
+def bn_slices_sum_relu(x, w, b, rm, rv, momentum, eps, C_, n1, n2=0):
+    return BnSlicesSumRelu.apply(x, w, b, rm, rv, momentum, eps, C_, n1, n2)
+
+
 class BnReluGroupMax(torch.autograd.Function):
     """max over `group` consecutive rows of relu(BatchNorm(x)) with batch statistics on fp32 rows [M, C] (DESA's `bn_blocks -> ReLU -> max over the ball`,
     model/model.py:188-192; round 6): kpf_bn_relu_gmax_forward / _backward — the normalised tensor is never written, and the backward's BatchNorm sums run over

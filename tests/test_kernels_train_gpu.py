@@ -1588,6 +1588,33 @@ def test_bn_relu_group_max_matches_batchnorm_relu_and_max(G, group, Cc, ld):
     assert rel(rm, rmr) < 1e-5 and rel(rv, rvr) < 1e-5
 
 
+@pytest.mark.parametrize("rows,Cc,n1,n2", [(4096, 128, 3, 1), (672, 128, 2, 0), (77, 24, 1, 2), (33, 8, 4, 0)])
+def test_bn_slices_sum_relu_matches_batchnorm_then_sums(rows, Cc, n1, n2):
+    """training.BnSlicesSumRelu (kpf_bn_ssr_forward / _backward) against F.batch_norm over the n C stacked columns followed by relu(S1) / relu(relu(S1) + S2) in float64:
+    output, input gradient, parameter gradients, running statistics."""
+    from keypointfusion_amd import training as T
+    g = torch.Generator().manual_seed(rows + Cc + n1)
+    n = n1 + n2
+    x = torch.randn(rows, n * Cc, generator=g) * 1.5 + 2.0 * torch.randn(n * Cc, generator=g)
+    w, b = torch.rand(n * Cc, generator=g) + 0.5, torch.randn(n * Cc, generator=g) * 0.5
+    dy = torch.randn(rows, Cc, generator=g)
+    xd, wd, bd = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    rm, rv = torch.zeros(n * Cc).cuda(), torch.ones(n * Cc).cuda()
+    out = T.bn_slices_sum_relu(xd, wd, bd, rm, rv, 0.1, 1e-5, Cc, n1, n2)
+    out.backward(dy.cuda())
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    rmr, rvr = torch.zeros(n * Cc).double(), torch.ones(n * Cc).double()
+    yr = F.batch_norm(xr, rmr, rvr, wr, br, True, 0.1, 1e-5).view(rows, n, Cc)
+    ref = torch.relu(yr[:, :n1].sum(1))
+    if n2:
+        ref = torch.relu(ref + yr[:, n1:].sum(1))
+    ref.backward(dy.double())
+    rel = lambda a, r: float((a.detach().cpu().double() - r.detach()).abs().max()) / max(float(r.detach().abs().max()), 1e-6)
+    assert rel(out, ref) < 2e-5
+    assert rel(xd.grad, xr.grad) < 2e-4 and rel(wd.grad, wr.grad) < 2e-4 and rel(bd.grad, br.grad) < 2e-4, (rel(xd.grad, xr.grad), rel(wd.grad, wr.grad), rel(bd.grad, br.grad))
+    assert rel(rm, rmr) < 1e-5 and rel(rv, rvr) < 1e-5
+
+
 def test_group_max_and_ball_group3_match_torch():
     """GroupMax (max over 64 consecutive rows with the winner kept) against torch.max and its autograd; BallGroup3 (the three radii channel-stacked, one backward
     launch) against BallGroup (radius by radius): same grouped rows and offsets, same index sets, same gradients towards the point / joint features."""
