@@ -43,6 +43,10 @@ extern "C" {
 #define KPF_OUT_NCHW 32u       /* store out[b][n][oy][ox] (dense), ignoring out_ld/out_coff */
 #define KPF_ACT_GELU_SAVE 2048u /* with KPF_ACT_GELU (ABI 13): also store the pre-activation acc + bias to the buffer passed in the `res` slot (res_ld / res_coff describe
                                   it; no residual is read) and use the exact erf GELU — the forward of a training Linear + GELU in one launch */
+#define KPF_MMA_BF16 8192u     /* kpf_conv2d_f32 (ABI 17): fp32 storage, but the products MAY take the operands rounded to bf16 in registers (16-bit MFMA, fp32 accumulation) —
+                                  what torch.autocast does to a Linear between fp32 tensors; honoured by the plain 1x1 / linear launches of the 256 x 128, 128 x 128 and
+                                  128 x 64 tiles (the fusion head's wide Linears in the mixed-precision training step), ignored elsewhere */
+#define KPF_MMA_F16 16384u     /* the same with f16 rounding */
 #define KPF_PRO_LN 4096u       /* kpf_conv2d_h16 with KPF_ACT_GELU (ABI 15): the LayerNorm in front of the layer (convNeXT/convnext.py:42-44, pwconv1(norm(x))) is folded
                                   into the GEMM: `in` is the un-normalised tensor, `w` holds W diag(ln_w), `bias` W ln_b + b, pro_shift s[n] = sum_k w[n][k] (of the
                                   16-bit weights, in fp32) and pro_scale the (mean, rstd) pair of every pixel (kpf_ln_stats_merge);

@@ -89,7 +89,10 @@ __device__ __forceinline__ float gelu_erf(float x) {
 
 // GELU for 16-bit outputs: kpf_gelu_h16 (kpf_common.h)
 __device__ __forceinline__ float gelu_h16(float x) { return kpf_gelu_h16(x); }
-enum { ARITH_F32 = 0, ARITH_SPLIT = 1, ARITH_SPLIT_W = 2, ARITH_BF16 = 3, ARITH_F16 = 4 };
+enum { ARITH_F32 = 0, ARITH_SPLIT = 1, ARITH_SPLIT_W = 2, ARITH_BF16 = 3, ARITH_F16 = 4, ARITH_R_BF16 = 5, ARITH_R_F16 = 6 };
+// ARITH_R_* (round 6): fp32 STORAGE on both sides, the operands rounded to bf16 / f16 in registers and multiplied on the 16-bit MFMA with fp32 accumulation — what
+// torch.autocast does to a Linear whose tensors stay fp32 around it (the fusion head's DESA Linears in the mixed-precision training step: KPF_MMA_BF16 / _F16).
+// Separate instantiations: the fp32 kernels' code is untouched.
 // the GELU every epilogue of one arithmetic uses (all tile shapes of a storage type must agree bit for bit: a sample's result must not depend on
 // which kernel its batch size selects)
 template <int ARITH>
@@ -155,7 +158,8 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
   constexpr int RPP = 8 * NW;               // rows staged per pass: every wave moves 8 rows x 128 B = one 1-KiB DMA
   constexpr int AP = (BM + RPP - 1) / RPP;  // A staging passes
   constexpr int BP = (BN + RPP - 1) / RPP;  // B staging passes
-  constexpr bool WHOLE = NS > 2 || ARITH == ARITH_F32;  // every wave issues every staging pass (no exec-masked DMA branches)
+  constexpr bool R16 = ARITH == ARITH_R_BF16 || ARITH == ARITH_R_F16;
+  constexpr bool WHOLE = NS > 2 || ARITH == ARITH_F32 || R16;  // every wave issues every staging pass (no exec-masked DMA branches)
   constexpr int BMR = WHOLE ? AP * RPP : BM;  // staged rows (whole passes; the extra rows are never read)
   constexpr int BNR = WHOLE ? BP * RPP : BN;
   constexpr int TILE = (BMR + BNR) * BK;
@@ -601,13 +605,36 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) xf[j][e] = fmaxf(fmaf(xf[j][e], sp[e], tp[e]), 0.f);
         }
+        if constexpr (ARITH == ARITH_R_BF16 || ARITH == ARITH_R_F16) {
+          // lane (l % 16, l / 16) holds k = 4 (l / 16) .. + 3 of its row of either operand: exactly what one v_mfma_f32_16x16x16 takes from it
+          typedef short r16x4 __attribute__((ext_vector_type(4)));
+          r16x4 wh[TN], xh[TM];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+          for (int i = 0; i < TN; ++i) {
+            if constexpr (ARITH == ARITH_R_BF16) wh[i] = __builtin_bit_cast(r16x4, bf16x4{(bf16_t)wf[i][0], (bf16_t)wf[i][1], (bf16_t)wf[i][2], (bf16_t)wf[i][3]});
+            else wh[i] = __builtin_bit_cast(r16x4, f16x4{(f16_t)wf[i][0], (f16_t)wf[i][1], (f16_t)wf[i][2], (f16_t)wf[i][3]});
+          }
+#pragma unroll
+          for (int j = 0; j < TM; ++j) {
+            if constexpr (ARITH == ARITH_R_BF16) xh[j] = __builtin_bit_cast(r16x4, bf16x4{(bf16_t)xf[j][0], (bf16_t)xf[j][1], (bf16_t)xf[j][2], (bf16_t)xf[j][3]});
+            else xh[j] = __builtin_bit_cast(r16x4, f16x4{(f16_t)xf[j][0], (f16_t)xf[j][1], (f16_t)xf[j][2], (f16_t)xf[j][3]});
+          }
 #pragma unroll
           for (int i = 0; i < TN; ++i)
 #pragma unroll
-            for (int j = 0; j < TM; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][e], xf[j][e], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TM; ++j) {
+              if constexpr (ARITH == ARITH_R_BF16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh[i], xh[j], acc[i][j], 0, 0, 0);
+              else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, wh[i]), __builtin_bit_cast(f16x4, xh[j]), acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+              for (int j = 0; j < TM; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][e], xf[j][e], acc[i][j], 0, 0, 0);
+        }
       }
     }
     if (NS == 2) __syncthreads();  // next tile landed (vmcnt drained by the barrier's fence); every wave is done reading `cur`
@@ -827,6 +854,10 @@ template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO, int EPI, int
 __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const ConvArgs a) {
   igemm_body<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH_F32, NS>(kpf_group_args(a));
 }
+template <int TM, int TN, int WM, int WN, bool IS1X1, int EPI, int ARITH>
+__global__ __launch_bounds__(64 * WM * WN) void igemm_r16_kernel(const ConvArgs a) {  // fp32 storage, 16-bit products (ARITH_R_*)
+  igemm_body<TM, TN, WM, WN, IS1X1, false, EPI, ARITH, 2>(kpf_group_args(a));
+}
 template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO, int EPI, int ARITH, int NS>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_split_kernel(const ConvArgs a) {
   igemm_body<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH, NS>(kpf_group_args(a));
@@ -852,7 +883,8 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void igemm_h16_occ_kernel(const Co
 template <int TM, int TN, int WM, int WN, bool IS1X1, bool HAS_PRO, int EPI, int ARITH, int NS>
 int launch_one(const ConvArgs& a, hipStream_t st) {
   constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN, RPP = 8 * WM * WN;
-  constexpr bool WHOLE = NS > 2 || ARITH == ARITH_F32;
+  constexpr bool R16 = ARITH == ARITH_R_BF16 || ARITH == ARITH_R_F16;
+  constexpr bool WHOLE = NS > 2 || ARITH == ARITH_F32 || R16;
   constexpr int BMR = WHOLE ? (BM + RPP - 1) / RPP * RPP : BM, BNR = WHOLE ? (BN + RPP - 1) / RPP * RPP : BN;
   constexpr bool H16 = ARITH == ARITH_BF16 || ARITH == ARITH_F16;
   size_t lds = (size_t)(NS * (BMR + BNR) * BK + (HAS_PRO ? 2 * a.Kp * (H16 ? 2 : 1) : 0)) * sizeof(float);
@@ -863,6 +895,8 @@ int launch_one(const ConvArgs& a, hipStream_t st) {
   void (*kern)(const ConvArgs);
   if constexpr (ARITH == ARITH_F32)
     kern = igemm_f32_kernel<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, NS>;
+  else if constexpr (R16)
+    kern = igemm_r16_kernel<TM, TN, WM, WN, IS1X1, EPI, ARITH>;
   else if constexpr (H16 && NS == 1)
     kern = igemm_h16_occ_kernel<TM, TN, WM, WN, IS1X1, HAS_PRO, EPI, ARITH>;
   else if constexpr (H16)
@@ -934,6 +968,14 @@ int launch_cfg(ConvArgs& a, bool is1x1, hipStream_t st) {
   static const int stagger = []() { const char* e = getenv("KPF_STAGGER"); return e ? atoi(e) : 0; }();
   const long skew = (long)BM * BN * a.Kp / (128L * 5 * 2048);
   a.skew = a.nblk >= 512 ? (int)(skew < stagger ? skew : stagger) : 0;
+  if constexpr ((TM == 4 && TN == 4 && WN == 2 && (WM == 4 || WM == 2)) || (TM == 2 && TN == 4 && WM == 4 && WN == 1)) {
+    // 16-bit products on fp32 storage (KPF_MMA_BF16 / _F16): plain 1x1 / linear layers on the three tile shapes the fusion head's wide Linears take; anything
+    // else keeps the fp32 products (the flag is a permission, not a demand)
+    if ((a.flags & (KPF_MMA_BF16 | KPF_MMA_F16)) && is1x1 && !a.ps && !(a.flags & (KPF_RES_ADD | KPF_ACT_GELU | KPF_IN_SPLIT | KPF_W_SPLIT | KPF_OUT_SPLIT | KPF_OUT_NCHW))) {
+      if (a.flags & KPF_MMA_BF16) return launch_one<TM, TN, WM, WN, true, false, EPI_LIN, ARITH_R_BF16, 2>(a, st);
+      return launch_one<TM, TN, WM, WN, true, false, EPI_LIN, ARITH_R_F16, 2>(a, st);
+    }
+  }
   if (a.flags & KPF_IN_SPLIT) return launch_arith<TM, TN, WM, WN, ARITH_SPLIT, NS_SPLIT>(a, is1x1, st);
   if (a.flags & KPF_W_SPLIT) return launch_arith<TM, TN, WM, WN, ARITH_SPLIT_W, NS_SPLIT>(a, is1x1, st);
   return launch_arith<TM, TN, WM, WN, ARITH_F32, NS_SPLIT == 1 ? 2 : 2>(a, is1x1, st);

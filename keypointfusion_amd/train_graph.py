@@ -47,6 +47,7 @@ XATTN_FUSED = bool(int(os.environ.get("KPF_XATTN_FUSED", "1")))  # the decoder l
 TR_MMA = os.environ.get("KPF_TR_MMA", "auto")  # GEMM arithmetic of the fused stacks: "auto" = the module's precision; "f32" | "bf16" | "f16" force one
 # 1 (default): DESA's three radii as ONE channel-stacked chain — grouped Linears (G = 3), BatchNorm / add + ReLU / group maximum over 3 x 128 channels, one
 # grouping launch each way (training.BallGroup3 / LinearSlices / GroupMax) — instead of three chains of small launches; 0: radius by radius
+HEAD_MMA = os.environ.get("KPF_HEAD_MMA", "auto")  # products of DESA's wide Linears: "auto" = the module's precision (16-bit operands in the mixed-precision step), "f32"
 BN2_FUSED = bool(int(os.environ.get("KPF_BN2_FUSED", "1")))  # DESA's relu(BatchNorm(local) + BatchNorm(features)) as one pass each way (training.Bn2AddRelu)
 UNSTACK_FUSED = bool(int(os.environ.get("KPF_UNSTACK_FUSED", "1")))  # the paired backbones' maps -> dense fp32 maps in two launches each way (training.UnstackRows)
 DESA_GROUPED = bool(int(os.environ.get("KPF_DESA_GROUPED", "1")))
@@ -496,7 +497,11 @@ class TrainGraph:
             wl = n3(".conv_l0_blocks.%d.weight")
             loc = linear_slices(GX3, wl, self.packs, [self.t[k] for i in range(3) for k in (p + ".conv_l0_blocks.%d.weight" % i, p + ".conv_l0_blocks.%d.bias" % i)])
             wf = n3(".conv_f0_blocks.%d.weight")
-            ft = linear_hip(GF3, self.wg(wf).flatten(1), self.wg(n3(".conv_f0_blocks.%d.bias")), "f32", None, "grp:" + wf[0], self.packs, 3)
+            # (mixed precision: the two wide Linears of the chain multiply operands rounded to the step's 16-bit type, fp32 storage and accumulation — KPF_HEAD_MMA)
+            from .training import head_mma
+            hm = (getattr(self.m, "precision", "f32") if HEAD_MMA == "auto" else HEAD_MMA)
+            with head_mma(hm):
+                ft = linear_hip(GF3, self.wg(wf).flatten(1), self.wg(n3(".conv_f0_blocks.%d.bias")), "f32", None, "grp:" + wf[0], self.packs, 3)
             if BN2_FUSED:  # relu(bn_l0(.) + bn_f0(.)): both normalisations, the sum and the ReLU in one pass over the two pre-activations (training.Bn2AddRelu)
                 from .training import bn2_add_relu
                 na, nb = n3(".bn_l0_blocks.%d"), n3(".bn_f0_blocks.%d")
@@ -509,7 +514,8 @@ class TrainGraph:
                 ft = self.bn_g(ft, n3(".bn_f0_blocks.%d"))
                 g = add_relu(loc, ft)
             wb = n3(".conv_blocks.%d.0.weight")
-            g = linear_hip(g, self.wg(wb).flatten(1), self.wg(n3(".conv_blocks.%d.0.bias")), "f32", None, "grp:" + wb[0], self.packs, 3)
+            with head_mma(hm):
+                g = linear_hip(g, self.wg(wb).flatten(1), self.wg(n3(".conv_blocks.%d.0.bias")), "f32", None, "grp:" + wb[0], self.packs, 3)
             if BN2_FUSED:  # BatchNorm + ReLU + the maximum over the ball in one pass (training.BnReluGroupMax): the normalised tensor is never written
                 from .training import bn_relu_group_max
                 nm = n3(".bn_blocks.%d.0")

@@ -776,6 +776,26 @@ class PackCache:
         L.check(lib.kpf_pack_conv_weights_multi(self.table.data_ptr(), len(self.entries), self.total_blocks, st), "kpf_pack_conv_weights_multi")
 
 
+# 16-bit products for fp32-storage GEMMs (KPF_MMA_BF16 / _F16 of include/kpf.h): a flag word that _conv_any adds to every fp32 launch while a `head_mma(...)` block
+# is open — TrainGraph opens one around DESA's wide Linears in the mixed-precision step (what autocast gives those Linears).  Conv2dNHWC records the word of its
+# forward and re-opens it for its data-gradient GEMM.
+_HEAD_MMA = [0]
+
+
+class head_mma:
+    def __init__(self, prec):
+        from . import lib as L
+        self.word = {"bf16": L.KPF_MMA_BF16, "f16": L.KPF_MMA_F16}.get(prec, 0) if not isinstance(prec, int) else int(prec)
+
+    def __enter__(self):
+        self.old, _HEAD_MMA[0] = _HEAD_MMA[0], self.word
+        return self
+
+    def __exit__(self, *exc):
+        _HEAD_MMA[0] = self.old
+        return False
+
+
 def _conv_any(pc, x4, prec, out_ld=None, res=None, flags=0, out2=None):
     """engine.conv (fp32) or engine16.conv16 (bf16 / f16) on an NHWC tensor [B, H, W, C]; returns the NHWC output tensor.  A GroupedPack
     (G convolutions over channel-stacked activations, one launch): x4 is [B, H, W, G*Cin], the result [B, OH, OW, G*N].  out_ld > N: the result
@@ -783,6 +803,8 @@ def _conv_any(pc, x4, prec, out_ld=None, res=None, flags=0, out2=None):
     from .engine import Act, conv
     B, H, W, Cc = x4.shape
     G = getattr(pc, "groups", 1)
+    if prec == "f32" and _HEAD_MMA[0]:
+        flags |= _HEAD_MMA[0]
     if out_ld is not None and out_ld != pc.N:
         assert G == 1 and pc.merge == 1
         tdt, kdt = (None, None) if prec == "f32" else __import__("keypointfusion_amd.engine16", fromlist=["DTYPES"]).DTYPES[prec]
@@ -2758,6 +2780,7 @@ class Conv2dNHWC(torch.autograd.Function):
         gelu_out: returns (z, gelu(z)) with z = x W^T + b from ONE launch (KPF_ACT_GELU_SAVE: the GEMM's epilogue stores both); gelu(z) carries no
         gradient — hand it to the following layer as g_pre together with gelu_in=True (that layer then skips its own GELU pass and returns d z)."""
         assert x.is_cuda and x.dim() == 4
+        ctx.mma16 = _HEAD_MMA[0]  # (the product type of this forward: the data-gradient GEMM of the backward takes the same)
         B, H, W, Cin = x.shape
         N, Cw, KH, KW = weight.shape
         cm = 4 if prec == "f32" else 8
@@ -2840,6 +2863,11 @@ class Conv2dNHWC(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, g2=None, g3=None):
+        with head_mma(int(getattr(ctx, "mma16", 0))):
+            return Conv2dNHWC._backward(ctx, dy, g2, g3)
+
+    @staticmethod
+    def _backward(ctx, dy, g2=None, g3=None):
         g_alias = (g3 if getattr(ctx, "gelu_out", False) else g2) if ctx.alias else None  # (outputs: y [, gelu(y) without gradient] [, the alias of x])
         x, weight, z = ctx.saved_tensors
         if dy is None:  # (only the alias was used)
