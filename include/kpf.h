@@ -29,6 +29,10 @@ extern "C" {
 #define KPF_DT_F32 0
 #define KPF_DT_BF16 1
 #define KPF_DT_F16 2
+/* kpf_conv2d_wgrad_groups / _deferred only (ABI 17): fp32 operands, the products taken on their bf16 / f16 roundings (16-bit MFMA, fp32 accumulation) — the weight
+ * gradient of a layer whose forward ran with KPF_MMA_BF16 / _F16; honoured by the 64 x 64 tile form, fp32 products otherwise */
+#define KPF_DT_F32_MMA_BF16 8
+#define KPF_DT_F32_MMA_F16 9
 
 /* kpf_conv_desc.flags */
 #define KPF_ACT_RELU 1u        /* y = relu(acc + bias)                                    */

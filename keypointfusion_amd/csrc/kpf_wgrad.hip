@@ -74,7 +74,9 @@ __device__ __forceinline__ void unpack8(const uint4, float, f32x4&, f32x4&) {}  
 // 16-byte global loads of 8 values into registers while the previous tile is multiplied, widened to fp32 on the way into LDS — the
 // MFMAs, accumulation and reduction are the fp32 ones (the master weight's gradient is not rounded), and the separate
 // 16-bit -> fp32 passes over dY and X disappear.
-template <int VN, int VK, typename TIN, bool GROUPED = false>
+// R16 (round 6; fp32 operands only): 0 = fp32 products; 1 / 2 = the operands rounded to bf16 / f16 in registers, four reduction rows per v_mfma_f32_16x16x16 (the weight
+// gradient of a Linear whose forward multiplied rounded operands: DESA's wide Linears in the mixed-precision step); accumulation, split and reduce unchanged.
+template <int VN, int VK, typename TIN, bool GROUPED = false, int R16 = 0>
 __device__ __forceinline__ void wgrad_f32_body(const WgradArgs& a, const int bx, const int split) {
   constexpr bool DMA = std::is_same<TIN, float>::value;
   constexpr int BN = 32 * VN, BK = 32 * VK;     // output tile; 2 x 2 waves, wave tile (16 VN) x (16 VK)
@@ -251,15 +253,49 @@ __device__ __forceinline__ void wgrad_f32_body(const WgradArgs& a, const int bx,
       if constexpr (DMA) stage(s + 1, lds + ((s + 1) & 1) * TILE);
       else load_regs(s + 1);  // in flight under this tile's MFMAs, written to the other buffer below
     }
+    if constexpr (R16 != 0) {
+      static_assert(RB % 16 == 0, "four MFMA k-groups of four rows");
+      typedef short r16x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-    for (int q = 0; q < RB / 4; ++q) {
-      const fvn af = *reinterpret_cast<const fvn*>(cur + a_off + 4 * q * BN);
-      const fvk bf = *reinterpret_cast<const fvk*>(cur + b_off + 4 * q * BK);
-      if (want_db) dbs += af;
+      for (int q = 0; q < RB / 16; ++q) {  // rows 16 q + 4 e + (lane / 16), e = 0..3: this lane's four k values of one 16-deep MFMA (both operands alike)
+        fvn af[4];
+        fvk bf[4];
 #pragma unroll
-      for (int i = 0; i < VN; ++i)
+        for (int e = 0; e < 4; ++e) {
+          af[e] = *reinterpret_cast<const fvn*>(cur + a_off + 4 * (4 * q + e) * BN);
+          bf[e] = *reinterpret_cast<const fvk*>(cur + b_off + 4 * (4 * q + e) * BK);
+          if (want_db) dbs += af[e];
+        }
+        r16x4 ah[VN], bh[VK];
 #pragma unroll
-        for (int j = 0; j < VK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < VN; ++i) {
+          if constexpr (R16 == 1) ah[i] = __builtin_bit_cast(r16x4, bf16x4{(bf16_t)af[0][i], (bf16_t)af[1][i], (bf16_t)af[2][i], (bf16_t)af[3][i]});
+          else ah[i] = __builtin_bit_cast(r16x4, f16x4{(f16_t)af[0][i], (f16_t)af[1][i], (f16_t)af[2][i], (f16_t)af[3][i]});
+        }
+#pragma unroll
+        for (int j = 0; j < VK; ++j) {
+          if constexpr (R16 == 1) bh[j] = __builtin_bit_cast(r16x4, bf16x4{(bf16_t)bf[0][j], (bf16_t)bf[1][j], (bf16_t)bf[2][j], (bf16_t)bf[3][j]});
+          else bh[j] = __builtin_bit_cast(r16x4, f16x4{(f16_t)bf[0][j], (f16_t)bf[1][j], (f16_t)bf[2][j], (f16_t)bf[3][j]});
+        }
+#pragma unroll
+        for (int i = 0; i < VN; ++i)
+#pragma unroll
+          for (int j = 0; j < VK; ++j) {
+            if constexpr (R16 == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, ah[i]), __builtin_bit_cast(f16x4, bh[j]), acc[i][j], 0, 0, 0);
+          }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < RB / 4; ++q) {
+        const fvn af = *reinterpret_cast<const fvn*>(cur + a_off + 4 * q * BN);
+        const fvk bf = *reinterpret_cast<const fvk*>(cur + b_off + 4 * q * BK);
+        if (want_db) dbs += af;
+#pragma unroll
+        for (int i = 0; i < VN; ++i)
+#pragma unroll
+          for (int j = 0; j < VK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
     }
     if constexpr (!DMA) {
       if (s + 1 < ns) write_lds(lds + ((s + 1) & 1) * TILE);
@@ -301,6 +337,10 @@ __device__ __forceinline__ void wgrad_f32_body(const WgradArgs& a, const int bx,
 template <int VN, int VK, typename TIN>
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradArgs a) {
   wgrad_f32_body<VN, VK, TIN>(wg_group_args<TIN>(a), blockIdx.x, blockIdx.y);
+}
+template <int R16>
+__global__ __launch_bounds__(256) void wgrad_r16_kernel(const WgradArgs a) {  // 64 x 64 tiles, fp32 operands, 16-bit products
+  wgrad_f32_body<2, 2, float, false, R16>(wg_group_args<float>(a), blockIdx.x, blockIdx.y);
 }
 
 // Grouped form for Linear layers over few rows (the 21-token stacks of the fusion head: M = 21 B): ~80 such weight gradients per
@@ -1164,7 +1204,15 @@ int launch_wgrad(const WgradArgs& a, const Plan& p, hipStream_t st) {
 }
 
 template <typename TIN>
-int launch_wgrad_any(const WgradArgs& a, const Plan& p, hipStream_t st) {
+int launch_wgrad_any(const WgradArgs& a, const Plan& p, hipStream_t st, int r16 = 0) {
+  if constexpr (std::is_same<TIN, float>::value) {
+    if (r16 && p.vn == 2 && p.vk == 2) {  // (the 64 x 64 form only: what the plan gives the layers that ask; other tile shapes keep fp32 products)
+      constexpr int LDS = 2 * RB * 32 * (2 + 2) * 4;
+      if (r16 == 1) hipLaunchKernelGGL(wgrad_r16_kernel<1>, dim3(p.tilesN * p.tilesK, p.S, a.groups), dim3(256), LDS, st, a);
+      else hipLaunchKernelGGL(wgrad_r16_kernel<2>, dim3(p.tilesN * p.tilesK, p.S, a.groups), dim3(256), LDS, st, a);
+      return kpf_check_launch("kpf_conv2d_wgrad");
+    }
+  }
   if (p.vn == 4 && p.vk == 4) return launch_wgrad<4, 4, TIN>(a, p, st);
   if (p.vn == 4) return launch_wgrad<4, 2, TIN>(a, p, st);
   if (p.vk == 4) return launch_wgrad<2, 4, TIN>(a, p, st);
@@ -1216,6 +1264,8 @@ static int conv2d_wgrad_impl(const void* dy, const void* x, int dtype, float* dw
   const bool trimmed = cin_valid != Cin || n_valid != N;
   KPF_REQUIRE(groups >= 1 && (long)groups * Cin <= ldx && (long)groups * N <= ldy, "kpf_conv2d_wgrad: %d groups of %d / %d channels exceed the pixel strides %d / %d", groups, Cin, N, ldx, ldy);
   KPF_REQUIRE(dy && x && dw && ws, "kpf_conv2d_wgrad_f32: null pointer");
+  int r16 = 0;  // KPF_DT_F32_MMA_BF16 / _F16: fp32 operands, products on their 16-bit roundings
+  if (dtype == KPF_DT_F32_MMA_BF16 || dtype == KPF_DT_F32_MMA_F16) r16 = dtype == KPF_DT_F32_MMA_BF16 ? 1 : 2, dtype = KPF_DT_F32;
   KPF_REQUIRE(dtype == KPF_DT_F32 || dtype == KPF_DT_BF16 || dtype == KPF_DT_F16, "kpf_conv2d_wgrad: unknown dtype %d", dtype);
   if (dtype != KPF_DT_F32)
     KPF_REQUIRE(Cin % 8 == 0 && ldx % 8 == 0 && N % 8 == 0 && ldy % 8 == 0, "kpf_conv2d_wgrad_h16: Cin, N, ldx, ldy must be multiples of 8");
@@ -1286,7 +1336,7 @@ static int conv2d_wgrad_impl(const void* dy, const void* x, int dtype, float* dw
     }
     rc = kpf_check_launch("kpf_conv2d_wgrad_h16");
   } else {
-    rc = dtype == KPF_DT_F32 ? launch_wgrad_any<float>(a, p, st)
+    rc = dtype == KPF_DT_F32 ? launch_wgrad_any<float>(a, p, st, r16)
                              : (dtype == KPF_DT_BF16 ? launch_wgrad_any<bf16_t>(a, p, st) : launch_wgrad_any<f16_t>(a, p, st));
   }
   if (rc != KPF_OK || direct) return rc;

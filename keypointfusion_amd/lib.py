@@ -17,6 +17,7 @@ KPF_RELU_AFTER_RES = 16
 KPF_RES_GELU_GRAD = 1024
 KPF_ACT_GELU_SAVE = 2048
 KPF_PRO_LN = 4096
+KPF_DT_F32_MMA_BF16, KPF_DT_F32_MMA_F16 = 8, 9  # weight gradients of fp32 operands on their 16-bit roundings (kpf_conv2d_wgrad_groups / _deferred)
 KPF_MMA_BF16, KPF_MMA_F16 = 8192, 16384  # kpf_conv2d_f32: fp32 storage, products on operands rounded to 16 bits in registers (ABI 17)
 KPF_OUT_NCHW = 32
 KPF_ACT_LEAKY = 64

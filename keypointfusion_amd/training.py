@@ -1214,6 +1214,8 @@ def conv_wgrad_hip(dy, x, wshape, stride, pad, want_db=True, groups=1, weight=No
     db = torch.empty(N * groups, device=x.device, dtype=torch.float32) if want_db else None
     st = torch.cuda.current_stream().cuda_stream
     dt = (L.KPF_DT_BF16 if dy.dtype == torch.bfloat16 else L.KPF_DT_F16) if h16 else L.KPF_DT_F32
+    if not h16 and _HEAD_MMA[0]:  # (inside a head_mma block: the layer's forward multiplied rounded operands, its weight gradient does too)
+        dt = L.KPF_DT_F32_MMA_BF16 if _HEAD_MMA[0] == L.KPF_MMA_BF16 else L.KPF_DT_F32_MMA_F16
     grp = DeferredParamGrads.wants_reduce(weight, N * groups, bias_ptr if want_db else None) if weight is not None and tuple(weight.shape) == tuple(wshape) else None
     if grp is not None:
         desc = L.WgradReduceDesc()

@@ -1615,6 +1615,36 @@ def test_bn_slices_sum_relu_matches_batchnorm_then_sums(rows, Cc, n1, n2):
     assert rel(rm, rmr) < 1e-5 and rel(rv, rvr) < 1e-5
 
 
+@pytest.mark.parametrize("prec,tdt", [("bf16", torch.bfloat16), ("f16", torch.float16)])
+def test_head_mma_products_of_rounded_operands(prec, tdt):
+    """training.head_mma (KPF_MMA_BF16 / _F16, KPF_DT_F32_MMA_*): a grouped Linear on fp32 tensors whose forward, data gradient and weight gradient multiply the
+    operands ROUNDED to the 16-bit type (fp32 accumulation) — against float64 products of the rounded operands (an fp32-product result would miss this bound by two
+    orders of magnitude: the test also proves the 16-bit path was taken), DESA's shape (three groups of 128 -> 128 over B * 21 * 64 rows)."""
+    from keypointfusion_amd import training as T
+    g = torch.Generator().manual_seed(17)
+    rows, G, K, N = 43008 // 8, 3, 128, 128
+    x = torch.randn(rows, G * K, generator=g)
+    w = torch.randn(G * N, K, generator=g) * 0.1
+    b = torch.randn(G * N, generator=g)
+    dy = torch.randn(rows, G * N, generator=g)
+    xd, wd, bd = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    with T.head_mma(prec):
+        y = T.linear_hip(xd, wd, bd, "f32", None, None, None, G)
+    y.backward(dy.cuda())
+    r = lambda t: t.to(tdt).double()
+    xr, wr, dyr = r(x).view(rows, G, K), r(w).view(G, N, K), r(dy).view(rows, G, N)
+    yr = torch.einsum("rgk,gnk->rgn", xr, wr).reshape(rows, G * N) + b.double()
+    dxr = torch.einsum("rgn,gnk->rgk", dyr, wr).reshape(rows, G * K)
+    dwr = torch.einsum("rgn,rgk->gnk", dyr, xr).reshape(G * N, K)
+    rel = lambda a, ref: float((a.detach().cpu().double() - ref).abs().max()) / float(ref.abs().max())
+    assert rel(y, yr) < 2e-5 and rel(xd.grad, dxr) < 2e-5 and rel(wd.grad, dwr) < 5e-5, (rel(y, yr), rel(xd.grad, dxr), rel(wd.grad, dwr))
+    assert rel(bd.grad, dy.double().sum(0)) < 2e-5  # (the bias gradient sums the UNROUNDED dY)
+    # outside the block the same call multiplies fp32 operands
+    y32 = T.linear_hip(xd.detach(), wd.detach(), bd.detach(), "f32", None, None, None, G)
+    y64 = torch.einsum("rgk,gnk->rgn", x.double().view(rows, G, K), w.double().view(G, N, K)).reshape(rows, G * N) + b.double()
+    assert rel(y32, y64) < 2e-5 and rel(y, y64) > 1e-4
+
+
 def test_group_max_and_ball_group3_match_torch():
     """GroupMax (max over 64 consecutive rows with the winner kept) against torch.max and its autograd; BallGroup3 (the three radii channel-stacked, one backward
     launch) against BallGroup (radius by radius): same grouped rows and offsets, same index sets, same gradients towards the point / joint features."""
